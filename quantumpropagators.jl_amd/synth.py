@@ -1,0 +1,186 @@
+"""Synthetic inputs for the `prop_step!` hot path.
+
+Counter-based (splitmix64) so that every rank / language regenerates identical
+bits from (seed, row, k) without communicating.  Host-side NumPy only; nothing
+here touches the GPU.
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse as sp
+
+MASK64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+_GOLDEN = np.uint64(0x9E3779B97F4A7C15)
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+
+BANDED_OFFSETS = (1, 2, 3, 4, 1024, 2048, 3072, 4096)
+DEFAULT_SEED = 20260612
+
+
+def splitmix64(x):
+    """One splitmix64 output step on a uint64 array (wrapping arithmetic)."""
+    with np.errstate(over="ignore"):
+        z = (x + _GOLDEN).astype(np.uint64)
+        z = (z ^ (z >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        return z ^ (z >> np.uint64(31))
+
+
+def _u01(h):
+    return (h >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def coupling(seed, i, k, rho, n_offsets):
+    """g(seed, i, k) = rho/(2 n_offsets) * u * exp(2 pi i phi)."""
+    i = np.asarray(i, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        x = np.uint64(seed) ^ (i * _GOLDEN + np.uint64(k) * _M1)
+    h1 = splitmix64(x)
+    h2 = splitmix64(h1)
+    u = _u01(h1)
+    phi = _u01(h2)
+    return (rho / (2.0 * n_offsets)) * u * np.exp(2j * np.pi * phi)
+
+
+def scattered_offsets(N, n_offsets=8, seed=DEFAULT_SEED):
+    """Seeded distinct offsets in [1, N/2)."""
+    out = []
+    k = 0
+    while len(out) < n_offsets:
+        h = int(splitmix64(np.array([seed + 7919 * k], dtype=np.uint64))[0])
+        d = 1 + h % (N // 2 - 1)
+        if d not in out:
+            out.append(d)
+        k += 1
+    return tuple(sorted(out))
+
+
+def hermitian_offsets_csr(N, offsets=BANDED_OFFSETS, rho=10.0, seed=DEFAULT_SEED,
+                          row_begin=0, row_end=None):
+    """Hermitian H with exactly 2*len(offsets) nnz per row, no diagonal:
+    H[i,(i+d_k)%N] = g(seed,i,k);  H[(i+d_k)%N, i] = conj(.).  Gershgorin:
+    spectrum in [-rho, rho].  Returns 0-based CSR (rowptr int64, col int32,
+    vals complex128) for rows [row_begin, row_end), columns ascending."""
+    row_end = N if row_end is None else row_end
+    nk = len(offsets)
+    assert 2 * max(offsets) < N, "offsets must be < N/2 so that columns are distinct"
+    rows = np.arange(row_begin, row_end, dtype=np.int64)
+    nloc = len(rows)
+    cols = np.empty((nloc, 2 * nk), dtype=np.int64)
+    vals = np.empty((nloc, 2 * nk), dtype=np.complex128)
+    for k, d in enumerate(offsets):
+        cols[:, 2 * k] = (rows + d) % N
+        vals[:, 2 * k] = coupling(seed, rows, k, rho, nk)
+        src = (rows - d) % N
+        cols[:, 2 * k + 1] = src
+        vals[:, 2 * k + 1] = np.conj(coupling(seed, src, k, rho, nk))
+    order = np.argsort(cols, axis=1, kind="stable")
+    cols = np.take_along_axis(cols, order, axis=1)
+    vals = np.take_along_axis(vals, order, axis=1)
+    rowptr = np.arange(0, (nloc + 1) * 2 * nk, 2 * nk, dtype=np.int64)
+    return rowptr, cols.reshape(-1).astype(np.int32), vals.reshape(-1)
+
+
+def random_state(N, seed=DEFAULT_SEED + 1, row_begin=0, row_end=None, normalize=True):
+    """Complex Gaussian (Box-Muller on the hash) state, normalised over all N."""
+    def part(a, b):
+        i = np.arange(a, b, dtype=np.uint64)
+        with np.errstate(over="ignore"):
+            h1 = splitmix64(np.uint64(seed) ^ (i * _GOLDEN))
+        h2 = splitmix64(h1)
+        u1 = 1.0 - _u01(h1)
+        u2 = _u01(h2)
+        r = np.sqrt(-2.0 * np.log(u1))
+        return r * np.exp(2j * np.pi * u2)
+    row_end = N if row_end is None else row_end
+    psi = part(row_begin, row_end)
+    if normalize:
+        nrm2 = 0.0
+        step = 1 << 22
+        for a in range(0, N, step):
+            p = part(a, min(N, a + step))
+            nrm2 += float(np.vdot(p, p).real)
+        psi = psi / np.sqrt(nrm2)
+    return psi.astype(np.complex128)
+
+
+def to_scipy(rowptr, col, vals, n_cols):
+    return sp.csr_matrix((vals, col, rowptr), shape=(len(rowptr) - 1, n_cols))
+
+
+# ---- test-size dense / random-sparse fixtures (NumPy Generator; not counter based)
+
+def dense_hermitian(N, rho=10.0, rng=None):
+    """GUE-like Hermitian with spectral radius ~ rho (restates what the
+    reference tests draw from QuantumControlTestUtils.random_matrix)."""
+    rng = np.random.default_rng(0) if rng is None else rng
+    X = (rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))) / np.sqrt(2)
+    H = (X + X.conj().T) / 2
+    return H * (rho / (2 * np.sqrt(N) * np.sqrt(0.5)))
+
+
+def dense_nonhermitian(N, rho=10.0, rng=None):
+    """Ginibre matrix scaled to spectral radius ~ rho (circular law)."""
+    rng = np.random.default_rng(0) if rng is None else rng
+    X = (rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))) / np.sqrt(2)
+    return X * (rho / np.sqrt(N))
+
+
+def sparse_random(N, density, rho=10.0, hermitian=False, rng=None):
+    rng = np.random.default_rng(0) if rng is None else rng
+    nnz_target = int(density * N * N)
+    r = rng.integers(0, N, nnz_target)
+    c = rng.integers(0, N, nnz_target)
+    v = (rng.standard_normal(nnz_target) + 1j * rng.standard_normal(nnz_target)) / np.sqrt(2)
+    A = sp.coo_matrix((v, (r, c)), shape=(N, N)).tocsr()
+    A.sum_duplicates()
+    if hermitian:
+        A = ((A + A.conj().T) / 2).tocsr()
+    scale = rho / (np.sqrt(N * density) if not hermitian else 2 * np.sqrt(N * density * 0.5))
+    A = (A * scale).tocsr()
+    A.sort_indices()
+    return A
+
+
+# ---- Liouvillian (restates src/generators.jl:473-524 formulas; host-side model build)
+
+def ham_to_superop(H, convention="TDSE"):
+    """L = 1 (x) H - H^T (x) 1  (src/generators.jl:473-486)."""
+    H = sp.csr_matrix(H, dtype=np.complex128)
+    Id = sp.identity(H.shape[0], dtype=np.complex128, format="csr")
+    L = sp.kron(Id, H) - sp.kron(H.T, Id)
+    return (L if convention == "TDSE" else 1j * L).tocsr()
+
+
+def lindblad_to_superop(A, convention="TDSE"):
+    """D = conj(A) (x) A - (1 (x) A^+A)/2 - ((A^+A)^T (x) 1)/2
+    (src/generators.jl:493-509)."""
+    A = sp.csr_matrix(A, dtype=np.complex128)
+    Ad = A.conj().T
+    AdT = Ad.T
+    AdA = Ad @ A
+    Id = sp.identity(A.shape[0], dtype=np.complex128, format="csr")
+    D = sp.kron(AdT, A) - sp.kron(Id, AdA) / 2 - sp.kron(AdA.T, Id) / 2
+    return (1j * D if convention == "TDSE" else D).tocsr()
+
+
+def liouvillian_tridiag(n, gamma=0.05, kappa=0.02, seed=DEFAULT_SEED, convention="TDSE"):
+    """Config C3: H_sys = tridiagonal hopping + flat-random diagonal
+    (n x n), c_ops = {sqrt(gamma) lowering, sqrt(kappa) diag dephasing}.
+    Returns a scipy CSR of dimension n^2 (non-Hermitian)."""
+    i = np.arange(n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        diag = 2.0 * _u01(splitmix64(np.uint64(seed) ^ (i * _GOLDEN))) - 1.0
+    hop = np.ones(n - 1)
+    H = sp.diags([hop, diag, hop], [-1, 0, 1], dtype=np.complex128, format="csr")
+    lower = sp.diags([np.sqrt(gamma) * np.sqrt(np.arange(1, n))], [1], dtype=np.complex128,
+                     format="csr")
+    deph = sp.diags([np.sqrt(kappa) * np.arange(n) / max(n - 1, 1)], [0], dtype=np.complex128,
+                    format="csr")
+    L = ham_to_superop(H, convention)
+    L = L + lindblad_to_superop(lower, convention) + lindblad_to_superop(deph, convention)
+    L = L.tocsr()
+    L.sum_duplicates()
+    L.sort_indices()
+    return L

@@ -1,0 +1,302 @@
+"""Pin the NumPy oracle against the reference's own known-answer tests.
+
+The reference holds no stored golden vectors for this path (its tests compare
+against dense `exp`, `eigvals` and analytic results computed in the same run), so
+each reference test is restated here with the same recipe and the same tolerance.
+Reference files are cited per test.  CPU only.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import scipy.linalg as sla
+import scipy.sparse as sp
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import qp_oracle as qo  # noqa: E402
+import qprop_amd.synth as synth  # noqa: E402
+
+
+def _rand_state(N, rng):
+    psi = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    return psi / np.linalg.norm(psi)
+
+
+def test_cheby_random_state():
+    """test/test_cheby.jl:6-49: N=1000 `Hermitian(rand(ComplexF64,N,N))`, dt=0.5,
+    coefficient count in {267, 268}, cheby! vs exp(-i H dt) to 1e-10."""
+    rng = np.random.default_rng(1)
+    N = 1000
+    X = rng.random((N, N)) + 1j * rng.random((N, N))
+    H = np.triu(X) + np.triu(X, 1).conj().T   # Julia Hermitian(X): upper triangle
+    H[np.diag_indices(N)] = H[np.diag_indices(N)].real
+    dt = 0.5
+    psi0 = rng.random(N) + 1j * rng.random(N)
+    psi0 /= np.linalg.norm(psi0)
+    evals, V = np.linalg.eigh(H)
+    expected = V @ (np.exp(-1j * evals * dt) * (V.conj().T @ psi0))
+    E_min = evals[0]
+    Delta = evals[-1] - evals[0]
+    a = qo.cheby_coeffs(Delta, dt)
+    assert len(a) in (267, 268)
+    wrk = qo.ChebyWrk(psi0, Delta, E_min, dt)
+    psi = psi0.copy()
+    qo.cheby(psi, H, dt, wrk)
+    assert np.linalg.norm(psi - expected) < 1e-10
+    assert wrk.n_matvec == len(a) - 1
+
+
+def test_cheby_backward_is_inverse():
+    """src/cheby.jl:158-162, :211 sign conventions: dt<0 undoes dt>0."""
+    rng = np.random.default_rng(2)
+    H = synth.dense_hermitian(64, rho=3.0, rng=rng)
+    ev = np.linalg.eigvalsh(H)
+    psi0 = _rand_state(64, rng)
+    wrk = qo.ChebyWrk(psi0, ev[-1] - ev[0], ev[0], 0.3)
+    psi = psi0.copy()
+    qo.cheby(psi, H, 0.3, wrk)
+    qo.cheby(psi, H, -0.3, wrk)
+    assert np.linalg.norm(psi - psi0) < 1e-12
+
+
+def test_cheby_check_normalization_trips():
+    """src/cheby.jl:194-200: too small a spectral radius must assert."""
+    rng = np.random.default_rng(3)
+    H = synth.dense_hermitian(64, rho=10.0, rng=rng)
+    psi0 = _rand_state(64, rng)
+    wrk = qo.ChebyWrk(psi0, 2.0, -1.0, 0.1)   # true range ~[-10, 10]
+    with pytest.raises(AssertionError, match="Incorrect normalization"):
+        qo.cheby(psi0.copy(), H, 0.1, wrk, check_normalization=True)
+
+
+def test_newton_random_hermitian():
+    """test/test_newton.jl:7-67: N=1000 Hermitian rho=10, dt=0.5, m_max=5,
+    max_restarts=200; norm preserved; vs dense exp to 1e-10."""
+    rng = np.random.default_rng(4)
+    N = 1000
+    H = synth.dense_hermitian(N, rho=10.0, rng=rng)
+    psi0 = _rand_state(N, rng)
+    ev, V = np.linalg.eigh(H)
+    expected = V @ (np.exp(-1j * ev * 0.5) * (V.conj().T @ psi0))
+    wrk = qo.NewtonWrk(psi0, m_max=5)
+    psi = psi0.copy()
+    qo.newton(psi, H, 0.5, wrk, max_restarts=200)
+    assert abs(np.linalg.norm(psi) - 1) < 1e-10
+    assert np.linalg.norm(psi - expected) < 1e-10
+    assert wrk.restarts > 0
+
+
+def test_newton_random_nonhermitian():
+    """test/test_newton.jl:70-127: N=1000 non-Hermitian rho=10, m_max=50."""
+    rng = np.random.default_rng(5)
+    N = 1000
+    H = synth.dense_nonhermitian(N, rho=10.0, rng=rng)
+    psi0 = _rand_state(N, rng)
+    expected = sla.expm(-1j * H * 0.5) @ psi0
+    wrk = qo.NewtonWrk(psi0, m_max=50)
+    psi = psi0.copy()
+    qo.newton(psi, H, 0.5, wrk, max_restarts=200)
+    assert np.linalg.norm(psi - expected) < 1e-10
+
+
+def test_newton_sparse_liouvillian_custom_func():
+    """test/test_newton.jl:130-177: sparse L of dimension 32^2, density 0.5,
+    m_max=50, func = exp, max_restarts=20, vs exp(Array(L*dt)) to 1e-10."""
+    rng = np.random.default_rng(6)
+    N = 32
+    L = synth.sparse_random(N * N, 0.5, rho=10.0, rng=rng)
+    psi0 = _rand_state(N, rng)
+    rho0 = np.outer(psi0, psi0.conj()).reshape(-1, order="F")
+    assert abs(np.trace(rho0.reshape(N, N, order="F")) - 1) < 1e-12
+    expected = sla.expm(L.toarray() * 0.5) @ rho0
+    wrk = qo.NewtonWrk(rho0, m_max=50)
+    rho = rho0.copy()
+    qo.newton(rho, L, 0.5, wrk, max_restarts=20, func=np.exp)
+    assert np.linalg.norm(rho - expected) < 1e-10
+
+
+def test_newton_eigenstate_shortcut():
+    """src/newton.jl:289-295: an eigenstate returns after one Arnoldi step."""
+    rng = np.random.default_rng(7)
+    H = synth.dense_hermitian(50, rho=4.0, rng=rng)
+    ev, V = np.linalg.eigh(H)
+    psi = V[:, 3].copy()
+    wrk = qo.NewtonWrk(psi, m_max=10)
+    qo.newton(psi, H, 0.7, wrk)
+    assert wrk.restarts == 0
+    assert np.linalg.norm(psi - np.exp(-1j * ev[3] * 0.7) * V[:, 3]) < 1e-12
+
+
+def test_ritzvals_nonhermitian():
+    """test/test_specrad.jl:14-45: ritzvals(X, psi, 180, 200; prec=1e-5) vs the
+    (Re,Im)-sorted eigvals extremes, relative 1 %."""
+    rng = np.random.default_rng(8)
+    N = 1000
+    X = synth.dense_nonhermitian(N, rho=10.0, rng=rng)
+    psi = _rand_state(N, rng)
+    ritz = qo.ritzvals(X, psi, 180, 200, prec=1e-5)
+    ev = qo._eigvals_sorted(X)
+    assert abs(ev[0] - ritz[0]) / abs(ev[0]) < 0.01
+    assert abs(ev[-1] - ritz[-1]) / abs(ev[-1]) < 0.01
+
+
+def test_ritzvals_hermitian():
+    """test/test_specrad.jl:47-77: ritzvals(H, psi, 20, 60; prec=1e-3), 2 %."""
+    rng = np.random.default_rng(9)
+    N = 1000
+    H = synth.dense_hermitian(N, rho=10.0, rng=rng)
+    psi = _rand_state(N, rng)
+    ritz = qo.ritzvals(H, psi, 20, 60, prec=1e-3)
+    ev = np.linalg.eigvalsh(H)
+    assert abs(ev[0] - ritz[0]) / abs(ev[0]) < 0.02
+    assert abs(ev[-1] - ritz[-1]) / abs(ev[-1]) < 0.02
+
+
+def test_specrange_methods():
+    """test/test_specrad.jl:80-144."""
+    rng = np.random.default_rng(10)
+    N = 1000
+    H = synth.sparse_random(N, 0.1, rho=10.0, hermitian=True, rng=rng)
+    ev = np.linalg.eigvalsh(H.toarray())
+    Delta = ev[-1] - ev[0]
+    psi = _rand_state(N, rng)
+    E_min, E_max = qo.specrange(H, "arnoldi", state=psi, prec=1e-4)
+    assert ev[0] - 0.05 * Delta <= E_min <= ev[0]
+    assert ev[-1] <= E_max < ev[-1] + 0.05 * Delta
+    E_min, E_max = qo.specrange(H, "diag")
+    assert abs(ev[0] - E_min) < 1e-12 and abs(ev[-1] - E_max) < 1e-12
+    with pytest.raises(KeyError):
+        qo.specrange(H, "manual")
+    with pytest.raises(KeyError):
+        qo.specrange(H, "manual", E_min=-1.0)
+    assert qo.specrange(H, "manual", E_min=-10, E_max=10) == (-10.0, 10.0)
+    E_min, E_max = qo.specrange(H, "auto", state=psi)
+    assert ev[0] - 0.05 * Delta <= E_min <= ev[0]
+    assert ev[-1] <= E_max < ev[-1] + 0.05 * Delta
+    assert qo.specrange(H, "auto", E_min=-10, E_max=10) == (-10.0, 10.0)
+
+
+def test_cheby_init_prop_spectral_envelope():
+    """test/test_specrad.jl:147-223 (manual range and specrange_buffer):
+    E in [-10,10] -> E_min ~ -10.1, Delta ~ 20.2; buffer 0.1 -> -11, 22."""
+    rng = np.random.default_rng(11)
+    H = synth.dense_hermitian(40, rho=5.0, rng=rng)
+    psi = _rand_state(40, rng)
+    tlist = np.linspace(0, 1, 11)
+    p = qo.init_prop(psi, H, tlist, "cheby", E_min=-10, E_max=10)
+    assert abs(p.wrk.E_min - (-10.1)) < 1e-12 and abs(p.wrk.Delta - 20.2) < 1e-12
+    p = qo.init_prop(psi, H, tlist, "cheby", E_min=-10, E_max=10, specrange_buffer=0.1)
+    assert abs(p.wrk.E_min - (-11.0)) < 1e-12 and abs(p.wrk.Delta - 22.0) < 1e-12
+
+
+def test_tls_rabi_analytic():
+    """test/test_propagate.jl:74-150: two-level Rabi flip, Cheby forward and
+    backward vs analytic result to 1e-12."""
+    sx = np.array([[0, 1], [1, 0]], dtype=complex)
+    sz = np.array([[1, 0], [0, -1]], dtype=complex)
+    Omega = 1.0
+    T = np.pi / (2 * Omega)              # quarter Rabi cycle
+    tlist = np.linspace(0, T, 101)
+    gen = qo.Generator([0.0 * sz, 0.5 * sx], [lambda t: Omega])
+    psi0 = np.array([1, 0], dtype=complex)
+    # exp(-i (Omega/2) sx T) |0> = cos(pi/4)|0> - i sin(pi/4)|1>
+    expected = np.array([1 / np.sqrt(2), -1j / np.sqrt(2)])
+    out = qo.propagate(psi0, gen, tlist, "cheby")
+    assert np.linalg.norm(out - expected) < 1e-12
+    back = qo.propagate(out, gen, tlist, "cheby", backward=True)
+    assert np.linalg.norm(back - psi0) < 1e-12
+
+
+def _optomech():
+    """test/optomech.jl:1-44 restated (deterministic, no RNG)."""
+    w_mech, g, eta = 10.0, 1.0, 2.0
+    Delta = -w_mech
+    N_cav, N_mech = 4, 10
+
+    def destroy(N):
+        return sp.diags([np.sqrt(np.arange(1, N + 1)).astype(complex)], [1], format="csr")
+
+    def ident(N):
+        return sp.identity(N + 1, dtype=complex, format="csr")
+    a = sp.kron(destroy(N_cav), ident(N_mech)).tocsr()
+    at = a.conj().T.tocsr()
+    b = sp.kron(ident(N_cav), destroy(N_mech)).tocsr()
+    bt = b.conj().T.tocsr()
+    H = (-Delta * at @ a + eta * (a + at)) + w_mech * bt @ b + (-g * (bt + b) @ at @ a)
+    psi0 = np.zeros((N_cav + 1) * (N_mech + 1), dtype=complex)
+    psi0[0 * (N_mech + 1) + 2] = 1.0
+    return H.tocsr(), psi0
+
+
+def test_optomech_newton_vs_cheby():
+    """test/test_propagate.jl:153-163: tlist = 0:0.2:50, Newton norm to 1e-12,
+    Newton vs Cheby to 1e-10 (specrange :auto -> :arnoldi since N=55 > 32)."""
+    H, psi0 = _optomech()
+    tlist = np.arange(0, 50 + 1e-9, 0.2)
+    psi1 = qo.propagate(psi0, H, tlist, "newton")
+    assert (np.linalg.norm(psi1) - 1.0) < 1e-12
+    rng = np.random.default_rng(12)
+    st = rng.random(55) * np.exp(2j * np.pi * rng.random(55))
+    st /= np.linalg.norm(st)
+    psi2 = qo.propagate(psi0, H, tlist, "cheby", specrange_state=st)
+    assert np.linalg.norm(psi1 - psi2) < 1e-10
+    ref = sla.expm(-1j * H.toarray() * 50.0) @ psi0
+    assert np.linalg.norm(psi2 - ref) < 1e-9
+
+
+def test_operator_mul():
+    """test/test_operator_linalg.jl:30-64: mul!(phi, Op, psi, alpha, beta) for
+    (1,0),(1,1),(2,1),(2,2); ScaledOperator; dot."""
+    rng = np.random.default_rng(13)
+    N = 30
+    H0 = synth.dense_hermitian(N, rng=rng)
+    H1 = synth.dense_hermitian(N, rng=rng)
+    H2 = synth.dense_hermitian(N, rng=rng)
+    psi = _rand_state(N, rng)
+    phi0 = _rand_state(N, rng)
+    for ops, coeffs in (([H0, H1, H2], [0.3, -1.2]), ([H1, H2], [0.7, 0.1 + 0.2j])):
+        Op = qo.Operator(ops, coeffs)
+        A = Op.toarray()
+        for alpha, beta in ((1, 0), (1, 1), (2, 1), (2, 2)):
+            out = Op.mul(psi, alpha, beta, C=phi0.copy())
+            assert np.linalg.norm(out - (beta * phi0 + alpha * (A @ psi))) < 1e-12
+        S = qo.ScaledOperator(0.5j, Op)
+        assert np.linalg.norm(S.mul(psi, 2, 1, C=phi0.copy()) - (phi0 + 2 * 0.5j * (A @ psi))) < 1e-12
+        assert abs(Op.dot(phi0, psi) - np.vdot(phi0, A @ psi)) < 1e-12
+
+
+def test_csc_to_csr_bit_exact():
+    """Index work at the boundary: Julia SparseMatrixCSC (1-based Int64) -> CSR."""
+    rng = np.random.default_rng(14)
+    A = synth.sparse_random(97, 0.08, rng=rng).tocsc()
+    A.sort_indices()
+    rowptr, col, vals = qo.csc_to_csr(97, 97, A.indptr + 1, A.indices + 1, A.data)
+    B = A.tocsr()
+    B.sort_indices()
+    assert np.array_equal(rowptr, B.indptr) and np.array_equal(col, B.indices)
+    assert np.array_equal(vals, B.data)
+    assert rowptr.dtype == np.int64 and col.dtype == np.int32
+
+
+def test_partition_rows():
+    rowptr = np.arange(0, 17 * 4, 4)
+    assert list(qo.partition_rows(rowptr, 3)) == [0, 6, 11, 16]
+    b = qo.partition_rows(rowptr, 4, balance="nnz")
+    assert list(b) == [0, 4, 8, 12, 16]
+
+
+def test_synthetic_hermitian():
+    rowptr, col, vals = synth.hermitian_offsets_csr(256, offsets=(1, 2, 3, 4, 16, 32, 48, 64))
+    H = synth.to_scipy(rowptr, col, vals, 256)
+    assert abs(H - H.conj().T).max() == 0
+    assert np.all(np.diff(rowptr) == 16)
+    assert np.max(np.abs(np.linalg.eigvalsh(H.toarray()))) <= 10.0
+    # row-range generation is consistent with the full matrix
+    r2, c2, v2 = synth.hermitian_offsets_csr(256, offsets=(1, 2, 3, 4, 16, 32, 48, 64),
+                                             row_begin=100, row_end=180)
+    assert np.array_equal(c2, col[rowptr[100]:rowptr[180]])
+    assert np.array_equal(v2, vals[rowptr[100]:rowptr[180]])
+    psi = synth.random_state(256)
+    assert abs(np.linalg.norm(psi) - 1) < 1e-14
+    assert np.array_equal(synth.random_state(256, row_begin=10, row_end=20), psi[10:20])

@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Chebyshev ``prop_step!``/s on the BASELINE.json config C2
+(N = 2^20 rows per GPU, CSR sparse Hermitian H with 16 nnz/row, complex fp64,
+manual spectral range [-10, 10], dt = 1 => 32 coefficients = 31 fused mat-vec terms).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one ``prop_step!`` = one pass of the hot path (31 fused SpMV terms) over the
+state.  For N > 1 the CSR rows are partitioned across the ranks (2^20 rows per GPU, weak
+scaling) and the needed slices of the term vector are exchanged over RCCL after every
+mat-vec.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s measured copy)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log2n", type=int, default=20, help="rows per GPU = 2^log2n")
+    ap.add_argument("--pattern", default="banded", choices=["banded", "scattered"])
+    ap.add_argument("--format", default="auto", choices=["auto", "rbcsr", "csr"])
+    ap.add_argument("--exchange", default="auto", choices=["auto", "halo", "allgather"])
+    ap.add_argument("--cpu-steps", type=int, default=4, help="steps of the CPU baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the prop_step! engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import qprop_amd.lib as L
+    import qprop_amd.synth as synth
+
+    rows = 1 << args.log2n
+    N = rows * world
+    r0, r1 = rank * rows, (rank + 1) * rows
+    offsets = synth.BANDED_OFFSETS if args.pattern == "banded" else synth.scattered_offsets(N)
+    Delta, E_min, dt = 20.0, -10.0, 1.0        # manual range [-10,10], specrange_buffer=0
+    fmt = {"auto": L.FMT_AUTO, "rbcsr": L.FMT_RBCSR, "csr": L.FMT_CSR}[args.format]
+
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = L.Context(local_rank, stream=stream)
+    rp, col, vals = synth.hermitian_offsets_csr(N, offsets=offsets, row_begin=r0, row_end=r1)
+    psi0_local = synth.random_state(N, row_begin=r0, row_end=r1)
+    nnz_local = int(rp[-1])
+    coeffs = L.cheby_coeffs(Delta, dt)
+    nterms = len(coeffs) - 1
+
+    parity = None
+    cpu = None
+    if world == 1:
+        op = L.Operator(ctx, [L.Matrix(ctx, rows, N, rp, col, vals)], 0, fmt)
+        wrk = L.ChebyWrk(ctx, N, Delta, E_min, dt)
+        psi = L.State(ctx, data=psi0_local)
+        fmt_used = op.format
+
+        def step():
+            L.cheby(psi, op, dt, wrk)
+
+        if args.cpu_steps > 0:
+            # CPU baseline: the oracle's C restatement of the reference's serial CSC path
+            # (checker / reported baseline only; never on the product path)
+            from oracle import ref_c
+            for _ in range(args.cpu_steps):
+                step()
+            gpu_k = psi.numpy()
+            psi.upload(psi0_local)
+            cpsi = psi0_local.copy()
+            colptr, rowval, nzval = rp, col.astype(np.int64), np.conj(vals)   # Hermitian: CSC(H) = conj CSR(H)
+            t0 = time.perf_counter()
+            for _ in range(args.cpu_steps):
+                ref_c.cheby_csc(colptr, rowval, nzval, cpsi, coeffs, Delta, E_min, dt)
+            tc = time.perf_counter() - t0
+            parity = float(np.linalg.norm(gpu_k - cpsi))
+            cpu = {"value": args.cpu_steps / tc, "unit": "prop_step/s", "cores": 1, "kind": "port",
+                   "sample": f"{args.cpu_steps} prop_steps of the same N=2^{args.log2n} workload "
+                             f"(oracle/cheby_ref.c: serial CSC SpMV + BLAS-1, reference operation order)",
+                   "ms_per_step": 1e3 * tc / args.cpu_steps,
+                   "l2_diff_vs_gpu_after_sample": parity}
+            del colptr, rowval, nzval, cpsi
+        exchange_used = "none"
+    else:
+        import qprop_amd.sharded as sharded
+        sh = sharded.ShardedCheby(ctx, rp, col, vals, N, r0, r1, Delta, E_min, dt, fmt=fmt,
+                                  exchange=args.exchange)
+        sh.set_state(psi0_local)
+        fmt_used = sh.op.format
+        exchange_used = sh.exchange
+
+        def step():
+            sh.step()
+    del rp, col, vals
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.reset_stats()
+    barrier()
+    ctx.timer_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ev_ms = ctx.timer_end()          # HIP events on the kernels' own stream
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    st = ctx.stats()
+    if dist is not None:
+        t = torch.tensor([elapsed, ev_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, ev_ms = float(t[0]), float(t[1])
+
+    steps_per_s = args.steps / elapsed
+    n_launch = args.steps * nterms
+    # algorithmic bytes of one fused term on one GPU: (20 z + 84) N + 4
+    alg_bytes = 20.0 * nnz_local + 4.0 * (rows + 1) + 80.0 * rows
+    avg_launch_s = (ev_ms * 1e-3) / n_launch
+    achieved = alg_bytes / avg_launch_s / 1e9
+    out = {
+        "metric": "Cheby prop_step!/s at N=2^20 CSR fp64 (2^20-row blocks advanced per second)",
+        "value": steps_per_s * world,
+        "unit": "prop_step/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "c128 (complex fp64)", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: Cheby prop_step!, CSR sparse Hermitian H, 16 nnz/row, "
+                               "complex fp64 values, int32 indices",
+                   "rows_per_gpu": rows, "N_total": N, "nnz_per_row": 16, "pattern": args.pattern,
+                   "offsets": [int(o) for o in offsets], "n_coeffs": int(len(coeffs)), "matvecs_per_step": nterms,
+                   "spectral_range": [-10.0, 10.0], "dt": dt, "device_format": {1: "csr", 2: "rbcsr"}[fmt_used],
+                   "parallelism": "single GPU" if world == 1 else f"row-partitioned x{world}, exchange={exchange_used}",
+                   "global_steps_per_s": steps_per_s},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "rbcsr_spmv_kernel<ChebyOp>" if fmt_used == 2 else "csr_spmv_kernel<16,ChebyOp>",
+                     "algorithmic_bytes_per_launch": alg_bytes,
+                     "avg_launch_us": avg_launch_s * 1e6,
+                     "launches_timed": n_launch, "hip_event_ms": ev_ms,
+                     "note": "avg launch duration = HIP-event time of the timed region on the kernels' stream / "
+                             "number of fused-term launches (includes launch gaps; multi-GPU: includes exchange)"},
+        "cpu_baseline": cpu,
+        "stats": {"n_matvec": st["n_matvec"], "kernel_launches": st["n_kernel_launches"]},
+    }
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,228 @@
+/* qprop.h -- C ABI of libqprop_hip.so, the MI355X (gfx950) engine behind
+ * QuantumPropagators.jl's `init_prop / prop_step! / propagate` for the Chebyshev and
+ * Newton/Arnoldi propagators.
+ *
+ * The reference is pure Julia: there is no existing FFI for this path.  The boundary it
+ * sits behind is Julia dispatch on `init_prop(state, generator, tlist, ::Val{:Method})`
+ * and `prop_step!(propagator)` (src/propagator.jl:208-264, :315-329); a backend package
+ * extension (the pattern of ext/QuantumPropagatorsExponentialUtilitiesExt.jl:74-210)
+ * would `ccall` the entry points below.  Each entry point cites the reference code it
+ * replaces (paths relative to the reference checkout, v0.8.5+dev).  INTEGRATION.md shows
+ * the Julia-side `ccall` stubs.
+ *
+ * Conventions
+ *  - every function returns an int status (QP_OK == 0); no C++ exception crosses;
+ *    qp_last_error() gives the thread-local message of the last failure.
+ *  - qp_c128 is layout- and ABI-compatible with C `double _Complex` and Julia
+ *    `ComplexF64` (two doubles, passed in two SSE registers on x86-64 SysV).
+ *  - host arrays belong to the caller; the library copies at *_create / upload and
+ *    never retains host pointers.  Device buffers belong to the handle unless wrapped
+ *    with qp_state_wrap().
+ *  - all device work of a context is enqueued on that context's HIP stream; calls that
+ *    return host scalars synchronise that stream, all others are asynchronous.
+ *  - handles are not thread-safe; distinct contexts may be used from distinct threads.
+ */
+#ifndef QPROP_H
+#define QPROP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { double re, im; } qp_c128;
+
+typedef struct qp_ctx qp_ctx;           /* device + stream */
+typedef struct qp_matrix qp_matrix;     /* one sparse matrix resident in HBM */
+typedef struct qp_operator qp_operator; /* lazy sum  sum_l c_l H_l  (Generators.Operator) */
+typedef struct qp_state qp_state;       /* one state vector, ComplexF64[n] in HBM */
+typedef struct qp_krylov qp_krylov;     /* (m_max+1) Arnoldi vectors, contiguous */
+typedef struct qp_cheby qp_cheby;       /* Cheby.ChebyWrk device workspace */
+typedef struct qp_newton qp_newton;     /* Newton.NewtonWrk device workspace */
+
+/* ---- status codes; the Julia glue maps them back to the reference's exceptions ---- */
+enum {
+  QP_OK = 0,
+  QP_E_BAD_ARG = 1,            /* ArgumentError */
+  QP_E_HIP = 2,                /* HIP runtime failure */
+  QP_E_DT_MISMATCH = 3,        /* @assert abs(dt) ~ abs(wrk.dt)        src/cheby.jl:157 */
+  QP_E_TOO_FEW_COEFFS = 4,     /* @assert length(a) > 1                src/cheby.jl:165 */
+  QP_E_NORMALIZATION = 5,      /* "Incorrect normalization"            src/cheby.jl:196-199 */
+  QP_E_MAX_RESTARTS = 6,       /* @assert s <= max_restarts            src/newton.jl:375 */
+  QP_E_DIVDIFF_UNDERFLOW = 7,  /* "Divided differences too small"      src/newton.jl:209 */
+  QP_E_NO_DEVICE = 8,          /* no MI355X visible: the product path has no CPU fallback */
+  QP_E_ALLOC = 9,
+  QP_E_INTERNAL = 10,
+  QP_E_M_MAX = 11              /* "Newton propagation requires m_max > 2" src/newton.jl:38-45 */
+};
+
+enum { QP_LAYOUT_CSR = 0, QP_LAYOUT_CSC = 1 };
+enum { QP_VAL_C128 = 0, QP_VAL_F64 = 1 };
+/* device storage format: AUTO picks RBCSR (row-block CSR: 64-row blocks stored
+ * lane-interleaved so that one wavefront streams a block with 1-KiB coalesced loads)
+ * unless padding would exceed 25 %, else plain CSR with a sub-wave-per-row kernel. */
+enum { QP_FMT_AUTO = 0, QP_FMT_CSR = 1, QP_FMT_RBCSR = 2 };
+enum { QP_FUNC_EXPMI = 0,    /* z -> exp(-i z)   default of newton!, src/newton.jl:247 */
+       QP_FUNC_EXP = 1,      /* z -> exp(z)      test/test_newton.jl:171 */
+       QP_FUNC_CALLBACK = 2 };
+enum { QP_SPECRANGE_ARNOLDI = 0, QP_SPECRANGE_DIAG = 1 };
+
+const char* qp_last_error(void);
+const char* qp_status_name(int status);
+int qp_version(void);
+int qp_device_count(int* n_out);
+
+/* ---- context -------------------------------------------------------------------- */
+/* `stream` may be NULL (the library creates one) or an existing hipStream_t, e.g.
+ * torch.cuda.current_stream().cuda_stream, so that torch.distributed collectives and
+ * library kernels are ordered on one stream. */
+int qp_ctx_create(int device, void* stream, qp_ctx** out);
+int qp_ctx_destroy(qp_ctx* ctx);
+int qp_sync(qp_ctx* ctx);
+
+typedef struct {
+  uint64_t n_matvec;       /* mat-vecs enqueued  (timing section "matrix-vector product") */
+  uint64_t n_cheby_steps;
+  uint64_t n_newton_steps;
+  uint64_t n_restarts;
+  uint64_t n_kernel_launches;
+  double spmv_bytes;       /* algorithmic bytes of fused mat-vec kernels */
+} qp_stats;
+int qp_stats_get(qp_ctx* ctx, qp_stats* out);
+int qp_stats_reset(qp_ctx* ctx);
+/* HIP-event timing of everything enqueued between begin and end on the ctx stream */
+int qp_timer_begin(qp_ctx* ctx);
+int qp_timer_end(qp_ctx* ctx, double* elapsed_ms_out);
+
+/* ---- index work at the boundary (host only; bit-exact; no GPU needed) ------------- */
+/* Julia SparseMatrixCSC{ComplexF64,Int64} (src/generators.jl:473-486) -> 0-based CSR,
+ * int64 rowptr, int32 col (ascending within a row), stable in the value order. */
+int qp_csc_to_csr_host(int64_t nrows, int64_t ncols, const int64_t* colptr,
+                       const int64_t* rowval, const qp_c128* nzval, int index_base,
+                       int64_t* rowptr_out, int32_t* col_out, qp_c128* vals_out);
+/* contiguous row blocks for `nparts` ranks; balance 0 = rows, 1 = nnz */
+int qp_partition_rows_host(const int64_t* rowptr, int64_t nrows, int nparts, int balance,
+                           int64_t* bounds_out /* nparts+1 */);
+
+/* ---- matrices --------------------------------------------------------------------- */
+/* ptr/idx: rowptr/col (CSR) or colptr/rowval (CSC), int64, `index_base` 0 or 1.
+ * nrows may be a row block of a larger operator (local rows, global ncols).
+ * The matrix handle holds the canonical host CSR (the result of the index work);
+ * qp_operator_create() lays it out in HBM.  `format` is reserved (pass QP_FMT_AUTO). */
+int qp_matrix_create(qp_ctx* ctx, int64_t nrows, int64_t ncols, int64_t nnz,
+                     const int64_t* ptr, const int64_t* idx, const void* vals, int val_dtype,
+                     int layout, int index_base, int format, qp_matrix** out);
+int qp_matrix_destroy(qp_matrix* m);
+int qp_matrix_info(const qp_matrix* m, int64_t* nrows, int64_t* ncols, int64_t* nnz,
+                   int* format, int64_t* stored_nnz);
+/* the canonical CSR held by the handle (tests: index work must be bit-exact) */
+int qp_matrix_get_csr(const qp_matrix* m, int64_t* rowptr, int32_t* col, qp_c128* vals);
+
+/* ---- Operator: lazy sum with drift terms (src/generators.jl:111-125) -------------- */
+/* ops[0..nops), the last `ncoeffs` of them carry coefficients (drift_offset =
+ * nops - ncoeffs, src/generators.jl:635).  All ops must share shape.  The library
+ * keeps one union sparsity pattern with a value plane per term; set_coeffs() is the
+ * device-side `evaluate!` (src/generators.jl:757-766): vals = sum_l c_l plane_l. */
+int qp_operator_create(qp_ctx* ctx, qp_matrix* const* ops, int nops, int ncoeffs,
+                       int format, qp_operator** out);
+int qp_operator_set_coeffs(qp_operator* op, const qp_c128* coeffs, int ncoeffs);
+int qp_operator_set_scale(qp_operator* op, qp_c128 scale); /* ScaledOperator :238-249 */
+int qp_operator_destroy(qp_operator* op);
+int qp_operator_info(const qp_operator* op, int64_t* nrows, int64_t* ncols, int64_t* nnz,
+                     int* format);
+/* read the DEVICE copy (union pattern, currently combined values) back as canonical
+ * CSR: the device-format round trip must be bit-exact. */
+int qp_operator_get_csr(qp_operator* op, int64_t* rowptr, int32_t* col, qp_c128* vals);
+
+/* ---- states and BLAS-1 (the six primitives of src/cheby.jl:146-148) ---------------- */
+int qp_state_create(qp_ctx* ctx, int64_t n, qp_state** out);
+int qp_state_wrap(qp_ctx* ctx, void* device_ptr, int64_t n, qp_state** out);
+int qp_state_destroy(qp_state* s);
+int qp_state_upload(qp_state* s, const qp_c128* host);
+int qp_state_download(const qp_state* s, qp_c128* host);
+void* qp_state_ptr(const qp_state* s);
+int64_t qp_state_len(const qp_state* s);
+int qp_copy(qp_state* dst, const qp_state* src);              /* copyto! */
+int qp_scal(qp_state* x, qp_c128 alpha);                      /* lmul!   */
+int qp_axpy(qp_c128 alpha, const qp_state* x, qp_state* y);   /* axpy!   */
+int qp_fill(qp_state* x, qp_c128 alpha);                      /* fill!   */
+int qp_dot(const qp_state* x, const qp_state* y, qp_c128* out);  /* dot: conj(x).y */
+int qp_norm(const qp_state* x, double* out);                  /* norm    */
+
+/* mul!(y, A, x, alpha, beta): y <- beta y + alpha A x    src/generators.jl:634-645 */
+int qp_mul(qp_operator* op, const qp_state* x, qp_state* y, qp_c128 alpha, qp_c128 beta);
+/* dot(x, A, y)                                            src/generators.jl:648-660 */
+int qp_dot_op(const qp_state* x, qp_operator* op, const qp_state* y, qp_state* tmp,
+              qp_c128* out);
+
+/* ---- Chebyshev (src/cheby.jl) ------------------------------------------------------ */
+/* cheby_coeffs / cheby_coeffs!  src/cheby.jl:25-39, :54-72.  Returns QP_E_BAD_ARG with
+ * *n_out = required length when cap is too small. */
+int qp_cheby_coeffs(double Delta, double dt, double limit, double* out, int cap, int* n_out);
+/* ChebyWrk  src/cheby.jl:87-124 (device workspace: two vectors instead of three) */
+int qp_cheby_create(qp_ctx* ctx, int64_t n, qp_cheby** out);
+int qp_cheby_destroy(qp_cheby* w);
+/* cheby!(psi, H, dt, wrk; E_min, check_normalization)  src/cheby.jl:150-213.
+ * `a[0..n_coeffs)`, Delta, E_min, wrk_dt, limit are the ChebyWrk fields; dt is signed.
+ * Whole step is enqueued without host synchronisation unless check_normalization. */
+int qp_cheby_step(qp_cheby* w, qp_operator* op, qp_state* psi, const double* a, int n_coeffs,
+                  double Delta, double E_min, double dt, double wrk_dt, double limit,
+                  int check_normalization);
+/* One fused term, for row-partitioned multi-GPU drivers that exchange x between terms:
+ *   s = (H x)[i];  t = c (s - beta x[xoff+i]) (+ v0[i] if v0);  if vout: vout[i] = t;
+ *   r = (acc_in ? acc_in[i] : a_prev x[xoff+i]) + a t;  acc_out[i] = phase r.
+ * x has op.ncols entries, the other vectors op.nrows; vout may alias v0. */
+int qp_cheby_term(qp_operator* op, const qp_state* x, int64_t xoff, const qp_state* v0,
+                  qp_state* vout, const qp_state* acc_in, qp_state* acc_out, qp_c128 c,
+                  double beta, double a_prev, double a, qp_c128 phase);
+
+/* ---- Arnoldi (src/arnoldi.jl) ------------------------------------------------------ */
+int qp_krylov_create(qp_ctx* ctx, int64_t n, int nvec, qp_krylov** out);
+int qp_krylov_destroy(qp_krylov* q);
+int qp_krylov_download(const qp_krylov* q, int i, qp_c128* host);
+/* arnoldi!(Hess, q, m, psi, H, dt; extended, norm_min)  src/arnoldi.jl:60-100.
+ * Hess: caller-allocated column-major ldh x ldh, zero-filled by the call (:78). */
+int qp_arnoldi(qp_operator* op, qp_krylov* q, int m, const qp_state* psi, double dt,
+               int extended, double norm_min, qp_c128* Hess, int ldh, int* m_out);
+/* extend_arnoldi!(Hess, q, m, H, dt; norm_min)  src/arnoldi.jl:115-129 (1-based m) */
+int qp_arnoldi_extend(qp_operator* op, qp_krylov* q, int m, double dt, double norm_min,
+                      qp_c128* Hess, int ldh, int* extended_out);
+/* diagonalize_hessenberg_matrix(Hess, m; accumulate)  src/arnoldi.jl:143-170 (host) */
+int qp_hessenberg_eigvals(const qp_c128* Hess, int ldh, int m, int accumulate, qp_c128* out);
+
+/* ---- Newton (src/newton.jl) -------------------------------------------------------- */
+typedef void (*qp_func_cb)(const qp_c128* z, qp_c128* out, void* user);
+/* extend_leja!  src/newton.jl:97-148 (zero-based arrays; newpoints is clobbered) */
+int qp_extend_leja(qp_c128* leja, int n, qp_c128* newpoints, int n_newpoints, int n_use);
+/* extend_newton_coeffs!  src/newton.jl:176-214 */
+int qp_extend_newton_coeffs(qp_c128* a, int n_a, const qp_c128* leja, int func_id,
+                            qp_func_cb cb, void* user, int n_leja, double radius);
+typedef struct {
+  int restarts, n_a, n_leja, m_last, n_matvec;
+  double radius, last_relerr, norm_psi;
+} qp_newton_stats;
+/* NewtonWrk(v0; m_max)  src/newton.jl:23-60 */
+int qp_newton_create(qp_ctx* ctx, int64_t n, int m_max, qp_newton** out);
+int qp_newton_destroy(qp_newton* w);
+/* newton!(psi, H, dt, wrk; func, norm_min, relerr, max_restarts)  src/newton.jl:246-385 */
+int qp_newton_step(qp_newton* w, qp_operator* op, qp_state* psi, double dt, int func_id,
+                   qp_func_cb cb, void* user, double norm_min, double relerr,
+                   int max_restarts, qp_newton_stats* stats);
+/* inspection of wrk.a / wrk.leja after a step (src/newton.jl:23-36) */
+int qp_newton_get_coeffs(const qp_newton* w, qp_c128* a, qp_c128* leja, int cap);
+
+/* ---- SpectralRange (src/specrad.jl) ------------------------------------------------ */
+/* ritzvals(G, state, m_min, m_max; prec, norm_min)  src/specrad.jl:170-220 */
+int qp_ritzvals(qp_operator* op, const qp_state* state, int m_min, int m_max, double prec,
+                double norm_min, qp_c128* out, int* n_out);
+/* specrange(H, :arnoldi; state, m_min, m_max, prec, norm_min, enlarge)  :88-112 */
+int qp_specrange_arnoldi(qp_operator* op, const qp_state* state, int m_min, int m_max,
+                         double prec, double norm_min, int enlarge, double* E_min,
+                         double* E_max);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QPROP_H */

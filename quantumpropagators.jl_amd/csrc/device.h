@@ -1,0 +1,106 @@
+// Device-side data structures and kernel launch declarations (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "qprop_internal.h"
+
+namespace qp {
+
+#define QP_HIP(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t e__ = (expr);                                                                 \
+    if (e__ != hipSuccess)                                                                   \
+      return qp::fail(QP_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, \
+                      __LINE__);                                                             \
+  } while (0)
+
+constexpr int kRB = 64;           // rows per row block = one wavefront
+constexpr int kRedBlocks = 256;   // fixed grid of the reduction kernels (deterministic order)
+constexpr int kThreads = 256;
+
+// ---- device view of one sparse operator -------------------------------------------
+struct DevMatrix {
+  int format = QP_FMT_RBCSR;
+  int64_t nrows = 0, ncols = 0, nnz = 0, stored = 0;
+  // RBCSR: 64-row blocks, element (r,k) of block b at bptr[b] + k*64 + r;
+  // cols packed 4 per lane: cols4[(bptr[b]>>2) + (k>>2)*64 + r].{x,y,z,w}
+  int64_t nblocks = 0;
+  int64_t* bptr = nullptr;    // nblocks+1
+  int32_t* cols = nullptr;    // stored (RBCSR: quad packed; CSR: plain)
+  double2* vals = nullptr;    // stored, the values the SpMV kernels read
+  // CSR
+  int64_t* rowptr = nullptr;  // nrows+1
+  int lanes_per_row = 16;     // CSR kernel: sub-wave width
+};
+
+// epilogue of the fused Chebyshev term (see qp_cheby_term in qprop.h)
+struct ChebyEpi {
+  const double2* xloc;   // x + xoff  (row-local element of the gathered vector)
+  const double2* v0;     // nullable
+  double2* vout;         // nullable, may alias v0
+  const double2* acc_in; // nullable
+  double2* acc_out;
+  double2 c;
+  double beta, a_prev, a;
+  double2 phase;
+  int apply_phase;
+  double* check_partials;  // nullable: per-workgroup {Re<v1,t>, Im<v1,t>, |v1|^2}
+};
+
+struct PlainEpi {
+  double2* y;
+  double2 alpha, beta;
+  int beta_zero;
+};
+
+struct Stats {
+  uint64_t n_matvec = 0, n_cheby_steps = 0, n_newton_steps = 0, n_restarts = 0, n_launch = 0;
+  double spmv_bytes = 0;
+};
+
+int launch_spmv_cheby(hipStream_t s, const DevMatrix& A, const double2* x, const ChebyEpi& e, Stats* st);
+int launch_spmv_plain(hipStream_t s, const DevMatrix& A, const double2* x, const PlainEpi& e, Stats* st);
+int spmv_grid_size(const DevMatrix& A);
+
+// small coefficient vectors are passed by value in the kernel-argument segment
+constexpr int kCoefBlock = 32;
+struct CoefBlock {
+  double2 c[kCoefBlock];
+};
+
+// planes: vals[p] = sum_l coef[l] * plane_l[p]   (coefs: host array)
+int launch_combine_planes(hipStream_t s, double2* vals, const double2* const* planes_dev, const double2* coefs,
+                          int nplanes, int64_t n, Stats* st);
+
+// BLAS-1
+int launch_fill(hipStream_t s, double2* x, double2 a, int64_t n, Stats* st);
+int launch_scal(hipStream_t s, double2* x, double2 a, int64_t n, Stats* st);
+int launch_axpy(hipStream_t s, double2 a, const double2* x, double2* y, int64_t n, Stats* st);
+// partials[kRedBlocks] (double2): sum conj(x) y   (x == y gives |x|^2 in .x)
+int launch_dot_partials(hipStream_t s, const double2* x, const double2* y, double2* partials, int64_t n,
+                        Stats* st);
+
+// Arnoldi building blocks.  `h_in` partials belong to the projection on q_prev that is
+// applied before the new inner product is accumulated (fused axpy -> dot pass).
+struct MgsArgs {
+  double2* w;              // q_{j+1}, updated in place
+  const double2* q_prev;   // nullable: projection to subtract first
+  const double2* q_cur;    // nullable: next inner product; null => accumulate |w|^2
+  const double2* part_in;  // partials of <q_prev, w> (kRedBlocks)
+  double2* part_out;       // partials of <q_cur, w'> or |w'|^2
+  double2* hess_prev;      // device Hess slot for dt*<q_prev,w> (nullable)
+  double dt;
+  int64_t n;
+};
+int launch_mgs_pass(hipStream_t s, const MgsArgs& a, Stats* st);
+// w *= 1/sqrt(sum part_in.x);  hess_slot = dt * norm
+int launch_norm_scale(hipStream_t s, double2* w, const double2* part_in, double2* hess_slot, double dt,
+                      int64_t n, Stats* st);
+// out = (use_out ? s0*out : 0) + sum_{i<m} coef[i] * Q[i*ldq + k];  optional |out|^2 partials
+int launch_combine_vecs(hipStream_t s, double2* out, int use_out, double2 s0, const double2* Q, int64_t ldq,
+                        int m, const double2* coefs /* host */, double2* norm_partials, int64_t n, Stats* st);
+// check_normalization finalize: reduce per-workgroup triples to one triple
+int launch_reduce_triples(hipStream_t s, const double* partials, int nwg, double* out3, Stats* st);
+
+}  // namespace qp

@@ -1,0 +1,1362 @@
+// C ABI of libqprop_hip.so: handles, the Operator lazy sum, BLAS-1, and the host-side
+// drivers of cheby!, arnoldi!, newton!, ritzvals/specrange that enqueue the HIP kernels
+// of kernels.hip.  Host logic follows the reference line by line (citations inline);
+// device work is stream-ordered, with host synchronisation only where the reference
+// algorithm needs a scalar on the host (once per Newton restart, once per Arnoldi call).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+#include "device.h"
+
+using qp::cplx;
+using qp::DevMatrix;
+using qp::kRB;
+using qp::kRedBlocks;
+using qp::Stats;
+
+// ---------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------
+namespace qp {
+static thread_local std::string g_last_error;
+void set_error(const char* msg) { g_last_error = msg ? msg : ""; }
+int fail(int status, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return status;
+}
+}  // namespace qp
+
+// ---------------------------------------------------------------------------
+// handle types
+// ---------------------------------------------------------------------------
+struct qp_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  Stats stats;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double2* d_part = nullptr;   // kRedBlocks partials for qp_dot / qp_norm
+  double2* h_part = nullptr;   // pinned mirror
+};
+
+struct qp_state {
+  qp_ctx* ctx;
+  double2* d;
+  int64_t n;
+  bool own;
+};
+
+struct qp_matrix {  // canonical host CSR (the result of the boundary's index work)
+  qp_ctx* ctx;
+  int64_t nrows, ncols, nnz;
+  std::vector<int64_t> rowptr;
+  std::vector<int32_t> col;
+  std::vector<cplx> vals;
+};
+
+struct qp_operator {
+  qp_ctx* ctx = nullptr;
+  DevMatrix A;
+  int nops = 0, ncoeffs = 0;
+  std::vector<int64_t> u_rowptr;  // union pattern (host), for get_csr and plane scatter
+  std::vector<int32_t> u_col;
+  std::vector<double2*> planes;   // device value planes, one per term, layout of A.vals
+  double2** planes_dev = nullptr;
+  double2* combined = nullptr;    // device, allocated on first non-trivial coefficient set
+  std::vector<cplx> coeffs;
+  cplx scale = 1.0;
+};
+
+struct qp_krylov {
+  qp_ctx* ctx;
+  int64_t n;
+  int nvec;
+  double2* Q = nullptr;         // nvec vectors of length n, contiguous
+  double2* hess_dev = nullptr;  // nvec x nvec column major
+  double* norms_dev = nullptr;  // nvec
+  double2* part = nullptr;      // 2 x kRedBlocks ping-pong partials
+  double2* q(int i) const { return Q + (size_t)i * n; }
+};
+
+struct qp_cheby {
+  qp_ctx* ctx;
+  int64_t n;
+  double2* bufA = nullptr;
+  double2* acc = nullptr;
+  double* chk_part = nullptr;  // per-workgroup triples (allocated on demand)
+  double* chk_out = nullptr;   // per-term triples
+  int chk_wg = 0, chk_terms = 0;
+};
+
+struct qp_newton {
+  qp_ctx* ctx;
+  int64_t n;
+  int m_max;
+  qp_krylov* q = nullptr;
+  double2* v = nullptr;
+  double2* npart = nullptr;  // kRedBlocks |psi|^2 partials
+  double2* h_npart = nullptr;
+  std::vector<cplx> a, leja;
+  double radius = 0;
+  int n_a = 0, n_leja = 0, restarts = 0;
+};
+
+namespace {
+
+inline double2 d2(cplx z) { return make_double2(z.real(), z.imag()); }
+inline double2 d2(qp_c128 z) { return make_double2(z.re, z.im); }
+inline cplx cx(qp_c128 z) { return cplx(z.re, z.im); }
+
+int use(qp_ctx* ctx) {
+  QP_HIP(hipSetDevice(ctx->device));
+  return QP_OK;
+}
+
+template <class T>
+int dev_alloc(T** p, size_t count) {
+  *p = nullptr;
+  if (count == 0) count = 1;
+  hipError_t e = hipMalloc((void**)p, count * sizeof(T));
+  if (e != hipSuccess) return qp::fail(QP_E_ALLOC, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+  return QP_OK;
+}
+
+#define QP_CHECK(expr)           \
+  do {                           \
+    int rc__ = (expr);           \
+    if (rc__ != QP_OK) return rc__; \
+  } while (0)
+
+// sum kRedBlocks partials on the host in index order
+cplx sum_partials(const double2* h) {
+  double re = 0, im = 0;
+  for (int i = 0; i < kRedBlocks; ++i) {
+    re += h[i].x;
+    im += h[i].y;
+  }
+  return cplx(re, im);
+}
+
+int dot_sync(qp_ctx* ctx, const double2* x, const double2* y, int64_t n, cplx* out) {
+  QP_CHECK(qp::launch_dot_partials(ctx->stream, x, y, ctx->d_part, n, &ctx->stats));
+  QP_HIP(hipMemcpyAsync(ctx->h_part, ctx->d_part, kRedBlocks * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
+  QP_HIP(hipStreamSynchronize(ctx->stream));
+  *out = sum_partials(ctx->h_part);
+  return QP_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// misc
+// ---------------------------------------------------------------------------
+extern "C" {
+
+const char* qp_last_error(void) { return qp::g_last_error.c_str(); }
+
+const char* qp_status_name(int s) {
+  switch (s) {
+    case QP_OK: return "QP_OK";
+    case QP_E_BAD_ARG: return "QP_E_BAD_ARG";
+    case QP_E_HIP: return "QP_E_HIP";
+    case QP_E_DT_MISMATCH: return "QP_E_DT_MISMATCH";
+    case QP_E_TOO_FEW_COEFFS: return "QP_E_TOO_FEW_COEFFS";
+    case QP_E_NORMALIZATION: return "QP_E_NORMALIZATION";
+    case QP_E_MAX_RESTARTS: return "QP_E_MAX_RESTARTS";
+    case QP_E_DIVDIFF_UNDERFLOW: return "QP_E_DIVDIFF_UNDERFLOW";
+    case QP_E_NO_DEVICE: return "QP_E_NO_DEVICE";
+    case QP_E_ALLOC: return "QP_E_ALLOC";
+    case QP_E_INTERNAL: return "QP_E_INTERNAL";
+    case QP_E_M_MAX: return "QP_E_M_MAX";
+    default: return "QP_E_UNKNOWN";
+  }
+}
+
+int qp_version(void) { return 100; }
+
+int qp_device_count(int* n_out) {
+  QP_TRY
+  if (!n_out) return qp::fail(QP_E_BAD_ARG, "n_out is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    n = 0;
+  }
+  *n_out = n;
+  return QP_OK;
+  QP_CATCH
+}
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+int qp_ctx_create(int device, void* stream, qp_ctx** out) {
+  QP_TRY
+  if (!out) return qp::fail(QP_E_BAD_ARG, "qp_ctx_create: out is NULL");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    return qp::fail(QP_E_NO_DEVICE,
+                    "no HIP device visible (%s): libqprop_hip has no CPU fallback for the prop_step! path",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+  }
+  if (device < 0 || device >= n) return qp::fail(QP_E_BAD_ARG, "device %d out of range [0,%d)", device, n);
+  QP_HIP(hipSetDevice(device));
+  auto ctx = std::make_unique<qp_ctx>();
+  ctx->device = device;
+  if (stream) {
+    ctx->stream = (hipStream_t)stream;
+  } else {
+    QP_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->own_stream = true;
+  }
+  QP_HIP(hipEventCreate(&ctx->ev0));
+  QP_HIP(hipEventCreate(&ctx->ev1));
+  QP_CHECK(dev_alloc(&ctx->d_part, kRedBlocks));
+  QP_HIP(hipHostMalloc((void**)&ctx->h_part, kRedBlocks * sizeof(double2), hipHostMallocDefault));
+  *out = ctx.release();
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_ctx_destroy(qp_ctx* ctx) {
+  QP_TRY
+  if (!ctx) return QP_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->d_part) (void)hipFree(ctx->d_part);
+  if (ctx->h_part) (void)hipHostFree(ctx->h_part);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_sync(qp_ctx* ctx) {
+  QP_TRY
+  if (!ctx) return qp::fail(QP_E_BAD_ARG, "ctx is NULL");
+  QP_CHECK(use(ctx));
+  QP_HIP(hipStreamSynchronize(ctx->stream));
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_stats_get(qp_ctx* ctx, qp_stats* out) {
+  if (!ctx || !out) return qp::fail(QP_E_BAD_ARG, "qp_stats_get: NULL argument");
+  out->n_matvec = ctx->stats.n_matvec;
+  out->n_cheby_steps = ctx->stats.n_cheby_steps;
+  out->n_newton_steps = ctx->stats.n_newton_steps;
+  out->n_restarts = ctx->stats.n_restarts;
+  out->n_kernel_launches = ctx->stats.n_launch;
+  out->spmv_bytes = ctx->stats.spmv_bytes;
+  return QP_OK;
+}
+
+int qp_stats_reset(qp_ctx* ctx) {
+  if (!ctx) return qp::fail(QP_E_BAD_ARG, "ctx is NULL");
+  ctx->stats = Stats();
+  return QP_OK;
+}
+
+int qp_timer_begin(qp_ctx* ctx) {
+  QP_TRY
+  if (!ctx) return qp::fail(QP_E_BAD_ARG, "ctx is NULL");
+  QP_CHECK(use(ctx));
+  QP_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_timer_end(qp_ctx* ctx, double* elapsed_ms_out) {
+  QP_TRY
+  if (!ctx || !elapsed_ms_out) return qp::fail(QP_E_BAD_ARG, "qp_timer_end: NULL argument");
+  QP_CHECK(use(ctx));
+  QP_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+  QP_HIP(hipEventSynchronize(ctx->ev1));
+  float ms = 0;
+  QP_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  *elapsed_ms_out = ms;
+  return QP_OK;
+  QP_CATCH
+}
+
+// ---------------------------------------------------------------------------
+// matrices: canonicalise to host CSR (bit-exact index work)
+// ---------------------------------------------------------------------------
+int qp_matrix_create(qp_ctx* ctx, int64_t nrows, int64_t ncols, int64_t nnz, const int64_t* ptr,
+                     const int64_t* idx, const void* vals, int val_dtype, int layout, int index_base,
+                     int format, qp_matrix** out) {
+  QP_TRY
+  (void)format;
+  if (!ctx || !out || !ptr || (nnz > 0 && (!idx || !vals)))
+    return qp::fail(QP_E_BAD_ARG, "qp_matrix_create: NULL argument");
+  if (nrows < 0 || ncols < 0 || nnz < 0 || ncols > INT32_MAX)
+    return qp::fail(QP_E_BAD_ARG, "qp_matrix_create: bad shape %lld x %lld, nnz %lld", (long long)nrows,
+                    (long long)ncols, (long long)nnz);
+  if (index_base != 0 && index_base != 1) return qp::fail(QP_E_BAD_ARG, "index_base must be 0 or 1");
+  if (val_dtype != QP_VAL_C128 && val_dtype != QP_VAL_F64) return qp::fail(QP_E_BAD_ARG, "bad val_dtype");
+  auto m = std::make_unique<qp_matrix>();
+  m->ctx = ctx;
+  m->nrows = nrows;
+  m->ncols = ncols;
+  m->nnz = nnz;
+  m->rowptr.resize(nrows + 1);
+  m->col.resize(nnz);
+  m->vals.resize(nnz);
+  std::vector<qp_c128> cv;
+  const qp_c128* v128 = nullptr;
+  if (val_dtype == QP_VAL_F64) {
+    cv.resize(nnz);
+    const double* r = static_cast<const double*>(vals);
+    for (int64_t p = 0; p < nnz; ++p) cv[p] = qp_c128{r[p], 0.0};
+    v128 = cv.data();
+  } else {
+    v128 = static_cast<const qp_c128*>(vals);
+  }
+  if (layout == QP_LAYOUT_CSC) {
+    if (ptr[ncols] - index_base != nnz) return qp::fail(QP_E_BAD_ARG, "colptr[end] does not match nnz");
+    int st = qp::csc_to_csr(nrows, ncols, ptr, idx, v128, index_base, m->rowptr.data(), m->col.data(),
+                            reinterpret_cast<qp_c128*>(m->vals.data()));
+    if (st != QP_OK) return qp::fail(st, "qp_matrix_create: row index out of range");
+  } else if (layout == QP_LAYOUT_CSR) {
+    if (ptr[nrows] - index_base != nnz) return qp::fail(QP_E_BAD_ARG, "rowptr[end] does not match nnz");
+    for (int64_t r = 0; r <= nrows; ++r) m->rowptr[r] = ptr[r] - index_base;
+    for (int64_t r = 0; r < nrows; ++r)
+      if (m->rowptr[r + 1] < m->rowptr[r]) return qp::fail(QP_E_BAD_ARG, "rowptr not monotone at row %lld", (long long)r);
+    for (int64_t p = 0; p < nnz; ++p) {
+      int64_t c = idx[p] - index_base;
+      if (c < 0 || c >= ncols) return qp::fail(QP_E_BAD_ARG, "column index out of range at %lld", (long long)p);
+      m->col[p] = (int32_t)c;
+      m->vals[p] = cplx(v128[p].re, v128[p].im);
+    }
+    // canonical form: columns ascending within each row (stable)
+    std::vector<std::pair<int32_t, cplx>> tmp;
+    for (int64_t r = 0; r < nrows; ++r) {
+      int64_t a = m->rowptr[r], b = m->rowptr[r + 1];
+      bool sorted = true;
+      for (int64_t p = a + 1; p < b; ++p)
+        if (m->col[p] < m->col[p - 1]) { sorted = false; break; }
+      if (sorted) continue;
+      tmp.resize(b - a);
+      for (int64_t p = a; p < b; ++p) tmp[p - a] = {m->col[p], m->vals[p]};
+      std::stable_sort(tmp.begin(), tmp.end(), [](auto& x, auto& y) { return x.first < y.first; });
+      for (int64_t p = a; p < b; ++p) { m->col[p] = tmp[p - a].first; m->vals[p] = tmp[p - a].second; }
+    }
+  } else {
+    return qp::fail(QP_E_BAD_ARG, "bad layout");
+  }
+  *out = m.release();
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_matrix_destroy(qp_matrix* m) {
+  delete m;
+  return QP_OK;
+}
+
+int qp_matrix_info(const qp_matrix* m, int64_t* nrows, int64_t* ncols, int64_t* nnz, int* format,
+                   int64_t* stored_nnz) {
+  if (!m) return qp::fail(QP_E_BAD_ARG, "matrix is NULL");
+  if (nrows) *nrows = m->nrows;
+  if (ncols) *ncols = m->ncols;
+  if (nnz) *nnz = m->nnz;
+  if (format) *format = QP_FMT_CSR;
+  if (stored_nnz) *stored_nnz = m->nnz;
+  return QP_OK;
+}
+
+int qp_matrix_get_csr(const qp_matrix* m, int64_t* rowptr, int32_t* col, qp_c128* vals) {
+  if (!m || !rowptr || !col || !vals) return qp::fail(QP_E_BAD_ARG, "qp_matrix_get_csr: NULL argument");
+  std::memcpy(rowptr, m->rowptr.data(), (m->nrows + 1) * sizeof(int64_t));
+  std::memcpy(col, m->col.data(), m->nnz * sizeof(int32_t));
+  std::memcpy(vals, m->vals.data(), m->nnz * sizeof(qp_c128));
+  return QP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Operator: union pattern + value planes in HBM
+// ---------------------------------------------------------------------------
+static int operator_free(qp_operator* op) {
+  if (!op) return QP_OK;
+  (void)hipSetDevice(op->ctx->device);
+  (void)hipStreamSynchronize(op->ctx->stream);
+  for (auto p : op->planes) (void)hipFree(p);
+  if (op->planes_dev) (void)hipFree(op->planes_dev);
+  if (op->combined) (void)hipFree(op->combined);
+  if (op->A.bptr) (void)hipFree(op->A.bptr);
+  if (op->A.rowptr) (void)hipFree(op->A.rowptr);
+  if (op->A.cols) (void)hipFree(op->A.cols);
+  delete op;
+  return QP_OK;
+}
+
+// position of union CSR entry (row r, k-th in row) inside the device value array
+static inline int64_t rb_val_pos(const std::vector<int64_t>& bptr, int64_t r, int64_t k) {
+  return bptr[r / kRB] + k * kRB + (r % kRB);
+}
+static inline int64_t rb_col_pos(const std::vector<int64_t>& bptr, int64_t r, int64_t k) {
+  return bptr[r / kRB] + (k >> 2) * (4 * kRB) + (r % kRB) * 4 + (k & 3);
+}
+
+int qp_operator_create(qp_ctx* ctx, qp_matrix* const* ops, int nops, int ncoeffs, int format,
+                       qp_operator** out) {
+  QP_TRY
+  if (!ctx || !ops || !out || nops < 1 || ncoeffs < 0 || ncoeffs > nops)
+    return qp::fail(QP_E_BAD_ARG, "qp_operator_create: bad arguments");
+  for (int l = 0; l < nops; ++l) {
+    if (!ops[l]) return qp::fail(QP_E_BAD_ARG, "ops[%d] is NULL", l);
+    if (ops[l]->nrows != ops[0]->nrows || ops[l]->ncols != ops[0]->ncols)
+      return qp::fail(QP_E_BAD_ARG, "ops[%d] shape differs from ops[0]", l);
+  }
+  QP_CHECK(use(ctx));
+  std::unique_ptr<qp_operator, int (*)(qp_operator*)> op(new qp_operator(), operator_free);
+  op->ctx = ctx;
+  op->nops = nops;
+  op->ncoeffs = ncoeffs;
+  op->coeffs.assign(ncoeffs, cplx(1.0));
+  const int64_t nrows = ops[0]->nrows, ncols = ops[0]->ncols;
+
+  // ---- union sparsity pattern (sorted merge per row) ----
+  auto& ur = op->u_rowptr;
+  auto& uc = op->u_col;
+  ur.assign(nrows + 1, 0);
+  if (nops == 1) {
+    ur = ops[0]->rowptr;
+    uc = ops[0]->col;
+  } else {
+    std::vector<int32_t> merged;
+    for (int64_t r = 0; r < nrows; ++r) {
+      merged.clear();
+      for (int l = 0; l < nops; ++l)
+        merged.insert(merged.end(), ops[l]->col.begin() + ops[l]->rowptr[r], ops[l]->col.begin() + ops[l]->rowptr[r + 1]);
+      std::sort(merged.begin(), merged.end());
+      merged.erase(std::unique(merged.begin(), merged.end()), merged.end());
+      uc.insert(uc.end(), merged.begin(), merged.end());
+      ur[r + 1] = (int64_t)uc.size();
+    }
+  }
+  const int64_t nnz = ur[nrows];
+
+  // ---- choose the device format ----
+  DevMatrix& A = op->A;
+  A.nrows = nrows;
+  A.ncols = ncols;
+  A.nnz = nnz;
+  A.nblocks = (nrows + kRB - 1) / kRB;
+  std::vector<int64_t> bptr(A.nblocks + 1, 0);
+  for (int64_t b = 0; b < A.nblocks; ++b) {
+    int64_t w = 0;
+    for (int64_t r = b * kRB; r < std::min(nrows, (b + 1) * kRB); ++r) w = std::max(w, ur[r + 1] - ur[r]);
+    w = (w + 3) & ~(int64_t)3;
+    bptr[b + 1] = bptr[b] + w * kRB;
+  }
+  const int64_t rb_stored = bptr[A.nblocks];
+  if (format == QP_FMT_AUTO) format = ((double)rb_stored <= 1.25 * (double)nnz + 1024.0) ? QP_FMT_RBCSR : QP_FMT_CSR;
+  if (format != QP_FMT_RBCSR && format != QP_FMT_CSR) return qp::fail(QP_E_BAD_ARG, "bad device format %d", format);
+  A.format = format;
+  A.stored = (format == QP_FMT_RBCSR) ? rb_stored : nnz;
+
+  // ---- column indices ----
+  std::vector<int32_t> hcols((size_t)std::max<int64_t>(A.stored, 1), 0);
+  if (format == QP_FMT_RBCSR) {
+    for (int64_t r = 0; r < nrows; ++r) {
+      const int64_t len = ur[r + 1] - ur[r];
+      const int64_t w = (bptr[r / kRB + 1] - bptr[r / kRB]) / kRB;
+      const int32_t padcol = len > 0 ? uc[ur[r]] : 0;
+      for (int64_t k = 0; k < w; ++k) hcols[rb_col_pos(bptr, r, k)] = (k < len) ? uc[ur[r] + k] : padcol;
+    }
+    QP_CHECK(dev_alloc(&A.bptr, bptr.size()));
+    QP_HIP(hipMemcpy(A.bptr, bptr.data(), bptr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+  } else {
+    std::copy(uc.begin(), uc.end(), hcols.begin());
+    QP_CHECK(dev_alloc(&A.rowptr, ur.size()));
+    QP_HIP(hipMemcpy(A.rowptr, ur.data(), ur.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    double mean = nrows > 0 ? (double)nnz / (double)nrows : 1.0;
+    int T = 2;
+    while (T < 64 && T < mean) T *= 2;
+    A.lanes_per_row = T;
+  }
+  QP_CHECK(dev_alloc(&A.cols, (size_t)A.stored));
+  QP_HIP(hipMemcpy(A.cols, hcols.data(), (size_t)A.stored * sizeof(int32_t), hipMemcpyHostToDevice));
+  hcols.clear();
+  hcols.shrink_to_fit();
+
+  // ---- value planes ----
+  std::vector<cplx> hplane((size_t)std::max<int64_t>(A.stored, 1));
+  for (int l = 0; l < nops; ++l) {
+    std::fill(hplane.begin(), hplane.end(), cplx(0.0));
+    const qp_matrix* M = ops[l];
+    for (int64_t r = 0; r < nrows; ++r) {
+      int64_t k = 0;  // position in the union row
+      for (int64_t p = M->rowptr[r]; p < M->rowptr[r + 1]; ++p) {
+        while (uc[ur[r] + k] != M->col[p]) ++k;
+        const int64_t pos = (format == QP_FMT_RBCSR) ? rb_val_pos(bptr, r, k) : ur[r] + k;
+        hplane[pos] += M->vals[p];  // duplicates within a row are summed, as in Julia sparse()
+      }
+    }
+    double2* dp = nullptr;
+    QP_CHECK(dev_alloc(&dp, (size_t)A.stored));
+    op->planes.push_back(dp);
+    QP_HIP(hipMemcpy(dp, hplane.data(), (size_t)A.stored * sizeof(double2), hipMemcpyHostToDevice));
+  }
+  QP_CHECK(dev_alloc(&op->planes_dev, (size_t)nops));
+  QP_HIP(hipMemcpy(op->planes_dev, op->planes.data(), nops * sizeof(double2*), hipMemcpyHostToDevice));
+  A.vals = op->planes[0];
+  qp_operator* raw = op.release();
+  // coefficients start at 1 (Operator with all-ones coeffs); make vals consistent
+  std::vector<qp_c128> ones(ncoeffs, qp_c128{1.0, 0.0});
+  int rc = qp_operator_set_coeffs(raw, ones.data(), ncoeffs);
+  if (rc != QP_OK) {
+    operator_free(raw);
+    return rc;
+  }
+  *out = raw;
+  return QP_OK;
+  QP_CATCH
+}
+
+static int operator_refresh(qp_operator* op) {
+  qp_ctx* ctx = op->ctx;
+  const int drift = op->nops - op->ncoeffs;  // src/generators.jl:635
+  std::vector<double2> eff(op->nops);
+  bool all_one = true;
+  for (int l = 0; l < op->nops; ++l) {
+    cplx c = op->scale;
+    if (l >= drift) c *= op->coeffs[l - drift];
+    eff[l] = d2(c);
+    if (!(c == cplx(1.0))) all_one = false;
+  }
+  if (op->nops == 1 && all_one) {
+    op->A.vals = op->planes[0];
+    return QP_OK;
+  }
+  if (!op->combined) QP_CHECK(dev_alloc(&op->combined, (size_t)op->A.stored));
+  QP_CHECK(qp::launch_combine_planes(ctx->stream, op->combined, op->planes_dev, eff.data(), op->nops, op->A.stored,
+                                     &ctx->stats));
+  op->A.vals = op->combined;
+  return QP_OK;
+}
+
+int qp_operator_set_coeffs(qp_operator* op, const qp_c128* coeffs, int ncoeffs) {
+  QP_TRY
+  if (!op || (ncoeffs > 0 && !coeffs)) return qp::fail(QP_E_BAD_ARG, "qp_operator_set_coeffs: NULL argument");
+  if (ncoeffs != op->ncoeffs) return qp::fail(QP_E_BAD_ARG, "expected %d coefficients, got %d", op->ncoeffs, ncoeffs);
+  QP_CHECK(use(op->ctx));
+  for (int i = 0; i < ncoeffs; ++i) op->coeffs[i] = cx(coeffs[i]);
+  return operator_refresh(op);
+  QP_CATCH
+}
+
+int qp_operator_set_scale(qp_operator* op, qp_c128 scale) {
+  QP_TRY
+  if (!op) return qp::fail(QP_E_BAD_ARG, "operator is NULL");
+  QP_CHECK(use(op->ctx));
+  op->scale = cx(scale);
+  return operator_refresh(op);
+  QP_CATCH
+}
+
+int qp_operator_destroy(qp_operator* op) {
+  QP_TRY
+  return operator_free(op);
+  QP_CATCH
+}
+
+int qp_operator_info(const qp_operator* op, int64_t* nrows, int64_t* ncols, int64_t* nnz, int* format) {
+  if (!op) return qp::fail(QP_E_BAD_ARG, "operator is NULL");
+  if (nrows) *nrows = op->A.nrows;
+  if (ncols) *ncols = op->A.ncols;
+  if (nnz) *nnz = op->A.nnz;
+  if (format) *format = op->A.format;
+  return QP_OK;
+}
+
+// download the *device* copy (current combined values) back as canonical CSR
+int qp_operator_get_csr(qp_operator* op, int64_t* rowptr, int32_t* col, qp_c128* vals) {
+  QP_TRY
+  if (!op || !rowptr || !col || !vals) return qp::fail(QP_E_BAD_ARG, "qp_operator_get_csr: NULL argument");
+  QP_CHECK(use(op->ctx));
+  const DevMatrix& A = op->A;
+  std::vector<cplx> hv((size_t)std::max<int64_t>(A.stored, 1));
+  std::vector<int32_t> hc((size_t)std::max<int64_t>(A.stored, 1));
+  QP_HIP(hipStreamSynchronize(op->ctx->stream));
+  QP_HIP(hipMemcpy(hv.data(), A.vals, (size_t)A.stored * sizeof(double2), hipMemcpyDeviceToHost));
+  QP_HIP(hipMemcpy(hc.data(), A.cols, (size_t)A.stored * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (A.format == QP_FMT_CSR) {
+    std::vector<int64_t> rp(A.nrows + 1);
+    QP_HIP(hipMemcpy(rp.data(), A.rowptr, rp.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+    std::memcpy(rowptr, rp.data(), rp.size() * sizeof(int64_t));
+    std::memcpy(col, hc.data(), (size_t)A.nnz * sizeof(int32_t));
+    std::memcpy(vals, hv.data(), (size_t)A.nnz * sizeof(qp_c128));
+  } else {
+    std::vector<int64_t> bptr(A.nblocks + 1);
+    QP_HIP(hipMemcpy(bptr.data(), A.bptr, bptr.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+    const auto& ur = op->u_rowptr;
+    for (int64_t r = 0; r <= A.nrows; ++r) rowptr[r] = ur[r];
+    for (int64_t r = 0; r < A.nrows; ++r)
+      for (int64_t k = 0; k < ur[r + 1] - ur[r]; ++k) {
+        col[ur[r] + k] = hc[rb_col_pos(bptr, r, k)];
+        cplx v = hv[rb_val_pos(bptr, r, k)];
+        vals[ur[r] + k] = qp_c128{v.real(), v.imag()};
+      }
+  }
+  return QP_OK;
+  QP_CATCH
+}
+
+// ---------------------------------------------------------------------------
+// states and BLAS-1
+// ---------------------------------------------------------------------------
+int qp_state_create(qp_ctx* ctx, int64_t n, qp_state** out) {
+  QP_TRY
+  if (!ctx || !out || n < 0) return qp::fail(QP_E_BAD_ARG, "qp_state_create: bad arguments");
+  QP_CHECK(use(ctx));
+  auto s = std::make_unique<qp_state>();
+  s->ctx = ctx;
+  s->n = n;
+  s->own = true;
+  QP_CHECK(dev_alloc(&s->d, (size_t)n));
+  QP_HIP(hipMemsetAsync(s->d, 0, (size_t)n * sizeof(double2), ctx->stream));
+  *out = s.release();
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_state_wrap(qp_ctx* ctx, void* device_ptr, int64_t n, qp_state** out) {
+  QP_TRY
+  if (!ctx || !out || !device_ptr || n < 0) return qp::fail(QP_E_BAD_ARG, "qp_state_wrap: bad arguments");
+  if ((uintptr_t)device_ptr % 16 != 0) return qp::fail(QP_E_BAD_ARG, "device pointer must be 16-byte aligned");
+  auto s = std::make_unique<qp_state>();
+  s->ctx = ctx;
+  s->d = static_cast<double2*>(device_ptr);
+  s->n = n;
+  s->own = false;
+  *out = s.release();
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_state_destroy(qp_state* s) {
+  QP_TRY
+  if (!s) return QP_OK;
+  if (s->own) {
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+    (void)hipFree(s->d);
+  }
+  delete s;
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_state_upload(qp_state* s, const qp_c128* host) {
+  QP_TRY
+  if (!s || !host) return qp::fail(QP_E_BAD_ARG, "qp_state_upload: NULL argument");
+  QP_CHECK(use(s->ctx));
+  QP_HIP(hipMemcpyAsync(s->d, host, (size_t)s->n * sizeof(double2), hipMemcpyHostToDevice, s->ctx->stream));
+  QP_HIP(hipStreamSynchronize(s->ctx->stream));
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_state_download(const qp_state* s, qp_c128* host) {
+  QP_TRY
+  if (!s || !host) return qp::fail(QP_E_BAD_ARG, "qp_state_download: NULL argument");
+  QP_CHECK(use(s->ctx));
+  QP_HIP(hipMemcpyAsync(host, s->d, (size_t)s->n * sizeof(double2), hipMemcpyDeviceToHost, s->ctx->stream));
+  QP_HIP(hipStreamSynchronize(s->ctx->stream));
+  return QP_OK;
+  QP_CATCH
+}
+
+void* qp_state_ptr(const qp_state* s) { return s ? s->d : nullptr; }
+int64_t qp_state_len(const qp_state* s) { return s ? s->n : -1; }
+
+int qp_copy(qp_state* dst, const qp_state* src) {
+  QP_TRY
+  if (!dst || !src || dst->n != src->n) return qp::fail(QP_E_BAD_ARG, "qp_copy: length mismatch");
+  QP_CHECK(use(dst->ctx));
+  if (dst->d != src->d)
+    QP_HIP(hipMemcpyAsync(dst->d, src->d, (size_t)dst->n * sizeof(double2), hipMemcpyDeviceToDevice, dst->ctx->stream));
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_scal(qp_state* x, qp_c128 alpha) {
+  QP_TRY
+  if (!x) return qp::fail(QP_E_BAD_ARG, "state is NULL");
+  QP_CHECK(use(x->ctx));
+  return qp::launch_scal(x->ctx->stream, x->d, d2(alpha), x->n, &x->ctx->stats);
+  QP_CATCH
+}
+
+int qp_axpy(qp_c128 alpha, const qp_state* x, qp_state* y) {
+  QP_TRY
+  if (!x || !y || x->n != y->n) return qp::fail(QP_E_BAD_ARG, "qp_axpy: length mismatch");
+  QP_CHECK(use(y->ctx));
+  return qp::launch_axpy(y->ctx->stream, d2(alpha), x->d, y->d, y->n, &y->ctx->stats);
+  QP_CATCH
+}
+
+int qp_fill(qp_state* x, qp_c128 alpha) {
+  QP_TRY
+  if (!x) return qp::fail(QP_E_BAD_ARG, "state is NULL");
+  QP_CHECK(use(x->ctx));
+  return qp::launch_fill(x->ctx->stream, x->d, d2(alpha), x->n, &x->ctx->stats);
+  QP_CATCH
+}
+
+int qp_dot(const qp_state* x, const qp_state* y, qp_c128* out) {
+  QP_TRY
+  if (!x || !y || !out || x->n != y->n) return qp::fail(QP_E_BAD_ARG, "qp_dot: bad arguments");
+  QP_CHECK(use(x->ctx));
+  cplx r;
+  QP_CHECK(dot_sync(x->ctx, x->d, y->d, x->n, &r));
+  *out = qp_c128{r.real(), r.imag()};
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_norm(const qp_state* x, double* out) {
+  QP_TRY
+  if (!x || !out) return qp::fail(QP_E_BAD_ARG, "qp_norm: bad arguments");
+  QP_CHECK(use(x->ctx));
+  cplx r;
+  QP_CHECK(dot_sync(x->ctx, x->d, x->d, x->n, &r));
+  *out = std::sqrt(r.real());
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_mul(qp_operator* op, const qp_state* x, qp_state* y, qp_c128 alpha, qp_c128 beta) {
+  QP_TRY
+  if (!op || !x || !y) return qp::fail(QP_E_BAD_ARG, "qp_mul: NULL argument");
+  if (x->n != op->A.ncols || y->n != op->A.nrows)
+    return qp::fail(QP_E_BAD_ARG, "qp_mul: shape mismatch (op %lld x %lld, x %lld, y %lld)", (long long)op->A.nrows,
+                    (long long)op->A.ncols, (long long)x->n, (long long)y->n);
+  if (x->d == y->d) return qp::fail(QP_E_BAD_ARG, "qp_mul: x and y must not alias");
+  QP_CHECK(use(op->ctx));
+  qp::PlainEpi e;
+  e.y = y->d;
+  e.alpha = d2(alpha);
+  e.beta = d2(beta);
+  e.beta_zero = (beta.re == 0.0 && beta.im == 0.0);
+  return qp::launch_spmv_plain(op->ctx->stream, op->A, x->d, e, &op->ctx->stats);
+  QP_CATCH
+}
+
+int qp_dot_op(const qp_state* x, qp_operator* op, const qp_state* y, qp_state* tmp, qp_c128* out) {
+  QP_TRY
+  if (!x || !op || !y || !tmp || !out) return qp::fail(QP_E_BAD_ARG, "qp_dot_op: NULL argument");
+  QP_CHECK(qp_mul(op, y, tmp, qp_c128{1, 0}, qp_c128{0, 0}));
+  return qp_dot(x, tmp, out);
+  QP_CATCH
+}
+
+// ---------------------------------------------------------------------------
+// Chebyshev
+// ---------------------------------------------------------------------------
+int qp_cheby_create(qp_ctx* ctx, int64_t n, qp_cheby** out) {
+  QP_TRY
+  if (!ctx || !out || n < 0) return qp::fail(QP_E_BAD_ARG, "qp_cheby_create: bad arguments");
+  QP_CHECK(use(ctx));
+  auto w = std::make_unique<qp_cheby>();
+  w->ctx = ctx;
+  w->n = n;
+  QP_CHECK(dev_alloc(&w->bufA, (size_t)n));
+  QP_CHECK(dev_alloc(&w->acc, (size_t)n));
+  *out = w.release();
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_cheby_destroy(qp_cheby* w) {
+  QP_TRY
+  if (!w) return QP_OK;
+  (void)hipSetDevice(w->ctx->device);
+  (void)hipStreamSynchronize(w->ctx->stream);
+  if (w->bufA) (void)hipFree(w->bufA);
+  if (w->acc) (void)hipFree(w->acc);
+  if (w->chk_part) (void)hipFree(w->chk_part);
+  if (w->chk_out) (void)hipFree(w->chk_out);
+  delete w;
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_cheby_term(qp_operator* op, const qp_state* x, int64_t xoff, const qp_state* v0, qp_state* vout,
+                  const qp_state* acc_in, qp_state* acc_out, qp_c128 c, double beta, double a_prev, double a,
+                  qp_c128 phase) {
+  QP_TRY
+  if (!op || !x || !acc_out) return qp::fail(QP_E_BAD_ARG, "qp_cheby_term: NULL argument");
+  const int64_t nr = op->A.nrows;
+  if (x->n != op->A.ncols || xoff < 0 || xoff + nr > x->n) return qp::fail(QP_E_BAD_ARG, "qp_cheby_term: x shape / offset mismatch");
+  if ((v0 && v0->n != nr) || (vout && vout->n != nr) || (acc_in && acc_in->n != nr) || acc_out->n != nr)
+    return qp::fail(QP_E_BAD_ARG, "qp_cheby_term: local vector length mismatch");
+  auto overlaps = [&](const qp_state* s) { return s && s->d < x->d + x->n && x->d < s->d + s->n; };
+  if (overlaps(vout) || overlaps(acc_out)) return qp::fail(QP_E_BAD_ARG, "qp_cheby_term: outputs must not overlap the gathered x");
+  QP_CHECK(use(op->ctx));
+  qp::ChebyEpi e;
+  e.xloc = x->d + xoff;
+  e.v0 = v0 ? v0->d : nullptr;
+  e.vout = vout ? vout->d : nullptr;
+  e.acc_in = acc_in ? acc_in->d : nullptr;
+  e.acc_out = acc_out->d;
+  e.c = d2(c);
+  e.beta = beta;
+  e.a_prev = a_prev;
+  e.a = a;
+  e.phase = d2(phase);
+  e.apply_phase = !(phase.re == 1.0 && phase.im == 0.0);
+  e.check_partials = nullptr;
+  return qp::launch_spmv_cheby(op->ctx->stream, op->A, x->d, e, &op->ctx->stats);
+  QP_CATCH
+}
+
+int qp_cheby_step(qp_cheby* w, qp_operator* op, qp_state* psi, const double* a, int n_coeffs, double Delta,
+                  double E_min, double dt, double wrk_dt, double limit, int check_normalization) {
+  QP_TRY
+  if (!w || !op || !psi || !a) return qp::fail(QP_E_BAD_ARG, "qp_cheby_step: NULL argument");
+  if (op->A.nrows != op->A.ncols || psi->n != op->A.nrows || w->n != psi->n)
+    return qp::fail(QP_E_BAD_ARG, "qp_cheby_step: shape mismatch");
+  // @assert abs(dt) ~ abs(wrk.dt)   (isapprox, rtol = sqrt(eps))   src/cheby.jl:157
+  {
+    const double x = std::fabs(dt), y = std::fabs(wrk_dt);
+    if (!(std::fabs(x - y) <= 1.4901161193847656e-08 * std::max(x, y)))
+      return qp::fail(QP_E_DT_MISMATCH, "wrk was initialized for dt=%g, not dt=abs(%g)", wrk_dt, dt);
+  }
+  if (n_coeffs < 2) return qp::fail(QP_E_TOO_FEW_COEFFS, "Need at least 2 Chebychev coefficients");
+  if (!(Delta > 0)) return qp::fail(QP_E_BAD_ARG, "Delta must be positive");
+  qp_ctx* ctx = op->ctx;
+  QP_CHECK(use(ctx));
+  const double beta = (Delta / 2) + E_min;                        // :156
+  cplx c = (dt > 0) ? cplx(0, -2.0) / Delta : cplx(0, 2.0) / Delta;  // :158-162
+  const cplx phase = std::exp(cplx(0, -1) * beta * dt);            // :211
+  const int nterms = n_coeffs - 1;
+  const DevMatrix& A = op->A;
+  const int nwg = qp::spmv_grid_size(A);
+  if (check_normalization) {
+    if (w->chk_wg < nwg) {
+      if (w->chk_part) QP_HIP(hipFree(w->chk_part));
+      QP_CHECK(dev_alloc(&w->chk_part, (size_t)3 * nwg));
+      w->chk_wg = nwg;
+    }
+    if (w->chk_terms < nterms) {
+      if (w->chk_out) QP_HIP(hipFree(w->chk_out));
+      QP_CHECK(dev_alloc(&w->chk_out, (size_t)3 * nterms));
+      w->chk_terms = nterms;
+    }
+  }
+  double2* P = psi->d;
+  double2* B = w->bufA;
+  double2* ACC = w->acc;
+  double2* result = nullptr;
+  for (int m = 1; m <= nterms; ++m) {
+    const bool last = (m == nterms);
+    qp::ChebyEpi e;
+    const double2* x;
+    if (m == 1) {
+      // v0 = Psi; Psi = a1 v0; v1 = c (H v0 - beta v0); Psi += a2 v1     :171-182
+      x = P;
+      e.v0 = nullptr;
+      e.vout = last ? nullptr : B;
+      e.acc_in = nullptr;
+      e.acc_out = ACC;
+      e.a_prev = a[0];
+      result = ACC;
+    } else {
+      // v2 = c (H v1 - beta v1) + v0; Psi += a_i v2; rotate            :186-207
+      double2* xb = (m % 2 == 0) ? B : P;   // holds v1 (gathered)
+      double2* ob = (m % 2 == 0) ? P : B;   // holds v0, overwritten in place by v2
+      x = xb;
+      e.v0 = ob;
+      e.vout = last ? nullptr : ob;
+      e.acc_in = ACC;
+      e.acc_out = (last && xb == B) ? P : ACC;  // P may be written only while it is not gathered
+      e.a_prev = 0.0;
+      result = e.acc_out;
+    }
+    e.xloc = x;
+    e.c = d2(c);
+    e.beta = beta;
+    e.a = a[m];
+    e.phase = d2(phase);
+    e.apply_phase = last ? 1 : 0;
+    // the reference checks terms i >= 3 only (inside the loop at :186)
+    e.check_partials = (check_normalization && m >= 2) ? w->chk_part : nullptr;
+    QP_CHECK(qp::launch_spmv_cheby(ctx->stream, A, x, e, &ctx->stats));
+    if (e.check_partials)
+      QP_CHECK(qp::launch_reduce_triples(ctx->stream, w->chk_part, nwg, w->chk_out + 3 * (m - 1), &ctx->stats));
+    if (m == 1) c *= 2.0;  // :184
+  }
+  if (result != P) QP_HIP(hipMemcpyAsync(P, result, (size_t)psi->n * sizeof(double2), hipMemcpyDeviceToDevice, ctx->stream));
+  ctx->stats.n_cheby_steps++;
+  if (check_normalization && nterms >= 2) {
+    std::vector<double> h((size_t)3 * nterms);
+    QP_HIP(hipMemcpyAsync(h.data(), w->chk_out, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    QP_HIP(hipStreamSynchronize(ctx->stream));
+    for (int m = 2; m <= nterms; ++m) {
+      const double* t = &h[3 * (m - 1)];
+      const double map_norm = std::hypot(t[0], t[1]) / (2 * t[2]);   // :195
+      if (!(map_norm <= 1.0 + limit))
+        return qp::fail(QP_E_NORMALIZATION, "Incorrect normalization (E_min=%g, Delta=%g)", E_min, Delta);
+    }
+  }
+  return QP_OK;
+  QP_CATCH
+}
+
+// ---------------------------------------------------------------------------
+// Arnoldi
+// ---------------------------------------------------------------------------
+int qp_krylov_create(qp_ctx* ctx, int64_t n, int nvec, qp_krylov** out) {
+  QP_TRY
+  if (!ctx || !out || n < 0 || nvec < 2) return qp::fail(QP_E_BAD_ARG, "qp_krylov_create: bad arguments");
+  QP_CHECK(use(ctx));
+  auto q = std::make_unique<qp_krylov>();
+  q->ctx = ctx;
+  q->n = n;
+  q->nvec = nvec;
+  QP_CHECK(dev_alloc(&q->Q, (size_t)n * nvec));
+  QP_CHECK(dev_alloc(&q->hess_dev, (size_t)nvec * nvec));
+  QP_CHECK(dev_alloc(&q->norms_dev, (size_t)nvec));
+  QP_CHECK(dev_alloc(&q->part, (size_t)2 * kRedBlocks));
+  *out = q.release();
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_krylov_destroy(qp_krylov* q) {
+  QP_TRY
+  if (!q) return QP_OK;
+  (void)hipSetDevice(q->ctx->device);
+  (void)hipStreamSynchronize(q->ctx->stream);
+  if (q->Q) (void)hipFree(q->Q);
+  if (q->hess_dev) (void)hipFree(q->hess_dev);
+  if (q->norms_dev) (void)hipFree(q->norms_dev);
+  if (q->part) (void)hipFree(q->part);
+  delete q;
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_krylov_download(const qp_krylov* q, int i, qp_c128* host) {
+  QP_TRY
+  if (!q || !host || i < 0 || i >= q->nvec) return qp::fail(QP_E_BAD_ARG, "qp_krylov_download: bad arguments");
+  QP_CHECK(use(q->ctx));
+  QP_HIP(hipMemcpyAsync(host, q->q(i), (size_t)q->n * sizeof(double2), hipMemcpyDeviceToHost, q->ctx->stream));
+  QP_HIP(hipStreamSynchronize(q->ctx->stream));
+  return QP_OK;
+  QP_CATCH
+}
+
+namespace {
+
+// q[j+1] = H q[j], then modified Gram-Schmidt against q[0..j] with the fused
+// axpy->dot passes; leaves |q[j+1]|^2 partials in part[(j+1)&1].  hess column `hcol`
+// (device, length >= j+1) receives dt*<q_i|q_j+1>.
+int arnoldi_column(qp_operator* op, qp_krylov* q, int j, double dt, double2* hcol) {
+  qp_ctx* ctx = op->ctx;
+  qp::PlainEpi pe;
+  pe.y = q->q(j + 1);
+  pe.alpha = make_double2(1.0, 0.0);
+  pe.beta = make_double2(0.0, 0.0);
+  pe.beta_zero = 1;
+  QP_CHECK(qp::launch_spmv_plain(ctx->stream, op->A, q->q(j), pe, &ctx->stats));  // src/arnoldi.jl:82
+  for (int i = 0; i <= j + 1; ++i) {                                              // :84-87
+    qp::MgsArgs a;
+    a.w = q->q(j + 1);
+    a.q_prev = (i > 0) ? q->q(i - 1) : nullptr;
+    a.q_cur = (i <= j) ? q->q(i) : nullptr;
+    a.part_in = q->part + (size_t)((i + 1) & 1) * kRedBlocks;
+    a.part_out = q->part + (size_t)(i & 1) * kRedBlocks;
+    a.hess_prev = (i > 0) ? hcol + (i - 1) : nullptr;
+    a.dt = dt;
+    a.n = q->n;
+    QP_CHECK(qp::launch_mgs_pass(ctx->stream, a, &ctx->stats));
+  }
+  return QP_OK;
+}
+
+}  // namespace
+
+__global__ void norm_guard_scale_kernel(double2* __restrict__ w, const double2* __restrict__ part_in, double2* hess_slot,
+                                        double* norm_slot, double dt, double norm_min, int64_t n);
+
+int qp_arnoldi(qp_operator* op, qp_krylov* q, int m, const qp_state* psi, double dt, int extended, double norm_min,
+               qp_c128* Hess, int ldh, int* m_out) {
+  QP_TRY
+  if (!op || !q || !psi || !Hess || !m_out) return qp::fail(QP_E_BAD_ARG, "qp_arnoldi: NULL argument");
+  const int dim = extended ? m + 1 : m;
+  if (m < 1 || ldh < dim || q->nvec < m + 1) return qp::fail(QP_E_BAD_ARG, "qp_arnoldi: Hess/q too small for m=%d", m);
+  if (op->A.nrows != op->A.ncols || psi->n != op->A.nrows || q->n != psi->n) return qp::fail(QP_E_BAD_ARG, "qp_arnoldi: shape mismatch");
+  qp_ctx* ctx = op->ctx;
+  QP_CHECK(use(ctx));
+  const int ldd = q->nvec;
+  std::memset(Hess, 0, sizeof(qp_c128) * (size_t)ldh * ldh);                                      // :78
+  QP_HIP(hipMemsetAsync(q->hess_dev, 0, sizeof(double2) * (size_t)ldd * ldd, ctx->stream));
+  QP_HIP(hipMemsetAsync(q->norms_dev, 0, sizeof(double) * (size_t)ldd, ctx->stream));
+  QP_HIP(hipMemcpyAsync(q->q(0), psi->d, (size_t)q->n * sizeof(double2), hipMemcpyDeviceToDevice, ctx->stream));  // :79
+  for (int j = 0; j < m; ++j) {
+    double2* hcol = q->hess_dev + (size_t)j * ldd;
+    QP_CHECK(arnoldi_column(op, q, j, dt, hcol));
+    if ((j + 1 < m) || extended) {                                                                 // :88-97
+      hipLaunchKernelGGL(norm_guard_scale_kernel, dim3(2048), dim3(qp::kThreads), 0, ctx->stream, q->q(j + 1),
+                         q->part + (size_t)((j + 1) & 1) * kRedBlocks, hcol + (j + 1), q->norms_dev + j, dt, norm_min, q->n);
+      QP_HIP(hipGetLastError());
+      ctx->stats.n_launch++;
+    }
+  }
+  std::vector<cplx> hh((size_t)ldd * ldd);
+  std::vector<double> hn(ldd);
+  QP_HIP(hipMemcpyAsync(hh.data(), q->hess_dev, hh.size() * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
+  QP_HIP(hipMemcpyAsync(hn.data(), q->norms_dev, hn.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  QP_HIP(hipStreamSynchronize(ctx->stream));
+  int m_eff = m;
+  for (int j = 0; j < m; ++j) {
+    if (((j + 1 < m) || extended) && hn[j] < norm_min) {  // dimensionality exhausted  :91-95
+      m_eff = j + 1;
+      break;
+    }
+  }
+  for (int j = 0; j < m_eff; ++j) {
+    const int rows = std::min(j + 2, dim);
+    for (int i = 0; i < rows; ++i) {
+      cplx v = hh[(size_t)j * ldd + i];
+      Hess[(size_t)j * ldh + i] = qp_c128{v.real(), v.imag()};
+    }
+  }
+  *m_out = m_eff;
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_arnoldi_extend(qp_operator* op, qp_krylov* q, int m, double dt, double norm_min, qp_c128* Hess, int ldh,
+                      int* extended_out) {
+  QP_TRY
+  if (!op || !q || !Hess) return qp::fail(QP_E_BAD_ARG, "qp_arnoldi_extend: NULL argument");
+  if (m < 2 || ldh < m || q->nvec < m + 1) return qp::fail(QP_E_BAD_ARG, "qp_arnoldi_extend: Hess/q too small for m=%d", m);
+  qp_ctx* ctx = op->ctx;
+  QP_CHECK(use(ctx));
+  if (extended_out) *extended_out = 0;
+  cplx n2;
+  QP_CHECK(dot_sync(ctx, q->q(m - 1), q->q(m - 1), q->n, &n2));
+  const double h = std::sqrt(n2.real());                                   // src/arnoldi.jl:116
+  if (h < norm_min) return QP_OK;                                          // :117
+  Hess[(size_t)(m - 2) * ldh + (m - 1)] = qp_c128{dt * h, 0.0};            // :118
+  const double inv = 1.0 / h;
+  QP_CHECK(qp::launch_scal(ctx->stream, q->q(m - 1), make_double2(inv, 0.0), q->n, &ctx->stats));  // :119
+  double2* hcol = q->hess_dev;  // scratch column
+  QP_CHECK(arnoldi_column(op, q, m - 1, dt, hcol));                        // :120-124
+  std::vector<cplx> hc(m);
+  QP_HIP(hipMemcpyAsync(hc.data(), hcol, (size_t)m * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
+  QP_HIP(hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < m; ++i) Hess[(size_t)(m - 1) * ldh + i] = qp_c128{hc[i].real(), hc[i].imag()};
+  if (extended_out) *extended_out = 1;
+  return QP_OK;
+  QP_CATCH
+}
+
+}  // extern "C"
+
+// norm + guarded scale: lmul!(1/h) only when h >= norm_min (src/arnoldi.jl:89-96); the
+// raw norm is kept so that the host can detect breakdown also for dt < 0.
+__global__ __launch_bounds__(qp::kThreads) void norm_guard_scale_kernel(double2* __restrict__ w,
+                                                                        const double2* __restrict__ part_in,
+                                                                        double2* hess_slot, double* norm_slot, double dt,
+                                                                        double norm_min, int64_t n) {
+  __shared__ double2 lds[qp::kThreads / 64];
+  double2 v = part_in[threadIdx.x];
+  for (int o = 32; o > 0; o >>= 1) {
+    v.x += __shfl_down(v.x, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const double s2 = lds[0].x + lds[1].x + lds[2].x + lds[3].x;
+  const double h = sqrt(s2);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    *hess_slot = make_double2(dt * h, 0.0);
+    *norm_slot = h;
+  }
+  if (h < norm_min) return;
+  const double inv = 1.0 / h;
+  for (int64_t i = (int64_t)blockIdx.x * qp::kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * qp::kThreads) {
+    double2 t = w[i];
+    t.x *= inv;
+    t.y *= inv;
+    w[i] = t;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Newton
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int qp_newton_create(qp_ctx* ctx, int64_t n, int m_max, qp_newton** out) {
+  QP_TRY
+  if (!ctx || !out || n < 0) return qp::fail(QP_E_BAD_ARG, "qp_newton_create: bad arguments");
+  if (m_max <= 2) return qp::fail(QP_E_M_MAX, "Newton propagation requires m_max > 2");          // src/newton.jl:38-40
+  if (m_max >= n) {                                                                              // :41-46
+    m_max = (int)n - 1;
+    if (m_max <= 2) return qp::fail(QP_E_M_MAX, "Newton propagation requires state dimension > 2");
+  }
+  QP_CHECK(use(ctx));
+  auto w = std::make_unique<qp_newton>();
+  w->ctx = ctx;
+  w->n = n;
+  w->m_max = m_max;
+  QP_CHECK(qp_krylov_create(ctx, n, m_max + 1, &w->q));
+  QP_CHECK(dev_alloc(&w->v, (size_t)n));
+  QP_CHECK(dev_alloc(&w->npart, (size_t)kRedBlocks));
+  QP_HIP(hipHostMalloc((void**)&w->h_npart, kRedBlocks * sizeof(double2), hipHostMallocDefault));
+  w->a.assign((size_t)10 * m_max + 1, cplx(0));      // :50-51
+  w->leja.assign((size_t)10 * m_max + 1, cplx(0));
+  *out = w.release();
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_newton_destroy(qp_newton* w) {
+  QP_TRY
+  if (!w) return QP_OK;
+  (void)hipSetDevice(w->ctx->device);
+  (void)hipStreamSynchronize(w->ctx->stream);
+  qp_krylov_destroy(w->q);
+  if (w->v) (void)hipFree(w->v);
+  if (w->npart) (void)hipFree(w->npart);
+  if (w->h_npart) (void)hipHostFree(w->h_npart);
+  delete w;
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_newton_get_coeffs(const qp_newton* w, qp_c128* a, qp_c128* leja, int cap) {
+  if (!w) return qp::fail(QP_E_BAD_ARG, "newton workspace is NULL");
+  if (cap < w->n_a) return qp::fail(QP_E_BAD_ARG, "need room for %d coefficients", w->n_a);
+  for (int i = 0; i < w->n_a; ++i) {
+    if (a) a[i] = qp_c128{w->a[i].real(), w->a[i].imag()};
+    if (leja) leja[i] = qp_c128{w->leja[i].real(), w->leja[i].imag()};
+  }
+  return QP_OK;
+}
+
+int qp_newton_step(qp_newton* w, qp_operator* op, qp_state* psi, double dt, int func_id, qp_func_cb cb, void* user,
+                   double norm_min, double relerr, int max_restarts, qp_newton_stats* stats) {
+  QP_TRY
+  if (!w || !op || !psi) return qp::fail(QP_E_BAD_ARG, "qp_newton_step: NULL argument");
+  if (op->A.nrows != op->A.ncols || psi->n != op->A.nrows || w->n != psi->n) return qp::fail(QP_E_BAD_ARG, "qp_newton_step: shape mismatch");
+  if (func_id == QP_FUNC_CALLBACK && !cb) return qp::fail(QP_E_BAD_ARG, "callback func is NULL");
+  if (func_id < 0 || func_id > QP_FUNC_CALLBACK) return qp::fail(QP_E_BAD_ARG, "bad func_id");
+  if (dt == 0.0) return qp::fail(QP_E_BAD_ARG, "dt must be non-zero");   // src/newton.jl:263
+  qp_ctx* ctx = op->ctx;
+  QP_CHECK(use(ctx));
+  const int m_max = w->m_max;
+  int m = m_max;                                                        // :253
+  std::fill(w->a.begin(), w->a.end(), cplx(0));                         // :254-255
+  std::fill(w->leja.begin(), w->leja.end(), cplx(0));
+  const int ldh = m_max + 1;
+  std::vector<cplx> Hess((size_t)ldh * ldh, cplx(0));
+  std::vector<cplx> R(m + 1), P(m + 1), Rn(m + 1), ritz;
+  int n_a = 0, n_leja = 0, s = 0, n_matvec = 0;
+  double last_relerr = 0, norm_psi = 0;
+  const size_t bytes = (size_t)w->n * sizeof(double2);
+  qp_state vstate{ctx, w->v, w->n, false};
+  QP_HIP(hipMemcpyAsync(w->v, psi->d, bytes, hipMemcpyDeviceToDevice, ctx->stream));  // :268
+  cplx n2;
+  QP_CHECK(dot_sync(ctx, w->v, w->v, w->n, &n2));
+  double beta = std::sqrt(n2.real());                                                // :271
+  QP_CHECK(qp::launch_scal(ctx->stream, w->v, make_double2(1.0 / beta, 0.0), w->n, &ctx->stats));  // :272
+  while (true) {                                                                     // :274
+    int m_req = m;
+    QP_CHECK(qp_arnoldi(op, w->q, m_req, &vstate, dt, 1, norm_min, reinterpret_cast<qp_c128*>(Hess.data()), ldh, &m));
+    n_matvec += m_req;
+    if (m == 1 && s == 0) {                                                          // :289-295
+      const cplx lam = beta * Hess[0];
+      const cplx f = qp::eval_func(func_id, cb, user, lam);
+      QP_CHECK(qp::launch_scal(ctx->stream, psi->d, d2(f), psi->n, &ctx->stats));
+      break;
+    }
+    ritz.assign((size_t)m * (m + 1) / 2, cplx(0));
+    if (qp::diagonalize_hessenberg(Hess.data(), ldh, m, true, ritz.data()) != QP_OK)  // :297
+      return qp::fail(QP_E_INTERNAL, "Hessenberg QR did not converge");
+    if (s == 0) {                                                                    // :301-303, :67-70
+      double rmax = 0;
+      for (auto& z : ritz) rmax = std::max(rmax, std::abs(z));
+      w->radius = 1.2 * rmax;
+    }
+    const int n_s = n_leja;                                                          // :307
+    if ((int)w->leja.size() < n_leja + m) w->leja.resize((size_t)2 * (n_leja + m), cplx(0));  // :105-110
+    qp::extend_leja(w->leja.data(), n_leja, ritz.data(), (int)ritz.size(), m);
+    n_leja += m;
+    if ((int)w->a.size() < n_leja) w->a.resize((size_t)2 * n_leja, cplx(0));         // :187-192
+    {
+      int st = qp::extend_newton_coeffs(w->a.data(), n_a, w->leja.data(), func_id, cb, user, n_leja, w->radius);  // :314
+      if (st == QP_E_DIVDIFF_UNDERFLOW) return qp::fail(st, "Divided differences too small");
+      if (st != QP_OK) return qp::fail(st, "extend_newton_coeffs failed (radius=%g)", w->radius);
+      n_a = n_leja;
+    }
+    // Newton polynomial in the extended Hessenberg matrix                           :328-343
+    const int mp = m + 1;
+    R.assign(mp, cplx(0));
+    P.assign(mp, cplx(0));
+    Rn.assign(mp, cplx(0));
+    R[0] = beta;
+    P[0] = w->a[n_s] * beta;
+    auto apply = [&](cplx z) {
+      for (int i = 0; i < mp; ++i) {
+        cplx acc = 0;
+        for (int k = 0; k < mp; ++k) acc += Hess[(size_t)k * ldh + i] * R[k];
+        Rn[i] = (acc - z * R[i]) / w->radius;
+      }
+      std::swap(R, Rn);
+    };
+    for (int k = 1; k <= m - 1; ++k) {
+      apply(w->leja[n_s + k - 1]);
+      for (int i = 0; i < mp; ++i) P[i] += w->a[n_s + k] * R[i];
+    }
+    // Psi = (s == 0 ? 0 : Psi) + sum_i P_i q_i                                      :346-352
+    QP_CHECK(qp::launch_combine_vecs(ctx->stream, psi->d, s == 0 ? 0 : 1, make_double2(1.0, 0.0), w->q->q(0), w->n, m,
+                                     reinterpret_cast<const double2*>(P.data()), w->npart, w->n, &ctx->stats));
+    QP_HIP(hipMemcpyAsync(w->h_npart, w->npart, kRedBlocks * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
+    // starting vector of the next restart                                            :356-367
+    apply(w->leja[n_s + m - 1]);
+    double b2 = 0;
+    for (int i = 0; i < mp; ++i) {
+      const double ab = std::abs(R[i]);
+      b2 += ab * ab;
+    }
+    beta = std::sqrt(b2);
+    for (int i = 0; i < mp; ++i) R[i] *= (1.0 / beta);
+    QP_CHECK(qp::launch_combine_vecs(ctx->stream, w->v, 1, d2(R[0]), w->q->q(1), w->n, m,
+                                     reinterpret_cast<const double2*>(R.data() + 1), nullptr, w->n, &ctx->stats));
+    QP_HIP(hipStreamSynchronize(ctx->stream));
+    norm_psi = std::sqrt(sum_partials(w->h_npart).real());
+    last_relerr = beta * std::abs(w->a[n_a - 1]) / (1 + norm_psi);                    // :370
+    if (last_relerr < relerr) break;
+    s += 1;
+    if (s > max_restarts) {                                                           // :375
+      w->restarts = s;
+      return qp::fail(QP_E_MAX_RESTARTS, "newton!: s=%d exceeds max_restarts=%d (relerr=%g)", s, max_restarts, last_relerr);
+    }
+  }
+  w->restarts = s;
+  w->n_leja = n_leja;
+  w->n_a = n_a;
+  ctx->stats.n_newton_steps++;
+  ctx->stats.n_restarts += s;
+  if (stats) {
+    stats->restarts = s;
+    stats->n_a = n_a;
+    stats->n_leja = n_leja;
+    stats->m_last = m;
+    stats->n_matvec = n_matvec;
+    stats->radius = w->radius;
+    stats->last_relerr = last_relerr;
+    stats->norm_psi = norm_psi;
+  }
+  return QP_OK;
+  QP_CATCH
+}
+
+// ---------------------------------------------------------------------------
+// SpectralRange
+// ---------------------------------------------------------------------------
+int qp_ritzvals(qp_operator* op, const qp_state* state, int m_min, int m_max, double prec, double norm_min,
+                qp_c128* out, int* n_out) {
+  QP_TRY
+  if (!op || !state || !out || !n_out) return qp::fail(QP_E_BAD_ARG, "qp_ritzvals: NULL argument");
+  if (m_max <= m_min) return qp::fail(QP_E_BAD_ARG, "m_max=%d must be larger than m_min=%d", m_max, m_min);  // src/specrad.jl:171-173
+  qp_ctx* ctx = op->ctx;
+  QP_CHECK(use(ctx));
+  int m = std::max(5, std::min(m_min, m_max - 1));                         // :174
+  if (m_max < m) return qp::fail(QP_E_BAD_ARG, "m_max=%d too small (need >= %d)", m_max, m);
+  const int ldh = m_max;
+  std::vector<cplx> Hess((size_t)ldh * ldh, cplx(0));
+  qp_krylov* q = nullptr;
+  QP_CHECK(qp_krylov_create(ctx, state->n, m_max + 1, &q));
+  std::unique_ptr<qp_krylov, int (*)(qp_krylov*)> guard(q, qp_krylov_destroy);
+  std::vector<cplx> ev;
+  auto stats3 = [&](double& lo, double& hi, double& im) {
+    lo = ev[0].real();
+    hi = ev[0].real();
+    im = std::fabs(ev[0].imag());
+    for (auto& z : ev) {
+      lo = std::min(lo, z.real());
+      hi = std::max(hi, z.real());
+      im = std::max(im, std::fabs(z.imag()));
+    }
+  };
+  auto diag = [&](int mm) -> int {
+    ev.assign(mm, cplx(0));
+    return qp::diagonalize_hessenberg(Hess.data(), ldh, mm, false, ev.data());
+  };
+  int m0 = m - 1;
+  QP_CHECK(qp_arnoldi(op, q, m0, state, 1.0, 0, norm_min, reinterpret_cast<qp_c128*>(Hess.data()), ldh, &m0));  // :182
+  if (diag(m0) != QP_OK) return qp::fail(QP_E_INTERNAL, "Hessenberg QR did not converge");
+  double lo0, hi0, im0;
+  stats3(lo0, hi0, im0);
+  if (m0 == m - 1) {
+    int ext = 0;
+    QP_CHECK(qp_arnoldi_extend(op, q, m, 1.0, norm_min, reinterpret_cast<qp_c128*>(Hess.data()), ldh, &ext));  // :190
+    if (diag(m) != QP_OK) return qp::fail(QP_E_INTERNAL, "Hessenberg QR did not converge");
+    double lo, hi, im;
+    stats3(lo, hi, im);
+    double er_lo = (lo0 != 0.0) ? std::fabs(1.0 - lo / lo0) : 0.0;
+    double er_hi = (hi0 != 0.0) ? std::fabs(1.0 - hi / hi0) : 0.0;
+    double ei = (im0 != 0.0) ? std::fabs(1.0 - im / im0) : 0.0;
+    while ((er_lo > prec) || (er_hi > prec) || ((im0 > 1e-14) && ei > prec)) {   // :198
+      lo0 = lo;
+      hi0 = hi;
+      im0 = im;
+      m = m + 1;
+      // quirk kept: the reference discards extend_arnoldi!'s return value, so Krylov
+      // exhaustion is never detected here (:204-205)
+      QP_CHECK(qp_arnoldi_extend(op, q, m, 1.0, norm_min, reinterpret_cast<qp_c128*>(Hess.data()), ldh, &ext));
+      if (diag(m) != QP_OK) return qp::fail(QP_E_INTERNAL, "Hessenberg QR did not converge");
+      stats3(lo, hi, im);
+      er_lo = std::fabs(1.0 - (lo / lo0));
+      er_hi = std::fabs(1.0 - (hi / hi0));
+      ei = std::fabs(1.0 - (im / im0));
+      if (m == m_max) break;                                                     // :213-216
+    }
+  }
+  *n_out = (int)ev.size();
+  for (size_t i = 0; i < ev.size(); ++i) out[i] = qp_c128{ev[i].real(), ev[i].imag()};
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_specrange_arnoldi(qp_operator* op, const qp_state* state, int m_min, int m_max, double prec, double norm_min,
+                         int enlarge, double* E_min, double* E_max) {
+  QP_TRY
+  if (!E_min || !E_max) return qp::fail(QP_E_BAD_ARG, "qp_specrange_arnoldi: NULL output");
+  m_min = std::max(5, std::min(m_min, m_max - 1));                              // src/specrad.jl:97
+  std::vector<qp_c128> R((size_t)std::max(m_max, 8));
+  int n = 0;
+  QP_CHECK(qp_ritzvals(op, state, m_min, m_max, prec, norm_min, R.data(), &n));
+  double lo = R[0].re, hi = R[n - 1].re;                                        // :103-104
+  if (enlarge && n > 1) {                                                        // :105-110
+    lo = 2 * lo - R[1].re;
+    hi = 2 * hi - R[n - 2].re;
+  }
+  *E_min = lo;
+  *E_max = hi;
+  return QP_OK;
+  QP_CATCH
+}
+
+}  // extern "C"

@@ -1,0 +1,351 @@
+// Host-side small dense numerics of the prop_step! path (m <= ~200): Bessel
+// coefficients, Hessenberg eigenvalues, Leja ordering, Newton divided differences,
+// and the bit-exact index work at the boundary (CSC -> CSR, row partition).
+// No HIP in this file: it is also linked into CPU-only test builds.
+#include "qprop_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <cstring>
+#include <vector>
+
+namespace qp {
+
+using cplx = std::complex<double>;
+
+// ---------------------------------------------------------------------------
+// Cheby coefficients -- src/cheby.jl:25-39.  SpecialFunctions.besselj(Int, Float64)
+// is openlibm's jn; glibc's jn is the same fdlibm lineage.
+// ---------------------------------------------------------------------------
+std::vector<double> cheby_coeffs(double Delta, double dt, double limit) {
+  double alpha = std::fabs(0.5 * Delta * dt);
+  std::vector<double> coeffs;
+  double a = ::jn(0, alpha);
+  coeffs.push_back(a);
+  double eps = std::fabs(a);
+  int i = 1;
+  while (eps > limit) {
+    a = 2.0 * ::jn(i, alpha);
+    coeffs.push_back(a);
+    eps = std::fabs(a);
+    ++i;
+    if (i > (1 << 24)) break;  // guard against limit <= 0
+  }
+  return coeffs;
+}
+
+// ---------------------------------------------------------------------------
+// Eigenvalues of a complex upper-Hessenberg matrix: shifted QR with Givens
+// rotations (Wilkinson shift, exceptional shifts at 10/20 iterations), eigenvalues
+// only, active-window updates.  Stands in for LAPACK `eigvals` at
+// src/arnoldi.jl:165; output sorted by (real, imag) like Julia's default sortby.
+// A is column-major n x n (lda = n) and is destroyed.
+// ---------------------------------------------------------------------------
+static inline double abs1(const cplx& z) { return std::fabs(z.real()) + std::fabs(z.imag()); }
+
+bool hessenberg_eigvals_inplace(int n, cplx* A, cplx* w) {
+  auto H = [&](int i, int j) -> cplx& { return A[(size_t)j * n + i]; };
+  const double eps = 2.220446049250313e-16;
+  std::vector<cplx> cs(n), sn(n);
+  int en = n - 1;
+  int its = 0;
+  const int max_its = 60;
+  double hnorm = 0.0;
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i <= std::min(j + 1, n - 1); ++i) hnorm += abs1(H(i, j));
+  if (hnorm == 0.0) hnorm = 1.0;
+  while (en >= 0) {
+    // find l: smallest index such that the block [l..en] is unreduced
+    int l = en;
+    for (; l > 0; --l) {
+      double s = abs1(H(l - 1, l - 1)) + abs1(H(l, l));
+      if (s == 0.0) s = hnorm;
+      if (abs1(H(l, l - 1)) <= eps * s) {
+        H(l, l - 1) = 0.0;
+        break;
+      }
+    }
+    if (l == en) {
+      w[en] = H(en, en);
+      --en;
+      its = 0;
+      continue;
+    }
+    if (its >= max_its) return false;
+    cplx mu;
+    if (its == 10 || its == 20) {
+      // exceptional shift
+      mu = H(en, en) + cplx(std::fabs(H(en, en - 1).real()) +
+                                (en >= 2 ? std::fabs(H(en - 1, en - 2).real()) : 0.0),
+                            0.0);
+    } else {
+      // Wilkinson shift: eigenvalue of trailing 2x2 closer to H(en,en)
+      cplx a = H(en - 1, en - 1), b = H(en - 1, en), c = H(en, en - 1), d = H(en, en);
+      cplx tr2 = 0.5 * (a - d);
+      cplx disc = std::sqrt(tr2 * tr2 + b * c);
+      cplx e1 = d + tr2 + disc, e2 = d + tr2 - disc;  // (a+d)/2 +- disc
+      mu = (std::abs(e1 - d) < std::abs(e2 - d)) ? e1 : e2;
+    }
+    ++its;
+    for (int i = l; i <= en; ++i) H(i, i) -= mu;
+    // QR factorisation of the active block by Givens rotations (from the left)
+    for (int k = l; k < en; ++k) {
+      cplx a = H(k, k), b = H(k + 1, k);
+      double r = std::sqrt(std::norm(a) + std::norm(b));
+      cplx c, s;
+      if (r == 0.0) {
+        c = 1.0;
+        s = 0.0;
+      } else {
+        c = a / r;
+        s = b / r;
+      }
+      cs[k] = c;
+      sn[k] = s;
+      // rows k, k+1, columns k..en:  [ conj(c) conj(s) ; -s c ]
+      for (int j = k; j <= en; ++j) {
+        cplx x = H(k, j), y = H(k + 1, j);
+        H(k, j) = std::conj(c) * x + std::conj(s) * y;
+        H(k + 1, j) = -s * x + c * y;
+      }
+      H(k + 1, k) = 0.0;
+    }
+    // multiply by the rotations from the right: columns k, k+1, rows l..min(k+1,en)
+    for (int k = l; k < en; ++k) {
+      cplx c = cs[k], s = sn[k];
+      int imax = std::min(k + 1, en);
+      for (int i = l; i <= imax; ++i) {
+        cplx x = H(i, k), y = H(i, k + 1);
+        H(i, k) = x * c + y * s;
+        H(i, k + 1) = -x * std::conj(s) + y * std::conj(c);
+      }
+    }
+    for (int i = l; i <= en; ++i) H(i, i) += mu;
+  }
+  std::sort(w, w + n, [](const cplx& x, const cplx& y) {
+    if (x.real() != y.real()) return x.real() < y.real();
+    return x.imag() < y.imag();
+  });
+  return true;
+}
+
+// diagonalize_hessenberg_matrix -- src/arnoldi.jl:143-170
+int diagonalize_hessenberg(const cplx* Hess, int ldh, int m, bool accumulate, cplx* out) {
+  int j_min = accumulate ? 1 : m;
+  int offset = 0;
+  std::vector<cplx> work;
+  for (int j = j_min; j <= m; ++j) {
+    auto Hm = [&](int r, int c) { return Hess[(size_t)c * ldh + r]; };
+    if (j == 1) {
+      out[0] = Hm(0, 0);
+    } else if (j == 2) {
+      cplx a = Hm(0, 0), c = Hm(1, 0), b = Hm(0, 1), d = Hm(1, 1);
+      cplx s = std::sqrt(a * a + 4.0 * b * c - 2.0 * a * d + d * d);
+      out[offset + 0] = 0.5 * (a + d - s);
+      out[offset + 1] = 0.5 * (a + d + s);
+    } else {
+      work.assign((size_t)j * j, cplx(0));
+      for (int c = 0; c < j; ++c)
+        for (int r = 0; r < j; ++r) work[(size_t)c * j + r] = Hm(r, c);
+      if (!hessenberg_eigvals_inplace(j, work.data(), out + offset)) return QP_E_INTERNAL;
+    }
+    offset += j;
+  }
+  return QP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// extend_leja! -- src/newton.jl:97-148 (zero-based; `leja` must hold n + n_use)
+// ---------------------------------------------------------------------------
+void extend_leja(cplx* leja, int n, cplx* newpoints, int n_new, int n_use) {
+  int u = n_new - 1;
+  int i_add_start = 0;
+  if (n == 0) {
+    cplx z_last = newpoints[u];
+    for (int i = 0; i < u; ++i) {
+      if (std::abs(newpoints[i]) > std::abs(z_last)) {
+        newpoints[u] = newpoints[i];
+        newpoints[i] = z_last;
+        z_last = newpoints[u];
+      }
+    }
+    leja[0] = newpoints[u];
+    i_add_start = 1;
+  }
+  double exponent = 1.0 / (double)(n + n_use);
+  for (int i_add = i_add_start; i_add < n_use; ++i_add) {
+    double p_max = 0.0;
+    int i_max = 0;
+    for (int i = 0; i <= u - i_add; ++i) {
+      double p = 1.0;
+      for (int j = 0; j < n + i_add; ++j) {
+        double d = std::abs(newpoints[i] - leja[j]);
+        p = p * std::pow(d, exponent);
+      }
+      if (p > p_max) {
+        p_max = p;
+        i_max = i;
+      }
+    }
+    leja[n + i_add] = newpoints[i_max];
+    newpoints[i_max] = newpoints[u - i_add];
+  }
+}
+
+cplx eval_func(int func_id, qp_func_cb cb, void* user, cplx z) {
+  switch (func_id) {
+    case QP_FUNC_EXPMI: return std::exp(cplx(0, -1) * z);
+    case QP_FUNC_EXP: return std::exp(z);
+    default: {
+      qp_c128 zi{z.real(), z.imag()}, zo{0, 0};
+      cb(&zi, &zo, user);
+      return cplx(zo.re, zo.im);
+    }
+  }
+}
+
+// extend_newton_coeffs! -- src/newton.jl:176-214 (zero-based; `a` must hold n_leja)
+int extend_newton_coeffs(cplx* a, int n_a, const cplx* leja, int func_id, qp_func_cb cb,
+                         void* user, int n_leja, double radius) {
+  int m = n_leja - n_a;
+  int n0 = n_a;
+  if (!(radius > 0)) return QP_E_BAD_ARG;
+  if (n_a == 0) {
+    a[0] = eval_func(func_id, cb, user, leja[0]);
+    n0 = 1;
+  }
+  for (int k = n0; k < n_a + m; ++k) {
+    cplx d = 1.0, pn = 0.0;
+    for (int n = 1; n <= k - 1; ++n) {
+      cplx zd = leja[k] - leja[n - 1];
+      d = d * zd / radius;
+      pn = pn + a[n] * d;
+    }
+    cplx zd = leja[k] - leja[k - 1];
+    d = d * zd / radius;
+    if (!(std::abs(d) > 1e-200)) return QP_E_DIVDIFF_UNDERFLOW;
+    a[k] = (eval_func(func_id, cb, user, leja[k]) - a[0] - pn) / d;
+  }
+  return QP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// CSC -> CSR (stable counting sort; columns end up ascending within each row because
+// CSC is traversed column by column)
+// ---------------------------------------------------------------------------
+int csc_to_csr(int64_t nrows, int64_t ncols, const int64_t* colptr, const int64_t* rowval,
+               const qp_c128* nzval, int base, int64_t* rowptr, int32_t* col, qp_c128* vals) {
+  int64_t nnz = colptr[ncols] - base;
+  std::fill(rowptr, rowptr + nrows + 1, (int64_t)0);
+  for (int64_t p = 0; p < nnz; ++p) {
+    int64_t r = rowval[p] - base;
+    if (r < 0 || r >= nrows) return QP_E_BAD_ARG;
+    rowptr[r + 1]++;
+  }
+  for (int64_t r = 0; r < nrows; ++r) rowptr[r + 1] += rowptr[r];
+  std::vector<int64_t> next(rowptr, rowptr + nrows);
+  for (int64_t c = 0; c < ncols; ++c) {
+    for (int64_t p = colptr[c] - base; p < colptr[c + 1] - base; ++p) {
+      int64_t r = rowval[p] - base;
+      int64_t dst = next[r]++;
+      col[dst] = (int32_t)c;
+      vals[dst] = nzval[p];
+    }
+  }
+  return QP_OK;
+}
+
+void partition_rows(const int64_t* rowptr, int64_t nrows, int nparts, int balance,
+                    int64_t* bounds) {
+  bounds[0] = 0;
+  if (balance == 0) {
+    int64_t base = nrows / nparts, rem = nrows % nparts;
+    for (int r = 0; r < nparts; ++r) bounds[r + 1] = bounds[r] + base + (r < rem ? 1 : 0);
+  } else {
+    int64_t nnz = rowptr[nrows];
+    for (int k = 1; k < nparts; ++k) {
+      int64_t target = (int64_t)(((__int128)k * nnz) / nparts);
+      bounds[k] = std::lower_bound(rowptr, rowptr + nrows + 1, target) - rowptr;
+    }
+    bounds[nparts] = nrows;
+  }
+}
+
+}  // namespace qp
+
+// ---------------------------------------------------------------------------
+// C ABI of the host-only entry points
+// ---------------------------------------------------------------------------
+using qp::cplx;
+
+extern "C" {
+
+int qp_cheby_coeffs(double Delta, double dt, double limit, double* out, int cap, int* n_out) {
+  QP_TRY
+  if (!n_out) return qp::fail(QP_E_BAD_ARG, "qp_cheby_coeffs: n_out is NULL");
+  auto c = qp::cheby_coeffs(Delta, dt, limit);
+  *n_out = (int)c.size();
+  if ((int)c.size() > cap || !out)
+    return qp::fail(QP_E_BAD_ARG, "qp_cheby_coeffs: need room for %d coefficients", (int)c.size());
+  std::memcpy(out, c.data(), c.size() * sizeof(double));
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_hessenberg_eigvals(const qp_c128* Hess, int ldh, int m, int accumulate, qp_c128* out) {
+  QP_TRY
+  if (!Hess || !out || m < 1 || ldh < m) return qp::fail(QP_E_BAD_ARG, "qp_hessenberg_eigvals: bad args");
+  int st = qp::diagonalize_hessenberg(reinterpret_cast<const cplx*>(Hess), ldh, m, accumulate != 0,
+                                      reinterpret_cast<cplx*>(out));
+  if (st != QP_OK) return qp::fail(st, "Hessenberg QR did not converge");
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_extend_leja(qp_c128* leja, int n, qp_c128* newpoints, int n_newpoints, int n_use) {
+  QP_TRY
+  if (!leja || !newpoints || n < 0 || n_use < 1 || n_newpoints < n_use)
+    return qp::fail(QP_E_BAD_ARG, "qp_extend_leja: bad args");
+  qp::extend_leja(reinterpret_cast<cplx*>(leja), n, reinterpret_cast<cplx*>(newpoints), n_newpoints,
+                  n_use);
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_extend_newton_coeffs(qp_c128* a, int n_a, const qp_c128* leja, int func_id, qp_func_cb cb,
+                            void* user, int n_leja, double radius) {
+  QP_TRY
+  if (!a || !leja || n_a < 0 || n_leja < n_a) return qp::fail(QP_E_BAD_ARG, "qp_extend_newton_coeffs: bad args");
+  if (func_id == QP_FUNC_CALLBACK && !cb) return qp::fail(QP_E_BAD_ARG, "callback func is NULL");
+  int st = qp::extend_newton_coeffs(reinterpret_cast<cplx*>(a), n_a, reinterpret_cast<const cplx*>(leja),
+                                    func_id, cb, user, n_leja, radius);
+  if (st == QP_E_DIVDIFF_UNDERFLOW) return qp::fail(st, "Divided differences too small");
+  if (st != QP_OK) return qp::fail(st, "qp_extend_newton_coeffs failed");
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_csc_to_csr_host(int64_t nrows, int64_t ncols, const int64_t* colptr, const int64_t* rowval,
+                       const qp_c128* nzval, int index_base, int64_t* rowptr_out, int32_t* col_out,
+                       qp_c128* vals_out) {
+  QP_TRY
+  if (!colptr || !rowval || !nzval || !rowptr_out || !col_out || !vals_out || nrows < 0 || ncols < 0 ||
+      ncols > INT32_MAX)
+    return qp::fail(QP_E_BAD_ARG, "qp_csc_to_csr_host: bad args");
+  int st = qp::csc_to_csr(nrows, ncols, colptr, rowval, nzval, index_base, rowptr_out, col_out, vals_out);
+  if (st != QP_OK) return qp::fail(st, "qp_csc_to_csr_host: row index out of range");
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_partition_rows_host(const int64_t* rowptr, int64_t nrows, int nparts, int balance,
+                           int64_t* bounds_out) {
+  QP_TRY
+  if (!rowptr || !bounds_out || nparts < 1 || nrows < 0) return qp::fail(QP_E_BAD_ARG, "qp_partition_rows_host: bad args");
+  qp::partition_rows(rowptr, nrows, nparts, balance, bounds_out);
+  return QP_OK;
+  QP_CATCH
+}
+
+}  // extern "C"

@@ -1,0 +1,494 @@
+// HIP kernels of the prop_step! hot path, written for CDNA4 / gfx950 (wave64).
+//
+//  K2/K3/K4  fused Chebyshev term  = SpMV + shift/scale + three-term recurrence + axpy
+//            (+ final phase)                    src/cheby.jl:171-211
+//  K7        plain SpMV   y = beta y + alpha H x       src/generators.jl:634-645
+//  K8/K9     fused "axpy -> dot" modified Gram-Schmidt pass, norm + scale
+//                                                       src/arnoldi.jl:82-96
+//  K11/K12   tall-skinny combine  out = s0 out + sum_i coef_i q_i (+ |out|^2)
+//                                                       src/newton.jl:346-367
+//  K6        operator value planes  vals = sum_l c_l plane_l   src/generators.jl:757-766
+//
+// All kernels are HBM-bandwidth bound (AI < 0.4 flop/B); the design rules are
+// 16-B-per-lane fully coalesced streams, no atomics (bitwise run-to-run determinism is
+// required by check_propagator's reinit test), reductions finished in the *next*
+// kernel's prologue instead of an extra launch or an in-launch fence.
+#include "device.h"
+
+namespace qp {
+
+// ---------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void cfma(double2& s, const double2 a, const double2 b) {
+  s.x = fma(a.x, b.x, s.x);
+  s.x = fma(-a.y, b.y, s.x);
+  s.y = fma(a.x, b.y, s.y);
+  s.y = fma(a.y, b.x, s.y);
+}
+__device__ __forceinline__ double2 cmul(const double2 a, const double2 b) {
+  return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ double2 cconj_mul(const double2 a, const double2 b) {  // conj(a)*b
+  return make_double2(a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// sum over the 256-thread workgroup, result broadcast to every thread; fixed order
+__device__ __forceinline__ double2 block_sum(double2 v, double2* lds4) {
+  v.x = wave_sum(v.x);
+  v.y = wave_sum(v.y);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  if (l == 0) lds4[w] = v;
+  __syncthreads();
+  double2 r = lds4[0];
+#pragma unroll
+  for (int i = 1; i < kThreads / 64; ++i) {
+    r.x += lds4[i].x;
+    r.y += lds4[i].y;
+  }
+  __syncthreads();
+  return r;
+}
+
+// XCD-aware workgroup remap: hardware deals workgroups round-robin over the 8 XCDs
+// (MI355X_MICROARCH "Workgroup dispatch"), so ids congruent mod 8 share an L2.  Give
+// each XCD one contiguous range of row blocks so the gather window of x stays in its
+// L2.  Bijective for any grid size; a different placement only changes speed.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
+  const unsigned q = nwg >> 3, r = nwg & 7u;
+  const unsigned xcd = bid & 7u, j = bid >> 3;
+  return xcd * q + (xcd < r ? xcd : r) + j;
+}
+
+// ---------------------------------------------------------------------------
+// epilogues
+// ---------------------------------------------------------------------------
+struct ChebyOp {
+  ChebyEpi e;
+  __device__ __forceinline__ void row(int64_t i, double2 s, double2& chk, double& nrm) const {
+    const double2 xi = e.xloc[i];
+    // t = c * (s - beta * x_i) [+ v0_i]        src/cheby.jl:178-179, :192-193, :202
+    double2 t = make_double2(fma(-e.beta, xi.x, s.x), fma(-e.beta, xi.y, s.y));
+    t = cmul(e.c, t);
+    if (e.check_partials) {  // src/cheby.jl:194-200: measured before "+ v0"
+      const double2 d = cconj_mul(xi, t);
+      chk.x += d.x;
+      chk.y += d.y;
+      nrm += xi.x * xi.x + xi.y * xi.y;
+    }
+    if (e.v0) {
+      const double2 v = e.v0[i];
+      t.x += v.x;
+      t.y += v.y;
+    }
+    if (e.vout) e.vout[i] = t;
+    double2 r;
+    if (e.acc_in) {
+      r = e.acc_in[i];
+    } else {
+      r = make_double2(e.a_prev * xi.x, e.a_prev * xi.y);  // lmul!(a[1], Psi)  :172
+    }
+    r.x = fma(e.a, t.x, r.x);  // axpy!(a[i], v, Psi)  :182, :205
+    r.y = fma(e.a, t.y, r.y);
+    if (e.apply_phase) r = cmul(e.phase, r);  // lmul!(exp(-i beta dt), Psi)  :211
+    e.acc_out[i] = r;
+  }
+};
+
+struct PlainOp {
+  PlainEpi e;
+  __device__ __forceinline__ void row(int64_t i, double2 s, double2&, double&) const {
+    double2 r = cmul(e.alpha, s);
+    if (!e.beta_zero) {
+      const double2 y = e.y[i];
+      const double2 by = cmul(e.beta, y);
+      r.x += by.x;
+      r.y += by.y;
+    }
+    e.y[i] = r;
+  }
+};
+
+template <class Op>
+__device__ __forceinline__ void finish_check(const Op&, double2, double, double2*) {}
+template <>
+__device__ __forceinline__ void finish_check<ChebyOp>(const ChebyOp& op, double2 chk, double nrm,
+                                                      double2* lds) {
+  if (op.e.check_partials) {
+    const double2 a = block_sum(chk, lds);
+    const double2 b = block_sum(make_double2(nrm, 0.0), lds);
+    if (threadIdx.x == 0) {
+      double* p = op.e.check_partials + 3 * (size_t)blockIdx.x;
+      p[0] = a.x;
+      p[1] = a.y;
+      p[2] = b.x;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// RBCSR SpMV: one wavefront streams one 64-row block, lane r owns row 64 b + r.
+// Per k: one 1-KiB coalesced load of 64 values, one 16-B gather of x per lane; column
+// indices arrive four k at a time in one 1-KiB load.  No cross-lane reduction, no LDS.
+// ---------------------------------------------------------------------------
+template <class Op>
+__global__ __launch_bounds__(kThreads) void rbcsr_spmv_kernel(const int64_t* __restrict__ bptr,
+                                                              const int4* __restrict__ cols4,
+                                                              const double2* __restrict__ vals,
+                                                              const double2* __restrict__ x,
+                                                              int64_t nblocks, int64_t nrows, Op op) {
+  __shared__ double2 lds[kThreads / 64];
+  const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int64_t b = (int64_t)wg * (kThreads / 64) + wave;
+  double2 chk = make_double2(0.0, 0.0);
+  double nrm = 0.0;
+  if (b < nblocks) {
+    const int64_t base = bptr[b];
+    const int nq = (int)((bptr[b + 1] - base) >> 8);  // width / 4
+    const double2* __restrict__ v = vals + base + lane;
+    const int4* __restrict__ c4 = cols4 + (base >> 2) + lane;
+    double2 s0 = make_double2(0.0, 0.0), s1 = make_double2(0.0, 0.0);
+#pragma unroll 2
+    for (int q = 0; q < nq; ++q) {
+      const int4 c = c4[(size_t)q * 64];
+      const double2 a0 = v[(size_t)(4 * q + 0) * 64];
+      const double2 a1 = v[(size_t)(4 * q + 1) * 64];
+      const double2 a2 = v[(size_t)(4 * q + 2) * 64];
+      const double2 a3 = v[(size_t)(4 * q + 3) * 64];
+      const double2 x0 = x[c.x];
+      const double2 x1 = x[c.y];
+      const double2 x2 = x[c.z];
+      const double2 x3 = x[c.w];
+      cfma(s0, a0, x0);
+      cfma(s1, a1, x1);
+      cfma(s0, a2, x2);
+      cfma(s1, a3, x3);
+    }
+    const int64_t row = b * kRB + lane;
+    if (row < nrows) op.row(row, make_double2(s0.x + s1.x, s0.y + s1.y), chk, nrm);
+  }
+  finish_check(op, chk, nrm, lds);
+}
+
+// ---------------------------------------------------------------------------
+// CSR SpMV, T lanes per row (sub-wave segmented reduction by shuffles).  General
+// fallback for matrices whose row lengths vary too much for RBCSR padding.
+// ---------------------------------------------------------------------------
+template <int T, class Op>
+__global__ __launch_bounds__(kThreads) void csr_spmv_kernel(const int64_t* __restrict__ rowptr,
+                                                            const int32_t* __restrict__ cols,
+                                                            const double2* __restrict__ vals,
+                                                            const double2* __restrict__ x, int64_t nrows,
+                                                            Op op) {
+  __shared__ double2 lds[kThreads / 64];
+  const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t row = ((int64_t)wg * kThreads + threadIdx.x) / T;
+  const int tl = threadIdx.x % T;
+  double2 s = make_double2(0.0, 0.0);
+  if (row < nrows) {
+    const int64_t p0 = rowptr[row], p1 = rowptr[row + 1];
+    for (int64_t p = p0 + tl; p < p1; p += T) cfma(s, vals[p], x[cols[p]]);
+  }
+#pragma unroll
+  for (int o = T / 2; o > 0; o >>= 1) {
+    s.x += __shfl_down(s.x, o, T);
+    s.y += __shfl_down(s.y, o, T);
+  }
+  double2 chk = make_double2(0.0, 0.0);
+  double nrm = 0.0;
+  if (row < nrows && tl == 0) op.row(row, s, chk, nrm);
+  finish_check(op, chk, nrm, lds);
+}
+
+int spmv_grid_size(const DevMatrix& A) {
+  if (A.format == QP_FMT_RBCSR) return (int)((A.nblocks + kThreads / 64 - 1) / (kThreads / 64));
+  const int64_t threads = A.nrows * A.lanes_per_row;
+  return (int)((threads + kThreads - 1) / kThreads);
+}
+
+template <class Op>
+static int launch_spmv(hipStream_t s, const DevMatrix& A, const double2* x, const Op& op, Stats* st) {
+  if (A.nrows == 0) return QP_OK;
+  const int grid = spmv_grid_size(A);
+  if (A.format == QP_FMT_RBCSR) {
+    hipLaunchKernelGGL(rbcsr_spmv_kernel<Op>, dim3(grid), dim3(kThreads), 0, s, A.bptr,
+                       reinterpret_cast<const int4*>(A.cols), A.vals, x, A.nblocks, A.nrows, op);
+  } else {
+#define QP_CSR_CASE(TT)                                                                                  \
+  case TT:                                                                                               \
+    hipLaunchKernelGGL((csr_spmv_kernel<TT, Op>), dim3(grid), dim3(kThreads), 0, s, A.rowptr, A.cols, A.vals, \
+                       x, A.nrows, op);                                                                  \
+    break;
+    switch (A.lanes_per_row) {
+      QP_CSR_CASE(2)
+      QP_CSR_CASE(4)
+      QP_CSR_CASE(8)
+      QP_CSR_CASE(16)
+      QP_CSR_CASE(32)
+      QP_CSR_CASE(64)
+      default:
+        return fail(QP_E_INTERNAL, "bad lanes_per_row %d", A.lanes_per_row);
+    }
+#undef QP_CSR_CASE
+  }
+  QP_HIP(hipGetLastError());
+  if (st) {
+    st->n_launch++;
+    st->n_matvec++;
+  }
+  return QP_OK;
+}
+
+int launch_spmv_cheby(hipStream_t s, const DevMatrix& A, const double2* x, const ChebyEpi& e, Stats* st) {
+  ChebyOp op{e};
+  int rc = launch_spmv(s, A, x, op, st);
+  // algorithmic bytes, SURVEY 8d: z (V + 4) N + 4 (N + 1) + 5 * 16 N
+  if (st && rc == QP_OK) st->spmv_bytes += 20.0 * (double)A.nnz + 4.0 * (double)(A.nrows + 1) + 80.0 * (double)A.nrows;
+  return rc;
+}
+
+int launch_spmv_plain(hipStream_t s, const DevMatrix& A, const double2* x, const PlainEpi& e, Stats* st) {
+  PlainOp op{e};
+  int rc = launch_spmv(s, A, x, op, st);
+  // plain SpMV: matrix + read x + write y  ((20 z + 36) N)
+  if (st && rc == QP_OK) st->spmv_bytes += 20.0 * (double)A.nnz + 4.0 * (double)(A.nrows + 1) + 32.0 * (double)A.nrows;
+  return rc;
+}
+
+// ---------------------------------------------------------------------------
+// elementwise / BLAS-1
+// ---------------------------------------------------------------------------
+static inline int ew_grid(int64_t n) {
+  int64_t g = (n + kThreads - 1) / kThreads;
+  if (g > 256 * 8) g = 256 * 8;  // 8 workgroups per CU, grid-stride the rest
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// coefficients travel as kernel arguments: no staging buffer that a later
+// set_coeffs() could overwrite while an earlier combine is still queued
+__global__ __launch_bounds__(kThreads) void combine_planes_kernel(double2* __restrict__ vals,
+                                                                  const double2* const* __restrict__ planes,
+                                                                  CoefBlock coefs, int first, int nplanes,
+                                                                  int accumulate, int64_t n) {
+  for (int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x; p < n; p += (int64_t)gridDim.x * kThreads) {
+    double2 acc = accumulate ? vals[p] : make_double2(0.0, 0.0);
+    for (int l = 0; l < nplanes; ++l) cfma(acc, coefs.c[l], planes[first + l][p]);
+    vals[p] = acc;
+  }
+}
+
+int launch_combine_planes(hipStream_t s, double2* vals, const double2* const* planes_dev, const double2* coefs,
+                          int nplanes, int64_t n, Stats* st) {
+  if (n == 0) return QP_OK;
+  for (int first = 0; first < nplanes; first += kCoefBlock) {
+    CoefBlock cb;
+    const int cnt = (nplanes - first < kCoefBlock) ? nplanes - first : kCoefBlock;
+    for (int l = 0; l < cnt; ++l) cb.c[l] = coefs[first + l];
+    hipLaunchKernelGGL(combine_planes_kernel, dim3(ew_grid(n)), dim3(kThreads), 0, s, vals, planes_dev, cb, first,
+                       cnt, first > 0 ? 1 : 0, n);
+    QP_HIP(hipGetLastError());
+    if (st) st->n_launch++;
+  }
+  return QP_OK;
+}
+
+__global__ __launch_bounds__(kThreads) void fill_kernel(double2* __restrict__ x, double2 a, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) x[i] = a;
+}
+__global__ __launch_bounds__(kThreads) void scal_kernel(double2* __restrict__ x, double2 a, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads)
+    x[i] = cmul(a, x[i]);
+}
+__global__ __launch_bounds__(kThreads) void axpy_kernel(double2 a, const double2* __restrict__ x,
+                                                        double2* __restrict__ y, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
+    double2 r = y[i];
+    cfma(r, a, x[i]);
+    y[i] = r;
+  }
+}
+
+int launch_fill(hipStream_t s, double2* x, double2 a, int64_t n, Stats* st) {
+  if (n == 0) return QP_OK;
+  hipLaunchKernelGGL(fill_kernel, dim3(ew_grid(n)), dim3(kThreads), 0, s, x, a, n);
+  QP_HIP(hipGetLastError());
+  if (st) st->n_launch++;
+  return QP_OK;
+}
+int launch_scal(hipStream_t s, double2* x, double2 a, int64_t n, Stats* st) {
+  if (n == 0) return QP_OK;
+  hipLaunchKernelGGL(scal_kernel, dim3(ew_grid(n)), dim3(kThreads), 0, s, x, a, n);
+  QP_HIP(hipGetLastError());
+  if (st) st->n_launch++;
+  return QP_OK;
+}
+int launch_axpy(hipStream_t s, double2 a, const double2* x, double2* y, int64_t n, Stats* st) {
+  if (n == 0) return QP_OK;
+  hipLaunchKernelGGL(axpy_kernel, dim3(ew_grid(n)), dim3(kThreads), 0, s, a, x, y, n);
+  QP_HIP(hipGetLastError());
+  if (st) st->n_launch++;
+  return QP_OK;
+}
+
+// reductions run on a fixed grid of kRedBlocks workgroups: partial b covers the
+// elements i with (i / kThreads) % kRedBlocks == b, summed in a fixed order
+__global__ __launch_bounds__(kThreads) void dot_partials_kernel(const double2* __restrict__ x,
+                                                                const double2* __restrict__ y,
+                                                                double2* __restrict__ partials, int64_t n) {
+  __shared__ double2 lds[kThreads / 64];
+  double2 acc = make_double2(0.0, 0.0);
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)kRedBlocks * kThreads) {
+    const double2 d = cconj_mul(x[i], y[i]);
+    acc.x += d.x;
+    acc.y += d.y;
+  }
+  acc = block_sum(acc, lds);
+  if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+
+int launch_dot_partials(hipStream_t s, const double2* x, const double2* y, double2* partials, int64_t n,
+                        Stats* st) {
+  hipLaunchKernelGGL(dot_partials_kernel, dim3(kRedBlocks), dim3(kThreads), 0, s, x, y, partials, n);
+  QP_HIP(hipGetLastError());
+  if (st) st->n_launch++;
+  return QP_OK;
+}
+
+// every workgroup re-reduces the previous kernel's kRedBlocks partials (one per
+// thread, kRedBlocks == kThreads) -- "combine in the next kernel's prologue"
+__device__ __forceinline__ double2 reduce_partials(const double2* __restrict__ part, double2* lds) {
+  static_assert(kRedBlocks == kThreads, "one partial per thread");
+  return block_sum(part[threadIdx.x], lds);
+}
+
+__global__ __launch_bounds__(kThreads) void mgs_pass_kernel(MgsArgs a) {
+  __shared__ double2 lds[kThreads / 64];
+  double2 coef = make_double2(0.0, 0.0);
+  if (a.q_prev) {
+    const double2 h = reduce_partials(a.part_in, lds);
+    // Hess[i,j] = dt <q_i|q_j+1>;  axpy!(-Hess[i,j]/dt, q_i, q_j+1)   src/arnoldi.jl:85-86
+    const double2 hd = make_double2(a.dt * h.x, a.dt * h.y);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.hess_prev) *a.hess_prev = hd;
+    coef = make_double2(-hd.x / a.dt, -hd.y / a.dt);
+  }
+  double2 acc = make_double2(0.0, 0.0);
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < a.n; i += (int64_t)kRedBlocks * kThreads) {
+    double2 w = a.w[i];
+    if (a.q_prev) {
+      cfma(w, coef, a.q_prev[i]);
+      a.w[i] = w;
+    }
+    if (a.q_cur) {
+      const double2 d = cconj_mul(a.q_cur[i], w);
+      acc.x += d.x;
+      acc.y += d.y;
+    } else {
+      acc.x += w.x * w.x + w.y * w.y;
+    }
+  }
+  acc = block_sum(acc, lds);
+  if (threadIdx.x == 0) a.part_out[blockIdx.x] = acc;
+}
+
+int launch_mgs_pass(hipStream_t s, const MgsArgs& a, Stats* st) {
+  hipLaunchKernelGGL(mgs_pass_kernel, dim3(kRedBlocks), dim3(kThreads), 0, s, a);
+  QP_HIP(hipGetLastError());
+  if (st) st->n_launch++;
+  return QP_OK;
+}
+
+__global__ __launch_bounds__(kThreads) void norm_scale_kernel(double2* __restrict__ w,
+                                                              const double2* __restrict__ part_in,
+                                                              double2* hess_slot, double dt, int64_t n) {
+  __shared__ double2 lds[kThreads / 64];
+  const double2 s2 = reduce_partials(part_in, lds);
+  const double h = sqrt(s2.x);  // h = norm(q[j+1])          src/arnoldi.jl:89
+  if (blockIdx.x == 0 && threadIdx.x == 0 && hess_slot) *hess_slot = make_double2(dt * h, 0.0);  // :90
+  const double inv = 1.0 / h;   // lmul!(1 / h, q[j+1])       :96
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
+    double2 v = w[i];
+    v.x *= inv;
+    v.y *= inv;
+    w[i] = v;
+  }
+}
+
+int launch_norm_scale(hipStream_t s, double2* w, const double2* part_in, double2* hess_slot, double dt,
+                      int64_t n, Stats* st) {
+  hipLaunchKernelGGL(norm_scale_kernel, dim3(ew_grid(n)), dim3(kThreads), 0, s, w, part_in, hess_slot, dt, n);
+  QP_HIP(hipGetLastError());
+  if (st) st->n_launch++;
+  return QP_OK;
+}
+
+__global__ __launch_bounds__(kThreads) void combine_vecs_kernel(double2* __restrict__ out, int use_out, double2 s0,
+                                                                const double2* __restrict__ Q, int64_t ldq, int m,
+                                                                CoefBlock coefs,
+                                                                double2* __restrict__ norm_partials, int64_t n) {
+  __shared__ double2 lds[kThreads / 64];
+  double nrm = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)kRedBlocks * kThreads) {
+    double2 r = make_double2(0.0, 0.0);
+    if (use_out) r = cmul(s0, out[i]);
+    for (int k = 0; k < m; ++k) cfma(r, coefs.c[k], Q[(size_t)k * ldq + i]);
+    out[i] = r;
+    nrm += r.x * r.x + r.y * r.y;
+  }
+  if (norm_partials) {
+    const double2 t = block_sum(make_double2(nrm, 0.0), lds);
+    if (threadIdx.x == 0) norm_partials[blockIdx.x] = t;
+  }
+}
+
+int launch_combine_vecs(hipStream_t s, double2* out, int use_out, double2 s0, const double2* Q, int64_t ldq,
+                        int m, const double2* coefs, double2* norm_partials, int64_t n, Stats* st) {
+  for (int first = 0; first < m || first == 0; first += kCoefBlock) {
+    CoefBlock cb;
+    const int cnt = (m - first < kCoefBlock) ? m - first : kCoefBlock;
+    for (int l = 0; l < cnt; ++l) cb.c[l] = coefs[first + l];
+    const bool lastc = (first + cnt >= m);
+    hipLaunchKernelGGL(combine_vecs_kernel, dim3(kRedBlocks), dim3(kThreads), 0, s, out, first > 0 ? 1 : use_out,
+                       first > 0 ? make_double2(1.0, 0.0) : s0, Q + (size_t)first * ldq, ldq, cnt, cb,
+                       lastc ? norm_partials : nullptr, n);
+    QP_HIP(hipGetLastError());
+    if (st) st->n_launch++;
+    if (lastc) break;
+  }
+  return QP_OK;
+}
+
+__global__ __launch_bounds__(kThreads) void reduce_triples_kernel(const double* __restrict__ partials, int nwg,
+                                                                  double* __restrict__ out3) {
+  __shared__ double2 lds[kThreads / 64];
+  double a = 0, b = 0, c = 0;
+  for (int i = threadIdx.x; i < nwg; i += kThreads) {
+    a += partials[3 * (size_t)i + 0];
+    b += partials[3 * (size_t)i + 1];
+    c += partials[3 * (size_t)i + 2];
+  }
+  const double2 ab = block_sum(make_double2(a, b), lds);
+  const double2 cc = block_sum(make_double2(c, 0.0), lds);
+  if (threadIdx.x == 0) {
+    out3[0] = ab.x;
+    out3[1] = ab.y;
+    out3[2] = cc.x;
+  }
+}
+
+int launch_reduce_triples(hipStream_t s, const double* partials, int nwg, double* out3, Stats* st) {
+  hipLaunchKernelGGL(reduce_triples_kernel, dim3(1), dim3(kThreads), 0, s, partials, nwg, out3);
+  QP_HIP(hipGetLastError());
+  if (st) st->n_launch++;
+  return QP_OK;
+}
+
+}  // namespace qp

@@ -1,0 +1,47 @@
+// Internal declarations shared by the translation units of libqprop_hip.so.
+#pragma once
+
+#include <complex>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <exception>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/qprop.h"
+
+namespace qp {
+
+int fail(int status, const char* fmt, ...);
+void set_error(const char* msg);
+
+using cplx = std::complex<double>;
+
+// host numerics (host_numerics.cpp)
+std::vector<double> cheby_coeffs(double Delta, double dt, double limit);
+bool hessenberg_eigvals_inplace(int n, cplx* A, cplx* w);
+int diagonalize_hessenberg(const cplx* Hess, int ldh, int m, bool accumulate, cplx* out);
+void extend_leja(cplx* leja, int n, cplx* newpoints, int n_new, int n_use);
+cplx eval_func(int func_id, qp_func_cb cb, void* user, cplx z);
+int extend_newton_coeffs(cplx* a, int n_a, const cplx* leja, int func_id, qp_func_cb cb, void* user,
+                         int n_leja, double radius);
+int csc_to_csr(int64_t nrows, int64_t ncols, const int64_t* colptr, const int64_t* rowval,
+               const qp_c128* nzval, int base, int64_t* rowptr, int32_t* col, qp_c128* vals);
+void partition_rows(const int64_t* rowptr, int64_t nrows, int nparts, int balance, int64_t* bounds);
+
+}  // namespace qp
+
+#define QP_TRY try {
+#define QP_CATCH                                                    \
+  }                                                                 \
+  catch (const std::bad_alloc&) {                                   \
+    return qp::fail(QP_E_ALLOC, "out of host memory");              \
+  }                                                                 \
+  catch (const std::exception& e) {                                 \
+    return qp::fail(QP_E_INTERNAL, "internal error: %s", e.what()); \
+  }                                                                 \
+  catch (...) {                                                     \
+    return qp::fail(QP_E_INTERNAL, "unknown internal error");       \
+  }

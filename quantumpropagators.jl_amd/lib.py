@@ -1,0 +1,646 @@
+"""ctypes binding of ``libqprop_hip.so`` (C ABI in ``include/qprop.h``).
+
+This is the only gateway from the Python host mirror to the engine.  There is no
+CPU fallback: if the shared library is missing, or no MI355X is visible when a context
+is created, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libqprop_hip.so")
+
+QP_OK = 0
+STATUS = {
+    0: "QP_OK", 1: "QP_E_BAD_ARG", 2: "QP_E_HIP", 3: "QP_E_DT_MISMATCH",
+    4: "QP_E_TOO_FEW_COEFFS", 5: "QP_E_NORMALIZATION", 6: "QP_E_MAX_RESTARTS",
+    7: "QP_E_DIVDIFF_UNDERFLOW", 8: "QP_E_NO_DEVICE", 9: "QP_E_ALLOC",
+    10: "QP_E_INTERNAL", 11: "QP_E_M_MAX",
+}
+LAYOUT_CSR, LAYOUT_CSC = 0, 1
+VAL_C128, VAL_F64 = 0, 1
+FMT_AUTO, FMT_CSR, FMT_RBCSR = 0, 1, 2
+FUNC_EXPMI, FUNC_EXP, FUNC_CALLBACK = 0, 1, 2
+
+
+class QPError(RuntimeError):
+    """A non-zero status from the C ABI.  ``status`` holds the code; subclasses mirror
+    the exception types the reference raises for the same condition."""
+
+    def __init__(self, status, message):
+        super().__init__(f"{STATUS.get(status, status)}: {message}")
+        self.status = status
+
+
+class QPAssertionError(QPError, AssertionError):
+    """Reference ``@assert`` failures (src/cheby.jl:157,165,196; src/newton.jl:209,375)."""
+
+
+class QPArgumentError(QPError, ValueError):
+    """Reference ``ArgumentError`` / ``error(...)`` on bad arguments."""
+
+
+class qp_c128(C.Structure):
+    _fields_ = [("re", C.c_double), ("im", C.c_double)]
+
+
+class qp_stats(C.Structure):
+    _fields_ = [("n_matvec", C.c_uint64), ("n_cheby_steps", C.c_uint64),
+                ("n_newton_steps", C.c_uint64), ("n_restarts", C.c_uint64),
+                ("n_kernel_launches", C.c_uint64), ("spmv_bytes", C.c_double)]
+
+
+class qp_newton_stats(C.Structure):
+    _fields_ = [("restarts", C.c_int), ("n_a", C.c_int), ("n_leja", C.c_int),
+                ("m_last", C.c_int), ("n_matvec", C.c_int), ("radius", C.c_double),
+                ("last_relerr", C.c_double), ("norm_psi", C.c_double)]
+
+
+FUNC_CB = C.CFUNCTYPE(None, C.POINTER(qp_c128), C.POINTER(qp_c128), C.c_void_p)
+
+_P = C.c_void_p
+_i64p = C.POINTER(C.c_int64)
+_i32p = C.POINTER(C.c_int32)
+_dp = C.POINTER(C.c_double)
+_cp = C.POINTER(qp_c128)
+
+# every symbol include/qprop.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "qp_last_error": (C.c_char_p, []),
+    "qp_status_name": (C.c_char_p, [C.c_int]),
+    "qp_version": (C.c_int, []),
+    "qp_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "qp_ctx_create": (C.c_int, [C.c_int, _P, C.POINTER(_P)]),
+    "qp_ctx_destroy": (C.c_int, [_P]),
+    "qp_sync": (C.c_int, [_P]),
+    "qp_stats_get": (C.c_int, [_P, C.POINTER(qp_stats)]),
+    "qp_stats_reset": (C.c_int, [_P]),
+    "qp_timer_begin": (C.c_int, [_P]),
+    "qp_timer_end": (C.c_int, [_P, _dp]),
+    "qp_csc_to_csr_host": (C.c_int, [C.c_int64, C.c_int64, _i64p, _i64p, _cp, C.c_int, _i64p, _i32p, _cp]),
+    "qp_partition_rows_host": (C.c_int, [_i64p, C.c_int64, C.c_int, C.c_int, _i64p]),
+    "qp_matrix_create": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, _i64p, _i64p, _P, C.c_int,
+                                   C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "qp_matrix_destroy": (C.c_int, [_P]),
+    "qp_matrix_info": (C.c_int, [_P, _i64p, _i64p, _i64p, C.POINTER(C.c_int), _i64p]),
+    "qp_matrix_get_csr": (C.c_int, [_P, _i64p, _i32p, _cp]),
+    "qp_operator_create": (C.c_int, [_P, C.POINTER(_P), C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "qp_operator_set_coeffs": (C.c_int, [_P, _cp, C.c_int]),
+    "qp_operator_set_scale": (C.c_int, [_P, qp_c128]),
+    "qp_operator_destroy": (C.c_int, [_P]),
+    "qp_operator_info": (C.c_int, [_P, _i64p, _i64p, _i64p, C.POINTER(C.c_int)]),
+    "qp_operator_get_csr": (C.c_int, [_P, _i64p, _i32p, _cp]),
+    "qp_state_create": (C.c_int, [_P, C.c_int64, C.POINTER(_P)]),
+    "qp_state_wrap": (C.c_int, [_P, _P, C.c_int64, C.POINTER(_P)]),
+    "qp_state_destroy": (C.c_int, [_P]),
+    "qp_state_upload": (C.c_int, [_P, _cp]),
+    "qp_state_download": (C.c_int, [_P, _cp]),
+    "qp_state_ptr": (_P, [_P]),
+    "qp_state_len": (C.c_int64, [_P]),
+    "qp_copy": (C.c_int, [_P, _P]),
+    "qp_scal": (C.c_int, [_P, qp_c128]),
+    "qp_axpy": (C.c_int, [qp_c128, _P, _P]),
+    "qp_fill": (C.c_int, [_P, qp_c128]),
+    "qp_dot": (C.c_int, [_P, _P, _cp]),
+    "qp_norm": (C.c_int, [_P, _dp]),
+    "qp_mul": (C.c_int, [_P, _P, _P, qp_c128, qp_c128]),
+    "qp_dot_op": (C.c_int, [_P, _P, _P, _P, _cp]),
+    "qp_cheby_coeffs": (C.c_int, [C.c_double, C.c_double, C.c_double, _dp, C.c_int, C.POINTER(C.c_int)]),
+    "qp_cheby_create": (C.c_int, [_P, C.c_int64, C.POINTER(_P)]),
+    "qp_cheby_destroy": (C.c_int, [_P]),
+    "qp_cheby_step": (C.c_int, [_P, _P, _P, _dp, C.c_int, C.c_double, C.c_double, C.c_double,
+                                C.c_double, C.c_double, C.c_int]),
+    "qp_cheby_term": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, _P, qp_c128, C.c_double, C.c_double,
+                                C.c_double, qp_c128]),
+    "qp_krylov_create": (C.c_int, [_P, C.c_int64, C.c_int, C.POINTER(_P)]),
+    "qp_krylov_destroy": (C.c_int, [_P]),
+    "qp_krylov_download": (C.c_int, [_P, C.c_int, _cp]),
+    "qp_arnoldi": (C.c_int, [_P, _P, C.c_int, _P, C.c_double, C.c_int, C.c_double, _cp, C.c_int,
+                             C.POINTER(C.c_int)]),
+    "qp_arnoldi_extend": (C.c_int, [_P, _P, C.c_int, C.c_double, C.c_double, _cp, C.c_int,
+                                    C.POINTER(C.c_int)]),
+    "qp_hessenberg_eigvals": (C.c_int, [_cp, C.c_int, C.c_int, C.c_int, _cp]),
+    "qp_extend_leja": (C.c_int, [_cp, C.c_int, _cp, C.c_int, C.c_int]),
+    "qp_extend_newton_coeffs": (C.c_int, [_cp, C.c_int, _cp, C.c_int, FUNC_CB, _P, C.c_int, C.c_double]),
+    "qp_newton_create": (C.c_int, [_P, C.c_int64, C.c_int, C.POINTER(_P)]),
+    "qp_newton_destroy": (C.c_int, [_P]),
+    "qp_newton_step": (C.c_int, [_P, _P, _P, C.c_double, C.c_int, FUNC_CB, _P, C.c_double, C.c_double,
+                                 C.c_int, C.POINTER(qp_newton_stats)]),
+    "qp_newton_get_coeffs": (C.c_int, [_P, _cp, _cp, C.c_int]),
+    "qp_ritzvals": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_double, C.c_double, _cp, C.POINTER(C.c_int)]),
+    "qp_specrange_arnoldi": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, _dp, _dp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library once.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C quantumpropagators.jl_amd/csrc`).  There is no CPU fallback.")
+    try:  # share torch's HIP runtime when torch is used in this process
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional for the library itself
+        pass
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status == QP_OK:
+        return
+    msg = load().qp_last_error().decode("utf-8", "replace")
+    if status in (3, 4, 5, 6, 7):
+        raise QPAssertionError(status, msg)
+    if status in (1, 11):
+        raise QPArgumentError(status, msg)
+    raise QPError(status, msg)
+
+
+def c128(z):
+    z = complex(z)
+    return qp_c128(z.real, z.imag)
+
+
+def _as_c128(a):
+    a = np.ascontiguousarray(a, dtype=np.complex128)
+    return a, a.ctypes.data_as(_cp)
+
+
+def _ptr(a, typ):
+    return a.ctypes.data_as(typ)
+
+
+def device_count():
+    n = C.c_int(0)
+    check(load().qp_device_count(C.byref(n)))
+    return n.value
+
+
+# ------------------------------------------------------------------------------
+# host-only helpers (run anywhere the library loads)
+# ------------------------------------------------------------------------------
+
+def cheby_coeffs(Delta, dt, limit=1e-12):
+    lib = load()
+    n = C.c_int(0)
+    cap = 64
+    while True:
+        out = np.empty(cap, dtype=np.float64)
+        st = lib.qp_cheby_coeffs(Delta, dt, limit, _ptr(out, _dp), cap, C.byref(n))
+        if st == QP_OK:
+            return out[: n.value].copy()
+        if n.value > cap:
+            cap = n.value
+            continue
+        check(st)
+
+
+def hessenberg_eigvals(Hess, m, accumulate=False):
+    Hess = np.asfortranarray(Hess, dtype=np.complex128)
+    ldh = Hess.shape[0]
+    n_out = m * (m + 1) // 2 if accumulate else m
+    out = np.empty(n_out, dtype=np.complex128)
+    check(load().qp_hessenberg_eigvals(_ptr(Hess, _cp), ldh, m, int(accumulate), _ptr(out, _cp)))
+    return out
+
+
+def extend_leja(leja, n, newpoints, n_use):
+    """Zero-based; returns (leja, n + n_use).  ``newpoints`` is clobbered."""
+    if len(leja) < n + n_use:
+        new = np.zeros(2 * (n + n_use), dtype=np.complex128)
+        new[:n] = leja[:n]
+        leja = new
+    assert leja.dtype == np.complex128 and newpoints.dtype == np.complex128
+    check(load().qp_extend_leja(_ptr(leja, _cp), n, _ptr(newpoints, _cp), len(newpoints), n_use))
+    return leja, n + n_use
+
+
+def _func_args(func):
+    """Map a Python callable / name to (func_id, callback, keepalive)."""
+    if func is None or func == "expmi":
+        return FUNC_EXPMI, FUNC_CB(0), None
+    if func == "exp":
+        return FUNC_EXP, FUNC_CB(0), None
+
+    def tramp(zp, outp, _user):
+        r = complex(func(complex(zp[0].re, zp[0].im)))
+        outp[0].re = r.real
+        outp[0].im = r.imag
+    cb = FUNC_CB(tramp)
+    return FUNC_CALLBACK, cb, cb
+
+
+def extend_newton_coeffs(a, n_a, leja, func, n_leja, radius):
+    if len(a) < n_leja:
+        new = np.zeros(2 * n_leja, dtype=np.complex128)
+        new[:n_a] = a[:n_a]
+        a = new
+    fid, cb, _keep = _func_args(func)
+    leja = np.ascontiguousarray(leja, dtype=np.complex128)
+    check(load().qp_extend_newton_coeffs(_ptr(a, _cp), n_a, _ptr(leja, _cp), fid, cb, None, n_leja, radius))
+    return a, n_leja
+
+
+def csc_to_csr(nrows, ncols, colptr, rowval, nzval, index_base=1):
+    colptr = np.ascontiguousarray(colptr, dtype=np.int64)
+    rowval = np.ascontiguousarray(rowval, dtype=np.int64)
+    nzval = np.ascontiguousarray(nzval, dtype=np.complex128)
+    nnz = int(colptr[-1]) - index_base
+    rowptr = np.empty(nrows + 1, dtype=np.int64)
+    col = np.empty(max(nnz, 1), dtype=np.int32)
+    vals = np.empty(max(nnz, 1), dtype=np.complex128)
+    check(load().qp_csc_to_csr_host(nrows, ncols, _ptr(colptr, _i64p), _ptr(rowval, _i64p), _ptr(nzval, _cp),
+                                    index_base, _ptr(rowptr, _i64p), _ptr(col, _i32p), _ptr(vals, _cp)))
+    return rowptr, col[:nnz], vals[:nnz]
+
+
+def partition_rows(rowptr, nparts, balance="rows"):
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+    out = np.empty(nparts + 1, dtype=np.int64)
+    check(load().qp_partition_rows_host(_ptr(rowptr, _i64p), len(rowptr) - 1, nparts,
+                                        0 if balance == "rows" else 1, _ptr(out, _i64p)))
+    return out
+
+
+# ------------------------------------------------------------------------------
+# handles
+# ------------------------------------------------------------------------------
+
+class Context:
+    """Device + HIP stream.  ``stream`` may be a raw hipStream_t (int), e.g.
+    ``torch.cuda.current_stream().cuda_stream``."""
+
+    def __init__(self, device=0, stream=None):
+        self._h = _P()
+        self.lib = load()
+        check(self.lib.qp_ctx_create(int(device), _P(stream) if stream else None, C.byref(self._h)))
+        self.device = int(device)
+
+    def sync(self):
+        check(self.lib.qp_sync(self._h))
+
+    def stats(self):
+        s = qp_stats()
+        check(self.lib.qp_stats_get(self._h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in qp_stats._fields_}
+
+    def reset_stats(self):
+        check(self.lib.qp_stats_reset(self._h))
+
+    def timer_begin(self):
+        check(self.lib.qp_timer_begin(self._h))
+
+    def timer_end(self):
+        ms = C.c_double(0)
+        check(self.lib.qp_timer_end(self._h, C.byref(ms)))
+        return ms.value
+
+    def close(self):
+        if self._h:
+            self.lib.qp_ctx_destroy(self._h)
+            self._h = _P()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Matrix:
+    """Canonical host CSR produced by the boundary's index work."""
+
+    def __init__(self, ctx, nrows, ncols, ptr, idx, vals, layout=LAYOUT_CSR, index_base=0):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        ptr = np.ascontiguousarray(ptr, dtype=np.int64)
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        vals = np.asarray(vals)
+        if np.iscomplexobj(vals):
+            vals = np.ascontiguousarray(vals, dtype=np.complex128)
+            dt = VAL_C128
+        else:
+            vals = np.ascontiguousarray(vals, dtype=np.float64)
+            dt = VAL_F64
+        nnz = int(ptr[-1]) - index_base
+        self._h = _P()
+        check(self.lib.qp_matrix_create(ctx._h, nrows, ncols, nnz, _ptr(ptr, _i64p), _ptr(idx, _i64p),
+                                        vals.ctypes.data_as(_P), dt, layout, index_base, FMT_AUTO,
+                                        C.byref(self._h)))
+        self.nrows, self.ncols, self.nnz = nrows, ncols, nnz
+
+    @classmethod
+    def from_scipy(cls, ctx, A):
+        import scipy.sparse as sp
+        if sp.isspmatrix_csc(A):
+            return cls(ctx, A.shape[0], A.shape[1], A.indptr, A.indices, A.data, layout=LAYOUT_CSC)
+        A = sp.csr_matrix(A)
+        return cls(ctx, A.shape[0], A.shape[1], A.indptr, A.indices, A.data, layout=LAYOUT_CSR)
+
+    @classmethod
+    def from_dense(cls, ctx, A):
+        import scipy.sparse as sp
+        return cls.from_scipy(ctx, sp.csr_matrix(np.asarray(A)))
+
+    def get_csr(self):
+        rowptr = np.empty(self.nrows + 1, dtype=np.int64)
+        col = np.empty(max(self.nnz, 1), dtype=np.int32)
+        vals = np.empty(max(self.nnz, 1), dtype=np.complex128)
+        check(self.lib.qp_matrix_get_csr(self._h, _ptr(rowptr, _i64p), _ptr(col, _i32p), _ptr(vals, _cp)))
+        return rowptr, col[: self.nnz], vals[: self.nnz]
+
+    def close(self):
+        if self._h:
+            self.lib.qp_matrix_destroy(self._h)
+            self._h = _P()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Operator:
+    """Device-resident lazy sum  sum_l c_l H_l  (Generators.Operator)."""
+
+    def __init__(self, ctx, ops, ncoeffs=0, fmt=FMT_AUTO):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        self.ops = list(ops)
+        arr = (_P * len(self.ops))(*[m._h for m in self.ops])
+        self._h = _P()
+        check(self.lib.qp_operator_create(ctx._h, arr, len(self.ops), int(ncoeffs), int(fmt), C.byref(self._h)))
+        self.ncoeffs = int(ncoeffs)
+        nr, nc, nnz, f = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int()
+        check(self.lib.qp_operator_info(self._h, C.byref(nr), C.byref(nc), C.byref(nnz), C.byref(f)))
+        self.nrows, self.ncols, self.nnz, self.format = nr.value, nc.value, nnz.value, f.value
+
+    @property
+    def shape(self):
+        return (self.nrows, self.ncols)
+
+    def set_coeffs(self, coeffs):
+        a, p = _as_c128(np.atleast_1d(coeffs))
+        check(self.lib.qp_operator_set_coeffs(self._h, p, len(a)))
+
+    def set_scale(self, s):
+        check(self.lib.qp_operator_set_scale(self._h, c128(s)))
+
+    def get_csr(self):
+        rowptr = np.empty(self.nrows + 1, dtype=np.int64)
+        col = np.empty(max(self.nnz, 1), dtype=np.int32)
+        vals = np.empty(max(self.nnz, 1), dtype=np.complex128)
+        check(self.lib.qp_operator_get_csr(self._h, _ptr(rowptr, _i64p), _ptr(col, _i32p), _ptr(vals, _cp)))
+        return rowptr, col[: self.nnz], vals[: self.nnz]
+
+    def mul(self, x, y, alpha=1.0, beta=0.0):
+        check(self.lib.qp_mul(self._h, x._h, y._h, c128(alpha), c128(beta)))
+        return y
+
+    def close(self):
+        if self._h:
+            self.lib.qp_operator_destroy(self._h)
+            self._h = _P()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class State:
+    """ComplexF64[n] in HBM."""
+
+    def __init__(self, ctx, n=None, data=None, device_ptr=None, keepalive=None):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        self._h = _P()
+        self._keep = keepalive
+        if device_ptr is not None:
+            check(self.lib.qp_state_wrap(ctx._h, _P(device_ptr), int(n), C.byref(self._h)))
+            self.n = int(n)
+        else:
+            if data is not None:
+                data = np.ascontiguousarray(data, dtype=np.complex128).reshape(-1)
+                n = len(data)
+            check(self.lib.qp_state_create(ctx._h, int(n), C.byref(self._h)))
+            self.n = int(n)
+            if data is not None:
+                self.upload(data)
+
+    @classmethod
+    def wrap_tensor(cls, ctx, t):
+        """View a contiguous complex128 torch tensor (on the ctx device) as a State."""
+        assert t.is_contiguous() and str(t.dtype) == "torch.complex128"
+        return cls(ctx, n=t.numel(), device_ptr=t.data_ptr(), keepalive=t)
+
+    def upload(self, data):
+        a, p = _as_c128(np.asarray(data).reshape(-1))
+        assert len(a) == self.n
+        check(self.lib.qp_state_upload(self._h, p))
+        return self
+
+    def numpy(self):
+        out = np.empty(self.n, dtype=np.complex128)
+        check(self.lib.qp_state_download(self._h, _ptr(out, _cp)))
+        return out
+
+    def copy_from(self, other):
+        check(self.lib.qp_copy(self._h, other._h))
+        return self
+
+    def scal(self, alpha):
+        check(self.lib.qp_scal(self._h, c128(alpha)))
+        return self
+
+    def axpy(self, alpha, x):
+        check(self.lib.qp_axpy(c128(alpha), x._h, self._h))
+        return self
+
+    def fill(self, alpha):
+        check(self.lib.qp_fill(self._h, c128(alpha)))
+        return self
+
+    def dot(self, y):
+        out = qp_c128()
+        check(self.lib.qp_dot(self._h, y._h, C.byref(out)))
+        return complex(out.re, out.im)
+
+    def norm(self):
+        out = C.c_double(0)
+        check(self.lib.qp_norm(self._h, C.byref(out)))
+        return out.value
+
+    @property
+    def ptr(self):
+        return self.lib.qp_state_ptr(self._h)
+
+    def __len__(self):
+        return self.n
+
+    def close(self):
+        if self._h:
+            self.lib.qp_state_destroy(self._h)
+            self._h = _P()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ChebyWrk:
+    """Cheby.ChebyWrk (src/cheby.jl:87-124) with its vectors in HBM."""
+
+    def __init__(self, ctx, n, Delta, E_min, dt, limit=1e-12):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        self.coeffs = cheby_coeffs(Delta, dt, limit)
+        self.n_coeffs = len(self.coeffs)
+        self.Delta, self.E_min, self.dt, self.limit = float(Delta), float(E_min), float(dt), float(limit)
+        self._h = _P()
+        check(self.lib.qp_cheby_create(ctx._h, int(n), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            self.lib.qp_cheby_destroy(self._h)
+            self._h = _P()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def cheby(psi, H, dt, wrk, E_min=None, check_normalization=False):
+    """``cheby!(psi, H, dt, wrk; E_min, check_normalization)`` on the device."""
+    E_min = wrk.E_min if E_min is None else E_min
+    check(wrk.lib.qp_cheby_step(wrk._h, H._h, psi._h, _ptr(wrk.coeffs, _dp), wrk.n_coeffs, wrk.Delta,
+                                float(E_min), float(dt), wrk.dt, wrk.limit, int(check_normalization)))
+    return psi
+
+
+def cheby_term(H, x, xoff, v0, vout, acc_in, acc_out, c, beta, a_prev, a, phase=1.0):
+    lib = H.lib
+    check(lib.qp_cheby_term(H._h, x._h, int(xoff), v0._h if v0 is not None else None,
+                            vout._h if vout is not None else None,
+                            acc_in._h if acc_in is not None else None, acc_out._h, c128(c), float(beta),
+                            float(a_prev), float(a), c128(phase)))
+
+
+class Krylov:
+    def __init__(self, ctx, n, nvec):
+        self.ctx, self.lib, self.n, self.nvec = ctx, ctx.lib, int(n), int(nvec)
+        self._h = _P()
+        check(self.lib.qp_krylov_create(ctx._h, self.n, self.nvec, C.byref(self._h)))
+
+    def vec(self, i):
+        out = np.empty(self.n, dtype=np.complex128)
+        check(self.lib.qp_krylov_download(self._h, int(i), _ptr(out, _cp)))
+        return out
+
+    def close(self):
+        if self._h:
+            self.lib.qp_krylov_destroy(self._h)
+            self._h = _P()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def arnoldi(Hess, q, m, psi, H, dt=1.0, extended=True, norm_min=1e-15):
+    """``arnoldi!``; ``Hess`` is a Fortran-ordered square complex128 array."""
+    assert Hess.flags.f_contiguous and Hess.dtype == np.complex128
+    m_out = C.c_int(0)
+    check(H.lib.qp_arnoldi(H._h, q._h, int(m), psi._h, float(dt), int(extended), float(norm_min),
+                           _ptr(Hess, _cp), Hess.shape[0], C.byref(m_out)))
+    return m_out.value
+
+
+def extend_arnoldi(Hess, q, m, H, dt=1.0, norm_min=1e-15):
+    assert Hess.flags.f_contiguous and Hess.dtype == np.complex128
+    ext = C.c_int(0)
+    check(H.lib.qp_arnoldi_extend(H._h, q._h, int(m), float(dt), float(norm_min), _ptr(Hess, _cp),
+                                  Hess.shape[0], C.byref(ext)))
+    return bool(ext.value)
+
+
+class NewtonWrk:
+    """Newton.NewtonWrk (src/newton.jl:23-60)."""
+
+    def __init__(self, ctx, n, m_max=10):
+        self.ctx, self.lib = ctx, ctx.lib
+        self._h = _P()
+        check(self.lib.qp_newton_create(ctx._h, int(n), int(m_max), C.byref(self._h)))
+        self.m_max = min(int(m_max), int(n) - 1)
+        self.restarts = 0
+        self.n_a = 0
+        self.n_leja = 0
+        self.radius = 0.0
+        self.stats = None
+
+    def coeffs(self):
+        a = np.empty(max(self.n_a, 1), dtype=np.complex128)
+        leja = np.empty(max(self.n_a, 1), dtype=np.complex128)
+        check(self.lib.qp_newton_get_coeffs(self._h, _ptr(a, _cp), _ptr(leja, _cp), len(a)))
+        return a[: self.n_a], leja[: self.n_a]
+
+    def close(self):
+        if self._h:
+            self.lib.qp_newton_destroy(self._h)
+            self._h = _P()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def newton(psi, H, dt, wrk, func=None, norm_min=1e-14, relerr=1e-12, max_restarts=50):
+    """``newton!(psi, H, dt, wrk; func, norm_min, relerr, max_restarts)`` on the device."""
+    fid, cb, _keep = _func_args(func)
+    st = qp_newton_stats()
+    check(wrk.lib.qp_newton_step(wrk._h, H._h, psi._h, float(dt), fid, cb, None, float(norm_min),
+                                 float(relerr), int(max_restarts), C.byref(st)))
+    wrk.restarts, wrk.n_a, wrk.n_leja, wrk.radius = st.restarts, st.n_a, st.n_leja, st.radius
+    wrk.stats = {k: getattr(st, k) for k, _ in qp_newton_stats._fields_}
+    return psi
+
+
+def ritzvals(G, state, m_min, m_max=None, prec=1e-5, norm_min=1e-15):
+    m_max = 2 * m_min if m_max is None else m_max
+    out = np.empty(max(m_max, 8), dtype=np.complex128)
+    n = C.c_int(0)
+    check(G.lib.qp_ritzvals(G._h, state._h, int(m_min), int(m_max), float(prec), float(norm_min),
+                            _ptr(out, _cp), C.byref(n)))
+    return out[: n.value].copy()
+
+
+def specrange_arnoldi(H, state, m_min=25, m_max=60, prec=1e-3, norm_min=1e-15, enlarge=True):
+    lo, hi = C.c_double(0), C.c_double(0)
+    check(H.lib.qp_specrange_arnoldi(H._h, state._h, int(m_min), int(m_max), float(prec), float(norm_min),
+                                     int(enlarge), C.byref(lo), C.byref(hi)))
+    return lo.value, hi.value

@@ -1,0 +1,422 @@
+"""Host-side mirror of the reference's propagator interface for the two hot-path methods.
+
+    init_prop(state, generator, tlist; method=Cheby|Newton, ...)   src/propagator.jl:208-264,
+                                       src/cheby_propagator.jl:87-175, src/newton_propagator.jl:62-113
+    prop_step!(propagator)             src/cheby_propagator.jl:348-386, src/newton_propagator.jl:120-153
+    reinit_prop!(propagator, state)    src/cheby_propagator.jl:243-299, src/propagator.jl:298-312
+    set_state!(propagator, state)      src/propagator.jl:367-377
+    set_t!(propagator, t)              src/pwc_utils.jl:48-71
+    propagate(state, generator, tlist) src/propagate.jl:167-344
+
+Julia's ``!`` cannot appear in Python identifiers: ``prop_step!`` is ``prop_step`` etc.
+Same argument names, meaning and error behaviour; the numerical work is done by
+``libqprop_hip.so`` on the GPU (no CPU fallback).  ``propagator.n`` keeps Julia's 1-based
+interval index so that the bookkeeping of src/pwc_utils.jl is restated verbatim.
+"""
+from __future__ import annotations
+
+import bisect
+import math
+import warnings
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import lib as L
+
+__all__ = ["Generator", "hamiltonian", "init_prop", "prop_step", "reinit_prop", "set_state", "set_t",
+           "propagate", "ChebyPropagator", "NewtonPropagator", "discretize", "discretize_on_midpoints"]
+
+
+# ----------------------------------------------------------------------------------------
+# controls (src/controls.jl) -- scalar host logic, O(#steps)
+# ----------------------------------------------------------------------------------------
+
+def get_tlist_midpoints(tlist):
+    """src/controls.jl:92-124 (first / last point preserved)."""
+    tlist = np.asarray(tlist, dtype=np.float64)
+    N = len(tlist)
+    if N < 3:
+        raise ValueError("In `get_tlist_midpoints`, argument `tlist` must have a length of at least 3")
+    mid = np.zeros(N - 1)
+    mid[0], mid[-1] = tlist[0], tlist[-1]
+    for i in range(1, N - 2):
+        mid[i] = tlist[i] + 0.5 * (tlist[i + 1] - tlist[i])
+    return mid
+
+
+def discretize_on_midpoints(control, tlist):
+    """src/controls.jl:189-208."""
+    if callable(control):
+        return np.array([float(control(t)) for t in get_tlist_midpoints(tlist)])
+    control = np.asarray(control, dtype=np.float64)
+    if len(control) == len(tlist) - 1:
+        return control.copy()
+    if len(control) == len(tlist):
+        vals = np.empty(len(tlist) - 1)
+        vals[0], vals[-1] = control[0], control[-1]
+        for i in range(1, len(vals) - 1):
+            vals[i] = 2 * control[i] - vals[i - 1]
+        return vals
+    raise ValueError("control array must be defined on the points of tlist")
+
+
+def discretize(control, tlist):
+    """src/controls.jl:43-68."""
+    if callable(control):
+        return discretize(discretize_on_midpoints(control, tlist), tlist)
+    control = np.asarray(control, dtype=np.float64)
+    if len(control) == len(tlist):
+        return control.copy()
+    if len(control) == len(tlist) - 1:
+        vals = np.zeros(len(control) + 1)
+        vals[0], vals[-1] = control[0], control[-1]
+        for i in range(1, len(vals) - 1):
+            vals[i] = 0.5 * (control[i - 1] + control[i])
+        return vals
+    raise ValueError("control array must be defined on intervals of tlist")
+
+
+def _get_uniform_dt(tlist, tol=1e-12, warn=False):
+    """src/propagator.jl:267-280."""
+    dt = float(tlist[1] - tlist[0])
+    for i in range(1, len(tlist) - 1):
+        dt_i = tlist[i + 1] - tlist[i]
+        if abs(dt_i - dt) > tol:
+            if warn:
+                warnings.warn(f"Non-uniform time grid: dt = {dt_i:.2e} in interval {i + 1} differs from the "
+                              f"first dt={dt:.2e} by {abs(dt_i - dt):.2e} > tol = {tol:.2e}")
+            return None
+    return dt
+
+
+# ----------------------------------------------------------------------------------------
+# generators (src/generators.jl:44-61, :388-469)
+# ----------------------------------------------------------------------------------------
+
+class Generator:
+    """sum_l a_l(t) H_l: ``ops`` (matrices), ``amplitudes`` for the last len(amplitudes)
+    ops (drift terms first, src/generators.jl:44-61).  Amplitudes here are the controls
+    themselves: callables of t, or arrays on tlist / on the intervals."""
+
+    def __init__(self, ops, amplitudes):
+        self.ops = list(ops)
+        self.amplitudes = list(amplitudes)
+        if len(self.amplitudes) > len(self.ops):
+            raise ValueError("more amplitudes than operators")
+
+
+def hamiltonian(*terms):
+    """``hamiltonian(H0, (H1, eps1), ...)`` -- src/generators.jl:388-469: drift terms are
+    summed into one operator and listed first."""
+    drift = None
+    ops, ampl = [], []
+    for t in terms:
+        if isinstance(t, tuple):
+            ops.append(t[0])
+            ampl.append(t[1])
+        else:
+            drift = t if drift is None else drift + t
+    if drift is not None:
+        ops.insert(0, drift)
+    if not ampl:
+        return ops[0]
+    return Generator(ops, ampl)
+
+
+def _to_matrix(ctx, A):
+    if isinstance(A, L.Matrix):
+        return A
+    if sp.issparse(A):
+        return L.Matrix.from_scipy(ctx, A)
+    return L.Matrix.from_dense(ctx, np.asarray(A))
+
+
+class _DeviceGenerator:
+    """The generator's matrices uploaded once; `evaluate!` only rewrites coefficients
+    (src/generators.jl:757-766) -- the only per-step host->device payload."""
+
+    def __init__(self, ctx, generator, fmt=L.FMT_AUTO):
+        if isinstance(generator, tuple) and len(generator) == 1:
+            generator = generator[0]          # `(H,)` in test/test_propagate.jl:157
+        if isinstance(generator, (tuple, list)):
+            generator = hamiltonian(*generator)
+        if isinstance(generator, Generator):
+            self.controls = list(generator.amplitudes)
+            mats = [_to_matrix(ctx, A) for A in generator.ops]
+        elif isinstance(generator, L.Operator):
+            self.controls = []
+            self.op = generator
+            return
+        else:
+            self.controls = []
+            mats = [_to_matrix(ctx, generator)]
+        self.op = L.Operator(ctx, mats, len(self.controls), fmt)
+
+    def set_vals(self, vals):
+        if self.controls:
+            self.op.set_coeffs(np.asarray(vals, dtype=np.complex128))
+        return self.op
+
+
+# ----------------------------------------------------------------------------------------
+# propagators
+# ----------------------------------------------------------------------------------------
+
+class PWCPropagator:
+    """Common fields: state, tlist, t, n, parameters, backward, inplace
+    (src/propagator.jl:119-126, src/pwc_utils.jl:5-24)."""
+
+    @property
+    def generator(self):  # hidden, src/propagator.jl:77-86
+        raise AttributeError("type PWCPropagator has no property generator")
+
+
+class ChebyPropagator(PWCPropagator):
+    pass
+
+
+class NewtonPropagator(PWCPropagator):
+    pass
+
+
+def _as_state(ctx, state, copy):
+    if isinstance(state, L.State):
+        if not copy:
+            return state
+        s = L.State(ctx, n=state.n)
+        s.copy_from(state)
+        return s
+    return L.State(ctx, data=np.asarray(state, dtype=np.complex128))
+
+
+def _specrange(op, method, ctx, n, rng=None, state=None, **kw):
+    """``specrange(H, method; kw...)`` -- src/specrad.jl:36-140."""
+    method = str(method).lower()
+    if method == "auto":                                           # :45-61
+        if "E_min" in kw and "E_max" in kw:
+            method = "manual"
+        elif n <= 32:
+            method = "diag"
+        else:
+            method = "arnoldi"
+    if method == "manual":                                         # :138-140
+        if "E_min" not in kw or "E_max" not in kw:
+            raise TypeError("UndefKeywordError: keyword argument E_min/E_max not assigned")
+        return float(kw["E_min"]), float(kw["E_max"])
+    if method == "diag":                                           # :124-128 (tiny: host eigvals of Array(H))
+        rp, col, vals = op.get_csr()
+        A = sp.csr_matrix((vals, col, rp), shape=op.shape).toarray()
+        ev = np.linalg.eigvals(A)
+        ev = ev[np.lexsort((ev.imag, ev.real))].real
+        return float(ev[0]), float(ev[-1])
+    if method == "arnoldi":                                        # :88-112
+        if state is None:                                          # random_state, :153-158
+            rng = np.random.default_rng() if rng is None else rng
+            psi = rng.random(n) * np.exp(2j * np.pi * rng.random(n))
+            psi /= np.linalg.norm(psi)
+            state = L.State(ctx, data=psi)
+        elif not isinstance(state, L.State):
+            state = L.State(ctx, data=state)
+        return L.specrange_arnoldi(op, state, m_min=kw.get("m_min", 25), m_max=kw.get("m_max", 60),
+                                   prec=kw.get("prec", 1e-3), norm_min=kw.get("norm_min", 1e-15),
+                                   enlarge=kw.get("enlarge", True))
+    raise ValueError(f"unknown specrange method {method!r}")
+
+
+def _cheby_get_spectral_envelope(p, control_ranges, method, **kw):
+    """src/cheby_propagator.jl:331-345."""
+    n = p.state.n
+    G_max = p._dgen.set_vals([r[1] for r in control_ranges])
+    E_min, E_max = _specrange(G_max, method, p.ctx, n, **kw)
+    G_min = p._dgen.set_vals([r[0] for r in control_ranges])
+    _E_min, _E_max = _specrange(G_min, method, p.ctx, n, **kw)
+    return min(_E_min, E_min), max(_E_max, E_max)
+
+
+def _method_name(method):
+    name = getattr(method, "__name__", method)
+    name = str(name).split(".")[-1].lower()
+    if name not in ("cheby", "newton"):
+        raise ValueError(f"Unknown propagation `method`: {method}")      # src/propagator.jl:262-264
+    return name
+
+
+def init_prop(state, generator, tlist, method, *, inplace=True, backward=False, verbose=False,
+              parameters=None, piecewise=None, pwc=None, ctx=None, device=0, device_format=L.FMT_AUTO,
+              # Cheby
+              control_ranges=None, specrange_method="auto", specrange_buffer=0.01,
+              cheby_coeffs_limit=1e-12, check_normalization=False, uniform_dt_tolerance=1e-12,
+              # Newton
+              m_max=10, func=None, norm_min=1e-14, relerr=1e-12, max_restarts=50,
+              **specrange_kwargs):
+    name = _method_name(method)
+    ctx = ctx if ctx is not None else (state.ctx if isinstance(state, L.State) else L.Context(device))
+    tlist = np.asarray(tlist, dtype=np.float64)
+    p = ChebyPropagator() if name == "cheby" else NewtonPropagator()
+    p.ctx = ctx
+    p.method = name
+    p.tlist = tlist
+    p.backward = bool(backward)
+    p.inplace = bool(inplace)
+    p._dgen = _DeviceGenerator(ctx, generator, device_format)
+    p.controls = p._dgen.controls
+    if name == "newton" and not inplace:
+        raise RuntimeError("The Newton propagator is only implemented in-place")   # newton_propagator.jl:94
+    if parameters is None:                                              # pwc_utils.jl:29-45
+        parameters = [discretize_on_midpoints(c, tlist) for c in p.controls]
+    else:
+        parameters = list(parameters)
+        for amp in parameters:
+            assert len(amp) == len(tlist) - 1
+    p.parameters = parameters
+    p.state = _as_state(ctx, state, copy=inplace)                       # copy when in-place (:158)
+    p.n = 1
+    p.t = float(tlist[0])
+    if backward:
+        p.n = len(tlist) - 1
+        p.t = float(tlist[p.n])
+    if name == "cheby":
+        controlvals = [discretize(c, tlist) for c in p.controls]
+        if control_ranges is None:
+            control_ranges = [(float(np.min(v)), float(np.max(v))) for v in controlvals]
+        else:
+            control_ranges = [tuple(r) for r in control_ranges]
+            for r in control_ranges:
+                assert r[0] <= r[1]
+        p.control_ranges = control_ranges
+        p.specrange_method = specrange_method
+        p.specrange_buffer = float(specrange_buffer)
+        p.specrange_options = dict(specrange_kwargs)
+        p.check_normalization = bool(check_normalization)
+        E_min, E_max = _cheby_get_spectral_envelope(p, control_ranges, specrange_method, **specrange_kwargs)
+        Delta = E_max - E_min
+        assert Delta > 0.0
+        delta = specrange_buffer * Delta                                # :131-133
+        E_min = E_min - delta / 2
+        Delta = Delta + delta
+        dt = _get_uniform_dt(tlist, tol=uniform_dt_tolerance, warn=True)
+        if dt is None:
+            raise RuntimeError("Chebychev propagation only works on a uniform time grid")
+        p.wrk = L.ChebyWrk(ctx, p.state.n, Delta, E_min, dt, limit=cheby_coeffs_limit)
+    else:
+        p.wrk = L.NewtonWrk(ctx, p.state.n, m_max=m_max)
+        p.func, p.norm_min, p.relerr, p.max_restarts = func, norm_min, relerr, max_restarts
+    if piecewise is True or pwc is True:
+        pass  # both propagators are piecewise-constant (src/propagator.jl:232-245)
+    return p
+
+
+def prop_step(p):
+    """``prop_step!(propagator)``: returns ``propagator.state`` (the same object when
+    in-place) or ``None`` past the end of the grid."""
+    n = p.n
+    tlist = p.tlist
+    if not (0 < n < len(tlist)):
+        return None
+    H = p._dgen.set_vals([par[n - 1] for par in p.parameters])          # _pwc_set_genop!  pwc_utils.jl:86-92
+    if not p.inplace:
+        new = L.State(p.ctx, n=p.state.n)
+        new.copy_from(p.state)
+        p.state = new
+    if p.method == "cheby":
+        dt = -p.wrk.dt if p.backward else p.wrk.dt
+        L.cheby(p.state, H, dt, p.wrk, check_normalization=p.check_normalization)
+    else:
+        dt = tlist[n] - tlist[n - 1]                                    # newton_propagator.jl:127-130
+        if p.backward:
+            dt = -dt
+        L.newton(p.state, H, dt, p.wrk, func=p.func, norm_min=p.norm_min, relerr=p.relerr,
+                 max_restarts=p.max_restarts)
+    if p.backward:                                                      # _pwc_advance_time!  pwc_utils.jl:102-112
+        p.t = float(tlist[n - 1])
+        p.n = n - 1
+    else:
+        p.t = float(tlist[n])
+        p.n = n + 1
+    return p.state
+
+
+def set_state(p, state):
+    """src/propagator.jl:367-377."""
+    if state is not p.state:
+        if p.inplace:
+            if isinstance(state, L.State):
+                p.state.copy_from(state)
+            else:
+                p.state.upload(np.asarray(state, dtype=np.complex128))
+        else:
+            p.state = _as_state(p.ctx, state, copy=False)
+    return p.state
+
+
+def set_t(p, t):
+    """``set_t!`` = ``_pwc_set_t!`` -- src/pwc_utils.jl:48-71 (snaps with a warning)."""
+    tlist = p.tlist
+    if t <= tlist[0]:
+        n = 1
+    else:
+        N = len(tlist)
+        if t >= tlist[-1]:
+            n = N
+        else:
+            n = min(bisect.bisect_left(tlist.tolist(), t) + 1, N)
+    if not math.isclose(t, tlist[n - 1], rel_tol=math.sqrt(np.finfo(float).eps)):
+        warnings.warn(f"Snapping t={t} to time grid value {tlist[n - 1]}")
+    p.n = n - 1 if p.backward else n
+    p.t = float(tlist[n - 1])
+
+
+def reinit_prop(p, state, transform_control_ranges=None, **_):
+    """src/cheby_propagator.jl:243-299 (Cheby: coefficients are recalculated when the
+    current ``parameters`` exceed the stored control ranges) / src/propagator.jl:298-312."""
+    state = set_state(p, state)
+    if p.method == "cheby":
+        tcr = transform_control_ranges or (lambda c, lo, hi, check: (lo, hi))
+        ranges = [(float(np.min(par)), float(np.max(par))) for par in p.parameters]
+        need = False
+        for c, (lo, hi), (slo, shi) in zip(p.controls, ranges, p.control_ranges):
+            lo_c, hi_c = tcr(c, lo, hi, True)
+            if lo_c < slo or hi_c > shi:
+                need = True
+                break
+        if need:
+            ranges = [tuple(tcr(c, lo, hi, False)) for c, (lo, hi) in zip(p.controls, ranges)]
+            E_min, E_max = _cheby_get_spectral_envelope(p, ranges, p.specrange_method, **p.specrange_options)
+            Delta = E_max - E_min
+            assert Delta > 0.0
+            delta = p.specrange_buffer * Delta
+            E_min = E_min - delta / 2
+            Delta = Delta + delta
+            dt = float(p.tlist[1] - p.tlist[0])
+            p.control_ranges = ranges
+            p.wrk = L.ChebyWrk(p.ctx, state.n, Delta, E_min, dt, limit=p.wrk.limit)
+    set_t(p, float(p.tlist[-1] if p.backward else p.tlist[0]))
+
+
+def propagate(state, generator, tlist, *, method, backward=False, inplace=True, storage=None,
+              observables=None, callback=None, **kwargs):
+    """``propagate(state, generator, tlist; method, ...)`` -- src/propagate.jl:167-344.
+    ``storage=True`` returns (final_state, array) with column i = state at tlist[i]
+    (or the observables' values).  States come back as NumPy arrays."""
+    p = init_prop(state, generator, tlist, method, backward=backward, inplace=inplace, **kwargs)
+    nt = len(p.tlist)
+
+    def obs(s):
+        psi = s.numpy()
+        if observables is None:
+            return psi
+        return np.array([o(psi) for o in observables])
+    store = None
+    if storage:
+        first = obs(p.state)
+        store = np.zeros((len(first), nt), dtype=first.dtype)
+        store[:, (nt - 1) if backward else 0] = first
+    for i in range(nt - 1):
+        prop_step(p)
+        if callback is not None:
+            callback(p, observables)
+        if storage:
+            store[:, (nt - 2 - i) if backward else (i + 1)] = obs(p.state)
+    out = p.state.numpy()
+    return (out, store) if storage else out

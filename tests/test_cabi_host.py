@@ -1,0 +1,173 @@
+"""CPU-side checks of the C ABI: the library loads, exports every symbol that
+include/qprop.h declares, its host-only numerics (Bessel coefficients, Hessenberg
+eigenvalues, Leja ordering, Newton divided differences) agree with the oracle, its
+index work is bit-exact, and the product path fails loudly without a GPU.
+No device compute happens here."""
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import qp_oracle as qo  # noqa: E402
+import qprop_amd.lib as L  # noqa: E402
+import qprop_amd.synth as synth  # noqa: E402
+
+
+def test_header_symbols_exported():
+    hdr = open(os.path.join(ROOT, "include", "qprop.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(qp_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"qp_func_cb"}
+    assert len(declared) > 50
+    lib = L.load()
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, f"symbols declared in qprop.h but not exported: {missing}"
+    unbound = sorted(declared - set(L.SIGNATURES))
+    assert not unbound, f"symbols without a ctypes signature: {unbound}"
+    assert lib.qp_version() >= 100
+
+
+def test_no_gpu_fails_loudly():
+    """The product path has no CPU fallback."""
+    if L.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(L.QPError) as ei:
+        L.Context(0)
+    assert ei.value.status == 8 and "no CPU fallback" in str(ei.value)
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "quantumpropagators.jl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "qp_oracle" not in src and "from oracle" not in src and "import oracle" not in src, f
+
+
+@pytest.mark.parametrize("Delta,dt", [(20.0, 1.0), (849.53, 0.5), (4.0, 1.0), (100.0, 1.0), (20.2, 0.05)])
+def test_cheby_coeffs_match_oracle(Delta, dt):
+    """src/cheby.jl:25-39; glibc jn vs scipy jv.  Count within +-1 (the append-then-test
+    at the 1e-12 limit), values to 5e-14 absolute (two libm-grade Bessel implementations at alpha ~ 212)."""
+    a = L.cheby_coeffs(Delta, dt)
+    b = qo.cheby_coeffs(Delta, dt)
+    assert abs(len(a) - len(b)) <= 1
+    n = min(len(a), len(b))
+    assert np.max(np.abs(a[:n] - b[:n])) < 5e-14
+    assert abs(a[-1]) <= 1e-12 < abs(a[-2])
+
+
+def test_cheby_coeffs_reference_count():
+    """test/test_cheby.jl:36: Delta = spectral range of Hermitian(rand(ComplexF64,N,N)),
+    N=1000 (~849.5), dt=0.5 gives 267 or 268 coefficients; BASELINE config C2
+    (alpha=10) gives 32."""
+    assert len(L.cheby_coeffs(20.0, 1.0)) == 32
+    assert len(L.cheby_coeffs(849.53, 0.5)) in (267, 268)
+
+
+@pytest.mark.parametrize("m,herm", [(1, False), (2, False), (3, False), (5, True), (20, False), (60, True), (200, False)])
+def test_hessenberg_eigvals(m, herm):
+    """src/arnoldi.jl:143-170 with our own complex QR standing in for LAPACK."""
+    rng = np.random.default_rng(m)
+    A = rng.standard_normal((m + 1, m + 1)) + 1j * rng.standard_normal((m + 1, m + 1))
+    if herm:
+        A = (A + A.conj().T) / 2
+    Hs = np.asfortranarray(np.triu(A, -1))
+    ev = L.hessenberg_eigvals(Hs, m)
+    ref = qo.diagonalize_hessenberg_matrix(Hs, m)
+    assert np.max(np.abs(np.sort_complex(ev) - np.sort_complex(ref))) < 1e-11 * max(1.0, np.max(np.abs(ref)))
+    if m > 2:  # sorted by (real, imag)
+        assert np.all(np.diff(ev.real) >= 0)
+    if m <= 20:
+        acc = L.hessenberg_eigvals(Hs, m, accumulate=True)
+        ref = qo.diagonalize_hessenberg_matrix(Hs, m, accumulate=True)
+        assert len(acc) == m * (m + 1) // 2
+        off = 0
+        for j in range(1, m + 1):
+            assert np.max(np.abs(np.sort_complex(acc[off:off + j]) - np.sort_complex(ref[off:off + j]))) < 1e-11
+            off += j
+
+
+def test_hessenberg_eigvals_from_arnoldi():
+    rng = np.random.default_rng(3)
+    H = synth.dense_nonhermitian(300, rng=rng)
+    psi = rng.standard_normal(300) + 1j * rng.standard_normal(300)
+    psi /= np.linalg.norm(psi)
+    m = 30
+    Hess = np.zeros((m + 1, m + 1), dtype=complex, order="F")
+    q = [np.empty(300, dtype=complex) for _ in range(m + 1)]
+    qo.arnoldi(Hess, q, m, psi, H, 0.5)
+    ev = L.hessenberg_eigvals(Hess, m, accumulate=True)
+    ref = qo.diagonalize_hessenberg_matrix(Hess, m, accumulate=True)
+    off = 0
+    for j in range(1, m + 1):
+        assert np.max(np.abs(np.sort_complex(ev[off:off + j]) - np.sort_complex(ref[off:off + j]))) < 1e-12
+        off += j
+
+
+def test_extend_leja_matches_oracle():
+    """src/newton.jl:97-148 -- selection order is index work: identical picks."""
+    rng = np.random.default_rng(5)
+    leja_a = np.zeros(41, dtype=complex)
+    leja_b = leja_a.copy()
+    n_a = n_b = 0
+    for rnd in range(4):
+        m = 10
+        pts = rng.standard_normal(m * (m + 1) // 2) + 1j * rng.standard_normal(m * (m + 1) // 2)
+        leja_a, n_a = qo.extend_leja(leja_a, n_a, pts.copy(), m)
+        leja_b, n_b = L.extend_leja(leja_b, n_b, pts.copy(), m)
+        assert n_a == n_b == (rnd + 1) * m
+        assert np.array_equal(leja_a[:n_a], leja_b[:n_b])
+
+
+@pytest.mark.parametrize("func", ["expmi", "exp", "callback"])
+def test_extend_newton_coeffs_matches_oracle(func):
+    """src/newton.jl:176-214."""
+    rng = np.random.default_rng(6)
+    pyf = {"expmi": lambda z: np.exp(-1j * z), "exp": np.exp, "callback": lambda z: 1.0 / (2.5 + z)}[func]
+    arg = func if func != "callback" else pyf
+    leja = np.zeros(0, dtype=complex)
+    a1 = np.zeros(31, dtype=complex)
+    a2 = a1.copy()
+    n1 = n2 = 0
+    nl = 0
+    for rnd in range(3):
+        m = 8
+        pts = (rng.standard_normal(36) + 1j * rng.standard_normal(36)) * 0.8
+        leja, nl = qo.extend_leja(leja, nl, pts, m)
+        a1, n1 = qo.extend_newton_coeffs(a1, n1, leja, pyf, nl, 2.0)
+        a2, n2 = L.extend_newton_coeffs(a2, n2, leja, arg, nl, 2.0)
+        assert n1 == n2 == nl
+        # divided differences cancel: compare absolutely, relative to the largest coefficient
+        assert np.max(np.abs(a1[:n1] - a2[:n2])) < 1e-12 * np.max(np.abs(a1[:n1]))
+
+
+def test_newton_coeffs_underflow_status():
+    leja = np.array([1.0, 1.0 + 1e-210], dtype=complex)
+    a = np.zeros(4, dtype=complex)
+    with pytest.raises(L.QPAssertionError, match="Divided differences too small"):
+        L.extend_newton_coeffs(a, 0, leja, "exp", 2, 1.0)
+
+
+def test_csc_to_csr_bit_exact():
+    rng = np.random.default_rng(7)
+    for n, dens in ((1, 1.0), (17, 0.3), (130, 0.05), (64, 0.0)):
+        A = synth.sparse_random(n, dens, rng=rng).tocsc() if dens > 0 else __import__("scipy.sparse").sparse.csc_matrix((n, n), dtype=complex)
+        A.sort_indices()
+        got = L.csc_to_csr(n, n, A.indptr + 1, A.indices + 1, A.data, index_base=1)
+        ref = qo.csc_to_csr(n, n, A.indptr + 1, A.indices + 1, A.data, index_base=1)
+        for g, r in zip(got, ref):
+            assert g.dtype == r.dtype and np.array_equal(g, r)
+
+
+def test_partition_rows_bit_exact():
+    rng = np.random.default_rng(8)
+    lens = rng.integers(0, 9, 1000)
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    for parts in (1, 2, 3, 8):
+        for bal in ("rows", "nnz"):
+            assert np.array_equal(L.partition_rows(rowptr, parts, bal), qo.partition_rows(rowptr, parts, bal))

@@ -1,0 +1,460 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on
+the same seeded inputs.  Tolerance for complex-fp64 results is ||delta psi||_2 < 1e-10
+(BASELINE.json north_star; the reference's own bar in test/test_cheby.jl:47 and
+test/test_newton.jl:65,125,175); index work is bit-exact."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import scipy.linalg as sla
+import scipy.sparse as sp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import qp_oracle as qo  # noqa: E402
+import qprop_amd.lib as L  # noqa: E402
+import qprop_amd.synth as synth  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = L.Context(0)
+    yield c
+    c.close()
+
+
+def _rand_state(N, rng):
+    psi = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    return psi / np.linalg.norm(psi)
+
+
+def _ragged(n, rng, max_len=9, empty_rows=True):
+    lens = rng.integers(0 if empty_rows else 1, max_len + 1, n)
+    rows = np.repeat(np.arange(n), lens)
+    cols = np.concatenate([rng.choice(n, l, replace=False) for l in lens]) if lens.sum() else np.zeros(0, int)
+    vals = rng.standard_normal(len(rows)) + 1j * rng.standard_normal(len(rows))
+    A = sp.csr_matrix((vals, (rows, cols)), shape=(n, n))
+    A.sort_indices()
+    return A
+
+
+# ---------------------------------------------------------------- index work / formats
+
+@pytest.mark.parametrize("fmt", [L.FMT_RBCSR, L.FMT_CSR])
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 200, 1000])
+def test_device_format_roundtrip_bit_exact(ctx, fmt, n):
+    rng = np.random.default_rng(n)
+    A = _ragged(n, rng)
+    M = L.Matrix.from_scipy(ctx, A.tocsc())          # CSC in, like Julia
+    rp, col, vals = M.get_csr()
+    assert np.array_equal(rp, A.indptr) and np.array_equal(col, A.indices) and np.array_equal(vals, A.data)
+    Op = L.Operator(ctx, [M], 0, fmt)
+    assert Op.format == fmt
+    rp, col, vals = Op.get_csr()
+    assert np.array_equal(rp, A.indptr) and np.array_equal(col, A.indices) and np.array_equal(vals, A.data)
+
+
+def test_operator_auto_format(ctx):
+    rp, col, vals = synth.hermitian_offsets_csr(512, offsets=(1, 2, 3, 4, 16, 32, 48, 64))
+    Op = L.Operator(ctx, [L.Matrix(ctx, 512, 512, rp, col, vals)])
+    assert Op.format == L.FMT_RBCSR
+    rng = np.random.default_rng(0)
+    lens = np.ones(512, int)
+    lens[::64] = 60     # one long row per block: padding would be ~30x
+    rows = np.repeat(np.arange(512), lens)
+    cols = np.concatenate([rng.choice(512, l, replace=False) for l in lens])
+    A = sp.csr_matrix((np.ones(len(rows), complex), (rows, cols)), shape=(512, 512))
+    assert L.Operator(ctx, [L.Matrix.from_scipy(ctx, A)]).format == L.FMT_CSR
+
+
+# ---------------------------------------------------------------- mul! / BLAS-1
+
+@pytest.mark.parametrize("fmt", [L.FMT_RBCSR, L.FMT_CSR])
+def test_operator_mul(ctx, fmt):
+    """test/test_operator_linalg.jl:30-64 on the device: mul!(phi, Op, psi, a, b) for
+    (1,0),(1,1),(2,1),(2,2), drift + 2 controls and no drift, ScaledOperator."""
+    rng = np.random.default_rng(21)
+    N = 300
+    mats = [_ragged(N, rng, empty_rows=(i == 0)) for i in range(3)]
+    psi, phi0 = _rand_state(N, rng), _rand_state(N, rng)
+    dmats = [L.Matrix.from_scipy(ctx, A) for A in mats]
+    for ops, dops, coeffs in ((mats, dmats, [0.3, -1.2 + 0.4j]), (mats[1:], dmats[1:], [0.7, 0.1 + 0.2j])):
+        ref = qo.Operator(ops, coeffs)
+        Op = L.Operator(ctx, dops, len(coeffs), fmt)
+        Op.set_coeffs(coeffs)
+        x = L.State(ctx, data=psi)
+        for alpha, beta in ((1, 0), (1, 1), (2, 1), (2, 2), (0.5 - 1j, 0.25j)):
+            y = L.State(ctx, data=phi0)
+            Op.mul(x, y, alpha, beta)
+            assert np.linalg.norm(y.numpy() - ref.mul(psi, alpha, beta, C=phi0.copy())) < 1e-12
+        Op.set_scale(0.5j)
+        y = L.State(ctx, data=phi0)
+        Op.mul(x, y, 2, 1)
+        assert np.linalg.norm(y.numpy() - qo.ScaledOperator(0.5j, ref).mul(psi, 2, 1, C=phi0.copy())) < 1e-12
+        Op.set_scale(1.0)
+        # device copy of the combined values == sum_l c_l H_l on the union pattern
+        rp, col, vals = Op.get_csr()
+        dense = sp.csr_matrix((vals, col, rp), shape=(N, N)).toarray()
+        assert np.linalg.norm(dense - ref.toarray()) < 1e-12
+
+
+def test_blas1(ctx):
+    rng = np.random.default_rng(22)
+    for n in (1, 255, 256, 70001):
+        x, y = _rand_state(n, rng), _rand_state(n, rng)
+        X, Y = L.State(ctx, data=x), L.State(ctx, data=y)
+        assert abs(X.dot(Y) - np.vdot(x, y)) < 1e-13
+        assert abs(X.norm() - np.linalg.norm(x)) < 1e-13
+        Y.axpy(0.3 - 2j, X)
+        y = y + (0.3 - 2j) * x
+        assert np.linalg.norm(Y.numpy() - y) < 1e-13
+        Y.scal(1j)
+        assert np.linalg.norm(Y.numpy() - 1j * y) < 1e-13
+        Y.copy_from(X)
+        assert np.array_equal(Y.numpy(), x)
+        Y.fill(2 - 1j)
+        assert np.all(Y.numpy() == 2 - 1j)
+
+
+# ---------------------------------------------------------------- Chebyshev
+
+def _cheby_case(ctx, H_sp, psi0, Delta, E_min, dt, fmt, steps=1, check=False):
+    N = len(psi0)
+    Op = L.Operator(ctx, [L.Matrix.from_scipy(ctx, H_sp)], 0, fmt)
+    wrk = L.ChebyWrk(ctx, N, Delta, E_min, abs(dt))
+    owrk = qo.ChebyWrk(psi0, Delta, E_min, abs(dt))
+    owrk.coeffs, owrk.n_coeffs = wrk.coeffs.copy(), wrk.n_coeffs   # identical coefficients
+    psi = L.State(ctx, data=psi0)
+    ref = psi0.copy()
+    for _ in range(steps):
+        L.cheby(psi, Op, dt, wrk, check_normalization=check)
+        qo.cheby(ref, H_sp, dt, owrk)
+    return psi.numpy(), ref, wrk
+
+
+@pytest.mark.parametrize("fmt", [L.FMT_RBCSR, L.FMT_CSR])
+def test_cheby_dense_c1(ctx, fmt):
+    """BASELINE config C1: N=128 dense random Hermitian, 200 time steps, vs oracle and
+    vs exp(-i H t)."""
+    rng = np.random.default_rng(31)
+    N = 128
+    H = synth.dense_hermitian(N, rho=5.0, rng=rng)
+    ev = np.linalg.eigvalsh(H)
+    psi0 = _rand_state(N, rng)
+    dt = 0.1
+    out, ref, wrk = _cheby_case(ctx, sp.csr_matrix(H), psi0, ev[-1] - ev[0], ev[0], dt, fmt, steps=200)
+    assert np.linalg.norm(out - ref) < TOL
+    V = np.linalg.eigh(H)[1]
+    exact = V @ (np.exp(-1j * ev * dt * 200) * (V.conj().T @ psi0))
+    assert np.linalg.norm(out - exact) < 1e-9
+    assert abs(np.linalg.norm(out) - 1) < 1e-10
+
+
+@pytest.mark.parametrize("fmt", [L.FMT_RBCSR, L.FMT_CSR])
+@pytest.mark.parametrize("N", [256, 1000, 16384])
+@pytest.mark.parametrize("dt", [1.0, -1.0])
+def test_cheby_synthetic(ctx, fmt, N, dt):
+    """Same generator as BASELINE config C2 at oracle-sized N; forward and backward."""
+    offs = (1, 2, 3, 4, 16, 32, 48, 64) if N < 16384 else synth.BANDED_OFFSETS
+    rp, col, vals = synth.hermitian_offsets_csr(N, offsets=offs)
+    H = synth.to_scipy(rp, col, vals, N)
+    psi0 = synth.random_state(N)
+    out, ref, wrk = _cheby_case(ctx, H, psi0, 20.0, -10.0, dt, fmt, steps=3)
+    assert wrk.n_coeffs == 32
+    assert np.linalg.norm(out - ref) < TOL
+    assert abs(np.linalg.norm(out) - 1) < 1e-11
+
+
+@pytest.mark.parametrize("alpha", [1e-9, 0.4, 50.0])
+def test_cheby_coefficient_count_edges(ctx, alpha):
+    """n_coeffs = 2 (single fused term, result copied back), odd/even term counts."""
+    N = 300
+    rp, col, vals = synth.hermitian_offsets_csr(N, offsets=(1, 5, 7, 30))
+    H = synth.to_scipy(rp, col, vals, N)
+    psi0 = synth.random_state(N)
+    dt = alpha / 10.0
+    out, ref, wrk = _cheby_case(ctx, H, psi0, 20.0, -10.0, dt, L.FMT_AUTO, steps=2)
+    if alpha < 1e-6:
+        assert wrk.n_coeffs == 2
+    assert np.linalg.norm(out - ref) < TOL
+
+
+def test_cheby_errors(ctx):
+    N = 128
+    rp, col, vals = synth.hermitian_offsets_csr(N, offsets=(1, 2, 3, 4))
+    Op = L.Operator(ctx, [L.Matrix(ctx, N, N, rp, col, vals)])
+    psi = L.State(ctx, data=synth.random_state(N))
+    wrk = L.ChebyWrk(ctx, N, 20.0, -10.0, 1.0)
+    with pytest.raises(L.QPAssertionError, match="wrk was initialized for dt"):   # src/cheby.jl:157
+        L.cheby(psi, Op, 0.5, wrk)
+    # src/cheby.jl:194-200: spectral radius far too small -> "Incorrect normalization"
+    wrk2 = L.ChebyWrk(ctx, N, 0.5, -0.25, 1.0)
+    with pytest.raises(L.QPAssertionError, match="Incorrect normalization"):
+        L.cheby(psi, Op, 1.0, wrk2, check_normalization=True)
+    # and a correct radius passes the check
+    psi.upload(synth.random_state(N))
+    L.cheby(psi, Op, 1.0, wrk, check_normalization=True)
+    assert abs(psi.norm() - 1) < 1e-11
+
+
+def test_cheby_deterministic(ctx):
+    """check_propagator's reinit test needs run-to-run reproducibility (1e-14); the
+    kernels use no atomics, so results are bitwise identical."""
+    N = 4096
+    rp, col, vals = synth.hermitian_offsets_csr(N, offsets=(1, 2, 3, 4, 16, 32, 48, 64))
+    Op = L.Operator(ctx, [L.Matrix(ctx, N, N, rp, col, vals)])
+    wrk = L.ChebyWrk(ctx, N, 20.0, -10.0, 1.0)
+    outs = []
+    for _ in range(2):
+        psi = L.State(ctx, data=synth.random_state(N))
+        L.cheby(psi, Op, 1.0, wrk)
+        outs.append(psi.numpy())
+    assert np.array_equal(outs[0], outs[1])
+
+
+def test_cheby_term_row_partition(ctx):
+    """The multi-GPU building block on one GPU: two row shards, each running
+    qp_cheby_term on its rows with a gathered x, reproduce the unsharded step."""
+    N = 1000
+    rp, col, vals = synth.hermitian_offsets_csr(N, offsets=(1, 2, 3, 4, 16, 32, 48, 64))
+    H = synth.to_scipy(rp, col, vals, N)
+    psi0 = synth.random_state(N)
+    Delta, E_min, dt = 20.0, -10.0, 1.0
+    a = L.cheby_coeffs(Delta, dt)
+    beta = Delta / 2 + E_min
+    bounds = L.partition_rows(rp, 2)
+    shards = []
+    for r in range(2):
+        r0, r1 = bounds[r], bounds[r + 1]
+        Hs = H[r0:r1]
+        shards.append((r0, r1, L.Operator(ctx, [L.Matrix(ctx, r1 - r0, N, Hs.indptr, Hs.indices, Hs.data)])))
+    G = [L.State(ctx, data=psi0), L.State(ctx, n=N)]       # gathered ping-pong buffers
+    acc = [L.State(ctx, n=r1 - r0) for r0, r1, _ in shards]
+    c = -2j / Delta
+    n = len(a)
+    for m in range(1, n):
+        xg, og = (G[0], G[1]) if m % 2 == 1 else (G[1], G[0])
+        last = m == n - 1
+        phase = np.exp(-1j * beta * dt) if last else 1.0
+        ohost = og.numpy()
+        for k, (r0, r1, Op) in enumerate(shards):
+            loc = L.State(ctx, data=ohost[r0:r1])        # local slice of the other buffer
+            if m == 1:
+                L.cheby_term(Op, xg, r0, None, loc, None, acc[k], c, beta, a[0], a[1], phase)
+            else:
+                L.cheby_term(Op, xg, r0, loc, None if last else loc, acc[k], acc[k], c, beta, 0.0, a[m], phase)
+            ohost[r0:r1] = loc.numpy()                   # "all-gather" through the host
+        og.upload(ohost)
+        if m == 1:
+            c = 2 * c
+    out = np.concatenate([s.numpy() for s in acc])
+    wrk = qo.ChebyWrk(psi0, Delta, E_min, dt)
+    wrk.coeffs, wrk.n_coeffs = a, len(a)
+    ref = qo.cheby(psi0.copy(), H, dt, wrk)
+    assert np.linalg.norm(out - ref) < TOL
+
+
+# ---------------------------------------------------------------- Arnoldi / Newton / specrange
+
+def test_arnoldi_matches_oracle(ctx):
+    rng = np.random.default_rng(41)
+    N, m, dt = 500, 12, 0.37
+    A = synth.sparse_random(N, 0.03, rng=rng)
+    psi = _rand_state(N, rng)
+    Op = L.Operator(ctx, [L.Matrix.from_scipy(ctx, A)])
+    for extended in (True, False):
+        q = L.Krylov(ctx, N, m + 1)
+        Hess = np.zeros((m + 1, m + 1), dtype=complex, order="F")
+        m_out = L.arnoldi(Hess, q, m, L.State(ctx, data=psi), Op, dt, extended=extended)
+        Href = np.zeros((m + 1, m + 1), dtype=complex)
+        qref = [np.empty(N, dtype=complex) for _ in range(m + 1)]
+        m_ref = qo.arnoldi(Href, qref, m, psi, A, dt, extended=extended)
+        assert m_out == m_ref == m
+        assert np.max(np.abs(Hess - Href)) < 1e-12
+        for i in range(m + 1):
+            assert np.linalg.norm(q.vec(i) - qref[i]) < 1e-11
+        if not extended:   # extend_arnoldi! by one column (src/arnoldi.jl:115-129)
+            q2 = L.Krylov(ctx, N, m + 2)
+            H2 = np.zeros((m + 1, m + 1), dtype=complex, order="F")
+            L.arnoldi(H2, q2, m, L.State(ctx, data=psi), Op, dt, extended=False)
+            assert L.extend_arnoldi(H2, q2, m + 1, Op, dt)
+            Href2 = np.zeros((m + 1, m + 1), dtype=complex)
+            qref2 = [np.empty(N, dtype=complex) for _ in range(m + 2)]
+            qo.arnoldi(Href2, qref2, m, psi, A, dt, extended=False)
+            qo.extend_arnoldi(Href2, qref2, m + 1, A, dt)
+            assert np.max(np.abs(H2 - Href2)) < 1e-12
+
+
+def test_arnoldi_breakdown(ctx):
+    """Krylov dimension smaller than m: reduced m is returned (src/arnoldi.jl:91-95),
+    also for negative dt."""
+    N = 64
+    d = np.arange(1, N + 1, dtype=float)
+    A = sp.diags([d], [0], format="csr", dtype=complex)
+    psi = np.zeros(N, dtype=complex)
+    psi[[3, 10, 20]] = 1 / np.sqrt(3)        # Krylov dimension 3
+    Op = L.Operator(ctx, [L.Matrix.from_scipy(ctx, A)])
+    for dt in (1.0, -1.0):
+        q = L.Krylov(ctx, N, 9)
+        Hess = np.zeros((9, 9), dtype=complex, order="F")
+        m_out = L.arnoldi(Hess, q, 8, L.State(ctx, data=psi), Op, dt, norm_min=1e-10)
+        Href = np.zeros((9, 9), dtype=complex)
+        qref = [np.empty(N, dtype=complex) for _ in range(9)]
+        m_ref = qo.arnoldi(Href, qref, 8, psi, A, dt, norm_min=1e-10)
+        assert m_out == m_ref == 3
+        assert np.max(np.abs(Hess[:, :3] - Href[:, :3])) < 1e-9
+        assert np.all(Hess[:, 3:] == 0)
+
+
+def _newton_case(ctx, A, psi0, dt, m_max, func=None, **kw):
+    N = len(psi0)
+    Op = L.Operator(ctx, [L.Matrix.from_scipy(ctx, sp.csr_matrix(A))])
+    wrk = L.NewtonWrk(ctx, N, m_max=m_max)
+    psi = L.State(ctx, data=psi0)
+    L.newton(psi, Op, dt, wrk, func=func, **kw)
+    owrk = qo.NewtonWrk(psi0, m_max=m_max)
+    pyf = {None: None, "exp": np.exp}.get(func, func)
+    ref = qo.newton(psi0.copy(), A, dt, owrk, func=pyf, **kw)
+    return psi.numpy(), ref, wrk, owrk
+
+
+def test_newton_hermitian(ctx):
+    """test/test_newton.jl:7-67: N=1000 Hermitian rho=10, dt=0.5, m_max=5, 200 restarts."""
+    rng = np.random.default_rng(42)
+    N = 1000
+    H = synth.dense_hermitian(N, rho=10.0, rng=rng)
+    psi0 = _rand_state(N, rng)
+    out, ref, wrk, owrk = _newton_case(ctx, H, psi0, 0.5, 5, max_restarts=200)
+    ev, V = np.linalg.eigh(H)
+    exact = V @ (np.exp(-1j * ev * 0.5) * (V.conj().T @ psi0))
+    assert np.linalg.norm(out - exact) < TOL
+    assert np.linalg.norm(out - ref) < TOL
+    assert abs(wrk.restarts - owrk.restarts) <= 1
+    assert abs(np.linalg.norm(out) - 1) < 1e-10
+
+
+def test_newton_nonhermitian(ctx):
+    """test/test_newton.jl:70-127: non-Hermitian rho=10, m_max=50; backward too."""
+    rng = np.random.default_rng(43)
+    N = 1000
+    H = synth.dense_nonhermitian(N, rho=10.0, rng=rng)
+    psi0 = _rand_state(N, rng)
+    for dt in (0.5, -0.5):
+        out, ref, wrk, owrk = _newton_case(ctx, H, psi0, dt, 50, max_restarts=200)
+        assert np.linalg.norm(out - sla.expm(-1j * H * dt) @ psi0) < TOL * max(1, np.linalg.norm(ref))
+        assert np.linalg.norm(out - ref) < TOL * max(1, np.linalg.norm(ref))
+
+
+@pytest.mark.parametrize("func", ["exp", "callback"])
+def test_newton_liouvillian_custom_func(ctx, func):
+    """test/test_newton.jl:130-177: sparse L (32^2), density 0.5, m_max=50,
+    func = exp (built in, and through the C callback), max_restarts=20."""
+    rng = np.random.default_rng(44)
+    n = 32
+    Lm = synth.sparse_random(n * n, 0.5, rho=10.0, rng=rng)
+    psi0 = _rand_state(n, rng)
+    rho0 = np.outer(psi0, psi0.conj()).reshape(-1, order="F")
+    f = "exp" if func == "exp" else (lambda z: np.exp(z))
+    N = n * n
+    Op = L.Operator(ctx, [L.Matrix.from_scipy(ctx, Lm)])
+    wrk = L.NewtonWrk(ctx, N, m_max=50)
+    rho = L.State(ctx, data=rho0)
+    L.newton(rho, Op, 0.5, wrk, func=f, max_restarts=20)
+    assert np.linalg.norm(rho.numpy() - sla.expm(Lm.toarray() * 0.5) @ rho0) < TOL
+
+
+def test_newton_c3_liouvillian(ctx):
+    """BASELINE config C3 at oracle size: tridiagonal-system Liouvillian (n=24 -> N=576),
+    m_max=20, several restarts; vs oracle and dense exp."""
+    Lm = synth.liouvillian_tridiag(24)
+    N = Lm.shape[0]
+    rho0 = synth.random_state(N)
+    out, ref, wrk, owrk = _newton_case(ctx, Lm, rho0, 0.8, 20)
+    assert np.linalg.norm(out - ref) < TOL
+    assert np.linalg.norm(out - sla.expm(-1j * Lm.toarray() * 0.8) @ rho0) < TOL
+    assert wrk.restarts >= 1 and abs(wrk.restarts - owrk.restarts) <= 1
+    a, leja = wrk.coeffs()
+    n = min(len(a), owrk.n_a)
+    assert np.max(np.abs(leja[:n] - owrk.leja[:n])) < 1e-8   # same Leja ordering
+
+
+def test_newton_eigenstate_and_errors(ctx):
+    rng = np.random.default_rng(45)
+    H = synth.dense_hermitian(50, rho=4.0, rng=rng)
+    ev, V = np.linalg.eigh(H)
+    Op = L.Operator(ctx, [L.Matrix.from_dense(ctx, H)])
+    wrk = L.NewtonWrk(ctx, 50, m_max=10)
+    psi = L.State(ctx, data=V[:, 3])
+    L.newton(psi, Op, 0.7, wrk)                      # src/newton.jl:289-295
+    assert wrk.restarts == 0
+    assert np.linalg.norm(psi.numpy() - np.exp(-1j * ev[3] * 0.7) * V[:, 3]) < 1e-12
+    with pytest.raises(L.QPArgumentError, match="m_max > 2"):   # src/newton.jl:38-40
+        L.NewtonWrk(ctx, 50, m_max=2)
+    psi = L.State(ctx, data=_rand_state(50, rng))
+    with pytest.raises(L.QPAssertionError):                    # src/newton.jl:375
+        L.newton(psi, Op, 50.0, L.NewtonWrk(ctx, 50, m_max=3), max_restarts=1)
+
+
+def test_ritzvals_and_specrange(ctx):
+    """test/test_specrad.jl:47-144 on the device, vs oracle (same start vector) and
+    vs exact eigenvalues."""
+    rng = np.random.default_rng(46)
+    N = 1000
+    H = synth.sparse_random(N, 0.1, rho=10.0, hermitian=True, rng=rng)
+    ev = np.linalg.eigvalsh(H.toarray())
+    Delta = ev[-1] - ev[0]
+    psi = _rand_state(N, rng)
+    Op = L.Operator(ctx, [L.Matrix.from_scipy(ctx, H)])
+    st = L.State(ctx, data=psi)
+    r_dev = L.ritzvals(Op, st, 20, 60, prec=1e-3)
+    r_ref = qo.ritzvals(H, psi, 20, 60, prec=1e-3)
+    assert len(r_dev) == len(r_ref)
+    assert np.max(np.abs(r_dev - r_ref)) < 1e-8
+    assert abs(ev[0] - r_dev[0].real) / abs(ev[0]) < 0.02 and abs(ev[-1] - r_dev[-1].real) / abs(ev[-1]) < 0.02
+    E_min, E_max = L.specrange_arnoldi(Op, st, prec=1e-4)
+    o_min, o_max = qo.specrange(H, "arnoldi", state=psi, prec=1e-4)
+    assert abs(E_min - o_min) < 1e-8 and abs(E_max - o_max) < 1e-8
+    assert ev[0] - 0.05 * Delta <= E_min <= ev[0]
+    assert ev[-1] <= E_max < ev[-1] + 0.05 * Delta
+
+
+# ---------------------------------------------------------------- full-size properties
+
+def test_full_size_properties(ctx):
+    """BASELINE config C2 at full size (N = 2^20, 16 nnz/row): the oracle is too slow
+    here, so check size-independent properties: unitarity (norm), forward/backward
+    round trip, linearity, and agreement of the two device formats."""
+    N = 1 << 20
+    rp, col, vals = synth.hermitian_offsets_csr(N)
+    M = L.Matrix(ctx, N, N, rp, col, vals)
+    del rp, col, vals
+    psi0 = synth.random_state(N)
+    wrk = L.ChebyWrk(ctx, N, 20.0, -10.0, 1.0)
+    assert wrk.n_coeffs == 32
+    res = {}
+    for fmt in (L.FMT_RBCSR, L.FMT_CSR):
+        Op = L.Operator(ctx, [M], 0, fmt)
+        psi = L.State(ctx, data=psi0)
+        L.cheby(psi, Op, 1.0, wrk)
+        L.cheby(psi, Op, 1.0, wrk)
+        res[fmt] = psi.numpy()
+        assert abs(np.linalg.norm(res[fmt]) - 1) < 1e-11
+        L.cheby(psi, Op, -1.0, wrk)
+        L.cheby(psi, Op, -1.0, wrk)
+        assert np.linalg.norm(psi.numpy() - psi0) < TOL
+        if fmt == L.FMT_RBCSR:      # linearity: U(a x + b y) = a U x + b U y
+            y0 = synth.random_state(N, seed=77)
+            a, b = 0.6 - 0.3j, -0.2 + 0.9j
+            Y = L.State(ctx, data=y0)
+            L.cheby(Y, Op, 1.0, wrk)
+            L.cheby(Y, Op, 1.0, wrk)
+            Z = L.State(ctx, data=a * psi0 + b * y0)
+            L.cheby(Z, Op, 1.0, wrk)
+            L.cheby(Z, Op, 1.0, wrk)
+            assert np.linalg.norm(Z.numpy() - (a * res[fmt] + b * Y.numpy())) < TOL
+        Op.close()
+    assert np.linalg.norm(res[L.FMT_RBCSR] - res[L.FMT_CSR]) < TOL

@@ -33,7 +33,7 @@ def _rand_state(N, rng):
 
 
 def _ragged(n, rng, max_len=9, empty_rows=True):
-    lens = rng.integers(0 if empty_rows else 1, max_len + 1, n)
+    lens = np.minimum(rng.integers(0 if empty_rows else 1, max_len + 1, n), n)
     rows = np.repeat(np.arange(n), lens)
     cols = np.concatenate([rng.choice(n, l, replace=False) for l in lens]) if lens.sum() else np.zeros(0, int)
     vals = rng.standard_normal(len(rows)) + 1j * rng.standard_normal(len(rows))

@@ -1,0 +1,105 @@
+"""Multi-process CPU test (gloo, world_size 2 and 3) of the row-partitioned Chebyshev
+driver: partition bookkeeping, halo-run computation, both exchange modes, forward and
+backward steps, uneven row blocks.  The local compute is a NumPy backend (the GPU kernels
+are covered by tests/test_gpu_parity.py::test_cheby_term_row_partition); the result must
+equal the oracle's unsharded cheby! to rounding."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, exchange, uneven, offsets, N, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from np_backend import NumpyBackend
+        from oracle import qp_oracle as qo
+        import qprop_amd.sharded as sharded
+        import qprop_amd.synth as synth
+        rp, col, vals = synth.hermitian_offsets_csr(N, offsets=offsets)
+        bounds = qo.partition_rows(rp, world)
+        if uneven:
+            bounds = bounds.copy()
+            bounds[1:-1] += 37
+        r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
+        lrp = rp[r0:r1 + 1] - rp[r0]
+        lcol, lvals = col[rp[r0]:rp[r1]], vals[rp[r0]:rp[r1]]
+        sh = sharded.ShardedCheby(None, lrp, lcol, lvals, N, r0, r1, 20.0, -10.0, 1.0, exchange=exchange,
+                                  backend=NumpyBackend(), gap_merge=8)
+        psi0 = synth.random_state(N)
+        sh.set_state(psi0[r0:r1])
+        sh.step()
+        sh.step()
+        sh.step(backward=True)
+        out = sh.local_state()
+        # oracle, unsharded
+        H = synth.to_scipy(rp, col, vals, N)
+        wrk = qo.ChebyWrk(psi0, 20.0, -10.0, 1.0)
+        ref = psi0.copy()
+        qo.cheby(ref, H, 1.0, wrk)
+        qo.cheby(ref, H, 1.0, wrk)
+        qo.cheby(ref, H, -1.0, wrk)
+        err = float(np.linalg.norm(out - ref[r0:r1]))
+        q.put((rank, err, sh.exchange, sh.halo_fraction, len(sh.recv_runs), len(sh.send_runs), sh.n_exchanges))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,exchange,uneven,offsets", [
+    (2, "allgather", False, (1, 2, 3, 4, 16, 32, 48, 64)),
+    (2, "halo", False, (1, 2, 3, 4, 16, 32, 48, 64)),
+    (2, "auto", True, (1, 2, 3, 4, 16, 32, 48, 64)),
+    (3, "auto", False, (1, 2, 3, 4, 16, 32, 48, 64)),
+    (2, "auto", False, (5, 77, 211, 333, 401, 467, 489, 499)),      # scattered -> allgather
+])
+def test_sharded_cheby_matches_oracle(world, exchange, uneven, offsets):
+    N = 1536
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, exchange, uneven, offsets, N, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=10) for _ in range(world))
+    coeffs_terms = 31
+    for rank, err, used, frac, nrecv, nsend, nex in res:
+        assert err < 1e-12, (rank, err)
+        assert nex == 3 * coeffs_terms       # one exchange per mat-vec: psi + 30 term vectors per step
+        if exchange != "auto":
+            assert used == exchange
+    if offsets[-1] == 64 and exchange == "auto":
+        assert all(r[2] == "halo" and r[3] < 0.5 for r in res)
+    if offsets[-1] == 499:
+        assert all(r[2] == "allgather" for r in res)
+
+
+def test_needed_runs():
+    import qprop_amd.sharded as sharded
+    bounds = np.array([0, 100, 200, 300])
+    col = np.array([95, 99, 100, 150, 199, 200, 201, 204, 290, 299, 3])
+    runs = sharded.needed_runs(col, 100, 200, bounds, gap_merge=4)
+    assert runs == [(0, 3, 4), (0, 95, 100), (2, 200, 205), (2, 290, 291), (2, 299, 300)]
+    assert sharded.needed_runs(col, 100, 200, bounds, gap_merge=1000) == [(0, 3, 100), (2, 200, 300)]
+    assert sharded.needed_runs(np.array([100, 150]), 100, 200, bounds) == []

@@ -73,6 +73,10 @@ const char* qp_last_error(void);
 const char* qp_status_name(int status);
 int qp_version(void);
 int qp_device_count(int* n_out);
+/* developer knob for A/B kernel experiments ("rbcsr_variant": bit0 nt matrix loads,
+ * bit1 early row-local loads, bit2 deeper unroll); process-global, not part of the
+ * reference-facing API. */
+int qp_tuning_set(const char* key, int value);
 
 /* ---- context -------------------------------------------------------------------- */
 /* `stream` may be NULL (the library creates one) or an existing hipStream_t, e.g.

@@ -62,6 +62,7 @@ struct Stats {
 int launch_spmv_cheby(hipStream_t s, const DevMatrix& A, const double2* x, const ChebyEpi& e, Stats* st);
 int launch_spmv_plain(hipStream_t s, const DevMatrix& A, const double2* x, const PlainEpi& e, Stats* st);
 int spmv_grid_size(const DevMatrix& A);
+extern int g_rbcsr_variant;
 
 // small coefficient vectors are passed by value in the kernel-argument segment
 constexpr int kCoefBlock = 32;

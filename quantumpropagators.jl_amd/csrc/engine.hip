@@ -181,6 +181,15 @@ const char* qp_status_name(int s) {
 
 int qp_version(void) { return 100; }
 
+int qp_tuning_set(const char* key, int value) {
+  if (!key) return qp::fail(QP_E_BAD_ARG, "key is NULL");
+  if (std::strcmp(key, "rbcsr_variant") == 0) {
+    qp::g_rbcsr_variant = value;
+    return QP_OK;
+  }
+  return qp::fail(QP_E_BAD_ARG, "unknown tuning key %s", key);
+}
+
 int qp_device_count(int* n_out) {
   QP_TRY
   if (!n_out) return qp::fail(QP_E_BAD_ARG, "n_out is NULL");

@@ -71,8 +71,19 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
 // ---------------------------------------------------------------------------
 struct ChebyOp {
   ChebyEpi e;
-  __device__ __forceinline__ void row(int64_t i, double2 s, double2& chk, double& nrm) const {
-    const double2 xi = e.xloc[i];
+  struct Pre {
+    double2 xi, v0, acc;
+  };
+  // row-local operands, issued ahead of the mat-vec loop so their latency overlaps it
+  __device__ __forceinline__ Pre pre(int64_t i) const {
+    Pre p;
+    p.xi = e.xloc[i];
+    p.v0 = e.v0 ? e.v0[i] : make_double2(0.0, 0.0);
+    p.acc = e.acc_in ? e.acc_in[i] : make_double2(0.0, 0.0);
+    return p;
+  }
+  __device__ __forceinline__ void row(int64_t i, double2 s, const Pre& p, double2& chk, double& nrm) const {
+    const double2 xi = p.xi;
     // t = c * (s - beta * x_i) [+ v0_i]        src/cheby.jl:178-179, :192-193, :202
     double2 t = make_double2(fma(-e.beta, xi.x, s.x), fma(-e.beta, xi.y, s.y));
     t = cmul(e.c, t);
@@ -83,14 +94,13 @@ struct ChebyOp {
       nrm += xi.x * xi.x + xi.y * xi.y;
     }
     if (e.v0) {
-      const double2 v = e.v0[i];
-      t.x += v.x;
-      t.y += v.y;
+      t.x += p.v0.x;
+      t.y += p.v0.y;
     }
     if (e.vout) e.vout[i] = t;
     double2 r;
     if (e.acc_in) {
-      r = e.acc_in[i];
+      r = p.acc;
     } else {
       r = make_double2(e.a_prev * xi.x, e.a_prev * xi.y);  // lmul!(a[1], Psi)  :172
     }
@@ -103,11 +113,18 @@ struct ChebyOp {
 
 struct PlainOp {
   PlainEpi e;
-  __device__ __forceinline__ void row(int64_t i, double2 s, double2&, double&) const {
+  struct Pre {
+    double2 y;
+  };
+  __device__ __forceinline__ Pre pre(int64_t i) const {
+    Pre p;
+    p.y = e.beta_zero ? make_double2(0.0, 0.0) : e.y[i];
+    return p;
+  }
+  __device__ __forceinline__ void row(int64_t i, double2 s, const Pre& p, double2&, double&) const {
     double2 r = cmul(e.alpha, s);
     if (!e.beta_zero) {
-      const double2 y = e.y[i];
-      const double2 by = cmul(e.beta, y);
+      const double2 by = cmul(e.beta, p.y);
       r.x += by.x;
       r.y += by.y;
     }
@@ -137,12 +154,39 @@ __device__ __forceinline__ void finish_check<ChebyOp>(const ChebyOp& op, double2
 // Per k: one 1-KiB coalesced load of 64 values, one 16-B gather of x per lane; column
 // indices arrive four k at a time in one 1-KiB load.  No cross-lane reduction, no LDS.
 // ---------------------------------------------------------------------------
-template <class Op>
+typedef double d2v __attribute__((ext_vector_type(2)));
+typedef int i4v __attribute__((ext_vector_type(4)));
+
+// streaming (read-once) loads of the matrix: the `nt` policy keeps the matrix from
+// displacing the vectors in L2 / Infinity Cache
+template <bool NT>
+__device__ __forceinline__ double2 ld_val(const double2* p) {
+  if (NT) {
+    const d2v t = __builtin_nontemporal_load(reinterpret_cast<const d2v*>(p));
+    return make_double2(t.x, t.y);
+  }
+  return *p;
+}
+template <bool NT>
+__device__ __forceinline__ int4 ld_col(const int4* p) {
+  if (NT) {
+    const i4v t = __builtin_nontemporal_load(reinterpret_cast<const i4v*>(p));
+    return make_int4(t.x, t.y, t.z, t.w);
+  }
+  return *p;
+}
+
+// VAR bit 0: nt matrix loads; bit 1: row-local operands prefetched before the loop;
+// bit 2: unroll 4 quads (16 value loads in flight per lane) instead of 2
+template <class Op, int VAR>
 __global__ __launch_bounds__(kThreads) void rbcsr_spmv_kernel(const int64_t* __restrict__ bptr,
                                                               const int4* __restrict__ cols4,
                                                               const double2* __restrict__ vals,
                                                               const double2* __restrict__ x,
                                                               int64_t nblocks, int64_t nrows, Op op) {
+  constexpr bool NT = (VAR & 1) != 0;
+  constexpr bool PRE = (VAR & 2) != 0;
+  constexpr int UNR = (VAR & 4) ? 4 : 2;
   __shared__ double2 lds[kThreads / 64];
   const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -155,14 +199,18 @@ __global__ __launch_bounds__(kThreads) void rbcsr_spmv_kernel(const int64_t* __r
     const int nq = (int)((bptr[b + 1] - base) >> 8);  // width / 4
     const double2* __restrict__ v = vals + base + lane;
     const int4* __restrict__ c4 = cols4 + (base >> 2) + lane;
+    const int64_t row = b * kRB + lane;
+    const int64_t rowc = row < nrows ? row : nrows - 1;
+    typename Op::Pre pre;
+    if (PRE) pre = op.pre(rowc);
     double2 s0 = make_double2(0.0, 0.0), s1 = make_double2(0.0, 0.0);
-#pragma unroll 2
+#pragma unroll UNR
     for (int q = 0; q < nq; ++q) {
-      const int4 c = c4[(size_t)q * 64];
-      const double2 a0 = v[(size_t)(4 * q + 0) * 64];
-      const double2 a1 = v[(size_t)(4 * q + 1) * 64];
-      const double2 a2 = v[(size_t)(4 * q + 2) * 64];
-      const double2 a3 = v[(size_t)(4 * q + 3) * 64];
+      const int4 c = ld_col<NT>(c4 + (size_t)q * 64);
+      const double2 a0 = ld_val<NT>(v + (size_t)(4 * q + 0) * 64);
+      const double2 a1 = ld_val<NT>(v + (size_t)(4 * q + 1) * 64);
+      const double2 a2 = ld_val<NT>(v + (size_t)(4 * q + 2) * 64);
+      const double2 a3 = ld_val<NT>(v + (size_t)(4 * q + 3) * 64);
       const double2 x0 = x[c.x];
       const double2 x1 = x[c.y];
       const double2 x2 = x[c.z];
@@ -172,8 +220,8 @@ __global__ __launch_bounds__(kThreads) void rbcsr_spmv_kernel(const int64_t* __r
       cfma(s0, a2, x2);
       cfma(s1, a3, x3);
     }
-    const int64_t row = b * kRB + lane;
-    if (row < nrows) op.row(row, make_double2(s0.x + s1.x, s0.y + s1.y), chk, nrm);
+    if (!PRE) pre = op.pre(rowc);
+    if (row < nrows) op.row(row, make_double2(s0.x + s1.x, s0.y + s1.y), pre, chk, nrm);
   }
   finish_check(op, chk, nrm, lds);
 }
@@ -204,9 +252,11 @@ __global__ __launch_bounds__(kThreads) void csr_spmv_kernel(const int64_t* __res
   }
   double2 chk = make_double2(0.0, 0.0);
   double nrm = 0.0;
-  if (row < nrows && tl == 0) op.row(row, s, chk, nrm);
+  if (row < nrows && tl == 0) op.row(row, s, op.pre(row), chk, nrm);
   finish_check(op, chk, nrm, lds);
 }
+
+int g_rbcsr_variant = 0;  // tuning knob (qp_tuning_set)
 
 int spmv_grid_size(const DevMatrix& A) {
   if (A.format == QP_FMT_RBCSR) return (int)((A.nblocks + kThreads / 64 - 1) / (kThreads / 64));
@@ -219,8 +269,22 @@ static int launch_spmv(hipStream_t s, const DevMatrix& A, const double2* x, cons
   if (A.nrows == 0) return QP_OK;
   const int grid = spmv_grid_size(A);
   if (A.format == QP_FMT_RBCSR) {
-    hipLaunchKernelGGL(rbcsr_spmv_kernel<Op>, dim3(grid), dim3(kThreads), 0, s, A.bptr,
-                       reinterpret_cast<const int4*>(A.cols), A.vals, x, A.nblocks, A.nrows, op);
+#define QP_RB_CASE(VV)                                                                                   \
+  case VV:                                                                                               \
+    hipLaunchKernelGGL((rbcsr_spmv_kernel<Op, VV>), dim3(grid), dim3(kThreads), 0, s, A.bptr,            \
+                       reinterpret_cast<const int4*>(A.cols), A.vals, x, A.nblocks, A.nrows, op);        \
+    break;
+    switch (g_rbcsr_variant & 7) {
+      QP_RB_CASE(0)
+      QP_RB_CASE(1)
+      QP_RB_CASE(2)
+      QP_RB_CASE(3)
+      QP_RB_CASE(4)
+      QP_RB_CASE(5)
+      QP_RB_CASE(6)
+      QP_RB_CASE(7)
+    }
+#undef QP_RB_CASE
   } else {
 #define QP_CSR_CASE(TT)                                                                                  \
   case TT:                                                                                               \

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -74,6 +75,7 @@ SIGNATURES = {
     "qp_status_name": (C.c_char_p, [C.c_int]),
     "qp_version": (C.c_int, []),
     "qp_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "qp_tuning_set": (C.c_int, [C.c_char_p, C.c_int]),
     "qp_ctx_create": (C.c_int, [C.c_int, _P, C.POINTER(_P)]),
     "qp_ctx_destroy": (C.c_int, [_P]),
     "qp_sync": (C.c_int, [_P]),
@@ -185,6 +187,10 @@ def _ptr(a, typ):
     return a.ctypes.data_as(typ)
 
 
+def tuning_set(key, value):
+    check(load().qp_tuning_set(key.encode(), int(value)))
+
+
 def device_count():
     n = C.c_int(0)
     check(load().qp_device_count(C.byref(n)))
@@ -290,6 +296,10 @@ class Context:
         self.lib = load()
         check(self.lib.qp_ctx_create(int(device), _P(stream) if stream else None, C.byref(self._h)))
         self.device = int(device)
+        self._children = weakref.WeakSet()   # handles that must be destroyed before the context
+
+    def _adopt(self, child):
+        self._children.add(child)
 
     def sync(self):
         check(self.lib.qp_sync(self._h))
@@ -312,6 +322,8 @@ class Context:
 
     def close(self):
         if self._h:
+            for child in list(self._children):   # native handles point at the native context
+                child.close()
             self.lib.qp_ctx_destroy(self._h)
             self._h = _P()
 
@@ -343,6 +355,7 @@ class Matrix:
                                         vals.ctypes.data_as(_P), dt, layout, index_base, FMT_AUTO,
                                         C.byref(self._h)))
         self.nrows, self.ncols, self.nnz = nrows, ncols, nnz
+        ctx._adopt(self)
 
     @classmethod
     def from_scipy(cls, ctx, A):
@@ -390,6 +403,7 @@ class Operator:
         nr, nc, nnz, f = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int()
         check(self.lib.qp_operator_info(self._h, C.byref(nr), C.byref(nc), C.byref(nnz), C.byref(f)))
         self.nrows, self.ncols, self.nnz, self.format = nr.value, nc.value, nnz.value, f.value
+        ctx._adopt(self)
 
     @property
     def shape(self):
@@ -444,6 +458,7 @@ class State:
             self.n = int(n)
             if data is not None:
                 self.upload(data)
+        ctx._adopt(self)
 
     @classmethod
     def wrap_tensor(cls, ctx, t):
@@ -518,6 +533,7 @@ class ChebyWrk:
         self.Delta, self.E_min, self.dt, self.limit = float(Delta), float(E_min), float(dt), float(limit)
         self._h = _P()
         check(self.lib.qp_cheby_create(ctx._h, int(n), C.byref(self._h)))
+        ctx._adopt(self)
 
     def close(self):
         if self._h:
@@ -552,6 +568,7 @@ class Krylov:
         self.ctx, self.lib, self.n, self.nvec = ctx, ctx.lib, int(n), int(nvec)
         self._h = _P()
         check(self.lib.qp_krylov_create(ctx._h, self.n, self.nvec, C.byref(self._h)))
+        ctx._adopt(self)
 
     def vec(self, i):
         out = np.empty(self.n, dtype=np.complex128)
@@ -594,6 +611,7 @@ class NewtonWrk:
         self.ctx, self.lib = ctx, ctx.lib
         self._h = _P()
         check(self.lib.qp_newton_create(ctx._h, int(n), int(m_max), C.byref(self._h)))
+        ctx._adopt(self)
         self.m_max = min(int(m_max), int(n) - 1)
         self.restarts = 0
         self.n_a = 0

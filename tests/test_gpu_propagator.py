@@ -1,0 +1,210 @@
+"""GPU tests of the host mirror of the reference's propagator interface
+(init_prop / prop_step! / reinit_prop! / set_state! / set_t! / propagate), restating the
+reference's own interface tests: test/test_propagate.jl:74-163, test/test_prop_interfaces.jl
+and the `check_propagator` contract (src/interfaces/propagator.jl:55-338)."""
+import os
+import sys
+import warnings
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import qp_oracle as qo  # noqa: E402
+import qprop_amd.lib as L  # noqa: E402
+import qprop_amd.propagator as P  # noqa: E402
+import qprop_amd.synth as synth  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = L.Context(0)
+    yield c
+    c.close()
+
+
+def _optomech():
+    """test/optomech.jl:1-44 (deterministic)."""
+    w_mech, g, eta = 10.0, 1.0, 2.0
+    Delta = -w_mech
+    N_cav, N_mech = 4, 10
+
+    def destroy(N):
+        return sp.diags([np.sqrt(np.arange(1, N + 1)).astype(complex)], [1], format="csr")
+
+    def ident(N):
+        return sp.identity(N + 1, dtype=complex, format="csr")
+    a = sp.kron(destroy(N_cav), ident(N_mech)).tocsr()
+    at = a.conj().T.tocsr()
+    b = sp.kron(ident(N_cav), destroy(N_mech)).tocsr()
+    bt = b.conj().T.tocsr()
+    H = (-Delta * at @ a + eta * (a + at)) + w_mech * bt @ b + (-g * (bt + b) @ at @ a)
+    psi0 = np.zeros((N_cav + 1) * (N_mech + 1), dtype=complex)
+    psi0[2] = 1.0
+    return H.tocsr(), psi0
+
+
+def test_tls_rabi(ctx):
+    """test/test_propagate.jl:74-150: Cheby forward/backward vs analytic, 1e-12; both
+    in-place and not-in-place (a new state object per step)."""
+    sx = np.array([[0, 1], [1, 0]], dtype=complex)
+    sz = np.array([[1, 0], [0, -1]], dtype=complex)
+    T = np.pi / 2
+    tlist = np.linspace(0, T, 101)
+    gen = P.hamiltonian(0.0 * sz, (0.5 * sx, lambda t: 1.0))
+    psi0 = np.array([1, 0], dtype=complex)
+    expected = np.array([1 / np.sqrt(2), -1j / np.sqrt(2)])
+    for inplace in (True, False):
+        out = P.propagate(psi0, gen, tlist, method="cheby", inplace=inplace, ctx=ctx)
+        assert np.linalg.norm(out - expected) < 1e-12
+        back = P.propagate(out, gen, tlist, method="cheby", backward=True, inplace=inplace, ctx=ctx)
+        assert np.linalg.norm(back - psi0) < 1e-12
+    out = P.propagate(psi0, gen, tlist, method="newton", ctx=ctx)
+    assert np.linalg.norm(out - expected) < 1e-12
+
+
+def test_optomech_newton_vs_cheby(ctx):
+    """test/test_propagate.jl:153-163: generator `(H,)`, tlist 0:0.2:50, Newton norm,
+    Newton vs Cheby < 1e-10 (specrange :auto -> :arnoldi for N=55), and vs the oracle."""
+    H, psi0 = _optomech()
+    tlist = np.arange(0, 50 + 1e-9, 0.2)
+    psi1 = P.propagate(psi0, (H,), tlist, method="newton", ctx=ctx)
+    assert (np.linalg.norm(psi1) - 1.0) < 1e-12
+    psi2 = P.propagate(psi0, (H,), tlist, method="cheby", ctx=ctx, rng=np.random.default_rng(1))
+    assert np.linalg.norm(psi1 - psi2) < 1e-10
+    ref = qo.propagate(psi0, H, tlist, "newton")
+    assert np.linalg.norm(psi1 - ref) < 1e-10
+
+
+def test_time_dependent_generator_matches_oracle(ctx):
+    """Drift + two controls, values rewritten every step (device `evaluate!`), storage."""
+    rng = np.random.default_rng(3)
+    N = 96
+    H0 = synth.dense_hermitian(N, rho=3.0, rng=rng)
+    H1 = synth.dense_hermitian(N, rho=1.0, rng=rng)
+    H2 = synth.dense_hermitian(N, rho=1.0, rng=rng)
+    tlist = np.linspace(0, 2.0, 41)
+    e1 = lambda t: 0.8 * np.sin(3 * t)        # noqa: E731
+    e2 = np.cos(np.linspace(0, 1, 40)) * 0.5    # defined on the intervals
+    psi0 = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    psi0 /= np.linalg.norm(psi0)
+    for method, kw in (("cheby", dict(E_min=-8.0, E_max=8.0)), ("newton", dict(m_max=8))):
+        out, store = P.propagate(psi0, P.hamiltonian(H0, (H1, e1), (H2, e2)), tlist, method=method,
+                                 storage=True, ctx=ctx, **kw)
+        ref, rstore = qo.propagate(psi0, qo.Generator([H0, H1, H2], [e1, e2]), tlist, method, storage=True, **kw)
+        assert np.linalg.norm(out - ref) < 1e-10
+        assert np.max(np.linalg.norm(store - rstore, axis=0)) < 1e-10
+
+
+def _check_propagator(p, psi0, atol=1e-14):
+    """The acceptance contract of src/interfaces/propagator.py:55-338, restated."""
+    tlist = p.tlist
+    assert p.t == (tlist[-1] if p.backward else tlist[0])
+    s0 = p.state
+    s1 = P.prop_step(p)
+    if p.inplace:
+        assert s1 is s0                       # identical object when in-place
+    else:
+        assert s1 is not s0                   # a new object when not
+    assert s1 is p.state
+    assert abs(p.t - (tlist[-2] if p.backward else tlist[1])) < atol
+    psi1 = s1.numpy()
+    assert abs(np.linalg.norm(psi1) - 1) < 1e-10
+    with pytest.raises(AttributeError):
+        p.generator
+    # run to the end: prop_step! returns nothing and leaves the propagator unchanged
+    while P.prop_step(p) is not None:
+        pass
+    assert p.t == (tlist[0] if p.backward else tlist[-1])
+    n_end, t_end = p.n, p.t
+    assert P.prop_step(p) is None and p.n == n_end and p.t == t_end
+    # set_t! / set_state!
+    P.set_t(p, tlist[3])
+    assert p.t == tlist[3]
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        P.set_t(p, 0.5 * (tlist[3] + tlist[4]) + 1e-3)
+        assert any("Snapping" in str(x.message) for x in w)
+    ret = P.set_state(p, psi0)
+    assert ret is p.state and np.array_equal(p.state.numpy(), psi0)
+    for par in p.parameters:
+        assert len(par) == len(tlist) - 1
+    # reinit_prop!: re-running the first step reproduces Psi_1 to 1e-14
+    P.reinit_prop(p, psi0)
+    assert p.t == (tlist[-1] if p.backward else tlist[0])
+    again = P.prop_step(p).numpy()
+    assert np.linalg.norm(again - psi1) < 1e-14
+
+
+@pytest.mark.parametrize("method,inplace,backward", [
+    ("cheby", True, False), ("cheby", False, False), ("cheby", True, True),
+    ("newton", True, False), ("newton", True, True)])
+def test_check_propagator_contract(ctx, method, inplace, backward):
+    """test/test_prop_interfaces.jl:12-103."""
+    rng = np.random.default_rng(5)
+    N = 40
+    H0 = synth.dense_hermitian(N, rho=2.0, rng=rng)
+    H1 = synth.dense_hermitian(N, rho=1.0, rng=rng)
+    tlist = np.linspace(0, 1.0, 11)
+    psi0 = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    psi0 /= np.linalg.norm(psi0)
+    p = P.init_prop(psi0, P.hamiltonian(H0, (H1, lambda t: np.sin(t))), tlist, method, inplace=inplace,
+                    backward=backward, ctx=ctx, rng=np.random.default_rng(0))
+    _check_propagator(p, psi0)
+
+
+def test_interface_errors(ctx):
+    """test/test_prop_interfaces.jl:79-89, 309-412."""
+    H = synth.dense_hermitian(40, rho=2.0, rng=np.random.default_rng(6))
+    psi0 = np.zeros(40, dtype=complex)
+    psi0[0] = 1
+    tlist = np.linspace(0, 1, 11)
+    with pytest.raises(RuntimeError, match="The Newton propagator is only implemented in-place"):
+        P.init_prop(psi0, H, tlist, "newton", inplace=False, ctx=ctx)
+    with pytest.raises(ValueError, match="Unknown propagation `method`"):
+        P.init_prop(psi0, H, tlist, "foo", ctx=ctx)
+    bad = np.array([0, 0.1, 0.2, 0.35, 0.5])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with pytest.raises(RuntimeError, match="uniform time grid"):
+            P.init_prop(psi0, H, bad, "cheby", ctx=ctx)
+    p = P.init_prop(psi0, H, bad, "newton", ctx=ctx)      # Newton takes non-uniform grids
+    while P.prop_step(p) is not None:
+        pass
+    assert abs(p.state.norm() - 1) < 1e-12
+
+
+def test_cheby_envelope_and_reinit(ctx):
+    """test/test_specrad.jl:147-223 + reinit coefficient refresh (cheby_propagator.jl:243-299)."""
+    rng = np.random.default_rng(7)
+    N = 64
+    H0 = synth.dense_hermitian(N, rho=3.0, rng=rng)
+    H1 = synth.dense_hermitian(N, rho=1.0, rng=rng)
+    psi0 = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    psi0 /= np.linalg.norm(psi0)
+    tlist = np.linspace(0, 1, 11)
+    p = P.init_prop(psi0, H0, tlist, "cheby", ctx=ctx, E_min=-10, E_max=10)
+    assert abs(p.wrk.E_min + 10.1) < 1e-12 and abs(p.wrk.Delta - 20.2) < 1e-12
+    p = P.init_prop(psi0, H0, tlist, "cheby", ctx=ctx, E_min=-10, E_max=10, specrange_buffer=0.1)
+    assert abs(p.wrk.E_min + 11.0) < 1e-12 and abs(p.wrk.Delta - 22.0) < 1e-12
+    # arnoldi envelope brackets the true spectrum of both extremal operators
+    amp = np.linspace(-1, 1, 10)
+    p = P.init_prop(psi0, P.hamiltonian(H0, (H1, amp)), tlist, "cheby", ctx=ctx, rng=np.random.default_rng(2))
+    for cval in (-1, 1):
+        ev = np.linalg.eigvalsh(H0 + cval * H1)
+        assert p.wrk.E_min <= ev[0] and ev[-1] <= p.wrk.E_min + p.wrk.Delta
+    n_before, D_before = p.wrk.n_coeffs, p.wrk.Delta
+    P.reinit_prop(p, psi0)                       # ranges unchanged: same workspace
+    assert p.wrk.n_coeffs == n_before
+    p.parameters[0] = p.parameters[0] * 5.0      # controls grew: coefficients are refreshed
+    P.reinit_prop(p, psi0)
+    assert p.wrk.Delta > D_before
+    while P.prop_step(p) is not None:
+        pass
+    ref = qo.propagate(psi0, qo.Generator([H0, H1], [amp * 5.0]), tlist, "cheby", E_min=p.wrk.E_min,
+                       E_max=p.wrk.E_min + p.wrk.Delta, specrange_buffer=0.0)
+    assert np.linalg.norm(p.state.numpy() - ref) < 1e-10

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""A/B timing of fused-Chebyshev-term kernel variants in ONE process, interleaved rounds
+(cdna_hip_programming.md rule 24).  Prints us per fused term and algorithmic GB/s.
+
+    python tools/kbench.py --log2n 20 --variants 0,1,2,3,4,5,6,7 --rounds 7
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import qprop_amd.lib as L  # noqa: E402
+import qprop_amd.synth as synth  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--log2n", type=int, default=20)
+    ap.add_argument("--variants", default="0,1,2,3,4,5,6,7")
+    ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--pattern", default="banded")
+    ap.add_argument("--formats", default="rbcsr")
+    args = ap.parse_args()
+    N = 1 << args.log2n
+    offs = synth.BANDED_OFFSETS if args.pattern == "banded" else synth.scattered_offsets(N)
+    rp, col, vals = synth.hermitian_offsets_csr(N, offsets=offs)
+    ctx = L.Context(0)
+    M = L.Matrix(ctx, N, N, rp, col, vals)
+    nnz = int(rp[-1])
+    del rp, col, vals
+    psi0 = synth.random_state(N)
+    wrk = L.ChebyWrk(ctx, N, 20.0, -10.0, 1.0)
+    nterms = wrk.n_coeffs - 1
+    alg = 20.0 * nnz + 4.0 * (N + 1) + 80.0 * N
+    cases = []
+    for f in args.formats.split(","):
+        op = L.Operator(ctx, [M], 0, {"rbcsr": L.FMT_RBCSR, "csr": L.FMT_CSR}[f])
+        vs = [int(v) for v in args.variants.split(",")] if f == "rbcsr" else [0]
+        for v in vs:
+            cases.append((f, v, op))
+    psi = L.State(ctx, data=psi0)
+    times = {(f, v): [] for f, v, _ in cases}
+    for f, v, op in cases:                      # warm-up
+        L.tuning_set("rbcsr_variant", v)
+        L.cheby(psi, op, 1.0, wrk)
+    ctx.sync()
+    for r in range(args.rounds):
+        for f, v, op in cases:
+            L.tuning_set("rbcsr_variant", v)
+            ctx.timer_begin()
+            for _ in range(args.steps):
+                L.cheby(psi, op, 1.0, wrk)
+            ms = ctx.timer_end()
+            times[(f, v)].append(1e3 * ms / (args.steps * nterms))
+    print(f"N=2^{args.log2n} pattern={args.pattern} terms/step={nterms} alg_bytes/term={alg:.0f}")
+    print(f"{'format':8s} {'var':>3s} {'median_us':>10s} {'min_us':>8s} {'GB/s(med)':>10s} {'frac8T':>7s}")
+    for (f, v), t in times.items():
+        med, mn = float(np.median(t)), float(np.min(t))
+        print(f"{f:8s} {v:3d} {med:10.2f} {mn:8.2f} {alg / med / 1e3:10.0f} {alg / med / 1e3 / 8000:7.3f}")
+    nrm = psi.norm()
+    print("norm drift after all steps:", abs(nrm - 1.0))
+
+
+if __name__ == "__main__":
+    main()

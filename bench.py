@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2n", type=int, default=20, help="rows per GPU = 2^log2n")
     ap.add_argument("--pattern", default="banded", choices=["banded", "scattered"])
-    ap.add_argument("--format", default="auto", choices=["auto", "rbcsr", "csr"])
+    ap.add_argument("--format", default="auto", choices=["auto", "hrb", "rbcsr", "csr"])
     ap.add_argument("--exchange", default="auto", choices=["auto", "halo", "allgather"])
     ap.add_argument("--cpu-steps", type=int, default=4, help="steps of the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
@@ -61,7 +61,7 @@ def main():
     r0, r1 = rank * rows, (rank + 1) * rows
     offsets = synth.BANDED_OFFSETS if args.pattern == "banded" else synth.scattered_offsets(N)
     Delta, E_min, dt = 20.0, -10.0, 1.0        # manual range [-10,10], specrange_buffer=0
-    fmt = {"auto": L.FMT_AUTO, "rbcsr": L.FMT_RBCSR, "csr": L.FMT_CSR}[args.format]
+    fmt = {"auto": L.FMT_AUTO, "hrb": L.FMT_HRB, "rbcsr": L.FMT_RBCSR, "csr": L.FMT_CSR}[args.format]
 
     stream = torch.cuda.current_stream().cuda_stream
     ctx = L.Context(local_rank, stream=stream)
@@ -158,12 +158,12 @@ def main():
                                "complex fp64 values, int32 indices",
                    "rows_per_gpu": rows, "N_total": N, "nnz_per_row": 16, "pattern": args.pattern,
                    "offsets": [int(o) for o in offsets], "n_coeffs": int(len(coeffs)), "matvecs_per_step": nterms,
-                   "spectral_range": [-10.0, 10.0], "dt": dt, "device_format": {1: "csr", 2: "rbcsr"}[fmt_used],
+                   "spectral_range": [-10.0, 10.0], "dt": dt, "device_format": {1: "csr", 2: "rbcsr", 3: "hrb (Hermitian-packed row blocks)"}[fmt_used],
                    "parallelism": "single GPU" if world == 1 else f"row-partitioned x{world}, exchange={exchange_used}",
                    "global_steps_per_s": steps_per_s},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "rbcsr_spmv_kernel<ChebyOp>" if fmt_used == 2 else "csr_spmv_kernel<16,ChebyOp>",
+                     "kernel": {1: "csr_spmv_kernel<16,ChebyOp>", 2: "rbcsr_spmv_kernel<ChebyOp,7>", 3: "hrb_spmv_kernel<ChebyOp,7>"}[fmt_used],
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "avg_launch_us": avg_launch_s * 1e6,
                      "launches_timed": n_launch, "hip_event_ms": ev_ms,

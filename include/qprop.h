@@ -60,10 +60,15 @@ enum {
 
 enum { QP_LAYOUT_CSR = 0, QP_LAYOUT_CSC = 1 };
 enum { QP_VAL_C128 = 0, QP_VAL_F64 = 1 };
-/* device storage format: AUTO picks RBCSR (row-block CSR: 64-row blocks stored
- * lane-interleaved so that one wavefront streams a block with 1-KiB coalesced loads)
- * unless padding would exceed 25 %, else plain CSR with a sub-wave-per-row kernel. */
-enum { QP_FMT_AUTO = 0, QP_FMT_CSR = 1, QP_FMT_RBCSR = 2 };
+/* device storage format.  RBCSR = row-block CSR: 64-row blocks stored lane-interleaved so
+ * that one wavefront streams a block with 1-KiB coalesced loads.  HRB = Hermitian-packed
+ * row blocks: only entries with col >= row carry values; an entry with col < row stores
+ * the position of its transpose and uses the complex conjugate (cheby! requires a
+ * Hermitian H, src/cheby.jl:135), which removes ~40 % of the matrix bytes.  CSR = plain
+ * CSR with a sub-wave per row.  AUTO: HRB when every term is exactly (bitwise) Hermitian,
+ * else RBCSR; CSR when row-block padding would exceed 25 %.  An HRB operator that is given
+ * complex coefficients re-lays itself out as RBCSR. */
+enum { QP_FMT_AUTO = 0, QP_FMT_CSR = 1, QP_FMT_RBCSR = 2, QP_FMT_HRB = 3 };
 enum { QP_FUNC_EXPMI = 0,    /* z -> exp(-i z)   default of newton!, src/newton.jl:247 */
        QP_FUNC_EXP = 1,      /* z -> exp(z)      test/test_newton.jl:171 */
        QP_FUNC_CALLBACK = 2 };

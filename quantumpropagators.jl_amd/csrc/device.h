@@ -32,6 +32,13 @@ struct DevMatrix {
   // CSR
   int64_t* rowptr = nullptr;  // nrows+1
   int lanes_per_row = 16;     // CSR kernel: sub-wave width
+  // HRB (Hermitian-packed row blocks): bptr/cols/vals hold the entries with col >= row;
+  // the entries with col < row are (lcols, lpos): column and the position in `vals` of
+  // the transposed entry, whose complex conjugate is the value.  Same block layout.
+  int64_t* lptr = nullptr;    // nblocks+1
+  int32_t* lcols = nullptr;   // lstored, quad packed
+  int32_t* lpos = nullptr;    // lstored, quad packed; -1 = padding
+  int64_t lstored = 0;
 };
 
 // epilogue of the fused Chebyshev term (see qp_cheby_term in qprop.h)

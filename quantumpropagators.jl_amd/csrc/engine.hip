@@ -61,9 +61,19 @@ struct qp_matrix {  // canonical host CSR (the result of the boundary's index wo
   std::vector<cplx> vals;
 };
 
+struct HostLayoutData {
+  int format = QP_FMT_RBCSR;
+  std::vector<int64_t> bptr;   // RBCSR: all entries; HRB: upper section (c >= r)
+  std::vector<int64_t> lptr;   // HRB: lower section (c < r)
+  std::vector<int32_t> nlow;   // HRB: number of lower entries per row
+  int64_t stored = 0, lstored = 0;
+};
+
 struct qp_operator {
   qp_ctx* ctx = nullptr;
   DevMatrix A;
+  HostLayoutData layout;
+  bool hermitian_planes = false;
   int nops = 0, ncoeffs = 0;
   std::vector<int64_t> u_rowptr;  // union pattern (host), for get_csr and plane scatter
   std::vector<int32_t> u_col;
@@ -398,26 +408,246 @@ int qp_matrix_get_csr(const qp_matrix* m, int64_t* rowptr, int32_t* col, qp_c128
 // ---------------------------------------------------------------------------
 // Operator: union pattern + value planes in HBM
 // ---------------------------------------------------------------------------
-static int operator_free(qp_operator* op) {
-  if (!op) return QP_OK;
-  (void)hipSetDevice(op->ctx->device);
-  (void)hipStreamSynchronize(op->ctx->stream);
+static int operator_free_device(qp_operator* op) {
   for (auto p : op->planes) (void)hipFree(p);
+  op->planes.clear();
   if (op->planes_dev) (void)hipFree(op->planes_dev);
   if (op->combined) (void)hipFree(op->combined);
   if (op->A.bptr) (void)hipFree(op->A.bptr);
   if (op->A.rowptr) (void)hipFree(op->A.rowptr);
   if (op->A.cols) (void)hipFree(op->A.cols);
+  if (op->A.lptr) (void)hipFree(op->A.lptr);
+  if (op->A.lcols) (void)hipFree(op->A.lcols);
+  if (op->A.lpos) (void)hipFree(op->A.lpos);
+  op->planes_dev = nullptr;
+  op->combined = nullptr;
+  op->A.bptr = op->A.rowptr = op->A.lptr = nullptr;
+  op->A.cols = op->A.lcols = op->A.lpos = nullptr;
+  op->A.vals = nullptr;
+  return QP_OK;
+}
+
+static int operator_free(qp_operator* op) {
+  if (!op) return QP_OK;
+  (void)hipSetDevice(op->ctx->device);
+  (void)hipStreamSynchronize(op->ctx->stream);
+  operator_free_device(op);
   delete op;
   return QP_OK;
 }
 
-// position of union CSR entry (row r, k-th in row) inside the device value array
+// ---- host-side layout of the two row-block formats --------------------------------
+// Within a 64-row block, entry k of row r sits at  base + 64 k + (r % 64); column
+// indices (and the lower section's positions) are packed four k per lane.
 static inline int64_t rb_val_pos(const std::vector<int64_t>& bptr, int64_t r, int64_t k) {
   return bptr[r / kRB] + k * kRB + (r % kRB);
 }
-static inline int64_t rb_col_pos(const std::vector<int64_t>& bptr, int64_t r, int64_t k) {
+static inline int64_t rb_quad_pos(const std::vector<int64_t>& bptr, int64_t r, int64_t k) {
   return bptr[r / kRB] + (k >> 2) * (4 * kRB) + (r % kRB) * 4 + (k & 3);
+}
+
+using HostLayout = HostLayoutData;
+
+// is this canonical CSR exactly Hermitian (bitwise conj-symmetric values, symmetric
+// pattern, real diagonal, strictly increasing columns)?
+static bool csr_is_hermitian(int64_t n, const std::vector<int64_t>& rp, const std::vector<int32_t>& col,
+                             const std::vector<cplx>& vals) {
+  int64_t nlower = 0, nupper = 0;
+  for (int64_t r = 0; r < n; ++r) {
+    for (int64_t p = rp[r]; p < rp[r + 1]; ++p) {
+      const int64_t c = col[p];
+      if (p > rp[r] && col[p - 1] >= c) return false;
+      if (c == r) {
+        if (vals[p].imag() != 0.0) return false;
+      } else if (c > r) {
+        ++nupper;
+      } else {
+        ++nlower;
+        const int32_t* b = col.data() + rp[c];
+        const int32_t* e = col.data() + rp[c + 1];
+        const int32_t* it = std::lower_bound(b, e, (int32_t)r);
+        if (it == e || *it != r) return false;
+        const cplx t = vals[it - col.data()];
+        if (!(t.real() == vals[p].real() && t.imag() == -vals[p].imag())) return false;
+      }
+    }
+  }
+  return nlower == nupper;
+}
+
+// Build every device array of `op` for `format` from the union pattern (op->u_rowptr /
+// u_col) and the per-term values given in union-CSR order.
+static int operator_build_device(qp_operator* op, int format, const std::vector<std::vector<cplx>>& planes_csr) {
+  qp_ctx* ctx = op->ctx;
+  const auto& ur = op->u_rowptr;
+  const auto& uc = op->u_col;
+  DevMatrix& A = op->A;
+  const int64_t nrows = A.nrows;
+  const int64_t nnz = ur[nrows];
+  const int nops = (int)planes_csr.size();
+  A.nblocks = (nrows + kRB - 1) / kRB;
+  A.format = format;
+  HostLayout& Lh = op->layout;
+  Lh = HostLayout();
+  Lh.format = format;
+
+  if (format == QP_FMT_CSR) {
+    A.stored = nnz;
+    QP_CHECK(dev_alloc(&A.rowptr, ur.size()));
+    QP_HIP(hipMemcpy(A.rowptr, ur.data(), ur.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    QP_CHECK(dev_alloc(&A.cols, (size_t)nnz));
+    QP_HIP(hipMemcpy(A.cols, uc.data(), (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice));
+    double mean = nrows > 0 ? (double)nnz / (double)nrows : 1.0;
+    int T = 2;
+    while (T < 64 && T < mean) T *= 2;
+    A.lanes_per_row = T;
+  } else {
+    const bool hrb = (format == QP_FMT_HRB);
+    Lh.bptr.assign(A.nblocks + 1, 0);
+    if (hrb) {
+      Lh.lptr.assign(A.nblocks + 1, 0);
+      Lh.nlow.assign(nrows, 0);
+      for (int64_t r = 0; r < nrows; ++r) {
+        const int32_t* b = uc.data() + ur[r];
+        const int32_t* e = uc.data() + ur[r + 1];
+        Lh.nlow[r] = (int32_t)(std::lower_bound(b, e, (int32_t)r) - b);
+      }
+    }
+    for (int64_t b = 0; b < A.nblocks; ++b) {
+      int64_t wu = 0, wl = 0;
+      for (int64_t r = b * kRB; r < std::min(nrows, (b + 1) * kRB); ++r) {
+        const int64_t len = ur[r + 1] - ur[r];
+        const int64_t nl = hrb ? Lh.nlow[r] : 0;
+        wu = std::max(wu, len - nl);
+        wl = std::max(wl, nl);
+      }
+      wu = (wu + 3) & ~(int64_t)3;
+      wl = (wl + 3) & ~(int64_t)3;
+      Lh.bptr[b + 1] = Lh.bptr[b] + wu * kRB;
+      if (hrb) Lh.lptr[b + 1] = Lh.lptr[b] + wl * kRB;
+    }
+    Lh.stored = Lh.bptr[A.nblocks] + kRB;   // + one block of slack: padded lower entries read vals[0..63]
+    Lh.lstored = hrb ? Lh.lptr[A.nblocks] : 0;
+    A.stored = Lh.stored;
+    A.lstored = Lh.lstored;
+    // upper (or full) column indices
+    std::vector<int32_t> hcols((size_t)A.stored, 0);
+    for (int64_t r = 0; r < nrows; ++r) {
+      const int64_t nl = hrb ? Lh.nlow[r] : 0;
+      const int64_t len = ur[r + 1] - ur[r] - nl;
+      const int64_t w = (Lh.bptr[r / kRB + 1] - Lh.bptr[r / kRB]) / kRB;
+      const int32_t padcol = (ur[r + 1] > ur[r]) ? uc[ur[r]] : 0;
+      for (int64_t k = 0; k < w; ++k) hcols[rb_quad_pos(Lh.bptr, r, k)] = (k < len) ? uc[ur[r] + nl + k] : padcol;
+    }
+    QP_CHECK(dev_alloc(&A.bptr, Lh.bptr.size()));
+    QP_HIP(hipMemcpy(A.bptr, Lh.bptr.data(), Lh.bptr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    QP_CHECK(dev_alloc(&A.cols, (size_t)A.stored));
+    QP_HIP(hipMemcpy(A.cols, hcols.data(), (size_t)A.stored * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (hrb) {
+      // lower section: (column, position of the conj-transposed value in the upper section)
+      std::vector<int32_t> lcols((size_t)std::max<int64_t>(A.lstored, 1), 0), lpos((size_t)std::max<int64_t>(A.lstored, 1), -1);
+      if (Lh.stored >= (int64_t)INT32_MAX) return qp::fail(QP_E_BAD_ARG, "Hermitian-packed format needs < 2^31 stored values per GPU");
+      for (int64_t r = 0; r < nrows; ++r) {
+        const int64_t nl = Lh.nlow[r];
+        const int64_t w = (Lh.lptr[r / kRB + 1] - Lh.lptr[r / kRB]) / kRB;
+        for (int64_t k = 0; k < w; ++k) {
+          const int64_t q = rb_quad_pos(Lh.lptr, r, k);
+          if (k < nl) {
+            const int64_t c = uc[ur[r] + k];
+            const int32_t* b = uc.data() + ur[c];
+            const int32_t* e = uc.data() + ur[c + 1];
+            const int64_t kk = (std::lower_bound(b, e, (int32_t)r) - b) - Lh.nlow[c];  // index of (c,r) among row c's upper entries
+            lcols[q] = (int32_t)c;
+            lpos[q] = (int32_t)rb_val_pos(Lh.bptr, c, kk);
+          } else {
+            lcols[q] = (int32_t)r;  // padded: any valid column, value masked by pos < 0
+            lpos[q] = -1;
+          }
+        }
+      }
+      QP_CHECK(dev_alloc(&A.lptr, Lh.lptr.size()));
+      QP_HIP(hipMemcpy(A.lptr, Lh.lptr.data(), Lh.lptr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+      QP_CHECK(dev_alloc(&A.lcols, lcols.size()));
+      QP_HIP(hipMemcpy(A.lcols, lcols.data(), lcols.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+      QP_CHECK(dev_alloc(&A.lpos, lpos.size()));
+      QP_HIP(hipMemcpy(A.lpos, lpos.data(), lpos.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+  }
+
+  // ---- value planes ----
+  std::vector<cplx> hplane((size_t)std::max<int64_t>(A.stored, 1));
+  for (int l = 0; l < nops; ++l) {
+    std::fill(hplane.begin(), hplane.end(), cplx(0.0));
+    const auto& pv = planes_csr[l];
+    for (int64_t r = 0; r < nrows; ++r) {
+      const int64_t nl = (format == QP_FMT_HRB) ? op->layout.nlow[r] : 0;
+      for (int64_t k = nl; k < ur[r + 1] - ur[r]; ++k) {
+        const int64_t pos = (format == QP_FMT_CSR) ? ur[r] + k : rb_val_pos(op->layout.bptr, r, k - nl);
+        hplane[pos] = pv[ur[r] + k];
+      }
+    }
+    double2* dp = nullptr;
+    QP_CHECK(dev_alloc(&dp, (size_t)A.stored));
+    op->planes.push_back(dp);
+    QP_HIP(hipMemcpy(dp, hplane.data(), (size_t)A.stored * sizeof(double2), hipMemcpyHostToDevice));
+  }
+  QP_CHECK(dev_alloc(&op->planes_dev, (size_t)nops));
+  QP_HIP(hipMemcpy(op->planes_dev, op->planes.data(), nops * sizeof(double2*), hipMemcpyHostToDevice));
+  A.vals = op->planes[0];
+  (void)ctx;
+  return QP_OK;
+}
+
+// current per-term values (device planes) back in union-CSR order
+static int operator_download_planes(qp_operator* op, std::vector<std::vector<cplx>>& planes_csr) {
+  const DevMatrix& A = op->A;
+  const auto& ur = op->u_rowptr;
+  const auto& uc = op->u_col;
+  const int64_t nnz = ur[A.nrows];
+  QP_HIP(hipStreamSynchronize(op->ctx->stream));
+  std::vector<cplx> hv((size_t)std::max<int64_t>(A.stored, 1));
+  planes_csr.assign(op->planes.size(), std::vector<cplx>());
+  for (size_t l = 0; l < op->planes.size(); ++l) {
+    QP_HIP(hipMemcpy(hv.data(), op->planes[l], (size_t)A.stored * sizeof(double2), hipMemcpyDeviceToHost));
+    auto& out = planes_csr[l];
+    out.assign((size_t)nnz, cplx(0));
+    for (int64_t r = 0; r < A.nrows; ++r) {
+      const int64_t nl = (A.format == QP_FMT_HRB) ? op->layout.nlow[r] : 0;
+      for (int64_t k = 0; k < ur[r + 1] - ur[r]; ++k) {
+        if (A.format == QP_FMT_CSR) {
+          out[ur[r] + k] = hv[ur[r] + k];
+        } else if (k >= nl) {
+          out[ur[r] + k] = hv[rb_val_pos(op->layout.bptr, r, k - nl)];
+        } else {  // lower entry of a Hermitian-packed operator: conj of its transpose
+          const int64_t c = uc[ur[r] + k];
+          const int32_t* b = uc.data() + ur[c];
+          const int32_t* e = uc.data() + ur[c + 1];
+          const int64_t kk = (std::lower_bound(b, e, (int32_t)r) - b) - op->layout.nlow[c];
+          out[ur[r] + k] = std::conj(hv[rb_val_pos(op->layout.bptr, c, kk)]);
+        }
+      }
+    }
+  }
+  return QP_OK;
+}
+
+static int choose_format(qp_operator* op, int requested, bool hermitian) {
+  const auto& ur = op->u_rowptr;
+  const int64_t nrows = op->A.nrows, nnz = ur[nrows];
+  const int64_t nblocks = (nrows + kRB - 1) / kRB;
+  int64_t rb_stored = 0;
+  for (int64_t b = 0; b < nblocks; ++b) {
+    int64_t w = 0;
+    for (int64_t r = b * kRB; r < std::min(nrows, (b + 1) * kRB); ++r) w = std::max(w, ur[r + 1] - ur[r]);
+    rb_stored += ((w + 3) & ~(int64_t)3) * kRB;
+  }
+  const bool rb_ok = (double)rb_stored <= 1.25 * (double)nnz + 1024.0;
+  if (requested == QP_FMT_AUTO) {
+    if (!rb_ok) return QP_FMT_CSR;
+    return hermitian ? QP_FMT_HRB : QP_FMT_RBCSR;
+  }
+  if (requested == QP_FMT_HRB && !hermitian) return -1;
+  return requested;
 }
 
 int qp_operator_create(qp_ctx* ctx, qp_matrix* const* ops, int nops, int ncoeffs, int format,
@@ -430,6 +660,7 @@ int qp_operator_create(qp_ctx* ctx, qp_matrix* const* ops, int nops, int ncoeffs
     if (ops[l]->nrows != ops[0]->nrows || ops[l]->ncols != ops[0]->ncols)
       return qp::fail(QP_E_BAD_ARG, "ops[%d] shape differs from ops[0]", l);
   }
+  if (format < QP_FMT_AUTO || format > QP_FMT_HRB) return qp::fail(QP_E_BAD_ARG, "bad device format %d", format);
   QP_CHECK(use(ctx));
   std::unique_ptr<qp_operator, int (*)(qp_operator*)> op(new qp_operator(), operator_free);
   op->ctx = ctx;
@@ -437,6 +668,8 @@ int qp_operator_create(qp_ctx* ctx, qp_matrix* const* ops, int nops, int ncoeffs
   op->ncoeffs = ncoeffs;
   op->coeffs.assign(ncoeffs, cplx(1.0));
   const int64_t nrows = ops[0]->nrows, ncols = ops[0]->ncols;
+  op->A.nrows = nrows;
+  op->A.ncols = ncols;
 
   // ---- union sparsity pattern (sorted merge per row) ----
   auto& ur = op->u_rowptr;
@@ -457,75 +690,30 @@ int qp_operator_create(qp_ctx* ctx, qp_matrix* const* ops, int nops, int ncoeffs
       ur[r + 1] = (int64_t)uc.size();
     }
   }
-  const int64_t nnz = ur[nrows];
+  op->A.nnz = ur[nrows];
 
-  // ---- choose the device format ----
-  DevMatrix& A = op->A;
-  A.nrows = nrows;
-  A.ncols = ncols;
-  A.nnz = nnz;
-  A.nblocks = (nrows + kRB - 1) / kRB;
-  std::vector<int64_t> bptr(A.nblocks + 1, 0);
-  for (int64_t b = 0; b < A.nblocks; ++b) {
-    int64_t w = 0;
-    for (int64_t r = b * kRB; r < std::min(nrows, (b + 1) * kRB); ++r) w = std::max(w, ur[r + 1] - ur[r]);
-    w = (w + 3) & ~(int64_t)3;
-    bptr[b + 1] = bptr[b] + w * kRB;
-  }
-  const int64_t rb_stored = bptr[A.nblocks];
-  if (format == QP_FMT_AUTO) format = ((double)rb_stored <= 1.25 * (double)nnz + 1024.0) ? QP_FMT_RBCSR : QP_FMT_CSR;
-  if (format != QP_FMT_RBCSR && format != QP_FMT_CSR) return qp::fail(QP_E_BAD_ARG, "bad device format %d", format);
-  A.format = format;
-  A.stored = (format == QP_FMT_RBCSR) ? rb_stored : nnz;
-
-  // ---- column indices ----
-  std::vector<int32_t> hcols((size_t)std::max<int64_t>(A.stored, 1), 0);
-  if (format == QP_FMT_RBCSR) {
-    for (int64_t r = 0; r < nrows; ++r) {
-      const int64_t len = ur[r + 1] - ur[r];
-      const int64_t w = (bptr[r / kRB + 1] - bptr[r / kRB]) / kRB;
-      const int32_t padcol = len > 0 ? uc[ur[r]] : 0;
-      for (int64_t k = 0; k < w; ++k) hcols[rb_col_pos(bptr, r, k)] = (k < len) ? uc[ur[r] + k] : padcol;
-    }
-    QP_CHECK(dev_alloc(&A.bptr, bptr.size()));
-    QP_HIP(hipMemcpy(A.bptr, bptr.data(), bptr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
-  } else {
-    std::copy(uc.begin(), uc.end(), hcols.begin());
-    QP_CHECK(dev_alloc(&A.rowptr, ur.size()));
-    QP_HIP(hipMemcpy(A.rowptr, ur.data(), ur.size() * sizeof(int64_t), hipMemcpyHostToDevice));
-    double mean = nrows > 0 ? (double)nnz / (double)nrows : 1.0;
-    int T = 2;
-    while (T < 64 && T < mean) T *= 2;
-    A.lanes_per_row = T;
-  }
-  QP_CHECK(dev_alloc(&A.cols, (size_t)A.stored));
-  QP_HIP(hipMemcpy(A.cols, hcols.data(), (size_t)A.stored * sizeof(int32_t), hipMemcpyHostToDevice));
-  hcols.clear();
-  hcols.shrink_to_fit();
-
-  // ---- value planes ----
-  std::vector<cplx> hplane((size_t)std::max<int64_t>(A.stored, 1));
+  // ---- per-term values in union order (duplicates within a row are summed, as Julia's sparse() does) ----
+  std::vector<std::vector<cplx>> planes_csr(nops);
   for (int l = 0; l < nops; ++l) {
-    std::fill(hplane.begin(), hplane.end(), cplx(0.0));
     const qp_matrix* M = ops[l];
+    auto& pv = planes_csr[l];
+    pv.assign((size_t)op->A.nnz, cplx(0));
     for (int64_t r = 0; r < nrows; ++r) {
-      int64_t k = 0;  // position in the union row
+      int64_t k = 0;
       for (int64_t p = M->rowptr[r]; p < M->rowptr[r + 1]; ++p) {
         while (uc[ur[r] + k] != M->col[p]) ++k;
-        const int64_t pos = (format == QP_FMT_RBCSR) ? rb_val_pos(bptr, r, k) : ur[r] + k;
-        hplane[pos] += M->vals[p];  // duplicates within a row are summed, as in Julia sparse()
+        pv[ur[r] + k] += M->vals[p];
       }
     }
-    double2* dp = nullptr;
-    QP_CHECK(dev_alloc(&dp, (size_t)A.stored));
-    op->planes.push_back(dp);
-    QP_HIP(hipMemcpy(dp, hplane.data(), (size_t)A.stored * sizeof(double2), hipMemcpyHostToDevice));
   }
-  QP_CHECK(dev_alloc(&op->planes_dev, (size_t)nops));
-  QP_HIP(hipMemcpy(op->planes_dev, op->planes.data(), nops * sizeof(double2*), hipMemcpyHostToDevice));
-  A.vals = op->planes[0];
+  bool hermitian = (nrows == ncols) && (format == QP_FMT_AUTO || format == QP_FMT_HRB);
+  for (int l = 0; hermitian && l < nops; ++l) hermitian = csr_is_hermitian(nrows, ur, uc, planes_csr[l]);
+  op->hermitian_planes = hermitian;
+  const int fmt = choose_format(op.get(), format, hermitian);
+  if (fmt < 0) return qp::fail(QP_E_BAD_ARG, "QP_FMT_HRB requested but the operator terms are not exactly Hermitian");
+  QP_CHECK(operator_build_device(op.get(), fmt, planes_csr));
+  planes_csr.clear();
   qp_operator* raw = op.release();
-  // coefficients start at 1 (Operator with all-ones coeffs); make vals consistent
   std::vector<qp_c128> ones(ncoeffs, qp_c128{1.0, 0.0});
   int rc = qp_operator_set_coeffs(raw, ones.data(), ncoeffs);
   if (rc != QP_OK) {
@@ -541,12 +729,22 @@ static int operator_refresh(qp_operator* op) {
   qp_ctx* ctx = op->ctx;
   const int drift = op->nops - op->ncoeffs;  // src/generators.jl:635
   std::vector<double2> eff(op->nops);
-  bool all_one = true;
+  bool all_one = true, all_real = true;
   for (int l = 0; l < op->nops; ++l) {
     cplx c = op->scale;
     if (l >= drift) c *= op->coeffs[l - drift];
     eff[l] = d2(c);
     if (!(c == cplx(1.0))) all_one = false;
+    if (c.imag() != 0.0) all_real = false;
+  }
+  if (op->A.format == QP_FMT_HRB && !all_real) {
+    // a complex combination of Hermitian terms is not Hermitian: leave the packed format
+    // (slow path, once): re-lay the planes out as full row-block CSR
+    std::vector<std::vector<cplx>> planes_csr;
+    QP_CHECK(operator_download_planes(op, planes_csr));
+    operator_free_device(op);
+    const int fmt = choose_format(op, QP_FMT_AUTO, false);
+    QP_CHECK(operator_build_device(op, fmt, planes_csr));
   }
   if (op->nops == 1 && all_one) {
     op->A.vals = op->planes[0];
@@ -593,15 +791,16 @@ int qp_operator_info(const qp_operator* op, int64_t* nrows, int64_t* ncols, int6
   return QP_OK;
 }
 
-// download the *device* copy (current combined values) back as canonical CSR
+// download the *device* copy (current combined values and indices) back as canonical CSR
 int qp_operator_get_csr(qp_operator* op, int64_t* rowptr, int32_t* col, qp_c128* vals) {
   QP_TRY
   if (!op || !rowptr || !col || !vals) return qp::fail(QP_E_BAD_ARG, "qp_operator_get_csr: NULL argument");
   QP_CHECK(use(op->ctx));
   const DevMatrix& A = op->A;
+  const auto& ur = op->u_rowptr;
+  QP_HIP(hipStreamSynchronize(op->ctx->stream));
   std::vector<cplx> hv((size_t)std::max<int64_t>(A.stored, 1));
   std::vector<int32_t> hc((size_t)std::max<int64_t>(A.stored, 1));
-  QP_HIP(hipStreamSynchronize(op->ctx->stream));
   QP_HIP(hipMemcpy(hv.data(), A.vals, (size_t)A.stored * sizeof(double2), hipMemcpyDeviceToHost));
   QP_HIP(hipMemcpy(hc.data(), A.cols, (size_t)A.stored * sizeof(int32_t), hipMemcpyDeviceToHost));
   if (A.format == QP_FMT_CSR) {
@@ -610,17 +809,36 @@ int qp_operator_get_csr(qp_operator* op, int64_t* rowptr, int32_t* col, qp_c128*
     std::memcpy(rowptr, rp.data(), rp.size() * sizeof(int64_t));
     std::memcpy(col, hc.data(), (size_t)A.nnz * sizeof(int32_t));
     std::memcpy(vals, hv.data(), (size_t)A.nnz * sizeof(qp_c128));
-  } else {
-    std::vector<int64_t> bptr(A.nblocks + 1);
-    QP_HIP(hipMemcpy(bptr.data(), A.bptr, bptr.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
-    const auto& ur = op->u_rowptr;
-    for (int64_t r = 0; r <= A.nrows; ++r) rowptr[r] = ur[r];
-    for (int64_t r = 0; r < A.nrows; ++r)
-      for (int64_t k = 0; k < ur[r + 1] - ur[r]; ++k) {
-        col[ur[r] + k] = hc[rb_col_pos(bptr, r, k)];
-        cplx v = hv[rb_val_pos(bptr, r, k)];
-        vals[ur[r] + k] = qp_c128{v.real(), v.imag()};
+    return QP_OK;
+  }
+  std::vector<int64_t> bptr(A.nblocks + 1), lptr;
+  QP_HIP(hipMemcpy(bptr.data(), A.bptr, bptr.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+  std::vector<int32_t> lc, lp;
+  if (A.format == QP_FMT_HRB) {
+    lptr.resize(A.nblocks + 1);
+    lc.resize((size_t)std::max<int64_t>(A.lstored, 1));
+    lp.resize(lc.size());
+    QP_HIP(hipMemcpy(lptr.data(), A.lptr, lptr.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+    QP_HIP(hipMemcpy(lc.data(), A.lcols, lc.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    QP_HIP(hipMemcpy(lp.data(), A.lpos, lp.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+  }
+  for (int64_t r = 0; r <= A.nrows; ++r) rowptr[r] = ur[r];
+  for (int64_t r = 0; r < A.nrows; ++r) {
+    const int64_t nl = (A.format == QP_FMT_HRB) ? op->layout.nlow[r] : 0;
+    for (int64_t k = 0; k < ur[r + 1] - ur[r]; ++k) {
+      cplx v;
+      int32_t c;
+      if (k >= nl) {
+        c = hc[rb_quad_pos(bptr, r, k - nl)];
+        v = hv[rb_val_pos(bptr, r, k - nl)];
+      } else {
+        const int64_t q = rb_quad_pos(lptr, r, k);
+        c = lc[q];
+        v = std::conj(hv[lp[q]]);
       }
+      col[ur[r] + k] = c;
+      vals[ur[r] + k] = qp_c128{v.real(), v.imag()};
+    }
   }
   return QP_OK;
   QP_CATCH

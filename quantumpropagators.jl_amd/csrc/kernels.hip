@@ -227,6 +227,96 @@ __global__ __launch_bounds__(kThreads) void rbcsr_spmv_kernel(const int64_t* __r
 }
 
 // ---------------------------------------------------------------------------
+// HRB SpMV (Hermitian-packed row blocks).  Upper section exactly as RBCSR.  For a lower
+// entry (r, c), c < r, the lane loads the value stored for (c, r) -- a line that the wave
+// owning row c streamed shortly before on the same XCD, i.e. an L2 hit -- and uses its
+// complex conjugate.  HBM sees 20 B per upper entry but only 8 B (column + position) per
+// lower entry.  The upper value loads keep the default cache policy (they are re-read
+// through L2); the lower index streams are read-once.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void cfma_conj(double2& s, const double2 a, const double2 b) {  // s += conj(a) * b
+  s.x = fma(a.x, b.x, s.x);
+  s.x = fma(a.y, b.y, s.x);
+  s.y = fma(a.x, b.y, s.y);
+  s.y = fma(-a.y, b.x, s.y);
+}
+__device__ __forceinline__ double2 ld_tr(const double2* __restrict__ vals, int pos) {
+  const double2 a = vals[pos < 0 ? 0 : pos];
+  return pos < 0 ? make_double2(0.0, 0.0) : a;
+}
+
+template <class Op, int VAR>
+__global__ __launch_bounds__(kThreads) void hrb_spmv_kernel(const int64_t* __restrict__ uptr,
+                                                            const int4* __restrict__ ucols4,
+                                                            const double2* __restrict__ uvals,
+                                                            const int64_t* __restrict__ lptr,
+                                                            const int4* __restrict__ lcols4,
+                                                            const int4* __restrict__ lpos4,
+                                                            const double2* __restrict__ x, int64_t nblocks,
+                                                            int64_t nrows, Op op) {
+  constexpr bool NT = (VAR & 1) != 0;
+  constexpr bool PRE = (VAR & 2) != 0;
+  constexpr int UNR = (VAR & 4) ? 2 : 1;
+  __shared__ double2 lds[kThreads / 64];
+  const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int64_t b = (int64_t)wg * (kThreads / 64) + wave;
+  double2 chk = make_double2(0.0, 0.0);
+  double nrm = 0.0;
+  if (b < nblocks) {
+    const int64_t ubase = uptr[b], lbase = lptr[b];
+    const int nuq = (int)((uptr[b + 1] - ubase) >> 8);
+    const int nlq = (int)((lptr[b + 1] - lbase) >> 8);
+    const double2* __restrict__ v = uvals + ubase + lane;
+    const int4* __restrict__ c4 = ucols4 + (ubase >> 2) + lane;
+    const int4* __restrict__ lc4 = lcols4 + (lbase >> 2) + lane;
+    const int4* __restrict__ lp4 = lpos4 + (lbase >> 2) + lane;
+    const int64_t row = b * kRB + lane;
+    const int64_t rowc = row < nrows ? row : nrows - 1;
+    typename Op::Pre pre;
+    if (PRE) pre = op.pre(rowc);
+    double2 s0 = make_double2(0.0, 0.0), s1 = make_double2(0.0, 0.0);
+#pragma unroll UNR
+    for (int q = 0; q < nlq; ++q) {   // lower section first: its values are already in L2
+      const int4 c = ld_col<NT>(lc4 + (size_t)q * 64);
+      const int4 p = ld_col<NT>(lp4 + (size_t)q * 64);
+      const double2 a0 = ld_tr(uvals, p.x);
+      const double2 a1 = ld_tr(uvals, p.y);
+      const double2 a2 = ld_tr(uvals, p.z);
+      const double2 a3 = ld_tr(uvals, p.w);
+      const double2 x0 = x[c.x];
+      const double2 x1 = x[c.y];
+      const double2 x2 = x[c.z];
+      const double2 x3 = x[c.w];
+      cfma_conj(s0, a0, x0);
+      cfma_conj(s1, a1, x1);
+      cfma_conj(s0, a2, x2);
+      cfma_conj(s1, a3, x3);
+    }
+#pragma unroll UNR
+    for (int q = 0; q < nuq; ++q) {
+      const int4 c = ld_col<NT>(c4 + (size_t)q * 64);
+      const double2 a0 = v[(size_t)(4 * q + 0) * 64];
+      const double2 a1 = v[(size_t)(4 * q + 1) * 64];
+      const double2 a2 = v[(size_t)(4 * q + 2) * 64];
+      const double2 a3 = v[(size_t)(4 * q + 3) * 64];
+      const double2 x0 = x[c.x];
+      const double2 x1 = x[c.y];
+      const double2 x2 = x[c.z];
+      const double2 x3 = x[c.w];
+      cfma(s0, a0, x0);
+      cfma(s1, a1, x1);
+      cfma(s0, a2, x2);
+      cfma(s1, a3, x3);
+    }
+    if (!PRE) pre = op.pre(rowc);
+    if (row < nrows) op.row(row, make_double2(s0.x + s1.x, s0.y + s1.y), pre, chk, nrm);
+  }
+  finish_check(op, chk, nrm, lds);
+}
+
+// ---------------------------------------------------------------------------
 // CSR SpMV, T lanes per row (sub-wave segmented reduction by shuffles).  General
 // fallback for matrices whose row lengths vary too much for RBCSR padding.
 // ---------------------------------------------------------------------------
@@ -256,10 +346,10 @@ __global__ __launch_bounds__(kThreads) void csr_spmv_kernel(const int64_t* __res
   finish_check(op, chk, nrm, lds);
 }
 
-int g_rbcsr_variant = 0;  // tuning knob (qp_tuning_set)
+int g_rbcsr_variant = 7;  // tuning knob (qp_tuning_set); 7 = nt + early row-local loads + deep unroll (A/B in profiles/)
 
 int spmv_grid_size(const DevMatrix& A) {
-  if (A.format == QP_FMT_RBCSR) return (int)((A.nblocks + kThreads / 64 - 1) / (kThreads / 64));
+  if (A.format == QP_FMT_RBCSR || A.format == QP_FMT_HRB) return (int)((A.nblocks + kThreads / 64 - 1) / (kThreads / 64));
   const int64_t threads = A.nrows * A.lanes_per_row;
   return (int)((threads + kThreads - 1) / kThreads);
 }
@@ -285,6 +375,25 @@ static int launch_spmv(hipStream_t s, const DevMatrix& A, const double2* x, cons
       QP_RB_CASE(7)
     }
 #undef QP_RB_CASE
+  } else if (A.format == QP_FMT_HRB) {
+#define QP_HRB_CASE(VV)                                                                                  \
+  case VV:                                                                                               \
+    hipLaunchKernelGGL((hrb_spmv_kernel<Op, VV>), dim3(grid), dim3(kThreads), 0, s, A.bptr,              \
+                       reinterpret_cast<const int4*>(A.cols), A.vals, A.lptr,                            \
+                       reinterpret_cast<const int4*>(A.lcols), reinterpret_cast<const int4*>(A.lpos), x, \
+                       A.nblocks, A.nrows, op);                                                          \
+    break;
+    switch (g_rbcsr_variant & 7) {
+      QP_HRB_CASE(0)
+      QP_HRB_CASE(1)
+      QP_HRB_CASE(2)
+      QP_HRB_CASE(3)
+      QP_HRB_CASE(4)
+      QP_HRB_CASE(5)
+      QP_HRB_CASE(6)
+      QP_HRB_CASE(7)
+    }
+#undef QP_HRB_CASE
   } else {
 #define QP_CSR_CASE(TT)                                                                                  \
   case TT:                                                                                               \

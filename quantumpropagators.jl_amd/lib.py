@@ -24,7 +24,7 @@ STATUS = {
 }
 LAYOUT_CSR, LAYOUT_CSC = 0, 1
 VAL_C128, VAL_F64 = 0, 1
-FMT_AUTO, FMT_CSR, FMT_RBCSR = 0, 1, 2
+FMT_AUTO, FMT_CSR, FMT_RBCSR, FMT_HRB = 0, 1, 2, 3
 FUNC_EXPMI, FUNC_EXP, FUNC_CALLBACK = 0, 1, 2
 
 
@@ -400,10 +400,13 @@ class Operator:
         self._h = _P()
         check(self.lib.qp_operator_create(ctx._h, arr, len(self.ops), int(ncoeffs), int(fmt), C.byref(self._h)))
         self.ncoeffs = int(ncoeffs)
+        self._refresh_info()
+        ctx._adopt(self)
+
+    def _refresh_info(self):
         nr, nc, nnz, f = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int()
         check(self.lib.qp_operator_info(self._h, C.byref(nr), C.byref(nc), C.byref(nnz), C.byref(f)))
         self.nrows, self.ncols, self.nnz, self.format = nr.value, nc.value, nnz.value, f.value
-        ctx._adopt(self)
 
     @property
     def shape(self):

@@ -58,10 +58,61 @@ def test_device_format_roundtrip_bit_exact(ctx, fmt, n):
     assert np.array_equal(rp, A.indptr) and np.array_equal(col, A.indices) and np.array_equal(vals, A.data)
 
 
+def _ragged_hermitian(n, rng):
+    A = _ragged(n, rng, max_len=5)
+    A = (A + A.conj().T).tocsr()
+    A.setdiag(rng.standard_normal(n))
+    A.sort_indices()
+    return A
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 200, 1000])
+def test_hermitian_packed_roundtrip_bit_exact(ctx, n):
+    """HRB stores only col >= row; the read-back must reproduce the full matrix bit for bit."""
+    rng = np.random.default_rng(100 + n)
+    A = _ragged_hermitian(n, rng)
+    M = L.Matrix.from_scipy(ctx, A)
+    Op = L.Operator(ctx, [M])                      # AUTO -> HRB for an exactly Hermitian matrix
+    assert Op.format == L.FMT_HRB
+    rp, col, vals = Op.get_csr()
+    assert np.array_equal(rp, A.indptr) and np.array_equal(col, A.indices) and np.array_equal(vals, A.data)
+    B = A.copy()
+    if B.nnz > 1 and n > 2:
+        B.data[0] += 1e-17j + 1e-3                 # break Hermiticity in one entry
+        if abs(B - B.conj().T).max() > 0:
+            assert L.Operator(ctx, [L.Matrix.from_scipy(ctx, B)]).format == L.FMT_RBCSR
+            with pytest.raises(L.QPArgumentError, match="not exactly Hermitian"):
+                L.Operator(ctx, [L.Matrix.from_scipy(ctx, B)], 0, L.FMT_HRB)
+
+
+def test_hermitian_packed_operator_sum(ctx):
+    """Lazy sum of Hermitian terms in HRB: real coefficients stay packed, a complex
+    coefficient re-lays the operator out as RBCSR (slow path) with identical results."""
+    rng = np.random.default_rng(23)
+    N = 300
+    mats = [_ragged_hermitian(N, rng) for _ in range(3)]
+    psi, phi0 = _rand_state(N, rng), _rand_state(N, rng)
+    Op = L.Operator(ctx, [L.Matrix.from_scipy(ctx, A) for A in mats], 2)
+    assert Op.format == L.FMT_HRB
+    x = L.State(ctx, data=psi)
+    for coeffs in ([0.3, -1.2], [1.0, 1.0], [0.7, 0.1 + 0.2j], [2.0, -0.5]):
+        Op.set_coeffs(coeffs)
+        ref = qo.Operator(mats, coeffs)
+        y = L.State(ctx, data=phi0)
+        Op.mul(x, y, 0.5 - 1j, 0.25j)
+        assert np.linalg.norm(y.numpy() - ref.mul(psi, 0.5 - 1j, 0.25j, C=phi0.copy())) < 1e-12
+        rp, col, vals = Op.get_csr()
+        dense = sp.csr_matrix((vals, col, rp), shape=(N, N)).toarray()
+        assert np.linalg.norm(dense - ref.toarray()) < 1e-12
+    Op._refresh_info()
+    assert Op.format == L.FMT_RBCSR       # left the packed format at the complex coefficient
+
+
 def test_operator_auto_format(ctx):
     rp, col, vals = synth.hermitian_offsets_csr(512, offsets=(1, 2, 3, 4, 16, 32, 48, 64))
     Op = L.Operator(ctx, [L.Matrix(ctx, 512, 512, rp, col, vals)])
-    assert Op.format == L.FMT_RBCSR
+    assert Op.format == L.FMT_HRB            # the synthetic H is exactly Hermitian
+    assert L.Operator(ctx, [L.Matrix(ctx, 512, 512, rp, col, vals)], 0, L.FMT_RBCSR).format == L.FMT_RBCSR
     rng = np.random.default_rng(0)
     lens = np.ones(512, int)
     lens[::64] = 60     # one long row per block: padding would be ~30x
@@ -136,7 +187,7 @@ def _cheby_case(ctx, H_sp, psi0, Delta, E_min, dt, fmt, steps=1, check=False):
     return psi.numpy(), ref, wrk
 
 
-@pytest.mark.parametrize("fmt", [L.FMT_RBCSR, L.FMT_CSR])
+@pytest.mark.parametrize("fmt", [L.FMT_HRB, L.FMT_RBCSR, L.FMT_CSR])
 def test_cheby_dense_c1(ctx, fmt):
     """BASELINE config C1: N=128 dense random Hermitian, 200 time steps, vs oracle and
     vs exp(-i H t)."""
@@ -154,7 +205,7 @@ def test_cheby_dense_c1(ctx, fmt):
     assert abs(np.linalg.norm(out) - 1) < 1e-10
 
 
-@pytest.mark.parametrize("fmt", [L.FMT_RBCSR, L.FMT_CSR])
+@pytest.mark.parametrize("fmt", [L.FMT_HRB, L.FMT_RBCSR, L.FMT_CSR])
 @pytest.mark.parametrize("N", [256, 1000, 16384])
 @pytest.mark.parametrize("dt", [1.0, -1.0])
 def test_cheby_synthetic(ctx, fmt, N, dt):
@@ -191,10 +242,15 @@ def test_cheby_errors(ctx):
     wrk = L.ChebyWrk(ctx, N, 20.0, -10.0, 1.0)
     with pytest.raises(L.QPAssertionError, match="wrk was initialized for dt"):   # src/cheby.jl:157
         L.cheby(psi, Op, 0.5, wrk)
-    # src/cheby.jl:194-200: spectral radius far too small -> "Incorrect normalization"
-    wrk2 = L.ChebyWrk(ctx, N, 0.5, -0.25, 1.0)
+    # src/cheby.jl:194-200: spectrum outside [E_min, E_min + Delta] -> "Incorrect normalization"
+    # (the check is a Rayleigh quotient, so use a one-sided violation; the oracle trips too)
+    wrk2 = L.ChebyWrk(ctx, N, 0.5, 3.0, 1.0)
     with pytest.raises(L.QPAssertionError, match="Incorrect normalization"):
         L.cheby(psi, Op, 1.0, wrk2, check_normalization=True)
+    H = synth.to_scipy(rp, col, vals, N)
+    with pytest.raises(AssertionError, match="Incorrect normalization"):
+        qo.cheby(synth.random_state(N), H, 1.0, qo.ChebyWrk(synth.random_state(N), 0.5, 3.0, 1.0),
+                 check_normalization=True)
     # and a correct radius passes the check
     psi.upload(synth.random_state(N))
     L.cheby(psi, Op, 1.0, wrk, check_normalization=True)
@@ -436,7 +492,7 @@ def test_full_size_properties(ctx):
     wrk = L.ChebyWrk(ctx, N, 20.0, -10.0, 1.0)
     assert wrk.n_coeffs == 32
     res = {}
-    for fmt in (L.FMT_RBCSR, L.FMT_CSR):
+    for fmt in (L.FMT_HRB, L.FMT_RBCSR, L.FMT_CSR):
         Op = L.Operator(ctx, [M], 0, fmt)
         psi = L.State(ctx, data=psi0)
         L.cheby(psi, Op, 1.0, wrk)
@@ -446,7 +502,7 @@ def test_full_size_properties(ctx):
         L.cheby(psi, Op, -1.0, wrk)
         L.cheby(psi, Op, -1.0, wrk)
         assert np.linalg.norm(psi.numpy() - psi0) < TOL
-        if fmt == L.FMT_RBCSR:      # linearity: U(a x + b y) = a U x + b U y
+        if fmt == L.FMT_HRB:        # linearity: U(a x + b y) = a U x + b U y
             y0 = synth.random_state(N, seed=77)
             a, b = 0.6 - 0.3j, -0.2 + 0.9j
             Y = L.State(ctx, data=y0)
@@ -458,3 +514,4 @@ def test_full_size_properties(ctx):
             assert np.linalg.norm(Z.numpy() - (a * res[fmt] + b * Y.numpy())) < TOL
         Op.close()
     assert np.linalg.norm(res[L.FMT_RBCSR] - res[L.FMT_CSR]) < TOL
+    assert np.linalg.norm(res[L.FMT_HRB] - res[L.FMT_RBCSR]) < TOL

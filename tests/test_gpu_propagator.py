@@ -63,8 +63,9 @@ def test_tls_rabi(ctx):
         assert np.linalg.norm(out - expected) < 1e-12
         back = P.propagate(out, gen, tlist, method="cheby", backward=True, inplace=inplace, ctx=ctx)
         assert np.linalg.norm(back - psi0) < 1e-12
-    out = P.propagate(psi0, gen, tlist, method="newton", ctx=ctx)
-    assert np.linalg.norm(out - expected) < 1e-12
+    # Newton on a two-level system is rejected, as in the reference (src/newton.jl:41-46)
+    with pytest.raises(L.QPArgumentError, match="state dimension > 2"):
+        P.propagate(psi0, gen, tlist, method="newton", ctx=ctx)
 
 
 def test_optomech_newton_vs_cheby(ctx):

@@ -38,8 +38,8 @@ def main():
     alg = 20.0 * nnz + 4.0 * (N + 1) + 80.0 * N
     cases = []
     for f in args.formats.split(","):
-        op = L.Operator(ctx, [M], 0, {"rbcsr": L.FMT_RBCSR, "csr": L.FMT_CSR}[f])
-        vs = [int(v) for v in args.variants.split(",")] if f == "rbcsr" else [0]
+        op = L.Operator(ctx, [M], 0, {"rbcsr": L.FMT_RBCSR, "csr": L.FMT_CSR, "hrb": L.FMT_HRB}[f])
+        vs = [int(v) for v in args.variants.split(",")] if f != "csr" else [0]
         for v in vs:
             cases.append((f, v, op))
     psi = L.State(ctx, data=psi0)

@@ -1,21 +1,24 @@
 """Row-partitioned Chebyshev ``prop_step!`` across the GPUs of one node.
 
 One process per GPU (``torch.distributed``, backend "nccl" = RCCL over xGMI).  Rank r owns
-the contiguous CSR row block [r0, r1) and the matching slices of every vector.  After each
-fused mat-vec term the freshly written slice of the term vector is exchanged so that the
-next term can gather from it:
+the contiguous CSR row block [r0, r1) and the matching slices of every vector.  The local
+operator is stored in *local numbering*: columns [0, nloc) are the rank's own rows, columns
+>= nloc are ghost slots, laid out as ``nloc + owner * M + position`` in one staging region
+that a single RCCL all-gather fills after every fused mat-vec term:
 
-* ``allgather``  -- ``all_gather_into_tensor`` of the N/G-row slices, in place in the
-  full-length buffer (what BASELINE.json's north_star names);
-* ``halo``       -- only the column runs a rank actually reads are sent, as grouped
-  point-to-point RCCL sends straight out of / into the full-length buffers (no packing).
-  For a banded H this is 2 x 4096 rows per rank instead of the whole vector; for a
-  scattered H it degenerates to the all-gather volume and ``auto`` picks ``allgather``.
+    slab  = v_local[send_idx]                     (pack: the rows some other rank reads)
+    all_gather_into_tensor(x[nloc:], slab)        (every rank's slab, M entries each)
 
-Chebyshev needs no reductions, so there is no other collective on the path.  The buffer
-rotation is the single-GPU one (engine.hip qp_cheby_step): two full-length buffers G0/G1
-that alternate between "gathered v1" and "local v0 -> v2 in place", plus a local
-accumulator.
+``send_idx`` is computed from the column indices (bit-exact index work): for a banded H it
+is 2 x 4096 rows per rank, so a term moves 128 KiB per rank instead of the whole vector;
+when the rows read most of the vector (scattered H) it degenerates to the plain all-gather
+of the N/G-row slices that BASELINE.json's north_star names (no pack, the slice itself is the
+send buffer).  Chebyshev needs no reductions, so this is the only collective on the path.
+In local numbering the square part of the block is still Hermitian, so the engine keeps it
+Hermitian-packed (ghost columns are "upper" by construction).
+
+The buffer rotation is the single-GPU one (engine.hip qp_cheby_step): two x buffers that
+alternate between "gathered v1" and "local v0 -> v2 in place", plus a local accumulator.
 
 The local compute goes through a *backend* object; the product backend is
 :class:`HipBackend` (C ABI, fails loudly without a GPU).  CPU tests inject a NumPy backend
@@ -29,25 +32,42 @@ from . import lib as L
 
 
 # ----------------------------------------------------------------------------------------
-# index work: which remote columns does my row block read?  (bit-exact, host)
+# index work (host, bit-exact)
 # ----------------------------------------------------------------------------------------
 
-def needed_runs(col, r0, r1, bounds, gap_merge=2048):
-    """Contiguous runs [(owner, lo, hi)] of global column indices outside [r0, r1) that
-    the local rows reference; runs of the same owner closer than ``gap_merge`` are merged."""
+def remote_columns(col, r0, r1):
+    """Sorted unique global column indices outside [r0, r1) that the local rows read."""
     col = np.asarray(col)
-    remote = np.unique(col[(col < r0) | (col >= r1)]).astype(np.int64)
-    runs = []
-    if len(remote) == 0:
-        return runs
+    return np.unique(col[(col < r0) | (col >= r1)]).astype(np.int64)
+
+
+def split_by_owner(remote, bounds):
+    """{owner: sorted global columns} for the rank owning each remote column."""
     owner = np.searchsorted(bounds, remote, side="right") - 1
-    start = 0
-    for i in range(1, len(remote) + 1):
-        brk = (i == len(remote)) or (owner[i] != owner[start]) or (remote[i] - remote[i - 1] > gap_merge)
-        if brk:
-            runs.append((int(owner[start]), int(remote[start]), int(remote[i - 1]) + 1))
-            start = i
-    return runs
+    return {int(o): remote[owner == o] for o in np.unique(owner)}
+
+
+def remap_columns(col, r0, r1, bounds, send_lists, M):
+    """Global -> local numbering: own columns c -> c - r0; a remote column c owned by o ->
+    nloc + o*M + (position of c in o's send list)."""
+    col = np.asarray(col, dtype=np.int64)
+    nloc = r1 - r0
+    out = np.empty(len(col), dtype=np.int64)
+    local = (col >= r0) & (col < r1)
+    out[local] = col[local] - r0
+    rem = ~local
+    if rem.any():
+        c = col[rem]
+        owner = np.searchsorted(bounds, c, side="right") - 1
+        pos = np.empty(len(c), dtype=np.int64)
+        for o in np.unique(owner):
+            sel = owner == o
+            sl = send_lists[int(o)]
+            p = np.searchsorted(sl, c[sel])
+            assert np.all(p < len(sl)) and np.array_equal(sl[p], c[sel]), "remote column missing from the owner's send list"
+            pos[sel] = p
+        out[rem] = nloc + owner * M + pos
+    return out
 
 
 class HipBackend:
@@ -63,8 +83,11 @@ class HipBackend:
     def zeros(self, n):
         return self.torch.zeros(2 * n, dtype=self.torch.float64, device=self.device)
 
-    def make_operator(self, rowptr, col, vals, nloc, N, fmt):
-        return L.Operator(self.ctx, [L.Matrix(self.ctx, nloc, N, rowptr, col, vals)], 0, fmt)
+    def index(self, idx):
+        return self.torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int64)).to(self.device)
+
+    def make_operator(self, rowptr, col, vals, nloc, ncols, fmt):
+        return L.Operator(self.ctx, [L.Matrix(self.ctx, nloc, ncols, rowptr, col, vals)], 0, fmt)
 
     def view(self, t, lo, hi):
         return L.State(self.ctx, n=hi - lo, device_ptr=t.data_ptr() + 16 * lo, keepalive=t)
@@ -79,87 +102,99 @@ class HipBackend:
     def read(self, t, lo, hi):
         return t[2 * lo: 2 * hi].cpu().numpy().view(np.complex128).copy()
 
-    def copy(self, dst, dlo, src, slo, n):
-        dst[2 * dlo: 2 * (dlo + n)].copy_(src[2 * slo: 2 * (slo + n)])
-
 
 class ShardedCheby:
-    """Chebyshev propagator for one row block of a row-partitioned H."""
+    """Chebyshev propagator for one row block of a row-partitioned H.
+
+    ``rowptr, col, vals``: the local rows [r0, r1) in CSR with *global* column indices."""
 
     def __init__(self, ctx, rowptr, col, vals, N, r0, r1, Delta, E_min, dt, fmt=L.FMT_AUTO,
-                 exchange="auto", group=None, backend=None, limit=1e-12, gap_merge=2048):
+                 exchange="auto", group=None, backend=None, limit=1e-12):
+        import torch
         import torch.distributed as dist
-        self.dist = dist
-        self.group = group
+        self.torch, self.dist, self.group = torch, dist, group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.N, self.r0, self.r1 = int(N), int(r0), int(r1)
-        self.nloc = self.r1 - self.r0
+        self.nloc = nloc = self.r1 - self.r0
         self.be = backend if backend is not None else HipBackend(ctx)
         self.Delta, self.E_min, self.dt, self.limit = float(Delta), float(E_min), float(dt), float(limit)
         self.coeffs = L.cheby_coeffs(Delta, dt, limit)
         if len(self.coeffs) < 2:
             raise L.QPAssertionError(4, "Need at least 2 Chebychev coefficients")
+        if exchange not in ("auto", "halo", "allgather"):
+            raise ValueError(f"unknown exchange mode {exchange!r}")
 
-        # ---- partition bookkeeping (index work) ----
-        mine = np.array([self.r0, self.r1], dtype=np.int64)
+        # ---- partition bookkeeping ----
         allb = [None] * self.world
-        dist.all_gather_object(allb, mine.tolist(), group=group)
-        self.bounds = np.array([b[0] for b in allb] + [allb[-1][1]], dtype=np.int64)
-        assert self.bounds[0] == 0 and self.bounds[-1] == self.N and np.all(np.diff(self.bounds) > 0), \
+        dist.all_gather_object(allb, [self.r0, self.r1], group=group)
+        self.bounds = bounds = np.array([b[0] for b in allb] + [allb[-1][1]], dtype=np.int64)
+        assert bounds[0] == 0 and bounds[-1] == self.N and np.all(np.diff(bounds) > 0), \
             "row blocks must tile [0, N) in rank order"
-        self.equal_blocks = bool(np.all(np.diff(self.bounds) == self.nloc))
-        self.recv_runs = needed_runs(col, self.r0, self.r1, self.bounds, gap_merge)
-        all_runs = [None] * self.world
-        dist.all_gather_object(all_runs, self.recv_runs, group=group)
-        # what I must send: runs requested by rank d whose owner is me
-        self.send_runs = [(d, lo, hi) for d in range(self.world) if d != self.rank
-                          for (o, lo, hi) in all_runs[d] if o == self.rank]
-        for (_, lo, hi) in self.send_runs:
-            assert self.r0 <= lo < hi <= self.r1
-        halo_rows = sum(hi - lo for r in all_runs for (_, lo, hi) in r)
-        full_rows = self.world * (self.N - self.nloc) if self.world > 1 else 1
-        self.halo_fraction = halo_rows / max(full_rows, 1)
+        remote = remote_columns(col, self.r0, self.r1)
+        frac = len(remote) / max(self.N - nloc, 1)
+        fracs = [None] * self.world
+        dist.all_gather_object(fracs, frac, group=group)
+        self.halo_fraction = float(max(fracs))
         if exchange == "auto":
-            exchange = "halo" if (self.halo_fraction < 0.5 or not self.equal_blocks) else "allgather"
-        if exchange == "allgather" and not self.equal_blocks:
-            raise ValueError("allgather exchange needs equal row blocks; use exchange='halo'")
+            exchange = "halo" if self.halo_fraction < 0.5 else "allgather"
         self.exchange = exchange
 
+        # ---- send lists: which of my rows does any other rank read? ----
+        if exchange == "halo":
+            wanted = split_by_owner(remote, bounds)
+            all_wanted = [None] * self.world
+            dist.all_gather_object(all_wanted, wanted, group=group)
+            send_lists = []
+            for o in range(self.world):
+                parts = [w[o] for w in all_wanted if o in w]
+                send_lists.append(np.unique(np.concatenate(parts)) if parts else np.zeros(0, dtype=np.int64))
+        else:
+            send_lists = [np.arange(bounds[o], bounds[o + 1], dtype=np.int64) for o in range(self.world)]
+        self.send_lists = send_lists
+        self.M = M = int(max(len(s) for s in send_lists)) if self.world > 1 else 0
+        self.send_idx_host = send_lists[self.rank] - self.r0
+        assert np.all((self.send_idx_host >= 0) & (self.send_idx_host < nloc))
+        # the slice itself is the send buffer when every row is sent and blocks are equal
+        self.direct_send = (exchange == "allgather" and len(self.send_idx_host) == nloc and M == nloc)
+        self.ncols_local = nloc + self.world * M if self.world > 1 else nloc
+        lcol = remap_columns(col, self.r0, self.r1, bounds, send_lists, M)
+
         # ---- device data ----
-        self.op = self.be.make_operator(rowptr, col, vals, self.nloc, self.N, fmt)
-        self.G = [self.be.zeros(self.N), self.be.zeros(self.N)]
-        self.acc_t = self.be.zeros(self.nloc)
-        self.Gfull = [self.be.view(g, 0, self.N) for g in self.G]
-        self.Gloc = [self.be.view(g, self.r0, self.r1) for g in self.G]
-        self.acc = self.be.view(self.acc_t, 0, self.nloc)
+        be = self.be
+        self.op = be.make_operator(rowptr, lcol, vals, nloc, self.ncols_local, fmt)
+        self.X = [be.zeros(self.ncols_local), be.zeros(self.ncols_local)]
+        self.acc_t = be.zeros(nloc)
+        self.Xfull = [be.view(x, 0, self.ncols_local) for x in self.X]
+        self.Xloc = [be.view(x, 0, nloc) for x in self.X]
+        self.acc = be.view(self.acc_t, 0, nloc)
+        if self.world > 1 and not self.direct_send:
+            self.slab = be.zeros(M)
+            idx = np.zeros(M, dtype=np.int64)            # padded with row 0 (never read by anyone)
+            idx[: len(self.send_idx_host)] = self.send_idx_host
+            self.send_idx = be.index(idx)
         self.n_exchanges = 0
 
-    # the state lives in G[0][r0:r1]
+    # the state lives in X[0][:nloc]
     def set_state(self, psi_local):
         assert len(psi_local) == self.nloc
-        self.be.write(self.G[0], self.r0, psi_local)
+        self.be.write(self.X[0], 0, psi_local)
 
     def local_state(self):
-        return self.be.read(self.G[0], self.r0, self.r1)
+        return self.be.read(self.X[0], 0, self.nloc)
 
     def _exchange(self, k):
-        """Make G[k] readable wherever the local rows gather from it."""
+        """Fill the ghost slots of X[k] with the other ranks' rows of the same vector."""
         if self.world == 1:
             return
-        dist = self.dist
-        g = self.G[k]
-        if self.exchange == "allgather":
-            dist.all_gather_into_tensor(g, g[2 * self.r0: 2 * self.r1], group=self.group)
+        x = self.X[k]
+        nloc = self.nloc
+        if self.direct_send:
+            send = x[: 2 * nloc]
         else:
-            ops = []
-            for (d, lo, hi) in self.send_runs:
-                ops.append(dist.P2POp(dist.isend, g[2 * lo: 2 * hi], d, group=self.group))
-            for (o, lo, hi) in self.recv_runs:
-                ops.append(dist.P2POp(dist.irecv, g[2 * lo: 2 * hi], o, group=self.group))
-            if ops:
-                for w in dist.batch_isend_irecv(ops):
-                    w.wait()
+            send = self.slab
+            self.torch.index_select(x[: 2 * nloc].view(-1, 2), 0, self.send_idx, out=send.view(-1, 2))
+        self.dist.all_gather_into_tensor(x[2 * nloc:], send, group=self.group)
         self.n_exchanges += 1
 
     def step(self, backward=False):
@@ -171,24 +206,24 @@ class ShardedCheby:
         c = (-2j / Delta) if dt > 0 else (2j / Delta)
         phase = np.exp(-1j * beta * dt)
         nterms = len(a) - 1
-        be, op, r0 = self.be, self.op, self.r0
+        be, op = self.be, self.op
         self._exchange(0)
         result_in_acc = True
         for m in range(1, nterms + 1):
             last = m == nterms
             xi, oi = (0, 1) if m % 2 == 1 else (1, 0)
-            x, oloc = self.Gfull[xi], self.Gloc[oi]
+            x, oloc = self.Xfull[xi], self.Xloc[oi]
             ph = phase if last else 1.0
             if m == 1:
-                be.term(op, x, r0, None, None if last else oloc, None, self.acc, c, beta, a[0], a[1], ph)
+                be.term(op, x, 0, None, None if last else oloc, None, self.acc, c, beta, a[0], a[1], ph)
             else:
-                # the state buffer G[0] may be written only while it is not being gathered
-                out = self.Gloc[0] if (last and xi == 1) else self.acc
-                be.term(op, x, r0, oloc, None if last else oloc, self.acc, out, c, beta, 0.0, a[m], ph)
+                # the state buffer X[0] may be written only while it is not being gathered
+                out = self.Xloc[0] if (last and xi == 1) else self.acc
+                be.term(op, x, 0, oloc, None if last else oloc, self.acc, out, c, beta, 0.0, a[m], ph)
                 result_in_acc = out is self.acc
             if not last:
                 self._exchange(oi)
             if m == 1:
                 c = 2 * c
         if result_in_acc:
-            be.copy(self.G[0], self.r0, self.acc_t, 0, self.nloc)
+            self.X[0][: 2 * self.nloc].copy_(self.acc_t)

@@ -16,8 +16,11 @@ class NumpyBackend:
     def zeros(self, n):
         return torch.zeros(2 * n, dtype=torch.float64)
 
-    def make_operator(self, rowptr, col, vals, nloc, N, fmt):
-        return _Op(sp.csr_matrix((vals, col, rowptr), shape=(nloc, N)))
+    def index(self, idx):
+        return torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int64))
+
+    def make_operator(self, rowptr, col, vals, nloc, ncols, fmt):
+        return _Op(sp.csr_matrix((vals, col, rowptr), shape=(nloc, ncols)))
 
     def view(self, t, lo, hi):
         return t.numpy()[2 * lo: 2 * hi].view(np.complex128)   # shares memory with the tensor
@@ -39,6 +42,3 @@ class NumpyBackend:
 
     def read(self, t, lo, hi):
         return self.view(t, lo, hi).copy()
-
-    def copy(self, dst, dlo, src, slo, n):
-        self.view(dst, dlo, dlo + n)[:] = self.view(src, slo, slo + n)

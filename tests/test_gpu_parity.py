@@ -72,7 +72,7 @@ def test_hermitian_packed_roundtrip_bit_exact(ctx, n):
     rng = np.random.default_rng(100 + n)
     A = _ragged_hermitian(n, rng)
     M = L.Matrix.from_scipy(ctx, A)
-    Op = L.Operator(ctx, [M])                      # AUTO -> HRB for an exactly Hermitian matrix
+    Op = L.Operator(ctx, [M], 0, L.FMT_HRB)
     assert Op.format == L.FMT_HRB
     rp, col, vals = Op.get_csr()
     assert np.array_equal(rp, A.indptr) and np.array_equal(col, A.indices) and np.array_equal(vals, A.data)
@@ -80,7 +80,7 @@ def test_hermitian_packed_roundtrip_bit_exact(ctx, n):
     if B.nnz > 1 and n > 2:
         B.data[0] += 1e-17j + 1e-3                 # break Hermiticity in one entry
         if abs(B - B.conj().T).max() > 0:
-            assert L.Operator(ctx, [L.Matrix.from_scipy(ctx, B)]).format == L.FMT_RBCSR
+            assert L.Operator(ctx, [L.Matrix.from_scipy(ctx, B)]).format in (L.FMT_RBCSR, L.FMT_CSR)
             with pytest.raises(L.QPArgumentError, match="not exactly Hermitian"):
                 L.Operator(ctx, [L.Matrix.from_scipy(ctx, B)], 0, L.FMT_HRB)
 
@@ -92,7 +92,7 @@ def test_hermitian_packed_operator_sum(ctx):
     N = 300
     mats = [_ragged_hermitian(N, rng) for _ in range(3)]
     psi, phi0 = _rand_state(N, rng), _rand_state(N, rng)
-    Op = L.Operator(ctx, [L.Matrix.from_scipy(ctx, A) for A in mats], 2)
+    Op = L.Operator(ctx, [L.Matrix.from_scipy(ctx, A) for A in mats], 2, L.FMT_HRB)
     assert Op.format == L.FMT_HRB
     x = L.State(ctx, data=psi)
     for coeffs in ([0.3, -1.2], [1.0, 1.0], [0.7, 0.1 + 0.2j], [2.0, -0.5]):
@@ -105,13 +105,15 @@ def test_hermitian_packed_operator_sum(ctx):
         dense = sp.csr_matrix((vals, col, rp), shape=(N, N)).toarray()
         assert np.linalg.norm(dense - ref.toarray()) < 1e-12
     Op._refresh_info()
-    assert Op.format == L.FMT_RBCSR       # left the packed format at the complex coefficient
+    assert Op.format in (L.FMT_RBCSR, L.FMT_CSR)   # left the packed format at the complex coefficient
 
 
 def test_operator_auto_format(ctx):
     rp, col, vals = synth.hermitian_offsets_csr(512, offsets=(1, 2, 3, 4, 16, 32, 48, 64))
     Op = L.Operator(ctx, [L.Matrix(ctx, 512, 512, rp, col, vals)])
-    assert Op.format == L.FMT_HRB            # the synthetic H is exactly Hermitian
+    assert Op.format == L.FMT_HRB            # the synthetic H is exactly Hermitian and banded
+    rs, cs, vs = synth.hermitian_offsets_csr(1 << 16, offsets=synth.scattered_offsets(1 << 16))
+    assert L.Operator(ctx, [L.Matrix(ctx, 1 << 16, 1 << 16, rs, cs, vs)]).format == L.FMT_RBCSR   # no L2 locality
     assert L.Operator(ctx, [L.Matrix(ctx, 512, 512, rp, col, vals)], 0, L.FMT_RBCSR).format == L.FMT_RBCSR
     rng = np.random.default_rng(0)
     lens = np.ones(512, int)
@@ -273,8 +275,11 @@ def test_cheby_deterministic(ctx):
 
 
 def test_cheby_term_row_partition(ctx):
-    """The multi-GPU building block on one GPU: two row shards, each running
-    qp_cheby_term on its rows with a gathered x, reproduce the unsharded step."""
+    """The multi-GPU building block on one GPU: two row shards in local numbering (own
+    columns + ghost slots, Hermitian-packed square part), each running qp_cheby_term on
+    its rows; the "all-gather" of the send slabs goes through the host.  Must reproduce
+    the unsharded step."""
+    import qprop_amd.sharded as sharded
     N = 1000
     rp, col, vals = synth.hermitian_offsets_csr(N, offsets=(1, 2, 3, 4, 16, 32, 48, 64))
     H = synth.to_scipy(rp, col, vals, N)
@@ -283,31 +288,54 @@ def test_cheby_term_row_partition(ctx):
     a = L.cheby_coeffs(Delta, dt)
     beta = Delta / 2 + E_min
     bounds = L.partition_rows(rp, 2)
+    G = 2
+    blocks = [(int(bounds[r]), int(bounds[r + 1])) for r in range(G)]
+    wanted = [sharded.split_by_owner(sharded.remote_columns(col[rp[r0]:rp[r1]], r0, r1), bounds) for r0, r1 in blocks]
+    send_lists = [np.unique(np.concatenate([w[o] for w in wanted if o in w])) for o in range(G)]
+    M = max(len(s) for s in send_lists)
     shards = []
-    for r in range(2):
-        r0, r1 = bounds[r], bounds[r + 1]
-        Hs = H[r0:r1]
-        shards.append((r0, r1, L.Operator(ctx, [L.Matrix(ctx, r1 - r0, N, Hs.indptr, Hs.indices, Hs.data)])))
-    G = [L.State(ctx, data=psi0), L.State(ctx, n=N)]       # gathered ping-pong buffers
-    acc = [L.State(ctx, n=r1 - r0) for r0, r1, _ in shards]
+    for (r0, r1) in blocks:
+        nloc = r1 - r0
+        lcol = sharded.remap_columns(col[rp[r0]:rp[r1]], r0, r1, bounds, send_lists, M)
+        Op = L.Operator(ctx, [L.Matrix(ctx, nloc, nloc + G * M, rp[r0:r1 + 1] - rp[r0], lcol, vals[rp[r0]:rp[r1]])])
+        assert Op.format == L.FMT_HRB          # the local square part stays Hermitian-packed
+        X = [L.State(ctx, n=nloc + G * M), L.State(ctx, n=nloc + G * M)]
+        shards.append(dict(r0=r0, r1=r1, nloc=nloc, Op=Op, X=X, acc=L.State(ctx, n=nloc)))
+
+    def exchange(k):
+        slabs = np.zeros((G, M), dtype=complex)
+        hosts = [sh["X"][k].numpy() for sh in shards]
+        for o, sh in enumerate(shards):
+            idx = send_lists[o] - sh["r0"]
+            slabs[o, :len(idx)] = hosts[o][idx]
+        for o, sh in enumerate(shards):
+            hosts[o][sh["nloc"]:] = slabs.reshape(-1)
+            sh["X"][k].upload(hosts[o])
+
+    for sh in shards:
+        h = np.zeros(sh["nloc"] + G * M, dtype=complex)
+        h[:sh["nloc"]] = psi0[sh["r0"]:sh["r1"]]
+        sh["X"][0].upload(h)
+    exchange(0)
     c = -2j / Delta
     n = len(a)
     for m in range(1, n):
-        xg, og = (G[0], G[1]) if m % 2 == 1 else (G[1], G[0])
+        xi, oi = (0, 1) if m % 2 == 1 else (1, 0)
         last = m == n - 1
         phase = np.exp(-1j * beta * dt) if last else 1.0
-        ohost = og.numpy()
-        for k, (r0, r1, Op) in enumerate(shards):
-            loc = L.State(ctx, data=ohost[r0:r1])        # local slice of the other buffer
+        for sh in shards:
+            nloc = sh["nloc"]
+            oloc = L.State(ctx, n=nloc, device_ptr=sh["X"][oi].ptr, keepalive=sh["X"][oi])
             if m == 1:
-                L.cheby_term(Op, xg, r0, None, loc, None, acc[k], c, beta, a[0], a[1], phase)
+                L.cheby_term(sh["Op"], sh["X"][xi], 0, None, oloc, None, sh["acc"], c, beta, a[0], a[1], phase)
             else:
-                L.cheby_term(Op, xg, r0, loc, None if last else loc, acc[k], acc[k], c, beta, 0.0, a[m], phase)
-            ohost[r0:r1] = loc.numpy()                   # "all-gather" through the host
-        og.upload(ohost)
+                L.cheby_term(sh["Op"], sh["X"][xi], 0, oloc, None if last else oloc, sh["acc"], sh["acc"], c, beta,
+                             0.0, a[m], phase)
+        if not last:
+            exchange(oi)
         if m == 1:
             c = 2 * c
-    out = np.concatenate([s.numpy() for s in acc])
+    out = np.concatenate([sh["acc"].numpy() for sh in shards])
     wrk = qo.ChebyWrk(psi0, Delta, E_min, dt)
     wrk.coeffs, wrk.n_coeffs = a, len(a)
     ref = qo.cheby(psi0.copy(), H, dt, wrk)

@@ -44,7 +44,7 @@ def _worker(rank, world, port, exchange, uneven, offsets, N, q):
         lrp = rp[r0:r1 + 1] - rp[r0]
         lcol, lvals = col[rp[r0]:rp[r1]], vals[rp[r0]:rp[r1]]
         sh = sharded.ShardedCheby(None, lrp, lcol, lvals, N, r0, r1, 20.0, -10.0, 1.0, exchange=exchange,
-                                  backend=NumpyBackend(), gap_merge=8)
+                                  backend=NumpyBackend())
         psi0 = synth.random_state(N)
         sh.set_state(psi0[r0:r1])
         sh.step()
@@ -59,7 +59,7 @@ def _worker(rank, world, port, exchange, uneven, offsets, N, q):
         qo.cheby(ref, H, 1.0, wrk)
         qo.cheby(ref, H, -1.0, wrk)
         err = float(np.linalg.norm(out - ref[r0:r1]))
-        q.put((rank, err, sh.exchange, sh.halo_fraction, len(sh.recv_runs), len(sh.send_runs), sh.n_exchanges))
+        q.put((rank, err, sh.exchange, sh.halo_fraction, sh.M, len(sh.send_idx_host), sh.n_exchanges))
     finally:
         dist.destroy_process_group()
 
@@ -84,22 +84,31 @@ def test_sharded_cheby_matches_oracle(world, exchange, uneven, offsets):
         assert p.exitcode == 0
     res = sorted(q.get(timeout=10) for _ in range(world))
     coeffs_terms = 31
-    for rank, err, used, frac, nrecv, nsend, nex in res:
+    for rank, err, used, frac, M, nsend, nex in res:
         assert err < 1e-12, (rank, err)
         assert nex == 3 * coeffs_terms       # one exchange per mat-vec: psi + 30 term vectors per step
         if exchange != "auto":
             assert used == exchange
     if offsets[-1] == 64 and exchange == "auto":
-        assert all(r[2] == "halo" and r[3] < 0.5 for r in res)
+        # banded: every rank sends only its 2 x 64 boundary rows
+        assert all(r[2] == "halo" and r[3] < 0.5 and r[5] <= 2 * 64 for r in res)
     if offsets[-1] == 499:
         assert all(r[2] == "allgather" for r in res)
 
 
-def test_needed_runs():
+def test_index_work():
+    """Local numbering: own columns first, ghost slot = nloc + owner*M + position."""
     import qprop_amd.sharded as sharded
     bounds = np.array([0, 100, 200, 300])
     col = np.array([95, 99, 100, 150, 199, 200, 201, 204, 290, 299, 3])
-    runs = sharded.needed_runs(col, 100, 200, bounds, gap_merge=4)
-    assert runs == [(0, 3, 4), (0, 95, 100), (2, 200, 205), (2, 290, 291), (2, 299, 300)]
-    assert sharded.needed_runs(col, 100, 200, bounds, gap_merge=1000) == [(0, 3, 100), (2, 200, 300)]
-    assert sharded.needed_runs(np.array([100, 150]), 100, 200, bounds) == []
+    remote = sharded.remote_columns(col, 100, 200)
+    assert list(remote) == [3, 95, 99, 200, 201, 204, 290, 299]
+    by = sharded.split_by_owner(remote, bounds)
+    assert sorted(by) == [0, 2] and list(by[0]) == [3, 95, 99] and list(by[2]) == [200, 201, 204, 290, 299]
+    send_lists = [np.array([3, 50, 95, 99]), np.array([100, 199]), np.array([200, 201, 204, 290, 299])]
+    M = 5
+    lc = sharded.remap_columns(col, 100, 200, bounds, send_lists, M)
+    assert list(lc) == [100 + 2, 100 + 3, 0, 50, 99, 100 + 10 + 0, 100 + 10 + 1, 100 + 10 + 2, 100 + 10 + 3,
+                        100 + 10 + 4, 100 + 0]
+    with pytest.raises(AssertionError):
+        sharded.remap_columns(np.array([7]), 100, 200, bounds, send_lists, M)

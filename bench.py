@@ -129,11 +129,16 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_enq = time.perf_counter() - t0
     ev_ms = ctx.timer_end()          # HIP events on the kernels' own stream
+    t_ev = time.perf_counter() - t0
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("QP_BENCH_DEBUG"):
+        print(f"[debug] rank {rank}: enqueue {1e3*t_enq:.2f} ms, +events {1e3*t_ev:.2f} ms, +sync/barrier "
+              f"{1e3*elapsed:.2f} ms, hip events {ev_ms:.2f} ms", file=sys.stderr)
     st = ctx.stats()
     if dist is not None:
         t = torch.tensor([elapsed, ev_ms], dtype=torch.float64, device="cuda")

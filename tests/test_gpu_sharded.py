@@ -1,27 +1,69 @@
-"""GPU test of the product multi-GPU driver (HipBackend + torch.distributed nccl=RCCL).
-Only one GPU is available to the test box, so this runs world_size = 1: it covers the
-torch-buffer <-> C-ABI plumbing, stream sharing and the local-numbering operator build;
-the exchange logic itself is covered by tests/test_sharded_gloo.py (CPU, world 2 and 3)
-and tests/test_gpu_parity.py::test_cheby_term_row_partition (two shards on one GPU)."""
+"""GPU test of the product multi-GPU driver (HipBackend + torch.distributed nccl = RCCL).
+Only one GPU is available to the test box, so this runs world_size = 1, in-process (no
+child process: a GPU-initialised parent must not exec).  It covers the torch-buffer <->
+C-ABI plumbing, stream sharing, the local-numbering operator build and the RCCL
+all_gather_into_tensor call shape; the multi-rank exchange logic is covered by
+tests/test_sharded_gloo.py (CPU, world 2 and 3) and
+tests/test_gpu_parity.py::test_cheby_term_row_partition (two shards on one GPU)."""
 import os
 import socket
-import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 
-def test_sharded_hip_backend_world1():
+@pytest.fixture(scope="module")
+def pg():
+    import torch
+    import torch.distributed as dist
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-               MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "sharded_gpu_worker.py")], env=env,
-                       capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stdout + r.stderr
-    assert "err=" in r.stdout
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    yield dist
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("exchange", ["auto", "allgather"])
+def test_sharded_hip_backend_world1(pg, exchange):
+    import torch
+    from oracle import qp_oracle as qo
+    import qprop_amd.lib as L
+    import qprop_amd.sharded as sharded
+    import qprop_amd.synth as synth
+    N = 4096
+    rp, col, vals = synth.hermitian_offsets_csr(N, offsets=(1, 2, 3, 4, 16, 32, 48, 64))
+    ctx = L.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    sh = sharded.ShardedCheby(ctx, rp, col, vals, N, 0, N, 20.0, -10.0, 1.0, exchange=exchange)
+    assert sh.op.format == L.FMT_HRB
+    psi0 = synth.random_state(N)
+    sh.set_state(psi0)
+    sh.step()
+    sh.step()
+    sh.step(backward=True)
+    torch.cuda.synchronize()
+    H = synth.to_scipy(rp, col, vals, N)
+    wrk = qo.ChebyWrk(psi0, 20.0, -10.0, 1.0)
+    ref = psi0.copy()
+    qo.cheby(ref, H, 1.0, wrk)
+    qo.cheby(ref, H, 1.0, wrk)
+    qo.cheby(ref, H, -1.0, wrk)
+    assert np.linalg.norm(sh.local_state() - ref) < 1e-10
+    # the collective the exchange uses, in the shape it uses it (views of one flat buffer)
+    x = torch.zeros(2 * 48, dtype=torch.float64, device="cuda")
+    x[:32] = torch.arange(32, dtype=torch.float64, device="cuda")
+    slab = torch.empty(2 * 8, dtype=torch.float64, device="cuda")
+    idx = torch.tensor([0, 1, 2, 3, 12, 13, 14, 15], device="cuda")
+    torch.index_select(x[:32].view(-1, 2), 0, idx, out=slab.view(-1, 2))
+    pg.all_gather_into_tensor(x[32:48], slab)
+    torch.cuda.synchronize()
+    assert x[32:48].tolist() == [0, 1, 2, 3, 4, 5, 6, 7, 24, 25, 26, 27, 28, 29, 30, 31]
+    ctx.close()

@@ -145,6 +145,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, ev_ms = float(t[0]), float(t[1])
 
+    # HBM traffic per launch of the dominant kernel: PMC counters need their own rocprofv3
+    # passes (tools/profile.sh), so the value measured for this exact command is read back
+    # from the committed summary under profiles/ (null when there is none for this kernel)
+    traffic = None
+    kern = {1: "csr_spmv_kernel<16,ChebyOp>", 2: "rbcsr_spmv_kernel<ChebyOp,7>", 3: "hrb_spmv_kernel<ChebyOp,7>"}[fmt_used]
+    pmc_file = os.path.join(ROOT, "profiles", "r01", "bench_hrb_pmc_summary.json")
+    if fmt_used == 3 and world == 1 and args.log2n == 20 and args.pattern == "banded" and os.path.exists(pmc_file):
+        with open(pmc_file) as f:
+            traffic = json.load(f)["hbm_traffic_bytes_per_launch"]
+
     steps_per_s = args.steps / elapsed
     n_launch = args.steps * nterms
     # algorithmic bytes of one fused term on one GPU: (20 z + 84) N + 4
@@ -167,8 +177,10 @@ def main():
                    "parallelism": "single GPU" if world == 1 else f"row-partitioned x{world}, exchange={exchange_used}",
                    "global_steps_per_s": steps_per_s},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": {1: "csr_spmv_kernel<16,ChebyOp>", 2: "rbcsr_spmv_kernel<ChebyOp,7>", 3: "hrb_spmv_kernel<ChebyOp,7>"}[fmt_used],
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_source": "profiles/r01/bench_hrb_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                                       "FETCH x2 gfx950 correction)" if traffic else None,
+                     "kernel": kern,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "avg_launch_us": avg_launch_s * 1e6,
                      "launches_timed": n_launch, "hip_event_ms": ev_ms,

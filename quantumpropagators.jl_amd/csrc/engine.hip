@@ -92,6 +92,9 @@ struct qp_krylov {
   double2* hess_dev = nullptr;  // nvec x nvec column major
   double* norms_dev = nullptr;  // nvec
   double2* part = nullptr;      // 2 x kRedBlocks ping-pong partials
+  double2* md_part = nullptr;   // kRedBlocks x 2 nvec multidot partials (low-sync MGS)
+  double2* gram = nullptr;      // nvec x nvec Gram rows <q_i|q_k>, k < i
+  double2* hcoef = nullptr;     // nvec projection coefficients
   double2* q(int i) const { return Q + (size_t)i * n; }
 };
 
@@ -195,6 +198,10 @@ int qp_tuning_set(const char* key, int value) {
   if (!key) return qp::fail(QP_E_BAD_ARG, "key is NULL");
   if (std::strcmp(key, "rbcsr_variant") == 0) {
     qp::g_rbcsr_variant = value;
+    return QP_OK;
+  }
+  if (std::strcmp(key, "arnoldi_mode") == 0) {
+    qp::g_arnoldi_mode = value;
     return QP_OK;
   }
   return qp::fail(QP_E_BAD_ARG, "unknown tuning key %s", key);
@@ -1179,6 +1186,9 @@ int qp_krylov_create(qp_ctx* ctx, int64_t n, int nvec, qp_krylov** out) {
   QP_CHECK(dev_alloc(&q->hess_dev, (size_t)nvec * nvec));
   QP_CHECK(dev_alloc(&q->norms_dev, (size_t)nvec));
   QP_CHECK(dev_alloc(&q->part, (size_t)2 * kRedBlocks));
+  QP_CHECK(dev_alloc(&q->md_part, (size_t)kRedBlocks * 2 * nvec));
+  QP_CHECK(dev_alloc(&q->gram, (size_t)nvec * nvec));
+  QP_CHECK(dev_alloc(&q->hcoef, (size_t)nvec));
   *out = q.release();
   return QP_OK;
   QP_CATCH
@@ -1193,6 +1203,9 @@ int qp_krylov_destroy(qp_krylov* q) {
   if (q->hess_dev) (void)hipFree(q->hess_dev);
   if (q->norms_dev) (void)hipFree(q->norms_dev);
   if (q->part) (void)hipFree(q->part);
+  if (q->md_part) (void)hipFree(q->md_part);
+  if (q->gram) (void)hipFree(q->gram);
+  if (q->hcoef) (void)hipFree(q->hcoef);
   delete q;
   return QP_OK;
   QP_CATCH
@@ -1221,6 +1234,12 @@ int arnoldi_column(qp_operator* op, qp_krylov* q, int j, double dt, double2* hco
   pe.beta = make_double2(0.0, 0.0);
   pe.beta_zero = 1;
   QP_CHECK(qp::launch_spmv_plain(ctx->stream, op->A, q->q(j), pe, &ctx->stats));  // src/arnoldi.jl:82
+  if (qp::g_arnoldi_mode == 1) {
+    // low-synchronisation MGS: same coefficients (to rounding), 3 launches per column;
+    // leaves |q[j+1]|^2 partials in part[(j+1)&1] like the sequential path
+    return qp::launch_mgs_lowsync(ctx->stream, q->Q, q->n, j, q->q(j + 1), q->md_part, q->gram, q->nvec, hcol,
+                                  q->hcoef, q->part + (size_t)((j + 1) & 1) * kRedBlocks, dt, q->n, &ctx->stats);
+  }
   for (int i = 0; i <= j + 1; ++i) {                                              // :84-87
     qp::MgsArgs a;
     a.w = q->q(j + 1);

@@ -346,6 +346,7 @@ __global__ __launch_bounds__(kThreads) void csr_spmv_kernel(const int64_t* __res
   finish_check(op, chk, nrm, lds);
 }
 
+int g_arnoldi_mode = 1;
 int g_rbcsr_variant = 7;  // tuning knob (qp_tuning_set); 7 = nt + early row-local loads + deep unroll (A/B in profiles/)
 
 int spmv_grid_size(const DevMatrix& A) {
@@ -636,6 +637,136 @@ int launch_combine_vecs(hipStream_t s, double2* out, int use_out, double2 s0, co
     if (st) st->n_launch++;
     if (lastc) break;
   }
+  return QP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Low-synchronisation modified Gram-Schmidt (one column in 3 launches instead of j+2).
+// MGS computes h_i = <q_i | w - sum_{k<i} h_k q_k> = c_i - sum_{k<i} <q_i|q_k> h_k with
+// c = Q^H w: given the classical inner products c and the Gram rows <q_i|q_k> of the
+// (not exactly orthogonal) basis, a triangular solve reproduces the MGS coefficients
+// (exactly in exact arithmetic, to rounding in floating point), and the projections are
+// then subtracted in the MGS order.  Kernel 1 (multidot) forms c and the new Gram row in
+// one pass over Q, kernel 2 (one workgroup) reduces the partials and solves, kernel 3
+// subtracts and accumulates |w|^2.
+// ---------------------------------------------------------------------------
+constexpr int kTI = 8;  // basis vectors per multidot tile (16 complex accumulators per lane)
+
+__global__ __launch_bounds__(kThreads) void multidot_kernel(const double2* __restrict__ Q, int64_t ldq, int j,
+                                                            const double2* __restrict__ w,
+                                                            double2* __restrict__ partials, int64_t n) {
+  __shared__ double2 lds[kThreads / 64];
+  const int i0 = blockIdx.y * kTI;
+  const int nv = 2 * (j + 1);
+  double2 ac[kTI], ag[kTI];
+#pragma unroll
+  for (int t = 0; t < kTI; ++t) ac[t] = ag[t] = make_double2(0.0, 0.0);
+  const double2* __restrict__ qj = Q + (size_t)j * ldq;
+  for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < n; e += (int64_t)kRedBlocks * kThreads) {
+    const double2 wv = w[e];
+    const double2 qv = qj[e];
+#pragma unroll
+    for (int t = 0; t < kTI; ++t) {
+      if (i0 + t <= j) {
+        const double2 qi = Q[(size_t)(i0 + t) * ldq + e];
+        const double2 a = cconj_mul(qi, wv);
+        const double2 b = cconj_mul(qi, qv);
+        ac[t].x += a.x;
+        ac[t].y += a.y;
+        ag[t].x += b.x;
+        ag[t].y += b.y;
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < kTI; ++t) {
+    if (i0 + t <= j) {
+      const double2 c = block_sum(ac[t], lds);
+      const double2 g = block_sum(ag[t], lds);
+      if (threadIdx.x == 0) {
+        partials[(size_t)blockIdx.x * nv + (i0 + t)] = c;
+        partials[(size_t)blockIdx.x * nv + (j + 1) + (i0 + t)] = g;
+      }
+    }
+  }
+}
+
+// one workgroup: reduce the multidot partials, store Gram row j, forward-substitute
+__global__ __launch_bounds__(kThreads) void mgs_solve_kernel(const double2* __restrict__ partials, int j,
+                                                             double2* __restrict__ G, int ldg,
+                                                             double2* __restrict__ hess_col,
+                                                             double2* __restrict__ coef, double dt) {
+  extern __shared__ double2 sm[];  // [0, nv): reduced values; [nv, nv + j + 1): h
+  const int nv = 2 * (j + 1);
+  double2* h = sm + nv;
+  for (int v = threadIdx.x; v < nv; v += kThreads) {
+    double2 s = make_double2(0.0, 0.0);
+    for (int b = 0; b < kRedBlocks; ++b) {
+      const double2 p = partials[(size_t)b * nv + v];
+      s.x += p.x;
+      s.y += p.y;
+    }
+    sm[v] = s;
+  }
+  __syncthreads();
+  // Gram row j:  G[j][k] = <q_j|q_k> = conj(<q_k|q_j>),  k < j
+  for (int k = threadIdx.x; k < j; k += kThreads) {
+    const double2 g = sm[(j + 1) + k];
+    G[(size_t)j * ldg + k] = make_double2(g.x, -g.y);
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    for (int i = 0; i <= j; ++i) {
+      double2 s = make_double2(0.0, 0.0);
+      for (int k = lane; k < i; k += 64) {
+        const double2 gik = (i == j) ? make_double2(sm[(j + 1) + k].x, -sm[(j + 1) + k].y) : G[(size_t)i * ldg + k];
+        cfma(s, gik, h[k]);
+      }
+      s.x = wave_sum(s.x);
+      s.y = wave_sum(s.y);
+      if (lane == 0) h[i] = make_double2(sm[i].x - s.x, sm[i].y - s.y);
+      __builtin_amdgcn_s_waitcnt(0);
+      __builtin_amdgcn_wave_barrier();
+    }
+    for (int i = lane; i <= j; i += 64) {
+      // Hess[i,j] = dt <q_i|q_j+1>;  axpy!(-Hess[i,j]/dt, q_i, q_j+1)   src/arnoldi.jl:85-86
+      const double2 hd = make_double2(dt * h[i].x, dt * h[i].y);
+      hess_col[i] = hd;
+      coef[i] = make_double2(-hd.x / dt, -hd.y / dt);
+    }
+  }
+}
+
+// w += sum_i coef[i] q_i (coefficients in device memory, applied in order), |w|^2 partials
+__global__ __launch_bounds__(kThreads) void mgs_update_kernel(double2* __restrict__ w, const double2* __restrict__ Q,
+                                                              int64_t ldq, int m, const double2* __restrict__ coef,
+                                                              double2* __restrict__ norm_partials, int64_t n) {
+  __shared__ double2 lds[kThreads / 64];
+  double nrm = 0.0;
+  for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < n; e += (int64_t)kRedBlocks * kThreads) {
+    double2 r = w[e];
+    for (int i = 0; i < m; ++i) cfma(r, coef[i], Q[(size_t)i * ldq + e]);
+    w[e] = r;
+    nrm += r.x * r.x + r.y * r.y;
+  }
+  const double2 t = block_sum(make_double2(nrm, 0.0), lds);
+  if (threadIdx.x == 0) norm_partials[blockIdx.x] = t;
+}
+
+int launch_mgs_lowsync(hipStream_t s, const double2* Q, int64_t ldq, int j, double2* w, double2* md_partials,
+                       double2* G, int ldg, double2* hess_col, double2* coef, double2* norm_partials, double dt,
+                       int64_t n, Stats* st) {
+  const int ntiles = (j + 1 + kTI - 1) / kTI;
+  hipLaunchKernelGGL(multidot_kernel, dim3(kRedBlocks, ntiles), dim3(kThreads), 0, s, Q, ldq, j, w, md_partials, n);
+  QP_HIP(hipGetLastError());
+  const size_t shmem = sizeof(double2) * (size_t)(3 * (j + 1));
+  hipLaunchKernelGGL(mgs_solve_kernel, dim3(1), dim3(kThreads), shmem, s, md_partials, j, G, ldg, hess_col, coef, dt);
+  QP_HIP(hipGetLastError());
+  hipLaunchKernelGGL(mgs_update_kernel, dim3(kRedBlocks), dim3(kThreads), 0, s, w, Q, ldq, j + 1, coef,
+                     norm_partials, n);
+  QP_HIP(hipGetLastError());
+  if (st) st->n_launch += 3;
   return QP_OK;
 }
 

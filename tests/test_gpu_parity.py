@@ -27,6 +27,14 @@ def ctx():
     c.close()
 
 
+@pytest.fixture(params=[1, 0], ids=["lowsync_mgs", "sequential_mgs"])
+def arnoldi_mode(request):
+    """Both orthogonalisation schedules of the engine must meet the same parity bar."""
+    L.tuning_set("arnoldi_mode", request.param)
+    yield request.param
+    L.tuning_set("arnoldi_mode", 1)
+
+
 def _rand_state(N, rng):
     psi = rng.standard_normal(N) + 1j * rng.standard_normal(N)
     return psi / np.linalg.norm(psi)
@@ -344,7 +352,7 @@ def test_cheby_term_row_partition(ctx):
 
 # ---------------------------------------------------------------- Arnoldi / Newton / specrange
 
-def test_arnoldi_matches_oracle(ctx):
+def test_arnoldi_matches_oracle(ctx, arnoldi_mode):
     rng = np.random.default_rng(41)
     N, m, dt = 500, 12, 0.37
     A = synth.sparse_random(N, 0.03, rng=rng)
@@ -373,7 +381,7 @@ def test_arnoldi_matches_oracle(ctx):
             assert np.max(np.abs(H2 - Href2)) < 1e-12
 
 
-def test_arnoldi_breakdown(ctx):
+def test_arnoldi_breakdown(ctx, arnoldi_mode):
     """Krylov dimension smaller than m: reduced m is returned (src/arnoldi.jl:91-95),
     also for negative dt."""
     N = 64
@@ -406,7 +414,7 @@ def _newton_case(ctx, A, psi0, dt, m_max, func=None, **kw):
     return psi.numpy(), ref, wrk, owrk
 
 
-def test_newton_hermitian(ctx):
+def test_newton_hermitian(ctx, arnoldi_mode):
     """test/test_newton.jl:7-67: N=1000 Hermitian rho=10, dt=0.5, m_max=5, 200 restarts."""
     rng = np.random.default_rng(42)
     N = 1000
@@ -421,7 +429,7 @@ def test_newton_hermitian(ctx):
     assert abs(np.linalg.norm(out) - 1) < 1e-10
 
 
-def test_newton_nonhermitian(ctx):
+def test_newton_nonhermitian(ctx, arnoldi_mode):
     """test/test_newton.jl:70-127: non-Hermitian rho=10, m_max=50; backward too."""
     rng = np.random.default_rng(43)
     N = 1000
@@ -451,7 +459,7 @@ def test_newton_liouvillian_custom_func(ctx, func):
     assert np.linalg.norm(rho.numpy() - sla.expm(Lm.toarray() * 0.5) @ rho0) < TOL
 
 
-def test_newton_c3_liouvillian(ctx):
+def test_newton_c3_liouvillian(ctx, arnoldi_mode):
     """BASELINE config C3 at oracle size: tridiagonal-system Liouvillian (n=24 -> N=576),
     m_max=20, several restarts; vs oracle and dense exp."""
     Lm = synth.liouvillian_tridiag(24)
@@ -483,7 +491,7 @@ def test_newton_eigenstate_and_errors(ctx):
         L.newton(psi, Op, 50.0, L.NewtonWrk(ctx, 50, m_max=3), max_restarts=1)
 
 
-def test_ritzvals_and_specrange(ctx):
+def test_ritzvals_and_specrange(ctx, arnoldi_mode):
     """test/test_specrad.jl:47-144 on the device, vs oracle (same start vector) and
     vs exact eigenvalues."""
     rng = np.random.default_rng(46)

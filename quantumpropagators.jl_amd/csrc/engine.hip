@@ -94,7 +94,7 @@ struct qp_krylov {
   double2* part = nullptr;      // 2 x kRedBlocks ping-pong partials
   double2* md_part = nullptr;   // kRedBlocks x 2 nvec multidot partials (low-sync MGS)
   double2* gram = nullptr;      // nvec x nvec Gram rows <q_i|q_k>, k < i
-  double2* hcoef = nullptr;     // nvec projection coefficients
+  double2* hcoef = nullptr;     // 2 nvec reduced inner products of the current column
   double2* q(int i) const { return Q + (size_t)i * n; }
 };
 
@@ -1188,7 +1188,7 @@ int qp_krylov_create(qp_ctx* ctx, int64_t n, int nvec, qp_krylov** out) {
   QP_CHECK(dev_alloc(&q->part, (size_t)2 * kRedBlocks));
   QP_CHECK(dev_alloc(&q->md_part, (size_t)kRedBlocks * 2 * nvec));
   QP_CHECK(dev_alloc(&q->gram, (size_t)nvec * nvec));
-  QP_CHECK(dev_alloc(&q->hcoef, (size_t)nvec));
+  QP_CHECK(dev_alloc(&q->hcoef, (size_t)2 * nvec));
   *out = q.release();
   return QP_OK;
   QP_CATCH

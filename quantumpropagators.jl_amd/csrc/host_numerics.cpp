@@ -173,23 +173,37 @@ void extend_leja(cplx* leja, int n, cplx* newpoints, int n_new, int n_use) {
     leja[0] = newpoints[u];
     i_add_start = 1;
   }
-  double exponent = 1.0 / (double)(n + n_use);
+  const double exponent = 1.0 / (double)(n + n_use);
+  // The reference recomputes p_i = prod_{j < n+i_add} |z_i - leja_j|^exponent from scratch
+  // for every i_add (O(m^3 n) pow calls -- the dominant host cost of a restart).  The
+  // product is a left-to-right chain over j, so caching it per candidate and appending
+  // one factor per new Leja point performs the identical sequence of multiplications:
+  // the selection is bit-for-bit the reference's at O(m^2 (n + m)) cost.
+  std::vector<double> prod((size_t)std::max(n_new, 1), 1.0);
+  int n_done = 0;  // number of Leja points already folded into prod[]
   for (int i_add = i_add_start; i_add < n_use; ++i_add) {
+    const int n_have = n + i_add;
+    for (int i = 0; i <= u - i_add; ++i) {
+      double p = prod[i];
+      for (int j = n_done; j < n_have; ++j) {
+        const double d = std::abs(newpoints[i] - leja[j]);
+        p = p * std::pow(d, exponent);
+      }
+      prod[i] = p;
+    }
+    n_done = n_have;
     double p_max = 0.0;
     int i_max = 0;
     for (int i = 0; i <= u - i_add; ++i) {
-      double p = 1.0;
-      for (int j = 0; j < n + i_add; ++j) {
-        double d = std::abs(newpoints[i] - leja[j]);
-        p = p * std::pow(d, exponent);
-      }
-      if (p > p_max) {
-        p_max = p;
+      if (prod[i] > p_max) {  // strict: first maximum wins (src/newton.jl:137-140)
+        p_max = prod[i];
         i_max = i;
       }
     }
     leja[n + i_add] = newpoints[i_max];
+    // remove the used point by replacing it with the last unused point (:145)
     newpoints[i_max] = newpoints[u - i_add];
+    prod[i_max] = prod[u - i_add];
   }
 }
 

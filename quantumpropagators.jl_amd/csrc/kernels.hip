@@ -691,62 +691,69 @@ __global__ __launch_bounds__(kThreads) void multidot_kernel(const double2* __res
   }
 }
 
-// one workgroup: reduce the multidot partials, store Gram row j, forward-substitute
-__global__ __launch_bounds__(kThreads) void mgs_solve_kernel(const double2* __restrict__ partials, int j,
-                                                             double2* __restrict__ G, int ldg,
-                                                             double2* __restrict__ hess_col,
-                                                             double2* __restrict__ coef, double dt) {
-  extern __shared__ double2 sm[];  // [0, nv): reduced values; [nv, nv + j + 1): h
+// one workgroup per value: sum the kRedBlocks multidot partials in a fixed order; the
+// workgroups of the Gram values also store row j:  G[j][k] = <q_j|q_k> = conj(<q_k|q_j>)
+__global__ __launch_bounds__(kThreads) void multidot_reduce_kernel(const double2* __restrict__ partials, int j,
+                                                                   double2* __restrict__ reduced,
+                                                                   double2* __restrict__ G, int ldg) {
+  __shared__ double2 lds[kThreads / 64];
+  static_assert(kRedBlocks == kThreads, "one partial per thread");
   const int nv = 2 * (j + 1);
-  double2* h = sm + nv;
-  for (int v = threadIdx.x; v < nv; v += kThreads) {
-    double2 s = make_double2(0.0, 0.0);
-    for (int b = 0; b < kRedBlocks; ++b) {
-      const double2 p = partials[(size_t)b * nv + v];
-      s.x += p.x;
-      s.y += p.y;
-    }
-    sm[v] = s;
+  const int v = blockIdx.x;
+  const double2 s = block_sum(partials[(size_t)threadIdx.x * nv + v], lds);
+  if (threadIdx.x == 0) {
+    reduced[v] = s;
+    const int k = v - (j + 1);
+    if (k >= 0 && k < j) G[(size_t)j * ldg + k] = make_double2(s.x, -s.y);
   }
-  __syncthreads();
-  // Gram row j:  G[j][k] = <q_j|q_k> = conj(<q_k|q_j>),  k < j
-  for (int k = threadIdx.x; k < j; k += kThreads) {
-    const double2 g = sm[(j + 1) + k];
-    G[(size_t)j * ldg + k] = make_double2(g.x, -g.y);
-  }
-  __syncthreads();
+}
+
+// Prologue (every workgroup, redundantly): forward substitution
+//   h_i = c_i - sum_{k<i} <q_i|q_k> h_k          (the MGS coefficients, see above)
+// by one wavefront, then  w -= sum_i (dt h_i / dt) q_i  in MGS order and |w|^2 partials.
+__global__ __launch_bounds__(kThreads) void mgs_update_kernel(double2* __restrict__ w, const double2* __restrict__ Q,
+                                                              int64_t ldq, int j, const double2* __restrict__ reduced,
+                                                              const double2* __restrict__ G, int ldg,
+                                                              double2* __restrict__ hess_col, double dt,
+                                                              double2* __restrict__ norm_partials, int64_t n) {
+  extern __shared__ double2 sm[];  // [0, j+1): h, then coefficients; [j+1, j+5): reduction scratch
+  double2* h = sm;
+  double2* lds = sm + (j + 1);
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
     for (int i = 0; i <= j; ++i) {
       double2 s = make_double2(0.0, 0.0);
       for (int k = lane; k < i; k += 64) {
-        const double2 gik = (i == j) ? make_double2(sm[(j + 1) + k].x, -sm[(j + 1) + k].y) : G[(size_t)i * ldg + k];
+        double2 gik;
+        if (i == j) {
+          const double2 g = reduced[(j + 1) + k];
+          gik = make_double2(g.x, -g.y);
+        } else {
+          gik = G[(size_t)i * ldg + k];
+        }
         cfma(s, gik, h[k]);
       }
       s.x = wave_sum(s.x);
       s.y = wave_sum(s.y);
-      if (lane == 0) h[i] = make_double2(sm[i].x - s.x, sm[i].y - s.y);
+      if (lane == 0) {
+        const double2 c = reduced[i];
+        h[i] = make_double2(c.x - s.x, c.y - s.y);
+      }
       __builtin_amdgcn_s_waitcnt(0);
       __builtin_amdgcn_wave_barrier();
     }
     for (int i = lane; i <= j; i += 64) {
       // Hess[i,j] = dt <q_i|q_j+1>;  axpy!(-Hess[i,j]/dt, q_i, q_j+1)   src/arnoldi.jl:85-86
       const double2 hd = make_double2(dt * h[i].x, dt * h[i].y);
-      hess_col[i] = hd;
-      coef[i] = make_double2(-hd.x / dt, -hd.y / dt);
+      if (blockIdx.x == 0) hess_col[i] = hd;
+      h[i] = make_double2(-hd.x / dt, -hd.y / dt);
     }
   }
-}
-
-// w += sum_i coef[i] q_i (coefficients in device memory, applied in order), |w|^2 partials
-__global__ __launch_bounds__(kThreads) void mgs_update_kernel(double2* __restrict__ w, const double2* __restrict__ Q,
-                                                              int64_t ldq, int m, const double2* __restrict__ coef,
-                                                              double2* __restrict__ norm_partials, int64_t n) {
-  __shared__ double2 lds[kThreads / 64];
+  __syncthreads();
   double nrm = 0.0;
   for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < n; e += (int64_t)kRedBlocks * kThreads) {
     double2 r = w[e];
-    for (int i = 0; i < m; ++i) cfma(r, coef[i], Q[(size_t)i * ldq + e]);
+    for (int i = 0; i <= j; ++i) cfma(r, h[i], Q[(size_t)i * ldq + e]);
     w[e] = r;
     nrm += r.x * r.x + r.y * r.y;
   }
@@ -755,16 +762,16 @@ __global__ __launch_bounds__(kThreads) void mgs_update_kernel(double2* __restric
 }
 
 int launch_mgs_lowsync(hipStream_t s, const double2* Q, int64_t ldq, int j, double2* w, double2* md_partials,
-                       double2* G, int ldg, double2* hess_col, double2* coef, double2* norm_partials, double dt,
+                       double2* G, int ldg, double2* hess_col, double2* reduced, double2* norm_partials, double dt,
                        int64_t n, Stats* st) {
   const int ntiles = (j + 1 + kTI - 1) / kTI;
   hipLaunchKernelGGL(multidot_kernel, dim3(kRedBlocks, ntiles), dim3(kThreads), 0, s, Q, ldq, j, w, md_partials, n);
   QP_HIP(hipGetLastError());
-  const size_t shmem = sizeof(double2) * (size_t)(3 * (j + 1));
-  hipLaunchKernelGGL(mgs_solve_kernel, dim3(1), dim3(kThreads), shmem, s, md_partials, j, G, ldg, hess_col, coef, dt);
+  hipLaunchKernelGGL(multidot_reduce_kernel, dim3(2 * (j + 1)), dim3(kThreads), 0, s, md_partials, j, reduced, G, ldg);
   QP_HIP(hipGetLastError());
-  hipLaunchKernelGGL(mgs_update_kernel, dim3(kRedBlocks), dim3(kThreads), 0, s, w, Q, ldq, j + 1, coef,
-                     norm_partials, n);
+  const size_t shmem = sizeof(double2) * (size_t)(j + 1 + kThreads / 64);
+  hipLaunchKernelGGL(mgs_update_kernel, dim3(kRedBlocks), dim3(kThreads), shmem, s, w, Q, ldq, j, reduced, G, ldg,
+                     hess_col, dt, norm_partials, n);
   QP_HIP(hipGetLastError());
   if (st) st->n_launch += 3;
   return QP_OK;

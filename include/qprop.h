@@ -66,7 +66,7 @@ enum { QP_VAL_C128 = 0, QP_VAL_F64 = 1 };
  * the position of its transpose and uses the complex conjugate (cheby! requires a
  * Hermitian H, src/cheby.jl:135), which removes ~40 % of the matrix bytes.  CSR = plain
  * CSR with a sub-wave per row.  AUTO: HRB when every term is exactly (bitwise) Hermitian,
- * else RBCSR; CSR when row-block padding would exceed 25 %.  An HRB operator that is given
+ * else RBCSR; CSR when row-block padding would exceed 50 %.  An HRB operator that is given
  * complex coefficients re-lays itself out as RBCSR. */
 enum { QP_FMT_AUTO = 0, QP_FMT_CSR = 1, QP_FMT_RBCSR = 2, QP_FMT_HRB = 3 };
 enum { QP_FUNC_EXPMI = 0,    /* z -> exp(-i z)   default of newton!, src/newton.jl:247 */
@@ -211,6 +211,10 @@ int qp_extend_newton_coeffs(qp_c128* a, int n_a, const qp_c128* leja, int func_i
 typedef struct {
   int restarts, n_a, n_leja, m_last, n_matvec;
   double radius, last_relerr, norm_psi;
+  /* host wall-clock breakdown of the call, milliseconds (replaces the TimerOutputs sections
+   * "arnoldi!", "diagonalize_hessenberg_matrix", "get Leja points", "get Newton coeffs",
+   * "evaluate polynomial" of src/newton.jl:276-343) */
+  double ms_arnoldi, ms_eig, ms_leja, ms_coeffs, ms_poly, ms_update;
 } qp_newton_stats;
 /* NewtonWrk(v0; m_max)  src/newton.jl:23-60 */
 int qp_newton_create(qp_ctx* ctx, int64_t n, int m_max, qp_newton** out);

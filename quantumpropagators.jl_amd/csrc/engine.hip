@@ -4,6 +4,7 @@
 // device work is stream-ordered, with host synchronisation only where the reference
 // algorithm needs a scalar on the host (once per Newton restart, once per Arnoldi call).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -652,7 +653,9 @@ static int choose_format(qp_operator* op, int requested, bool hermitian) {
     for (int64_t r = b * kRB; r < std::min(nrows, (b + 1) * kRB); ++r) w = std::max(w, ur[r + 1] - ur[r]);
     rb_stored += ((w + 3) & ~(int64_t)3) * kRB;
   }
-  const bool rb_ok = (double)rb_stored <= 1.25 * (double)nnz + 1024.0;
+  // the row-block kernels stream ~1.6x faster than the sub-wave CSR kernel at equal bytes
+  // (profiles/r01/kbench_*): accept up to 50 % padding before falling back
+  const bool rb_ok = (double)rb_stored <= 1.5 * (double)nnz + 1024.0;
   if (requested == QP_FMT_AUTO) {
     if (!rb_ok) return QP_FMT_CSR;
     if (!hermitian) return QP_FMT_RBCSR;
@@ -1444,9 +1447,16 @@ int qp_newton_step(qp_newton* w, qp_operator* op, qp_state* psi, double dt, int 
   QP_CHECK(dot_sync(ctx, w->v, w->v, w->n, &n2));
   double beta = std::sqrt(n2.real());                                                // :271
   QP_CHECK(qp::launch_scal(ctx->stream, w->v, make_double2(1.0 / beta, 0.0), w->n, &ctx->stats));  // :272
+  double ms_arnoldi = 0, ms_eig = 0, ms_leja = 0, ms_coeffs = 0, ms_poly = 0, ms_update = 0;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms_since = [](std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  };
   while (true) {                                                                     // :274
     int m_req = m;
+    auto t0 = now();
     QP_CHECK(qp_arnoldi(op, w->q, m_req, &vstate, dt, 1, norm_min, reinterpret_cast<qp_c128*>(Hess.data()), ldh, &m));
+    ms_arnoldi += ms_since(t0);
     n_matvec += m_req;
     if (m == 1 && s == 0) {                                                          // :289-295
       const cplx lam = beta * Hess[0];
@@ -1455,8 +1465,10 @@ int qp_newton_step(qp_newton* w, qp_operator* op, qp_state* psi, double dt, int 
       break;
     }
     ritz.assign((size_t)m * (m + 1) / 2, cplx(0));
+    t0 = now();
     if (qp::diagonalize_hessenberg(Hess.data(), ldh, m, true, ritz.data()) != QP_OK)  // :297
       return qp::fail(QP_E_INTERNAL, "Hessenberg QR did not converge");
+    ms_eig += ms_since(t0);
     if (s == 0) {                                                                    // :301-303, :67-70
       double rmax = 0;
       for (auto& z : ritz) rmax = std::max(rmax, std::abs(z));
@@ -1464,16 +1476,21 @@ int qp_newton_step(qp_newton* w, qp_operator* op, qp_state* psi, double dt, int 
     }
     const int n_s = n_leja;                                                          // :307
     if ((int)w->leja.size() < n_leja + m) w->leja.resize((size_t)2 * (n_leja + m), cplx(0));  // :105-110
+    t0 = now();
     qp::extend_leja(w->leja.data(), n_leja, ritz.data(), (int)ritz.size(), m);
+    ms_leja += ms_since(t0);
     n_leja += m;
     if ((int)w->a.size() < n_leja) w->a.resize((size_t)2 * n_leja, cplx(0));         // :187-192
     {
+      t0 = now();
       int st = qp::extend_newton_coeffs(w->a.data(), n_a, w->leja.data(), func_id, cb, user, n_leja, w->radius);  // :314
+      ms_coeffs += ms_since(t0);
       if (st == QP_E_DIVDIFF_UNDERFLOW) return qp::fail(st, "Divided differences too small");
       if (st != QP_OK) return qp::fail(st, "extend_newton_coeffs failed (radius=%g)", w->radius);
       n_a = n_leja;
     }
     // Newton polynomial in the extended Hessenberg matrix                           :328-343
+    t0 = now();
     const int mp = m + 1;
     R.assign(mp, cplx(0));
     P.assign(mp, cplx(0));
@@ -1492,6 +1509,8 @@ int qp_newton_step(qp_newton* w, qp_operator* op, qp_state* psi, double dt, int 
       apply(w->leja[n_s + k - 1]);
       for (int i = 0; i < mp; ++i) P[i] += w->a[n_s + k] * R[i];
     }
+    ms_poly += ms_since(t0);
+    t0 = now();
     // Psi = (s == 0 ? 0 : Psi) + sum_i P_i q_i                                      :346-352
     QP_CHECK(qp::launch_combine_vecs(ctx->stream, psi->d, s == 0 ? 0 : 1, make_double2(1.0, 0.0), w->q->q(0), w->n, m,
                                      reinterpret_cast<const double2*>(P.data()), w->npart, w->n, &ctx->stats));
@@ -1509,6 +1528,7 @@ int qp_newton_step(qp_newton* w, qp_operator* op, qp_state* psi, double dt, int 
                                      reinterpret_cast<const double2*>(R.data() + 1), nullptr, w->n, &ctx->stats));
     QP_HIP(hipStreamSynchronize(ctx->stream));
     norm_psi = std::sqrt(sum_partials(w->h_npart).real());
+    ms_update += ms_since(t0);
     last_relerr = beta * std::abs(w->a[n_a - 1]) / (1 + norm_psi);                    // :370
     if (last_relerr < relerr) break;
     s += 1;
@@ -1531,6 +1551,12 @@ int qp_newton_step(qp_newton* w, qp_operator* op, qp_state* psi, double dt, int 
     stats->radius = w->radius;
     stats->last_relerr = last_relerr;
     stats->norm_psi = norm_psi;
+    stats->ms_arnoldi = ms_arnoldi;
+    stats->ms_eig = ms_eig;
+    stats->ms_leja = ms_leja;
+    stats->ms_coeffs = ms_coeffs;
+    stats->ms_poly = ms_poly;
+    stats->ms_update = ms_update;
   }
   return QP_OK;
   QP_CATCH

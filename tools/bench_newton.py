@@ -53,11 +53,14 @@ def main():
     ctx.sync()
     ctx.reset_stats()
     restarts, matvecs = 0, 0
+    host = {k: 0.0 for k in ("ms_arnoldi", "ms_eig", "ms_leja", "ms_coeffs", "ms_poly", "ms_update")}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         L.newton(psi, op, args.dt, wrk)
         restarts += wrk.restarts + 1          # Arnoldi sweeps = restarts + 1
         matvecs += wrk.stats["n_matvec"]
+        for k in host:
+            host[k] += wrk.stats[k]
     ctx.sync()
     el = time.perf_counter() - t0
     st = ctx.stats()
@@ -78,6 +81,7 @@ def main():
         "roofline": {"bound": "hbm (launch-latency limited at this N)", "achieved": sweep_bytes * sweeps_per_s / 1e9,
                      "peak": 8000.0, "unit": "GB/s", "frac": sweep_bytes * sweeps_per_s / 1e9 / 8000.0,
                      "algorithmic_bytes_per_sweep": sweep_bytes},
+        "host_ms_per_step": {k: v / args.steps for k, v in host.items()},
         "norm": psi.norm(), "parity_l2_vs_oracle_one_step": parity}))
 
 

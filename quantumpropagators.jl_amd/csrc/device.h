@@ -53,6 +53,17 @@ struct ChebyEpi {
   double2 phase;
   int apply_phase;
   double* check_partials;  // nullable: per-workgroup {Re<v1,t>, Im<v1,t>, |v1|^2}
+  // fused pack for the multi-GPU exchange: rows with mirror[slot] >= 0 also store the new
+  // term vector into slab[mirror[slot]] (slot = 64 * position-in-row-set + lane)
+  const int32_t* mirror = nullptr;
+  double2* slab = nullptr;
+};
+
+// a subset of the 64-row blocks of an operator (device list), optionally with a mirror map
+struct RowSet {
+  const int32_t* block_map = nullptr;  // nullptr = all blocks
+  int64_t nmap = 0;
+  bool count = true;                   // count this launch as a mat-vec in the stats
 };
 
 struct PlainEpi {
@@ -66,7 +77,8 @@ struct Stats {
   double spmv_bytes = 0;
 };
 
-int launch_spmv_cheby(hipStream_t s, const DevMatrix& A, const double2* x, const ChebyEpi& e, Stats* st);
+int launch_spmv_cheby(hipStream_t s, const DevMatrix& A, const double2* x, const ChebyEpi& e, Stats* st,
+                      const RowSet* rs = nullptr);
 int launch_spmv_plain(hipStream_t s, const DevMatrix& A, const double2* x, const PlainEpi& e, Stats* st);
 int spmv_grid_size(const DevMatrix& A);
 extern int g_rbcsr_variant;

@@ -85,6 +85,15 @@ struct qp_operator {
   cplx scale = 1.0;
 };
 
+struct qp_split {   // boundary / interior partition of an operator's row blocks (multi-GPU overlap)
+  qp_operator* op = nullptr;
+  int32_t* bmap_boundary = nullptr;
+  int32_t* bmap_interior = nullptr;
+  int32_t* mirror = nullptr;          // 64 * n_boundary entries: slab position or -1
+  int64_t n_boundary = 0, n_interior = 0, nsend = 0;
+  hipEvent_t ev_b = nullptr, ev_i = nullptr;
+};
+
 struct qp_krylov {
   qp_ctx* ctx;
   int64_t n;
@@ -1170,6 +1179,124 @@ int qp_cheby_step(qp_cheby* w, qp_operator* op, qp_state* psi, const double* a, 
         return qp::fail(QP_E_NORMALIZATION, "Incorrect normalization (E_min=%g, Delta=%g)", E_min, Delta);
     }
   }
+  return QP_OK;
+  QP_CATCH
+}
+
+// ---------------------------------------------------------------------------
+// boundary / interior split of one fused term (overlap of the multi-GPU exchange)
+// ---------------------------------------------------------------------------
+int qp_split_create(qp_operator* op, const int64_t* send_rows, int64_t nsend, qp_split** out) {
+  QP_TRY
+  if (!op || !out || nsend < 0 || (nsend > 0 && !send_rows)) return qp::fail(QP_E_BAD_ARG, "qp_split_create: bad arguments");
+  const DevMatrix& A = op->A;
+  if (A.format != QP_FMT_RBCSR && A.format != QP_FMT_HRB)
+    return qp::fail(QP_E_BAD_ARG, "qp_split_create needs a row-block device format (got %d)", A.format);
+  QP_CHECK(use(op->ctx));
+  const auto& ur = op->u_rowptr;
+  const auto& uc = op->u_col;
+  std::vector<char> is_boundary((size_t)A.nblocks, 0);
+  std::vector<int32_t> slot_of_row((size_t)A.nrows, -1);
+  for (int64_t i = 0; i < nsend; ++i) {
+    const int64_t r = send_rows[i];
+    if (r < 0 || r >= A.nrows) return qp::fail(QP_E_BAD_ARG, "send row %lld out of range", (long long)r);
+    if (slot_of_row[r] >= 0) return qp::fail(QP_E_BAD_ARG, "send row %lld listed twice", (long long)r);
+    slot_of_row[r] = (int32_t)i;
+    is_boundary[r / kRB] = 1;
+  }
+  for (int64_t r = 0; r < A.nrows; ++r)   // rows that read a ghost column must wait for the exchange
+    if (ur[r + 1] > ur[r] && uc[ur[r + 1] - 1] >= A.nrows) is_boundary[r / kRB] = 1;
+  std::vector<int32_t> bb, bi;
+  for (int64_t b = 0; b < A.nblocks; ++b) (is_boundary[b] ? bb : bi).push_back((int32_t)b);
+  std::vector<int32_t> mirror(bb.size() * kRB + 1, -1);
+  for (size_t k = 0; k < bb.size(); ++k)
+    for (int l = 0; l < kRB; ++l) {
+      const int64_t r = (int64_t)bb[k] * kRB + l;
+      if (r < A.nrows) mirror[k * kRB + l] = slot_of_row[r];
+    }
+  auto sp = std::make_unique<qp_split>();
+  sp->op = op;
+  sp->n_boundary = (int64_t)bb.size();
+  sp->n_interior = (int64_t)bi.size();
+  sp->nsend = nsend;
+  QP_CHECK(dev_alloc(&sp->bmap_boundary, bb.size()));
+  QP_CHECK(dev_alloc(&sp->bmap_interior, bi.size()));
+  QP_CHECK(dev_alloc(&sp->mirror, mirror.size()));
+  if (!bb.empty()) QP_HIP(hipMemcpy(sp->bmap_boundary, bb.data(), bb.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (!bi.empty()) QP_HIP(hipMemcpy(sp->bmap_interior, bi.data(), bi.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  QP_HIP(hipMemcpy(sp->mirror, mirror.data(), mirror.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  QP_HIP(hipEventCreateWithFlags(&sp->ev_b, hipEventDisableTiming));
+  QP_HIP(hipEventCreateWithFlags(&sp->ev_i, hipEventDisableTiming));
+  *out = sp.release();
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_split_destroy(qp_split* sp) {
+  QP_TRY
+  if (!sp) return QP_OK;
+  (void)hipSetDevice(sp->op->ctx->device);
+  (void)hipDeviceSynchronize();
+  if (sp->bmap_boundary) (void)hipFree(sp->bmap_boundary);
+  if (sp->bmap_interior) (void)hipFree(sp->bmap_interior);
+  if (sp->mirror) (void)hipFree(sp->mirror);
+  if (sp->ev_b) (void)hipEventDestroy(sp->ev_b);
+  if (sp->ev_i) (void)hipEventDestroy(sp->ev_i);
+  delete sp;
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_split_info(const qp_split* sp, int64_t* n_boundary_blocks, int64_t* n_interior_blocks) {
+  if (!sp) return qp::fail(QP_E_BAD_ARG, "split is NULL");
+  if (n_boundary_blocks) *n_boundary_blocks = sp->n_boundary;
+  if (n_interior_blocks) *n_interior_blocks = sp->n_interior;
+  return QP_OK;
+}
+
+int qp_cheby_term_split(qp_operator* op, qp_split* sp, void* boundary_stream, int first, const qp_state* x,
+                        int64_t xoff, const qp_state* v0, qp_state* vout, const qp_state* acc_in, qp_state* acc_out,
+                        qp_state* slab, qp_c128 c, double beta, double a_prev, double a, qp_c128 phase) {
+  QP_TRY
+  if (!op || !sp || sp->op != op || !boundary_stream || !x || !acc_out)
+    return qp::fail(QP_E_BAD_ARG, "qp_cheby_term_split: bad arguments");
+  const int64_t nr = op->A.nrows;
+  if (x->n != op->A.ncols || xoff < 0 || xoff + nr > x->n) return qp::fail(QP_E_BAD_ARG, "qp_cheby_term_split: x shape / offset mismatch");
+  if ((v0 && v0->n != nr) || (vout && vout->n != nr) || (acc_in && acc_in->n != nr) || acc_out->n != nr)
+    return qp::fail(QP_E_BAD_ARG, "qp_cheby_term_split: local vector length mismatch");
+  if (slab && slab->n < sp->nsend) return qp::fail(QP_E_BAD_ARG, "qp_cheby_term_split: slab too small");
+  qp_ctx* ctx = op->ctx;
+  QP_CHECK(use(ctx));
+  hipStream_t S_c = ctx->stream, S_x = (hipStream_t)boundary_stream;
+  qp::ChebyEpi e;
+  e.xloc = x->d + xoff;
+  e.v0 = v0 ? v0->d : nullptr;
+  e.vout = vout ? vout->d : nullptr;
+  e.acc_in = acc_in ? acc_in->d : nullptr;
+  e.acc_out = acc_out->d;
+  e.c = d2(c);
+  e.beta = beta;
+  e.a_prev = a_prev;
+  e.a = a;
+  e.phase = d2(phase);
+  e.apply_phase = !(phase.re == 1.0 && phase.im == 0.0);
+  e.check_partials = nullptr;
+  if (!first) {
+    // boundary(m) overwrites rows that interior(m-1) gathered from, and vice versa
+    QP_HIP(hipStreamWaitEvent(S_x, sp->ev_i, 0));
+    QP_HIP(hipStreamWaitEvent(S_c, sp->ev_b, 0));
+  }
+  qp::RowSet rb{sp->bmap_boundary, sp->n_boundary, false};
+  qp::RowSet ri{sp->bmap_interior, sp->n_interior, true};
+  qp::ChebyEpi eb = e;
+  if (slab && vout) {   // the slab carries the new term vector (what the next term gathers)
+    eb.mirror = sp->mirror;
+    eb.slab = slab->d;
+  }
+  if (sp->n_boundary > 0) QP_CHECK(qp::launch_spmv_cheby(S_x, op->A, x->d, eb, &ctx->stats, &rb));
+  QP_HIP(hipEventRecord(sp->ev_b, S_x));
+  if (sp->n_interior > 0) QP_CHECK(qp::launch_spmv_cheby(S_c, op->A, x->d, e, &ctx->stats, &ri));
+  QP_HIP(hipEventRecord(sp->ev_i, S_c));
   return QP_OK;
   QP_CATCH
 }

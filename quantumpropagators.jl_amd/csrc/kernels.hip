@@ -82,7 +82,8 @@ struct ChebyOp {
     p.acc = e.acc_in ? e.acc_in[i] : make_double2(0.0, 0.0);
     return p;
   }
-  __device__ __forceinline__ void row(int64_t i, double2 s, const Pre& p, double2& chk, double& nrm) const {
+  __device__ __forceinline__ void row(int64_t i, double2 s, const Pre& p, double2& chk, double& nrm,
+                                      int64_t slot) const {
     const double2 xi = p.xi;
     // t = c * (s - beta * x_i) [+ v0_i]        src/cheby.jl:178-179, :192-193, :202
     double2 t = make_double2(fma(-e.beta, xi.x, s.x), fma(-e.beta, xi.y, s.y));
@@ -98,6 +99,10 @@ struct ChebyOp {
       t.y += p.v0.y;
     }
     if (e.vout) e.vout[i] = t;
+    if (e.mirror) {
+      const int sp = e.mirror[slot];
+      if (sp >= 0) e.slab[sp] = t;
+    }
     double2 r;
     if (e.acc_in) {
       r = p.acc;
@@ -121,7 +126,7 @@ struct PlainOp {
     p.y = e.beta_zero ? make_double2(0.0, 0.0) : e.y[i];
     return p;
   }
-  __device__ __forceinline__ void row(int64_t i, double2 s, const Pre& p, double2&, double&) const {
+  __device__ __forceinline__ void row(int64_t i, double2 s, const Pre& p, double2&, double&, int64_t) const {
     double2 r = cmul(e.alpha, s);
     if (!e.beta_zero) {
       const double2 by = cmul(e.beta, p.y);
@@ -183,7 +188,8 @@ __global__ __launch_bounds__(kThreads) void rbcsr_spmv_kernel(const int64_t* __r
                                                               const int4* __restrict__ cols4,
                                                               const double2* __restrict__ vals,
                                                               const double2* __restrict__ x,
-                                                              int64_t nblocks, int64_t nrows, Op op) {
+                                                              int64_t nblocks, int64_t nrows, Op op,
+                                                              const int32_t* __restrict__ block_map) {
   constexpr bool NT = (VAR & 1) != 0;
   constexpr bool PRE = (VAR & 2) != 0;
   constexpr int UNR = (VAR & 4) ? 4 : 2;
@@ -191,10 +197,11 @@ __global__ __launch_bounds__(kThreads) void rbcsr_spmv_kernel(const int64_t* __r
   const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  const int64_t b = (int64_t)wg * (kThreads / 64) + wave;
+  const int64_t idx = (int64_t)wg * (kThreads / 64) + wave;  // position in the row set
   double2 chk = make_double2(0.0, 0.0);
   double nrm = 0.0;
-  if (b < nblocks) {
+  if (idx < nblocks) {
+    const int64_t b = block_map ? (int64_t)block_map[idx] : idx;
     const int64_t base = bptr[b];
     const int nq = (int)((bptr[b + 1] - base) >> 8);  // width / 4
     const double2* __restrict__ v = vals + base + lane;
@@ -221,7 +228,7 @@ __global__ __launch_bounds__(kThreads) void rbcsr_spmv_kernel(const int64_t* __r
       cfma(s1, a3, x3);
     }
     if (!PRE) pre = op.pre(rowc);
-    if (row < nrows) op.row(row, make_double2(s0.x + s1.x, s0.y + s1.y), pre, chk, nrm);
+    if (row < nrows) op.row(row, make_double2(s0.x + s1.x, s0.y + s1.y), pre, chk, nrm, idx * kRB + lane);
   }
   finish_check(op, chk, nrm, lds);
 }
@@ -253,7 +260,8 @@ __global__ __launch_bounds__(kThreads) void hrb_spmv_kernel(const int64_t* __res
                                                             const int4* __restrict__ lcols4,
                                                             const int4* __restrict__ lpos4,
                                                             const double2* __restrict__ x, int64_t nblocks,
-                                                            int64_t nrows, Op op) {
+                                                            int64_t nrows, Op op,
+                                                            const int32_t* __restrict__ block_map) {
   constexpr bool NT = (VAR & 1) != 0;
   constexpr bool PRE = (VAR & 2) != 0;
   constexpr int UNR = (VAR & 4) ? 2 : 1;
@@ -261,10 +269,11 @@ __global__ __launch_bounds__(kThreads) void hrb_spmv_kernel(const int64_t* __res
   const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  const int64_t b = (int64_t)wg * (kThreads / 64) + wave;
+  const int64_t idx = (int64_t)wg * (kThreads / 64) + wave;  // position in the row set
   double2 chk = make_double2(0.0, 0.0);
   double nrm = 0.0;
-  if (b < nblocks) {
+  if (idx < nblocks) {
+    const int64_t b = block_map ? (int64_t)block_map[idx] : idx;
     const int64_t ubase = uptr[b], lbase = lptr[b];
     const int nuq = (int)((uptr[b + 1] - ubase) >> 8);
     const int nlq = (int)((lptr[b + 1] - lbase) >> 8);
@@ -311,7 +320,7 @@ __global__ __launch_bounds__(kThreads) void hrb_spmv_kernel(const int64_t* __res
       cfma(s1, a3, x3);
     }
     if (!PRE) pre = op.pre(rowc);
-    if (row < nrows) op.row(row, make_double2(s0.x + s1.x, s0.y + s1.y), pre, chk, nrm);
+    if (row < nrows) op.row(row, make_double2(s0.x + s1.x, s0.y + s1.y), pre, chk, nrm, idx * kRB + lane);
   }
   finish_check(op, chk, nrm, lds);
 }
@@ -342,7 +351,7 @@ __global__ __launch_bounds__(kThreads) void csr_spmv_kernel(const int64_t* __res
   }
   double2 chk = make_double2(0.0, 0.0);
   double nrm = 0.0;
-  if (row < nrows && tl == 0) op.row(row, s, op.pre(row), chk, nrm);
+  if (row < nrows && tl == 0) op.row(row, s, op.pre(row), chk, nrm, row);
   finish_check(op, chk, nrm, lds);
 }
 
@@ -356,14 +365,24 @@ int spmv_grid_size(const DevMatrix& A) {
 }
 
 template <class Op>
-static int launch_spmv(hipStream_t s, const DevMatrix& A, const double2* x, const Op& op, Stats* st) {
+static int launch_spmv(hipStream_t s, const DevMatrix& A, const double2* x, const Op& op, Stats* st,
+                       const RowSet* rs = nullptr) {
   if (A.nrows == 0) return QP_OK;
-  const int grid = spmv_grid_size(A);
+  int grid = spmv_grid_size(A);
+  const int32_t* bmap = nullptr;
+  int64_t nblk = A.nblocks;
+  if (rs && rs->block_map) {
+    if (A.format != QP_FMT_RBCSR && A.format != QP_FMT_HRB) return fail(QP_E_BAD_ARG, "row sets need a row-block format");
+    bmap = rs->block_map;
+    nblk = rs->nmap;
+    if (nblk == 0) return QP_OK;
+    grid = (int)((nblk + kThreads / 64 - 1) / (kThreads / 64));
+  }
   if (A.format == QP_FMT_RBCSR) {
 #define QP_RB_CASE(VV)                                                                                   \
   case VV:                                                                                               \
     hipLaunchKernelGGL((rbcsr_spmv_kernel<Op, VV>), dim3(grid), dim3(kThreads), 0, s, A.bptr,            \
-                       reinterpret_cast<const int4*>(A.cols), A.vals, x, A.nblocks, A.nrows, op);        \
+                       reinterpret_cast<const int4*>(A.cols), A.vals, x, nblk, A.nrows, op, bmap);          \
     break;
     switch (g_rbcsr_variant & 7) {
       QP_RB_CASE(0)
@@ -382,7 +401,7 @@ static int launch_spmv(hipStream_t s, const DevMatrix& A, const double2* x, cons
     hipLaunchKernelGGL((hrb_spmv_kernel<Op, VV>), dim3(grid), dim3(kThreads), 0, s, A.bptr,              \
                        reinterpret_cast<const int4*>(A.cols), A.vals, A.lptr,                            \
                        reinterpret_cast<const int4*>(A.lcols), reinterpret_cast<const int4*>(A.lpos), x, \
-                       A.nblocks, A.nrows, op);                                                          \
+                       nblk, A.nrows, op, bmap);                                                         \
     break;
     switch (g_rbcsr_variant & 7) {
       QP_HRB_CASE(0)
@@ -416,16 +435,18 @@ static int launch_spmv(hipStream_t s, const DevMatrix& A, const double2* x, cons
   QP_HIP(hipGetLastError());
   if (st) {
     st->n_launch++;
-    st->n_matvec++;
+    if (!rs || rs->count) st->n_matvec++;
   }
   return QP_OK;
 }
 
-int launch_spmv_cheby(hipStream_t s, const DevMatrix& A, const double2* x, const ChebyEpi& e, Stats* st) {
+int launch_spmv_cheby(hipStream_t s, const DevMatrix& A, const double2* x, const ChebyEpi& e, Stats* st,
+                      const RowSet* rs) {
   ChebyOp op{e};
-  int rc = launch_spmv(s, A, x, op, st);
+  int rc = launch_spmv(s, A, x, op, st, rs);
   // algorithmic bytes, SURVEY 8d: z (V + 4) N + 4 (N + 1) + 5 * 16 N
-  if (st && rc == QP_OK) st->spmv_bytes += 20.0 * (double)A.nnz + 4.0 * (double)(A.nrows + 1) + 80.0 * (double)A.nrows;
+  if (st && rc == QP_OK && (!rs || rs->count))
+    st->spmv_bytes += 20.0 * (double)A.nnz + 4.0 * (double)(A.nrows + 1) + 80.0 * (double)A.nrows;
   return rc;
 }
 

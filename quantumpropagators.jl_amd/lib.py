@@ -120,6 +120,11 @@ SIGNATURES = {
                                 C.c_double, C.c_double, C.c_int]),
     "qp_cheby_term": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, _P, qp_c128, C.c_double, C.c_double,
                                 C.c_double, qp_c128]),
+    "qp_split_create": (C.c_int, [_P, _i64p, C.c_int64, C.POINTER(_P)]),
+    "qp_split_destroy": (C.c_int, [_P]),
+    "qp_split_info": (C.c_int, [_P, _i64p, _i64p]),
+    "qp_cheby_term_split": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_int64, _P, _P, _P, _P, _P, qp_c128, C.c_double,
+                                      C.c_double, C.c_double, qp_c128]),
     "qp_krylov_create": (C.c_int, [_P, C.c_int64, C.c_int, C.POINTER(_P)]),
     "qp_krylov_destroy": (C.c_int, [_P]),
     "qp_krylov_download": (C.c_int, [_P, C.c_int, _cp]),
@@ -566,6 +571,40 @@ def cheby_term(H, x, xoff, v0, vout, acc_in, acc_out, c, beta, a_prev, a, phase=
                             vout._h if vout is not None else None,
                             acc_in._h if acc_in is not None else None, acc_out._h, c128(c), float(beta),
                             float(a_prev), float(a), c128(phase)))
+
+
+class Split:
+    """Boundary / interior partition of an operator's row blocks (multi-GPU overlap)."""
+
+    def __init__(self, op, send_rows):
+        self.op, self.lib = op, op.lib
+        rows = np.ascontiguousarray(send_rows, dtype=np.int64)
+        self._h = _P()
+        check(self.lib.qp_split_create(op._h, _ptr(rows, _i64p), len(rows), C.byref(self._h)))
+        nb, ni = C.c_int64(), C.c_int64()
+        check(self.lib.qp_split_info(self._h, C.byref(nb), C.byref(ni)))
+        self.n_boundary, self.n_interior = nb.value, ni.value
+        op.ctx._adopt(self)
+
+    def close(self):
+        if self._h:
+            self.lib.qp_split_destroy(self._h)
+            self._h = _P()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def cheby_term_split(H, split, boundary_stream, first, x, xoff, v0, vout, acc_in, acc_out, slab, c, beta, a_prev, a,
+                     phase=1.0):
+    check(H.lib.qp_cheby_term_split(H._h, split._h, _P(boundary_stream), int(bool(first)), x._h, int(xoff),
+                                    v0._h if v0 is not None else None, vout._h if vout is not None else None,
+                                    acc_in._h if acc_in is not None else None, acc_out._h,
+                                    slab._h if slab is not None else None, c128(c), float(beta), float(a_prev),
+                                    float(a), c128(phase)))
 
 
 class Krylov:

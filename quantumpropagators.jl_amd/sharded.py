@@ -95,6 +95,27 @@ class HipBackend:
     def term(self, op, x, xoff, v0, vout, acc_in, acc_out, c, beta, a_prev, a, phase):
         L.cheby_term(op, x, xoff, v0, vout, acc_in, acc_out, c, beta, a_prev, a, phase)
 
+    # ---- overlap of the exchange with compute (boundary rows on a side stream) ----
+    def make_split(self, op, send_rows):
+        if op.format not in (L.FMT_RBCSR, L.FMT_HRB):
+            return None
+        return L.Split(op, send_rows)
+
+    def new_stream(self):
+        return self.torch.cuda.Stream(device=self.device)
+
+    def stream(self, s):
+        return self.torch.cuda.stream(s)
+
+    def join(self, s):
+        cur = self.torch.cuda.current_stream(self.device)
+        s.wait_stream(cur)
+        cur.wait_stream(s)
+
+    def term_split(self, op, split, side, first, x, xoff, v0, vout, acc_in, acc_out, slab, c, beta, a_prev, a, phase):
+        L.cheby_term_split(op, split, side.cuda_stream, first, x, xoff, v0, vout, acc_in, acc_out, slab, c, beta,
+                           a_prev, a, phase)
+
     def write(self, t, lo, arr):
         arr = np.ascontiguousarray(arr, dtype=np.complex128)
         t[2 * lo: 2 * (lo + len(arr))].copy_(self.torch.from_numpy(arr.view(np.float64)))
@@ -109,7 +130,8 @@ class ShardedCheby:
     ``rowptr, col, vals``: the local rows [r0, r1) in CSR with *global* column indices."""
 
     def __init__(self, ctx, rowptr, col, vals, N, r0, r1, Delta, E_min, dt, fmt=L.FMT_AUTO,
-                 exchange="auto", group=None, backend=None, limit=1e-12):
+                 exchange="auto", group=None, backend=None, limit=1e-12, overlap=True,
+                 _debug_send_rows=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
@@ -151,13 +173,15 @@ class ShardedCheby:
                 send_lists.append(np.unique(np.concatenate(parts)) if parts else np.zeros(0, dtype=np.int64))
         else:
             send_lists = [np.arange(bounds[o], bounds[o + 1], dtype=np.int64) for o in range(self.world)]
+        if _debug_send_rows is not None:     # single-rank tests of the pack / overlap machinery
+            send_lists = [np.asarray(_debug_send_rows, dtype=np.int64) + self.r0]
         self.send_lists = send_lists
-        self.M = M = int(max(len(s) for s in send_lists)) if self.world > 1 else 0
+        self.M = M = int(max(len(s) for s in send_lists)) if (self.world > 1 or _debug_send_rows is not None) else 0
         self.send_idx_host = send_lists[self.rank] - self.r0
         assert np.all((self.send_idx_host >= 0) & (self.send_idx_host < nloc))
         # the slice itself is the send buffer when every row is sent and blocks are equal
         self.direct_send = (exchange == "allgather" and len(self.send_idx_host) == nloc and M == nloc)
-        self.ncols_local = nloc + self.world * M if self.world > 1 else nloc
+        self.ncols_local = nloc + self.world * M
         lcol = remap_columns(col, self.r0, self.r1, bounds, send_lists, M)
 
         # ---- device data ----
@@ -168,11 +192,22 @@ class ShardedCheby:
         self.Xfull = [be.view(x, 0, self.ncols_local) for x in self.X]
         self.Xloc = [be.view(x, 0, nloc) for x in self.X]
         self.acc = be.view(self.acc_t, 0, nloc)
-        if self.world > 1 and not self.direct_send:
+        self.exchanging = M > 0
+        self.split = None
+        if self.exchanging and not self.direct_send:
             self.slab = be.zeros(M)
+            self.slab_state = be.view(self.slab, 0, M)
             idx = np.zeros(M, dtype=np.int64)            # padded with row 0 (never read by anyone)
             idx[: len(self.send_idx_host)] = self.send_idx_host
             self.send_idx = be.index(idx)
+            # overlap: the few row blocks that feed or read the exchange run on a side stream,
+            # so the all-gather of term m hides behind the interior rows of term m
+            if overlap and hasattr(be, "make_split"):
+                self.split = be.make_split(self.op, self.send_idx_host)
+                if self.split is not None and self.split.n_interior == 0:
+                    self.split = None
+                if self.split is not None:
+                    self.side = be.new_stream()
         self.n_exchanges = 0
 
     # the state lives in X[0][:nloc]
@@ -183,9 +218,10 @@ class ShardedCheby:
     def local_state(self):
         return self.be.read(self.X[0], 0, self.nloc)
 
-    def _exchange(self, k):
-        """Fill the ghost slots of X[k] with the other ranks' rows of the same vector."""
-        if self.world == 1:
+    def _exchange(self, k, packed=False):
+        """Fill the ghost slots of X[k] with the other ranks' rows of the same vector.
+        ``packed``: the slab already holds the send rows (fused pack of the term kernel)."""
+        if not self.exchanging:
             return
         x = self.X[k]
         nloc = self.nloc
@@ -193,12 +229,15 @@ class ShardedCheby:
             send = x[: 2 * nloc]
         else:
             send = self.slab
-            self.torch.index_select(x[: 2 * nloc].view(-1, 2), 0, self.send_idx, out=send.view(-1, 2))
+            if not packed:
+                self.torch.index_select(x[: 2 * nloc].view(-1, 2), 0, self.send_idx, out=send.view(-1, 2))
         self.dist.all_gather_into_tensor(x[2 * nloc:], send, group=self.group)
         self.n_exchanges += 1
 
     def step(self, backward=False):
         """One ``cheby!`` (src/cheby.jl:150-213) on the partitioned state."""
+        if self.split is not None:
+            return self._step_overlapped(backward)
         a = self.coeffs
         Delta = self.Delta
         dt = -self.dt if backward else self.dt
@@ -225,5 +264,44 @@ class ShardedCheby:
                 self._exchange(oi)
             if m == 1:
                 c = 2 * c
+        if result_in_acc:
+            self.X[0][: 2 * self.nloc].copy_(self.acc_t)
+
+    def _step_overlapped(self, backward=False):
+        """Same arithmetic as :meth:`step`; per term the boundary row blocks run on the side
+        stream, immediately followed there by the all-gather of their packed output, while
+        the interior row blocks (which read no ghost slot) run on the main stream."""
+        a = self.coeffs
+        Delta = self.Delta
+        dt = -self.dt if backward else self.dt
+        beta = Delta / 2 + self.E_min
+        c = (-2j / Delta) if dt > 0 else (2j / Delta)
+        phase = np.exp(-1j * beta * dt)
+        nterms = len(a) - 1
+        be, op, side = self.be, self.op, self.side
+        be.join(side)
+        with be.stream(side):
+            self._exchange(0)
+        result_in_acc = True
+        for m in range(1, nterms + 1):
+            last = m == nterms
+            xi, oi = (0, 1) if m % 2 == 1 else (1, 0)
+            x, oloc = self.Xfull[xi], self.Xloc[oi]
+            ph = phase if last else 1.0
+            slab = None if last else self.slab_state
+            if m == 1:
+                be.term_split(op, self.split, side, True, x, 0, None, None if last else oloc, None, self.acc, slab,
+                              c, beta, a[0], a[1], ph)
+            else:
+                out = self.Xloc[0] if (last and xi == 1) else self.acc
+                be.term_split(op, self.split, side, False, x, 0, oloc, None if last else oloc, self.acc, out, slab,
+                              c, beta, 0.0, a[m], ph)
+                result_in_acc = out is self.acc
+            if not last:
+                with be.stream(side):
+                    self._exchange(oi, packed=True)
+            if m == 1:
+                c = 2 * c
+        be.join(side)
         if result_in_acc:
             self.X[0][: 2 * self.nloc].copy_(self.acc_t)

@@ -67,3 +67,52 @@ def test_sharded_hip_backend_world1(pg, exchange):
     torch.cuda.synchronize()
     assert x[32:48].tolist() == [0, 1, 2, 3, 4, 5, 6, 7, 24, 25, 26, 27, 28, 29, 30, 31]
     ctx.close()
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_sharded_overlap_machinery_world1(pg, overlap):
+    """Boundary / interior split on two HIP streams, fused pack into the slab and the RCCL
+    all-gather on the side stream -- with one rank, using a forced send set (the first and
+    last 200 rows), so that every piece of the multi-GPU step runs on the one GPU here."""
+    import torch
+    from oracle import qp_oracle as qo
+    import qprop_amd.lib as L
+    import qprop_amd.sharded as sharded
+    import qprop_amd.synth as synth
+    N = 8192
+    rp, col, vals = synth.hermitian_offsets_csr(N, offsets=(1, 2, 3, 4, 16, 32, 48, 64))
+    ctx = L.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    send = np.concatenate([np.arange(0, 200), np.arange(N - 200, N)])
+    sh = sharded.ShardedCheby(ctx, rp, col, vals, N, 0, N, 20.0, -10.0, 1.0, exchange="halo", overlap=overlap,
+                              _debug_send_rows=send)
+    assert sh.M == 400 and (sh.split is not None) == overlap
+    if overlap:
+        assert sh.split.n_boundary == 8 and sh.split.n_interior == N // 64 - 8
+    psi0 = synth.random_state(N)
+    sh.set_state(psi0)
+    for _ in range(3):
+        sh.step()
+    sh.step(backward=True)
+    torch.cuda.synchronize()
+    H = synth.to_scipy(rp, col, vals, N)
+    wrk = qo.ChebyWrk(psi0, 20.0, -10.0, 1.0)
+    ref = psi0.copy()
+    for _ in range(3):
+        qo.cheby(ref, H, 1.0, wrk)
+    qo.cheby(ref, H, -1.0, wrk)
+    assert np.linalg.norm(sh.local_state() - ref) < 1e-10
+    assert sh.n_exchanges == 4 * 31
+    # the last exchanged vector (term 30 of 31 wrote X[1]): ghost slots == slab == its send rows
+    x1 = sh.be.read(sh.X[1], 0, sh.ncols_local)
+    slab = sh.be.read(sh.slab, 0, sh.M)
+    assert np.array_equal(x1[N:N + 400], slab) and np.array_equal(slab, x1[send])
+    # determinism of the two-stream schedule
+    sh2 = sharded.ShardedCheby(ctx, rp, col, vals, N, 0, N, 20.0, -10.0, 1.0, exchange="halo", overlap=overlap,
+                               _debug_send_rows=send)
+    sh2.set_state(psi0)
+    for _ in range(3):
+        sh2.step()
+    sh2.step(backward=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(sh2.local_state(), sh.local_state())
+    ctx.close()

@@ -26,7 +26,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, exchange, uneven, offsets, N, q):
+def _worker(rank, world, port, exchange, uneven, offsets, N, q, overlap=True):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -44,7 +44,7 @@ def _worker(rank, world, port, exchange, uneven, offsets, N, q):
         lrp = rp[r0:r1 + 1] - rp[r0]
         lcol, lvals = col[rp[r0]:rp[r1]], vals[rp[r0]:rp[r1]]
         sh = sharded.ShardedCheby(None, lrp, lcol, lvals, N, r0, r1, 20.0, -10.0, 1.0, exchange=exchange,
-                                  backend=NumpyBackend())
+                                  backend=NumpyBackend(), overlap=overlap)
         psi0 = synth.random_state(N)
         sh.set_state(psi0[r0:r1])
         sh.step()
@@ -59,24 +59,27 @@ def _worker(rank, world, port, exchange, uneven, offsets, N, q):
         qo.cheby(ref, H, 1.0, wrk)
         qo.cheby(ref, H, -1.0, wrk)
         err = float(np.linalg.norm(out - ref[r0:r1]))
-        q.put((rank, err, sh.exchange, sh.halo_fraction, sh.M, len(sh.send_idx_host), sh.n_exchanges))
+        q.put((rank, err, sh.exchange, sh.halo_fraction, sh.M, len(sh.send_idx_host), sh.n_exchanges,
+               sh.split is not None))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,exchange,uneven,offsets", [
-    (2, "allgather", False, (1, 2, 3, 4, 16, 32, 48, 64)),
-    (2, "halo", False, (1, 2, 3, 4, 16, 32, 48, 64)),
-    (2, "auto", True, (1, 2, 3, 4, 16, 32, 48, 64)),
-    (3, "auto", False, (1, 2, 3, 4, 16, 32, 48, 64)),
-    (2, "auto", False, (5, 77, 211, 333, 401, 467, 489, 499)),      # scattered -> allgather
+@pytest.mark.parametrize("world,exchange,uneven,offsets,overlap", [
+    (2, "allgather", False, (1, 2, 3, 4, 16, 32, 48, 64), True),
+    (2, "halo", False, (1, 2, 3, 4, 16, 32, 48, 64), True),
+    (2, "halo", False, (1, 2, 3, 4, 16, 32, 48, 64), False),
+    (2, "auto", True, (1, 2, 3, 4, 16, 32, 48, 64), True),
+    (3, "auto", False, (1, 2, 3, 4, 16, 32, 48, 64), True),
+    (2, "auto", False, (5, 77, 211, 333, 401, 467, 489, 499), True),      # scattered -> allgather
 ])
-def test_sharded_cheby_matches_oracle(world, exchange, uneven, offsets):
+def test_sharded_cheby_matches_oracle(world, exchange, uneven, offsets, overlap):
     N = 1536
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, exchange, uneven, offsets, N, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, exchange, uneven, offsets, N, q, overlap))
+             for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -84,7 +87,8 @@ def test_sharded_cheby_matches_oracle(world, exchange, uneven, offsets):
         assert p.exitcode == 0
     res = sorted(q.get(timeout=10) for _ in range(world))
     coeffs_terms = 31
-    for rank, err, used, frac, M, nsend, nex in res:
+    for rank, err, used, frac, M, nsend, nex, split in res:
+        assert split == (overlap and used == "halo")        # overlapped path exercised where it applies
         assert err < 1e-12, (rank, err)
         assert nex == 3 * coeffs_terms       # one exchange per mat-vec: psi + 30 term vectors per step
         if exchange != "auto":

@@ -86,7 +86,8 @@ struct qp_operator {
 };
 
 struct qp_split {   // boundary / interior partition of an operator's row blocks (multi-GPU overlap)
-  qp_operator* op = nullptr;
+  qp_operator* op = nullptr;          // identity check only; never dereferenced at destroy time
+  int device = 0;
   int32_t* bmap_boundary = nullptr;
   int32_t* bmap_interior = nullptr;
   int32_t* mirror = nullptr;          // 64 * n_boundary entries: slab position or -1
@@ -1216,6 +1217,7 @@ int qp_split_create(qp_operator* op, const int64_t* send_rows, int64_t nsend, qp
     }
   auto sp = std::make_unique<qp_split>();
   sp->op = op;
+  sp->device = op->ctx->device;
   sp->n_boundary = (int64_t)bb.size();
   sp->n_interior = (int64_t)bi.size();
   sp->nsend = nsend;
@@ -1235,7 +1237,7 @@ int qp_split_create(qp_operator* op, const int64_t* send_rows, int64_t nsend, qp
 int qp_split_destroy(qp_split* sp) {
   QP_TRY
   if (!sp) return QP_OK;
-  (void)hipSetDevice(sp->op->ctx->device);
+  (void)hipSetDevice(sp->device);
   (void)hipDeviceSynchronize();
   if (sp->bmap_boundary) (void)hipFree(sp->bmap_boundary);
   if (sp->bmap_interior) (void)hipFree(sp->bmap_interior);

@@ -102,10 +102,26 @@ def test_sharded_overlap_machinery_world1(pg, overlap):
     qo.cheby(ref, H, -1.0, wrk)
     assert np.linalg.norm(sh.local_state() - ref) < 1e-10
     assert sh.n_exchanges == 4 * 31
-    # the last exchanged vector (term 30 of 31 wrote X[1]): ghost slots == slab == its send rows
-    x1 = sh.be.read(sh.X[1], 0, sh.ncols_local)
+    # the last exchanged vector is v_30 (term 30 of 31 wrote X[0] and packed its send rows):
+    # the ghost slots of X[0] hold the all-gathered slab
+    ghost = sh.be.read(sh.X[0], N, N + 400)
     slab = sh.be.read(sh.slab, 0, sh.M)
-    assert np.array_equal(x1[N:N + 400], slab) and np.array_equal(slab, x1[send])
+    assert np.array_equal(ghost, slab) and np.linalg.norm(slab) > 0
+    # the fused pack (overlap) and the index_select pack (no overlap) must agree bit for bit
+    other = sharded.ShardedCheby(ctx, rp, col, vals, N, 0, N, 20.0, -10.0, 1.0, exchange="halo",
+                                 overlap=not overlap, _debug_send_rows=send)
+    other.set_state(psi0)
+    for _ in range(3):
+        other.step()
+    other.step(backward=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(other.be.read(other.X[0], N, N + 400), ghost)
+    assert np.array_equal(other.local_state(), sh.local_state())
+    # an explicit (unfused) exchange packs exactly the send rows
+    sh._exchange(1)
+    torch.cuda.synchronize()
+    x1 = sh.be.read(sh.X[1], 0, sh.ncols_local)
+    assert np.array_equal(x1[N:N + 400], x1[send])
     # determinism of the two-stream schedule
     sh2 = sharded.ShardedCheby(ctx, rp, col, vals, N, 0, N, 20.0, -10.0, 1.0, exchange="halo", overlap=overlap,
                                _debug_send_rows=send)

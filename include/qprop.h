@@ -193,13 +193,17 @@ int qp_cheby_term(qp_operator* op, const qp_state* x, int64_t xoff, const qp_sta
  * that itself reads a ghost column >= nrows) and *interior* blocks.  qp_cheby_term_split
  * runs one fused term as two launches: the boundary blocks on `boundary_stream` (they also
  * pack the new term vector into slab[i] for send_rows[i]), the interior blocks on the
- * operator's context stream, with HIP events ordering consecutive calls (`first` != 0 for
- * the first call after the two streams were joined by the caller).  The caller enqueues the
+ * operator's context stream (`first` != 0 for the first call after the two streams were
+ * joined by the caller).  Consecutive calls are ordered by a HIP event on the side stream and,
+ * on the main stream, by a completion counter that only the interior workgroups adjacent to
+ * boundary rows poll (tuning key "split_mode" = 0 falls back to events on both streams).  The caller enqueues the
  * RCCL all-gather of `slab` on `boundary_stream` after the call. */
 typedef struct qp_split qp_split;
 int qp_split_create(qp_operator* op, const int64_t* send_rows, int64_t nsend, qp_split** out);
 int qp_split_destroy(qp_split* sp);
 int qp_split_info(const qp_split* sp, int64_t* n_boundary_blocks, int64_t* n_interior_blocks);
+/* device sync + check that no in-launch wait of the split schedule ever timed out */
+int qp_split_check(qp_split* sp);
 int qp_cheby_term_split(qp_operator* op, qp_split* sp, void* boundary_stream, int first,
                         const qp_state* x, int64_t xoff, const qp_state* v0, qp_state* vout,
                         const qp_state* acc_in, qp_state* acc_out, qp_state* slab, qp_c128 c,

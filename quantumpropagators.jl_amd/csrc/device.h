@@ -60,10 +60,26 @@ struct ChebyEpi {
 };
 
 // a subset of the 64-row blocks of an operator (device list), optionally with a mirror map
+// In-launch dependency between the boundary launch of term m (side stream) and the
+// interior launch of term m+1 (main stream), replacing a cross-queue event wait that costs
+// ~11 us of idle queue per term on gfx950 (profiles/r01/overlap_timeline.txt).
+//   signal: every workgroup of the boundary launch adds 1 after an agent-scope release;
+//   wait:   workgroups at position >= wait_from_wg of the interior launch (the row blocks
+//           adjacent to boundary rows, listed last) poll until *wait >= wait_target, then
+//           acquire at agent scope (cdna_hip_programming.md Guideline 16 recipe).
+struct SyncArgs {
+  unsigned* signal = nullptr;
+  const unsigned* wait = nullptr;
+  unsigned wait_target = 0;
+  unsigned wait_from_wg = 0;
+  unsigned* timeout_flag = nullptr;
+};
+
 struct RowSet {
   const int32_t* block_map = nullptr;  // nullptr = all blocks
   int64_t nmap = 0;
   bool count = true;                   // count this launch as a mat-vec in the stats
+  SyncArgs sync;
 };
 
 struct PlainEpi {
@@ -82,6 +98,7 @@ int launch_spmv_cheby(hipStream_t s, const DevMatrix& A, const double2* x, const
 int launch_spmv_plain(hipStream_t s, const DevMatrix& A, const double2* x, const PlainEpi& e, Stats* st);
 int spmv_grid_size(const DevMatrix& A);
 extern int g_rbcsr_variant;
+extern int g_split_mode;  // 0 = cross-stream events on both streams, 1 = in-launch counter for the main stream
 
 // small coefficient vectors are passed by value in the kernel-argument segment
 constexpr int kCoefBlock = 32;

@@ -93,6 +93,10 @@ struct qp_split {   // boundary / interior partition of an operator's row blocks
   int32_t* mirror = nullptr;          // 64 * n_boundary entries: slab position or -1
   int64_t n_boundary = 0, n_interior = 0, nsend = 0;
   hipEvent_t ev_b = nullptr, ev_i = nullptr;
+  // in-launch hand-off boundary(m) -> interior(m+1) (see SyncArgs in device.h)
+  unsigned* counter = nullptr;        // [0] signal counter, [1] spin-timeout flag
+  unsigned signals_issued = 0;
+  unsigned wait_from_wg = 0;          // interior workgroups at or beyond this position poll
 };
 
 struct qp_krylov {
@@ -213,6 +217,10 @@ int qp_tuning_set(const char* key, int value) {
   }
   if (std::strcmp(key, "arnoldi_mode") == 0) {
     qp::g_arnoldi_mode = value;
+    return QP_OK;
+  }
+  if (std::strcmp(key, "split_mode") == 0) {
+    qp::g_split_mode = value;
     return QP_OK;
   }
   return qp::fail(QP_E_BAD_ARG, "unknown tuning key %s", key);
@@ -1207,8 +1215,28 @@ int qp_split_create(qp_operator* op, const int64_t* send_rows, int64_t nsend, qp
   }
   for (int64_t r = 0; r < A.nrows; ++r)   // rows that read a ghost column must wait for the exchange
     if (ur[r + 1] > ur[r] && uc[ur[r + 1] - 1] >= A.nrows) is_boundary[r / kRB] = 1;
-  std::vector<int32_t> bb, bi;
-  for (int64_t b = 0; b < A.nblocks; ++b) (is_boundary[b] ? bb : bi).push_back((int32_t)b);
+  // interior blocks that exchange data with boundary rows inside the local block (they gather
+  // from boundary rows, or boundary rows gather from them) are listed last: only they have to
+  // wait for the boundary launch of the previous term
+  std::vector<char> adjacent((size_t)A.nblocks, 0);
+  for (int64_t r = 0; r < A.nrows; ++r) {
+    const bool rb_ = is_boundary[r / kRB];
+    for (int64_t p = ur[r]; p < ur[r + 1]; ++p) {
+      const int64_t c = uc[p];
+      if (c >= A.nrows) continue;
+      const bool cb = is_boundary[c / kRB];
+      if (rb_ && !cb) adjacent[c / kRB] = 1;
+      if (!rb_ && cb) adjacent[r / kRB] = 1;
+    }
+  }
+  std::vector<int32_t> bb, bi, bi_adj;
+  for (int64_t b = 0; b < A.nblocks; ++b) {
+    if (is_boundary[b]) bb.push_back((int32_t)b);
+    else if (adjacent[b]) bi_adj.push_back((int32_t)b);
+    else bi.push_back((int32_t)b);
+  }
+  const unsigned wait_from_wg = (unsigned)(bi.size() / (qp::kThreads / 64));
+  bi.insert(bi.end(), bi_adj.begin(), bi_adj.end());
   std::vector<int32_t> mirror(bb.size() * kRB + 1, -1);
   for (size_t k = 0; k < bb.size(); ++k)
     for (int l = 0; l < kRB; ++l) {
@@ -1229,6 +1257,9 @@ int qp_split_create(qp_operator* op, const int64_t* send_rows, int64_t nsend, qp
   QP_HIP(hipMemcpy(sp->mirror, mirror.data(), mirror.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   QP_HIP(hipEventCreateWithFlags(&sp->ev_b, hipEventDisableTiming));
   QP_HIP(hipEventCreateWithFlags(&sp->ev_i, hipEventDisableTiming));
+  QP_CHECK(dev_alloc(&sp->counter, 2));
+  QP_HIP(hipMemset(sp->counter, 0, 2 * sizeof(unsigned)));
+  sp->wait_from_wg = wait_from_wg;
   *out = sp.release();
   return QP_OK;
   QP_CATCH
@@ -1242,6 +1273,7 @@ int qp_split_destroy(qp_split* sp) {
   if (sp->bmap_boundary) (void)hipFree(sp->bmap_boundary);
   if (sp->bmap_interior) (void)hipFree(sp->bmap_interior);
   if (sp->mirror) (void)hipFree(sp->mirror);
+  if (sp->counter) (void)hipFree(sp->counter);
   if (sp->ev_b) (void)hipEventDestroy(sp->ev_b);
   if (sp->ev_i) (void)hipEventDestroy(sp->ev_i);
   delete sp;
@@ -1254,6 +1286,19 @@ int qp_split_info(const qp_split* sp, int64_t* n_boundary_blocks, int64_t* n_int
   if (n_boundary_blocks) *n_boundary_blocks = sp->n_boundary;
   if (n_interior_blocks) *n_interior_blocks = sp->n_interior;
   return QP_OK;
+}
+
+/* synchronises the device; returns QP_E_INTERNAL if an in-launch wait ever timed out */
+int qp_split_check(qp_split* sp) {
+  QP_TRY
+  if (!sp) return qp::fail(QP_E_BAD_ARG, "split is NULL");
+  QP_HIP(hipSetDevice(sp->device));
+  QP_HIP(hipDeviceSynchronize());
+  unsigned h[2] = {0, 0};
+  QP_HIP(hipMemcpy(h, sp->counter, sizeof(h), hipMemcpyDeviceToHost));
+  if (h[1] != 0) return qp::fail(QP_E_INTERNAL, "an interior launch timed out waiting for its boundary launch");
+  return QP_OK;
+  QP_CATCH
 }
 
 int qp_cheby_term_split(qp_operator* op, qp_split* sp, void* boundary_stream, int first, const qp_state* x,
@@ -1283,13 +1328,32 @@ int qp_cheby_term_split(qp_operator* op, qp_split* sp, void* boundary_stream, in
   e.phase = d2(phase);
   e.apply_phase = !(phase.re == 1.0 && phase.im == 0.0);
   e.check_partials = nullptr;
-  if (!first) {
-    // boundary(m) overwrites rows that interior(m-1) gathered from, and vice versa
-    QP_HIP(hipStreamWaitEvent(S_x, sp->ev_i, 0));
-    QP_HIP(hipStreamWaitEvent(S_c, sp->ev_b, 0));
-  }
   qp::RowSet rb{sp->bmap_boundary, sp->n_boundary, false};
   qp::RowSet ri{sp->bmap_interior, sp->n_interior, true};
+  const bool flag_mode = (qp::g_split_mode == 1);
+  if (first && flag_mode) {
+    // the caller joined both streams: restart the signal counter (keeps it far from wrap)
+    QP_HIP(hipMemsetAsync(sp->counter, 0, sizeof(unsigned), S_c));
+    sp->signals_issued = 0;
+    QP_HIP(hipEventRecord(sp->ev_i, S_c));
+    QP_HIP(hipStreamWaitEvent(S_x, sp->ev_i, 0));
+  }
+  if (!first) {
+    // boundary(m) overwrites rows that interior(m-1) gathered from, and vice versa.  The side
+    // stream takes a queue-level event wait (its idle time is hidden); the main stream either
+    // does the same (mode 0) or lets only the adjacent workgroups of the interior launch poll
+    // the boundary launch's completion counter (mode 1: no idle gap between interior launches)
+    QP_HIP(hipStreamWaitEvent(S_x, sp->ev_i, 0));
+    if (!flag_mode) QP_HIP(hipStreamWaitEvent(S_c, sp->ev_b, 0));
+  }
+  if (flag_mode) {
+    ri.sync.wait = sp->counter;
+    ri.sync.wait_target = sp->signals_issued;      // every boundary workgroup launched so far
+    ri.sync.wait_from_wg = sp->wait_from_wg;
+    ri.sync.timeout_flag = sp->counter + 1;
+    rb.sync.signal = sp->counter;
+    sp->signals_issued += (unsigned)((sp->n_boundary + qp::kThreads / 64 - 1) / (qp::kThreads / 64));
+  }
   qp::ChebyEpi eb = e;
   if (slab && vout) {   // the slab carries the new term vector (what the next term gathers)
     eb.mirror = sp->mirror;

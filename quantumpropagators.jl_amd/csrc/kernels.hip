@@ -67,6 +67,38 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
 }
 
 // ---------------------------------------------------------------------------
+// in-launch producer/consumer hand-off between two launches on different streams
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void sync_wait(const SyncArgs& sy, unsigned wg) {
+  if (sy.wait && wg >= sy.wait_from_wg) {
+    if (threadIdx.x == 0) {
+      unsigned spins = 0;
+      while (__hip_atomic_load(sy.wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sy.wait_target) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1u << 24)) {  // bounded: never hang the queue; the host checks the flag
+          if (sy.timeout_flag) __hip_atomic_store(sy.timeout_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+  }
+}
+__device__ __forceinline__ void sync_signal(const SyncArgs& sy) {
+  if (sy.signal) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_fetch_add(sy.signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // epilogues
 // ---------------------------------------------------------------------------
 struct ChebyOp {
@@ -189,12 +221,13 @@ __global__ __launch_bounds__(kThreads) void rbcsr_spmv_kernel(const int64_t* __r
                                                               const double2* __restrict__ vals,
                                                               const double2* __restrict__ x,
                                                               int64_t nblocks, int64_t nrows, Op op,
-                                                              const int32_t* __restrict__ block_map) {
+                                                              const int32_t* __restrict__ block_map, SyncArgs sy) {
   constexpr bool NT = (VAR & 1) != 0;
   constexpr bool PRE = (VAR & 2) != 0;
   constexpr int UNR = (VAR & 4) ? 4 : 2;
   __shared__ double2 lds[kThreads / 64];
   const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
+  sync_wait(sy, wg);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int64_t idx = (int64_t)wg * (kThreads / 64) + wave;  // position in the row set
@@ -231,6 +264,7 @@ __global__ __launch_bounds__(kThreads) void rbcsr_spmv_kernel(const int64_t* __r
     if (row < nrows) op.row(row, make_double2(s0.x + s1.x, s0.y + s1.y), pre, chk, nrm, idx * kRB + lane);
   }
   finish_check(op, chk, nrm, lds);
+  sync_signal(sy);
 }
 
 // ---------------------------------------------------------------------------
@@ -261,12 +295,13 @@ __global__ __launch_bounds__(kThreads) void hrb_spmv_kernel(const int64_t* __res
                                                             const int4* __restrict__ lpos4,
                                                             const double2* __restrict__ x, int64_t nblocks,
                                                             int64_t nrows, Op op,
-                                                            const int32_t* __restrict__ block_map) {
+                                                            const int32_t* __restrict__ block_map, SyncArgs sy) {
   constexpr bool NT = (VAR & 1) != 0;
   constexpr bool PRE = (VAR & 2) != 0;
   constexpr int UNR = (VAR & 4) ? 2 : 1;
   __shared__ double2 lds[kThreads / 64];
   const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
+  sync_wait(sy, wg);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int64_t idx = (int64_t)wg * (kThreads / 64) + wave;  // position in the row set
@@ -323,6 +358,7 @@ __global__ __launch_bounds__(kThreads) void hrb_spmv_kernel(const int64_t* __res
     if (row < nrows) op.row(row, make_double2(s0.x + s1.x, s0.y + s1.y), pre, chk, nrm, idx * kRB + lane);
   }
   finish_check(op, chk, nrm, lds);
+  sync_signal(sy);
 }
 
 // ---------------------------------------------------------------------------
@@ -356,6 +392,7 @@ __global__ __launch_bounds__(kThreads) void csr_spmv_kernel(const int64_t* __res
 }
 
 int g_arnoldi_mode = 1;
+int g_split_mode = 1;
 int g_rbcsr_variant = 7;  // tuning knob (qp_tuning_set); 7 = nt + early row-local loads + deep unroll (A/B in profiles/)
 
 int spmv_grid_size(const DevMatrix& A) {
@@ -371,6 +408,7 @@ static int launch_spmv(hipStream_t s, const DevMatrix& A, const double2* x, cons
   int grid = spmv_grid_size(A);
   const int32_t* bmap = nullptr;
   int64_t nblk = A.nblocks;
+  const SyncArgs sy = rs ? rs->sync : SyncArgs();
   if (rs && rs->block_map) {
     if (A.format != QP_FMT_RBCSR && A.format != QP_FMT_HRB) return fail(QP_E_BAD_ARG, "row sets need a row-block format");
     bmap = rs->block_map;
@@ -382,7 +420,7 @@ static int launch_spmv(hipStream_t s, const DevMatrix& A, const double2* x, cons
 #define QP_RB_CASE(VV)                                                                                   \
   case VV:                                                                                               \
     hipLaunchKernelGGL((rbcsr_spmv_kernel<Op, VV>), dim3(grid), dim3(kThreads), 0, s, A.bptr,            \
-                       reinterpret_cast<const int4*>(A.cols), A.vals, x, nblk, A.nrows, op, bmap);          \
+                       reinterpret_cast<const int4*>(A.cols), A.vals, x, nblk, A.nrows, op, bmap, sy);      \
     break;
     switch (g_rbcsr_variant & 7) {
       QP_RB_CASE(0)
@@ -401,7 +439,7 @@ static int launch_spmv(hipStream_t s, const DevMatrix& A, const double2* x, cons
     hipLaunchKernelGGL((hrb_spmv_kernel<Op, VV>), dim3(grid), dim3(kThreads), 0, s, A.bptr,              \
                        reinterpret_cast<const int4*>(A.cols), A.vals, A.lptr,                            \
                        reinterpret_cast<const int4*>(A.lcols), reinterpret_cast<const int4*>(A.lpos), x, \
-                       nblk, A.nrows, op, bmap);                                                         \
+                       nblk, A.nrows, op, bmap, sy);                                                     \
     break;
     switch (g_rbcsr_variant & 7) {
       QP_HRB_CASE(0)

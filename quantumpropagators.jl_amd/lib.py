@@ -123,6 +123,7 @@ SIGNATURES = {
     "qp_split_create": (C.c_int, [_P, _i64p, C.c_int64, C.POINTER(_P)]),
     "qp_split_destroy": (C.c_int, [_P]),
     "qp_split_info": (C.c_int, [_P, _i64p, _i64p]),
+    "qp_split_check": (C.c_int, [_P]),
     "qp_cheby_term_split": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_int64, _P, _P, _P, _P, _P, qp_c128, C.c_double,
                                       C.c_double, C.c_double, qp_c128]),
     "qp_krylov_create": (C.c_int, [_P, C.c_int64, C.c_int, C.POINTER(_P)]),
@@ -585,6 +586,9 @@ class Split:
         check(self.lib.qp_split_info(self._h, C.byref(nb), C.byref(ni)))
         self.n_boundary, self.n_interior = nb.value, ni.value
         op.ctx._adopt(self)
+
+    def check(self):
+        check(self.lib.qp_split_check(self._h))
 
     def close(self):
         if self._h:

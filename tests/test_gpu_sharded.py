@@ -69,8 +69,8 @@ def test_sharded_hip_backend_world1(pg, exchange):
     ctx.close()
 
 
-@pytest.mark.parametrize("overlap", [True, False])
-def test_sharded_overlap_machinery_world1(pg, overlap):
+@pytest.mark.parametrize("overlap,split_mode", [(True, 1), (True, 0), (False, 1)])
+def test_sharded_overlap_machinery_world1(pg, overlap, split_mode):
     """Boundary / interior split on two HIP streams, fused pack into the slab and the RCCL
     all-gather on the side stream -- with one rank, using a forced send set (the first and
     last 200 rows), so that every piece of the multi-GPU step runs on the one GPU here."""
@@ -80,6 +80,7 @@ def test_sharded_overlap_machinery_world1(pg, overlap):
     import qprop_amd.sharded as sharded
     import qprop_amd.synth as synth
     N = 8192
+    L.tuning_set("split_mode", split_mode)
     rp, col, vals = synth.hermitian_offsets_csr(N, offsets=(1, 2, 3, 4, 16, 32, 48, 64))
     ctx = L.Context(0, stream=torch.cuda.current_stream().cuda_stream)
     send = np.concatenate([np.arange(0, 200), np.arange(N - 200, N)])
@@ -131,4 +132,8 @@ def test_sharded_overlap_machinery_world1(pg, overlap):
     sh2.step(backward=True)
     torch.cuda.synchronize()
     assert np.array_equal(sh2.local_state(), sh.local_state())
+    if overlap:
+        sh.split.check()          # no in-launch wait ever timed out
+        sh2.split.check()
+    L.tuning_set("split_mode", 1)
     ctx.close()

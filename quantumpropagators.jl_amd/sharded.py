@@ -112,6 +112,12 @@ class HipBackend:
         s.wait_stream(cur)
         cur.wait_stream(s)
 
+    def current_stream(self):
+        return self.torch.cuda.current_stream(self.device)
+
+    def set_stream(self, s):
+        self.torch.cuda.set_stream(s)
+
     def term_split(self, op, split, side, first, x, xoff, v0, vout, acc_in, acc_out, slab, c, beta, a_prev, a, phase):
         L.cheby_term_split(op, split, side.cuda_stream, first, x, xoff, v0, vout, acc_in, acc_out, slab, c, beta,
                            a_prev, a, phase)
@@ -280,28 +286,34 @@ class ShardedCheby:
         nterms = len(a) - 1
         be, op, side = self.be, self.op, self.side
         be.join(side)
-        with be.stream(side):
+        # the side stream is the thread's current stream for the whole step, so that the
+        # collectives order themselves against it without a per-term stream context switch;
+        # the interior launches go to the context's (main) stream explicitly
+        main = be.current_stream()
+        be.set_stream(side)
+        try:
             self._exchange(0)
-        result_in_acc = True
-        for m in range(1, nterms + 1):
-            last = m == nterms
-            xi, oi = (0, 1) if m % 2 == 1 else (1, 0)
-            x, oloc = self.Xfull[xi], self.Xloc[oi]
-            ph = phase if last else 1.0
-            slab = None if last else self.slab_state
-            if m == 1:
-                be.term_split(op, self.split, side, True, x, 0, None, None if last else oloc, None, self.acc, slab,
-                              c, beta, a[0], a[1], ph)
-            else:
-                out = self.Xloc[0] if (last and xi == 1) else self.acc
-                be.term_split(op, self.split, side, False, x, 0, oloc, None if last else oloc, self.acc, out, slab,
-                              c, beta, 0.0, a[m], ph)
-                result_in_acc = out is self.acc
-            if not last:
-                with be.stream(side):
+            result_in_acc = True
+            for m in range(1, nterms + 1):
+                last = m == nterms
+                xi, oi = (0, 1) if m % 2 == 1 else (1, 0)
+                x, oloc = self.Xfull[xi], self.Xloc[oi]
+                ph = phase if last else 1.0
+                slab = None if last else self.slab_state
+                if m == 1:
+                    be.term_split(op, self.split, side, True, x, 0, None, None if last else oloc, None, self.acc,
+                                  slab, c, beta, a[0], a[1], ph)
+                else:
+                    out = self.Xloc[0] if (last and xi == 1) else self.acc
+                    be.term_split(op, self.split, side, False, x, 0, oloc, None if last else oloc, self.acc, out,
+                                  slab, c, beta, 0.0, a[m], ph)
+                    result_in_acc = out is self.acc
+                if not last:
                     self._exchange(oi, packed=True)
-            if m == 1:
-                c = 2 * c
+                if m == 1:
+                    c = 2 * c
+        finally:
+            be.set_stream(main)
         be.join(side)
         if result_in_acc:
             self.X[0][: 2 * self.nloc].copy_(self.acc_t)

@@ -64,6 +64,12 @@ class NumpyBackend:
     def join(self, s):
         pass
 
+    def current_stream(self):
+        return None
+
+    def set_stream(self, s):
+        pass
+
     def term_split(self, op, split, side, first, x, xoff, v0, vout, acc_in, acc_out, slab, c, beta, a_prev, a, phase):
         nloc = op.A.shape[0]
         v0c = None if v0 is None else v0.copy()          # in-place v0 -> v2: keep the old values for both halves

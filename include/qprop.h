@@ -179,6 +179,12 @@ int qp_cheby_destroy(qp_cheby* w);
 int qp_cheby_step(qp_cheby* w, qp_operator* op, qp_state* psi, const double* a, int n_coeffs,
                   double Delta, double E_min, double dt, double wrk_dt, double limit,
                   int check_normalization);
+/* Batched states (BASELINE configs[4]; the reference propagates one state per propagator,
+ * optimal-control callers step many): `psi` is a panel of `batch` states stored with the
+ * state index contiguous, psi[i*batch + s], length n*batch; `w` was created for n*batch.
+ * Same arithmetic as qp_cheby_step for every state, the matrix is streamed once for all. */
+int qp_cheby_step_batched(qp_cheby* w, qp_operator* op, qp_state* psi, int batch, const double* a,
+                          int n_coeffs, double Delta, double E_min, double dt, double wrk_dt);
 /* One fused term, for row-partitioned multi-GPU drivers that exchange x between terms:
  *   s = (H x)[i];  t = c (s - beta x[xoff+i]) (+ v0[i] if v0);  if vout: vout[i] = t;
  *   r = (acc_in ? acc_in[i] : a_prev x[xoff+i]) + a t;  acc_out[i] = phase r.

@@ -110,6 +110,12 @@ struct CoefBlock {
 int launch_combine_planes(hipStream_t s, double2* vals, const double2* const* planes_dev, const double2* coefs,
                           int nplanes, int64_t n, Stats* st);
 
+// batched states: CSR SpMM with the fused Chebyshev epilogue, panel X[i*b + s]
+int launch_spmm_cheby(hipStream_t s, const int64_t* rowptr, const int32_t* cols, const double2* vals,
+                      const double2* X, int64_t nrows, int64_t nnz, int b, const ChebyEpi& e, Stats* st);
+int launch_gather_csr_vals(hipStream_t s, double2* out, const double2* vals, const int64_t* map, int64_t nnz,
+                           Stats* st);
+
 // BLAS-1
 int launch_fill(hipStream_t s, double2* x, double2 a, int64_t n, Stats* st);
 int launch_scal(hipStream_t s, double2* x, double2 a, int64_t n, Stats* st);

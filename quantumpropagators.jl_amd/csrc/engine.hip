@@ -75,6 +75,12 @@ struct qp_operator {
   DevMatrix A;
   HostLayoutData layout;
   bool hermitian_planes = false;
+  // CSR-ordered mirror of the current values for the batched (SpMM) path, built lazily
+  int64_t* m_rowptr = nullptr;
+  int32_t* m_cols = nullptr;
+  int64_t* m_map = nullptr;     // position in A.vals (>= 0) or -(position)-1 for a conj-transposed value
+  double2* m_vals = nullptr;
+  uint64_t vals_epoch = 1, m_epoch = 0;
   int nops = 0, ncoeffs = 0;
   std::vector<int64_t> u_rowptr;  // union pattern (host), for get_csr and plane scatter
   std::vector<int32_t> u_col;
@@ -445,6 +451,15 @@ static int operator_free_device(qp_operator* op) {
   if (op->A.lptr) (void)hipFree(op->A.lptr);
   if (op->A.lcols) (void)hipFree(op->A.lcols);
   if (op->A.lpos) (void)hipFree(op->A.lpos);
+  if (op->m_rowptr) (void)hipFree(op->m_rowptr);
+  if (op->m_cols) (void)hipFree(op->m_cols);
+  if (op->m_map) (void)hipFree(op->m_map);
+  if (op->m_vals) (void)hipFree(op->m_vals);
+  op->m_rowptr = nullptr;
+  op->m_cols = nullptr;
+  op->m_map = nullptr;
+  op->m_vals = nullptr;
+  op->m_epoch = 0;
   op->planes_dev = nullptr;
   op->combined = nullptr;
   op->A.bptr = op->A.rowptr = op->A.lptr = nullptr;
@@ -773,6 +788,7 @@ int qp_operator_create(qp_ctx* ctx, qp_matrix* const* ops, int nops, int ncoeffs
 
 static int operator_refresh(qp_operator* op) {
   qp_ctx* ctx = op->ctx;
+  op->vals_epoch++;
   const int drift = op->nops - op->ncoeffs;  // src/generators.jl:635
   std::vector<double2> eff(op->nops);
   bool all_one = true, all_real = true;
@@ -1188,6 +1204,117 @@ int qp_cheby_step(qp_cheby* w, qp_operator* op, qp_state* psi, const double* a, 
         return qp::fail(QP_E_NORMALIZATION, "Incorrect normalization (E_min=%g, Delta=%g)", E_min, Delta);
     }
   }
+  return QP_OK;
+  QP_CATCH
+}
+
+// ---------------------------------------------------------------------------
+// batched states (BASELINE configs[4]): panel X[i*b + s]
+// ---------------------------------------------------------------------------
+static int operator_csr_mirror(qp_operator* op) {
+  qp_ctx* ctx = op->ctx;
+  const DevMatrix& A = op->A;
+  const auto& ur = op->u_rowptr;
+  const auto& uc = op->u_col;
+  const int64_t nnz = A.nnz;
+  if (!op->m_rowptr) {
+    std::vector<int64_t> map((size_t)std::max<int64_t>(nnz, 1));
+    for (int64_t r = 0; r < A.nrows; ++r) {
+      const int64_t nl = (A.format == QP_FMT_HRB) ? op->layout.nlow[r] : 0;
+      for (int64_t k = 0; k < ur[r + 1] - ur[r]; ++k) {
+        int64_t m;
+        if (A.format == QP_FMT_CSR) {
+          m = ur[r] + k;
+        } else if (k >= nl) {
+          m = rb_val_pos(op->layout.bptr, r, k - nl);
+        } else {
+          const int64_t c = uc[ur[r] + k];
+          const int32_t* b = uc.data() + ur[c];
+          const int32_t* e = uc.data() + ur[c + 1];
+          const int64_t kk = (std::lower_bound(b, e, (int32_t)r) - b) - op->layout.nlow[c];
+          m = -rb_val_pos(op->layout.bptr, c, kk) - 1;
+        }
+        map[ur[r] + k] = m;
+      }
+    }
+    QP_CHECK(dev_alloc(&op->m_rowptr, ur.size()));
+    QP_CHECK(dev_alloc(&op->m_cols, (size_t)nnz));
+    QP_CHECK(dev_alloc(&op->m_map, (size_t)nnz));
+    QP_CHECK(dev_alloc(&op->m_vals, (size_t)nnz));
+    QP_HIP(hipMemcpy(op->m_rowptr, ur.data(), ur.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    QP_HIP(hipMemcpy(op->m_cols, uc.data(), (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice));
+    QP_HIP(hipMemcpy(op->m_map, map.data(), (size_t)nnz * sizeof(int64_t), hipMemcpyHostToDevice));
+    op->m_epoch = 0;
+  }
+  if (op->m_epoch != op->vals_epoch) {
+    QP_CHECK(qp::launch_gather_csr_vals(ctx->stream, op->m_vals, A.vals, op->m_map, nnz, &ctx->stats));
+    op->m_epoch = op->vals_epoch;
+  }
+  return QP_OK;
+}
+
+int qp_cheby_step_batched(qp_cheby* w, qp_operator* op, qp_state* psi, int batch, const double* a, int n_coeffs,
+                          double Delta, double E_min, double dt, double wrk_dt) {
+  QP_TRY
+  if (!w || !op || !psi || !a || batch < 1) return qp::fail(QP_E_BAD_ARG, "qp_cheby_step_batched: bad arguments");
+  const int64_t n = op->A.nrows;
+  if (op->A.nrows != op->A.ncols || psi->n != n * batch || w->n != psi->n)
+    return qp::fail(QP_E_BAD_ARG, "qp_cheby_step_batched: shape mismatch (operator %lld, batch %d, panel %lld)",
+                    (long long)n, batch, (long long)psi->n);
+  {
+    const double x = std::fabs(dt), y = std::fabs(wrk_dt);
+    if (!(std::fabs(x - y) <= 1.4901161193847656e-08 * std::max(x, y)))
+      return qp::fail(QP_E_DT_MISMATCH, "wrk was initialized for dt=%g, not dt=abs(%g)", wrk_dt, dt);
+  }
+  if (n_coeffs < 2) return qp::fail(QP_E_TOO_FEW_COEFFS, "Need at least 2 Chebychev coefficients");
+  if (!(Delta > 0)) return qp::fail(QP_E_BAD_ARG, "Delta must be positive");
+  qp_ctx* ctx = op->ctx;
+  QP_CHECK(use(ctx));
+  QP_CHECK(operator_csr_mirror(op));
+  const double beta = (Delta / 2) + E_min;
+  cplx c = (dt > 0) ? cplx(0, -2.0) / Delta : cplx(0, 2.0) / Delta;
+  const cplx phase = std::exp(cplx(0, -1) * beta * dt);
+  const int nterms = n_coeffs - 1;
+  double2* P = psi->d;
+  double2* B = w->bufA;
+  double2* ACC = w->acc;
+  double2* result = nullptr;
+  for (int m = 1; m <= nterms; ++m) {   // same buffer rotation as qp_cheby_step, element = (row, state)
+    const bool last = (m == nterms);
+    qp::ChebyEpi e;
+    const double2* x;
+    if (m == 1) {
+      x = P;
+      e.v0 = nullptr;
+      e.vout = last ? nullptr : B;
+      e.acc_in = nullptr;
+      e.acc_out = ACC;
+      e.a_prev = a[0];
+      result = ACC;
+    } else {
+      double2* xb = (m % 2 == 0) ? B : P;
+      double2* ob = (m % 2 == 0) ? P : B;
+      x = xb;
+      e.v0 = ob;
+      e.vout = last ? nullptr : ob;
+      e.acc_in = ACC;
+      e.acc_out = (last && xb == B) ? P : ACC;
+      e.a_prev = 0.0;
+      result = e.acc_out;
+    }
+    e.xloc = x;
+    e.c = d2(c);
+    e.beta = beta;
+    e.a = a[m];
+    e.phase = d2(phase);
+    e.apply_phase = last ? 1 : 0;
+    e.check_partials = nullptr;
+    QP_CHECK(qp::launch_spmm_cheby(ctx->stream, op->m_rowptr, op->m_cols, op->m_vals, x, n, op->A.nnz, batch, e,
+                                   &ctx->stats));
+    if (m == 1) c *= 2.0;
+  }
+  if (result != P) QP_HIP(hipMemcpyAsync(P, result, (size_t)psi->n * sizeof(double2), hipMemcpyDeviceToDevice, ctx->stream));
+  ctx->stats.n_cheby_steps++;
   return QP_OK;
   QP_CATCH
 }

@@ -391,6 +391,90 @@ __global__ __launch_bounds__(kThreads) void csr_spmv_kernel(const int64_t* __res
   finish_check(op, chk, nrm, lds);
 }
 
+static inline int ew_grid(int64_t n);
+
+// ---------------------------------------------------------------------------
+// Batched states (BASELINE configs[4]): b states as a panel X[i*b + s] (state index
+// contiguous).  One wavefront per row, lane = state: the matrix entry is wave-uniform
+// (scalar loads, broadcast for free), every gather of X[col, :] is a contiguous 16*b-byte
+// burst, and the matrix traffic is amortised over the b states (20 z + 80 b bytes per row).
+// There is no dense contraction to feed MFMA: H has scalar entries, so per row this is z
+// AXPYs of length b (0.4 flop/B at b = 64, far below the fp64 ridge).
+// ---------------------------------------------------------------------------
+template <class Op>
+__global__ __launch_bounds__(kThreads) void csr_spmm_kernel(const int64_t* __restrict__ rowptr,
+                                                            const int32_t* __restrict__ cols,
+                                                            const double2* __restrict__ vals,
+                                                            const double2* __restrict__ X, int64_t nrows, int b,
+                                                            Op op) {
+  const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)wg * (kThreads / 64) + wave;
+  if (row >= nrows) return;
+  const int64_t p0 = rowptr[row], p1 = rowptr[row + 1];
+  double2 chk = make_double2(0.0, 0.0);
+  double nrm = 0.0;
+  for (int s0 = 0; s0 < b; s0 += 64) {
+    const int st = s0 + lane;
+    if (st >= b) break;
+    const int64_t e = row * (int64_t)b + st;
+    const typename Op::Pre pre = op.pre(e);
+    double2 acc0 = make_double2(0.0, 0.0), acc1 = make_double2(0.0, 0.0);
+    int64_t p = p0;
+    for (; p + 3 < p1; p += 4) {
+      const double2 a0 = vals[p], a1 = vals[p + 1], a2 = vals[p + 2], a3 = vals[p + 3];
+      const double2 x0 = X[(int64_t)cols[p] * b + st];
+      const double2 x1 = X[(int64_t)cols[p + 1] * b + st];
+      const double2 x2 = X[(int64_t)cols[p + 2] * b + st];
+      const double2 x3 = X[(int64_t)cols[p + 3] * b + st];
+      cfma(acc0, a0, x0);
+      cfma(acc1, a1, x1);
+      cfma(acc0, a2, x2);
+      cfma(acc1, a3, x3);
+    }
+    for (; p < p1; ++p) cfma(acc0, vals[p], X[(int64_t)cols[p] * b + st]);
+    op.row(e, make_double2(acc0.x + acc1.x, acc0.y + acc1.y), pre, chk, nrm, e);
+  }
+}
+
+int launch_spmm_cheby(hipStream_t s, const int64_t* rowptr, const int32_t* cols, const double2* vals,
+                      const double2* X, int64_t nrows, int64_t nnz, int b, const ChebyEpi& e, Stats* st) {
+  if (nrows == 0) return QP_OK;
+  ChebyOp op{e};
+  const int grid = (int)((nrows + kThreads / 64 - 1) / (kThreads / 64));
+  hipLaunchKernelGGL(csr_spmm_kernel<ChebyOp>, dim3(grid), dim3(kThreads), 0, s, rowptr, cols, vals, X, nrows, b, op);
+  QP_HIP(hipGetLastError());
+  if (st) {
+    st->n_launch++;
+    st->n_matvec++;
+    st->spmv_bytes += 20.0 * (double)nnz + 4.0 * (double)(nrows + 1) + 80.0 * (double)nrows * b;
+  }
+  return QP_OK;
+}
+
+// CSR-ordered copy of the current operator values: out[p] = map[p] >= 0 ? vals[map[p]]
+//                                                          : conj(vals[-map[p]-1])
+__global__ __launch_bounds__(kThreads) void gather_csr_vals_kernel(double2* __restrict__ out,
+                                                                   const double2* __restrict__ vals,
+                                                                   const int64_t* __restrict__ map, int64_t nnz) {
+  for (int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x; p < nnz; p += (int64_t)gridDim.x * kThreads) {
+    const int64_t m = map[p];
+    double2 v = vals[m >= 0 ? m : -m - 1];
+    if (m < 0) v.y = -v.y;
+    out[p] = v;
+  }
+}
+
+int launch_gather_csr_vals(hipStream_t s, double2* out, const double2* vals, const int64_t* map, int64_t nnz,
+                           Stats* st) {
+  if (nnz == 0) return QP_OK;
+  hipLaunchKernelGGL(gather_csr_vals_kernel, dim3(ew_grid(nnz)), dim3(kThreads), 0, s, out, vals, map, nnz);
+  QP_HIP(hipGetLastError());
+  if (st) st->n_launch++;
+  return QP_OK;
+}
+
 int g_arnoldi_mode = 1;
 int g_split_mode = 1;
 int g_rbcsr_variant = 7;  // tuning knob (qp_tuning_set); 7 = nt + early row-local loads + deep unroll (A/B in profiles/)

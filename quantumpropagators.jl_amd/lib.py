@@ -118,6 +118,8 @@ SIGNATURES = {
     "qp_cheby_destroy": (C.c_int, [_P]),
     "qp_cheby_step": (C.c_int, [_P, _P, _P, _dp, C.c_int, C.c_double, C.c_double, C.c_double,
                                 C.c_double, C.c_double, C.c_int]),
+    "qp_cheby_step_batched": (C.c_int, [_P, _P, _P, C.c_int, _dp, C.c_int, C.c_double, C.c_double, C.c_double,
+                                        C.c_double]),
     "qp_cheby_term": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, _P, qp_c128, C.c_double, C.c_double,
                                 C.c_double, qp_c128]),
     "qp_split_create": (C.c_int, [_P, _i64p, C.c_int64, C.POINTER(_P)]),
@@ -564,6 +566,14 @@ def cheby(psi, H, dt, wrk, E_min=None, check_normalization=False):
     check(wrk.lib.qp_cheby_step(wrk._h, H._h, psi._h, _ptr(wrk.coeffs, _dp), wrk.n_coeffs, wrk.Delta,
                                 float(E_min), float(dt), wrk.dt, wrk.limit, int(check_normalization)))
     return psi
+
+
+def cheby_batched(psi_panel, H, dt, wrk, batch, E_min=None):
+    """``cheby!`` for ``batch`` states at once; ``psi_panel[i*batch + s]`` (state index contiguous)."""
+    E_min = wrk.E_min if E_min is None else E_min
+    check(wrk.lib.qp_cheby_step_batched(wrk._h, H._h, psi_panel._h, int(batch), _ptr(wrk.coeffs, _dp), wrk.n_coeffs,
+                                        wrk.Delta, float(E_min), float(dt), wrk.dt))
+    return psi_panel
 
 
 def cheby_term(H, x, xoff, v0, vout, acc_in, acc_out, c, beta, a_prev, a, phase=1.0):

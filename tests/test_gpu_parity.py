@@ -350,6 +350,54 @@ def test_cheby_term_row_partition(ctx):
     assert np.linalg.norm(out - ref) < TOL
 
 
+@pytest.mark.parametrize("fmt", [L.FMT_HRB, L.FMT_RBCSR, L.FMT_CSR])
+@pytest.mark.parametrize("batch", [1, 5, 64, 70])
+def test_cheby_batched_matches_oracle(ctx, fmt, batch):
+    """BASELINE configs[4] at oracle size: a panel of `batch` states through the SpMM path
+    equals `batch` independent oracle propagations; forward and backward; any device format
+    (the CSR-ordered mirror is gathered from the device values, conj-transposed for HRB)."""
+    N = 777
+    rp, col, vals = synth.hermitian_offsets_csr(N, offsets=(1, 2, 3, 4, 16, 32, 48, 64))
+    H = synth.to_scipy(rp, col, vals, N)
+    Op = L.Operator(ctx, [L.Matrix(ctx, N, N, rp, col, vals)], 0, fmt)
+    states = np.stack([synth.random_state(N, seed=1000 + s) for s in range(batch)], axis=1)   # [N, batch]
+    wrk = L.ChebyWrk(ctx, N * batch, 20.0, -10.0, 0.7)
+    panel = L.State(ctx, data=states.reshape(-1))
+    for dt in (0.7, 0.7, -0.7):
+        L.cheby_batched(panel, Op, dt, wrk, batch)
+    out = panel.numpy().reshape(N, batch)
+    for s in range(batch):
+        owrk = qo.ChebyWrk(states[:, s], 20.0, -10.0, 0.7)
+        owrk.coeffs, owrk.n_coeffs = wrk.coeffs.copy(), wrk.n_coeffs
+        ref = states[:, s].copy()
+        for dt in (0.7, 0.7, -0.7):
+            qo.cheby(ref, H, dt, owrk)
+        assert np.linalg.norm(out[:, s] - ref) < TOL
+
+
+def test_cheby_batched_tracks_coefficients(ctx):
+    """The CSR mirror follows qp_operator_set_coeffs (device-side `evaluate!`)."""
+    rng = np.random.default_rng(77)
+    N, batch = 200, 8
+    H0 = synth.dense_hermitian(N, rho=2.0, rng=rng)
+    H1 = synth.dense_hermitian(N, rho=1.0, rng=rng)
+    Op = L.Operator(ctx, [L.Matrix.from_dense(ctx, H0), L.Matrix.from_dense(ctx, H1)], 1)
+    states = np.stack([_rand_state(N, rng) for _ in range(batch)], axis=1)
+    wrk = L.ChebyWrk(ctx, N * batch, 12.0, -6.0, 0.2)
+    panel = L.State(ctx, data=states.reshape(-1))
+    ref = states.copy()
+    for cval in (0.5, -1.0, 0.25):
+        Op.set_coeffs([cval])
+        L.cheby_batched(panel, Op, 0.2, wrk, batch)
+        for s in range(batch):
+            owrk = qo.ChebyWrk(ref[:, s], 12.0, -6.0, 0.2)
+            owrk.coeffs, owrk.n_coeffs = wrk.coeffs.copy(), wrk.n_coeffs
+            col_ = ref[:, s].copy()
+            qo.cheby(col_, H0 + cval * H1, 0.2, owrk)
+            ref[:, s] = col_
+    assert np.linalg.norm(panel.numpy().reshape(N, batch) - ref) < TOL
+
+
 # ---------------------------------------------------------------- Arnoldi / Newton / specrange
 
 def test_arnoldi_matches_oracle(ctx, arnoldi_mode):

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""BASELINE configs[4]: batched 64 states x N = 2^18 CSR H (16 nnz/row), Chebyshev, one
+MI355X.  Prints one JSON line: panel prop_steps/s, state-steps/s, algorithmic GB/s.
+
+    python tools/bench_batched.py --log2n 18 --batch 64 --steps 10
+"""
+import argparse, json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import qprop_amd.lib as L, qprop_amd.synth as synth
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--log2n", type=int, default=18)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    args = ap.parse_args()
+    N, b = 1 << args.log2n, args.batch
+    rp, col, vals = synth.hermitian_offsets_csr(N)
+    ctx = L.Context(0)
+    op = L.Operator(ctx, [L.Matrix(ctx, N, N, rp, col, vals)])
+    nnz = int(rp[-1])
+    states = np.stack([synth.random_state(N, seed=500 + s) for s in range(b)], axis=1)
+    panel = L.State(ctx, data=states.reshape(-1))
+    wrk = L.ChebyWrk(ctx, N * b, 20.0, -10.0, 1.0)
+    nterms = wrk.n_coeffs - 1
+    for _ in range(args.warmup):
+        L.cheby_batched(panel, op, 1.0, wrk, b)
+    ctx.sync()
+    ctx.timer_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        L.cheby_batched(panel, op, 1.0, wrk, b)
+    ev = ctx.timer_end()
+    el = time.perf_counter() - t0
+    alg = 20.0 * nnz + 4.0 * (N + 1) + 80.0 * N * b          # SURVEY 8d batched model per term
+    per_term = ev * 1e-3 / (args.steps * nterms)
+    norms = np.linalg.norm(panel.numpy().reshape(N, b), axis=0)
+    # the same states one at a time through the single-state kernel, for comparison
+    single = L.State(ctx, data=states[:, 0].copy())
+    w1 = L.ChebyWrk(ctx, N, 20.0, -10.0, 1.0)
+    for _ in range(3):
+        L.cheby(single, op, 1.0, w1)
+    ctx.sync()
+    ctx.timer_begin()
+    for _ in range(20):
+        L.cheby(single, op, 1.0, w1)
+    ev1 = ctx.timer_end() / 20
+    print(json.dumps({
+        "metric": "batched Cheby prop_step!/s, 64 states x N=2^18 CSR (BASELINE configs[4])",
+        "value": args.steps / el, "unit": "panel prop_step/s", "state_steps_per_s": b * args.steps / el,
+        "ms_per_panel_step": 1e3 * el / args.steps,
+        "config": {"N": N, "batch": b, "nnz_per_row": nnz / N, "matvecs_per_step": nterms},
+        "roofline": {"bound": "hbm", "achieved": alg / per_term / 1e9, "peak": 8000.0, "unit": "GB/s",
+                     "frac": alg / per_term / 1e9 / 8000.0, "algorithmic_bytes_per_launch": alg,
+                     "avg_launch_us": per_term * 1e6, "kernel": "csr_spmm_kernel<ChebyOp>"},
+        "single_state_ms_per_step_same_N": ev1, "speedup_vs_one_state_at_a_time": b * ev1 / (1e3 * el / args.steps),
+        "max_norm_drift": float(np.max(np.abs(norms - 1.0)))}))
+
+
+if __name__ == "__main__":
+    main()

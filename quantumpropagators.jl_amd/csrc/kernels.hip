@@ -401,49 +401,93 @@ static inline int ew_grid(int64_t n);
 // There is no dense contraction to feed MFMA: H has scalar entries, so per row this is z
 // AXPYs of length b (0.4 flop/B at b = 64, far below the fp64 ridge).
 // ---------------------------------------------------------------------------
-template <class Op>
+// TS = states per tile.  A workgroup covers 256/TS rows x TS states; gridDim.y walks the state
+// tiles, so the chip streams all rows for one tile of states before the next: the gather
+// window of a banded H (+-4096 rows) is 4096 * 16 * TS bytes per direction and must stay
+// inside an XCD's 4 MiB L2 -- with all 64 states per pass it does not (measured 3.1 TB/s
+// algorithmic, the far gathers spill to HBM), with TS = 16 it does, at the price of streaming
+// the matrix 64/TS times.
+template <class Op, int TS>
 __global__ __launch_bounds__(kThreads) void csr_spmm_kernel(const int64_t* __restrict__ rowptr,
                                                             const int32_t* __restrict__ cols,
                                                             const double2* __restrict__ vals,
                                                             const double2* __restrict__ X, int64_t nrows, int b,
                                                             Op op) {
+  constexpr int RPW = kThreads / TS;   // rows per workgroup
+  constexpr int CH = TS;               // matrix entries staged per row and chunk (one per lane of the row)
+  // (value, column) of the workgroup's rows, staged through LDS so that the TS lanes of a row
+  // read each entry as an LDS broadcast instead of TS redundant global loads; +1 pads the
+  // row stride off the bank period
+  __shared__ double2 s_val[RPW][CH + 1];
+  __shared__ int s_col[RPW][CH + 1];
   const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)wg * (kThreads / 64) + wave;
-  if (row >= nrows) return;
-  const int64_t p0 = rowptr[row], p1 = rowptr[row + 1];
+  const int rl = threadIdx.x / TS, sl = threadIdx.x % TS;
+  const int64_t row = (int64_t)wg * RPW + rl;
+  const int st = blockIdx.y * TS + sl;
+  const bool rvalid = row < nrows;
+  const bool active = rvalid && st < b;
+  const int64_t p0 = rvalid ? rowptr[row] : 0, p1 = rvalid ? rowptr[row + 1] : 0;
+  // longest row of the workgroup (uniform loop bound)
+  int len = (int)(p1 - p0);
+  __shared__ int s_maxlen;
+  if (threadIdx.x == 0) s_maxlen = 0;
+  __syncthreads();
+  if (sl == 0) atomicMax(&s_maxlen, len);
+  __syncthreads();
+  const int maxlen = s_maxlen;
   double2 chk = make_double2(0.0, 0.0);
   double nrm = 0.0;
-  for (int s0 = 0; s0 < b; s0 += 64) {
-    const int st = s0 + lane;
-    if (st >= b) break;
-    const int64_t e = row * (int64_t)b + st;
-    const typename Op::Pre pre = op.pre(e);
-    double2 acc0 = make_double2(0.0, 0.0), acc1 = make_double2(0.0, 0.0);
-    int64_t p = p0;
-    for (; p + 3 < p1; p += 4) {
-      const double2 a0 = vals[p], a1 = vals[p + 1], a2 = vals[p + 2], a3 = vals[p + 3];
-      const double2 x0 = X[(int64_t)cols[p] * b + st];
-      const double2 x1 = X[(int64_t)cols[p + 1] * b + st];
-      const double2 x2 = X[(int64_t)cols[p + 2] * b + st];
-      const double2 x3 = X[(int64_t)cols[p + 3] * b + st];
-      cfma(acc0, a0, x0);
-      cfma(acc1, a1, x1);
-      cfma(acc0, a2, x2);
-      cfma(acc1, a3, x3);
+  const int64_t e = active ? row * (int64_t)b + st : 0;
+  typename Op::Pre pre;
+  if (active) pre = op.pre(e);
+  double2 acc0 = make_double2(0.0, 0.0), acc1 = make_double2(0.0, 0.0);
+  for (int k0 = 0; k0 < maxlen; k0 += CH) {
+    if (k0 > 0) __syncthreads();
+    if (k0 + sl < len) {
+      s_val[rl][sl] = vals[p0 + k0 + sl];
+      s_col[rl][sl] = cols[p0 + k0 + sl];
     }
-    for (; p < p1; ++p) cfma(acc0, vals[p], X[(int64_t)cols[p] * b + st]);
-    op.row(e, make_double2(acc0.x + acc1.x, acc0.y + acc1.y), pre, chk, nrm, e);
+    __syncthreads();
+    const int cnt = min(CH, len - k0);
+    if (active) {
+      int k = 0;
+      for (; k + 3 < cnt; k += 4) {
+        const double2 x0 = X[(int64_t)s_col[rl][k] * b + st];
+        const double2 x1 = X[(int64_t)s_col[rl][k + 1] * b + st];
+        const double2 x2 = X[(int64_t)s_col[rl][k + 2] * b + st];
+        const double2 x3 = X[(int64_t)s_col[rl][k + 3] * b + st];
+        cfma(acc0, s_val[rl][k], x0);
+        cfma(acc1, s_val[rl][k + 1], x1);
+        cfma(acc0, s_val[rl][k + 2], x2);
+        cfma(acc1, s_val[rl][k + 3], x3);
+      }
+      for (; k < cnt; ++k) cfma(acc0, s_val[rl][k], X[(int64_t)s_col[rl][k] * b + st]);
+    }
   }
+  if (active) op.row(e, make_double2(acc0.x + acc1.x, acc0.y + acc1.y), pre, chk, nrm, e);
 }
+
+int g_spmm_tile = 16;
 
 int launch_spmm_cheby(hipStream_t s, const int64_t* rowptr, const int32_t* cols, const double2* vals,
                       const double2* X, int64_t nrows, int64_t nnz, int b, const ChebyEpi& e, Stats* st) {
   if (nrows == 0) return QP_OK;
   ChebyOp op{e};
-  const int grid = (int)((nrows + kThreads / 64 - 1) / (kThreads / 64));
-  hipLaunchKernelGGL(csr_spmm_kernel<ChebyOp>, dim3(grid), dim3(kThreads), 0, s, rowptr, cols, vals, X, nrows, b, op);
+  int ts = g_spmm_tile;
+  if (ts != 16 && ts != 32 && ts != 64) ts = 16;
+  const int rpw = kThreads / ts;
+  dim3 grid((unsigned)((nrows + rpw - 1) / rpw), (unsigned)((b + ts - 1) / ts));
+  switch (ts) {
+    case 16:
+      hipLaunchKernelGGL((csr_spmm_kernel<ChebyOp, 16>), grid, dim3(kThreads), 0, s, rowptr, cols, vals, X, nrows, b, op);
+      break;
+    case 32:
+      hipLaunchKernelGGL((csr_spmm_kernel<ChebyOp, 32>), grid, dim3(kThreads), 0, s, rowptr, cols, vals, X, nrows, b, op);
+      break;
+    default:
+      hipLaunchKernelGGL((csr_spmm_kernel<ChebyOp, 64>), grid, dim3(kThreads), 0, s, rowptr, cols, vals, X, nrows, b, op);
+      break;
+  }
   QP_HIP(hipGetLastError());
   if (st) {
     st->n_launch++;

@@ -17,10 +17,12 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--tile", type=int, default=16)
     args = ap.parse_args()
     N, b = 1 << args.log2n, args.batch
     rp, col, vals = synth.hermitian_offsets_csr(N)
     ctx = L.Context(0)
+    L.tuning_set("spmm_tile", args.tile)
     op = L.Operator(ctx, [L.Matrix(ctx, N, N, rp, col, vals)])
     nnz = int(rp[-1])
     states = np.stack([synth.random_state(N, seed=500 + s) for s in range(b)], axis=1)
@@ -53,7 +55,7 @@ def main():
         "metric": "batched Cheby prop_step!/s, 64 states x N=2^18 CSR (BASELINE configs[4])",
         "value": args.steps / el, "unit": "panel prop_step/s", "state_steps_per_s": b * args.steps / el,
         "ms_per_panel_step": 1e3 * el / args.steps,
-        "config": {"N": N, "batch": b, "nnz_per_row": nnz / N, "matvecs_per_step": nterms},
+        "config": {"N": N, "batch": b, "states_per_pass": args.tile, "nnz_per_row": nnz / N, "matvecs_per_step": nterms},
         "roofline": {"bound": "hbm", "achieved": alg / per_term / 1e9, "peak": 8000.0, "unit": "GB/s",
                      "frac": alg / per_term / 1e9 / 8000.0, "algorithmic_bytes_per_launch": alg,
                      "avg_launch_us": per_term * 1e6, "kernel": "csr_spmm_kernel<ChebyOp>"},

@@ -27,7 +27,11 @@ struct DevMatrix {
   // cols packed 4 per lane: cols4[(bptr[b]>>2) + (k>>2)*64 + r].{x,y,z,w}
   int64_t nblocks = 0;
   int64_t* bptr = nullptr;    // nblocks+1
-  int32_t* cols = nullptr;    // stored (RBCSR: quad packed; CSR: plain)
+  int32_t* cols = nullptr;    // CSR: plain int32.  Row-block formats: a byte stream; block b's
+                              // quad-packed column section starts at byte cmeta[b] >> 1 and holds
+                              // int32 columns, or (cmeta[b] & 1) int16 deltas to the lane's row
+  int64_t* cmeta = nullptr;   // nblocks (row-block formats)
+  int64_t colbytes = 0;
   double2* vals = nullptr;    // stored, the values the SpMV kernels read
   // CSR
   int64_t* rowptr = nullptr;  // nrows+1
@@ -36,7 +40,9 @@ struct DevMatrix {
   // the entries with col < row are (lcols, lpos): column and the position in `vals` of
   // the transposed entry, whose complex conjugate is the value.  Same block layout.
   int64_t* lptr = nullptr;    // nblocks+1
-  int32_t* lcols = nullptr;   // lstored, quad packed
+  int32_t* lcols = nullptr;   // byte stream like `cols`, indexed through lcmeta
+  int64_t* lcmeta = nullptr;  // nblocks
+  int64_t lcolbytes = 0;
   int32_t* lpos = nullptr;    // lstored, quad packed; -1 = padding
   int64_t lstored = 0;
 };

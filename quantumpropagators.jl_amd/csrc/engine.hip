@@ -67,6 +67,7 @@ struct HostLayoutData {
   std::vector<int64_t> bptr;   // RBCSR: all entries; HRB: upper section (c >= r)
   std::vector<int64_t> lptr;   // HRB: lower section (c < r)
   std::vector<int32_t> nlow;   // HRB: number of lower entries per row
+  std::vector<int64_t> cmeta, lcmeta;  // per block: (byte offset of the column section << 1) | is16
   int64_t stored = 0, lstored = 0;
 };
 
@@ -452,6 +453,9 @@ static int operator_free_device(qp_operator* op) {
   if (op->A.bptr) (void)hipFree(op->A.bptr);
   if (op->A.rowptr) (void)hipFree(op->A.rowptr);
   if (op->A.cols) (void)hipFree(op->A.cols);
+  if (op->A.cmeta) (void)hipFree(op->A.cmeta);
+  if (op->A.lcmeta) (void)hipFree(op->A.lcmeta);
+  op->A.cmeta = op->A.lcmeta = nullptr;
   if (op->A.lptr) (void)hipFree(op->A.lptr);
   if (op->A.lcols) (void)hipFree(op->A.lcols);
   if (op->A.lpos) (void)hipFree(op->A.lpos);
@@ -524,6 +528,68 @@ static bool csr_is_hermitian(int64_t n, const std::vector<int64_t>& rp, const st
   return nlower == nupper;
 }
 
+// Encode the quad-packed column sections of all blocks: per block either int32 columns or,
+// if every entry is within +-32767 of its row, int16 deltas to the row (2 bytes of index
+// traffic per entry instead of 4).  `get(r, k, &is_pad)` returns the column of entry k of
+// row r in this section (pad entries: any valid column).
+template <class GetCol>
+static void encode_col_sections(int64_t nrows, int64_t nblocks, const std::vector<int64_t>& ptr, GetCol get,
+                                std::vector<char>& bytes, std::vector<int64_t>& meta) {
+  meta.assign((size_t)nblocks, 0);
+  bytes.clear();
+  for (int64_t b = 0; b < nblocks; ++b) {
+    const int64_t w = (ptr[b + 1] - ptr[b]) / kRB;
+    bool ok16 = true;
+    for (int64_t l = 0; l < kRB && ok16; ++l) {
+      const int64_t r = b * kRB + l;
+      if (r >= nrows) break;
+      for (int64_t k = 0; k < w; ++k) {
+        bool pad = false;
+        const int64_t c = get(r, k, &pad);
+        if (!pad && (c - r > 32767 || r - c > 32767)) { ok16 = false; break; }
+      }
+    }
+    while (bytes.size() % 16) bytes.push_back(0);
+    meta[b] = ((int64_t)bytes.size() << 1) | (ok16 ? 1 : 0);
+    const size_t esz = ok16 ? 2 : 4;
+    const size_t off = bytes.size();
+    bytes.resize(off + (size_t)w * kRB * esz, 0);
+    for (int64_t l = 0; l < kRB; ++l) {
+      const int64_t r = b * kRB + l;
+      const int64_t rc = std::min(r, nrows - 1);   // the kernel decodes deltas against the clamped row
+      for (int64_t k = 0; k < w; ++k) {
+        bool pad = (r >= nrows);
+        int64_t c = pad ? rc : get(r, k, &pad);
+        if (pad && ok16) c = rc;
+        const size_t q = (size_t)(k >> 2) * (4 * kRB) + (size_t)l * 4 + (k & 3);   // quad-packed slot
+        if (ok16) {
+          const int16_t d = (int16_t)(c - rc);
+          std::memcpy(&bytes[off + q * 2], &d, 2);
+        } else {
+          const int32_t c32 = (int32_t)c;
+          std::memcpy(&bytes[off + q * 4], &c32, 4);
+        }
+      }
+    }
+  }
+  while (bytes.size() % 16) bytes.push_back(0);
+}
+
+static int64_t decode_col(const std::vector<char>& bytes, const std::vector<int64_t>& meta, int64_t nrows, int64_t r,
+                          int64_t k) {
+  const int64_t m = meta[r / kRB];
+  const size_t off = (size_t)(m >> 1);
+  const size_t q = (size_t)(k >> 2) * (4 * kRB) + (size_t)(r % kRB) * 4 + (k & 3);
+  if (m & 1) {
+    int16_t d;
+    std::memcpy(&d, &bytes[off + q * 2], 2);
+    return std::min(r, nrows - 1) + d;
+  }
+  int32_t c;
+  std::memcpy(&c, &bytes[off + q * 4], 4);
+  return c;
+}
+
 // Build every device array of `op` for `format` from the union pattern (op->u_rowptr /
 // u_col) and the per-term values given in union-CSR order.
 static int operator_build_device(qp_operator* op, int format, const std::vector<std::vector<cplx>>& planes_csr) {
@@ -580,44 +646,54 @@ static int operator_build_device(qp_operator* op, int format, const std::vector<
     A.stored = Lh.stored;
     A.lstored = Lh.lstored;
     // upper (or full) column indices
-    std::vector<int32_t> hcols((size_t)A.stored, 0);
-    for (int64_t r = 0; r < nrows; ++r) {
-      const int64_t nl = hrb ? Lh.nlow[r] : 0;
-      const int64_t len = ur[r + 1] - ur[r] - nl;
-      const int64_t w = (Lh.bptr[r / kRB + 1] - Lh.bptr[r / kRB]) / kRB;
-      const int32_t padcol = (ur[r + 1] > ur[r]) ? uc[ur[r]] : 0;
-      for (int64_t k = 0; k < w; ++k) hcols[rb_quad_pos(Lh.bptr, r, k)] = (k < len) ? uc[ur[r] + nl + k] : padcol;
+    {
+      std::vector<char> cbytes;
+      encode_col_sections(nrows, A.nblocks, Lh.bptr,
+                          [&](int64_t r, int64_t k, bool* pad) -> int64_t {
+                            const int64_t nl = hrb ? Lh.nlow[r] : 0;
+                            const int64_t len = ur[r + 1] - ur[r] - nl;
+                            if (k < len) return uc[ur[r] + nl + k];
+                            *pad = true;
+                            return (ur[r + 1] > ur[r]) ? uc[ur[r]] : 0;
+                          },
+                          cbytes, Lh.cmeta);
+      A.colbytes = (int64_t)cbytes.size();
+      QP_CHECK(dev_alloc(reinterpret_cast<char**>(&A.cols), cbytes.size()));
+      QP_HIP(hipMemcpy(A.cols, cbytes.data(), cbytes.size(), hipMemcpyHostToDevice));
+      QP_CHECK(dev_alloc(&A.cmeta, Lh.cmeta.size()));
+      QP_HIP(hipMemcpy(A.cmeta, Lh.cmeta.data(), Lh.cmeta.size() * sizeof(int64_t), hipMemcpyHostToDevice));
     }
     QP_CHECK(dev_alloc(&A.bptr, Lh.bptr.size()));
     QP_HIP(hipMemcpy(A.bptr, Lh.bptr.data(), Lh.bptr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
-    QP_CHECK(dev_alloc(&A.cols, (size_t)A.stored));
-    QP_HIP(hipMemcpy(A.cols, hcols.data(), (size_t)A.stored * sizeof(int32_t), hipMemcpyHostToDevice));
     if (hrb) {
       // lower section: (column, position of the conj-transposed value in the upper section)
-      std::vector<int32_t> lcols((size_t)std::max<int64_t>(A.lstored, 1), 0), lpos((size_t)std::max<int64_t>(A.lstored, 1), -1);
+      std::vector<int32_t> lpos((size_t)std::max<int64_t>(A.lstored, 1), -1);
       if (Lh.stored >= (int64_t)INT32_MAX) return qp::fail(QP_E_BAD_ARG, "Hermitian-packed format needs < 2^31 stored values per GPU");
       for (int64_t r = 0; r < nrows; ++r) {
         const int64_t nl = Lh.nlow[r];
-        const int64_t w = (Lh.lptr[r / kRB + 1] - Lh.lptr[r / kRB]) / kRB;
-        for (int64_t k = 0; k < w; ++k) {
-          const int64_t q = rb_quad_pos(Lh.lptr, r, k);
-          if (k < nl) {
-            const int64_t c = uc[ur[r] + k];
-            const int32_t* b = uc.data() + ur[c];
-            const int32_t* e = uc.data() + ur[c + 1];
-            const int64_t kk = (std::lower_bound(b, e, (int32_t)r) - b) - Lh.nlow[c];  // index of (c,r) among row c's upper entries
-            lcols[q] = (int32_t)c;
-            lpos[q] = (int32_t)rb_val_pos(Lh.bptr, c, kk);
-          } else {
-            lcols[q] = (int32_t)r;  // padded: any valid column, value masked by pos < 0
-            lpos[q] = -1;
-          }
+        for (int64_t k = 0; k < nl; ++k) {
+          const int64_t c = uc[ur[r] + k];
+          const int32_t* b = uc.data() + ur[c];
+          const int32_t* e = uc.data() + ur[c + 1];
+          const int64_t kk = (std::lower_bound(b, e, (int32_t)r) - b) - Lh.nlow[c];  // index of (c,r) among row c's upper entries
+          lpos[rb_quad_pos(Lh.lptr, r, k)] = (int32_t)rb_val_pos(Lh.bptr, c, kk);
         }
       }
+      std::vector<char> lbytes;
+      encode_col_sections(nrows, A.nblocks, Lh.lptr,
+                          [&](int64_t r, int64_t k, bool* pad) -> int64_t {
+                            if (k < Lh.nlow[r]) return uc[ur[r] + k];
+                            *pad = true;          // padded: any valid column, value masked by pos < 0
+                            return r;
+                          },
+                          lbytes, Lh.lcmeta);
+      A.lcolbytes = (int64_t)lbytes.size();
       QP_CHECK(dev_alloc(&A.lptr, Lh.lptr.size()));
       QP_HIP(hipMemcpy(A.lptr, Lh.lptr.data(), Lh.lptr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
-      QP_CHECK(dev_alloc(&A.lcols, lcols.size()));
-      QP_HIP(hipMemcpy(A.lcols, lcols.data(), lcols.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+      QP_CHECK(dev_alloc(reinterpret_cast<char**>(&A.lcols), std::max<size_t>(lbytes.size(), 16)));
+      if (!lbytes.empty()) QP_HIP(hipMemcpy(A.lcols, lbytes.data(), lbytes.size(), hipMemcpyHostToDevice));
+      QP_CHECK(dev_alloc(&A.lcmeta, Lh.lcmeta.size()));
+      QP_HIP(hipMemcpy(A.lcmeta, Lh.lcmeta.data(), Lh.lcmeta.size() * sizeof(int64_t), hipMemcpyHostToDevice));
       QP_CHECK(dev_alloc(&A.lpos, lpos.size()));
       QP_HIP(hipMemcpy(A.lpos, lpos.data(), lpos.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
@@ -866,26 +942,31 @@ int qp_operator_get_csr(qp_operator* op, int64_t* rowptr, int32_t* col, qp_c128*
   const auto& ur = op->u_rowptr;
   QP_HIP(hipStreamSynchronize(op->ctx->stream));
   std::vector<cplx> hv((size_t)std::max<int64_t>(A.stored, 1));
-  std::vector<int32_t> hc((size_t)std::max<int64_t>(A.stored, 1));
   QP_HIP(hipMemcpy(hv.data(), A.vals, (size_t)A.stored * sizeof(double2), hipMemcpyDeviceToHost));
-  QP_HIP(hipMemcpy(hc.data(), A.cols, (size_t)A.stored * sizeof(int32_t), hipMemcpyDeviceToHost));
   if (A.format == QP_FMT_CSR) {
     std::vector<int64_t> rp(A.nrows + 1);
+    std::vector<int32_t> hc((size_t)std::max<int64_t>(A.nnz, 1));
     QP_HIP(hipMemcpy(rp.data(), A.rowptr, rp.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+    QP_HIP(hipMemcpy(hc.data(), A.cols, (size_t)A.nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
     std::memcpy(rowptr, rp.data(), rp.size() * sizeof(int64_t));
     std::memcpy(col, hc.data(), (size_t)A.nnz * sizeof(int32_t));
     std::memcpy(vals, hv.data(), (size_t)A.nnz * sizeof(qp_c128));
     return QP_OK;
   }
-  std::vector<int64_t> bptr(A.nblocks + 1), lptr;
+  std::vector<int64_t> bptr(A.nblocks + 1), cmeta((size_t)A.nblocks), lptr, lcmeta;
+  std::vector<char> cbytes((size_t)std::max<int64_t>(A.colbytes, 1)), lbytes;
   QP_HIP(hipMemcpy(bptr.data(), A.bptr, bptr.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
-  std::vector<int32_t> lc, lp;
+  QP_HIP(hipMemcpy(cmeta.data(), A.cmeta, cmeta.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+  QP_HIP(hipMemcpy(cbytes.data(), A.cols, (size_t)A.colbytes, hipMemcpyDeviceToHost));
+  std::vector<int32_t> lp;
   if (A.format == QP_FMT_HRB) {
     lptr.resize(A.nblocks + 1);
-    lc.resize((size_t)std::max<int64_t>(A.lstored, 1));
-    lp.resize(lc.size());
+    lcmeta.resize((size_t)A.nblocks);
+    lbytes.resize((size_t)std::max<int64_t>(A.lcolbytes, 1));
+    lp.resize((size_t)std::max<int64_t>(A.lstored, 1));
     QP_HIP(hipMemcpy(lptr.data(), A.lptr, lptr.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
-    QP_HIP(hipMemcpy(lc.data(), A.lcols, lc.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    QP_HIP(hipMemcpy(lcmeta.data(), A.lcmeta, lcmeta.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (A.lcolbytes > 0) QP_HIP(hipMemcpy(lbytes.data(), A.lcols, (size_t)A.lcolbytes, hipMemcpyDeviceToHost));
     QP_HIP(hipMemcpy(lp.data(), A.lpos, lp.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
   }
   for (int64_t r = 0; r <= A.nrows; ++r) rowptr[r] = ur[r];
@@ -893,16 +974,15 @@ int qp_operator_get_csr(qp_operator* op, int64_t* rowptr, int32_t* col, qp_c128*
     const int64_t nl = (A.format == QP_FMT_HRB) ? op->layout.nlow[r] : 0;
     for (int64_t k = 0; k < ur[r + 1] - ur[r]; ++k) {
       cplx v;
-      int32_t c;
+      int64_t c;
       if (k >= nl) {
-        c = hc[rb_quad_pos(bptr, r, k - nl)];
+        c = decode_col(cbytes, cmeta, A.nrows, r, k - nl);
         v = hv[rb_val_pos(bptr, r, k - nl)];
       } else {
-        const int64_t q = rb_quad_pos(lptr, r, k);
-        c = lc[q];
-        v = std::conj(hv[lp[q]]);
+        c = decode_col(lbytes, lcmeta, A.nrows, r, k);
+        v = std::conj(hv[lp[rb_quad_pos(lptr, r, k)]]);
       }
-      col[ur[r] + k] = c;
+      col[ur[r] + k] = (int32_t)c;
       vals[ur[r] + k] = qp_c128{v.real(), v.imag()};
     }
   }

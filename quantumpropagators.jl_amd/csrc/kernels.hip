@@ -213,11 +213,31 @@ __device__ __forceinline__ int4 ld_col(const int4* p) {
   return *p;
 }
 
+typedef int i2v __attribute__((ext_vector_type(2)));
+
+// Column indices of quad q for this lane.  A block stores either int32 columns or, when
+// every column of the block is within +-32767 of its row (banded H), int16 deltas to the
+// lane's own row: 2 instead of 4 bytes per entry of index traffic.
+template <bool NT>
+__device__ __forceinline__ int4 ld_cols(const char* __restrict__ colbytes, int64_t meta, int q, int lane, int rowc) {
+  const char* p = colbytes + (meta >> 1);
+  if (meta & 1) {
+    const i2v* q8 = reinterpret_cast<const i2v*>(p) + (size_t)q * 64 + lane;
+    i2v t;
+    if (NT) t = __builtin_nontemporal_load(q8);
+    else t = *q8;
+    return make_int4(rowc + (short)(t.x & 0xffff), rowc + (short)(t.x >> 16), rowc + (short)(t.y & 0xffff),
+                     rowc + (short)(t.y >> 16));
+  }
+  return ld_col<NT>(reinterpret_cast<const int4*>(p) + (size_t)q * 64 + lane);
+}
+
 // VAR bit 0: nt matrix loads; bit 1: row-local operands prefetched before the loop;
 // bit 2: unroll 4 quads (16 value loads in flight per lane) instead of 2
 template <class Op, int VAR>
 __global__ __launch_bounds__(kThreads) void rbcsr_spmv_kernel(const int64_t* __restrict__ bptr,
-                                                              const int4* __restrict__ cols4,
+                                                              const int64_t* __restrict__ cmeta,
+                                                              const char* __restrict__ colbytes,
                                                               const double2* __restrict__ vals,
                                                               const double2* __restrict__ x,
                                                               int64_t nblocks, int64_t nrows, Op op,
@@ -238,7 +258,7 @@ __global__ __launch_bounds__(kThreads) void rbcsr_spmv_kernel(const int64_t* __r
     const int64_t base = bptr[b];
     const int nq = (int)((bptr[b + 1] - base) >> 8);  // width / 4
     const double2* __restrict__ v = vals + base + lane;
-    const int4* __restrict__ c4 = cols4 + (base >> 2) + lane;
+    const int64_t cm = cmeta[b];
     const int64_t row = b * kRB + lane;
     const int64_t rowc = row < nrows ? row : nrows - 1;
     typename Op::Pre pre;
@@ -246,7 +266,7 @@ __global__ __launch_bounds__(kThreads) void rbcsr_spmv_kernel(const int64_t* __r
     double2 s0 = make_double2(0.0, 0.0), s1 = make_double2(0.0, 0.0);
 #pragma unroll UNR
     for (int q = 0; q < nq; ++q) {
-      const int4 c = ld_col<NT>(c4 + (size_t)q * 64);
+      const int4 c = ld_cols<NT>(colbytes, cm, q, lane, (int)rowc);
       const double2 a0 = ld_val<NT>(v + (size_t)(4 * q + 0) * 64);
       const double2 a1 = ld_val<NT>(v + (size_t)(4 * q + 1) * 64);
       const double2 a2 = ld_val<NT>(v + (size_t)(4 * q + 2) * 64);
@@ -288,10 +308,12 @@ __device__ __forceinline__ double2 ld_tr(const double2* __restrict__ vals, int p
 
 template <class Op, int VAR>
 __global__ __launch_bounds__(kThreads) void hrb_spmv_kernel(const int64_t* __restrict__ uptr,
-                                                            const int4* __restrict__ ucols4,
+                                                            const int64_t* __restrict__ ucmeta,
+                                                            const char* __restrict__ ucolbytes,
                                                             const double2* __restrict__ uvals,
                                                             const int64_t* __restrict__ lptr,
-                                                            const int4* __restrict__ lcols4,
+                                                            const int64_t* __restrict__ lcmeta,
+                                                            const char* __restrict__ lcolbytes,
                                                             const int4* __restrict__ lpos4,
                                                             const double2* __restrict__ x, int64_t nblocks,
                                                             int64_t nrows, Op op,
@@ -313,8 +335,7 @@ __global__ __launch_bounds__(kThreads) void hrb_spmv_kernel(const int64_t* __res
     const int nuq = (int)((uptr[b + 1] - ubase) >> 8);
     const int nlq = (int)((lptr[b + 1] - lbase) >> 8);
     const double2* __restrict__ v = uvals + ubase + lane;
-    const int4* __restrict__ c4 = ucols4 + (ubase >> 2) + lane;
-    const int4* __restrict__ lc4 = lcols4 + (lbase >> 2) + lane;
+    const int64_t ucm = ucmeta[b], lcm = lcmeta[b];
     const int4* __restrict__ lp4 = lpos4 + (lbase >> 2) + lane;
     const int64_t row = b * kRB + lane;
     const int64_t rowc = row < nrows ? row : nrows - 1;
@@ -323,7 +344,7 @@ __global__ __launch_bounds__(kThreads) void hrb_spmv_kernel(const int64_t* __res
     double2 s0 = make_double2(0.0, 0.0), s1 = make_double2(0.0, 0.0);
 #pragma unroll UNR
     for (int q = 0; q < nlq; ++q) {   // lower section first: its values are already in L2
-      const int4 c = ld_col<NT>(lc4 + (size_t)q * 64);
+      const int4 c = ld_cols<NT>(lcolbytes, lcm, q, lane, (int)rowc);
       const int4 p = ld_col<NT>(lp4 + (size_t)q * 64);
       const double2 a0 = ld_tr(uvals, p.x);
       const double2 a1 = ld_tr(uvals, p.y);
@@ -340,7 +361,7 @@ __global__ __launch_bounds__(kThreads) void hrb_spmv_kernel(const int64_t* __res
     }
 #pragma unroll UNR
     for (int q = 0; q < nuq; ++q) {
-      const int4 c = ld_col<NT>(c4 + (size_t)q * 64);
+      const int4 c = ld_cols<NT>(ucolbytes, ucm, q, lane, (int)rowc);
       const double2 a0 = v[(size_t)(4 * q + 0) * 64];
       const double2 a1 = v[(size_t)(4 * q + 1) * 64];
       const double2 a2 = v[(size_t)(4 * q + 2) * 64];
@@ -547,8 +568,8 @@ static int launch_spmv(hipStream_t s, const DevMatrix& A, const double2* x, cons
   if (A.format == QP_FMT_RBCSR) {
 #define QP_RB_CASE(VV)                                                                                   \
   case VV:                                                                                               \
-    hipLaunchKernelGGL((rbcsr_spmv_kernel<Op, VV>), dim3(grid), dim3(kThreads), 0, s, A.bptr,            \
-                       reinterpret_cast<const int4*>(A.cols), A.vals, x, nblk, A.nrows, op, bmap, sy);      \
+    hipLaunchKernelGGL((rbcsr_spmv_kernel<Op, VV>), dim3(grid), dim3(kThreads), 0, s, A.bptr, A.cmeta,   \
+                       reinterpret_cast<const char*>(A.cols), A.vals, x, nblk, A.nrows, op, bmap, sy);      \
     break;
     switch (g_rbcsr_variant & 7) {
       QP_RB_CASE(0)
@@ -564,9 +585,9 @@ static int launch_spmv(hipStream_t s, const DevMatrix& A, const double2* x, cons
   } else if (A.format == QP_FMT_HRB) {
 #define QP_HRB_CASE(VV)                                                                                  \
   case VV:                                                                                               \
-    hipLaunchKernelGGL((hrb_spmv_kernel<Op, VV>), dim3(grid), dim3(kThreads), 0, s, A.bptr,              \
-                       reinterpret_cast<const int4*>(A.cols), A.vals, A.lptr,                            \
-                       reinterpret_cast<const int4*>(A.lcols), reinterpret_cast<const int4*>(A.lpos), x, \
+    hipLaunchKernelGGL((hrb_spmv_kernel<Op, VV>), dim3(grid), dim3(kThreads), 0, s, A.bptr, A.cmeta,     \
+                       reinterpret_cast<const char*>(A.cols), A.vals, A.lptr, A.lcmeta,                  \
+                       reinterpret_cast<const char*>(A.lcols), reinterpret_cast<const int4*>(A.lpos), x, \
                        nblk, A.nrows, op, bmap, sy);                                                     \
     break;
     switch (g_rbcsr_variant & 7) {

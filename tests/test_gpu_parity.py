@@ -116,6 +116,25 @@ def test_hermitian_packed_operator_sum(ctx):
     assert Op.format in (L.FMT_RBCSR, L.FMT_CSR)   # left the packed format at the complex coefficient
 
 
+@pytest.mark.parametrize("fmt", [L.FMT_HRB, L.FMT_RBCSR])
+def test_column_delta_encoding_roundtrip_and_parity(ctx, fmt):
+    """Row blocks whose columns are all within +-32767 of their row store int16 deltas, the
+    others int32 columns; a matrix with both kinds of blocks must round-trip bit-exactly and
+    multiply correctly (N > 2^16 so that far and wrap-around couplings overflow int16)."""
+    N = 1 << 17
+    rp, col, vals = synth.hermitian_offsets_csr(N, offsets=(1, 2, 3, 40000))   # 40000 > 32767: every block int32
+    rp2, col2, vals2 = synth.hermitian_offsets_csr(N, offsets=(1, 2, 3, 30000))  # interior int16, wrap blocks int32
+    rng = np.random.default_rng(5)
+    x = _rand_state(N, rng)
+    for (a, b, c) in ((rp, col, vals), (rp2, col2, vals2)):
+        Op = L.Operator(ctx, [L.Matrix(ctx, N, N, a, b, c)], 0, fmt)
+        r_, c_, v_ = Op.get_csr()
+        assert np.array_equal(r_, a) and np.array_equal(c_, b) and np.array_equal(v_, c)
+        y = L.State(ctx, n=N)
+        Op.mul(L.State(ctx, data=x), y)
+        assert np.linalg.norm(y.numpy() - synth.to_scipy(a, b, c, N) @ x) < 1e-12
+
+
 def test_operator_auto_format(ctx):
     rp, col, vals = synth.hermitian_offsets_csr(512, offsets=(1, 2, 3, 4, 16, 32, 48, 64))
     Op = L.Operator(ctx, [L.Matrix(ctx, 512, 512, rp, col, vals)])

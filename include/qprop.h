@@ -84,9 +84,12 @@ int qp_device_count(int* n_out);
 int qp_tuning_set(const char* key, int value);
 
 /* ---- context -------------------------------------------------------------------- */
-/* `stream` may be NULL (the library creates one) or an existing hipStream_t, e.g.
- * torch.cuda.current_stream().cuda_stream, so that torch.distributed collectives and
- * library kernels are ordered on one stream. */
+/* `stream` may be NULL (the library creates a non-blocking stream of its own), an existing
+ * hipStream_t, or QP_STREAM_NULL for HIP's null (legacy default) stream -- whose handle is 0
+ * and therefore cannot be passed literally.  Pass the caller's stream (e.g.
+ * torch.cuda.current_stream().cuda_stream, which IS the null stream unless the caller set
+ * another one) whenever the caller's own copies / collectives touch the same buffers. */
+#define QP_STREAM_NULL ((void*)(intptr_t)-1)
 int qp_ctx_create(int device, void* stream, qp_ctx** out);
 int qp_ctx_destroy(qp_ctx* ctx);
 int qp_sync(qp_ctx* ctx);

@@ -270,7 +270,9 @@ int qp_ctx_create(int device, void* stream, qp_ctx** out) {
   QP_HIP(hipSetDevice(device));
   auto ctx = std::make_unique<qp_ctx>();
   ctx->device = device;
-  if (stream) {
+  if (stream == QP_STREAM_NULL) {
+    ctx->stream = nullptr;   // HIP's null stream
+  } else if (stream) {
     ctx->stream = (hipStream_t)stream;
   } else {
     QP_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
@@ -532,6 +534,7 @@ static bool csr_is_hermitian(int64_t n, const std::vector<int64_t>& rp, const st
 // if every entry is within +-32767 of its row, int16 deltas to the row (2 bytes of index
 // traffic per entry instead of 4).  `get(r, k, &is_pad)` returns the column of entry k of
 // row r in this section (pad entries: any valid column).
+extern "C++" {
 template <class GetCol>
 static void encode_col_sections(int64_t nrows, int64_t nblocks, const std::vector<int64_t>& ptr, GetCol get,
                                 std::vector<char>& bytes, std::vector<int64_t>& meta) {
@@ -574,6 +577,7 @@ static void encode_col_sections(int64_t nrows, int64_t nblocks, const std::vecto
   }
   while (bytes.size() % 16) bytes.push_back(0);
 }
+}  // extern "C++"
 
 static int64_t decode_col(const std::vector<char>& bytes, const std::vector<int64_t>& meta, int64_t nrows, int64_t r,
                           int64_t k) {

@@ -298,13 +298,21 @@ def partition_rows(rowptr, nparts, balance="rows"):
 # ------------------------------------------------------------------------------
 
 class Context:
-    """Device + HIP stream.  ``stream`` may be a raw hipStream_t (int), e.g.
-    ``torch.cuda.current_stream().cuda_stream``."""
+    """Device + HIP stream.  ``stream=None``: the library creates its own stream;
+    otherwise a raw hipStream_t (int), e.g. ``torch.cuda.current_stream().cuda_stream`` --
+    which is 0 (HIP's null stream) unless the caller switched streams; 0 is passed on as
+    QP_STREAM_NULL so that library kernels and the caller's copies share that stream."""
 
     def __init__(self, device=0, stream=None):
         self._h = _P()
         self.lib = load()
-        check(self.lib.qp_ctx_create(int(device), _P(stream) if stream else None, C.byref(self._h)))
+        if stream is None:
+            sarg = None
+        elif int(stream) == 0:
+            sarg = _P(-1)            # QP_STREAM_NULL
+        else:
+            sarg = _P(int(stream))
+        check(self.lib.qp_ctx_create(int(device), sarg, C.byref(self._h)))
         self.device = int(device)
         self._children = weakref.WeakSet()   # handles that must be destroyed before the context
 

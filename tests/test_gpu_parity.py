@@ -618,3 +618,43 @@ def test_full_size_properties(ctx):
         Op.close()
     assert np.linalg.norm(res[L.FMT_RBCSR] - res[L.FMT_CSR]) < TOL
     assert np.linalg.norm(res[L.FMT_HRB] - res[L.FMT_RBCSR]) < TOL
+
+
+def test_newton_c3_full_size(ctx):
+    """BASELINE configs[2] at full size: N = 2^18 non-Hermitian Liouvillian (n = 512), Newton
+    with m_max = 20, one step against the NumPy oracle (a few seconds of CPU)."""
+    Lm = synth.liouvillian_tridiag(512)
+    N = Lm.shape[0]
+    assert N == 1 << 18
+    rho0 = synth.random_state(N)
+    Op = L.Operator(ctx, [L.Matrix.from_scipy(ctx, Lm)])
+    wrk = L.NewtonWrk(ctx, N, m_max=20)
+    rho = L.State(ctx, data=rho0)
+    L.newton(rho, Op, 0.5, wrk)
+    owrk = qo.NewtonWrk(rho0, m_max=20)
+    ref = qo.newton(rho0.copy(), Lm, 0.5, owrk)
+    assert np.linalg.norm(rho.numpy() - ref) < TOL
+    assert abs(wrk.restarts - owrk.restarts) <= 1
+
+
+def test_batched_c5_full_size_properties(ctx):
+    """BASELINE configs[4] at full size: 64 states x N = 2^18.  Every state of the panel must
+    equal the single-state kernel's result for that state (different kernel, same operator),
+    norms are conserved and a backward step undoes a forward one."""
+    N, b = 1 << 18, 64
+    rp, col, vals = synth.hermitian_offsets_csr(N)
+    Op = L.Operator(ctx, [L.Matrix(ctx, N, N, rp, col, vals)])
+    del rp, col, vals
+    states = np.stack([synth.random_state(N, seed=500 + s) for s in range(b)], axis=1)
+    panel = L.State(ctx, data=states.reshape(-1))
+    wrk = L.ChebyWrk(ctx, N * b, 20.0, -10.0, 1.0)
+    L.cheby_batched(panel, Op, 1.0, wrk, b)
+    out = panel.numpy().reshape(N, b)
+    assert np.max(np.abs(np.linalg.norm(out, axis=0) - 1.0)) < 1e-11
+    w1 = L.ChebyWrk(ctx, N, 20.0, -10.0, 1.0)
+    for s in (0, 17, 63):
+        single = L.State(ctx, data=states[:, s].copy())
+        L.cheby(single, Op, 1.0, w1)
+        assert np.linalg.norm(single.numpy() - out[:, s]) < TOL
+    L.cheby_batched(panel, Op, -1.0, wrk, b)
+    assert np.linalg.norm(panel.numpy().reshape(N, b) - states) < 1e-9

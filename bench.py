@@ -140,6 +140,8 @@ def main():
         print(f"[debug] rank {rank}: enqueue {1e3*t_enq:.2f} ms, +events {1e3*t_ev:.2f} ms, +sync/barrier "
               f"{1e3*elapsed:.2f} ms, hip events {ev_ms:.2f} ms", file=sys.stderr)
     st = ctx.stats()
+    if world > 1:
+        sh.check()      # outside the timed region: the overlapped schedule never timed out
     if dist is not None:
         t = torch.tensor([elapsed, ev_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -215,6 +215,14 @@ class ShardedCheby:
                 if self.split is not None:
                     self.side = be.new_stream()
         self.n_exchanges = 0
+        # start the ranks aligned: a rank that is still building its operator must not keep
+        # the others waiting inside their first collective
+        dist.barrier(group=group)
+
+    def check(self):
+        """Synchronise and verify that no in-launch wait of the overlapped schedule timed out."""
+        if self.split is not None and hasattr(self.split, "check"):
+            self.split.check()
 
     # the state lives in X[0][:nloc]
     def set_state(self, psi_local):

@@ -137,10 +137,14 @@ class ShardedCheby:
 
     def __init__(self, ctx, rowptr, col, vals, N, r0, r1, Delta, E_min, dt, fmt=L.FMT_AUTO,
                  exchange="auto", group=None, backend=None, limit=1e-12, overlap=True,
-                 _debug_send_rows=None):
+                 host_staged=False, _debug_send_rows=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
+        # host_staged: move the slabs through pinned host memory and a CPU collective (gloo).
+        # Only for testing the full HIP path with several ranks sharing one GPU, where RCCL
+        # refuses to form a communicator; never used by bench.py.
+        self.host_staged = bool(host_staged)
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.N, self.r0, self.r1 = int(N), int(r0), int(r1)
@@ -245,7 +249,13 @@ class ShardedCheby:
             send = self.slab
             if not packed:
                 self.torch.index_select(x[: 2 * nloc].view(-1, 2), 0, self.send_idx, out=send.view(-1, 2))
-        self.dist.all_gather_into_tensor(x[2 * nloc:], send, group=self.group)
+        if self.host_staged:
+            h_send = send.cpu()                              # synchronises the current stream
+            h_recv = self.torch.empty(self.world * h_send.numel(), dtype=h_send.dtype)
+            self.dist.all_gather_into_tensor(h_recv, h_send, group=self.group)
+            x[2 * nloc:].copy_(h_recv)
+        else:
+            self.dist.all_gather_into_tensor(x[2 * nloc:], send, group=self.group)
         self.n_exchanges += 1
 
     def step(self, backward=False):

@@ -14,9 +14,11 @@ def pytest_configure(config):
 
 
 def _has_gpu():
+    # device_count() does not initialise the GPU in this process (is_available() would), which
+    # keeps the parent clean for tests that start GPU child processes
     try:
         import torch
-        return torch.cuda.is_available()
+        return torch.cuda.device_count() > 0
     except Exception:
         return False
 

@@ -1,0 +1,64 @@
+"""Worker of tests/test_00_multirank_gpu.py: one rank of a 2- or 3-rank row-partitioned
+Chebyshev run in which ALL ranks share GPU 0.  The product HIP path runs unchanged (local
+numbering, Hermitian-packed local blocks, boundary/interior split on two streams, fused
+pack); only the collective is staged through the host with gloo, because RCCL cannot form a
+communicator of several ranks on one device.  Compares against the NumPy oracle."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import qp_oracle as qo  # noqa: E402
+import qprop_amd.lib as L  # noqa: E402
+import qprop_amd.sharded as sharded  # noqa: E402
+import qprop_amd.synth as synth  # noqa: E402
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    overlap = os.environ.get("QP_OVERLAP", "1") == "1"
+    exchange = os.environ.get("QP_EXCHANGE", "auto")
+    uneven = os.environ.get("QP_UNEVEN", "0") == "1"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    N = 12288
+    offsets = (1, 2, 3, 4, 16, 32, 48, 64) if exchange != "allgather" else (5, 777, 2111, 3333, 4001, 4667, 5889, 6099)
+    rp, col, vals = synth.hermitian_offsets_csr(N, offsets=offsets)
+    bounds = qo.partition_rows(rp, world).copy()
+    if uneven:
+        bounds[1:-1] += 100
+    r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
+    ctx = L.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    sh = sharded.ShardedCheby(ctx, rp[r0:r1 + 1] - rp[r0], col[rp[r0]:rp[r1]], vals[rp[r0]:rp[r1]], N, r0, r1,
+                              20.0, -10.0, 1.0, exchange=exchange, overlap=overlap, host_staged=True)
+    psi0 = synth.random_state(N)
+    sh.set_state(psi0[r0:r1])
+    for _ in range(3):
+        sh.step()
+    sh.step(backward=True)
+    torch.cuda.synchronize()
+    sh.check()
+    out = sh.local_state()
+    H = synth.to_scipy(rp, col, vals, N)
+    wrk = qo.ChebyWrk(psi0, 20.0, -10.0, 1.0)
+    ref = psi0.copy()
+    for _ in range(3):
+        qo.cheby(ref, H, 1.0, wrk)
+    qo.cheby(ref, H, -1.0, wrk)
+    err = float(np.linalg.norm(out - ref[r0:r1]))
+    print(f"rank {rank}/{world}: err={err:.3e} format={sh.op.format} exchange={sh.exchange} M={sh.M} "
+          f"split={'yes' if sh.split is not None else 'no'}", flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    if not err < 1e-10:
+        sys.exit(3)
+    if exchange != "allgather" and (sh.op.format != L.FMT_HRB or (sh.split is not None) != overlap):
+        sys.exit(4)
+
+
+if __name__ == "__main__":
+    main()

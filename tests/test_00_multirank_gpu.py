@@ -1,0 +1,49 @@
+"""End-to-end multi-rank test of the product HIP path on ONE GPU: 2 and 3 processes share GPU
+0 (collective staged through the host with gloo -- see tests/multirank_gpu_worker.py).  This
+file sorts first on purpose: the children must be started before this process initialises the
+GPU (a GPU-initialised parent must not fork+exec on the test pool)."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(world, **env_extra):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "multirank_gpu_worker.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for p, out in zip(procs, outs):
+        assert p.returncode == 0, out[-3000:]
+        assert "err=" in out
+    return outs
+
+
+@pytest.mark.parametrize("world,overlap,exchange,uneven", [
+    (2, "1", "auto", "0"),
+    (2, "0", "auto", "0"),
+    (3, "1", "auto", "1"),
+    (2, "1", "allgather", "0"),
+])
+def test_multirank_hip_path_one_gpu(world, overlap, exchange, uneven):
+    _run(world, QP_OVERLAP=overlap, QP_EXCHANGE=exchange, QP_UNEVEN=uneven)

@@ -186,8 +186,13 @@ def main():
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "avg_launch_us": avg_launch_s * 1e6,
                      "launches_timed": n_launch, "hip_event_ms": ev_ms,
+                     "traffic_rate_gbs": (traffic / avg_launch_s / 1e9) if traffic else None,
                      "note": "avg launch duration = HIP-event time of the timed region on the kernels' stream / "
-                             "number of fused-term launches (includes launch gaps; multi-GPU: includes exchange)"},
+                             "number of fused-term launches (includes launch gaps; multi-GPU: includes exchange). "
+                             "`achieved` uses the contract's algorithmic CSR bytes (SURVEY 8d: (20 z + 84) N); the "
+                             "shipped Hermitian-packed format with int16 column deltas stores 272 B/row instead of "
+                             "404 B/row, so `achieved` can exceed what the same bytes would allow -- `traffic` is the "
+                             "HBM bytes the PMC counters saw per launch and `traffic_rate_gbs` the real HBM rate"},
         "cpu_baseline": cpu,
         "stats": {"n_matvec": st["n_matvec"], "kernel_launches": st["n_kernel_launches"]},
     }

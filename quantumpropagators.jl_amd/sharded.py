@@ -102,7 +102,9 @@ class HipBackend:
         return L.Split(op, send_rows)
 
     def new_stream(self):
-        return self.torch.cuda.Stream(device=self.device)
+        # high priority: the few boundary workgroups (and the collective behind them) should
+        # not queue behind the thousands of interior workgroups of the previous term
+        return self.torch.cuda.Stream(device=self.device, priority=-1)
 
     def stream(self, s):
         return self.torch.cuda.stream(s)

@@ -1575,7 +1575,7 @@ int qp_cheby_term_split(qp_operator* op, qp_split* sp, void* boundary_stream, in
     eb.slab = slab->d;
   }
   if (sp->n_boundary > 0) QP_CHECK(qp::launch_spmv_cheby(S_x, op->A, x->d, eb, &ctx->stats, &rb));
-  QP_HIP(hipEventRecord(sp->ev_b, S_x));
+  if (!flag_mode) QP_HIP(hipEventRecord(sp->ev_b, S_x));
   if (sp->n_interior > 0) QP_CHECK(qp::launch_spmv_cheby(S_c, op->A, x->d, e, &ctx->stats, &ri));
   QP_HIP(hipEventRecord(sp->ev_i, S_c));
   return QP_OK;

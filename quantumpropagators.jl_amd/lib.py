@@ -622,11 +622,13 @@ class Split:
 
 def cheby_term_split(H, split, boundary_stream, first, x, xoff, v0, vout, acc_in, acc_out, slab, c, beta, a_prev, a,
                      phase=1.0):
-    check(H.lib.qp_cheby_term_split(H._h, split._h, _P(boundary_stream), int(bool(first)), x._h, int(xoff),
-                                    v0._h if v0 is not None else None, vout._h if vout is not None else None,
-                                    acc_in._h if acc_in is not None else None, acc_out._h,
-                                    slab._h if slab is not None else None, c128(c), float(beta), float(a_prev),
-                                    float(a), c128(phase)))
+    # hot in the multi-GPU loop (one call per term): keep the Python side minimal
+    st = H.lib.qp_cheby_term_split(H._h, split._h, boundary_stream, 1 if first else 0, x._h, xoff,
+                                   v0._h if v0 is not None else None, vout._h if vout is not None else None,
+                                   acc_in._h if acc_in is not None else None, acc_out._h,
+                                   slab._h if slab is not None else None, c128(c), beta, a_prev, a, c128(phase))
+    if st:
+        check(st)
 
 
 class Krylov:

@@ -47,11 +47,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the prop_step! engine has no CPU fallback")
+    # QP_BENCH_ONE_GPU=1 (testing only): all ranks share GPU 0 and the collective is staged through
+    # the host with gloo, so that the multi-rank code path of this script can be exercised on a
+    # 1-GPU box.  Numbers from that mode are meaningless and are labelled as such.
+    one_gpu = os.environ.get("QP_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import qprop_amd.lib as L
     import qprop_amd.synth as synth
@@ -107,7 +116,7 @@ def main():
     else:
         import qprop_amd.sharded as sharded
         sh = sharded.ShardedCheby(ctx, rp, col, vals, N, r0, r1, Delta, E_min, dt, fmt=fmt,
-                                  exchange=args.exchange)
+                                  exchange=args.exchange, host_staged=one_gpu)
         sh.set_state(psi0_local)
         fmt_used = sh.op.format
         exchange_used = sh.exchange
@@ -143,7 +152,7 @@ def main():
     if world > 1:
         sh.check()      # outside the timed region: the overlapped schedule never timed out
     if dist is not None:
-        t = torch.tensor([elapsed, ev_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, ev_ms], dtype=torch.float64, device="cpu" if one_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, ev_ms = float(t[0]), float(t[1])
 
@@ -176,7 +185,9 @@ def main():
                    "rows_per_gpu": rows, "N_total": N, "nnz_per_row": 16, "pattern": args.pattern,
                    "offsets": [int(o) for o in offsets], "n_coeffs": int(len(coeffs)), "matvecs_per_step": nterms,
                    "spectral_range": [-10.0, 10.0], "dt": dt, "device_format": {1: "csr", 2: "rbcsr", 3: "hrb (Hermitian-packed row blocks)"}[fmt_used],
-                   "parallelism": "single GPU" if world == 1 else f"row-partitioned x{world}, exchange={exchange_used}",
+                   "parallelism": "single GPU" if world == 1 else (
+                       f"row-partitioned x{world}, exchange={exchange_used}"
+                       + (" [TEST MODE: ranks share one GPU, host-staged gloo]" if one_gpu else "")),
                    "global_steps_per_s": steps_per_s},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -104,6 +104,7 @@ int launch_spmv_cheby(hipStream_t s, const DevMatrix& A, const double2* x, const
 int launch_spmv_plain(hipStream_t s, const DevMatrix& A, const double2* x, const PlainEpi& e, Stats* st);
 int spmv_grid_size(const DevMatrix& A);
 extern int g_rbcsr_variant;
+extern int g_hrb_lower_last;  // HRB kernel: process the lower (conj-transposed) section after the upper one
 extern int g_spmm_tile;   // states per pass of the batched SpMM kernel (16, 32 or 64)
 extern int g_split_mode;  // 0 = cross-stream events on both streams, 1 = in-launch counter for the main stream
 

@@ -226,6 +226,10 @@ int qp_tuning_set(const char* key, int value) {
     qp::g_arnoldi_mode = value;
     return QP_OK;
   }
+  if (std::strcmp(key, "hrb_lower_last") == 0) {
+    qp::g_hrb_lower_last = value;
+    return QP_OK;
+  }
   if (std::strcmp(key, "spmm_tile") == 0) {
     qp::g_spmm_tile = value;
     return QP_OK;

@@ -317,7 +317,8 @@ __global__ __launch_bounds__(kThreads) void hrb_spmv_kernel(const int64_t* __res
                                                             const int4* __restrict__ lpos4,
                                                             const double2* __restrict__ x, int64_t nblocks,
                                                             int64_t nrows, Op op,
-                                                            const int32_t* __restrict__ block_map, SyncArgs sy) {
+                                                            const int32_t* __restrict__ block_map, SyncArgs sy,
+                                                            int lower_last) {
   constexpr bool NT = (VAR & 1) != 0;
   constexpr bool PRE = (VAR & 2) != 0;
   constexpr int UNR = (VAR & 4) ? 2 : 1;
@@ -342,38 +343,52 @@ __global__ __launch_bounds__(kThreads) void hrb_spmv_kernel(const int64_t* __res
     typename Op::Pre pre;
     if (PRE) pre = op.pre(rowc);
     double2 s0 = make_double2(0.0, 0.0), s1 = make_double2(0.0, 0.0);
+    auto lower = [&]() {
 #pragma unroll UNR
-    for (int q = 0; q < nlq; ++q) {   // lower section first: its values are already in L2
-      const int4 c = ld_cols<NT>(lcolbytes, lcm, q, lane, (int)rowc);
-      const int4 p = ld_col<NT>(lp4 + (size_t)q * 64);
-      const double2 a0 = ld_tr(uvals, p.x);
-      const double2 a1 = ld_tr(uvals, p.y);
-      const double2 a2 = ld_tr(uvals, p.z);
-      const double2 a3 = ld_tr(uvals, p.w);
-      const double2 x0 = x[c.x];
-      const double2 x1 = x[c.y];
-      const double2 x2 = x[c.z];
-      const double2 x3 = x[c.w];
-      cfma_conj(s0, a0, x0);
-      cfma_conj(s1, a1, x1);
-      cfma_conj(s0, a2, x2);
-      cfma_conj(s1, a3, x3);
-    }
+      for (int q = 0; q < nlq; ++q) {
+        const int4 c = ld_cols<NT>(lcolbytes, lcm, q, lane, (int)rowc);
+        const int4 p = ld_col<NT>(lp4 + (size_t)q * 64);
+        const double2 a0 = ld_tr(uvals, p.x);
+        const double2 a1 = ld_tr(uvals, p.y);
+        const double2 a2 = ld_tr(uvals, p.z);
+        const double2 a3 = ld_tr(uvals, p.w);
+        const double2 x0 = x[c.x];
+        const double2 x1 = x[c.y];
+        const double2 x2 = x[c.z];
+        const double2 x3 = x[c.w];
+        cfma_conj(s0, a0, x0);
+        cfma_conj(s1, a1, x1);
+        cfma_conj(s0, a2, x2);
+        cfma_conj(s1, a3, x3);
+      }
+    };
+    auto upper = [&]() {
 #pragma unroll UNR
-    for (int q = 0; q < nuq; ++q) {
-      const int4 c = ld_cols<NT>(ucolbytes, ucm, q, lane, (int)rowc);
-      const double2 a0 = v[(size_t)(4 * q + 0) * 64];
-      const double2 a1 = v[(size_t)(4 * q + 1) * 64];
-      const double2 a2 = v[(size_t)(4 * q + 2) * 64];
-      const double2 a3 = v[(size_t)(4 * q + 3) * 64];
-      const double2 x0 = x[c.x];
-      const double2 x1 = x[c.y];
-      const double2 x2 = x[c.z];
-      const double2 x3 = x[c.w];
-      cfma(s0, a0, x0);
-      cfma(s1, a1, x1);
-      cfma(s0, a2, x2);
-      cfma(s1, a3, x3);
+      for (int q = 0; q < nuq; ++q) {
+        const int4 c = ld_cols<NT>(ucolbytes, ucm, q, lane, (int)rowc);
+        const double2 a0 = v[(size_t)(4 * q + 0) * 64];
+        const double2 a1 = v[(size_t)(4 * q + 1) * 64];
+        const double2 a2 = v[(size_t)(4 * q + 2) * 64];
+        const double2 a3 = v[(size_t)(4 * q + 3) * 64];
+        const double2 x0 = x[c.x];
+        const double2 x1 = x[c.y];
+        const double2 x2 = x[c.z];
+        const double2 x3 = x[c.w];
+        cfma(s0, a0, x0);
+        cfma(s1, a1, x1);
+        cfma(s0, a2, x2);
+        cfma(s1, a3, x3);
+      }
+    };
+    // order of the two sections (tuning key "hrb_lower_last"): the conj-transposed values of
+    // the lower section are found in L2 only if the wave that owns them has already fetched
+    // them; summation order changes with it, bitwise reproducibility per setting is kept
+    if (lower_last) {
+      upper();
+      lower();
+    } else {
+      lower();
+      upper();
     }
     if (!PRE) pre = op.pre(rowc);
     if (row < nrows) op.row(row, make_double2(s0.x + s1.x, s0.y + s1.y), pre, chk, nrm, idx * kRB + lane);
@@ -540,6 +555,7 @@ int launch_gather_csr_vals(hipStream_t s, double2* out, const double2* vals, con
   return QP_OK;
 }
 
+int g_hrb_lower_last = 0;
 int g_arnoldi_mode = 1;
 int g_split_mode = 1;
 int g_rbcsr_variant = 7;  // tuning knob (qp_tuning_set); 7 = nt + early row-local loads + deep unroll (A/B in profiles/)
@@ -588,7 +604,7 @@ static int launch_spmv(hipStream_t s, const DevMatrix& A, const double2* x, cons
     hipLaunchKernelGGL((hrb_spmv_kernel<Op, VV>), dim3(grid), dim3(kThreads), 0, s, A.bptr, A.cmeta,     \
                        reinterpret_cast<const char*>(A.cols), A.vals, A.lptr, A.lcmeta,                  \
                        reinterpret_cast<const char*>(A.lcols), reinterpret_cast<const int4*>(A.lpos), x, \
-                       nblk, A.nrows, op, bmap, sy);                                                     \
+                       nblk, A.nrows, op, bmap, sy, g_hrb_lower_last);                                   \
     break;
     switch (g_rbcsr_variant & 7) {
       QP_HRB_CASE(0)

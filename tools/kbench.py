@@ -24,11 +24,13 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--pattern", default="banded")
     ap.add_argument("--formats", default="rbcsr")
+    ap.add_argument("--lower-last", type=int, default=0)
     args = ap.parse_args()
     N = 1 << args.log2n
     offs = synth.BANDED_OFFSETS if args.pattern == "banded" else synth.scattered_offsets(N)
     rp, col, vals = synth.hermitian_offsets_csr(N, offsets=offs)
     ctx = L.Context(0)
+    L.tuning_set("hrb_lower_last", args.lower_last)
     M = L.Matrix(ctx, N, N, rp, col, vals)
     nnz = int(rp[-1])
     del rp, col, vals

@@ -37,7 +37,8 @@ def main():
     ap.add_argument("--pattern", default="banded", choices=["banded", "scattered"])
     ap.add_argument("--format", default="auto", choices=["auto", "hrb", "rbcsr", "csr"])
     ap.add_argument("--exchange", default="auto", choices=["auto", "halo", "allgather"])
-    ap.add_argument("--cpu-steps", type=int, default=4, help="steps of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=16,
+                    help="steps of the CPU baseline sample (0 = skip); 16 steps ~ 10 s of one core")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -125,6 +126,20 @@ def main():
             sh.step()
     del rp, col, vals
 
+    pcie = None
+    if world == 1 and os.environ.get("QP_BENCH_PCIE") == "1":
+        # what a host-resident caller (the Julia glue without a device state type) would see:
+        # the state is downloaded after every step.  Reported separately, never as `value`.
+        host = np.empty(N, dtype=np.complex128)
+        for _ in range(3):
+            step()
+            host[:] = psi.numpy()
+        t0p = time.perf_counter()
+        for _ in range(20):
+            step()
+            host[:] = psi.numpy()
+        pcie = 20 / (time.perf_counter() - t0p)
+
     def barrier():
         if dist is not None:
             dist.barrier()
@@ -205,6 +220,7 @@ def main():
                              "404 B/row, so `achieved` can exceed what the same bytes would allow -- `traffic` is the "
                              "HBM bytes the PMC counters saw per launch and `traffic_rate_gbs` the real HBM rate"},
         "cpu_baseline": cpu,
+        "pcie_inclusive_steps_per_s": pcie,
         "stats": {"n_matvec": st["n_matvec"], "kernel_launches": st["n_kernel_launches"]},
     }
     if rank == 0:

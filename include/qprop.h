@@ -232,6 +232,27 @@ int qp_arnoldi_extend(qp_operator* op, qp_krylov* q, int m, double dt, double no
 /* diagonalize_hessenberg_matrix(Hess, m; accumulate)  src/arnoldi.jl:143-170 (host) */
 int qp_hessenberg_eigvals(const qp_c128* Hess, int ldh, int m, int accumulate, qp_c128* out);
 
+/* Building blocks of a row-partitioned Arnoldi / Newton (the inner products of
+ * src/arnoldi.jl:85,89 become partial sums over the local rows; the caller all-reduces them).
+ * Column j (0-based): q_{j+1} = H q_j by qp_mul into qp_krylov_vec(q, j+1), then
+ *   qp_krylov_multidot  -> reduced[0..j] = <q_i|q_{j+1}>, reduced[j+1..2j+1] = <q_i|q_j>   (local sums)
+ *   [all-reduce reduced]
+ *   qp_krylov_project   -> MGS coefficients from the global sums, q_{j+1} -= Q h, hess_col[i] = dt h_i,
+ *                          256 partial sums of |q_{j+1}|^2 over the local rows
+ *   [all-reduce norm_partials]
+ *   qp_krylov_normalize -> h = sqrt(sum), hess_norm[0] = (dt h, 0), hess_norm[1] = (h, 0),
+ *                          q_{j+1} *= 1/h unless h < norm_min. */
+int qp_krylov_vec(qp_krylov* q, int i, qp_state** out);   /* non-owning view of Arnoldi vector i */
+int qp_krylov_multidot(qp_krylov* q, int j, qp_state* reduced);
+int qp_krylov_project(qp_krylov* q, int j, double dt, const qp_state* reduced, qp_state* hess_col,
+                      qp_state* norm_partials);
+int qp_krylov_normalize(qp_krylov* q, int j, double dt, double norm_min, const qp_state* norm_partials,
+                        qp_state* hess_norm);
+/* out = (use_out ? s0 out : 0) + sum_{i<m} coefs[i] q[first+i]  (src/newton.jl:346-367);
+ * optional 256 partial sums of |out|^2 */
+int qp_combine(qp_state* out, int use_out, qp_c128 s0, qp_krylov* q, int first, int m, const qp_c128* coefs,
+               qp_state* norm_partials);
+
 /* ---- Newton (src/newton.jl) -------------------------------------------------------- */
 typedef void (*qp_func_cb)(const qp_c128* z, qp_c128* out, void* user);
 /* extend_leja!  src/newton.jl:97-148 (zero-based arrays; newpoints is clobbered) */

@@ -150,6 +150,11 @@ int launch_mgs_pass(hipStream_t s, const MgsArgs& a, Stats* st);
 int launch_mgs_lowsync(hipStream_t s, const double2* Q, int64_t ldq, int j, double2* w, double2* md_partials,
                        double2* G, int ldg, double2* hess_col, double2* reduced, double2* norm_partials, double dt,
                        int64_t n, Stats* st);
+int launch_mgs_multidot(hipStream_t s, const double2* Q, int64_t ldq, int j, const double2* w, double2* md_partials,
+                        double2* reduced, int64_t n, Stats* st);
+int launch_mgs_project(hipStream_t s, const double2* Q, int64_t ldq, int j, double2* w, const double2* reduced,
+                       double2* G, int ldg, double2* hess_col, double2* norm_partials, double dt, int64_t n,
+                       Stats* st);
 extern int g_arnoldi_mode;  // 0 = sequential fused MGS passes, 1 = low-synchronisation MGS
 // w *= 1/sqrt(sum part_in.x);  hess_slot = dt * norm
 int launch_norm_scale(hipStream_t s, double2* w, const double2* part_in, double2* hess_slot, double dt,

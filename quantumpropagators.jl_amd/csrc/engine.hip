@@ -1751,6 +1751,68 @@ int qp_arnoldi_extend(qp_operator* op, qp_krylov* q, int m, double dt, double no
 
 }  // extern "C"
 
+// ---------------------------------------------------------------------------
+// building blocks of a row-partitioned Arnoldi / Newton (the caller owns the collectives)
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int qp_krylov_vec(qp_krylov* q, int i, qp_state** out) {
+  QP_TRY
+  if (!q || !out || i < 0 || i >= q->nvec) return qp::fail(QP_E_BAD_ARG, "qp_krylov_vec: bad arguments");
+  return qp_state_wrap(q->ctx, q->q(i), q->n, out);
+  QP_CATCH
+}
+
+int qp_krylov_multidot(qp_krylov* q, int j, qp_state* reduced) {
+  QP_TRY
+  if (!q || !reduced || j < 0 || j + 1 >= q->nvec || reduced->n < 2 * (j + 1))
+    return qp::fail(QP_E_BAD_ARG, "qp_krylov_multidot: bad arguments");
+  QP_CHECK(use(q->ctx));
+  return qp::launch_mgs_multidot(q->ctx->stream, q->Q, q->n, j, q->q(j + 1), q->md_part, reduced->d, q->n, &q->ctx->stats);
+  QP_CATCH
+}
+
+int qp_krylov_project(qp_krylov* q, int j, double dt, const qp_state* reduced, qp_state* hess_col,
+                      qp_state* norm_partials) {
+  QP_TRY
+  if (!q || !reduced || !hess_col || !norm_partials || j < 0 || j + 1 >= q->nvec || reduced->n < 2 * (j + 1) ||
+      hess_col->n < j + 1 || norm_partials->n < kRedBlocks)
+    return qp::fail(QP_E_BAD_ARG, "qp_krylov_project: bad arguments");
+  QP_CHECK(use(q->ctx));
+  return qp::launch_mgs_project(q->ctx->stream, q->Q, q->n, j, q->q(j + 1), reduced->d, q->gram, q->nvec, hess_col->d,
+                                norm_partials->d, dt, q->n, &q->ctx->stats);
+  QP_CATCH
+}
+
+int qp_krylov_normalize(qp_krylov* q, int j, double dt, double norm_min, const qp_state* norm_partials,
+                        qp_state* hess_norm) {
+  QP_TRY
+  if (!q || !norm_partials || !hess_norm || j < 0 || j + 1 >= q->nvec || norm_partials->n < kRedBlocks || hess_norm->n < 2)
+    return qp::fail(QP_E_BAD_ARG, "qp_krylov_normalize: bad arguments");
+  QP_CHECK(use(q->ctx));
+  hipLaunchKernelGGL(norm_guard_scale_kernel, dim3(2048), dim3(qp::kThreads), 0, q->ctx->stream, q->q(j + 1),
+                     norm_partials->d, hess_norm->d, reinterpret_cast<double*>(hess_norm->d + 1), dt, norm_min, q->n);
+  QP_HIP(hipGetLastError());
+  q->ctx->stats.n_launch++;
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_combine(qp_state* out, int use_out, qp_c128 s0, qp_krylov* q, int first, int m, const qp_c128* coefs,
+               qp_state* norm_partials) {
+  QP_TRY
+  if (!out || !q || !coefs || first < 0 || m < 1 || first + m > q->nvec || out->n != q->n ||
+      (norm_partials && norm_partials->n < kRedBlocks))
+    return qp::fail(QP_E_BAD_ARG, "qp_combine: bad arguments");
+  QP_CHECK(use(q->ctx));
+  return qp::launch_combine_vecs(q->ctx->stream, out->d, use_out, d2(s0), q->q(first), q->n, m,
+                                 reinterpret_cast<const double2*>(coefs), norm_partials ? norm_partials->d : nullptr,
+                                 q->n, &q->ctx->stats);
+  QP_CATCH
+}
+
+}  // extern "C"
+
 // norm + guarded scale: lmul!(1/h) only when h >= norm_min (src/arnoldi.jl:89-96); the
 // raw norm is kept so that the host can detect breakdown also for dt < 0.
 __global__ __launch_bounds__(qp::kThreads) void norm_guard_scale_kernel(double2* __restrict__ w,

@@ -915,21 +915,17 @@ __global__ __launch_bounds__(kThreads) void multidot_kernel(const double2* __res
   }
 }
 
-// one workgroup per value: sum the kRedBlocks multidot partials in a fixed order; the
-// workgroups of the Gram values also store row j:  G[j][k] = <q_j|q_k> = conj(<q_k|q_j>)
+// one workgroup per value: sum the kRedBlocks multidot partials in a fixed order.  In a
+// row-partitioned run these are the sums over the local rows; the caller all-reduces
+// `reduced` over the ranks before the projection kernel consumes it.
 __global__ __launch_bounds__(kThreads) void multidot_reduce_kernel(const double2* __restrict__ partials, int j,
-                                                                   double2* __restrict__ reduced,
-                                                                   double2* __restrict__ G, int ldg) {
+                                                                   double2* __restrict__ reduced) {
   __shared__ double2 lds[kThreads / 64];
   static_assert(kRedBlocks == kThreads, "one partial per thread");
   const int nv = 2 * (j + 1);
   const int v = blockIdx.x;
   const double2 s = block_sum(partials[(size_t)threadIdx.x * nv + v], lds);
-  if (threadIdx.x == 0) {
-    reduced[v] = s;
-    const int k = v - (j + 1);
-    if (k >= 0 && k < j) G[(size_t)j * ldg + k] = make_double2(s.x, -s.y);
-  }
+  if (threadIdx.x == 0) reduced[v] = s;
 }
 
 // Prologue (every workgroup, redundantly): forward substitution
@@ -937,12 +933,18 @@ __global__ __launch_bounds__(kThreads) void multidot_reduce_kernel(const double2
 // by one wavefront, then  w -= sum_i (dt h_i / dt) q_i  in MGS order and |w|^2 partials.
 __global__ __launch_bounds__(kThreads) void mgs_update_kernel(double2* __restrict__ w, const double2* __restrict__ Q,
                                                               int64_t ldq, int j, const double2* __restrict__ reduced,
-                                                              const double2* __restrict__ G, int ldg,
+                                                              double2* __restrict__ G, int ldg,
                                                               double2* __restrict__ hess_col, double dt,
                                                               double2* __restrict__ norm_partials, int64_t n) {
   extern __shared__ double2 sm[];  // [0, j+1): h, then coefficients; [j+1, j+5): reduction scratch
   double2* h = sm;
   double2* lds = sm + (j + 1);
+  if (blockIdx.x == 0) {  // Gram row j for the later columns:  G[j][k] = <q_j|q_k> = conj(<q_k|q_j>)
+    for (int k = threadIdx.x; k < j; k += kThreads) {
+      const double2 g = reduced[(j + 1) + k];
+      G[(size_t)j * ldg + k] = make_double2(g.x, -g.y);
+    }
+  }
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
     for (int i = 0; i <= j; ++i) {
@@ -985,20 +987,34 @@ __global__ __launch_bounds__(kThreads) void mgs_update_kernel(double2* __restric
   if (threadIdx.x == 0) norm_partials[blockIdx.x] = t;
 }
 
-int launch_mgs_lowsync(hipStream_t s, const double2* Q, int64_t ldq, int j, double2* w, double2* md_partials,
-                       double2* G, int ldg, double2* hess_col, double2* reduced, double2* norm_partials, double dt,
-                       int64_t n, Stats* st) {
+int launch_mgs_multidot(hipStream_t s, const double2* Q, int64_t ldq, int j, const double2* w, double2* md_partials,
+                        double2* reduced, int64_t n, Stats* st) {
   const int ntiles = (j + 1 + kTI - 1) / kTI;
   hipLaunchKernelGGL(multidot_kernel, dim3(kRedBlocks, ntiles), dim3(kThreads), 0, s, Q, ldq, j, w, md_partials, n);
   QP_HIP(hipGetLastError());
-  hipLaunchKernelGGL(multidot_reduce_kernel, dim3(2 * (j + 1)), dim3(kThreads), 0, s, md_partials, j, reduced, G, ldg);
+  hipLaunchKernelGGL(multidot_reduce_kernel, dim3(2 * (j + 1)), dim3(kThreads), 0, s, md_partials, j, reduced);
   QP_HIP(hipGetLastError());
+  if (st) st->n_launch += 2;
+  return QP_OK;
+}
+
+int launch_mgs_project(hipStream_t s, const double2* Q, int64_t ldq, int j, double2* w, const double2* reduced,
+                       double2* G, int ldg, double2* hess_col, double2* norm_partials, double dt, int64_t n,
+                       Stats* st) {
   const size_t shmem = sizeof(double2) * (size_t)(j + 1 + kThreads / 64);
   hipLaunchKernelGGL(mgs_update_kernel, dim3(kRedBlocks), dim3(kThreads), shmem, s, w, Q, ldq, j, reduced, G, ldg,
                      hess_col, dt, norm_partials, n);
   QP_HIP(hipGetLastError());
-  if (st) st->n_launch += 3;
+  if (st) st->n_launch++;
   return QP_OK;
+}
+
+int launch_mgs_lowsync(hipStream_t s, const double2* Q, int64_t ldq, int j, double2* w, double2* md_partials,
+                       double2* G, int ldg, double2* hess_col, double2* reduced, double2* norm_partials, double dt,
+                       int64_t n, Stats* st) {
+  int rc = launch_mgs_multidot(s, Q, ldq, j, w, md_partials, reduced, n, st);
+  if (rc != QP_OK) return rc;
+  return launch_mgs_project(s, Q, ldq, j, w, reduced, G, ldg, hess_col, norm_partials, dt, n, st);
 }
 
 __global__ __launch_bounds__(kThreads) void reduce_triples_kernel(const double* __restrict__ partials, int nwg,

@@ -131,6 +131,11 @@ SIGNATURES = {
     "qp_krylov_create": (C.c_int, [_P, C.c_int64, C.c_int, C.POINTER(_P)]),
     "qp_krylov_destroy": (C.c_int, [_P]),
     "qp_krylov_download": (C.c_int, [_P, C.c_int, _cp]),
+    "qp_krylov_vec": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
+    "qp_krylov_multidot": (C.c_int, [_P, C.c_int, _P]),
+    "qp_krylov_project": (C.c_int, [_P, C.c_int, C.c_double, _P, _P, _P]),
+    "qp_krylov_normalize": (C.c_int, [_P, C.c_int, C.c_double, C.c_double, _P, _P]),
+    "qp_combine": (C.c_int, [_P, C.c_int, qp_c128, _P, C.c_int, C.c_int, _cp, _P]),
     "qp_arnoldi": (C.c_int, [_P, _P, C.c_int, _P, C.c_double, C.c_int, C.c_double, _cp, C.c_int,
                              C.POINTER(C.c_int)]),
     "qp_arnoldi_extend": (C.c_int, [_P, _P, C.c_int, C.c_double, C.c_double, _cp, C.c_int,
@@ -642,6 +647,30 @@ class Krylov:
         out = np.empty(self.n, dtype=np.complex128)
         check(self.lib.qp_krylov_download(self._h, int(i), _ptr(out, _cp)))
         return out
+
+    def view(self, i):
+        """Non-owning State view of Arnoldi vector i."""
+        h = _P()
+        check(self.lib.qp_krylov_vec(self._h, int(i), C.byref(h)))
+        s = State.__new__(State)
+        s.ctx, s.lib, s._h, s._keep, s.n = self.ctx, self.lib, h, self, self.n
+        self.ctx._adopt(s)
+        return s
+
+    # building blocks of a row-partitioned Arnoldi (the caller all-reduces between them)
+    def multidot(self, j, reduced):
+        check(self.lib.qp_krylov_multidot(self._h, int(j), reduced._h))
+
+    def project(self, j, dt, reduced, hess_col, norm_partials):
+        check(self.lib.qp_krylov_project(self._h, int(j), float(dt), reduced._h, hess_col._h, norm_partials._h))
+
+    def normalize(self, j, dt, norm_min, norm_partials, hess_norm):
+        check(self.lib.qp_krylov_normalize(self._h, int(j), float(dt), float(norm_min), norm_partials._h, hess_norm._h))
+
+    def combine(self, out, use_out, s0, first, m, coefs, norm_partials=None):
+        a, p = _as_c128(np.atleast_1d(coefs))
+        check(self.lib.qp_combine(out._h, int(bool(use_out)), c128(s0), self._h, int(first), int(m), p,
+                                  norm_partials._h if norm_partials is not None else None))
 
     def close(self):
         if self._h:

@@ -131,6 +131,13 @@ class HipBackend:
     def read(self, t, lo, hi):
         return t[2 * lo: 2 * hi].cpu().numpy().view(np.complex128).copy()
 
+    # ---- Arnoldi / Newton building blocks ----
+    def krylov(self, n, nvec):
+        return L.Krylov(self.ctx, n, nvec)
+
+    def mul(self, op, x, y):
+        op.mul(x, y)
+
 
 class ShardedCheby:
     """Chebyshev propagator for one row block of a row-partitioned H.
@@ -337,3 +344,144 @@ class ShardedCheby:
         be.join(side)
         if result_in_acc:
             self.X[0][: 2 * self.nloc].copy_(self.acc_t)
+
+
+class ShardedNewton:
+    """Newton / restarted Arnoldi (``newton!``, src/newton.jl:246-385) for one row block of a
+    row-partitioned generator.  Vectors are sharded like in :class:`ShardedCheby`; the Arnoldi
+    inner products are partial sums over the local rows that are all-reduced (two small
+    collectives per column: 2(j+1) inner products, then the 256 partial sums of the norm),
+    the mat-vec input is completed by the same packed all-gather of the ghost slots, and the
+    small dense algebra (Hessenberg eigenvalues, Leja points, Newton coefficients) is done
+    redundantly on every rank by the library's host routines, so that all ranks take the same
+    restart decisions.  Serial schedule (no overlap): at the sizes where a single GPU holds the
+    problem this path is latency-bound; it exists for Hilbert spaces that need several GPUs."""
+
+    def __init__(self, ctx, rowptr, col, vals, N, r0, r1, m_max=10, fmt=L.FMT_AUTO, exchange="auto", group=None,
+                 backend=None, host_staged=False):
+        # partition, send lists, local operator and ghost exchange are those of the Chebyshev driver
+        self.base = ShardedCheby(ctx, rowptr, col, vals, N, r0, r1, 2.0, -1.0, 1.0, fmt=fmt, exchange=exchange,
+                                 group=group, backend=backend, overlap=False, host_staged=host_staged)
+        b = self.base
+        self.torch, self.dist, self.group, self.be = b.torch, b.dist, group, b.be
+        self.nloc, self.N = b.nloc, b.N
+        if m_max <= 2:
+            raise L.QPArgumentError(11, "Newton propagation requires m_max > 2")
+        if m_max >= self.N:
+            m_max = self.N - 1
+            if m_max <= 2:
+                raise L.QPArgumentError(11, "Newton propagation requires state dimension > 2")
+        self.m_max = m_max
+        be = self.be
+        ld = m_max + 1
+        self.q = be.krylov(self.nloc, ld)
+        self.qv = [self.q.view(i) for i in range(ld)]
+        self.v_t = be.zeros(self.nloc)
+        self.v = be.view(self.v_t, 0, self.nloc)
+        self.psi_t = be.zeros(self.nloc)
+        self.psi = be.view(self.psi_t, 0, self.nloc)
+        self.red_t = be.zeros(2 * ld)
+        self.red = be.view(self.red_t, 0, 2 * ld)
+        self.np_t = be.zeros(256)
+        self.npart = be.view(self.np_t, 0, 256)
+        self.hess_t = be.zeros(ld * ld)
+        self.hcol = [be.view(self.hess_t, j * ld, (j + 1) * ld) for j in range(ld)]
+        self.hn_t = be.zeros(2 * ld)
+        self.hnorm = [be.view(self.hn_t, 2 * j, 2 * j + 2) for j in range(ld)]
+        self.restarts = 0
+        self.n_matvec = 0
+
+    def set_state(self, psi_local):
+        self.be.write(self.psi_t, 0, psi_local)
+
+    def local_state(self):
+        return self.be.read(self.psi_t, 0, self.nloc)
+
+    def _allreduce(self, t):
+        if self.base.world > 1:
+            if self.base.host_staged:
+                h = t.cpu()
+                self.dist.all_reduce(h, group=self.group)
+                t.copy_(h)
+            else:
+                self.dist.all_reduce(t, group=self.group)
+
+    def _global_norm(self, t):
+        s = (t * t).sum().reshape(1)
+        self._allreduce(s)
+        return float(np.sqrt(float(s.cpu()[0])))
+
+    def _arnoldi(self, m, dt, norm_min):
+        """``arnoldi!(Hess, q, m, v, H, dt; extended=true)``  src/arnoldi.jl:60-100."""
+        b, be, ld = self.base, self.be, self.m_max + 1
+        self.hess_t.zero_()
+        self.hn_t.zero_()
+        self.qv[0].copy_from(self.v)
+        for j in range(m):
+            b.Xloc[0].copy_from(self.qv[j])       # q_j into the local part of the exchange buffer
+            b._exchange(0)
+            be.mul(b.op, b.Xfull[0], self.qv[j + 1])                 # :82
+            self.q.multidot(j, self.red)
+            self._allreduce(self.red_t[: 4 * (j + 1)])
+            self.q.project(j, dt, self.red, self.hcol[j], self.npart)  # :84-87
+            self._allreduce(self.np_t)
+            self.q.normalize(j, dt, norm_min, self.npart, self.hnorm[j])   # :88-97
+        self.n_matvec += m
+        hh = be.read(self.hess_t, 0, ld * ld).reshape(ld, ld)       # hh[j] = column j
+        hn = be.read(self.hn_t, 0, 2 * ld).reshape(ld, 2)
+        Hess = np.zeros((ld, ld), dtype=np.complex128, order="F")
+        m_eff = m
+        for j in range(m):
+            if hn[j, 1].real < norm_min:                              # dimensionality exhausted  :91-95
+                m_eff = j + 1
+                break
+        for j in range(m_eff):
+            Hess[: j + 1, j] = hh[j, : j + 1]
+            Hess[j + 1, j] = hn[j, 0]
+        return m_eff, Hess
+
+    def step(self, dt, func=None, norm_min=1e-14, relerr=1e-12, max_restarts=50):
+        be, q = self.be, self.q
+        f = (lambda z: np.exp(-1j * z)) if func is None else func
+        m = self.m_max
+        a = np.zeros(10 * self.m_max + 1, dtype=np.complex128)
+        leja = np.zeros(10 * self.m_max + 1, dtype=np.complex128)
+        n_a = n_leja = 0
+        s = 0
+        self.v.copy_from(self.psi)                                       # :268
+        beta = self._global_norm(self.v_t)                              # :271
+        self.v.scal(1.0 / beta)
+        while True:
+            m, Hess = self._arnoldi(m, float(dt), norm_min)             # :277
+            if m == 1 and s == 0:                                       # :289-295
+                self.psi.scal(complex(f(beta * Hess[0, 0])))
+                break
+            ritz = L.hessenberg_eigvals(Hess, m, accumulate=True)       # :297
+            if s == 0:
+                radius = 1.2 * float(np.max(np.abs(ritz)))
+            n_s = n_leja
+            leja, n_leja = L.extend_leja(leja, n_leja, ritz.copy(), m)
+            a, n_a = L.extend_newton_coeffs(a, n_a, leja, func, n_leja, radius)
+            mp = m + 1
+            Hm = Hess[:mp, :mp]
+            R = np.zeros(mp, dtype=np.complex128)
+            P = np.zeros(mp, dtype=np.complex128)
+            R[0] = beta
+            P[0] = a[n_s] * beta
+            for k in range(1, m):                                       # :334-343
+                R = (Hm @ R - leja[n_s + k - 1] * R) / radius
+                P = P + a[n_s + k] * R
+            q.combine(self.psi, s != 0, 1.0, 0, m, P[:m], self.npart)   # :346-352
+            self._allreduce(self.np_t)
+            norm_psi = float(np.sqrt(be.read(self.np_t, 0, 256).real.sum()))
+            R = (Hm @ R - leja[n_s + m - 1] * R) / radius               # :356-362
+            beta = float(np.linalg.norm(np.abs(R)))
+            R = R * (1.0 / beta)
+            q.combine(self.v, True, R[0], 1, m, R[1:mp])                # :363-367
+            if beta * abs(a[n_a - 1]) / (1 + norm_psi) < relerr:        # :370
+                break
+            s += 1
+            if s > max_restarts:
+                raise L.QPAssertionError(6, f"newton!: s={s} exceeds max_restarts={max_restarts}")
+        self.restarts = s
+        return s

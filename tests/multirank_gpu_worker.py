@@ -18,8 +18,38 @@ import qprop_amd.sharded as sharded  # noqa: E402
 import qprop_amd.synth as synth  # noqa: E402
 
 
+def newton_main(rank, world):
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    Lm = synth.liouvillian_tridiag(32)                       # N = 1024, non-Hermitian
+    N = Lm.shape[0]
+    bounds = qo.partition_rows(Lm.indptr.astype(np.int64), world)
+    r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
+    ctx = L.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    lrp = Lm.indptr[r0:r1 + 1].astype(np.int64) - Lm.indptr[r0]
+    sn = sharded.ShardedNewton(ctx, lrp, Lm.indices[Lm.indptr[r0]:Lm.indptr[r1]], Lm.data[Lm.indptr[r0]:Lm.indptr[r1]],
+                               N, r0, r1, m_max=12, host_staged=True)
+    rho0 = synth.random_state(N)
+    sn.set_state(rho0[r0:r1])
+    for dt in (0.3, 0.3, -0.3):
+        sn.step(dt)
+    torch.cuda.synchronize()
+    ref = rho0.copy()
+    owrk = qo.NewtonWrk(ref, m_max=12)
+    for dt in (0.3, 0.3, -0.3):
+        qo.newton(ref, Lm, dt, owrk)
+    err = float(np.linalg.norm(sn.local_state() - ref[r0:r1]))
+    print(f"rank {rank}/{world}: newton err={err:.3e} restarts={sn.restarts} exchange={sn.base.exchange}", flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    if not err < 1e-10:
+        sys.exit(3)
+
+
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    if os.environ.get("QP_METHOD") == "newton":
+        return newton_main(rank, world)
     overlap = os.environ.get("QP_OVERLAP", "1") == "1"
     exchange = os.environ.get("QP_EXCHANGE", "auto")
     uneven = os.environ.get("QP_UNEVEN", "0") == "1"

@@ -12,6 +12,66 @@ class _Op:
         self.format = 1
 
 
+class NpVec(np.ndarray):
+    """ndarray view with the few State methods the drivers call."""
+
+    def copy_from(self, other):
+        self[:] = other
+        return self
+
+    def scal(self, alpha):
+        self *= alpha
+        return self
+
+
+class NumpyKrylov:
+    """CPU emulation of qp_krylov + the row-partitioned Arnoldi building blocks."""
+
+    def __init__(self, n, nvec):
+        self.Q = np.zeros((nvec, n), dtype=np.complex128)
+        self.G = np.zeros((nvec, nvec), dtype=np.complex128)
+        self.n, self.nvec = n, nvec
+
+    def view(self, i):
+        return self.Q[i].view(NpVec)
+
+    def multidot(self, j, reduced):
+        w = self.Q[j + 1]
+        for i in range(j + 1):
+            reduced[i] = np.vdot(self.Q[i], w)
+            reduced[j + 1 + i] = np.vdot(self.Q[i], self.Q[j])
+
+    def project(self, j, dt, reduced, hess_col, norm_partials):
+        self.G[j, :j] = np.conj(reduced[j + 1: 2 * j + 1])
+        h = np.zeros(j + 1, dtype=np.complex128)
+        for i in range(j + 1):
+            Gi = np.conj(reduced[j + 1: j + 1 + i]) if i == j else self.G[i, :i]
+            h[i] = reduced[i] - np.dot(Gi, h[:i])
+        w = self.Q[j + 1]
+        for i in range(j + 1):
+            hd = dt * h[i]
+            hess_col[i] = hd
+            w += (-hd / dt) * self.Q[i]
+        norm_partials[:] = 0
+        norm_partials[0] = np.vdot(w, w).real
+
+    def normalize(self, j, dt, norm_min, norm_partials, hess_norm):
+        h = float(np.sqrt(norm_partials.real.sum()))
+        hess_norm[0] = dt * h
+        hess_norm[1] = h
+        if h >= norm_min:
+            self.Q[j + 1] *= 1.0 / h
+
+    def combine(self, out, use_out, s0, first, m, coefs, norm_partials=None):
+        r = (s0 * out) if use_out else np.zeros_like(out)
+        for i in range(m):
+            r = r + coefs[i] * self.Q[first + i]
+        out[:] = r
+        if norm_partials is not None:
+            norm_partials[:] = 0
+            norm_partials[0] = np.vdot(r, r).real
+
+
 class NumpyBackend:
     def zeros(self, n):
         return torch.zeros(2 * n, dtype=torch.float64)
@@ -23,7 +83,13 @@ class NumpyBackend:
         return _Op(sp.csr_matrix((vals, col, rowptr), shape=(nloc, ncols)))
 
     def view(self, t, lo, hi):
-        return t.numpy()[2 * lo: 2 * hi].view(np.complex128)   # shares memory with the tensor
+        return t.numpy()[2 * lo: 2 * hi].view(np.complex128).view(NpVec)   # shares memory with the tensor
+
+    def krylov(self, n, nvec):
+        return NumpyKrylov(n, nvec)
+
+    def mul(self, op, x, y):
+        y[:] = op.A @ x
 
     def term(self, op, x, xoff, v0, vout, acc_in, acc_out, c, beta, a_prev, a, phase):
         nloc = op.A.shape[0]

@@ -47,3 +47,9 @@ def _run(world, **env_extra):
 ])
 def test_multirank_hip_path_one_gpu(world, overlap, exchange, uneven):
     _run(world, QP_OVERLAP=overlap, QP_EXCHANGE=exchange, QP_UNEVEN=uneven)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_multirank_newton_one_gpu(world):
+    """Row-partitioned newton! (all-reduced Arnoldi inner products) with ranks sharing the GPU."""
+    _run(world, QP_METHOD="newton")

@@ -137,3 +137,34 @@ def test_sharded_overlap_machinery_world1(pg, overlap, split_mode):
         sh2.split.check()
     L.tuning_set("split_mode", 1)
     ctx.close()
+
+
+def test_sharded_newton_world1(pg):
+    """ShardedNewton with the product HipBackend (device Arnoldi building blocks + all-reduce
+    call shape) at world 1 against the oracle and against the single-GPU qp_newton_step."""
+    import torch
+    from oracle import qp_oracle as qo
+    import qprop_amd.lib as L
+    import qprop_amd.sharded as sharded
+    import qprop_amd.synth as synth
+    Lm = synth.liouvillian_tridiag(24)
+    N = Lm.shape[0]
+    ctx = L.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    sn = sharded.ShardedNewton(ctx, Lm.indptr.astype(np.int64), Lm.indices, Lm.data, N, 0, N, m_max=12)
+    rho0 = synth.random_state(N)
+    sn.set_state(rho0)
+    for dt in (0.4, 0.4, -0.4):
+        sn.step(dt)
+    torch.cuda.synchronize()
+    ref = rho0.copy()
+    owrk = qo.NewtonWrk(ref, m_max=12)
+    for dt in (0.4, 0.4, -0.4):
+        qo.newton(ref, Lm, dt, owrk)
+    assert np.linalg.norm(sn.local_state() - ref) < 1e-10
+    Op = L.Operator(ctx, [L.Matrix.from_scipy(ctx, Lm)])
+    wrk = L.NewtonWrk(ctx, N, m_max=12)
+    rho = L.State(ctx, data=rho0)
+    for dt in (0.4, 0.4, -0.4):
+        L.newton(rho, Op, dt, wrk)
+    assert np.linalg.norm(sn.local_state() - rho.numpy()) < 1e-12
+    ctx.close()

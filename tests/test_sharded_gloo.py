@@ -116,3 +116,53 @@ def test_index_work():
                         100 + 10 + 4, 100 + 0]
     with pytest.raises(AssertionError):
         sharded.remap_columns(np.array([7]), 100, 200, bounds, send_lists, M)
+
+
+def _newton_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from np_backend import NumpyBackend
+        from oracle import qp_oracle as qo
+        import qprop_amd.sharded as sharded
+        import qprop_amd.synth as synth
+        Lm = synth.liouvillian_tridiag(24)                       # N = 576, non-Hermitian
+        N = Lm.shape[0]
+        bounds = qo.partition_rows(Lm.indptr.astype(np.int64), world)
+        r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
+        lrp = Lm.indptr[r0:r1 + 1].astype(np.int64) - Lm.indptr[r0]
+        lcol, lvals = Lm.indices[Lm.indptr[r0]:Lm.indptr[r1]], Lm.data[Lm.indptr[r0]:Lm.indptr[r1]]
+        sn = sharded.ShardedNewton(None, lrp, lcol, lvals, N, r0, r1, m_max=12, backend=NumpyBackend())
+        rho0 = synth.random_state(N)
+        sn.set_state(rho0[r0:r1])
+        restarts = [sn.step(0.4), sn.step(0.4), sn.step(-0.4)]
+        out = sn.local_state()
+        ref = rho0.copy()
+        owrk = qo.NewtonWrk(ref, m_max=12)
+        oracle_restarts = []
+        for dt in (0.4, 0.4, -0.4):
+            qo.newton(ref, Lm, dt, owrk)
+            oracle_restarts.append(owrk.restarts)
+        q.put((rank, float(np.linalg.norm(out - ref[r0:r1])), restarts, oracle_restarts, sn.base.exchange))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_newton_matches_oracle(world):
+    """Row-partitioned newton!: all-reduced Arnoldi inner products, replicated small dense algebra."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_newton_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=10) for _ in range(world))
+    for rank, err, restarts, oracle_restarts, exch in res:
+        assert err < 1e-10, (rank, err)
+        assert all(abs(a - b) <= 1 for a, b in zip(restarts, oracle_restarts))
+    assert len({tuple(r[2]) for r in res}) == 1          # every rank took the same restart decisions

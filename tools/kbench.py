@@ -19,6 +19,7 @@ import qprop_amd.synth as synth  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--log2n", type=int, default=20)
+    ap.add_argument("--n", type=int, default=0, help="explicit N (overrides --log2n)")
     ap.add_argument("--variants", default="0,1,2,3,4,5,6,7")
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--steps", type=int, default=4)
@@ -26,7 +27,7 @@ def main():
     ap.add_argument("--formats", default="rbcsr")
     ap.add_argument("--lower-last", type=int, default=0)
     args = ap.parse_args()
-    N = 1 << args.log2n
+    N = args.n if args.n else 1 << args.log2n
     offs = synth.BANDED_OFFSETS if args.pattern == "banded" else synth.scattered_offsets(N)
     rp, col, vals = synth.hermitian_offsets_csr(N, offsets=offs)
     ctx = L.Context(0)
@@ -58,7 +59,7 @@ def main():
                 L.cheby(psi, op, 1.0, wrk)
             ms = ctx.timer_end()
             times[(f, v)].append(1e3 * ms / (args.steps * nterms))
-    print(f"N=2^{args.log2n} pattern={args.pattern} terms/step={nterms} alg_bytes/term={alg:.0f}")
+    print(f"N={N} pattern={args.pattern} terms/step={nterms} alg_bytes/term={alg:.0f}")
     print(f"{'format':8s} {'var':>3s} {'median_us':>10s} {'min_us':>8s} {'GB/s(med)':>10s} {'frac8T':>7s}")
     for (f, v), t in times.items():
         med, mn = float(np.median(t)), float(np.min(t))

@@ -278,6 +278,27 @@ int qp_newton_step(qp_newton* w, qp_operator* op, qp_state* psi, double dt, int 
 /* inspection of wrk.a / wrk.leja after a step (src/newton.jl:23-36) */
 int qp_newton_get_coeffs(const qp_newton* w, qp_c128* a, qp_c128* leja, int cap);
 
+/* ---- propagate step loop (src/propagate.jl:283-344), rows N1/N2 of SURVEY 8f --------- */
+/* Runs `nsteps` prop_step!s in ONE call: per step the coefficients of the operator are taken
+ * from coeff_table[step*ncoeffs .. ] (the values `parameters[control][n]` that
+ * _pwc_set_genop! would look up, src/pwc_utils.jl:86-92) and the time step from dts[step]
+ * (signed; Cheby needs |dts[step]| ~ wrk_dt).  Optional outputs, filled without any host
+ * synchronisation inside the loop and downloaded once at the end:
+ *   expvals_out[(step+1)*nobs + o] = <psi|O_o|psi> after the step (row 0: initial state)
+ *                                    -- map_observable for matrices, src/storage.jl:121-123
+ *   states_out[(step+1)*n ..]      = the state after the step (row 0: initial state)
+ * method 0 = Cheby (spec fields of qp_cheby_step), 1 = Newton (fields of qp_newton_step). */
+typedef struct {
+  int method;
+  qp_cheby* cheby;  const double* a;  int n_coeffs;  double Delta, E_min, wrk_dt, limit;
+  int check_normalization;
+  qp_newton* newton;  int func_id;  qp_func_cb cb;  void* user;
+  double norm_min, relerr;  int max_restarts;
+} qp_prop_spec;
+int qp_propagate(qp_operator* op, qp_state* psi, const qp_prop_spec* spec, const double* dts,
+                 const qp_c128* coeff_table, int ncoeffs, int nsteps, qp_operator* const* observables,
+                 int nobs, qp_c128* expvals_out, qp_c128* states_out);
+
 /* ---- SpectralRange (src/specrad.jl) ------------------------------------------------ */
 /* ritzvals(G, state, m_min, m_max; prec, norm_min)  src/specrad.jl:170-220 */
 int qp_ritzvals(qp_operator* op, const qp_state* state, int m_min, int m_max, double prec,

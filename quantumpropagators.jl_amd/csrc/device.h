@@ -105,6 +105,7 @@ int launch_spmv_plain(hipStream_t s, const DevMatrix& A, const double2* x, const
 int spmv_grid_size(const DevMatrix& A);
 extern int g_rbcsr_variant;
 extern int g_hrb_lower_last;  // HRB kernel: process the lower (conj-transposed) section after the upper one
+extern int g_small_nnz;   // qp_propagate: register-resident Cheby systems up to this nnz run as ONE persistent launch (0: off)
 extern int g_spmm_tile;   // states per pass of the batched SpMM kernel (16, 32 or 64)
 extern int g_split_mode;  // 0 = cross-stream events on both streams, 1 = in-launch counter for the main stream
 
@@ -121,6 +122,46 @@ int launch_combine_planes(hipStream_t s, double2* vals, const double2* const* pl
 // batched states: CSR SpMM with the fused Chebyshev epilogue, panel X[i*b + s]
 int launch_spmm_cheby(hipStream_t s, const int64_t* rowptr, const int32_t* cols, const double2* vals,
                       const double2* X, int64_t nrows, int64_t nnz, int b, const ChebyEpi& e, Stats* st);
+// ---- small systems: the whole Cheby time grid in one single-workgroup launch -------------
+struct SmallObs {
+  const int64_t* rowptr;
+  const int32_t* cols;
+  const double2* vals;
+};
+struct SmallArgs {
+  int64_t n = 0, nnz = 0;
+  int lanes = 1;                       // lanes per row (power of two <= 64)
+  int ent = 1;                         // entries per lane per row
+  int rows_per_group = 1;              // rows per lane group;  rows_per_group * ent <= kSmallEpt
+  int obs_lanes = 1;                   // lanes per row for the observables
+  const int64_t* rowptr = nullptr;     // CSR mirror of the operator
+  const int32_t* cols = nullptr;
+  const int64_t* map = nullptr;        // position in a plane; negative: conj of plane[-m-1]
+  const double2* const* planes = nullptr;
+  int nops = 0, ncoeffs = 0;
+  double2 scale = {1.0, 0.0};
+  const double2* table = nullptr;      // [nsteps * ncoeffs]
+  int nsteps = 0;
+  const double* a = nullptr;           // Chebychev coefficients
+  int n_coeffs = 0;
+  double2 c = {0.0, 0.0};
+  double beta = 0.0;
+  double2 phase = {1.0, 0.0};
+  double2* psi = nullptr;              // in / out
+  int nobs = 0;
+  const SmallObs* obs = nullptr;
+  double2* expvals = nullptr;          // [(nsteps + 1) * nobs]
+  double2* states = nullptr;           // [(nsteps + 1) * n] or null
+  int check = 0;
+  double limit = 0.0;
+  int* fail = nullptr;                 // {flag, step, term}
+};
+constexpr int kSmallThreads = 512;
+constexpr int kSmallEpt = 8;
+constexpr int64_t kSmallLdsRows = 2048;
+bool small_plan(int64_t n, int64_t maxrow, SmallArgs* a);
+int launch_cheby_propagate_small(hipStream_t s, const SmallArgs& a, Stats* st);
+
 int launch_gather_csr_vals(hipStream_t s, double2* out, const double2* vals, const int64_t* map, int64_t nnz,
                            Stats* st);
 

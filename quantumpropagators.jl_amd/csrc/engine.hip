@@ -230,6 +230,10 @@ int qp_tuning_set(const char* key, int value) {
     qp::g_hrb_lower_last = value;
     return QP_OK;
   }
+  if (std::strcmp(key, "small_nnz") == 0) {
+    qp::g_small_nnz = value;
+    return QP_OK;
+  }
   if (std::strcmp(key, "spmm_tile") == 0) {
     qp::g_spmm_tile = value;
     return QP_OK;
@@ -779,6 +783,10 @@ static int choose_format(qp_operator* op, int requested, bool hermitian) {
   const bool rb_ok = (double)rb_stored <= 1.5 * (double)nnz + 1024.0;
   if (requested == QP_FMT_AUTO) {
     if (!rb_ok) return QP_FMT_CSR;
+    // few, long rows (small dense generators: the reference's test and benchmark sizes): a
+    // row block gives one wavefront 64 rows to walk entry by entry -- too few wavefronts to
+    // hide the latency.  One wavefront per row instead (CSR kernel, 64 lanes per row).
+    if (nblocks < 2048 && nnz >= 32 * nrows) return QP_FMT_CSR;
     if (!hermitian) return QP_FMT_RBCSR;
     // Hermitian packing pays only if the transposed values are still in the XCD's L2
     // (4 MiB) when the lower entry is processed: the rows stream in order, so require
@@ -2031,6 +2039,189 @@ int qp_newton_step(qp_newton* w, qp_operator* op, qp_state* psi, double dt, int 
     stats->ms_coeffs = ms_coeffs;
     stats->ms_poly = ms_poly;
     stats->ms_update = ms_update;
+  }
+  return QP_OK;
+  QP_CATCH
+}
+
+// ---------------------------------------------------------------------------
+// propagate step loop (src/propagate.jl:283-344)
+// ---------------------------------------------------------------------------
+// Small systems: the whole time grid in one persistent single-workgroup launch
+// (kernels.hip: cheby_propagate_small_kernel).  Same arguments as qp_propagate, method 0.
+static int propagate_cheby_small(qp_operator* op, qp_state* psi, const qp_prop_spec* spec, qp::SmallArgs a,
+                                 const double* dts,
+                                 const qp_c128* coeff_table, int ncoeffs, int nsteps, qp_operator* const* observables,
+                                 int nobs, qp_c128* expvals_out, qp_c128* states_out) {
+  qp_ctx* ctx = op->ctx;
+  qp_cheby* w = spec->cheby;
+  const int64_t n = psi->n;
+  const size_t rows = (size_t)nsteps + 1;
+  if (!w || !spec->a) return qp::fail(QP_E_BAD_ARG, "qp_propagate: NULL Chebychev workspace");
+  if (op->A.nrows != op->A.ncols || n != op->A.nrows || w->n != n) return qp::fail(QP_E_BAD_ARG, "qp_propagate: shape mismatch");
+  if (spec->n_coeffs < 2) return qp::fail(QP_E_TOO_FEW_COEFFS, "Need at least 2 Chebychev coefficients");
+  if (!(spec->Delta > 0)) return qp::fail(QP_E_BAD_ARG, "Delta must be positive");
+  for (int k = 0; k < nsteps; ++k) {
+    const double x = std::fabs(dts[k]), y = std::fabs(spec->wrk_dt);   // src/cheby.jl:157
+    if (!(std::fabs(x - y) <= 1.4901161193847656e-08 * std::max(x, y)))
+      return qp::fail(QP_E_DT_MISMATCH, "wrk was initialized for dt=%g, not dt=abs(%g)", spec->wrk_dt, dts[k]);
+    if ((dts[k] > 0) != (dts[0] > 0)) return qp::fail(QP_E_BAD_ARG, "qp_propagate: time steps change sign");
+  }
+  QP_CHECK(operator_csr_mirror(op));
+  for (int o = 0; o < nobs; ++o) QP_CHECK(operator_csr_mirror(observables[o]));
+  const double dt = dts[0];
+  const double beta = (spec->Delta / 2) + spec->E_min;
+  const cplx c = (dt > 0) ? cplx(0, -2.0) / spec->Delta : cplx(0, 2.0) / spec->Delta;
+
+  a.n = n;
+  a.nnz = op->A.nnz;
+  a.rowptr = op->m_rowptr;
+  a.cols = op->m_cols;
+  a.map = op->m_map;
+  a.planes = op->planes_dev;
+  a.nops = op->nops;
+  a.ncoeffs = ncoeffs;
+  a.scale = d2(op->scale);
+  a.nsteps = nsteps;
+  a.n_coeffs = spec->n_coeffs;
+  a.c = d2(c);
+  a.beta = beta;
+  a.phase = d2(std::exp(cplx(0, -1) * beta * dt));
+  a.psi = psi->d;
+  a.nobs = nobs;
+  a.check = spec->check_normalization ? 1 : 0;
+  a.limit = spec->limit;
+
+  // one staging buffer: [table | a | obs descriptors | fail | expvals | work | states]
+  std::vector<void*> owned;
+  struct Free {
+    std::vector<void*>& v;
+    ~Free() {
+      for (void* p : v) (void)hipFree(p);
+    }
+  } guard{owned};
+  auto upload = [&](const void* src, size_t bytes, void** out) -> int {
+    void* d = nullptr;
+    QP_HIP(hipMalloc(&d, std::max<size_t>(bytes, 16)));
+    owned.push_back(d);
+    if (src && bytes) QP_HIP(hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    *out = d;
+    return QP_OK;
+  };
+  void* p = nullptr;
+  QP_CHECK(upload(coeff_table, sizeof(qp_c128) * (size_t)nsteps * ncoeffs, &p));
+  a.table = static_cast<const double2*>(p);
+  QP_CHECK(upload(spec->a, sizeof(double) * (size_t)spec->n_coeffs, &p));
+  a.a = static_cast<const double*>(p);
+  std::vector<qp::SmallObs> hobs((size_t)nobs);
+  for (int o = 0; o < nobs; ++o) hobs[o] = qp::SmallObs{observables[o]->m_rowptr, observables[o]->m_cols, observables[o]->m_vals};
+  QP_CHECK(upload(hobs.data(), sizeof(qp::SmallObs) * (size_t)nobs, &p));
+  a.obs = static_cast<const qp::SmallObs*>(p);
+  QP_CHECK(upload(nullptr, sizeof(int) * 4, &p));
+  a.fail = static_cast<int*>(p);
+  QP_HIP(hipMemsetAsync(a.fail, 0, sizeof(int) * 4, ctx->stream));
+  QP_CHECK(upload(nullptr, sizeof(double2) * rows * (size_t)nobs, &p));
+  a.expvals = static_cast<double2*>(p);
+  if (states_out) {
+    QP_CHECK(upload(nullptr, sizeof(double2) * rows * (size_t)n, &p));
+    a.states = static_cast<double2*>(p);
+  }
+  QP_CHECK(qp::launch_cheby_propagate_small(ctx->stream, a, &ctx->stats));
+  ctx->stats.n_cheby_steps += nsteps;
+  int fail[4] = {0, 0, 0, 0};
+  QP_HIP(hipMemcpyAsync(fail, a.fail, sizeof(fail), hipMemcpyDeviceToHost, ctx->stream));
+  if (nobs > 0)
+    QP_HIP(hipMemcpyAsync(expvals_out, a.expvals, sizeof(double2) * rows * (size_t)nobs, hipMemcpyDeviceToHost, ctx->stream));
+  if (states_out)
+    QP_HIP(hipMemcpyAsync(states_out, a.states, sizeof(double2) * rows * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  QP_HIP(hipStreamSynchronize(ctx->stream));
+  // leave the operator as the step-by-step loop would: holding the last interval's values
+  if (ncoeffs > 0) QP_CHECK(qp_operator_set_coeffs(op, coeff_table + (size_t)(nsteps - 1) * ncoeffs, ncoeffs));
+  if (fail[0])
+    return qp::fail(QP_E_NORMALIZATION, "Incorrect normalization (E_min=%g, Delta=%g) in step %d, term %d", spec->E_min,
+                    spec->Delta, fail[1] + 1, fail[2] + 1);
+  return QP_OK;
+}
+
+int qp_propagate(qp_operator* op, qp_state* psi, const qp_prop_spec* spec, const double* dts,
+                 const qp_c128* coeff_table, int ncoeffs, int nsteps, qp_operator* const* observables, int nobs,
+                 qp_c128* expvals_out, qp_c128* states_out) {
+  QP_TRY
+  if (!op || !psi || !spec || !dts || nsteps < 0 || nobs < 0 || (nobs > 0 && (!observables || !expvals_out)))
+    return qp::fail(QP_E_BAD_ARG, "qp_propagate: bad arguments");
+  if (ncoeffs != op->ncoeffs || (ncoeffs > 0 && nsteps > 0 && !coeff_table))
+    return qp::fail(QP_E_BAD_ARG, "qp_propagate: expected %d coefficients per step", op->ncoeffs);
+  if (spec->method != 0 && spec->method != 1) return qp::fail(QP_E_BAD_ARG, "qp_propagate: bad method");
+  for (int o = 0; o < nobs; ++o)
+    if (!observables[o] || observables[o]->A.nrows != psi->n || observables[o]->A.ncols != psi->n)
+      return qp::fail(QP_E_BAD_ARG, "qp_propagate: observable %d has the wrong shape", o);
+  qp_ctx* ctx = op->ctx;
+  QP_CHECK(use(ctx));
+  const int64_t n = psi->n;
+  const size_t rows = (size_t)nsteps + 1;
+  if (spec->method == 0 && nsteps > 0 && op->A.nnz <= qp::g_small_nnz && op->nops <= 64) {
+    qp::SmallArgs plan;
+    int64_t maxrow = 0;
+    for (int64_t r = 0; r < n; ++r) maxrow = std::max<int64_t>(maxrow, op->u_rowptr[r + 1] - op->u_rowptr[r]);
+    if (qp::small_plan(n, maxrow, &plan))
+      return propagate_cheby_small(op, psi, spec, plan, dts, coeff_table, ncoeffs, nsteps, observables, nobs,
+                                   expvals_out, states_out);
+  }
+  // device staging, released at the end: observable partials and the state history
+  double2* d_part = nullptr;
+  double2* d_tmp = nullptr;
+  double2* d_states = nullptr;
+  struct Free {
+    double2 *&a, *&b, *&c;
+    ~Free() {
+      if (a) (void)hipFree(a);
+      if (b) (void)hipFree(b);
+      if (c) (void)hipFree(c);
+    }
+  } guard{d_part, d_tmp, d_states};
+  if (nobs > 0) {
+    QP_CHECK(dev_alloc(&d_part, rows * nobs * kRedBlocks));
+    QP_CHECK(dev_alloc(&d_tmp, (size_t)n));
+  }
+  if (states_out) QP_CHECK(dev_alloc(&d_states, rows * (size_t)n));
+  auto record = [&](size_t row) -> int {
+    for (int o = 0; o < nobs; ++o) {   // <psi|O|psi> = dot(psi, O psi)
+      qp::PlainEpi e;
+      e.y = d_tmp;
+      e.alpha = make_double2(1.0, 0.0);
+      e.beta = make_double2(0.0, 0.0);
+      e.beta_zero = 1;
+      QP_CHECK(qp::launch_spmv_plain(ctx->stream, observables[o]->A, psi->d, e, &ctx->stats));
+      QP_CHECK(qp::launch_dot_partials(ctx->stream, psi->d, d_tmp, d_part + (row * nobs + o) * kRedBlocks, n, &ctx->stats));
+    }
+    if (d_states)
+      QP_HIP(hipMemcpyAsync(d_states + row * (size_t)n, psi->d, (size_t)n * sizeof(double2), hipMemcpyDeviceToDevice, ctx->stream));
+    return QP_OK;
+  };
+  QP_CHECK(record(0));
+  for (int k = 0; k < nsteps; ++k) {
+    if (ncoeffs > 0) QP_CHECK(qp_operator_set_coeffs(op, coeff_table + (size_t)k * ncoeffs, ncoeffs));
+    if (spec->method == 0) {
+      QP_CHECK(qp_cheby_step(spec->cheby, op, psi, spec->a, spec->n_coeffs, spec->Delta, spec->E_min, dts[k],
+                             spec->wrk_dt, spec->limit, spec->check_normalization));
+    } else {
+      QP_CHECK(qp_newton_step(spec->newton, op, psi, dts[k], spec->func_id, spec->cb, spec->user, spec->norm_min,
+                              spec->relerr, spec->max_restarts, nullptr));
+    }
+    QP_CHECK(record((size_t)k + 1));
+  }
+  if (nobs > 0) {
+    std::vector<cplx> hp(rows * nobs * kRedBlocks);
+    QP_HIP(hipMemcpyAsync(hp.data(), d_part, hp.size() * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
+    QP_HIP(hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < rows * nobs; ++i) {
+      const cplx v = sum_partials(reinterpret_cast<const double2*>(hp.data() + i * kRedBlocks));
+      expvals_out[i] = qp_c128{v.real(), v.imag()};
+    }
+  }
+  if (states_out) {
+    QP_HIP(hipMemcpyAsync(states_out, d_states, rows * (size_t)n * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
+    QP_HIP(hipStreamSynchronize(ctx->stream));
   }
   return QP_OK;
   QP_CATCH

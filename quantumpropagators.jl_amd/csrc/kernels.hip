@@ -414,7 +414,20 @@ __global__ __launch_bounds__(kThreads) void csr_spmv_kernel(const int64_t* __res
   double2 s = make_double2(0.0, 0.0);
   if (row < nrows) {
     const int64_t p0 = rowptr[row], p1 = rowptr[row + 1];
-    for (int64_t p = p0 + tl; p < p1; p += T) cfma(s, vals[p], x[cols[p]]);
+    int64_t p = p0 + tl;
+    double2 s1 = make_double2(0.0, 0.0);
+    for (; p + 3 * T < p1; p += 4 * T) {   // four independent load chains in flight
+      const int32_t c0 = cols[p], c1 = cols[p + T], c2 = cols[p + 2 * T], c3 = cols[p + 3 * T];
+      const double2 a0 = vals[p], a1 = vals[p + T], a2 = vals[p + 2 * T], a3 = vals[p + 3 * T];
+      const double2 x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
+      cfma(s, a0, x0);
+      cfma(s1, a1, x1);
+      cfma(s, a2, x2);
+      cfma(s1, a3, x3);
+    }
+    for (; p < p1; p += T) cfma(s, vals[p], x[cols[p]]);
+    s.x += s1.x;
+    s.y += s1.y;
   }
 #pragma unroll
   for (int o = T / 2; o > 0; o >>= 1) {
@@ -550,6 +563,257 @@ int launch_gather_csr_vals(hipStream_t s, double2* out, const double2* vals, con
                            Stats* st) {
   if (nnz == 0) return QP_OK;
   hipLaunchKernelGGL(gather_csr_vals_kernel, dim3(ew_grid(nnz)), dim3(kThreads), 0, s, out, vals, map, nnz);
+  QP_HIP(hipGetLastError());
+  if (st) st->n_launch++;
+  return QP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Small systems (the reference's own test sizes: N = 2 ... about a thousand): a launch per
+// Chebychev term is bound by the launch itself, not by the matrix.  One persistent
+// workgroup runs the WHOLE time grid -- evaluate!(G, tlist, n) per interval, the
+// three-term recurrence (src/cheby.jl:171-211), the observables and the state storage of
+// propagate (src/propagate.jl:283-344) -- with a workgroup barrier where the multi-launch
+// path has a kernel boundary.  The vectors live in LDS and every lane keeps its share of
+// the matrix in registers: a group of `lanes` lanes owns rows g, g + G, ... (`rows_per_group`
+// of them), each lane `ent` entries of each row; rows_per_group * ent <= kSmallEpt.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double2 small_block_sum(double2 v, double2* red) {
+  v.x = wave_sum(v.x);
+  v.y = wave_sum(v.y);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  if (l == 0) red[w] = v;
+  __syncthreads();
+  double2 r = red[0];
+#pragma unroll
+  for (int i = 1; i < kSmallThreads / 64; ++i) {
+    r.x += red[i].x;
+    r.y += red[i].y;
+  }
+  __syncthreads();
+  return r;
+}
+
+template <int E, int R>
+__global__ __launch_bounds__(kSmallThreads) void cheby_propagate_small_kernel(SmallArgs s) {
+  constexpr int NS = E * R;   // register slots in use
+  extern __shared__ double2 small_lds[];
+  double2* red = small_lds;                        // [16] reduction scratch
+  double2* coef = small_lds + kSmallThreads / 64;  // [nops] effective coefficients of the step
+  double2* vec = coef + s.nops;
+  const int64_t n = s.n;
+  double2* A = vec;
+  double2* B = vec + n;
+  double2* ACC = vec + 2 * n;
+  const int T = s.lanes;
+  const int tid = threadIdx.x;
+  const int lane = tid & (T - 1);
+  const int64_t grp = tid / T, ngrp = kSmallThreads / T;
+  const int nterms = s.n_coeffs - 1;
+  const int drift = s.nops - s.ncoeffs;
+
+  for (int64_t i = tid; i < n; i += kSmallThreads) A[i] = s.psi[i];
+  // register-resident share of the matrix: slot e <-> (row grp + (e / E) ngrp, entry lane + (e % E) T)
+  int32_t rc[NS];
+  int32_t rm[NS];   // 0: no entry; +(m+1): plane[m]; -(m+1): conj(plane[m])
+  double2 rv[NS];
+#pragma unroll
+  for (int e = 0; e < NS; ++e) {
+    rc[e] = 0;
+    rm[e] = 0;
+    rv[e] = make_double2(0.0, 0.0);
+    const int64_t r = grp + (int64_t)(e / E) * ngrp;
+    if (r < n) {
+      const int64_t k = s.rowptr[r] + lane + (int64_t)(e % E) * T;
+      if (k < s.rowptr[r + 1]) {
+        rc[e] = s.cols[k];
+        const int64_t m = s.map[k];
+        rm[e] = (int32_t)(m >= 0 ? m + 1 : m);   // m < 0 already encodes -(pos + 1)
+      }
+    }
+  }
+  __syncthreads();
+
+  // <psi|O|psi> for every observable and the state history, at storage row `row`
+  const int TO = s.obs_lanes;
+  const int olane = tid & (TO - 1);
+  const int64_t ogrp = tid / TO, ongrp = kSmallThreads / TO;
+  auto record = [&](const double2* psi, int row) {
+    for (int o = 0; o < s.nobs; ++o) {
+      const SmallObs ob = s.obs[o];
+      double2 part = make_double2(0.0, 0.0);
+      for (int64_t r = ogrp; r < n; r += ongrp) {
+        double2 sum = make_double2(0.0, 0.0);
+        for (int64_t k = ob.rowptr[r] + olane; k < ob.rowptr[r + 1]; k += TO) cfma(sum, ob.vals[k], psi[ob.cols[k]]);
+        for (int off = TO >> 1; off > 0; off >>= 1) {
+          sum.x += __shfl_xor(sum.x, off);
+          sum.y += __shfl_xor(sum.y, off);
+        }
+        if (olane == 0) {
+          const double2 d = cconj_mul(psi[r], sum);
+          part.x += d.x;
+          part.y += d.y;
+        }
+      }
+      part = small_block_sum(part, red);
+      if (tid == 0) s.expvals[(size_t)row * s.nobs + o] = part;
+    }
+    if (s.states)
+      for (int64_t i = tid; i < n; i += kSmallThreads) s.states[(size_t)row * n + i] = psi[i];
+  };
+  record(A, 0);
+
+  double2* v0 = A;   // holds Psi at the start of every step
+  double2* v1 = B;
+  for (int step = 0; step < s.nsteps; ++step) {
+    // evaluate!(G, tlist, n): values of this interval      src/pwc_utils.jl:86-92
+    if (s.ncoeffs > 0 || step == 0) {
+      if (tid < s.nops) {
+        double2 cl = s.scale;
+        if (tid >= drift) cl = cmul(cl, s.table[(size_t)step * s.ncoeffs + (tid - drift)]);
+        coef[tid] = cl;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < NS; ++e) rv[e] = make_double2(0.0, 0.0);
+      for (int l = 0; l < s.nops; ++l) {
+        const double2* pl = s.planes[l];
+        const double2 cl = coef[l];
+        double2 v[NS];
+#pragma unroll
+        for (int e = 0; e < NS; ++e)   // independent loads, all in flight together
+          v[e] = rm[e] != 0 ? pl[rm[e] > 0 ? rm[e] - 1 : -rm[e] - 1] : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int e = 0; e < NS; ++e) {
+          if (rm[e] < 0) v[e].y = -v[e].y;
+          cfma(rv[e], cl, v[e]);
+        }
+      }
+    }
+    double2 c = s.c;
+    double2* x = v0;    // gathered vector (v1 of the recurrence; Psi for the first term)
+    double2* ob = v1;   // holds v0 of the recurrence, overwritten in place by v2
+    for (int m = 1; m <= nterms; ++m) {
+      const bool last = (m == nterms);
+      const double am = s.a[m];
+      double2 chk = make_double2(0.0, 0.0);
+      double nrm = 0.0;
+      double2 sum = make_double2(0.0, 0.0);
+#pragma unroll
+      for (int e = 0; e < NS; ++e) {
+        {
+          cfma(sum, rv[e], x[rc[e]]);
+          if ((e + 1) % E == 0) {   // the row is complete
+            for (int off = T >> 1; off > 0; off >>= 1) {
+              sum.x += __shfl_xor(sum.x, off);
+              sum.y += __shfl_xor(sum.y, off);
+            }
+            const int64_t r = grp + (int64_t)(e / E) * ngrp;
+            if (lane == 0 && r < n) {
+              const double2 xi = x[r];
+              // t = c (H x - beta x) [+ v0]                  src/cheby.jl:178-179, :192-193, :202
+              double2 t = make_double2(fma(-s.beta, xi.x, sum.x), fma(-s.beta, xi.y, sum.y));
+              t = cmul(c, t);
+              if (s.check && m >= 2) {                        // :194-200
+                const double2 d = cconj_mul(xi, t);
+                chk.x += d.x;
+                chk.y += d.y;
+                nrm += xi.x * xi.x + xi.y * xi.y;
+              }
+              double2 acc;
+              if (m == 1) {
+                acc = make_double2(s.a[0] * xi.x, s.a[0] * xi.y);   // lmul!(a[1], Psi)  :172
+              } else {
+                const double2 o = ob[r];
+                t.x += o.x;
+                t.y += o.y;
+                acc = ACC[r];
+              }
+              acc.x = fma(am, t.x, acc.x);                    // axpy!(a[i], v, Psi)  :182, :205
+              acc.y = fma(am, t.y, acc.y);
+              if (last) {
+                ob[r] = cmul(s.phase, acc);                   // lmul!(exp(-i beta dt), Psi)  :211
+              } else {
+                ob[r] = t;
+                ACC[r] = acc;
+              }
+            }
+            sum = make_double2(0.0, 0.0);
+          }
+        }
+      }
+      if (s.check && m >= 2) {
+        const double2 cs = small_block_sum(chk, red);
+        const double2 ns = small_block_sum(make_double2(nrm, 0.0), red);
+        if (tid == 0 && !(hypot(cs.x, cs.y) / (2 * ns.x) <= 1.0 + s.limit) && s.fail[0] == 0) {
+          s.fail[0] = 1;
+          s.fail[1] = step;
+          s.fail[2] = m;
+        }
+      }
+      __syncthreads();
+      if (m == 1) {
+        c.x *= 2.0;                                            // :184
+        c.y *= 2.0;
+      }
+      double2* tmp = x;
+      x = ob;
+      ob = tmp;
+    }
+    // the new Psi was written to the last `ob`, which the swap above left in `x`
+    v1 = ob;
+    v0 = x;
+    record(v0, step + 1);
+  }
+  __syncthreads();
+  for (int64_t i = tid; i < n; i += kSmallThreads) s.psi[i] = v0[i];
+}
+
+int g_small_nnz = kSmallThreads * kSmallEpt;
+
+// lanes per row, entries per lane and rows per lane group such that the whole matrix is
+// register-resident; false when the system does not fit (the caller then runs the general loop)
+bool small_plan(int64_t n, int64_t maxrow, SmallArgs* a) {
+  if (n < 1 || n > kSmallLdsRows) return false;
+  for (int t = 1; t <= 64; t <<= 1) {
+    const int64_t ngrp = kSmallThreads / t;
+    const int64_t rows = (n + ngrp - 1) / ngrp;
+    int64_t ent = 1;
+    while (ent * t < maxrow) ent <<= 1;   // compile-time variants: 1, 2, 4, 8
+    int64_t rows_p2 = 1;
+    while (rows_p2 < rows) rows_p2 <<= 1;
+    if (rows_p2 * ent <= kSmallEpt) {   // smallest t: fewest cross-lane reduction levels
+      a->lanes = t;
+      a->ent = (int)ent;
+      a->rows_per_group = (int)rows_p2;
+      int to = 1;
+      while (to < 64 && (int64_t)kSmallThreads / (2 * to) >= n) to <<= 1;
+      a->obs_lanes = to;
+      return true;
+    }
+  }
+  return false;
+}
+
+int launch_cheby_propagate_small(hipStream_t s, const SmallArgs& a, Stats* st) {
+  const size_t lds = sizeof(double2) * (kSmallThreads / 64 + (size_t)a.nops + 3 * (size_t)a.n);
+  void (*kern)(SmallArgs) = nullptr;
+  switch (a.ent * 16 + a.rows_per_group) {
+    case 1 * 16 + 1: kern = cheby_propagate_small_kernel<1, 1>; break;
+    case 2 * 16 + 1: kern = cheby_propagate_small_kernel<2, 1>; break;
+    case 4 * 16 + 1: kern = cheby_propagate_small_kernel<4, 1>; break;
+    case 8 * 16 + 1: kern = cheby_propagate_small_kernel<8, 1>; break;
+    case 1 * 16 + 2: kern = cheby_propagate_small_kernel<1, 2>; break;
+    case 2 * 16 + 2: kern = cheby_propagate_small_kernel<2, 2>; break;
+    case 4 * 16 + 2: kern = cheby_propagate_small_kernel<4, 2>; break;
+    case 1 * 16 + 4: kern = cheby_propagate_small_kernel<1, 4>; break;
+    case 2 * 16 + 4: kern = cheby_propagate_small_kernel<2, 4>; break;
+    case 1 * 16 + 8: kern = cheby_propagate_small_kernel<1, 8>; break;
+    default: return fail(QP_E_BAD_ARG, "small plan (%d entries, %d rows per group) has no kernel", a.ent, a.rows_per_group);
+  }
+  if (lds > 48 * 1024)
+    QP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(1), dim3(kSmallThreads), lds, s, a);
   QP_HIP(hipGetLastError());
   if (st) st->n_launch++;
   return QP_OK;

@@ -65,6 +65,13 @@ class qp_newton_stats(C.Structure):
 
 FUNC_CB = C.CFUNCTYPE(None, C.POINTER(qp_c128), C.POINTER(qp_c128), C.c_void_p)
 
+
+class qp_prop_spec(C.Structure):
+    _fields_ = [("method", C.c_int), ("cheby", C.c_void_p), ("a", C.POINTER(C.c_double)), ("n_coeffs", C.c_int),
+                ("Delta", C.c_double), ("E_min", C.c_double), ("wrk_dt", C.c_double), ("limit", C.c_double),
+                ("check_normalization", C.c_int), ("newton", C.c_void_p), ("func_id", C.c_int), ("cb", FUNC_CB),
+                ("user", C.c_void_p), ("norm_min", C.c_double), ("relerr", C.c_double), ("max_restarts", C.c_int)]
+
 _P = C.c_void_p
 _i64p = C.POINTER(C.c_int64)
 _i32p = C.POINTER(C.c_int32)
@@ -148,6 +155,8 @@ SIGNATURES = {
     "qp_newton_step": (C.c_int, [_P, _P, _P, C.c_double, C.c_int, FUNC_CB, _P, C.c_double, C.c_double,
                                  C.c_int, C.POINTER(qp_newton_stats)]),
     "qp_newton_get_coeffs": (C.c_int, [_P, _cp, _cp, C.c_int]),
+    "qp_propagate": (C.c_int, [_P, _P, C.POINTER(qp_prop_spec), _dp, _cp, C.c_int, C.c_int, C.POINTER(_P), C.c_int,
+                               _cp, _cp]),
     "qp_ritzvals": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_double, C.c_double, _cp, C.POINTER(C.c_int)]),
     "qp_specrange_arnoldi": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, _dp, _dp]),
 }
@@ -743,6 +752,41 @@ def newton(psi, H, dt, wrk, func=None, norm_min=1e-14, relerr=1e-12, max_restart
     wrk.restarts, wrk.n_a, wrk.n_leja, wrk.radius = st.restarts, st.n_a, st.n_leja, st.radius
     wrk.stats = {k: getattr(st, k) for k, _ in qp_newton_stats._fields_}
     return psi
+
+
+def propagate_steps(H, psi, wrk, dts, coeff_table=None, observables=(), store_states=False, func=None,
+                    norm_min=1e-14, relerr=1e-12, max_restarts=50, check_normalization=False):
+    """The ``propagate`` step loop (src/propagate.jl:283-344) in one library call.
+    ``wrk``: a ChebyWrk or NewtonWrk; ``dts``: signed time step per interval; ``coeff_table``:
+    [nsteps, ncoeffs] operator coefficients per interval.  Returns (expvals [nsteps+1, nobs] or
+    None, states [nsteps+1, n] or None); ``psi`` holds the final state."""
+    dts = np.ascontiguousarray(dts, dtype=np.float64)
+    nsteps = len(dts)
+    spec = qp_prop_spec()
+    keep = None
+    if isinstance(wrk, ChebyWrk):
+        spec.method, spec.cheby = 0, wrk._h
+        spec.a, spec.n_coeffs = _ptr(wrk.coeffs, _dp), wrk.n_coeffs
+        spec.Delta, spec.E_min, spec.wrk_dt, spec.limit = wrk.Delta, wrk.E_min, wrk.dt, wrk.limit
+        spec.check_normalization = int(check_normalization)
+    else:
+        fid, cb, keep = _func_args(func)
+        spec.method, spec.newton, spec.func_id, spec.cb = 1, wrk._h, fid, cb
+        spec.norm_min, spec.relerr, spec.max_restarts = norm_min, relerr, int(max_restarts)
+    ncoeffs = H.ncoeffs
+    if ncoeffs:
+        tab = np.ascontiguousarray(coeff_table, dtype=np.complex128).reshape(nsteps, ncoeffs)
+        tabp = _ptr(tab, _cp)
+    else:
+        tabp = None
+    nobs = len(observables)
+    obs_arr = (_P * max(nobs, 1))(*[o._h for o in observables]) if nobs else None
+    ev = np.empty((nsteps + 1, nobs), dtype=np.complex128) if nobs else None
+    st = np.empty((nsteps + 1, psi.n), dtype=np.complex128) if store_states else None
+    check(H.lib.qp_propagate(H._h, psi._h, C.byref(spec), _ptr(dts, _dp), tabp, ncoeffs, nsteps, obs_arr, nobs,
+                             _ptr(ev, _cp) if nobs else None, _ptr(st, _cp) if store_states else None))
+    del keep
+    return ev, st
 
 
 def ritzvals(G, state, m_min, m_max=None, prec=1e-5, norm_min=1e-15):

@@ -394,19 +394,77 @@ def reinit_prop(p, state, transform_control_ranges=None, **_):
     set_t(p, float(p.tlist[-1] if p.backward else p.tlist[0]))
 
 
+def _is_matrix_observable(o):
+    return sp.issparse(o) or (isinstance(o, np.ndarray) and o.ndim == 2)
+
+
+def _propagate_fused(p, storage, observables):
+    """The whole step loop in one ``qp_propagate`` call (no per-step host round trip):
+    possible when nothing has to call back into the host between steps."""
+    nt = len(p.tlist)
+    nsteps = nt - 1
+    order = range(nsteps, 0, -1) if p.backward else range(1, nt)        # interval index n per step
+    if p.method == "cheby":
+        dts = np.full(nsteps, -p.wrk.dt if p.backward else p.wrk.dt)
+    else:
+        dts = np.array([p.tlist[n] - p.tlist[n - 1] for n in order])
+        if p.backward:
+            dts = -dts
+    table = None
+    if p.controls:
+        table = np.array([[par[n - 1] for par in p.parameters] for n in order], dtype=np.complex128)
+    obs_ops = []
+    if storage and observables is not None:
+        obs_ops = [L.Operator(p.ctx, [_to_matrix(p.ctx, o)], 0, L.FMT_AUTO) for o in observables]
+    kw = {}
+    if p.method == "newton":
+        kw = dict(func=p.func, norm_min=p.norm_min, relerr=p.relerr, max_restarts=p.max_restarts)
+    else:
+        kw = dict(check_normalization=p.check_normalization)
+    H = p._dgen.op
+    ev, st = L.propagate_steps(H, p.state, p.wrk, dts, table, observables=obs_ops,
+                               store_states=bool(storage) and observables is None, **kw)
+    p.n = 0 if p.backward else nt
+    p.t = float(p.tlist[0] if p.backward else p.tlist[-1])
+    rows = ev if obs_ops else st
+    if rows is None:
+        return None
+    store = rows.T.copy()                                               # column i <-> tlist[i]
+    return store[:, ::-1].copy() if p.backward else store
+
+
 def propagate(state, generator, tlist, *, method, backward=False, inplace=True, storage=None,
-              observables=None, callback=None, **kwargs):
+              observables=None, callback=None, fused=None, **kwargs):
     """``propagate(state, generator, tlist; method, ...)`` -- src/propagate.jl:167-344.
     ``storage=True`` returns (final_state, array) with column i = state at tlist[i]
-    (or the observables' values).  States come back as NumPy arrays."""
+    (or the observables' values).  States come back as NumPy arrays.
+
+    Observables are callables ``o(psi)`` or matrices (expectation value ``dot(psi, O, psi)``,
+    src/storage.jl:121-123).  Without a callback and with matrix observables (or none) the step
+    loop runs inside the library (``fused``, default on in that case)."""
     p = init_prop(state, generator, tlist, method, backward=backward, inplace=inplace, **kwargs)
     nt = len(p.tlist)
+    can_fuse = (callback is None and p.inplace and
+                (observables is None or all(_is_matrix_observable(o) for o in observables)))
+    if fused is None:
+        fused = can_fuse
+    elif fused and not can_fuse:
+        raise ValueError("fused propagation needs inplace=True, no callback and matrix observables")
+    if fused:
+        store = _propagate_fused(p, storage, observables)
+        out = p.state.numpy()
+        return (out, store) if storage else out
+
+    def one(o, psi):
+        if _is_matrix_observable(o):
+            return np.vdot(psi, o @ psi)
+        return o(psi)
 
     def obs(s):
         psi = s.numpy()
         if observables is None:
             return psi
-        return np.array([o(psi) for o in observables])
+        return np.array([one(o, psi) for o in observables])
     store = None
     if storage:
         first = obs(p.state)

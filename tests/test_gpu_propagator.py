@@ -209,3 +209,93 @@ def test_cheby_envelope_and_reinit(ctx):
     ref = qo.propagate(psi0, qo.Generator([H0, H1], [amp * 5.0]), tlist, "cheby", E_min=p.wrk.E_min,
                        E_max=p.wrk.E_min + p.wrk.Delta, specrange_buffer=0.0)
     assert np.linalg.norm(p.state.numpy() - ref) < 1e-10
+
+
+@pytest.mark.parametrize("method", ["cheby", "newton"])
+@pytest.mark.parametrize("backward", [False, True])
+def test_fused_propagate_equals_stepwise(ctx, method, backward):
+    """qp_propagate (the step loop inside the library, src/propagate.jl:283-344) gives
+    bit-identical states to calling prop_step! from the host; matrix observables are
+    dot(psi, O, psi) (src/storage.jl:121-123); backward storage is filled from the end."""
+    rng = np.random.default_rng(11)
+    N = 80
+    H0 = synth.dense_hermitian(N, rho=3.0, rng=rng)
+    H1 = synth.dense_hermitian(N, rho=1.0, rng=rng)
+    tlist = np.linspace(0, 1.5, 31)
+    if method == "newton":                      # Newton also takes a non-uniform grid
+        tlist = np.cumsum(np.concatenate([[0.0], 0.03 + 0.04 * rng.random(30)]))
+    eps = lambda t: 0.7 * np.cos(2 * t)        # noqa: E731
+    gen = P.hamiltonian(H0, (H1, eps))
+    kw = dict(E_min=-6.0, E_max=6.0) if method == "cheby" else dict(m_max=7)
+    psi0 = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    psi0 /= np.linalg.norm(psi0)
+    L.tuning_set("small_nnz", 0)                # the general loop: one launch per term
+    try:
+        out_f, st_f = P.propagate(psi0, gen, tlist, method=method, backward=backward, storage=True, ctx=ctx,
+                                  fused=True, **kw)
+    finally:
+        L.tuning_set("small_nnz", 65536)
+    out_s, st_s = P.propagate(psi0, gen, tlist, method=method, backward=backward, storage=True, ctx=ctx,
+                              fused=False, **kw)
+    assert np.array_equal(out_f, out_s) and np.array_equal(st_f, st_s)
+    # default: small Cheby systems run the whole grid in one persistent launch
+    out_p, st_p = P.propagate(psi0, gen, tlist, method=method, backward=backward, storage=True, ctx=ctx, **kw)
+    assert np.max(np.linalg.norm(st_p - st_s, axis=0)) < 1e-13 and np.linalg.norm(out_p - out_s) < 1e-13
+    ref, rstore = qo.propagate(psi0, qo.Generator([H0, H1], [eps]), tlist, method, backward=backward,
+                               storage=True, **kw)
+    assert np.max(np.linalg.norm(st_f - rstore, axis=0)) < 1e-10
+    # observables: one dense Hermitian, one sparse non-Hermitian matrix
+    O1 = synth.dense_hermitian(N, rho=1.0, rng=rng)
+    O2 = sp.random(N, N, density=0.1, random_state=5, format="csr") * (1 + 0.5j)
+    out_o, ev = P.propagate(psi0, gen, tlist, method=method, backward=backward, storage=True,
+                            observables=[O1, O2], ctx=ctx, **kw)
+    assert np.array_equal(out_o, out_p) and ev.shape == (2, len(tlist))
+    want = np.array([[np.vdot(st_p[:, i], O @ st_p[:, i]) for i in range(len(tlist))] for O in (O1, O2)])
+    assert np.max(np.abs(ev - want)) < 1e-12
+    # without storage only the final state comes back
+    assert np.array_equal(P.propagate(psi0, gen, tlist, method=method, backward=backward, ctx=ctx, **kw), out_p)
+    with pytest.raises(ValueError):
+        P.propagate(psi0, gen, tlist, method=method, ctx=ctx, fused=True, callback=lambda *a: None, **kw)
+
+
+@pytest.mark.parametrize("N,dense,ncontrols", [(2, True, 1), (3, True, 0), (55, False, 0), (64, True, 2),
+                                               (130, True, 1), (700, False, 2), (2048, False, 1), (3000, False, 1)])
+def test_persistent_small_cheby(ctx, N, dense, ncontrols):
+    """The single-launch time grid for small systems (register-resident rows, LDS vectors,
+    streaming rows, vectors in global memory -- one case each) against the oracle, the
+    general loop, with observables, backward, and the normalization check."""
+    rng = np.random.default_rng(N)
+    if dense:
+        mats = [synth.dense_hermitian(N, rho=2.0 if i == 0 else 0.5, rng=rng) for i in range(ncontrols + 1)]
+    else:
+        mats = [synth.sparse_random(N, min(1.0, 12.0 / N), rho=2.0 if i == 0 else 0.5, hermitian=True, rng=rng)
+                for i in range(ncontrols + 1)]
+    nt = 25
+    tlist = np.linspace(0, 1.0, nt)
+    ctrls = [(lambda t, k=k: 0.6 * np.sin((k + 2) * t + 0.3)) for k in range(ncontrols)]
+    gen = P.hamiltonian(mats[0], *[(m, c) for m, c in zip(mats[1:], ctrls)]) if ncontrols else (mats[0],)
+    ogen = qo.Generator(mats, ctrls) if ncontrols else mats[0]
+    psi0 = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    psi0 /= np.linalg.norm(psi0)
+    kw = dict(E_min=-4.0, E_max=4.0)
+    for backward in (False, True):
+        out, st = P.propagate(psi0, gen, tlist, method="cheby", storage=True, backward=backward, ctx=ctx, **kw)
+        ref, rst = qo.propagate(psi0, ogen, tlist, "cheby", storage=True, backward=backward, **kw)
+        assert np.max(np.linalg.norm(st - rst, axis=0)) < 1e-10 and np.linalg.norm(out - ref) < 1e-10
+        L.tuning_set("small_nnz", 0)
+        try:
+            out_g = P.propagate(psi0, gen, tlist, method="cheby", backward=backward, ctx=ctx, **kw)
+        finally:
+            L.tuning_set("small_nnz", 65536)
+        assert np.linalg.norm(out - out_g) < 1e-13
+    O = mats[0]
+    _, ev = P.propagate(psi0, gen, tlist, method="cheby", storage=True, observables=[O], ctx=ctx, **kw)
+    O_ = O.toarray() if sp.issparse(O) else O
+    _, st = P.propagate(psi0, gen, tlist, method="cheby", storage=True, ctx=ctx, **kw)
+    want = np.array([np.vdot(st[:, i], O_ @ st[:, i]) for i in range(nt)])
+    assert np.max(np.abs(ev[0] - want)) < 1e-12
+    # spectral range too narrow: "Incorrect normalization" surfaces from inside the launch
+    with pytest.raises(L.QPError, match="Incorrect normalization"):
+        P.propagate(psi0, gen, tlist, method="cheby", ctx=ctx, E_min=3.0, E_max=3.2, check_normalization=True)
+    # and the operator is left holding the last interval's coefficients
+    P.propagate(psi0, gen, tlist, method="cheby", ctx=ctx, check_normalization=True, **kw)

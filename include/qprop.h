@@ -101,6 +101,7 @@ typedef struct {
   uint64_t n_restarts;
   uint64_t n_kernel_launches;
   double spmv_bytes;       /* algorithmic bytes of fused mat-vec kernels */
+  uint64_t n_graph_launches; /* hipGraph replays of a whole cheby! step (their kernels are counted above) */
 } qp_stats;
 int qp_stats_get(qp_ctx* ctx, qp_stats* out);
 int qp_stats_reset(qp_ctx* ctx);

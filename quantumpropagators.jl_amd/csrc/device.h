@@ -95,7 +95,7 @@ struct PlainEpi {
 };
 
 struct Stats {
-  uint64_t n_matvec = 0, n_cheby_steps = 0, n_newton_steps = 0, n_restarts = 0, n_launch = 0;
+  uint64_t n_matvec = 0, n_cheby_steps = 0, n_newton_steps = 0, n_restarts = 0, n_launch = 0, n_graph_launch = 0;
   double spmv_bytes = 0;
 };
 
@@ -105,6 +105,7 @@ int launch_spmv_plain(hipStream_t s, const DevMatrix& A, const double2* x, const
 int spmv_grid_size(const DevMatrix& A);
 extern int g_rbcsr_variant;
 extern int g_hrb_lower_last;  // HRB kernel: process the lower (conj-transposed) section after the upper one
+extern int g_cheby_graph; // qp_cheby_step: replay a repeated step as a hipGraph when the mat-vec grid has at most this many workgroups (0: off)
 extern int g_small_nnz;   // qp_propagate: register-resident Cheby systems up to this nnz run as ONE persistent launch (0: off)
 extern int g_spmm_tile;   // states per pass of the batched SpMM kernel (16, 32 or 64)
 extern int g_split_mode;  // 0 = cross-stream events on both streams, 1 = in-launch counter for the main stream

@@ -128,6 +128,22 @@ struct qp_cheby {
   double* chk_part = nullptr;  // per-workgroup triples (allocated on demand)
   double* chk_out = nullptr;   // per-term triples
   int chk_wg = 0, chk_terms = 0;
+  // hipGraph of one step's launches: replayed while the key (everything a launch argument
+  // is derived from) stays the same, rebuilt when it changes
+  struct GraphKey {
+    const void *vals = nullptr, *cols = nullptr, *rowptr = nullptr, *psi = nullptr;
+    int format = -1, variant = -1, n_coeffs = 0;
+    double dt = 0, Delta = 0, E_min = 0;
+    uint64_t a_hash = 0;
+    bool operator==(const GraphKey& o) const {
+      return vals == o.vals && cols == o.cols && rowptr == o.rowptr && psi == o.psi && format == o.format &&
+             variant == o.variant && n_coeffs == o.n_coeffs && dt == o.dt && Delta == o.Delta && E_min == o.E_min &&
+             a_hash == o.a_hash;
+    }
+  };
+  GraphKey gkey, gpending;
+  hipGraphExec_t gexec = nullptr;
+  Stats gstats;   // what one replay adds to the context's counters
 };
 
 struct qp_newton {
@@ -230,6 +246,10 @@ int qp_tuning_set(const char* key, int value) {
     qp::g_hrb_lower_last = value;
     return QP_OK;
   }
+  if (std::strcmp(key, "cheby_graph") == 0) {
+    qp::g_cheby_graph = value;
+    return QP_OK;
+  }
   if (std::strcmp(key, "small_nnz") == 0) {
     qp::g_small_nnz = value;
     return QP_OK;
@@ -327,6 +347,7 @@ int qp_stats_get(qp_ctx* ctx, qp_stats* out) {
   out->n_restarts = ctx->stats.n_restarts;
   out->n_kernel_launches = ctx->stats.n_launch;
   out->spmv_bytes = ctx->stats.spmv_bytes;
+  out->n_graph_launches = ctx->stats.n_graph_launch;
   return QP_OK;
 }
 
@@ -1181,6 +1202,7 @@ int qp_cheby_destroy(qp_cheby* w) {
   if (w->acc) (void)hipFree(w->acc);
   if (w->chk_part) (void)hipFree(w->chk_part);
   if (w->chk_out) (void)hipFree(w->chk_out);
+  if (w->gexec) (void)hipGraphExecDestroy(w->gexec);
   delete w;
   return QP_OK;
   QP_CATCH
@@ -1215,40 +1237,14 @@ int qp_cheby_term(qp_operator* op, const qp_state* x, int64_t xoff, const qp_sta
   QP_CATCH
 }
 
-int qp_cheby_step(qp_cheby* w, qp_operator* op, qp_state* psi, const double* a, int n_coeffs, double Delta,
-                  double E_min, double dt, double wrk_dt, double limit, int check_normalization) {
-  QP_TRY
-  if (!w || !op || !psi || !a) return qp::fail(QP_E_BAD_ARG, "qp_cheby_step: NULL argument");
-  if (op->A.nrows != op->A.ncols || psi->n != op->A.nrows || w->n != psi->n)
-    return qp::fail(QP_E_BAD_ARG, "qp_cheby_step: shape mismatch");
-  // @assert abs(dt) ~ abs(wrk.dt)   (isapprox, rtol = sqrt(eps))   src/cheby.jl:157
-  {
-    const double x = std::fabs(dt), y = std::fabs(wrk_dt);
-    if (!(std::fabs(x - y) <= 1.4901161193847656e-08 * std::max(x, y)))
-      return qp::fail(QP_E_DT_MISMATCH, "wrk was initialized for dt=%g, not dt=abs(%g)", wrk_dt, dt);
-  }
-  if (n_coeffs < 2) return qp::fail(QP_E_TOO_FEW_COEFFS, "Need at least 2 Chebychev coefficients");
-  if (!(Delta > 0)) return qp::fail(QP_E_BAD_ARG, "Delta must be positive");
+// the launches of one cheby! call (src/cheby.jl:171-211): n_coeffs - 1 fused mat-vec + term
+// kernels and, when the result does not land in Psi's buffer, one copy
+static int cheby_step_launches(qp_cheby* w, qp_operator* op, qp_state* psi, const double* a, int n_coeffs, double beta,
+                               cplx c, cplx phase, bool check_normalization) {
   qp_ctx* ctx = op->ctx;
-  QP_CHECK(use(ctx));
-  const double beta = (Delta / 2) + E_min;                        // :156
-  cplx c = (dt > 0) ? cplx(0, -2.0) / Delta : cplx(0, 2.0) / Delta;  // :158-162
-  const cplx phase = std::exp(cplx(0, -1) * beta * dt);            // :211
-  const int nterms = n_coeffs - 1;
   const DevMatrix& A = op->A;
+  const int nterms = n_coeffs - 1;
   const int nwg = qp::spmv_grid_size(A);
-  if (check_normalization) {
-    if (w->chk_wg < nwg) {
-      if (w->chk_part) QP_HIP(hipFree(w->chk_part));
-      QP_CHECK(dev_alloc(&w->chk_part, (size_t)3 * nwg));
-      w->chk_wg = nwg;
-    }
-    if (w->chk_terms < nterms) {
-      if (w->chk_out) QP_HIP(hipFree(w->chk_out));
-      QP_CHECK(dev_alloc(&w->chk_out, (size_t)3 * nterms));
-      w->chk_terms = nterms;
-    }
-  }
   double2* P = psi->d;
   double2* B = w->bufA;
   double2* ACC = w->acc;
@@ -1291,7 +1287,109 @@ int qp_cheby_step(qp_cheby* w, qp_operator* op, qp_state* psi, const double* a, 
       QP_CHECK(qp::launch_reduce_triples(ctx->stream, w->chk_part, nwg, w->chk_out + 3 * (m - 1), &ctx->stats));
     if (m == 1) c *= 2.0;  // :184
   }
-  if (result != P) QP_HIP(hipMemcpyAsync(P, result, (size_t)psi->n * sizeof(double2), hipMemcpyDeviceToDevice, ctx->stream));
+  if (result != P)
+    QP_HIP(hipMemcpyAsync(P, result, (size_t)psi->n * sizeof(double2), hipMemcpyDeviceToDevice, ctx->stream));
+  return QP_OK;
+}
+
+int qp_cheby_step(qp_cheby* w, qp_operator* op, qp_state* psi, const double* a, int n_coeffs, double Delta,
+                  double E_min, double dt, double wrk_dt, double limit, int check_normalization) {
+  QP_TRY
+  if (!w || !op || !psi || !a) return qp::fail(QP_E_BAD_ARG, "qp_cheby_step: NULL argument");
+  if (op->A.nrows != op->A.ncols || psi->n != op->A.nrows || w->n != psi->n)
+    return qp::fail(QP_E_BAD_ARG, "qp_cheby_step: shape mismatch");
+  // @assert abs(dt) ~ abs(wrk.dt)   (isapprox, rtol = sqrt(eps))   src/cheby.jl:157
+  {
+    const double x = std::fabs(dt), y = std::fabs(wrk_dt);
+    if (!(std::fabs(x - y) <= 1.4901161193847656e-08 * std::max(x, y)))
+      return qp::fail(QP_E_DT_MISMATCH, "wrk was initialized for dt=%g, not dt=abs(%g)", wrk_dt, dt);
+  }
+  if (n_coeffs < 2) return qp::fail(QP_E_TOO_FEW_COEFFS, "Need at least 2 Chebychev coefficients");
+  if (!(Delta > 0)) return qp::fail(QP_E_BAD_ARG, "Delta must be positive");
+  qp_ctx* ctx = op->ctx;
+  QP_CHECK(use(ctx));
+  const double beta = (Delta / 2) + E_min;                        // :156
+  cplx c = (dt > 0) ? cplx(0, -2.0) / Delta : cplx(0, 2.0) / Delta;  // :158-162
+  const cplx phase = std::exp(cplx(0, -1) * beta * dt);            // :211
+  const int nterms = n_coeffs - 1;
+  const DevMatrix& A = op->A;
+  const int nwg = qp::spmv_grid_size(A);
+  if (check_normalization) {
+    if (w->chk_wg < nwg) {
+      if (w->chk_part) QP_HIP(hipFree(w->chk_part));
+      QP_CHECK(dev_alloc(&w->chk_part, (size_t)3 * nwg));
+      w->chk_wg = nwg;
+    }
+    if (w->chk_terms < nterms) {
+      if (w->chk_out) QP_HIP(hipFree(w->chk_out));
+      QP_CHECK(dev_alloc(&w->chk_out, (size_t)3 * nterms));
+      w->chk_terms = nterms;
+    }
+  }
+  // launch-bound systems (a term takes less than its launch): replay the step as a hipGraph
+  bool done = false;
+  if (qp::g_cheby_graph && !check_normalization && ctx->stream != nullptr && ctx->stream != hipStreamLegacy) {
+    qp_cheby::GraphKey key;
+    key.vals = A.vals;
+    key.cols = A.cols;
+    key.rowptr = A.format == QP_FMT_CSR ? (const void*)A.rowptr : (const void*)A.bptr;
+    key.psi = psi->d;
+    key.format = A.format;
+    key.variant = qp::g_rbcsr_variant;
+    key.n_coeffs = n_coeffs;
+    key.dt = dt;
+    key.Delta = Delta;
+    key.E_min = E_min;
+    uint64_t h = 1469598103934665603ull;   // FNV-1a over the coefficient bits
+    for (int i = 0; i < n_coeffs; ++i) {
+      uint64_t bits;
+      std::memcpy(&bits, &a[i], 8);
+      h = (h ^ bits) * 1099511628211ull;
+    }
+    key.a_hash = h;
+    auto replay = [&]() -> int {
+      QP_HIP(hipGraphLaunch(w->gexec, ctx->stream));
+      ctx->stats.n_graph_launch++;
+      ctx->stats.n_matvec += w->gstats.n_matvec;
+      ctx->stats.n_launch += w->gstats.n_launch;
+      ctx->stats.spmv_bytes += w->gstats.spmv_bytes;
+      return QP_OK;
+    };
+    if (w->gexec && key == w->gkey) {
+      QP_CHECK(replay());
+      done = true;
+    } else if (key == w->gpending && (int64_t)spmv_grid_size(A) <= qp::g_cheby_graph) {
+      // second identical call in a row: record it
+      hipGraph_t graph = nullptr;
+      const Stats before = ctx->stats;
+      QP_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+      const int rc = cheby_step_launches(w, op, psi, a, n_coeffs, beta, c, phase, false);
+      w->gstats = Stats();
+      w->gstats.n_matvec = ctx->stats.n_matvec - before.n_matvec;
+      w->gstats.n_launch = ctx->stats.n_launch - before.n_launch;
+      w->gstats.spmv_bytes = ctx->stats.spmv_bytes - before.spmv_bytes;
+      ctx->stats = before;
+      const hipError_t ec = hipStreamEndCapture(ctx->stream, &graph);
+      if (rc != QP_OK) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc;
+      }
+      QP_HIP(ec);
+      if (w->gexec) {
+        (void)hipGraphExecDestroy(w->gexec);
+        w->gexec = nullptr;
+      }
+      const hipError_t ei = hipGraphInstantiate(&w->gexec, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      QP_HIP(ei);
+      w->gkey = key;
+      QP_CHECK(replay());
+      done = true;
+    } else {
+      w->gpending = key;
+    }
+  }
+  if (!done) QP_CHECK(cheby_step_launches(w, op, psi, a, n_coeffs, beta, c, phase, check_normalization != 0));
   ctx->stats.n_cheby_steps++;
   if (check_normalization && nterms >= 2) {
     std::vector<double> h((size_t)3 * nterms);

@@ -770,6 +770,7 @@ __global__ __launch_bounds__(kSmallThreads) void cheby_propagate_small_kernel(Sm
 }
 
 int g_small_nnz = kSmallThreads * kSmallEpt;
+int g_cheby_graph = 0;     // measured (profiles/r01/propagate_loop.txt): no gain over plain launches on ROCm 7.0, so off
 
 // lanes per row, entries per lane and rows per lane group such that the whole matrix is
 // register-resident; false when the system does not fit (the caller then runs the general loop)

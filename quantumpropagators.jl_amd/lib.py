@@ -52,7 +52,8 @@ class qp_c128(C.Structure):
 class qp_stats(C.Structure):
     _fields_ = [("n_matvec", C.c_uint64), ("n_cheby_steps", C.c_uint64),
                 ("n_newton_steps", C.c_uint64), ("n_restarts", C.c_uint64),
-                ("n_kernel_launches", C.c_uint64), ("spmv_bytes", C.c_double)]
+                ("n_kernel_launches", C.c_uint64), ("spmv_bytes", C.c_double),
+                ("n_graph_launches", C.c_uint64)]
 
 
 class qp_newton_stats(C.Structure):

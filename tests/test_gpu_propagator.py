@@ -234,7 +234,7 @@ def test_fused_propagate_equals_stepwise(ctx, method, backward):
         out_f, st_f = P.propagate(psi0, gen, tlist, method=method, backward=backward, storage=True, ctx=ctx,
                                   fused=True, **kw)
     finally:
-        L.tuning_set("small_nnz", 65536)
+        L.tuning_set("small_nnz", 4096)
     out_s, st_s = P.propagate(psi0, gen, tlist, method=method, backward=backward, storage=True, ctx=ctx,
                               fused=False, **kw)
     assert np.array_equal(out_f, out_s) and np.array_equal(st_f, st_s)
@@ -286,7 +286,7 @@ def test_persistent_small_cheby(ctx, N, dense, ncontrols):
         try:
             out_g = P.propagate(psi0, gen, tlist, method="cheby", backward=backward, ctx=ctx, **kw)
         finally:
-            L.tuning_set("small_nnz", 65536)
+            L.tuning_set("small_nnz", 4096)
         assert np.linalg.norm(out - out_g) < 1e-13
     O = mats[0]
     _, ev = P.propagate(psi0, gen, tlist, method="cheby", storage=True, observables=[O], ctx=ctx, **kw)
@@ -299,3 +299,28 @@ def test_persistent_small_cheby(ctx, N, dense, ncontrols):
         P.propagate(psi0, gen, tlist, method="cheby", ctx=ctx, E_min=3.0, E_max=3.2, check_normalization=True)
     # and the operator is left holding the last interval's coefficients
     P.propagate(psi0, gen, tlist, method="cheby", ctx=ctx, check_normalization=True, **kw)
+
+
+def test_cheby_graph_replay_is_bit_identical(ctx):
+    """Knob `cheby_graph`: a repeated cheby! step replayed as a hipGraph enqueues exactly the
+    same launches; the counters of qp_stats advance as if they had been launched one by one."""
+    rng = np.random.default_rng(21)
+    N = 1500
+    H = synth.sparse_random(N, 10.0 / N, rho=2.0, hermitian=True, rng=rng)
+    tlist = np.linspace(0, 1.0, 21)
+    psi0 = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    psi0 /= np.linalg.norm(psi0)
+    kw = dict(E_min=-4.0, E_max=4.0, fused=False)
+    ctx.reset_stats()
+    ref = P.propagate(psi0, (H,), tlist, method="cheby", ctx=ctx, **kw)
+    plain = ctx.stats()
+    L.tuning_set("cheby_graph", 1024)
+    try:
+        ctx.reset_stats()
+        out = P.propagate(psi0, (H,), tlist, method="cheby", ctx=ctx, **kw)
+        st = ctx.stats()
+    finally:
+        L.tuning_set("cheby_graph", 0)
+    assert np.array_equal(out, ref)
+    assert st["n_graph_launches"] == len(tlist) - 2        # the first call only arms the key
+    assert st["n_matvec"] == plain["n_matvec"] and st["spmv_bytes"] == plain["spmv_bytes"]

@@ -1,6 +1,8 @@
 """Step loop of `propagate` (src/propagate.jl:283-344) in the launch-bound regime:
   host   : prop_step! driven from Python, one launch per Chebychev term
-  loop   : qp_propagate, general path (same launches, loop inside the library)
+  graph  : the same, every repeated cheby! step replayed as a hipGraph
+  loop   : qp_propagate, general path (one launch per term, loop inside the library)
+  loop+g : qp_propagate with the hipGraph replay
   small  : qp_propagate, one persistent single-workgroup launch for the whole time grid
 Wall time per step of the loop only (init_prop excluded), state storage off."""
 import os
@@ -31,12 +33,13 @@ def run(ctx, N, nt, mode, method, kw):
     psi0 = rng.standard_normal(N) + 1j * rng.standard_normal(N)
     psi0 /= np.linalg.norm(psi0)
     L.tuning_set("small_nnz", 65536 if mode == "small" else 0)
+    L.tuning_set("cheby_graph", 1024 if mode in ("graph", "loop+g", "small") else 0)
     best = None
     for _ in range(3):
         p = P.init_prop(psi0, gen, tlist, method, ctx=ctx, **kw)
         ctx.sync()
         t0 = time.perf_counter()
-        if mode == "host":
+        if mode in ("host", "graph"):
             while P.prop_step(p) is not None:
                 pass
         else:
@@ -44,20 +47,21 @@ def run(ctx, N, nt, mode, method, kw):
         ctx.sync()
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
-    L.tuning_set("small_nnz", 65536)
+    L.tuning_set("small_nnz", 4096)
+    L.tuning_set("cheby_graph", 0)
     return 1e6 * best / (nt - 1), p.wrk.n_coeffs if method == "cheby" else 0
 
 
 def main():
     ctx = L.Context(0)
-    for N, nt in ((2, 2001), (64, 2001), (128, 1001), (1024, 1001)):
-        for mode in ("host", "loop", "small"):
+    for N, nt in ((2, 2001), (64, 2001), (128, 1001), (1024, 1001), (65536, 501)):
+        for mode in ("host", "graph", "loop", "loop+g", "small"):
             us, nc = run(ctx, N, nt, mode, "cheby", dict(E_min=-20.0, E_max=20.0))
-            print(f"cheby  N={N:5d} {mode:5s} {us:8.2f} us/step  ({nc} coefficients, {us / max(nc - 1, 1):6.2f} us/term)")
+            print(f"cheby  N={N:5d} {mode:6s} {us:8.2f} us/step  ({nc} coefficients, {us / max(nc - 1, 1):6.2f} us/term)")
     for N, nt in ((64, 501), (200, 501), (4096, 501)):
         for mode in ("host", "loop"):
             us, _ = run(ctx, N, nt, mode, "newton", dict(m_max=10))
-            print(f"newton N={N:5d} {mode:5s} {us:8.2f} us/step")
+            print(f"newton N={N:5d} {mode:6s} {us:8.2f} us/step")
     ctx.close()
 
 

@@ -158,8 +158,29 @@ struct SmallArgs {
   int* fail = nullptr;                 // {flag, step, term}
 };
 constexpr int kSmallThreads = 512;
-constexpr int kSmallEpt = 8;
+constexpr int kSmallEpt = 16;
 constexpr int64_t kSmallLdsRows = 2048;
+// arnoldi! (src/arnoldi.jl:74-100) for a register-resident operator: all m columns in one
+// single-workgroup launch, Krylov basis in LDS (and written to Q for the caller)
+struct SmallArnoldiArgs {
+  int64_t n = 0;
+  int lanes = 1, ent = 1, rows_per_group = 1;
+  const int64_t* rowptr = nullptr;
+  const int32_t* cols = nullptr;
+  const int64_t* map = nullptr;
+  const double2* vals = nullptr;       // current values of the operator, device layout
+  const double2* start = nullptr;      // q_0
+  double2* Q = nullptr;                // [m + 1][n]
+  double2* hess = nullptr;             // column major, leading dimension ldd (zeroed by the caller)
+  double* norms = nullptr;             // [ldd]
+  int ldd = 0, m = 0, extended = 0;
+  double dt = 1.0, norm_min = 0.0;
+};
+constexpr size_t kSmallLdsBytes = 152 * 1024;
+inline bool small_arnoldi_fits(int64_t n, int m) {
+  return sizeof(double2) * ((size_t)kSmallThreads / 64 + (size_t)(m + 2) * (size_t)n) <= kSmallLdsBytes;
+}
+int launch_arnoldi_small(hipStream_t s, const SmallArnoldiArgs& a, Stats* st);
 bool small_plan(int64_t n, int64_t maxrow, SmallArgs* a);
 int launch_cheby_propagate_small(hipStream_t s, const SmallArgs& a, Stats* st);
 

@@ -1409,7 +1409,7 @@ int qp_cheby_step(qp_cheby* w, qp_operator* op, qp_state* psi, const double* a, 
 // ---------------------------------------------------------------------------
 // batched states (BASELINE configs[4]): panel X[i*b + s]
 // ---------------------------------------------------------------------------
-static int operator_csr_mirror(qp_operator* op) {
+static int operator_csr_mirror(qp_operator* op, bool gather = true) {
   qp_ctx* ctx = op->ctx;
   const DevMatrix& A = op->A;
   const auto& ur = op->u_rowptr;
@@ -1444,7 +1444,7 @@ static int operator_csr_mirror(qp_operator* op) {
     QP_HIP(hipMemcpy(op->m_map, map.data(), (size_t)nnz * sizeof(int64_t), hipMemcpyHostToDevice));
     op->m_epoch = 0;
   }
-  if (op->m_epoch != op->vals_epoch) {
+  if (gather && op->m_epoch != op->vals_epoch) {
     QP_CHECK(qp::launch_gather_csr_vals(ctx->stream, op->m_vals, A.vals, op->m_map, nnz, &ctx->stats));
     op->m_epoch = op->vals_epoch;
   }
@@ -1794,15 +1794,47 @@ int qp_arnoldi(qp_operator* op, qp_krylov* q, int m, const qp_state* psi, double
   std::memset(Hess, 0, sizeof(qp_c128) * (size_t)ldh * ldh);                                      // :78
   QP_HIP(hipMemsetAsync(q->hess_dev, 0, sizeof(double2) * (size_t)ldd * ldd, ctx->stream));
   QP_HIP(hipMemsetAsync(q->norms_dev, 0, sizeof(double) * (size_t)ldd, ctx->stream));
-  QP_HIP(hipMemcpyAsync(q->q(0), psi->d, (size_t)q->n * sizeof(double2), hipMemcpyDeviceToDevice, ctx->stream));  // :79
-  for (int j = 0; j < m; ++j) {
-    double2* hcol = q->hess_dev + (size_t)j * ldd;
-    QP_CHECK(arnoldi_column(op, q, j, dt, hcol));
-    if ((j + 1 < m) || extended) {                                                                 // :88-97
-      hipLaunchKernelGGL(norm_guard_scale_kernel, dim3(2048), dim3(qp::kThreads), 0, ctx->stream, q->q(j + 1),
-                         q->part + (size_t)((j + 1) & 1) * kRedBlocks, hcol + (j + 1), q->norms_dev + j, dt, norm_min, q->n);
-      QP_HIP(hipGetLastError());
-      ctx->stats.n_launch++;
+  qp::SmallArgs plan;
+  bool small = false;
+  if (op->A.nnz <= qp::g_small_nnz && qp::small_arnoldi_fits(q->n, m)) {
+    int64_t maxrow = 0;
+    for (int64_t r = 0; r < q->n; ++r) maxrow = std::max<int64_t>(maxrow, op->u_rowptr[r + 1] - op->u_rowptr[r]);
+    small = qp::small_plan(q->n, maxrow, &plan);
+  }
+  if (small) {
+    // all m columns in one persistent single-workgroup launch (kernels.hip: arnoldi_small_kernel)
+    QP_CHECK(operator_csr_mirror(op, false));
+    qp::SmallArnoldiArgs a;
+    a.n = q->n;
+    a.lanes = plan.lanes;
+    a.ent = plan.ent;
+    a.rows_per_group = plan.rows_per_group;
+    a.rowptr = op->m_rowptr;
+    a.cols = op->m_cols;
+    a.map = op->m_map;
+    a.vals = op->A.vals;
+    a.start = psi->d;
+    a.Q = q->Q;
+    a.hess = q->hess_dev;
+    a.norms = q->norms_dev;
+    a.ldd = ldd;
+    a.m = m;
+    a.extended = extended;
+    a.dt = dt;
+    a.norm_min = norm_min;
+    QP_CHECK(qp::launch_arnoldi_small(ctx->stream, a, &ctx->stats));
+  } else {
+    QP_HIP(hipMemcpyAsync(q->q(0), psi->d, (size_t)q->n * sizeof(double2), hipMemcpyDeviceToDevice, ctx->stream));  // :79
+    for (int j = 0; j < m; ++j) {
+      double2* hcol = q->hess_dev + (size_t)j * ldd;
+      QP_CHECK(arnoldi_column(op, q, j, dt, hcol));
+      if ((j + 1 < m) || extended) {                                                               // :88-97
+        hipLaunchKernelGGL(norm_guard_scale_kernel, dim3(2048), dim3(qp::kThreads), 0, ctx->stream, q->q(j + 1),
+                           q->part + (size_t)((j + 1) & 1) * kRedBlocks, hcol + (j + 1), q->norms_dev + j, dt, norm_min,
+                           q->n);
+        QP_HIP(hipGetLastError());
+        ctx->stats.n_launch++;
+      }
     }
   }
   std::vector<cplx> hh((size_t)ldd * ldd);

@@ -769,6 +769,152 @@ __global__ __launch_bounds__(kSmallThreads) void cheby_propagate_small_kernel(Sm
   for (int64_t i = tid; i < n; i += kSmallThreads) s.psi[i] = v0[i];
 }
 
+// ---------------------------------------------------------------------------
+// arnoldi! for small systems: m columns = m mat-vecs + m (m + 1) / 2 projections + m norms,
+// about 5 m launches on the general path, each bound by its launch.  Here: one workgroup,
+// the operator in registers, the Krylov basis and the work vector in LDS, modified
+// Gram-Schmidt in the reference's order (src/arnoldi.jl:82-97).
+// ---------------------------------------------------------------------------
+template <int E, int R>
+__global__ __launch_bounds__(kSmallThreads) void arnoldi_small_kernel(SmallArnoldiArgs s) {
+  constexpr int NS = E * R;
+  extern __shared__ double2 small_lds[];
+  double2* red = small_lds;
+  double2* QL = small_lds + kSmallThreads / 64;   // [m + 1][n]
+  const int64_t n = s.n;
+  double2* W = QL + (size_t)(s.m + 1) * n;
+  const int T = s.lanes;
+  const int tid = threadIdx.x;
+  const int lane = tid & (T - 1);
+  const int64_t grp = tid / T, ngrp = kSmallThreads / T;
+
+  int32_t rc[NS];
+  double2 rv[NS];
+#pragma unroll
+  for (int e = 0; e < NS; ++e) {
+    rc[e] = 0;
+    rv[e] = make_double2(0.0, 0.0);
+    const int64_t r = grp + (int64_t)(e / E) * ngrp;
+    if (r < n) {
+      const int64_t k = s.rowptr[r] + lane + (int64_t)(e % E) * T;
+      if (k < s.rowptr[r + 1]) {
+        rc[e] = s.cols[k];
+        const int64_t mp = s.map[k];
+        double2 v = s.vals[mp >= 0 ? mp : -mp - 1];
+        if (mp < 0) v.y = -v.y;
+        rv[e] = v;
+      }
+    }
+  }
+  for (int64_t i = tid; i < n; i += kSmallThreads) {   // q_0 = start   :79
+    const double2 v = s.start[i];
+    QL[i] = v;
+    s.Q[i] = v;
+  }
+  __syncthreads();
+
+  for (int j = 0; j < s.m; ++j) {
+    const double2* x = QL + (size_t)j * n;
+    double2* hcol = s.hess + (size_t)j * s.ldd;
+    // W = H q_j                                             :82
+    double2 sum = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int e = 0; e < NS; ++e) {
+      cfma(sum, rv[e], x[rc[e]]);
+      if ((e + 1) % E == 0) {
+        for (int off = T >> 1; off > 0; off >>= 1) {
+          sum.x += __shfl_xor(sum.x, off);
+          sum.y += __shfl_xor(sum.y, off);
+        }
+        const int64_t r = grp + (int64_t)(e / E) * ngrp;
+        if (lane == 0 && r < n) W[r] = sum;
+        sum = make_double2(0.0, 0.0);
+      }
+    }
+    __syncthreads();
+    // Hess[i,j] = dt <q_i|W>;  W -= (Hess[i,j] / dt) q_i     :84-87
+    for (int i = 0; i <= j; ++i) {
+      const double2* qi = QL + (size_t)i * n;
+      double2 part = make_double2(0.0, 0.0);
+      for (int64_t e = tid; e < n; e += kSmallThreads) {
+        const double2 d = cconj_mul(qi[e], W[e]);
+        part.x += d.x;
+        part.y += d.y;
+      }
+      const double2 h = small_block_sum(part, red);
+      const double2 hd = make_double2(s.dt * h.x, s.dt * h.y);
+      if (tid == 0) hcol[i] = hd;
+      const double2 coef = make_double2(-hd.x / s.dt, -hd.y / s.dt);
+      for (int64_t e = tid; e < n; e += kSmallThreads) {
+        double2 r = W[e];
+        cfma(r, coef, qi[e]);
+        W[e] = r;
+      }
+    }
+    double nrm = 0.0;
+    for (int64_t e = tid; e < n; e += kSmallThreads) {
+      const double2 r = W[e];
+      nrm += r.x * r.x + r.y * r.y;
+    }
+    const double hn = sqrt(small_block_sum(make_double2(nrm, 0.0), red).x);   // :88
+    bool stop = false;
+    double inv = 1.0;
+    if ((j + 1 < s.m) || s.extended) {                        // :88-97
+      if (tid == 0) {
+        hcol[j + 1] = make_double2(s.dt * hn, 0.0);
+        s.norms[j] = hn;
+      }
+      if (hn < s.norm_min) {
+        stop = true;                                          // dimensionality exhausted  :91-95
+      } else {
+        inv = 1.0 / hn;
+      }
+    }
+    double2* qn = QL + (size_t)(j + 1) * n;
+    for (int64_t e = tid; e < n; e += kSmallThreads) {
+      double2 r = W[e];
+      r.x *= inv;
+      r.y *= inv;
+      qn[e] = r;
+      s.Q[(size_t)(j + 1) * n + e] = r;
+    }
+    if (stop) break;
+    __syncthreads();
+  }
+}
+
+int launch_arnoldi_small(hipStream_t s, const SmallArnoldiArgs& a, Stats* st) {
+  const size_t lds = sizeof(double2) * (kSmallThreads / 64 + (size_t)(a.m + 2) * (size_t)a.n);
+  void (*kern)(SmallArnoldiArgs) = nullptr;
+  switch (a.ent * 32 + a.rows_per_group) {
+    case 1 * 32 + 1: kern = arnoldi_small_kernel<1, 1>; break;
+    case 2 * 32 + 1: kern = arnoldi_small_kernel<2, 1>; break;
+    case 4 * 32 + 1: kern = arnoldi_small_kernel<4, 1>; break;
+    case 8 * 32 + 1: kern = arnoldi_small_kernel<8, 1>; break;
+    case 1 * 32 + 2: kern = arnoldi_small_kernel<1, 2>; break;
+    case 2 * 32 + 2: kern = arnoldi_small_kernel<2, 2>; break;
+    case 4 * 32 + 2: kern = arnoldi_small_kernel<4, 2>; break;
+    case 1 * 32 + 4: kern = arnoldi_small_kernel<1, 4>; break;
+    case 2 * 32 + 4: kern = arnoldi_small_kernel<2, 4>; break;
+    case 1 * 32 + 8: kern = arnoldi_small_kernel<1, 8>; break;
+    case 16 * 32 + 1: kern = arnoldi_small_kernel<16, 1>; break;
+    case 8 * 32 + 2: kern = arnoldi_small_kernel<8, 2>; break;
+    case 4 * 32 + 4: kern = arnoldi_small_kernel<4, 4>; break;
+    case 2 * 32 + 8: kern = arnoldi_small_kernel<2, 8>; break;
+    case 1 * 32 + 16: kern = arnoldi_small_kernel<1, 16>; break;
+    default: return fail(QP_E_BAD_ARG, "small plan (%d entries, %d rows per group) has no kernel", a.ent, a.rows_per_group);
+  }
+  if (lds > 48 * 1024)
+    QP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(1), dim3(kSmallThreads), lds, s, a);
+  QP_HIP(hipGetLastError());
+  if (st) {
+    st->n_launch++;
+    st->n_matvec += a.m;
+  }
+  return QP_OK;
+}
+
 int g_small_nnz = kSmallThreads * kSmallEpt;
 int g_cheby_graph = 0;     // measured (profiles/r01/propagate_loop.txt): no gain over plain launches on ROCm 7.0, so off
 
@@ -780,7 +926,7 @@ bool small_plan(int64_t n, int64_t maxrow, SmallArgs* a) {
     const int64_t ngrp = kSmallThreads / t;
     const int64_t rows = (n + ngrp - 1) / ngrp;
     int64_t ent = 1;
-    while (ent * t < maxrow) ent <<= 1;   // compile-time variants: 1, 2, 4, 8
+    while (ent * t < maxrow) ent <<= 1;   // compile-time variants: 1, 2, 4, 8, 16
     int64_t rows_p2 = 1;
     while (rows_p2 < rows) rows_p2 <<= 1;
     if (rows_p2 * ent <= kSmallEpt) {   // smallest t: fewest cross-lane reduction levels
@@ -799,17 +945,22 @@ bool small_plan(int64_t n, int64_t maxrow, SmallArgs* a) {
 int launch_cheby_propagate_small(hipStream_t s, const SmallArgs& a, Stats* st) {
   const size_t lds = sizeof(double2) * (kSmallThreads / 64 + (size_t)a.nops + 3 * (size_t)a.n);
   void (*kern)(SmallArgs) = nullptr;
-  switch (a.ent * 16 + a.rows_per_group) {
-    case 1 * 16 + 1: kern = cheby_propagate_small_kernel<1, 1>; break;
-    case 2 * 16 + 1: kern = cheby_propagate_small_kernel<2, 1>; break;
-    case 4 * 16 + 1: kern = cheby_propagate_small_kernel<4, 1>; break;
-    case 8 * 16 + 1: kern = cheby_propagate_small_kernel<8, 1>; break;
-    case 1 * 16 + 2: kern = cheby_propagate_small_kernel<1, 2>; break;
-    case 2 * 16 + 2: kern = cheby_propagate_small_kernel<2, 2>; break;
-    case 4 * 16 + 2: kern = cheby_propagate_small_kernel<4, 2>; break;
-    case 1 * 16 + 4: kern = cheby_propagate_small_kernel<1, 4>; break;
-    case 2 * 16 + 4: kern = cheby_propagate_small_kernel<2, 4>; break;
-    case 1 * 16 + 8: kern = cheby_propagate_small_kernel<1, 8>; break;
+  switch (a.ent * 32 + a.rows_per_group) {
+    case 1 * 32 + 1: kern = cheby_propagate_small_kernel<1, 1>; break;
+    case 2 * 32 + 1: kern = cheby_propagate_small_kernel<2, 1>; break;
+    case 4 * 32 + 1: kern = cheby_propagate_small_kernel<4, 1>; break;
+    case 8 * 32 + 1: kern = cheby_propagate_small_kernel<8, 1>; break;
+    case 1 * 32 + 2: kern = cheby_propagate_small_kernel<1, 2>; break;
+    case 2 * 32 + 2: kern = cheby_propagate_small_kernel<2, 2>; break;
+    case 4 * 32 + 2: kern = cheby_propagate_small_kernel<4, 2>; break;
+    case 1 * 32 + 4: kern = cheby_propagate_small_kernel<1, 4>; break;
+    case 2 * 32 + 4: kern = cheby_propagate_small_kernel<2, 4>; break;
+    case 1 * 32 + 8: kern = cheby_propagate_small_kernel<1, 8>; break;
+    case 16 * 32 + 1: kern = cheby_propagate_small_kernel<16, 1>; break;
+    case 8 * 32 + 2: kern = cheby_propagate_small_kernel<8, 2>; break;
+    case 4 * 32 + 4: kern = cheby_propagate_small_kernel<4, 4>; break;
+    case 2 * 32 + 8: kern = cheby_propagate_small_kernel<2, 8>; break;
+    case 1 * 32 + 16: kern = cheby_propagate_small_kernel<1, 16>; break;
     default: return fail(QP_E_BAD_ARG, "small plan (%d entries, %d rows per group) has no kernel", a.ent, a.rows_per_group);
   }
   if (lds > 48 * 1024)

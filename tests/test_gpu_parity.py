@@ -658,3 +658,59 @@ def test_batched_c5_full_size_properties(ctx):
         assert np.linalg.norm(single.numpy() - out[:, s]) < TOL
     L.cheby_batched(panel, Op, -1.0, wrk, b)
     assert np.linalg.norm(panel.numpy().reshape(N, b) - states) < 1e-9
+
+
+# ---------------------------------------------------------------- persistent single-launch Arnoldi
+
+@pytest.mark.parametrize("N,dense,m,per_row", [(3, True, 2, 0), (64, True, 10, 0), (55, False, 10, 5.0),
+                                               (300, False, 12, 5.0), (500, False, 10, 4.0), (1000, False, 4, 1.5)])
+def test_arnoldi_persistent_small(ctx, N, dense, m, per_row):
+    """Register-resident operators run arnoldi! (src/arnoldi.jl:74-100) as one persistent
+    launch: same Hessenberg matrix and Krylov vectors as the oracle and as the general
+    (launch per kernel) path, extended or not, dt of either sign."""
+    rng = np.random.default_rng(100 + N)
+    A = synth.dense_nonhermitian(N, rho=3.0, rng=rng) if dense else synth.sparse_random(N, min(1.0, per_row / N), rho=3.0, rng=rng)
+    A = sp.csr_matrix(A)
+    psi = _rand_state(N, rng)
+    Op = L.Operator(ctx, [L.Matrix.from_scipy(ctx, A)])
+    for extended, dt in ((True, 0.4), (False, -0.7)):
+        res = {}
+        for small in (1, 0):
+            L.tuning_set("small_nnz", 8192 if small else 0)
+            try:
+                ctx.reset_stats()
+                q = L.Krylov(ctx, N, m + 1)
+                Hess = np.zeros((m + 1, m + 1), dtype=complex, order="F")
+                m_out = L.arnoldi(Hess, q, m, L.State(ctx, data=psi), Op, dt, extended=extended)
+                res[small] = (m_out, Hess, [q.vec(i) for i in range(m + 1)], ctx.stats()["n_kernel_launches"])
+            finally:
+                L.tuning_set("small_nnz", 8192)
+        assert res[1][3] == 1 and res[0][3] > m       # one launch vs several per column
+        Href = np.zeros((m + 1, m + 1), dtype=complex)
+        qref = [np.empty(N, dtype=complex) for _ in range(m + 1)]
+        m_ref = qo.arnoldi(Href, qref, m, psi, A, dt, extended=extended)
+        for m_out, Hess, qs, _ in res.values():
+            assert m_out == m_ref
+            assert np.max(np.abs(Hess - Href)) < 1e-12
+            for i in range(m_ref + (1 if extended else 0)):
+                assert np.linalg.norm(qs[i] - qref[i]) < 1e-11
+
+
+def test_newton_persistent_small_liouvillian(ctx):
+    """Newton on a small open-system Liouvillian (N = n^2 = 256): every Arnoldi sweep is one
+    launch; result equals the general path and the oracle."""
+    n = 16
+    Lv = synth.liouvillian_tridiag(n)
+    N = n * n
+    rng = np.random.default_rng(9)
+    rho0 = _rand_state(N, rng)
+    outs = {}
+    for small in (1, 0):
+        L.tuning_set("small_nnz", 8192 if small else 0)
+        try:
+            out, ref, wrk, owrk = _newton_case(ctx, Lv, rho0, 0.5, 10)
+        finally:
+            L.tuning_set("small_nnz", 8192)
+        assert np.linalg.norm(out - ref) < TOL
+        outs[small] = out
+    assert np.linalg.norm(outs[0] - outs[1]) < 1e-12

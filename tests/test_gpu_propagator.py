@@ -234,7 +234,7 @@ def test_fused_propagate_equals_stepwise(ctx, method, backward):
         out_f, st_f = P.propagate(psi0, gen, tlist, method=method, backward=backward, storage=True, ctx=ctx,
                                   fused=True, **kw)
     finally:
-        L.tuning_set("small_nnz", 4096)
+        L.tuning_set("small_nnz", 8192)
     out_s, st_s = P.propagate(psi0, gen, tlist, method=method, backward=backward, storage=True, ctx=ctx,
                               fused=False, **kw)
     assert np.array_equal(out_f, out_s) and np.array_equal(st_f, st_s)
@@ -286,7 +286,7 @@ def test_persistent_small_cheby(ctx, N, dense, ncontrols):
         try:
             out_g = P.propagate(psi0, gen, tlist, method="cheby", backward=backward, ctx=ctx, **kw)
         finally:
-            L.tuning_set("small_nnz", 4096)
+            L.tuning_set("small_nnz", 8192)
         assert np.linalg.norm(out - out_g) < 1e-13
     O = mats[0]
     _, ev = P.propagate(psi0, gen, tlist, method="cheby", storage=True, observables=[O], ctx=ctx, **kw)

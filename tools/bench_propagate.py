@@ -19,6 +19,9 @@ import qprop_amd.synth as synth  # noqa: E402
 
 
 def model(N, rng):
+    if N == 512:   # 7 entries per row: register-resident
+        rp, col, val = synth.hermitian_offsets_csr(N, (1, 2, 16), rho=3.0)
+        return synth.to_scipy(rp, col, val, N), sp.identity(N, dtype=complex, format="csr") * 0.1
     if N <= 256:
         return synth.dense_hermitian(N, rho=3.0, rng=rng), synth.dense_hermitian(N, rho=1.0, rng=rng)
     rp, col, val = synth.hermitian_offsets_csr(N, (1, 2, 3, 16, 32, 48), rho=3.0)
@@ -39,7 +42,7 @@ def run(ctx, N, nt, mode, method, kw):
         p = P.init_prop(psi0, gen, tlist, method, ctx=ctx, **kw)
         ctx.sync()
         t0 = time.perf_counter()
-        if mode in ("host", "graph"):
+        if mode in ("host", "graph") or method == "newton":
             while P.prop_step(p) is not None:
                 pass
         else:
@@ -47,7 +50,7 @@ def run(ctx, N, nt, mode, method, kw):
         ctx.sync()
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
-    L.tuning_set("small_nnz", 4096)
+    L.tuning_set("small_nnz", 8192)
     L.tuning_set("cheby_graph", 0)
     return 1e6 * best / (nt - 1), p.wrk.n_coeffs if method == "cheby" else 0
 
@@ -58,8 +61,8 @@ def main():
         for mode in ("host", "graph", "loop", "loop+g", "small"):
             us, nc = run(ctx, N, nt, mode, "cheby", dict(E_min=-20.0, E_max=20.0))
             print(f"cheby  N={N:5d} {mode:6s} {us:8.2f} us/step  ({nc} coefficients, {us / max(nc - 1, 1):6.2f} us/term)")
-    for N, nt in ((64, 501), (200, 501), (4096, 501)):
-        for mode in ("host", "loop"):
+    for N, nt in ((64, 501), (200, 501), (512, 501)):
+        for mode in ("host", "small"):
             us, _ = run(ctx, N, nt, mode, "newton", dict(m_max=10))
             print(f"newton N={N:5d} {mode:6s} {us:8.2f} us/step")
     ctx.close()

@@ -63,6 +63,13 @@ struct ChebyEpi {
   // term vector into slab[mirror[slot]] (slot = 64 * position-in-row-set + lane)
   const int32_t* mirror = nullptr;
   double2* slab = nullptr;
+  // deferred accumulation of Psi: the row epilogue of term m has v_{m-2} (v0), v_{m-1}
+  // (xloc) and v_m at hand, so Psi += a_{m-2} v_{m-2} + a_{m-1} v_{m-1} + a_m v_m can be one
+  // read + one write of the accumulator every third term -- the same FMA sequence
+  int acc_skip = 0;      // 1: this term does not touch the accumulator
+  int n_defer = 0;       // earlier terms folded into this update (0, 1 or 2)
+  double a_d1 = 0.0;     // coefficient of v_{m-1}
+  double a_d2 = 0.0;     // coefficient of v_{m-2}
 };
 
 // a subset of the 64-row blocks of an operator (device list), optionally with a mirror map
@@ -105,6 +112,7 @@ int launch_spmv_plain(hipStream_t s, const DevMatrix& A, const double2* x, const
 int spmv_grid_size(const DevMatrix& A);
 extern int g_rbcsr_variant;
 extern int g_hrb_lower_last;  // HRB kernel: process the lower (conj-transposed) section after the upper one
+extern int g_acc_defer;   // qp_cheby_step: touch the Psi accumulator every third term only (1, default) or every term (0)
 extern int g_cheby_graph; // qp_cheby_step: replay a repeated step as a hipGraph when the mat-vec grid has at most this many workgroups (0: off)
 extern int g_small_nnz;   // qp_propagate: register-resident Cheby systems up to this nnz run as ONE persistent launch (0: off)
 extern int g_spmm_tile;   // states per pass of the batched SpMM kernel (16, 32 or 64)

@@ -246,6 +246,10 @@ int qp_tuning_set(const char* key, int value) {
     qp::g_hrb_lower_last = value;
     return QP_OK;
   }
+  if (std::strcmp(key, "acc_defer") == 0) {
+    qp::g_acc_defer = value;
+    return QP_OK;
+  }
   if (std::strcmp(key, "cheby_graph") == 0) {
     qp::g_cheby_graph = value;
     return QP_OK;
@@ -1249,6 +1253,16 @@ static int cheby_step_launches(qp_cheby* w, qp_operator* op, qp_state* psi, cons
   double2* B = w->bufA;
   double2* ACC = w->acc;
   double2* result = nullptr;
+  // terms whose epilogue updates the Psi accumulator: every third one counted from the last
+  // (the epilogue of term m holds v_{m-2}, v_{m-1}, v_m of the row), every one when the knob
+  // is off.  The first update must still see Psi = v_0, which term 2 overwrites.
+  std::vector<char> upd((size_t)nterms + 1, qp::g_acc_defer ? 0 : 1);
+  if (qp::g_acc_defer) {
+    int m0 = nterms;
+    for (; m0 >= 1; m0 -= 3) upd[m0] = 1;
+    if (m0 + 3 == 3) upd[1] = 1;
+  }
+  int last_upd = 0;
   for (int m = 1; m <= nterms; ++m) {
     const bool last = (m == nterms);
     qp::ChebyEpi e;
@@ -1260,7 +1274,6 @@ static int cheby_step_launches(qp_cheby* w, qp_operator* op, qp_state* psi, cons
       e.vout = last ? nullptr : B;
       e.acc_in = nullptr;
       e.acc_out = ACC;
-      e.a_prev = a[0];
       result = ACC;
     } else {
       // v2 = c (H v1 - beta v1) + v0; Psi += a_i v2; rotate            :186-207
@@ -1269,10 +1282,20 @@ static int cheby_step_launches(qp_cheby* w, qp_operator* op, qp_state* psi, cons
       x = xb;
       e.v0 = ob;
       e.vout = last ? nullptr : ob;
-      e.acc_in = ACC;
+      e.acc_in = last_upd > 0 ? ACC : nullptr;
       e.acc_out = (last && xb == B) ? P : ACC;  // P may be written only while it is not gathered
-      e.a_prev = 0.0;
       result = e.acc_out;
+    }
+    e.a_prev = last_upd == 0 ? a[0] : 0.0;
+    if (upd[m]) {
+      e.n_defer = m - last_upd - 1;
+      e.a_d1 = m >= 2 ? a[m - 1] : 0.0;
+      e.a_d2 = m >= 3 ? a[m - 2] : 0.0;
+      last_upd = m;
+    } else {
+      e.acc_skip = 1;
+      e.acc_in = nullptr;
+      e.acc_out = nullptr;
     }
     e.xloc = x;
     e.c = d2(c);

@@ -135,11 +135,21 @@ struct ChebyOp {
       const int sp = e.mirror[slot];
       if (sp >= 0) e.slab[sp] = t;
     }
+    if (e.acc_skip) return;  // folded into a later term's update
     double2 r;
     if (e.acc_in) {
       r = p.acc;
     } else {
-      r = make_double2(e.a_prev * xi.x, e.a_prev * xi.y);  // lmul!(a[1], Psi)  :172
+      const double2 ps = (e.n_defer == 1) ? p.v0 : xi;     // Psi itself: v_0
+      r = make_double2(e.a_prev * ps.x, e.a_prev * ps.y);  // lmul!(a[1], Psi)  :172
+    }
+    if (e.n_defer == 2) {
+      r.x = fma(e.a_d2, p.v0.x, r.x);
+      r.y = fma(e.a_d2, p.v0.y, r.y);
+    }
+    if (e.n_defer >= 1) {
+      r.x = fma(e.a_d1, xi.x, r.x);
+      r.y = fma(e.a_d1, xi.y, r.y);
     }
     r.x = fma(e.a, t.x, r.x);  // axpy!(a[i], v, Psi)  :182, :205
     r.y = fma(e.a, t.y, r.y);
@@ -916,6 +926,7 @@ int launch_arnoldi_small(hipStream_t s, const SmallArnoldiArgs& a, Stats* st) {
 }
 
 int g_small_nnz = kSmallThreads * kSmallEpt;
+int g_acc_defer = 1;
 int g_cheby_graph = 0;     // measured (profiles/r01/propagate_loop.txt): no gain over plain launches on ROCm 7.0, so off
 
 // lanes per row, entries per lane and rows per lane group such that the whole matrix is

@@ -714,3 +714,32 @@ def test_newton_persistent_small_liouvillian(ctx):
         assert np.linalg.norm(out - ref) < TOL
         outs[small] = out
     assert np.linalg.norm(outs[0] - outs[1]) < 1e-12
+
+
+@pytest.mark.parametrize("fmt", [L.FMT_CSR, L.FMT_RBCSR, L.FMT_HRB])
+@pytest.mark.parametrize("dt", [0.05, 0.3, 0.9, 2.0])
+def test_cheby_deferred_accumulation_bit_identical(ctx, fmt, dt):
+    """Psi += a_i v_i folded into every third term's epilogue (knob acc_defer, default on) runs
+    the same FMA sequence as the term-by-term update of src/cheby.jl:182/:205: results are
+    bit-identical for every residue of the number of terms mod 3."""
+    N = 3000
+    rp, col, val = synth.hermitian_offsets_csr(N, (1, 2, 7, 64), rho=6.0)
+    H = synth.to_scipy(rp, col, val, N)
+    Op = L.Operator(ctx, [L.Matrix.from_scipy(ctx, H)], fmt=fmt)
+    psi0 = synth.random_state(N)
+    seen = set()
+    for shrink in (1.0, 0.8, 0.6):
+        wrk = L.ChebyWrk(ctx, N, 14.0 * shrink, -7.0 * shrink, dt)
+        seen.add((wrk.n_coeffs - 1) % 3)
+        outs = []
+        for knob in (1, 0):
+            L.tuning_set("acc_defer", knob)
+            try:
+                psi = L.State(ctx, data=psi0)
+                for _ in range(3):
+                    L.cheby(psi, Op, dt, wrk)
+                outs.append(psi.numpy())
+            finally:
+                L.tuning_set("acc_defer", 1)
+        assert np.array_equal(outs[0], outs[1])
+    assert len(seen) >= 2

@@ -192,10 +192,23 @@ int qp_cheby_step_batched(qp_cheby* w, qp_operator* op, qp_state* psi, int batch
 /* One fused term, for row-partitioned multi-GPU drivers that exchange x between terms:
  *   s = (H x)[i];  t = c (s - beta x[xoff+i]) (+ v0[i] if v0);  if vout: vout[i] = t;
  *   r = (acc_in ? acc_in[i] : a_prev x[xoff+i]) + a t;  acc_out[i] = phase r.
- * x has op.ncols entries, the other vectors op.nrows; vout may alias v0. */
+ * x has op.ncols entries, the other vectors op.nrows; vout may alias v0.
+ * `defer` (nullable) moves accumulator traffic out of two of every three terms: the row
+ * epilogue of term m sees v_{m-2} = v0[i] and v_{m-1} = x[xoff+i], so the axpys of src/cheby.jl
+ * :182/:205 for those two terms can be applied here, in the same order and with the same FMAs:
+ *   skip != 0 : the term does not touch acc_in / acc_out (both may be NULL);
+ *   otherwise : r = (acc_in ? acc_in[i] : a_prev * (n_defer == 1 ? v0[i] : x[xoff+i]));
+ *               if n_defer == 2: r += a_d2 v0[i];  if n_defer >= 1: r += a_d1 x[xoff+i];
+ *               r += a t;  acc_out[i] = phase r.
+ * qp_acc_schedule_host fills one entry per term for a cheby! of n_coeffs coefficients. */
+typedef struct {
+  int skip, n_defer;
+  double a_d1, a_d2;
+} qp_acc_defer;
+int qp_acc_schedule_host(const double* a, int n_coeffs, qp_acc_defer* out /* n_coeffs-1 */);
 int qp_cheby_term(qp_operator* op, const qp_state* x, int64_t xoff, const qp_state* v0,
                   qp_state* vout, const qp_state* acc_in, qp_state* acc_out, qp_c128 c,
-                  double beta, double a_prev, double a, qp_c128 phase);
+                  double beta, double a_prev, double a, qp_c128 phase, const qp_acc_defer* defer);
 
 /* Overlap of the multi-GPU exchange with compute (no reference counterpart: the reference
  * is single-process).  qp_split_create partitions the operator's 64-row blocks into
@@ -217,7 +230,7 @@ int qp_split_check(qp_split* sp);
 int qp_cheby_term_split(qp_operator* op, qp_split* sp, void* boundary_stream, int first,
                         const qp_state* x, int64_t xoff, const qp_state* v0, qp_state* vout,
                         const qp_state* acc_in, qp_state* acc_out, qp_state* slab, qp_c128 c,
-                        double beta, double a_prev, double a, qp_c128 phase);
+                        double beta, double a_prev, double a, qp_c128 phase, const qp_acc_defer* defer);
 
 /* ---- Arnoldi (src/arnoldi.jl) ------------------------------------------------------ */
 int qp_krylov_create(qp_ctx* ctx, int64_t n, int nvec, qp_krylov** out);

@@ -1212,14 +1212,57 @@ int qp_cheby_destroy(qp_cheby* w) {
   QP_CATCH
 }
 
+// terms whose epilogue updates the Psi accumulator: every third one counted from the last
+// (the epilogue of term m holds v_{m-2}, v_{m-1}, v_m of the row).  The first update must
+// still see Psi = v_0, which term 2 overwrites in place, so it is forced to term <= 2.
+static void acc_schedule(const double* a, int n_coeffs, bool defer, qp_acc_defer* out) {
+  const int nterms = n_coeffs - 1;
+  std::vector<char> upd((size_t)nterms + 1, defer ? 0 : 1);
+  if (defer) {
+    int m0 = nterms;
+    for (; m0 >= 1; m0 -= 3) upd[m0] = 1;
+    if (m0 + 3 == 3) upd[1] = 1;
+  }
+  int last_upd = 0;
+  for (int m = 1; m <= nterms; ++m) {
+    qp_acc_defer& d = out[m - 1];
+    d = qp_acc_defer{0, 0, 0.0, 0.0};
+    if (upd[m]) {
+      d.n_defer = m - last_upd - 1;
+      d.a_d1 = (d.n_defer >= 1) ? a[m - 1] : 0.0;
+      d.a_d2 = (d.n_defer == 2) ? a[m - 2] : 0.0;
+      last_upd = m;
+    } else {
+      d.skip = 1;
+    }
+  }
+}
+
+static void set_defer(qp::ChebyEpi& e, const qp_acc_defer* d) {
+  if (!d) return;
+  e.acc_skip = d->skip ? 1 : 0;
+  e.n_defer = d->skip ? 0 : d->n_defer;
+  e.a_d1 = d->a_d1;
+  e.a_d2 = d->a_d2;
+}
+
+int qp_acc_schedule_host(const double* a, int n_coeffs, qp_acc_defer* out) {
+  if (!a || !out || n_coeffs < 2) return qp::fail(QP_E_BAD_ARG, "qp_acc_schedule_host: bad arguments");
+  acc_schedule(a, n_coeffs, true, out);
+  return QP_OK;
+}
+
 int qp_cheby_term(qp_operator* op, const qp_state* x, int64_t xoff, const qp_state* v0, qp_state* vout,
                   const qp_state* acc_in, qp_state* acc_out, qp_c128 c, double beta, double a_prev, double a,
-                  qp_c128 phase) {
+                  qp_c128 phase, const qp_acc_defer* defer) {
   QP_TRY
-  if (!op || !x || !acc_out) return qp::fail(QP_E_BAD_ARG, "qp_cheby_term: NULL argument");
+  const bool skip = defer && defer->skip;
+  if (!op || !x || (!acc_out && !skip)) return qp::fail(QP_E_BAD_ARG, "qp_cheby_term: NULL argument");
+  if (defer && !skip && (defer->n_defer < 0 || defer->n_defer > 2 || (defer->n_defer > 0 && !v0 && (defer->n_defer == 2 || !acc_in))))
+    return qp::fail(QP_E_BAD_ARG, "qp_cheby_term: deferred accumulation needs v0");
   const int64_t nr = op->A.nrows;
   if (x->n != op->A.ncols || xoff < 0 || xoff + nr > x->n) return qp::fail(QP_E_BAD_ARG, "qp_cheby_term: x shape / offset mismatch");
-  if ((v0 && v0->n != nr) || (vout && vout->n != nr) || (acc_in && acc_in->n != nr) || acc_out->n != nr)
+  if ((v0 && v0->n != nr) || (vout && vout->n != nr) || (acc_in && acc_in->n != nr) || (acc_out && acc_out->n != nr))
     return qp::fail(QP_E_BAD_ARG, "qp_cheby_term: local vector length mismatch");
   auto overlaps = [&](const qp_state* s) { return s && s->d < x->d + x->n && x->d < s->d + s->n; };
   if (overlaps(vout) || overlaps(acc_out)) return qp::fail(QP_E_BAD_ARG, "qp_cheby_term: outputs must not overlap the gathered x");
@@ -1228,8 +1271,8 @@ int qp_cheby_term(qp_operator* op, const qp_state* x, int64_t xoff, const qp_sta
   e.xloc = x->d + xoff;
   e.v0 = v0 ? v0->d : nullptr;
   e.vout = vout ? vout->d : nullptr;
-  e.acc_in = acc_in ? acc_in->d : nullptr;
-  e.acc_out = acc_out->d;
+  e.acc_in = (acc_in && !skip) ? acc_in->d : nullptr;
+  e.acc_out = (acc_out && !skip) ? acc_out->d : nullptr;
   e.c = d2(c);
   e.beta = beta;
   e.a_prev = a_prev;
@@ -1237,6 +1280,7 @@ int qp_cheby_term(qp_operator* op, const qp_state* x, int64_t xoff, const qp_sta
   e.phase = d2(phase);
   e.apply_phase = !(phase.re == 1.0 && phase.im == 0.0);
   e.check_partials = nullptr;
+  set_defer(e, defer);
   return qp::launch_spmv_cheby(op->ctx->stream, op->A, x->d, e, &op->ctx->stats);
   QP_CATCH
 }
@@ -1253,16 +1297,9 @@ static int cheby_step_launches(qp_cheby* w, qp_operator* op, qp_state* psi, cons
   double2* B = w->bufA;
   double2* ACC = w->acc;
   double2* result = nullptr;
-  // terms whose epilogue updates the Psi accumulator: every third one counted from the last
-  // (the epilogue of term m holds v_{m-2}, v_{m-1}, v_m of the row), every one when the knob
-  // is off.  The first update must still see Psi = v_0, which term 2 overwrites.
-  std::vector<char> upd((size_t)nterms + 1, qp::g_acc_defer ? 0 : 1);
-  if (qp::g_acc_defer) {
-    int m0 = nterms;
-    for (; m0 >= 1; m0 -= 3) upd[m0] = 1;
-    if (m0 + 3 == 3) upd[1] = 1;
-  }
-  int last_upd = 0;
+  std::vector<qp_acc_defer> sched((size_t)nterms);
+  acc_schedule(a, n_coeffs, qp::g_acc_defer != 0, sched.data());
+  bool updated = false;   // has any term written the accumulator yet?
   for (int m = 1; m <= nterms; ++m) {
     const bool last = (m == nterms);
     qp::ChebyEpi e;
@@ -1282,20 +1319,17 @@ static int cheby_step_launches(qp_cheby* w, qp_operator* op, qp_state* psi, cons
       x = xb;
       e.v0 = ob;
       e.vout = last ? nullptr : ob;
-      e.acc_in = last_upd > 0 ? ACC : nullptr;
+      e.acc_in = updated ? ACC : nullptr;
       e.acc_out = (last && xb == B) ? P : ACC;  // P may be written only while it is not gathered
       result = e.acc_out;
     }
-    e.a_prev = last_upd == 0 ? a[0] : 0.0;
-    if (upd[m]) {
-      e.n_defer = m - last_upd - 1;
-      e.a_d1 = m >= 2 ? a[m - 1] : 0.0;
-      e.a_d2 = m >= 3 ? a[m - 2] : 0.0;
-      last_upd = m;
-    } else {
-      e.acc_skip = 1;
+    e.a_prev = updated ? 0.0 : a[0];
+    set_defer(e, &sched[m - 1]);
+    if (sched[m - 1].skip) {
       e.acc_in = nullptr;
       e.acc_out = nullptr;
+    } else {
+      updated = true;
     }
     e.xloc = x;
     e.c = d2(c);
@@ -1651,13 +1685,17 @@ int qp_split_check(qp_split* sp) {
 
 int qp_cheby_term_split(qp_operator* op, qp_split* sp, void* boundary_stream, int first, const qp_state* x,
                         int64_t xoff, const qp_state* v0, qp_state* vout, const qp_state* acc_in, qp_state* acc_out,
-                        qp_state* slab, qp_c128 c, double beta, double a_prev, double a, qp_c128 phase) {
+                        qp_state* slab, qp_c128 c, double beta, double a_prev, double a, qp_c128 phase,
+                        const qp_acc_defer* defer) {
   QP_TRY
-  if (!op || !sp || sp->op != op || !boundary_stream || !x || !acc_out)
+  const bool skip = defer && defer->skip;
+  if (!op || !sp || sp->op != op || !boundary_stream || !x || (!acc_out && !skip))
     return qp::fail(QP_E_BAD_ARG, "qp_cheby_term_split: bad arguments");
+  if (defer && !skip && (defer->n_defer < 0 || defer->n_defer > 2 || (defer->n_defer > 0 && !v0 && (defer->n_defer == 2 || !acc_in))))
+    return qp::fail(QP_E_BAD_ARG, "qp_cheby_term_split: deferred accumulation needs v0");
   const int64_t nr = op->A.nrows;
   if (x->n != op->A.ncols || xoff < 0 || xoff + nr > x->n) return qp::fail(QP_E_BAD_ARG, "qp_cheby_term_split: x shape / offset mismatch");
-  if ((v0 && v0->n != nr) || (vout && vout->n != nr) || (acc_in && acc_in->n != nr) || acc_out->n != nr)
+  if ((v0 && v0->n != nr) || (vout && vout->n != nr) || (acc_in && acc_in->n != nr) || (acc_out && acc_out->n != nr))
     return qp::fail(QP_E_BAD_ARG, "qp_cheby_term_split: local vector length mismatch");
   if (slab && slab->n < sp->nsend) return qp::fail(QP_E_BAD_ARG, "qp_cheby_term_split: slab too small");
   qp_ctx* ctx = op->ctx;
@@ -1667,8 +1705,8 @@ int qp_cheby_term_split(qp_operator* op, qp_split* sp, void* boundary_stream, in
   e.xloc = x->d + xoff;
   e.v0 = v0 ? v0->d : nullptr;
   e.vout = vout ? vout->d : nullptr;
-  e.acc_in = acc_in ? acc_in->d : nullptr;
-  e.acc_out = acc_out->d;
+  e.acc_in = (acc_in && !skip) ? acc_in->d : nullptr;
+  e.acc_out = (acc_out && !skip) ? acc_out->d : nullptr;
   e.c = d2(c);
   e.beta = beta;
   e.a_prev = a_prev;
@@ -1676,6 +1714,7 @@ int qp_cheby_term_split(qp_operator* op, qp_split* sp, void* boundary_stream, in
   e.phase = d2(phase);
   e.apply_phase = !(phase.re == 1.0 && phase.im == 0.0);
   e.check_partials = nullptr;
+  set_defer(e, defer);
   qp::RowSet rb{sp->bmap_boundary, sp->n_boundary, false};
   qp::RowSet ri{sp->bmap_interior, sp->n_interior, true};
   const bool flag_mode = (qp::g_split_mode == 1);

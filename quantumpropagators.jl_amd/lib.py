@@ -67,6 +67,10 @@ class qp_newton_stats(C.Structure):
 FUNC_CB = C.CFUNCTYPE(None, C.POINTER(qp_c128), C.POINTER(qp_c128), C.c_void_p)
 
 
+class qp_acc_defer(C.Structure):
+    _fields_ = [("skip", C.c_int), ("n_defer", C.c_int), ("a_d1", C.c_double), ("a_d2", C.c_double)]
+
+
 class qp_prop_spec(C.Structure):
     _fields_ = [("method", C.c_int), ("cheby", C.c_void_p), ("a", C.POINTER(C.c_double)), ("n_coeffs", C.c_int),
                 ("Delta", C.c_double), ("E_min", C.c_double), ("wrk_dt", C.c_double), ("limit", C.c_double),
@@ -129,13 +133,14 @@ SIGNATURES = {
     "qp_cheby_step_batched": (C.c_int, [_P, _P, _P, C.c_int, _dp, C.c_int, C.c_double, C.c_double, C.c_double,
                                         C.c_double]),
     "qp_cheby_term": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, _P, qp_c128, C.c_double, C.c_double,
-                                C.c_double, qp_c128]),
+                                C.c_double, qp_c128, C.POINTER(qp_acc_defer)]),
+    "qp_acc_schedule_host": (C.c_int, [_dp, C.c_int, C.POINTER(qp_acc_defer)]),
     "qp_split_create": (C.c_int, [_P, _i64p, C.c_int64, C.POINTER(_P)]),
     "qp_split_destroy": (C.c_int, [_P]),
     "qp_split_info": (C.c_int, [_P, _i64p, _i64p]),
     "qp_split_check": (C.c_int, [_P]),
     "qp_cheby_term_split": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_int64, _P, _P, _P, _P, _P, qp_c128, C.c_double,
-                                      C.c_double, C.c_double, qp_c128]),
+                                      C.c_double, C.c_double, qp_c128, C.POINTER(qp_acc_defer)]),
     "qp_krylov_create": (C.c_int, [_P, C.c_int64, C.c_int, C.POINTER(_P)]),
     "qp_krylov_destroy": (C.c_int, [_P]),
     "qp_krylov_download": (C.c_int, [_P, C.c_int, _cp]),
@@ -599,12 +604,23 @@ def cheby_batched(psi_panel, H, dt, wrk, batch, E_min=None):
     return psi_panel
 
 
-def cheby_term(H, x, xoff, v0, vout, acc_in, acc_out, c, beta, a_prev, a, phase=1.0):
+def acc_schedule(coeffs):
+    """Per term of a ``cheby!`` with these coefficients: a ``qp_acc_defer`` telling the fused
+    term kernel whether it touches the Psi accumulator (every third term does, folding the
+    two before it; include/qprop.h, qp_acc_defer).  Host only."""
+    a = np.ascontiguousarray(coeffs, dtype=np.float64)
+    out = (qp_acc_defer * (len(a) - 1))()
+    check(load().qp_acc_schedule_host(_ptr(a, _dp), len(a), out))
+    return out
+
+
+def cheby_term(H, x, xoff, v0, vout, acc_in, acc_out, c, beta, a_prev, a, phase=1.0, defer=None):
     lib = H.lib
     check(lib.qp_cheby_term(H._h, x._h, int(xoff), v0._h if v0 is not None else None,
                             vout._h if vout is not None else None,
-                            acc_in._h if acc_in is not None else None, acc_out._h, c128(c), float(beta),
-                            float(a_prev), float(a), c128(phase)))
+                            acc_in._h if acc_in is not None else None,
+                            acc_out._h if acc_out is not None else None, c128(c), float(beta),
+                            float(a_prev), float(a), c128(phase), C.byref(defer) if defer is not None else None))
 
 
 class Split:
@@ -636,12 +652,14 @@ class Split:
 
 
 def cheby_term_split(H, split, boundary_stream, first, x, xoff, v0, vout, acc_in, acc_out, slab, c, beta, a_prev, a,
-                     phase=1.0):
+                     phase=1.0, defer=None):
     # hot in the multi-GPU loop (one call per term): keep the Python side minimal
     st = H.lib.qp_cheby_term_split(H._h, split._h, boundary_stream, 1 if first else 0, x._h, xoff,
                                    v0._h if v0 is not None else None, vout._h if vout is not None else None,
-                                   acc_in._h if acc_in is not None else None, acc_out._h,
-                                   slab._h if slab is not None else None, c128(c), beta, a_prev, a, c128(phase))
+                                   acc_in._h if acc_in is not None else None,
+                                   acc_out._h if acc_out is not None else None,
+                                   slab._h if slab is not None else None, c128(c), beta, a_prev, a, c128(phase),
+                                   C.byref(defer) if defer is not None else None)
     if st:
         check(st)
 

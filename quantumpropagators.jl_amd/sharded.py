@@ -92,8 +92,8 @@ class HipBackend:
     def view(self, t, lo, hi):
         return L.State(self.ctx, n=hi - lo, device_ptr=t.data_ptr() + 16 * lo, keepalive=t)
 
-    def term(self, op, x, xoff, v0, vout, acc_in, acc_out, c, beta, a_prev, a, phase):
-        L.cheby_term(op, x, xoff, v0, vout, acc_in, acc_out, c, beta, a_prev, a, phase)
+    def term(self, op, x, xoff, v0, vout, acc_in, acc_out, c, beta, a_prev, a, phase, defer=None):
+        L.cheby_term(op, x, xoff, v0, vout, acc_in, acc_out, c, beta, a_prev, a, phase, defer)
 
     # ---- overlap of the exchange with compute (boundary rows on a side stream) ----
     def make_split(self, op, send_rows):
@@ -120,9 +120,10 @@ class HipBackend:
     def set_stream(self, s):
         self.torch.cuda.set_stream(s)
 
-    def term_split(self, op, split, side, first, x, xoff, v0, vout, acc_in, acc_out, slab, c, beta, a_prev, a, phase):
+    def term_split(self, op, split, side, first, x, xoff, v0, vout, acc_in, acc_out, slab, c, beta, a_prev, a, phase,
+                   defer=None):
         L.cheby_term_split(op, split, side.cuda_stream, first, x, xoff, v0, vout, acc_in, acc_out, slab, c, beta,
-                           a_prev, a, phase)
+                           a_prev, a, phase, defer)
 
     def write(self, t, lo, arr):
         arr = np.ascontiguousarray(arr, dtype=np.complex128)
@@ -163,6 +164,8 @@ class ShardedCheby:
         self.coeffs = L.cheby_coeffs(Delta, dt, limit)
         if len(self.coeffs) < 2:
             raise L.QPAssertionError(4, "Need at least 2 Chebychev coefficients")
+        # which terms touch the Psi accumulator (every third one, folding the two before it)
+        self.sched = L.acc_schedule(self.coeffs)
         if exchange not in ("auto", "halo", "allgather"):
             raise ValueError(f"unknown exchange mode {exchange!r}")
 
@@ -281,18 +284,25 @@ class ShardedCheby:
         be, op = self.be, self.op
         self._exchange(0)
         result_in_acc = True
+        updated = False                 # has a term written the accumulator yet?
         for m in range(1, nterms + 1):
             last = m == nterms
             xi, oi = (0, 1) if m % 2 == 1 else (1, 0)
             x, oloc = self.Xfull[xi], self.Xloc[oi]
             ph = phase if last else 1.0
+            d = self.sched[m - 1]
+            acc_in = self.acc if (updated and not d.skip) else None
+            a_prev = 0.0 if updated else a[0]
             if m == 1:
-                be.term(op, x, 0, None, None if last else oloc, None, self.acc, c, beta, a[0], a[1], ph)
+                be.term(op, x, 0, None, None if last else oloc, None, None if d.skip else self.acc, c, beta, a_prev,
+                        a[1], ph, d)
             else:
                 # the state buffer X[0] may be written only while it is not being gathered
                 out = self.Xloc[0] if (last and xi == 1) else self.acc
-                be.term(op, x, 0, oloc, None if last else oloc, self.acc, out, c, beta, 0.0, a[m], ph)
+                be.term(op, x, 0, oloc, None if last else oloc, acc_in, None if d.skip else out, c, beta, a_prev,
+                        a[m], ph, d)
                 result_in_acc = out is self.acc
+            updated = updated or not d.skip
             if not last:
                 self._exchange(oi)
             if m == 1:
@@ -321,20 +331,25 @@ class ShardedCheby:
         try:
             self._exchange(0)
             result_in_acc = True
+            updated = False
             for m in range(1, nterms + 1):
                 last = m == nterms
                 xi, oi = (0, 1) if m % 2 == 1 else (1, 0)
                 x, oloc = self.Xfull[xi], self.Xloc[oi]
                 ph = phase if last else 1.0
                 slab = None if last else self.slab_state
+                d = self.sched[m - 1]
+                acc_in = self.acc if (updated and not d.skip) else None
+                a_prev = 0.0 if updated else a[0]
                 if m == 1:
-                    be.term_split(op, self.split, side, True, x, 0, None, None if last else oloc, None, self.acc,
-                                  slab, c, beta, a[0], a[1], ph)
+                    be.term_split(op, self.split, side, True, x, 0, None, None if last else oloc, None,
+                                  None if d.skip else self.acc, slab, c, beta, a_prev, a[1], ph, d)
                 else:
                     out = self.Xloc[0] if (last and xi == 1) else self.acc
-                    be.term_split(op, self.split, side, False, x, 0, oloc, None if last else oloc, self.acc, out,
-                                  slab, c, beta, 0.0, a[m], ph)
+                    be.term_split(op, self.split, side, False, x, 0, oloc, None if last else oloc, acc_in,
+                                  None if d.skip else out, slab, c, beta, a_prev, a[m], ph, d)
                     result_in_acc = out is self.acc
+                updated = updated or not d.skip
                 if not last:
                     self._exchange(oi, packed=True)
                 if m == 1:

@@ -91,17 +91,32 @@ class NumpyBackend:
     def mul(self, op, x, y):
         y[:] = op.A @ x
 
-    def term(self, op, x, xoff, v0, vout, acc_in, acc_out, c, beta, a_prev, a, phase):
+    @staticmethod
+    def _accumulate(defer, acc_in, a_prev, xi, v0_old, a, t, phase):
+        """Epilogue of include/qprop.h qp_cheby_term incl. qp_acc_defer; None when skipped."""
+        if defer is not None and defer.skip:
+            return None
+        nd = 0 if defer is None else defer.n_defer
+        r = acc_in if acc_in is not None else a_prev * (v0_old if nd == 1 else xi)
+        if nd == 2:
+            r = r + defer.a_d2 * v0_old
+        if nd >= 1:
+            r = r + defer.a_d1 * xi
+        return phase * (r + a * t)
+
+    def term(self, op, x, xoff, v0, vout, acc_in, acc_out, c, beta, a_prev, a, phase, defer=None):
         nloc = op.A.shape[0]
         s = op.A @ x
         xi = x[xoff: xoff + nloc]
         t = c * (s - beta * xi)
+        v0_old = None if v0 is None else v0.copy()
         if v0 is not None:
             t = t + v0
         if vout is not None:
             vout[:] = t
-        r = (acc_in if acc_in is not None else a_prev * xi) + a * t
-        acc_out[:] = phase * r
+        r = self._accumulate(defer, acc_in, a_prev, xi, v0_old, a, t, phase)
+        if r is not None:
+            acc_out[:] = r
 
     # ---- boundary / interior split (CPU emulation of qp_split / qp_cheby_term_split) ----
     def make_split(self, op, send_rows):
@@ -136,7 +151,8 @@ class NumpyBackend:
     def set_stream(self, s):
         pass
 
-    def term_split(self, op, split, side, first, x, xoff, v0, vout, acc_in, acc_out, slab, c, beta, a_prev, a, phase):
+    def term_split(self, op, split, side, first, x, xoff, v0, vout, acc_in, acc_out, slab, c, beta, a_prev, a, phase,
+                   defer=None):
         nloc = op.A.shape[0]
         v0c = None if v0 is None else v0.copy()          # in-place v0 -> v2: keep the old values for both halves
         xc = x.copy()
@@ -152,8 +168,10 @@ class NumpyBackend:
                 t = t + v0c[rows]
             if vout is not None:
                 vout[rows] = t
-            r = (acc_c[rows] if acc_c is not None else a_prev * xi) + a * t
-            acc_out[rows] = phase * r
+            r = self._accumulate(defer, None if acc_c is None else acc_c[rows], a_prev, xi,
+                                 None if v0c is None else v0c[rows], a, t, phase)
+            if r is not None:
+                acc_out[rows] = r
             if not poison and slab is not None and vout is not None:
                 pos = {int(r_): i for i, r_ in enumerate(split.send_rows)}
                 for r_, tv in zip(rows, t):

@@ -88,6 +88,7 @@ def main():
         wrk = L.ChebyWrk(ctx, N, Delta, E_min, dt)
         psi = L.State(ctx, data=psi0_local)
         fmt_used = op.format
+        layout = op.layout_info()
 
         def step():
             L.cheby(psi, op, dt, wrk)
@@ -120,6 +121,7 @@ def main():
                                   exchange=args.exchange, host_staged=one_gpu)
         sh.set_state(psi0_local)
         fmt_used = sh.op.format
+        layout = sh.op.layout_info()
         exchange_used = sh.exchange
 
         def step():
@@ -176,7 +178,7 @@ def main():
     # from the committed summary under profiles/ (null when there is none for this kernel)
     traffic = None
     kern = {1: "csr_spmv_kernel<16,ChebyOp>", 2: "rbcsr_spmv_kernel<ChebyOp,7>", 3: "hrb_spmv_kernel<ChebyOp,7>"}[fmt_used]
-    pmc_file = os.path.join(ROOT, "profiles", "r01", "bench_hrb16d_pmc_summary.json")
+    pmc_file = os.path.join(ROOT, "profiles", "r01", "bench_stencil_pmc_summary.json")
     if fmt_used == 3 and world == 1 and args.log2n == 20 and args.pattern == "banded" and os.path.exists(pmc_file):
         with open(pmc_file) as f:
             traffic = json.load(f)["hbm_traffic_bytes_per_launch"]
@@ -199,26 +201,31 @@ def main():
                                "complex fp64 values, int32 indices",
                    "rows_per_gpu": rows, "N_total": N, "nnz_per_row": 16, "pattern": args.pattern,
                    "offsets": [int(o) for o in offsets], "n_coeffs": int(len(coeffs)), "matvecs_per_step": nterms,
-                   "spectral_range": [-10.0, 10.0], "dt": dt, "device_format": {1: "csr", 2: "rbcsr", 3: "hrb (Hermitian-packed row blocks)"}[fmt_used],
+                   "spectral_range": [-10.0, 10.0], "dt": dt,
+                   "device_format": {1: "csr", 2: "rbcsr", 3: "hrb (Hermitian-packed row blocks)"}[fmt_used],
+                   "device_layout": layout,
                    "parallelism": "single GPU" if world == 1 else (
                        f"row-partitioned x{world}, exchange={exchange_used}"
                        + (" [TEST MODE: ranks share one GPU, host-staged gloo]" if one_gpu else "")),
                    "global_steps_per_s": steps_per_s},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "traffic_source": "profiles/r01/bench_hrb16d_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                     "traffic_source": "profiles/r01/bench_stencil_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                        "FETCH x2 gfx950 correction)" if traffic else None,
                      "kernel": kern,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "avg_launch_us": avg_launch_s * 1e6,
                      "launches_timed": n_launch, "hip_event_ms": ev_ms,
                      "traffic_rate_gbs": (traffic / avg_launch_s / 1e9) if traffic else None,
+                     "traffic_frac_of_peak": (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
                      "note": "avg launch duration = HIP-event time of the timed region on the kernels' stream / "
                              "number of fused-term launches (includes launch gaps; multi-GPU: includes exchange). "
-                             "`achieved` uses the contract's algorithmic CSR bytes (SURVEY 8d: (20 z + 84) N); the "
-                             "shipped Hermitian-packed format with int16 column deltas stores 272 B/row instead of "
-                             "404 B/row, so `achieved` can exceed what the same bytes would allow -- `traffic` is the "
-                             "HBM bytes the PMC counters saw per launch and `traffic_rate_gbs` the real HBM rate"},
+                             "`achieved` uses the contract's algorithmic CSR bytes (SURVEY 8d: (20 z + 84) N = 404 B/row); "
+                             "the shipped layout moves fewer: Hermitian packing (lower triangle read back from L2 as "
+                             "conjugates), stencil row blocks (block-wide column distances instead of per-entry "
+                             "indices) and the Psi accumulator touched every third term, about 190 B/row, so "
+                             "`achieved` exceeds what the same bytes would allow -- `traffic` is the HBM bytes the "
+                             "PMC counters saw per launch, `traffic_rate_gbs` / `traffic_frac_of_peak` the real HBM rate"},
         "cpu_baseline": cpu,
         "pcie_inclusive_steps_per_s": pcie,
         "stats": {"n_matvec": st["n_matvec"], "kernel_launches": st["n_kernel_launches"]},

@@ -145,6 +145,12 @@ int qp_operator_set_scale(qp_operator* op, qp_c128 scale); /* ScaledOperator :23
 int qp_operator_destroy(qp_operator* op);
 int qp_operator_info(const qp_operator* op, int64_t* nrows, int64_t* ncols, int64_t* nnz,
                      int* format);
+/* How the operator is laid out on the device (row-block formats; zeros for CSR):
+ * out[0] = 64-row blocks, out[1] / out[2] = blocks whose upper (or full) / lower column
+ * section is a stencil section (one column distance per slot for the whole block),
+ * out[3] = bytes of index data a mat-vec streams (column sections + transpose positions
+ * of the non-stencil lower sections), out[4] = stored values. */
+int qp_operator_layout_info(const qp_operator* op, int64_t out[5]);
 /* read the DEVICE copy (union pattern, currently combined values) back as canonical
  * CSR: the device-format round trip must be bit-exact. */
 int qp_operator_get_csr(qp_operator* op, int64_t* rowptr, int32_t* col, qp_c128* vals);

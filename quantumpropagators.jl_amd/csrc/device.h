@@ -28,8 +28,9 @@ struct DevMatrix {
   int64_t nblocks = 0;
   int64_t* bptr = nullptr;    // nblocks+1
   int32_t* cols = nullptr;    // CSR: plain int32.  Row-block formats: a byte stream; block b's
-                              // quad-packed column section starts at byte cmeta[b] >> 1 and holds
-                              // int32 columns, or (cmeta[b] & 1) int16 deltas to the lane's row
+                              // column section starts at byte cmeta[b] >> 2; cmeta[b] & 3 = 0: quad-packed
+                              // int32 columns, 1: quad-packed int16 deltas to the lane's row, 2: stencil
+                              // block, one int32 delta per slot for all 64 rows
   int64_t* cmeta = nullptr;   // nblocks (row-block formats)
   int64_t colbytes = 0;
   double2* vals = nullptr;    // stored, the values the SpMV kernels read
@@ -112,6 +113,7 @@ int launch_spmv_plain(hipStream_t s, const DevMatrix& A, const double2* x, const
 int spmv_grid_size(const DevMatrix& A);
 extern int g_rbcsr_variant;
 extern int g_hrb_lower_last;  // HRB kernel: process the lower (conj-transposed) section after the upper one
+extern int g_stencil;     // operator build: encode blocks with block-wide column distances as stencil blocks (1, default)
 extern int g_acc_defer;   // qp_cheby_step: touch the Psi accumulator every third term only (1, default) or every term (0)
 extern int g_cheby_graph; // qp_cheby_step: replay a repeated step as a hipGraph when the mat-vec grid has at most this many workgroups (0: off)
 extern int g_small_nnz;   // qp_propagate: register-resident Cheby systems up to this nnz run as ONE persistent launch (0: off)

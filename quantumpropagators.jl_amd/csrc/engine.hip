@@ -116,6 +116,7 @@ struct qp_krylov {
   double2* part = nullptr;      // 2 x kRedBlocks ping-pong partials
   double2* md_part = nullptr;   // kRedBlocks x 2 nvec multidot partials (low-sync MGS)
   double2* gram = nullptr;      // nvec x nvec Gram rows <q_i|q_k>, k < i
+  int gram_rows = 0;            // rows 0 .. gram_rows-1 of `gram` describe the current basis
   double2* hcoef = nullptr;     // 2 nvec reduced inner products of the current column
   double2* q(int i) const { return Q + (size_t)i * n; }
 };
@@ -244,6 +245,10 @@ int qp_tuning_set(const char* key, int value) {
   }
   if (std::strcmp(key, "hrb_lower_last") == 0) {
     qp::g_hrb_lower_last = value;
+    return QP_OK;
+  }
+  if (std::strcmp(key, "stencil") == 0) {
+    qp::g_stencil = value;
     return QP_OK;
   }
   if (std::strcmp(key, "acc_defer") == 0) {
@@ -568,13 +573,31 @@ static bool csr_is_hermitian(int64_t n, const std::vector<int64_t>& rp, const st
 // traffic per entry instead of 4).  `get(r, k, &is_pad)` returns the column of entry k of
 // row r in this section (pad entries: any valid column).
 extern "C++" {
-template <class GetCol>
+// 32-byte record of one slot of a *stencil* lower section (see below)
+struct LowerStencilSlot {
+  int32_t delta, cb0;
+  int64_t pb0, pb1, pad;
+};
+static_assert(sizeof(LowerStencilSlot) == 32, "layout shared with kernels.hip");
+
+// mode of a block's column section (low two bits of its meta word, the rest is the byte offset)
+enum { kColInt32 = 0, kColInt16 = 1, kColStencil = 2 };
+
+// `special(b, w, out)`: a chance to emit a block in the stencil encoding (returns true and
+// appends its bytes) before the per-entry encodings are tried.
+template <class GetCol, class Special>
 static void encode_col_sections(int64_t nrows, int64_t nblocks, const std::vector<int64_t>& ptr, GetCol get,
-                                std::vector<char>& bytes, std::vector<int64_t>& meta) {
+                                Special special, std::vector<char>& bytes, std::vector<int64_t>& meta) {
   meta.assign((size_t)nblocks, 0);
   bytes.clear();
   for (int64_t b = 0; b < nblocks; ++b) {
     const int64_t w = (ptr[b + 1] - ptr[b]) / kRB;
+    while (bytes.size() % 32) bytes.push_back(0);
+    const size_t start = bytes.size();
+    if (w > 0 && special(b, w, bytes)) {
+      meta[b] = ((int64_t)start << 2) | kColStencil;
+      continue;
+    }
     bool ok16 = true;
     for (int64_t l = 0; l < kRB && ok16; ++l) {
       const int64_t r = b * kRB + l;
@@ -585,8 +608,7 @@ static void encode_col_sections(int64_t nrows, int64_t nblocks, const std::vecto
         if (!pad && (c - r > 32767 || r - c > 32767)) { ok16 = false; break; }
       }
     }
-    while (bytes.size() % 16) bytes.push_back(0);
-    meta[b] = ((int64_t)bytes.size() << 1) | (ok16 ? 1 : 0);
+    meta[b] = ((int64_t)bytes.size() << 2) | (ok16 ? kColInt16 : kColInt32);
     const size_t esz = ok16 ? 2 : 4;
     const size_t off = bytes.size();
     bytes.resize(off + (size_t)w * kRB * esz, 0);
@@ -608,16 +630,60 @@ static void encode_col_sections(int64_t nrows, int64_t nblocks, const std::vecto
       }
     }
   }
-  while (bytes.size() % 16) bytes.push_back(0);
+  while (bytes.size() % 32) bytes.push_back(0);
+}
+
+// Stencil blocks: every row of the 64-row block has its k-th entry at the same distance
+// delta_k from the diagonal (grids, lattices, tensor-product operators: most blocks of a
+// banded H).  The section then stores w int32 deltas for the whole block instead of w x 64
+// per-lane indices: the index stream disappears from HBM traffic (wave-uniform loads).
+// Pad entries (value 0) take the block's delta too, so row + delta must stay a valid column.
+template <class GetCol>
+static bool try_stencil_upper(int64_t nrows, int64_t ncols, int64_t b, int64_t w, GetCol get, std::vector<char>& out) {
+  std::vector<int32_t> delta((size_t)w, 0);
+  for (int64_t k = 0; k < w; ++k) {
+    bool have = false;
+    int64_t d = 0;
+    for (int64_t l = 0; l < kRB; ++l) {
+      const int64_t r = b * kRB + l;
+      if (r >= nrows) break;
+      bool pad = false;
+      const int64_t c = get(r, k, &pad);
+      if (pad) continue;
+      if (!have) {
+        d = c - r;
+        have = true;
+      } else if (c - r != d) {
+        return false;
+      }
+    }
+    if (!have) d = 0;   // a slot of pure padding (width rounded up to a quad): column = row
+    if (d > INT32_MAX || d < INT32_MIN) return false;
+    // every lane (pad entries and the clamped rows of a partial last block included) must
+    // land on a valid column
+    const int64_t r_lo = b * kRB, r_hi = std::min(b * kRB + kRB - 1, nrows - 1);
+    if (r_lo + d < 0 || r_hi + d >= ncols) return false;
+    delta[(size_t)k] = (int32_t)d;
+  }
+  const size_t off = out.size();
+  out.resize(off + (size_t)w * 4);
+  std::memcpy(&out[off], delta.data(), (size_t)w * 4);
+  return true;
 }
 }  // extern "C++"
 
 static int64_t decode_col(const std::vector<char>& bytes, const std::vector<int64_t>& meta, int64_t nrows, int64_t r,
-                          int64_t k) {
+                          int64_t k, bool lower = false) {
   const int64_t m = meta[r / kRB];
-  const size_t off = (size_t)(m >> 1);
+  const size_t off = (size_t)(m >> 2);
+  const int mode = (int)(m & 3);
+  if (mode == kColStencil) {
+    int32_t d;
+    std::memcpy(&d, &bytes[off + (size_t)k * (lower ? sizeof(LowerStencilSlot) : 4)], 4);
+    return std::min(r, nrows - 1) + d;
+  }
   const size_t q = (size_t)(k >> 2) * (4 * kRB) + (size_t)(r % kRB) * 4 + (k & 3);
-  if (m & 1) {
+  if (mode == kColInt16) {
     int16_t d;
     std::memcpy(&d, &bytes[off + q * 2], 2);
     return std::min(r, nrows - 1) + d;
@@ -625,6 +691,17 @@ static int64_t decode_col(const std::vector<char>& bytes, const std::vector<int6
   int32_t c;
   std::memcpy(&c, &bytes[off + q * 4], 4);
   return c;
+}
+
+// position in the upper value array of the conj-transposed value of lower entry k of row r,
+// for a block whose lower section is in the stencil encoding
+static int64_t decode_lower_stencil_pos(const std::vector<char>& bytes, const std::vector<int64_t>& meta, int64_t nrows,
+                                        int64_t r, int64_t k) {
+  const int64_t m = meta[r / kRB];
+  LowerStencilSlot e;
+  std::memcpy(&e, &bytes[(size_t)(m >> 2) + (size_t)k * sizeof(LowerStencilSlot)], sizeof(e));
+  const int64_t c = std::min(r, nrows - 1) + e.delta;
+  return ((c >> 6) == e.cb0 ? e.pb0 : e.pb1) + (c & 63);
 }
 
 // Build every device array of `op` for `format` from the union pattern (op->u_rowptr /
@@ -685,13 +762,16 @@ static int operator_build_device(qp_operator* op, int format, const std::vector<
     // upper (or full) column indices
     {
       std::vector<char> cbytes;
-      encode_col_sections(nrows, A.nblocks, Lh.bptr,
-                          [&](int64_t r, int64_t k, bool* pad) -> int64_t {
-                            const int64_t nl = hrb ? Lh.nlow[r] : 0;
-                            const int64_t len = ur[r + 1] - ur[r] - nl;
-                            if (k < len) return uc[ur[r] + nl + k];
-                            *pad = true;
-                            return (ur[r + 1] > ur[r]) ? uc[ur[r]] : 0;
+      auto get_upper = [&](int64_t r, int64_t k, bool* pad) -> int64_t {
+        const int64_t nl = hrb ? Lh.nlow[r] : 0;
+        const int64_t len = ur[r + 1] - ur[r] - nl;
+        if (k < len) return uc[ur[r] + nl + k];
+        *pad = true;
+        return (ur[r + 1] > ur[r]) ? uc[ur[r]] : 0;
+      };
+      encode_col_sections(nrows, A.nblocks, Lh.bptr, get_upper,
+                          [&](int64_t b, int64_t w, std::vector<char>& out) {
+                            return qp::g_stencil != 0 && try_stencil_upper(nrows, A.ncols, b, w, get_upper, out);
                           },
                           cbytes, Lh.cmeta);
       A.colbytes = (int64_t)cbytes.size();
@@ -717,13 +797,54 @@ static int operator_build_device(qp_operator* op, int format, const std::vector<
         }
       }
       std::vector<char> lbytes;
+      // stencil lower block: every row has a real entry in every slot, at a block-wide
+      // distance delta_k, and the conj-transposed values sit at one slot per column block
+      // (at most two column blocks per slot): position = pb(column block) + column % 64
+      auto try_stencil_lower = [&](int64_t b, int64_t w, std::vector<char>& out) -> bool {
+        if (qp::g_stencil == 0) return false;
+        std::vector<LowerStencilSlot> slots((size_t)w);
+        for (int64_t k = 0; k < w; ++k) {
+          LowerStencilSlot e{0, 0, -1, -1, 0};
+          bool have = false;
+          for (int64_t l = 0; l < kRB; ++l) {
+            const int64_t r = b * kRB + l;
+            if (r >= nrows) break;
+            if (k >= Lh.nlow[r]) return false;
+            const int64_t c = uc[ur[r] + k];
+            const int64_t base = (int64_t)lpos[rb_quad_pos(Lh.lptr, r, k)] - (c & 63);
+            if (!have) {
+              e.delta = (int32_t)(c - r);
+              e.cb0 = (int32_t)(c >> 6);
+              e.pb0 = base;
+              have = true;
+            } else if (c - r != e.delta) {
+              return false;
+            }
+            if ((c >> 6) == e.cb0) {
+              if (base != e.pb0) return false;
+            } else if ((c >> 6) == e.cb0 + 1) {
+              if (e.pb1 < 0) e.pb1 = base;
+              else if (base != e.pb1) return false;
+            } else {
+              return false;
+            }
+          }
+          if (!have) return false;
+          if (e.pb1 < 0) e.pb1 = e.pb0;
+          slots[(size_t)k] = e;
+        }
+        const size_t off = out.size();
+        out.resize(off + (size_t)w * sizeof(LowerStencilSlot));
+        std::memcpy(&out[off], slots.data(), (size_t)w * sizeof(LowerStencilSlot));
+        return true;
+      };
       encode_col_sections(nrows, A.nblocks, Lh.lptr,
                           [&](int64_t r, int64_t k, bool* pad) -> int64_t {
                             if (k < Lh.nlow[r]) return uc[ur[r] + k];
                             *pad = true;          // padded: any valid column, value masked by pos < 0
                             return r;
                           },
-                          lbytes, Lh.lcmeta);
+                          try_stencil_lower, lbytes, Lh.lcmeta);
       A.lcolbytes = (int64_t)lbytes.size();
       QP_CHECK(dev_alloc(&A.lptr, Lh.lptr.size()));
       QP_HIP(hipMemcpy(A.lptr, Lh.lptr.data(), Lh.lptr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
@@ -974,6 +1095,26 @@ int qp_operator_info(const qp_operator* op, int64_t* nrows, int64_t* ncols, int6
   return QP_OK;
 }
 
+int qp_operator_layout_info(const qp_operator* op, int64_t out[5]) {
+  if (!op || !out) return qp::fail(QP_E_BAD_ARG, "qp_operator_layout_info: NULL argument");
+  for (int i = 0; i < 5; ++i) out[i] = 0;
+  const DevMatrix& A = op->A;
+  out[4] = A.stored;
+  if (A.format == QP_FMT_CSR) return QP_OK;
+  const HostLayout& Lh = op->layout;
+  out[0] = A.nblocks;
+  int64_t idx_bytes = A.colbytes + A.lcolbytes;
+  for (int64_t b = 0; b < A.nblocks; ++b) {
+    if ((Lh.cmeta[b] & 3) == kColStencil) out[1]++;
+    if (A.format == QP_FMT_HRB) {
+      if ((Lh.lcmeta[b] & 3) == kColStencil) out[2]++;
+      else idx_bytes += (Lh.lptr[b + 1] - Lh.lptr[b]) * (int64_t)sizeof(int32_t);
+    }
+  }
+  out[3] = idx_bytes;
+  return QP_OK;
+}
+
 // download the *device* copy (current combined values and indices) back as canonical CSR
 int qp_operator_get_csr(qp_operator* op, int64_t* rowptr, int32_t* col, qp_c128* vals) {
   QP_TRY
@@ -1020,8 +1161,9 @@ int qp_operator_get_csr(qp_operator* op, int64_t* rowptr, int32_t* col, qp_c128*
         c = decode_col(cbytes, cmeta, A.nrows, r, k - nl);
         v = hv[rb_val_pos(bptr, r, k - nl)];
       } else {
-        c = decode_col(lbytes, lcmeta, A.nrows, r, k);
-        v = std::conj(hv[lp[rb_quad_pos(lptr, r, k)]]);
+        c = decode_col(lbytes, lcmeta, A.nrows, r, k, true);
+        const bool stencil = (lcmeta[r / kRB] & 3) == kColStencil;
+        v = std::conj(hv[stencil ? decode_lower_stencil_pos(lbytes, lcmeta, A.nrows, r, k) : lp[rb_quad_pos(lptr, r, k)]]);
       }
       col[ur[r] + k] = (int32_t)c;
       vals[ur[r] + k] = qp_c128{v.real(), v.imag()};
@@ -1771,6 +1913,8 @@ int qp_krylov_create(qp_ctx* ctx, int64_t n, int nvec, qp_krylov** out) {
   QP_CHECK(dev_alloc(&q->part, (size_t)2 * kRedBlocks));
   QP_CHECK(dev_alloc(&q->md_part, (size_t)kRedBlocks * 2 * nvec));
   QP_CHECK(dev_alloc(&q->gram, (size_t)nvec * nvec));
+  // rows that were never computed read as NaN: a use of a stale Gram row is loud, not subtle
+  QP_HIP(hipMemsetAsync(q->gram, 0xFF, sizeof(double2) * (size_t)nvec * nvec, ctx->stream));
   QP_CHECK(dev_alloc(&q->hcoef, (size_t)2 * nvec));
   *out = q.release();
   return QP_OK;
@@ -1817,12 +1961,16 @@ int arnoldi_column(qp_operator* op, qp_krylov* q, int j, double dt, double2* hco
   pe.beta = make_double2(0.0, 0.0);
   pe.beta_zero = 1;
   QP_CHECK(qp::launch_spmv_plain(ctx->stream, op->A, q->q(j), pe, &ctx->stats));  // src/arnoldi.jl:82
-  if (qp::g_arnoldi_mode == 1) {
+  if (qp::g_arnoldi_mode == 1 && q->gram_rows >= j) {
     // low-synchronisation MGS: same coefficients (to rounding), 3 launches per column;
-    // leaves |q[j+1]|^2 partials in part[(j+1)&1] like the sequential path
+    // leaves |q[j+1]|^2 partials in part[(j+1)&1] like the sequential path.  Needs the Gram
+    // rows of the earlier basis vectors, which only this path maintains (a basis built by
+    // the persistent small-system kernel or by sequential passes continues sequentially).
+    q->gram_rows = j + 1;
     return qp::launch_mgs_lowsync(ctx->stream, q->Q, q->n, j, q->q(j + 1), q->md_part, q->gram, q->nvec, hcol,
                                   q->hcoef, q->part + (size_t)((j + 1) & 1) * kRedBlocks, dt, q->n, &ctx->stats);
   }
+  q->gram_rows = std::min(q->gram_rows, j);
   for (int i = 0; i <= j + 1; ++i) {                                              // :84-87
     qp::MgsArgs a;
     a.w = q->q(j + 1);
@@ -1885,6 +2033,7 @@ int qp_arnoldi(qp_operator* op, qp_krylov* q, int m, const qp_state* psi, double
     a.dt = dt;
     a.norm_min = norm_min;
     QP_CHECK(qp::launch_arnoldi_small(ctx->stream, a, &ctx->stats));
+    q->gram_rows = 0;
   } else {
     QP_HIP(hipMemcpyAsync(q->q(0), psi->d, (size_t)q->n * sizeof(double2), hipMemcpyDeviceToDevice, ctx->stream));  // :79
     for (int j = 0; j < m; ++j) {

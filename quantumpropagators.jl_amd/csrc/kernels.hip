@@ -230,8 +230,13 @@ typedef int i2v __attribute__((ext_vector_type(2)));
 // lane's own row: 2 instead of 4 bytes per entry of index traffic.
 template <bool NT>
 __device__ __forceinline__ int4 ld_cols(const char* __restrict__ colbytes, int64_t meta, int q, int lane, int rowc) {
-  const char* p = colbytes + (meta >> 1);
-  if (meta & 1) {
+  const char* p = colbytes + (meta >> 2);
+  const int mode = (int)(meta & 3);
+  if (mode == 2) {  // stencil block: one delta per slot for the whole block (wave-uniform load)
+    const int4 d = *(reinterpret_cast<const int4*>(p) + q);
+    return make_int4(rowc + d.x, rowc + d.y, rowc + d.z, rowc + d.w);
+  }
+  if (mode == 1) {
     const i2v* q8 = reinterpret_cast<const i2v*>(p) + (size_t)q * 64 + lane;
     i2v t;
     if (NT) t = __builtin_nontemporal_load(q8);
@@ -241,6 +246,13 @@ __device__ __forceinline__ int4 ld_cols(const char* __restrict__ colbytes, int64
   }
   return ld_col<NT>(reinterpret_cast<const int4*>(p) + (size_t)q * 64 + lane);
 }
+
+// one slot of a stencil lower section (engine.hip: LowerStencilSlot): column = row + delta,
+// the conj-transposed value sits at pb(column block) + column % 64
+struct LowerStencilSlot {
+  int delta, cb0;
+  int64_t pb0, pb1, pad;
+};
 
 // VAR bit 0: nt matrix loads; bit 1: row-local operands prefetched before the loop;
 // bit 2: unroll 4 quads (16 value loads in flight per lane) instead of 2
@@ -353,7 +365,25 @@ __global__ __launch_bounds__(kThreads) void hrb_spmv_kernel(const int64_t* __res
     typename Op::Pre pre;
     if (PRE) pre = op.pre(rowc);
     double2 s0 = make_double2(0.0, 0.0), s1 = make_double2(0.0, 0.0);
+    auto lower_stencil = [&]() {
+      const LowerStencilSlot* __restrict__ ls = reinterpret_cast<const LowerStencilSlot*>(lcolbytes + (lcm >> 2));
+#pragma unroll 2
+      for (int k = 0; k < 4 * nlq; k += 2) {
+        const LowerStencilSlot e0 = ls[k], e1 = ls[k + 1];
+        const int c0 = (int)rowc + e0.delta, c1 = (int)rowc + e1.delta;
+        const double2 a0 = uvals[((c0 >> 6) == e0.cb0 ? e0.pb0 : e0.pb1) + (c0 & 63)];
+        const double2 a1 = uvals[((c1 >> 6) == e1.cb0 ? e1.pb0 : e1.pb1) + (c1 & 63)];
+        const double2 x0 = x[c0];
+        const double2 x1 = x[c1];
+        cfma_conj(s0, a0, x0);
+        cfma_conj(s1, a1, x1);
+      }
+    };
     auto lower = [&]() {
+      if ((lcm & 3) == 2) {
+        lower_stencil();
+        return;
+      }
 #pragma unroll UNR
       for (int q = 0; q < nlq; ++q) {
         const int4 c = ld_cols<NT>(lcolbytes, lcm, q, lane, (int)rowc);
@@ -926,6 +956,7 @@ int launch_arnoldi_small(hipStream_t s, const SmallArnoldiArgs& a, Stats* st) {
 }
 
 int g_small_nnz = kSmallThreads * kSmallEpt;
+int g_stencil = 1;
 int g_acc_defer = 1;
 int g_cheby_graph = 0;     // measured (profiles/r01/propagate_loop.txt): no gain over plain launches on ROCm 7.0, so off
 

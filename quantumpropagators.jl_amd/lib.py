@@ -110,6 +110,7 @@ SIGNATURES = {
     "qp_operator_destroy": (C.c_int, [_P]),
     "qp_operator_info": (C.c_int, [_P, _i64p, _i64p, _i64p, C.POINTER(C.c_int)]),
     "qp_operator_get_csr": (C.c_int, [_P, _i64p, _i32p, _cp]),
+    "qp_operator_layout_info": (C.c_int, [_P, _i64p]),
     "qp_state_create": (C.c_int, [_P, C.c_int64, C.POINTER(_P)]),
     "qp_state_wrap": (C.c_int, [_P, _P, C.c_int64, C.POINTER(_P)]),
     "qp_state_destroy": (C.c_int, [_P]),
@@ -449,6 +450,14 @@ class Operator:
     @property
     def shape(self):
         return (self.nrows, self.ncols)
+
+    def layout_info(self):
+        """Device layout: 64-row blocks, blocks with a stencil upper / lower column section,
+        index bytes a mat-vec streams, stored values."""
+        out = np.zeros(5, dtype=np.int64)
+        check(self.lib.qp_operator_layout_info(self._h, _ptr(out, _i64p)))
+        return dict(zip(("blocks", "stencil_upper_blocks", "stencil_lower_blocks", "index_bytes", "stored"),
+                        (int(v) for v in out)))
 
     def set_coeffs(self, coeffs):
         a, p = _as_c128(np.atleast_1d(coeffs))

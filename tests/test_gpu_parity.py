@@ -743,3 +743,50 @@ def test_cheby_deferred_accumulation_bit_identical(ctx, fmt, dt):
                 L.tuning_set("acc_defer", 1)
         assert np.array_equal(outs[0], outs[1])
     assert len(seen) >= 2
+
+
+@pytest.mark.parametrize("fmt", [L.FMT_RBCSR, L.FMT_HRB])
+@pytest.mark.parametrize("N", [64 * 40, 64 * 40 + 17, 200])
+def test_stencil_blocks_bit_identical(ctx, fmt, N):
+    """Blocks whose rows all sit at the same distances from the diagonal are stored as stencil
+    sections (one delta per slot per block instead of per-lane indices; for the Hermitian
+    lower section also no transpose positions).  The decode is exact: device round trip and
+    Cheby steps are bit-identical to the per-lane encodings (knob `stencil` = 0), with
+    wrap-around rows, a partial last block and irregular rows mixed in."""
+    offs = (1, 2, 7, 64, 130) if N > 300 else (1, 3)
+    rp, col, val = synth.hermitian_offsets_csr(N, offs, rho=6.0)
+    H = synth.to_scipy(rp, col, val, N).tolil()
+    if N > 300:                               # irregular rows inside otherwise regular blocks
+        H[700, 900] = 0.3 + 0.1j
+        H[900, 700] = 0.3 - 0.1j
+    H = sp.csr_matrix(H)
+    H.sort_indices()
+    psi0 = synth.random_state(N)
+    outs, infos = [], []
+    for knob in (1, 0):
+        L.tuning_set("stencil", knob)
+        try:
+            Op = L.Operator(ctx, [L.Matrix.from_scipy(ctx, H)], fmt=fmt)
+        finally:
+            L.tuning_set("stencil", 1)
+        infos.append(Op.layout_info())
+        rp2, col2, val2 = Op.get_csr()
+        assert np.array_equal(rp2, H.indptr) and np.array_equal(col2, H.indices) and np.array_equal(val2, H.data)
+        wrk = L.ChebyWrk(ctx, N, 16.0, -8.0, 0.4)
+        psi = L.State(ctx, data=psi0)
+        for _ in range(3):
+            L.cheby(psi, Op, 0.4, wrk)
+        outs.append(psi.numpy())
+    assert np.array_equal(outs[0], outs[1])
+    on, off = infos
+    assert off["stencil_upper_blocks"] == 0 and off["stencil_lower_blocks"] == 0
+    if N > 300:
+        assert 0 < on["stencil_upper_blocks"] < on["blocks"]          # interior blocks only
+        assert on["index_bytes"] < 0.9 * off["index_bytes"]
+        if fmt == L.FMT_HRB:
+            assert 0 < on["stencil_lower_blocks"] < on["blocks"]
+    ref = psi0.copy()
+    owrk = qo.ChebyWrk(ref, 16.0, -8.0, 0.4)
+    for _ in range(3):
+        qo.cheby(ref, H, 0.4, owrk)
+    assert np.linalg.norm(outs[0] - ref) < TOL

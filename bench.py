@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--pattern", default="banded", choices=["banded", "scattered"])
     ap.add_argument("--format", default="auto", choices=["auto", "hrb", "rbcsr", "csr"])
     ap.add_argument("--exchange", default="auto", choices=["auto", "halo", "allgather"])
+    ap.add_argument("--driver", default="native", choices=["native", "torch"],
+                    help="multi-GPU step: one library call with its own RCCL communicator, or the Python loop")
     ap.add_argument("--cpu-steps", type=int, default=16,
                     help="steps of the CPU baseline sample (0 = skip); 16 steps ~ 10 s of one core")
     args = ap.parse_args()
@@ -117,15 +119,36 @@ def main():
         exchange_used = "none"
     else:
         import qprop_amd.sharded as sharded
+        # native: the whole step is one library call and the exchange runs on an RCCL
+        # communicator the library owns (qp_sharded_cheby_step); otherwise the step loop is
+        # driven from Python with torch.distributed collectives.  The native path is used only
+        # if, on every rank, one step of it reproduces the torch-driven step bit for bit.
+        want_native = (args.driver == "native") and not one_gpu
         sh = sharded.ShardedCheby(ctx, rp, col, vals, N, r0, r1, Delta, E_min, dt, fmt=fmt,
-                                  exchange=args.exchange, host_staged=one_gpu)
-        sh.set_state(psi0_local)
+                                  exchange=args.exchange, host_staged=one_gpu, native=want_native)
         fmt_used = sh.op.format
         layout = sh.op.layout_info()
         exchange_used = sh.exchange
+        use_native = sh.native is not None
+        if use_native:
+            sh.set_state(psi0_local)
+            sh.step(native=True)
+            torch.cuda.synchronize()
+            got = sh.local_state()
+            sh.set_state(psi0_local)
+            sh.step(native=False)
+            torch.cuda.synchronize()
+            same = torch.tensor([1 if np.array_equal(got, sh.local_state()) else 0], device="cuda")
+            dist.all_reduce(same, op=dist.ReduceOp.MIN)
+            use_native = bool(same.item())
+            driver_note = "native (library step, RCCL communicator of the library)" if use_native else \
+                "torch.distributed (native step disagreed with it in the self-check)"
+        else:
+            driver_note = "torch.distributed (step loop in Python)"
+        sh.set_state(psi0_local)
 
         def step():
-            sh.step()
+            sh.step(native=use_native)
     del rp, col, vals
 
     pcie = None
@@ -143,6 +166,7 @@ def main():
         pcie = 20 / (time.perf_counter() - t0p)
 
     def barrier():
+        torch.cuda.synchronize()     # nothing of ours in flight while the barrier's collective runs
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -205,7 +229,7 @@ def main():
                    "device_format": {1: "csr", 2: "rbcsr", 3: "hrb (Hermitian-packed row blocks)"}[fmt_used],
                    "device_layout": layout,
                    "parallelism": "single GPU" if world == 1 else (
-                       f"row-partitioned x{world}, exchange={exchange_used}"
+                       f"row-partitioned x{world}, exchange={exchange_used}, driver={driver_note}"
                        + (" [TEST MODE: ranks share one GPU, host-staged gloo]" if one_gpu else "")),
                    "global_steps_per_s": steps_per_s},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

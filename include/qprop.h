@@ -238,6 +238,43 @@ int qp_cheby_term_split(qp_operator* op, qp_split* sp, void* boundary_stream, in
                         const qp_state* acc_in, qp_state* acc_out, qp_state* slab, qp_c128 c,
                         double beta, double a_prev, double a, qp_c128 phase, const qp_acc_defer* defer);
 
+/* ---- row-partitioned cheby! with the exchange inside the library (RCCL over xGMI) ----
+ * No reference counterpart (the reference is single-process).  One process per GPU; the
+ * caller partitions H by rows, renumbers columns locally (own rows [0, nloc), then `world`
+ * ghost slabs of M rows each: nloc + owner*M + position) and creates the operator on those
+ * local rows.  qp_comm wraps an RCCL communicator created from a ncclUniqueId that rank 0
+ * obtains (qp_comm_unique_id) and the caller distributes by any means; `rccl_lib_path` is
+ * the librccl.so to use (the one PyTorch-ROCm ships when the caller also uses torch).
+ * qp_sharded_cheby_step runs one cheby! (src/cheby.jl:150-213) on the partitioned state with
+ * ONE host call: per term the boundary row blocks go to a high-priority side stream, pack the
+ * rows other ranks read into `slab`, and ncclAllGather follows on that stream while the
+ * interior row blocks run on the context stream (see qp_cheby_term_split). */
+typedef struct qp_comm qp_comm;
+int qp_comm_unique_id(const char* rccl_lib_path, char id_out[128]);
+int qp_comm_create(qp_ctx* ctx, const char* rccl_lib_path, const char id[128], int rank, int world,
+                   qp_comm** out);
+int qp_comm_destroy(qp_comm* comm);
+/* recv[r*count .. (r+1)*count) = rank r's send[0..count);  stream NULL = the ctx stream */
+int qp_comm_allgather(qp_comm* comm, const qp_state* send, qp_state* recv, int64_t count,
+                      void* stream);
+typedef struct qp_sharded_cheby qp_sharded_cheby;
+typedef struct {
+  qp_operator* op;          /* local rows, local column numbering */
+  qp_split* split;          /* NULL: no overlap, everything on the context stream */
+  qp_comm* comm;            /* NULL: no exchange (single rank, M = 0) */
+  qp_state* X0;             /* op.ncols entries; X0[0..nloc) holds Psi before and after a step */
+  qp_state* X1;             /* op.ncols entries, work */
+  qp_state* acc;            /* nloc entries, work */
+  qp_state* slab;           /* M entries: send buffer (NULL when direct_send) */
+  const int64_t* send_rows; /* host, nsend <= M local rows that other ranks read */
+  int64_t nsend, M;
+  int direct_send;          /* every local row is sent and nloc == M: X[0..nloc) is the send buffer */
+} qp_sharded_cheby_desc;
+int qp_sharded_cheby_create(const qp_sharded_cheby_desc* desc, qp_sharded_cheby** out);
+int qp_sharded_cheby_destroy(qp_sharded_cheby* s);
+int qp_sharded_cheby_step(qp_sharded_cheby* s, const double* a, int n_coeffs, double Delta,
+                          double E_min, double dt);
+
 /* ---- Arnoldi (src/arnoldi.jl) ------------------------------------------------------ */
 int qp_krylov_create(qp_ctx* ctx, int64_t n, int nvec, qp_krylov** out);
 int qp_krylov_destroy(qp_krylov* q);

@@ -71,6 +71,12 @@ class qp_acc_defer(C.Structure):
     _fields_ = [("skip", C.c_int), ("n_defer", C.c_int), ("a_d1", C.c_double), ("a_d2", C.c_double)]
 
 
+class qp_sharded_cheby_desc(C.Structure):
+    _fields_ = [("op", C.c_void_p), ("split", C.c_void_p), ("comm", C.c_void_p), ("X0", C.c_void_p),
+                ("X1", C.c_void_p), ("acc", C.c_void_p), ("slab", C.c_void_p), ("send_rows", C.POINTER(C.c_int64)),
+                ("nsend", C.c_int64), ("M", C.c_int64), ("direct_send", C.c_int)]
+
+
 class qp_prop_spec(C.Structure):
     _fields_ = [("method", C.c_int), ("cheby", C.c_void_p), ("a", C.POINTER(C.c_double)), ("n_coeffs", C.c_int),
                 ("Delta", C.c_double), ("E_min", C.c_double), ("wrk_dt", C.c_double), ("limit", C.c_double),
@@ -142,6 +148,13 @@ SIGNATURES = {
     "qp_split_check": (C.c_int, [_P]),
     "qp_cheby_term_split": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_int64, _P, _P, _P, _P, _P, qp_c128, C.c_double,
                                       C.c_double, C.c_double, qp_c128, C.POINTER(qp_acc_defer)]),
+    "qp_comm_unique_id": (C.c_int, [C.c_char_p, C.c_char_p]),
+    "qp_comm_create": (C.c_int, [_P, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(_P)]),
+    "qp_comm_destroy": (C.c_int, [_P]),
+    "qp_comm_allgather": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
+    "qp_sharded_cheby_create": (C.c_int, [C.POINTER(qp_sharded_cheby_desc), C.POINTER(_P)]),
+    "qp_sharded_cheby_destroy": (C.c_int, [_P]),
+    "qp_sharded_cheby_step": (C.c_int, [_P, _dp, C.c_int, C.c_double, C.c_double, C.c_double]),
     "qp_krylov_create": (C.c_int, [_P, C.c_int64, C.c_int, C.POINTER(_P)]),
     "qp_krylov_destroy": (C.c_int, [_P]),
     "qp_krylov_download": (C.c_int, [_P, C.c_int, _cp]),
@@ -671,6 +684,83 @@ def cheby_term_split(H, split, boundary_stream, first, x, xoff, v0, vout, acc_in
                                    C.byref(defer) if defer is not None else None)
     if st:
         check(st)
+
+
+def rccl_library_path():
+    """The librccl.so of this process: the one PyTorch-ROCm ships (torch.distributed's "nccl"
+    backend is that RCCL), so that the library's communicator and torch's use the same code."""
+    import torch
+    path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    if not os.path.exists(path):
+        path = "/opt/rocm/lib/librccl.so"
+    return path
+
+
+class Comm:
+    """RCCL communicator owned by the library (include/qprop.h, qp_comm).  ``exchange_id``:
+    a callable that takes rank 0's 128-byte id (None on the other ranks) and returns it on every
+    rank -- e.g. a ``torch.distributed.broadcast_object_list`` over any backend."""
+
+    def __init__(self, ctx, rank, world, exchange_id, lib_path=None):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.rank, self.world = int(rank), int(world)
+        path = (lib_path or rccl_library_path()).encode()
+        uid = None
+        if self.rank == 0:
+            buf = C.create_string_buffer(128)
+            check(self.lib.qp_comm_unique_id(path, buf))
+            uid = buf.raw
+        uid = exchange_id(uid)
+        assert isinstance(uid, (bytes, bytearray)) and len(uid) == 128
+        self._h = _P()
+        check(self.lib.qp_comm_create(ctx._h, path, bytes(uid), self.rank, self.world, C.byref(self._h)))
+        ctx._adopt(self)
+
+    def allgather(self, send, recv, count, stream=None):
+        check(self.lib.qp_comm_allgather(self._h, send._h, recv._h, int(count), stream))
+
+    def close(self):
+        if self._h:
+            self.lib.qp_comm_destroy(self._h)
+            self._h = _P()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ShardedChebyStepper:
+    """One host call per ``cheby!`` on a row-partitioned state (qp_sharded_cheby_step)."""
+
+    def __init__(self, op, split, comm, X0, X1, acc, slab, send_rows, M, direct_send):
+        self.lib = op.lib
+        rows = np.ascontiguousarray(send_rows, dtype=np.int64)
+        d = qp_sharded_cheby_desc()
+        d.op, d.split, d.comm = op._h, (split._h if split is not None else None), (comm._h if comm is not None else None)
+        d.X0, d.X1, d.acc, d.slab = X0._h, X1._h, acc._h, (slab._h if slab is not None else None)
+        d.send_rows, d.nsend, d.M, d.direct_send = _ptr(rows, _i64p), len(rows), int(M), int(bool(direct_send))
+        self._keep = (op, split, comm, X0, X1, acc, slab)
+        self._h = _P()
+        check(self.lib.qp_sharded_cheby_create(C.byref(d), C.byref(self._h)))
+        op.ctx._adopt(self)
+
+    def step(self, coeffs, Delta, E_min, dt):
+        st = self.lib.qp_sharded_cheby_step(self._h, _ptr(coeffs, _dp), len(coeffs), Delta, E_min, dt)
+        if st:
+            check(st)
+
+    def close(self):
+        if self._h:
+            self.lib.qp_sharded_cheby_destroy(self._h)
+            self._h = _P()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Krylov:

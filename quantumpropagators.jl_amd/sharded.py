@@ -147,7 +147,7 @@ class ShardedCheby:
 
     def __init__(self, ctx, rowptr, col, vals, N, r0, r1, Delta, E_min, dt, fmt=L.FMT_AUTO,
                  exchange="auto", group=None, backend=None, limit=1e-12, overlap=True,
-                 host_staged=False, _debug_send_rows=None):
+                 host_staged=False, native=False, _debug_send_rows=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
@@ -231,6 +231,25 @@ class ShardedCheby:
                 if self.split is not None:
                     self.side = be.new_stream()
         self.n_exchanges = 0
+        # native: the whole step is one library call, with the exchange on an RCCL communicator
+        # the library owns (qp_sharded_cheby_step).  The torch.distributed group only carries
+        # the communicator's id.  Needs the HIP backend and one GPU per rank.
+        self.native = None
+        if native and isinstance(be, HipBackend) and not self.host_staged:
+            comm = None
+            if self.exchanging:
+                def exchange_id(uid):
+                    box = [uid]
+                    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0,
+                                               group=group)
+                    return box[0]
+                comm = L.Comm(ctx, self.rank, self.world, exchange_id)
+            self.comm = comm
+            self.native = L.ShardedChebyStepper(
+                self.op, self.split, comm, self.Xfull[0], self.Xfull[1], self.acc,
+                None if (not self.exchanging or self.direct_send) else self.slab_state,
+                self.send_idx_host if (self.exchanging and not self.direct_send) else np.zeros(0, dtype=np.int64),
+                M, self.direct_send)
         # start the ranks aligned: a rank that is still building its operator must not keep
         # the others waiting inside their first collective
         dist.barrier(group=group)
@@ -270,8 +289,15 @@ class ShardedCheby:
             self.dist.all_gather_into_tensor(x[2 * nloc:], send, group=self.group)
         self.n_exchanges += 1
 
-    def step(self, backward=False):
-        """One ``cheby!`` (src/cheby.jl:150-213) on the partitioned state."""
+    def step(self, backward=False, native=None):
+        """One ``cheby!`` (src/cheby.jl:150-213) on the partitioned state.  ``native``:
+        force (True) or forbid (False) the one-call library step; default: use it if built."""
+        if native is None:
+            native = self.native is not None
+        if native:
+            self.native.step(self.coeffs, self.Delta, self.E_min, -self.dt if backward else self.dt)
+            self.n_exchanges += len(self.coeffs) - 1 if self.exchanging else 0
+            return None
         if self.split is not None:
             return self._step_overlapped(backward)
         a = self.coeffs

@@ -168,3 +168,57 @@ def test_sharded_newton_world1(pg):
         L.newton(rho, Op, dt, wrk)
     assert np.linalg.norm(sn.local_state() - rho.numpy()) < 1e-12
     ctx.close()
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+@pytest.mark.parametrize("exchange", ["halo", "allgather"])
+def test_native_rccl_step_world1(pg, overlap, exchange):
+    """qp_sharded_cheby_step: the whole partitioned cheby! as ONE library call, exchange by
+    ncclAllGather on a communicator the library owns (qp_comm, RCCL resolved from torch's
+    librccl.so).  World 1 here (one GPU per rank is an RCCL requirement), with a forced send
+    set so that pack, all-gather, side stream and in-launch hand-off all run; the result is
+    bit-identical to the torch.distributed-driven step of the same object and matches the
+    oracle."""
+    import torch
+    from oracle import qp_oracle as qo
+    import qprop_amd.lib as L
+    import qprop_amd.sharded as sharded
+    import qprop_amd.synth as synth
+    N = 8192
+    rp, col, vals = synth.hermitian_offsets_csr(N, offsets=(1, 2, 3, 4, 16, 32, 48, 64))
+    ctx = L.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    send = np.concatenate([np.arange(0, 200), np.arange(N - 200, N)]) if exchange == "halo" else None
+    sh = sharded.ShardedCheby(ctx, rp, col, vals, N, 0, N, 20.0, -10.0, 1.0, exchange=exchange, overlap=overlap,
+                              native=True, _debug_send_rows=send)
+    assert sh.native is not None
+    if exchange == "halo":
+        assert sh.M == 400 and (sh.split is not None) == overlap
+    psi0 = synth.random_state(N)
+    results = []
+    for native in (True, False):
+        sh.set_state(psi0)
+        ctx.reset_stats()
+        for _ in range(3):
+            sh.step(native=native)
+        sh.step(backward=True, native=native)
+        torch.cuda.synchronize()
+        sh.check()
+        results.append((sh.local_state(), sh.be.read(sh.X[0], N, sh.ncols_local), ctx.stats()["n_matvec"]))
+    assert np.array_equal(results[0][0], results[1][0])          # state
+    assert np.array_equal(results[0][1], results[1][1])          # ghost slots after the last exchange
+    assert results[0][2] == results[1][2] == 4 * 31
+    H = synth.to_scipy(rp, col, vals, N)
+    wrk = qo.ChebyWrk(psi0, 20.0, -10.0, 1.0)
+    ref = psi0.copy()
+    for _ in range(3):
+        qo.cheby(ref, H, 1.0, wrk)
+    qo.cheby(ref, H, -1.0, wrk)
+    assert np.linalg.norm(results[0][0] - ref) < 1e-10
+    # the library's all-gather on its own
+    a = L.State(ctx, data=np.arange(5, dtype=complex) + 1j)
+    b = L.State(ctx, n=5)
+    if sh.comm is not None:
+        sh.comm.allgather(a, b, 5)
+        ctx.sync()
+        assert np.array_equal(b.numpy(), a.numpy())
+    ctx.close()

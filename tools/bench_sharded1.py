@@ -22,7 +22,9 @@ K = 30
 res = {}
 for name, kw in (("plain (no exchange)", dict()), ("exchange, serial", dict(_debug_send_rows=send, overlap=False)),
                  ("exchange, overlap/events", dict(_debug_send_rows=send, overlap=True, mode=0)),
-                 ("exchange, overlap/flag", dict(_debug_send_rows=send, overlap=True, mode=1))):
+                 ("exchange, overlap/flag", dict(_debug_send_rows=send, overlap=True, mode=1)),
+                 ("native, serial", dict(_debug_send_rows=send, overlap=False, native=True)),
+                 ("native, overlap/flag", dict(_debug_send_rows=send, overlap=True, mode=1, native=True))):
     L.tuning_set("split_mode", kw.pop("mode", 1))
     sh = sharded.ShardedCheby(ctx, rp, col, vals, N, 0, N, 20.0, -10.0, 1.0, exchange="halo", **kw)
     sh.set_state(psi0)

@@ -487,8 +487,25 @@ class Operator:
         return rowptr, col[: self.nnz], vals[: self.nnz]
 
     def mul(self, x, y, alpha=1.0, beta=0.0):
+        """``mul!(y, op, x, alpha, beta)``: y = beta y + alpha op x  (src/generators.jl:634-645)."""
         check(self.lib.qp_mul(self._h, x._h, y._h, c128(alpha), c128(beta)))
         return y
+
+    def dot(self, x, y):
+        """``dot(x, op, y)`` = <x| op |y>  (src/generators.jl:648-660)."""
+        out = qp_c128()
+        tmp = State(self.ctx, n=self.nrows)
+        check(self.lib.qp_dot_op(x._h, self._h, y._h, tmp._h, C.byref(out)))
+        return complex(out.re, out.im)
+
+    def __mul__(self, state):
+        """``op * state``: a new state."""
+        if not isinstance(state, State):
+            return NotImplemented
+        return self.mul(state, State(self.ctx, n=self.nrows))
+
+    def size(self, dim=None):
+        return self.shape if dim is None else self.shape[dim]
 
     def close(self):
         if self._h:
@@ -572,6 +589,48 @@ class State:
 
     def __len__(self):
         return self.n
+
+    # ---- the state interface of the reference (src/interfaces/state.jl:92-140), on the device:
+    # similar / copy / copyto! / zero / fill! / lmul! / axpy! / norm / dot and the out-of-place
+    # `state + state`, `state - state`, `a * state`.  Elements can be read (`state[i]`) but the
+    # type is deliberately not a host array.
+    dtype = np.complex128
+
+    @property
+    def shape(self):
+        return (self.n,)
+
+    def similar(self):
+        return State(self.ctx, n=self.n)
+
+    def copy(self):
+        return State(self.ctx, n=self.n).copy_from(self)
+
+    def zero(self):
+        return State(self.ctx, n=self.n)          # qp_state_create zero-fills
+
+    def lmul(self, a):
+        return self.scal(a)
+
+    def __add__(self, other):
+        return self.copy().axpy(1.0, other)
+
+    def __sub__(self, other):
+        return self.copy().axpy(-1.0, other)
+
+    def __mul__(self, a):
+        return self.copy().scal(a)
+
+    __rmul__ = __mul__
+
+    def __getitem__(self, i):
+        if not isinstance(i, (int, np.integer)):
+            raise TypeError("a device state is indexed by one integer")
+        if i < 0:
+            i += self.n
+        if not 0 <= i < self.n:
+            raise IndexError(i)
+        return complex(self.numpy()[i])
 
     def close(self):
         if self._h:

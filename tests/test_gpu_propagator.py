@@ -324,3 +324,46 @@ def test_cheby_graph_replay_is_bit_identical(ctx):
     assert np.array_equal(out, ref)
     assert st["n_graph_launches"] == len(tlist) - 2        # the first call only arms the key
     assert st["n_matvec"] == plain["n_matvec"] and st["spmv_bytes"] == plain["spmv_bytes"]
+
+
+def test_interfaces_device_types(ctx):
+    """QuantumPropagators.Interfaces.check_state / check_operator / check_propagator for the
+    device-resident types (src/interfaces/*.jl; test/test_prop_interfaces.jl and the
+    `check_*` calls of test/test_propagate.jl), including that the checks do catch a type
+    that breaks the contract."""
+    import qprop_amd.interfaces as I
+    rng = np.random.default_rng(31)
+    N = 300
+    psi = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    psi /= np.linalg.norm(psi)
+    state = L.State(ctx, data=psi)
+    assert I.check_state(state, normalized=True)
+    assert not I.check_state(2.0 * state, normalized=True, quiet=True)
+    for A in (synth.dense_hermitian(N, rho=3.0, rng=rng), synth.sparse_random(N, 0.05, rho=3.0, rng=rng)):
+        Op = L.Operator(ctx, [L.Matrix.from_scipy(ctx, sp.csr_matrix(A))])
+        assert I.check_operator(Op, state=state, atol=1e-12)
+        A_ = A.toarray() if sp.issparse(A) else A
+        assert np.linalg.norm((Op * state).numpy() - A_ @ psi) < 1e-12
+        assert abs(Op.dot(state, state) - np.vdot(psi, A_ @ psi)) < 1e-12
+
+    class Broken(L.State):                        # axpy! that forgets the factor
+        def axpy(self, alpha, x):
+            return L.State.axpy(self, 1.0, x)
+
+        def similar(self):
+            return Broken(self.ctx, n=self.n)
+
+        def copy(self):
+            return Broken(self.ctx, n=self.n).copy_from(self)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert not I.check_state(Broken(ctx, data=psi))
+        assert any("axpy!" in str(x.message) for x in w)
+    H0 = synth.dense_hermitian(N, rho=3.0, rng=rng)
+    H1 = synth.dense_hermitian(N, rho=1.0, rng=rng)
+    tlist = np.linspace(0, 1.0, 11)
+    for method, kw in (("cheby", dict(E_min=-6.0, E_max=6.0)), ("newton", dict(m_max=6))):
+        for inplace, backward in ((True, False), (True, True)) + (((False, False),) if method == "cheby" else ()):
+            p = P.init_prop(psi, P.hamiltonian(H0, (H1, lambda t: 0.3 * t)), tlist, method, ctx=ctx,
+                            inplace=inplace, backward=backward, **kw)
+            assert I.check_propagator(p, atol=1e-13)

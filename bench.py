@@ -141,7 +141,8 @@ def main():
             same = torch.tensor([1 if np.array_equal(got, sh.local_state()) else 0], device="cuda")
             dist.all_reduce(same, op=dist.ReduceOp.MIN)
             use_native = bool(same.item())
-            driver_note = "native (library step, RCCL communicator of the library)" if use_native else \
+            driver_note = ("native (library step, RCCL communicator of the library, "
+                           + ("ncclSend/ncclRecv with the neighbours" if sh.p2p else "ncclAllGather") + ")") if use_native else \
                 "torch.distributed (native step disagreed with it in the self-check)"
         else:
             driver_note = "torch.distributed (step loop in Python)"

@@ -269,6 +269,13 @@ typedef struct {
   const int64_t* send_rows; /* host, nsend <= M local rows that other ranks read */
   int64_t nsend, M;
   int direct_send;          /* every local row is sent and nloc == M: X[0..nloc) is the send buffer */
+  /* neighbour exchange instead of the all-gather (banded H: each rank reads from few others):
+   * the slab goes to the ranks in send_to, the slabs of the ranks in recv_from land in their
+   * ghost slots, as one ncclGroup of ncclSend / ncclRecv.  n_send_to < 0: all-gather. */
+  const int* send_to;
+  int n_send_to;
+  const int* recv_from;
+  int n_recv_from;
 } qp_sharded_cheby_desc;
 int qp_sharded_cheby_create(const qp_sharded_cheby_desc* desc, qp_sharded_cheby** out);
 int qp_sharded_cheby_destroy(qp_sharded_cheby* s);

@@ -2673,6 +2673,10 @@ struct RcclApi {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -2685,8 +2689,13 @@ int rccl_load(const char* path, RcclApi* api) {
   api->CommInitRank = reinterpret_cast<decltype(api->CommInitRank)>(dlsym(h, "ncclCommInitRank"));
   api->CommDestroy = reinterpret_cast<decltype(api->CommDestroy)>(dlsym(h, "ncclCommDestroy"));
   api->AllGather = reinterpret_cast<decltype(api->AllGather)>(dlsym(h, "ncclAllGather"));
+  api->Send = reinterpret_cast<decltype(api->Send)>(dlsym(h, "ncclSend"));
+  api->Recv = reinterpret_cast<decltype(api->Recv)>(dlsym(h, "ncclRecv"));
+  api->GroupStart = reinterpret_cast<decltype(api->GroupStart)>(dlsym(h, "ncclGroupStart"));
+  api->GroupEnd = reinterpret_cast<decltype(api->GroupEnd)>(dlsym(h, "ncclGroupEnd"));
   api->GetErrorString = reinterpret_cast<decltype(api->GetErrorString)>(dlsym(h, "ncclGetErrorString"));
-  if (!api->GetUniqueId || !api->CommInitRank || !api->CommDestroy || !api->AllGather || !api->GetErrorString)
+  if (!api->GetUniqueId || !api->CommInitRank || !api->CommDestroy || !api->AllGather || !api->Send || !api->Recv ||
+      !api->GroupStart || !api->GroupEnd || !api->GetErrorString)
     return qp::fail(QP_E_INTERNAL, "%s does not export the RCCL entry points", path);
   return QP_OK;
 }
@@ -2720,6 +2729,8 @@ struct qp_sharded_cheby {
   int64_t* send_rows_dev = nullptr;   // M entries, padded with row 0
   hipStream_t side = nullptr;         // high priority: boundary blocks + collectives
   hipEvent_t ev_main = nullptr, ev_side = nullptr;
+  std::vector<int> send_to, recv_from;
+  bool p2p = false;
 };
 
 extern "C" {
@@ -2791,11 +2802,26 @@ int qp_sharded_cheby_create(const qp_sharded_cheby_desc* desc, qp_sharded_cheby*
   if (d.split && (d.split->op != d.op || d.direct_send || d.M == 0)) return qp::fail(QP_E_BAD_ARG, "qp_sharded_cheby_create: split does not fit this exchange");
   for (int64_t i = 0; i < d.nsend; ++i)
     if (d.send_rows[i] < 0 || d.send_rows[i] >= nloc) return qp::fail(QP_E_BAD_ARG, "qp_sharded_cheby_create: send row out of range");
+  const bool p2p = d.M > 0 && d.n_send_to >= 0;
+  if (p2p) {
+    if (d.n_recv_from < 0 || (d.n_send_to > 0 && !d.send_to) || (d.n_recv_from > 0 && !d.recv_from))
+      return qp::fail(QP_E_BAD_ARG, "qp_sharded_cheby_create: bad neighbour lists");
+    for (int i = 0; i < d.n_send_to; ++i)
+      if (d.send_to[i] < 0 || d.send_to[i] >= world) return qp::fail(QP_E_BAD_ARG, "qp_sharded_cheby_create: send_to rank out of range");
+    for (int i = 0; i < d.n_recv_from; ++i)
+      if (d.recv_from[i] < 0 || d.recv_from[i] >= world) return qp::fail(QP_E_BAD_ARG, "qp_sharded_cheby_create: recv_from rank out of range");
+  }
   qp_ctx* ctx = d.op->ctx;
   QP_CHECK(use(ctx));
   auto s = std::make_unique<qp_sharded_cheby>();
   s->d = d;
-  s->d.send_rows = nullptr;   // host array of the caller: not kept
+  s->d.send_rows = nullptr;   // host arrays of the caller: not kept
+  s->p2p = p2p;
+  if (p2p) {
+    s->send_to.assign(d.send_to, d.send_to + d.n_send_to);
+    s->recv_from.assign(d.recv_from, d.recv_from + d.n_recv_from);
+  }
+  s->d.send_to = s->d.recv_from = nullptr;
   s->ctx = ctx;
   s->nloc = nloc;
   if (d.M > 0 && !d.direct_send) {
@@ -2867,7 +2893,16 @@ int qp_sharded_cheby_step(qp_sharded_cheby* s, const double* a, int n_coeffs, do
         ctx->stats.n_launch++;
       }
     }
-    QP_RCCL(d.comm->api, d.comm->api.AllGather(send, X[k]->d + nloc, (size_t)(2 * d.M), ncclDouble, d.comm->comm, S_x));
+    const RcclApi& api = d.comm->api;
+    if (s->p2p) {   // neighbour exchange: my slab to who reads it, their slabs into their ghost slots
+      QP_RCCL(api, api.GroupStart());
+      for (int o : s->recv_from)
+        QP_RCCL(api, api.Recv(X[k]->d + nloc + (int64_t)o * d.M, (size_t)(2 * d.M), ncclDouble, o, d.comm->comm, S_x));
+      for (int o : s->send_to) QP_RCCL(api, api.Send(send, (size_t)(2 * d.M), ncclDouble, o, d.comm->comm, S_x));
+      QP_RCCL(api, api.GroupEnd());
+    } else {
+      QP_RCCL(api, api.AllGather(send, X[k]->d + nloc, (size_t)(2 * d.M), ncclDouble, d.comm->comm, S_x));
+    }
     return QP_OK;
   };
 

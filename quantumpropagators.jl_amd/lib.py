@@ -74,7 +74,9 @@ class qp_acc_defer(C.Structure):
 class qp_sharded_cheby_desc(C.Structure):
     _fields_ = [("op", C.c_void_p), ("split", C.c_void_p), ("comm", C.c_void_p), ("X0", C.c_void_p),
                 ("X1", C.c_void_p), ("acc", C.c_void_p), ("slab", C.c_void_p), ("send_rows", C.POINTER(C.c_int64)),
-                ("nsend", C.c_int64), ("M", C.c_int64), ("direct_send", C.c_int)]
+                ("nsend", C.c_int64), ("M", C.c_int64), ("direct_send", C.c_int),
+                ("send_to", C.POINTER(C.c_int)), ("n_send_to", C.c_int),
+                ("recv_from", C.POINTER(C.c_int)), ("n_recv_from", C.c_int)]
 
 
 class qp_prop_spec(C.Structure):
@@ -793,10 +795,17 @@ class Comm:
 class ShardedChebyStepper:
     """One host call per ``cheby!`` on a row-partitioned state (qp_sharded_cheby_step)."""
 
-    def __init__(self, op, split, comm, X0, X1, acc, slab, send_rows, M, direct_send):
+    def __init__(self, op, split, comm, X0, X1, acc, slab, send_rows, M, direct_send, send_to=None, recv_from=None):
         self.lib = op.lib
         rows = np.ascontiguousarray(send_rows, dtype=np.int64)
         d = qp_sharded_cheby_desc()
+        if send_to is not None:           # neighbour exchange (ncclSend / ncclRecv) instead of the all-gather
+            st = np.ascontiguousarray(send_to, dtype=np.int32)
+            rf = np.ascontiguousarray(recv_from, dtype=np.int32)
+            d.send_to, d.n_send_to = st.ctypes.data_as(C.POINTER(C.c_int)), len(st)
+            d.recv_from, d.n_recv_from = rf.ctypes.data_as(C.POINTER(C.c_int)), len(rf)
+        else:
+            d.n_send_to = -1
         d.op, d.split, d.comm = op._h, (split._h if split is not None else None), (comm._h if comm is not None else None)
         d.X0, d.X1, d.acc, d.slab = X0._h, X1._h, acc._h, (slab._h if slab is not None else None)
         d.send_rows, d.nsend, d.M, d.direct_send = _ptr(rows, _i64p), len(rows), int(M), int(bool(direct_send))

@@ -147,7 +147,7 @@ class ShardedCheby:
 
     def __init__(self, ctx, rowptr, col, vals, N, r0, r1, Delta, E_min, dt, fmt=L.FMT_AUTO,
                  exchange="auto", group=None, backend=None, limit=1e-12, overlap=True,
-                 host_staged=False, native=False, _debug_send_rows=None):
+                 host_staged=False, native=False, p2p="auto", _debug_send_rows=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
@@ -185,6 +185,7 @@ class ShardedCheby:
         self.exchange = exchange
 
         # ---- send lists: which of my rows does any other rank read? ----
+        self.send_to = self.recv_from = None       # neighbour lists (halo exchange only)
         if exchange == "halo":
             wanted = split_by_owner(remote, bounds)
             all_wanted = [None] * self.world
@@ -193,10 +194,13 @@ class ShardedCheby:
             for o in range(self.world):
                 parts = [w[o] for w in all_wanted if o in w]
                 send_lists.append(np.unique(np.concatenate(parts)) if parts else np.zeros(0, dtype=np.int64))
+            self.recv_from = sorted(int(o) for o in wanted)
+            self.send_to = sorted(r for r, w in enumerate(all_wanted) if self.rank in w)
         else:
             send_lists = [np.arange(bounds[o], bounds[o + 1], dtype=np.int64) for o in range(self.world)]
         if _debug_send_rows is not None:     # single-rank tests of the pack / overlap machinery
             send_lists = [np.asarray(_debug_send_rows, dtype=np.int64) + self.r0]
+            self.send_to = self.recv_from = [0]
         self.send_lists = send_lists
         self.M = M = int(max(len(s) for s in send_lists)) if (self.world > 1 or _debug_send_rows is not None) else 0
         self.send_idx_host = send_lists[self.rank] - self.r0
@@ -235,6 +239,7 @@ class ShardedCheby:
         # the library owns (qp_sharded_cheby_step).  The torch.distributed group only carries
         # the communicator's id.  Needs the HIP backend and one GPU per rank.
         self.native = None
+        self.p2p = False
         if native and isinstance(be, HipBackend) and not self.host_staged:
             comm = None
             if self.exchanging:
@@ -245,11 +250,18 @@ class ShardedCheby:
                     return box[0]
                 comm = L.Comm(ctx, self.rank, self.world, exchange_id)
             self.comm = comm
+            # neighbour exchange when every rank talks to few others (banded H: 2), else all-gather
+            npeers = [None] * self.world
+            dist.all_gather_object(npeers, 0 if self.send_to is None else max(len(self.send_to), len(self.recv_from)),
+                                   group=group)
+            use_p2p = (self.exchanging and self.exchange == "halo" and not self.direct_send and
+                       (p2p is True or (p2p == "auto" and max(npeers) <= max(2, self.world // 2))))
+            self.p2p = bool(use_p2p)
             self.native = L.ShardedChebyStepper(
                 self.op, self.split, comm, self.Xfull[0], self.Xfull[1], self.acc,
                 None if (not self.exchanging or self.direct_send) else self.slab_state,
                 self.send_idx_host if (self.exchanging and not self.direct_send) else np.zeros(0, dtype=np.int64),
-                M, self.direct_send)
+                M, self.direct_send, self.send_to if use_p2p else None, self.recv_from if use_p2p else None)
         # start the ranks aligned: a rank that is still building its operator must not keep
         # the others waiting inside their first collective
         dist.barrier(group=group)

@@ -171,8 +171,8 @@ def test_sharded_newton_world1(pg):
 
 
 @pytest.mark.parametrize("overlap", [True, False])
-@pytest.mark.parametrize("exchange", ["halo", "allgather"])
-def test_native_rccl_step_world1(pg, overlap, exchange):
+@pytest.mark.parametrize("exchange,p2p", [("halo", True), ("halo", False), ("allgather", False)])
+def test_native_rccl_step_world1(pg, overlap, exchange, p2p):
     """qp_sharded_cheby_step: the whole partitioned cheby! as ONE library call, exchange by
     ncclAllGather on a communicator the library owns (qp_comm, RCCL resolved from torch's
     librccl.so).  World 1 here (one GPU per rank is an RCCL requirement), with a forced send
@@ -189,8 +189,8 @@ def test_native_rccl_step_world1(pg, overlap, exchange):
     ctx = L.Context(0, stream=torch.cuda.current_stream().cuda_stream)
     send = np.concatenate([np.arange(0, 200), np.arange(N - 200, N)]) if exchange == "halo" else None
     sh = sharded.ShardedCheby(ctx, rp, col, vals, N, 0, N, 20.0, -10.0, 1.0, exchange=exchange, overlap=overlap,
-                              native=True, _debug_send_rows=send)
-    assert sh.native is not None
+                              native=True, p2p=p2p, _debug_send_rows=send)
+    assert sh.native is not None and sh.p2p == p2p      # p2p: ncclSend/ncclRecv to itself at world 1
     if exchange == "halo":
         assert sh.M == 400 and (sh.split is not None) == overlap
     psi0 = synth.random_state(N)

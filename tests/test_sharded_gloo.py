@@ -45,6 +45,19 @@ def _worker(rank, world, port, exchange, uneven, offsets, N, q, overlap=True):
         lcol, lvals = col[rp[r0]:rp[r1]], vals[rp[r0]:rp[r1]]
         sh = sharded.ShardedCheby(None, lrp, lcol, lvals, N, r0, r1, 20.0, -10.0, 1.0, exchange=exchange,
                                   backend=NumpyBackend(), overlap=overlap)
+        # neighbour lists of the halo exchange (what the native driver's ncclSend / ncclRecv
+        # pairs are built from): o sends to r exactly when r receives from o, and a rank
+        # receives from every owner of a ghost column it reads
+        if sh.exchange == "halo":
+            lists = [None] * world
+            dist.all_gather_object(lists, (sh.send_to, sh.recv_from))
+            for r_, (st, rf) in enumerate(lists):
+                assert all(r_ in lists[o][0] for o in rf) and all(r_ in lists[o][1] for o in st)
+            ghosts = lcol[(lcol < r0) | (lcol >= r1)]
+            owners = set((np.searchsorted(bounds, ghosts, side="right") - 1).tolist())
+            assert owners == set(sh.recv_from)
+        else:
+            assert sh.send_to is None and sh.recv_from is None
         psi0 = synth.random_state(N)
         sh.set_state(psi0[r0:r1])
         sh.step()

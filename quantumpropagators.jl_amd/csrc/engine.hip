@@ -1679,6 +1679,9 @@ int qp_cheby_step_batched(qp_cheby* w, qp_operator* op, qp_state* psi, int batch
   double2* B = w->bufA;
   double2* ACC = w->acc;
   double2* result = nullptr;
+  std::vector<qp_acc_defer> sched((size_t)nterms);
+  acc_schedule(a, n_coeffs, qp::g_acc_defer != 0, sched.data());
+  bool updated = false;
   for (int m = 1; m <= nterms; ++m) {   // same buffer rotation as qp_cheby_step, element = (row, state)
     const bool last = (m == nterms);
     qp::ChebyEpi e;
@@ -1689,7 +1692,6 @@ int qp_cheby_step_batched(qp_cheby* w, qp_operator* op, qp_state* psi, int batch
       e.vout = last ? nullptr : B;
       e.acc_in = nullptr;
       e.acc_out = ACC;
-      e.a_prev = a[0];
       result = ACC;
     } else {
       double2* xb = (m % 2 == 0) ? B : P;
@@ -1697,10 +1699,17 @@ int qp_cheby_step_batched(qp_cheby* w, qp_operator* op, qp_state* psi, int batch
       x = xb;
       e.v0 = ob;
       e.vout = last ? nullptr : ob;
-      e.acc_in = ACC;
+      e.acc_in = updated ? ACC : nullptr;
       e.acc_out = (last && xb == B) ? P : ACC;
-      e.a_prev = 0.0;
       result = e.acc_out;
+    }
+    e.a_prev = updated ? 0.0 : a[0];
+    set_defer(e, &sched[(size_t)m - 1]);
+    if (sched[(size_t)m - 1].skip) {
+      e.acc_in = nullptr;
+      e.acc_out = nullptr;
+    } else {
+      updated = true;
     }
     e.xloc = x;
     e.c = d2(c);

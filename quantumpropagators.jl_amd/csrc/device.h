@@ -33,7 +33,9 @@ struct DevMatrix {
                               // block, one int32 delta per slot for all 64 rows
   int64_t* cmeta = nullptr;   // nblocks (row-block formats)
   int64_t colbytes = 0;
-  double2* vals = nullptr;    // stored, the values the SpMV kernels read
+  double2* vals = nullptr;    // stored, the current values (always valid)
+  const double* vals_r = nullptr;  // non-null: every value is real and this copy of the real parts is
+                                   // what the SpMV kernels stream (half the matrix bytes)
   // CSR
   int64_t* rowptr = nullptr;  // nrows+1
   int lanes_per_row = 16;     // CSR kernel: sub-wave width
@@ -113,6 +115,7 @@ int launch_spmv_plain(hipStream_t s, const DevMatrix& A, const double2* x, const
 int spmv_grid_size(const DevMatrix& A);
 extern int g_rbcsr_variant;
 extern int g_hrb_lower_last;  // HRB kernel: process the lower (conj-transposed) section after the upper one
+extern int g_real_vals;   // operator refresh: stream a real copy of the values when they are all real (1, default)
 extern int g_stencil;     // operator build: encode blocks with block-wide column distances as stencil blocks (1, default)
 extern int g_acc_defer;   // qp_cheby_step: touch the Psi accumulator every third term only (1, default) or every term (0)
 extern int g_cheby_graph; // qp_cheby_step: replay a repeated step as a hipGraph when the mat-vec grid has at most this many workgroups (0: off)
@@ -127,6 +130,7 @@ struct CoefBlock {
 };
 
 // planes: vals[p] = sum_l coef[l] * plane_l[p]   (coefs: host array)
+int launch_real_part(hipStream_t s, double* out, const double2* v, int64_t n, Stats* st);
 int launch_combine_planes(hipStream_t s, double2* vals, const double2* const* planes_dev, const double2* coefs,
                           int nplanes, int64_t n, Stats* st);
 

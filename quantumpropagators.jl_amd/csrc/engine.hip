@@ -91,6 +91,9 @@ struct qp_operator {
   std::vector<double2*> planes;   // device value planes, one per term, layout of A.vals
   double2** planes_dev = nullptr;
   double2* combined = nullptr;    // device, allocated on first non-trivial coefficient set
+  bool planes_real = false;       // every value of every term has a zero imaginary part
+  double* real_vals = nullptr;    // device copy of the real parts of the current values (see DevMatrix::vals_r)
+  const double2* real_of = nullptr;  // the complex array real_vals was extracted from, when still valid
   std::vector<cplx> coeffs;
   cplx scale = 1.0;
 };
@@ -248,6 +251,10 @@ int qp_tuning_set(const char* key, int value) {
   }
   if (std::strcmp(key, "hrb_lower_last") == 0) {
     qp::g_hrb_lower_last = value;
+    return QP_OK;
+  }
+  if (std::strcmp(key, "real_vals") == 0) {
+    qp::g_real_vals = value;
     return QP_OK;
   }
   if (std::strcmp(key, "stencil") == 0) {
@@ -493,6 +500,10 @@ static int operator_free_device(qp_operator* op) {
   op->planes.clear();
   if (op->planes_dev) (void)hipFree(op->planes_dev);
   if (op->combined) (void)hipFree(op->combined);
+  if (op->real_vals) (void)hipFree(op->real_vals);
+  op->real_vals = nullptr;
+  op->real_of = nullptr;
+  op->A.vals_r = nullptr;
   if (op->A.bptr) (void)hipFree(op->A.bptr);
   if (op->A.rowptr) (void)hipFree(op->A.rowptr);
   if (op->A.cols) (void)hipFree(op->A.cols);
@@ -861,6 +872,13 @@ static int operator_build_device(qp_operator* op, int format, const std::vector<
   }
 
   // ---- value planes ----
+  op->planes_real = true;
+  for (const auto& pv : planes_csr)
+    for (const cplx& v : pv)
+      if (v.imag() != 0.0) {
+        op->planes_real = false;
+        break;
+      }
   std::vector<cplx> hplane((size_t)std::max<int64_t>(A.stored, 1));
   for (int l = 0; l < nops; ++l) {
     std::fill(hplane.begin(), hplane.end(), cplx(0.0));
@@ -1055,12 +1073,24 @@ static int operator_refresh(qp_operator* op) {
   }
   if (op->nops == 1 && all_one) {
     op->A.vals = op->planes[0];
-    return QP_OK;
+  } else {
+    if (!op->combined) QP_CHECK(dev_alloc(&op->combined, (size_t)op->A.stored));
+    QP_CHECK(qp::launch_combine_planes(ctx->stream, op->combined, op->planes_dev, eff.data(), op->nops, op->A.stored,
+                                       &ctx->stats));
+    op->A.vals = op->combined;
+    op->real_of = nullptr;   // rewritten
   }
-  if (!op->combined) QP_CHECK(dev_alloc(&op->combined, (size_t)op->A.stored));
-  QP_CHECK(qp::launch_combine_planes(ctx->stream, op->combined, op->planes_dev, eff.data(), op->nops, op->A.stored,
-                                     &ctx->stats));
-  op->A.vals = op->combined;
+  // real terms with real coefficients: the mat-vec kernels stream a real copy (8 instead of 16
+  // bytes per value); everything else keeps reading the complex array
+  op->A.vals_r = nullptr;
+  if (qp::g_real_vals && op->planes_real && all_real && op->A.stored > 0) {
+    if (!op->real_vals) QP_CHECK(dev_alloc(&op->real_vals, (size_t)op->A.stored));
+    if (op->real_of != op->A.vals) {
+      QP_CHECK(qp::launch_real_part(ctx->stream, op->real_vals, op->A.vals, op->A.stored, &ctx->stats));
+      op->real_of = (op->A.vals == op->combined) ? nullptr : op->A.vals;   // a plane never changes
+    }
+    op->A.vals_r = op->real_vals;
+  }
   return QP_OK;
 }
 
@@ -1532,7 +1562,7 @@ int qp_cheby_step(qp_cheby* w, qp_operator* op, qp_state* psi, const double* a, 
   bool done = false;
   if (qp::g_cheby_graph && !check_normalization && ctx->stream != nullptr && ctx->stream != hipStreamLegacy) {
     qp_cheby::GraphKey key;
-    key.vals = A.vals;
+    key.vals = A.vals_r ? (const void*)A.vals_r : (const void*)A.vals;
     key.cols = A.cols;
     key.rowptr = A.format == QP_FMT_CSR ? (const void*)A.rowptr : (const void*)A.bptr;
     key.psi = psi->d;

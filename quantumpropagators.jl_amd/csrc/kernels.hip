@@ -214,6 +214,13 @@ __device__ __forceinline__ double2 ld_val(const double2* p) {
   }
   return *p;
 }
+// real-valued operators (all terms and coefficients real: half the matrix bytes); the value
+// enters the same complex FMA sequence with a zero imaginary part, so results are identical
+template <bool NT>
+__device__ __forceinline__ double2 ld_val(const double* p) {
+  if (NT) return make_double2(__builtin_nontemporal_load(p), 0.0);
+  return make_double2(*p, 0.0);
+}
 template <bool NT>
 __device__ __forceinline__ int4 ld_col(const int4* p) {
   if (NT) {
@@ -256,11 +263,11 @@ struct LowerStencilSlot {
 
 // VAR bit 0: nt matrix loads; bit 1: row-local operands prefetched before the loop;
 // bit 2: unroll 4 quads (16 value loads in flight per lane) instead of 2
-template <class Op, int VAR>
+template <class Op, int VAR, class VT>
 __global__ __launch_bounds__(kThreads) void rbcsr_spmv_kernel(const int64_t* __restrict__ bptr,
                                                               const int64_t* __restrict__ cmeta,
                                                               const char* __restrict__ colbytes,
-                                                              const double2* __restrict__ vals,
+                                                              const VT* __restrict__ vals,
                                                               const double2* __restrict__ x,
                                                               int64_t nblocks, int64_t nrows, Op op,
                                                               const int32_t* __restrict__ block_map, SyncArgs sy) {
@@ -279,7 +286,7 @@ __global__ __launch_bounds__(kThreads) void rbcsr_spmv_kernel(const int64_t* __r
     const int64_t b = block_map ? (int64_t)block_map[idx] : idx;
     const int64_t base = bptr[b];
     const int nq = (int)((bptr[b + 1] - base) >> 8);  // width / 4
-    const double2* __restrict__ v = vals + base + lane;
+    const VT* __restrict__ v = vals + base + lane;
     const int64_t cm = cmeta[b];
     const int64_t row = b * kRB + lane;
     const int64_t rowc = row < nrows ? row : nrows - 1;
@@ -323,16 +330,17 @@ __device__ __forceinline__ void cfma_conj(double2& s, const double2 a, const dou
   s.y = fma(a.x, b.y, s.y);
   s.y = fma(-a.y, b.x, s.y);
 }
-__device__ __forceinline__ double2 ld_tr(const double2* __restrict__ vals, int pos) {
-  const double2 a = vals[pos < 0 ? 0 : pos];
+template <class VT>
+__device__ __forceinline__ double2 ld_tr(const VT* __restrict__ vals, int pos) {
+  const double2 a = ld_val<false>(vals + (pos < 0 ? 0 : pos));
   return pos < 0 ? make_double2(0.0, 0.0) : a;
 }
 
-template <class Op, int VAR>
+template <class Op, int VAR, class VT>
 __global__ __launch_bounds__(kThreads) void hrb_spmv_kernel(const int64_t* __restrict__ uptr,
                                                             const int64_t* __restrict__ ucmeta,
                                                             const char* __restrict__ ucolbytes,
-                                                            const double2* __restrict__ uvals,
+                                                            const VT* __restrict__ uvals,
                                                             const int64_t* __restrict__ lptr,
                                                             const int64_t* __restrict__ lcmeta,
                                                             const char* __restrict__ lcolbytes,
@@ -357,7 +365,7 @@ __global__ __launch_bounds__(kThreads) void hrb_spmv_kernel(const int64_t* __res
     const int64_t ubase = uptr[b], lbase = lptr[b];
     const int nuq = (int)((uptr[b + 1] - ubase) >> 8);
     const int nlq = (int)((lptr[b + 1] - lbase) >> 8);
-    const double2* __restrict__ v = uvals + ubase + lane;
+    const VT* __restrict__ v = uvals + ubase + lane;
     const int64_t ucm = ucmeta[b], lcm = lcmeta[b];
     const int4* __restrict__ lp4 = lpos4 + (lbase >> 2) + lane;
     const int64_t row = b * kRB + lane;
@@ -371,8 +379,8 @@ __global__ __launch_bounds__(kThreads) void hrb_spmv_kernel(const int64_t* __res
       for (int k = 0; k < 4 * nlq; k += 2) {
         const LowerStencilSlot e0 = ls[k], e1 = ls[k + 1];
         const int c0 = (int)rowc + e0.delta, c1 = (int)rowc + e1.delta;
-        const double2 a0 = uvals[((c0 >> 6) == e0.cb0 ? e0.pb0 : e0.pb1) + (c0 & 63)];
-        const double2 a1 = uvals[((c1 >> 6) == e1.cb0 ? e1.pb0 : e1.pb1) + (c1 & 63)];
+        const double2 a0 = ld_val<false>(uvals + (((c0 >> 6) == e0.cb0 ? e0.pb0 : e0.pb1) + (c0 & 63)));
+        const double2 a1 = ld_val<false>(uvals + (((c1 >> 6) == e1.cb0 ? e1.pb0 : e1.pb1) + (c1 & 63)));
         const double2 x0 = x[c0];
         const double2 x1 = x[c1];
         cfma_conj(s0, a0, x0);
@@ -406,10 +414,10 @@ __global__ __launch_bounds__(kThreads) void hrb_spmv_kernel(const int64_t* __res
 #pragma unroll UNR
       for (int q = 0; q < nuq; ++q) {
         const int4 c = ld_cols<NT>(ucolbytes, ucm, q, lane, (int)rowc);
-        const double2 a0 = v[(size_t)(4 * q + 0) * 64];
-        const double2 a1 = v[(size_t)(4 * q + 1) * 64];
-        const double2 a2 = v[(size_t)(4 * q + 2) * 64];
-        const double2 a3 = v[(size_t)(4 * q + 3) * 64];
+        const double2 a0 = ld_val<false>(v + (size_t)(4 * q + 0) * 64);
+        const double2 a1 = ld_val<false>(v + (size_t)(4 * q + 1) * 64);
+        const double2 a2 = ld_val<false>(v + (size_t)(4 * q + 2) * 64);
+        const double2 a3 = ld_val<false>(v + (size_t)(4 * q + 3) * 64);
         const double2 x0 = x[c.x];
         const double2 x1 = x[c.y];
         const double2 x2 = x[c.z];
@@ -441,10 +449,10 @@ __global__ __launch_bounds__(kThreads) void hrb_spmv_kernel(const int64_t* __res
 // CSR SpMV, T lanes per row (sub-wave segmented reduction by shuffles).  General
 // fallback for matrices whose row lengths vary too much for RBCSR padding.
 // ---------------------------------------------------------------------------
-template <int T, class Op>
+template <int T, class Op, class VT>
 __global__ __launch_bounds__(kThreads) void csr_spmv_kernel(const int64_t* __restrict__ rowptr,
                                                             const int32_t* __restrict__ cols,
-                                                            const double2* __restrict__ vals,
+                                                            const VT* __restrict__ vals,
                                                             const double2* __restrict__ x, int64_t nrows,
                                                             Op op) {
   __shared__ double2 lds[kThreads / 64];
@@ -458,14 +466,15 @@ __global__ __launch_bounds__(kThreads) void csr_spmv_kernel(const int64_t* __res
     double2 s1 = make_double2(0.0, 0.0);
     for (; p + 3 * T < p1; p += 4 * T) {   // four independent load chains in flight
       const int32_t c0 = cols[p], c1 = cols[p + T], c2 = cols[p + 2 * T], c3 = cols[p + 3 * T];
-      const double2 a0 = vals[p], a1 = vals[p + T], a2 = vals[p + 2 * T], a3 = vals[p + 3 * T];
+      const double2 a0 = ld_val<false>(vals + p), a1 = ld_val<false>(vals + p + T), a2 = ld_val<false>(vals + p + 2 * T),
+                    a3 = ld_val<false>(vals + p + 3 * T);
       const double2 x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
       cfma(s, a0, x0);
       cfma(s1, a1, x1);
       cfma(s, a2, x2);
       cfma(s1, a3, x3);
     }
-    for (; p < p1; p += T) cfma(s, vals[p], x[cols[p]]);
+    for (; p < p1; p += T) cfma(s, ld_val<false>(vals + p), x[cols[p]]);
     s.x += s1.x;
     s.y += s1.y;
   }
@@ -956,6 +965,7 @@ int launch_arnoldi_small(hipStream_t s, const SmallArnoldiArgs& a, Stats* st) {
 }
 
 int g_small_nnz = kSmallThreads * kSmallEpt;
+int g_real_vals = 1;
 int g_stencil = 1;
 int g_acc_defer = 1;
 int g_cheby_graph = 0;     // measured (profiles/r01/propagate_loop.txt): no gain over plain launches on ROCm 7.0, so off
@@ -1042,8 +1052,12 @@ static int launch_spmv(hipStream_t s, const DevMatrix& A, const double2* x, cons
   if (A.format == QP_FMT_RBCSR) {
 #define QP_RB_CASE(VV)                                                                                   \
   case VV:                                                                                               \
-    hipLaunchKernelGGL((rbcsr_spmv_kernel<Op, VV>), dim3(grid), dim3(kThreads), 0, s, A.bptr, A.cmeta,   \
-                       reinterpret_cast<const char*>(A.cols), A.vals, x, nblk, A.nrows, op, bmap, sy);      \
+    if (A.vals_r)                                                                                        \
+      hipLaunchKernelGGL((rbcsr_spmv_kernel<Op, VV, double>), dim3(grid), dim3(kThreads), 0, s, A.bptr, A.cmeta, \
+                         reinterpret_cast<const char*>(A.cols), A.vals_r, x, nblk, A.nrows, op, bmap, sy); \
+    else                                                                                                 \
+      hipLaunchKernelGGL((rbcsr_spmv_kernel<Op, VV, double2>), dim3(grid), dim3(kThreads), 0, s, A.bptr, A.cmeta, \
+                         reinterpret_cast<const char*>(A.cols), A.vals, x, nblk, A.nrows, op, bmap, sy);   \
     break;
     switch (g_rbcsr_variant & 7) {
       QP_RB_CASE(0)
@@ -1059,10 +1073,16 @@ static int launch_spmv(hipStream_t s, const DevMatrix& A, const double2* x, cons
   } else if (A.format == QP_FMT_HRB) {
 #define QP_HRB_CASE(VV)                                                                                  \
   case VV:                                                                                               \
-    hipLaunchKernelGGL((hrb_spmv_kernel<Op, VV>), dim3(grid), dim3(kThreads), 0, s, A.bptr, A.cmeta,     \
-                       reinterpret_cast<const char*>(A.cols), A.vals, A.lptr, A.lcmeta,                  \
-                       reinterpret_cast<const char*>(A.lcols), reinterpret_cast<const int4*>(A.lpos), x, \
-                       nblk, A.nrows, op, bmap, sy, g_hrb_lower_last);                                   \
+    if (A.vals_r)                                                                                        \
+      hipLaunchKernelGGL((hrb_spmv_kernel<Op, VV, double>), dim3(grid), dim3(kThreads), 0, s, A.bptr, A.cmeta, \
+                         reinterpret_cast<const char*>(A.cols), A.vals_r, A.lptr, A.lcmeta,              \
+                         reinterpret_cast<const char*>(A.lcols), reinterpret_cast<const int4*>(A.lpos), x, \
+                         nblk, A.nrows, op, bmap, sy, g_hrb_lower_last);                                 \
+    else                                                                                                 \
+      hipLaunchKernelGGL((hrb_spmv_kernel<Op, VV, double2>), dim3(grid), dim3(kThreads), 0, s, A.bptr, A.cmeta, \
+                         reinterpret_cast<const char*>(A.cols), A.vals, A.lptr, A.lcmeta,                \
+                         reinterpret_cast<const char*>(A.lcols), reinterpret_cast<const int4*>(A.lpos), x, \
+                         nblk, A.nrows, op, bmap, sy, g_hrb_lower_last);                                 \
     break;
     switch (g_rbcsr_variant & 7) {
       QP_HRB_CASE(0)
@@ -1078,8 +1098,12 @@ static int launch_spmv(hipStream_t s, const DevMatrix& A, const double2* x, cons
   } else {
 #define QP_CSR_CASE(TT)                                                                                  \
   case TT:                                                                                               \
-    hipLaunchKernelGGL((csr_spmv_kernel<TT, Op>), dim3(grid), dim3(kThreads), 0, s, A.rowptr, A.cols, A.vals, \
-                       x, A.nrows, op);                                                                  \
+    if (A.vals_r)                                                                                        \
+      hipLaunchKernelGGL((csr_spmv_kernel<TT, Op, double>), dim3(grid), dim3(kThreads), 0, s, A.rowptr, A.cols, \
+                         A.vals_r, x, A.nrows, op);                                                      \
+    else                                                                                                 \
+      hipLaunchKernelGGL((csr_spmv_kernel<TT, Op, double2>), dim3(grid), dim3(kThreads), 0, s, A.rowptr, A.cols, \
+                         A.vals, x, A.nrows, op);                                                        \
     break;
     switch (A.lanes_per_row) {
       QP_CSR_CASE(2)
@@ -1140,6 +1164,19 @@ __global__ __launch_bounds__(kThreads) void combine_planes_kernel(double2* __res
     for (int l = 0; l < nplanes; ++l) cfma(acc, coefs.c[l], planes[first + l][p]);
     vals[p] = acc;
   }
+}
+
+__global__ __launch_bounds__(kThreads) void real_part_kernel(double* __restrict__ out, const double2* __restrict__ v,
+                                                             int64_t n) {
+  for (int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x; p < n; p += (int64_t)gridDim.x * kThreads) out[p] = v[p].x;
+}
+
+int launch_real_part(hipStream_t s, double* out, const double2* v, int64_t n, Stats* st) {
+  if (n == 0) return QP_OK;
+  hipLaunchKernelGGL(real_part_kernel, dim3(ew_grid(n)), dim3(kThreads), 0, s, out, v, n);
+  QP_HIP(hipGetLastError());
+  if (st) st->n_launch++;
+  return QP_OK;
 }
 
 int launch_combine_planes(hipStream_t s, double2* vals, const double2* const* planes_dev, const double2* coefs,

@@ -790,3 +790,49 @@ def test_stencil_blocks_bit_identical(ctx, fmt, N):
     for _ in range(3):
         qo.cheby(ref, H, 0.4, owrk)
     assert np.linalg.norm(outs[0] - ref) < TOL
+
+
+@pytest.mark.parametrize("fmt", [L.FMT_CSR, L.FMT_RBCSR, L.FMT_HRB])
+def test_real_valued_operator_streams_real_copy(ctx, fmt):
+    """An operator whose terms and coefficients are all real is streamed from a real copy of
+    its values (8 instead of 16 bytes per entry).  The real value enters the same complex FMA
+    sequence with a zero imaginary part: mul!, cheby! and newton! are bit-identical to the
+    complex path (knob `real_vals` = 0), and a complex coefficient switches back."""
+    N = 2000
+    rp, col, val = synth.hermitian_offsets_csr(N, (1, 2, 7, 64), rho=6.0)
+    H0 = synth.to_scipy(rp, col, val.real.astype(complex), N)          # real symmetric
+    H1 = sp.diags([np.linspace(-1, 1, N)], [0], format="csr", dtype=complex)
+    psi0 = synth.random_state(N)
+    outs = []
+    for knob in (1, 0):
+        L.tuning_set("real_vals", knob)
+        try:
+            Op = L.Operator(ctx, [L.Matrix.from_scipy(ctx, H0), L.Matrix.from_scipy(ctx, H1)], ncoeffs=1, fmt=fmt)
+            res = []
+            for cval in (0.5, -0.25):
+                Op.set_coeffs([cval])
+                x, y = L.State(ctx, data=psi0), L.State(ctx, n=N)
+                Op.mul(x, y, 0.7 - 0.2j, 0.0)
+                res.append(y.numpy())
+                wrk = L.ChebyWrk(ctx, N, 16.0, -8.0, 0.3)
+                for _ in range(2):
+                    L.cheby(x, Op, 0.3, wrk)
+                res.append(x.numpy())
+                nw = L.NewtonWrk(ctx, N, m_max=8)
+                L.newton(x, Op, 0.1, nw)
+                res.append(x.numpy())
+            rp2, col2, val2 = Op.get_csr()
+            res.append(val2)
+            Op.set_coeffs([0.5 + 0.5j])          # complex coefficient: complex values again
+            x, y = L.State(ctx, data=psi0), L.State(ctx, n=N)
+            Op.mul(x, y)
+            res.append(y.numpy())
+            outs.append(res)
+        finally:
+            L.tuning_set("real_vals", 1)
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    Hc = (H0 + 0.5 * H1).tocsr()
+    assert np.linalg.norm(outs[0][0] - (0.7 - 0.2j) * (Hc @ psi0)) < 1e-12
+    Hz = (H0 + (0.5 + 0.5j) * H1).tocsr()
+    assert np.linalg.norm(outs[0][-1] - Hz @ psi0) < 1e-12

@@ -26,10 +26,13 @@ def main():
     ap.add_argument("--pattern", default="banded")
     ap.add_argument("--formats", default="rbcsr")
     ap.add_argument("--lower-last", type=int, default=0)
+    ap.add_argument("--real", action="store_true", help="real symmetric H (values streamed as fp64 instead of complex)")
     args = ap.parse_args()
     N = args.n if args.n else 1 << args.log2n
     offs = synth.BANDED_OFFSETS if args.pattern == "banded" else synth.scattered_offsets(N)
     rp, col, vals = synth.hermitian_offsets_csr(N, offsets=offs)
+    if args.real:
+        vals = vals.real.astype(np.complex128)
     ctx = L.Context(0)
     L.tuning_set("hrb_lower_last", args.lower_last)
     M = L.Matrix(ctx, N, N, rp, col, vals)

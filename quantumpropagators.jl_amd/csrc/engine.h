@@ -1,0 +1,197 @@
+// Internal header of the engine translation units (engine_*.hip): handle types behind the
+// opaque pointers of include/qprop.h and the small helpers they share.
+#pragma once
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+#include "device.h"
+
+using qp::cplx;
+using qp::DevMatrix;
+using qp::kRB;
+using qp::kRedBlocks;
+using qp::Stats;
+
+// ---------------------------------------------------------------------------
+// handle types
+// ---------------------------------------------------------------------------
+struct qp_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  Stats stats;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double2* d_part = nullptr;   // kRedBlocks partials for qp_dot / qp_norm
+  double2* h_part = nullptr;   // pinned mirror
+};
+
+struct qp_state {
+  qp_ctx* ctx;
+  double2* d;
+  int64_t n;
+  bool own;
+};
+
+struct qp_matrix {  // canonical host CSR (the result of the boundary's index work)
+  qp_ctx* ctx;
+  int64_t nrows, ncols, nnz;
+  std::vector<int64_t> rowptr;
+  std::vector<int32_t> col;
+  std::vector<cplx> vals;
+};
+
+struct HostLayoutData {
+  int format = QP_FMT_RBCSR;
+  std::vector<int64_t> bptr;   // RBCSR: all entries; HRB: upper section (c >= r)
+  std::vector<int64_t> lptr;   // HRB: lower section (c < r)
+  std::vector<int32_t> nlow;   // HRB: number of lower entries per row
+  std::vector<int64_t> cmeta, lcmeta;  // per block: (byte offset of the column section << 1) | is16
+  int64_t stored = 0, lstored = 0;
+};
+
+struct qp_operator {
+  qp_ctx* ctx = nullptr;
+  DevMatrix A;
+  HostLayoutData layout;
+  bool hermitian_planes = false;
+  // CSR-ordered mirror of the current values for the batched (SpMM) path, built lazily
+  int64_t* m_rowptr = nullptr;
+  int32_t* m_cols = nullptr;
+  int64_t* m_map = nullptr;     // position in A.vals (>= 0) or -(position)-1 for a conj-transposed value
+  double2* m_vals = nullptr;
+  uint64_t vals_epoch = 1, m_epoch = 0;
+  int nops = 0, ncoeffs = 0;
+  std::vector<int64_t> u_rowptr;  // union pattern (host), for get_csr and plane scatter
+  std::vector<int32_t> u_col;
+  std::vector<double2*> planes;   // device value planes, one per term, layout of A.vals
+  double2** planes_dev = nullptr;
+  double2* combined = nullptr;    // device, allocated on first non-trivial coefficient set
+  bool planes_real = false;       // every value of every term has a zero imaginary part
+  double* real_vals = nullptr;    // device copy of the real parts of the current values (see DevMatrix::vals_r)
+  const double2* real_of = nullptr;  // the complex array real_vals was extracted from, when still valid
+  std::vector<cplx> coeffs;
+  cplx scale = 1.0;
+};
+
+struct qp_split {   // boundary / interior partition of an operator's row blocks (multi-GPU overlap)
+  qp_operator* op = nullptr;          // identity check only; never dereferenced at destroy time
+  int device = 0;
+  int32_t* bmap_boundary = nullptr;
+  int32_t* bmap_interior = nullptr;
+  int32_t* mirror = nullptr;          // 64 * n_boundary entries: slab position or -1
+  int64_t n_boundary = 0, n_interior = 0, nsend = 0;
+  hipEvent_t ev_b = nullptr, ev_i = nullptr;
+  // in-launch hand-off boundary(m) -> interior(m+1) (see SyncArgs in device.h)
+  unsigned* counter = nullptr;        // [0] signal counter, [1] spin-timeout flag
+  unsigned signals_issued = 0;
+  unsigned wait_from_wg = 0;          // interior workgroups at or beyond this position poll
+};
+
+struct qp_krylov {
+  qp_ctx* ctx;
+  int64_t n;
+  int nvec;
+  double2* Q = nullptr;         // nvec vectors of length n, contiguous
+  double2* hess_dev = nullptr;  // nvec x nvec column major
+  double* norms_dev = nullptr;  // nvec
+  double2* part = nullptr;      // 2 x kRedBlocks ping-pong partials
+  double2* md_part = nullptr;   // kRedBlocks x 2 nvec multidot partials (low-sync MGS)
+  double2* gram = nullptr;      // nvec x nvec Gram rows <q_i|q_k>, k < i
+  int gram_rows = 0;            // rows 0 .. gram_rows-1 of `gram` describe the current basis
+  double2* hcoef = nullptr;     // 2 nvec reduced inner products of the current column
+  double2* q(int i) const { return Q + (size_t)i * n; }
+};
+
+struct qp_cheby {
+  qp_ctx* ctx;
+  int64_t n;
+  double2* bufA = nullptr;
+  double2* acc = nullptr;
+  double* chk_part = nullptr;  // per-workgroup triples (allocated on demand)
+  double* chk_out = nullptr;   // per-term triples
+  int chk_wg = 0, chk_terms = 0;
+  // hipGraph of one step's launches: replayed while the key (everything a launch argument
+  // is derived from) stays the same, rebuilt when it changes
+  struct GraphKey {
+    const void *vals = nullptr, *cols = nullptr, *rowptr = nullptr, *psi = nullptr;
+    int format = -1, variant = -1, n_coeffs = 0;
+    double dt = 0, Delta = 0, E_min = 0;
+    uint64_t a_hash = 0;
+    bool operator==(const GraphKey& o) const {
+      return vals == o.vals && cols == o.cols && rowptr == o.rowptr && psi == o.psi && format == o.format &&
+             variant == o.variant && n_coeffs == o.n_coeffs && dt == o.dt && Delta == o.Delta && E_min == o.E_min &&
+             a_hash == o.a_hash;
+    }
+  };
+  GraphKey gkey, gpending;
+  hipGraphExec_t gexec = nullptr;
+  Stats gstats;   // what one replay adds to the context's counters
+};
+
+struct qp_newton {
+  qp_ctx* ctx;
+  int64_t n;
+  int m_max;
+  qp_krylov* q = nullptr;
+  double2* v = nullptr;
+  double2* npart = nullptr;  // kRedBlocks |psi|^2 partials
+  double2* h_npart = nullptr;
+  std::vector<cplx> a, leja;
+  double radius = 0;
+  int n_a = 0, n_leja = 0, restarts = 0;
+};
+
+
+inline double2 d2(cplx z) { return make_double2(z.real(), z.imag()); }
+inline double2 d2(qp_c128 z) { return make_double2(z.re, z.im); }
+inline cplx cx(qp_c128 z) { return cplx(z.re, z.im); }
+
+inline int use(qp_ctx* ctx) {
+  QP_HIP(hipSetDevice(ctx->device));
+  return QP_OK;
+}
+
+template <class T>
+inline int dev_alloc(T** p, size_t count) {
+  *p = nullptr;
+  if (count == 0) count = 1;
+  hipError_t e = hipMalloc((void**)p, count * sizeof(T));
+  if (e != hipSuccess) return qp::fail(QP_E_ALLOC, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+  return QP_OK;
+}
+
+#define QP_CHECK(expr)           \
+  do {                           \
+    int rc__ = (expr);           \
+    if (rc__ != QP_OK) return rc__; \
+  } while (0)
+
+// sum kRedBlocks partials on the host in index order
+inline cplx sum_partials(const double2* h) {
+  double re = 0, im = 0;
+  for (int i = 0; i < kRedBlocks; ++i) {
+    re += h[i].x;
+    im += h[i].y;
+  }
+  return cplx(re, im);
+}
+
+inline int dot_sync(qp_ctx* ctx, const double2* x, const double2* y, int64_t n, cplx* out) {
+  QP_CHECK(qp::launch_dot_partials(ctx->stream, x, y, ctx->d_part, n, &ctx->stats));
+  QP_HIP(hipMemcpyAsync(ctx->h_part, ctx->d_part, kRedBlocks * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
+  QP_HIP(hipStreamSynchronize(ctx->stream));
+  *out = sum_partials(ctx->h_part);
+  return QP_OK;
+}
+
+
+// ---- shared between the engine translation units -------------------------------------
+// CSR-ordered mirror of the operator (index arrays; `gather`: also the current values)
+int operator_csr_mirror(qp_operator* op, bool gather = true);
+// which terms of a cheby! touch the Psi accumulator (include/qprop.h, qp_acc_defer)
+void acc_schedule(const double* a, int n_coeffs, bool defer, qp_acc_defer* out);
+void set_defer(qp::ChebyEpi& e, const qp_acc_defer* d);

@@ -1,0 +1,731 @@
+// cheby!: one step, batched states, one fused term (plain and boundary/interior split),
+// and the propagate step loop.
+#include "engine.h"
+
+// terms whose epilogue updates the Psi accumulator: every third one counted from the last
+// (the epilogue of term m holds v_{m-2}, v_{m-1}, v_m of the row).  The first update must
+// still see Psi = v_0, which term 2 overwrites in place, so it is forced to term <= 2.
+void acc_schedule(const double* a, int n_coeffs, bool defer, qp_acc_defer* out) {
+  const int nterms = n_coeffs - 1;
+  std::vector<char> upd((size_t)nterms + 1, defer ? 0 : 1);
+  if (defer) {
+    int m0 = nterms;
+    for (; m0 >= 1; m0 -= 3) upd[m0] = 1;
+    if (m0 + 3 == 3) upd[1] = 1;
+  }
+  int last_upd = 0;
+  for (int m = 1; m <= nterms; ++m) {
+    qp_acc_defer& d = out[m - 1];
+    d = qp_acc_defer{0, 0, 0.0, 0.0};
+    if (upd[m]) {
+      d.n_defer = m - last_upd - 1;
+      d.a_d1 = (d.n_defer >= 1) ? a[m - 1] : 0.0;
+      d.a_d2 = (d.n_defer == 2) ? a[m - 2] : 0.0;
+      last_upd = m;
+    } else {
+      d.skip = 1;
+    }
+  }
+}
+
+void set_defer(qp::ChebyEpi& e, const qp_acc_defer* d) {
+  if (!d) return;
+  e.acc_skip = d->skip ? 1 : 0;
+  e.n_defer = d->skip ? 0 : d->n_defer;
+  e.a_d1 = d->a_d1;
+  e.a_d2 = d->a_d2;
+}
+
+extern "C" {
+
+// ---------------------------------------------------------------------------
+// Chebyshev
+// ---------------------------------------------------------------------------
+int qp_cheby_create(qp_ctx* ctx, int64_t n, qp_cheby** out) {
+  QP_TRY
+  if (!ctx || !out || n < 0) return qp::fail(QP_E_BAD_ARG, "qp_cheby_create: bad arguments");
+  QP_CHECK(use(ctx));
+  auto w = std::make_unique<qp_cheby>();
+  w->ctx = ctx;
+  w->n = n;
+  QP_CHECK(dev_alloc(&w->bufA, (size_t)n));
+  QP_CHECK(dev_alloc(&w->acc, (size_t)n));
+  *out = w.release();
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_cheby_destroy(qp_cheby* w) {
+  QP_TRY
+  if (!w) return QP_OK;
+  (void)hipSetDevice(w->ctx->device);
+  (void)hipStreamSynchronize(w->ctx->stream);
+  if (w->bufA) (void)hipFree(w->bufA);
+  if (w->acc) (void)hipFree(w->acc);
+  if (w->chk_part) (void)hipFree(w->chk_part);
+  if (w->chk_out) (void)hipFree(w->chk_out);
+  if (w->gexec) (void)hipGraphExecDestroy(w->gexec);
+  delete w;
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_acc_schedule_host(const double* a, int n_coeffs, qp_acc_defer* out) {
+  if (!a || !out || n_coeffs < 2) return qp::fail(QP_E_BAD_ARG, "qp_acc_schedule_host: bad arguments");
+  acc_schedule(a, n_coeffs, true, out);
+  return QP_OK;
+}
+
+int qp_cheby_term(qp_operator* op, const qp_state* x, int64_t xoff, const qp_state* v0, qp_state* vout,
+                  const qp_state* acc_in, qp_state* acc_out, qp_c128 c, double beta, double a_prev, double a,
+                  qp_c128 phase, const qp_acc_defer* defer) {
+  QP_TRY
+  const bool skip = defer && defer->skip;
+  if (!op || !x || (!acc_out && !skip)) return qp::fail(QP_E_BAD_ARG, "qp_cheby_term: NULL argument");
+  if (defer && !skip && (defer->n_defer < 0 || defer->n_defer > 2 || (defer->n_defer > 0 && !v0 && (defer->n_defer == 2 || !acc_in))))
+    return qp::fail(QP_E_BAD_ARG, "qp_cheby_term: deferred accumulation needs v0");
+  const int64_t nr = op->A.nrows;
+  if (x->n != op->A.ncols || xoff < 0 || xoff + nr > x->n) return qp::fail(QP_E_BAD_ARG, "qp_cheby_term: x shape / offset mismatch");
+  if ((v0 && v0->n != nr) || (vout && vout->n != nr) || (acc_in && acc_in->n != nr) || (acc_out && acc_out->n != nr))
+    return qp::fail(QP_E_BAD_ARG, "qp_cheby_term: local vector length mismatch");
+  auto overlaps = [&](const qp_state* s) { return s && s->d < x->d + x->n && x->d < s->d + s->n; };
+  if (overlaps(vout) || overlaps(acc_out)) return qp::fail(QP_E_BAD_ARG, "qp_cheby_term: outputs must not overlap the gathered x");
+  QP_CHECK(use(op->ctx));
+  qp::ChebyEpi e;
+  e.xloc = x->d + xoff;
+  e.v0 = v0 ? v0->d : nullptr;
+  e.vout = vout ? vout->d : nullptr;
+  e.acc_in = (acc_in && !skip) ? acc_in->d : nullptr;
+  e.acc_out = (acc_out && !skip) ? acc_out->d : nullptr;
+  e.c = d2(c);
+  e.beta = beta;
+  e.a_prev = a_prev;
+  e.a = a;
+  e.phase = d2(phase);
+  e.apply_phase = !(phase.re == 1.0 && phase.im == 0.0);
+  e.check_partials = nullptr;
+  set_defer(e, defer);
+  return qp::launch_spmv_cheby(op->ctx->stream, op->A, x->d, e, &op->ctx->stats);
+  QP_CATCH
+}
+
+// the launches of one cheby! call (src/cheby.jl:171-211): n_coeffs - 1 fused mat-vec + term
+// kernels and, when the result does not land in Psi's buffer, one copy
+static int cheby_step_launches(qp_cheby* w, qp_operator* op, qp_state* psi, const double* a, int n_coeffs, double beta,
+                               cplx c, cplx phase, bool check_normalization) {
+  qp_ctx* ctx = op->ctx;
+  const DevMatrix& A = op->A;
+  const int nterms = n_coeffs - 1;
+  const int nwg = qp::spmv_grid_size(A);
+  double2* P = psi->d;
+  double2* B = w->bufA;
+  double2* ACC = w->acc;
+  double2* result = nullptr;
+  std::vector<qp_acc_defer> sched((size_t)nterms);
+  acc_schedule(a, n_coeffs, qp::g_acc_defer != 0, sched.data());
+  bool updated = false;   // has any term written the accumulator yet?
+  for (int m = 1; m <= nterms; ++m) {
+    const bool last = (m == nterms);
+    qp::ChebyEpi e;
+    const double2* x;
+    if (m == 1) {
+      // v0 = Psi; Psi = a1 v0; v1 = c (H v0 - beta v0); Psi += a2 v1     :171-182
+      x = P;
+      e.v0 = nullptr;
+      e.vout = last ? nullptr : B;
+      e.acc_in = nullptr;
+      e.acc_out = ACC;
+      result = ACC;
+    } else {
+      // v2 = c (H v1 - beta v1) + v0; Psi += a_i v2; rotate            :186-207
+      double2* xb = (m % 2 == 0) ? B : P;   // holds v1 (gathered)
+      double2* ob = (m % 2 == 0) ? P : B;   // holds v0, overwritten in place by v2
+      x = xb;
+      e.v0 = ob;
+      e.vout = last ? nullptr : ob;
+      e.acc_in = updated ? ACC : nullptr;
+      e.acc_out = (last && xb == B) ? P : ACC;  // P may be written only while it is not gathered
+      result = e.acc_out;
+    }
+    e.a_prev = updated ? 0.0 : a[0];
+    set_defer(e, &sched[m - 1]);
+    if (sched[m - 1].skip) {
+      e.acc_in = nullptr;
+      e.acc_out = nullptr;
+    } else {
+      updated = true;
+    }
+    e.xloc = x;
+    e.c = d2(c);
+    e.beta = beta;
+    e.a = a[m];
+    e.phase = d2(phase);
+    e.apply_phase = last ? 1 : 0;
+    // the reference checks terms i >= 3 only (inside the loop at :186)
+    e.check_partials = (check_normalization && m >= 2) ? w->chk_part : nullptr;
+    QP_CHECK(qp::launch_spmv_cheby(ctx->stream, A, x, e, &ctx->stats));
+    if (e.check_partials)
+      QP_CHECK(qp::launch_reduce_triples(ctx->stream, w->chk_part, nwg, w->chk_out + 3 * (m - 1), &ctx->stats));
+    if (m == 1) c *= 2.0;  // :184
+  }
+  if (result != P)
+    QP_HIP(hipMemcpyAsync(P, result, (size_t)psi->n * sizeof(double2), hipMemcpyDeviceToDevice, ctx->stream));
+  return QP_OK;
+}
+
+int qp_cheby_step(qp_cheby* w, qp_operator* op, qp_state* psi, const double* a, int n_coeffs, double Delta,
+                  double E_min, double dt, double wrk_dt, double limit, int check_normalization) {
+  QP_TRY
+  if (!w || !op || !psi || !a) return qp::fail(QP_E_BAD_ARG, "qp_cheby_step: NULL argument");
+  if (op->A.nrows != op->A.ncols || psi->n != op->A.nrows || w->n != psi->n)
+    return qp::fail(QP_E_BAD_ARG, "qp_cheby_step: shape mismatch");
+  // @assert abs(dt) ~ abs(wrk.dt)   (isapprox, rtol = sqrt(eps))   src/cheby.jl:157
+  {
+    const double x = std::fabs(dt), y = std::fabs(wrk_dt);
+    if (!(std::fabs(x - y) <= 1.4901161193847656e-08 * std::max(x, y)))
+      return qp::fail(QP_E_DT_MISMATCH, "wrk was initialized for dt=%g, not dt=abs(%g)", wrk_dt, dt);
+  }
+  if (n_coeffs < 2) return qp::fail(QP_E_TOO_FEW_COEFFS, "Need at least 2 Chebychev coefficients");
+  if (!(Delta > 0)) return qp::fail(QP_E_BAD_ARG, "Delta must be positive");
+  qp_ctx* ctx = op->ctx;
+  QP_CHECK(use(ctx));
+  const double beta = (Delta / 2) + E_min;                        // :156
+  cplx c = (dt > 0) ? cplx(0, -2.0) / Delta : cplx(0, 2.0) / Delta;  // :158-162
+  const cplx phase = std::exp(cplx(0, -1) * beta * dt);            // :211
+  const int nterms = n_coeffs - 1;
+  const DevMatrix& A = op->A;
+  const int nwg = qp::spmv_grid_size(A);
+  if (check_normalization) {
+    if (w->chk_wg < nwg) {
+      if (w->chk_part) QP_HIP(hipFree(w->chk_part));
+      QP_CHECK(dev_alloc(&w->chk_part, (size_t)3 * nwg));
+      w->chk_wg = nwg;
+    }
+    if (w->chk_terms < nterms) {
+      if (w->chk_out) QP_HIP(hipFree(w->chk_out));
+      QP_CHECK(dev_alloc(&w->chk_out, (size_t)3 * nterms));
+      w->chk_terms = nterms;
+    }
+  }
+  // launch-bound systems (a term takes less than its launch): replay the step as a hipGraph
+  bool done = false;
+  if (qp::g_cheby_graph && !check_normalization && ctx->stream != nullptr && ctx->stream != hipStreamLegacy) {
+    qp_cheby::GraphKey key;
+    key.vals = A.vals_r ? (const void*)A.vals_r : (const void*)A.vals;
+    key.cols = A.cols;
+    key.rowptr = A.format == QP_FMT_CSR ? (const void*)A.rowptr : (const void*)A.bptr;
+    key.psi = psi->d;
+    key.format = A.format;
+    key.variant = qp::g_rbcsr_variant;
+    key.n_coeffs = n_coeffs;
+    key.dt = dt;
+    key.Delta = Delta;
+    key.E_min = E_min;
+    uint64_t h = 1469598103934665603ull;   // FNV-1a over the coefficient bits
+    for (int i = 0; i < n_coeffs; ++i) {
+      uint64_t bits;
+      std::memcpy(&bits, &a[i], 8);
+      h = (h ^ bits) * 1099511628211ull;
+    }
+    key.a_hash = h;
+    auto replay = [&]() -> int {
+      QP_HIP(hipGraphLaunch(w->gexec, ctx->stream));
+      ctx->stats.n_graph_launch++;
+      ctx->stats.n_matvec += w->gstats.n_matvec;
+      ctx->stats.n_launch += w->gstats.n_launch;
+      ctx->stats.spmv_bytes += w->gstats.spmv_bytes;
+      return QP_OK;
+    };
+    if (w->gexec && key == w->gkey) {
+      QP_CHECK(replay());
+      done = true;
+    } else if (key == w->gpending && (int64_t)spmv_grid_size(A) <= qp::g_cheby_graph) {
+      // second identical call in a row: record it
+      hipGraph_t graph = nullptr;
+      const Stats before = ctx->stats;
+      QP_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+      const int rc = cheby_step_launches(w, op, psi, a, n_coeffs, beta, c, phase, false);
+      w->gstats = Stats();
+      w->gstats.n_matvec = ctx->stats.n_matvec - before.n_matvec;
+      w->gstats.n_launch = ctx->stats.n_launch - before.n_launch;
+      w->gstats.spmv_bytes = ctx->stats.spmv_bytes - before.spmv_bytes;
+      ctx->stats = before;
+      const hipError_t ec = hipStreamEndCapture(ctx->stream, &graph);
+      if (rc != QP_OK) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc;
+      }
+      QP_HIP(ec);
+      if (w->gexec) {
+        (void)hipGraphExecDestroy(w->gexec);
+        w->gexec = nullptr;
+      }
+      const hipError_t ei = hipGraphInstantiate(&w->gexec, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      QP_HIP(ei);
+      w->gkey = key;
+      QP_CHECK(replay());
+      done = true;
+    } else {
+      w->gpending = key;
+    }
+  }
+  if (!done) QP_CHECK(cheby_step_launches(w, op, psi, a, n_coeffs, beta, c, phase, check_normalization != 0));
+  ctx->stats.n_cheby_steps++;
+  if (check_normalization && nterms >= 2) {
+    std::vector<double> h((size_t)3 * nterms);
+    QP_HIP(hipMemcpyAsync(h.data(), w->chk_out, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    QP_HIP(hipStreamSynchronize(ctx->stream));
+    for (int m = 2; m <= nterms; ++m) {
+      const double* t = &h[3 * (m - 1)];
+      const double map_norm = std::hypot(t[0], t[1]) / (2 * t[2]);   // :195
+      if (!(map_norm <= 1.0 + limit))
+        return qp::fail(QP_E_NORMALIZATION, "Incorrect normalization (E_min=%g, Delta=%g)", E_min, Delta);
+    }
+  }
+  return QP_OK;
+  QP_CATCH
+}
+
+// ---------------------------------------------------------------------------
+// batched states (BASELINE configs[4]): panel X[i*b + s]
+// ---------------------------------------------------------------------------
+int qp_cheby_step_batched(qp_cheby* w, qp_operator* op, qp_state* psi, int batch, const double* a, int n_coeffs,
+                          double Delta, double E_min, double dt, double wrk_dt) {
+  QP_TRY
+  if (!w || !op || !psi || !a || batch < 1) return qp::fail(QP_E_BAD_ARG, "qp_cheby_step_batched: bad arguments");
+  const int64_t n = op->A.nrows;
+  if (op->A.nrows != op->A.ncols || psi->n != n * batch || w->n != psi->n)
+    return qp::fail(QP_E_BAD_ARG, "qp_cheby_step_batched: shape mismatch (operator %lld, batch %d, panel %lld)",
+                    (long long)n, batch, (long long)psi->n);
+  {
+    const double x = std::fabs(dt), y = std::fabs(wrk_dt);
+    if (!(std::fabs(x - y) <= 1.4901161193847656e-08 * std::max(x, y)))
+      return qp::fail(QP_E_DT_MISMATCH, "wrk was initialized for dt=%g, not dt=abs(%g)", wrk_dt, dt);
+  }
+  if (n_coeffs < 2) return qp::fail(QP_E_TOO_FEW_COEFFS, "Need at least 2 Chebychev coefficients");
+  if (!(Delta > 0)) return qp::fail(QP_E_BAD_ARG, "Delta must be positive");
+  qp_ctx* ctx = op->ctx;
+  QP_CHECK(use(ctx));
+  QP_CHECK(operator_csr_mirror(op));
+  const double beta = (Delta / 2) + E_min;
+  cplx c = (dt > 0) ? cplx(0, -2.0) / Delta : cplx(0, 2.0) / Delta;
+  const cplx phase = std::exp(cplx(0, -1) * beta * dt);
+  const int nterms = n_coeffs - 1;
+  double2* P = psi->d;
+  double2* B = w->bufA;
+  double2* ACC = w->acc;
+  double2* result = nullptr;
+  std::vector<qp_acc_defer> sched((size_t)nterms);
+  acc_schedule(a, n_coeffs, qp::g_acc_defer != 0, sched.data());
+  bool updated = false;
+  for (int m = 1; m <= nterms; ++m) {   // same buffer rotation as qp_cheby_step, element = (row, state)
+    const bool last = (m == nterms);
+    qp::ChebyEpi e;
+    const double2* x;
+    if (m == 1) {
+      x = P;
+      e.v0 = nullptr;
+      e.vout = last ? nullptr : B;
+      e.acc_in = nullptr;
+      e.acc_out = ACC;
+      result = ACC;
+    } else {
+      double2* xb = (m % 2 == 0) ? B : P;
+      double2* ob = (m % 2 == 0) ? P : B;
+      x = xb;
+      e.v0 = ob;
+      e.vout = last ? nullptr : ob;
+      e.acc_in = updated ? ACC : nullptr;
+      e.acc_out = (last && xb == B) ? P : ACC;
+      result = e.acc_out;
+    }
+    e.a_prev = updated ? 0.0 : a[0];
+    set_defer(e, &sched[(size_t)m - 1]);
+    if (sched[(size_t)m - 1].skip) {
+      e.acc_in = nullptr;
+      e.acc_out = nullptr;
+    } else {
+      updated = true;
+    }
+    e.xloc = x;
+    e.c = d2(c);
+    e.beta = beta;
+    e.a = a[m];
+    e.phase = d2(phase);
+    e.apply_phase = last ? 1 : 0;
+    e.check_partials = nullptr;
+    QP_CHECK(qp::launch_spmm_cheby(ctx->stream, op->m_rowptr, op->m_cols, op->m_vals, x, n, op->A.nnz, batch, e,
+                                   &ctx->stats));
+    if (m == 1) c *= 2.0;
+  }
+  if (result != P) QP_HIP(hipMemcpyAsync(P, result, (size_t)psi->n * sizeof(double2), hipMemcpyDeviceToDevice, ctx->stream));
+  ctx->stats.n_cheby_steps++;
+  return QP_OK;
+  QP_CATCH
+}
+
+// ---------------------------------------------------------------------------
+// boundary / interior split of one fused term (overlap of the multi-GPU exchange)
+// ---------------------------------------------------------------------------
+int qp_split_create(qp_operator* op, const int64_t* send_rows, int64_t nsend, qp_split** out) {
+  QP_TRY
+  if (!op || !out || nsend < 0 || (nsend > 0 && !send_rows)) return qp::fail(QP_E_BAD_ARG, "qp_split_create: bad arguments");
+  const DevMatrix& A = op->A;
+  if (A.format != QP_FMT_RBCSR && A.format != QP_FMT_HRB)
+    return qp::fail(QP_E_BAD_ARG, "qp_split_create needs a row-block device format (got %d)", A.format);
+  QP_CHECK(use(op->ctx));
+  const auto& ur = op->u_rowptr;
+  const auto& uc = op->u_col;
+  std::vector<char> is_boundary((size_t)A.nblocks, 0);
+  std::vector<int32_t> slot_of_row((size_t)A.nrows, -1);
+  for (int64_t i = 0; i < nsend; ++i) {
+    const int64_t r = send_rows[i];
+    if (r < 0 || r >= A.nrows) return qp::fail(QP_E_BAD_ARG, "send row %lld out of range", (long long)r);
+    if (slot_of_row[r] >= 0) return qp::fail(QP_E_BAD_ARG, "send row %lld listed twice", (long long)r);
+    slot_of_row[r] = (int32_t)i;
+    is_boundary[r / kRB] = 1;
+  }
+  for (int64_t r = 0; r < A.nrows; ++r)   // rows that read a ghost column must wait for the exchange
+    if (ur[r + 1] > ur[r] && uc[ur[r + 1] - 1] >= A.nrows) is_boundary[r / kRB] = 1;
+  // interior blocks that exchange data with boundary rows inside the local block (they gather
+  // from boundary rows, or boundary rows gather from them) are listed last: only they have to
+  // wait for the boundary launch of the previous term
+  std::vector<char> adjacent((size_t)A.nblocks, 0);
+  for (int64_t r = 0; r < A.nrows; ++r) {
+    const bool rb_ = is_boundary[r / kRB];
+    for (int64_t p = ur[r]; p < ur[r + 1]; ++p) {
+      const int64_t c = uc[p];
+      if (c >= A.nrows) continue;
+      const bool cb = is_boundary[c / kRB];
+      if (rb_ && !cb) adjacent[c / kRB] = 1;
+      if (!rb_ && cb) adjacent[r / kRB] = 1;
+    }
+  }
+  std::vector<int32_t> bb, bi, bi_adj;
+  for (int64_t b = 0; b < A.nblocks; ++b) {
+    if (is_boundary[b]) bb.push_back((int32_t)b);
+    else if (adjacent[b]) bi_adj.push_back((int32_t)b);
+    else bi.push_back((int32_t)b);
+  }
+  const unsigned wait_from_wg = (unsigned)(bi.size() / (qp::kThreads / 64));
+  bi.insert(bi.end(), bi_adj.begin(), bi_adj.end());
+  std::vector<int32_t> mirror(bb.size() * kRB + 1, -1);
+  for (size_t k = 0; k < bb.size(); ++k)
+    for (int l = 0; l < kRB; ++l) {
+      const int64_t r = (int64_t)bb[k] * kRB + l;
+      if (r < A.nrows) mirror[k * kRB + l] = slot_of_row[r];
+    }
+  auto sp = std::make_unique<qp_split>();
+  sp->op = op;
+  sp->device = op->ctx->device;
+  sp->n_boundary = (int64_t)bb.size();
+  sp->n_interior = (int64_t)bi.size();
+  sp->nsend = nsend;
+  QP_CHECK(dev_alloc(&sp->bmap_boundary, bb.size()));
+  QP_CHECK(dev_alloc(&sp->bmap_interior, bi.size()));
+  QP_CHECK(dev_alloc(&sp->mirror, mirror.size()));
+  if (!bb.empty()) QP_HIP(hipMemcpy(sp->bmap_boundary, bb.data(), bb.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (!bi.empty()) QP_HIP(hipMemcpy(sp->bmap_interior, bi.data(), bi.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  QP_HIP(hipMemcpy(sp->mirror, mirror.data(), mirror.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  QP_HIP(hipEventCreateWithFlags(&sp->ev_b, hipEventDisableTiming));
+  QP_HIP(hipEventCreateWithFlags(&sp->ev_i, hipEventDisableTiming));
+  QP_CHECK(dev_alloc(&sp->counter, 2));
+  QP_HIP(hipMemset(sp->counter, 0, 2 * sizeof(unsigned)));
+  sp->wait_from_wg = wait_from_wg;
+  *out = sp.release();
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_split_destroy(qp_split* sp) {
+  QP_TRY
+  if (!sp) return QP_OK;
+  (void)hipSetDevice(sp->device);
+  (void)hipDeviceSynchronize();
+  if (sp->bmap_boundary) (void)hipFree(sp->bmap_boundary);
+  if (sp->bmap_interior) (void)hipFree(sp->bmap_interior);
+  if (sp->mirror) (void)hipFree(sp->mirror);
+  if (sp->counter) (void)hipFree(sp->counter);
+  if (sp->ev_b) (void)hipEventDestroy(sp->ev_b);
+  if (sp->ev_i) (void)hipEventDestroy(sp->ev_i);
+  delete sp;
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_split_info(const qp_split* sp, int64_t* n_boundary_blocks, int64_t* n_interior_blocks) {
+  if (!sp) return qp::fail(QP_E_BAD_ARG, "split is NULL");
+  if (n_boundary_blocks) *n_boundary_blocks = sp->n_boundary;
+  if (n_interior_blocks) *n_interior_blocks = sp->n_interior;
+  return QP_OK;
+}
+
+/* synchronises the device; returns QP_E_INTERNAL if an in-launch wait ever timed out */
+int qp_split_check(qp_split* sp) {
+  QP_TRY
+  if (!sp) return qp::fail(QP_E_BAD_ARG, "split is NULL");
+  QP_HIP(hipSetDevice(sp->device));
+  QP_HIP(hipDeviceSynchronize());
+  unsigned h[2] = {0, 0};
+  QP_HIP(hipMemcpy(h, sp->counter, sizeof(h), hipMemcpyDeviceToHost));
+  if (h[1] != 0) return qp::fail(QP_E_INTERNAL, "an interior launch timed out waiting for its boundary launch");
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_cheby_term_split(qp_operator* op, qp_split* sp, void* boundary_stream, int first, const qp_state* x,
+                        int64_t xoff, const qp_state* v0, qp_state* vout, const qp_state* acc_in, qp_state* acc_out,
+                        qp_state* slab, qp_c128 c, double beta, double a_prev, double a, qp_c128 phase,
+                        const qp_acc_defer* defer) {
+  QP_TRY
+  const bool skip = defer && defer->skip;
+  if (!op || !sp || sp->op != op || !boundary_stream || !x || (!acc_out && !skip))
+    return qp::fail(QP_E_BAD_ARG, "qp_cheby_term_split: bad arguments");
+  if (defer && !skip && (defer->n_defer < 0 || defer->n_defer > 2 || (defer->n_defer > 0 && !v0 && (defer->n_defer == 2 || !acc_in))))
+    return qp::fail(QP_E_BAD_ARG, "qp_cheby_term_split: deferred accumulation needs v0");
+  const int64_t nr = op->A.nrows;
+  if (x->n != op->A.ncols || xoff < 0 || xoff + nr > x->n) return qp::fail(QP_E_BAD_ARG, "qp_cheby_term_split: x shape / offset mismatch");
+  if ((v0 && v0->n != nr) || (vout && vout->n != nr) || (acc_in && acc_in->n != nr) || (acc_out && acc_out->n != nr))
+    return qp::fail(QP_E_BAD_ARG, "qp_cheby_term_split: local vector length mismatch");
+  if (slab && slab->n < sp->nsend) return qp::fail(QP_E_BAD_ARG, "qp_cheby_term_split: slab too small");
+  qp_ctx* ctx = op->ctx;
+  QP_CHECK(use(ctx));
+  hipStream_t S_c = ctx->stream, S_x = (hipStream_t)boundary_stream;
+  qp::ChebyEpi e;
+  e.xloc = x->d + xoff;
+  e.v0 = v0 ? v0->d : nullptr;
+  e.vout = vout ? vout->d : nullptr;
+  e.acc_in = (acc_in && !skip) ? acc_in->d : nullptr;
+  e.acc_out = (acc_out && !skip) ? acc_out->d : nullptr;
+  e.c = d2(c);
+  e.beta = beta;
+  e.a_prev = a_prev;
+  e.a = a;
+  e.phase = d2(phase);
+  e.apply_phase = !(phase.re == 1.0 && phase.im == 0.0);
+  e.check_partials = nullptr;
+  set_defer(e, defer);
+  qp::RowSet rb{sp->bmap_boundary, sp->n_boundary, false};
+  qp::RowSet ri{sp->bmap_interior, sp->n_interior, true};
+  const bool flag_mode = (qp::g_split_mode == 1);
+  if (first && flag_mode) {
+    // the caller joined both streams: restart the signal counter (keeps it far from wrap)
+    QP_HIP(hipMemsetAsync(sp->counter, 0, sizeof(unsigned), S_c));
+    sp->signals_issued = 0;
+    QP_HIP(hipEventRecord(sp->ev_i, S_c));
+    QP_HIP(hipStreamWaitEvent(S_x, sp->ev_i, 0));
+  }
+  if (!first) {
+    // boundary(m) overwrites rows that interior(m-1) gathered from, and vice versa.  The side
+    // stream takes a queue-level event wait (its idle time is hidden); the main stream either
+    // does the same (mode 0) or lets only the adjacent workgroups of the interior launch poll
+    // the boundary launch's completion counter (mode 1: no idle gap between interior launches)
+    QP_HIP(hipStreamWaitEvent(S_x, sp->ev_i, 0));
+    if (!flag_mode) QP_HIP(hipStreamWaitEvent(S_c, sp->ev_b, 0));
+  }
+  if (flag_mode) {
+    ri.sync.wait = sp->counter;
+    ri.sync.wait_target = sp->signals_issued;      // every boundary workgroup launched so far
+    ri.sync.wait_from_wg = sp->wait_from_wg;
+    ri.sync.timeout_flag = sp->counter + 1;
+    rb.sync.signal = sp->counter;
+    sp->signals_issued += (unsigned)((sp->n_boundary + qp::kThreads / 64 - 1) / (qp::kThreads / 64));
+  }
+  qp::ChebyEpi eb = e;
+  if (slab && vout) {   // the slab carries the new term vector (what the next term gathers)
+    eb.mirror = sp->mirror;
+    eb.slab = slab->d;
+  }
+  if (sp->n_boundary > 0) QP_CHECK(qp::launch_spmv_cheby(S_x, op->A, x->d, eb, &ctx->stats, &rb));
+  if (!flag_mode) QP_HIP(hipEventRecord(sp->ev_b, S_x));
+  if (sp->n_interior > 0) QP_CHECK(qp::launch_spmv_cheby(S_c, op->A, x->d, e, &ctx->stats, &ri));
+  QP_HIP(hipEventRecord(sp->ev_i, S_c));
+  return QP_OK;
+  QP_CATCH
+}
+
+// ---------------------------------------------------------------------------
+// propagate step loop (src/propagate.jl:283-344)
+// ---------------------------------------------------------------------------
+// Small systems: the whole time grid in one persistent single-workgroup launch
+// (kernels.hip: cheby_propagate_small_kernel).  Same arguments as qp_propagate, method 0.
+static int propagate_cheby_small(qp_operator* op, qp_state* psi, const qp_prop_spec* spec, qp::SmallArgs a,
+                                 const double* dts,
+                                 const qp_c128* coeff_table, int ncoeffs, int nsteps, qp_operator* const* observables,
+                                 int nobs, qp_c128* expvals_out, qp_c128* states_out) {
+  qp_ctx* ctx = op->ctx;
+  qp_cheby* w = spec->cheby;
+  const int64_t n = psi->n;
+  const size_t rows = (size_t)nsteps + 1;
+  if (!w || !spec->a) return qp::fail(QP_E_BAD_ARG, "qp_propagate: NULL Chebychev workspace");
+  if (op->A.nrows != op->A.ncols || n != op->A.nrows || w->n != n) return qp::fail(QP_E_BAD_ARG, "qp_propagate: shape mismatch");
+  if (spec->n_coeffs < 2) return qp::fail(QP_E_TOO_FEW_COEFFS, "Need at least 2 Chebychev coefficients");
+  if (!(spec->Delta > 0)) return qp::fail(QP_E_BAD_ARG, "Delta must be positive");
+  for (int k = 0; k < nsteps; ++k) {
+    const double x = std::fabs(dts[k]), y = std::fabs(spec->wrk_dt);   // src/cheby.jl:157
+    if (!(std::fabs(x - y) <= 1.4901161193847656e-08 * std::max(x, y)))
+      return qp::fail(QP_E_DT_MISMATCH, "wrk was initialized for dt=%g, not dt=abs(%g)", spec->wrk_dt, dts[k]);
+    if ((dts[k] > 0) != (dts[0] > 0)) return qp::fail(QP_E_BAD_ARG, "qp_propagate: time steps change sign");
+  }
+  QP_CHECK(operator_csr_mirror(op));
+  for (int o = 0; o < nobs; ++o) QP_CHECK(operator_csr_mirror(observables[o]));
+  const double dt = dts[0];
+  const double beta = (spec->Delta / 2) + spec->E_min;
+  const cplx c = (dt > 0) ? cplx(0, -2.0) / spec->Delta : cplx(0, 2.0) / spec->Delta;
+
+  a.n = n;
+  a.nnz = op->A.nnz;
+  a.rowptr = op->m_rowptr;
+  a.cols = op->m_cols;
+  a.map = op->m_map;
+  a.planes = op->planes_dev;
+  a.nops = op->nops;
+  a.ncoeffs = ncoeffs;
+  a.scale = d2(op->scale);
+  a.nsteps = nsteps;
+  a.n_coeffs = spec->n_coeffs;
+  a.c = d2(c);
+  a.beta = beta;
+  a.phase = d2(std::exp(cplx(0, -1) * beta * dt));
+  a.psi = psi->d;
+  a.nobs = nobs;
+  a.check = spec->check_normalization ? 1 : 0;
+  a.limit = spec->limit;
+
+  // one staging buffer: [table | a | obs descriptors | fail | expvals | work | states]
+  std::vector<void*> owned;
+  struct Free {
+    std::vector<void*>& v;
+    ~Free() {
+      for (void* p : v) (void)hipFree(p);
+    }
+  } guard{owned};
+  auto upload = [&](const void* src, size_t bytes, void** out) -> int {
+    void* d = nullptr;
+    QP_HIP(hipMalloc(&d, std::max<size_t>(bytes, 16)));
+    owned.push_back(d);
+    if (src && bytes) QP_HIP(hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    *out = d;
+    return QP_OK;
+  };
+  void* p = nullptr;
+  QP_CHECK(upload(coeff_table, sizeof(qp_c128) * (size_t)nsteps * ncoeffs, &p));
+  a.table = static_cast<const double2*>(p);
+  QP_CHECK(upload(spec->a, sizeof(double) * (size_t)spec->n_coeffs, &p));
+  a.a = static_cast<const double*>(p);
+  std::vector<qp::SmallObs> hobs((size_t)nobs);
+  for (int o = 0; o < nobs; ++o) hobs[o] = qp::SmallObs{observables[o]->m_rowptr, observables[o]->m_cols, observables[o]->m_vals};
+  QP_CHECK(upload(hobs.data(), sizeof(qp::SmallObs) * (size_t)nobs, &p));
+  a.obs = static_cast<const qp::SmallObs*>(p);
+  QP_CHECK(upload(nullptr, sizeof(int) * 4, &p));
+  a.fail = static_cast<int*>(p);
+  QP_HIP(hipMemsetAsync(a.fail, 0, sizeof(int) * 4, ctx->stream));
+  QP_CHECK(upload(nullptr, sizeof(double2) * rows * (size_t)nobs, &p));
+  a.expvals = static_cast<double2*>(p);
+  if (states_out) {
+    QP_CHECK(upload(nullptr, sizeof(double2) * rows * (size_t)n, &p));
+    a.states = static_cast<double2*>(p);
+  }
+  QP_CHECK(qp::launch_cheby_propagate_small(ctx->stream, a, &ctx->stats));
+  ctx->stats.n_cheby_steps += nsteps;
+  int fail[4] = {0, 0, 0, 0};
+  QP_HIP(hipMemcpyAsync(fail, a.fail, sizeof(fail), hipMemcpyDeviceToHost, ctx->stream));
+  if (nobs > 0)
+    QP_HIP(hipMemcpyAsync(expvals_out, a.expvals, sizeof(double2) * rows * (size_t)nobs, hipMemcpyDeviceToHost, ctx->stream));
+  if (states_out)
+    QP_HIP(hipMemcpyAsync(states_out, a.states, sizeof(double2) * rows * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  QP_HIP(hipStreamSynchronize(ctx->stream));
+  // leave the operator as the step-by-step loop would: holding the last interval's values
+  if (ncoeffs > 0) QP_CHECK(qp_operator_set_coeffs(op, coeff_table + (size_t)(nsteps - 1) * ncoeffs, ncoeffs));
+  if (fail[0])
+    return qp::fail(QP_E_NORMALIZATION, "Incorrect normalization (E_min=%g, Delta=%g) in step %d, term %d", spec->E_min,
+                    spec->Delta, fail[1] + 1, fail[2] + 1);
+  return QP_OK;
+}
+
+int qp_propagate(qp_operator* op, qp_state* psi, const qp_prop_spec* spec, const double* dts,
+                 const qp_c128* coeff_table, int ncoeffs, int nsteps, qp_operator* const* observables, int nobs,
+                 qp_c128* expvals_out, qp_c128* states_out) {
+  QP_TRY
+  if (!op || !psi || !spec || !dts || nsteps < 0 || nobs < 0 || (nobs > 0 && (!observables || !expvals_out)))
+    return qp::fail(QP_E_BAD_ARG, "qp_propagate: bad arguments");
+  if (ncoeffs != op->ncoeffs || (ncoeffs > 0 && nsteps > 0 && !coeff_table))
+    return qp::fail(QP_E_BAD_ARG, "qp_propagate: expected %d coefficients per step", op->ncoeffs);
+  if (spec->method != 0 && spec->method != 1) return qp::fail(QP_E_BAD_ARG, "qp_propagate: bad method");
+  for (int o = 0; o < nobs; ++o)
+    if (!observables[o] || observables[o]->A.nrows != psi->n || observables[o]->A.ncols != psi->n)
+      return qp::fail(QP_E_BAD_ARG, "qp_propagate: observable %d has the wrong shape", o);
+  qp_ctx* ctx = op->ctx;
+  QP_CHECK(use(ctx));
+  const int64_t n = psi->n;
+  const size_t rows = (size_t)nsteps + 1;
+  if (spec->method == 0 && nsteps > 0 && op->A.nnz <= qp::g_small_nnz && op->nops <= 64) {
+    qp::SmallArgs plan;
+    int64_t maxrow = 0;
+    for (int64_t r = 0; r < n; ++r) maxrow = std::max<int64_t>(maxrow, op->u_rowptr[r + 1] - op->u_rowptr[r]);
+    if (qp::small_plan(n, maxrow, &plan))
+      return propagate_cheby_small(op, psi, spec, plan, dts, coeff_table, ncoeffs, nsteps, observables, nobs,
+                                   expvals_out, states_out);
+  }
+  // device staging, released at the end: observable partials and the state history
+  double2* d_part = nullptr;
+  double2* d_tmp = nullptr;
+  double2* d_states = nullptr;
+  struct Free {
+    double2 *&a, *&b, *&c;
+    ~Free() {
+      if (a) (void)hipFree(a);
+      if (b) (void)hipFree(b);
+      if (c) (void)hipFree(c);
+    }
+  } guard{d_part, d_tmp, d_states};
+  if (nobs > 0) {
+    QP_CHECK(dev_alloc(&d_part, rows * nobs * kRedBlocks));
+    QP_CHECK(dev_alloc(&d_tmp, (size_t)n));
+  }
+  if (states_out) QP_CHECK(dev_alloc(&d_states, rows * (size_t)n));
+  auto record = [&](size_t row) -> int {
+    for (int o = 0; o < nobs; ++o) {   // <psi|O|psi> = dot(psi, O psi)
+      qp::PlainEpi e;
+      e.y = d_tmp;
+      e.alpha = make_double2(1.0, 0.0);
+      e.beta = make_double2(0.0, 0.0);
+      e.beta_zero = 1;
+      QP_CHECK(qp::launch_spmv_plain(ctx->stream, observables[o]->A, psi->d, e, &ctx->stats));
+      QP_CHECK(qp::launch_dot_partials(ctx->stream, psi->d, d_tmp, d_part + (row * nobs + o) * kRedBlocks, n, &ctx->stats));
+    }
+    if (d_states)
+      QP_HIP(hipMemcpyAsync(d_states + row * (size_t)n, psi->d, (size_t)n * sizeof(double2), hipMemcpyDeviceToDevice, ctx->stream));
+    return QP_OK;
+  };
+  QP_CHECK(record(0));
+  for (int k = 0; k < nsteps; ++k) {
+    if (ncoeffs > 0) QP_CHECK(qp_operator_set_coeffs(op, coeff_table + (size_t)k * ncoeffs, ncoeffs));
+    if (spec->method == 0) {
+      QP_CHECK(qp_cheby_step(spec->cheby, op, psi, spec->a, spec->n_coeffs, spec->Delta, spec->E_min, dts[k],
+                             spec->wrk_dt, spec->limit, spec->check_normalization));
+    } else {
+      QP_CHECK(qp_newton_step(spec->newton, op, psi, dts[k], spec->func_id, spec->cb, spec->user, spec->norm_min,
+                              spec->relerr, spec->max_restarts, nullptr));
+    }
+    QP_CHECK(record((size_t)k + 1));
+  }
+  if (nobs > 0) {
+    std::vector<cplx> hp(rows * nobs * kRedBlocks);
+    QP_HIP(hipMemcpyAsync(hp.data(), d_part, hp.size() * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
+    QP_HIP(hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < rows * nobs; ++i) {
+      const cplx v = sum_partials(reinterpret_cast<const double2*>(hp.data() + i * kRedBlocks));
+      expvals_out[i] = qp_c128{v.real(), v.imag()};
+    }
+  }
+  if (states_out) {
+    QP_HIP(hipMemcpyAsync(states_out, d_states, rows * (size_t)n * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
+    QP_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  return QP_OK;
+  QP_CATCH
+}
+
+}  // extern "C"

@@ -1,0 +1,1213 @@
+// C ABI of libqprop_hip.so: handles, the Operator lazy sum, BLAS-1, and the host-side
+// drivers of cheby!, arnoldi!, newton!, ritzvals/specrange that enqueue the HIP kernels
+// of kernels.hip.  Host logic follows the reference line by line (citations inline);
+// device work is stream-ordered, with host synchronisation only where the reference
+// algorithm needs a scalar on the host (once per Newton restart, once per Arnoldi call).
+#include "engine.h"
+
+// ---------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------
+namespace qp {
+static thread_local std::string g_last_error;
+void set_error(const char* msg) { g_last_error = msg ? msg : ""; }
+int fail(int status, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return status;
+}
+}  // namespace qp
+
+// ---------------------------------------------------------------------------
+// misc
+// ---------------------------------------------------------------------------
+extern "C" {
+
+const char* qp_last_error(void) { return qp::g_last_error.c_str(); }
+
+const char* qp_status_name(int s) {
+  switch (s) {
+    case QP_OK: return "QP_OK";
+    case QP_E_BAD_ARG: return "QP_E_BAD_ARG";
+    case QP_E_HIP: return "QP_E_HIP";
+    case QP_E_DT_MISMATCH: return "QP_E_DT_MISMATCH";
+    case QP_E_TOO_FEW_COEFFS: return "QP_E_TOO_FEW_COEFFS";
+    case QP_E_NORMALIZATION: return "QP_E_NORMALIZATION";
+    case QP_E_MAX_RESTARTS: return "QP_E_MAX_RESTARTS";
+    case QP_E_DIVDIFF_UNDERFLOW: return "QP_E_DIVDIFF_UNDERFLOW";
+    case QP_E_NO_DEVICE: return "QP_E_NO_DEVICE";
+    case QP_E_ALLOC: return "QP_E_ALLOC";
+    case QP_E_INTERNAL: return "QP_E_INTERNAL";
+    case QP_E_M_MAX: return "QP_E_M_MAX";
+    default: return "QP_E_UNKNOWN";
+  }
+}
+
+int qp_version(void) { return 100; }
+
+int qp_tuning_set(const char* key, int value) {
+  if (!key) return qp::fail(QP_E_BAD_ARG, "key is NULL");
+  if (std::strcmp(key, "rbcsr_variant") == 0) {
+    qp::g_rbcsr_variant = value;
+    return QP_OK;
+  }
+  if (std::strcmp(key, "arnoldi_mode") == 0) {
+    qp::g_arnoldi_mode = value;
+    return QP_OK;
+  }
+  if (std::strcmp(key, "hrb_lower_last") == 0) {
+    qp::g_hrb_lower_last = value;
+    return QP_OK;
+  }
+  if (std::strcmp(key, "real_vals") == 0) {
+    qp::g_real_vals = value;
+    return QP_OK;
+  }
+  if (std::strcmp(key, "stencil") == 0) {
+    qp::g_stencil = value;
+    return QP_OK;
+  }
+  if (std::strcmp(key, "acc_defer") == 0) {
+    qp::g_acc_defer = value;
+    return QP_OK;
+  }
+  if (std::strcmp(key, "cheby_graph") == 0) {
+    qp::g_cheby_graph = value;
+    return QP_OK;
+  }
+  if (std::strcmp(key, "small_nnz") == 0) {
+    qp::g_small_nnz = value;
+    return QP_OK;
+  }
+  if (std::strcmp(key, "spmm_tile") == 0) {
+    qp::g_spmm_tile = value;
+    return QP_OK;
+  }
+  if (std::strcmp(key, "split_mode") == 0) {
+    qp::g_split_mode = value;
+    return QP_OK;
+  }
+  return qp::fail(QP_E_BAD_ARG, "unknown tuning key %s", key);
+}
+
+int qp_device_count(int* n_out) {
+  QP_TRY
+  if (!n_out) return qp::fail(QP_E_BAD_ARG, "n_out is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    n = 0;
+  }
+  *n_out = n;
+  return QP_OK;
+  QP_CATCH
+}
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+int qp_ctx_create(int device, void* stream, qp_ctx** out) {
+  QP_TRY
+  if (!out) return qp::fail(QP_E_BAD_ARG, "qp_ctx_create: out is NULL");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    return qp::fail(QP_E_NO_DEVICE,
+                    "no HIP device visible (%s): libqprop_hip has no CPU fallback for the prop_step! path",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+  }
+  if (device < 0 || device >= n) return qp::fail(QP_E_BAD_ARG, "device %d out of range [0,%d)", device, n);
+  QP_HIP(hipSetDevice(device));
+  auto ctx = std::make_unique<qp_ctx>();
+  ctx->device = device;
+  if (stream == QP_STREAM_NULL) {
+    ctx->stream = nullptr;   // HIP's null stream
+  } else if (stream) {
+    ctx->stream = (hipStream_t)stream;
+  } else {
+    QP_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->own_stream = true;
+  }
+  QP_HIP(hipEventCreate(&ctx->ev0));
+  QP_HIP(hipEventCreate(&ctx->ev1));
+  QP_CHECK(dev_alloc(&ctx->d_part, kRedBlocks));
+  QP_HIP(hipHostMalloc((void**)&ctx->h_part, kRedBlocks * sizeof(double2), hipHostMallocDefault));
+  *out = ctx.release();
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_ctx_destroy(qp_ctx* ctx) {
+  QP_TRY
+  if (!ctx) return QP_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->d_part) (void)hipFree(ctx->d_part);
+  if (ctx->h_part) (void)hipHostFree(ctx->h_part);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_sync(qp_ctx* ctx) {
+  QP_TRY
+  if (!ctx) return qp::fail(QP_E_BAD_ARG, "ctx is NULL");
+  QP_CHECK(use(ctx));
+  QP_HIP(hipStreamSynchronize(ctx->stream));
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_stats_get(qp_ctx* ctx, qp_stats* out) {
+  if (!ctx || !out) return qp::fail(QP_E_BAD_ARG, "qp_stats_get: NULL argument");
+  out->n_matvec = ctx->stats.n_matvec;
+  out->n_cheby_steps = ctx->stats.n_cheby_steps;
+  out->n_newton_steps = ctx->stats.n_newton_steps;
+  out->n_restarts = ctx->stats.n_restarts;
+  out->n_kernel_launches = ctx->stats.n_launch;
+  out->spmv_bytes = ctx->stats.spmv_bytes;
+  out->n_graph_launches = ctx->stats.n_graph_launch;
+  return QP_OK;
+}
+
+int qp_stats_reset(qp_ctx* ctx) {
+  if (!ctx) return qp::fail(QP_E_BAD_ARG, "ctx is NULL");
+  ctx->stats = Stats();
+  return QP_OK;
+}
+
+int qp_timer_begin(qp_ctx* ctx) {
+  QP_TRY
+  if (!ctx) return qp::fail(QP_E_BAD_ARG, "ctx is NULL");
+  QP_CHECK(use(ctx));
+  QP_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_timer_end(qp_ctx* ctx, double* elapsed_ms_out) {
+  QP_TRY
+  if (!ctx || !elapsed_ms_out) return qp::fail(QP_E_BAD_ARG, "qp_timer_end: NULL argument");
+  QP_CHECK(use(ctx));
+  QP_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+  QP_HIP(hipEventSynchronize(ctx->ev1));
+  float ms = 0;
+  QP_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  *elapsed_ms_out = ms;
+  return QP_OK;
+  QP_CATCH
+}
+
+// ---------------------------------------------------------------------------
+// matrices: canonicalise to host CSR (bit-exact index work)
+// ---------------------------------------------------------------------------
+int qp_matrix_create(qp_ctx* ctx, int64_t nrows, int64_t ncols, int64_t nnz, const int64_t* ptr,
+                     const int64_t* idx, const void* vals, int val_dtype, int layout, int index_base,
+                     int format, qp_matrix** out) {
+  QP_TRY
+  (void)format;
+  if (!ctx || !out || !ptr || (nnz > 0 && (!idx || !vals)))
+    return qp::fail(QP_E_BAD_ARG, "qp_matrix_create: NULL argument");
+  if (nrows < 0 || ncols < 0 || nnz < 0 || ncols > INT32_MAX)
+    return qp::fail(QP_E_BAD_ARG, "qp_matrix_create: bad shape %lld x %lld, nnz %lld", (long long)nrows,
+                    (long long)ncols, (long long)nnz);
+  if (index_base != 0 && index_base != 1) return qp::fail(QP_E_BAD_ARG, "index_base must be 0 or 1");
+  if (val_dtype != QP_VAL_C128 && val_dtype != QP_VAL_F64) return qp::fail(QP_E_BAD_ARG, "bad val_dtype");
+  auto m = std::make_unique<qp_matrix>();
+  m->ctx = ctx;
+  m->nrows = nrows;
+  m->ncols = ncols;
+  m->nnz = nnz;
+  m->rowptr.resize(nrows + 1);
+  m->col.resize(nnz);
+  m->vals.resize(nnz);
+  std::vector<qp_c128> cv;
+  const qp_c128* v128 = nullptr;
+  if (val_dtype == QP_VAL_F64) {
+    cv.resize(nnz);
+    const double* r = static_cast<const double*>(vals);
+    for (int64_t p = 0; p < nnz; ++p) cv[p] = qp_c128{r[p], 0.0};
+    v128 = cv.data();
+  } else {
+    v128 = static_cast<const qp_c128*>(vals);
+  }
+  if (layout == QP_LAYOUT_CSC) {
+    if (ptr[ncols] - index_base != nnz) return qp::fail(QP_E_BAD_ARG, "colptr[end] does not match nnz");
+    int st = qp::csc_to_csr(nrows, ncols, ptr, idx, v128, index_base, m->rowptr.data(), m->col.data(),
+                            reinterpret_cast<qp_c128*>(m->vals.data()));
+    if (st != QP_OK) return qp::fail(st, "qp_matrix_create: row index out of range");
+  } else if (layout == QP_LAYOUT_CSR) {
+    if (ptr[nrows] - index_base != nnz) return qp::fail(QP_E_BAD_ARG, "rowptr[end] does not match nnz");
+    for (int64_t r = 0; r <= nrows; ++r) m->rowptr[r] = ptr[r] - index_base;
+    for (int64_t r = 0; r < nrows; ++r)
+      if (m->rowptr[r + 1] < m->rowptr[r]) return qp::fail(QP_E_BAD_ARG, "rowptr not monotone at row %lld", (long long)r);
+    for (int64_t p = 0; p < nnz; ++p) {
+      int64_t c = idx[p] - index_base;
+      if (c < 0 || c >= ncols) return qp::fail(QP_E_BAD_ARG, "column index out of range at %lld", (long long)p);
+      m->col[p] = (int32_t)c;
+      m->vals[p] = cplx(v128[p].re, v128[p].im);
+    }
+    // canonical form: columns ascending within each row (stable)
+    std::vector<std::pair<int32_t, cplx>> tmp;
+    for (int64_t r = 0; r < nrows; ++r) {
+      int64_t a = m->rowptr[r], b = m->rowptr[r + 1];
+      bool sorted = true;
+      for (int64_t p = a + 1; p < b; ++p)
+        if (m->col[p] < m->col[p - 1]) { sorted = false; break; }
+      if (sorted) continue;
+      tmp.resize(b - a);
+      for (int64_t p = a; p < b; ++p) tmp[p - a] = {m->col[p], m->vals[p]};
+      std::stable_sort(tmp.begin(), tmp.end(), [](auto& x, auto& y) { return x.first < y.first; });
+      for (int64_t p = a; p < b; ++p) { m->col[p] = tmp[p - a].first; m->vals[p] = tmp[p - a].second; }
+    }
+  } else {
+    return qp::fail(QP_E_BAD_ARG, "bad layout");
+  }
+  *out = m.release();
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_matrix_destroy(qp_matrix* m) {
+  delete m;
+  return QP_OK;
+}
+
+int qp_matrix_info(const qp_matrix* m, int64_t* nrows, int64_t* ncols, int64_t* nnz, int* format,
+                   int64_t* stored_nnz) {
+  if (!m) return qp::fail(QP_E_BAD_ARG, "matrix is NULL");
+  if (nrows) *nrows = m->nrows;
+  if (ncols) *ncols = m->ncols;
+  if (nnz) *nnz = m->nnz;
+  if (format) *format = QP_FMT_CSR;
+  if (stored_nnz) *stored_nnz = m->nnz;
+  return QP_OK;
+}
+
+int qp_matrix_get_csr(const qp_matrix* m, int64_t* rowptr, int32_t* col, qp_c128* vals) {
+  if (!m || !rowptr || !col || !vals) return qp::fail(QP_E_BAD_ARG, "qp_matrix_get_csr: NULL argument");
+  std::memcpy(rowptr, m->rowptr.data(), (m->nrows + 1) * sizeof(int64_t));
+  std::memcpy(col, m->col.data(), m->nnz * sizeof(int32_t));
+  std::memcpy(vals, m->vals.data(), m->nnz * sizeof(qp_c128));
+  return QP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Operator: union pattern + value planes in HBM
+// ---------------------------------------------------------------------------
+static int operator_free_device(qp_operator* op) {
+  for (auto p : op->planes) (void)hipFree(p);
+  op->planes.clear();
+  if (op->planes_dev) (void)hipFree(op->planes_dev);
+  if (op->combined) (void)hipFree(op->combined);
+  if (op->real_vals) (void)hipFree(op->real_vals);
+  op->real_vals = nullptr;
+  op->real_of = nullptr;
+  op->A.vals_r = nullptr;
+  if (op->A.bptr) (void)hipFree(op->A.bptr);
+  if (op->A.rowptr) (void)hipFree(op->A.rowptr);
+  if (op->A.cols) (void)hipFree(op->A.cols);
+  if (op->A.cmeta) (void)hipFree(op->A.cmeta);
+  if (op->A.lcmeta) (void)hipFree(op->A.lcmeta);
+  op->A.cmeta = op->A.lcmeta = nullptr;
+  if (op->A.lptr) (void)hipFree(op->A.lptr);
+  if (op->A.lcols) (void)hipFree(op->A.lcols);
+  if (op->A.lpos) (void)hipFree(op->A.lpos);
+  if (op->m_rowptr) (void)hipFree(op->m_rowptr);
+  if (op->m_cols) (void)hipFree(op->m_cols);
+  if (op->m_map) (void)hipFree(op->m_map);
+  if (op->m_vals) (void)hipFree(op->m_vals);
+  op->m_rowptr = nullptr;
+  op->m_cols = nullptr;
+  op->m_map = nullptr;
+  op->m_vals = nullptr;
+  op->m_epoch = 0;
+  op->planes_dev = nullptr;
+  op->combined = nullptr;
+  op->A.bptr = op->A.rowptr = op->A.lptr = nullptr;
+  op->A.cols = op->A.lcols = op->A.lpos = nullptr;
+  op->A.vals = nullptr;
+  return QP_OK;
+}
+
+static int operator_free(qp_operator* op) {
+  if (!op) return QP_OK;
+  (void)hipSetDevice(op->ctx->device);
+  (void)hipStreamSynchronize(op->ctx->stream);
+  operator_free_device(op);
+  delete op;
+  return QP_OK;
+}
+
+// ---- host-side layout of the two row-block formats --------------------------------
+// Within a 64-row block, entry k of row r sits at  base + 64 k + (r % 64); column
+// indices (and the lower section's positions) are packed four k per lane.
+static inline int64_t rb_val_pos(const std::vector<int64_t>& bptr, int64_t r, int64_t k) {
+  return bptr[r / kRB] + k * kRB + (r % kRB);
+}
+static inline int64_t rb_quad_pos(const std::vector<int64_t>& bptr, int64_t r, int64_t k) {
+  return bptr[r / kRB] + (k >> 2) * (4 * kRB) + (r % kRB) * 4 + (k & 3);
+}
+
+using HostLayout = HostLayoutData;
+
+// is this canonical CSR exactly Hermitian (bitwise conj-symmetric values, symmetric
+// pattern, real diagonal, strictly increasing columns)?
+// Columns >= n (ghost columns of a row-partitioned operator in local numbering) are
+// outside the square part and always carry their values.
+static bool csr_is_hermitian(int64_t n, const std::vector<int64_t>& rp, const std::vector<int32_t>& col,
+                             const std::vector<cplx>& vals) {
+  int64_t nlower = 0, nupper = 0;
+  for (int64_t r = 0; r < n; ++r) {
+    for (int64_t p = rp[r]; p < rp[r + 1]; ++p) {
+      const int64_t c = col[p];
+      if (p > rp[r] && col[p - 1] >= c) return false;
+      if (c == r) {
+        if (vals[p].imag() != 0.0) return false;
+      } else if (c >= n) {
+        continue;
+      } else if (c > r) {
+        ++nupper;
+      } else {
+        ++nlower;
+        const int32_t* b = col.data() + rp[c];
+        const int32_t* e = col.data() + rp[c + 1];
+        const int32_t* it = std::lower_bound(b, e, (int32_t)r);
+        if (it == e || *it != r) return false;
+        const cplx t = vals[it - col.data()];
+        if (!(t.real() == vals[p].real() && t.imag() == -vals[p].imag())) return false;
+      }
+    }
+  }
+  return nlower == nupper;
+}
+
+// Encode the quad-packed column sections of all blocks: per block either int32 columns or,
+// if every entry is within +-32767 of its row, int16 deltas to the row (2 bytes of index
+// traffic per entry instead of 4).  `get(r, k, &is_pad)` returns the column of entry k of
+// row r in this section (pad entries: any valid column).
+extern "C++" {
+// 32-byte record of one slot of a *stencil* lower section (see below)
+struct LowerStencilSlot {
+  int32_t delta, cb0;
+  int64_t pb0, pb1, pad;
+};
+static_assert(sizeof(LowerStencilSlot) == 32, "layout shared with kernels.hip");
+
+// mode of a block's column section (low two bits of its meta word, the rest is the byte offset)
+enum { kColInt32 = 0, kColInt16 = 1, kColStencil = 2 };
+
+// `special(b, w, out)`: a chance to emit a block in the stencil encoding (returns true and
+// appends its bytes) before the per-entry encodings are tried.
+template <class GetCol, class Special>
+static void encode_col_sections(int64_t nrows, int64_t nblocks, const std::vector<int64_t>& ptr, GetCol get,
+                                Special special, std::vector<char>& bytes, std::vector<int64_t>& meta) {
+  meta.assign((size_t)nblocks, 0);
+  bytes.clear();
+  for (int64_t b = 0; b < nblocks; ++b) {
+    const int64_t w = (ptr[b + 1] - ptr[b]) / kRB;
+    while (bytes.size() % 32) bytes.push_back(0);
+    const size_t start = bytes.size();
+    if (w > 0 && special(b, w, bytes)) {
+      meta[b] = ((int64_t)start << 2) | kColStencil;
+      continue;
+    }
+    bool ok16 = true;
+    for (int64_t l = 0; l < kRB && ok16; ++l) {
+      const int64_t r = b * kRB + l;
+      if (r >= nrows) break;
+      for (int64_t k = 0; k < w; ++k) {
+        bool pad = false;
+        const int64_t c = get(r, k, &pad);
+        if (!pad && (c - r > 32767 || r - c > 32767)) { ok16 = false; break; }
+      }
+    }
+    meta[b] = ((int64_t)bytes.size() << 2) | (ok16 ? kColInt16 : kColInt32);
+    const size_t esz = ok16 ? 2 : 4;
+    const size_t off = bytes.size();
+    bytes.resize(off + (size_t)w * kRB * esz, 0);
+    for (int64_t l = 0; l < kRB; ++l) {
+      const int64_t r = b * kRB + l;
+      const int64_t rc = std::min(r, nrows - 1);   // the kernel decodes deltas against the clamped row
+      for (int64_t k = 0; k < w; ++k) {
+        bool pad = (r >= nrows);
+        int64_t c = pad ? rc : get(r, k, &pad);
+        if (pad && ok16) c = rc;
+        const size_t q = (size_t)(k >> 2) * (4 * kRB) + (size_t)l * 4 + (k & 3);   // quad-packed slot
+        if (ok16) {
+          const int16_t d = (int16_t)(c - rc);
+          std::memcpy(&bytes[off + q * 2], &d, 2);
+        } else {
+          const int32_t c32 = (int32_t)c;
+          std::memcpy(&bytes[off + q * 4], &c32, 4);
+        }
+      }
+    }
+  }
+  while (bytes.size() % 32) bytes.push_back(0);
+}
+
+// Stencil blocks: every row of the 64-row block has its k-th entry at the same distance
+// delta_k from the diagonal (grids, lattices, tensor-product operators: most blocks of a
+// banded H).  The section then stores w int32 deltas for the whole block instead of w x 64
+// per-lane indices: the index stream disappears from HBM traffic (wave-uniform loads).
+// Pad entries (value 0) take the block's delta too, so row + delta must stay a valid column.
+template <class GetCol>
+static bool try_stencil_upper(int64_t nrows, int64_t ncols, int64_t b, int64_t w, GetCol get, std::vector<char>& out) {
+  std::vector<int32_t> delta((size_t)w, 0);
+  for (int64_t k = 0; k < w; ++k) {
+    bool have = false;
+    int64_t d = 0;
+    for (int64_t l = 0; l < kRB; ++l) {
+      const int64_t r = b * kRB + l;
+      if (r >= nrows) break;
+      bool pad = false;
+      const int64_t c = get(r, k, &pad);
+      if (pad) continue;
+      if (!have) {
+        d = c - r;
+        have = true;
+      } else if (c - r != d) {
+        return false;
+      }
+    }
+    if (!have) d = 0;   // a slot of pure padding (width rounded up to a quad): column = row
+    if (d > INT32_MAX || d < INT32_MIN) return false;
+    // every lane (pad entries and the clamped rows of a partial last block included) must
+    // land on a valid column
+    const int64_t r_lo = b * kRB, r_hi = std::min(b * kRB + kRB - 1, nrows - 1);
+    if (r_lo + d < 0 || r_hi + d >= ncols) return false;
+    delta[(size_t)k] = (int32_t)d;
+  }
+  const size_t off = out.size();
+  out.resize(off + (size_t)w * 4);
+  std::memcpy(&out[off], delta.data(), (size_t)w * 4);
+  return true;
+}
+}  // extern "C++"
+
+static int64_t decode_col(const std::vector<char>& bytes, const std::vector<int64_t>& meta, int64_t nrows, int64_t r,
+                          int64_t k, bool lower = false) {
+  const int64_t m = meta[r / kRB];
+  const size_t off = (size_t)(m >> 2);
+  const int mode = (int)(m & 3);
+  if (mode == kColStencil) {
+    int32_t d;
+    std::memcpy(&d, &bytes[off + (size_t)k * (lower ? sizeof(LowerStencilSlot) : 4)], 4);
+    return std::min(r, nrows - 1) + d;
+  }
+  const size_t q = (size_t)(k >> 2) * (4 * kRB) + (size_t)(r % kRB) * 4 + (k & 3);
+  if (mode == kColInt16) {
+    int16_t d;
+    std::memcpy(&d, &bytes[off + q * 2], 2);
+    return std::min(r, nrows - 1) + d;
+  }
+  int32_t c;
+  std::memcpy(&c, &bytes[off + q * 4], 4);
+  return c;
+}
+
+// position in the upper value array of the conj-transposed value of lower entry k of row r,
+// for a block whose lower section is in the stencil encoding
+static int64_t decode_lower_stencil_pos(const std::vector<char>& bytes, const std::vector<int64_t>& meta, int64_t nrows,
+                                        int64_t r, int64_t k) {
+  const int64_t m = meta[r / kRB];
+  LowerStencilSlot e;
+  std::memcpy(&e, &bytes[(size_t)(m >> 2) + (size_t)k * sizeof(LowerStencilSlot)], sizeof(e));
+  const int64_t c = std::min(r, nrows - 1) + e.delta;
+  return ((c >> 6) == e.cb0 ? e.pb0 : e.pb1) + (c & 63);
+}
+
+// Build every device array of `op` for `format` from the union pattern (op->u_rowptr /
+// u_col) and the per-term values given in union-CSR order.
+static int operator_build_device(qp_operator* op, int format, const std::vector<std::vector<cplx>>& planes_csr) {
+  qp_ctx* ctx = op->ctx;
+  const auto& ur = op->u_rowptr;
+  const auto& uc = op->u_col;
+  DevMatrix& A = op->A;
+  const int64_t nrows = A.nrows;
+  const int64_t nnz = ur[nrows];
+  const int nops = (int)planes_csr.size();
+  A.nblocks = (nrows + kRB - 1) / kRB;
+  A.format = format;
+  HostLayout& Lh = op->layout;
+  Lh = HostLayout();
+  Lh.format = format;
+
+  if (format == QP_FMT_CSR) {
+    A.stored = nnz;
+    QP_CHECK(dev_alloc(&A.rowptr, ur.size()));
+    QP_HIP(hipMemcpy(A.rowptr, ur.data(), ur.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    QP_CHECK(dev_alloc(&A.cols, (size_t)nnz));
+    QP_HIP(hipMemcpy(A.cols, uc.data(), (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice));
+    double mean = nrows > 0 ? (double)nnz / (double)nrows : 1.0;
+    int T = 2;
+    while (T < 64 && T < mean) T *= 2;
+    A.lanes_per_row = T;
+  } else {
+    const bool hrb = (format == QP_FMT_HRB);
+    Lh.bptr.assign(A.nblocks + 1, 0);
+    if (hrb) {
+      Lh.lptr.assign(A.nblocks + 1, 0);
+      Lh.nlow.assign(nrows, 0);
+      for (int64_t r = 0; r < nrows; ++r) {
+        const int32_t* b = uc.data() + ur[r];
+        const int32_t* e = uc.data() + ur[r + 1];
+        Lh.nlow[r] = (int32_t)(std::lower_bound(b, e, (int32_t)r) - b);
+      }
+    }
+    for (int64_t b = 0; b < A.nblocks; ++b) {
+      int64_t wu = 0, wl = 0;
+      for (int64_t r = b * kRB; r < std::min(nrows, (b + 1) * kRB); ++r) {
+        const int64_t len = ur[r + 1] - ur[r];
+        const int64_t nl = hrb ? Lh.nlow[r] : 0;
+        wu = std::max(wu, len - nl);
+        wl = std::max(wl, nl);
+      }
+      wu = (wu + 3) & ~(int64_t)3;
+      wl = (wl + 3) & ~(int64_t)3;
+      Lh.bptr[b + 1] = Lh.bptr[b] + wu * kRB;
+      if (hrb) Lh.lptr[b + 1] = Lh.lptr[b] + wl * kRB;
+    }
+    Lh.stored = Lh.bptr[A.nblocks] + kRB;   // + one block of slack: padded lower entries read vals[0..63]
+    Lh.lstored = hrb ? Lh.lptr[A.nblocks] : 0;
+    A.stored = Lh.stored;
+    A.lstored = Lh.lstored;
+    // upper (or full) column indices
+    {
+      std::vector<char> cbytes;
+      auto get_upper = [&](int64_t r, int64_t k, bool* pad) -> int64_t {
+        const int64_t nl = hrb ? Lh.nlow[r] : 0;
+        const int64_t len = ur[r + 1] - ur[r] - nl;
+        if (k < len) return uc[ur[r] + nl + k];
+        *pad = true;
+        return (ur[r + 1] > ur[r]) ? uc[ur[r]] : 0;
+      };
+      encode_col_sections(nrows, A.nblocks, Lh.bptr, get_upper,
+                          [&](int64_t b, int64_t w, std::vector<char>& out) {
+                            return qp::g_stencil != 0 && try_stencil_upper(nrows, A.ncols, b, w, get_upper, out);
+                          },
+                          cbytes, Lh.cmeta);
+      A.colbytes = (int64_t)cbytes.size();
+      QP_CHECK(dev_alloc(reinterpret_cast<char**>(&A.cols), cbytes.size()));
+      QP_HIP(hipMemcpy(A.cols, cbytes.data(), cbytes.size(), hipMemcpyHostToDevice));
+      QP_CHECK(dev_alloc(&A.cmeta, Lh.cmeta.size()));
+      QP_HIP(hipMemcpy(A.cmeta, Lh.cmeta.data(), Lh.cmeta.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    }
+    QP_CHECK(dev_alloc(&A.bptr, Lh.bptr.size()));
+    QP_HIP(hipMemcpy(A.bptr, Lh.bptr.data(), Lh.bptr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    if (hrb) {
+      // lower section: (column, position of the conj-transposed value in the upper section)
+      std::vector<int32_t> lpos((size_t)std::max<int64_t>(A.lstored, 1), -1);
+      if (Lh.stored >= (int64_t)INT32_MAX) return qp::fail(QP_E_BAD_ARG, "Hermitian-packed format needs < 2^31 stored values per GPU");
+      for (int64_t r = 0; r < nrows; ++r) {
+        const int64_t nl = Lh.nlow[r];
+        for (int64_t k = 0; k < nl; ++k) {
+          const int64_t c = uc[ur[r] + k];
+          const int32_t* b = uc.data() + ur[c];
+          const int32_t* e = uc.data() + ur[c + 1];
+          const int64_t kk = (std::lower_bound(b, e, (int32_t)r) - b) - Lh.nlow[c];  // index of (c,r) among row c's upper entries
+          lpos[rb_quad_pos(Lh.lptr, r, k)] = (int32_t)rb_val_pos(Lh.bptr, c, kk);
+        }
+      }
+      std::vector<char> lbytes;
+      // stencil lower block: every row has a real entry in every slot, at a block-wide
+      // distance delta_k, and the conj-transposed values sit at one slot per column block
+      // (at most two column blocks per slot): position = pb(column block) + column % 64
+      auto try_stencil_lower = [&](int64_t b, int64_t w, std::vector<char>& out) -> bool {
+        if (qp::g_stencil == 0) return false;
+        std::vector<LowerStencilSlot> slots((size_t)w);
+        for (int64_t k = 0; k < w; ++k) {
+          LowerStencilSlot e{0, 0, -1, -1, 0};
+          bool have = false;
+          for (int64_t l = 0; l < kRB; ++l) {
+            const int64_t r = b * kRB + l;
+            if (r >= nrows) break;
+            if (k >= Lh.nlow[r]) return false;
+            const int64_t c = uc[ur[r] + k];
+            const int64_t base = (int64_t)lpos[rb_quad_pos(Lh.lptr, r, k)] - (c & 63);
+            if (!have) {
+              e.delta = (int32_t)(c - r);
+              e.cb0 = (int32_t)(c >> 6);
+              e.pb0 = base;
+              have = true;
+            } else if (c - r != e.delta) {
+              return false;
+            }
+            if ((c >> 6) == e.cb0) {
+              if (base != e.pb0) return false;
+            } else if ((c >> 6) == e.cb0 + 1) {
+              if (e.pb1 < 0) e.pb1 = base;
+              else if (base != e.pb1) return false;
+            } else {
+              return false;
+            }
+          }
+          if (!have) return false;
+          if (e.pb1 < 0) e.pb1 = e.pb0;
+          slots[(size_t)k] = e;
+        }
+        const size_t off = out.size();
+        out.resize(off + (size_t)w * sizeof(LowerStencilSlot));
+        std::memcpy(&out[off], slots.data(), (size_t)w * sizeof(LowerStencilSlot));
+        return true;
+      };
+      encode_col_sections(nrows, A.nblocks, Lh.lptr,
+                          [&](int64_t r, int64_t k, bool* pad) -> int64_t {
+                            if (k < Lh.nlow[r]) return uc[ur[r] + k];
+                            *pad = true;          // padded: any valid column, value masked by pos < 0
+                            return r;
+                          },
+                          try_stencil_lower, lbytes, Lh.lcmeta);
+      A.lcolbytes = (int64_t)lbytes.size();
+      QP_CHECK(dev_alloc(&A.lptr, Lh.lptr.size()));
+      QP_HIP(hipMemcpy(A.lptr, Lh.lptr.data(), Lh.lptr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+      QP_CHECK(dev_alloc(reinterpret_cast<char**>(&A.lcols), std::max<size_t>(lbytes.size(), 16)));
+      if (!lbytes.empty()) QP_HIP(hipMemcpy(A.lcols, lbytes.data(), lbytes.size(), hipMemcpyHostToDevice));
+      QP_CHECK(dev_alloc(&A.lcmeta, Lh.lcmeta.size()));
+      QP_HIP(hipMemcpy(A.lcmeta, Lh.lcmeta.data(), Lh.lcmeta.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+      QP_CHECK(dev_alloc(&A.lpos, lpos.size()));
+      QP_HIP(hipMemcpy(A.lpos, lpos.data(), lpos.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+  }
+
+  // ---- value planes ----
+  op->planes_real = true;
+  for (const auto& pv : planes_csr)
+    for (const cplx& v : pv)
+      if (v.imag() != 0.0) {
+        op->planes_real = false;
+        break;
+      }
+  std::vector<cplx> hplane((size_t)std::max<int64_t>(A.stored, 1));
+  for (int l = 0; l < nops; ++l) {
+    std::fill(hplane.begin(), hplane.end(), cplx(0.0));
+    const auto& pv = planes_csr[l];
+    for (int64_t r = 0; r < nrows; ++r) {
+      const int64_t nl = (format == QP_FMT_HRB) ? op->layout.nlow[r] : 0;
+      for (int64_t k = nl; k < ur[r + 1] - ur[r]; ++k) {
+        const int64_t pos = (format == QP_FMT_CSR) ? ur[r] + k : rb_val_pos(op->layout.bptr, r, k - nl);
+        hplane[pos] = pv[ur[r] + k];
+      }
+    }
+    double2* dp = nullptr;
+    QP_CHECK(dev_alloc(&dp, (size_t)A.stored));
+    op->planes.push_back(dp);
+    QP_HIP(hipMemcpy(dp, hplane.data(), (size_t)A.stored * sizeof(double2), hipMemcpyHostToDevice));
+  }
+  QP_CHECK(dev_alloc(&op->planes_dev, (size_t)nops));
+  QP_HIP(hipMemcpy(op->planes_dev, op->planes.data(), nops * sizeof(double2*), hipMemcpyHostToDevice));
+  A.vals = op->planes[0];
+  (void)ctx;
+  return QP_OK;
+}
+
+// current per-term values (device planes) back in union-CSR order
+static int operator_download_planes(qp_operator* op, std::vector<std::vector<cplx>>& planes_csr) {
+  const DevMatrix& A = op->A;
+  const auto& ur = op->u_rowptr;
+  const auto& uc = op->u_col;
+  const int64_t nnz = ur[A.nrows];
+  QP_HIP(hipStreamSynchronize(op->ctx->stream));
+  std::vector<cplx> hv((size_t)std::max<int64_t>(A.stored, 1));
+  planes_csr.assign(op->planes.size(), std::vector<cplx>());
+  for (size_t l = 0; l < op->planes.size(); ++l) {
+    QP_HIP(hipMemcpy(hv.data(), op->planes[l], (size_t)A.stored * sizeof(double2), hipMemcpyDeviceToHost));
+    auto& out = planes_csr[l];
+    out.assign((size_t)nnz, cplx(0));
+    for (int64_t r = 0; r < A.nrows; ++r) {
+      const int64_t nl = (A.format == QP_FMT_HRB) ? op->layout.nlow[r] : 0;
+      for (int64_t k = 0; k < ur[r + 1] - ur[r]; ++k) {
+        if (A.format == QP_FMT_CSR) {
+          out[ur[r] + k] = hv[ur[r] + k];
+        } else if (k >= nl) {
+          out[ur[r] + k] = hv[rb_val_pos(op->layout.bptr, r, k - nl)];
+        } else {  // lower entry of a Hermitian-packed operator: conj of its transpose
+          const int64_t c = uc[ur[r] + k];
+          const int32_t* b = uc.data() + ur[c];
+          const int32_t* e = uc.data() + ur[c + 1];
+          const int64_t kk = (std::lower_bound(b, e, (int32_t)r) - b) - op->layout.nlow[c];
+          out[ur[r] + k] = std::conj(hv[rb_val_pos(op->layout.bptr, c, kk)]);
+        }
+      }
+    }
+  }
+  return QP_OK;
+}
+
+static int choose_format(qp_operator* op, int requested, bool hermitian) {
+  const auto& ur = op->u_rowptr;
+  const int64_t nrows = op->A.nrows, nnz = ur[nrows];
+  const int64_t nblocks = (nrows + kRB - 1) / kRB;
+  int64_t rb_stored = 0;
+  for (int64_t b = 0; b < nblocks; ++b) {
+    int64_t w = 0;
+    for (int64_t r = b * kRB; r < std::min(nrows, (b + 1) * kRB); ++r) w = std::max(w, ur[r + 1] - ur[r]);
+    rb_stored += ((w + 3) & ~(int64_t)3) * kRB;
+  }
+  // the row-block kernels stream ~1.6x faster than the sub-wave CSR kernel at equal bytes
+  // (profiles/r01/kbench_*): accept up to 50 % padding before falling back
+  const bool rb_ok = (double)rb_stored <= 1.5 * (double)nnz + 1024.0;
+  if (requested == QP_FMT_AUTO) {
+    if (!rb_ok) return QP_FMT_CSR;
+    // few, long rows (small dense generators: the reference's test and benchmark sizes): a
+    // row block gives one wavefront 64 rows to walk entry by entry -- too few wavefronts to
+    // hide the latency.  One wavefront per row instead (CSR kernel, 64 lanes per row).
+    if (nblocks < 2048 && nnz >= 32 * nrows) return QP_FMT_CSR;
+    if (!hermitian) return QP_FMT_RBCSR;
+    // Hermitian packing pays only if the transposed values are still in the XCD's L2
+    // (4 MiB) when the lower entry is processed: the rows stream in order, so require
+    // (row - col) * bytes-per-row <= 2 MiB for at least 85 % of the lower entries.
+    // Measured (profiles/r01/kbench): banded 53.6 vs 72.1 us per term, scattered 103.8 vs 93.4.
+    const auto& uc = op->u_col;
+    const double row_bytes = 14.0 * (double)nnz / (double)std::max<int64_t>(nrows, 1) + 80.0;
+    const int64_t maxdist = (int64_t)(2.0 * 1048576.0 / row_bytes);
+    int64_t nlow = 0, nnear = 0;
+    for (int64_t r = 0; r < nrows; ++r)
+      for (int64_t p = ur[r]; p < ur[r + 1] && uc[p] < r; ++p) {
+        ++nlow;
+        if (r - uc[p] <= maxdist) ++nnear;
+      }
+    return ((double)nnear >= 0.85 * (double)nlow) ? QP_FMT_HRB : QP_FMT_RBCSR;
+  }
+  if (requested == QP_FMT_HRB && !hermitian) return -1;
+  return requested;
+}
+
+int qp_operator_create(qp_ctx* ctx, qp_matrix* const* ops, int nops, int ncoeffs, int format,
+                       qp_operator** out) {
+  QP_TRY
+  if (!ctx || !ops || !out || nops < 1 || ncoeffs < 0 || ncoeffs > nops)
+    return qp::fail(QP_E_BAD_ARG, "qp_operator_create: bad arguments");
+  for (int l = 0; l < nops; ++l) {
+    if (!ops[l]) return qp::fail(QP_E_BAD_ARG, "ops[%d] is NULL", l);
+    if (ops[l]->nrows != ops[0]->nrows || ops[l]->ncols != ops[0]->ncols)
+      return qp::fail(QP_E_BAD_ARG, "ops[%d] shape differs from ops[0]", l);
+  }
+  if (format < QP_FMT_AUTO || format > QP_FMT_HRB) return qp::fail(QP_E_BAD_ARG, "bad device format %d", format);
+  QP_CHECK(use(ctx));
+  std::unique_ptr<qp_operator, int (*)(qp_operator*)> op(new qp_operator(), operator_free);
+  op->ctx = ctx;
+  op->nops = nops;
+  op->ncoeffs = ncoeffs;
+  op->coeffs.assign(ncoeffs, cplx(1.0));
+  const int64_t nrows = ops[0]->nrows, ncols = ops[0]->ncols;
+  op->A.nrows = nrows;
+  op->A.ncols = ncols;
+
+  // ---- union sparsity pattern (sorted merge per row) ----
+  auto& ur = op->u_rowptr;
+  auto& uc = op->u_col;
+  ur.assign(nrows + 1, 0);
+  if (nops == 1) {
+    ur = ops[0]->rowptr;
+    uc = ops[0]->col;
+  } else {
+    std::vector<int32_t> merged;
+    for (int64_t r = 0; r < nrows; ++r) {
+      merged.clear();
+      for (int l = 0; l < nops; ++l)
+        merged.insert(merged.end(), ops[l]->col.begin() + ops[l]->rowptr[r], ops[l]->col.begin() + ops[l]->rowptr[r + 1]);
+      std::sort(merged.begin(), merged.end());
+      merged.erase(std::unique(merged.begin(), merged.end()), merged.end());
+      uc.insert(uc.end(), merged.begin(), merged.end());
+      ur[r + 1] = (int64_t)uc.size();
+    }
+  }
+  op->A.nnz = ur[nrows];
+
+  // ---- per-term values in union order (duplicates within a row are summed, as Julia's sparse() does) ----
+  std::vector<std::vector<cplx>> planes_csr(nops);
+  for (int l = 0; l < nops; ++l) {
+    const qp_matrix* M = ops[l];
+    auto& pv = planes_csr[l];
+    pv.assign((size_t)op->A.nnz, cplx(0));
+    for (int64_t r = 0; r < nrows; ++r) {
+      int64_t k = 0;
+      for (int64_t p = M->rowptr[r]; p < M->rowptr[r + 1]; ++p) {
+        while (uc[ur[r] + k] != M->col[p]) ++k;
+        pv[ur[r] + k] += M->vals[p];
+      }
+    }
+  }
+  bool hermitian = (ncols >= nrows) && (format == QP_FMT_AUTO || format == QP_FMT_HRB);
+  for (int l = 0; hermitian && l < nops; ++l) hermitian = csr_is_hermitian(nrows, ur, uc, planes_csr[l]);
+  op->hermitian_planes = hermitian;
+  const int fmt = choose_format(op.get(), format, hermitian);
+  if (fmt < 0) return qp::fail(QP_E_BAD_ARG, "QP_FMT_HRB requested but the operator terms are not exactly Hermitian");
+  QP_CHECK(operator_build_device(op.get(), fmt, planes_csr));
+  planes_csr.clear();
+  qp_operator* raw = op.release();
+  std::vector<qp_c128> ones(ncoeffs, qp_c128{1.0, 0.0});
+  int rc = qp_operator_set_coeffs(raw, ones.data(), ncoeffs);
+  if (rc != QP_OK) {
+    operator_free(raw);
+    return rc;
+  }
+  *out = raw;
+  return QP_OK;
+  QP_CATCH
+}
+
+static int operator_refresh(qp_operator* op) {
+  qp_ctx* ctx = op->ctx;
+  op->vals_epoch++;
+  const int drift = op->nops - op->ncoeffs;  // src/generators.jl:635
+  std::vector<double2> eff(op->nops);
+  bool all_one = true, all_real = true;
+  for (int l = 0; l < op->nops; ++l) {
+    cplx c = op->scale;
+    if (l >= drift) c *= op->coeffs[l - drift];
+    eff[l] = d2(c);
+    if (!(c == cplx(1.0))) all_one = false;
+    if (c.imag() != 0.0) all_real = false;
+  }
+  if (op->A.format == QP_FMT_HRB && !all_real) {
+    // a complex combination of Hermitian terms is not Hermitian: leave the packed format
+    // (slow path, once): re-lay the planes out as full row-block CSR
+    std::vector<std::vector<cplx>> planes_csr;
+    QP_CHECK(operator_download_planes(op, planes_csr));
+    operator_free_device(op);
+    const int fmt = choose_format(op, QP_FMT_AUTO, false);
+    QP_CHECK(operator_build_device(op, fmt, planes_csr));
+  }
+  if (op->nops == 1 && all_one) {
+    op->A.vals = op->planes[0];
+  } else {
+    if (!op->combined) QP_CHECK(dev_alloc(&op->combined, (size_t)op->A.stored));
+    QP_CHECK(qp::launch_combine_planes(ctx->stream, op->combined, op->planes_dev, eff.data(), op->nops, op->A.stored,
+                                       &ctx->stats));
+    op->A.vals = op->combined;
+    op->real_of = nullptr;   // rewritten
+  }
+  // real terms with real coefficients: the mat-vec kernels stream a real copy (8 instead of 16
+  // bytes per value); everything else keeps reading the complex array
+  op->A.vals_r = nullptr;
+  if (qp::g_real_vals && op->planes_real && all_real && op->A.stored > 0) {
+    if (!op->real_vals) QP_CHECK(dev_alloc(&op->real_vals, (size_t)op->A.stored));
+    if (op->real_of != op->A.vals) {
+      QP_CHECK(qp::launch_real_part(ctx->stream, op->real_vals, op->A.vals, op->A.stored, &ctx->stats));
+      op->real_of = (op->A.vals == op->combined) ? nullptr : op->A.vals;   // a plane never changes
+    }
+    op->A.vals_r = op->real_vals;
+  }
+  return QP_OK;
+}
+
+int qp_operator_set_coeffs(qp_operator* op, const qp_c128* coeffs, int ncoeffs) {
+  QP_TRY
+  if (!op || (ncoeffs > 0 && !coeffs)) return qp::fail(QP_E_BAD_ARG, "qp_operator_set_coeffs: NULL argument");
+  if (ncoeffs != op->ncoeffs) return qp::fail(QP_E_BAD_ARG, "expected %d coefficients, got %d", op->ncoeffs, ncoeffs);
+  QP_CHECK(use(op->ctx));
+  for (int i = 0; i < ncoeffs; ++i) op->coeffs[i] = cx(coeffs[i]);
+  return operator_refresh(op);
+  QP_CATCH
+}
+
+int qp_operator_set_scale(qp_operator* op, qp_c128 scale) {
+  QP_TRY
+  if (!op) return qp::fail(QP_E_BAD_ARG, "operator is NULL");
+  QP_CHECK(use(op->ctx));
+  op->scale = cx(scale);
+  return operator_refresh(op);
+  QP_CATCH
+}
+
+int qp_operator_destroy(qp_operator* op) {
+  QP_TRY
+  return operator_free(op);
+  QP_CATCH
+}
+
+int qp_operator_info(const qp_operator* op, int64_t* nrows, int64_t* ncols, int64_t* nnz, int* format) {
+  if (!op) return qp::fail(QP_E_BAD_ARG, "operator is NULL");
+  if (nrows) *nrows = op->A.nrows;
+  if (ncols) *ncols = op->A.ncols;
+  if (nnz) *nnz = op->A.nnz;
+  if (format) *format = op->A.format;
+  return QP_OK;
+}
+
+int qp_operator_layout_info(const qp_operator* op, int64_t out[5]) {
+  if (!op || !out) return qp::fail(QP_E_BAD_ARG, "qp_operator_layout_info: NULL argument");
+  for (int i = 0; i < 5; ++i) out[i] = 0;
+  const DevMatrix& A = op->A;
+  out[4] = A.stored;
+  if (A.format == QP_FMT_CSR) return QP_OK;
+  const HostLayout& Lh = op->layout;
+  out[0] = A.nblocks;
+  int64_t idx_bytes = A.colbytes + A.lcolbytes;
+  for (int64_t b = 0; b < A.nblocks; ++b) {
+    if ((Lh.cmeta[b] & 3) == kColStencil) out[1]++;
+    if (A.format == QP_FMT_HRB) {
+      if ((Lh.lcmeta[b] & 3) == kColStencil) out[2]++;
+      else idx_bytes += (Lh.lptr[b + 1] - Lh.lptr[b]) * (int64_t)sizeof(int32_t);
+    }
+  }
+  out[3] = idx_bytes;
+  return QP_OK;
+}
+
+// download the *device* copy (current combined values and indices) back as canonical CSR
+int qp_operator_get_csr(qp_operator* op, int64_t* rowptr, int32_t* col, qp_c128* vals) {
+  QP_TRY
+  if (!op || !rowptr || !col || !vals) return qp::fail(QP_E_BAD_ARG, "qp_operator_get_csr: NULL argument");
+  QP_CHECK(use(op->ctx));
+  const DevMatrix& A = op->A;
+  const auto& ur = op->u_rowptr;
+  QP_HIP(hipStreamSynchronize(op->ctx->stream));
+  std::vector<cplx> hv((size_t)std::max<int64_t>(A.stored, 1));
+  QP_HIP(hipMemcpy(hv.data(), A.vals, (size_t)A.stored * sizeof(double2), hipMemcpyDeviceToHost));
+  if (A.format == QP_FMT_CSR) {
+    std::vector<int64_t> rp(A.nrows + 1);
+    std::vector<int32_t> hc((size_t)std::max<int64_t>(A.nnz, 1));
+    QP_HIP(hipMemcpy(rp.data(), A.rowptr, rp.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+    QP_HIP(hipMemcpy(hc.data(), A.cols, (size_t)A.nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
+    std::memcpy(rowptr, rp.data(), rp.size() * sizeof(int64_t));
+    std::memcpy(col, hc.data(), (size_t)A.nnz * sizeof(int32_t));
+    std::memcpy(vals, hv.data(), (size_t)A.nnz * sizeof(qp_c128));
+    return QP_OK;
+  }
+  std::vector<int64_t> bptr(A.nblocks + 1), cmeta((size_t)A.nblocks), lptr, lcmeta;
+  std::vector<char> cbytes((size_t)std::max<int64_t>(A.colbytes, 1)), lbytes;
+  QP_HIP(hipMemcpy(bptr.data(), A.bptr, bptr.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+  QP_HIP(hipMemcpy(cmeta.data(), A.cmeta, cmeta.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+  QP_HIP(hipMemcpy(cbytes.data(), A.cols, (size_t)A.colbytes, hipMemcpyDeviceToHost));
+  std::vector<int32_t> lp;
+  if (A.format == QP_FMT_HRB) {
+    lptr.resize(A.nblocks + 1);
+    lcmeta.resize((size_t)A.nblocks);
+    lbytes.resize((size_t)std::max<int64_t>(A.lcolbytes, 1));
+    lp.resize((size_t)std::max<int64_t>(A.lstored, 1));
+    QP_HIP(hipMemcpy(lptr.data(), A.lptr, lptr.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+    QP_HIP(hipMemcpy(lcmeta.data(), A.lcmeta, lcmeta.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (A.lcolbytes > 0) QP_HIP(hipMemcpy(lbytes.data(), A.lcols, (size_t)A.lcolbytes, hipMemcpyDeviceToHost));
+    QP_HIP(hipMemcpy(lp.data(), A.lpos, lp.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+  }
+  for (int64_t r = 0; r <= A.nrows; ++r) rowptr[r] = ur[r];
+  for (int64_t r = 0; r < A.nrows; ++r) {
+    const int64_t nl = (A.format == QP_FMT_HRB) ? op->layout.nlow[r] : 0;
+    for (int64_t k = 0; k < ur[r + 1] - ur[r]; ++k) {
+      cplx v;
+      int64_t c;
+      if (k >= nl) {
+        c = decode_col(cbytes, cmeta, A.nrows, r, k - nl);
+        v = hv[rb_val_pos(bptr, r, k - nl)];
+      } else {
+        c = decode_col(lbytes, lcmeta, A.nrows, r, k, true);
+        const bool stencil = (lcmeta[r / kRB] & 3) == kColStencil;
+        v = std::conj(hv[stencil ? decode_lower_stencil_pos(lbytes, lcmeta, A.nrows, r, k) : lp[rb_quad_pos(lptr, r, k)]]);
+      }
+      col[ur[r] + k] = (int32_t)c;
+      vals[ur[r] + k] = qp_c128{v.real(), v.imag()};
+    }
+  }
+  return QP_OK;
+  QP_CATCH
+}
+
+// ---------------------------------------------------------------------------
+// states and BLAS-1
+// ---------------------------------------------------------------------------
+int qp_state_create(qp_ctx* ctx, int64_t n, qp_state** out) {
+  QP_TRY
+  if (!ctx || !out || n < 0) return qp::fail(QP_E_BAD_ARG, "qp_state_create: bad arguments");
+  QP_CHECK(use(ctx));
+  auto s = std::make_unique<qp_state>();
+  s->ctx = ctx;
+  s->n = n;
+  s->own = true;
+  QP_CHECK(dev_alloc(&s->d, (size_t)n));
+  QP_HIP(hipMemsetAsync(s->d, 0, (size_t)n * sizeof(double2), ctx->stream));
+  *out = s.release();
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_state_wrap(qp_ctx* ctx, void* device_ptr, int64_t n, qp_state** out) {
+  QP_TRY
+  if (!ctx || !out || !device_ptr || n < 0) return qp::fail(QP_E_BAD_ARG, "qp_state_wrap: bad arguments");
+  if ((uintptr_t)device_ptr % 16 != 0) return qp::fail(QP_E_BAD_ARG, "device pointer must be 16-byte aligned");
+  auto s = std::make_unique<qp_state>();
+  s->ctx = ctx;
+  s->d = static_cast<double2*>(device_ptr);
+  s->n = n;
+  s->own = false;
+  *out = s.release();
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_state_destroy(qp_state* s) {
+  QP_TRY
+  if (!s) return QP_OK;
+  if (s->own) {
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+    (void)hipFree(s->d);
+  }
+  delete s;
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_state_upload(qp_state* s, const qp_c128* host) {
+  QP_TRY
+  if (!s || !host) return qp::fail(QP_E_BAD_ARG, "qp_state_upload: NULL argument");
+  QP_CHECK(use(s->ctx));
+  QP_HIP(hipMemcpyAsync(s->d, host, (size_t)s->n * sizeof(double2), hipMemcpyHostToDevice, s->ctx->stream));
+  QP_HIP(hipStreamSynchronize(s->ctx->stream));
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_state_download(const qp_state* s, qp_c128* host) {
+  QP_TRY
+  if (!s || !host) return qp::fail(QP_E_BAD_ARG, "qp_state_download: NULL argument");
+  QP_CHECK(use(s->ctx));
+  QP_HIP(hipMemcpyAsync(host, s->d, (size_t)s->n * sizeof(double2), hipMemcpyDeviceToHost, s->ctx->stream));
+  QP_HIP(hipStreamSynchronize(s->ctx->stream));
+  return QP_OK;
+  QP_CATCH
+}
+
+void* qp_state_ptr(const qp_state* s) { return s ? s->d : nullptr; }
+int64_t qp_state_len(const qp_state* s) { return s ? s->n : -1; }
+
+int qp_copy(qp_state* dst, const qp_state* src) {
+  QP_TRY
+  if (!dst || !src || dst->n != src->n) return qp::fail(QP_E_BAD_ARG, "qp_copy: length mismatch");
+  QP_CHECK(use(dst->ctx));
+  if (dst->d != src->d)
+    QP_HIP(hipMemcpyAsync(dst->d, src->d, (size_t)dst->n * sizeof(double2), hipMemcpyDeviceToDevice, dst->ctx->stream));
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_scal(qp_state* x, qp_c128 alpha) {
+  QP_TRY
+  if (!x) return qp::fail(QP_E_BAD_ARG, "state is NULL");
+  QP_CHECK(use(x->ctx));
+  return qp::launch_scal(x->ctx->stream, x->d, d2(alpha), x->n, &x->ctx->stats);
+  QP_CATCH
+}
+
+int qp_axpy(qp_c128 alpha, const qp_state* x, qp_state* y) {
+  QP_TRY
+  if (!x || !y || x->n != y->n) return qp::fail(QP_E_BAD_ARG, "qp_axpy: length mismatch");
+  QP_CHECK(use(y->ctx));
+  return qp::launch_axpy(y->ctx->stream, d2(alpha), x->d, y->d, y->n, &y->ctx->stats);
+  QP_CATCH
+}
+
+int qp_fill(qp_state* x, qp_c128 alpha) {
+  QP_TRY
+  if (!x) return qp::fail(QP_E_BAD_ARG, "state is NULL");
+  QP_CHECK(use(x->ctx));
+  return qp::launch_fill(x->ctx->stream, x->d, d2(alpha), x->n, &x->ctx->stats);
+  QP_CATCH
+}
+
+int qp_dot(const qp_state* x, const qp_state* y, qp_c128* out) {
+  QP_TRY
+  if (!x || !y || !out || x->n != y->n) return qp::fail(QP_E_BAD_ARG, "qp_dot: bad arguments");
+  QP_CHECK(use(x->ctx));
+  cplx r;
+  QP_CHECK(dot_sync(x->ctx, x->d, y->d, x->n, &r));
+  *out = qp_c128{r.real(), r.imag()};
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_norm(const qp_state* x, double* out) {
+  QP_TRY
+  if (!x || !out) return qp::fail(QP_E_BAD_ARG, "qp_norm: bad arguments");
+  QP_CHECK(use(x->ctx));
+  cplx r;
+  QP_CHECK(dot_sync(x->ctx, x->d, x->d, x->n, &r));
+  *out = std::sqrt(r.real());
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_mul(qp_operator* op, const qp_state* x, qp_state* y, qp_c128 alpha, qp_c128 beta) {
+  QP_TRY
+  if (!op || !x || !y) return qp::fail(QP_E_BAD_ARG, "qp_mul: NULL argument");
+  if (x->n != op->A.ncols || y->n != op->A.nrows)
+    return qp::fail(QP_E_BAD_ARG, "qp_mul: shape mismatch (op %lld x %lld, x %lld, y %lld)", (long long)op->A.nrows,
+                    (long long)op->A.ncols, (long long)x->n, (long long)y->n);
+  if (x->d == y->d) return qp::fail(QP_E_BAD_ARG, "qp_mul: x and y must not alias");
+  QP_CHECK(use(op->ctx));
+  qp::PlainEpi e;
+  e.y = y->d;
+  e.alpha = d2(alpha);
+  e.beta = d2(beta);
+  e.beta_zero = (beta.re == 0.0 && beta.im == 0.0);
+  return qp::launch_spmv_plain(op->ctx->stream, op->A, x->d, e, &op->ctx->stats);
+  QP_CATCH
+}
+
+int qp_dot_op(const qp_state* x, qp_operator* op, const qp_state* y, qp_state* tmp, qp_c128* out) {
+  QP_TRY
+  if (!x || !op || !y || !tmp || !out) return qp::fail(QP_E_BAD_ARG, "qp_dot_op: NULL argument");
+  QP_CHECK(qp_mul(op, y, tmp, qp_c128{1, 0}, qp_c128{0, 0}));
+  return qp_dot(x, tmp, out);
+  QP_CATCH
+}
+
+}  // extern "C"
+
+// CSR-ordered mirror of the operator for the batched (SpMM) path and the persistent
+// small-system kernels, built lazily
+int operator_csr_mirror(qp_operator* op, bool gather) {
+  qp_ctx* ctx = op->ctx;
+  const DevMatrix& A = op->A;
+  const auto& ur = op->u_rowptr;
+  const auto& uc = op->u_col;
+  const int64_t nnz = A.nnz;
+  if (!op->m_rowptr) {
+    std::vector<int64_t> map((size_t)std::max<int64_t>(nnz, 1));
+    for (int64_t r = 0; r < A.nrows; ++r) {
+      const int64_t nl = (A.format == QP_FMT_HRB) ? op->layout.nlow[r] : 0;
+      for (int64_t k = 0; k < ur[r + 1] - ur[r]; ++k) {
+        int64_t m;
+        if (A.format == QP_FMT_CSR) {
+          m = ur[r] + k;
+        } else if (k >= nl) {
+          m = rb_val_pos(op->layout.bptr, r, k - nl);
+        } else {
+          const int64_t c = uc[ur[r] + k];
+          const int32_t* b = uc.data() + ur[c];
+          const int32_t* e = uc.data() + ur[c + 1];
+          const int64_t kk = (std::lower_bound(b, e, (int32_t)r) - b) - op->layout.nlow[c];
+          m = -rb_val_pos(op->layout.bptr, c, kk) - 1;
+        }
+        map[ur[r] + k] = m;
+      }
+    }
+    QP_CHECK(dev_alloc(&op->m_rowptr, ur.size()));
+    QP_CHECK(dev_alloc(&op->m_cols, (size_t)nnz));
+    QP_CHECK(dev_alloc(&op->m_map, (size_t)nnz));
+    QP_CHECK(dev_alloc(&op->m_vals, (size_t)nnz));
+    QP_HIP(hipMemcpy(op->m_rowptr, ur.data(), ur.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    QP_HIP(hipMemcpy(op->m_cols, uc.data(), (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice));
+    QP_HIP(hipMemcpy(op->m_map, map.data(), (size_t)nnz * sizeof(int64_t), hipMemcpyHostToDevice));
+    op->m_epoch = 0;
+  }
+  if (gather && op->m_epoch != op->vals_epoch) {
+    QP_CHECK(qp::launch_gather_csr_vals(ctx->stream, op->m_vals, A.vals, op->m_map, nnz, &ctx->stats));
+    op->m_epoch = op->vals_epoch;
+  }
+  return QP_OK;
+}
+

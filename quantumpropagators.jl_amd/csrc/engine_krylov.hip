@@ -1,0 +1,583 @@
+// arnoldi!, newton!, ritzvals / specrange and the building blocks of their row-partitioned
+// variants.
+#include "engine.h"
+
+extern "C" {
+
+// ---------------------------------------------------------------------------
+// Arnoldi
+// ---------------------------------------------------------------------------
+int qp_krylov_create(qp_ctx* ctx, int64_t n, int nvec, qp_krylov** out) {
+  QP_TRY
+  if (!ctx || !out || n < 0 || nvec < 2) return qp::fail(QP_E_BAD_ARG, "qp_krylov_create: bad arguments");
+  QP_CHECK(use(ctx));
+  auto q = std::make_unique<qp_krylov>();
+  q->ctx = ctx;
+  q->n = n;
+  q->nvec = nvec;
+  QP_CHECK(dev_alloc(&q->Q, (size_t)n * nvec));
+  QP_CHECK(dev_alloc(&q->hess_dev, (size_t)nvec * nvec));
+  QP_CHECK(dev_alloc(&q->norms_dev, (size_t)nvec));
+  QP_CHECK(dev_alloc(&q->part, (size_t)2 * kRedBlocks));
+  QP_CHECK(dev_alloc(&q->md_part, (size_t)kRedBlocks * 2 * nvec));
+  QP_CHECK(dev_alloc(&q->gram, (size_t)nvec * nvec));
+  // rows that were never computed read as NaN: a use of a stale Gram row is loud, not subtle
+  QP_HIP(hipMemsetAsync(q->gram, 0xFF, sizeof(double2) * (size_t)nvec * nvec, ctx->stream));
+  QP_CHECK(dev_alloc(&q->hcoef, (size_t)2 * nvec));
+  *out = q.release();
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_krylov_destroy(qp_krylov* q) {
+  QP_TRY
+  if (!q) return QP_OK;
+  (void)hipSetDevice(q->ctx->device);
+  (void)hipStreamSynchronize(q->ctx->stream);
+  if (q->Q) (void)hipFree(q->Q);
+  if (q->hess_dev) (void)hipFree(q->hess_dev);
+  if (q->norms_dev) (void)hipFree(q->norms_dev);
+  if (q->part) (void)hipFree(q->part);
+  if (q->md_part) (void)hipFree(q->md_part);
+  if (q->gram) (void)hipFree(q->gram);
+  if (q->hcoef) (void)hipFree(q->hcoef);
+  delete q;
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_krylov_download(const qp_krylov* q, int i, qp_c128* host) {
+  QP_TRY
+  if (!q || !host || i < 0 || i >= q->nvec) return qp::fail(QP_E_BAD_ARG, "qp_krylov_download: bad arguments");
+  QP_CHECK(use(q->ctx));
+  QP_HIP(hipMemcpyAsync(host, q->q(i), (size_t)q->n * sizeof(double2), hipMemcpyDeviceToHost, q->ctx->stream));
+  QP_HIP(hipStreamSynchronize(q->ctx->stream));
+  return QP_OK;
+  QP_CATCH
+}
+
+namespace {
+
+// q[j+1] = H q[j], then modified Gram-Schmidt against q[0..j] with the fused
+// axpy->dot passes; leaves |q[j+1]|^2 partials in part[(j+1)&1].  hess column `hcol`
+// (device, length >= j+1) receives dt*<q_i|q_j+1>.
+int arnoldi_column(qp_operator* op, qp_krylov* q, int j, double dt, double2* hcol) {
+  qp_ctx* ctx = op->ctx;
+  qp::PlainEpi pe;
+  pe.y = q->q(j + 1);
+  pe.alpha = make_double2(1.0, 0.0);
+  pe.beta = make_double2(0.0, 0.0);
+  pe.beta_zero = 1;
+  QP_CHECK(qp::launch_spmv_plain(ctx->stream, op->A, q->q(j), pe, &ctx->stats));  // src/arnoldi.jl:82
+  if (qp::g_arnoldi_mode == 1 && q->gram_rows >= j) {
+    // low-synchronisation MGS: same coefficients (to rounding), 3 launches per column;
+    // leaves |q[j+1]|^2 partials in part[(j+1)&1] like the sequential path.  Needs the Gram
+    // rows of the earlier basis vectors, which only this path maintains (a basis built by
+    // the persistent small-system kernel or by sequential passes continues sequentially).
+    q->gram_rows = j + 1;
+    return qp::launch_mgs_lowsync(ctx->stream, q->Q, q->n, j, q->q(j + 1), q->md_part, q->gram, q->nvec, hcol,
+                                  q->hcoef, q->part + (size_t)((j + 1) & 1) * kRedBlocks, dt, q->n, &ctx->stats);
+  }
+  q->gram_rows = std::min(q->gram_rows, j);
+  for (int i = 0; i <= j + 1; ++i) {                                              // :84-87
+    qp::MgsArgs a;
+    a.w = q->q(j + 1);
+    a.q_prev = (i > 0) ? q->q(i - 1) : nullptr;
+    a.q_cur = (i <= j) ? q->q(i) : nullptr;
+    a.part_in = q->part + (size_t)((i + 1) & 1) * kRedBlocks;
+    a.part_out = q->part + (size_t)(i & 1) * kRedBlocks;
+    a.hess_prev = (i > 0) ? hcol + (i - 1) : nullptr;
+    a.dt = dt;
+    a.n = q->n;
+    QP_CHECK(qp::launch_mgs_pass(ctx->stream, a, &ctx->stats));
+  }
+  return QP_OK;
+}
+
+}  // namespace
+
+__global__ void norm_guard_scale_kernel(double2* __restrict__ w, const double2* __restrict__ part_in, double2* hess_slot,
+                                        double* norm_slot, double dt, double norm_min, int64_t n);
+
+int qp_arnoldi(qp_operator* op, qp_krylov* q, int m, const qp_state* psi, double dt, int extended, double norm_min,
+               qp_c128* Hess, int ldh, int* m_out) {
+  QP_TRY
+  if (!op || !q || !psi || !Hess || !m_out) return qp::fail(QP_E_BAD_ARG, "qp_arnoldi: NULL argument");
+  const int dim = extended ? m + 1 : m;
+  if (m < 1 || ldh < dim || q->nvec < m + 1) return qp::fail(QP_E_BAD_ARG, "qp_arnoldi: Hess/q too small for m=%d", m);
+  if (op->A.nrows != op->A.ncols || psi->n != op->A.nrows || q->n != psi->n) return qp::fail(QP_E_BAD_ARG, "qp_arnoldi: shape mismatch");
+  qp_ctx* ctx = op->ctx;
+  QP_CHECK(use(ctx));
+  const int ldd = q->nvec;
+  std::memset(Hess, 0, sizeof(qp_c128) * (size_t)ldh * ldh);                                      // :78
+  QP_HIP(hipMemsetAsync(q->hess_dev, 0, sizeof(double2) * (size_t)ldd * ldd, ctx->stream));
+  QP_HIP(hipMemsetAsync(q->norms_dev, 0, sizeof(double) * (size_t)ldd, ctx->stream));
+  qp::SmallArgs plan;
+  bool small = false;
+  if (op->A.nnz <= qp::g_small_nnz && qp::small_arnoldi_fits(q->n, m)) {
+    int64_t maxrow = 0;
+    for (int64_t r = 0; r < q->n; ++r) maxrow = std::max<int64_t>(maxrow, op->u_rowptr[r + 1] - op->u_rowptr[r]);
+    small = qp::small_plan(q->n, maxrow, &plan);
+  }
+  if (small) {
+    // all m columns in one persistent single-workgroup launch (kernels.hip: arnoldi_small_kernel)
+    QP_CHECK(operator_csr_mirror(op, false));
+    qp::SmallArnoldiArgs a;
+    a.n = q->n;
+    a.lanes = plan.lanes;
+    a.ent = plan.ent;
+    a.rows_per_group = plan.rows_per_group;
+    a.rowptr = op->m_rowptr;
+    a.cols = op->m_cols;
+    a.map = op->m_map;
+    a.vals = op->A.vals;
+    a.start = psi->d;
+    a.Q = q->Q;
+    a.hess = q->hess_dev;
+    a.norms = q->norms_dev;
+    a.ldd = ldd;
+    a.m = m;
+    a.extended = extended;
+    a.dt = dt;
+    a.norm_min = norm_min;
+    QP_CHECK(qp::launch_arnoldi_small(ctx->stream, a, &ctx->stats));
+    q->gram_rows = 0;
+  } else {
+    QP_HIP(hipMemcpyAsync(q->q(0), psi->d, (size_t)q->n * sizeof(double2), hipMemcpyDeviceToDevice, ctx->stream));  // :79
+    for (int j = 0; j < m; ++j) {
+      double2* hcol = q->hess_dev + (size_t)j * ldd;
+      QP_CHECK(arnoldi_column(op, q, j, dt, hcol));
+      if ((j + 1 < m) || extended) {                                                               // :88-97
+        hipLaunchKernelGGL(norm_guard_scale_kernel, dim3(2048), dim3(qp::kThreads), 0, ctx->stream, q->q(j + 1),
+                           q->part + (size_t)((j + 1) & 1) * kRedBlocks, hcol + (j + 1), q->norms_dev + j, dt, norm_min,
+                           q->n);
+        QP_HIP(hipGetLastError());
+        ctx->stats.n_launch++;
+      }
+    }
+  }
+  std::vector<cplx> hh((size_t)ldd * ldd);
+  std::vector<double> hn(ldd);
+  QP_HIP(hipMemcpyAsync(hh.data(), q->hess_dev, hh.size() * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
+  QP_HIP(hipMemcpyAsync(hn.data(), q->norms_dev, hn.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  QP_HIP(hipStreamSynchronize(ctx->stream));
+  int m_eff = m;
+  for (int j = 0; j < m; ++j) {
+    if (((j + 1 < m) || extended) && hn[j] < norm_min) {  // dimensionality exhausted  :91-95
+      m_eff = j + 1;
+      break;
+    }
+  }
+  for (int j = 0; j < m_eff; ++j) {
+    const int rows = std::min(j + 2, dim);
+    for (int i = 0; i < rows; ++i) {
+      cplx v = hh[(size_t)j * ldd + i];
+      Hess[(size_t)j * ldh + i] = qp_c128{v.real(), v.imag()};
+    }
+  }
+  *m_out = m_eff;
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_arnoldi_extend(qp_operator* op, qp_krylov* q, int m, double dt, double norm_min, qp_c128* Hess, int ldh,
+                      int* extended_out) {
+  QP_TRY
+  if (!op || !q || !Hess) return qp::fail(QP_E_BAD_ARG, "qp_arnoldi_extend: NULL argument");
+  if (m < 2 || ldh < m || q->nvec < m + 1) return qp::fail(QP_E_BAD_ARG, "qp_arnoldi_extend: Hess/q too small for m=%d", m);
+  qp_ctx* ctx = op->ctx;
+  QP_CHECK(use(ctx));
+  if (extended_out) *extended_out = 0;
+  cplx n2;
+  QP_CHECK(dot_sync(ctx, q->q(m - 1), q->q(m - 1), q->n, &n2));
+  const double h = std::sqrt(n2.real());                                   // src/arnoldi.jl:116
+  if (h < norm_min) return QP_OK;                                          // :117
+  Hess[(size_t)(m - 2) * ldh + (m - 1)] = qp_c128{dt * h, 0.0};            // :118
+  const double inv = 1.0 / h;
+  QP_CHECK(qp::launch_scal(ctx->stream, q->q(m - 1), make_double2(inv, 0.0), q->n, &ctx->stats));  // :119
+  double2* hcol = q->hess_dev;  // scratch column
+  QP_CHECK(arnoldi_column(op, q, m - 1, dt, hcol));                        // :120-124
+  std::vector<cplx> hc(m);
+  QP_HIP(hipMemcpyAsync(hc.data(), hcol, (size_t)m * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
+  QP_HIP(hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < m; ++i) Hess[(size_t)(m - 1) * ldh + i] = qp_c128{hc[i].real(), hc[i].imag()};
+  if (extended_out) *extended_out = 1;
+  return QP_OK;
+  QP_CATCH
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// building blocks of a row-partitioned Arnoldi / Newton (the caller owns the collectives)
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int qp_krylov_vec(qp_krylov* q, int i, qp_state** out) {
+  QP_TRY
+  if (!q || !out || i < 0 || i >= q->nvec) return qp::fail(QP_E_BAD_ARG, "qp_krylov_vec: bad arguments");
+  return qp_state_wrap(q->ctx, q->q(i), q->n, out);
+  QP_CATCH
+}
+
+int qp_krylov_multidot(qp_krylov* q, int j, qp_state* reduced) {
+  QP_TRY
+  if (!q || !reduced || j < 0 || j + 1 >= q->nvec || reduced->n < 2 * (j + 1))
+    return qp::fail(QP_E_BAD_ARG, "qp_krylov_multidot: bad arguments");
+  QP_CHECK(use(q->ctx));
+  return qp::launch_mgs_multidot(q->ctx->stream, q->Q, q->n, j, q->q(j + 1), q->md_part, reduced->d, q->n, &q->ctx->stats);
+  QP_CATCH
+}
+
+int qp_krylov_project(qp_krylov* q, int j, double dt, const qp_state* reduced, qp_state* hess_col,
+                      qp_state* norm_partials) {
+  QP_TRY
+  if (!q || !reduced || !hess_col || !norm_partials || j < 0 || j + 1 >= q->nvec || reduced->n < 2 * (j + 1) ||
+      hess_col->n < j + 1 || norm_partials->n < kRedBlocks)
+    return qp::fail(QP_E_BAD_ARG, "qp_krylov_project: bad arguments");
+  QP_CHECK(use(q->ctx));
+  return qp::launch_mgs_project(q->ctx->stream, q->Q, q->n, j, q->q(j + 1), reduced->d, q->gram, q->nvec, hess_col->d,
+                                norm_partials->d, dt, q->n, &q->ctx->stats);
+  QP_CATCH
+}
+
+int qp_krylov_normalize(qp_krylov* q, int j, double dt, double norm_min, const qp_state* norm_partials,
+                        qp_state* hess_norm) {
+  QP_TRY
+  if (!q || !norm_partials || !hess_norm || j < 0 || j + 1 >= q->nvec || norm_partials->n < kRedBlocks || hess_norm->n < 2)
+    return qp::fail(QP_E_BAD_ARG, "qp_krylov_normalize: bad arguments");
+  QP_CHECK(use(q->ctx));
+  hipLaunchKernelGGL(norm_guard_scale_kernel, dim3(2048), dim3(qp::kThreads), 0, q->ctx->stream, q->q(j + 1),
+                     norm_partials->d, hess_norm->d, reinterpret_cast<double*>(hess_norm->d + 1), dt, norm_min, q->n);
+  QP_HIP(hipGetLastError());
+  q->ctx->stats.n_launch++;
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_combine(qp_state* out, int use_out, qp_c128 s0, qp_krylov* q, int first, int m, const qp_c128* coefs,
+               qp_state* norm_partials) {
+  QP_TRY
+  if (!out || !q || !coefs || first < 0 || m < 1 || first + m > q->nvec || out->n != q->n ||
+      (norm_partials && norm_partials->n < kRedBlocks))
+    return qp::fail(QP_E_BAD_ARG, "qp_combine: bad arguments");
+  QP_CHECK(use(q->ctx));
+  return qp::launch_combine_vecs(q->ctx->stream, out->d, use_out, d2(s0), q->q(first), q->n, m,
+                                 reinterpret_cast<const double2*>(coefs), norm_partials ? norm_partials->d : nullptr,
+                                 q->n, &q->ctx->stats);
+  QP_CATCH
+}
+
+}  // extern "C"
+
+// norm + guarded scale: lmul!(1/h) only when h >= norm_min (src/arnoldi.jl:89-96); the
+// raw norm is kept so that the host can detect breakdown also for dt < 0.
+__global__ __launch_bounds__(qp::kThreads) void norm_guard_scale_kernel(double2* __restrict__ w,
+                                                                        const double2* __restrict__ part_in,
+                                                                        double2* hess_slot, double* norm_slot, double dt,
+                                                                        double norm_min, int64_t n) {
+  __shared__ double2 lds[qp::kThreads / 64];
+  double2 v = part_in[threadIdx.x];
+  for (int o = 32; o > 0; o >>= 1) {
+    v.x += __shfl_down(v.x, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const double s2 = lds[0].x + lds[1].x + lds[2].x + lds[3].x;
+  const double h = sqrt(s2);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    *hess_slot = make_double2(dt * h, 0.0);
+    *norm_slot = h;
+  }
+  if (h < norm_min) return;
+  const double inv = 1.0 / h;
+  for (int64_t i = (int64_t)blockIdx.x * qp::kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * qp::kThreads) {
+    double2 t = w[i];
+    t.x *= inv;
+    t.y *= inv;
+    w[i] = t;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Newton
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int qp_newton_create(qp_ctx* ctx, int64_t n, int m_max, qp_newton** out) {
+  QP_TRY
+  if (!ctx || !out || n < 0) return qp::fail(QP_E_BAD_ARG, "qp_newton_create: bad arguments");
+  if (m_max <= 2) return qp::fail(QP_E_M_MAX, "Newton propagation requires m_max > 2");          // src/newton.jl:38-40
+  if (m_max >= n) {                                                                              // :41-46
+    m_max = (int)n - 1;
+    if (m_max <= 2) return qp::fail(QP_E_M_MAX, "Newton propagation requires state dimension > 2");
+  }
+  QP_CHECK(use(ctx));
+  auto w = std::make_unique<qp_newton>();
+  w->ctx = ctx;
+  w->n = n;
+  w->m_max = m_max;
+  QP_CHECK(qp_krylov_create(ctx, n, m_max + 1, &w->q));
+  QP_CHECK(dev_alloc(&w->v, (size_t)n));
+  QP_CHECK(dev_alloc(&w->npart, (size_t)kRedBlocks));
+  QP_HIP(hipHostMalloc((void**)&w->h_npart, kRedBlocks * sizeof(double2), hipHostMallocDefault));
+  w->a.assign((size_t)10 * m_max + 1, cplx(0));      // :50-51
+  w->leja.assign((size_t)10 * m_max + 1, cplx(0));
+  *out = w.release();
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_newton_destroy(qp_newton* w) {
+  QP_TRY
+  if (!w) return QP_OK;
+  (void)hipSetDevice(w->ctx->device);
+  (void)hipStreamSynchronize(w->ctx->stream);
+  qp_krylov_destroy(w->q);
+  if (w->v) (void)hipFree(w->v);
+  if (w->npart) (void)hipFree(w->npart);
+  if (w->h_npart) (void)hipHostFree(w->h_npart);
+  delete w;
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_newton_get_coeffs(const qp_newton* w, qp_c128* a, qp_c128* leja, int cap) {
+  if (!w) return qp::fail(QP_E_BAD_ARG, "newton workspace is NULL");
+  if (cap < w->n_a) return qp::fail(QP_E_BAD_ARG, "need room for %d coefficients", w->n_a);
+  for (int i = 0; i < w->n_a; ++i) {
+    if (a) a[i] = qp_c128{w->a[i].real(), w->a[i].imag()};
+    if (leja) leja[i] = qp_c128{w->leja[i].real(), w->leja[i].imag()};
+  }
+  return QP_OK;
+}
+
+int qp_newton_step(qp_newton* w, qp_operator* op, qp_state* psi, double dt, int func_id, qp_func_cb cb, void* user,
+                   double norm_min, double relerr, int max_restarts, qp_newton_stats* stats) {
+  QP_TRY
+  if (!w || !op || !psi) return qp::fail(QP_E_BAD_ARG, "qp_newton_step: NULL argument");
+  if (op->A.nrows != op->A.ncols || psi->n != op->A.nrows || w->n != psi->n) return qp::fail(QP_E_BAD_ARG, "qp_newton_step: shape mismatch");
+  if (func_id == QP_FUNC_CALLBACK && !cb) return qp::fail(QP_E_BAD_ARG, "callback func is NULL");
+  if (func_id < 0 || func_id > QP_FUNC_CALLBACK) return qp::fail(QP_E_BAD_ARG, "bad func_id");
+  if (dt == 0.0) return qp::fail(QP_E_BAD_ARG, "dt must be non-zero");   // src/newton.jl:263
+  qp_ctx* ctx = op->ctx;
+  QP_CHECK(use(ctx));
+  const int m_max = w->m_max;
+  int m = m_max;                                                        // :253
+  std::fill(w->a.begin(), w->a.end(), cplx(0));                         // :254-255
+  std::fill(w->leja.begin(), w->leja.end(), cplx(0));
+  const int ldh = m_max + 1;
+  std::vector<cplx> Hess((size_t)ldh * ldh, cplx(0));
+  std::vector<cplx> R(m + 1), P(m + 1), Rn(m + 1), ritz;
+  int n_a = 0, n_leja = 0, s = 0, n_matvec = 0;
+  double last_relerr = 0, norm_psi = 0;
+  const size_t bytes = (size_t)w->n * sizeof(double2);
+  qp_state vstate{ctx, w->v, w->n, false};
+  QP_HIP(hipMemcpyAsync(w->v, psi->d, bytes, hipMemcpyDeviceToDevice, ctx->stream));  // :268
+  cplx n2;
+  QP_CHECK(dot_sync(ctx, w->v, w->v, w->n, &n2));
+  double beta = std::sqrt(n2.real());                                                // :271
+  QP_CHECK(qp::launch_scal(ctx->stream, w->v, make_double2(1.0 / beta, 0.0), w->n, &ctx->stats));  // :272
+  double ms_arnoldi = 0, ms_eig = 0, ms_leja = 0, ms_coeffs = 0, ms_poly = 0, ms_update = 0;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms_since = [](std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  };
+  while (true) {                                                                     // :274
+    int m_req = m;
+    auto t0 = now();
+    QP_CHECK(qp_arnoldi(op, w->q, m_req, &vstate, dt, 1, norm_min, reinterpret_cast<qp_c128*>(Hess.data()), ldh, &m));
+    ms_arnoldi += ms_since(t0);
+    n_matvec += m_req;
+    if (m == 1 && s == 0) {                                                          // :289-295
+      const cplx lam = beta * Hess[0];
+      const cplx f = qp::eval_func(func_id, cb, user, lam);
+      QP_CHECK(qp::launch_scal(ctx->stream, psi->d, d2(f), psi->n, &ctx->stats));
+      break;
+    }
+    ritz.assign((size_t)m * (m + 1) / 2, cplx(0));
+    t0 = now();
+    if (qp::diagonalize_hessenberg(Hess.data(), ldh, m, true, ritz.data()) != QP_OK)  // :297
+      return qp::fail(QP_E_INTERNAL, "Hessenberg QR did not converge");
+    ms_eig += ms_since(t0);
+    if (s == 0) {                                                                    // :301-303, :67-70
+      double rmax = 0;
+      for (auto& z : ritz) rmax = std::max(rmax, std::abs(z));
+      w->radius = 1.2 * rmax;
+    }
+    const int n_s = n_leja;                                                          // :307
+    if ((int)w->leja.size() < n_leja + m) w->leja.resize((size_t)2 * (n_leja + m), cplx(0));  // :105-110
+    t0 = now();
+    qp::extend_leja(w->leja.data(), n_leja, ritz.data(), (int)ritz.size(), m);
+    ms_leja += ms_since(t0);
+    n_leja += m;
+    if ((int)w->a.size() < n_leja) w->a.resize((size_t)2 * n_leja, cplx(0));         // :187-192
+    {
+      t0 = now();
+      int st = qp::extend_newton_coeffs(w->a.data(), n_a, w->leja.data(), func_id, cb, user, n_leja, w->radius);  // :314
+      ms_coeffs += ms_since(t0);
+      if (st == QP_E_DIVDIFF_UNDERFLOW) return qp::fail(st, "Divided differences too small");
+      if (st != QP_OK) return qp::fail(st, "extend_newton_coeffs failed (radius=%g)", w->radius);
+      n_a = n_leja;
+    }
+    // Newton polynomial in the extended Hessenberg matrix                           :328-343
+    t0 = now();
+    const int mp = m + 1;
+    R.assign(mp, cplx(0));
+    P.assign(mp, cplx(0));
+    Rn.assign(mp, cplx(0));
+    R[0] = beta;
+    P[0] = w->a[n_s] * beta;
+    auto apply = [&](cplx z) {
+      for (int i = 0; i < mp; ++i) {
+        cplx acc = 0;
+        for (int k = 0; k < mp; ++k) acc += Hess[(size_t)k * ldh + i] * R[k];
+        Rn[i] = (acc - z * R[i]) / w->radius;
+      }
+      std::swap(R, Rn);
+    };
+    for (int k = 1; k <= m - 1; ++k) {
+      apply(w->leja[n_s + k - 1]);
+      for (int i = 0; i < mp; ++i) P[i] += w->a[n_s + k] * R[i];
+    }
+    ms_poly += ms_since(t0);
+    t0 = now();
+    // Psi = (s == 0 ? 0 : Psi) + sum_i P_i q_i                                      :346-352
+    QP_CHECK(qp::launch_combine_vecs(ctx->stream, psi->d, s == 0 ? 0 : 1, make_double2(1.0, 0.0), w->q->q(0), w->n, m,
+                                     reinterpret_cast<const double2*>(P.data()), w->npart, w->n, &ctx->stats));
+    QP_HIP(hipMemcpyAsync(w->h_npart, w->npart, kRedBlocks * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
+    // starting vector of the next restart                                            :356-367
+    apply(w->leja[n_s + m - 1]);
+    double b2 = 0;
+    for (int i = 0; i < mp; ++i) {
+      const double ab = std::abs(R[i]);
+      b2 += ab * ab;
+    }
+    beta = std::sqrt(b2);
+    for (int i = 0; i < mp; ++i) R[i] *= (1.0 / beta);
+    QP_CHECK(qp::launch_combine_vecs(ctx->stream, w->v, 1, d2(R[0]), w->q->q(1), w->n, m,
+                                     reinterpret_cast<const double2*>(R.data() + 1), nullptr, w->n, &ctx->stats));
+    QP_HIP(hipStreamSynchronize(ctx->stream));
+    norm_psi = std::sqrt(sum_partials(w->h_npart).real());
+    ms_update += ms_since(t0);
+    last_relerr = beta * std::abs(w->a[n_a - 1]) / (1 + norm_psi);                    // :370
+    if (last_relerr < relerr) break;
+    s += 1;
+    if (s > max_restarts) {                                                           // :375
+      w->restarts = s;
+      return qp::fail(QP_E_MAX_RESTARTS, "newton!: s=%d exceeds max_restarts=%d (relerr=%g)", s, max_restarts, last_relerr);
+    }
+  }
+  w->restarts = s;
+  w->n_leja = n_leja;
+  w->n_a = n_a;
+  ctx->stats.n_newton_steps++;
+  ctx->stats.n_restarts += s;
+  if (stats) {
+    stats->restarts = s;
+    stats->n_a = n_a;
+    stats->n_leja = n_leja;
+    stats->m_last = m;
+    stats->n_matvec = n_matvec;
+    stats->radius = w->radius;
+    stats->last_relerr = last_relerr;
+    stats->norm_psi = norm_psi;
+    stats->ms_arnoldi = ms_arnoldi;
+    stats->ms_eig = ms_eig;
+    stats->ms_leja = ms_leja;
+    stats->ms_coeffs = ms_coeffs;
+    stats->ms_poly = ms_poly;
+    stats->ms_update = ms_update;
+  }
+  return QP_OK;
+  QP_CATCH
+}
+
+// ---------------------------------------------------------------------------
+// SpectralRange
+// ---------------------------------------------------------------------------
+int qp_ritzvals(qp_operator* op, const qp_state* state, int m_min, int m_max, double prec, double norm_min,
+                qp_c128* out, int* n_out) {
+  QP_TRY
+  if (!op || !state || !out || !n_out) return qp::fail(QP_E_BAD_ARG, "qp_ritzvals: NULL argument");
+  if (m_max <= m_min) return qp::fail(QP_E_BAD_ARG, "m_max=%d must be larger than m_min=%d", m_max, m_min);  // src/specrad.jl:171-173
+  qp_ctx* ctx = op->ctx;
+  QP_CHECK(use(ctx));
+  int m = std::max(5, std::min(m_min, m_max - 1));                         // :174
+  if (m_max < m) return qp::fail(QP_E_BAD_ARG, "m_max=%d too small (need >= %d)", m_max, m);
+  const int ldh = m_max;
+  std::vector<cplx> Hess((size_t)ldh * ldh, cplx(0));
+  qp_krylov* q = nullptr;
+  QP_CHECK(qp_krylov_create(ctx, state->n, m_max + 1, &q));
+  std::unique_ptr<qp_krylov, int (*)(qp_krylov*)> guard(q, qp_krylov_destroy);
+  std::vector<cplx> ev;
+  auto stats3 = [&](double& lo, double& hi, double& im) {
+    lo = ev[0].real();
+    hi = ev[0].real();
+    im = std::fabs(ev[0].imag());
+    for (auto& z : ev) {
+      lo = std::min(lo, z.real());
+      hi = std::max(hi, z.real());
+      im = std::max(im, std::fabs(z.imag()));
+    }
+  };
+  auto diag = [&](int mm) -> int {
+    ev.assign(mm, cplx(0));
+    return qp::diagonalize_hessenberg(Hess.data(), ldh, mm, false, ev.data());
+  };
+  int m0 = m - 1;
+  QP_CHECK(qp_arnoldi(op, q, m0, state, 1.0, 0, norm_min, reinterpret_cast<qp_c128*>(Hess.data()), ldh, &m0));  // :182
+  if (diag(m0) != QP_OK) return qp::fail(QP_E_INTERNAL, "Hessenberg QR did not converge");
+  double lo0, hi0, im0;
+  stats3(lo0, hi0, im0);
+  if (m0 == m - 1) {
+    int ext = 0;
+    QP_CHECK(qp_arnoldi_extend(op, q, m, 1.0, norm_min, reinterpret_cast<qp_c128*>(Hess.data()), ldh, &ext));  // :190
+    if (diag(m) != QP_OK) return qp::fail(QP_E_INTERNAL, "Hessenberg QR did not converge");
+    double lo, hi, im;
+    stats3(lo, hi, im);
+    double er_lo = (lo0 != 0.0) ? std::fabs(1.0 - lo / lo0) : 0.0;
+    double er_hi = (hi0 != 0.0) ? std::fabs(1.0 - hi / hi0) : 0.0;
+    double ei = (im0 != 0.0) ? std::fabs(1.0 - im / im0) : 0.0;
+    while ((er_lo > prec) || (er_hi > prec) || ((im0 > 1e-14) && ei > prec)) {   // :198
+      lo0 = lo;
+      hi0 = hi;
+      im0 = im;
+      m = m + 1;
+      // quirk kept: the reference discards extend_arnoldi!'s return value, so Krylov
+      // exhaustion is never detected here (:204-205)
+      QP_CHECK(qp_arnoldi_extend(op, q, m, 1.0, norm_min, reinterpret_cast<qp_c128*>(Hess.data()), ldh, &ext));
+      if (diag(m) != QP_OK) return qp::fail(QP_E_INTERNAL, "Hessenberg QR did not converge");
+      stats3(lo, hi, im);
+      er_lo = std::fabs(1.0 - (lo / lo0));
+      er_hi = std::fabs(1.0 - (hi / hi0));
+      ei = std::fabs(1.0 - (im / im0));
+      if (m == m_max) break;                                                     // :213-216
+    }
+  }
+  *n_out = (int)ev.size();
+  for (size_t i = 0; i < ev.size(); ++i) out[i] = qp_c128{ev[i].real(), ev[i].imag()};
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_specrange_arnoldi(qp_operator* op, const qp_state* state, int m_min, int m_max, double prec, double norm_min,
+                         int enlarge, double* E_min, double* E_max) {
+  QP_TRY
+  if (!E_min || !E_max) return qp::fail(QP_E_BAD_ARG, "qp_specrange_arnoldi: NULL output");
+  m_min = std::max(5, std::min(m_min, m_max - 1));                              // src/specrad.jl:97
+  std::vector<qp_c128> R((size_t)std::max(m_max, 8));
+  int n = 0;
+  QP_CHECK(qp_ritzvals(op, state, m_min, m_max, prec, norm_min, R.data(), &n));
+  double lo = R[0].re, hi = R[n - 1].re;                                        // :103-104
+  if (enlarge && n > 1) {                                                        // :105-110
+    lo = 2 * lo - R[1].re;
+    hi = 2 * hi - R[n - 2].re;
+  }
+  *E_min = lo;
+  *E_max = hi;
+  return QP_OK;
+  QP_CATCH
+}
+
+}  // extern "C"

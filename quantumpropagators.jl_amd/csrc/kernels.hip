@@ -254,7 +254,7 @@ __device__ __forceinline__ int4 ld_cols(const char* __restrict__ colbytes, int64
   return ld_col<NT>(reinterpret_cast<const int4*>(p) + (size_t)q * 64 + lane);
 }
 
-// one slot of a stencil lower section (engine.hip: LowerStencilSlot): column = row + delta,
+// one slot of a stencil lower section (engine_core.hip: LowerStencilSlot): column = row + delta,
 // the conj-transposed value sits at pb(column block) + column % 64
 struct LowerStencilSlot {
   int delta, cb0;

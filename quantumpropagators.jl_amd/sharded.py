@@ -17,7 +17,7 @@ send buffer).  Chebyshev needs no reductions, so this is the only collective on 
 In local numbering the square part of the block is still Hermitian, so the engine keeps it
 Hermitian-packed (ghost columns are "upper" by construction).
 
-The buffer rotation is the single-GPU one (engine.hip qp_cheby_step): two x buffers that
+The buffer rotation is the single-GPU one (engine_cheby.hip qp_cheby_step): two x buffers that
 alternate between "gathered v1" and "local v0 -> v2 in place", plus a local accumulator.
 
 The local compute goes through a *backend* object; the product backend is

@@ -10,7 +10,10 @@
 #include <string>
 #include <vector>
 
+// the library is built with -fvisibility=hidden: only the C ABI of qprop.h is exported
+#pragma GCC visibility push(default)
 #include "../../include/qprop.h"
+#pragma GCC visibility pop
 
 namespace qp {
 

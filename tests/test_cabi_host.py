@@ -171,3 +171,41 @@ def test_partition_rows_bit_exact():
     for parts in (1, 2, 3, 8):
         for bal in ("rows", "nnz"):
             assert np.array_equal(L.partition_rows(rowptr, parts, bal), qo.partition_rows(rowptr, parts, bal))
+
+
+def test_accumulator_schedule_host():
+    """qp_acc_schedule_host (include/qprop.h, qp_acc_defer): the Psi accumulator is touched
+    every third term, the last term always, the first update no later than term 2 (Psi = v_0 is
+    overwritten by term 2) -- and replaying the folded updates reproduces the term-by-term
+    axpy sequence of src/cheby.jl:172/:182/:205 exactly."""
+    import qprop_amd.lib as L
+    rng = np.random.default_rng(0)
+    for n_coeffs in range(2, 40):
+        a = rng.standard_normal(n_coeffs)
+        sched = L.acc_schedule(a)
+        nterms = n_coeffs - 1
+        assert len(sched) == nterms and not sched[nterms - 1].skip
+        upd = [m for m in range(1, nterms + 1) if not sched[m - 1].skip]
+        assert upd[0] <= 2 and all(b - c <= 3 for b, c in zip(upd[1:], upd[:-1]))
+        assert len(upd) <= nterms // 3 + 2
+        # v_0 .. v_nterms as random numbers; sequential reference
+        v = rng.standard_normal(nterms + 1) + 1j * rng.standard_normal(nterms + 1)
+        ref = a[0] * v[0]
+        for m in range(1, nterms + 1):
+            ref = ref + a[m] * v[m]
+        acc, last = None, 0
+        for m in range(1, nterms + 1):
+            d = sched[m - 1]
+            if d.skip:
+                continue
+            assert d.n_defer == m - last - 1
+            r = acc if acc is not None else a[0] * (v[m - 2] if d.n_defer == 1 else v[m - 1])
+            if acc is None:
+                assert (m - 1 - d.n_defer) == 0          # the first update starts from Psi = v_0
+            if d.n_defer == 2:
+                r = r + d.a_d2 * v[m - 2]
+            if d.n_defer >= 1:
+                r = r + d.a_d1 * v[m - 1]
+            acc = r + a[m] * v[m]
+            last = m
+        assert acc == ref

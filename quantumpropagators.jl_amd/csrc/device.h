@@ -132,7 +132,7 @@ struct CoefBlock {
 // planes: vals[p] = sum_l coef[l] * plane_l[p]   (coefs: host array)
 int launch_real_part(hipStream_t s, double* out, const double2* v, int64_t n, Stats* st);
 int launch_combine_planes(hipStream_t s, double2* vals, const double2* const* planes_dev, const double2* coefs,
-                          int nplanes, int64_t n, Stats* st);
+                          int nplanes, int64_t n, double* vals_r, Stats* st);
 
 // batched states: CSR SpMM with the fused Chebyshev epilogue, panel X[i*b + s]
 int launch_spmm_cheby(hipStream_t s, const int64_t* rowptr, const int32_t* cols, const double2* vals,

@@ -881,26 +881,24 @@ static int operator_refresh(qp_operator* op) {
     const int fmt = choose_format(op, QP_FMT_AUTO, false);
     QP_CHECK(operator_build_device(op, fmt, planes_csr));
   }
+  // real terms with real coefficients: the mat-vec kernels stream a real copy (8 instead of 16
+  // bytes per value); everything else keeps reading the complex array
+  const bool want_real = qp::g_real_vals && op->planes_real && all_real && op->A.stored > 0;
+  if (want_real && !op->real_vals) QP_CHECK(dev_alloc(&op->real_vals, (size_t)op->A.stored));
   if (op->nops == 1 && all_one) {
     op->A.vals = op->planes[0];
+    if (want_real && op->real_of != op->A.vals) {   // a plane never changes: extract once
+      QP_CHECK(qp::launch_real_part(ctx->stream, op->real_vals, op->A.vals, op->A.stored, &ctx->stats));
+      op->real_of = op->A.vals;
+    }
   } else {
     if (!op->combined) QP_CHECK(dev_alloc(&op->combined, (size_t)op->A.stored));
     QP_CHECK(qp::launch_combine_planes(ctx->stream, op->combined, op->planes_dev, eff.data(), op->nops, op->A.stored,
-                                       &ctx->stats));
+                                       want_real ? op->real_vals : nullptr, &ctx->stats));
     op->A.vals = op->combined;
-    op->real_of = nullptr;   // rewritten
+    op->real_of = nullptr;
   }
-  // real terms with real coefficients: the mat-vec kernels stream a real copy (8 instead of 16
-  // bytes per value); everything else keeps reading the complex array
-  op->A.vals_r = nullptr;
-  if (qp::g_real_vals && op->planes_real && all_real && op->A.stored > 0) {
-    if (!op->real_vals) QP_CHECK(dev_alloc(&op->real_vals, (size_t)op->A.stored));
-    if (op->real_of != op->A.vals) {
-      QP_CHECK(qp::launch_real_part(ctx->stream, op->real_vals, op->A.vals, op->A.stored, &ctx->stats));
-      op->real_of = (op->A.vals == op->combined) ? nullptr : op->A.vals;   // a plane never changes
-    }
-    op->A.vals_r = op->real_vals;
-  }
+  op->A.vals_r = want_real ? op->real_vals : nullptr;
   return QP_OK;
 }
 

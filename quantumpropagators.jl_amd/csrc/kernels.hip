@@ -1158,11 +1158,12 @@ static inline int ew_grid(int64_t n) {
 __global__ __launch_bounds__(kThreads) void combine_planes_kernel(double2* __restrict__ vals,
                                                                   const double2* const* __restrict__ planes,
                                                                   CoefBlock coefs, int first, int nplanes,
-                                                                  int accumulate, int64_t n) {
+                                                                  int accumulate, int64_t n, double* __restrict__ vals_r) {
   for (int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x; p < n; p += (int64_t)gridDim.x * kThreads) {
     double2 acc = accumulate ? vals[p] : make_double2(0.0, 0.0);
     for (int l = 0; l < nplanes; ++l) cfma(acc, coefs.c[l], planes[first + l][p]);
     vals[p] = acc;
+    if (vals_r) vals_r[p] = acc.x;   // real copy for the mat-vec kernels of an all-real operator
   }
 }
 
@@ -1180,14 +1181,15 @@ int launch_real_part(hipStream_t s, double* out, const double2* v, int64_t n, St
 }
 
 int launch_combine_planes(hipStream_t s, double2* vals, const double2* const* planes_dev, const double2* coefs,
-                          int nplanes, int64_t n, Stats* st) {
+                          int nplanes, int64_t n, double* vals_r, Stats* st) {
   if (n == 0) return QP_OK;
   for (int first = 0; first < nplanes; first += kCoefBlock) {
     CoefBlock cb;
     const int cnt = (nplanes - first < kCoefBlock) ? nplanes - first : kCoefBlock;
     for (int l = 0; l < cnt; ++l) cb.c[l] = coefs[first + l];
+    const bool last_chunk = first + cnt >= nplanes;
     hipLaunchKernelGGL(combine_planes_kernel, dim3(ew_grid(n)), dim3(kThreads), 0, s, vals, planes_dev, cb, first,
-                       cnt, first > 0 ? 1 : 0, n);
+                       cnt, first > 0 ? 1 : 0, n, last_chunk ? vals_r : nullptr);
     QP_HIP(hipGetLastError());
     if (st) st->n_launch++;
   }

@@ -68,7 +68,9 @@ enum { QP_VAL_C128 = 0, QP_VAL_F64 = 1 };
  * CSR with a sub-wave per row.  AUTO: HRB when every term is exactly (bitwise) Hermitian,
  * else RBCSR; CSR when row-block padding would exceed 50 %.  An HRB operator that is given
  * complex coefficients re-lays itself out as RBCSR. */
-enum { QP_FMT_AUTO = 0, QP_FMT_CSR = 1, QP_FMT_RBCSR = 2, QP_FMT_HRB = 3 };
+enum { QP_FMT_AUTO = 0, QP_FMT_CSR = 1, QP_FMT_RBCSR = 2, QP_FMT_HRB = 3,
+       QP_FMT_MATFREE = 4 /* reported by qp_operator_info for qp_liouvillian_create operators */ };
+enum { QP_CONV_TDSE = 0, QP_CONV_LVN = 1 };   /* `convention` of liouvillian(), src/generators.jl:473-631 */
 enum { QP_FUNC_EXPMI = 0,    /* z -> exp(-i z)   default of newton!, src/newton.jl:247 */
        QP_FUNC_EXP = 1,      /* z -> exp(z)      test/test_newton.jl:171 */
        QP_FUNC_CALLBACK = 2 };
@@ -237,6 +239,22 @@ int qp_cheby_term_split(qp_operator* op, qp_split* sp, void* boundary_stream, in
                         const qp_state* x, int64_t xoff, const qp_state* v0, qp_state* vout,
                         const qp_state* acc_in, qp_state* acc_out, qp_state* slab, qp_c128 c,
                         double beta, double a_prev, double a, qp_c128 phase, const qp_acc_defer* defer);
+
+/* ---- matrix-free Liouvillian ------------------------------------------
+ * liouvillian(H, c_ops; convention) (src/generators.jl:473-631) builds the n^2 x n^2 sparse
+ * superoperator  L = s_h (1 (x) H - H^T (x) 1) + s_d sum_k (A_k^{+T} (x) A_k - (1 (x) G_k + G_k^T (x) 1) / 2),
+ * G_k = A_k^+ A_k, (s_h, s_d) = (1, i) for :TDSE and (i, 1) for :LvN, acting on the
+ * column-major vec(rho).  For DENSE H and A_k that matrix has 2 n^3 entries; this operator
+ * applies the same map to rho as n x n GEMMs instead (fp64 matrix cores, rocBLAS zgemm):
+ *   L rho = M_L rho - rho M_R + s_d sum_k A_k rho A_k^+,   M_L/R = s_h H -/+ (s_d / 2) sum_k G_k,
+ * with H = sum_l c_l H_l the usual lazy sum (qp_operator_set_coeffs; the first
+ * nterms - ncoeffs terms are the drift).  Matrices are dense, column-major (Julia layout).
+ * The result is a qp_operator of size n^2: qp_mul, qp_dot_op, the Arnoldi / Newton / specrange
+ * entry points and qp_cheby_step accept it (qp_cheby_step with an unfused epilogue); the entry
+ * points that need stored entries (get_csr, split, batched, persistent kernels) do not. */
+int qp_liouvillian_create(qp_ctx* ctx, int64_t n, const qp_c128* const* H_terms, int nterms,
+                          int ncoeffs, const qp_c128* const* c_ops, int nc, int convention,
+                          qp_operator** out);
 
 /* ---- row-partitioned cheby! with the exchange inside the library (RCCL over xGMI) ----
  * No reference counterpart (the reference is single-process).  One process per GPU; the

@@ -19,6 +19,8 @@ constexpr int kRB = 64;           // rows per row block = one wavefront
 constexpr int kRedBlocks = 256;   // fixed grid of the reduction kernels (deterministic order)
 constexpr int kThreads = 256;
 
+struct Stats;
+
 // ---- device view of one sparse operator -------------------------------------------
 struct DevMatrix {
   int format = QP_FMT_RBCSR;
@@ -48,6 +50,12 @@ struct DevMatrix {
   int64_t lcolbytes = 0;
   int32_t* lpos = nullptr;    // lstored, quad packed; -1 = padding
   int64_t lstored = 0;
+  // QP_FMT_MATFREE: no stored entries; y = beta y + alpha A x is delegated to the owner
+  // (engine_liouville.hip), and the Chebyshev term runs it followed by an unfused epilogue
+  void* matfree = nullptr;
+  int (*matfree_apply)(hipStream_t s, void* self, const double2* x, double2* y, double2 alpha, double2 beta,
+                       Stats* st) = nullptr;
+  double2* (*matfree_scratch)(void* self) = nullptr;   // n entries of workspace for the Chebyshev term
 };
 
 // epilogue of the fused Chebyshev term (see qp_cheby_term in qprop.h)

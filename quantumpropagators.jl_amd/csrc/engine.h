@@ -75,6 +75,10 @@ struct qp_operator {
   const double2* real_of = nullptr;  // the complex array real_vals was extracted from, when still valid
   std::vector<cplx> coeffs;
   cplx scale = 1.0;
+  // QP_FMT_MATFREE operators (engine_liouville.hip): owner data and its hooks
+  void* mf = nullptr;
+  int (*mf_refresh)(qp_operator* op) = nullptr;   // coefficients or scale changed
+  void (*mf_free)(qp_operator* op) = nullptr;
 };
 
 struct qp_split {   // boundary / interior partition of an operator's row blocks (multi-GPU overlap)

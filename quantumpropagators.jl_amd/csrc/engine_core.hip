@@ -344,6 +344,7 @@ static int operator_free(qp_operator* op) {
   if (!op) return QP_OK;
   (void)hipSetDevice(op->ctx->device);
   (void)hipStreamSynchronize(op->ctx->stream);
+  if (op->mf_free) op->mf_free(op);
   operator_free_device(op);
   delete op;
   return QP_OK;
@@ -862,6 +863,7 @@ int qp_operator_create(qp_ctx* ctx, qp_matrix* const* ops, int nops, int ncoeffs
 static int operator_refresh(qp_operator* op) {
   qp_ctx* ctx = op->ctx;
   op->vals_epoch++;
+  if (op->A.format == QP_FMT_MATFREE) return op->mf_refresh(op);
   const int drift = op->nops - op->ncoeffs;  // src/generators.jl:635
   std::vector<double2> eff(op->nops);
   bool all_one = true, all_real = true;
@@ -941,7 +943,7 @@ int qp_operator_layout_info(const qp_operator* op, int64_t out[5]) {
   for (int i = 0; i < 5; ++i) out[i] = 0;
   const DevMatrix& A = op->A;
   out[4] = A.stored;
-  if (A.format == QP_FMT_CSR) return QP_OK;
+  if (A.format == QP_FMT_CSR || A.format == QP_FMT_MATFREE) return QP_OK;
   const HostLayout& Lh = op->layout;
   out[0] = A.nblocks;
   int64_t idx_bytes = A.colbytes + A.lcolbytes;
@@ -960,6 +962,7 @@ int qp_operator_layout_info(const qp_operator* op, int64_t out[5]) {
 int qp_operator_get_csr(qp_operator* op, int64_t* rowptr, int32_t* col, qp_c128* vals) {
   QP_TRY
   if (!op || !rowptr || !col || !vals) return qp::fail(QP_E_BAD_ARG, "qp_operator_get_csr: NULL argument");
+  if (op->A.format == QP_FMT_MATFREE) return qp::fail(QP_E_BAD_ARG, "a matrix-free operator has no stored entries");
   QP_CHECK(use(op->ctx));
   const DevMatrix& A = op->A;
   const auto& ur = op->u_rowptr;
@@ -1168,6 +1171,7 @@ int qp_dot_op(const qp_state* x, qp_operator* op, const qp_state* y, qp_state* t
 // CSR-ordered mirror of the operator for the batched (SpMM) path and the persistent
 // small-system kernels, built lazily
 int operator_csr_mirror(qp_operator* op, bool gather) {
+  if (op->A.format == QP_FMT_MATFREE) return qp::fail(QP_E_BAD_ARG, "a matrix-free operator has no stored entries");
   qp_ctx* ctx = op->ctx;
   const DevMatrix& A = op->A;
   const auto& ur = op->u_rowptr;

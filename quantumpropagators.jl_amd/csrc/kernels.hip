@@ -1125,8 +1125,32 @@ static int launch_spmv(hipStream_t s, const DevMatrix& A, const double2* x, cons
   return QP_OK;
 }
 
+// Chebyshev term for an operator without stored entries: s = A x by the owner's apply, then
+// the same row epilogue as the fused kernels
+__global__ __launch_bounds__(kThreads) void cheby_epilogue_kernel(const double2* __restrict__ s, int64_t n, ChebyOp op) {
+  __shared__ double2 lds[kThreads / 64];
+  double2 chk = make_double2(0.0, 0.0);
+  double nrm = 0.0;
+  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i < n) op.row(i, s[i], op.pre(i), chk, nrm, i);
+  finish_check(op, chk, nrm, lds);
+}
+
 int launch_spmv_cheby(hipStream_t s, const DevMatrix& A, const double2* x, const ChebyEpi& e, Stats* st,
                       const RowSet* rs) {
+  if (A.format == QP_FMT_MATFREE) {
+    if (rs) return fail(QP_E_BAD_ARG, "row sets need a row-block format");
+    if (e.check_partials) return fail(QP_E_BAD_ARG, "check_normalization is not available for a matrix-free operator");
+    double2* tmp = A.matfree_scratch(A.matfree);
+    int rc = A.matfree_apply(s, A.matfree, x, tmp, make_double2(1.0, 0.0), make_double2(0.0, 0.0), st);
+    if (rc != QP_OK) return rc;
+    ChebyOp op{e};
+    const int grid = (int)((A.nrows + kThreads - 1) / kThreads);
+    hipLaunchKernelGGL(cheby_epilogue_kernel, dim3(grid), dim3(kThreads), 0, s, tmp, A.nrows, op);
+    QP_HIP(hipGetLastError());
+    if (st) st->n_launch++;
+    return QP_OK;
+  }
   ChebyOp op{e};
   int rc = launch_spmv(s, A, x, op, st, rs);
   // algorithmic bytes, SURVEY 8d: z (V + 4) N + 4 (N + 1) + 5 * 16 N
@@ -1136,6 +1160,8 @@ int launch_spmv_cheby(hipStream_t s, const DevMatrix& A, const double2* x, const
 }
 
 int launch_spmv_plain(hipStream_t s, const DevMatrix& A, const double2* x, const PlainEpi& e, Stats* st) {
+  if (A.format == QP_FMT_MATFREE)
+    return A.matfree_apply(s, A.matfree, x, e.y, e.alpha, e.beta_zero ? make_double2(0.0, 0.0) : e.beta, st);
   PlainOp op{e};
   int rc = launch_spmv(s, A, x, op, st);
   // plain SpMV: matrix + read x + write y  ((20 z + 36) N)

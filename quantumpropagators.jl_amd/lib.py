@@ -24,7 +24,7 @@ STATUS = {
 }
 LAYOUT_CSR, LAYOUT_CSC = 0, 1
 VAL_C128, VAL_F64 = 0, 1
-FMT_AUTO, FMT_CSR, FMT_RBCSR, FMT_HRB = 0, 1, 2, 3
+FMT_AUTO, FMT_CSR, FMT_RBCSR, FMT_HRB, FMT_MATFREE = 0, 1, 2, 3, 4
 FUNC_EXPMI, FUNC_EXP, FUNC_CALLBACK = 0, 1, 2
 
 
@@ -150,6 +150,8 @@ SIGNATURES = {
     "qp_split_check": (C.c_int, [_P]),
     "qp_cheby_term_split": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_int64, _P, _P, _P, _P, _P, qp_c128, C.c_double,
                                       C.c_double, C.c_double, qp_c128, C.POINTER(qp_acc_defer)]),
+    "qp_liouvillian_create": (C.c_int, [_P, C.c_int64, C.POINTER(_cp), C.c_int, C.c_int, C.POINTER(_cp), C.c_int,
+                                        C.c_int, C.POINTER(_P)]),
     "qp_comm_unique_id": (C.c_int, [C.c_char_p, C.c_char_p]),
     "qp_comm_create": (C.c_int, [_P, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(_P)]),
     "qp_comm_destroy": (C.c_int, [_P]),
@@ -425,6 +427,8 @@ class Matrix:
         return cls.from_scipy(ctx, sp.csr_matrix(np.asarray(A)))
 
     def get_csr(self):
+        if self.format == FMT_MATFREE:
+            raise QPArgumentError(1, "a matrix-free operator has no stored entries")
         rowptr = np.empty(self.nrows + 1, dtype=np.int64)
         col = np.empty(max(self.nnz, 1), dtype=np.int32)
         vals = np.empty(max(self.nnz, 1), dtype=np.complex128)
@@ -482,6 +486,8 @@ class Operator:
         check(self.lib.qp_operator_set_scale(self._h, c128(s)))
 
     def get_csr(self):
+        if self.format == FMT_MATFREE:
+            raise QPArgumentError(1, "a matrix-free operator has no stored entries")
         rowptr = np.empty(self.nrows + 1, dtype=np.int64)
         col = np.empty(max(self.nnz, 1), dtype=np.int32)
         vals = np.empty(max(self.nnz, 1), dtype=np.complex128)
@@ -519,6 +525,50 @@ class Operator:
             self.close()
         except Exception:
             pass
+
+
+CONV_TDSE, CONV_LVN = 0, 1
+
+
+class Liouvillian(Operator):
+    """Matrix-free ``liouvillian(H, c_ops; convention)`` (src/generators.jl:473-631) for dense
+    ``H = sum_l c_l H_l`` and Lindblad operators: applies the superoperator to the column-major
+    ``vec(rho)`` as n x n GEMMs instead of storing an n^2 x n^2 sparse matrix
+    (include/qprop.h, qp_liouvillian_create).  Everything an :class:`Operator` offers except
+    the entry points that need stored entries."""
+
+    def __init__(self, ctx, H_terms, c_ops=(), ncoeffs=0, convention="TDSE"):
+        self.ctx, self.lib = ctx, ctx.lib
+        conv = {"TDSE": CONV_TDSE, "LVN": CONV_LVN}[str(convention).upper().lstrip(":")]
+        mats = [np.asarray(H.toarray() if hasattr(H, "toarray") else H, dtype=np.complex128) for H in H_terms]
+        cops = [np.asarray(A.toarray() if hasattr(A, "toarray") else A, dtype=np.complex128) for A in c_ops]
+        if not mats and not cops:
+            raise ValueError("Empty Liouvillian, must give at least one of `H` or `c_ops`")   # :627-630
+        n = (mats + cops)[0].shape[0]
+        for M in mats + cops:
+            if M.shape != (n, n):
+                raise ValueError("all operators must be square matrices of one size")
+        # column-major (Julia) storage
+        hbuf = [np.ascontiguousarray(M.T).reshape(-1) for M in mats]
+        cbuf = [np.ascontiguousarray(M.T).reshape(-1) for M in cops]
+        harr = (_cp * max(len(hbuf), 1))(*[_ptr(b, _cp) for b in hbuf])
+        carr = (_cp * max(len(cbuf), 1))(*[_ptr(b, _cp) for b in cbuf])
+        if "QP_ROCBLAS_PATH" not in os.environ:     # the rocBLAS this process already uses (PyTorch-ROCm's)
+            try:
+                import torch
+                cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librocblas.so")
+                if os.path.exists(cand):
+                    os.environ["QP_ROCBLAS_PATH"] = cand
+            except ImportError:
+                pass
+        self._h = _P()
+        check(self.lib.qp_liouvillian_create(ctx._h, n, harr, len(hbuf), int(ncoeffs), carr, len(cbuf), conv,
+                                             C.byref(self._h)))
+        self.ops = []
+        self.ncoeffs = int(ncoeffs)
+        self.n_hilbert = n
+        self._refresh_info()
+        ctx._adopt(self)
 
 
 class State:

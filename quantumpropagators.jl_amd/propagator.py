@@ -24,7 +24,7 @@ import scipy.sparse as sp
 
 from . import lib as L
 
-__all__ = ["Generator", "hamiltonian", "init_prop", "prop_step", "reinit_prop", "set_state", "set_t",
+__all__ = ["Generator", "hamiltonian", "liouvillian", "MatrixFreeLiouvillian", "init_prop", "prop_step", "reinit_prop", "set_state", "set_t",
            "propagate", "ChebyPropagator", "NewtonPropagator", "discretize", "discretize_on_midpoints"]
 
 
@@ -124,6 +124,50 @@ def hamiltonian(*terms):
     return Generator(ops, ampl)
 
 
+class MatrixFreeLiouvillian:
+    """What :func:`liouvillian` returns for ``matrix_free=True``: the Hamiltonian terms, the
+    amplitudes of the controlled ones and the Lindblad operators, kept as n x n matrices.  On
+    the device it becomes ``lib.Liouvillian`` (GEMMs on rho) instead of an n^2 x n^2 sparse
+    matrix."""
+
+    def __init__(self, ops, amplitudes, c_ops, convention):
+        self.ops, self.amplitudes, self.c_ops, self.convention = list(ops), list(amplitudes), list(c_ops), convention
+
+
+def liouvillian(H, c_ops=(), *, convention, matrix_free=False):
+    """``liouvillian(H, c_ops; convention)`` -- src/generators.jl:515-631.  ``H``: a matrix, a
+    tuple ``(H0, (H1, eps1), ...)``, a :class:`Generator` or ``None``; ``convention`` is
+    mandatory ("TDSE" or "LvN").  Returns the superoperator as sparse matrices (a
+    :class:`Generator` with the dissipator folded into the drift when H is time-dependent), or,
+    with ``matrix_free=True``, a :class:`MatrixFreeLiouvillian` for dense operators."""
+    conv = str(convention).lstrip(":")
+    if conv.upper() not in ("TDSE", "LVN"):
+        raise ValueError("convention must be :TDSE or :LvN")                          # :486-488
+    conv = "TDSE" if conv.upper() == "TDSE" else "LvN"
+    if isinstance(H, (tuple, list)):
+        H = hamiltonian(*H)
+    if H is None and len(c_ops) == 0:
+        raise ValueError("Empty Liouvillian, must give at least one of `H` or `c_ops`")  # :627-630
+    ops = [] if H is None else (H.ops if isinstance(H, Generator) else [H])
+    ampl = H.amplitudes if isinstance(H, Generator) else []
+    if matrix_free:
+        return MatrixFreeLiouvillian(ops, ampl, c_ops, conv)
+    from . import synth
+    drift_n = len(ops) - len(ampl)
+    drift = None
+    for A in c_ops:                                                                      # dissipator :512-520
+        D = synth.lindblad_to_superop(A, conv)
+        drift = D if drift is None else drift + D
+    terms = []
+    for i, op in enumerate(ops):
+        Lh = synth.ham_to_superop(sp.csr_matrix(op), conv)
+        if i < drift_n:
+            drift = Lh if drift is None else drift + Lh
+        else:
+            terms.append((Lh, ampl[i - drift_n]))
+    return hamiltonian(*([] if drift is None else [drift.tocsr()]), *terms)
+
+
 def _to_matrix(ctx, A):
     if isinstance(A, L.Matrix):
         return A
@@ -141,6 +185,11 @@ class _DeviceGenerator:
             generator = generator[0]          # `(H,)` in test/test_propagate.jl:157
         if isinstance(generator, (tuple, list)):
             generator = hamiltonian(*generator)
+        if isinstance(generator, MatrixFreeLiouvillian):
+            self.controls = list(generator.amplitudes)
+            self.op = L.Liouvillian(ctx, generator.ops, generator.c_ops, ncoeffs=len(self.controls),
+                                    convention=generator.convention)
+            return
         if isinstance(generator, Generator):
             self.controls = list(generator.amplitudes)
             mats = [_to_matrix(ctx, A) for A in generator.ops]
@@ -196,7 +245,7 @@ def _specrange(op, method, ctx, n, rng=None, state=None, **kw):
     if method == "auto":                                           # :45-61
         if "E_min" in kw and "E_max" in kw:
             method = "manual"
-        elif n <= 32:
+        elif n <= 32 and op.format != L.FMT_MATFREE:
             method = "diag"
         else:
             method = "arnoldi"

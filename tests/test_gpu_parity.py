@@ -836,3 +836,107 @@ def test_real_valued_operator_streams_real_copy(ctx, fmt):
     assert np.linalg.norm(outs[0][0] - (0.7 - 0.2j) * (Hc @ psi0)) < 1e-12
     Hz = (H0 + (0.5 + 0.5j) * H1).tocsr()
     assert np.linalg.norm(outs[0][-1] - Hz @ psi0) < 1e-12
+
+
+# ---------------------------------------------------------------- matrix-free Liouvillian (N4)
+
+def _dense_open_system(n, rng, nterms=2, nc=2):
+    Hs = [synth.dense_hermitian(n, rho=2.0 if l == 0 else 0.7, rng=rng) for l in range(nterms)]
+    cops = [0.3 * (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))) / np.sqrt(n) for _ in range(nc)]
+    return Hs, cops
+
+
+@pytest.mark.parametrize("convention", ["TDSE", "LvN"])
+@pytest.mark.parametrize("n,nterms,nc", [(3, 1, 0), (8, 2, 1), (33, 2, 2), (64, 0, 1)])
+def test_matrix_free_liouvillian_matches_superoperator(ctx, convention, n, nterms, nc):
+    """qp_liouvillian_create applies liouvillian(H, c_ops; convention) (src/generators.jl:473-631)
+    as GEMMs on the n x n density matrix; the n^2 x n^2 sparse superoperator built from the
+    reference's kron formulas is the check: mul! (3- and 5-argument), dot, coefficient updates,
+    scale, both conventions, H only / c_ops only."""
+    rng = np.random.default_rng(1000 + n)
+    Hs, cops = _dense_open_system(n, rng, nterms, nc)
+    ncoeffs = max(nterms - 1, 0)
+    Lmf = L.Liouvillian(ctx, Hs, cops, ncoeffs=ncoeffs, convention=convention)
+    assert Lmf.shape == (n * n, n * n) and Lmf.format == L.FMT_MATFREE
+    rho = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    x = np.ascontiguousarray(rho.T).reshape(-1)            # column-major vec(rho)
+    y0 = rng.standard_normal(n * n) + 1j * rng.standard_normal(n * n)
+    for cvals, scale in (([1.0] * ncoeffs, 1.0), ([0.4 - 0.3j] * ncoeffs, 1.0), ([0.4] * ncoeffs, 0.5 - 1.5j)):
+        Lmf.set_coeffs(cvals) if ncoeffs else None
+        Lmf.set_scale(scale)
+        Lref = sp.csr_matrix((n * n, n * n), dtype=complex)
+        for l, H in enumerate(Hs):
+            c = 1.0 if l < nterms - ncoeffs else cvals[l - (nterms - ncoeffs)]
+            Lref = Lref + c * synth.ham_to_superop(sp.csr_matrix(H), convention)
+        for A in cops:
+            Lref = Lref + synth.lindblad_to_superop(sp.csr_matrix(A), convention)
+        Lref = (scale * Lref).tocsr()
+        xs, ys = L.State(ctx, data=x), L.State(ctx, n=n * n)
+        Lmf.mul(xs, ys)
+        ref = Lref @ x
+        tol = 1e-12 * max(1.0, np.linalg.norm(ref))
+        assert np.linalg.norm(ys.numpy() - ref) < tol
+        ys.upload(y0)
+        Lmf.mul(xs, ys, 0.7 - 0.2j, -0.3 + 0.1j)
+        assert np.linalg.norm(ys.numpy() - ((-0.3 + 0.1j) * y0 + (0.7 - 0.2j) * ref)) < tol
+        assert abs(Lmf.dot(xs, xs) - np.vdot(x, ref)) < tol
+    # explicit physics check (TDSE: i d rho/dt = L rho):  L rho = [H, rho] + i D(rho)
+    if convention == "TDSE":
+        Lmf.set_scale(1.0)
+        if ncoeffs:
+            Lmf.set_coeffs([1.0] * ncoeffs)
+        H = sum(Hs) if Hs else np.zeros((n, n))
+        want = H @ rho - rho @ H
+        for A in cops:
+            G = A.conj().T @ A
+            want = want + 1j * (A @ rho @ A.conj().T - 0.5 * (G @ rho + rho @ G))
+        xs, ys = L.State(ctx, data=x), L.State(ctx, n=n * n)
+        Lmf.mul(xs, ys)
+        assert np.linalg.norm(ys.numpy() - np.ascontiguousarray(want.T).reshape(-1)) < 1e-12 * max(1.0, np.linalg.norm(want))
+    with pytest.raises(L.QPError):
+        Lmf.get_csr()
+
+
+def test_matrix_free_liouvillian_newton_and_cheby(ctx):
+    """Newton on the matrix-free Liouvillian equals Newton on the sparse superoperator and the
+    oracle (trace preserved, rho stays Hermitian); without dissipation the superoperator is
+    Hermitian and cheby! applies (unfused epilogue)."""
+    rng = np.random.default_rng(77)
+    n = 24
+    Hs, cops = _dense_open_system(n, rng, 1, 2)
+    psi = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    psi /= np.linalg.norm(psi)
+    rho0 = np.outer(psi, psi.conj())
+    x0 = np.ascontiguousarray(rho0.T).reshape(-1)
+    Lsp = (synth.ham_to_superop(sp.csr_matrix(Hs[0]), "TDSE") + sum(synth.lindblad_to_superop(sp.csr_matrix(A), "TDSE") for A in cops)).tocsr()
+    Lmf = L.Liouvillian(ctx, Hs, cops, convention="TDSE")
+    Lop = L.Operator(ctx, [L.Matrix.from_scipy(ctx, Lsp)])
+    outs = []
+    for Op in (Lmf, Lop):
+        xs = L.State(ctx, data=x0)
+        wrk = L.NewtonWrk(ctx, n * n, m_max=10)
+        for _ in range(5):
+            L.newton(xs, Op, 0.2, wrk)
+        outs.append(xs.numpy())
+    assert np.linalg.norm(outs[0] - outs[1]) < 1e-11
+    ref = x0.copy()
+    owrk = qo.NewtonWrk(ref, m_max=10)
+    for _ in range(5):
+        ref = qo.newton(ref, Lsp, 0.2, owrk)
+    assert np.linalg.norm(outs[0] - ref) < TOL
+    rho = outs[0].reshape(n, n).T
+    assert abs(np.trace(rho) - 1.0) < 1e-10 and np.linalg.norm(rho - rho.conj().T) < 1e-10
+    # closed system: Hermitian superoperator, Chebyshev
+    Lc = L.Liouvillian(ctx, Hs, (), convention="TDSE")
+    Lcs = synth.ham_to_superop(sp.csr_matrix(Hs[0]), "TDSE").tocsr()
+    xs = L.State(ctx, data=x0)
+    wrk = L.ChebyWrk(ctx, n * n, 12.0, -6.0, 0.3)
+    for _ in range(3):
+        L.cheby(xs, Lc, 0.3, wrk)
+    ref = x0.copy()
+    owrk = qo.ChebyWrk(ref, 12.0, -6.0, 0.3)
+    for _ in range(3):
+        qo.cheby(ref, Lcs, 0.3, owrk)
+    assert np.linalg.norm(xs.numpy() - ref) < TOL
+    U = np.linalg.matrix_power(__import__("scipy.linalg", fromlist=["expm"]).expm(-1j * 0.3 * Hs[0]), 3)
+    assert np.linalg.norm(xs.numpy().reshape(n, n).T - U @ rho0 @ U.conj().T) < 1e-9

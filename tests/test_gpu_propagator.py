@@ -367,3 +367,38 @@ def test_interfaces_device_types(ctx):
             p = P.init_prop(psi, P.hamiltonian(H0, (H1, lambda t: 0.3 * t)), tlist, method, ctx=ctx,
                             inplace=inplace, backward=backward, **kw)
             assert I.check_propagator(p, atol=1e-13)
+
+
+@pytest.mark.parametrize("convention", ["TDSE", "LvN"])
+def test_liouvillian_generator_sparse_and_matrix_free(ctx, convention):
+    """liouvillian((H0, (H1, eps)), c_ops; convention) (src/generators.jl:515-631): the sparse
+    superoperator generator (dissipator folded into the drift, the commutator of H1 driven by
+    eps) and the matrix-free one give the same Newton propagation; with :TDSE it is the
+    Lindblad dynamics (trace 1, Hermitian rho)."""
+    rng = np.random.default_rng(5)
+    n = 12
+    H0 = synth.dense_hermitian(n, rho=2.0, rng=rng)
+    H1 = synth.dense_hermitian(n, rho=0.8, rng=rng)
+    cops = [0.3 * (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))) / np.sqrt(n)]
+    eps = lambda t: 0.5 * np.sin(2 * t)       # noqa: E731
+    tlist = np.linspace(0, 1.0, 21)
+    psi = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    psi /= np.linalg.norm(psi)
+    rho0 = np.ascontiguousarray(np.outer(psi, psi.conj()).T).reshape(-1)
+    Lsp = P.liouvillian((H0, (H1, eps)), cops, convention=convention)
+    Lmf = P.liouvillian((H0, (H1, eps)), cops, convention=convention, matrix_free=True)
+    assert isinstance(Lsp, P.Generator) and len(Lsp.ops) == 2 and len(Lsp.amplitudes) == 1
+    func = None if convention == "TDSE" else "exp"          # LvN: d rho/dt = L rho  ->  exp(L dt)
+    dt_sign = {}
+    out_sp = P.propagate(rho0, Lsp, tlist, method="newton", ctx=ctx, m_max=8, func=func, **dt_sign)
+    out_mf = P.propagate(rho0, Lmf, tlist, method="newton", ctx=ctx, m_max=8, func=func, **dt_sign)
+    assert np.linalg.norm(out_sp - out_mf) < 1e-11
+    if convention == "TDSE":
+        rho = out_mf.reshape(n, n).T
+        assert abs(np.trace(rho) - 1) < 1e-10 and np.linalg.norm(rho - rho.conj().T) < 1e-10
+        ref = qo.propagate(rho0, qo.Generator([Lsp.ops[0], Lsp.ops[1]], [eps]), tlist, "newton", m_max=8)
+        assert np.linalg.norm(out_mf - ref) < 1e-10
+    with pytest.raises(ValueError):
+        P.liouvillian(H0, cops, convention="foo")
+    with pytest.raises(ValueError):
+        P.liouvillian(None, (), convention="TDSE")

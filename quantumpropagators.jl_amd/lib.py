@@ -427,8 +427,6 @@ class Matrix:
         return cls.from_scipy(ctx, sp.csr_matrix(np.asarray(A)))
 
     def get_csr(self):
-        if self.format == FMT_MATFREE:
-            raise QPArgumentError(1, "a matrix-free operator has no stored entries")
         rowptr = np.empty(self.nrows + 1, dtype=np.int64)
         col = np.empty(max(self.nnz, 1), dtype=np.int32)
         vals = np.empty(max(self.nnz, 1), dtype=np.complex128)

@@ -123,6 +123,7 @@ int launch_spmv_plain(hipStream_t s, const DevMatrix& A, const double2* x, const
 int spmv_grid_size(const DevMatrix& A);
 extern int g_rbcsr_variant;
 extern int g_hrb_lower_last;  // HRB kernel: process the lower (conj-transposed) section after the upper one
+extern int g_liouville_fused_n;  // matrix-free Liouvillian: largest n that takes the fused matrix-core kernel (else library GEMMs)
 extern int g_real_vals;   // operator refresh: stream a real copy of the values when they are all real (1, default)
 extern int g_stencil;     // operator build: encode blocks with block-wide column distances as stencil blocks (1, default)
 extern int g_acc_defer;   // qp_cheby_step: touch the Psi accumulator every third term only (1, default) or every term (0)

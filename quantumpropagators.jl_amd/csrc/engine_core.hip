@@ -63,6 +63,10 @@ int qp_tuning_set(const char* key, int value) {
     qp::g_hrb_lower_last = value;
     return QP_OK;
   }
+  if (std::strcmp(key, "liouville_fused_n") == 0) {
+    qp::g_liouville_fused_n = value;
+    return QP_OK;
+  }
   if (std::strcmp(key, "real_vals") == 0) {
     qp::g_real_vals = value;
     return QP_OK;

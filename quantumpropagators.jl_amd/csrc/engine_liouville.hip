@@ -65,7 +65,8 @@ struct Liouville {
   double2* G = nullptr;        // sum_k A_k^+ A_k
   double2* ML = nullptr;       // s_h H - (s_d / 2) G, including the operator's scale
   double2* MR = nullptr;       // s_h H + (s_d / 2) G, including the operator's scale
-  double2* T = nullptr;        // n x n workspace: A_k rho
+  double2* T = nullptr;        // n x n workspace: A_k rho (library path)
+  double2* Tk = nullptr;       // nc x (n x n) workspace: all A_k rho (fused path)
   double2* scratch = nullptr;  // n^2 workspace for the unfused Chebyshev term
   cplx scale = 1.0;            // the operator's scale, applied to the dissipator GEMMs
 };
@@ -91,6 +92,165 @@ __global__ __launch_bounds__(qp::kThreads) void liouville_combine_kernel(double2
     ML[p] = make_double2(h.x - gg.x, h.y - gg.y);
     MR[p] = make_double2(h.x + gg.x, h.y + gg.y);
   }
+}
+
+// ---------------------------------------------------------------------------
+// Hand-written fp64 matrix-core kernel for the sizes where a chain of library GEMMs is bound
+// by its launches (n <= 512):  Y = beta Y + sum_j alpha_j P_j op_j(Q_j)  in ONE launch, all
+// matrices n x n, column-major.  v_mfma_f64_16x16x4_f64: lane l holds A[l & 15][l >> 4] and
+// B[l >> 4][l & 15]; D register r of lane l is D[(l >> 4) + 4 r][l & 15].  A complex
+// product is four real ones (Re += ar br - ai bi, Im += ar bi + ai br).
+//   * one workgroup = one 16 x 16 tile of Y (BM = 1); its four wavefronts split the inner
+//     dimension in four and are summed through LDS in wave order (deterministic);
+//   * operands go from L2 straight into registers in the MFMA lane layout (the matrices are at
+//     most 4 MB each), software-pipelined D k-steps ahead across the flattened (term, k) loop;
+//   * `batched`: workgroup z computes only term z into Y + z n^2 (the K products A_k rho).
+// ---------------------------------------------------------------------------
+typedef double v4d __attribute__((ext_vector_type(4)));
+constexpr int kMaxTerms = 10;
+struct GemmTerm {
+  const double2* P;
+  const double2* Q;
+  double2 alpha;
+  int conjT;   // 0: Q, 1: Q^H
+};
+struct GemmTerms {
+  GemmTerm t[kMaxTerms];
+  int n_terms;
+};
+
+template <int BM>
+__global__ __launch_bounds__(256) void zgemm_sum_kernel(double2* __restrict__ Y, int n, double2 beta, GemmTerms terms,
+                                                        int batched) {
+  constexpr int D = (BM == 1) ? 8 : 3;   // k-steps of prefetch
+  __shared__ double red[3][BM * BM][2][4][64];   // partial tiles of waves 1..3
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int row0 = blockIdx.x * 16 * BM, col0 = blockIdx.y * 16 * BM;
+  const int first = batched ? blockIdx.z : 0;
+  const int nt = batched ? 1 : terms.n_terms;
+  double2* __restrict__ Yz = Y + (batched ? (size_t)blockIdx.z * n * n : 0);
+  // this wave's share of the inner dimension, in k-steps of 4
+  const int ksteps = (n + 3) / 4;
+  const int per = (ksteps + 3) / 4;
+  const int sbeg = wave * per;
+  const int send = min(ksteps, sbeg + per);
+  const int nsteps = max(send - sbeg, 0);
+  const int total = nt * nsteps;
+  const int li = lane & 15, lk = lane >> 4;
+
+  v4d cr[BM][BM], ci[BM][BM];
+#pragma unroll
+  for (int a = 0; a < BM; ++a)
+#pragma unroll
+    for (int b = 0; b < BM; ++b) cr[a][b] = ci[a][b] = v4d{0.0, 0.0, 0.0, 0.0};
+
+  double2 fa[D][BM], fb[D][BM];
+  auto load = [&](int slot, int flat) {
+    const int t = first + flat / nsteps;
+    const int k = (sbeg + flat % nsteps) * 4 + lk;
+    const GemmTerm& tm = terms.t[t];
+    const bool kin = k < n;
+#pragma unroll
+    for (int a = 0; a < BM; ++a) {
+      const int r = row0 + a * 16 + li;
+      const bool ok = kin && r < n;
+      const double2 v = tm.P[ok ? (size_t)k * n + r : 0];
+      fa[slot][a] = ok ? v : make_double2(0.0, 0.0);
+    }
+#pragma unroll
+    for (int b = 0; b < BM; ++b) {
+      const int c = col0 + b * 16 + li;
+      const bool ok = kin && c < n;
+      double2 v;
+      if (tm.conjT) {   // op(Q)[k][c] = conj(Q[c][k])
+        v = tm.Q[ok ? (size_t)k * n + c : 0];
+        v.y = -v.y;
+      } else {
+        v = tm.Q[ok ? (size_t)c * n + k : 0];
+      }
+      fb[slot][b] = ok ? v : make_double2(0.0, 0.0);
+    }
+  };
+  auto compute = [&](int slot, int flat) {
+    const double2 al = terms.t[first + flat / nsteps].alpha;
+#pragma unroll
+    for (int a = 0; a < BM; ++a) {
+      const double2 x = fa[slot][a];
+      const double ar = al.x * x.x - al.y * x.y, ai = al.x * x.y + al.y * x.x;   // alpha_j folded into the A fragment
+#pragma unroll
+      for (int b = 0; b < BM; ++b) {
+        const double2 y = fb[slot][b];
+        cr[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, y.x, cr[a][b], 0, 0, 0);
+        cr[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, y.y, cr[a][b], 0, 0, 0);
+        ci[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, y.y, ci[a][b], 0, 0, 0);
+        ci[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, y.x, ci[a][b], 0, 0, 0);
+      }
+    }
+  };
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (d < total) load(d, d);
+  for (int s = 0; s < total; s += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      if (s + d < total) {
+        compute(d, s + d);
+        if (s + d + D < total) load(d, s + d + D);
+      }
+    }
+  }
+  // sum the four k-quarters in wave order
+  if (wave > 0) {
+#pragma unroll
+    for (int a = 0; a < BM; ++a)
+#pragma unroll
+      for (int b = 0; b < BM; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          red[wave - 1][a * BM + b][0][r][lane] = cr[a][b][r];
+          red[wave - 1][a * BM + b][1][r][lane] = ci[a][b][r];
+        }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const bool bz = (beta.x == 0.0 && beta.y == 0.0) || batched;
+#pragma unroll
+    for (int a = 0; a < BM; ++a)
+#pragma unroll
+      for (int b = 0; b < BM; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          double vr = cr[a][b][r], vi = ci[a][b][r];
+          for (int w = 0; w < 3; ++w) {
+            vr += red[w][a * BM + b][0][r][lane];
+            vi += red[w][a * BM + b][1][r][lane];
+          }
+          const int row = row0 + a * 16 + lk + 4 * r, col = col0 + b * 16 + li;
+          if (row < n && col < n) {
+            double2* y = Yz + (size_t)col * n + row;
+            if (!bz) {
+              const double2 o = *y;
+              vr += beta.x * o.x - beta.y * o.y;
+              vi += beta.x * o.y + beta.y * o.x;
+            }
+            *y = make_double2(vr, vi);
+          }
+        }
+  }
+}
+
+int launch_zgemm_sum(hipStream_t s, double2* Y, int n, double2 beta, const GemmTerms& terms, int batched, Stats* st) {
+  if (terms.n_terms == 0) return QP_OK;
+  // 16 x 16 tiles: as many workgroups as the matrix offers.  (A 32 x 32 tile per wavefront halves
+  // the operand traffic but measured slower than the library chain from n = 320 on, where the
+  // library is used anyway: profiles/r01/liouville_matrix_free.txt.)
+  const int tiles = (n + 15) / 16;
+  const dim3 grid(tiles, tiles, batched ? terms.n_terms : 1);
+  hipLaunchKernelGGL(zgemm_sum_kernel<1>, grid, dim3(256), 0, s, Y, n, beta, terms, batched);
+  QP_HIP(hipGetLastError());
+  if (st) st->n_launch++;
+  return QP_OK;
 }
 
 inline const rocblas_double_complex* rc(const double2* p) { return reinterpret_cast<const rocblas_double_complex*>(p); }
@@ -122,6 +282,25 @@ int liouville_refresh(qp_operator* op) {
 int liouville_apply(hipStream_t s, void* self, const double2* x, double2* y, double2 alpha, double2 beta, Stats* st) {
   Liouville* L = static_cast<Liouville*>(self);
   const rocblas_int n = (rocblas_int)L->n;
+  if (L->n <= qp::g_liouville_fused_n && 2 + L->nc <= kMaxTerms) {
+    // two launches of the fused matrix-core kernel: T_k = A_k X (batched), then
+    // Y = beta Y + alpha (M_L X - X M_R) + alpha scale s_d sum_k T_k A_k^+
+    const cplx a(alpha.x, alpha.y);
+    if (L->nc > 0) {
+      GemmTerms t1;
+      t1.n_terms = L->nc;
+      for (int k = 0; k < L->nc; ++k) t1.t[k] = GemmTerm{L->A[k], x, make_double2(1.0, 0.0), 0};
+      QP_CHECK(launch_zgemm_sum(s, L->Tk, n, make_double2(0.0, 0.0), t1, 1, st));
+    }
+    GemmTerms t2;
+    t2.n_terms = 2 + L->nc;
+    t2.t[0] = GemmTerm{L->ML, x, d2(a), 0};
+    t2.t[1] = GemmTerm{x, L->MR, d2(-a), 0};
+    for (int k = 0; k < L->nc; ++k) t2.t[2 + k] = GemmTerm{L->Tk + (size_t)k * L->n * L->n, L->A[k], d2(a * L->scale * L->s_d), 1};
+    QP_CHECK(launch_zgemm_sum(s, y, n, beta, t2, 0, st));
+    if (st) st->n_matvec++;
+    return QP_OK;
+  }
   QP_ROCBLAS(L->api.set_stream(L->blas, s));
   const cplx a(alpha.x, alpha.y);
   const rocblas_double_complex al = rz(a), mal = rz(-a), be = rz(cplx(beta.x, beta.y)), one = rz(1.0), zero = rz(0.0);
@@ -153,6 +332,7 @@ void liouville_free(qp_operator* op) {
   if (L->ML) (void)hipFree(L->ML);
   if (L->MR) (void)hipFree(L->MR);
   if (L->T) (void)hipFree(L->T);
+  if (L->Tk) (void)hipFree(L->Tk);
   if (L->scratch) (void)hipFree(L->scratch);
   if (L->blas) (void)L->api.destroy_handle(L->blas);
   delete L;
@@ -208,6 +388,7 @@ int qp_liouvillian_create(qp_ctx* ctx, int64_t n, const qp_c128* const* H_terms,
   QP_CHECK(dev_alloc(&Lp->ML, n2));
   QP_CHECK(dev_alloc(&Lp->MR, n2));
   QP_CHECK(dev_alloc(&Lp->T, n2));
+  if (nc > 0) QP_CHECK(dev_alloc(&Lp->Tk, n2 * (size_t)nc));
   QP_CHECK(dev_alloc(&Lp->scratch, n2 * 1));   // vec(rho) has n^2 entries
   if (nc > 0) {
     QP_CHECK(dev_alloc(&Lp->G, n2));

@@ -20,7 +20,10 @@ FP64_MATRIX_PEAK_TF = 78.6      # MI355X fp64 matrix = fp64 vector rate (spec)
 def main():
     ctx = L.Context(0)
     rng = np.random.default_rng(0)
-    for n, nc in ((128, 1), (256, 1), (512, 2), (1024, 2), (2048, 1)):
+    sizes = ((128, 1), (256, 1), (512, 2), (1024, 2), (2048, 1))
+    if len(sys.argv) > 1:      # e.g. "64,1 192,1 384,2": n,c_ops pairs; each is run with both implementations
+        sizes = tuple(tuple(int(v) for v in a.split(",")) for a in sys.argv[1:])
+    for n, nc in sizes:
         H = synth.dense_hermitian(n, rho=2.0, rng=rng)
         cops = [0.2 * (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))) / np.sqrt(n) for _ in range(nc)]
         Lmf = L.Liouvillian(ctx, [H], cops, convention="TDSE")
@@ -35,7 +38,16 @@ def main():
             Lmf.mul(x, y)
         us = 1e3 * ctx.timer_end() / reps
         flops = 8.0 * n ** 3 * (2 + 2 * nc)
+        L.tuning_set("liouville_fused_n", 0)          # the chain of rocBLAS zgemm calls, for comparison
+        for _ in range(3):
+            Lmf.mul(x, y)
+        ctx.timer_begin()
+        for _ in range(reps):
+            Lmf.mul(x, y)
+        us_lib = 1e3 * ctx.timer_end() / reps
+        L.tuning_set("liouville_fused_n", 256)
         out = {"n": n, "N": n * n, "c_ops": nc, "gemms_per_apply": 2 + 2 * nc, "us_per_apply": us,
+               "us_per_apply_rocblas_chain": us_lib, "path": "fused mfma kernel" if n <= 256 else "rocblas zgemm chain",
                "tflops": flops / us / 1e6, "frac_fp64_matrix_peak": flops / us / 1e6 / FP64_MATRIX_PEAK_TF,
                # 1 (x) H - H^T (x) 1: 2 n^3 entries; per dense Lindblad operator n^4 + 2 n^3 more
                "sparse_superoperator_entries": 2 * n ** 3 + nc * (n ** 4 + 2 * n ** 3)}

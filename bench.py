@@ -145,7 +145,8 @@ def main():
                            + ("ncclSend/ncclRecv with the neighbours" if sh.p2p else "ncclAllGather") + ")") if use_native else \
                 "torch.distributed (native step disagreed with it in the self-check)"
         else:
-            driver_note = "torch.distributed (step loop in Python)"
+            driver_note = "torch.distributed (step loop in Python" + (
+                f"; native driver unavailable: {sh.native_error})" if getattr(sh, "native_error", None) else ")")
         sh.set_state(psi0_local)
 
         def step():

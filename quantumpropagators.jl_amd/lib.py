@@ -817,8 +817,8 @@ class Comm:
         uid = None
         if self.rank == 0:
             buf = C.create_string_buffer(128)
-            check(self.lib.qp_comm_unique_id(path, buf))
-            uid = buf.raw
+            if self.lib.qp_comm_unique_id(path, buf) == QP_OK:   # on failure the other ranks learn it (None)
+                uid = buf.raw
         uid = exchange_id(uid)
         assert isinstance(uid, (bytes, bytearray)) and len(uid) == 128
         self._h = _P()

@@ -240,28 +240,58 @@ class ShardedCheby:
         # the communicator's id.  Needs the HIP backend and one GPU per rank.
         self.native = None
         self.p2p = False
+        self.native_error = None
         if native and isinstance(be, HipBackend) and not self.host_staged:
-            comm = None
+            # Every step below that can fail is followed by an agreement over the torch group, so
+            # that either all ranks use the native driver or none does (a rank that raised while the
+            # others entered a collective would leave them waiting).
+            def agree(err):
+                errs = [None] * self.world
+                dist.all_gather_object(errs, None if err is None else str(err), group=group)
+                bad = [e for e in errs if e is not None]
+                return bad[0] if bad else None
+
+            def exchange_id(uid):
+                box = [uid]
+                dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0,
+                                           group=group)
+                if box[0] is None:
+                    raise RuntimeError("rank 0 could not obtain an RCCL id")
+                return box[0]
+            comm, err = None, None
             if self.exchanging:
-                def exchange_id(uid):
-                    box = [uid]
-                    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0,
-                                               group=group)
-                    return box[0]
-                comm = L.Comm(ctx, self.rank, self.world, exchange_id)
-            self.comm = comm
+                try:
+                    comm = L.Comm(ctx, self.rank, self.world, exchange_id)
+                except Exception as exc:      # noqa: BLE001 -- reported, and the Python driver is used instead
+                    err = exc
+                err = agree(err)
+            self.comm = comm if err is None else None
             # neighbour exchange when every rank talks to few others (banded H: 2), else all-gather
             npeers = [None] * self.world
             dist.all_gather_object(npeers, 0 if self.send_to is None else max(len(self.send_to), len(self.recv_from)),
                                    group=group)
             use_p2p = (self.exchanging and self.exchange == "halo" and not self.direct_send and
                        (p2p is True or (p2p == "auto" and max(npeers) <= max(2, self.world // 2))))
-            self.p2p = bool(use_p2p)
-            self.native = L.ShardedChebyStepper(
-                self.op, self.split, comm, self.Xfull[0], self.Xfull[1], self.acc,
-                None if (not self.exchanging or self.direct_send) else self.slab_state,
-                self.send_idx_host if (self.exchanging and not self.direct_send) else np.zeros(0, dtype=np.int64),
-                M, self.direct_send, self.send_to if use_p2p else None, self.recv_from if use_p2p else None)
+            stepper = None
+            if err is None:
+                try:
+                    stepper = L.ShardedChebyStepper(
+                        self.op, self.split, comm, self.Xfull[0], self.Xfull[1], self.acc,
+                        None if (not self.exchanging or self.direct_send) else self.slab_state,
+                        self.send_idx_host if (self.exchanging and not self.direct_send) else np.zeros(0, dtype=np.int64),
+                        M, self.direct_send, self.send_to if use_p2p else None, self.recv_from if use_p2p else None)
+                except Exception as exc:      # noqa: BLE001
+                    err = exc
+                err = agree(err)
+            if err is None:
+                self.native, self.p2p = stepper, bool(use_p2p)
+            else:
+                self.native_error = str(err)
+                if stepper is not None:
+                    stepper.close()
+                if comm is not None:
+                    comm.close()
+                    self.comm = None
         # start the ranks aligned: a rank that is still building its operator must not keep
         # the others waiting inside their first collective
         dist.barrier(group=group)

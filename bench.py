@@ -37,6 +37,10 @@ def main():
     ap.add_argument("--pattern", default="banded", choices=["banded", "scattered"])
     ap.add_argument("--format", default="auto", choices=["auto", "hrb", "rbcsr", "csr"])
     ap.add_argument("--exchange", default="auto", choices=["auto", "halo", "allgather"])
+    ap.add_argument("--dt", type=float, default=1.0, help="time step; alpha = 10 dt, i.e. 32 coefficients at dt = 1 "
+                    "(SURVEY 8d also asks for alpha = 2 and 50: --dt 0.2 / --dt 5)")
+    ap.add_argument("--real", action="store_true", help="real-symmetric H (the f64 variant of SURVEY 8d): values "
+                    "are streamed as fp64; algorithmic bytes (12 z + 84) N")
     ap.add_argument("--driver", default="native", choices=["native", "torch"],
                     help="multi-GPU step: one library call with its own RCCL communicator, or the Python loop")
     ap.add_argument("--cpu-steps", type=int, default=16,
@@ -72,12 +76,14 @@ def main():
     N = rows * world
     r0, r1 = rank * rows, (rank + 1) * rows
     offsets = synth.BANDED_OFFSETS if args.pattern == "banded" else synth.scattered_offsets(N)
-    Delta, E_min, dt = 20.0, -10.0, 1.0        # manual range [-10,10], specrange_buffer=0
+    Delta, E_min, dt = 20.0, -10.0, args.dt    # manual range [-10,10], specrange_buffer=0
     fmt = {"auto": L.FMT_AUTO, "hrb": L.FMT_HRB, "rbcsr": L.FMT_RBCSR, "csr": L.FMT_CSR}[args.format]
 
     stream = torch.cuda.current_stream().cuda_stream
     ctx = L.Context(local_rank, stream=stream)
     rp, col, vals = synth.hermitian_offsets_csr(N, offsets=offsets, row_begin=r0, row_end=r1)
+    if args.real:
+        vals = vals.real.astype(np.complex128)
     psi0_local = synth.random_state(N, row_begin=r0, row_end=r1)
     nnz_local = int(rp[-1])
     coeffs = L.cheby_coeffs(Delta, dt)
@@ -85,6 +91,7 @@ def main():
 
     parity = None
     cpu = None
+    cpu_omp = None
     if world == 1:
         op = L.Operator(ctx, [L.Matrix(ctx, rows, N, rp, col, vals)], 0, fmt)
         wrk = L.ChebyWrk(ctx, N, Delta, E_min, dt)
@@ -116,6 +123,22 @@ def main():
                    "ms_per_step": 1e3 * tc / args.cpu_steps,
                    "l2_diff_vs_gpu_after_sample": parity}
             del colptr, rowval, nzval, cpsi
+            # the same arithmetic with every host core: row-parallel CSR, passes fused (OpenMP)
+            nthreads = ref_c.omp_threads()
+            opsi = psi0_local.copy()
+            col64 = col.astype(np.int64)
+            ref_c.cheby_csr_omp(rp, col64, vals, opsi, coeffs, Delta, E_min, dt)       # warm-up, first touch
+            opsi = psi0_local.copy()
+            osteps = 2 * args.cpu_steps
+            t0 = time.perf_counter()
+            for _ in range(osteps):
+                ref_c.cheby_csr_omp(rp, col64, vals, opsi, coeffs, Delta, E_min, dt)
+            to = time.perf_counter() - t0
+            cpu_omp = {"value": osteps / to, "unit": "prop_step/s", "cores": int(nthreads), "kind": "port",
+                       "sample": f"{osteps} prop_steps of the same workload (oracle/cheby_ref.c: OpenMP row-parallel CSR "
+                                 f"mat-vec with the term's BLAS-1 passes fused into the row loop)",
+                       "ms_per_step": 1e3 * to / osteps}
+            del col64, opsi
         exchange_used = "none"
     else:
         import qprop_amd.sharded as sharded
@@ -173,6 +196,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # on-box streaming ceiling: y += a x over 2^26 complex elements, 48 B per element
+    stream_gbs = None
+    if world == 1:
+        ns = 1 << 26
+        sx, sy = L.State(ctx, n=ns), L.State(ctx, n=ns)
+        sx.fill(1.0)
+        for _ in range(2):
+            sy.axpy(0.5, sx)
+        ctx.timer_begin()
+        for _ in range(10):
+            sy.axpy(0.5, sx)
+        stream_gbs = 10 * 48.0 * ns / (ctx.timer_end() * 1e-3) / 1e9
+        sx.close()
+        sy.close()
+
     for _ in range(args.warmup):
         step()
     ctx.reset_stats()
@@ -205,14 +243,15 @@ def main():
     traffic = None
     kern = {1: "csr_spmv_kernel<16,ChebyOp>", 2: "rbcsr_spmv_kernel<ChebyOp,7>", 3: "hrb_spmv_kernel<ChebyOp,7>"}[fmt_used]
     pmc_file = os.path.join(ROOT, "profiles", "r01", "bench_stencil_pmc_summary.json")
-    if fmt_used == 3 and world == 1 and args.log2n == 20 and args.pattern == "banded" and os.path.exists(pmc_file):
+    if (fmt_used == 3 and world == 1 and args.log2n == 20 and args.pattern == "banded" and not args.real and
+            os.path.exists(pmc_file)):
         with open(pmc_file) as f:
             traffic = json.load(f)["hbm_traffic_bytes_per_launch"]
 
     steps_per_s = args.steps / elapsed
     n_launch = args.steps * nterms
     # algorithmic bytes of one fused term on one GPU: (20 z + 84) N + 4
-    alg_bytes = 20.0 * nnz_local + 4.0 * (rows + 1) + 80.0 * rows
+    alg_bytes = (12.0 if args.real else 20.0) * nnz_local + 4.0 * (rows + 1) + 80.0 * rows
     avg_launch_s = (ev_ms * 1e-3) / n_launch
     achieved = alg_bytes / avg_launch_s / 1e9
     out = {
@@ -222,9 +261,10 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "c128 (complex fp64)", "data": "synthetic",
+        "dtype": "c128 state, f64 matrix values" if args.real else "c128 (complex fp64)", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: Cheby prop_step!, CSR sparse Hermitian H, 16 nnz/row, "
-                               "complex fp64 values, int32 indices",
+                               + ("real fp64 values (f64 variant), " if args.real else "complex fp64 values, ")
+                               + "int32 indices",
                    "rows_per_gpu": rows, "N_total": N, "nnz_per_row": 16, "pattern": args.pattern,
                    "offsets": [int(o) for o in offsets], "n_coeffs": int(len(coeffs)), "matvecs_per_step": nterms,
                    "spectral_range": [-10.0, 10.0], "dt": dt,
@@ -243,6 +283,8 @@ def main():
                      "avg_launch_us": avg_launch_s * 1e6,
                      "launches_timed": n_launch, "hip_event_ms": ev_ms,
                      "traffic_rate_gbs": (traffic / avg_launch_s / 1e9) if traffic else None,
+                     "hbm_stream_measured_gbs": stream_gbs,
+                     "traffic_frac_of_stream": (traffic / avg_launch_s / 1e9 / stream_gbs) if (traffic and stream_gbs) else None,
                      "traffic_frac_of_peak": (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
                      "note": "avg launch duration = HIP-event time of the timed region on the kernels' stream / "
                              "number of fused-term launches (includes launch gaps; multi-GPU: includes exchange). "
@@ -253,6 +295,7 @@ def main():
                              "`achieved` exceeds what the same bytes would allow -- `traffic` is the HBM bytes the "
                              "PMC counters saw per launch, `traffic_rate_gbs` / `traffic_frac_of_peak` the real HBM rate"},
         "cpu_baseline": cpu,
+        "cpu_baseline_all_cores": cpu_omp,
         "pcie_inclusive_steps_per_s": pcie,
         "stats": {"n_matvec": st["n_matvec"], "kernel_launches": st["n_kernel_launches"]},
     }

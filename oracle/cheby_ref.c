@@ -57,3 +57,50 @@ int qp_ref_cheby_csc(int64_t n, const int64_t* colptr, const int64_t* rowval, co
   for (int64_t i = 0; i < n; ++i) psi[i] *= ph;
   return nmv;
 }
+
+/* All-cores variant (CPU baseline): the same cheby! arithmetic with a row-parallel
+ * CSR mat-vec and the shift / scale / recurrence / accumulate passes of a term fused into the
+ * row loop -- what a tuned multi-threaded CPU implementation of the path would do.  H is
+ * passed in CSR (for the Hermitian benchmark matrix that is the conjugate of its CSC).
+ * Summation order differs from the serial port (row-wise dot products), so it agrees with it to
+ * rounding, not bit for bit.  Returns the number of mat-vecs. */
+int qp_ref_cheby_csr_omp(int64_t n, const int64_t* rowptr, const int64_t* col, const c128* val, c128* psi,
+                         c128* v0, c128* v1, const double* a, int n_coeffs, double Delta, double E_min,
+                         double dt) {
+  if (n_coeffs < 2 || !(Delta > 0)) return -1;
+  const double beta = (Delta / 2) + E_min;
+  c128 c = (dt > 0) ? (-2.0 * I) / Delta : (2.0 * I) / Delta;
+  const c128 ph = cexp(-I * beta * dt);
+  int nmv = 0;
+  /* term 1: v0 = Psi; v1 = c (H v0 - beta v0); Psi = a0 v0 + a1 v1 */
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) v0[i] = psi[i];
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) {
+    c128 s = 0.0;
+    for (int64_t p = rowptr[i]; p < rowptr[i + 1]; ++p) s += val[p] * v0[col[p]];
+    const c128 t = c * (s - beta * v0[i]);
+    v1[i] = t;
+    psi[i] = a[0] * v0[i] + a[1] * t;
+  }
+  ++nmv;
+  c *= 2;
+  for (int k = 2; k < n_coeffs; ++k) {
+    /* v2 = c (H v1 - beta v1) + v0, written over v0 (row-local); Psi += a_k v2 */
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+      c128 s = 0.0;
+      for (int64_t p = rowptr[i]; p < rowptr[i + 1]; ++p) s += val[p] * v1[col[p]];
+      const c128 t = c * (s - beta * v1[i]) + v0[i];
+      v0[i] = t;
+      psi[i] += a[k] * t;
+    }
+    ++nmv;
+    c128* tmp = v0;
+    v0 = v1;
+    v1 = tmp;
+  }
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) psi[i] *= ph;
+  return nmv;
+}

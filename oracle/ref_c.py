@@ -11,6 +11,33 @@ _SO = os.path.join(_HERE, "libqp_ref.so")
 _lib = None
 
 
+def usable_cores():
+    """Cores this process may really use: the affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                txt = f.read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        n = min(n, max(1, int(q / int(f.read()) + 0.5)))
+        except (OSError, ValueError, IndexError):
+            pass
+    return n
+
+
+def omp_threads():
+    """Thread count of the OpenMP variant (fixed before libgomp starts: OMP_NUM_THREADS)."""
+    if "OMP_NUM_THREADS" not in os.environ:
+        os.environ["OMP_NUM_THREADS"] = str(usable_cores())
+    return int(os.environ["OMP_NUM_THREADS"])
+
+
 def build():
     subprocess.check_call(["make", "-s", "-C", _HERE])
 
@@ -18,11 +45,14 @@ def build():
 def load():
     global _lib
     if _lib is None:
+        omp_threads()
         if not os.path.exists(_SO):
             build()
         _lib = C.CDLL(_SO)
         _lib.qp_ref_cheby_csc.restype = C.c_int
         _lib.qp_ref_cheby_csc.argtypes = [C.c_int64] + [C.c_void_p] * 8 + [C.c_int, C.c_double, C.c_double, C.c_double]
+        _lib.qp_ref_cheby_csr_omp.restype = C.c_int
+        _lib.qp_ref_cheby_csr_omp.argtypes = [C.c_int64] + [C.c_void_p] * 7 + [C.c_int, C.c_double, C.c_double, C.c_double]
     return _lib
 
 
@@ -39,5 +69,23 @@ def cheby_csc(colptr, rowval, nzval, psi, a, Delta, E_min, dt):
     p = lambda x: x.ctypes.data_as(C.c_void_p)  # noqa: E731
     nmv = lib.qp_ref_cheby_csc(n, p(colptr), p(rowval), p(nzval), p(psi), p(w[0]), p(w[1]), p(w[2]), p(a),
                                len(a), float(Delta), float(E_min), float(dt))
+    assert nmv == len(a) - 1
+    return psi
+
+
+def cheby_csr_omp(rowptr, col, val, psi, a, Delta, E_min, dt):
+    """All-cores variant (OpenMP, row-parallel CSR, fused passes); in-place on ``psi``.  The
+    thread count is OpenMP's (OMP_NUM_THREADS or all cores)."""
+    lib = load()
+    n = len(psi)
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+    col = np.ascontiguousarray(col, dtype=np.int64)
+    val = np.ascontiguousarray(val, dtype=np.complex128)
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    assert psi.dtype == np.complex128 and psi.flags.c_contiguous
+    w = [np.empty(n, dtype=np.complex128) for _ in range(2)]
+    p = lambda x: x.ctypes.data_as(C.c_void_p)  # noqa: E731
+    nmv = lib.qp_ref_cheby_csr_omp(n, p(rowptr), p(col), p(val), p(psi), p(w[0]), p(w[1]), p(a), len(a),
+                                   float(Delta), float(E_min), float(dt))
     assert nmv == len(a) - 1
     return psi

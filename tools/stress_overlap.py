@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Race hunt for the overlapped multi-GPU schedule on one GPU (world = 1, forced send set):
-many steps of the overlapped/flag schedule must stay bit-identical to the serial schedule, for
-several sizes (different kernel durations -> different interleavings of the two streams)."""
+many steps of every schedule -- Python-driven (events / in-launch counter) and the native
+one-call driver (all-gather, neighbour send/recv, serial) -- must stay bit-identical to the
+serial Python-driven schedule, for several sizes (different kernel durations -> different
+interleavings of the two streams)."""
 import os, sys, socket
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,7 +25,10 @@ for log2n, steps in ((14, 300), (16, 300), (18, 200), (20, 100)):
     send = np.concatenate([np.arange(0, w), np.arange(N - w, N)])
     psi0 = synth.random_state(N)
     outs = {}
-    for name, kw, mode in (("serial", dict(overlap=False), 1), ("flag", dict(overlap=True), 1), ("events", dict(overlap=True), 0)):
+    for name, kw, mode in (("serial", dict(overlap=False), 1), ("flag", dict(overlap=True), 1), ("events", dict(overlap=True), 0),
+                           ("native", dict(overlap=True, native=True, p2p=False), 1),
+                           ("native-p2p", dict(overlap=True, native=True, p2p=True), 1),
+                           ("native-serial", dict(overlap=False, native=True), 1)):
         L.tuning_set("split_mode", mode)
         sh = sharded.ShardedCheby(ctx, rp, col, vals, N, 0, N, 20.0, -10.0, 1.0, exchange="halo", _debug_send_rows=send, **kw)
         sh.set_state(psi0)
@@ -33,9 +38,9 @@ for log2n, steps in ((14, 300), (16, 300), (18, 200), (20, 100)):
         sh.check()
         outs[name] = (sh.local_state(), sh.be.read(sh.X[0], N, N + len(send)))
         del sh
-    for name in ("flag", "events"):
+    for name in ("flag", "events", "native", "native-p2p", "native-serial"):
         same = np.array_equal(outs[name][0], outs["serial"][0]) and np.array_equal(outs[name][1], outs["serial"][1])
-        print(f"N=2^{log2n} steps={steps} {name:7s} == serial: {same}  norm={np.linalg.norm(outs[name][0]):.15f}", flush=True)
+        print(f"N=2^{log2n} steps={steps} {name:13s} == serial: {same}  norm={np.linalg.norm(outs[name][0]):.15f}", flush=True)
         bad += 0 if same else 1
     L.tuning_set("split_mode", 1)
     ctx.close()

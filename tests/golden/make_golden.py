@@ -106,6 +106,45 @@ def main():
                         rowval=(A.indices + 1).astype(np.int64), nzval=A.data, rowptr=rowptr, col=col, vals=vals,
                         rp1000=rp1000, parts_rows_8=qo.partition_rows(rp1000, 8), parts_nnz_8=qo.partition_rows(rp1000, 8, "nnz"),
                         parts_rows_3=qo.partition_rows(rp1000, 3), parts_nnz_3=qo.partition_rows(rp1000, 3, "nnz"))
+    # F2: config C1 -- N = 128 dense complex Hermitian, Cheby, 200 steps (alpha ~ 5), checkpoints every 50 steps;
+    #     the exact exponential is the independent check (test/test_cheby.jl:24-47 pattern)
+    rng = np.random.default_rng(128)
+    N = 128
+    Hd = synth.dense_hermitian(N, rho=10.0, rng=rng)
+    evd = np.linalg.eigvalsh(Hd)
+    E_min, E_max = float(np.floor(evd[0]) - 1), float(np.ceil(evd[-1]) + 1)
+    dt = 10.0 / (E_max - E_min)                     # alpha = Delta dt / 2 = 5
+    psi0 = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    psi0 /= np.linalg.norm(psi0)
+    wrk = qo.ChebyWrk(psi0, E_max - E_min, E_min, dt)
+    psi = psi0.copy()
+    cps = []
+    for k in range(200):
+        qo.cheby(psi, Hd, dt, wrk)
+        if (k + 1) % 50 == 0:
+            cps.append(psi.copy())
+    np.savez_compressed(os.path.join(HERE, "F2_cheby_c1_dense128.npz"), H=Hd, psi0=psi0, dt=dt, E_min=E_min, E_max=E_max,
+                        n_coeffs=np.int64(wrk.n_coeffs), checkpoints=np.stack(cps, axis=1))
+
+    # F7: Liouvillian superoperator applied to rho (src/generators.jl:473-631), n = 6, two Lindblad operators,
+    #     both conventions, with a control coefficient: frozen targets for the sparse and the matrix-free operator
+    rng = np.random.default_rng(7)
+    n = 6
+    H0 = synth.dense_hermitian(n, rho=2.0, rng=rng)
+    H1 = synth.dense_hermitian(n, rho=1.0, rng=rng)
+    cops = np.stack([0.4 * (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))) for _ in range(2)])
+    rho = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    vec = np.ascontiguousarray(rho.T).reshape(-1)    # column-major vec(rho)
+    eps = 0.35
+    out = {}
+    for conv in ("TDSE", "LvN"):
+        Ls = synth.ham_to_superop(sp.csr_matrix(H0), conv) + eps * synth.ham_to_superop(sp.csr_matrix(H1), conv)
+        for A in cops:
+            Ls = Ls + synth.lindblad_to_superop(sp.csr_matrix(A), conv)
+        out[f"L_{conv}"] = Ls.toarray()
+        out[f"Lrho_{conv}"] = Ls @ vec
+    np.savez_compressed(os.path.join(HERE, "F7_liouvillian_n6.npz"), H0=H0, H1=H1, c_ops=cops, rho=rho, eps=eps, **out)
+
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

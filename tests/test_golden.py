@@ -101,6 +101,37 @@ def test_f6_index_work_via_cabi():
         assert np.array_equal(L.partition_rows(f["rp1000"], parts, "nnz"), f[f"parts_nnz_{parts}"])
 
 
+def test_f2_c1_dense_oracle_and_exact():
+    f = _load("F2_cheby_c1_dense128.npz")
+    H, dt = f["H"], float(f["dt"])
+    wrk = qo.ChebyWrk(f["psi0"], float(f["E_max"]) - float(f["E_min"]), float(f["E_min"]), dt)
+    assert wrk.n_coeffs == int(f["n_coeffs"])
+    psi = f["psi0"].copy()
+    for k in range(200):
+        qo.cheby(psi, H, dt, wrk)
+        if (k + 1) % 50 == 0:
+            assert np.linalg.norm(psi - f["checkpoints"][:, (k + 1) // 50 - 1]) < 1e-12
+    ev, V = np.linalg.eigh(H)
+    exact = V @ (np.exp(-1j * ev * 200 * dt) * (V.conj().T @ f["psi0"]))
+    assert np.linalg.norm(f["checkpoints"][:, -1] - exact) < TOL
+
+
+def test_f7_liouvillian_formulas():
+    """The frozen superoperator equals the Lindblad map written out on rho (:TDSE: i d rho/dt = L rho)."""
+    f = _load("F7_liouvillian_n6.npz")
+    rho, n = f["rho"], f["rho"].shape[0]
+    H = f["H0"] + float(f["eps"]) * f["H1"]
+    comm = H @ rho - rho @ H
+    diss = np.zeros_like(rho)
+    for A in f["c_ops"]:
+        G = A.conj().T @ A
+        diss = diss + A @ rho @ A.conj().T - 0.5 * (G @ rho + rho @ G)
+    vec = lambda M: np.ascontiguousarray(M.T).reshape(-1)       # noqa: E731
+    assert np.linalg.norm(f["Lrho_TDSE"] - vec(comm + 1j * diss)) < 1e-12
+    assert np.linalg.norm(f["Lrho_LvN"] - vec(1j * comm + diss)) < 1e-12
+    assert f["L_TDSE"].shape == (n * n, n * n)
+
+
 # ------------------------------------------------------------------ GPU: HIP path vs fixtures
 
 @pytest.fixture(scope="module")
@@ -166,3 +197,44 @@ def test_gpu_f5_specrange(ctx):
     assert len(ritz) == len(f["ritz"]) and np.max(np.abs(ritz - f["ritz"])) < 1e-8
     lo, hi = L.specrange_arnoldi(Op, st, prec=1e-4)
     assert abs(lo - float(f["E_min"])) < 1e-8 and abs(hi - float(f["E_max"])) < 1e-8
+
+
+@pytest.mark.gpu
+def test_gpu_f2_c1_dense(ctx):
+    """BASELINE config C1: N = 128 dense Hermitian, Cheby, 200 steps, through propagate()."""
+    import qprop_amd.propagator as P
+    f = _load("F2_cheby_c1_dense128.npz")
+    dt = float(f["dt"])
+    tlist = dt * np.arange(201)
+    _, st = P.propagate(f["psi0"], (f["H"],), tlist, method="cheby", storage=True, ctx=ctx, E_min=float(f["E_min"]),
+                        E_max=float(f["E_max"]), specrange_buffer=0.0)
+    for k in range(4):
+        assert np.linalg.norm(st[:, 50 * (k + 1)] - f["checkpoints"][:, k]) < TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("convention", ["TDSE", "LvN"])
+def test_gpu_f7_liouvillian(ctx, convention):
+    """Sparse superoperator and matrix-free operator (both implementations) against the frozen L rho."""
+    import qprop_amd.propagator as P
+    f = _load("F7_liouvillian_n6.npz")
+    vec = np.ascontiguousarray(f["rho"].T).reshape(-1)
+    want = f[f"Lrho_{convention}"]
+    gen = P.liouvillian((f["H0"], (f["H1"], lambda t: float(f["eps"]))), list(f["c_ops"]), convention=convention)
+    Lsp = gen.ops[0] + float(f["eps"]) * gen.ops[1]
+    assert np.max(np.abs(Lsp.toarray() - f[f"L_{convention}"])) < 1e-13
+    x = L.State(ctx, data=vec)
+    for fused in (4096, 0):
+        L.tuning_set("liouville_fused_n", fused)
+        try:
+            Lmf = L.Liouvillian(ctx, [f["H0"], f["H1"]], list(f["c_ops"]), ncoeffs=1, convention=convention)
+            Lmf.set_coeffs([float(f["eps"])])
+            y = L.State(ctx, n=len(vec))
+            Lmf.mul(x, y)
+            assert np.linalg.norm(y.numpy() - want) < 1e-12
+        finally:
+            L.tuning_set("liouville_fused_n", 256)
+    Op = L.Operator(ctx, [L.Matrix.from_scipy(ctx, sp.csr_matrix(Lsp))])
+    y = L.State(ctx, n=len(vec))
+    Op.mul(x, y)
+    assert np.linalg.norm(y.numpy() - want) < 1e-12

@@ -209,3 +209,67 @@ def test_accumulator_schedule_host():
             acc = r + a[m] * v[m]
             last = m
         assert acc == ref
+
+
+# ---- property tests of the boundary's index work (bit-exact, no GPU) ------------------------
+
+from hypothesis import given, settings, strategies as st   # noqa: E402
+
+
+@st.composite
+def _sparse_csc(draw):
+    """A Julia-style SparseMatrixCSC: 1-based Int64 colptr / rowval, rows ascending per column,
+    possibly empty columns and rows, rectangular."""
+    nrows = draw(st.integers(1, 40))
+    ncols = draw(st.integers(1, 40))
+    seed = draw(st.integers(0, 2 ** 31 - 1))
+    rng = np.random.default_rng(seed)
+    colptr = [1]
+    rowval = []
+    for _ in range(ncols):
+        k = int(rng.integers(0, min(nrows, 7) + 1)) if rng.random() > 0.2 else 0
+        rows = np.sort(rng.choice(nrows, size=k, replace=False)) + 1
+        rowval.extend(int(r) for r in rows)
+        colptr.append(colptr[-1] + k)
+    nz = rng.standard_normal(len(rowval)) + 1j * rng.standard_normal(len(rowval))
+    return nrows, ncols, np.array(colptr, dtype=np.int64), np.array(rowval, dtype=np.int64), nz
+
+
+@settings(max_examples=150, deadline=None)
+@given(_sparse_csc())
+def test_csc_to_csr_property(m):
+    """qp_csc_to_csr_host against SciPy for arbitrary (empty rows/columns, rectangular) CSC input:
+    same pattern, same values bit for bit, columns ascending within a row, and identical to the
+    oracle's restatement."""
+    import scipy.sparse as sp
+    import qprop_amd.lib as L
+    from oracle import qp_oracle as qo
+    nrows, ncols, colptr, rowval, nz = m
+    rp, col, vals = L.csc_to_csr(nrows, ncols, colptr, rowval, nz)
+    A = sp.csc_matrix((nz, rowval - 1, colptr - 1), shape=(nrows, ncols)).tocsr()
+    A.sort_indices()
+    assert np.array_equal(rp, A.indptr) and np.array_equal(col, A.indices) and np.array_equal(vals, A.data)
+    orp, ocol, ovals = qo.csc_to_csr(nrows, ncols, colptr, rowval, nz)
+    assert np.array_equal(rp, orp) and np.array_equal(col, ocol) and np.array_equal(vals, ovals)
+    for r in range(nrows):
+        assert np.all(np.diff(col[rp[r]:rp[r + 1]]) > 0)
+
+
+@settings(max_examples=150, deadline=None)
+@given(st.lists(st.integers(0, 12), min_size=1, max_size=300), st.integers(1, 9), st.sampled_from(["rows", "nnz"]))
+def test_partition_rows_property(lens, nparts, balance):
+    """qp_partition_rows_host: contiguous blocks that tile [0, nrows), monotone, identical to the
+    oracle, and balanced: by rows within one row, by nnz within the longest row."""
+    import qprop_amd.lib as L
+    from oracle import qp_oracle as qo
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    nrows = len(lens)
+    b = L.partition_rows(rp, nparts, balance)
+    assert b[0] == 0 and b[-1] == nrows and np.all(np.diff(b) >= 0) and len(b) == nparts + 1
+    assert np.array_equal(b, qo.partition_rows(rp, nparts, balance))
+    if balance == "rows":
+        sizes = np.diff(b)
+        assert sizes.max() - sizes.min() <= 1
+    else:
+        w = rp[b[1:]] - rp[b[:-1]]
+        assert w.max() <= rp[-1] / nparts + max(lens) + 1

@@ -957,3 +957,72 @@ def test_matrix_free_liouvillian_newton_and_cheby(ctx, liouville_path):
     assert np.linalg.norm(xs.numpy() - ref) < TOL
     U = np.linalg.matrix_power(__import__("scipy.linalg", fromlist=["expm"]).expm(-1j * 0.3 * Hs[0]), 3)
     assert np.linalg.norm(xs.numpy().reshape(n, n).T - U @ rho0 @ U.conj().T) < 1e-9
+
+
+# ---------------------------------------------------------------- property test over random operators
+
+from hypothesis import HealthCheck, given, settings, strategies as st   # noqa: E402
+
+
+@st.composite
+def _random_operator(draw):
+    """Band-structured + randomly perturbed sparse matrices: regular stencil blocks, wrap-around,
+    ragged and empty rows, real or complex values, Hermitian or not, any size."""
+    n = draw(st.integers(1, 700))
+    seed = draw(st.integers(0, 2 ** 31 - 1))
+    hermitian = draw(st.booleans())
+    real = draw(st.booleans())
+    n_offsets = draw(st.integers(0, 5))
+    n_random = draw(st.integers(0, 60))
+    n_empty = draw(st.integers(0, 3))
+    rng = np.random.default_rng(seed)
+    A = sp.lil_matrix((n, n), dtype=complex)
+    val = (lambda k: rng.standard_normal(k)) if real else (lambda k: rng.standard_normal(k) + 1j * rng.standard_normal(k))
+    for d in rng.integers(0, max(1, n // 2 + 1), n_offsets):
+        rows = np.arange(n)
+        A[rows, (rows + int(d)) % n] = val(n)
+    if n_random:
+        A[rng.integers(0, n, n_random), rng.integers(0, n, n_random)] = val(n_random)
+    for r in rng.integers(0, n, n_empty):
+        A[int(r), :] = 0
+    A = sp.csr_matrix(A)
+    if hermitian:
+        A = sp.csr_matrix(A + A.conj().T)
+    A.eliminate_zeros()
+    A.sort_indices()
+    return A, hermitian, real, seed
+
+
+@pytest.mark.parametrize("fmt", [L.FMT_AUTO, L.FMT_CSR, L.FMT_RBCSR, L.FMT_HRB])
+@settings(max_examples=25, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(_random_operator())
+def test_random_operators_all_formats(ctx, fmt, m):
+    """Whatever the structure: the device copy reads back bit for bit, mul! and one cheby! term
+    (through cheby_term, no spectral assumptions) match SciPy / the formula, and the real copy,
+    stencil and int16 encodings (all on by default) never change a result."""
+    A, hermitian, real, seed = m
+    n = A.shape[0]
+    hermitian = (abs(A - A.conj().T) > 0).nnz == 0          # a random draw can be Hermitian by accident
+    if fmt == L.FMT_HRB and not hermitian:
+        with pytest.raises(L.QPError):
+            L.Operator(ctx, [L.Matrix.from_scipy(ctx, A)], fmt=fmt)
+        return
+    Op = L.Operator(ctx, [L.Matrix.from_scipy(ctx, A)], fmt=fmt)
+    rp, col, vals = Op.get_csr()
+    assert np.array_equal(rp, A.indptr) and np.array_equal(col, A.indices) and np.array_equal(vals, A.data)
+    rng = np.random.default_rng(seed + 1)
+    x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    y0 = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    xs, ys = L.State(ctx, data=x), L.State(ctx, data=y0)
+    Op.mul(xs, ys, 0.3 - 0.7j, 1.1 + 0.2j)
+    ref = (1.1 + 0.2j) * y0 + (0.3 - 0.7j) * (A @ x)
+    scale = max(1.0, np.linalg.norm(ref))
+    assert np.linalg.norm(ys.numpy() - ref) < 1e-12 * scale
+    v0 = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    acc = L.State(ctx, data=y0)
+    vout = L.State(ctx, data=v0)
+    c, beta, a = 0.2 - 0.4j, 0.3, 0.7
+    L.cheby_term(Op, xs, 0, vout, vout, acc, acc, c, beta, 0.0, a, 1.0)
+    t = c * (A @ x - beta * x) + v0
+    assert np.linalg.norm(vout.numpy() - t) < 1e-12 * max(1.0, np.linalg.norm(t))
+    assert np.linalg.norm(acc.numpy() - (y0 + a * t)) < 1e-12 * max(1.0, np.linalg.norm(y0 + a * t))

@@ -402,3 +402,61 @@ def test_liouvillian_generator_sparse_and_matrix_free(ctx, convention):
         P.liouvillian(H0, cops, convention="foo")
     with pytest.raises(ValueError):
         P.liouvillian(None, (), convention="TDSE")
+
+
+def test_liouvillian_reference_tests(ctx):
+    """test/test_liouvillian.jl restated.  "TLS dissipation" (:12-50): pure dissipator, analytic
+    rho(T) -- propagated here with Newton (the reference uses :expprop) through the sparse and the
+    matrix-free operator.  "LvN" (:53-124): N = 100, H = H0 + eps H1, 99 decay + 100 dephasing
+    Lindblad operators; L rho equals the Lindblad right-hand side for both conventions, with and
+    without the control term, for the sparse generator and the matrix-free operator."""
+    ket = lambda i, n: np.eye(n, dtype=complex)[:, i]                     # noqa: E731
+    ketbra = lambda i, j, n: np.outer(ket(i, n), ket(j, n).conj())        # noqa: E731
+    g1, g2, T = 0.5, 0.2, 1.0
+    A1, A2 = np.sqrt(g1) * ketbra(0, 1, 2), np.sqrt(2 * g2) * ketbra(1, 1, 2)
+    psi0 = (ket(0, 2) + ket(1, 2)) / np.sqrt(2)
+    rho0 = np.ascontiguousarray(np.outer(psi0, psi0.conj()).T).reshape(-1)
+    expected = 0.5 * np.array([[2 - np.exp(-g1 * T), np.exp(-(g1 / 2 + g2) * T)],
+                               [np.exp(-(g1 / 2 + g2) * T), np.exp(-g1 * T)]], dtype=complex)
+    tlist = np.linspace(0, T, 11)
+    for mf in (False, True):
+        Lg = P.liouvillian(None, [A1, A2], convention="TDSE", matrix_free=mf)
+        out = P.propagate(rho0, Lg, tlist, method="newton", ctx=ctx, m_max=3)
+        rho = out.reshape(2, 2).T
+        assert abs(1 - np.trace(rho)) < 1e-12 and abs(np.trace(rho @ rho)) < 1.0
+        assert np.linalg.norm(rho - expected) < 1e-11
+    # ---- "LvN"
+    rng = np.random.default_rng(100)
+    N = 100
+    H0 = synth.dense_hermitian(N, rho=1.0, rng=rng)
+    H1 = synth.dense_hermitian(N, rho=0.1, rng=rng)
+    Hfull = H0 + H1
+    psi = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    psi /= np.linalg.norm(psi)
+    r0 = np.outer(psi, psi.conj())
+    vec = np.ascontiguousarray(r0.T).reshape(-1)
+    unvec = lambda v: v.reshape(N, N).T                                     # noqa: E731
+    x = L.State(ctx, data=vec)
+
+    def apply(gen_or_op):
+        if isinstance(gen_or_op, L.Operator):
+            op = gen_or_op
+        else:
+            op = L.Operator(ctx, [L.Matrix.from_scipy(ctx, sp.csr_matrix(gen_or_op))])
+        y = L.State(ctx, n=N * N)
+        op.mul(x, y)
+        return unvec(y.numpy())
+    comm = Hfull @ r0 - r0 @ Hfull
+    assert np.linalg.norm(1j * comm - apply(P.liouvillian(Hfull, convention="LvN"))) < 1e-13
+    assert np.linalg.norm(comm - apply(P.liouvillian(Hfull, convention="TDSE"))) < 1e-13
+    cops = [np.sqrt(0.2) * ketbra(0, i, N) for i in range(1, N)] + [np.sqrt(0.1) * ketbra(i, i, N) for i in range(N)]
+    diss = sum(A @ r0 @ A.conj().T - 0.5 * (A.conj().T @ A @ r0) - 0.5 * (r0 @ A.conj().T @ A) for A in cops)
+    Lm = P.liouvillian(H0, [sp.csr_matrix(A) for A in cops], convention="LvN")
+    assert sp.issparse(Lm)
+    assert np.linalg.norm(apply(Lm) - (1j * (H0 @ r0 - r0 @ H0) + diss)) < 1e-13
+    Lg = P.liouvillian((H0, (H1, lambda t: 1.0)), [sp.csr_matrix(A) for A in cops], convention="LvN")
+    assert isinstance(Lg, P.Generator) and len(Lg.ops) == 2
+    assert np.linalg.norm(apply(Lg.ops[0] + Lg.ops[1] * Lg.amplitudes[0](0.0)) - (1j * comm + diss)) < 1e-13
+    Lmf = L.Liouvillian(ctx, [H0, H1], cops, ncoeffs=1, convention="LvN")      # 199 Lindblad operators: library GEMM chain
+    Lmf.set_coeffs([1.0])
+    assert np.linalg.norm(apply(Lmf) - (1j * comm + diss)) < 1e-12

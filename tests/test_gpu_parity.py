@@ -994,7 +994,9 @@ def _random_operator(draw):
 
 
 @pytest.mark.parametrize("fmt", [L.FMT_AUTO, L.FMT_CSR, L.FMT_RBCSR, L.FMT_HRB])
-@settings(max_examples=25, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@settings(max_examples=int(os.environ.get("QP_HYP_EXAMPLES", "25")), deadline=None,
+          derandomize="QP_HYP_EXAMPLES" not in os.environ,      # fixed examples by default; set the variable to explore
+          suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
 @given(_random_operator())
 def test_random_operators_all_formats(ctx, fmt, m):
     """Whatever the structure: the device copy reads back bit for bit, mul! and one cheby! term

@@ -460,3 +460,28 @@ def test_liouvillian_reference_tests(ctx):
     Lmf = L.Liouvillian(ctx, [H0, H1], cops, ncoeffs=1, convention="LvN")      # 199 Lindblad operators: library GEMM chain
     Lmf.set_coeffs([1.0])
     assert np.linalg.norm(apply(Lmf) - (1j * comm + diss)) < 1e-12
+
+
+def test_propagate_steps_error_behaviour(ctx):
+    """qp_propagate keeps cheby!'s argument checks (src/cheby.jl:157) on both of its paths
+    (persistent small-system kernel and launch-per-term loop) and rejects malformed calls."""
+    rng = np.random.default_rng(3)
+    for N in (12, 3000):              # register-resident / general
+        H = synth.sparse_random(N, min(1.0, 6.0 / N), rho=2.0, hermitian=True, rng=rng)
+        Op = L.Operator(ctx, [L.Matrix.from_scipy(ctx, H)])
+        psi = L.State(ctx, data=synth.random_state(N))
+        wrk = L.ChebyWrk(ctx, N, 8.0, -4.0, 0.1)
+        with pytest.raises(L.QPAssertionError, match="wrk was initialized for dt"):
+            L.propagate_steps(Op, psi, wrk, np.array([0.1, 0.2]))
+        if N == 12:                   # one launch for the whole grid: the direction cannot change inside it
+            with pytest.raises(L.QPArgumentError, match="change sign"):
+                L.propagate_steps(Op, psi, wrk, np.array([0.1, -0.1]))
+        wrong = L.Operator(ctx, [L.Matrix.from_scipy(ctx, sp.identity(N + 1, dtype=complex, format="csr"))])
+        with pytest.raises(L.QPArgumentError, match="wrong shape"):
+            L.propagate_steps(Op, psi, wrk, np.array([0.1]), observables=[wrong])
+        with pytest.raises(L.QPArgumentError):
+            L.propagate_steps(Op, L.State(ctx, n=N + 1), wrk, np.array([0.1]))
+        # zero steps: the initial row only
+        ev, st = L.propagate_steps(Op, psi, wrk, np.zeros(0), observables=[Op], store_states=True)
+        assert ev.shape == (1, 1) and st.shape == (1, N)
+        assert np.array_equal(st[0], psi.numpy())

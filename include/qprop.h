@@ -55,7 +55,8 @@ enum {
   QP_E_NO_DEVICE = 8,          /* no MI355X visible: the product path has no CPU fallback */
   QP_E_ALLOC = 9,
   QP_E_INTERNAL = 10,
-  QP_E_M_MAX = 11              /* "Newton propagation requires m_max > 2" src/newton.jl:38-45 */
+  QP_E_M_MAX = 11,             /* "Newton propagation requires m_max > 2" src/newton.jl:38-45 */
+  QP_E_RCCL = 12               /* a collective of the library's own communicator failed (qp_comm_*) */
 };
 
 enum { QP_LAYOUT_CSR = 0, QP_LAYOUT_CSC = 1 };

@@ -43,6 +43,7 @@ const char* qp_status_name(int s) {
     case QP_E_ALLOC: return "QP_E_ALLOC";
     case QP_E_INTERNAL: return "QP_E_INTERNAL";
     case QP_E_M_MAX: return "QP_E_M_MAX";
+    case QP_E_RCCL: return "QP_E_RCCL";
     default: return "QP_E_UNKNOWN";
   }
 }

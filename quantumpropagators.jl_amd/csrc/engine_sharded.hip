@@ -28,7 +28,7 @@ struct RcclApi {
 int rccl_load(const char* path, RcclApi* api) {
   if (!path || !*path) return qp::fail(QP_E_BAD_ARG, "path of librccl.so is empty");
   void* h = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
-  if (!h) return qp::fail(QP_E_INTERNAL, "dlopen(%s) failed: %s", path, dlerror());
+  if (!h) return qp::fail(QP_E_RCCL, "dlopen(%s) failed: %s", path, dlerror());
   api->handle = h;
   api->GetUniqueId = reinterpret_cast<decltype(api->GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
   api->CommInitRank = reinterpret_cast<decltype(api->CommInitRank)>(dlsym(h, "ncclCommInitRank"));
@@ -41,14 +41,14 @@ int rccl_load(const char* path, RcclApi* api) {
   api->GetErrorString = reinterpret_cast<decltype(api->GetErrorString)>(dlsym(h, "ncclGetErrorString"));
   if (!api->GetUniqueId || !api->CommInitRank || !api->CommDestroy || !api->AllGather || !api->Send || !api->Recv ||
       !api->GroupStart || !api->GroupEnd || !api->GetErrorString)
-    return qp::fail(QP_E_INTERNAL, "%s does not export the RCCL entry points", path);
+    return qp::fail(QP_E_RCCL, "%s does not export the RCCL entry points", path);
   return QP_OK;
 }
 
 #define QP_RCCL(api, expr)                                                                             \
   do {                                                                                                 \
     ncclResult_t r__ = (expr);                                                                         \
-    if (r__ != ncclSuccess) return qp::fail(QP_E_INTERNAL, "RCCL: %s failed: %s", #expr, (api).GetErrorString(r__)); \
+    if (r__ != ncclSuccess) return qp::fail(QP_E_RCCL, "RCCL: %s failed: %s", #expr, (api).GetErrorString(r__)); \
   } while (0)
 
 __global__ __launch_bounds__(qp::kThreads) void pack_rows_kernel(double2* __restrict__ slab,

@@ -20,7 +20,7 @@ STATUS = {
     0: "QP_OK", 1: "QP_E_BAD_ARG", 2: "QP_E_HIP", 3: "QP_E_DT_MISMATCH",
     4: "QP_E_TOO_FEW_COEFFS", 5: "QP_E_NORMALIZATION", 6: "QP_E_MAX_RESTARTS",
     7: "QP_E_DIVDIFF_UNDERFLOW", 8: "QP_E_NO_DEVICE", 9: "QP_E_ALLOC",
-    10: "QP_E_INTERNAL", 11: "QP_E_M_MAX",
+    10: "QP_E_INTERNAL", 11: "QP_E_M_MAX", 12: "QP_E_RCCL",
 }
 LAYOUT_CSR, LAYOUT_CSC = 0, 1
 VAL_C128, VAL_F64 = 0, 1

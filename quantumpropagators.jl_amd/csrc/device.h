@@ -198,6 +198,7 @@ struct SmallArnoldiArgs {
   double* norms = nullptr;             // [ldd]
   int ldd = 0, m = 0, extended = 0;
   double dt = 1.0, norm_min = 0.0;
+  int normalize_start = 0;             // q_0 = start / |start|, |start| -> norms[ldd - 1]
 };
 constexpr size_t kSmallLdsBytes = 152 * 1024;
 inline bool small_arnoldi_fits(int64_t n, int m) {

@@ -24,6 +24,8 @@ int qp_krylov_create(qp_ctx* ctx, int64_t n, int nvec, qp_krylov** out) {
   // rows that were never computed read as NaN: a use of a stale Gram row is loud, not subtle
   QP_HIP(hipMemsetAsync(q->gram, 0xFF, sizeof(double2) * (size_t)nvec * nvec, ctx->stream));
   QP_CHECK(dev_alloc(&q->hcoef, (size_t)2 * nvec));
+  QP_HIP(hipHostMalloc((void**)&q->h_hess, sizeof(double2) * (size_t)nvec * nvec, hipHostMallocDefault));
+  QP_HIP(hipHostMalloc((void**)&q->h_norms, sizeof(double) * (size_t)nvec, hipHostMallocDefault));
   *out = q.release();
   return QP_OK;
   QP_CATCH
@@ -40,6 +42,8 @@ int qp_krylov_destroy(qp_krylov* q) {
   if (q->part) (void)hipFree(q->part);
   if (q->md_part) (void)hipFree(q->md_part);
   if (q->gram) (void)hipFree(q->gram);
+  if (q->h_hess) (void)hipHostFree(q->h_hess);
+  if (q->h_norms) (void)hipHostFree(q->h_norms);
   if (q->hcoef) (void)hipFree(q->hcoef);
   delete q;
   return QP_OK;
@@ -99,8 +103,11 @@ int arnoldi_column(qp_operator* op, qp_krylov* q, int j, double dt, double2* hco
 __global__ void norm_guard_scale_kernel(double2* __restrict__ w, const double2* __restrict__ part_in, double2* hess_slot,
                                         double* norm_slot, double dt, double norm_min, int64_t n);
 
-int qp_arnoldi(qp_operator* op, qp_krylov* q, int m, const qp_state* psi, double dt, int extended, double norm_min,
-               qp_c128* Hess, int ldh, int* m_out) {
+// arnoldi! with an optional normalisation of the start vector: beta_out != NULL means `psi` is
+// not normalised; q_0 = psi / |psi| and *beta_out = |psi| (newton! :268-272 folded in, so that
+// the persistent small-system kernel does it in the same launch).
+static int arnoldi_impl(qp_operator* op, qp_krylov* q, int m, const qp_state* psi, double dt, int extended,
+                        double norm_min, qp_c128* Hess, int ldh, int* m_out, double* beta_out) {
   QP_TRY
   if (!op || !q || !psi || !Hess || !m_out) return qp::fail(QP_E_BAD_ARG, "qp_arnoldi: NULL argument");
   const int dim = extended ? m + 1 : m;
@@ -110,8 +117,6 @@ int qp_arnoldi(qp_operator* op, qp_krylov* q, int m, const qp_state* psi, double
   QP_CHECK(use(ctx));
   const int ldd = q->nvec;
   std::memset(Hess, 0, sizeof(qp_c128) * (size_t)ldh * ldh);                                      // :78
-  QP_HIP(hipMemsetAsync(q->hess_dev, 0, sizeof(double2) * (size_t)ldd * ldd, ctx->stream));
-  QP_HIP(hipMemsetAsync(q->norms_dev, 0, sizeof(double) * (size_t)ldd, ctx->stream));
   qp::SmallArgs plan;
   bool small = false;
   if (op->A.nnz <= qp::g_small_nnz && qp::small_arnoldi_fits(q->n, m)) {
@@ -140,10 +145,19 @@ int qp_arnoldi(qp_operator* op, qp_krylov* q, int m, const qp_state* psi, double
     a.extended = extended;
     a.dt = dt;
     a.norm_min = norm_min;
+    a.normalize_start = beta_out ? 1 : 0;     // the kernel also zero-fills hess / norms
     QP_CHECK(qp::launch_arnoldi_small(ctx->stream, a, &ctx->stats));
     q->gram_rows = 0;
   } else {
+    QP_HIP(hipMemsetAsync(q->hess_dev, 0, sizeof(double2) * (size_t)ldd * ldd, ctx->stream));
+    QP_HIP(hipMemsetAsync(q->norms_dev, 0, sizeof(double) * (size_t)ldd, ctx->stream));
     QP_HIP(hipMemcpyAsync(q->q(0), psi->d, (size_t)q->n * sizeof(double2), hipMemcpyDeviceToDevice, ctx->stream));  // :79
+    if (beta_out) {
+      cplx n2;
+      QP_CHECK(dot_sync(ctx, q->q(0), q->q(0), q->n, &n2));
+      *beta_out = std::sqrt(n2.real());
+      QP_CHECK(qp::launch_scal(ctx->stream, q->q(0), make_double2(1.0 / *beta_out, 0.0), q->n, &ctx->stats));
+    }
     for (int j = 0; j < m; ++j) {
       double2* hcol = q->hess_dev + (size_t)j * ldd;
       QP_CHECK(arnoldi_column(op, q, j, dt, hcol));
@@ -156,11 +170,13 @@ int qp_arnoldi(qp_operator* op, qp_krylov* q, int m, const qp_state* psi, double
       }
     }
   }
-  std::vector<cplx> hh((size_t)ldd * ldd);
-  std::vector<double> hn(ldd);
-  QP_HIP(hipMemcpyAsync(hh.data(), q->hess_dev, hh.size() * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
-  QP_HIP(hipMemcpyAsync(hn.data(), q->norms_dev, hn.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  // one download of the Hessenberg matrix and the norms, into pinned memory
+  const cplx* hh = reinterpret_cast<const cplx*>(q->h_hess);
+  const double* hn = q->h_norms;
+  QP_HIP(hipMemcpyAsync(q->h_hess, q->hess_dev, (size_t)ldd * ldd * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
+  QP_HIP(hipMemcpyAsync(q->h_norms, q->norms_dev, (size_t)ldd * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   QP_HIP(hipStreamSynchronize(ctx->stream));
+  if (small && beta_out) *beta_out = hn[ldd - 1];   // written by the kernel (slot ldd - 1 is never a column's)
   int m_eff = m;
   for (int j = 0; j < m; ++j) {
     if (((j + 1 < m) || extended) && hn[j] < norm_min) {  // dimensionality exhausted  :91-95
@@ -178,6 +194,11 @@ int qp_arnoldi(qp_operator* op, qp_krylov* q, int m, const qp_state* psi, double
   *m_out = m_eff;
   return QP_OK;
   QP_CATCH
+}
+
+int qp_arnoldi(qp_operator* op, qp_krylov* q, int m, const qp_state* psi, double dt, int extended, double norm_min,
+               qp_c128* Hess, int ldh, int* m_out) {
+  return arnoldi_impl(op, q, m, psi, dt, extended, norm_min, Hess, ldh, m_out, nullptr);
 }
 
 int qp_arnoldi_extend(qp_operator* op, qp_krylov* q, int m, double dt, double norm_min, qp_c128* Hess, int ldh,
@@ -371,13 +392,9 @@ int qp_newton_step(qp_newton* w, qp_operator* op, qp_state* psi, double dt, int 
   std::vector<cplx> R(m + 1), P(m + 1), Rn(m + 1), ritz;
   int n_a = 0, n_leja = 0, s = 0, n_matvec = 0;
   double last_relerr = 0, norm_psi = 0;
-  const size_t bytes = (size_t)w->n * sizeof(double2);
   qp_state vstate{ctx, w->v, w->n, false};
-  QP_HIP(hipMemcpyAsync(w->v, psi->d, bytes, hipMemcpyDeviceToDevice, ctx->stream));  // :268
-  cplx n2;
-  QP_CHECK(dot_sync(ctx, w->v, w->v, w->n, &n2));
-  double beta = std::sqrt(n2.real());                                                // :271
-  QP_CHECK(qp::launch_scal(ctx->stream, w->v, make_double2(1.0 / beta, 0.0), w->n, &ctx->stats));  // :272
+  // v = Psi / beta, beta = |Psi| (:268-272) is done by the first Arnoldi sweep itself (q_0)
+  double beta = 0.0;
   double ms_arnoldi = 0, ms_eig = 0, ms_leja = 0, ms_coeffs = 0, ms_poly = 0, ms_update = 0;
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto ms_since = [](std::chrono::steady_clock::time_point t0) {
@@ -386,7 +403,8 @@ int qp_newton_step(qp_newton* w, qp_operator* op, qp_state* psi, double dt, int 
   while (true) {                                                                     // :274
     int m_req = m;
     auto t0 = now();
-    QP_CHECK(qp_arnoldi(op, w->q, m_req, &vstate, dt, 1, norm_min, reinterpret_cast<qp_c128*>(Hess.data()), ldh, &m));
+    QP_CHECK(arnoldi_impl(op, w->q, m_req, s == 0 ? psi : &vstate, dt, 1, norm_min,
+                          reinterpret_cast<qp_c128*>(Hess.data()), ldh, &m, s == 0 ? &beta : nullptr));
     ms_arnoldi += ms_since(t0);
     n_matvec += m_req;
     if (m == 1 && s == 0) {                                                          // :289-295
@@ -455,8 +473,9 @@ int qp_newton_step(qp_newton* w, qp_operator* op, qp_state* psi, double dt, int 
     }
     beta = std::sqrt(b2);
     for (int i = 0; i < mp; ++i) R[i] *= (1.0 / beta);
-    QP_CHECK(qp::launch_combine_vecs(ctx->stream, w->v, 1, d2(R[0]), w->q->q(1), w->n, m,
-                                     reinterpret_cast<const double2*>(R.data() + 1), nullptr, w->n, &ctx->stats));
+    // v = sum_{i=0..m} R_i q_i   (q_0 is the start vector of this sweep)
+    QP_CHECK(qp::launch_combine_vecs(ctx->stream, w->v, 0, make_double2(1.0, 0.0), w->q->q(0), w->n, m + 1,
+                                     reinterpret_cast<const double2*>(R.data()), nullptr, w->n, &ctx->stats));
     QP_HIP(hipStreamSynchronize(ctx->stream));
     norm_psi = std::sqrt(sum_partials(w->h_npart).real());
     ms_update += ms_since(t0);

@@ -855,8 +855,24 @@ __global__ __launch_bounds__(kSmallThreads) void arnoldi_small_kernel(SmallArnol
       }
     }
   }
+  // fill!(Hess, 0) :78 (the caller reads the whole matrix back)
+  for (int i = tid; i < s.ldd * s.ldd; i += kSmallThreads) s.hess[i] = make_double2(0.0, 0.0);
+  for (int i = tid; i < s.ldd; i += kSmallThreads) s.norms[i] = 0.0;
+  double inv0 = 1.0;
+  if (s.normalize_start) {   // newton! :271-272: beta = |Psi|, v = Psi / beta
+    double nrm = 0.0;
+    for (int64_t i = tid; i < n; i += kSmallThreads) {
+      const double2 v = s.start[i];
+      nrm += v.x * v.x + v.y * v.y;
+    }
+    const double beta0 = sqrt(small_block_sum(make_double2(nrm, 0.0), red).x);
+    inv0 = 1.0 / beta0;
+    if (tid == 0) s.norms[s.ldd - 1] = beta0;
+  }
   for (int64_t i = tid; i < n; i += kSmallThreads) {   // q_0 = start   :79
-    const double2 v = s.start[i];
+    double2 v = s.start[i];
+    v.x *= inv0;
+    v.y *= inv0;
     QL[i] = v;
     s.Q[i] = v;
   }

@@ -147,6 +147,7 @@ struct qp_newton {
   double2* npart = nullptr;  // kRedBlocks |psi|^2 partials
   double2* h_npart = nullptr;
   std::vector<cplx> a, leja;
+  std::vector<cplx> Hess, R, P, Rn, ritz;   // host work arrays of a step, kept between calls
   double radius = 0;
   int n_a = 0, n_leja = 0, restarts = 0;
 };

@@ -388,8 +388,8 @@ int qp_newton_step(qp_newton* w, qp_operator* op, qp_state* psi, double dt, int 
   std::fill(w->a.begin(), w->a.end(), cplx(0));                         // :254-255
   std::fill(w->leja.begin(), w->leja.end(), cplx(0));
   const int ldh = m_max + 1;
-  std::vector<cplx> Hess((size_t)ldh * ldh, cplx(0));
-  std::vector<cplx> R(m + 1), P(m + 1), Rn(m + 1), ritz;
+  std::vector<cplx>&Hess = w->Hess, &R = w->R, &P = w->P, &Rn = w->Rn, &ritz = w->ritz;
+  Hess.assign((size_t)ldh * ldh, cplx(0));
   int n_a = 0, n_leja = 0, s = 0, n_matvec = 0;
   double last_relerr = 0, norm_psi = 0;
   qp_state vstate{ctx, w->v, w->n, false};

@@ -134,7 +134,7 @@ bool hessenberg_eigvals_inplace(int n, cplx* A, cplx* w) {
 int diagonalize_hessenberg(const cplx* Hess, int ldh, int m, bool accumulate, cplx* out) {
   int j_min = accumulate ? 1 : m;
   int offset = 0;
-  std::vector<cplx> work;
+  static thread_local std::vector<cplx> work;   // reused between calls (no allocation in a restart loop)
   for (int j = j_min; j <= m; ++j) {
     auto Hm = [&](int r, int c) { return Hess[(size_t)c * ldh + r]; };
     if (j == 1) {

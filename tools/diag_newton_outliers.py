@@ -25,5 +25,5 @@ for k in range(150):
 ts = np.array([r[0] for r in rows])
 print("median %.2f ms, mean %.2f, max %.2f" % (np.median(ts), ts.mean(), ts.max()))
 for i, r in enumerate(rows):
-    if r[0] > 2 * np.median(ts):
-        print(i, "t=%.2fs" % r[1], "%.2f ms" % r[0], r[2])
+    if r[0] > 1.5 * np.median(ts[:20]) or i < 3:
+        print(i, "t=%.3fs" % r[1], "%.2f ms" % r[0], r[2])

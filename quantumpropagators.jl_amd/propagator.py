@@ -504,26 +504,42 @@ def propagate(state, generator, tlist, *, method, backward=False, inplace=True, 
         out = p.state.numpy()
         return (out, store) if storage else out
 
-    def one(o, psi):
-        if _is_matrix_observable(o):
+    import inspect
+
+    def n_positional(f):
+        try:
+            return sum(1 for q in inspect.signature(f).parameters.values()
+                       if q.kind in (q.POSITIONAL_ONLY, q.POSITIONAL_OR_KEYWORD) and q.default is q.empty)
+        except (TypeError, ValueError):
+            return 1
+    arity = [0 if _is_matrix_observable(o) else n_positional(o) for o in (observables or ())]
+
+    def one(k, o, psi, slot):
+        """map_observable (src/storage.jl:100-123): a matrix -> dot(psi, O, psi); a function of
+        ``(state, tlist, i)`` or of ``state`` (``i`` is the 0-based index into tlist here)."""
+        if arity[k] == 0:
             return np.vdot(psi, o @ psi)
+        if arity[k] >= 3:
+            return o(psi, p.tlist, slot)
         return o(psi)
 
-    def obs(s):
+    def obs(s, slot):
         psi = s.numpy()
         if observables is None:
             return psi
-        return np.array([one(o, psi) for o in observables])
+        return np.array([one(k, o, psi, slot) for k, o in enumerate(observables)])
     store = None
     if storage:
-        first = obs(p.state)
+        slot0 = (nt - 1) if backward else 0
+        first = obs(p.state, slot0)
         store = np.zeros((len(first), nt), dtype=first.dtype)
-        store[:, (nt - 1) if backward else 0] = first
+        store[:, slot0] = first
     for i in range(nt - 1):
         prop_step(p)
         if callback is not None:
             callback(p, observables)
         if storage:
-            store[:, (nt - 2 - i) if backward else (i + 1)] = obs(p.state)
+            slot = (nt - 2 - i) if backward else (i + 1)
+            store[:, slot] = obs(p.state, slot)
     out = p.state.numpy()
     return (out, store) if storage else out

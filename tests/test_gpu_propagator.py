@@ -485,3 +485,29 @@ def test_propagate_steps_error_behaviour(ctx):
         ev, st = L.propagate_steps(Op, psi, wrk, np.zeros(0), observables=[Op], store_states=True)
         assert ev.shape == (1, 1) and st.shape == (1, N)
         assert np.array_equal(st[0], psi.numpy())
+
+
+def test_time_dependent_observables(ctx):
+    """Observables as functions of ``(state, tlist, i)`` besides functions of the state and
+    matrices (map_observable, src/storage.jl:100-123; test/test_timedependent_observables.jl):
+    a rotating-frame population evaluated with the time of the storage slot."""
+    rng = np.random.default_rng(8)
+    N = 20
+    H = synth.dense_hermitian(N, rho=2.0, rng=rng)
+    tlist = np.linspace(0, 1.0, 9)
+    psi0 = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    psi0 /= np.linalg.norm(psi0)
+    target = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    target /= np.linalg.norm(target)
+    O = synth.dense_hermitian(N, rho=1.0, rng=rng)
+    rotating = lambda psi, tl, i: np.exp(1j * 0.7 * tl[i]) * np.vdot(target, psi)        # noqa: E731
+    overlap = lambda psi: abs(np.vdot(target, psi)) ** 2                                  # noqa: E731
+    for backward in (False, True):
+        _, ev = P.propagate(psi0, (H,), tlist, method="cheby", storage=True, backward=backward, ctx=ctx,
+                            observables=[rotating, overlap, O], E_min=-4.0, E_max=4.0)
+        _, st = P.propagate(psi0, (H,), tlist, method="cheby", storage=True, backward=backward, ctx=ctx,
+                            E_min=-4.0, E_max=4.0)
+        for i in range(len(tlist)):
+            assert abs(ev[0, i] - np.exp(1j * 0.7 * tlist[i]) * np.vdot(target, st[:, i])) < 1e-12
+            assert abs(ev[1, i] - abs(np.vdot(target, st[:, i])) ** 2) < 1e-12
+            assert abs(ev[2, i] - np.vdot(st[:, i], O @ st[:, i])) < 1e-12

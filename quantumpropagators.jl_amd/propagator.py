@@ -214,11 +214,34 @@ class _DeviceGenerator:
 
 class PWCPropagator:
     """Common fields: state, tlist, t, n, parameters, backward, inplace
-    (src/propagator.jl:119-126, src/pwc_utils.jl:5-24)."""
+    (src/propagator.jl:119-126, src/pwc_utils.jl:5-24).  Property access follows
+    src/propagator.jl:77-127: ``generator`` is hidden, ``state`` / ``t`` change only through
+    ``set_state`` / ``set_t``, ``tlist`` is read-only, ``parameters`` may be re-bound."""
+
+    PUBLIC_PROPERTIES = ("state", "tlist", "t", "parameters", "backward", "inplace")     # propertynames, :119-126
+    _MESSAGES = {"state": "The state of a propagator can only be set via `set_state!`",
+                 "tlist": "The tlist of a propagator is read-only",
+                 "t": "The current time of a propagator can only be set via `set_t!`"}
 
     @property
     def generator(self):  # hidden, src/propagator.jl:77-86
-        raise AttributeError("type PWCPropagator has no property generator")
+        raise AttributeError(f"type {type(self).__name__} has no property generator")
+
+    def __setattr__(self, name, value):
+        if name == "generator":
+            raise AttributeError(f"type {type(self).__name__} has no property generator")
+        if name in self._MESSAGES and self.__dict__.get("_sealed", False):
+            raise AttributeError(self._MESSAGES[name])
+        object.__setattr__(self, name, value)
+
+    def _set(self, name, value):
+        """Internal write access for prop_step! / set_state! / set_t!."""
+        object.__setattr__(self, name, value)
+
+    def propertynames(self, private=False):
+        if not private:
+            return self.PUBLIC_PROPERTIES
+        return tuple(dict.fromkeys(self.PUBLIC_PROPERTIES + tuple(self.__dict__)))
 
 
 class ChebyPropagator(PWCPropagator):
@@ -353,6 +376,7 @@ def init_prop(state, generator, tlist, method, *, inplace=True, backward=False, 
         p.func, p.norm_min, p.relerr, p.max_restarts = func, norm_min, relerr, max_restarts
     if piecewise is True or pwc is True:
         pass  # both propagators are piecewise-constant (src/propagator.jl:232-245)
+    p._set("_sealed", True)
     return p
 
 
@@ -367,7 +391,7 @@ def prop_step(p):
     if not p.inplace:
         new = L.State(p.ctx, n=p.state.n)
         new.copy_from(p.state)
-        p.state = new
+        p._set("state", new)
     if p.method == "cheby":
         dt = -p.wrk.dt if p.backward else p.wrk.dt
         L.cheby(p.state, H, dt, p.wrk, check_normalization=p.check_normalization)
@@ -378,10 +402,10 @@ def prop_step(p):
         L.newton(p.state, H, dt, p.wrk, func=p.func, norm_min=p.norm_min, relerr=p.relerr,
                  max_restarts=p.max_restarts)
     if p.backward:                                                      # _pwc_advance_time!  pwc_utils.jl:102-112
-        p.t = float(tlist[n - 1])
+        p._set("t", float(tlist[n - 1]))
         p.n = n - 1
     else:
-        p.t = float(tlist[n])
+        p._set("t", float(tlist[n]))
         p.n = n + 1
     return p.state
 
@@ -395,7 +419,7 @@ def set_state(p, state):
             else:
                 p.state.upload(np.asarray(state, dtype=np.complex128))
         else:
-            p.state = _as_state(p.ctx, state, copy=False)
+            p._set("state", _as_state(p.ctx, state, copy=False))
     return p.state
 
 
@@ -413,7 +437,7 @@ def set_t(p, t):
     if not math.isclose(t, tlist[n - 1], rel_tol=math.sqrt(np.finfo(float).eps)):
         warnings.warn(f"Snapping t={t} to time grid value {tlist[n - 1]}")
     p.n = n - 1 if p.backward else n
-    p.t = float(tlist[n - 1])
+    p._set("t", float(tlist[n - 1]))
 
 
 def reinit_prop(p, state, transform_control_ranges=None, **_):
@@ -474,7 +498,7 @@ def _propagate_fused(p, storage, observables):
     ev, st = L.propagate_steps(H, p.state, p.wrk, dts, table, observables=obs_ops,
                                store_states=bool(storage) and observables is None, **kw)
     p.n = 0 if p.backward else nt
-    p.t = float(p.tlist[0] if p.backward else p.tlist[-1])
+    p._set("t", float(p.tlist[0] if p.backward else p.tlist[-1]))
     rows = ev if obs_ops else st
     if rows is None:
         return None

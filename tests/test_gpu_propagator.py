@@ -511,3 +511,31 @@ def test_time_dependent_observables(ctx):
             assert abs(ev[0, i] - np.exp(1j * 0.7 * tlist[i]) * np.vdot(target, st[:, i])) < 1e-12
             assert abs(ev[1, i] - abs(np.vdot(target, st[:, i])) ** 2) < 1e-12
             assert abs(ev[2, i] - np.vdot(st[:, i], O @ st[:, i])) < 1e-12
+
+
+def test_propagator_property_access(ctx):
+    """test/test_prop_interfaces.jl:309-336 ("Propagator property access"): generator hidden,
+    state / tlist / t not assignable, parameters re-bindable, the public property names."""
+    rng = np.random.default_rng(6)
+    N = 10
+    tlist = np.linspace(0, 10, 101)
+    H0 = synth.dense_hermitian(N, rho=1.0, rng=rng)
+    H1 = synth.dense_hermitian(N, rho=0.2, rng=rng)
+    psi = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    psi /= np.linalg.norm(psi)
+    p = P.init_prop(psi, P.hamiltonian(H0, (H1, lambda t: np.sin(t))), tlist, "cheby", ctx=ctx, E_min=-3.0, E_max=3.0)
+    with pytest.raises(AttributeError):
+        p.generator
+    for name, value in (("state", p.state), ("tlist", tlist), ("t", 0.0), ("generator", H0)):
+        with pytest.raises(AttributeError):
+            setattr(p, name, value)
+    new_params = [par.copy() for par in p.parameters]
+    p.parameters = new_params
+    assert p.parameters is new_params
+    assert p.propertynames() == ("state", "tlist", "t", "parameters", "backward", "inplace")
+    priv = p.propertynames(True)
+    assert len(priv) >= 6 and all(q in priv for q in p.propertynames())
+    P.prop_step(p)                       # the propagator itself still advances state and t
+    assert p.t == tlist[1]
+    with pytest.raises(ValueError):      # "init_prop unknown method" (:371-381)
+        P.init_prop(psi, H0, tlist, 42, ctx=ctx)

@@ -32,16 +32,20 @@ __all__ = ["Generator", "hamiltonian", "liouvillian", "MatrixFreeLiouvillian", "
 # controls (src/controls.jl) -- scalar host logic, O(#steps)
 # ----------------------------------------------------------------------------------------
 
-def get_tlist_midpoints(tlist):
-    """src/controls.jl:92-124 (first / last point preserved)."""
+def get_tlist_midpoints(tlist, preserve_start=True, preserve_end=True):
+    """src/controls.jl:92-124: midpoints of the (not necessarily uniform) intervals; by default the
+    first and the last point of ``tlist`` are kept instead of the outer midpoints."""
     tlist = np.asarray(tlist, dtype=np.float64)
     N = len(tlist)
     if N < 3:
         raise ValueError("In `get_tlist_midpoints`, argument `tlist` must have a length of at least 3")
-    mid = np.zeros(N - 1)
-    mid[0], mid[-1] = tlist[0], tlist[-1]
-    for i in range(1, N - 2):
-        mid[i] = tlist[i] + 0.5 * (tlist[i + 1] - tlist[i])
+    if np.any(np.diff(tlist) <= 0.0):
+        raise AssertionError("dt > 0.0")                                  # the `@assert dt > 0.0` of :107-120
+    mid = tlist[:-1] + 0.5 * np.diff(tlist)
+    if preserve_start:
+        mid[0] = tlist[0]
+    if preserve_end:
+        mid[-1] = tlist[-1]
     return mid
 
 
@@ -61,10 +65,12 @@ def discretize_on_midpoints(control, tlist):
     raise ValueError("control array must be defined on the points of tlist")
 
 
-def discretize(control, tlist):
+def discretize(control, tlist, via_midpoints=True):
     """src/controls.jl:43-68."""
     if callable(control):
-        return discretize(discretize_on_midpoints(control, tlist), tlist)
+        if via_midpoints:
+            return discretize(discretize_on_midpoints(control, tlist), tlist)
+        return np.array([float(control(t)) for t in tlist])
     control = np.asarray(control, dtype=np.float64)
     if len(control) == len(tlist):
         return control.copy()

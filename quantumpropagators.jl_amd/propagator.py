@@ -113,19 +113,33 @@ class Generator:
 
 
 def hamiltonian(*terms):
-    """``hamiltonian(H0, (H1, eps1), ...)`` -- src/generators.jl:388-469: drift terms are
-    summed into one operator and listed first."""
+    """``hamiltonian(H0, (H1, eps1), ...)`` -- src/generators.jl:388-469 (``_make_generator``): the
+    drift terms are summed into one operator listed first; terms that share an amplitude (the same
+    function object, or equal arrays) are merged by summing their operators; a term must be an
+    operator or a 2-tuple ``(op, amplitude)``.  Without time-dependent terms the drift operator
+    itself is returned."""
     drift = None
     ops, ampl = [], []
     for t in terms:
-        if isinstance(t, tuple):
-            ops.append(t[0])
-            ampl.append(t[1])
+        if isinstance(t, (tuple, list)):
+            if len(t) != 2:
+                raise ValueError("time-dependent term must be 2-tuple")                   # :401
+            op, a = t
+            k = next((i for i, b in enumerate(ampl)
+                      if b is a or (isinstance(a, np.ndarray) and isinstance(b, np.ndarray) and np.array_equal(a, b))),
+                     None)
+            if k is None:
+                ops.append(op)
+                ampl.append(a)
+            else:
+                ops[k] = ops[k] + op                                                      # :412-424
         else:
             drift = t if drift is None else drift + t
     if drift is not None:
         ops.insert(0, drift)
     if not ampl:
+        if not ops:
+            raise ValueError("Generator has no terms")                                    # :452
         return ops[0]
     return Generator(ops, ampl)
 

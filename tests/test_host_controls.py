@@ -78,3 +78,11 @@ def test_hamiltonian_collects_drift_terms():
     assert isinstance(G, P.Generator) and len(G.ops) == 2 and len(G.amplitudes) == 1
     assert np.array_equal(G.ops[0], A + B) and G.ops[1] is C and G.amplitudes[0] is eps
     assert P.hamiltonian(A) is A
+    # terms with the same amplitude are merged (src/generators.jl:408-424)
+    pulse = np.linspace(0, 1, 5)
+    G = P.hamiltonian(A, (B, eps), (C, eps), (B, pulse), (C, pulse.copy()))
+    assert len(G.ops) == 3 and np.array_equal(G.ops[1], B + C) and np.array_equal(G.ops[2], B + C)
+    with pytest.raises(ValueError, match="2-tuple"):
+        P.hamiltonian(A, (B, eps, 1.0))
+    with pytest.raises(ValueError, match="no terms"):
+        P.hamiltonian()

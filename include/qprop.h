@@ -272,6 +272,17 @@ typedef struct qp_comm qp_comm;
 int qp_comm_unique_id(const char* rccl_lib_path, char id_out[128]);
 int qp_comm_create(qp_ctx* ctx, const char* rccl_lib_path, const char id[128], int rank, int world,
                    qp_comm** out);
+/* A communicator whose exchange is performed by the caller: qp_sharded_cheby_step calls `cb`
+ * where it would enqueue the RCCL collective.  The callback must make `send[0..count)` of every
+ * rank r arrive at `recv_base + r * count` on the ranks that read it (all of them when
+ * n_send_to < 0; otherwise this rank sends to send_to[] and receives the slabs of recv_from[]),
+ * ordered after the work already queued on `stream` and before anything queued on it later.
+ * For drivers that own their transport (MPI.jl ...) and for testing the step with several ranks
+ * on one GPU, where RCCL will not form a communicator. */
+typedef int (*qp_exchange_cb)(void* user, const qp_c128* send_dev, int64_t count, qp_c128* recv_base_dev,
+                              const int* send_to, int n_send_to, const int* recv_from, int n_recv_from,
+                              void* stream);
+int qp_comm_create_callback(qp_ctx* ctx, int rank, int world, qp_exchange_cb cb, void* user, qp_comm** out);
 int qp_comm_destroy(qp_comm* comm);
 /* recv[r*count .. (r+1)*count) = rank r's send[0..count);  stream NULL = the ctx stream */
 int qp_comm_allgather(qp_comm* comm, const qp_state* send, qp_state* recv, int64_t count,

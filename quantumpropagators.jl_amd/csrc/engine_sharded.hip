@@ -65,6 +65,8 @@ struct qp_comm {
   RcclApi api;
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1;
+  qp_exchange_cb cb = nullptr;   // non-null: the caller performs the exchange (no RCCL)
+  void* cb_user = nullptr;
 };
 
 struct qp_sharded_cheby {
@@ -110,6 +112,20 @@ int qp_comm_create(qp_ctx* ctx, const char* rccl_lib_path, const char id[128], i
   QP_CATCH
 }
 
+int qp_comm_create_callback(qp_ctx* ctx, int rank, int world, qp_exchange_cb cb, void* user, qp_comm** out) {
+  QP_TRY
+  if (!ctx || !out || !cb || world < 1 || rank < 0 || rank >= world) return qp::fail(QP_E_BAD_ARG, "qp_comm_create_callback: bad arguments");
+  auto c = std::make_unique<qp_comm>();
+  c->ctx = ctx;
+  c->rank = rank;
+  c->world = world;
+  c->cb = cb;
+  c->cb_user = user;
+  *out = c.release();
+  return QP_OK;
+  QP_CATCH
+}
+
 int qp_comm_destroy(qp_comm* comm) {
   QP_TRY
   if (!comm) return QP_OK;
@@ -127,6 +143,12 @@ int qp_comm_allgather(qp_comm* comm, const qp_state* send, qp_state* recv, int64
     return qp::fail(QP_E_BAD_ARG, "qp_comm_allgather: bad arguments");
   QP_CHECK(use(comm->ctx));
   hipStream_t s = stream ? (hipStream_t)stream : comm->ctx->stream;
+  if (comm->cb) {
+    if (comm->cb(comm->cb_user, reinterpret_cast<const qp_c128*>(send->d), count, reinterpret_cast<qp_c128*>(recv->d),
+                 nullptr, -1, nullptr, 0, (void*)s) != 0)
+      return qp::fail(QP_E_RCCL, "the caller's exchange callback failed");
+    return QP_OK;
+  }
   QP_RCCL(comm->api, comm->api.AllGather(send->d, recv->d, (size_t)(2 * count), ncclDouble, comm->comm, s));
   return QP_OK;
   QP_CATCH
@@ -237,6 +259,14 @@ int qp_sharded_cheby_step(qp_sharded_cheby* s, const double* a, int n_coeffs, do
         QP_HIP(hipGetLastError());
         ctx->stats.n_launch++;
       }
+    }
+    if (d.comm->cb) {   // the caller's transport
+      const int rc = d.comm->cb(d.comm->cb_user, reinterpret_cast<const qp_c128*>(send), d.M,
+                                reinterpret_cast<qp_c128*>(X[k]->d + nloc), s->p2p ? s->send_to.data() : nullptr,
+                                s->p2p ? (int)s->send_to.size() : -1, s->p2p ? s->recv_from.data() : nullptr,
+                                s->p2p ? (int)s->recv_from.size() : 0, (void*)S_x);
+      if (rc != 0) return qp::fail(QP_E_RCCL, "the caller's exchange callback failed (%d)", rc);
+      return QP_OK;
     }
     const RcclApi& api = d.comm->api;
     if (s->p2p) {   // neighbour exchange: my slab to who reads it, their slabs into their ghost slots

@@ -154,6 +154,7 @@ SIGNATURES = {
                                         C.c_int, C.POINTER(_P)]),
     "qp_comm_unique_id": (C.c_int, [C.c_char_p, C.c_char_p]),
     "qp_comm_create": (C.c_int, [_P, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(_P)]),
+    "qp_comm_create_callback": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.POINTER(_P)]),
     "qp_comm_destroy": (C.c_int, [_P]),
     "qp_comm_allgather": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
     "qp_sharded_cheby_create": (C.c_int, [C.POINTER(qp_sharded_cheby_desc), C.POINTER(_P)]),
@@ -827,6 +828,48 @@ class Comm:
 
     def allgather(self, send, recv, count, stream=None):
         check(self.lib.qp_comm_allgather(self._h, send._h, recv._h, int(count), stream))
+
+    def close(self):
+        if self._h:
+            self.lib.qp_comm_destroy(self._h)
+            self._h = _P()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+EXCHANGE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int), C.c_int,
+                          C.POINTER(C.c_int), C.c_int, C.c_void_p)
+
+
+class CallbackComm:
+    """A ``qp_comm`` whose exchange is done by Python (include/qprop.h, qp_comm_create_callback):
+    ``exchange(send_ptr, count, recv_base_ptr, send_to, recv_from, stream)`` with device
+    pointers as ints and the neighbour lists as Python lists (None = all-gather)."""
+
+    def __init__(self, ctx, rank, world, exchange):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.rank, self.world = int(rank), int(world)
+
+        def _cb(user, send, count, recv, send_to, nst, recv_from, nrf, stream):
+            try:
+                st = None if nst < 0 else [send_to[i] for i in range(nst)]
+                rf = None if nst < 0 else [recv_from[i] for i in range(nrf)]
+                exchange(send, int(count), recv, st, rf, stream)
+                return 0
+            except Exception as exc:      # noqa: BLE001 -- must not propagate through the C frame
+                import traceback
+                traceback.print_exc()
+                self.error = exc
+                return 1
+        self.error = None
+        self._cb = EXCHANGE_CB(_cb)
+        self._h = _P()
+        check(self.lib.qp_comm_create_callback(ctx._h, self.rank, self.world, C.cast(self._cb, _P), None, C.byref(self._h)))
+        ctx._adopt(self)
 
     def close(self):
         if self._h:

@@ -241,7 +241,7 @@ class ShardedCheby:
         self.native = None
         self.p2p = False
         self.native_error = None
-        if native and isinstance(be, HipBackend) and not self.host_staged:
+        if native and isinstance(be, HipBackend):
             # Every step below that can fail is followed by an agreement over the torch group, so
             # that either all ranks use the native driver or none does (a rank that raised while the
             # others entered a collective would leave them waiting).
@@ -259,7 +259,11 @@ class ShardedCheby:
                     raise RuntimeError("rank 0 could not obtain an RCCL id")
                 return box[0]
             comm, err = None, None
-            if self.exchanging:
+            if self.exchanging and self.host_staged:
+                # testing with several ranks on one GPU: the library's step loop with the exchange
+                # handed back to this process (host-staged through the torch group)
+                comm = L.CallbackComm(ctx, self.rank, self.world, self._host_exchange)
+            elif self.exchanging:
                 try:
                     comm = L.Comm(ctx, self.rank, self.world, exchange_id)
                 except Exception as exc:      # noqa: BLE001 -- reported, and the Python driver is used instead
@@ -295,6 +299,20 @@ class ShardedCheby:
         # start the ranks aligned: a rank that is still building its operator must not keep
         # the others waiting inside their first collective
         dist.barrier(group=group)
+
+    def _host_exchange(self, send_ptr, count, recv_ptr, send_to, recv_from, stream):
+        """Exchange callback of the native driver in host-staged mode (qp_exchange_cb): every
+        rank's slab through pinned host memory and a CPU all-gather; only the slabs this rank
+        reads (``recv_from``; all for an all-gather) are written to its ghost slots."""
+        torch = self.torch
+        torch.cuda.synchronize()
+        h_send = torch.from_numpy(L.State(self.be.ctx, n=count, device_ptr=send_ptr).numpy().view(np.float64))
+        h_all = torch.empty(self.world * h_send.numel(), dtype=h_send.dtype)
+        self.dist.all_gather_into_tensor(h_all, h_send, group=self.group)
+        h_all = h_all.numpy().view(np.complex128).reshape(self.world, count)
+        for o in (range(self.world) if recv_from is None else recv_from):
+            L.State(self.be.ctx, n=count, device_ptr=recv_ptr + 16 * count * o).upload(h_all[o])
+        torch.cuda.synchronize()
 
     def check(self):
         """Synchronise and verify that no in-launch wait of the overlapped schedule timed out."""

@@ -53,6 +53,8 @@ def main():
     overlap = os.environ.get("QP_OVERLAP", "1") == "1"
     exchange = os.environ.get("QP_EXCHANGE", "auto")
     uneven = os.environ.get("QP_UNEVEN", "0") == "1"
+    native = os.environ.get("QP_NATIVE", "0") == "1"     # the library's one-call step with a callback communicator
+    p2p = {"auto": "auto", "1": True, "0": False}[os.environ.get("QP_P2P", "auto")]
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     N = 12288
@@ -64,7 +66,10 @@ def main():
     r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
     ctx = L.Context(0, stream=torch.cuda.current_stream().cuda_stream)
     sh = sharded.ShardedCheby(ctx, rp[r0:r1 + 1] - rp[r0], col[rp[r0]:rp[r1]], vals[rp[r0]:rp[r1]], N, r0, r1,
-                              20.0, -10.0, 1.0, exchange=exchange, overlap=overlap, host_staged=True)
+                              20.0, -10.0, 1.0, exchange=exchange, overlap=overlap, host_staged=True, native=native,
+                              p2p=p2p)
+    if native and (sh.native is None or (p2p is True and not sh.p2p)):
+        sys.exit(5)
     psi0 = synth.random_state(N)
     sh.set_state(psi0[r0:r1])
     for _ in range(3):
@@ -81,7 +86,8 @@ def main():
     qo.cheby(ref, H, -1.0, wrk)
     err = float(np.linalg.norm(out - ref[r0:r1]))
     print(f"rank {rank}/{world}: err={err:.3e} format={sh.op.format} exchange={sh.exchange} M={sh.M} "
-          f"split={'yes' if sh.split is not None else 'no'}", flush=True)
+          f"split={'yes' if sh.split is not None else 'no'} native={'yes' if sh.native is not None else 'no'} "
+          f"p2p={sh.p2p}", flush=True)
     dist.barrier()
     dist.destroy_process_group()
     if not err < 1e-10:

@@ -49,6 +49,21 @@ def test_multirank_hip_path_one_gpu(world, overlap, exchange, uneven):
     _run(world, QP_OVERLAP=overlap, QP_EXCHANGE=exchange, QP_UNEVEN=uneven)
 
 
+@pytest.mark.parametrize("world,overlap,exchange,uneven,p2p", [
+    (2, "1", "auto", "0", "1"),        # neighbour lists (send/recv form of the exchange), overlap
+    (3, "1", "auto", "1", "1"),        # three ranks, uneven blocks
+    (3, "0", "auto", "1", "0"),        # all-gather form, serial schedule
+    (2, "1", "allgather", "0", "0"),   # scattered H: the slice itself is the send buffer
+])
+def test_multirank_native_driver_one_gpu(world, overlap, exchange, uneven, p2p):
+    """qp_sharded_cheby_step (the whole partitioned cheby! in one library call) with 2 and 3 ranks
+    sharing the GPU: the exchange is handed back through qp_comm_create_callback and staged through
+    the host, everything else -- term loop, two streams, fused pack, neighbour slots -- is the code
+    that runs with RCCL on one GPU per rank."""
+    outs = _run(world, QP_OVERLAP=overlap, QP_EXCHANGE=exchange, QP_UNEVEN=uneven, QP_NATIVE="1", QP_P2P=p2p)
+    assert all("native=yes" in o for o in outs)
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_multirank_newton_one_gpu(world):
     """Row-partitioned newton! (all-reduced Arnoldi inner products) with ranks sharing the GPU."""

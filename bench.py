@@ -146,7 +146,7 @@ def main():
         # communicator the library owns (qp_sharded_cheby_step); otherwise the step loop is
         # driven from Python with torch.distributed collectives.  The native path is used only
         # if, on every rank, one step of it reproduces the torch-driven step bit for bit.
-        want_native = (args.driver == "native") and not one_gpu
+        want_native = args.driver == "native"     # (test mode: callback communicator, host-staged)
         sh = sharded.ShardedCheby(ctx, rp, col, vals, N, r0, r1, Delta, E_min, dt, fmt=fmt,
                                   exchange=args.exchange, host_staged=one_gpu, native=want_native)
         fmt_used = sh.op.format
@@ -161,11 +161,12 @@ def main():
             sh.set_state(psi0_local)
             sh.step(native=False)
             torch.cuda.synchronize()
-            same = torch.tensor([1 if np.array_equal(got, sh.local_state()) else 0], device="cuda")
+            same = torch.tensor([1 if np.array_equal(got, sh.local_state()) else 0], device="cpu" if one_gpu else "cuda")
             dist.all_reduce(same, op=dist.ReduceOp.MIN)
             use_native = bool(same.item())
-            driver_note = ("native (library step, RCCL communicator of the library, "
-                           + ("ncclSend/ncclRecv with the neighbours" if sh.p2p else "ncclAllGather") + ")") if use_native else \
+            how = ("exchange handed back through a callback communicator" if one_gpu else
+                   "RCCL communicator of the library, " + ("ncclSend/ncclRecv with the neighbours" if sh.p2p else "ncclAllGather"))
+            driver_note = f"native (library step, {how})" if use_native else \
                 "torch.distributed (native step disagreed with it in the self-check)"
         else:
             driver_note = "torch.distributed (step loop in Python" + (

@@ -59,16 +59,28 @@ def main():
     torch.cuda.set_device(0)
     N = 12288
     offsets = (1, 2, 3, 4, 16, 32, 48, 64) if exchange != "allgather" else (5, 777, 2111, 3333, 4001, 4667, 5889, 6099)
+    fuzz = os.environ.get("QP_FUZZ_SEED")
+    if fuzz is not None:      # tools/fuzz_sharded.py: random size, band structure, partition and schedule
+        rng = np.random.default_rng(int(fuzz))
+        N = int(rng.integers(1500, 20000))
+        offsets = tuple(sorted(set(int(o) for o in rng.integers(1, max(2, N // int(rng.choice([8, 64, 512]))), int(rng.integers(1, 7))))))
+        overlap = bool(rng.random() < 0.6)
+        native = bool(rng.random() < 0.6)
+        p2p = [True, False, "auto"][int(rng.integers(0, 3))]
+        exchange = ["auto", "halo", "allgather"][int(rng.integers(0, 3))]
     rp, col, vals = synth.hermitian_offsets_csr(N, offsets=offsets)
     bounds = qo.partition_rows(rp, world).copy()
     if uneven:
         bounds[1:-1] += 100
+    if fuzz is not None:
+        cuts = np.sort(rng.choice(np.arange(64, N - 64), size=world - 1, replace=False))
+        bounds = np.concatenate([[0], cuts, [N]]).astype(np.int64)
     r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
     ctx = L.Context(0, stream=torch.cuda.current_stream().cuda_stream)
     sh = sharded.ShardedCheby(ctx, rp[r0:r1 + 1] - rp[r0], col[rp[r0]:rp[r1]], vals[rp[r0]:rp[r1]], N, r0, r1,
                               20.0, -10.0, 1.0, exchange=exchange, overlap=overlap, host_staged=True, native=native,
                               p2p=p2p)
-    if native and (sh.native is None or (p2p is True and not sh.p2p)):
+    if fuzz is None and native and (sh.native is None or (p2p is True and not sh.p2p)):
         sys.exit(5)
     psi0 = synth.random_state(N)
     sh.set_state(psi0[r0:r1])
@@ -92,7 +104,7 @@ def main():
     dist.destroy_process_group()
     if not err < 1e-10:
         sys.exit(3)
-    if exchange != "allgather" and (sh.op.format != L.FMT_HRB or (sh.split is not None) != overlap):
+    if fuzz is None and exchange != "allgather" and (sh.op.format != L.FMT_HRB or (sh.split is not None) != overlap):
         sys.exit(4)
 
 

@@ -273,3 +273,24 @@ def test_partition_rows_property(lens, nparts, balance):
     else:
         w = rp[b[1:]] - rp[b[:-1]]
         assert w.max() <= rp[-1] / nparts + max(lens) + 1
+
+
+def test_host_numerics_under_sanitizers(tmp_path):
+    """The host numerics of the library, compiled with g++ -fsanitize=address,undefined and run on
+    random inputs (tests/sanitize_host_numerics.cpp): no out-of-bounds access, no undefined behaviour."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    csrc = os.path.join(ROOT, "quantumpropagators.jl_amd", "csrc")
+    exe = str(tmp_path / "host_san")
+    build = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                            "-I", csrc, os.path.join(csrc, "host_numerics.cpp"),
+                            os.path.join(ROOT, "tests", "sanitize_host_numerics.cpp"), "-o", exe],
+                           capture_output=True, text=True)
+    if build.returncode != 0 and "sanitize" in build.stderr and "cannot find" in build.stderr:
+        pytest.skip("sanitizer runtime not installed")
+    assert build.returncode == 0, build.stderr[-2000:]
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, (run.stdout + run.stderr)[-3000:]
+    assert "sanitizer run clean" in run.stdout

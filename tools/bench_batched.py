@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
-"""BASELINE configs[4]: batched 64 states x N = 2^18 CSR H (16 nnz/row), Chebyshev, one
-MI355X.  Prints one JSON line: panel prop_steps/s, state-steps/s, algorithmic GB/s.
+"""BASELINE configs[4]: batched 64 states x N = 2^18 CSR H (16 nnz/row), Chebyshev.  One MI355X, or
+the batch split over the GPUs of a node (strong scaling: the 64 states are divided, H is replicated,
+no communication -- SURVEY 8e).  Prints one JSON line: panel prop_steps/s, state-steps/s, GB/s.
 
     python tools/bench_batched.py --log2n 18 --batch 64 --steps 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        tools/bench_batched.py --batch 64
 """
 import argparse, json, os, sys, time
 import numpy as np
@@ -19,25 +22,46 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--tile", type=int, default=16)
     args = ap.parse_args()
-    N, b = 1 << args.log2n, args.batch
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.batch % world:
+            raise SystemExit(f"--batch {args.batch} is not divisible by {world} ranks")
+    N, b_total = 1 << args.log2n, args.batch
+    b = b_total // world                     # this rank's share of the states
+    s0 = rank * b
     rp, col, vals = synth.hermitian_offsets_csr(N)
-    ctx = L.Context(0)
+    ctx = L.Context(local_rank)
     L.tuning_set("spmm_tile", args.tile)
     op = L.Operator(ctx, [L.Matrix(ctx, N, N, rp, col, vals)])
     nnz = int(rp[-1])
-    states = np.stack([synth.random_state(N, seed=500 + s) for s in range(b)], axis=1)
+    states = np.stack([synth.random_state(N, seed=500 + s0 + s) for s in range(b)], axis=1)
     panel = L.State(ctx, data=states.reshape(-1))
     wrk = L.ChebyWrk(ctx, N * b, 20.0, -10.0, 1.0)
     nterms = wrk.n_coeffs - 1
     for _ in range(args.warmup):
         L.cheby_batched(panel, op, 1.0, wrk, b)
     ctx.sync()
+    if dist is not None:
+        dist.barrier()
     ctx.timer_begin()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         L.cheby_batched(panel, op, 1.0, wrk, b)
     ev = ctx.timer_end()
+    if dist is not None:
+        dist.barrier()
     el = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([el, ev], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el, ev = float(t[0]), float(t[1])
     alg = 20.0 * nnz + 4.0 * (N + 1) + 80.0 * N * b          # SURVEY 8d batched model per term
     per_term = ev * 1e-3 / (args.steps * nterms)
     norms = np.linalg.norm(panel.numpy().reshape(N, b), axis=0)
@@ -51,16 +75,19 @@ def main():
     for _ in range(20):
         L.cheby(single, op, 1.0, w1)
     ev1 = ctx.timer_end() / 20
-    print(json.dumps({
+    if rank == 0:
+      print(json.dumps({
         "metric": "batched Cheby prop_step!/s, 64 states x N=2^18 CSR (BASELINE configs[4])",
-        "value": args.steps / el, "unit": "panel prop_step/s", "state_steps_per_s": b * args.steps / el,
-        "ms_per_panel_step": 1e3 * el / args.steps,
-        "config": {"N": N, "batch": b, "states_per_pass": args.tile, "nnz_per_row": nnz / N, "matvecs_per_step": nterms},
+        "value": args.steps / el, "unit": "panel prop_step/s", "state_steps_per_s": b_total * args.steps / el,
+        "ms_per_panel_step": 1e3 * el / args.steps, "n_gpus": world, "scaling": "strong (batch split, no communication)",
+        "config": {"N": N, "batch": b_total, "states_per_gpu": b, "states_per_pass": args.tile, "nnz_per_row": nnz / N, "matvecs_per_step": nterms},
         "roofline": {"bound": "hbm", "achieved": alg / per_term / 1e9, "peak": 8000.0, "unit": "GB/s",
                      "frac": alg / per_term / 1e9 / 8000.0, "algorithmic_bytes_per_launch": alg,
                      "avg_launch_us": per_term * 1e6, "kernel": "csr_spmm_kernel<ChebyOp>"},
         "single_state_ms_per_step_same_N": ev1, "speedup_vs_one_state_at_a_time": b * ev1 / (1e3 * el / args.steps),
         "max_norm_drift": float(np.max(np.abs(norms - 1.0)))}))
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -233,15 +233,18 @@ struct MgsArgs {
 };
 int launch_mgs_pass(hipStream_t s, const MgsArgs& a, Stats* st);
 // low-synchronisation MGS of column j (see kernels.hip): c = Q^H w and the Gram row in one
-// pass, triangular solve in one workgroup, w -= Q h with |w|^2 partials
+// pass, a small reduction whose last workgroup (ticket counter) solves for the MGS
+// coefficients, then w -= Q h with |w|^2 partials: three launches
 int launch_mgs_lowsync(hipStream_t s, const double2* Q, int64_t ldq, int j, double2* w, double2* md_partials,
-                       double2* G, int ldg, double2* hess_col, double2* reduced, double2* norm_partials, double dt,
-                       int64_t n, Stats* st);
+                       double2* G, int ldg, double2* hess_col, double2* reduced, double2* coef, unsigned* ticket,
+                       double2* norm_partials, double dt, int64_t n, Stats* st);
+// the same in pieces for row-partitioned runs: local sums -> (all-reduce by the caller) ->
+// solve (one workgroup) + update
 int launch_mgs_multidot(hipStream_t s, const double2* Q, int64_t ldq, int j, const double2* w, double2* md_partials,
                         double2* reduced, int64_t n, Stats* st);
 int launch_mgs_project(hipStream_t s, const double2* Q, int64_t ldq, int j, double2* w, const double2* reduced,
-                       double2* G, int ldg, double2* hess_col, double2* norm_partials, double dt, int64_t n,
-                       Stats* st);
+                       double2* G, int ldg, double2* hess_col, double2* coef, double2* norm_partials, double dt,
+                       int64_t n, Stats* st);
 extern int g_arnoldi_mode;  // 0 = sequential fused MGS passes, 1 = low-synchronisation MGS
 // w *= 1/sqrt(sum part_in.x);  hess_slot = dt * norm
 int launch_norm_scale(hipStream_t s, double2* w, const double2* part_in, double2* hess_slot, double dt,

@@ -107,6 +107,8 @@ struct qp_krylov {
   double2* gram = nullptr;      // nvec x nvec Gram rows <q_i|q_k>, k < i
   int gram_rows = 0;            // rows 0 .. gram_rows-1 of `gram` describe the current basis
   double2* hcoef = nullptr;     // 2 nvec reduced inner products of the current column
+  double2* mgs_coef = nullptr;  // nvec axpy coefficients of the current column (low-sync MGS)
+  unsigned* ticket = nullptr;   // finishing-workgroup counter of the multidot launch (zero between launches)
   double2* h_hess = nullptr;    // pinned host mirrors of hess_dev / norms_dev
   double* h_norms = nullptr;
   double2* q(int i) const { return Q + (size_t)i * n; }

@@ -24,6 +24,9 @@ int qp_krylov_create(qp_ctx* ctx, int64_t n, int nvec, qp_krylov** out) {
   // rows that were never computed read as NaN: a use of a stale Gram row is loud, not subtle
   QP_HIP(hipMemsetAsync(q->gram, 0xFF, sizeof(double2) * (size_t)nvec * nvec, ctx->stream));
   QP_CHECK(dev_alloc(&q->hcoef, (size_t)2 * nvec));
+  QP_CHECK(dev_alloc(&q->mgs_coef, (size_t)nvec));
+  QP_HIP(hipMalloc((void**)&q->ticket, sizeof(unsigned)));
+  QP_HIP(hipMemsetAsync(q->ticket, 0, sizeof(unsigned), ctx->stream));
   QP_HIP(hipHostMalloc((void**)&q->h_hess, sizeof(double2) * (size_t)nvec * nvec, hipHostMallocDefault));
   QP_HIP(hipHostMalloc((void**)&q->h_norms, sizeof(double) * (size_t)nvec, hipHostMallocDefault));
   *out = q.release();
@@ -45,6 +48,8 @@ int qp_krylov_destroy(qp_krylov* q) {
   if (q->h_hess) (void)hipHostFree(q->h_hess);
   if (q->h_norms) (void)hipHostFree(q->h_norms);
   if (q->hcoef) (void)hipFree(q->hcoef);
+  if (q->mgs_coef) (void)hipFree(q->mgs_coef);
+  if (q->ticket) (void)hipFree(q->ticket);
   delete q;
   return QP_OK;
   QP_CATCH
@@ -80,7 +85,8 @@ int arnoldi_column(qp_operator* op, qp_krylov* q, int j, double dt, double2* hco
     // the persistent small-system kernel or by sequential passes continues sequentially).
     q->gram_rows = j + 1;
     return qp::launch_mgs_lowsync(ctx->stream, q->Q, q->n, j, q->q(j + 1), q->md_part, q->gram, q->nvec, hcol,
-                                  q->hcoef, q->part + (size_t)((j + 1) & 1) * kRedBlocks, dt, q->n, &ctx->stats);
+                                  q->hcoef, q->mgs_coef, q->ticket, q->part + (size_t)((j + 1) & 1) * kRedBlocks, dt,
+                                  q->n, &ctx->stats);
   }
   q->gram_rows = std::min(q->gram_rows, j);
   for (int i = 0; i <= j + 1; ++i) {                                              // :84-87
@@ -151,6 +157,7 @@ static int arnoldi_impl(qp_operator* op, qp_krylov* q, int m, const qp_state* ps
   } else {
     QP_HIP(hipMemsetAsync(q->hess_dev, 0, sizeof(double2) * (size_t)ldd * ldd, ctx->stream));
     QP_HIP(hipMemsetAsync(q->norms_dev, 0, sizeof(double) * (size_t)ldd, ctx->stream));
+    QP_HIP(hipMemsetAsync(q->ticket, 0, sizeof(unsigned), ctx->stream));
     QP_HIP(hipMemcpyAsync(q->q(0), psi->d, (size_t)q->n * sizeof(double2), hipMemcpyDeviceToDevice, ctx->stream));  // :79
     if (beta_out) {
       cplx n2;
@@ -258,7 +265,7 @@ int qp_krylov_project(qp_krylov* q, int j, double dt, const qp_state* reduced, q
     return qp::fail(QP_E_BAD_ARG, "qp_krylov_project: bad arguments");
   QP_CHECK(use(q->ctx));
   return qp::launch_mgs_project(q->ctx->stream, q->Q, q->n, j, q->q(j + 1), reduced->d, q->gram, q->nvec, hess_col->d,
-                                norm_partials->d, dt, q->n, &q->ctx->stats);
+                                q->mgs_coef, norm_partials->d, dt, q->n, &q->ctx->stats);
   QP_CATCH
 }
 

@@ -1411,150 +1411,319 @@ int launch_combine_vecs(hipStream_t s, double2* out, int use_out, double2 s0, co
 // (not exactly orthogonal) basis, a triangular solve reproduces the MGS coefficients
 // (exactly in exact arithmetic, to rounding in floating point), and the projections are
 // then subtracted in the MGS order.  Kernel 1 (multidot) forms c and the new Gram row in
-// one pass over Q, kernel 2 (one workgroup) reduces the partials and solves, kernel 3
-// subtracts and accumulates |w|^2.
+// one pass over Q; kernel 2 reduces the partials (one workgroup per value) and its last
+// workgroup solves; kernel 3 subtracts and accumulates |w|^2.  (Row-partitioned runs need an
+// all-reduce between the sums and the solve: there the solve is a launch of its own.)
 // ---------------------------------------------------------------------------
 constexpr int kTI = 8;  // basis vectors per multidot tile (16 complex accumulators per lane)
 
+__device__ __forceinline__ int tri_index(int i, int k) { return i * (i - 1) / 2 + k; }  // k < i
+
+// Forward substitution  h_i = c_i - sum_{k<i} <q_i|q_k> h_k  (the MGS coefficients, see above) by
+// one wavefront, column by column: once h_k is final every later row subtracts its <q_i|q_k> h_k
+// (no reduction; row i accumulates in ascending k).  `red` = [c_0..c_j | <q_0|q_j> .. <q_j|q_j>]
+// and the packed strict lower triangle `Gt` of the Gram matrix (rows 1..j), both in LDS; h starts
+// as a copy of c.  Leaves Hess[i,j] = dt h_i in hess_col and the axpy coefficients -Hess[i,j]/dt
+// (src/arnoldi.jl:85-86) in coef.
+__device__ __forceinline__ void mgs_solve_wave(int j, const double2* red, const double2* Gt, double2* h,
+                                               double2* __restrict__ hess_col, double2* __restrict__ coef, double dt) {
+  const int lane = threadIdx.x;
+  for (int i = lane; i <= j; i += 64) h[i] = red[i];
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  for (int k = 0; k < j; ++k) {
+    const double2 hk = h[k];
+    for (int i = k + 1 + lane; i <= j; i += 64) {
+      const double2 g = Gt[tri_index(i, k)];
+      double2 v = h[i];
+      v.x = fma(-g.x, hk.x, v.x);
+      v.x = fma(g.y, hk.y, v.x);
+      v.y = fma(-g.x, hk.y, v.y);
+      v.y = fma(-g.y, hk.x, v.y);
+      h[i] = v;
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+  }
+  for (int i = lane; i <= j; i += 64) {
+    const double2 hd = make_double2(dt * h[i].x, dt * h[i].y);
+    hess_col[i] = hd;
+    coef[i] = make_double2(-hd.x / dt, -hd.y / dt);
+  }
+}
+
+// Gram rows into LDS (packed lower triangle): rows 1..j-1 from G, row j = conj of the fresh
+// <q_k|q_j> in red[(j+1)+k]; row j is also stored to G for the later columns.
+__device__ __forceinline__ void mgs_stage_gram(int j, const double2* red, double2* Gt, double2* __restrict__ G, int ldg) {
+  const int total = j * (j + 1) / 2;
+  for (int idx = threadIdx.x; idx < total; idx += kThreads) {
+    int i = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)idx)) * 0.5f);
+    while (i * (i - 1) / 2 > idx) --i;
+    while ((i + 1) * i / 2 <= idx) ++i;
+    const int k = idx - i * (i - 1) / 2;
+    double2 g;
+    if (i == j) {
+      const double2 r = red[(j + 1) + k];
+      g = make_double2(r.x, -r.y);
+      G[(size_t)j * ldg + k] = g;
+    } else {
+      g = G[(size_t)i * ldg + k];
+    }
+    Gt[idx] = g;
+  }
+}
+
+// LDS of the finishing workgroup: red[2(j+1)] | h[j+1] | Gt[j(j+1)/2]
+__host__ __device__ inline size_t mgs_solve_lds(int j) {
+  return sizeof(double2) * (size_t)(3 * (j + 1) + j * (j + 1) / 2);
+}
+
+// partials are stored value-major: partials[v * kRedBlocks + workgroup]
 __global__ __launch_bounds__(kThreads) void multidot_kernel(const double2* __restrict__ Q, int64_t ldq, int j,
                                                             const double2* __restrict__ w,
                                                             double2* __restrict__ partials, int64_t n) {
-  __shared__ double2 lds[kThreads / 64];
+  __shared__ double2 wsum[kThreads / 64][2 * kTI];
   const int i0 = blockIdx.y * kTI;
-  const int nv = 2 * (j + 1);
   double2 ac[kTI], ag[kTI];
 #pragma unroll
   for (int t = 0; t < kTI; ++t) ac[t] = ag[t] = make_double2(0.0, 0.0);
   const double2* __restrict__ qj = Q + (size_t)j * ldq;
-  for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < n; e += (int64_t)kRedBlocks * kThreads) {
-    const double2 wv = w[e];
-    const double2 qv = qj[e];
+  // two elements per lane and round: 2 (kTI + 2) loads in flight; each accumulator still adds its
+  // elements in ascending order
+  const int64_t stride = (int64_t)kRedBlocks * kThreads;
+  for (int64_t e0 = (int64_t)blockIdx.x * kThreads + threadIdx.x; e0 < n; e0 += 2 * stride) {
+    const int64_t e1 = e0 + stride;
+    const bool two = e1 < n;
+    const double2 zero = make_double2(0.0, 0.0);
+    const double2 wv0 = w[e0], qv0 = qj[e0];
+    const double2 wv1 = two ? w[e1] : zero, qv1 = two ? qj[e1] : zero;
+    double2 qa[kTI], qb[kTI];
 #pragma unroll
     for (int t = 0; t < kTI; ++t) {
       if (i0 + t <= j) {
-        const double2 qi = Q[(size_t)(i0 + t) * ldq + e];
-        const double2 a = cconj_mul(qi, wv);
-        const double2 b = cconj_mul(qi, qv);
-        ac[t].x += a.x;
-        ac[t].y += a.y;
-        ag[t].x += b.x;
-        ag[t].y += b.y;
+        qa[t] = Q[(size_t)(i0 + t) * ldq + e0];
+        qb[t] = two ? Q[(size_t)(i0 + t) * ldq + e1] : zero;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < kTI; ++t) {
+      if (i0 + t <= j) {
+        const double2 a0 = cconj_mul(qa[t], wv0), b0 = cconj_mul(qa[t], qv0);
+        ac[t].x += a0.x;
+        ac[t].y += a0.y;
+        ag[t].x += b0.x;
+        ag[t].y += b0.y;
+        if (two) {
+          const double2 a1 = cconj_mul(qb[t], wv1), b1 = cconj_mul(qb[t], qv1);
+          ac[t].x += a1.x;
+          ac[t].y += a1.y;
+          ag[t].x += b1.x;
+          ag[t].y += b1.y;
+        }
       }
     }
   }
+  // workgroup sums in the order of block_sum, with one barrier for all 2 kTI values
+  const int wvid = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
   for (int t = 0; t < kTI; ++t) {
     if (i0 + t <= j) {
-      const double2 c = block_sum(ac[t], lds);
-      const double2 g = block_sum(ag[t], lds);
-      if (threadIdx.x == 0) {
-        partials[(size_t)blockIdx.x * nv + (i0 + t)] = c;
-        partials[(size_t)blockIdx.x * nv + (j + 1) + (i0 + t)] = g;
+      ac[t].x = wave_sum(ac[t].x);
+      ac[t].y = wave_sum(ac[t].y);
+      ag[t].x = wave_sum(ag[t].x);
+      ag[t].y = wave_sum(ag[t].y);
+      if (lane == 0) {
+        wsum[wvid][t] = ac[t];
+        wsum[wvid][kTI + t] = ag[t];
       }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * kTI) {
+    const int t = threadIdx.x % kTI;
+    if (i0 + t <= j) {
+      double2 r = wsum[0][threadIdx.x];
+#pragma unroll
+      for (int k = 1; k < kThreads / 64; ++k) {
+        r.x += wsum[k][threadIdx.x].x;
+        r.y += wsum[k][threadIdx.x].y;
+      }
+      const int v = (threadIdx.x < kTI ? 0 : j + 1) + (i0 + t);
+      partials[(size_t)v * kRedBlocks + blockIdx.x] = r;
     }
   }
 }
 
-// one workgroup per value: sum the kRedBlocks multidot partials in a fixed order.  In a
+// One workgroup per value: sum the kRedBlocks multidot partials in a fixed order.  In a
 // row-partitioned run these are the sums over the local rows; the caller all-reduces
-// `reduced` over the ranks before the projection kernel consumes it.
+// `reduced` over the ranks before the solve consumes it (ticket == NULL).  On one GPU the
+// workgroup that finishes last (agent-scope release / acquire around one counter) goes on to
+// solve for the MGS coefficients; which workgroup that is does not influence any value.  Every
+// workgroup starts by pulling the older Gram rows into LDS so that the finishing one has them.
 __global__ __launch_bounds__(kThreads) void multidot_reduce_kernel(const double2* __restrict__ partials, int j,
-                                                                   double2* __restrict__ reduced) {
+                                                                   double2* __restrict__ reduced, unsigned* ticket,
+                                                                   double2* __restrict__ G, int ldg,
+                                                                   double2* __restrict__ hess_col,
+                                                                   double2* __restrict__ coef, double dt) {
+  extern __shared__ double2 dyn[];
   __shared__ double2 lds[kThreads / 64];
   static_assert(kRedBlocks == kThreads, "one partial per thread");
   const int nv = 2 * (j + 1);
   const int v = blockIdx.x;
-  const double2 s = block_sum(partials[(size_t)threadIdx.x * nv + v], lds);
-  if (threadIdx.x == 0) reduced[v] = s;
-}
-
-// Prologue (every workgroup, redundantly): forward substitution
-//   h_i = c_i - sum_{k<i} <q_i|q_k> h_k          (the MGS coefficients, see above)
-// by one wavefront, then  w -= sum_i (dt h_i / dt) q_i  in MGS order and |w|^2 partials.
-__global__ __launch_bounds__(kThreads) void mgs_update_kernel(double2* __restrict__ w, const double2* __restrict__ Q,
-                                                              int64_t ldq, int j, const double2* __restrict__ reduced,
-                                                              double2* __restrict__ G, int ldg,
-                                                              double2* __restrict__ hess_col, double dt,
-                                                              double2* __restrict__ norm_partials, int64_t n) {
-  extern __shared__ double2 sm[];  // [0, j+1): h, then coefficients; [j+1, j+5): reduction scratch
-  double2* h = sm;
-  double2* lds = sm + (j + 1);
-  if (blockIdx.x == 0) {  // Gram row j for the later columns:  G[j][k] = <q_j|q_k> = conj(<q_k|q_j>)
-    for (int k = threadIdx.x; k < j; k += kThreads) {
-      const double2 g = reduced[(j + 1) + k];
-      G[(size_t)j * ldg + k] = make_double2(g.x, -g.y);
+  double2* red = dyn;
+  double2* h = dyn + nv;
+  double2* Gt = h + (j + 1);
+  if (ticket) {
+    const int older = j * (j - 1) / 2;   // rows 1 .. j-1
+    for (int idx = threadIdx.x; idx < older; idx += kThreads) {
+      int i = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)idx)) * 0.5f);
+      while (i * (i - 1) / 2 > idx) --i;
+      while ((i + 1) * i / 2 <= idx) ++i;
+      Gt[idx] = G[(size_t)i * ldg + (idx - i * (i - 1) / 2)];
     }
   }
-  if (threadIdx.x < 64) {
-    const int lane = threadIdx.x;
-    for (int i = 0; i <= j; ++i) {
-      double2 s = make_double2(0.0, 0.0);
-      for (int k = lane; k < i; k += 64) {
-        double2 gik;
-        if (i == j) {
-          const double2 g = reduced[(j + 1) + k];
-          gik = make_double2(g.x, -g.y);
-        } else {
-          gik = G[(size_t)i * ldg + k];
-        }
-        cfma(s, gik, h[k]);
-      }
-      s.x = wave_sum(s.x);
-      s.y = wave_sum(s.y);
-      if (lane == 0) {
-        const double2 c = reduced[i];
-        h[i] = make_double2(c.x - s.x, c.y - s.y);
-      }
-      __builtin_amdgcn_s_waitcnt(0);
-      __builtin_amdgcn_wave_barrier();
-    }
-    for (int i = lane; i <= j; i += 64) {
-      // Hess[i,j] = dt <q_i|q_j+1>;  axpy!(-Hess[i,j]/dt, q_i, q_j+1)   src/arnoldi.jl:85-86
-      const double2 hd = make_double2(dt * h[i].x, dt * h[i].y);
-      if (blockIdx.x == 0) hess_col[i] = hd;
-      h[i] = make_double2(-hd.x / dt, -hd.y / dt);
+  const double2 s = block_sum(partials[(size_t)v * kRedBlocks + threadIdx.x], lds);
+  if (threadIdx.x == 0) reduced[v] = s;
+  if (!ticket) return;
+  __shared__ unsigned s_last;
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (t + 1 == gridDim.x) ? 1u : 0u;
+    if (s_last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
   }
   __syncthreads();
+  if (!s_last) return;
+  for (int k = threadIdx.x; k < nv; k += kThreads) red[k] = reduced[k];
+  __syncthreads();
+  for (int k = threadIdx.x; k < j; k += kThreads) {   // Gram row j = conj of the fresh <q_k|q_j>
+    const double2 r = red[(j + 1) + k];
+    const double2 g = make_double2(r.x, -r.y);
+    Gt[tri_index(j, k)] = g;
+    G[(size_t)j * ldg + k] = g;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) mgs_solve_wave(j, red, Gt, h, hess_col, coef, dt);
+  if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// the solve as its own single-workgroup launch (row-partitioned runs: after the all-reduce)
+__global__ __launch_bounds__(kThreads) void mgs_solve_kernel(int j, const double2* __restrict__ reduced,
+                                                             double2* __restrict__ G, int ldg,
+                                                             double2* __restrict__ hess_col, double2* __restrict__ coef,
+                                                             double dt) {
+  extern __shared__ double2 dyn[];
+  const int nv = 2 * (j + 1);
+  double2* red = dyn;
+  double2* h = dyn + nv;
+  double2* Gt = h + (j + 1);
+  for (int v = threadIdx.x; v < nv; v += kThreads) red[v] = reduced[v];
+  __syncthreads();
+  mgs_stage_gram(j, red, Gt, G, ldg);
+  __syncthreads();
+  if (threadIdx.x < 64) mgs_solve_wave(j, red, Gt, h, hess_col, coef, dt);
+}
+
+// w += sum_i coef_i q_i in MGS order (coef_i = -h_i) and |w|^2 partials; two elements per lane
+// and four basis vectors per round in flight
+__global__ __launch_bounds__(kThreads) void mgs_update_kernel(double2* __restrict__ w, const double2* __restrict__ Q,
+                                                              int64_t ldq, int j, const double2* __restrict__ coef,
+                                                              double2* __restrict__ norm_partials, int64_t n) {
+  extern __shared__ double2 sm[];  // [0, j+1): coefficients; [j+1, j+5): reduction scratch
+  double2* h = sm;
+  double2* lds = sm + (j + 1);
+  for (int i = threadIdx.x; i <= j; i += kThreads) h[i] = coef[i];
+  __syncthreads();
   double nrm = 0.0;
-  for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < n; e += (int64_t)kRedBlocks * kThreads) {
-    double2 r = w[e];
-    for (int i = 0; i <= j; ++i) cfma(r, h[i], Q[(size_t)i * ldq + e]);
-    w[e] = r;
-    nrm += r.x * r.x + r.y * r.y;
+  const int64_t stride = (int64_t)kRedBlocks * kThreads;
+  for (int64_t e0 = (int64_t)blockIdx.x * kThreads + threadIdx.x; e0 < n; e0 += 2 * stride) {
+    const int64_t e1 = e0 + stride;
+    const bool two = e1 < n;
+    double2 r0 = w[e0];
+    double2 r1 = two ? w[e1] : make_double2(0.0, 0.0);
+    int i = 0;
+    for (; i + 3 <= j; i += 4) {
+      double2 a[4], b[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        a[t] = Q[(size_t)(i + t) * ldq + e0];
+        b[t] = two ? Q[(size_t)(i + t) * ldq + e1] : make_double2(0.0, 0.0);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        cfma(r0, h[i + t], a[t]);
+        cfma(r1, h[i + t], b[t]);
+      }
+    }
+    for (; i <= j; ++i) {
+      const double2 a = Q[(size_t)i * ldq + e0];
+      const double2 b = two ? Q[(size_t)i * ldq + e1] : make_double2(0.0, 0.0);
+      cfma(r0, h[i], a);
+      cfma(r1, h[i], b);
+    }
+    w[e0] = r0;
+    nrm += r0.x * r0.x + r0.y * r0.y;
+    if (two) {
+      w[e1] = r1;
+      nrm += r1.x * r1.x + r1.y * r1.y;
+    }
   }
   const double2 t = block_sum(make_double2(nrm, 0.0), lds);
   if (threadIdx.x == 0) norm_partials[blockIdx.x] = t;
 }
 
-int launch_mgs_multidot(hipStream_t s, const double2* Q, int64_t ldq, int j, const double2* w, double2* md_partials,
-                        double2* reduced, int64_t n, Stats* st) {
+static int launch_multidot(hipStream_t s, const double2* Q, int64_t ldq, int j, const double2* w, double2* md_partials,
+                           int64_t n, Stats* st) {
   const int ntiles = (j + 1 + kTI - 1) / kTI;
   hipLaunchKernelGGL(multidot_kernel, dim3(kRedBlocks, ntiles), dim3(kThreads), 0, s, Q, ldq, j, w, md_partials, n);
-  QP_HIP(hipGetLastError());
-  hipLaunchKernelGGL(multidot_reduce_kernel, dim3(2 * (j + 1)), dim3(kThreads), 0, s, md_partials, j, reduced);
-  QP_HIP(hipGetLastError());
-  if (st) st->n_launch += 2;
-  return QP_OK;
-}
-
-int launch_mgs_project(hipStream_t s, const double2* Q, int64_t ldq, int j, double2* w, const double2* reduced,
-                       double2* G, int ldg, double2* hess_col, double2* norm_partials, double dt, int64_t n,
-                       Stats* st) {
-  const size_t shmem = sizeof(double2) * (size_t)(j + 1 + kThreads / 64);
-  hipLaunchKernelGGL(mgs_update_kernel, dim3(kRedBlocks), dim3(kThreads), shmem, s, w, Q, ldq, j, reduced, G, ldg,
-                     hess_col, dt, norm_partials, n);
   QP_HIP(hipGetLastError());
   if (st) st->n_launch++;
   return QP_OK;
 }
 
-int launch_mgs_lowsync(hipStream_t s, const double2* Q, int64_t ldq, int j, double2* w, double2* md_partials,
-                       double2* G, int ldg, double2* hess_col, double2* reduced, double2* norm_partials, double dt,
-                       int64_t n, Stats* st) {
-  int rc = launch_mgs_multidot(s, Q, ldq, j, w, md_partials, reduced, n, st);
+int launch_mgs_multidot(hipStream_t s, const double2* Q, int64_t ldq, int j, const double2* w, double2* md_partials,
+                        double2* reduced, int64_t n, Stats* st) {
+  int rc = launch_multidot(s, Q, ldq, j, w, md_partials, n, st);
   if (rc != QP_OK) return rc;
-  return launch_mgs_project(s, Q, ldq, j, w, reduced, G, ldg, hess_col, norm_partials, dt, n, st);
+  hipLaunchKernelGGL(multidot_reduce_kernel, dim3(2 * (j + 1)), dim3(kThreads), 0, s, md_partials, j, reduced,
+                     (unsigned*)nullptr, (double2*)nullptr, 0, (double2*)nullptr, (double2*)nullptr, 0.0);
+  QP_HIP(hipGetLastError());
+  if (st) st->n_launch++;
+  return QP_OK;
+}
+
+static int launch_mgs_update(hipStream_t s, const double2* Q, int64_t ldq, int j, double2* w, const double2* coef,
+                             double2* norm_partials, int64_t n, Stats* st) {
+  const size_t shmem = sizeof(double2) * (size_t)(j + 1 + kThreads / 64);
+  hipLaunchKernelGGL(mgs_update_kernel, dim3(kRedBlocks), dim3(kThreads), shmem, s, w, Q, ldq, j, coef, norm_partials, n);
+  QP_HIP(hipGetLastError());
+  if (st) st->n_launch++;
+  return QP_OK;
+}
+
+int launch_mgs_project(hipStream_t s, const double2* Q, int64_t ldq, int j, double2* w, const double2* reduced,
+                       double2* G, int ldg, double2* hess_col, double2* coef, double2* norm_partials, double dt,
+                       int64_t n, Stats* st) {
+  hipLaunchKernelGGL(mgs_solve_kernel, dim3(1), dim3(kThreads), mgs_solve_lds(j), s, j, reduced, G, ldg, hess_col, coef, dt);
+  QP_HIP(hipGetLastError());
+  if (st) st->n_launch++;
+  return launch_mgs_update(s, Q, ldq, j, w, coef, norm_partials, n, st);
+}
+
+int launch_mgs_lowsync(hipStream_t s, const double2* Q, int64_t ldq, int j, double2* w, double2* md_partials,
+                       double2* G, int ldg, double2* hess_col, double2* reduced, double2* coef, unsigned* ticket,
+                       double2* norm_partials, double dt, int64_t n, Stats* st) {
+  int rc = launch_multidot(s, Q, ldq, j, w, md_partials, n, st);
+  if (rc != QP_OK) return rc;
+  hipLaunchKernelGGL(multidot_reduce_kernel, dim3(2 * (j + 1)), dim3(kThreads), mgs_solve_lds(j), s, md_partials, j,
+                     reduced, ticket, G, ldg, hess_col, coef, dt);
+  QP_HIP(hipGetLastError());
+  if (st) st->n_launch++;
+  return launch_mgs_update(s, Q, ldq, j, w, coef, norm_partials, n, st);
 }
 
 __global__ __launch_bounds__(kThreads) void reduce_triples_kernel(const double* __restrict__ partials, int nwg,

@@ -25,7 +25,7 @@ import scipy.sparse as sp
 from . import lib as L
 
 __all__ = ["Generator", "hamiltonian", "liouvillian", "MatrixFreeLiouvillian", "init_prop", "prop_step", "reinit_prop", "set_state", "set_t",
-           "propagate", "ChebyPropagator", "NewtonPropagator", "discretize", "discretize_on_midpoints"]
+           "propagate", "ode_function", "QuantumODEFunction", "ChebyPropagator", "NewtonPropagator", "discretize", "discretize_on_midpoints"]
 
 
 # ----------------------------------------------------------------------------------------
@@ -226,6 +226,60 @@ class _DeviceGenerator:
         if self.controls:
             self.op.set_coeffs(np.asarray(vals, dtype=np.complex128))
         return self.op
+
+
+class QuantumODEFunction:
+    """``f = ode_function(generator, tlist; c=-1im)`` -- src/ode_function.jl:54-98: the right-hand
+    side d|Psi>/dt = c H(t) |Psi> for an ODE solver.  ``f(du, u, p, t)`` writes into the device
+    state ``du`` and returns it; ``f(u, p, t)`` returns a new device state.  ``p`` (the solver's
+    parameters, the reference's ``vals_dict``) maps a control -- by identity -- to the value that
+    replaces it; every other control must be a callable of ``t``
+    (``evaluate(control::Vector, t)`` is an error, src/controls.jl:388-396).  The matrices stay
+    on the device; a call uploads the coefficients and launches one ``mul!(du, H, u, c, false)``."""
+
+    def __init__(self, ctx, generator, c=-1j, device_format=L.FMT_AUTO):
+        self.ctx = ctx
+        self.generator = generator
+        self._dgen = _DeviceGenerator(ctx, generator, device_format)
+        self.c = complex(c)
+
+    @property
+    def operator(self):
+        return self._dgen.op
+
+    def _evaluate(self, p, t):
+        vals = []
+        for control in self._dgen.controls:
+            hit = None
+            if p:
+                items = p.items() if hasattr(p, "items") else p
+                hit = next((v for k, v in items if k is control), None)
+            if hit is not None:
+                vals.append(hit)
+            elif callable(control):
+                vals.append(control(float(t)))
+            else:
+                raise TypeError("`evaluate(control::Vector, t::Float64)` is invalid. Use e.g. `evaluate(…, tlist, n)`.")
+        return self._dgen.set_vals(vals)
+
+    def __call__(self, *args):
+        if len(args) == 4:
+            du, u, p, t = args
+        elif len(args) == 3:
+            u, p, t = args
+            du = L.State(self.ctx, n=u.n)
+        else:
+            raise TypeError("f(du, u, p, t) or f(u, p, t)")
+        H = self._evaluate(p, t)
+        return H.mul(u, du, self.c, 0.0)
+
+
+def ode_function(generator, tlist=None, *, c=-1j, ctx=None, device=0, device_format=L.FMT_AUTO):
+    """src/ode_function.jl:54-63.  ``tlist`` is accepted for signature parity (the reference uses
+    it only to build the first operator)."""
+    ctx = ctx if ctx is not None else L.Context(device)
+    return QuantumODEFunction(ctx, generator, c=c, device_format=device_format)
+
 
 
 # ----------------------------------------------------------------------------------------

@@ -539,3 +539,49 @@ def test_propagator_property_access(ctx):
     assert p.t == tlist[1]
     with pytest.raises(ValueError):      # "init_prop unknown method" (:371-381)
         P.init_prop(psi, H0, tlist, 42, ctx=ctx)
+
+
+def test_ode_function(ctx):
+    """src/ode_function.jl:54-98: f(du, u, p, t) = c H(t) u on the device, in place and not in
+    place, with `vals_dict` substitution; integrating it with classical RK4 reproduces the
+    Chebyshev propagation of the same generator."""
+    H0, psi0 = _optomech()
+    N = H0.shape[0]
+    H1 = sp.diags([np.linspace(-1, 1, N).astype(complex)], [0], format="csr")
+    eps = lambda t: 0.3 * np.sin(20.0 * t)  # noqa: E731
+    gen = P.hamiltonian(H0, (H1, eps))
+    tlist = np.linspace(0, 0.2, 2001)
+    f = P.ode_function(gen, tlist, ctx=ctx)
+    u = L.State(ctx, data=psi0)
+    du = L.State(ctx, n=N)
+    out = f(du, u, None, 0.2)
+    assert out is du
+    ref = -1j * ((H0 + eps(0.2) * H1) @ psi0)
+    assert np.linalg.norm(du.numpy() - ref) < 1e-12
+    new = f(u, {}, 0.2)                                     # not in place: a new state
+    assert new is not u and np.linalg.norm(new.numpy() - ref) < 1e-12
+    sub = f(u, [(eps, 2.0)], 0.2)                           # vals_dict, keyed by identity
+    assert np.linalg.norm(sub.numpy() - (-1j * ((H0 + 2.0 * H1) @ psi0))) < 1e-12
+    g = P.ode_function(P.hamiltonian(H0, (H1, np.zeros(len(tlist)))), tlist, ctx=ctx, c=1.0)
+    with pytest.raises(TypeError, match="is invalid"):      # src/controls.jl:388-396
+        g(u, None, 0.2)
+    arr = g.generator.amplitudes[0]
+    assert np.linalg.norm(g(u, [(arr, 0.5)], 0.2).numpy() - ((H0 + 0.5 * H1) @ psi0)) < 1e-12
+    # RK4 over the grid against the PWC Chebyshev propagation (midpoint values) of the same H(t)
+    k = [L.State(ctx, n=N) for _ in range(4)]
+    tmp = L.State(ctx, n=N)
+    for i in range(len(tlist) - 1):
+        t, h = tlist[i], tlist[i + 1] - tlist[i]
+        f(k[0], u, None, t)
+        tmp.copy_from(u); tmp.axpy(h / 2, k[0])             # noqa: E702
+        f(k[1], tmp, None, t + h / 2)
+        tmp.copy_from(u); tmp.axpy(h / 2, k[1])             # noqa: E702
+        f(k[2], tmp, None, t + h / 2)
+        tmp.copy_from(u); tmp.axpy(h, k[2])                 # noqa: E702
+        f(k[3], tmp, None, t + h)
+        for w, kk in zip((h / 6, h / 3, h / 3, h / 6), k):
+            u.axpy(w, kk)
+    cheb = P.propagate(psi0, gen, tlist, method="cheby", ctx=ctx)
+    cheb = cheb.numpy() if hasattr(cheb, "numpy") else np.asarray(cheb)
+    assert np.linalg.norm(u.numpy() - cheb) < 1e-6          # O(dt^2) PWC vs O(dt^4) RK4 on the same H(t)
+    assert abs(np.linalg.norm(u.numpy()) - 1.0) < 1e-8

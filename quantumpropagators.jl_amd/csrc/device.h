@@ -130,6 +130,7 @@ extern int g_acc_defer;   // qp_cheby_step: touch the Psi accumulator every thir
 extern int g_cheby_graph; // qp_cheby_step: replay a repeated step as a hipGraph when the mat-vec grid has at most this many workgroups (0: off)
 extern int g_small_nnz;   // qp_propagate: register-resident Cheby systems up to this nnz run as ONE persistent launch (0: off)
 extern int g_spmm_tile;   // states per pass of the batched SpMM kernel (16, 32 or 64)
+extern int g_spmm_nt;     // nontemporal matrix / row-local streams in the batched SpMM kernel
 extern int g_split_mode;  // 0 = cross-stream events on both streams, 1 = in-launch counter for the main stream
 
 // small coefficient vectors are passed by value in the kernel-argument segment

@@ -101,7 +101,33 @@ __device__ __forceinline__ void sync_signal(const SyncArgs& sy) {
 // ---------------------------------------------------------------------------
 // epilogues
 // ---------------------------------------------------------------------------
-struct ChebyOp {
+// NT: the row-local streams (v0, the accumulator, the new term) are nontemporal -- for the
+// batched panel, where they would evict the gather window of X from L2 and are not touched
+// again before the next launch
+typedef double d2nt __attribute__((ext_vector_type(2)));
+template <bool NT>
+__device__ __forceinline__ double2 ld_stream(const double2* p) {
+  if (NT) {
+    const d2nt t = __builtin_nontemporal_load(reinterpret_cast<const d2nt*>(p));
+    return make_double2(t.x, t.y);
+  }
+  return *p;
+}
+template <bool NT>
+__device__ __forceinline__ void st_stream(double2* p, const double2 v) {
+  if (NT) {
+    d2nt t;
+    t.x = v.x;
+    t.y = v.y;
+    __builtin_nontemporal_store(t, reinterpret_cast<d2nt*>(p));
+  } else {
+    *p = v;
+  }
+}
+
+template <bool NT>
+struct ChebyOpT {
+  static constexpr bool kStream = NT;
   ChebyEpi e;
   struct Pre {
     double2 xi, v0, acc;
@@ -110,8 +136,8 @@ struct ChebyOp {
   __device__ __forceinline__ Pre pre(int64_t i) const {
     Pre p;
     p.xi = e.xloc[i];
-    p.v0 = e.v0 ? e.v0[i] : make_double2(0.0, 0.0);
-    p.acc = e.acc_in ? e.acc_in[i] : make_double2(0.0, 0.0);
+    p.v0 = e.v0 ? ld_stream<NT>(e.v0 + i) : make_double2(0.0, 0.0);
+    p.acc = e.acc_in ? ld_stream<NT>(e.acc_in + i) : make_double2(0.0, 0.0);
     return p;
   }
   __device__ __forceinline__ void row(int64_t i, double2 s, const Pre& p, double2& chk, double& nrm,
@@ -130,7 +156,7 @@ struct ChebyOp {
       t.x += p.v0.x;
       t.y += p.v0.y;
     }
-    if (e.vout) e.vout[i] = t;
+    if (e.vout) st_stream<NT>(e.vout + i, t);
     if (e.mirror) {
       const int sp = e.mirror[slot];
       if (sp >= 0) e.slab[sp] = t;
@@ -154,9 +180,10 @@ struct ChebyOp {
     r.x = fma(e.a, t.x, r.x);  // axpy!(a[i], v, Psi)  :182, :205
     r.y = fma(e.a, t.y, r.y);
     if (e.apply_phase) r = cmul(e.phase, r);  // lmul!(exp(-i beta dt), Psi)  :211
-    e.acc_out[i] = r;
+    st_stream<NT>(e.acc_out + i, r);
   }
 };
+using ChebyOp = ChebyOpT<false>;
 
 struct PlainOp {
   PlainEpi e;
@@ -542,8 +569,8 @@ __global__ __launch_bounds__(kThreads) void csr_spmm_kernel(const int64_t* __res
   for (int k0 = 0; k0 < maxlen; k0 += CH) {
     if (k0 > 0) __syncthreads();
     if (k0 + sl < len) {
-      s_val[rl][sl] = vals[p0 + k0 + sl];
-      s_col[rl][sl] = cols[p0 + k0 + sl];
+      s_val[rl][sl] = ld_stream<Op::kStream>(vals + p0 + k0 + sl);
+      s_col[rl][sl] = Op::kStream ? __builtin_nontemporal_load(cols + p0 + k0 + sl) : cols[p0 + k0 + sl];
     }
     __syncthreads();
     const int cnt = min(CH, len - k0);
@@ -567,24 +594,32 @@ __global__ __launch_bounds__(kThreads) void csr_spmm_kernel(const int64_t* __res
 
 int g_spmm_tile = 16;
 
+// nontemporal matrix and row-local streams in the batched kernel: 0 never, 2 always, 1 when one
+// panel vector is larger than what the caches could keep until the next launch anyway
+int g_spmm_nt = 1;
+
+template <int TS>
+static void launch_spmm_cheby_t(hipStream_t s, const int64_t* rowptr, const int32_t* cols, const double2* vals,
+                                const double2* X, int64_t nrows, int b, const ChebyEpi& e) {
+  const int rpw = kThreads / TS;
+  dim3 grid((unsigned)((nrows + rpw - 1) / rpw), (unsigned)((b + TS - 1) / TS));
+  const bool nt = g_spmm_nt == 2 || (g_spmm_nt == 1 && (double)nrows * b * sizeof(double2) >= 128.0 * 1024 * 1024);
+  if (nt) {
+    ChebyOpT<true> op{e};
+    hipLaunchKernelGGL((csr_spmm_kernel<ChebyOpT<true>, TS>), grid, dim3(kThreads), 0, s, rowptr, cols, vals, X, nrows, b, op);
+  } else {
+    ChebyOp op{e};
+    hipLaunchKernelGGL((csr_spmm_kernel<ChebyOp, TS>), grid, dim3(kThreads), 0, s, rowptr, cols, vals, X, nrows, b, op);
+  }
+}
+
 int launch_spmm_cheby(hipStream_t s, const int64_t* rowptr, const int32_t* cols, const double2* vals,
                       const double2* X, int64_t nrows, int64_t nnz, int b, const ChebyEpi& e, Stats* st) {
   if (nrows == 0) return QP_OK;
-  ChebyOp op{e};
-  int ts = g_spmm_tile;
-  if (ts != 16 && ts != 32 && ts != 64) ts = 16;
-  const int rpw = kThreads / ts;
-  dim3 grid((unsigned)((nrows + rpw - 1) / rpw), (unsigned)((b + ts - 1) / ts));
-  switch (ts) {
-    case 16:
-      hipLaunchKernelGGL((csr_spmm_kernel<ChebyOp, 16>), grid, dim3(kThreads), 0, s, rowptr, cols, vals, X, nrows, b, op);
-      break;
-    case 32:
-      hipLaunchKernelGGL((csr_spmm_kernel<ChebyOp, 32>), grid, dim3(kThreads), 0, s, rowptr, cols, vals, X, nrows, b, op);
-      break;
-    default:
-      hipLaunchKernelGGL((csr_spmm_kernel<ChebyOp, 64>), grid, dim3(kThreads), 0, s, rowptr, cols, vals, X, nrows, b, op);
-      break;
+  switch (g_spmm_tile) {
+    case 32: launch_spmm_cheby_t<32>(s, rowptr, cols, vals, X, nrows, b, e); break;
+    case 64: launch_spmm_cheby_t<64>(s, rowptr, cols, vals, X, nrows, b, e); break;
+    default: launch_spmm_cheby_t<16>(s, rowptr, cols, vals, X, nrows, b, e); break;
   }
   QP_HIP(hipGetLastError());
   if (st) {

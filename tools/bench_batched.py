@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--tile", type=int, default=16)
+    ap.add_argument("--nt", type=int, default=None, help="nontemporal streams in the batched kernel (knob spmm_nt)")
     args = ap.parse_args()
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -38,6 +39,8 @@ def main():
     rp, col, vals = synth.hermitian_offsets_csr(N)
     ctx = L.Context(local_rank)
     L.tuning_set("spmm_tile", args.tile)
+    if args.nt is not None:
+        L.tuning_set("spmm_nt", args.nt)
     op = L.Operator(ctx, [L.Matrix(ctx, N, N, rp, col, vals)])
     nnz = int(rp[-1])
     states = np.stack([synth.random_state(N, seed=500 + s0 + s) for s in range(b)], axis=1)

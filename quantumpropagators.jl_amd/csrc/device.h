@@ -129,6 +129,7 @@ extern int g_stencil;     // operator build: encode blocks with block-wide colum
 extern int g_acc_defer;   // qp_cheby_step: touch the Psi accumulator every third term only (1, default) or every term (0)
 extern int g_cheby_graph; // qp_cheby_step: replay a repeated step as a hipGraph when the mat-vec grid has at most this many workgroups (0: off)
 extern int g_small_nnz;   // qp_propagate: register-resident Cheby systems up to this nnz run as ONE persistent launch (0: off)
+extern int g_newton_pipeline;  // newton!: Hessenberg eigenvalues overlap the Arnoldi sweep
 extern int g_spmm_tile;   // states per pass of the batched SpMM kernel (16, 32 or 64)
 extern int g_spmm_nt;     // nontemporal matrix / row-local streams in the batched SpMM kernel
 extern int g_split_mode;  // 0 = cross-stream events on both streams, 1 = in-launch counter for the main stream

@@ -2,6 +2,7 @@
 // opaque pointers of include/qprop.h and the small helpers they share.
 #pragma once
 
+#include <vector>
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -111,6 +112,9 @@ struct qp_krylov {
   unsigned* ticket = nullptr;   // finishing-workgroup counter of the multidot launch (zero between launches)
   double2* h_hess = nullptr;    // pinned host mirrors of hess_dev / norms_dev
   double* h_norms = nullptr;
+  double2* hess_map = nullptr;  // the same pinned buffers as the device sees them: the multi-launch
+  double* norms_map = nullptr;  // Arnoldi sweep writes its Hessenberg entries straight to the host
+  std::vector<hipEvent_t> col_events;  // one per column: "column j is on the host" (pipelined restarts)
   double2* q(int i) const { return Q + (size_t)i * n; }
 };
 

@@ -92,6 +92,10 @@ int qp_tuning_set(const char* key, int value) {
     qp::g_spmm_tile = value;
     return QP_OK;
   }
+  if (std::strcmp(key, "newton_pipeline") == 0) {
+    qp::g_newton_pipeline = value;
+    return QP_OK;
+  }
   if (std::strcmp(key, "spmm_nt") == 0) {
     qp::g_spmm_nt = value;
     return QP_OK;

@@ -2,6 +2,8 @@
 // variants.
 #include "engine.h"
 
+#include <functional>
+
 extern "C" {
 
 // ---------------------------------------------------------------------------
@@ -29,6 +31,8 @@ int qp_krylov_create(qp_ctx* ctx, int64_t n, int nvec, qp_krylov** out) {
   QP_HIP(hipMemsetAsync(q->ticket, 0, sizeof(unsigned), ctx->stream));
   QP_HIP(hipHostMalloc((void**)&q->h_hess, sizeof(double2) * (size_t)nvec * nvec, hipHostMallocDefault));
   QP_HIP(hipHostMalloc((void**)&q->h_norms, sizeof(double) * (size_t)nvec, hipHostMallocDefault));
+  QP_HIP(hipHostGetDevicePointer((void**)&q->hess_map, q->h_hess, 0));
+  QP_HIP(hipHostGetDevicePointer((void**)&q->norms_map, q->h_norms, 0));
   *out = q.release();
   return QP_OK;
   QP_CATCH
@@ -50,6 +54,7 @@ int qp_krylov_destroy(qp_krylov* q) {
   if (q->hcoef) (void)hipFree(q->hcoef);
   if (q->mgs_coef) (void)hipFree(q->mgs_coef);
   if (q->ticket) (void)hipFree(q->ticket);
+  for (hipEvent_t e : q->col_events) (void)hipEventDestroy(e);
   delete q;
   return QP_OK;
   QP_CATCH
@@ -112,8 +117,15 @@ __global__ void norm_guard_scale_kernel(double2* __restrict__ w, const double2* 
 // arnoldi! with an optional normalisation of the start vector: beta_out != NULL means `psi` is
 // not normalised; q_0 = psi / |psi| and *beta_out = |psi| (newton! :268-272 folded in, so that
 // the persistent small-system kernel does it in the same launch).
+//
+// on_column != NULL (multi-launch path only): the sweep is enqueued whole, every column followed by
+// an event; the host then takes the columns as they arrive and calls on_column(j) once column j is
+// in Hess -- the caller's work on the leading (j+1) x (j+1) block (newton!: its eigenvalues,
+// src/newton.jl:297) overlaps the device's work on the later columns.
+using ColumnHook = std::function<int(int)>;
 static int arnoldi_impl(qp_operator* op, qp_krylov* q, int m, const qp_state* psi, double dt, int extended,
-                        double norm_min, qp_c128* Hess, int ldh, int* m_out, double* beta_out) {
+                        double norm_min, qp_c128* Hess, int ldh, int* m_out, double* beta_out,
+                        const ColumnHook* on_column = nullptr) {
   QP_TRY
   if (!op || !q || !psi || !Hess || !m_out) return qp::fail(QP_E_BAD_ARG, "qp_arnoldi: NULL argument");
   const int dim = extended ? m + 1 : m;
@@ -125,6 +137,7 @@ static int arnoldi_impl(qp_operator* op, qp_krylov* q, int m, const qp_state* ps
   std::memset(Hess, 0, sizeof(qp_c128) * (size_t)ldh * ldh);                                      // :78
   qp::SmallArgs plan;
   bool small = false;
+  bool piped = false;
   if (op->A.nnz <= qp::g_small_nnz && qp::small_arnoldi_fits(q->n, m)) {
     int64_t maxrow = 0;
     for (int64_t r = 0; r < q->n; ++r) maxrow = std::max<int64_t>(maxrow, op->u_rowptr[r + 1] - op->u_rowptr[r]);
@@ -155,8 +168,11 @@ static int arnoldi_impl(qp_operator* op, qp_krylov* q, int m, const qp_state* ps
     QP_CHECK(qp::launch_arnoldi_small(ctx->stream, a, &ctx->stats));
     q->gram_rows = 0;
   } else {
-    QP_HIP(hipMemsetAsync(q->hess_dev, 0, sizeof(double2) * (size_t)ldd * ldd, ctx->stream));
-    QP_HIP(hipMemsetAsync(q->norms_dev, 0, sizeof(double) * (size_t)ldd, ctx->stream));
+    piped = on_column != nullptr;
+    // Hessenberg entries and norms go straight into the pinned host buffers (nothing of an earlier
+    // sweep is in flight: every sweep ends with a synchronisation)
+    std::memset(q->h_hess, 0, sizeof(double2) * (size_t)ldd * ldd);
+    std::memset(q->h_norms, 0, sizeof(double) * (size_t)ldd);
     QP_HIP(hipMemsetAsync(q->ticket, 0, sizeof(unsigned), ctx->stream));
     QP_HIP(hipMemcpyAsync(q->q(0), psi->d, (size_t)q->n * sizeof(double2), hipMemcpyDeviceToDevice, ctx->stream));  // :79
     if (beta_out) {
@@ -165,39 +181,52 @@ static int arnoldi_impl(qp_operator* op, qp_krylov* q, int m, const qp_state* ps
       *beta_out = std::sqrt(n2.real());
       QP_CHECK(qp::launch_scal(ctx->stream, q->q(0), make_double2(1.0 / *beta_out, 0.0), q->n, &ctx->stats));
     }
+    if (piped) {
+      while ((int)q->col_events.size() < m) {
+        hipEvent_t e;
+        QP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        q->col_events.push_back(e);
+      }
+    }
     for (int j = 0; j < m; ++j) {
-      double2* hcol = q->hess_dev + (size_t)j * ldd;
+      double2* hcol = q->hess_map + (size_t)j * ldd;
       QP_CHECK(arnoldi_column(op, q, j, dt, hcol));
       if ((j + 1 < m) || extended) {                                                               // :88-97
         hipLaunchKernelGGL(norm_guard_scale_kernel, dim3(2048), dim3(qp::kThreads), 0, ctx->stream, q->q(j + 1),
-                           q->part + (size_t)((j + 1) & 1) * kRedBlocks, hcol + (j + 1), q->norms_dev + j, dt, norm_min,
+                           q->part + (size_t)((j + 1) & 1) * kRedBlocks, hcol + (j + 1), q->norms_map + j, dt, norm_min,
                            q->n);
         QP_HIP(hipGetLastError());
         ctx->stats.n_launch++;
       }
+      if (piped) QP_HIP(hipEventRecord(q->col_events[j], ctx->stream));
     }
   }
-  // one download of the Hessenberg matrix and the norms, into pinned memory
   const cplx* hh = reinterpret_cast<const cplx*>(q->h_hess);
   const double* hn = q->h_norms;
-  QP_HIP(hipMemcpyAsync(q->h_hess, q->hess_dev, (size_t)ldd * ldd * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
-  QP_HIP(hipMemcpyAsync(q->h_norms, q->norms_dev, (size_t)ldd * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  QP_HIP(hipStreamSynchronize(ctx->stream));
+  if (small) {
+    // one download of the Hessenberg matrix and the norms, into pinned memory
+    QP_HIP(hipMemcpyAsync(q->h_hess, q->hess_dev, (size_t)ldd * ldd * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
+    QP_HIP(hipMemcpyAsync(q->h_norms, q->norms_dev, (size_t)ldd * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  if (!piped) QP_HIP(hipStreamSynchronize(ctx->stream));
   if (small && beta_out) *beta_out = hn[ldd - 1];   // written by the kernel (slot ldd - 1 is never a column's)
   int m_eff = m;
+  int hook_rc = QP_OK;
   for (int j = 0; j < m; ++j) {
-    if (((j + 1 < m) || extended) && hn[j] < norm_min) {  // dimensionality exhausted  :91-95
-      m_eff = j + 1;
-      break;
-    }
-  }
-  for (int j = 0; j < m_eff; ++j) {
+    if (piped) QP_HIP(hipEventSynchronize(q->col_events[j]));
     const int rows = std::min(j + 2, dim);
     for (int i = 0; i < rows; ++i) {
       cplx v = hh[(size_t)j * ldd + i];
       Hess[(size_t)j * ldh + i] = qp_c128{v.real(), v.imag()};
     }
+    if (piped && (hook_rc = (*on_column)(j)) != QP_OK) break;
+    if (((j + 1 < m) || extended) && hn[j] < norm_min) {  // dimensionality exhausted  :91-95
+      m_eff = j + 1;
+      break;
+    }
   }
+  if (piped) QP_HIP(hipStreamSynchronize(ctx->stream));   // the columns after a breakdown are discarded
+  if (hook_rc != QP_OK) return hook_rc;
   *m_out = m_eff;
   return QP_OK;
   QP_CATCH
@@ -410,9 +439,23 @@ int qp_newton_step(qp_newton* w, qp_operator* op, qp_state* psi, double dt, int 
   while (true) {                                                                     // :274
     int m_req = m;
     auto t0 = now();
+    // Ritz values of every leading block (:297), block j+1 as soon as column j has arrived -- on
+    // the multi-launch path while the device is still orthogonalising the later columns
+    ritz.assign((size_t)m_req * (m_req + 1) / 2, cplx(0));
+    double ms_eig_sweep = 0;
+    int blocks_done = 0;
+    const ColumnHook eig_block = [&](int j) -> int {
+      auto t1 = now();
+      const int st = qp::diagonalize_hessenberg_block(Hess.data(), ldh, j + 1, ritz.data() + (size_t)j * (j + 1) / 2);
+      ms_eig_sweep += ms_since(t1);
+      blocks_done = j + 1;
+      return st == QP_OK ? QP_OK : qp::fail(QP_E_INTERNAL, "Hessenberg QR did not converge");
+    };
     QP_CHECK(arnoldi_impl(op, w->q, m_req, s == 0 ? psi : &vstate, dt, 1, norm_min,
-                          reinterpret_cast<qp_c128*>(Hess.data()), ldh, &m, s == 0 ? &beta : nullptr));
-    ms_arnoldi += ms_since(t0);
+                          reinterpret_cast<qp_c128*>(Hess.data()), ldh, &m, s == 0 ? &beta : nullptr,
+                          qp::g_newton_pipeline ? &eig_block : nullptr));
+    ms_arnoldi += ms_since(t0) - ms_eig_sweep;
+    ms_eig += ms_eig_sweep;
     n_matvec += m_req;
     if (m == 1 && s == 0) {                                                          // :289-295
       const cplx lam = beta * Hess[0];
@@ -420,10 +463,10 @@ int qp_newton_step(qp_newton* w, qp_operator* op, qp_state* psi, double dt, int 
       QP_CHECK(qp::launch_scal(ctx->stream, psi->d, d2(f), psi->n, &ctx->stats));
       break;
     }
-    ritz.assign((size_t)m * (m + 1) / 2, cplx(0));
     t0 = now();
-    if (qp::diagonalize_hessenberg(Hess.data(), ldh, m, true, ritz.data()) != QP_OK)  // :297
-      return qp::fail(QP_E_INTERNAL, "Hessenberg QR did not converge");
+    for (int j = blocks_done; j < m; ++j)   // persistent-kernel sweep, or the pipeline switched off
+      QP_CHECK(eig_block(j));
+    ritz.resize((size_t)m * (m + 1) / 2);
     ms_eig += ms_since(t0);
     if (s == 0) {                                                                    // :301-303, :67-70
       double rmax = 0;

@@ -130,26 +130,32 @@ bool hessenberg_eigvals_inplace(int n, cplx* A, cplx* w) {
   return true;
 }
 
+// eigenvalues of the leading j x j block -- one round of the loop of src/arnoldi.jl:150-168
+int diagonalize_hessenberg_block(const cplx* Hess, int ldh, int j, cplx* out) {
+  static thread_local std::vector<cplx> work;   // reused between calls (no allocation in a restart loop)
+  auto Hm = [&](int r, int c) { return Hess[(size_t)c * ldh + r]; };
+  if (j == 1) {
+    out[0] = Hm(0, 0);
+  } else if (j == 2) {
+    cplx a = Hm(0, 0), c = Hm(1, 0), b = Hm(0, 1), d = Hm(1, 1);
+    cplx s = std::sqrt(a * a + 4.0 * b * c - 2.0 * a * d + d * d);
+    out[0] = 0.5 * (a + d - s);
+    out[1] = 0.5 * (a + d + s);
+  } else {
+    work.assign((size_t)j * j, cplx(0));
+    for (int c = 0; c < j; ++c)
+      for (int r = 0; r < j; ++r) work[(size_t)c * j + r] = Hm(r, c);
+    if (!hessenberg_eigvals_inplace(j, work.data(), out)) return QP_E_INTERNAL;
+  }
+  return QP_OK;
+}
+
 // diagonalize_hessenberg_matrix -- src/arnoldi.jl:143-170
 int diagonalize_hessenberg(const cplx* Hess, int ldh, int m, bool accumulate, cplx* out) {
-  int j_min = accumulate ? 1 : m;
   int offset = 0;
-  static thread_local std::vector<cplx> work;   // reused between calls (no allocation in a restart loop)
-  for (int j = j_min; j <= m; ++j) {
-    auto Hm = [&](int r, int c) { return Hess[(size_t)c * ldh + r]; };
-    if (j == 1) {
-      out[0] = Hm(0, 0);
-    } else if (j == 2) {
-      cplx a = Hm(0, 0), c = Hm(1, 0), b = Hm(0, 1), d = Hm(1, 1);
-      cplx s = std::sqrt(a * a + 4.0 * b * c - 2.0 * a * d + d * d);
-      out[offset + 0] = 0.5 * (a + d - s);
-      out[offset + 1] = 0.5 * (a + d + s);
-    } else {
-      work.assign((size_t)j * j, cplx(0));
-      for (int c = 0; c < j; ++c)
-        for (int r = 0; r < j; ++r) work[(size_t)c * j + r] = Hm(r, c);
-      if (!hessenberg_eigvals_inplace(j, work.data(), out + offset)) return QP_E_INTERNAL;
-    }
+  for (int j = accumulate ? 1 : m; j <= m; ++j) {
+    const int st = diagonalize_hessenberg_block(Hess, ldh, j, out + offset);
+    if (st != QP_OK) return st;
     offset += j;
   }
   return QP_OK;

@@ -592,6 +592,7 @@ __global__ __launch_bounds__(kThreads) void csr_spmm_kernel(const int64_t* __res
   if (active) op.row(e, make_double2(acc0.x + acc1.x, acc0.y + acc1.y), pre, chk, nrm, e);
 }
 
+int g_newton_pipeline = 1;  // 1: newton! takes the Hessenberg columns as they arrive (eigenvalues overlap the sweep)
 int g_spmm_tile = 16;
 
 // nontemporal matrix and row-local streams in the batched kernel: 0 never, 2 always, 1 when one

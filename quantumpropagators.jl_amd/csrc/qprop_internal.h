@@ -26,6 +26,7 @@ using cplx = std::complex<double>;
 std::vector<double> cheby_coeffs(double Delta, double dt, double limit);
 bool hessenberg_eigvals_inplace(int n, cplx* A, cplx* w);
 int diagonalize_hessenberg(const cplx* Hess, int ldh, int m, bool accumulate, cplx* out);
+int diagonalize_hessenberg_block(const cplx* Hess, int ldh, int j, cplx* out);
 void extend_leja(cplx* leja, int n, cplx* newpoints, int n_new, int n_use);
 cplx eval_func(int func_id, qp_func_cb cb, void* user, cplx z);
 int extend_newton_coeffs(cplx* a, int n_a, const cplx* leja, int func_id, qp_func_cb cb, void* user,

@@ -18,13 +18,15 @@ rp, col, vals = synth.hermitian_offsets_csr(N)
 ctx = L.Context(0, stream=torch.cuda.current_stream().cuda_stream)
 psi0 = synth.random_state(N)
 send = np.concatenate([np.arange(0, 4096), np.arange(N - 4096, N)])
-K = 30
+K = int(os.environ.get("QP_STEPS", "30"))
 res = {}
 for name, kw in (("plain (no exchange)", dict()), ("exchange, serial", dict(_debug_send_rows=send, overlap=False)),
                  ("exchange, overlap/events", dict(_debug_send_rows=send, overlap=True, mode=0)),
                  ("exchange, overlap/flag", dict(_debug_send_rows=send, overlap=True, mode=1)),
                  ("native, serial", dict(_debug_send_rows=send, overlap=False, native=True)),
                  ("native, overlap/flag", dict(_debug_send_rows=send, overlap=True, mode=1, native=True))):
+    if os.environ.get("QP_ONLY") and os.environ["QP_ONLY"] != name:
+        continue
     L.tuning_set("split_mode", kw.pop("mode", 1))
     sh = sharded.ShardedCheby(ctx, rp, col, vals, N, 0, N, 20.0, -10.0, 1.0, exchange="halo", **kw)
     sh.set_state(psi0)

@@ -243,7 +243,7 @@ def main():
     # from the committed summary under profiles/ (null when there is none for this kernel)
     traffic = None
     kern = {1: "csr_spmv_kernel<16,ChebyOp>", 2: "rbcsr_spmv_kernel<ChebyOp,7>", 3: "hrb_spmv_kernel<ChebyOp,7>"}[fmt_used]
-    pmc_file = os.path.join(ROOT, "profiles", "r01", "bench_head_pmc_summary.json")
+    pmc_file = os.path.join(ROOT, "profiles", "r01", "bench_final_pmc_summary.json")
     if (fmt_used == 3 and world == 1 and args.log2n == 20 and args.pattern == "banded" and not args.real and
             os.path.exists(pmc_file)):
         with open(pmc_file) as f:
@@ -277,7 +277,7 @@ def main():
                    "global_steps_per_s": steps_per_s},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "traffic_source": "profiles/r01/bench_head_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                     "traffic_source": "profiles/r01/bench_final_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                        "FETCH x2 gfx950 correction)" if traffic else None,
                      "kernel": kern,
                      "algorithmic_bytes_per_launch": alg_bytes,

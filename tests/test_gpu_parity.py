@@ -1028,3 +1028,31 @@ def test_random_operators_all_formats(ctx, fmt, m):
     t = c * (A @ x - beta * x) + v0
     assert np.linalg.norm(vout.numpy() - t) < 1e-12 * max(1.0, np.linalg.norm(t))
     assert np.linalg.norm(acc.numpy() - (y0 + a * t)) < 1e-12 * max(1.0, np.linalg.norm(y0 + a * t))
+
+
+@pytest.mark.parametrize("pipeline", [1, 0])
+def test_newton_breakdown_multilaunch_path(ctx, pipeline):
+    """Krylov space exhausted (src/arnoldi.jl:91-95, src/newton.jl:277-279) on the multi-launch
+    Arnoldi path (more entries than the persistent kernel takes), where newton! computes the
+    eigenvalues of the leading blocks while the later columns are still being orthogonalised:
+    the columns after the breakdown are discarded, m shrinks to the Krylov dimension for all
+    later restarts, and the result is exact.  Also with the pipeline switched off."""
+    N = 20000
+    rng = np.random.default_rng(5)
+    lam = np.array([-3.0, 0.5, 2.0, 7.5])
+    d = lam[rng.integers(0, 4, N)]
+    A = sp.diags([d], [0], format="csr", dtype=complex)      # four distinct eigenvalues: Krylov dimension 4
+    psi0 = _rand_state(N, rng)
+    L.tuning_set("newton_pipeline", pipeline)
+    try:
+        Op = L.Operator(ctx, [L.Matrix.from_scipy(ctx, A)])
+        q = L.Krylov(ctx, N, 11)
+        Hess = np.zeros((11, 11), dtype=complex, order="F")
+        m_out = L.arnoldi(Hess, q, 10, L.State(ctx, data=psi0), Op, 0.7, norm_min=1e-9)
+        assert m_out == 4 and np.all(Hess[:, 4:] == 0)
+        out, ref, wrk, owrk = _newton_case(ctx, A, psi0, 0.7, 10, norm_min=1e-9)
+        assert np.linalg.norm(out - np.exp(-0.7j * d) * psi0) < TOL
+        assert np.linalg.norm(out - ref) < TOL
+        assert wrk.restarts == owrk.restarts
+    finally:
+        L.tuning_set("newton_pipeline", 1)

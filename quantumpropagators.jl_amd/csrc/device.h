@@ -183,7 +183,8 @@ struct SmallArgs {
   int* fail = nullptr;                 // {flag, step, term}
 };
 constexpr int kSmallThreads = 512;
-constexpr int kSmallEpt = 16;
+constexpr int kSmallEpt = 16;          // register slots per lane of the persistent Chebychev kernel
+constexpr int kSmallEptArnoldi = 32;   // ... of the persistent Arnoldi kernel (fewer live values per slot)
 constexpr int64_t kSmallLdsRows = 2048;
 // arnoldi! (src/arnoldi.jl:74-100) for a register-resident operator: all m columns in one
 // single-workgroup launch, Krylov basis in LDS (and written to Q for the caller)
@@ -207,7 +208,7 @@ inline bool small_arnoldi_fits(int64_t n, int m) {
   return sizeof(double2) * ((size_t)kSmallThreads / 64 + (size_t)(m + 2) * (size_t)n) <= kSmallLdsBytes;
 }
 int launch_arnoldi_small(hipStream_t s, const SmallArnoldiArgs& a, Stats* st);
-bool small_plan(int64_t n, int64_t maxrow, SmallArgs* a);
+bool small_plan(int64_t n, int64_t maxrow, SmallArgs* a, int max_slots = kSmallEpt);
 int launch_cheby_propagate_small(hipStream_t s, const SmallArgs& a, Stats* st);
 
 int launch_gather_csr_vals(hipStream_t s, double2* out, const double2* vals, const int64_t* map, int64_t nnz,

@@ -138,10 +138,11 @@ static int arnoldi_impl(qp_operator* op, qp_krylov* q, int m, const qp_state* ps
   qp::SmallArgs plan;
   bool small = false;
   bool piped = false;
-  if (op->A.nnz <= qp::g_small_nnz && qp::small_arnoldi_fits(q->n, m)) {
+  if (qp::g_small_nnz > 0 && op->A.nnz <= (int64_t)qp::g_small_nnz * (qp::kSmallEptArnoldi / qp::kSmallEpt) &&
+      qp::small_arnoldi_fits(q->n, m)) {
     int64_t maxrow = 0;
     for (int64_t r = 0; r < q->n; ++r) maxrow = std::max<int64_t>(maxrow, op->u_rowptr[r + 1] - op->u_rowptr[r]);
-    small = qp::small_plan(q->n, maxrow, &plan);
+    small = qp::small_plan(q->n, maxrow, &plan, qp::kSmallEptArnoldi);
   }
   if (small) {
     // all m columns in one persistent single-workgroup launch (kernels.hip: arnoldi_small_kernel)

@@ -1003,6 +1003,12 @@ int launch_arnoldi_small(hipStream_t s, const SmallArnoldiArgs& a, Stats* st) {
     case 4 * 32 + 4: kern = arnoldi_small_kernel<4, 4>; break;
     case 2 * 32 + 8: kern = arnoldi_small_kernel<2, 8>; break;
     case 1 * 32 + 16: kern = arnoldi_small_kernel<1, 16>; break;
+    case 32 * 32 + 1: kern = arnoldi_small_kernel<32, 1>; break;
+    case 16 * 32 + 2: kern = arnoldi_small_kernel<16, 2>; break;
+    case 8 * 32 + 4: kern = arnoldi_small_kernel<8, 4>; break;
+    case 4 * 32 + 8: kern = arnoldi_small_kernel<4, 8>; break;
+    case 2 * 32 + 16: kern = arnoldi_small_kernel<2, 16>; break;
+    case 1 * 32 + 32: kern = arnoldi_small_kernel<1, 32>; break;
     default: return fail(QP_E_BAD_ARG, "small plan (%d entries, %d rows per group) has no kernel", a.ent, a.rows_per_group);
   }
   if (lds > 48 * 1024)
@@ -1025,16 +1031,16 @@ int g_cheby_graph = 0;     // measured (profiles/r01/propagate_loop.txt): no gai
 
 // lanes per row, entries per lane and rows per lane group such that the whole matrix is
 // register-resident; false when the system does not fit (the caller then runs the general loop)
-bool small_plan(int64_t n, int64_t maxrow, SmallArgs* a) {
+bool small_plan(int64_t n, int64_t maxrow, SmallArgs* a, int max_slots) {
   if (n < 1 || n > kSmallLdsRows) return false;
   for (int t = 1; t <= 64; t <<= 1) {
     const int64_t ngrp = kSmallThreads / t;
     const int64_t rows = (n + ngrp - 1) / ngrp;
     int64_t ent = 1;
-    while (ent * t < maxrow) ent <<= 1;   // compile-time variants: 1, 2, 4, 8, 16
+    while (ent * t < maxrow) ent <<= 1;   // compile-time variants: 1, 2, 4, 8, 16 (Arnoldi: also 32)
     int64_t rows_p2 = 1;
     while (rows_p2 < rows) rows_p2 <<= 1;
-    if (rows_p2 * ent <= kSmallEpt) {   // smallest t: fewest cross-lane reduction levels
+    if (rows_p2 * ent <= max_slots) {   // smallest t: fewest cross-lane reduction levels
       a->lanes = t;
       a->ent = (int)ent;
       a->rows_per_group = (int)rows_p2;

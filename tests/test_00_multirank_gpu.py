@@ -68,3 +68,42 @@ def test_multirank_native_driver_one_gpu(world, overlap, exchange, uneven, p2p):
 def test_multirank_newton_one_gpu(world):
     """Row-partitioned newton! (all-reduced Arnoldi inner products) with ranks sharing the GPU."""
     _run(world, QP_METHOD="newton")
+
+
+@pytest.mark.parametrize("world,driver", [(2, "native"), (3, "torch")])
+def test_bench_multirank_flow_one_gpu(world, driver):
+    """bench.py as the driver launches it for N > 1 (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from
+    the environment), in its test mode where the ranks share GPU 0 and the exchange is staged through
+    the host: partition, self-check of the native step against the torch-driven one, barrier + max
+    over ranks, one JSON line from rank 0 with the whole-job value."""
+    import json
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", QP_BENCH_ONE_GPU="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3",
+                                       "--warmup", "1", "--log2n", "14", "--driver", driver], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=240))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for p, (out, err) in zip(procs, outs):
+        assert p.returncode == 0, err[-3000:]
+    lines = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and not any(ln.startswith("{") for o, _ in outs[1:] for ln in o.splitlines())
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["value"] > 0 and abs(d["value"] - world * d["config"]["global_steps_per_s"]) < 1e-9 * d["value"]
+    assert d["config"]["N_total"] == world << 14 and d["roofline"]["frac"] > 0 and d["cpu_baseline"] is None
+    par = d["config"]["parallelism"]
+    assert f"row-partitioned x{world}" in par and "TEST MODE" in par
+    assert ("driver=native (library step" in par) if driver == "native" else ("driver=torch.distributed" in par)

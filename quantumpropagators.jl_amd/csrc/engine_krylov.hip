@@ -142,7 +142,9 @@ static int arnoldi_impl(qp_operator* op, qp_krylov* q, int m, const qp_state* ps
       qp::small_arnoldi_fits(q->n, m)) {
     int64_t maxrow = 0;
     for (int64_t r = 0; r < q->n; ++r) maxrow = std::max<int64_t>(maxrow, op->u_rowptr[r + 1] - op->u_rowptr[r]);
-    small = qp::small_plan(q->n, maxrow, &plan, qp::kSmallEptArnoldi);
+    // the plan of the 16-slot kernels where it exists (same lanes per row, hence the same rounding, as
+    // before the 32-slot variants were added), the larger one only for systems that need it
+    small = qp::small_plan(q->n, maxrow, &plan, qp::kSmallEpt) || qp::small_plan(q->n, maxrow, &plan, qp::kSmallEptArnoldi);
   }
   if (small) {
     // all m columns in one persistent single-workgroup launch (kernels.hip: arnoldi_small_kernel)

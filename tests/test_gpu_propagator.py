@@ -229,14 +229,14 @@ def test_fused_propagate_equals_stepwise(ctx, method, backward):
     kw = dict(E_min=-6.0, E_max=6.0) if method == "cheby" else dict(m_max=7)
     psi0 = rng.standard_normal(N) + 1j * rng.standard_normal(N)
     psi0 /= np.linalg.norm(psi0)
-    L.tuning_set("small_nnz", 0)                # the general loop: one launch per term
-    try:
+    L.tuning_set("small_nnz", 0)                # the general loop on both sides: one launch per term / per
+    try:                                        # Arnoldi step (the persistent kernels round differently)
         out_f, st_f = P.propagate(psi0, gen, tlist, method=method, backward=backward, storage=True, ctx=ctx,
                                   fused=True, **kw)
+        out_s, st_s = P.propagate(psi0, gen, tlist, method=method, backward=backward, storage=True, ctx=ctx,
+                                  fused=False, **kw)
     finally:
         L.tuning_set("small_nnz", 8192)
-    out_s, st_s = P.propagate(psi0, gen, tlist, method=method, backward=backward, storage=True, ctx=ctx,
-                              fused=False, **kw)
     assert np.array_equal(out_f, out_s) and np.array_equal(st_f, st_s)
     # default: small Cheby systems run the whole grid in one persistent launch
     out_p, st_p = P.propagate(psi0, gen, tlist, method=method, backward=backward, storage=True, ctx=ctx, **kw)

@@ -660,11 +660,15 @@ int qp_propagate(qp_operator* op, qp_state* psi, const qp_prop_spec* spec, const
   QP_CHECK(use(ctx));
   const int64_t n = psi->n;
   const size_t rows = (size_t)nsteps + 1;
-  if (spec->method == 0 && nsteps > 0 && op->A.nnz <= qp::g_small_nnz && op->nops <= 64) {
+  if (spec->method == 0 && nsteps > 0 && qp::g_small_nnz > 0 && op->A.nnz <= 2 * (int64_t)qp::g_small_nnz && op->nops <= 64) {
     qp::SmallArgs plan;
     int64_t maxrow = 0;
     for (int64_t r = 0; r < n; ++r) maxrow = std::max<int64_t>(maxrow, op->u_rowptr[r + 1] - op->u_rowptr[r]);
-    if (qp::small_plan(n, maxrow, &plan))
+    // 16 register slots per lane where that is enough; otherwise 32 (the upper 16 values of a lane
+    // live in LDS: 128 KB, which leaves room for vectors of up to 600 rows)
+    bool ok = op->A.nnz <= qp::g_small_nnz && qp::small_plan(n, maxrow, &plan, qp::kSmallEpt);
+    if (!ok && n <= 600) ok = qp::small_plan(n, maxrow, &plan, 2 * qp::kSmallEpt);
+    if (ok)
       return propagate_cheby_small(op, psi, spec, plan, dts, coeff_table, ncoeffs, nsteps, observables, nobs,
                                    expvals_out, states_out);
   }

@@ -699,24 +699,38 @@ __global__ __launch_bounds__(kSmallThreads) void cheby_propagate_small_kernel(Sm
 
   for (int64_t i = tid; i < n; i += kSmallThreads) A[i] = s.psi[i];
   // register-resident share of the matrix: slot e <-> (row grp + (e / E) ngrp, entry lane + (e % E) T)
+  // More than 16 slots per lane: column (12 bits), plane position + 1 (19 bits) and the conjugation
+  // flag (sign bit) share one register; the values of the slots from 16 on live in LDS, [slot][thread];
+  // evaluate! and the mat-vec go through the slots 8 at a time.
+  constexpr bool PACK = NS > 16;
+  constexpr int CHK = PACK ? 8 : NS;
+  constexpr int NR = PACK ? 16 : NS;
+  double2* vlds = vec + 3 * n;         // (NS - NR) * kSmallThreads values (the launcher sizes the allocation)
   int32_t rc[NS];
-  int32_t rm[NS];   // 0: no entry; +(m+1): plane[m]; -(m+1): conj(plane[m])
-  double2 rv[NS];
+  int32_t rm[PACK ? 1 : NS];   // 0: no entry; +(m+1): plane[m]; -(m+1): conj(plane[m])
+  double2 rv[NR];
 #pragma unroll
   for (int e = 0; e < NS; ++e) {
     rc[e] = 0;
-    rm[e] = 0;
-    rv[e] = make_double2(0.0, 0.0);
+    if (!PACK) rm[e] = 0;
+    if (e < NR) rv[e] = make_double2(0.0, 0.0);
     const int64_t r = grp + (int64_t)(e / E) * ngrp;
     if (r < n) {
       const int64_t k = s.rowptr[r] + lane + (int64_t)(e % E) * T;
       if (k < s.rowptr[r + 1]) {
-        rc[e] = s.cols[k];
-        const int64_t m = s.map[k];
-        rm[e] = (int32_t)(m >= 0 ? m + 1 : m);   // m < 0 already encodes -(pos + 1)
+        const int64_t m = s.map[k];                // m < 0 encodes -(pos + 1): conj(plane[pos])
+        if (PACK) {
+          const int64_t pos1 = m >= 0 ? m + 1 : -m;
+          rc[e] = (int32_t)((uint32_t)s.cols[k] | ((uint32_t)pos1 << 12) | (m < 0 ? 0x80000000u : 0u));
+        } else {
+          rc[e] = s.cols[k];
+          rm[e] = (int32_t)(m >= 0 ? m + 1 : m);
+        }
       }
     }
+    if (PACK && (e % CHK) == CHK - 1) __builtin_amdgcn_sched_barrier(0);
   }
+  auto col_of = [&](int e) -> int { return PACK ? (rc[e] & 0xfff) : rc[e]; };
   __syncthreads();
 
   // <psi|O|psi> for every observable and the state history, at storage row `row`
@@ -760,18 +774,34 @@ __global__ __launch_bounds__(kSmallThreads) void cheby_propagate_small_kernel(Sm
       }
       __syncthreads();
 #pragma unroll
-      for (int e = 0; e < NS; ++e) rv[e] = make_double2(0.0, 0.0);
+      for (int e = 0; e < NR; ++e) rv[e] = make_double2(0.0, 0.0);
       for (int l = 0; l < s.nops; ++l) {
         const double2* pl = s.planes[l];
         const double2 cl = coef[l];
-        double2 v[NS];
 #pragma unroll
-        for (int e = 0; e < NS; ++e)   // independent loads, all in flight together
-          v[e] = rm[e] != 0 ? pl[rm[e] > 0 ? rm[e] - 1 : -rm[e] - 1] : make_double2(0.0, 0.0);
+        for (int e0 = 0; e0 < NS; e0 += CHK) {
+          double2 v[CHK];
 #pragma unroll
-        for (int e = 0; e < NS; ++e) {
-          if (rm[e] < 0) v[e].y = -v[e].y;
-          cfma(rv[e], cl, v[e]);
+          for (int u = 0; u < CHK; ++u) {   // independent loads, all in flight together
+            const int e = e0 + u;
+            int pos1;
+            if (PACK) pos1 = (rc[e] >> 12) & 0x7ffff;
+            else pos1 = rm[e] > 0 ? rm[e] : -rm[e];
+            v[u] = pos1 != 0 ? pl[pos1 - 1] : make_double2(0.0, 0.0);
+          }
+#pragma unroll
+          for (int u = 0; u < CHK; ++u) {
+            const int e = e0 + u;
+            if (PACK ? (rc[e] < 0) : (rm[e] < 0)) v[u].y = -v[u].y;
+            if (e < NR) {
+              cfma(rv[e], cl, v[u]);
+            } else {   // own slot of this thread only: no barrier needed
+              double2 acc = (l == 0) ? make_double2(0.0, 0.0) : vlds[(size_t)(e - NR) * kSmallThreads + tid];
+              cfma(acc, cl, v[u]);
+              vlds[(size_t)(e - NR) * kSmallThreads + tid] = acc;
+            }
+          }
+          if (PACK) __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
@@ -787,7 +817,8 @@ __global__ __launch_bounds__(kSmallThreads) void cheby_propagate_small_kernel(Sm
 #pragma unroll
       for (int e = 0; e < NS; ++e) {
         {
-          cfma(sum, rv[e], x[rc[e]]);
+          cfma(sum, e < NR ? rv[e] : vlds[(size_t)(e - NR) * kSmallThreads + tid], x[col_of(e)]);
+          if (PACK && (e % CHK) == CHK - 1) __builtin_amdgcn_sched_barrier(0);   // at most CHK gathers in flight
           if ((e + 1) % E == 0) {   // the row is complete
             for (int off = T >> 1; off > 0; off >>= 1) {
               sum.x += __shfl_xor(sum.x, off);
@@ -1022,7 +1053,7 @@ int launch_arnoldi_small(hipStream_t s, const SmallArnoldiArgs& a, Stats* st) {
   return QP_OK;
 }
 
-int g_small_nnz = kSmallThreads * kSmallEpt;
+int g_small_nnz = kSmallThreads * kSmallEpt;   // x2 for systems that need the 32-slot variants
 int g_liouville_fused_n = 256;
 int g_real_vals = 1;
 int g_stencil = 1;
@@ -1054,7 +1085,9 @@ bool small_plan(int64_t n, int64_t maxrow, SmallArgs* a, int max_slots) {
 }
 
 int launch_cheby_propagate_small(hipStream_t s, const SmallArgs& a, Stats* st) {
-  const size_t lds = sizeof(double2) * (kSmallThreads / 64 + (size_t)a.nops + 3 * (size_t)a.n);
+  const int slots = a.ent * a.rows_per_group;
+  const size_t lds = sizeof(double2) * (kSmallThreads / 64 + (size_t)a.nops + 3 * (size_t)a.n +
+                                        (slots > 16 ? (size_t)(slots - 16) * kSmallThreads : 0));
   void (*kern)(SmallArgs) = nullptr;
   switch (a.ent * 32 + a.rows_per_group) {
     case 1 * 32 + 1: kern = cheby_propagate_small_kernel<1, 1>; break;
@@ -1072,6 +1105,12 @@ int launch_cheby_propagate_small(hipStream_t s, const SmallArgs& a, Stats* st) {
     case 4 * 32 + 4: kern = cheby_propagate_small_kernel<4, 4>; break;
     case 2 * 32 + 8: kern = cheby_propagate_small_kernel<2, 8>; break;
     case 1 * 32 + 16: kern = cheby_propagate_small_kernel<1, 16>; break;
+    case 32 * 32 + 1: kern = cheby_propagate_small_kernel<32, 1>; break;
+    case 16 * 32 + 2: kern = cheby_propagate_small_kernel<16, 2>; break;
+    case 8 * 32 + 4: kern = cheby_propagate_small_kernel<8, 4>; break;
+    case 4 * 32 + 8: kern = cheby_propagate_small_kernel<4, 8>; break;
+    case 2 * 32 + 16: kern = cheby_propagate_small_kernel<2, 16>; break;
+    case 1 * 32 + 32: kern = cheby_propagate_small_kernel<1, 32>; break;
     default: return fail(QP_E_BAD_ARG, "small plan (%d entries, %d rows per group) has no kernel", a.ent, a.rows_per_group);
   }
   if (lds > 48 * 1024)

@@ -259,7 +259,7 @@ def test_fused_propagate_equals_stepwise(ctx, method, backward):
 
 
 @pytest.mark.parametrize("N,dense,ncontrols", [(2, True, 1), (3, True, 0), (55, False, 0), (64, True, 2),
-                                               (130, True, 1), (700, False, 2), (2048, False, 1), (3000, False, 1)])
+                                               (100, True, 1), (128, True, 2), (130, True, 1), (700, False, 2), (2048, False, 1), (3000, False, 1)])
 def test_persistent_small_cheby(ctx, N, dense, ncontrols):
     """The single-launch time grid for small systems (register-resident rows, LDS vectors,
     streaming rows, vectors in global memory -- one case each) against the oracle, the

@@ -252,6 +252,9 @@ extern int g_arnoldi_mode;  // 0 = sequential fused MGS passes, 1 = low-synchron
 // w *= 1/sqrt(sum part_in.x);  hess_slot = dt * norm
 int launch_norm_scale(hipStream_t s, double2* w, const double2* part_in, double2* hess_slot, double dt,
                       int64_t n, Stats* st);
+bool launch_combine2_vecs(hipStream_t s, double2* out1, int use_out1, int m1, const double2* coefs1, double2* out2, int m2,
+                          const double2* coefs2, const double2* Q, int64_t ldq, double2* norm_partials, int64_t n,
+                          Stats* st);
 // out = (use_out ? s0*out : 0) + sum_{i<m} coef[i] * Q[i*ldq + k];  optional |out|^2 partials
 int launch_combine_vecs(hipStream_t s, double2* out, int use_out, double2 s0, const double2* Q, int64_t ldq,
                         int m, const double2* coefs /* host */, double2* norm_partials, int64_t n, Stats* st);

@@ -513,11 +513,7 @@ int qp_newton_step(qp_newton* w, qp_operator* op, qp_state* psi, double dt, int 
     }
     ms_poly += ms_since(t0);
     t0 = now();
-    // Psi = (s == 0 ? 0 : Psi) + sum_i P_i q_i                                      :346-352
-    QP_CHECK(qp::launch_combine_vecs(ctx->stream, psi->d, s == 0 ? 0 : 1, make_double2(1.0, 0.0), w->q->q(0), w->n, m,
-                                     reinterpret_cast<const double2*>(P.data()), w->npart, w->n, &ctx->stats));
-    QP_HIP(hipMemcpyAsync(w->h_npart, w->npart, kRedBlocks * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
-    // starting vector of the next restart                                            :356-367
+    // starting vector of the next restart (host part)                                :356-367
     apply(w->leja[n_s + m - 1]);
     double b2 = 0;
     for (int i = 0; i < mp; ++i) {
@@ -526,9 +522,17 @@ int qp_newton_step(qp_newton* w, qp_operator* op, qp_state* psi, double dt, int 
     }
     beta = std::sqrt(b2);
     for (int i = 0; i < mp; ++i) R[i] *= (1.0 / beta);
-    // v = sum_{i=0..m} R_i q_i   (q_0 is the start vector of this sweep)
-    QP_CHECK(qp::launch_combine_vecs(ctx->stream, w->v, 0, make_double2(1.0, 0.0), w->q->q(0), w->n, m + 1,
-                                     reinterpret_cast<const double2*>(R.data()), nullptr, w->n, &ctx->stats));
+    // Psi = (s == 0 ? 0 : Psi) + sum_{i<m} P_i q_i  (:346-352)  and  v = sum_{i<=m} R_i q_i  (q_0 is the
+    // start vector of this sweep): one pass over the basis; fixed-size coefficient blocks, else one by one
+    if (!qp::launch_combine2_vecs(ctx->stream, psi->d, s == 0 ? 0 : 1, m, reinterpret_cast<const double2*>(P.data()), w->v,
+                                  m + 1, reinterpret_cast<const double2*>(R.data()), w->q->q(0), w->n, w->npart, w->n,
+                                  &ctx->stats)) {
+      QP_CHECK(qp::launch_combine_vecs(ctx->stream, psi->d, s == 0 ? 0 : 1, make_double2(1.0, 0.0), w->q->q(0), w->n, m,
+                                       reinterpret_cast<const double2*>(P.data()), w->npart, w->n, &ctx->stats));
+      QP_CHECK(qp::launch_combine_vecs(ctx->stream, w->v, 0, make_double2(1.0, 0.0), w->q->q(0), w->n, m + 1,
+                                       reinterpret_cast<const double2*>(R.data()), nullptr, w->n, &ctx->stats));
+    }
+    QP_HIP(hipMemcpyAsync(w->h_npart, w->npart, kRedBlocks * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
     QP_HIP(hipStreamSynchronize(ctx->stream));
     norm_psi = std::sqrt(sum_partials(w->h_npart).real());
     ms_update += ms_since(t0);

@@ -1468,6 +1468,83 @@ __global__ __launch_bounds__(kThreads) void combine_vecs_kernel(double2* __restr
   }
 }
 
+// Two combinations of the same basis in one pass over Q (newton!: Psi += sum_i P_i q_i and the next
+// restart vector v = sum_i R_i q_i, src/newton.jl:346-367): out1 = (use_out1 ? out1 : 0) + sum_{k<m1}
+// c1_k q_k with |out1|^2 partials, out2 = sum_{k<m2} c2_k q_k; each output sees its terms in the
+// order of the single-output kernel.  Two elements per lane and four basis vectors per round in flight.
+__global__ __launch_bounds__(kThreads) void combine2_vecs_kernel(double2* __restrict__ out1, int use_out1, int m1,
+                                                                 CoefBlock c1, double2* __restrict__ out2, int m2,
+                                                                 CoefBlock c2, const double2* __restrict__ Q, int64_t ldq,
+                                                                 double2* __restrict__ norm_partials, int64_t n) {
+  __shared__ double2 lds[kThreads / 64];
+  double nrm = 0.0;
+  const int mm = m1 > m2 ? m1 : m2;
+  const int64_t stride = (int64_t)kRedBlocks * kThreads;
+  const double2 zero = make_double2(0.0, 0.0);
+  for (int64_t e0 = (int64_t)blockIdx.x * kThreads + threadIdx.x; e0 < n; e0 += 2 * stride) {
+    const int64_t e1 = e0 + stride;
+    const bool two = e1 < n;
+    double2 a0 = use_out1 ? out1[e0] : zero, a1 = (use_out1 && two) ? out1[e1] : zero;
+    double2 b0 = zero, b1 = zero;
+    int k = 0;
+    for (; k + 3 < mm; k += 4) {
+      double2 q0[4], q1[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        q0[t] = Q[(size_t)(k + t) * ldq + e0];
+        q1[t] = two ? Q[(size_t)(k + t) * ldq + e1] : zero;
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (k + t < m1) {
+          cfma(a0, c1.c[k + t], q0[t]);
+          cfma(a1, c1.c[k + t], q1[t]);
+        }
+        if (k + t < m2) {
+          cfma(b0, c2.c[k + t], q0[t]);
+          cfma(b1, c2.c[k + t], q1[t]);
+        }
+      }
+    }
+    for (; k < mm; ++k) {
+      const double2 q0 = Q[(size_t)k * ldq + e0];
+      const double2 q1 = two ? Q[(size_t)k * ldq + e1] : zero;
+      if (k < m1) {
+        cfma(a0, c1.c[k], q0);
+        cfma(a1, c1.c[k], q1);
+      }
+      if (k < m2) {
+        cfma(b0, c2.c[k], q0);
+        cfma(b1, c2.c[k], q1);
+      }
+    }
+    out1[e0] = a0;
+    out2[e0] = b0;
+    nrm += a0.x * a0.x + a0.y * a0.y;
+    if (two) {
+      out1[e1] = a1;
+      out2[e1] = b1;
+      nrm += a1.x * a1.x + a1.y * a1.y;
+    }
+  }
+  const double2 t = block_sum(make_double2(nrm, 0.0), lds);
+  if (threadIdx.x == 0) norm_partials[blockIdx.x] = t;
+}
+
+// false when one of the coefficient lists does not fit one launch (the caller then combines one by one)
+bool launch_combine2_vecs(hipStream_t s, double2* out1, int use_out1, int m1, const double2* coefs1, double2* out2, int m2,
+                          const double2* coefs2, const double2* Q, int64_t ldq, double2* norm_partials, int64_t n,
+                          Stats* st) {
+  if (m1 > kCoefBlock || m2 > kCoefBlock || m1 < 1 || m2 < 1) return false;
+  CoefBlock c1, c2;
+  for (int l = 0; l < m1; ++l) c1.c[l] = coefs1[l];
+  for (int l = 0; l < m2; ++l) c2.c[l] = coefs2[l];
+  hipLaunchKernelGGL(combine2_vecs_kernel, dim3(kRedBlocks), dim3(kThreads), 0, s, out1, use_out1, m1, c1, out2, m2, c2, Q, ldq,
+                     norm_partials, n);
+  if (st) st->n_launch++;
+  return hipGetLastError() == hipSuccess;
+}
+
 int launch_combine_vecs(hipStream_t s, double2* out, int use_out, double2 s0, const double2* Q, int64_t ldq,
                         int m, const double2* coefs, double2* norm_partials, int64_t n, Stats* st) {
   for (int first = 0; first < m || first == 0; first += kCoefBlock) {

@@ -154,6 +154,7 @@ struct qp_newton {
   double2* h_npart = nullptr;
   std::vector<cplx> a, leja;
   std::vector<cplx> Hess, R, P, Rn, ritz;   // host work arrays of a step, kept between calls
+  std::vector<double> leja_prod;            // head of each Leja candidate's product chain (built while the columns arrive)
   double radius = 0;
   int n_a = 0, n_leja = 0, restarts = 0;
 };

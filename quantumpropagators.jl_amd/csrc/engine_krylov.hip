@@ -445,20 +445,33 @@ int qp_newton_step(qp_newton* w, qp_operator* op, qp_state* psi, double dt, int 
     // Ritz values of every leading block (:297), block j+1 as soon as column j has arrived -- on
     // the multi-launch path while the device is still orthogonalising the later columns
     ritz.assign((size_t)m_req * (m_req + 1) / 2, cplx(0));
-    double ms_eig_sweep = 0;
+    // ... and, from the second restart on, the head of every candidate's Leja product chain (the
+    // factors of the Leja points of the earlier restarts, src/newton.jl:127-136) -- valid as long
+    // as the sweep does not break down (the exponent depends on m)
+    std::vector<double>& lprod = w->leja_prod;
+    lprod.assign(ritz.size(), 1.0);
+    const double lexp = 1.0 / (double)(n_leja + m_req);
+    double ms_eig_sweep = 0, ms_fold_sweep = 0;
     int blocks_done = 0;
     const ColumnHook eig_block = [&](int j) -> int {
       auto t1 = now();
-      const int st = qp::diagonalize_hessenberg_block(Hess.data(), ldh, j + 1, ritz.data() + (size_t)j * (j + 1) / 2);
+      const size_t off = (size_t)j * (j + 1) / 2;
+      const int st = qp::diagonalize_hessenberg_block(Hess.data(), ldh, j + 1, ritz.data() + off);
       ms_eig_sweep += ms_since(t1);
+      if (st == QP_OK && n_leja > 0) {
+        t1 = now();
+        for (int i = 0; i <= j; ++i) lprod[off + i] = qp::leja_fold_candidate(w->leja.data(), n_leja, ritz[off + i], lexp);
+        ms_fold_sweep += ms_since(t1);
+      }
       blocks_done = j + 1;
       return st == QP_OK ? QP_OK : qp::fail(QP_E_INTERNAL, "Hessenberg QR did not converge");
     };
     QP_CHECK(arnoldi_impl(op, w->q, m_req, s == 0 ? psi : &vstate, dt, 1, norm_min,
                           reinterpret_cast<qp_c128*>(Hess.data()), ldh, &m, s == 0 ? &beta : nullptr,
                           qp::g_newton_pipeline ? &eig_block : nullptr));
-    ms_arnoldi += ms_since(t0) - ms_eig_sweep;
+    ms_arnoldi += ms_since(t0) - ms_eig_sweep - ms_fold_sweep;
     ms_eig += ms_eig_sweep;
+    ms_leja += ms_fold_sweep;
     n_matvec += m_req;
     if (m == 1 && s == 0) {                                                          // :289-295
       const cplx lam = beta * Hess[0];
@@ -470,6 +483,7 @@ int qp_newton_step(qp_newton* w, qp_operator* op, qp_state* psi, double dt, int 
     for (int j = blocks_done; j < m; ++j)   // persistent-kernel sweep, or the pipeline switched off
       QP_CHECK(eig_block(j));
     ritz.resize((size_t)m * (m + 1) / 2);
+    const bool folded = (m == m_req) && n_leja > 0;   // same exponent as assumed above
     ms_eig += ms_since(t0);
     if (s == 0) {                                                                    // :301-303, :67-70
       double rmax = 0;
@@ -479,7 +493,7 @@ int qp_newton_step(qp_newton* w, qp_operator* op, qp_state* psi, double dt, int 
     const int n_s = n_leja;                                                          // :307
     if ((int)w->leja.size() < n_leja + m) w->leja.resize((size_t)2 * (n_leja + m), cplx(0));  // :105-110
     t0 = now();
-    qp::extend_leja(w->leja.data(), n_leja, ritz.data(), (int)ritz.size(), m);
+    qp::extend_leja(w->leja.data(), n_leja, ritz.data(), (int)ritz.size(), m, folded ? lprod.data() : nullptr);
     ms_leja += ms_since(t0);
     n_leja += m;
     if ((int)w->a.size() < n_leja) w->a.resize((size_t)2 * n_leja, cplx(0));         // :187-192

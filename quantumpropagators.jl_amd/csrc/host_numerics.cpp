@@ -164,7 +164,16 @@ int diagonalize_hessenberg(const cplx* Hess, int ldh, int m, bool accumulate, cp
 // ---------------------------------------------------------------------------
 // extend_leja! -- src/newton.jl:97-148 (zero-based; `leja` must hold n + n_use)
 // ---------------------------------------------------------------------------
-void extend_leja(cplx* leja, int n, cplx* newpoints, int n_new, int n_use) {
+// prod_folded (optional, n > 0): prod_folded[i] = prod_{j<n} |newpoints[i] - leja[j]|^(1/(n+n_use)), multiplied
+// left to right from 1.0 -- the head of each candidate's product chain, which a caller may have built
+// while the candidates were arriving (leja_fold_candidate); the selection is unchanged bit for bit.
+double leja_fold_candidate(const cplx* leja, int n, cplx z, double exponent) {
+  double p = 1.0;
+  for (int j = 0; j < n; ++j) p = p * std::pow(std::abs(z - leja[j]), exponent);
+  return p;
+}
+
+void extend_leja(cplx* leja, int n, cplx* newpoints, int n_new, int n_use, const double* prod_folded) {
   int u = n_new - 1;
   int i_add_start = 0;
   if (n == 0) {
@@ -187,6 +196,10 @@ void extend_leja(cplx* leja, int n, cplx* newpoints, int n_new, int n_use) {
   // the selection is bit-for-bit the reference's at O(m^2 (n + m)) cost.
   std::vector<double> prod((size_t)std::max(n_new, 1), 1.0);
   int n_done = 0;  // number of Leja points already folded into prod[]
+  if (prod_folded && n > 0) {
+    std::copy(prod_folded, prod_folded + n_new, prod.begin());
+    n_done = n;
+  }
   for (int i_add = i_add_start; i_add < n_use; ++i_add) {
     const int n_have = n + i_add;
     for (int i = 0; i <= u - i_add; ++i) {
@@ -327,8 +340,15 @@ int qp_extend_leja(qp_c128* leja, int n, qp_c128* newpoints, int n_newpoints, in
   QP_TRY
   if (!leja || !newpoints || n < 0 || n_use < 1 || n_newpoints < n_use)
     return qp::fail(QP_E_BAD_ARG, "qp_extend_leja: bad args");
+  // through the pre-folded form that newton! uses (the head of every candidate's product chain built
+  // first, as the restart loop does while the Hessenberg columns arrive): same chain, same selection
+  const cplx* lj = reinterpret_cast<const cplx*>(leja);
+  const cplx* np_ = reinterpret_cast<const cplx*>(newpoints);
+  std::vector<double> head((size_t)n_newpoints, 1.0);
+  if (n > 0)
+    for (int i = 0; i < n_newpoints; ++i) head[i] = qp::leja_fold_candidate(lj, n, np_[i], 1.0 / (double)(n + n_use));
   qp::extend_leja(reinterpret_cast<cplx*>(leja), n, reinterpret_cast<cplx*>(newpoints), n_newpoints,
-                  n_use);
+                  n_use, n > 0 ? head.data() : nullptr);
   return QP_OK;
   QP_CATCH
 }

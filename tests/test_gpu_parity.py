@@ -1056,3 +1056,48 @@ def test_newton_breakdown_multilaunch_path(ctx, pipeline):
         assert wrk.restarts == owrk.restarts
     finally:
         L.tuning_set("newton_pipeline", 1)
+
+
+def test_independent_handles_from_concurrent_threads():
+    """SURVEY 8b threading contract: callers step many independent propagators from their own
+    threads; every context owns its stream, there is no shared mutable state, so qp_* calls on
+    different handles may run concurrently (ctypes releases the GIL) and each thread reproduces
+    the single-threaded result bit for bit."""
+    import threading
+    N = 6000
+    rp, col, vals = synth.hermitian_offsets_csr(N, offsets=(1, 2, 3, 17, 64, 200, 511, 900))
+    Lm = synth.liouvillian_tridiag(20)
+    nthreads = 4
+
+    def work(seed, out, k):
+        try:
+            c = L.Context(0)
+            op = L.Operator(c, [L.Matrix(c, N, N, rp, col, vals)])
+            psi = L.State(c, data=synth.random_state(N, seed=seed))
+            wrk = L.ChebyWrk(c, N, 20.0, -10.0, 0.7)
+            for _ in range(25):
+                L.cheby(psi, op, 0.7, wrk)
+            lop = L.Operator(c, [L.Matrix.from_scipy(c, Lm)])
+            rho = L.State(c, data=synth.random_state(Lm.shape[0], seed=seed + 100))
+            nw = L.NewtonWrk(c, Lm.shape[0], m_max=12)
+            for _ in range(4):
+                L.newton(rho, lop, 0.4, nw)
+            out[k] = (psi.numpy(), rho.numpy())
+            c.close()
+        except Exception as e:  # noqa: BLE001
+            out[k] = e
+
+    serial = [None] * nthreads
+    for k in range(nthreads):
+        work(1000 + k, serial, k)
+    threaded = [None] * nthreads
+    ts = [threading.Thread(target=work, args=(1000 + k, threaded, k)) for k in range(nthreads)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for k in range(nthreads):
+        assert not isinstance(serial[k], Exception), serial[k]
+        assert not isinstance(threaded[k], Exception), threaded[k]
+        assert np.array_equal(serial[k][0], threaded[k][0]) and np.array_equal(serial[k][1], threaded[k][1])
+        assert abs(np.linalg.norm(serial[k][0]) - 1.0) < 1e-12

@@ -248,6 +248,10 @@ int launch_mgs_multidot(hipStream_t s, const double2* Q, int64_t ldq, int j, con
 int launch_mgs_project(hipStream_t s, const double2* Q, int64_t ldq, int j, double2* w, const double2* reduced,
                        double2* G, int ldg, double2* hess_col, double2* coef, double2* norm_partials, double dt,
                        int64_t n, Stats* st);
+// the solve keeps the packed Gram triangle of columns 0..j in LDS (3 (j+1) + j (j+1)/2 complex numbers):
+// up to j = 87 within the 64 KB a launch gets without opting in to more; longer bases continue with
+// the sequential passes
+inline bool mgs_lowsync_fits(int j) { return sizeof(double2) * (size_t)(3 * (j + 1) + j * (j + 1) / 2) <= 64 * 1024; }
 extern int g_arnoldi_mode;  // 0 = sequential fused MGS passes, 1 = low-synchronisation MGS
 // w *= 1/sqrt(sum part_in.x);  hess_slot = dt * norm
 int launch_norm_scale(hipStream_t s, double2* w, const double2* part_in, double2* hess_slot, double dt,

@@ -83,7 +83,7 @@ int arnoldi_column(qp_operator* op, qp_krylov* q, int j, double dt, double2* hco
   pe.beta = make_double2(0.0, 0.0);
   pe.beta_zero = 1;
   QP_CHECK(qp::launch_spmv_plain(ctx->stream, op->A, q->q(j), pe, &ctx->stats));  // src/arnoldi.jl:82
-  if (qp::g_arnoldi_mode == 1 && q->gram_rows >= j) {
+  if (qp::g_arnoldi_mode == 1 && q->gram_rows >= j && qp::mgs_lowsync_fits(j)) {
     // low-synchronisation MGS: same coefficients (to rounding), 3 launches per column;
     // leaves |q[j+1]|^2 partials in part[(j+1)&1] like the sequential path.  Needs the Gram
     // rows of the earlier basis vectors, which only this path maintains (a basis built by

@@ -1866,6 +1866,7 @@ static int launch_mgs_update(hipStream_t s, const double2* Q, int64_t ldq, int j
 int launch_mgs_project(hipStream_t s, const double2* Q, int64_t ldq, int j, double2* w, const double2* reduced,
                        double2* G, int ldg, double2* hess_col, double2* coef, double2* norm_partials, double dt,
                        int64_t n, Stats* st) {
+  if (!mgs_lowsync_fits(j)) return fail(QP_E_BAD_ARG, "Krylov basis of %d vectors is too long for the low-synchronisation projection", j + 1);
   hipLaunchKernelGGL(mgs_solve_kernel, dim3(1), dim3(kThreads), mgs_solve_lds(j), s, j, reduced, G, ldg, hess_col, coef, dt);
   QP_HIP(hipGetLastError());
   if (st) st->n_launch++;

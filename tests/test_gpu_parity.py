@@ -1101,3 +1101,18 @@ def test_independent_handles_from_concurrent_threads():
         assert not isinstance(threaded[k], Exception), threaded[k]
         assert np.array_equal(serial[k][0], threaded[k][0]) and np.array_equal(serial[k][1], threaded[k][1])
         assert abs(np.linalg.norm(serial[k][0]) - 1.0) < 1e-12
+
+
+def test_newton_long_krylov_basis(ctx):
+    """m_max = 120: beyond the Krylov length whose Gram triangle the low-synchronisation solve keeps
+    in LDS (j <= 87), the later columns continue with the sequential Gram-Schmidt passes -- same
+    result, one restart."""
+    rng = np.random.default_rng(77)
+    N = 1500
+    H = synth.sparse_random(N, 24.0 / N, rho=6.0, hermitian=True, rng=rng)     # > 16384 entries: multi-launch path
+    psi0 = _rand_state(N, rng)
+    out, ref, wrk, owrk = _newton_case(ctx, H, psi0, 2.0, 120)
+    import scipy.sparse.linalg as spla
+    exact = spla.expm_multiply(-2.0j * sp.csc_matrix(H), psi0)
+    assert np.linalg.norm(out - exact) < TOL and np.linalg.norm(out - ref) < TOL
+    assert wrk.restarts == owrk.restarts

@@ -1116,3 +1116,35 @@ def test_newton_long_krylov_basis(ctx):
     exact = spla.expm_multiply(-2.0j * sp.csc_matrix(H), psi0)
     assert np.linalg.norm(out - exact) < TOL and np.linalg.norm(out - ref) < TOL
     assert wrk.restarts == owrk.restarts
+
+
+@pytest.mark.parametrize("tile", [16, 32, 64])
+def test_cheby_batched_streaming_variants_bit_identical(ctx, tile):
+    """Knobs of the batched kernel: the nontemporal variant (picked automatically for panels larger
+    than the caches, forced here on a small one) and the states-per-pass tile change the memory
+    access pattern only -- every (row, state) element sees the same FMA sequence."""
+    N, batch = 1500, 40
+    rp, col, vals = synth.hermitian_offsets_csr(N, offsets=(1, 2, 3, 4, 16, 32, 48, 300))
+    Op = L.Operator(ctx, [L.Matrix(ctx, N, N, rp, col, vals)])
+    states = np.stack([synth.random_state(N, seed=2000 + s) for s in range(batch)], axis=1)
+    outs = {}
+    try:
+        for nt in (0, 2):
+            L.tuning_set("spmm_nt", nt)
+            L.tuning_set("spmm_tile", tile)
+            wrk = L.ChebyWrk(ctx, N * batch, 20.0, -10.0, 0.9)
+            panel = L.State(ctx, data=states.reshape(-1))
+            for dt in (0.9, -0.9, 0.9):
+                L.cheby_batched(panel, Op, dt, wrk, batch)
+            outs[nt] = panel.numpy()
+    finally:
+        L.tuning_set("spmm_nt", 1)
+        L.tuning_set("spmm_tile", 16)
+    assert np.array_equal(outs[0], outs[2])
+    L.tuning_set("spmm_tile", 16)
+    wrk = L.ChebyWrk(ctx, N * batch, 20.0, -10.0, 0.9)
+    panel = L.State(ctx, data=states.reshape(-1))
+    for dt in (0.9, -0.9, 0.9):
+        L.cheby_batched(panel, Op, dt, wrk, batch)
+    assert np.array_equal(panel.numpy(), outs[0])            # the tile does not change any value either
+    assert np.max(np.abs(np.linalg.norm(outs[0].reshape(N, batch), axis=0) - 1.0)) < 1e-12

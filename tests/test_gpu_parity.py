@@ -1148,3 +1148,30 @@ def test_cheby_batched_streaming_variants_bit_identical(ctx, tile):
         L.cheby_batched(panel, Op, dt, wrk, batch)
     assert np.array_equal(panel.numpy(), outs[0])            # the tile does not change any value either
     assert np.max(np.abs(np.linalg.norm(outs[0].reshape(N, batch), axis=0) - 1.0)) < 1e-12
+
+
+@pytest.mark.parametrize("N", [100, 128])
+def test_newton_dense_128_persistent_arnoldi(ctx, N):
+    """Config C1's size through newton!: 10000 / 16384 stored entries run the Arnoldi sweeps in the
+    32-slot variants of the persistent single-workgroup kernel; same result as the multi-launch path
+    (to rounding) and as the oracle."""
+    rng = np.random.default_rng(N)
+    H = synth.dense_hermitian(N, rho=5.0, rng=rng)
+    psi0 = _rand_state(N, rng)
+    out, ref, wrk, owrk = _newton_case(ctx, H, psi0, 0.3, 10)
+    assert np.linalg.norm(out - ref) < TOL and wrk.restarts == owrk.restarts
+    ev, V = np.linalg.eigh(H)
+    assert np.linalg.norm(out - V @ (np.exp(-0.3j * ev) * (V.conj().T @ psi0))) < TOL
+    st0 = ctx.stats()["n_kernel_launches"]
+    L.newton(L.State(ctx, data=psi0), L.Operator(ctx, [L.Matrix.from_dense(ctx, H)]), 0.3, L.NewtonWrk(ctx, N, m_max=10))
+    small_launches = ctx.stats()["n_kernel_launches"] - st0
+    L.tuning_set("small_nnz", 0)
+    try:
+        out_g, _, _, _ = _newton_case(ctx, H, psi0, 0.3, 10)
+        st1 = ctx.stats()["n_kernel_launches"]
+        L.newton(L.State(ctx, data=psi0), L.Operator(ctx, [L.Matrix.from_dense(ctx, H)]), 0.3, L.NewtonWrk(ctx, N, m_max=10))
+        general_launches = ctx.stats()["n_kernel_launches"] - st1
+    finally:
+        L.tuning_set("small_nnz", 8192)
+    assert np.linalg.norm(out - out_g) < 1e-12
+    assert small_launches * 3 < general_launches          # one launch per sweep instead of ~5 per column

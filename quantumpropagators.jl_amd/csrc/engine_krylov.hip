@@ -114,6 +114,12 @@ int arnoldi_column(qp_operator* op, qp_krylov* q, int j, double dt, double2* hco
 __global__ void norm_guard_scale_kernel(double2* __restrict__ w, const double2* __restrict__ part_in, double2* hess_slot,
                                         double* norm_slot, double dt, double norm_min, int64_t n);
 
+// workgroups of norm_guard_scale_kernel: every one re-reduces the 256 partials, so no more of them than
+// two elements per lane need (the partial order, hence the norm, does not depend on the grid)
+static inline int guard_grid(int64_t n) {
+  return (int)std::max<int64_t>(64, std::min<int64_t>(2048, (n + 2 * qp::kThreads - 1) / (2 * qp::kThreads)));
+}
+
 // arnoldi! with an optional normalisation of the start vector: beta_out != NULL means `psi` is
 // not normalised; q_0 = psi / |psi| and *beta_out = |psi| (newton! :268-272 folded in, so that
 // the persistent small-system kernel does it in the same launch).
@@ -195,7 +201,7 @@ static int arnoldi_impl(qp_operator* op, qp_krylov* q, int m, const qp_state* ps
       double2* hcol = q->hess_map + (size_t)j * ldd;
       QP_CHECK(arnoldi_column(op, q, j, dt, hcol));
       if ((j + 1 < m) || extended) {                                                               // :88-97
-        hipLaunchKernelGGL(norm_guard_scale_kernel, dim3(2048), dim3(qp::kThreads), 0, ctx->stream, q->q(j + 1),
+        hipLaunchKernelGGL(norm_guard_scale_kernel, dim3(guard_grid(q->n)), dim3(qp::kThreads), 0, ctx->stream, q->q(j + 1),
                            q->part + (size_t)((j + 1) & 1) * kRedBlocks, hcol + (j + 1), q->norms_map + j, dt, norm_min,
                            q->n);
         QP_HIP(hipGetLastError());
@@ -307,7 +313,7 @@ int qp_krylov_normalize(qp_krylov* q, int j, double dt, double norm_min, const q
   if (!q || !norm_partials || !hess_norm || j < 0 || j + 1 >= q->nvec || norm_partials->n < kRedBlocks || hess_norm->n < 2)
     return qp::fail(QP_E_BAD_ARG, "qp_krylov_normalize: bad arguments");
   QP_CHECK(use(q->ctx));
-  hipLaunchKernelGGL(norm_guard_scale_kernel, dim3(2048), dim3(qp::kThreads), 0, q->ctx->stream, q->q(j + 1),
+  hipLaunchKernelGGL(norm_guard_scale_kernel, dim3(guard_grid(q->n)), dim3(qp::kThreads), 0, q->ctx->stream, q->q(j + 1),
                      norm_partials->d, hess_norm->d, reinterpret_cast<double*>(hess_norm->d + 1), dt, norm_min, q->n);
   QP_HIP(hipGetLastError());
   q->ctx->stats.n_launch++;

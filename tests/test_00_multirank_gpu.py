@@ -107,3 +107,15 @@ def test_bench_multirank_flow_one_gpu(world, driver):
     par = d["config"]["parallelism"]
     assert f"row-partitioned x{world}" in par and "TEST MODE" in par
     assert ("driver=native (library step" in par) if driver == "native" else ("driver=torch.distributed" in par)
+
+
+def test_c_consumer_runs(tmp_path):
+    """examples/c_abi_demo.c -- a plain-C program on the C ABI, no Python / torch in the process: its own
+    checks (norm, Newton == Cheby, forward + backward = identity, the reference's dt assertion) pass."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_c_consumer import _build
+    exe = _build(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=180)
+    sys.stdout.write(r.stdout)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "C ABI demo ok" in r.stdout and "QP_E_DT_MISMATCH" in r.stdout

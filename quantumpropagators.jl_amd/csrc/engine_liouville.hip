@@ -96,7 +96,7 @@ __global__ __launch_bounds__(qp::kThreads) void liouville_combine_kernel(double2
 
 // ---------------------------------------------------------------------------
 // Hand-written fp64 matrix-core kernel for the sizes where a chain of library GEMMs is bound
-// by its launches (n <= 512):  Y = beta Y + sum_j alpha_j P_j op_j(Q_j)  in ONE launch, all
+// by its launches (default: n <= 320):  Y = beta Y + sum_j alpha_j P_j op_j(Q_j)  in ONE launch, all
 // matrices n x n, column-major.  v_mfma_f64_16x16x4_f64: lane l holds A[l & 15][l >> 4] and
 // B[l >> 4][l & 15]; D register r of lane l is D[(l >> 4) + 4 r][l & 15].  A complex
 // product is four real ones (Re += ar br - ai bi, Im += ar bi + ai br).

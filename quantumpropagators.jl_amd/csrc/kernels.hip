@@ -1054,7 +1054,7 @@ int launch_arnoldi_small(hipStream_t s, const SmallArnoldiArgs& a, Stats* st) {
 }
 
 int g_small_nnz = kSmallThreads * kSmallEpt;   // x2 for systems that need the 32-slot variants
-int g_liouville_fused_n = 256;
+int g_liouville_fused_n = 320;
 int g_real_vals = 1;
 int g_stencil = 1;
 int g_acc_defer = 1;

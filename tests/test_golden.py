@@ -233,7 +233,7 @@ def test_gpu_f7_liouvillian(ctx, convention):
             Lmf.mul(x, y)
             assert np.linalg.norm(y.numpy() - want) < 1e-12
         finally:
-            L.tuning_set("liouville_fused_n", 256)
+            L.tuning_set("liouville_fused_n", 320)
     Op = L.Operator(ctx, [L.Matrix.from_scipy(ctx, sp.csr_matrix(Lsp))])
     y = L.State(ctx, n=len(vec))
     Op.mul(x, y)

@@ -852,7 +852,7 @@ def liouville_path(request):
     matrix-core kernel (n <= 256 by default) and the chain of rocBLAS zgemm calls."""
     L.tuning_set("liouville_fused_n", request.param)
     yield request.param
-    L.tuning_set("liouville_fused_n", 256)
+    L.tuning_set("liouville_fused_n", 320)
 
 
 @pytest.mark.parametrize("convention", ["TDSE", "LvN"])

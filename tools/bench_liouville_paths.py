@@ -23,4 +23,4 @@ for n, nc in ((192, 1), (256, 1), (320, 1), (384, 1), (512, 1), (512, 2), (640, 
     fl = 8.0 * n ** 3 * (2 + 2 * nc)
     print(f"n={n:5d} c_ops={nc}: " + "  ".join(f"{k} {v:8.1f} us ({fl / v / 1e6:5.1f} TF)" for k, v in res.items()), flush=True)
     Lmf.close()
-L.tuning_set("liouville_fused_n", 256)
+L.tuning_set("liouville_fused_n", 320)

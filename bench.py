@@ -41,6 +41,8 @@ def main():
                     "(SURVEY 8d also asks for alpha = 2 and 50: --dt 0.2 / --dt 5)")
     ap.add_argument("--real", action="store_true", help="real-symmetric H (the f64 variant of SURVEY 8d): values "
                     "are streamed as fp64; algorithmic bytes (12 z + 84) N")
+    ap.add_argument("--schedule", default="auto", choices=["auto", "overlap", "serial"],
+                    help="N > 1: boundary/interior overlap of the exchange, the exchange in line, or whichever a short trial finds faster")
     ap.add_argument("--driver", default="native", choices=["native", "torch"],
                     help="multi-GPU step: one library call with its own RCCL communicator, or the Python loop")
     ap.add_argument("--cpu-steps", type=int, default=16,
@@ -150,34 +152,72 @@ def main():
         # driven from Python with torch.distributed collectives.  The native path is used only
         # if, on every rank, one step of it reproduces the torch-driven step bit for bit.
         want_native = args.driver == "native"     # (test mode: callback communicator, host-staged)
-        sh = sharded.ShardedCheby(ctx, rp, col, vals, N, r0, r1, Delta, E_min, dt, fmt=fmt,
-                                  exchange=args.exchange, host_staged=one_gpu, native=want_native)
+
+        def build(overlap):
+            """One schedule of the partitioned step, ready to run: (stepper, native?, note)."""
+            sh_ = sharded.ShardedCheby(ctx, rp, col, vals, N, r0, r1, Delta, E_min, dt, fmt=fmt, exchange=args.exchange,
+                                       host_staged=one_gpu, native=want_native, overlap=overlap)
+            nat = sh_.native is not None
+            if nat:
+                sh_.set_state(psi0_local)
+                sh_.step(native=True)
+                torch.cuda.synchronize()
+                got = sh_.local_state()
+                sh_.set_state(psi0_local)
+                sh_.step(native=False)
+                torch.cuda.synchronize()
+                same = torch.tensor([1 if np.array_equal(got, sh_.local_state()) else 0], device="cpu" if one_gpu else "cuda")
+                dist.all_reduce(same, op=dist.ReduceOp.MIN)
+                nat = bool(same.item())
+                how = ("exchange handed back through a callback communicator" if one_gpu else
+                       "RCCL communicator of the library, " + ("ncclSend/ncclRecv with the neighbours" if sh_.p2p else "ncclAllGather"))
+                note = f"native (library step, {how})" if nat else \
+                    "torch.distributed (native step disagreed with it in the self-check)"
+            else:
+                note = "torch.distributed (step loop in Python" + (
+                    f"; native driver unavailable: {sh_.native_error})" if getattr(sh_, "native_error", None) else ")")
+            sh_.set_state(psi0_local)
+            return sh_, nat, note
+
+        def trial(sh_, nat, k=4):
+            """Seconds per step of a schedule, the slowest rank's (every rank sees the same number)."""
+            sh_.set_state(psi0_local)
+            for _ in range(2):
+                sh_.step(native=nat)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0_ = time.perf_counter()
+            for _ in range(k):
+                sh_.step(native=nat)
+            torch.cuda.synchronize()
+            t_ = torch.tensor([(time.perf_counter() - t0_) / k], dtype=torch.float64, device="cpu" if one_gpu else "cuda")
+            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+            sh_.set_state(psi0_local)
+            return float(t_[0])
+
+        # Two schedules of the same arithmetic (bit-identical results): the boundary / interior overlap
+        # hides the exchange behind the interior launch but pays for a second stream; the serial one has
+        # the exchange in line.  Which is faster depends on the exchange latency of the machine, so both
+        # are timed for a few steps before the measurement and the faster one is measured ("auto").
+        sh, use_native, driver_note = build(args.schedule != "serial")
+        schedule_note = args.schedule
+        if args.schedule == "auto" and sh.split is not None:
+            sh2, nat2, note2 = build(False)
+            t_overlap, t_serial = trial(sh, use_native), trial(sh2, nat2)
+            schedule_note = f"auto: overlap {1e3 * t_overlap:.3f} ms/step, serial {1e3 * t_serial:.3f} ms/step"
+            if t_serial < t_overlap:
+                sh, sh2, use_native, driver_note = sh2, sh, nat2, note2
+                schedule_note += " -> serial"
+            else:
+                schedule_note += " -> overlap"
+            del sh2
         fmt_used = sh.op.format
         layout = sh.op.layout_info()
         exchange_used = sh.exchange
-        use_native = sh.native is not None
-        if use_native:
-            sh.set_state(psi0_local)
-            sh.step(native=True)
-            torch.cuda.synchronize()
-            got = sh.local_state()
-            sh.set_state(psi0_local)
-            sh.step(native=False)
-            torch.cuda.synchronize()
-            same = torch.tensor([1 if np.array_equal(got, sh.local_state()) else 0], device="cpu" if one_gpu else "cuda")
-            dist.all_reduce(same, op=dist.ReduceOp.MIN)
-            use_native = bool(same.item())
-            how = ("exchange handed back through a callback communicator" if one_gpu else
-                   "RCCL communicator of the library, " + ("ncclSend/ncclRecv with the neighbours" if sh.p2p else "ncclAllGather"))
-            driver_note = f"native (library step, {how})" if use_native else \
-                "torch.distributed (native step disagreed with it in the self-check)"
-        else:
-            driver_note = "torch.distributed (step loop in Python" + (
-                f"; native driver unavailable: {sh.native_error})" if getattr(sh, "native_error", None) else ")")
-        sh.set_state(psi0_local)
 
         def step():
             sh.step(native=use_native)
+
     pcie = None
     if world == 1 and os.environ.get("QP_BENCH_PCIE") == "1":
         # what a host-resident caller (the Julia glue without a device state type) would see:
@@ -275,7 +315,7 @@ def main():
                    "device_format": {1: "csr", 2: "rbcsr", 3: "hrb (Hermitian-packed row blocks)"}[fmt_used],
                    "device_layout": layout,
                    "parallelism": "single GPU" if world == 1 else (
-                       f"row-partitioned x{world}, exchange={exchange_used}, driver={driver_note}"
+                       f"row-partitioned x{world}, exchange={exchange_used}, schedule={schedule_note}, driver={driver_note}"
                        + (" [TEST MODE: ranks share one GPU, host-staged gloo]" if one_gpu else "")),
                    "global_steps_per_s": steps_per_s},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -21,6 +21,9 @@
  *  - all device work of a context is enqueued on that context's HIP stream; calls that
  *    return host scalars synchronise that stream, all others are asynchronous.
  *  - handles are not thread-safe; distinct contexts may be used from distinct threads.
+ *  - handles may be destroyed in ANY order, a context also before the handles created from it
+ *    (a garbage collector's finalizers -- Python's, Julia's -- run in no particular order); a
+ *    compute call on a handle whose context is gone returns QP_E_BAD_ARG.
  */
 #ifndef QPROP_H
 #define QPROP_H

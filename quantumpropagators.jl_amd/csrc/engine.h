@@ -28,6 +28,10 @@ struct qp_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double2* d_part = nullptr;   // kRedBlocks partials for qp_dot / qp_norm
   double2* h_part = nullptr;   // pinned mirror
+  // qp_ctx_destroy releases the resources and marks the record, which itself stays allocated: handles
+  // created from the context may be destroyed in any order, also after it (finalizers of a garbage
+  // collector -- Python's, Julia's -- run in no particular order)
+  bool closed = false;
 };
 
 struct qp_state {
@@ -165,6 +169,7 @@ inline double2 d2(qp_c128 z) { return make_double2(z.re, z.im); }
 inline cplx cx(qp_c128 z) { return cplx(z.re, z.im); }
 
 inline int use(qp_ctx* ctx) {
+  if (ctx->closed) return qp::fail(QP_E_BAD_ARG, "the context of this handle has been destroyed");
   QP_HIP(hipSetDevice(ctx->device));
   return QP_OK;
 }

@@ -159,7 +159,7 @@ int qp_ctx_create(int device, void* stream, qp_ctx** out) {
 
 int qp_ctx_destroy(qp_ctx* ctx) {
   QP_TRY
-  if (!ctx) return QP_OK;
+  if (!ctx || ctx->closed) return QP_OK;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->d_part) (void)hipFree(ctx->d_part);
@@ -167,7 +167,13 @@ int qp_ctx_destroy(qp_ctx* ctx) {
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
-  delete ctx;
+  // the record stays (a few dozen bytes): child handles destroyed later still find their device in it
+  ctx->d_part = nullptr;
+  ctx->h_part = nullptr;
+  ctx->ev0 = ctx->ev1 = nullptr;
+  ctx->stream = nullptr;      // what a late child destroy synchronises: the null stream
+  ctx->own_stream = false;
+  ctx->closed = true;
   return QP_OK;
   QP_CATCH
 }

@@ -86,7 +86,7 @@ def test_bench_multirank_flow_one_gpu(world, driver):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", QP_BENCH_ONE_GPU="1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3",
-                                       "--warmup", "1", "--log2n", "14", "--driver", driver], env=env,
+                                       "--warmup", "1", "--log2n", "16", "--driver", driver], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
     for p in procs:
@@ -103,9 +103,11 @@ def test_bench_multirank_flow_one_gpu(world, driver):
     d = json.loads(lines[0])
     assert d["n_gpus"] == world and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
     assert d["value"] > 0 and abs(d["value"] - world * d["config"]["global_steps_per_s"]) < 1e-9 * d["value"]
-    assert d["config"]["N_total"] == world << 14 and d["roofline"]["frac"] > 0 and d["cpu_baseline"] is None
+    assert d["config"]["N_total"] == world << 16 and d["roofline"]["frac"] > 0 and d["cpu_baseline"] is None
     par = d["config"]["parallelism"]
     assert f"row-partitioned x{world}" in par and "TEST MODE" in par
+    assert "exchange=halo" in par                       # 2^16 rows per rank: banded H exchanges halos only
+    assert "schedule=auto: overlap" in par and ("-> overlap" in par or "-> serial" in par)   # both schedules were timed
     assert ("driver=native (library step" in par) if driver == "native" else ("driver=torch.distributed" in par)
 
 

@@ -1175,3 +1175,26 @@ def test_newton_dense_128_persistent_arnoldi(ctx, N):
         L.tuning_set("small_nnz", 8192)
     assert np.linalg.norm(out - out_g) < 1e-12
     assert small_launches * 3 < general_launches          # one launch per sweep instead of ~5 per column
+
+
+def test_handles_destroyed_in_any_order():
+    """C-ABI convention: finalizers run in no particular order, so a context may be destroyed before
+    the handles made from it; their destroy calls still succeed and compute calls fail cleanly."""
+    import ctypes as C
+    c = L.Context(0)
+    lib = c.lib
+    N = 500
+    rp, col, vals = synth.hermitian_offsets_csr(N, offsets=(1, 2, 7, 30))
+    op = L.Operator(c, [L.Matrix(c, N, N, rp, col, vals)])
+    x, y = L.State(c, data=synth.random_state(N)), L.State(c, n=N)
+    wrk = L.ChebyWrk(c, N, 20.0, -10.0, 0.5)
+    kry = L.Krylov(c, N, 6)
+    L.cheby(x, op, 0.5, wrk)
+    c.sync()
+    assert lib.qp_ctx_destroy(c._h) == 0                 # the context goes first ...
+    assert lib.qp_ctx_destroy(c._h) == 0                 # ... (idempotent) ...
+    st = lib.qp_mul(op._h, x._h, y._h, L.c128(1.0), L.c128(0.0))
+    assert st != 0 and b"context" in lib.qp_last_error()  # ... compute calls say so ...
+    for h in (kry, wrk, y, x, op):                        # ... and the children can still be destroyed
+        h.close()
+    c._h = C.c_void_p()                                   # nothing left for Context.close()

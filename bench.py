@@ -210,6 +210,7 @@ def main():
                 schedule_note += " -> serial"
             else:
                 schedule_note += " -> overlap"
+            sh2.close()
             del sh2
         fmt_used = sh.op.format
         layout = sh.op.layout_info()
@@ -346,6 +347,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
+        sh.close()      # the library's communicator goes before the process group it was bootstrapped over
         dist.destroy_process_group()
 
 

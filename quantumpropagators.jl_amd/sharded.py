@@ -314,6 +314,18 @@ class ShardedCheby:
             L.State(self.be.ctx, n=count, device_ptr=recv_ptr + 16 * count * o).upload(h_all[o])
         torch.cuda.synchronize()
 
+    def close(self):
+        """Release the library handles now, in dependency order (stepper, communicator, split, operator),
+        instead of whenever the garbage collector gets to them -- e.g. before the process group that the
+        communicator was bootstrapped over is destroyed.  The object must not be used afterwards."""
+        if getattr(self, "torch", None) is not None and isinstance(self.be, HipBackend):
+            self.torch.cuda.synchronize()
+        for name in ("native", "comm", "split", "op"):
+            h = getattr(self, name, None)
+            if h is not None and hasattr(h, "close"):
+                h.close()
+            setattr(self, name, None)
+
     def check(self):
         """Synchronise and verify that no in-launch wait of the overlapped schedule timed out."""
         if self.split is not None and hasattr(self.split, "check"):

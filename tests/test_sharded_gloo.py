@@ -74,6 +74,9 @@ def _worker(rank, world, port, exchange, uneven, offsets, N, q, overlap=True):
         err = float(np.linalg.norm(out - ref[r0:r1]))
         q.put((rank, err, sh.exchange, sh.halo_fraction, sh.M, len(sh.send_idx_host), sh.n_exchanges,
                sh.split is not None))
+        sh.close()                      # explicit release before the process group goes (idempotent)
+        sh.close()
+        assert sh.op is None and sh.split is None and sh.native is None
     finally:
         dist.destroy_process_group()
 

@@ -201,7 +201,9 @@ def main():
         # are timed for a few steps before the measurement and the faster one is measured ("auto").
         sh, use_native, driver_note = build(args.schedule != "serial")
         schedule_note = args.schedule
-        if args.schedule == "auto" and sh.split is not None:
+        has_split = torch.tensor([1 if sh.split is not None else 0], device="cpu" if one_gpu else "cuda")
+        dist.all_reduce(has_split, op=dist.ReduceOp.MIN)      # the same decision on every rank
+        if args.schedule == "auto" and bool(has_split.item()):
             sh2, nat2, note2 = build(False)
             t_overlap, t_serial = trial(sh, use_native), trial(sh2, nat2)
             schedule_note = f"auto: overlap {1e3 * t_overlap:.3f} ms/step, serial {1e3 * t_serial:.3f} ms/step"

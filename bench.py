@@ -225,15 +225,17 @@ def main():
     if world == 1 and os.environ.get("QP_BENCH_PCIE") == "1":
         # what a host-resident caller (the Julia glue without a device state type) would see:
         # the state is downloaded after every step.  Reported separately, never as `value`.
-        host = np.empty(N, dtype=np.complex128)
+        # The caller's array is registered (pinned) once, as the glue does for the propagator's state.
+        host = L.host_register(np.empty(N, dtype=np.complex128))
         for _ in range(3):
             step()
-            host[:] = psi.numpy()
+            psi.download(host)
         t0p = time.perf_counter()
         for _ in range(20):
             step()
-            host[:] = psi.numpy()
+            psi.download(host)
         pcie = 20 / (time.perf_counter() - t0p)
+        L.host_unregister(host)
 
     def barrier():
         torch.cuda.synchronize()     # nothing of ours in flight while the barrier's collective runs

@@ -167,6 +167,12 @@ int qp_state_wrap(qp_ctx* ctx, void* device_ptr, int64_t n, qp_state** out);
 int qp_state_destroy(qp_state* s);
 int qp_state_upload(qp_state* s, const qp_c128* host);
 int qp_state_download(const qp_state* s, qp_c128* host);
+/* Pin a caller-owned host array (page-lock it for the device) so that qp_state_upload / _download from
+ * and to it run at PCIe speed instead of through the runtime's staging buffers: a host-resident
+ * caller -- the propagator types of the reference keep `state` in host memory (src/propagator.jl:119-126) --
+ * registers its state vector once and unregisters it before the array is freed. */
+int qp_host_register(void* host, size_t bytes);
+int qp_host_unregister(void* host);
 void* qp_state_ptr(const qp_state* s);
 int64_t qp_state_len(const qp_state* s);
 int qp_copy(qp_state* dst, const qp_state* src);              /* copyto! */

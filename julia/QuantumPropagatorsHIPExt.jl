@@ -103,6 +103,14 @@ function set_coeffs!(op::Handle, coeffs::Vector{ComplexF64})
         (Ptr{Cvoid}, Ptr{ComplexF64}, Cint), op, coeffs, length(coeffs)))
 end
 
+# Page-lock the propagator's host-resident state vector (src/propagator.jl:119-126 keeps `state` on the
+# host) so that the hand-back after every step runs at PCIe speed; undone by `unpin!` in the finalizer of
+# the propagator that owns the vector.
+pin!(Ψ::Vector{ComplexF64}) =
+    (GC.@preserve Ψ check(ccall((:qp_host_register, LIB), Cint, (Ptr{Cvoid}, Csize_t), pointer(Ψ), sizeof(Ψ))); Ψ)
+unpin!(Ψ::Vector{ComplexF64}) =
+    GC.@preserve Ψ ccall((:qp_host_unregister, LIB), Cint, (Ptr{Cvoid},), pointer(Ψ))
+
 function make_state(ctx::Handle, Ψ::Vector{ComplexF64})
     out = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:qp_state_create, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Ptr{Cvoid}}), ctx, length(Ψ), out))
@@ -245,11 +253,16 @@ function init_prop(state, generator::Generator, tlist, ::Val{:ChebyHIP};
         n = length(tlist) - 1
         t = float(tlist[n+1])
     end
-    return ChebyHIPPropagator{typeof(generator)}(
+    p = ChebyHIPPropagator{typeof(generator)}(
         generator, Ψ, t, n, tlist, parameters, controls, control_ranges, backward, inplace,
         specrange_method, specrange_buffer, Dict{Symbol,Any}(specrange_kwargs), check_normalization,
         ctx, op, dstate, wrk, coeffs, Δ, E_min, dt, cheby_coeffs_limit,
         length(generator.ops) - length(generator.amplitudes))
+    if inplace                                     # the in-place propagator owns Ψ for its whole life: pin it
+        pin!(Ψ)
+        finalizer(q -> unpin!(getfield(q, :state)), p)
+    end
+    return p
 end
 
 # prop_step!(::ChebyPropagator)   src/cheby_propagator.jl:348-386

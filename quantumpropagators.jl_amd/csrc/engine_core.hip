@@ -1101,6 +1101,22 @@ int qp_state_download(const qp_state* s, qp_c128* host) {
   QP_CATCH
 }
 
+int qp_host_register(void* host, size_t bytes) {
+  QP_TRY
+  if (!host || bytes == 0) return qp::fail(QP_E_BAD_ARG, "qp_host_register: NULL / empty array");
+  QP_HIP(hipHostRegister(host, bytes, hipHostRegisterDefault));
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_host_unregister(void* host) {
+  QP_TRY
+  if (!host) return qp::fail(QP_E_BAD_ARG, "qp_host_unregister: NULL");
+  QP_HIP(hipHostUnregister(host));
+  return QP_OK;
+  QP_CATCH
+}
+
 void* qp_state_ptr(const qp_state* s) { return s ? s->d : nullptr; }
 int64_t qp_state_len(const qp_state* s) { return s ? s->n : -1; }
 

@@ -124,6 +124,8 @@ SIGNATURES = {
     "qp_state_destroy": (C.c_int, [_P]),
     "qp_state_upload": (C.c_int, [_P, _cp]),
     "qp_state_download": (C.c_int, [_P, _cp]),
+    "qp_host_register": (C.c_int, [_P, C.c_size_t]),
+    "qp_host_unregister": (C.c_int, [_P]),
     "qp_state_ptr": (_P, [_P]),
     "qp_state_len": (C.c_int64, [_P]),
     "qp_copy": (C.c_int, [_P, _P]),
@@ -570,6 +572,17 @@ class Liouvillian(Operator):
         ctx._adopt(self)
 
 
+def host_register(array):
+    """Page-lock a NumPy array for fast uploads / downloads (qp_host_register); keep it alive until
+    :func:`host_unregister`."""
+    check(load().qp_host_register(array.ctypes.data_as(C.c_void_p), array.nbytes))
+    return array
+
+
+def host_unregister(array):
+    check(load().qp_host_unregister(array.ctypes.data_as(C.c_void_p)))
+
+
 class State:
     """ComplexF64[n] in HBM."""
 
@@ -605,6 +618,12 @@ class State:
 
     def numpy(self):
         out = np.empty(self.n, dtype=np.complex128)
+        check(self.lib.qp_state_download(self._h, _ptr(out, _cp)))
+        return out
+
+    def download(self, out):
+        """Into an existing complex128 array (no allocation; pinned arrays -- :func:`host_register` -- at PCIe speed)."""
+        assert out.dtype == np.complex128 and out.flags.c_contiguous and out.size == self.n
         check(self.lib.qp_state_download(self._h, _ptr(out, _cp)))
         return out
 

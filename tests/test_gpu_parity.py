@@ -1198,3 +1198,25 @@ def test_handles_destroyed_in_any_order():
     for h in (kry, wrk, y, x, op):                        # ... and the children can still be destroyed
         h.close()
     c._h = C.c_void_p()                                   # nothing left for Context.close()
+
+
+def test_host_register_pinned_transfers(ctx):
+    """qp_host_register / qp_host_unregister: a caller-owned (pinned) array as the source / target of
+    uploads and downloads -- same bytes as through pageable memory."""
+    N = 1 << 18
+    a = synth.random_state(N)
+    pinned = L.host_register(a.copy())
+    try:
+        s = L.State(ctx, data=pinned)
+        out = L.host_register(np.empty(N, dtype=np.complex128))
+        try:
+            s.download(out)
+            assert np.array_equal(out, a) and np.array_equal(s.numpy(), a)
+            s.upload(out * 2)
+            assert np.array_equal(s.numpy(), 2 * a)
+        finally:
+            L.host_unregister(out)
+    finally:
+        L.host_unregister(pinned)
+    with pytest.raises(L.QPError):
+        L.host_unregister(np.empty(16, dtype=np.complex128))     # was never registered

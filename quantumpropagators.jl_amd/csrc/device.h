@@ -10,9 +10,11 @@ namespace qp {
 #define QP_HIP(expr)                                                                         \
   do {                                                                                       \
     hipError_t e__ = (expr);                                                                 \
-    if (e__ != hipSuccess)                                                                   \
+    if (e__ != hipSuccess) {                                                                 \
+      (void)hipGetLastError(); /* reported here: do not leave it for a later hipGetLastError() */ \
       return qp::fail(QP_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, \
                       __LINE__);                                                             \
+    }                                                                                        \
   } while (0)
 
 constexpr int kRB = 64;           // rows per row block = one wavefront

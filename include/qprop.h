@@ -84,10 +84,15 @@ const char* qp_last_error(void);
 const char* qp_status_name(int status);
 int qp_version(void);
 int qp_device_count(int* n_out);
-/* developer knob for A/B kernel experiments ("rbcsr_variant": bit0 nt matrix loads,
- * bit1 early row-local loads, bit2 deeper unroll); process-global, not part of the
- * reference-facing API. */
+/* Developer knobs for A/B kernel experiments (e.g. "rbcsr_variant": bit0 nt matrix loads, bit1 early
+ * row-local loads, bit2 deeper unroll; the full list is `struct Tuning` in csrc/device.h); not part of
+ * the reference-facing API.  Every context owns a copy of the knobs: qp_ctx_tuning_set changes the
+ * copy of ONE context (and of the handles created from it), so contexts driven from different threads
+ * never see each other's switches (SURVEY 8b "no global mutable state").  qp_tuning_set only changes
+ * the defaults that contexts created AFTERWARDS start from; existing contexts are not touched. */
 int qp_tuning_set(const char* key, int value);
+int qp_ctx_tuning_set(qp_ctx* ctx, const char* key, int value);
+int qp_ctx_tuning_get(qp_ctx* ctx, const char* key, int* value_out);
 
 /* ---- context -------------------------------------------------------------------- */
 /* `stream` may be NULL (the library creates a non-blocking stream of its own), an existing
@@ -157,6 +162,11 @@ int qp_operator_info(const qp_operator* op, int64_t* nrows, int64_t* ncols, int6
  * out[3] = bytes of index data a mat-vec streams (column sections + transpose positions
  * of the non-stencil lower sections), out[4] = stored values. */
 int qp_operator_layout_info(const qp_operator* op, int64_t out[5]);
+/* How qp_cheby_step_batched will visit the rows for a panel of `batch` states (wave-per-row kernel,
+ * more than 32 states): out[0] = inner dimension g detected in the pattern (far offsets are multiples of
+ * g: H = H_a (x) 1 + 1 (x) H_c), out[1] = strip width (rows are visited strip by strip so that the gather
+ * window of the panel stays inside an XCD's L2); both 0 when the rows are visited in natural order. */
+int qp_operator_spmm_walk(qp_operator* op, int batch, int64_t out[2]);
 /* read the DEVICE copy (union pattern, currently combined values) back as canonical
  * CSR: the device-format round trip must be bit-exact. */
 int qp_operator_get_csr(qp_operator* op, int64_t* rowptr, int32_t* col, qp_c128* vals);

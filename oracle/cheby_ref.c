@@ -12,6 +12,7 @@
 #include <complex.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 typedef double _Complex c128;
@@ -104,3 +105,60 @@ int qp_ref_cheby_csr_omp(int64_t n, const int64_t* rowptr, const int64_t* col, c
   for (int64_t i = 0; i < n; ++i) psi[i] *= ph;
   return nmv;
 }
+
+/* The all-cores variant on buffers of its own, every page first touched by the thread that later
+ * works on it (static schedule over the rows, the schedule of the compute loops): on a multi-socket
+ * host the matrix and the vectors are then spread over the memory controllers instead of sitting
+ * on the node of the thread that built them. */
+typedef struct {
+  int64_t n;
+  int64_t *rowptr, *col;
+  c128 *val, *psi, *v0, *v1;
+} qp_ref_omp;
+
+void qp_ref_omp_free(qp_ref_omp* h) {
+  if (!h) return;
+  free(h->rowptr);
+  free(h->col);
+  free(h->val);
+  free(h->psi);
+  free(h->v0);
+  free(h->v1);
+  free(h);
+}
+
+qp_ref_omp* qp_ref_omp_setup(int64_t n, const int64_t* rowptr, const int64_t* col, const c128* val, const c128* psi) {
+  qp_ref_omp* h = (qp_ref_omp*)calloc(1, sizeof(qp_ref_omp));
+  if (!h) return NULL;
+  const int64_t nnz = rowptr[n];
+  h->n = n;
+  h->rowptr = (int64_t*)malloc((size_t)(n + 1) * sizeof(int64_t));
+  h->col = (int64_t*)malloc((size_t)(nnz > 0 ? nnz : 1) * sizeof(int64_t));
+  h->val = (c128*)malloc((size_t)(nnz > 0 ? nnz : 1) * sizeof(c128));
+  h->psi = (c128*)malloc((size_t)(n > 0 ? n : 1) * sizeof(c128));
+  h->v0 = (c128*)malloc((size_t)(n > 0 ? n : 1) * sizeof(c128));
+  h->v1 = (c128*)malloc((size_t)(n > 0 ? n : 1) * sizeof(c128));
+  if (!h->rowptr || !h->col || !h->val || !h->psi || !h->v0 || !h->v1) {
+    qp_ref_omp_free(h);
+    return NULL;
+  }
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) {
+    h->rowptr[i] = rowptr[i];
+    for (int64_t p = rowptr[i]; p < rowptr[i + 1]; ++p) {
+      h->col[p] = col[p];
+      h->val[p] = val[p];
+    }
+    h->psi[i] = psi[i];
+    h->v0[i] = 0.0;
+    h->v1[i] = 0.0;
+  }
+  h->rowptr[n] = nnz;
+  return h;
+}
+
+int qp_ref_omp_step(qp_ref_omp* h, const double* a, int n_coeffs, double Delta, double E_min, double dt) {
+  return qp_ref_cheby_csr_omp(h->n, h->rowptr, h->col, h->val, h->psi, h->v0, h->v1, a, n_coeffs, Delta, E_min, dt);
+}
+
+void qp_ref_omp_get_psi(const qp_ref_omp* h, c128* out) { memcpy(out, h->psi, (size_t)h->n * sizeof(c128)); }

@@ -22,10 +22,12 @@ constexpr int kRedBlocks = 256;   // fixed grid of the reduction kernels (determ
 constexpr int kThreads = 256;
 
 struct Stats;
+struct Tuning;
 
 // ---- device view of one sparse operator -------------------------------------------
 struct DevMatrix {
   int format = QP_FMT_RBCSR;
+  const Tuning* tun = nullptr;   // the owning context's knobs (never null once the operator exists)
   int64_t nrows = 0, ncols = 0, nnz = 0, stored = 0;
   // RBCSR: 64-row blocks, element (r,k) of block b at bptr[b] + k*64 + r;
   // cols packed 4 per lane: cols4[(bptr[b]>>2) + (k>>2)*64 + r].{x,y,z,w}
@@ -123,18 +125,29 @@ int launch_spmv_cheby(hipStream_t s, const DevMatrix& A, const double2* x, const
                       const RowSet* rs = nullptr);
 int launch_spmv_plain(hipStream_t s, const DevMatrix& A, const double2* x, const PlainEpi& e, Stats* st);
 int spmv_grid_size(const DevMatrix& A);
-extern int g_rbcsr_variant;
-extern int g_hrb_lower_last;  // HRB kernel: process the lower (conj-transposed) section after the upper one
-extern int g_liouville_fused_n;  // matrix-free Liouvillian: largest n that takes the fused matrix-core kernel (else library GEMMs)
-extern int g_real_vals;   // operator refresh: stream a real copy of the values when they are all real (1, default)
-extern int g_stencil;     // operator build: encode blocks with block-wide column distances as stencil blocks (1, default)
-extern int g_acc_defer;   // qp_cheby_step: touch the Psi accumulator every third term only (1, default) or every term (0)
-extern int g_cheby_graph; // qp_cheby_step: replay a repeated step as a hipGraph when the mat-vec grid has at most this many workgroups (0: off)
-extern int g_small_nnz;   // qp_propagate: register-resident Cheby systems up to this nnz run as ONE persistent launch (0: off)
-extern int g_newton_pipeline;  // newton!: Hessenberg eigenvalues overlap the Arnoldi sweep
-extern int g_spmm_tile;   // states per pass of the batched SpMM kernel (16, 32 or 64)
-extern int g_spmm_nt;     // nontemporal matrix / row-local streams in the batched SpMM kernel
-extern int g_split_mode;  // 0 = cross-stream events on both streams, 1 = in-launch counter for the main stream
+// Developer knobs for A/B measurements.  Every context carries its own copy (qp_ctx::tun, set with
+// qp_ctx_tuning_set); qp_tuning_set only changes the defaults that contexts created afterwards start
+// from, so handles driven from different threads never observe each other's switches.
+struct Tuning {
+  int rbcsr_variant = 7;      // bit 0 nt matrix loads, bit 1 early row-local loads, bit 2 deeper unroll (A/B in profiles/)
+  int hrb_lower_last = 0;     // HRB kernel: process the lower (conj-transposed) section after the upper one
+  int arnoldi_mode = 1;       // 0 = sequential fused MGS passes, 1 = low-synchronisation MGS
+  int split_mode = 1;         // 0 = cross-stream events on both streams, 1 = in-launch counter for the main stream
+  int liouville_fused_n = 320;  // matrix-free Liouvillian: largest n that takes the fused matrix-core kernel (else library GEMMs)
+  int real_vals = 1;          // operator refresh: stream a real copy of the values when they are all real
+  int stencil = 1;            // operator build: encode blocks with block-wide column distances as stencil blocks
+  int acc_defer = 1;          // qp_cheby_step: touch the Psi accumulator every third term only (1) or every term (0)
+  int cheby_graph = 0;        // qp_cheby_step: replay a repeated step as a hipGraph when the mat-vec grid has at most this many workgroups (0: off; measured: no gain)
+  int small_nnz = 8192;       // qp_propagate: register-resident Cheby systems up to this nnz run as ONE persistent launch (0: off)
+  int newton_pipeline = 1;    // newton!: Hessenberg eigenvalues overlap the Arnoldi sweep
+  int spmm_tile = 16;         // states per pass of the tiled batched SpMM kernel (16, 32 or 64)
+  int spmm_rows = 1;          // batched SpMM: wave-per-row kernel (lane = state) for panels of more than 32 states (0: always the state-tiled kernel)
+  int spmm_rw = 1;            // batched SpMM, wave-per-row kernel: rows per wavefront (1, 2, 4 or 8)
+  int spmm_strip = 0;         // batched SpMM row walk: inner-index strip width (0 = chosen from the L2 size; -1 = natural row order)
+  int spmm_nt = 1;            // nontemporal matrix / row-local streams in the batched SpMM kernel: 0 never, 2 always, 1 for large panels
+};
+// address of the knob called `key` inside `t`, or nullptr
+int* tuning_field(Tuning& t, const char* key);
 
 // small coefficient vectors are passed by value in the kernel-argument segment
 constexpr int kCoefBlock = 32;
@@ -149,7 +162,10 @@ int launch_combine_planes(hipStream_t s, double2* vals, const double2* const* pl
 
 // batched states: CSR SpMM with the fused Chebyshev epilogue, panel X[i*b + s]
 int launch_spmm_cheby(hipStream_t s, const int64_t* rowptr, const int32_t* cols, const double2* vals,
-                      const double2* X, int64_t nrows, int64_t nnz, int b, const ChebyEpi& e, Stats* st);
+                      const double2* X, int64_t nrows, int64_t nnz, int b, const ChebyEpi& e, const Tuning& tun,
+                      bool rows_kernel, const int32_t* order, Stats* st);
+// panels of more than 32 states take the wave-per-row kernel (lane = state) unless knob spmm_rows is 0
+inline bool spmm_uses_rows_kernel(const Tuning& tun, int b) { return tun.spmm_rows != 0 && b > 32; }
 // ---- small systems: the whole Cheby time grid in one single-workgroup launch -------------
 struct SmallObs {
   const int64_t* rowptr;
@@ -254,7 +270,6 @@ int launch_mgs_project(hipStream_t s, const double2* Q, int64_t ldq, int j, doub
 // up to j = 87 within the 64 KB a launch gets without opting in to more; longer bases continue with
 // the sequential passes
 inline bool mgs_lowsync_fits(int j) { return sizeof(double2) * (size_t)(3 * (j + 1) + j * (j + 1) / 2) <= 64 * 1024; }
-extern int g_arnoldi_mode;  // 0 = sequential fused MGS passes, 1 = low-synchronisation MGS
 // w *= 1/sqrt(sum part_in.x);  hess_slot = dt * norm
 int launch_norm_scale(hipStream_t s, double2* w, const double2* part_in, double2* hess_slot, double dt,
                       int64_t n, Stats* st);

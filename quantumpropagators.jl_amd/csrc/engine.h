@@ -32,6 +32,7 @@ struct qp_ctx {
   // created from the context may be destroyed in any order, also after it (finalizers of a garbage
   // collector -- Python's, Julia's -- run in no particular order)
   bool closed = false;
+  qp::Tuning tun;              // this context's developer knobs (qp_ctx_tuning_set)
 };
 
 struct qp_state {
@@ -69,6 +70,12 @@ struct qp_operator {
   int64_t* m_map = nullptr;     // position in A.vals (>= 0) or -(position)-1 for a conj-transposed value
   double2* m_vals = nullptr;
   uint64_t vals_epoch = 1, m_epoch = 0;
+  // row walk of the batched path (operator_spmm_order): device permutation of the rows, or null for
+  // the natural order; rebuilt when the panel width or the knob it was built for changes
+  int32_t* m_order = nullptr;
+  int m_order_batch = 0, m_order_knob = 0;
+  bool m_order_valid = false;
+  int64_t m_order_g = 0, m_order_sw = 0;   // what was detected: inner dimension and strip width (0: none)
   int nops = 0, ncoeffs = 0;
   std::vector<int64_t> u_rowptr;  // union pattern (host), for get_csr and plane scatter
   std::vector<int32_t> u_col;
@@ -211,6 +218,8 @@ inline int dot_sync(qp_ctx* ctx, const double2* x, const double2* y, int64_t n, 
 // ---- shared between the engine translation units -------------------------------------
 // CSR-ordered mirror of the operator (index arrays; `gather`: also the current values)
 int operator_csr_mirror(qp_operator* op, bool gather = true);
+// row order in which the batched (SpMM) kernel visits the rows for a panel of `batch` states
+int operator_spmm_order(qp_operator* op, int batch, const int32_t** order_out);
 // which terms of a cheby! touch the Psi accumulator (include/qprop.h, qp_acc_defer)
 void acc_schedule(const double* a, int n_coeffs, bool defer, qp_acc_defer* out);
 void set_defer(qp::ChebyEpi& e, const qp_acc_defer* d);

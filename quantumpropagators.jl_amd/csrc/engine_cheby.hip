@@ -122,7 +122,7 @@ static int cheby_step_launches(qp_cheby* w, qp_operator* op, qp_state* psi, cons
   double2* ACC = w->acc;
   double2* result = nullptr;
   std::vector<qp_acc_defer> sched((size_t)nterms);
-  acc_schedule(a, n_coeffs, qp::g_acc_defer != 0, sched.data());
+  acc_schedule(a, n_coeffs, ctx->tun.acc_defer != 0, sched.data());
   bool updated = false;   // has any term written the accumulator yet?
   for (int m = 1; m <= nterms; ++m) {
     const bool last = (m == nterms);
@@ -209,14 +209,14 @@ int qp_cheby_step(qp_cheby* w, qp_operator* op, qp_state* psi, const double* a, 
   }
   // launch-bound systems (a term takes less than its launch): replay the step as a hipGraph
   bool done = false;
-  if (qp::g_cheby_graph && !check_normalization && ctx->stream != nullptr && ctx->stream != hipStreamLegacy) {
+  if (ctx->tun.cheby_graph && !check_normalization && ctx->stream != nullptr && ctx->stream != hipStreamLegacy) {
     qp_cheby::GraphKey key;
     key.vals = A.vals_r ? (const void*)A.vals_r : (const void*)A.vals;
     key.cols = A.cols;
     key.rowptr = A.format == QP_FMT_CSR ? (const void*)A.rowptr : (const void*)A.bptr;
     key.psi = psi->d;
     key.format = A.format;
-    key.variant = qp::g_rbcsr_variant;
+    key.variant = ctx->tun.rbcsr_variant * 2 + ctx->tun.hrb_lower_last;
     key.n_coeffs = n_coeffs;
     key.dt = dt;
     key.Delta = Delta;
@@ -239,7 +239,7 @@ int qp_cheby_step(qp_cheby* w, qp_operator* op, qp_state* psi, const double* a, 
     if (w->gexec && key == w->gkey) {
       QP_CHECK(replay());
       done = true;
-    } else if (key == w->gpending && (int64_t)spmv_grid_size(A) <= qp::g_cheby_graph) {
+    } else if (key == w->gpending && (int64_t)spmv_grid_size(A) <= ctx->tun.cheby_graph) {
       // second identical call in a row: record it
       hipGraph_t graph = nullptr;
       const Stats before = ctx->stats;
@@ -308,6 +308,10 @@ int qp_cheby_step_batched(qp_cheby* w, qp_operator* op, qp_state* psi, int batch
   qp_ctx* ctx = op->ctx;
   QP_CHECK(use(ctx));
   QP_CHECK(operator_csr_mirror(op));
+  // kernel choice (knob spmm_rows): the wave-per-row kernel for wide panels, else the state-tiled kernel
+  const bool rows_kernel = qp::spmm_uses_rows_kernel(ctx->tun, batch);
+  const int32_t* order = nullptr;   // row walk of the wave-per-row kernel
+  if (rows_kernel) QP_CHECK(operator_spmm_order(op, batch, &order));
   const double beta = (Delta / 2) + E_min;
   cplx c = (dt > 0) ? cplx(0, -2.0) / Delta : cplx(0, 2.0) / Delta;
   const cplx phase = std::exp(cplx(0, -1) * beta * dt);
@@ -317,7 +321,7 @@ int qp_cheby_step_batched(qp_cheby* w, qp_operator* op, qp_state* psi, int batch
   double2* ACC = w->acc;
   double2* result = nullptr;
   std::vector<qp_acc_defer> sched((size_t)nterms);
-  acc_schedule(a, n_coeffs, qp::g_acc_defer != 0, sched.data());
+  acc_schedule(a, n_coeffs, ctx->tun.acc_defer != 0, sched.data());
   bool updated = false;
   for (int m = 1; m <= nterms; ++m) {   // same buffer rotation as qp_cheby_step, element = (row, state)
     const bool last = (m == nterms);
@@ -356,7 +360,7 @@ int qp_cheby_step_batched(qp_cheby* w, qp_operator* op, qp_state* psi, int batch
     e.apply_phase = last ? 1 : 0;
     e.check_partials = nullptr;
     QP_CHECK(qp::launch_spmm_cheby(ctx->stream, op->m_rowptr, op->m_cols, op->m_vals, x, n, op->A.nnz, batch, e,
-                                   &ctx->stats));
+                                   ctx->tun, rows_kernel, order, &ctx->stats));
     if (m == 1) c *= 2.0;
   }
   if (result != P) QP_HIP(hipMemcpyAsync(P, result, (size_t)psi->n * sizeof(double2), hipMemcpyDeviceToDevice, ctx->stream));
@@ -508,7 +512,7 @@ int qp_cheby_term_split(qp_operator* op, qp_split* sp, void* boundary_stream, in
   set_defer(e, defer);
   qp::RowSet rb{sp->bmap_boundary, sp->n_boundary, false};
   qp::RowSet ri{sp->bmap_interior, sp->n_interior, true};
-  const bool flag_mode = (qp::g_split_mode == 1);
+  const bool flag_mode = (op->ctx->tun.split_mode == 1);
   if (first && flag_mode) {
     // the caller joined both streams: restart the signal counter (keeps it far from wrap)
     QP_HIP(hipMemsetAsync(sp->counter, 0, sizeof(unsigned), S_c));
@@ -660,13 +664,13 @@ int qp_propagate(qp_operator* op, qp_state* psi, const qp_prop_spec* spec, const
   QP_CHECK(use(ctx));
   const int64_t n = psi->n;
   const size_t rows = (size_t)nsteps + 1;
-  if (spec->method == 0 && nsteps > 0 && qp::g_small_nnz > 0 && op->A.nnz <= 2 * (int64_t)qp::g_small_nnz && op->nops <= 64) {
+  if (spec->method == 0 && nsteps > 0 && ctx->tun.small_nnz > 0 && op->A.nnz <= 2 * (int64_t)ctx->tun.small_nnz && op->nops <= 64) {
     qp::SmallArgs plan;
     int64_t maxrow = 0;
     for (int64_t r = 0; r < n; ++r) maxrow = std::max<int64_t>(maxrow, op->u_rowptr[r + 1] - op->u_rowptr[r]);
     // 16 register slots per lane where that is enough; otherwise 32 (the upper 16 values of a lane
     // live in LDS: 128 KB, which leaves room for vectors of up to 600 rows)
-    bool ok = op->A.nnz <= qp::g_small_nnz && qp::small_plan(n, maxrow, &plan, qp::kSmallEpt);
+    bool ok = op->A.nnz <= ctx->tun.small_nnz && qp::small_plan(n, maxrow, &plan, qp::kSmallEpt);
     if (!ok && n <= 600) ok = qp::small_plan(n, maxrow, &plan, 2 * qp::kSmallEpt);
     if (ok)
       return propagate_cheby_small(op, psi, spec, plan, dts, coeff_table, ncoeffs, nsteps, observables, nobs,

@@ -3,6 +3,9 @@
 // of kernels.hip.  Host logic follows the reference line by line (citations inline);
 // device work is stream-ordered, with host synchronisation only where the reference
 // algorithm needs a scalar on the host (once per Newton restart, once per Arnoldi call).
+#include <mutex>
+#include <numeric>
+
 #include "engine.h"
 
 // ---------------------------------------------------------------------------
@@ -50,61 +53,37 @@ const char* qp_status_name(int s) {
 
 int qp_version(void) { return 100; }
 
+}  // extern "C"
+
+// defaults that new contexts start from (qp_tuning_set); a context's own copy is qp_ctx::tun
+static std::mutex g_tuning_mutex;
+static qp::Tuning g_tuning_defaults;
+
+extern "C" {
+
 int qp_tuning_set(const char* key, int value) {
   if (!key) return qp::fail(QP_E_BAD_ARG, "key is NULL");
-  if (std::strcmp(key, "rbcsr_variant") == 0) {
-    qp::g_rbcsr_variant = value;
-    return QP_OK;
-  }
-  if (std::strcmp(key, "arnoldi_mode") == 0) {
-    qp::g_arnoldi_mode = value;
-    return QP_OK;
-  }
-  if (std::strcmp(key, "hrb_lower_last") == 0) {
-    qp::g_hrb_lower_last = value;
-    return QP_OK;
-  }
-  if (std::strcmp(key, "liouville_fused_n") == 0) {
-    qp::g_liouville_fused_n = value;
-    return QP_OK;
-  }
-  if (std::strcmp(key, "real_vals") == 0) {
-    qp::g_real_vals = value;
-    return QP_OK;
-  }
-  if (std::strcmp(key, "stencil") == 0) {
-    qp::g_stencil = value;
-    return QP_OK;
-  }
-  if (std::strcmp(key, "acc_defer") == 0) {
-    qp::g_acc_defer = value;
-    return QP_OK;
-  }
-  if (std::strcmp(key, "cheby_graph") == 0) {
-    qp::g_cheby_graph = value;
-    return QP_OK;
-  }
-  if (std::strcmp(key, "small_nnz") == 0) {
-    qp::g_small_nnz = value;
-    return QP_OK;
-  }
-  if (std::strcmp(key, "spmm_tile") == 0) {
-    qp::g_spmm_tile = value;
-    return QP_OK;
-  }
-  if (std::strcmp(key, "newton_pipeline") == 0) {
-    qp::g_newton_pipeline = value;
-    return QP_OK;
-  }
-  if (std::strcmp(key, "spmm_nt") == 0) {
-    qp::g_spmm_nt = value;
-    return QP_OK;
-  }
-  if (std::strcmp(key, "split_mode") == 0) {
-    qp::g_split_mode = value;
-    return QP_OK;
-  }
-  return qp::fail(QP_E_BAD_ARG, "unknown tuning key %s", key);
+  std::lock_guard<std::mutex> lock(g_tuning_mutex);
+  int* f = qp::tuning_field(g_tuning_defaults, key);
+  if (!f) return qp::fail(QP_E_BAD_ARG, "unknown tuning key %s", key);
+  *f = value;
+  return QP_OK;
+}
+
+int qp_ctx_tuning_set(qp_ctx* ctx, const char* key, int value) {
+  if (!ctx || !key) return qp::fail(QP_E_BAD_ARG, "qp_ctx_tuning_set: NULL argument");
+  int* f = qp::tuning_field(ctx->tun, key);
+  if (!f) return qp::fail(QP_E_BAD_ARG, "unknown tuning key %s", key);
+  *f = value;
+  return QP_OK;
+}
+
+int qp_ctx_tuning_get(qp_ctx* ctx, const char* key, int* value_out) {
+  if (!ctx || !key || !value_out) return qp::fail(QP_E_BAD_ARG, "qp_ctx_tuning_get: NULL argument");
+  const int* f = qp::tuning_field(ctx->tun, key);
+  if (!f) return qp::fail(QP_E_BAD_ARG, "unknown tuning key %s", key);
+  *value_out = *f;
+  return QP_OK;
 }
 
 int qp_device_count(int* n_out) {
@@ -140,6 +119,10 @@ int qp_ctx_create(int device, void* stream, qp_ctx** out) {
   QP_HIP(hipSetDevice(device));
   auto ctx = std::make_unique<qp_ctx>();
   ctx->device = device;
+  {
+    std::lock_guard<std::mutex> lock(g_tuning_mutex);
+    ctx->tun = g_tuning_defaults;
+  }
   if (stream == QP_STREAM_NULL) {
     ctx->stream = nullptr;   // HIP's null stream
   } else if (stream) {
@@ -346,6 +329,9 @@ static int operator_free_device(qp_operator* op) {
   if (op->m_cols) (void)hipFree(op->m_cols);
   if (op->m_map) (void)hipFree(op->m_map);
   if (op->m_vals) (void)hipFree(op->m_vals);
+  if (op->m_order) (void)hipFree(op->m_order);
+  op->m_order = nullptr;
+  op->m_order_valid = false;
   op->m_rowptr = nullptr;
   op->m_cols = nullptr;
   op->m_map = nullptr;
@@ -615,7 +601,7 @@ static int operator_build_device(qp_operator* op, int format, const std::vector<
       };
       encode_col_sections(nrows, A.nblocks, Lh.bptr, get_upper,
                           [&](int64_t b, int64_t w, std::vector<char>& out) {
-                            return qp::g_stencil != 0 && try_stencil_upper(nrows, A.ncols, b, w, get_upper, out);
+                            return ctx->tun.stencil != 0 && try_stencil_upper(nrows, A.ncols, b, w, get_upper, out);
                           },
                           cbytes, Lh.cmeta);
       A.colbytes = (int64_t)cbytes.size();
@@ -645,7 +631,7 @@ static int operator_build_device(qp_operator* op, int format, const std::vector<
       // distance delta_k, and the conj-transposed values sit at one slot per column block
       // (at most two column blocks per slot): position = pb(column block) + column % 64
       auto try_stencil_lower = [&](int64_t b, int64_t w, std::vector<char>& out) -> bool {
-        if (qp::g_stencil == 0) return false;
+        if (ctx->tun.stencil == 0) return false;
         std::vector<LowerStencilSlot> slots((size_t)w);
         for (int64_t k = 0; k < w; ++k) {
           LowerStencilSlot e{0, 0, -1, -1, 0};
@@ -818,6 +804,7 @@ int qp_operator_create(qp_ctx* ctx, qp_matrix* const* ops, int nops, int ncoeffs
   QP_CHECK(use(ctx));
   std::unique_ptr<qp_operator, int (*)(qp_operator*)> op(new qp_operator(), operator_free);
   op->ctx = ctx;
+  op->A.tun = &ctx->tun;
   op->nops = nops;
   op->ncoeffs = ncoeffs;
   op->coeffs.assign(ncoeffs, cplx(1.0));
@@ -904,7 +891,7 @@ static int operator_refresh(qp_operator* op) {
   }
   // real terms with real coefficients: the mat-vec kernels stream a real copy (8 instead of 16
   // bytes per value); everything else keeps reading the complex array
-  const bool want_real = qp::g_real_vals && op->planes_real && all_real && op->A.stored > 0;
+  const bool want_real = op->ctx->tun.real_vals && op->planes_real && all_real && op->A.stored > 0;
   if (want_real && !op->real_vals) QP_CHECK(dev_alloc(&op->real_vals, (size_t)op->A.stored));
   if (op->nops == 1 && all_one) {
     op->A.vals = op->planes[0];
@@ -975,6 +962,22 @@ int qp_operator_layout_info(const qp_operator* op, int64_t out[5]) {
   }
   out[3] = idx_bytes;
   return QP_OK;
+}
+
+int qp_operator_spmm_walk(qp_operator* op, int batch, int64_t out[2]) {
+  QP_TRY
+  if (!op || !out || batch < 1) return qp::fail(QP_E_BAD_ARG, "qp_operator_spmm_walk: bad arguments");
+  if (op->A.format == QP_FMT_MATFREE) return qp::fail(QP_E_BAD_ARG, "a matrix-free operator has no stored entries");
+  QP_CHECK(use(op->ctx));
+  out[0] = out[1] = 0;
+  if (qp::spmm_uses_rows_kernel(op->ctx->tun, batch)) {
+    const int32_t* order = nullptr;
+    QP_CHECK(operator_spmm_order(op, batch, &order));
+    out[0] = order ? op->m_order_g : 0;
+    out[1] = order ? op->m_order_sw : 0;
+  }
+  return QP_OK;
+  QP_CATCH
 }
 
 // download the *device* copy (current combined values and indices) back as canonical CSR
@@ -1205,6 +1208,100 @@ int qp_dot_op(const qp_state* x, qp_operator* op, const qp_state* y, qp_state* t
 
 // CSR-ordered mirror of the operator for the batched (SpMM) path and the persistent
 // small-system kernels, built lazily
+// Row walk for the batched kernel (kernels.hip: spmm_rows_kernel).  The pattern is
+// sampled for its offsets d = col - row (folded to (-n/2, n/2]); when the far ones (|d| >= 64) are all
+// multiples of one inner dimension g -- H = H_a (x) 1 + 1 (x) H_c, i = a g + c: lattice and tensor-product
+// operators -- the rows are listed strip by strip: `sw` consecutive inner indices c, all outer indices a
+// in turn.  Then the rows that gather a given row of X (its +-k g and +-near neighbours) are visited
+// within a few strip widths of each other instead of 2 a_max g rows apart, and the strip width is chosen
+// so that this window, plus the rows in flight, fits half an XCD's L2 at `batch` states per row.
+// Anything else (no far offsets, no common inner dimension, strips narrower than four times the near
+// reach) keeps the natural order.  Index work only: the arithmetic per row does not change.
+static void spmm_walk_host(const qp_operator* op, int batch, int knob, std::vector<int32_t>* order,
+                           int64_t* g_out, int64_t* sw_out) {
+  order->clear();
+  *g_out = *sw_out = 0;
+  const int64_t n = op->A.nrows;
+  const auto& ur = op->u_rowptr;
+  const auto& uc = op->u_col;
+  if (knob < 0 || n < 4096 || n > INT32_MAX || op->A.ncols != n || ur.empty()) return;
+  int64_t g = 0, far_max = 0, near_max = 0;
+  const int64_t nsample = std::min<int64_t>(n, 4096), stride = n / nsample;
+  for (int64_t t = 0; t < nsample; ++t) {
+    const int64_t r = t * stride;
+    for (int64_t p = ur[r]; p < ur[r + 1]; ++p) {
+      int64_t d = (int64_t)uc[p] - r;
+      if (d > n / 2) d -= n;
+      if (d <= -(n + 1) / 2) d += n;
+      d = std::llabs(d);
+      if (d >= 64) {
+        g = std::gcd(g, d);
+        far_max = std::max(far_max, d);
+      } else {
+        near_max = std::max(near_max, d);
+      }
+    }
+  }
+  if (g < 256 || far_max / g > 64) return;
+  const int64_t amax = far_max / g;
+  const int64_t l2_budget = 1280 * 1024;                 // under a third of an XCD's 4 MiB L2 for the gather window (measured at
+                                                         // 64 states: strips of 64 beat 128 and 32, profiles/r02/batched_c5_sweep.txt)
+  const int64_t row_bytes = (int64_t)std::min(batch, 64) * (int64_t)sizeof(double2);
+  int64_t sw;
+  if (knob > 0) {
+    sw = knob;
+  } else {
+    const int64_t inflight = 512;                         // rows an XCD has in flight (32 CUs x 16 waves)
+    sw = (l2_budget / row_bytes - inflight) / (2 * amax + 1);
+  }
+  sw = std::min(sw, g);
+  while (sw > 1 && g % sw != 0) --sw;                     // every strip the same width
+  if (sw < 1) return;
+  if (knob == 0 && (sw < 4 * std::max<int64_t>(near_max, 1) || sw < 16)) return;
+  if (sw >= g) return;                                    // one strip = the natural order
+  order->resize((size_t)n);
+  const int64_t na = (n + g - 1) / g;
+  size_t k = 0;
+  for (int64_t c0 = 0; c0 < g; c0 += sw)
+    for (int64_t a = 0; a < na; ++a)
+      for (int64_t c = c0; c < c0 + sw; ++c) {
+        const int64_t i = a * g + c;
+        if (i < n) (*order)[k++] = (int32_t)i;
+      }
+  if ((int64_t)k != n) {   // cannot happen; fall back to the natural order rather than skip rows
+    order->clear();
+    return;
+  }
+  *g_out = g;
+  *sw_out = sw;
+}
+
+int operator_spmm_order(qp_operator* op, int batch, const int32_t** order_out) {
+  qp_ctx* ctx = op->ctx;
+  const int knob = ctx->tun.spmm_strip;
+  if (op->m_order_valid && op->m_order_batch == batch && op->m_order_knob == knob) {
+    *order_out = op->m_order;
+    return QP_OK;
+  }
+  if (op->m_order) (void)hipFree(op->m_order);
+  op->m_order = nullptr;
+  op->m_order_valid = true;
+  op->m_order_batch = batch;
+  op->m_order_knob = knob;
+  op->m_order_g = op->m_order_sw = 0;
+  *order_out = nullptr;
+  std::vector<int32_t> order;
+  int64_t g = 0, sw = 0;
+  spmm_walk_host(op, batch, knob, &order, &g, &sw);
+  if (order.empty()) return QP_OK;
+  QP_CHECK(dev_alloc(&op->m_order, order.size()));
+  QP_HIP(hipMemcpy(op->m_order, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  op->m_order_g = g;
+  op->m_order_sw = sw;
+  *order_out = op->m_order;
+  return QP_OK;
+}
+
 int operator_csr_mirror(qp_operator* op, bool gather) {
   if (op->A.format == QP_FMT_MATFREE) return qp::fail(QP_E_BAD_ARG, "a matrix-free operator has no stored entries");
   qp_ctx* ctx = op->ctx;

@@ -83,7 +83,7 @@ int arnoldi_column(qp_operator* op, qp_krylov* q, int j, double dt, double2* hco
   pe.beta = make_double2(0.0, 0.0);
   pe.beta_zero = 1;
   QP_CHECK(qp::launch_spmv_plain(ctx->stream, op->A, q->q(j), pe, &ctx->stats));  // src/arnoldi.jl:82
-  if (qp::g_arnoldi_mode == 1 && q->gram_rows >= j && qp::mgs_lowsync_fits(j)) {
+  if (ctx->tun.arnoldi_mode == 1 && q->gram_rows >= j && qp::mgs_lowsync_fits(j)) {
     // low-synchronisation MGS: same coefficients (to rounding), 3 launches per column;
     // leaves |q[j+1]|^2 partials in part[(j+1)&1] like the sequential path.  Needs the Gram
     // rows of the earlier basis vectors, which only this path maintains (a basis built by
@@ -144,7 +144,7 @@ static int arnoldi_impl(qp_operator* op, qp_krylov* q, int m, const qp_state* ps
   qp::SmallArgs plan;
   bool small = false;
   bool piped = false;
-  if (qp::g_small_nnz > 0 && op->A.nnz <= (int64_t)qp::g_small_nnz * (qp::kSmallEptArnoldi / qp::kSmallEpt) &&
+  if (ctx->tun.small_nnz > 0 && op->A.nnz <= (int64_t)ctx->tun.small_nnz * (qp::kSmallEptArnoldi / qp::kSmallEpt) &&
       qp::small_arnoldi_fits(q->n, m)) {
     int64_t maxrow = 0;
     for (int64_t r = 0; r < q->n; ++r) maxrow = std::max<int64_t>(maxrow, op->u_rowptr[r + 1] - op->u_rowptr[r]);
@@ -474,7 +474,7 @@ int qp_newton_step(qp_newton* w, qp_operator* op, qp_state* psi, double dt, int 
     };
     QP_CHECK(arnoldi_impl(op, w->q, m_req, s == 0 ? psi : &vstate, dt, 1, norm_min,
                           reinterpret_cast<qp_c128*>(Hess.data()), ldh, &m, s == 0 ? &beta : nullptr,
-                          qp::g_newton_pipeline ? &eig_block : nullptr));
+                          ctx->tun.newton_pipeline ? &eig_block : nullptr));
     ms_arnoldi += ms_since(t0) - ms_eig_sweep - ms_fold_sweep;
     ms_eig += ms_eig_sweep;
     ms_leja += ms_fold_sweep;

@@ -282,7 +282,7 @@ int liouville_refresh(qp_operator* op) {
 int liouville_apply(hipStream_t s, void* self, const double2* x, double2* y, double2 alpha, double2 beta, Stats* st) {
   Liouville* L = static_cast<Liouville*>(self);
   const rocblas_int n = (rocblas_int)L->n;
-  if (L->n <= qp::g_liouville_fused_n && 2 + L->nc <= kMaxTerms) {
+  if (L->n <= L->ctx->tun.liouville_fused_n && 2 + L->nc <= kMaxTerms) {
     // two launches of the fused matrix-core kernel: T_k = A_k X (batched), then
     // Y = beta Y + alpha (M_L X - X M_R) + alpha scale s_d sum_k T_k A_k^+
     const cplx a(alpha.x, alpha.y);
@@ -356,6 +356,7 @@ int qp_liouvillian_create(qp_ctx* ctx, int64_t n, const qp_c128* const* H_terms,
   auto op = std::make_unique<qp_operator>();
   auto L = std::make_unique<Liouville>();
   op->ctx = ctx;
+  op->A.tun = &ctx->tun;
   L->ctx = ctx;
   L->n = n;
   L->nterms = nterms;

@@ -237,7 +237,7 @@ int qp_sharded_cheby_step(qp_sharded_cheby* s, const double* a, int n_coeffs, do
   cplx c = (dt > 0) ? cplx(0, -2.0) / Delta : cplx(0, 2.0) / Delta;      // :158-162
   const cplx phase = std::exp(cplx(0, -1) * beta * dt);                  // :211
   std::vector<qp_acc_defer> sched((size_t)nterms);
-  acc_schedule(a, n_coeffs, qp::g_acc_defer != 0, sched.data());
+  acc_schedule(a, n_coeffs, ctx->tun.acc_defer != 0, sched.data());
   const bool exchanging = d.M > 0;
   const bool overlap = d.split != nullptr;
   hipStream_t S_c = ctx->stream;

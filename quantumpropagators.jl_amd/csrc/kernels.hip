@@ -13,6 +13,8 @@
 // 16-B-per-lane fully coalesced streams, no atomics (bitwise run-to-run determinism is
 // required by check_propagator's reinit test), reductions finished in the *next*
 // kernel's prologue instead of an extra launch or an in-launch fence.
+#include <cstring>
+
 #include "device.h"
 
 namespace qp {
@@ -592,19 +594,139 @@ __global__ __launch_bounds__(kThreads) void csr_spmm_kernel(const int64_t* __res
   if (active) op.row(e, make_double2(acc0.x + acc1.x, acc0.y + acc1.y), pre, chk, nrm, e);
 }
 
-int g_newton_pipeline = 1;  // 1: newton! takes the Hessenberg columns as they arrive (eigenvalues overlap the sweep)
-int g_spmm_tile = 16;
+// ---------------------------------------------------------------------------
+// Batched states, one wavefront per row, lane = state (the default for panels of more than 32
+// states).  A matrix entry is the same for all 64 lanes: the wave loads the row's (value, column)
+// pairs once, one entry per lane in a single coalesced burst, and broadcasts them through SGPRs
+// (v_readlane), so the matrix is streamed ONCE for all states (the tiled kernel above streams it
+// 64 / TS times) and every gather of X[col, :] is one line-aligned 1-KiB wave access.
+//
+// What decides the speed is how often a row of X comes from HBM: row r is gathered by every row
+// i with H[i, r] != 0.  For H = H_a (x) 1 + 1 (x) H_c -- the lattice / tensor-product operators of
+// BASELINE's workloads: offsets +-1..4 and +-1024 k -- those rows are a span of 8192 rows apart in
+// natural order, 8 MiB of X at 64 states, twice an XCD's L2.  `order` (operator_spmm_order in
+// engine_core.hip) lists the rows strip by strip -- for a strip of `sw` inner indices c, all outer
+// indices a in turn, i = a g + c -- so that the +-k g neighbours are the rows visited just before and
+// just after, and the window a wave can hit in L2 shrinks to (2 a_max + 1) sw rows.  Any
+// permutation gives the same values bit for bit (rows are independent); it only moves traffic.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double readlane_f64(double v, int l) {   // l wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
 
-// nontemporal matrix and row-local streams in the batched kernel: 0 never, 2 always, 1 when one
-// panel vector is larger than what the caches could keep until the next launch anyway
-int g_spmm_nt = 1;
+// One wavefront walks RW consecutive positions of the row walk.  The dependent loads in front of a
+// row's gathers (walk position -> row, row pointers, the row's entries) are issued for all RW rows
+// together, so a row costs one round of up to 16 gathers instead of a chain of four memory latencies.
+template <class Op, int RW, int G>
+__global__ __launch_bounds__(kThreads) void spmm_rows_kernel(const int64_t* __restrict__ rowptr,
+                                                             const int32_t* __restrict__ cols,
+                                                             const double2* __restrict__ vals,
+                                                             const double2* __restrict__ X, int64_t nrows, int b, Op op,
+                                                             const int32_t* __restrict__ order) {
+  const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int64_t pos0 = ((int64_t)wg * (kThreads / 64) + wave) * RW;
+  if (pos0 >= nrows) return;
+  const int nr = (int)min((int64_t)RW, nrows - pos0);   // wave-uniform
+  const int st = blockIdx.y * 64 + lane;
+  const bool active = st < b;
+  const int stc = active ? st : b - 1;
+  const double2* __restrict__ Xs = X + stc;
+  // lanes 0 .. nr-1: row of walk position pos0 + lane and its pointer pair
+  int rv = 0;
+  int64_t pv0 = 0, pv1 = 0;
+  if (lane < nr) {
+    rv = order ? order[pos0 + lane] : (int)(pos0 + lane);
+    pv0 = rowptr[rv];
+    pv1 = rowptr[rv + 1];
+  }
+  int64_t rowi[RW], p0[RW];
+  int len[RW], mc[RW];
+  double2 mv[RW];
+#pragma unroll
+  for (int l = 0; l < RW; ++l) {
+    rowi[l] = __builtin_amdgcn_readlane(rv, l);
+    const int lo = __builtin_amdgcn_readlane((int)(pv0 & 0xffffffff), l), hi = __builtin_amdgcn_readlane((int)(pv0 >> 32), l);
+    p0[l] = ((int64_t)hi << 32) | (uint32_t)lo;
+    len[l] = __builtin_amdgcn_readlane((int)(pv1 - pv0), l);
+  }
+  // entries 0 .. 63 of every row: one coalesced load of values and one of columns per row, all in flight
+#pragma unroll
+  for (int l = 0; l < RW; ++l) {
+    mv[l] = make_double2(0.0, 0.0);
+    mc[l] = 0;
+    if (l < nr && lane < len[l]) {
+      mv[l] = ld_stream<Op::kStream>(vals + p0[l] + lane);
+      mc[l] = Op::kStream ? __builtin_nontemporal_load(cols + p0[l] + lane) : cols[p0[l] + lane];
+    }
+  }
+  double2 chk = make_double2(0.0, 0.0);
+  double nrm = 0.0;
+  // row-local operands of all RW rows first, their stores last: the wave's accesses to each of the
+  // streamed vectors (v0, the accumulator, the new term) come as one burst of RW KiB
+  typename Op::Pre pre[RW];
+  double2 res[RW];
+#pragma unroll
+  for (int l = 0; l < RW; ++l)
+    if (l < nr) pre[l] = op.pre(rowi[l] * (int64_t)b + stc);
+#pragma unroll
+  for (int l = 0; l < RW; ++l) {
+    if (l >= nr) break;
+    double2 acc0 = make_double2(0.0, 0.0), acc1 = make_double2(0.0, 0.0);
+    double2 cv = mv[l];
+    int cc = mc[l];
+    for (int k0 = 0; k0 < len[l]; k0 += 64) {
+      const int cnt = min(64, len[l] - k0);   // wave-uniform
+      if (k0 > 0) {
+        cv = make_double2(0.0, 0.0);
+        cc = 0;
+        if (lane < cnt) {
+          cv = ld_stream<Op::kStream>(vals + p0[l] + k0 + lane);
+          cc = Op::kStream ? __builtin_nontemporal_load(cols + p0[l] + k0 + lane) : cols[p0[l] + k0 + lane];
+        }
+      }
+      // the sums run in the order of csr_spmm_kernel: within groups of four, entries alternate between
+      // two partial sums; the remainder goes to the first.  Up to G gathers in flight.
+      int k = 0;
+#define QP_SPMM_GROUP(GG)                                                                              \
+  {                                                                                                    \
+    double2 x[GG];                                                                                     \
+    _Pragma("unroll") for (int u = 0; u < GG; ++u) x[u] = Xs[(int64_t)__builtin_amdgcn_readlane(cc, k + u) * b]; \
+    _Pragma("unroll") for (int u = 0; u < GG; u += 2) {                                                \
+      cfma(acc0, make_double2(readlane_f64(cv.x, k + u), readlane_f64(cv.y, k + u)), x[u]);            \
+      cfma(acc1, make_double2(readlane_f64(cv.x, k + u + 1), readlane_f64(cv.y, k + u + 1)), x[u + 1]); \
+    }                                                                                                  \
+    k += GG;                                                                                           \
+  }
+      if (G >= 16)
+        while (k + 15 < cnt) QP_SPMM_GROUP(16)
+      while (k + 7 < cnt) QP_SPMM_GROUP(8)
+      if (k + 3 < cnt) QP_SPMM_GROUP(4)
+#undef QP_SPMM_GROUP
+      for (; k < cnt; ++k)
+        cfma(acc0, make_double2(readlane_f64(cv.x, k), readlane_f64(cv.y, k)), Xs[(int64_t)__builtin_amdgcn_readlane(cc, k) * b]);
+    }
+    res[l] = make_double2(acc0.x + acc1.x, acc0.y + acc1.y);
+  }
+#pragma unroll
+  for (int l = 0; l < RW; ++l)
+    if (l < nr && active) {
+      const int64_t e = rowi[l] * (int64_t)b + stc;
+      op.row(e, res[l], pre[l], chk, nrm, e);
+    }
+}
 
+// knob spmm_nt -- nontemporal matrix and row-local streams in the batched kernel: 0 never, 2 always,
+// 1 when one panel vector is larger than what the caches could keep until the next launch anyway
 template <int TS>
 static void launch_spmm_cheby_t(hipStream_t s, const int64_t* rowptr, const int32_t* cols, const double2* vals,
-                                const double2* X, int64_t nrows, int b, const ChebyEpi& e) {
+                                const double2* X, int64_t nrows, int b, const ChebyEpi& e, int spmm_nt) {
   const int rpw = kThreads / TS;
   dim3 grid((unsigned)((nrows + rpw - 1) / rpw), (unsigned)((b + TS - 1) / TS));
-  const bool nt = g_spmm_nt == 2 || (g_spmm_nt == 1 && (double)nrows * b * sizeof(double2) >= 128.0 * 1024 * 1024);
+  const bool nt = spmm_nt == 2 || (spmm_nt == 1 && (double)nrows * b * sizeof(double2) >= 128.0 * 1024 * 1024);
   if (nt) {
     ChebyOpT<true> op{e};
     hipLaunchKernelGGL((csr_spmm_kernel<ChebyOpT<true>, TS>), grid, dim3(kThreads), 0, s, rowptr, cols, vals, X, nrows, b, op);
@@ -615,12 +737,35 @@ static void launch_spmm_cheby_t(hipStream_t s, const int64_t* rowptr, const int3
 }
 
 int launch_spmm_cheby(hipStream_t s, const int64_t* rowptr, const int32_t* cols, const double2* vals,
-                      const double2* X, int64_t nrows, int64_t nnz, int b, const ChebyEpi& e, Stats* st) {
+                      const double2* X, int64_t nrows, int64_t nnz, int b, const ChebyEpi& e, const Tuning& tun,
+                      bool rows_kernel, const int32_t* order, Stats* st) {
   if (nrows == 0) return QP_OK;
-  switch (g_spmm_tile) {
-    case 32: launch_spmm_cheby_t<32>(s, rowptr, cols, vals, X, nrows, b, e); break;
-    case 64: launch_spmm_cheby_t<64>(s, rowptr, cols, vals, X, nrows, b, e); break;
-    default: launch_spmm_cheby_t<16>(s, rowptr, cols, vals, X, nrows, b, e); break;
+  if (rows_kernel) {
+    const bool nt = tun.spmm_nt == 2 || (tun.spmm_nt == 1 && (double)nrows * b * sizeof(double2) >= 128.0 * 1024 * 1024);
+#define QP_SPMM_ROWS(RW)                                                                                         \
+  {                                                                                                              \
+    const int64_t per_wg = (int64_t)(kThreads / 64) * RW;                                                        \
+    dim3 grid((unsigned)((nrows + per_wg - 1) / per_wg), (unsigned)((b + 63) / 64));                             \
+    if (nt) {                                                                                                    \
+      ChebyOpT<true> op{e};                                                                                      \
+      hipLaunchKernelGGL((spmm_rows_kernel<ChebyOpT<true>, RW, 8>), grid, dim3(kThreads), 0, s, rowptr, cols, vals, X, nrows, b, op, order); \
+    } else {                                                                                                     \
+      ChebyOp op{e};                                                                                             \
+      hipLaunchKernelGGL((spmm_rows_kernel<ChebyOp, RW, 8>), grid, dim3(kThreads), 0, s, rowptr, cols, vals, X, nrows, b, op, order); \
+    }                                                                                                            \
+  }
+    switch (tun.spmm_rw) {
+      case 2: QP_SPMM_ROWS(2) break;
+      case 4: QP_SPMM_ROWS(4) break;
+      case 8: QP_SPMM_ROWS(8) break;
+      default: QP_SPMM_ROWS(1) break;
+    }
+#undef QP_SPMM_ROWS
+  } else
+  switch (tun.spmm_tile) {
+    case 32: launch_spmm_cheby_t<32>(s, rowptr, cols, vals, X, nrows, b, e, tun.spmm_nt); break;
+    case 64: launch_spmm_cheby_t<64>(s, rowptr, cols, vals, X, nrows, b, e, tun.spmm_nt); break;
+    default: launch_spmm_cheby_t<16>(s, rowptr, cols, vals, X, nrows, b, e, tun.spmm_nt); break;
   }
   QP_HIP(hipGetLastError());
   if (st) {
@@ -1053,12 +1198,27 @@ int launch_arnoldi_small(hipStream_t s, const SmallArnoldiArgs& a, Stats* st) {
   return QP_OK;
 }
 
-int g_small_nnz = kSmallThreads * kSmallEpt;   // x2 for systems that need the 32-slot variants
-int g_liouville_fused_n = 320;
-int g_real_vals = 1;
-int g_stencil = 1;
-int g_acc_defer = 1;
-int g_cheby_graph = 0;     // measured (profiles/r01/propagate_loop.txt): no gain over plain launches on ROCm 7.0, so off
+static_assert(kSmallThreads * kSmallEpt == 8192, "Tuning::small_nnz default = one register slot set (x2 for the 32-slot variants)");
+
+int* tuning_field(Tuning& t, const char* key) {
+  struct Entry {
+    const char* name;
+    int Tuning::*field;
+  };
+  static const Entry table[] = {
+      {"rbcsr_variant", &Tuning::rbcsr_variant}, {"hrb_lower_last", &Tuning::hrb_lower_last},
+      {"arnoldi_mode", &Tuning::arnoldi_mode},   {"split_mode", &Tuning::split_mode},
+      {"liouville_fused_n", &Tuning::liouville_fused_n}, {"real_vals", &Tuning::real_vals},
+      {"stencil", &Tuning::stencil},             {"acc_defer", &Tuning::acc_defer},
+      {"cheby_graph", &Tuning::cheby_graph},     {"small_nnz", &Tuning::small_nnz},
+      {"newton_pipeline", &Tuning::newton_pipeline}, {"spmm_tile", &Tuning::spmm_tile},
+      {"spmm_nt", &Tuning::spmm_nt},             {"spmm_rows", &Tuning::spmm_rows},
+      {"spmm_strip", &Tuning::spmm_strip},       {"spmm_rw", &Tuning::spmm_rw},
+  };
+  for (const Entry& e : table)
+    if (std::strcmp(e.name, key) == 0) return &(t.*(e.field));
+  return nullptr;
+}
 
 // lanes per row, entries per lane and rows per lane group such that the whole matrix is
 // register-resident; false when the system does not fit (the caller then runs the general loop)
@@ -1121,11 +1281,6 @@ int launch_cheby_propagate_small(hipStream_t s, const SmallArgs& a, Stats* st) {
   return QP_OK;
 }
 
-int g_hrb_lower_last = 0;
-int g_arnoldi_mode = 1;
-int g_split_mode = 1;
-int g_rbcsr_variant = 7;  // tuning knob (qp_tuning_set); 7 = nt + early row-local loads + deep unroll (A/B in profiles/)
-
 int spmv_grid_size(const DevMatrix& A) {
   if (A.format == QP_FMT_RBCSR || A.format == QP_FMT_HRB) return (int)((A.nblocks + kThreads / 64 - 1) / (kThreads / 64));
   const int64_t threads = A.nrows * A.lanes_per_row;
@@ -1140,6 +1295,8 @@ static int launch_spmv(hipStream_t s, const DevMatrix& A, const double2* x, cons
   const int32_t* bmap = nullptr;
   int64_t nblk = A.nblocks;
   const SyncArgs sy = rs ? rs->sync : SyncArgs();
+  static const Tuning kDefaults;
+  const Tuning& tun = A.tun ? *A.tun : kDefaults;
   if (rs && rs->block_map) {
     if (A.format != QP_FMT_RBCSR && A.format != QP_FMT_HRB) return fail(QP_E_BAD_ARG, "row sets need a row-block format");
     bmap = rs->block_map;
@@ -1157,7 +1314,7 @@ static int launch_spmv(hipStream_t s, const DevMatrix& A, const double2* x, cons
       hipLaunchKernelGGL((rbcsr_spmv_kernel<Op, VV, double2>), dim3(grid), dim3(kThreads), 0, s, A.bptr, A.cmeta, \
                          reinterpret_cast<const char*>(A.cols), A.vals, x, nblk, A.nrows, op, bmap, sy);   \
     break;
-    switch (g_rbcsr_variant & 7) {
+    switch (tun.rbcsr_variant & 7) {
       QP_RB_CASE(0)
       QP_RB_CASE(1)
       QP_RB_CASE(2)
@@ -1175,14 +1332,14 @@ static int launch_spmv(hipStream_t s, const DevMatrix& A, const double2* x, cons
       hipLaunchKernelGGL((hrb_spmv_kernel<Op, VV, double>), dim3(grid), dim3(kThreads), 0, s, A.bptr, A.cmeta, \
                          reinterpret_cast<const char*>(A.cols), A.vals_r, A.lptr, A.lcmeta,              \
                          reinterpret_cast<const char*>(A.lcols), reinterpret_cast<const int4*>(A.lpos), x, \
-                         nblk, A.nrows, op, bmap, sy, g_hrb_lower_last);                                 \
+                         nblk, A.nrows, op, bmap, sy, tun.hrb_lower_last);                                 \
     else                                                                                                 \
       hipLaunchKernelGGL((hrb_spmv_kernel<Op, VV, double2>), dim3(grid), dim3(kThreads), 0, s, A.bptr, A.cmeta, \
                          reinterpret_cast<const char*>(A.cols), A.vals, A.lptr, A.lcmeta,                \
                          reinterpret_cast<const char*>(A.lcols), reinterpret_cast<const int4*>(A.lpos), x, \
-                         nblk, A.nrows, op, bmap, sy, g_hrb_lower_last);                                 \
+                         nblk, A.nrows, op, bmap, sy, tun.hrb_lower_last);                                 \
     break;
-    switch (g_rbcsr_variant & 7) {
+    switch (tun.rbcsr_variant & 7) {
       QP_HRB_CASE(0)
       QP_HRB_CASE(1)
       QP_HRB_CASE(2)

@@ -98,6 +98,8 @@ SIGNATURES = {
     "qp_version": (C.c_int, []),
     "qp_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "qp_tuning_set": (C.c_int, [C.c_char_p, C.c_int]),
+    "qp_ctx_tuning_set": (C.c_int, [_P, C.c_char_p, C.c_int]),
+    "qp_ctx_tuning_get": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int)]),
     "qp_ctx_create": (C.c_int, [C.c_int, _P, C.POINTER(_P)]),
     "qp_ctx_destroy": (C.c_int, [_P]),
     "qp_sync": (C.c_int, [_P]),
@@ -119,6 +121,7 @@ SIGNATURES = {
     "qp_operator_info": (C.c_int, [_P, _i64p, _i64p, _i64p, C.POINTER(C.c_int)]),
     "qp_operator_get_csr": (C.c_int, [_P, _i64p, _i32p, _cp]),
     "qp_operator_layout_info": (C.c_int, [_P, _i64p]),
+    "qp_operator_spmm_walk": (C.c_int, [_P, C.c_int, _i64p]),
     "qp_state_create": (C.c_int, [_P, C.c_int64, C.POINTER(_P)]),
     "qp_state_wrap": (C.c_int, [_P, _P, C.c_int64, C.POINTER(_P)]),
     "qp_state_destroy": (C.c_int, [_P]),
@@ -238,8 +241,21 @@ def _ptr(a, typ):
     return a.ctypes.data_as(typ)
 
 
-def tuning_set(key, value):
+_live_contexts = weakref.WeakSet()
+
+
+def tuning_set(key, value, ctx=None):
+    """Developer knob.  With ``ctx``: that context only (``qp_ctx_tuning_set``).  Without: the default
+    for contexts created later (``qp_tuning_set``) AND every live ``Context`` of this Python process,
+    one by one -- a convenience for single-threaded A/B scripts; the library itself keeps no
+    process-global knob state."""
+    if ctx is not None:
+        ctx.tuning_set(key, value)
+        return
     check(load().qp_tuning_set(key.encode(), int(value)))
+    for c in list(_live_contexts):
+        if c._h:
+            c.tuning_set(key, value)
 
 
 def device_count():
@@ -356,6 +372,15 @@ class Context:
         check(self.lib.qp_ctx_create(int(device), sarg, C.byref(self._h)))
         self.device = int(device)
         self._children = weakref.WeakSet()   # handles that must be destroyed before the context
+        _live_contexts.add(self)
+
+    def tuning_set(self, key, value):
+        check(self.lib.qp_ctx_tuning_set(self._h, key.encode(), int(value)))
+
+    def tuning_get(self, key):
+        v = C.c_int(0)
+        check(self.lib.qp_ctx_tuning_get(self._h, key.encode(), C.byref(v)))
+        return v.value
 
     def _adopt(self, child):
         self._children.add(child)
@@ -478,6 +503,13 @@ class Operator:
         check(self.lib.qp_operator_layout_info(self._h, _ptr(out, _i64p)))
         return dict(zip(("blocks", "stencil_upper_blocks", "stencil_lower_blocks", "index_bytes", "stored"),
                         (int(v) for v in out)))
+
+    def spmm_walk(self, batch):
+        """Row walk of the batched kernel for ``batch`` states: (inner dimension, strip width), (0, 0)
+        for the natural row order."""
+        out = np.zeros(2, dtype=np.int64)
+        check(self.lib.qp_operator_spmm_walk(self._h, int(batch), _ptr(out, _i64p)))
+        return int(out[0]), int(out[1])
 
     def set_coeffs(self, coeffs):
         a, p = _as_c128(np.atleast_1d(coeffs))

@@ -1150,6 +1150,59 @@ def test_cheby_batched_streaming_variants_bit_identical(ctx, tile):
     assert np.max(np.abs(np.linalg.norm(outs[0].reshape(N, batch), axis=0) - 1.0)) < 1e-12
 
 
+@pytest.mark.parametrize("batch", [40, 64, 70])
+def test_cheby_batched_rows_kernel_and_row_walk_bit_identical(ctx, batch):
+    """Panels of more than 32 states take the wave-per-row kernel (lane = state, matrix entries
+    broadcast through SGPRs).  It sums a row in the order of the tiled kernel, and the strip-wise row
+    walk (tensor-structured H: far offsets multiples of g = 256 here) is index work only: tiled kernel,
+    natural order, automatic and forced strips, one to eight rows per wavefront all give the same bits,
+    and the oracle's values."""
+    N = 8192
+    rp, col, vals = synth.hermitian_offsets_csr(N, offsets=(1, 2, 3, 4, 256, 512, 768, 1024))
+    Op = L.Operator(ctx, [L.Matrix(ctx, N, N, rp, col, vals)])
+    H = synth.to_scipy(rp, col, vals, N)
+    states = np.stack([synth.random_state(N, seed=3000 + s) for s in range(batch)], axis=1)
+    outs, walks = {}, {}
+    try:
+        for rows, strip, rw in ((0, 0, 1), (1, -1, 1), (1, 0, 1), (1, 32, 1), (1, 64, 1), (1, 48, 1), (1, 32, 2), (1, 64, 4), (1, -1, 8)):
+            ctx.tuning_set("spmm_rows", rows)
+            ctx.tuning_set("spmm_strip", strip)
+            ctx.tuning_set("spmm_rw", rw)
+            wrk = L.ChebyWrk(ctx, N * batch, 20.0, -10.0, 0.7)
+            panel = L.State(ctx, data=states.reshape(-1))
+            for dt in (0.7, -0.7, 0.7):
+                L.cheby_batched(panel, Op, dt, wrk, batch)
+            outs[(rows, strip, rw)] = panel.numpy()
+            if rw == 1:
+                walks[(rows, strip)] = Op.spmm_walk(batch)
+    finally:
+        ctx.tuning_set("spmm_rows", 1)
+        ctx.tuning_set("spmm_strip", 0)
+        ctx.tuning_set("spmm_rw", 1)
+    ref = outs[(0, 0, 1)]
+    for k, v in outs.items():
+        assert np.array_equal(v, ref), k
+    assert walks[(1, -1)] == (0, 0)
+    assert walks[(1, 32)] == (256, 32) and walks[(1, 64)] == (256, 64)
+    assert walks[(1, 48)] == (256, 32)          # strips divide the inner dimension
+    owrk = qo.ChebyWrk(states[:, 0].copy(), 20.0, -10.0, 0.7)
+    for s in (0, batch - 1):
+        r = qo.cheby(states[:, s].copy(), H, 0.7, owrk)
+        assert np.linalg.norm(ref.reshape(N, batch)[:, s] - r) < TOL
+
+
+def test_spmm_row_walk_detection(ctx):
+    """Which patterns get a strip-wise row walk: the BASELINE lattice (inner dimension 1024, strips of
+    64 inner indices at 64 states); not a scattered pattern (no common inner dimension), not a
+    plain band (no far offsets)."""
+    N = 1 << 15
+    for offs, want in ((synth.BANDED_OFFSETS, (1024, 64)), (synth.scattered_offsets(N), (0, 0)), ((1, 2, 3, 4, 5, 6, 7, 8), (0, 0))):
+        rp, col, vals = synth.hermitian_offsets_csr(N, offsets=offs)
+        Op = L.Operator(ctx, [L.Matrix(ctx, N, N, rp, col, vals)])
+        assert Op.spmm_walk(64) == want, (offs, Op.spmm_walk(64))
+        Op.close()
+
+
 @pytest.mark.parametrize("N", [100, 128])
 def test_newton_dense_128_persistent_arnoldi(ctx, N):
     """Config C1's size through newton!: 10000 / 16384 stored entries run the Arnoldi sweeps in the

@@ -22,6 +22,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--tile", type=int, default=16)
     ap.add_argument("--nt", type=int, default=None, help="nontemporal streams in the batched kernel (knob spmm_nt)")
+    ap.add_argument("--rows", type=int, default=1, help="1 = wave-per-row kernel, lane = state (default for > 32 states); 0 = state-tiled kernel")
+    ap.add_argument("--offsets", default="", help="comma-separated offsets instead of the banded lattice pattern (diagnostics)")
+    ap.add_argument("--rw", type=int, default=1, help="rows per wavefront of the wave-per-row kernel (1, 2, 4, 8)")
+    ap.add_argument("--strip", type=int, default=0, help="row walk of the wave-per-row kernel: strip width (0 = automatic, -1 = natural order)")
     args = ap.parse_args()
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -36,9 +40,13 @@ def main():
     N, b_total = 1 << args.log2n, args.batch
     b = b_total // world                     # this rank's share of the states
     s0 = rank * b
-    rp, col, vals = synth.hermitian_offsets_csr(N)
+    rp, col, vals = synth.hermitian_offsets_csr(N, offsets=tuple(int(o) for o in args.offsets.split(","))) if args.offsets else \
+        synth.hermitian_offsets_csr(N)
     ctx = L.Context(local_rank)
     L.tuning_set("spmm_tile", args.tile)
+    L.tuning_set("spmm_rows", args.rows)
+    L.tuning_set("spmm_strip", args.strip)
+    L.tuning_set("spmm_rw", args.rw)
     if args.nt is not None:
         L.tuning_set("spmm_nt", args.nt)
     op = L.Operator(ctx, [L.Matrix(ctx, N, N, rp, col, vals)])
@@ -65,6 +73,7 @@ def main():
         t = torch.tensor([el, ev], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el, ev = float(t[0]), float(t[1])
+    kern = "spmm_rows_kernel (wave per row, lane = state)" if (args.rows >= 1 and b > 32) else "csr_spmm_kernel (state-tiled)"
     alg = 20.0 * nnz + 4.0 * (N + 1) + 80.0 * N * b          # SURVEY 8d batched model per term
     per_term = ev * 1e-3 / (args.steps * nterms)
     norms = np.linalg.norm(panel.numpy().reshape(N, b), axis=0)
@@ -83,10 +92,11 @@ def main():
         "metric": "batched Cheby prop_step!/s, 64 states x N=2^18 CSR (BASELINE configs[4])",
         "value": args.steps / el, "unit": "panel prop_step/s", "state_steps_per_s": b_total * args.steps / el,
         "ms_per_panel_step": 1e3 * el / args.steps, "n_gpus": world, "scaling": "strong (batch split, no communication)",
-        "config": {"N": N, "batch": b_total, "states_per_gpu": b, "states_per_pass": args.tile, "nnz_per_row": nnz / N, "matvecs_per_step": nterms},
+        "config": {"N": N, "batch": b_total, "states_per_gpu": b, "row_walk": dict(zip(("inner_dimension", "strip_width"), op.spmm_walk(b))),
+                   "kernel": kern, "nnz_per_row": nnz / N, "matvecs_per_step": nterms},
         "roofline": {"bound": "hbm", "achieved": alg / per_term / 1e9, "peak": 8000.0, "unit": "GB/s",
                      "frac": alg / per_term / 1e9 / 8000.0, "algorithmic_bytes_per_launch": alg,
-                     "avg_launch_us": per_term * 1e6, "kernel": "csr_spmm_kernel<ChebyOp>"},
+                     "avg_launch_us": per_term * 1e6, "kernel": kern},
         "single_state_ms_per_step_same_N": ev1, "speedup_vs_one_state_at_a_time": b * ev1 / (1e3 * el / args.steps),
         "max_norm_drift": float(np.max(np.abs(norms - 1.0)))}))
     if dist is not None:

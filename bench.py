@@ -1,31 +1,82 @@
 #!/usr/bin/env python3
-"""Headline benchmark: Chebyshev ``prop_step!``/s on the BASELINE.json config C2
-(N = 2^20 rows per GPU, CSR sparse Hermitian H with 16 nnz/row, complex fp64,
-manual spectral range [-10, 10], dt = 1 => 32 coefficients = 31 fused mat-vec terms).
+"""Headline benchmark: Chebyshev ``prop_step!``/s on BASELINE.json's configs.
 
-    python bench.py                      # = --gpus 1 --steps 100 --warmup 10, about 20 s with the CPU baselines
+    python bench.py                      # = --gpus 1 --steps 100 --warmup 10: config C2, a few minutes with
+                                         #   the PMC passes, the CPU baselines and the extra points
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one ``prop_step!`` = one pass of the hot path (31 fused SpMV terms) over the
-state.  For N > 1 the CSR rows are partitioned across the ranks (2^20 rows per GPU, weak
-scaling) and the needed slices of the term vector are exchanged over RCCL after every
-mat-vec.  Rank 0 prints ONE JSON line.
+One "step" = one ``prop_step!`` = one pass of the hot path (31 fused SpMV terms at dt = 1) over the state.
+
+* N = 1 (``--config c2``, the default there): BASELINE configs[1], N = 2^20 rows, CSR sparse Hermitian H with
+  16 nnz/row, complex fp64, manual spectral range [-10, 10].
+* N > 1 (``--config c4``, the default there): BASELINE configs[3], 2^21 rows per GPU (N = 2^24 at 8 GPUs) row-partitioned,
+  the needed slices of the term vector exchanged over RCCL after every mat-vec; weak scaling.  ``value`` counts
+  2^20-row blocks advanced per second, the unit of the one-GPU line, so the driver's per-N values compare.  The
+  STRONG point BASELINE's metric also names (N = 2^20 in total, split over the ranks) is measured after the timed
+  region and reported under ``strong_scaling_point``; ``--config c2 --scaling strong`` makes it the headline.
+
+Rank 0 prints ONE JSON line.  ``roofline.frac`` prices the bytes the SHIPPED device layout has to move
+(tools/bench_points.py: cheby_layout_bytes) and cannot exceed 1; the contract's CSR figure is kept as
+``roofline.effective_csr_equiv_gbs``.  ``roofline.traffic`` is measured in this run: two child processes of this
+script under ``rocprofv3 --pmc`` (FETCH_SIZE, WRITE_SIZE; one pass each as the pool requires), or, if the profiler
+is not usable, the value of the committed profile, labelled as such.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s measured copy)
+KERNEL_OF_FORMAT = {1: "csr_spmv_kernel", 2: "rbcsr_spmv_kernel", 3: "hrb_spmv_kernel"}
+STATIC_PMC = os.path.join("profiles", "r02", "bench_pmc_summary.json")
+
+
+def pmc_traffic(argv_inner, kernel_substr, timeout_s):
+    """HBM bytes per launch of the dominant kernel, measured now: this script re-run as a CHILD process
+    under rocprofv3, one pass per counter (the guide's HBM / rocprofv3 recipe: FETCH_SIZE x 2 on gfx950,
+    WRITE_SIZE as is, units KiB).  Returns (bytes, detail) or (None, reason)."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    env = dict(os.environ, TMPDIR="/tmp")
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="qp_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--",
+               sys.executable, os.path.join(ROOT, "bench.py")] + argv_inner
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+        except (subprocess.TimeoutExpired, OSError) as e:
+            shutil.rmtree(out, ignore_errors=True)
+            return None, f"{counter} pass failed: {type(e).__name__}"
+        got = []
+        for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+            with open(f) as fh:
+                for row in csv.DictReader(fh):
+                    if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                        got.append(float(row["Counter_Value"]))
+        shutil.rmtree(out, ignore_errors=True)
+        if r.returncode != 0 or not got:
+            return None, f"{counter} pass: rc {r.returncode}, {len(got)} dispatches of {kernel_substr}"
+        vals[counter] = (sum(got) / len(got) * 1024.0, len(got))
+    fetch, write = 2.0 * vals["FETCH_SIZE"][0], vals["WRITE_SIZE"][0]
+    return fetch + write, {"FETCH_SIZE_bytes_x2": fetch, "WRITE_SIZE_bytes": write,
+                           "dispatches": [vals["FETCH_SIZE"][1], vals["WRITE_SIZE"][1]]}
 
 
 def main():
@@ -33,20 +84,28 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--log2n", type=int, default=20, help="rows per GPU = 2^log2n")
-    ap.add_argument("--pattern", default="banded", choices=["banded", "scattered"])
+    ap.add_argument("--config", default="auto", choices=["auto", "c2", "c4"],
+                    help="c2: BASELINE configs[1], 2^20 rows per GPU (default at 1 GPU); c4: configs[3], 2^21 rows per GPU = "
+                         "N 2^24 at 8 GPUs (default at more than 1)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: rows per GPU fixed; strong: 2^log2n rows in TOTAL, split over the GPUs")
+    ap.add_argument("--log2n", type=int, default=None, help="rows per GPU (weak) or in total (strong) = 2^log2n; overrides --config")
+    ap.add_argument("--pattern", default="banded", choices=["banded", "scattered", "random", "random-window"])
     ap.add_argument("--format", default="auto", choices=["auto", "hrb", "rbcsr", "csr"])
     ap.add_argument("--exchange", default="auto", choices=["auto", "halo", "allgather"])
     ap.add_argument("--dt", type=float, default=1.0, help="time step; alpha = 10 dt, i.e. 32 coefficients at dt = 1 "
                     "(SURVEY 8d also asks for alpha = 2 and 50: --dt 0.2 / --dt 5)")
     ap.add_argument("--real", action="store_true", help="real-symmetric H (the f64 variant of SURVEY 8d): values "
-                    "are streamed as fp64; algorithmic bytes (12 z + 84) N")
+                    "are streamed as fp64")
     ap.add_argument("--schedule", default="auto", choices=["auto", "overlap", "serial"],
                     help="N > 1: boundary/interior overlap of the exchange, the exchange in line, or whichever a short trial finds faster")
     ap.add_argument("--driver", default="native", choices=["native", "torch"],
                     help="multi-GPU step: one library call with its own RCCL communicator, or the Python loop")
     ap.add_argument("--cpu-steps", type=int, default=16,
                     help="steps of the CPU baseline sample (0 = skip); 16 steps ~ 10 s of one core")
+    ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with rocprofv3 child runs")
+    ap.add_argument("--no-extras", action="store_true", help="headline only: no extra points (formats, patterns, C3, C5)")
+    ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling point")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -73,23 +132,42 @@ def main():
 
     import qprop_amd.lib as L
     import qprop_amd.synth as synth
+    import bench_points as bp
 
-    rows = 1 << args.log2n
-    N = rows * world
+    config = args.config if args.config != "auto" else ("c2" if world == 1 else "c4")
+    log2n = args.log2n if args.log2n is not None else (20 if config == "c2" else 21)
+    if args.scaling == "strong":
+        if (1 << log2n) % world:
+            raise SystemExit("--scaling strong needs a rank count that divides 2^log2n")
+        N = 1 << log2n
+        rows = N // world
+    else:
+        rows = 1 << log2n
+        N = rows * world
+    if args.pattern.startswith("random") and world > 1:
+        raise SystemExit("the random patterns are single-GPU points")
     r0, r1 = rank * rows, (rank + 1) * rows
-    offsets = synth.BANDED_OFFSETS if args.pattern == "banded" else synth.scattered_offsets(N)
     Delta, E_min, dt = 20.0, -10.0, args.dt    # manual range [-10,10], specrange_buffer=0
     fmt = {"auto": L.FMT_AUTO, "hrb": L.FMT_HRB, "rbcsr": L.FMT_RBCSR, "csr": L.FMT_CSR}[args.format]
 
     stream = torch.cuda.current_stream().cuda_stream
     ctx = L.Context(local_rank, stream=stream)
-    rp, col, vals = synth.hermitian_offsets_csr(N, offsets=offsets, row_begin=r0, row_end=r1)
+    rp, col, vals = bp.pattern_csr(args.pattern, N, r0, r1)
     if args.real:
         vals = vals.real.astype(np.complex128)
     psi0_local = synth.random_state(N, row_begin=r0, row_end=r1)
     nnz_local = int(rp[-1])
     coeffs = L.cheby_coeffs(Delta, dt)
     nterms = len(coeffs) - 1
+
+    def barrier():
+        torch.cuda.synchronize()     # nothing of ours in flight while the barrier's collective runs
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def dev_tensor(x):
+        return torch.tensor(x, dtype=torch.float64, device="cpu" if one_gpu else "cuda")
 
     parity = None
     cpu = None
@@ -98,8 +176,6 @@ def main():
         op = L.Operator(ctx, [L.Matrix(ctx, rows, N, rp, col, vals)], 0, fmt)
         wrk = L.ChebyWrk(ctx, N, Delta, E_min, dt)
         psi = L.State(ctx, data=psi0_local)
-        fmt_used = op.format
-        layout = op.layout_info()
 
         def step():
             L.cheby(psi, op, dt, wrk)
@@ -117,34 +193,39 @@ def main():
                 psi.upload(psi0_local)
                 cpsi = psi0_local.copy()
                 colptr, rowval, nzval = rp, col.astype(np.int64), np.conj(vals)   # Hermitian: CSC(H) = conj CSR(H)
+                ref_c.load()
+                flags = ref_c.build_flags()
                 t0 = time.perf_counter()
                 for _ in range(args.cpu_steps):
                     ref_c.cheby_csc(colptr, rowval, nzval, cpsi, coeffs, Delta, E_min, dt)
                 tc = time.perf_counter() - t0
                 parity = float(np.linalg.norm(gpu_k - cpsi))
                 cpu = {"value": args.cpu_steps / tc, "unit": "prop_step/s", "cores": 1, "kind": "port",
-                       "sample": f"{args.cpu_steps} prop_steps of the same N=2^{args.log2n} workload "
-                                 f"(oracle/cheby_ref.c: serial CSC SpMV + BLAS-1, reference operation order)",
+                       "sample": f"{args.cpu_steps} prop_steps of the same N=2^{log2n} workload "
+                                 f"(oracle/cheby_ref.c: serial CSC SpMV + BLAS-1, reference operation order; gcc {flags})",
                        "ms_per_step": 1e3 * tc / args.cpu_steps,
                        "l2_diff_vs_gpu_after_sample": parity}
                 del colptr, rowval, nzval, cpsi
-                # the same arithmetic with every host core: row-parallel CSR, passes fused (OpenMP)
+                # the same arithmetic with every host core: row-parallel CSR, passes fused (OpenMP), every
+                # buffer first touched by the thread that works on it
                 nthreads = ref_c.omp_threads()
-                opsi = psi0_local.copy()
-                col64 = col.astype(np.int64)
-                ref_c.cheby_csr_omp(rp, col64, vals, opsi, coeffs, Delta, E_min, dt)       # warm-up, first touch
-                opsi = psi0_local.copy()
+                omp = ref_c.ChebyCsrOmp(rp, col.astype(np.int64), vals, psi0_local)
+                omp.step(coeffs, Delta, E_min, dt)       # warm-up
                 osteps = 2 * args.cpu_steps
                 t0 = time.perf_counter()
                 for _ in range(osteps):
-                    ref_c.cheby_csr_omp(rp, col64, vals, opsi, coeffs, Delta, E_min, dt)
+                    omp.step(coeffs, Delta, E_min, dt)
                 to = time.perf_counter() - t0
+                omp.close()
                 cpu_omp = {"value": osteps / to, "unit": "prop_step/s", "cores": int(nthreads), "kind": "port",
                            "sample": f"{osteps} prop_steps of the same workload (oracle/cheby_ref.c: OpenMP row-parallel CSR "
-                                     f"mat-vec with the term's BLAS-1 passes fused into the row loop)",
+                                     f"mat-vec with the term's BLAS-1 passes fused into the row loop, buffers first touched "
+                                     f"in parallel; gcc {flags})",
                            "ms_per_step": 1e3 * to / osteps}
-                del col64, opsi
         exchange_used = "none"
+        schedule_note = driver_note = None
+        ncols_local = N
+        op_for_layout = op
     else:
         import qprop_amd.sharded as sharded
         # native: the whole step is one library call and the exchange runs on an RCCL
@@ -153,79 +234,86 @@ def main():
         # if, on every rank, one step of it reproduces the torch-driven step bit for bit.
         want_native = args.driver == "native"     # (test mode: callback communicator, host-staged)
 
-        def build(overlap):
-            """One schedule of the partitioned step, ready to run: (stepper, native?, note)."""
-            sh_ = sharded.ShardedCheby(ctx, rp, col, vals, N, r0, r1, Delta, E_min, dt, fmt=fmt, exchange=args.exchange,
-                                       host_staged=one_gpu, native=want_native, overlap=overlap)
-            nat = sh_.native is not None
-            if nat:
-                sh_.set_state(psi0_local)
-                sh_.step(native=True)
-                torch.cuda.synchronize()
-                got = sh_.local_state()
-                sh_.set_state(psi0_local)
-                sh_.step(native=False)
-                torch.cuda.synchronize()
-                same = torch.tensor([1 if np.array_equal(got, sh_.local_state()) else 0], device="cpu" if one_gpu else "cuda")
-                dist.all_reduce(same, op=dist.ReduceOp.MIN)
-                nat = bool(same.item())
-                how = ("exchange handed back through a callback communicator" if one_gpu else
-                       "RCCL communicator of the library, " + ("ncclSend/ncclRecv with the neighbours" if sh_.p2p else "ncclAllGather"))
-                note = f"native (library step, {how})" if nat else \
-                    "torch.distributed (native step disagreed with it in the self-check)"
-            else:
-                note = "torch.distributed (step loop in Python" + (
-                    f"; native driver unavailable: {sh_.native_error})" if getattr(sh_, "native_error", None) else ")")
-            sh_.set_state(psi0_local)
-            return sh_, nat, note
+        def make_stepper(rp_, col_, vals_, N_, r0_, r1_, psi0_):
+            """Both schedules of the partitioned step for one problem -> (stepper, native?, exchange, notes, layout op)."""
+            def build(overlap):
+                sh_ = sharded.ShardedCheby(ctx, rp_, col_, vals_, N_, r0_, r1_, Delta, E_min, dt, fmt=fmt, exchange=args.exchange,
+                                           host_staged=one_gpu, native=want_native, overlap=overlap)
+                nat = sh_.native is not None
+                if nat:
+                    sh_.set_state(psi0_)
+                    sh_.step(native=True)
+                    torch.cuda.synchronize()
+                    got = sh_.local_state()
+                    sh_.set_state(psi0_)
+                    sh_.step(native=False)
+                    torch.cuda.synchronize()
+                    same = torch.tensor([1 if np.array_equal(got, sh_.local_state()) else 0], device="cpu" if one_gpu else "cuda")
+                    dist.all_reduce(same, op=dist.ReduceOp.MIN)
+                    nat = bool(same.item())
+                    how = ("exchange handed back through a callback communicator" if one_gpu else
+                           "RCCL communicator of the library, " + ("ncclSend/ncclRecv with the neighbours" if sh_.p2p else "ncclAllGather"))
+                    note = f"native (library step, {how})" if nat else \
+                        "torch.distributed (native step disagreed with it in the self-check)"
+                else:
+                    note = "torch.distributed (step loop in Python" + (
+                        f"; native driver unavailable: {sh_.native_error})" if getattr(sh_, "native_error", None) else ")")
+                sh_.set_state(psi0_)
+                return sh_, nat, note
 
-        def trial(sh_, nat, k=4):
-            """Seconds per step of a schedule, the slowest rank's (every rank sees the same number)."""
-            sh_.set_state(psi0_local)
-            for _ in range(2):
-                sh_.step(native=nat)
-            torch.cuda.synchronize()
-            dist.barrier()
-            t0_ = time.perf_counter()
-            for _ in range(k):
-                sh_.step(native=nat)
-            torch.cuda.synchronize()
-            t_ = torch.tensor([(time.perf_counter() - t0_) / k], dtype=torch.float64, device="cpu" if one_gpu else "cuda")
-            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
-            sh_.set_state(psi0_local)
-            return float(t_[0])
+            def trial(sh_, nat, k=4):
+                """Seconds per step of a schedule, the slowest rank's (every rank sees the same number)."""
+                sh_.set_state(psi0_)
+                for _ in range(2):
+                    sh_.step(native=nat)
+                torch.cuda.synchronize()
+                dist.barrier()
+                t0_ = time.perf_counter()
+                for _ in range(k):
+                    sh_.step(native=nat)
+                torch.cuda.synchronize()
+                t_ = dev_tensor([(time.perf_counter() - t0_) / k])
+                dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+                sh_.set_state(psi0_)
+                return float(t_[0])
 
-        # Two schedules of the same arithmetic (bit-identical results): the boundary / interior overlap
-        # hides the exchange behind the interior launch but pays for a second stream; the serial one has
-        # the exchange in line.  Which is faster depends on the exchange latency of the machine, so both
-        # are timed for a few steps before the measurement and the faster one is measured ("auto").
-        sh, use_native, driver_note = build(args.schedule != "serial")
-        schedule_note = args.schedule
-        has_split = torch.tensor([1 if sh.split is not None else 0], device="cpu" if one_gpu else "cuda")
-        dist.all_reduce(has_split, op=dist.ReduceOp.MIN)      # the same decision on every rank
-        if args.schedule == "auto" and bool(has_split.item()):
-            sh2, nat2, note2 = build(False)
-            t_overlap, t_serial = trial(sh, use_native), trial(sh2, nat2)
-            schedule_note = f"auto: overlap {1e3 * t_overlap:.3f} ms/step, serial {1e3 * t_serial:.3f} ms/step"
-            if t_serial < t_overlap:
-                sh, sh2, use_native, driver_note = sh2, sh, nat2, note2
-                schedule_note += " -> serial"
-            else:
-                schedule_note += " -> overlap"
-            sh2.close()
-            del sh2
-        fmt_used = sh.op.format
-        layout = sh.op.layout_info()
+            # Two schedules of the same arithmetic (bit-identical results): the boundary / interior overlap
+            # hides the exchange behind the interior launch but pays for a second stream; the serial one has
+            # the exchange in line.  Which is faster depends on the exchange latency of the machine, so both
+            # are timed for a few steps before the measurement and the faster one is measured ("auto").
+            sh_, nat, dnote = build(args.schedule != "serial")
+            snote = args.schedule
+            has_split = torch.tensor([1 if sh_.split is not None else 0], device="cpu" if one_gpu else "cuda")
+            dist.all_reduce(has_split, op=dist.ReduceOp.MIN)      # the same decision on every rank
+            if args.schedule == "auto" and bool(has_split.item()):
+                sh2, nat2, note2 = build(False)
+                t_overlap, t_serial = trial(sh_, nat), trial(sh2, nat2)
+                snote = f"auto: overlap {1e3 * t_overlap:.3f} ms/step, serial {1e3 * t_serial:.3f} ms/step"
+                if t_serial < t_overlap:
+                    sh_, sh2, nat, dnote = sh2, sh_, nat2, note2
+                    snote += " -> serial"
+                else:
+                    snote += " -> overlap"
+                sh2.close()
+                del sh2
+            return sh_, nat, snote, dnote
+
+        sh, use_native, schedule_note, driver_note = make_stepper(rp, col, vals, N, r0, r1, psi0_local)
         exchange_used = sh.exchange
+        ncols_local = rows + world * sh.M     # the local slice plus the ghost slots the exchange fills
+        op_for_layout = sh.op
 
         def step():
             sh.step(native=use_native)
 
+    fmt_used = op_for_layout.format
+    model = bp.cheby_layout_bytes(op_for_layout, rows, ncols_local, nnz_local, coeffs, real_copy=args.real)
+    layout = model["layout"]
+
     pcie = None
     if world == 1 and os.environ.get("QP_BENCH_PCIE") == "1":
-        # what a host-resident caller (the Julia glue without a device state type) would see:
+        # what a host-resident caller (a glue layer without a device state type) would see:
         # the state is downloaded after every step.  Reported separately, never as `value`.
-        # The caller's array is registered (pinned) once, as the glue does for the propagator's state.
         host = L.host_register(np.empty(N, dtype=np.complex128))
         for _ in range(3):
             step()
@@ -236,12 +324,6 @@ def main():
             psi.download(host)
         pcie = 20 / (time.perf_counter() - t0p)
         L.host_unregister(host)
-
-    def barrier():
-        torch.cuda.synchronize()     # nothing of ours in flight while the barrier's collective runs
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     # on-box streaming ceiling: y += a x over 2^26 complex elements, 48 B per element
     stream_gbs = None
@@ -277,47 +359,108 @@ def main():
         print(f"[debug] rank {rank}: enqueue {1e3*t_enq:.2f} ms, +events {1e3*t_ev:.2f} ms, +sync/barrier "
               f"{1e3*elapsed:.2f} ms, hip events {ev_ms:.2f} ms", file=sys.stderr)
     st = ctx.stats()
-    if world == 1 and args.cpu_steps > 0:
-        cpu_baselines()  # after the timed region: 16 busy OpenMP threads must not sit next to the measurement
     if world > 1:
         sh.check()      # outside the timed region: the overlapped schedule never timed out
     if dist is not None:
-        t = torch.tensor([elapsed, ev_ms], dtype=torch.float64, device="cpu" if one_gpu else "cuda")
+        t = dev_tensor([elapsed, ev_ms])
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, ev_ms = float(t[0]), float(t[1])
 
-    # HBM traffic per launch of the dominant kernel: PMC counters need their own rocprofv3
-    # passes (tools/profile.sh), so the value measured for this exact command is read back
-    # from the committed summary under profiles/ (null when there is none for this kernel)
-    traffic = None
-    kern = {1: "csr_spmv_kernel<16,ChebyOp>", 2: "rbcsr_spmv_kernel<ChebyOp,7>", 3: "hrb_spmv_kernel<ChebyOp,7>"}[fmt_used]
-    pmc_file = os.path.join(ROOT, "profiles", "r01", "bench_final_pmc_summary.json")
-    if (fmt_used == 3 and world == 1 and args.log2n == 20 and args.pattern == "banded" and not args.real and
-            os.path.exists(pmc_file)):
-        with open(pmc_file) as f:
-            traffic = json.load(f)["hbm_traffic_bytes_per_launch"]
+    # ---- N > 1: the strong-scaling point of BASELINE's metric (N = 2^20 in total) ----------------------
+    strong = None
+    if world > 1 and args.scaling == "weak" and not args.no_strong and (1 << 20) % world == 0:
+        Ns = 1 << 20
+        rs = Ns // world
+        s0, s1 = rank * rs, (rank + 1) * rs
+        rps, cols_, valss = bp.pattern_csr(args.pattern, Ns, s0, s1)
+        psis = synth.random_state(Ns, row_begin=s0, row_end=s1)
+        sh_s, nat_s, snote_s, dnote_s = make_stepper(rps, cols_, valss, Ns, s0, s1, psis)
+        ksteps = max(10, args.steps // 2)
+        for _ in range(5):
+            sh_s.step(native=nat_s)
+        barrier()
+        t0s = time.perf_counter()
+        for _ in range(ksteps):
+            sh_s.step(native=nat_s)
+        torch.cuda.synchronize()
+        dist.barrier()
+        ts = dev_tensor([time.perf_counter() - t0s])
+        dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+        sh_s.check()
+        strong = {"workload": "Cheby prop_step!, N=2^20 CSR fp64 in TOTAL, row-partitioned over the ranks (strong scaling)",
+                  "N_total": Ns, "rows_per_gpu": rs, "steps": ksteps, "prop_steps_per_s": ksteps / float(ts[0]),
+                  "ms_per_step": 1e3 * float(ts[0]) / ksteps, "exchange": sh_s.exchange, "schedule": snote_s, "driver": dnote_s}
+        sh_s.close()
+        del sh_s
 
     steps_per_s = args.steps / elapsed
     n_launch = args.steps * nterms
-    # algorithmic bytes of one fused term on one GPU: (20 z + 84) N + 4
-    alg_bytes = (12.0 if args.real else 20.0) * nnz_local + 4.0 * (rows + 1) + 80.0 * rows
     avg_launch_s = (ev_ms * 1e-3) / n_launch
-    achieved = alg_bytes / avg_launch_s / 1e9
+    achieved = model["per_term"] / avg_launch_s / 1e9
+    csr_equiv = model["csr_equivalent_per_term"] / avg_launch_s / 1e9
+    kern = KERNEL_OF_FORMAT[fmt_used] + "<ChebyOp>"
+    blocks_per_step = N / float(1 << 20)
+
+    # ---- single GPU: CPU baselines, HBM traffic measured under rocprofv3, the other points ------------
+    traffic = traffic_src = traffic_detail = None
+    extras = None
+    if world == 1:
+        if args.cpu_steps > 0:
+            cpu_baselines()  # after the timed region: busy OpenMP threads must not sit next to the measurement
+        headline = (config == "c2" and log2n == 20 and args.pattern == "banded" and args.format == "auto" and not args.real
+                    and args.dt == 1.0)
+        if not args.no_pmc:
+            inner = ["--steps", "3", "--warmup", "1", "--cpu-steps", "0", "--no-pmc", "--no-extras", "--log2n", str(log2n),
+                     "--pattern", args.pattern, "--format", args.format, "--dt", str(args.dt)] + (["--real"] if args.real else [])
+            traffic, traffic_detail = pmc_traffic(inner, KERNEL_OF_FORMAT[fmt_used], timeout_s=240)
+            if traffic is not None:
+                traffic_src = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE --kernel-trace on child runs of "
+                               "this command (3 steps each); mean per launch of the kernel, FETCH_SIZE x 2 (gfx950), KiB -> bytes")
+        if traffic is None and headline and os.path.exists(os.path.join(ROOT, STATIC_PMC)):
+            with open(os.path.join(ROOT, STATIC_PMC)) as f:
+                traffic = json.load(f)["hbm_traffic_bytes_per_launch"]
+            traffic_src = (f"STATIC: from the committed profile {STATIC_PMC} of the same command on another box "
+                           f"(not measured in this run: {traffic_detail if isinstance(traffic_detail, str) else 'PMC passes disabled'})")
+            traffic_detail = None
+        if not args.no_extras and headline:
+            psi.close()
+            wrk.close()
+            op.close()
+            extras = {}
+            for name, kw in (("c2_rbcsr_generic_format", dict(pattern="banded", log2n=20, fmt="rbcsr")),
+                             ("c2_scattered_pattern", dict(pattern="scattered", log2n=20)),
+                             ("c2_random_columns", dict(pattern="random", log2n=20)),
+                             ("c2_random_columns_windowed", dict(pattern="random-window", log2n=20)),
+                             ("banded_N_2^22_out_of_infinity_cache", dict(pattern="banded", log2n=22, steps=5))):
+                try:
+                    extras[name] = bp.measure_cheby(ctx, **kw)
+                except Exception as e:  # noqa: BLE001  (an extra point must not take the headline down)
+                    extras[name] = {"error": f"{type(e).__name__}: {e}"}
+            for name, fn in (("c3_newton", bp.measure_newton_c3), ("c5_batched", bp.measure_batched_c5)):
+                try:
+                    extras[name] = fn(ctx)
+                except Exception as e:  # noqa: BLE001
+                    extras[name] = {"error": f"{type(e).__name__}: {e}"}
+
+    workload = {"c2": "BASELINE configs[1]: Cheby prop_step!, N=2^20 CSR sparse Hermitian H, 16 nnz/row",
+                "c4": "BASELINE configs[3]: Cheby prop_step!, CSR sparse H row-partitioned, 2^21 rows per GPU (N=2^24 at 8 GPUs), "
+                      "RCCL exchange of psi after each mat-vec"}[config]
+    if args.log2n is not None or args.scaling == "strong":
+        workload += f" [size overridden: 2^{log2n} rows {'in total (strong scaling)' if args.scaling == 'strong' else 'per GPU'}]"
     out = {
         "metric": "Cheby prop_step!/s at N=2^20 CSR fp64 (2^20-row blocks advanced per second)",
-        "value": steps_per_s * world,
+        "value": steps_per_s * blocks_per_step,
         "unit": "prop_step/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "c128 state, f64 matrix values" if args.real else "c128 (complex fp64)", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: Cheby prop_step!, CSR sparse Hermitian H, 16 nnz/row, "
-                               + ("real fp64 values (f64 variant), " if args.real else "complex fp64 values, ")
-                               + "int32 indices",
-                   "rows_per_gpu": rows, "N_total": N, "nnz_per_row": 16, "pattern": args.pattern,
-                   "offsets": [int(o) for o in offsets], "n_coeffs": int(len(coeffs)), "matvecs_per_step": nterms,
+        "config": {"workload": workload + (", real fp64 values (f64 variant)" if args.real else ", complex fp64 values") + ", int32 indices",
+                   "rows_per_gpu": rows, "N_total": N, "blocks_of_2^20_rows_per_step": blocks_per_step,
+                   "nnz_per_row": nnz_local / rows, "pattern": args.pattern,
+                   "n_coeffs": int(len(coeffs)), "matvecs_per_step": nterms,
                    "spectral_range": [-10.0, 10.0], "dt": dt,
-                   "device_format": {1: "csr", 2: "rbcsr", 3: "hrb (Hermitian-packed row blocks)"}[fmt_used],
+                   "device_format": bp.FMT_NAME[fmt_used],
                    "device_layout": layout,
                    "parallelism": "single GPU" if world == 1 else (
                        f"row-partitioned x{world}, exchange={exchange_used}, schedule={schedule_note}, driver={driver_note}"
@@ -325,27 +468,32 @@ def main():
                    "global_steps_per_s": steps_per_s},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "traffic_source": "profiles/r01/bench_final_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                                       "FETCH x2 gfx950 correction)" if traffic else None,
+                     "traffic_source": traffic_src, "traffic_detail": traffic_detail,
                      "kernel": kern,
-                     "algorithmic_bytes_per_launch": alg_bytes,
+                     "layout_bytes_per_launch": model["per_term"],
+                     "layout_bytes_matrix": model["matrix_per_term"], "layout_bytes_vectors": model["vectors_per_term"],
                      "avg_launch_us": avg_launch_s * 1e6,
                      "launches_timed": n_launch, "hip_event_ms": ev_ms,
+                     "effective_csr_equiv_gbs": csr_equiv,
+                     "effective_csr_equiv_frac": csr_equiv / HBM_PEAK_GBS,
+                     "csr_equivalent_bytes_per_launch": model["csr_equivalent_per_term"],
                      "traffic_rate_gbs": (traffic / avg_launch_s / 1e9) if traffic else None,
-                     "hbm_stream_measured_gbs": stream_gbs,
-                     "traffic_frac_of_stream": (traffic / avg_launch_s / 1e9 / stream_gbs) if (traffic and stream_gbs) else None,
                      "traffic_frac_of_peak": (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                     "note": "avg launch duration = HIP-event time of the timed region on the kernels' stream / "
-                             "number of fused-term launches (includes launch gaps; multi-GPU: includes exchange). "
-                             "`achieved` uses the contract's algorithmic CSR bytes (SURVEY 8d: (20 z + 84) N = 404 B/row); "
-                             "the shipped layout moves fewer: Hermitian packing (lower triangle read back from L2 as "
-                             "conjugates), stencil row blocks (block-wide column distances instead of per-entry "
-                             "indices) and the Psi accumulator touched every third term, about 190 B/row, so "
-                             "`achieved` exceeds what the same bytes would allow -- `traffic` is the HBM bytes the "
-                             "PMC counters saw per launch, `traffic_rate_gbs` / `traffic_frac_of_peak` the real HBM rate"},
+                     "traffic_over_layout_bytes": (traffic / model["per_term"]) if traffic else None,
+                     "hbm_stream_measured_gbs": stream_gbs,
+                     "note": "avg launch duration = HIP-event time of the timed region on the kernels' stream / number of "
+                             "fused-term launches (includes launch gaps; multi-GPU: includes the exchange).  `achieved` = bytes "
+                             "the shipped device layout must move per launch (stored values + index bytes + block metadata + "
+                             "the vector streams with the accumulator touched by every third term only) / that duration; "
+                             "`effective_csr_equiv_gbs` prices the same time with the contract's CSR bytes (SURVEY 8d: (20 z + "
+                             "84) N = 404 B/row), which a Hermitian-packed / stencil-encoded layout undercuts; `traffic` = "
+                             "HBM bytes per launch from the PMC counters (Infinity-Cache hits are counted by FETCH_SIZE: at "
+                             "N = 2^20 part of the working set is served on-die, see extras[banded_N_2^22...] for the point beyond it)"},
         "cpu_baseline": cpu,
         "cpu_baseline_all_cores": cpu_omp,
         "pcie_inclusive_steps_per_s": pcie,
+        "strong_scaling_point": strong,
+        "extras": extras,
         "stats": {"n_matvec": st["n_matvec"], "kernel_launches": st["n_kernel_launches"]},
     }
     if rank == 0:

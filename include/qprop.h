@@ -291,6 +291,12 @@ typedef struct qp_comm qp_comm;
 int qp_comm_unique_id(const char* rccl_lib_path, char id_out[128]);
 int qp_comm_create(qp_ctx* ctx, const char* rccl_lib_path, const char id[128], int rank, int world,
                    qp_comm** out);
+/* The same in two phases: qp_comm_prepare is LOCAL (dlopen of librccl, symbol resolution; no communication),
+ * qp_comm_connect is the COLLECTIVE ncclCommInitRank.  A caller with several ranks makes sure every rank
+ * came through qp_comm_prepare (agreeing over whatever channel carried the id) before any rank connects: a rank
+ * that failed locally would otherwise leave the others blocked in the collective.  qp_comm_create = both. */
+int qp_comm_prepare(qp_ctx* ctx, const char* rccl_lib_path, int rank, int world, qp_comm** out);
+int qp_comm_connect(qp_comm* comm, const char id[128]);
 /* A communicator whose exchange is performed by the caller: qp_sharded_cheby_step calls `cb`
  * where it would enqueue the RCCL collective.  The callback must make `send[0..count)` of every
  * rank r arrive at `recv_base + r * count` on the ranks that read it (all of them when

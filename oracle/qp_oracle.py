@@ -663,6 +663,10 @@ def init_prop(state, generator, tlist, method, backward=False, parameters=None,
               uniform_dt_tolerance=1e-12, m_max=10, func=None, norm_min=1e-14,
               relerr=1e-12, max_restarts=50, specrange_state=None, **specrange_kwargs):
     """src/cheby_propagator.jl:87-175 and src/newton_propagator.jl:62-113."""
+    if isinstance(generator, tuple) and len(generator) == 1 and not isinstance(generator[0], (tuple, list)):
+        # `(H,)`: a tuple generator without controls evaluates to its drift matrix
+        # (src/controls.jl:442-463; test/test_propagate.jl:22,157)
+        generator = generator[0]
     p = PWCPropagator()
     p.method = method.lower()
     p.generator = generator

@@ -132,7 +132,7 @@ struct Tuning {
   int rbcsr_variant = 7;      // bit 0 nt matrix loads, bit 1 early row-local loads, bit 2 deeper unroll (A/B in profiles/)
   int hrb_lower_last = 0;     // HRB kernel: process the lower (conj-transposed) section after the upper one
   int arnoldi_mode = 1;       // 0 = sequential fused MGS passes, 1 = low-synchronisation MGS
-  int split_mode = 1;         // 0 = cross-stream events on both streams, 1 = in-launch counter for the main stream
+  int split_mode = 2;         // boundary -> interior hand-off: 0 = cross-stream events, 1 = in-launch counter, 2 = the counter when at most 256 workgroups poll
   int liouville_fused_n = 320;  // matrix-free Liouvillian: largest n that takes the fused matrix-core kernel (else library GEMMs)
   int real_vals = 1;          // operator refresh: stream a real copy of the values when they are all real
   int stencil = 1;            // operator build: encode blocks with block-wide column distances as stencil blocks

@@ -102,10 +102,15 @@ struct qp_split {   // boundary / interior partition of an operator's row blocks
   int64_t n_boundary = 0, n_interior = 0, nsend = 0;
   hipEvent_t ev_b = nullptr, ev_i = nullptr;
   // in-launch hand-off boundary(m) -> interior(m+1) (see SyncArgs in device.h)
-  unsigned* counter = nullptr;        // [0] signal counter, [1] spin-timeout flag
+  unsigned* counter = nullptr;        // [0] signal counter (device memory)
+  unsigned* timeout_host = nullptr;   // spin-timeout flag: pinned host memory mapped into the device, so the host can
+  unsigned* timeout_dev = nullptr;    //   look at it without synchronising (its device address)
   unsigned signals_issued = 0;
   unsigned wait_from_wg = 0;          // interior workgroups at or beyond this position poll
+  unsigned n_waiting_wg = 0;          // how many of them there are
 };
+// QP_E_INTERNAL once an in-launch wait of this split has ever timed out (no synchronisation)
+int split_timed_out(const qp_split* sp);
 
 struct qp_krylov {
   qp_ctx* ctx;

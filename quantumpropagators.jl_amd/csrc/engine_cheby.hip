@@ -28,6 +28,13 @@ void acc_schedule(const double* a, int n_coeffs, bool defer, qp_acc_defer* out) 
   }
 }
 
+int split_timed_out(const qp_split* sp) {
+  if (sp && sp->timeout_host && __atomic_load_n(sp->timeout_host, __ATOMIC_RELAXED) != 0)
+    return qp::fail(QP_E_INTERNAL, "an interior launch of an earlier term timed out waiting for its boundary launch: "
+                                   "the state of this partitioned cheby! is not valid");
+  return QP_OK;
+}
+
 void set_defer(qp::ChebyEpi& e, const qp_acc_defer* d) {
   if (!d) return;
   e.acc_skip = d->skip ? 1 : 0;
@@ -436,7 +443,14 @@ int qp_split_create(qp_operator* op, const int64_t* send_rows, int64_t nsend, qp
   QP_HIP(hipEventCreateWithFlags(&sp->ev_i, hipEventDisableTiming));
   QP_CHECK(dev_alloc(&sp->counter, 2));
   QP_HIP(hipMemset(sp->counter, 0, 2 * sizeof(unsigned)));
+  QP_HIP(hipHostMalloc((void**)&sp->timeout_host, sizeof(unsigned), hipHostMallocMapped));
+  *sp->timeout_host = 0;
+  QP_HIP(hipHostGetDevicePointer((void**)&sp->timeout_dev, sp->timeout_host, 0));
   sp->wait_from_wg = wait_from_wg;
+  {
+    const unsigned total = (unsigned)((bi.size() + qp::kThreads / 64 - 1) / (qp::kThreads / 64));
+    sp->n_waiting_wg = total > wait_from_wg ? total - wait_from_wg : 0;
+  }
   *out = sp.release();
   return QP_OK;
   QP_CATCH
@@ -451,6 +465,7 @@ int qp_split_destroy(qp_split* sp) {
   if (sp->bmap_interior) (void)hipFree(sp->bmap_interior);
   if (sp->mirror) (void)hipFree(sp->mirror);
   if (sp->counter) (void)hipFree(sp->counter);
+  if (sp->timeout_host) (void)hipHostFree(sp->timeout_host);
   if (sp->ev_b) (void)hipEventDestroy(sp->ev_b);
   if (sp->ev_i) (void)hipEventDestroy(sp->ev_i);
   delete sp;
@@ -471,10 +486,7 @@ int qp_split_check(qp_split* sp) {
   if (!sp) return qp::fail(QP_E_BAD_ARG, "split is NULL");
   QP_HIP(hipSetDevice(sp->device));
   QP_HIP(hipDeviceSynchronize());
-  unsigned h[2] = {0, 0};
-  QP_HIP(hipMemcpy(h, sp->counter, sizeof(h), hipMemcpyDeviceToHost));
-  if (h[1] != 0) return qp::fail(QP_E_INTERNAL, "an interior launch timed out waiting for its boundary launch");
-  return QP_OK;
+  return split_timed_out(sp);
   QP_CATCH
 }
 
@@ -512,7 +524,13 @@ int qp_cheby_term_split(qp_operator* op, qp_split* sp, void* boundary_stream, in
   set_defer(e, defer);
   qp::RowSet rb{sp->bmap_boundary, sp->n_boundary, false};
   qp::RowSet ri{sp->bmap_interior, sp->n_interior, true};
-  const bool flag_mode = (op->ctx->tun.split_mode == 1);
+  QP_CHECK(split_timed_out(sp));
+  // knob split_mode: 1 = in-launch counter hand-off, 0 = events on both streams, 2 (default) = the counter
+  // where it is safe by construction: the polling workgroups hold their CU slots while the boundary launch
+  // they wait for may sit behind a collective that depends on other ranks, so they must be few enough to
+  // leave room for that launch and the collective's kernel on every CU (at most one per CU here)
+  const int mode = op->ctx->tun.split_mode;
+  const bool flag_mode = mode == 1 || (mode == 2 && sp->n_waiting_wg <= 256);
   if (first && flag_mode) {
     // the caller joined both streams: restart the signal counter (keeps it far from wrap)
     QP_HIP(hipMemsetAsync(sp->counter, 0, sizeof(unsigned), S_c));
@@ -532,7 +550,7 @@ int qp_cheby_term_split(qp_operator* op, qp_split* sp, void* boundary_stream, in
     ri.sync.wait = sp->counter;
     ri.sync.wait_target = sp->signals_issued;      // every boundary workgroup launched so far
     ri.sync.wait_from_wg = sp->wait_from_wg;
-    ri.sync.timeout_flag = sp->counter + 1;
+    ri.sync.timeout_flag = sp->timeout_dev;
     rb.sync.signal = sp->counter;
     sp->signals_issued += (unsigned)((sp->n_boundary + qp::kThreads / 64 - 1) / (qp::kThreads / 64));
   }

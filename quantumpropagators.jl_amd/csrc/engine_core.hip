@@ -220,7 +220,7 @@ int qp_matrix_create(qp_ctx* ctx, int64_t nrows, int64_t ncols, int64_t nnz, con
   (void)format;
   if (!ctx || !out || !ptr || (nnz > 0 && (!idx || !vals)))
     return qp::fail(QP_E_BAD_ARG, "qp_matrix_create: NULL argument");
-  if (nrows < 0 || ncols < 0 || nnz < 0 || ncols > INT32_MAX)
+  if (nrows < 0 || ncols < 0 || nnz < 0 || ncols > INT32_MAX)   // columns are int32 on the device
     return qp::fail(QP_E_BAD_ARG, "qp_matrix_create: bad shape %lld x %lld, nnz %lld", (long long)nrows,
                     (long long)ncols, (long long)nnz);
   if (index_base != 0 && index_base != 1) return qp::fail(QP_E_BAD_ARG, "index_base must be 0 or 1");
@@ -247,9 +247,12 @@ int qp_matrix_create(qp_ctx* ctx, int64_t nrows, int64_t ncols, int64_t nnz, con
     if (ptr[ncols] - index_base != nnz) return qp::fail(QP_E_BAD_ARG, "colptr[end] does not match nnz");
     int st = qp::csc_to_csr(nrows, ncols, ptr, idx, v128, index_base, m->rowptr.data(), m->col.data(),
                             reinterpret_cast<qp_c128*>(m->vals.data()));
-    if (st != QP_OK) return qp::fail(st, "qp_matrix_create: row index out of range");
+    if (st != QP_OK)
+      return qp::fail(st, "qp_matrix_create: colptr must start at the index base, be monotone and end at nnz, and every "
+                          "row index must lie in [base, base + nrows)");
   } else if (layout == QP_LAYOUT_CSR) {
     if (ptr[nrows] - index_base != nnz) return qp::fail(QP_E_BAD_ARG, "rowptr[end] does not match nnz");
+    if (ptr[0] != index_base) return qp::fail(QP_E_BAD_ARG, "rowptr[0] must equal the index base (%d)", index_base);
     for (int64_t r = 0; r <= nrows; ++r) m->rowptr[r] = ptr[r] - index_base;
     for (int64_t r = 0; r < nrows; ++r)
       if (m->rowptr[r + 1] < m->rowptr[r]) return qp::fail(QP_E_BAD_ARG, "rowptr not monotone at row %lld", (long long)r);
@@ -784,7 +787,8 @@ static int choose_format(qp_operator* op, int requested, bool hermitian) {
         ++nlow;
         if (r - uc[p] <= maxdist) ++nnear;
       }
-    return ((double)nnear >= 0.85 * (double)nlow) ? QP_FMT_HRB : QP_FMT_RBCSR;
+    // (the packed format addresses the transposed values with int32 positions)
+    return ((double)nnear >= 0.85 * (double)nlow && rb_stored < (int64_t)INT32_MAX) ? QP_FMT_HRB : QP_FMT_RBCSR;
   }
   if (requested == QP_FMT_HRB && !hermitian) return -1;
   return requested;

@@ -95,19 +95,47 @@ int qp_comm_unique_id(const char* rccl_lib_path, char id_out[128]) {
   QP_CATCH
 }
 
-int qp_comm_create(qp_ctx* ctx, const char* rccl_lib_path, const char id[128], int rank, int world, qp_comm** out) {
+// Communicator set-up in two phases, so that a caller can make sure EVERY rank got through the part
+// that may fail locally (dlopen of librccl, symbol resolution) before any rank enters the collective
+// ncclCommInitRank -- a rank that failed locally would otherwise leave the others blocked in it.
+int qp_comm_prepare(qp_ctx* ctx, const char* rccl_lib_path, int rank, int world, qp_comm** out) {
   QP_TRY
-  if (!ctx || !id || !out || world < 1 || rank < 0 || rank >= world) return qp::fail(QP_E_BAD_ARG, "qp_comm_create: bad arguments");
+  if (!ctx || !out || world < 1 || rank < 0 || rank >= world) return qp::fail(QP_E_BAD_ARG, "qp_comm_prepare: bad arguments");
   QP_CHECK(use(ctx));
   auto c = std::make_unique<qp_comm>();
   c->ctx = ctx;
   c->rank = rank;
   c->world = world;
   QP_CHECK(rccl_load(rccl_lib_path, &c->api));
+  *out = c.release();
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_comm_connect(qp_comm* c, const char id[128]) {
+  QP_TRY
+  if (!c || !id) return qp::fail(QP_E_BAD_ARG, "qp_comm_connect: NULL argument");
+  if (c->cb) return qp::fail(QP_E_BAD_ARG, "qp_comm_connect: a callback communicator has nothing to connect");
+  if (c->comm) return qp::fail(QP_E_BAD_ARG, "qp_comm_connect: already connected");
+  QP_CHECK(use(c->ctx));
   ncclUniqueId uid;
   std::memcpy(&uid, id, sizeof(uid));
-  QP_RCCL(c->api, c->api.CommInitRank(&c->comm, world, uid, rank));
-  *out = c.release();
+  QP_RCCL(c->api, c->api.CommInitRank(&c->comm, c->world, uid, c->rank));
+  return QP_OK;
+  QP_CATCH
+}
+
+int qp_comm_create(qp_ctx* ctx, const char* rccl_lib_path, const char id[128], int rank, int world, qp_comm** out) {
+  QP_TRY
+  if (!id || !out) return qp::fail(QP_E_BAD_ARG, "qp_comm_create: bad arguments");
+  qp_comm* c = nullptr;
+  QP_CHECK(qp_comm_prepare(ctx, rccl_lib_path, rank, world, &c));
+  const int rc = qp_comm_connect(c, id);
+  if (rc != QP_OK) {
+    delete c;
+    return rc;
+  }
+  *out = c;
   return QP_OK;
   QP_CATCH
 }
@@ -149,6 +177,7 @@ int qp_comm_allgather(qp_comm* comm, const qp_state* send, qp_state* recv, int64
       return qp::fail(QP_E_RCCL, "the caller's exchange callback failed");
     return QP_OK;
   }
+  if (!comm->comm) return qp::fail(QP_E_BAD_ARG, "qp_comm_allgather: the communicator is not connected (qp_comm_connect)");
   QP_RCCL(comm->api, comm->api.AllGather(send->d, recv->d, (size_t)(2 * count), ncclDouble, comm->comm, s));
   return QP_OK;
   QP_CATCH
@@ -162,6 +191,7 @@ int qp_sharded_cheby_create(const qp_sharded_cheby_desc* desc, qp_sharded_cheby*
   const int world = d.comm ? d.comm->world : 1;
   if (d.M < 0 || d.nsend < 0 || d.nsend > d.M || (d.nsend > 0 && !d.send_rows)) return qp::fail(QP_E_BAD_ARG, "qp_sharded_cheby_create: bad send set");
   if (d.M > 0 && !d.comm) return qp::fail(QP_E_BAD_ARG, "qp_sharded_cheby_create: an exchange needs a communicator");
+  if (d.M > 0 && !d.comm->cb && !d.comm->comm) return qp::fail(QP_E_BAD_ARG, "qp_sharded_cheby_create: the communicator is not connected (qp_comm_connect)");
   if (ncols != nloc + (d.M > 0 ? (int64_t)world * d.M : 0)) return qp::fail(QP_E_BAD_ARG, "qp_sharded_cheby_create: operator has %lld columns, expected nloc + world * M = %lld", (long long)ncols, (long long)(nloc + (int64_t)world * d.M));
   if (d.X0->n != ncols || d.X1->n != ncols || d.acc->n != nloc) return qp::fail(QP_E_BAD_ARG, "qp_sharded_cheby_create: vector length mismatch");
   if (d.M > 0 && !d.direct_send && (!d.slab || d.slab->n < d.M)) return qp::fail(QP_E_BAD_ARG, "qp_sharded_cheby_create: slab too small");
@@ -271,16 +301,33 @@ int qp_sharded_cheby_step(qp_sharded_cheby* s, const double* a, int n_coeffs, do
     const RcclApi& api = d.comm->api;
     if (s->p2p) {   // neighbour exchange: my slab to who reads it, their slabs into their ghost slots
       QP_RCCL(api, api.GroupStart());
-      for (int o : s->recv_from)
-        QP_RCCL(api, api.Recv(X[k]->d + nloc + (int64_t)o * d.M, (size_t)(2 * d.M), ncclDouble, o, d.comm->comm, S_x));
-      for (int o : s->send_to) QP_RCCL(api, api.Send(send, (size_t)(2 * d.M), ncclDouble, o, d.comm->comm, S_x));
-      QP_RCCL(api, api.GroupEnd());
+      // a failure inside the group must not leave the thread inside an open group (later collectives of
+      // this thread -- torch's included -- would be queued and never launched): remember the first one,
+      // close the group, then report
+      ncclResult_t first = ncclSuccess;
+      const char* what = "";
+      for (int o : s->recv_from) {
+        if (first != ncclSuccess) break;
+        first = api.Recv(X[k]->d + nloc + (int64_t)o * d.M, (size_t)(2 * d.M), ncclDouble, o, d.comm->comm, S_x);
+        what = "ncclRecv";
+      }
+      for (int o : s->send_to) {
+        if (first != ncclSuccess) break;
+        first = api.Send(send, (size_t)(2 * d.M), ncclDouble, o, d.comm->comm, S_x);
+        what = "ncclSend";
+      }
+      const ncclResult_t end = api.GroupEnd();
+      if (first != ncclSuccess) return qp::fail(QP_E_RCCL, "RCCL: %s failed: %s", what, api.GetErrorString(first));
+      if (end != ncclSuccess) return qp::fail(QP_E_RCCL, "RCCL: ncclGroupEnd failed: %s", api.GetErrorString(end));
     } else {
       QP_RCCL(api, api.AllGather(send, X[k]->d + nloc, (size_t)(2 * d.M), ncclDouble, d.comm->comm, S_x));
     }
     return QP_OK;
   };
 
+  // an in-launch wait of an EARLIER step that gave up (bounded spin) left a wrong state behind: the flag
+  // sits in host-visible memory, so looking at it costs no synchronisation
+  if (overlap) QP_CHECK(split_timed_out(d.split));
   if (overlap) {   // join: the side stream starts after everything queued on the main stream
     QP_HIP(hipEventRecord(s->ev_main, S_c));
     QP_HIP(hipStreamWaitEvent(S_x, s->ev_main, 0));
@@ -318,6 +365,7 @@ int qp_sharded_cheby_step(qp_sharded_cheby* s, const double* a, int n_coeffs, do
   if (result_in_acc)
     QP_HIP(hipMemcpyAsync(d.X0->d, d.acc->d, (size_t)nloc * sizeof(double2), hipMemcpyDeviceToDevice, S_c));
   ctx->stats.n_cheby_steps++;
+  if (overlap) QP_CHECK(split_timed_out(d.split));
   return QP_OK;
   QP_CATCH
 }

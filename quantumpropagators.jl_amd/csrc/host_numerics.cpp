@@ -269,7 +269,13 @@ int extend_newton_coeffs(cplx* a, int n_a, const cplx* leja, int func_id, qp_fun
 // ---------------------------------------------------------------------------
 int csc_to_csr(int64_t nrows, int64_t ncols, const int64_t* colptr, const int64_t* rowval,
                const qp_c128* nzval, int base, int64_t* rowptr, int32_t* col, qp_c128* vals) {
+  // the pointer array is validated before anything is indexed through it: it must start at the index
+  // base, be monotone and stay inside [0, nnz]
+  if (colptr[0] != base) return QP_E_BAD_ARG;
   int64_t nnz = colptr[ncols] - base;
+  if (nnz < 0) return QP_E_BAD_ARG;
+  for (int64_t c = 0; c < ncols; ++c)
+    if (colptr[c + 1] < colptr[c] || colptr[c + 1] - base > nnz) return QP_E_BAD_ARG;
   std::fill(rowptr, rowptr + nrows + 1, (int64_t)0);
   for (int64_t p = 0; p < nnz; ++p) {
     int64_t r = rowval[p] - base;

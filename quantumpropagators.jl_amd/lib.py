@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libqprop_hip.so")
 
 QP_OK = 0
+QP_E_RCCL = 12
 STATUS = {
     0: "QP_OK", 1: "QP_E_BAD_ARG", 2: "QP_E_HIP", 3: "QP_E_DT_MISMATCH",
     4: "QP_E_TOO_FEW_COEFFS", 5: "QP_E_NORMALIZATION", 6: "QP_E_MAX_RESTARTS",
@@ -159,6 +160,8 @@ SIGNATURES = {
                                         C.c_int, C.POINTER(_P)]),
     "qp_comm_unique_id": (C.c_int, [C.c_char_p, C.c_char_p]),
     "qp_comm_create": (C.c_int, [_P, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(_P)]),
+    "qp_comm_prepare": (C.c_int, [_P, C.c_char_p, C.c_int, C.c_int, C.POINTER(_P)]),
+    "qp_comm_connect": (C.c_int, [_P, C.c_char_p]),
     "qp_comm_create_callback": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.POINTER(_P)]),
     "qp_comm_destroy": (C.c_int, [_P]),
     "qp_comm_allgather": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
@@ -860,21 +863,43 @@ def rccl_library_path():
 class Comm:
     """RCCL communicator owned by the library (include/qprop.h, qp_comm).  ``exchange_id``:
     a callable that takes rank 0's 128-byte id (None on the other ranks) and returns it on every
-    rank -- e.g. a ``torch.distributed.broadcast_object_list`` over any backend."""
+    rank -- e.g. a ``torch.distributed.broadcast_object_list`` over any backend.  ``agree``: a callable
+    that takes this rank's error (or None) and returns the first error of ANY rank (or None) on every
+    rank.  Set-up runs in two phases: the part that can fail on one rank alone (dlopen of librccl,
+    symbol resolution: ``qp_comm_prepare``) comes first, the ranks agree that all came through, and
+    only then all enter the collective ``ncclCommInitRank`` (``qp_comm_connect``) -- a rank that failed
+    locally would otherwise leave the others blocked in it.  Both callables are called exactly once, in
+    this order, on every rank, whatever happens locally."""
 
-    def __init__(self, ctx, rank, world, exchange_id, lib_path=None):
+    def __init__(self, ctx, rank, world, exchange_id, lib_path=None, agree=None):
         self.ctx, self.lib = ctx, ctx.lib
         self.rank, self.world = int(rank), int(world)
         path = (lib_path or rccl_library_path()).encode()
+        self._h = _P()
+        local_err = None
+        if self.lib.qp_comm_prepare(ctx._h, path, self.rank, self.world, C.byref(self._h)) != QP_OK:
+            local_err = self.lib.qp_last_error().decode(errors="replace")
+            self._h = _P()
         uid = None
-        if self.rank == 0:
+        if self.rank == 0 and local_err is None:
             buf = C.create_string_buffer(128)
             if self.lib.qp_comm_unique_id(path, buf) == QP_OK:   # on failure the other ranks learn it (None)
                 uid = buf.raw
-        uid = exchange_id(uid)
+        try:
+            uid = exchange_id(uid)                               # raises on every rank when rank 0 has no id
+            err = agree(local_err) if agree is not None else local_err
+        except Exception:
+            self.close()
+            raise
+        if err is not None:
+            self.close()
+            raise QPError(QP_E_RCCL, f"RCCL communicator set-up failed on a rank: {err}")
         assert isinstance(uid, (bytes, bytearray)) and len(uid) == 128
-        self._h = _P()
-        check(self.lib.qp_comm_create(ctx._h, path, bytes(uid), self.rank, self.world, C.byref(self._h)))
+        st = self.lib.qp_comm_connect(self._h, bytes(uid))
+        if st != QP_OK:
+            msg = self.lib.qp_last_error().decode(errors="replace")
+            self.close()
+            raise QPError(st, msg)
         ctx._adopt(self)
 
     def allgather(self, send, recv, count, stream=None):

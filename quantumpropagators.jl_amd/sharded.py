@@ -265,7 +265,7 @@ class ShardedCheby:
                 comm = L.CallbackComm(ctx, self.rank, self.world, self._host_exchange)
             elif self.exchanging:
                 try:
-                    comm = L.Comm(ctx, self.rank, self.world, exchange_id)
+                    comm = L.Comm(ctx, self.rank, self.world, exchange_id, agree=agree)
                 except Exception as exc:      # noqa: BLE001 -- reported, and the Python driver is used instead
                     err = exc
                 err = agree(err)

@@ -82,6 +82,36 @@ def hermitian_offsets_csr(N, offsets=BANDED_OFFSETS, rho=10.0, seed=DEFAULT_SEED
     return rowptr, cols.reshape(-1).astype(np.int32), vals.reshape(-1)
 
 
+def random_columns_csr(N, n_pairs=8, window=None, rho=10.0, seed=DEFAULT_SEED):
+    """Hermitian H whose columns are drawn PER ROW (no translation invariance: the irregular case that
+    plain "CSR" implies), 2 n_pairs entries per row, no diagonal.  Rows are cut into blocks of `window`
+    consecutive rows (default: one block = all N, columns anywhere); inside a block, pairing k couples
+    row i with pi_k(i), where pi_k is a single cycle through the block in a seeded random order -- so every
+    row gets exactly one partner forwards and one backwards per pairing, H[i, pi_k(i)] = g,
+    H[pi_k(i), i] = conj(g).  Two pairings giving a row the same partner are merged (a row then has
+    fewer than 2 n_pairs entries: about n_pairs^2 / window of the rows).  |g| <= rho / (2 n_pairs):
+    Gershgorin keeps the spectrum inside [-rho, rho].  Returns 0-based CSR (rowptr int64, col int32,
+    vals complex128), columns ascending."""
+    W = N if window is None else int(window)
+    assert N % W == 0 and W > 2
+    rng = np.random.default_rng(seed)
+    rows_all, cols_all, vals_all = [], [], []
+    nblk = N // W
+    for k in range(n_pairs):
+        # one random cyclic order per block: sigma[b] lists the block's rows; pi(sigma[j]) = sigma[j + 1]
+        sigma = np.argsort(rng.random((nblk, W)), axis=1).astype(np.int64)
+        src = (sigma + (np.arange(nblk, dtype=np.int64) * W)[:, None]).reshape(-1)
+        dst = (np.roll(sigma, -1, axis=1) + (np.arange(nblk, dtype=np.int64) * W)[:, None]).reshape(-1)
+        g = coupling(seed, src, k, rho, n_pairs)
+        rows_all += [src, dst]
+        cols_all += [dst, src]
+        vals_all += [g, np.conj(g)]
+    A = sp.coo_matrix((np.concatenate(vals_all), (np.concatenate(rows_all), np.concatenate(cols_all))), shape=(N, N)).tocsr()
+    A.sum_duplicates()
+    A.sort_indices()
+    return A.indptr.astype(np.int64), A.indices.astype(np.int32), A.data.astype(np.complex128)
+
+
 def random_state(N, seed=DEFAULT_SEED + 1, row_begin=0, row_end=None, normalize=True):
     """Complex Gaussian (Box-Muller on the hash) state, normalised over all N."""
     def part(a, b):

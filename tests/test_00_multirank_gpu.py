@@ -102,13 +102,45 @@ def test_bench_multirank_flow_one_gpu(world, driver):
     assert len(lines) == 1 and not any(ln.startswith("{") for o, _ in outs[1:] for ln in o.splitlines())
     d = json.loads(lines[0])
     assert d["n_gpus"] == world and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
-    assert d["value"] > 0 and abs(d["value"] - world * d["config"]["global_steps_per_s"]) < 1e-9 * d["value"]
-    assert d["config"]["N_total"] == world << 16 and d["roofline"]["frac"] > 0 and d["cpu_baseline"] is None
+    blocks = d["config"]["blocks_of_2^20_rows_per_step"]
+    assert blocks == world / 16.0                       # value counts 2^20-row blocks: N_total / 2^20 of them per step
+    assert d["value"] > 0 and abs(d["value"] - blocks * d["config"]["global_steps_per_s"]) < 1e-9 * d["value"]
+    assert d["config"]["N_total"] == world << 16 and d["cpu_baseline"] is None
+    rf = d["roofline"]
+    assert 0 < rf["frac"] <= 1.0 and rf["achieved"] <= rf["peak"]          # bytes of the shipped layout: a physical fraction
+    assert rf["layout_bytes_per_launch"] < rf["csr_equivalent_bytes_per_launch"]
+    assert abs(rf["effective_csr_equiv_gbs"] * rf["layout_bytes_per_launch"] - rf["achieved"] * rf["csr_equivalent_bytes_per_launch"]) \
+        < 1e-6 * rf["achieved"] * rf["csr_equivalent_bytes_per_launch"]
+    sp_ = d["strong_scaling_point"]
+    if world == 2:                                      # N = 2^20 in total, split over the ranks
+        assert sp_["N_total"] == 1 << 20 and sp_["rows_per_gpu"] == 1 << 19 and sp_["prop_steps_per_s"] > 0
+    else:
+        assert sp_ is None                              # 3 does not divide 2^20
     par = d["config"]["parallelism"]
     assert f"row-partitioned x{world}" in par and "TEST MODE" in par
     assert "exchange=halo" in par                       # 2^16 rows per rank: banded H exchanges halos only
     assert "schedule=auto: overlap" in par and ("-> overlap" in par or "-> serial" in par)   # both schedules were timed
     assert ("driver=native (library step" in par) if driver == "native" else ("driver=torch.distributed" in par)
+
+
+def test_bench_single_gpu_line_is_physical():
+    """bench.py on one GPU (small size): `roofline.frac` prices the shipped layout's bytes and stays below 1, the
+    contract's CSR figure is reported separately, and `traffic` is measured in the run (child processes under
+    rocprofv3 --pmc), not read from a file."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "1", "--cpu-steps", "0",
+                        "--log2n", "17", "--no-extras"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    rf = d["roofline"]
+    assert d["n_gpus"] == 1 and d["config"]["N_total"] == 1 << 17 and abs(d["value"] - d["config"]["global_steps_per_s"] / 8) < 1e-9 * d["value"]
+    assert 0 < rf["frac"] <= 1.0
+    assert rf["layout_bytes_per_launch"] < rf["csr_equivalent_bytes_per_launch"] == (20 * 16 + 84) * (1 << 17) + 4
+    assert rf["traffic_source"].startswith("measured in this run"), rf["traffic_source"]
+    assert 0.3 * rf["layout_bytes_per_launch"] < rf["traffic"] < 3.0 * rf["layout_bytes_per_launch"]
+    assert rf["traffic_detail"]["dispatches"][0] >= 31
 
 
 def test_c_consumer_runs(tmp_path):

@@ -164,6 +164,25 @@ def test_csc_to_csr_bit_exact():
             assert g.dtype == r.dtype and np.array_equal(g, r)
 
 
+def test_csc_pointer_array_is_validated():
+    """The boundary rejects a pointer array before indexing through it: colptr must start at the index
+    base, be monotone and stay within nnz (a bad one used to index rowval / nzval out of bounds)."""
+    import pytest
+    n = 6
+    colptr = np.array([1, 3, 3, 5, 6, 6, 7], dtype=np.int64)       # 1-based, 6 entries
+    rowval = np.array([1, 4, 2, 6, 3, 5], dtype=np.int64)
+    nzval = np.arange(6, dtype=np.complex128)
+    L.csc_to_csr(n, n, colptr, rowval, nzval, index_base=1)         # the good one passes
+    for bad in (np.array([2, 3, 3, 5, 6, 6, 7]),                    # colptr[0] != base
+                np.array([1, 3, 2, 5, 6, 6, 7]),                    # not monotone
+                np.array([1, 3, 3, 9, 6, 6, 7]),                    # an entry beyond nnz
+                np.array([1, 3, 3, 5, 6, 6, 0])):                   # negative nnz
+        with pytest.raises(L.QPArgumentError):
+            L.csc_to_csr(n, n, bad.astype(np.int64), rowval, nzval, index_base=1)
+    with pytest.raises(L.QPArgumentError):                          # row index out of range
+        L.csc_to_csr(n, n, colptr, rowval + 1, nzval, index_base=1)
+
+
 def test_partition_rows_bit_exact():
     rng = np.random.default_rng(8)
     lens = rng.integers(0, 9, 1000)

@@ -584,16 +584,21 @@ def test_ritzvals_and_specrange(ctx, arnoldi_mode):
 # ---------------------------------------------------------------- full-size properties
 
 def test_full_size_properties(ctx):
-    """BASELINE config C2 at full size (N = 2^20, 16 nnz/row): the oracle is too slow
-    here, so check size-independent properties: unitarity (norm), forward/backward
-    round trip, linearity, and agreement of the two device formats."""
+    """BASELINE config C2 at full size (N = 2^20, 16 nnz/row): size-independent properties --
+    unitarity (norm), forward/backward round trip, linearity, agreement of the three device formats --
+    and, since two steps cost the C restatement of the reference's serial CSC path
+    (oracle/cheby_ref.c) only a second or two, a direct comparison with it at the full size."""
+    from oracle import ref_c
     N = 1 << 20
     rp, col, vals = synth.hermitian_offsets_csr(N)
     M = L.Matrix(ctx, N, N, rp, col, vals)
-    del rp, col, vals
     psi0 = synth.random_state(N)
     wrk = L.ChebyWrk(ctx, N, 20.0, -10.0, 1.0)
     assert wrk.n_coeffs == 32
+    cref = psi0.copy()
+    for _ in range(2):    # Hermitian H: CSC(H) = conj CSR(H)
+        ref_c.cheby_csc(rp, col.astype(np.int64), np.conj(vals), cref, wrk.coeffs, 20.0, -10.0, 1.0)
+    del rp, col, vals
     res = {}
     for fmt in (L.FMT_HRB, L.FMT_RBCSR, L.FMT_CSR):
         Op = L.Operator(ctx, [M], 0, fmt)
@@ -602,6 +607,7 @@ def test_full_size_properties(ctx):
         L.cheby(psi, Op, 1.0, wrk)
         res[fmt] = psi.numpy()
         assert abs(np.linalg.norm(res[fmt]) - 1) < 1e-11
+        assert np.linalg.norm(res[fmt] - cref) < TOL, fmt          # the oracle at the full BASELINE size
         L.cheby(psi, Op, -1.0, wrk)
         L.cheby(psi, Op, -1.0, wrk)
         assert np.linalg.norm(psi.numpy() - psi0) < TOL
@@ -618,6 +624,60 @@ def test_full_size_properties(ctx):
         Op.close()
     assert np.linalg.norm(res[L.FMT_RBCSR] - res[L.FMT_CSR]) < TOL
     assert np.linalg.norm(res[L.FMT_HRB] - res[L.FMT_RBCSR]) < TOL
+
+
+@pytest.mark.parametrize("window", [None, 1024])
+@pytest.mark.parametrize("fmt", [L.FMT_AUTO, L.FMT_HRB, L.FMT_RBCSR, L.FMT_CSR])
+def test_random_columns_matches_oracle(ctx, window, fmt):
+    """An irregular H -- columns drawn per row, globally or inside 1024-row windows, 14-16 entries per
+    row (no translation invariance: no stencil blocks, per-entry indices) -- through every device
+    format against the oracle, forward and backward, plus the bit-exact device round trip."""
+    N = 1 << 14
+    rp, col, vals = synth.random_columns_csr(N, window=window, seed=4242)
+    H = synth.to_scipy(rp, col, vals, N)
+    assert abs(H - H.conj().T).max() == 0 and set(np.diff(rp)) <= {14, 15, 16}
+    Op = L.Operator(ctx, [L.Matrix(ctx, N, N, rp, col, vals)], 0, fmt)
+    lay = Op.layout_info()
+    if Op.format != L.FMT_CSR:
+        assert lay["stencil_upper_blocks"] == 0 and lay["stencil_lower_blocks"] == 0   # nothing translation invariant to encode
+    r2, c2, v2 = Op.get_csr()
+    assert np.array_equal(r2, rp) and np.array_equal(c2, col) and np.array_equal(v2, vals)
+    psi0 = synth.random_state(N, seed=99)
+    wrk = L.ChebyWrk(ctx, N, 20.0, -10.0, 0.8)
+    owrk = qo.ChebyWrk(psi0, 20.0, -10.0, 0.8)
+    psi = L.State(ctx, data=psi0)
+    ref = psi0.copy()
+    for dt in (0.8, 0.8, -0.8):
+        L.cheby(psi, Op, dt, wrk)
+        ref = qo.cheby(ref, H, dt, owrk)
+        assert np.linalg.norm(psi.numpy() - ref) < TOL
+
+
+def test_random_columns_full_size_properties(ctx):
+    """The irregular pattern at the BASELINE size (N = 2^20, columns anywhere): which encodings fire
+    (none of the stencil ones; AUTO leaves the Hermitian packing, whose transposed values would not
+    be in L2), unitarity, forward / backward round trip, and all device formats agree."""
+    N = 1 << 20
+    rp, col, vals = synth.random_columns_csr(N)
+    M = L.Matrix(ctx, N, N, rp, col, vals)
+    del rp, col, vals
+    psi0 = synth.random_state(N)
+    wrk = L.ChebyWrk(ctx, N, 20.0, -10.0, 1.0)
+    res = {}
+    for fmt in (L.FMT_AUTO, L.FMT_HRB, L.FMT_CSR):
+        Op = L.Operator(ctx, [M], 0, fmt)
+        if fmt == L.FMT_AUTO:
+            assert Op.format == L.FMT_RBCSR
+            lay = Op.layout_info()
+            assert lay["stencil_upper_blocks"] == 0 and lay["index_bytes"] >= 4 * 15 * N
+        psi = L.State(ctx, data=psi0)
+        L.cheby(psi, Op, 1.0, wrk)
+        res[fmt] = psi.numpy()
+        assert abs(np.linalg.norm(res[fmt]) - 1) < 1e-11
+        L.cheby(psi, Op, -1.0, wrk)
+        assert np.linalg.norm(psi.numpy() - psi0) < TOL
+        Op.close()
+    assert np.linalg.norm(res[L.FMT_AUTO] - res[L.FMT_CSR]) < TOL and np.linalg.norm(res[L.FMT_HRB] - res[L.FMT_CSR]) < TOL
 
 
 def test_newton_c3_full_size(ctx):

@@ -48,6 +48,31 @@ def _optomech():
     return H.tocsr(), psi0
 
 
+def test_tls_rabi_verbatim(ctx):
+    """test/test_propagate.jl:10-71, :74-150 with the reference's own literals through the device path:
+    `(H,)` tuple generator, H = [[0, 0.5], [0.5, 0]], tlist = range(0, 1.5 pi, length = 101), expected
+    [-1/sqrt 2, -i/sqrt 2], forward + backward 1e-12, storage forward == storage backward 1e-12;
+    in place (mutable state, :10-71) and not in place ("Immutable TLS", :74-150)."""
+    psi0 = np.array([1, 0], dtype=complex)
+    H = np.array([[0, 0.5], [0.5, 0]], dtype=complex)
+    tlist = np.linspace(0, 1.5 * np.pi, 101)
+    generator = (H,)
+    expected = np.array([-1 / np.sqrt(2), -1j / np.sqrt(2)])
+    for inplace in (True, False):
+        out, storage = P.propagate(psi0, generator, tlist, method="cheby", inplace=inplace, storage=True, ctx=ctx)
+        assert np.linalg.norm(out - expected) < 1e-12
+        pop0 = np.abs(storage[0, :]) ** 2
+        assert abs(pop0[-1] - 0.5) < 1e-8 and abs(pop0[0] - 1.0) < 1e-15
+        back, storage_bw = P.propagate(out, generator, tlist, method="cheby", backward=True, inplace=inplace,
+                                       storage=True, ctx=ctx)
+        assert np.linalg.norm(back - psi0) < 1e-12
+        assert abs(abs(storage_bw[0, 0]) ** 2 - 1.0) < 1e-8
+        assert np.linalg.norm(storage - storage_bw) < 1e-12
+    # the oracle and the device agree on every stored state
+    _, ostore = qo.propagate(psi0, generator, tlist, "cheby", storage=True)
+    assert np.linalg.norm(storage - ostore) < 1e-12
+
+
 def test_tls_rabi(ctx):
     """test/test_propagate.jl:74-150: Cheby forward/backward vs analytic, 1e-12; both
     in-place and not-in-place (a new state object per step)."""

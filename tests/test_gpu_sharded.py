@@ -69,7 +69,7 @@ def test_sharded_hip_backend_world1(pg, exchange):
     ctx.close()
 
 
-@pytest.mark.parametrize("overlap,split_mode", [(True, 1), (True, 0), (False, 1)])
+@pytest.mark.parametrize("overlap,split_mode", [(True, 1), (True, 0), (True, 2), (False, 1)])
 def test_sharded_overlap_machinery_world1(pg, overlap, split_mode):
     """Boundary / interior split on two HIP streams, fused pack into the slab and the RCCL
     all-gather on the side stream -- with one rank, using a forced send set (the first and
@@ -135,7 +135,7 @@ def test_sharded_overlap_machinery_world1(pg, overlap, split_mode):
     if overlap:
         sh.split.check()          # no in-launch wait ever timed out
         sh2.split.check()
-    L.tuning_set("split_mode", 1)
+    L.tuning_set("split_mode", 2)
     ctx.close()
 
 

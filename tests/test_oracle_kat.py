@@ -208,6 +208,26 @@ def test_tls_rabi_analytic():
     assert np.linalg.norm(back - psi0) < 1e-12
 
 
+def test_tls_rabi_verbatim():
+    """test/test_propagate.jl:10-71 and :74-150 with the reference's literals: H = [[0, 0.5], [0.5, 0]] given
+    as the tuple generator `(H,)`, tlist = range(0, 1.5 pi, length = 101) -- a 3 pi / 2 pulse --, expected
+    [-1/sqrt 2, -i/sqrt 2] ("note the phases"), forward and backward to 1e-12, the stored populations and the
+    forward / backward storage arrays (method Cheby, as :110-112 and :138-147)."""
+    psi0 = np.array([1, 0], dtype=complex)
+    H = np.array([[0, 0.5], [0.5, 0]], dtype=complex)
+    tlist = np.linspace(0, 1.5 * np.pi, 101)
+    generator = (H,)
+    out, storage = qo.propagate(psi0, generator, tlist, "cheby", storage=True)
+    expected = np.array([-1 / np.sqrt(2), -1j / np.sqrt(2)])
+    assert np.linalg.norm(out - expected) < 1e-12                       # :105, :112
+    pop0 = np.abs(storage[0, :]) ** 2
+    assert abs(pop0[-1] - 0.5) < 1e-8 and abs(pop0[0] - 1.0) < 1e-15    # :44 (isapprox)
+    back, storage_bw = qo.propagate(out, generator, tlist, "cheby", backward=True, storage=True)
+    assert np.linalg.norm(back - psi0) < 1e-12                          # :66, :147
+    assert abs(abs(storage_bw[0, 0]) ** 2 - 1.0) < 1e-8                 # :67
+    assert np.linalg.norm(storage - storage_bw) < 1e-12                 # :69
+
+
 def _optomech():
     """test/optomech.jl:1-44 restated (deterministic, no RNG)."""
     w_mech, g, eta = 10.0, 1.0, 2.0

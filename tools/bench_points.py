@@ -1,0 +1,189 @@
+"""Measured points shared by bench.py (the extra keys of its JSON line) and the per-config tools
+(kbench.py, bench_newton.py, bench_batched.py): byte models of the SHIPPED device layouts and short
+single-GPU measurements of the other BASELINE configs / patterns.  Everything here calls the product
+path through the C ABI (qprop_amd.lib); nothing imports the oracle."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+import qprop_amd.lib as L  # noqa: E402
+import qprop_amd.synth as synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; 6.3 TB/s measured copy)
+FMT_NAME = {1: "csr", 2: "rbcsr", 3: "hrb (Hermitian-packed row blocks)", 4: "matrix-free"}
+
+
+def cheby_layout_bytes(op, rows, ncols, nnz, coeffs, real_copy=False):
+    """HBM bytes ONE cheby! step must move with the operator laid out as it is on the device, split by
+    stream, and the same per fused term (averages over the step's terms).
+
+    matrix  stored values (16 B, or 8 B when the all-real copy is streamed; the Hermitian-packed
+            format stores the upper triangle only: the lower entries re-read those values through L2)
+            + index bytes (column sections, transpose positions; stencil blocks store none per entry)
+            + per-block pointers / metadata (or the CSR row pointers)
+    vectors per term: the gathered vector once (16 B per column), v_{m-2} read and v_m written in place
+            (16 B per row each; not read by term 1, not written by the last), and the Psi accumulator
+            read + written only by the terms of the deferred schedule (qp_acc_schedule_host)
+    This is what `roofline.frac` prices: it cannot exceed the chip's peak.  The contract's CSR figure
+    ((20 z + 84) N per term) is reported next to it as `csr_equivalent`."""
+    lay = op.layout_info()
+    fmt = op.format
+    nterms = len(coeffs) - 1
+    vbytes = 8.0 if real_copy else 16.0
+    if fmt == L.FMT_CSR:
+        matrix = vbytes * nnz + 4.0 * nnz + 8.0 * (rows + 1)
+    else:
+        per_block = 32.0 if fmt == L.FMT_HRB else 16.0     # bptr + cmeta (+ lptr + lcmeta)
+        matrix = vbytes * lay["stored"] + lay["index_bytes"] + per_block * lay["blocks"]
+    sched = L.acc_schedule(coeffs)
+    vec = 0.0
+    updated = False
+    for m in range(1, nterms + 1):
+        vec += 16.0 * ncols                      # gathered vector
+        if m >= 2:
+            vec += 16.0 * rows                   # v_{m-2}
+        if m < nterms:
+            vec += 16.0 * rows                   # v_m
+        if not sched[m - 1].skip:
+            vec += (32.0 if updated else 16.0) * rows
+            updated = True
+    step = nterms * matrix + vec
+    return {"per_step": step, "per_term": step / nterms, "matrix_per_term": matrix, "vectors_per_term": vec / nterms,
+            "csr_equivalent_per_term": (12.0 if real_copy else 20.0) * nnz + 4.0 * (rows + 1) + 80.0 * rows,
+            "layout": lay}
+
+
+def pattern_csr(pattern, N, row_begin=0, row_end=None):
+    if pattern == "banded":
+        return synth.hermitian_offsets_csr(N, offsets=synth.BANDED_OFFSETS, row_begin=row_begin, row_end=row_end)
+    if pattern == "scattered":
+        return synth.hermitian_offsets_csr(N, offsets=synth.scattered_offsets(N), row_begin=row_begin, row_end=row_end)
+    if row_begin != 0 or (row_end is not None and row_end != N):
+        raise ValueError("the random patterns are generated whole (single GPU)")
+    if pattern == "random":
+        return synth.random_columns_csr(N)
+    if pattern == "random-window":
+        return synth.random_columns_csr(N, window=4096)
+    raise ValueError(pattern)
+
+
+def measure_cheby(ctx, pattern="banded", log2n=20, fmt="auto", steps=10, warmup=2, real=False, dt=1.0):
+    """Cheby prop_step! on one GPU for a pattern / size / device format; per-term time from HIP events on
+    the kernels' stream; layout-byte and CSR-equivalent rates."""
+    N = 1 << log2n
+    rp, col, vals = pattern_csr(pattern, N)
+    if real:
+        vals = vals.real.astype(np.complex128)
+    nnz = int(rp[-1])
+    f = {"auto": L.FMT_AUTO, "hrb": L.FMT_HRB, "rbcsr": L.FMT_RBCSR, "csr": L.FMT_CSR}[fmt]
+    M = L.Matrix(ctx, N, N, rp, col, vals)
+    del rp, col, vals
+    op = L.Operator(ctx, [M], 0, f)
+    wrk = L.ChebyWrk(ctx, N, 20.0, -10.0, dt)
+    psi = L.State(ctx, data=synth.random_state(N))
+    nterms = wrk.n_coeffs - 1
+    for _ in range(warmup):
+        L.cheby(psi, op, dt, wrk)
+    ctx.sync()
+    ctx.timer_begin()
+    for _ in range(steps):
+        L.cheby(psi, op, dt, wrk)
+    ms = ctx.timer_end()
+    t_term = ms * 1e-3 / (steps * nterms)
+    by = cheby_layout_bytes(op, N, N, nnz, wrk.coeffs, real_copy=real)
+    lay = by["layout"]
+    out = {"pattern": pattern, "N": N, "nnz_per_row": nnz / N, "device_format": FMT_NAME[op.format],
+           "ms_per_step": ms / steps, "steps_per_s": 1e3 * steps / ms, "us_per_term": t_term * 1e6,
+           "layout_bytes_per_term": by["per_term"], "layout_gbs": by["per_term"] / t_term / 1e9,
+           "frac": by["per_term"] / t_term / 1e9 / HBM_PEAK_GBS,
+           "csr_equivalent_gbs": by["csr_equivalent_per_term"] / t_term / 1e9,
+           "encodings": {"row_blocks": lay["blocks"], "stencil_upper_blocks": lay["stencil_upper_blocks"],
+                         "stencil_lower_blocks": lay["stencil_lower_blocks"], "index_bytes": lay["index_bytes"]},
+           "norm_drift": abs(psi.norm() - 1.0)}
+    for h in (psi, wrk, op, M):
+        h.close()
+    return out
+
+
+def measure_newton_c3(ctx, n=512, m=20, dt=0.5, steps=10, warmup=60):
+    """BASELINE configs[2]: N = n^2 non-Hermitian Liouvillian, Newton / restarted Arnoldi with m_max = m."""
+    Lm = synth.liouvillian_tridiag(n)
+    N, nnz = Lm.shape[0], Lm.nnz
+    M = L.Matrix.from_scipy(ctx, Lm)
+    op = L.Operator(ctx, [M])
+    rho0 = synth.random_state(N)
+    wrk = L.NewtonWrk(ctx, N, m_max=m)
+    psi = L.State(ctx, data=rho0)
+    for _ in range(warmup):
+        L.newton(psi, op, dt, wrk)
+    psi.upload(rho0)          # the open system relaxes: time the same steps every run
+    ctx.sync()
+    ctx.reset_stats()
+    sweeps = matvecs = 0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        L.newton(psi, op, dt, wrk)
+        sweeps += wrk.restarts + 1
+        matvecs += wrk.stats["n_matvec"]
+    ctx.sync()
+    el = time.perf_counter() - t0
+    st = ctx.stats()
+    z = nnz / N
+    # SURVEY 8d model per Arnoldi sweep (this implementation's low-sync MGS reads the basis twice per column)
+    sweep_bytes = m * (20 * z + 36) * N + 64 * N * m * (m + 1) / 2 + 64 * N * m + 32 * N * m + 16 * (m + 2) * N + 16 * (m + 3) * N
+    out = {"workload": "BASELINE configs[2]: Newton prop_step!, N=2^18 non-Hermitian sparse Liouvillian, m_max=20",
+           "N": N, "nnz_per_row": z, "m_max": m, "dt": dt, "steps": steps, "device_format": FMT_NAME[op.format],
+           "ms_per_step": 1e3 * el / steps, "steps_per_s": steps / el,
+           "arnoldi_sweeps_per_step": sweeps / steps, "matvecs_per_step": matvecs / steps,
+           "kernel_launches_per_step": st["n_kernel_launches"] / steps,
+           "launches_per_column": st["n_kernel_launches"] / max(matvecs, 1),
+           "ms_per_sweep": 1e3 * el / sweeps,
+           "algorithmic_gbs": sweep_bytes * sweeps / el / 1e9, "frac": sweep_bytes * sweeps / el / 1e9 / HBM_PEAK_GBS,
+           "norm": psi.norm()}
+    for h in (psi, wrk, op, M):
+        h.close()
+    return out
+
+
+def measure_batched_c5(ctx, log2n=18, batch=64, steps=5, warmup=2):
+    """BASELINE configs[4]: `batch` states x N = 2^log2n CSR H, Chebyshev on the panel."""
+    N = 1 << log2n
+    rp, col, vals = synth.hermitian_offsets_csr(N)
+    nnz = int(rp[-1])
+    M = L.Matrix(ctx, N, N, rp, col, vals)
+    op = L.Operator(ctx, [M])
+    states = np.stack([synth.random_state(N, seed=500 + s) for s in range(batch)], axis=1)
+    panel = L.State(ctx, data=states.reshape(-1))
+    del states
+    wrk = L.ChebyWrk(ctx, N * batch, 20.0, -10.0, 1.0)
+    nterms = wrk.n_coeffs - 1
+    for _ in range(warmup):
+        L.cheby_batched(panel, op, 1.0, wrk, batch)
+    ctx.sync()
+    ctx.timer_begin()
+    for _ in range(steps):
+        L.cheby_batched(panel, op, 1.0, wrk, batch)
+    ms = ctx.timer_end()
+    t_term = ms * 1e-3 / (steps * nterms)
+    alg = 20.0 * nnz + 4.0 * (N + 1) + 80.0 * N * batch          # SURVEY 8d batched model per term
+    sched = L.acc_schedule(wrk.coeffs)
+    nupd = sum(0 if d.skip else 1 for d in sched)
+    # what the shipped step must move per term: matrix once (CSR mirror: 20 B per entry + row pointers + walk order),
+    # X, v_{m-2} read, v_m written, accumulator read + written by the terms of the deferred schedule
+    lay = 20.0 * nnz + 12.0 * N + 16.0 * N * batch * (3.0 - 2.0 / nterms + (2.0 * nupd - 1.0) / nterms)
+    norms = np.linalg.norm(panel.numpy().reshape(N, batch), axis=0)
+    out = {"workload": "BASELINE configs[4]: batched Cheby prop_step!, 64 states x N=2^18 CSR H (16 nnz/row)",
+           "N": N, "batch": batch, "steps": steps, "ms_per_panel_step": ms / steps,
+           "state_steps_per_s": batch * steps / (ms * 1e-3), "us_per_term": t_term * 1e6,
+           "row_walk": dict(zip(("inner_dimension", "strip_width"), op.spmm_walk(batch))),
+           "layout_bytes_per_term": lay, "layout_gbs": lay / t_term / 1e9, "frac": lay / t_term / 1e9 / HBM_PEAK_GBS,
+           "algorithmic_gbs": alg / t_term / 1e9, "algorithmic_frac": alg / t_term / 1e9 / HBM_PEAK_GBS,
+           "max_norm_drift": float(np.max(np.abs(norms - 1.0)))}
+    for h in (panel, wrk, op, M):
+        h.close()
+    return out

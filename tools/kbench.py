@@ -29,8 +29,9 @@ def main():
     ap.add_argument("--real", action="store_true", help="real symmetric H (values streamed as fp64 instead of complex)")
     args = ap.parse_args()
     N = args.n if args.n else 1 << args.log2n
-    offs = synth.BANDED_OFFSETS if args.pattern == "banded" else synth.scattered_offsets(N)
-    rp, col, vals = synth.hermitian_offsets_csr(N, offsets=offs)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import bench_points as bp
+    rp, col, vals = bp.pattern_csr(args.pattern, N)      # banded | scattered | random | random-window
     if args.real:
         vals = vals.real.astype(np.complex128)
     ctx = L.Context(0)
@@ -63,10 +64,15 @@ def main():
             ms = ctx.timer_end()
             times[(f, v)].append(1e3 * ms / (args.steps * nterms))
     print(f"N={N} pattern={args.pattern} terms/step={nterms} alg_bytes/term={alg:.0f}")
-    print(f"{'format':8s} {'var':>3s} {'median_us':>10s} {'min_us':>8s} {'GB/s(med)':>10s} {'frac8T':>7s}")
+    print(f"{'format':8s} {'var':>3s} {'median_us':>10s} {'min_us':>8s} {'csr-equiv GB/s':>15s} {'frac8T':>7s} {'layout MB':>10s} {'layout GB/s':>12s} {'frac8T':>7s}  encodings")
+    ops = {(f, v): op for f, v, op in cases}
     for (f, v), t in times.items():
         med, mn = float(np.median(t)), float(np.min(t))
-        print(f"{f:8s} {v:3d} {med:10.2f} {mn:8.2f} {alg / med / 1e3:10.0f} {alg / med / 1e3 / 8000:7.3f}")
+        by = bp.cheby_layout_bytes(ops[(f, v)], N, N, nnz, wrk.coeffs, real_copy=args.real)
+        lay = by["layout"]
+        print(f"{f:8s} {v:3d} {med:10.2f} {mn:8.2f} {alg / med / 1e3:15.0f} {alg / med / 1e3 / 8000:7.3f} {by['per_term'] / 1e6:10.1f} "
+              f"{by['per_term'] / med / 1e3:12.0f} {by['per_term'] / med / 1e3 / 8000:7.3f}  "
+              f"blocks {lay['blocks']} stencil upper/lower {lay['stencil_upper_blocks']}/{lay['stencil_lower_blocks']} index bytes {lay['index_bytes']}")
     nrm = psi.norm()
     print("norm drift after all steps:", abs(nrm - 1.0))
 

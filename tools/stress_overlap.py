@@ -42,7 +42,7 @@ for log2n, steps in ((14, 300), (16, 300), (18, 200), (20, 100)):
         same = np.array_equal(outs[name][0], outs["serial"][0]) and np.array_equal(outs[name][1], outs["serial"][1])
         print(f"N=2^{log2n} steps={steps} {name:13s} == serial: {same}  norm={np.linalg.norm(outs[name][0]):.15f}", flush=True)
         bad += 0 if same else 1
-    L.tuning_set("split_mode", 1)
+    L.tuning_set("split_mode", 2)
     ctx.close()
 dist.destroy_process_group()
 sys.exit(1 if bad else 0)

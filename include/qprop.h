@@ -180,7 +180,10 @@ int qp_state_download(const qp_state* s, qp_c128* host);
 /* Pin a caller-owned host array (page-lock it for the device) so that qp_state_upload / _download from
  * and to it run at PCIe speed instead of through the runtime's staging buffers: a host-resident
  * caller -- the propagator types of the reference keep `state` in host memory (src/propagator.jl:119-126) --
- * registers its state vector once and unregisters it before the array is freed. */
+ * registers its state vector once and unregisters it before the array is freed.  The registration is
+ * portable (valid for every device of the process): qp_host_unregister may run on any thread, e.g. from a
+ * finalizer.  Only transfers from / to the registered array itself benefit: a caller that allocates a fresh
+ * array per step (the reference's inplace = false mode) downloads through pageable memory. */
 int qp_host_register(void* host, size_t bytes);
 int qp_host_unregister(void* host);
 void* qp_state_ptr(const qp_state* s);

@@ -4,13 +4,24 @@
 #     propagate(Ψ, H, tlist; method = :ChebyHIP)      # or :NewtonHIP
 #     p = init_prop(Ψ, H, tlist; method = :ChebyHIP);  prop_step!(p); reinit_prop!(p, Ψ); ...
 #
+# `H` may be anything the reference's own propagators take: a `Generator` (from `hamiltonian(...)` /
+# `liouvillian(...)`), a tuple generator `(H0, (H1, ϵ1), ...)` -- including the `(H,)` of
+# test/test_propagate.jl:22,157 --, a static `Operator`, or a plain matrix (src/controls.jl:442-475).
+#
+# `Ψ` may be a host vector -- then `p.state` is a host `Vector{ComplexF64}` (pinned; 16·N bytes come back
+# over PCIe after every step, as the reference's interface implies) -- or a device-resident
+# `HIPState(Ψ)`: then `p.state` IS the device vector, `prop_step!` returns it without any transfer, and
+# the vector-space interface the reference requires of a state (src/interfaces/state.jl:92…:
+# copyto!, lmul!, axpy!, dot, norm, fill!, similar, copy, zero) runs on the GPU.
+#
 # It follows the pattern of the reference's own third-party backend,
-# ext/QuantumPropagatorsExponentialUtilitiesExt.jl:74-210 (a propagator struct, an
-# `init_prop` method for a new `Val`, a `prop_step!` method).  STATUS: written against
-# include/qprop.h and the reference sources cited inline; Julia is not installed in the build
-# container, so this file has NOT been executed.  The Python ctypes mirror
-# (quantumpropagators.jl_amd/lib.py + propagator.py) calls exactly the same entry points and is
-# what the test-suite runs.
+# ext/QuantumPropagatorsExponentialUtilitiesExt.jl:74-210 (a propagator struct, an `init_prop` method for
+# a new `Val`, a `prop_step!` method).  STATUS: written against include/qprop.h and the reference sources
+# cited inline; Julia is not installed in the build container, so this file has NOT been executed.  What IS
+# checked mechanically: tests/test_julia_glue_signatures.py parses every `ccall` below and compares name,
+# return type, arity and argument types with include/qprop.h.  The Python ctypes mirror
+# (quantumpropagators.jl_amd/lib.py + propagator.py) calls exactly the same entry points and is what the
+# test-suite runs on the GPU.
 module QuantumPropagatorsHIPExt
 
 using LinearAlgebra
@@ -19,10 +30,13 @@ using QuantumPropagators
 using QuantumPropagators: PWCPropagator, _pwc_process_parameters, _pwc_advance_time!, _pwc_set_t!,
     _get_uniform_dt
 using QuantumPropagators.Controls: get_controls, discretize, evaluate
-using QuantumPropagators.Generators: Generator, Operator
+using QuantumPropagators.Generators: Generator, Operator, hamiltonian
 import QuantumPropagators: init_prop, prop_step!, reinit_prop!, set_state!, set_t!
 
 const LIB = "libqprop_hip"     # quantumpropagators.jl_amd/lib/ on the loader path (or a JLL)
+
+# qp_c128 of include/qprop.h: two doubles, passed by value -- the layout of ComplexF64
+const C128 = ComplexF64
 
 # ------------------------------------------------------------------------------------------
 # status codes -> the reference's exception types (include/qprop.h, "status codes")
@@ -44,7 +58,8 @@ function check(status::Cint)
     end
 end
 
-# opaque handle with a finalizer; `destroy` is the name of the C destructor
+# opaque handle with a finalizer; `destroy` is the name of the C destructor.  The library lets handles
+# be destroyed in any order (a context's record outlives qp_ctx_destroy), so finalizers need no ordering.
 mutable struct Handle
     ptr::Ptr{Cvoid}
     destroy::Symbol
@@ -68,6 +83,106 @@ function make_ctx(device::Integer = 0)
     return Handle(out[], :qp_ctx_destroy)
 end
 
+# one context per device and task tree, created on first use (contexts are cheap: a stream and two events)
+const _CTX = Dict{Int,Handle}()
+default_ctx(device::Integer = 0) = get!(() -> make_ctx(device), _CTX, Int(device))
+
+# ------------------------------------------------------------------------------------------
+# HIPState: a device-resident state vector   (SURVEY 8f N3; src/interfaces/state.jl:92…)
+# ------------------------------------------------------------------------------------------
+"""
+    HIPState(Ψ::AbstractVector; device = 0)     # upload
+    HIPState(undef, n; device = 0)
+
+Complex state vector in HBM.  An `AbstractVector{ComplexF64}` whose vector-space operations -- the ones
+`check_state` (src/interfaces/state.jl:92…) asks for and `cheby!` / `newton!` use (src/cheby.jl:146-148) --
+are library calls on the device: `copyto!`, `lmul!`, `axpy!`, `dot`, `norm`, `fill!`, `similar`, `copy`,
+`zero`, `+`, `-`, `*` by a number.  `Array(Ψ)` / `copyto!(::Vector, Ψ)` download; scalar `getindex` works (one
+element, slow: for debugging and printing only).  Passing a `HIPState` to `init_prop` / `propagate` with
+`method = :ChebyHIP | :NewtonHIP` keeps the propagator's `state` on the device: `prop_step!` returns it
+without a transfer.
+"""
+mutable struct HIPState <: AbstractVector{ComplexF64}
+    h::Handle
+    ctx::Handle
+    n::Int
+end
+
+function HIPState(::UndefInitializer, n::Integer; device::Integer = 0, ctx::Handle = default_ctx(device))
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:qp_state_create, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Ptr{Cvoid}}), ctx, n, out))
+    return HIPState(Handle(out[], :qp_state_destroy, ctx), ctx, Int(n))
+end
+function HIPState(Ψ::AbstractVector; device::Integer = 0, ctx::Handle = default_ctx(device))
+    s = HIPState(undef, length(Ψ); ctx)
+    copyto!(s, Ψ)
+    return s
+end
+
+Base.size(s::HIPState) = (s.n,)
+Base.length(s::HIPState) = s.n
+Base.IndexStyle(::Type{HIPState}) = IndexLinear()
+Base.similar(s::HIPState) = HIPState(undef, s.n; ctx = s.ctx)
+Base.similar(s::HIPState, ::Type{ComplexF64}) = similar(s)
+Base.similar(s::HIPState, ::Type{ComplexF64}, dims::Dims{1}) = HIPState(undef, dims[1]; ctx = s.ctx)
+Base.copy(s::HIPState) = copyto!(similar(s), s)
+Base.zero(s::HIPState) = fill!(similar(s), 0)
+QuantumPropagators.Interfaces.supports_inplace(::Type{HIPState}) = true     # src/interfaces/supports_inplace.jl
+
+# host <-> device
+function Base.copyto!(dst::HIPState, src::AbstractVector)
+    length(src) == dst.n || throw(DimensionMismatch("HIPState of length $(dst.n), source of length $(length(src))"))
+    host = convert(Vector{ComplexF64}, src)
+    GC.@preserve host check(ccall((:qp_state_upload, LIB), Cint, (Ptr{Cvoid}, Ptr{C128}), dst.h, host))
+    return dst
+end
+function Base.copyto!(dst::Vector{ComplexF64}, src::HIPState)
+    length(dst) == src.n || throw(DimensionMismatch("HIPState of length $(src.n), destination of length $(length(dst))"))
+    GC.@preserve dst check(ccall((:qp_state_download, LIB), Cint, (Ptr{Cvoid}, Ptr{C128}), src.h, dst))
+    return dst
+end
+Base.Array(s::HIPState) = copyto!(Vector{ComplexF64}(undef, s.n), s)
+Base.collect(s::HIPState) = Array(s)
+Base.getindex(s::HIPState, i::Int) = Array(s)[i]      # one download per call: debugging / show only
+
+# device <-> device: the six primitives of src/cheby.jl:146-148
+function Base.copyto!(dst::HIPState, src::HIPState)
+    check(ccall((:qp_copy, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), dst.h, src.h))
+    return dst
+end
+function LinearAlgebra.lmul!(a::Number, x::HIPState)
+    check(ccall((:qp_scal, LIB), Cint, (Ptr{Cvoid}, C128), x.h, ComplexF64(a)))
+    return x
+end
+LinearAlgebra.rmul!(x::HIPState, a::Number) = lmul!(a, x)
+function LinearAlgebra.axpy!(a::Number, x::HIPState, y::HIPState)
+    check(ccall((:qp_axpy, LIB), Cint, (C128, Ptr{Cvoid}, Ptr{Cvoid}), ComplexF64(a), x.h, y.h))
+    return y
+end
+function Base.fill!(x::HIPState, a::Number)
+    check(ccall((:qp_fill, LIB), Cint, (Ptr{Cvoid}, C128), x.h, ComplexF64(a)))
+    return x
+end
+function LinearAlgebra.dot(x::HIPState, y::HIPState)
+    out = Ref{ComplexF64}(0)
+    check(ccall((:qp_dot, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{C128}), x.h, y.h, out))
+    return out[]
+end
+function LinearAlgebra.norm(x::HIPState)
+    out = Ref{Cdouble}(0.0)
+    check(ccall((:qp_norm, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), x.h, out))
+    return out[]
+end
+Base.:+(x::HIPState, y::HIPState) = axpy!(1, y, copy(x))
+Base.:-(x::HIPState, y::HIPState) = axpy!(-1, y, copy(x))
+Base.:*(a::Number, x::HIPState) = lmul!(a, copy(x))
+Base.:*(x::HIPState, a::Number) = a * x
+Base.:(==)(x::HIPState, y::HIPState) = Array(x) == Array(y)
+Base.isapprox(x::HIPState, y::HIPState; kwargs...) = isapprox(Array(x), Array(y); kwargs...)
+
+# ------------------------------------------------------------------------------------------
+# operators
+# ------------------------------------------------------------------------------------------
 # One term of the generator.  The library converts Julia's 1-based SparseMatrixCSC{ComplexF64,Int64}
 # (src/generators.jl:473-486) to its device format; nothing is copied on the Julia side.
 function make_matrix(ctx::Handle, A::AbstractMatrix)
@@ -84,8 +199,8 @@ function make_matrix(ctx::Handle, A::AbstractMatrix)
     return Handle(out[], :qp_matrix_destroy, ctx)
 end
 
-# Generators.Operator on the device: lazy sum Σ c_l H_l, drift terms first
-# (src/generators.jl:111-125); mul! at :634-645 becomes qp_mul.
+# Generators.Operator on the device: lazy sum Σ c_l H_l, the first `length(ops) - ncoeffs` ops are drift
+# terms with c = 1 (src/generators.jl:111-125, :635); mul! at :634-645 becomes qp_mul.
 function make_operator(ctx::Handle, ops::AbstractVector, ncoeffs::Integer)
     mats = [make_matrix(ctx, O) for O in ops]
     ptrs = Ptr{Cvoid}[m.ptr for m in mats]
@@ -100,28 +215,52 @@ end
 function set_coeffs!(op::Handle, coeffs::Vector{ComplexF64})
     isempty(coeffs) && return nothing
     GC.@preserve coeffs check(ccall((:qp_operator_set_coeffs, LIB), Cint,
-        (Ptr{Cvoid}, Ptr{ComplexF64}, Cint), op, coeffs, length(coeffs)))
+        (Ptr{Cvoid}, Ptr{C128}, Cint), op, coeffs, length(coeffs)))
 end
 
-# Page-lock the propagator's host-resident state vector (src/propagator.jl:119-126 keeps `state` on the
-# host) so that the hand-back after every step runs at PCIe speed; undone by `unpin!` in the finalizer of
-# the propagator that owns the vector.
+# mul!(C, A::Operator, B, α, β) on device vectors   src/generators.jl:634-645
+function hip_mul!(y::HIPState, op::Handle, x::HIPState, α::Number = true, β::Number = false)
+    check(ccall((:qp_mul, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, C128, C128),
+        op, x.h, y.h, ComplexF64(α), ComplexF64(β)))
+    return y
+end
+
+# What the reference accepts as a generator, as (ops, amplitudes, static coefficients):
+#   Generator                 -> its ops and amplitudes                      (src/generators.jl:45-62)
+#   tuple (H0, (H1, ϵ1), ...) -> hamiltonian(terms...) of the same terms     (src/controls.jl:442-463 sums the
+#                                same matrices with the same coefficients; `(H,)` is the drift alone)
+#   Operator                  -> ops with constant coefficients              (src/generators.jl:119-135)
+#   a matrix                  -> one drift term                              (src/controls.jl:309-313, :466-475)
+struct LazySum
+    ops::Vector{Any}
+    amplitudes::Vector{Any}
+    coeffs::Vector{ComplexF64}     # constant coefficients of a static Operator (applied once)
+end
+lazy_sum(G::Generator) = LazySum(Any[G.ops...], Any[G.amplitudes...], ComplexF64[])
+lazy_sum(O::Operator) = LazySum(Any[O.ops...], Any[], ComplexF64[O.coeffs...])
+lazy_sum(A::AbstractMatrix) = LazySum(Any[A], Any[], ComplexF64[])
+lazy_sum(terms::Tuple) = lazy_sum(hamiltonian(terms...; check = false))
+lazy_sum(G) = throw(ArgumentError("the HIP backend needs a Generator, a tuple generator, an Operator or a matrix, not a $(typeof(G))"))
+
+function device_operator(ctx::Handle, G::LazySum)
+    ncoeffs = isempty(G.amplitudes) ? length(G.coeffs) : length(G.amplitudes)
+    op = make_operator(ctx, G.ops, ncoeffs)
+    isempty(G.coeffs) || set_coeffs!(op, G.coeffs)
+    return op
+end
+
+# the coefficients of interval n: evaluate(ampl, tlist, n; vals_dict)   src/pwc_utils.jl:86-92
+interval_coeffs(G::LazySum, tlist, n, vals_dict) =
+    ComplexF64[evaluate(a, tlist, n; vals_dict) for a in G.amplitudes]
+
+# Page-lock a host-resident state vector (src/propagator.jl:119-126 keeps `state` on the host) so that the
+# hand-back after every step runs at PCIe speed; undone by `unpin!` in the finalizer of the propagator that
+# owns the vector.  The registration is portable across devices and threads (qprop.h), so the finalizer may
+# run anywhere.  Only the in-place mode benefits: inplace = false hands out a fresh, unpinned vector per step.
 pin!(Ψ::Vector{ComplexF64}) =
     (GC.@preserve Ψ check(ccall((:qp_host_register, LIB), Cint, (Ptr{Cvoid}, Csize_t), pointer(Ψ), sizeof(Ψ))); Ψ)
 unpin!(Ψ::Vector{ComplexF64}) =
     GC.@preserve Ψ ccall((:qp_host_unregister, LIB), Cint, (Ptr{Cvoid},), pointer(Ψ))
-
-function make_state(ctx::Handle, Ψ::Vector{ComplexF64})
-    out = Ref{Ptr{Cvoid}}(C_NULL)
-    check(ccall((:qp_state_create, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Ptr{Cvoid}}), ctx, length(Ψ), out))
-    s = Handle(out[], :qp_state_destroy, ctx)
-    upload!(s, Ψ)
-    return s
-end
-upload!(s::Handle, Ψ::Vector{ComplexF64}) =
-    GC.@preserve Ψ check(ccall((:qp_state_upload, LIB), Cint, (Ptr{Cvoid}, Ptr{ComplexF64}), s, Ψ))
-download!(Ψ::Vector{ComplexF64}, s::Handle) =
-    GC.@preserve Ψ check(ccall((:qp_state_download, LIB), Cint, (Ptr{Cvoid}, Ptr{ComplexF64}), s, Ψ))
 
 # cheby_coeffs(Δ, dt; limit)   src/cheby.jl:25-39
 function hip_cheby_coeffs(Δ::Float64, dt::Float64, limit::Float64)
@@ -157,13 +296,13 @@ function hip_specrange(ctx::Handle, op::Handle, N::Integer, method::Symbol; kwar
             state = rand(N) .* exp.((2π * im) .* rand(N))
             state ./= norm(state)
         end
-        s = make_state(ctx, Vector{ComplexF64}(state))
+        s = state isa HIPState ? state : HIPState(Vector{ComplexF64}(state); ctx)
         m_max = get(kwargs, :m_max, 60)
         m_min = get(kwargs, :m_min, 25)
         lo = Ref{Cdouble}(0.0); hi = Ref{Cdouble}(0.0)
         check(ccall((:qp_specrange_arnoldi, LIB), Cint,
             (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Cdouble, Cdouble, Cint, Ptr{Cdouble}, Ptr{Cdouble}),
-            op, s, m_min, m_max, get(kwargs, :prec, 1e-3), get(kwargs, :norm_min, 1e-15),
+            op, s.h, m_min, m_max, get(kwargs, :prec, 1e-3), get(kwargs, :norm_min, 1e-15),
             get(kwargs, :enlarge, true) ? 1 : 0, lo, hi))
         return lo[], hi[]
     else
@@ -174,9 +313,12 @@ end
 # ------------------------------------------------------------------------------------------
 # propagators
 # ------------------------------------------------------------------------------------------
+# `state` is what the caller sees: a HIPState (device-resident: it IS `dstate`) or a host Vector mirror.
+const StateT = Union{HIPState,Vector{ComplexF64}}
+
 mutable struct ChebyHIPPropagator{GT} <: PWCPropagator
     const generator::GT
-    state::Vector{ComplexF64}          # host mirror returned to callers (identical object when in-place)
+    state::StateT
     t::Float64
     n::Int64
     const tlist::Vector{Float64}
@@ -190,25 +332,28 @@ mutable struct ChebyHIPPropagator{GT} <: PWCPropagator
     specrange_options::Dict{Symbol,Any}
     check_normalization::Bool
     # device side
+    lazy::LazySum
     ctx::Handle
     op::Handle
-    dstate::Handle
+    dstate::HIPState
     wrk::Handle
     coeffs::Vector{Float64}
     Δ::Float64
     E_min::Float64
     dt::Float64
     limit::Float64
-    drift_offset::Int
 end
 
 set_t!(p::ChebyHIPPropagator, t) = _pwc_set_t!(p, t)
 
-function _envelope(ctx, op, generator::Generator, N, control_ranges, method; kwargs...)
+function _envelope(ctx, op, G::LazySum, N, control_ranges, method; kwargs...)
     # cheby_get_spectral_envelope   src/cheby_propagator.jl:331-345: all controls at their
-    # minimum / maximum simultaneously
+    # minimum / maximum simultaneously; a generator without controls has one operator
+    if isempty(G.amplitudes)
+        return hip_specrange(ctx, op, N, method; kwargs...)
+    end
     controls = collect(keys(control_ranges))
-    amps(vals) = ComplexF64[evaluate(a, [0.0, 1.0], 1; vals_dict = vals) for a in generator.amplitudes]
+    amps(vals) = ComplexF64[evaluate(a, [0.0, 1.0], 1; vals_dict = vals) for a in G.amplitudes]
     set_coeffs!(op, amps(IdDict(c => control_ranges[c][2] for c in controls)))
     E_min, E_max = hip_specrange(ctx, op, N, method; kwargs...)
     set_coeffs!(op, amps(IdDict(c => control_ranges[c][1] for c in controls)))
@@ -216,13 +361,24 @@ function _envelope(ctx, op, generator::Generator, N, control_ranges, method; kwa
     return min(E_min, _E_min), max(E_max, _E_max)
 end
 
+# the propagator's state pair for a caller state: (what the caller sees, the device vector)
+function _state_pair(ctx::Handle, state, inplace::Bool)
+    if state isa HIPState
+        d = inplace ? copy(state) : state            # init_prop copies when in-place  (src/cheby_propagator.jl:158)
+        return d, d
+    end
+    Ψ = Vector{ComplexF64}(inplace ? copy(state) : state)
+    return Ψ, HIPState(Ψ; ctx)
+end
+
 # init_prop(state, generator, tlist, ::Val{:Cheby}; …)   src/cheby_propagator.jl:87-175
-function init_prop(state, generator::Generator, tlist, ::Val{:ChebyHIP};
+function init_prop(state, generator, tlist, ::Val{:ChebyHIP};
                    inplace = true, backward = false, verbose = false, parameters = nothing,
                    control_ranges = nothing, specrange_method = :auto, specrange_buffer = 0.01,
                    cheby_coeffs_limit = 1e-12, check_normalization = false,
                    uniform_dt_tolerance = 1e-12, device = 0, specrange_kwargs...)
     tlist = convert(Vector{Float64}, tlist)
+    G = lazy_sum(generator)
     controls = get_controls(generator)
     controlvals = [discretize(control, tlist) for control in controls]
     parameters = _pwc_process_parameters(parameters, controls, tlist)
@@ -230,10 +386,10 @@ function init_prop(state, generator::Generator, tlist, ::Val{:ChebyHIP};
         control_ranges = IdDict(c => (minimum(controlvals[i]), maximum(controlvals[i]))
                                 for (i, c) in enumerate(controls))
     end
-    ctx = make_ctx(device)
-    op = make_operator(ctx, generator.ops, length(generator.amplitudes))
+    ctx = state isa HIPState ? state.ctx : default_ctx(device)
+    op = device_operator(ctx, G)
     N = length(state)
-    E_min, E_max = _envelope(ctx, op, generator, N, control_ranges, specrange_method; specrange_kwargs...)
+    E_min, E_max = _envelope(ctx, op, G, N, control_ranges, specrange_method; specrange_kwargs...)
     Δ = E_max - E_min
     @assert Δ > 0.0
     δ = specrange_buffer * Δ                       # :131-133
@@ -242,8 +398,7 @@ function init_prop(state, generator::Generator, tlist, ::Val{:ChebyHIP};
     dt = _get_uniform_dt(tlist; tol = uniform_dt_tolerance, warn = true)
     isnothing(dt) && error("Chebychev propagation only works on a uniform time grid")
     coeffs = hip_cheby_coeffs(Δ, dt, cheby_coeffs_limit)
-    Ψ = Vector{ComplexF64}(inplace ? copy(state) : state)
-    dstate = make_state(ctx, Ψ)
+    Ψ, dstate = _state_pair(ctx, state, inplace)
     wrk_out = Ref{Ptr{Cvoid}}(C_NULL)              # ChebyWrk, src/cheby.jl:87-124
     check(ccall((:qp_cheby_create, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Ptr{Cvoid}}), ctx, N, wrk_out))
     wrk = Handle(wrk_out[], :qp_cheby_destroy, ctx)
@@ -256,13 +411,24 @@ function init_prop(state, generator::Generator, tlist, ::Val{:ChebyHIP};
     p = ChebyHIPPropagator{typeof(generator)}(
         generator, Ψ, t, n, tlist, parameters, controls, control_ranges, backward, inplace,
         specrange_method, specrange_buffer, Dict{Symbol,Any}(specrange_kwargs), check_normalization,
-        ctx, op, dstate, wrk, coeffs, Δ, E_min, dt, cheby_coeffs_limit,
-        length(generator.ops) - length(generator.amplitudes))
-    if inplace                                     # the in-place propagator owns Ψ for its whole life: pin it
+        G, ctx, op, dstate, wrk, coeffs, Δ, E_min, dt, cheby_coeffs_limit)
+    if inplace && Ψ isa Vector{ComplexF64}         # the in-place propagator owns its host mirror for its whole life: pin it
         pin!(Ψ)
-        finalizer(q -> unpin!(getfield(q, :state)), p)
+        finalizer(q -> (s = getfield(q, :state); s isa Vector{ComplexF64} && unpin!(s)), p)
     end
     return p
+end
+
+# the state after a step, as the caller sees it: nothing to do for a device-resident state; the host
+# mirror is refreshed (in place: the same, pinned, vector; not in place: a new vector per step)
+function _hand_back!(p)
+    p.state isa HIPState && return p.state
+    if p.inplace
+        copyto!(p.state, p.dstate)
+    else
+        setfield!(p, :state, Array(p.dstate))
+    end
+    return p.state
 end
 
 # prop_step!(::ChebyPropagator)   src/cheby_propagator.jl:348-386
@@ -270,37 +436,37 @@ function prop_step!(p::ChebyHIPPropagator)
     n = p.n
     tlist = getfield(p, :tlist)
     (0 < n < length(tlist)) || return nothing
-    generator = getfield(p, :generator)
     vals_dict = IdDict(c => p.parameters[c][n] for c in p.controls)        # _pwc_set_genop!  src/pwc_utils.jl:86-92
-    set_coeffs!(p.op, ComplexF64[evaluate(a, tlist, n; vals_dict) for a in generator.amplitudes])
+    set_coeffs!(p.op, interval_coeffs(p.lazy, tlist, n, vals_dict))
     dt = p.backward ? -p.dt : p.dt
     coeffs = p.coeffs
+    if !p.inplace && p.state isa HIPState         # a new state object per step  (src/interfaces/propagator.jl:154-156)
+        p.dstate = copy(p.dstate)
+        setfield!(p, :state, p.dstate)
+    end
     GC.@preserve coeffs check(ccall((:qp_cheby_step, LIB), Cint,                 # cheby!  src/cheby.jl:150-213
         (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Cint, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cint),
-        p.wrk, p.op, p.dstate, coeffs, length(coeffs), p.Δ, p.E_min, dt, p.dt, p.limit,
+        p.wrk, p.op, p.dstate.h, coeffs, length(coeffs), p.Δ, p.E_min, dt, p.dt, p.limit,
         p.check_normalization ? 1 : 0))
-    # hand the state back (16·N bytes per step; a device-resident state type is row N3 of SURVEY 8f)
-    if p.inplace
-        download!(p.state, p.dstate)
-    else
-        Ψ = similar(p.state)
-        download!(Ψ, p.dstate)
-        setfield!(p, :state, Ψ)
-    end
+    _hand_back!(p)
     _pwc_advance_time!(p)                                                        # src/pwc_utils.jl:102-112
     return p.state
 end
 
 # set_state!   src/propagator.jl:367-377
 function set_state!(p::Union{ChebyHIPPropagator}, state)
+    if p.state isa HIPState
+        state ≢ p.state && copyto!(p.dstate, state)     # HIPState or host vector: device copy or upload
+        return p.state
+    end
     if state ≢ p.state
         if p.inplace
-            copyto!(p.state, state)
+            copyto!(p.state, state isa HIPState ? Array(state) : state)
         else
-            setfield!(p, :state, convert(Vector{ComplexF64}, state))
+            setfield!(p, :state, state isa HIPState ? Array(state) : convert(Vector{ComplexF64}, state))
         end
     end
-    upload!(p.dstate, p.state)
+    copyto!(p.dstate, p.state)
     return p.state
 end
 
@@ -316,7 +482,7 @@ function reinit_prop!(p::ChebyHIPPropagator, state; transform_control_ranges = (
         for c in p.controls
             ranges[c] = transform_control_ranges(c, ranges[c][1], ranges[c][2], false)
         end
-        E_min, E_max = _envelope(p.ctx, p.op, getfield(p, :generator), length(p.state), ranges,
+        E_min, E_max = _envelope(p.ctx, p.op, p.lazy, length(p.state), ranges,
                                  p.specrange_method; p.specrange_options...)
         Δ = E_max - E_min
         @assert Δ > 0.0
@@ -341,7 +507,7 @@ end
 
 mutable struct NewtonHIPPropagator{GT} <: PWCPropagator
     const generator::GT
-    state::Vector{ComplexF64}
+    state::StateT
     t::Float64
     n::Int64
     const tlist::Vector{Float64}
@@ -353,9 +519,10 @@ mutable struct NewtonHIPPropagator{GT} <: PWCPropagator
     norm_min::Float64
     relerr::Float64
     max_restarts::Int64
+    lazy::LazySum
     ctx::Handle
     op::Handle
-    dstate::Handle
+    dstate::HIPState
     wrk::Handle
     stats::Base.RefValue{NewtonStats}
 end
@@ -369,18 +536,18 @@ function _func_trampoline(z::Ptr{ComplexF64}, out::Ptr{ComplexF64}, user::Ptr{Cv
     return nothing
 end
 
-function init_prop(state, generator::Generator, tlist, ::Val{:NewtonHIP};
+function init_prop(state, generator, tlist, ::Val{:NewtonHIP};
                    inplace = true, backward = false, verbose = false, parameters = nothing,
                    m_max = 10, func = nothing, norm_min = 1e-14, relerr = 1e-12, max_restarts = 50,
                    device = 0, _...)
     inplace || error("The Newton propagator is only implemented in-place")     # src/newton_propagator.jl:94
     tlist = convert(Vector{Float64}, tlist)
+    G = lazy_sum(generator)
     controls = get_controls(generator)
     parameters = _pwc_process_parameters(parameters, controls, tlist)
-    ctx = make_ctx(device)
-    op = make_operator(ctx, generator.ops, length(generator.amplitudes))
-    Ψ = Vector{ComplexF64}(copy(state))
-    dstate = make_state(ctx, Ψ)
+    ctx = state isa HIPState ? state.ctx : default_ctx(device)
+    op = device_operator(ctx, G)
+    Ψ, dstate = _state_pair(ctx, state, true)
     wrk_out = Ref{Ptr{Cvoid}}(C_NULL)                                            # NewtonWrk, src/newton.jl:23-60
     check(ccall((:qp_newton_create, LIB), Cint, (Ptr{Cvoid}, Int64, Cint, Ptr{Ptr{Cvoid}}), ctx, length(Ψ), m_max, wrk_out))
     wrk = Handle(wrk_out[], :qp_newton_destroy, ctx)
@@ -390,9 +557,14 @@ function init_prop(state, generator::Generator, tlist, ::Val{:NewtonHIP};
         n = length(tlist) - 1
         t = float(tlist[n+1])
     end
-    return NewtonHIPPropagator{typeof(generator)}(generator, Ψ, t, n, tlist, parameters, controls, backward, inplace,
-        func, norm_min, relerr, max_restarts, ctx, op, dstate, wrk,
+    p = NewtonHIPPropagator{typeof(generator)}(generator, Ψ, t, n, tlist, parameters, controls, backward, inplace,
+        func, norm_min, relerr, max_restarts, G, ctx, op, dstate, wrk,
         Ref(NewtonStats(0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0)))
+    if Ψ isa Vector{ComplexF64}
+        pin!(Ψ)
+        finalizer(q -> (s = getfield(q, :state); s isa Vector{ComplexF64} && unpin!(s)), p)
+    end
+    return p
 end
 
 function prop_step!(p::NewtonHIPPropagator)
@@ -401,9 +573,8 @@ function prop_step!(p::NewtonHIPPropagator)
     (0 < n < length(tlist)) || return nothing
     dt = tlist[n+1] - tlist[n]                                                   # :127-130 (non-uniform grids allowed)
     p.backward && (dt = -dt)
-    generator = getfield(p, :generator)
     vals_dict = IdDict(c => p.parameters[c][n] for c in p.controls)
-    set_coeffs!(p.op, ComplexF64[evaluate(a, tlist, n; vals_dict) for a in generator.amplitudes])
+    set_coeffs!(p.op, interval_coeffs(p.lazy, tlist, n, vals_dict))
     if isnothing(p.func)
         func_id, cb, user, box = 0, C_NULL, C_NULL, nothing                     # QP_FUNC_EXPMI
     else
@@ -413,15 +584,19 @@ function prop_step!(p::NewtonHIPPropagator)
     end
     GC.@preserve box check(ccall((:qp_newton_step, LIB), Cint,                   # newton!  src/newton.jl:246-385
         (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cdouble, Cint, Ptr{NewtonStats}),
-        p.wrk, p.op, p.dstate, dt, func_id, cb, user, p.norm_min, p.relerr, p.max_restarts, p.stats))
-    download!(p.state, p.dstate)
+        p.wrk, p.op, p.dstate.h, dt, func_id, cb, user, p.norm_min, p.relerr, p.max_restarts, p.stats))
+    _hand_back!(p)
     _pwc_advance_time!(p)
     return p.state
 end
 
 function set_state!(p::NewtonHIPPropagator, state)
-    state ≢ p.state && copyto!(p.state, state)
-    upload!(p.dstate, p.state)
+    if p.state isa HIPState
+        state ≢ p.state && copyto!(p.dstate, state)
+        return p.state
+    end
+    state ≢ p.state && copyto!(p.state, state isa HIPState ? Array(state) : state)
+    copyto!(p.dstate, p.state)
     return p.state
 end
 

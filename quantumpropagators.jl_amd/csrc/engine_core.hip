@@ -1111,7 +1111,9 @@ int qp_state_download(const qp_state* s, qp_c128* host) {
 int qp_host_register(void* host, size_t bytes) {
   QP_TRY
   if (!host || bytes == 0) return qp::fail(QP_E_BAD_ARG, "qp_host_register: NULL / empty array");
-  QP_HIP(hipHostRegister(host, bytes, hipHostRegisterDefault));
+  // portable: the registration holds for every device / context of the process, so it may be undone from
+  // any thread (a garbage collector's finalizer thread included), whichever device is current there
+  QP_HIP(hipHostRegister(host, bytes, hipHostRegisterPortable));
   return QP_OK;
   QP_CATCH
 }

@@ -46,10 +46,127 @@ def newton_main(rank, world):
         sys.exit(3)
 
 
+def c4_main(rank, world):
+    """BASELINE configs[3] at its size on ONE GPU: N = 2^24 rows, `world` ranks of 2^24 / world rows each sharing
+    GPU 0, the library's one-call step (native driver) with the exchange handed back through the callback
+    communicator.  Size-independent properties (norm, forward / backward round trip) and, for the state after
+    ONE step, a comparison with the C restatement of the reference on windows of 2^18 rows -- after n terms a row
+    depends on the rows within n x 4096 of it, so the middle of a window that wide is exact -- one window in the
+    interior of a rank, one across the boundary between two ranks, one across the periodic wrap."""
+    from oracle import ref_c
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    N = 1 << int(os.environ.get("QP_LOG2N", "24"))
+    rows = N // world
+    r0, r1 = rank * rows, (rank + 1) * rows
+    rp, col, vals = synth.hermitian_offsets_csr(N, row_begin=r0, row_end=r1)
+    ctx = L.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    sh = sharded.ShardedCheby(ctx, rp, col, vals, N, r0, r1, 20.0, -10.0, 1.0, exchange="auto", overlap=True,
+                              host_staged=True, native=True)
+    del rp, col, vals
+    if sh.native is None or sh.exchange != "halo" or sh.split is None:
+        sys.exit(5)
+    psi0 = synth.random_state(N, row_begin=r0, row_end=r1)
+    sh.set_state(psi0)
+    sh.step()
+    torch.cuda.synchronize()
+    one = sh.local_state()
+    sh.step()
+    torch.cuda.synchronize()
+    two = sh.local_state()
+    n2 = torch.tensor([float(np.vdot(one, one).real), float(np.vdot(two, two).real)], dtype=torch.float64)
+    dist.all_reduce(n2)
+    sh.step(backward=True)
+    sh.step(backward=True)
+    torch.cuda.synchronize()
+    sh.check()
+    back = float(np.linalg.norm(sh.local_state() - psi0))
+    # windows of the oracle: (centre row, half width of the compared middle)
+    W, half = 1 << 18, 2048
+    coeffs = L.cheby_coeffs(20.0, 1.0)
+    assert (len(coeffs) - 1) * 4096 + half < W // 2
+    werr = 0.0
+    for centre in (rows // 2 + 12345, 3 * rows, 0):            # interior of rank 0 | ranks 2 / 3 | ranks world-1 / 0
+        lo = centre - W // 2                                  # window rows lo .. lo + W (mod N)
+        wrows = (np.arange(lo, lo + W, dtype=np.int64)) % N
+        mine = np.nonzero((wrows >= r0) & (wrows < r1) & (np.abs(np.arange(W) - W // 2) < half))[0]
+        if len(mine) == 0:
+            continue
+        # the window's rows of H with columns renumbered into the window (entries leaving it dropped: they
+        # only influence rows closer than 31 x 4096 to the window's edge)
+        parts = []
+        for a, b in ((lo % N, min(N, lo % N + W)), (0, (lo % N + W) - N)):
+            if b > a:
+                parts.append(synth.hermitian_offsets_csr(N, row_begin=a, row_end=b))
+        wcol = np.concatenate([p_[1] for p_ in parts]).astype(np.int64)
+        wval = np.concatenate([p_[2] for p_ in parts])
+        wloc = (wcol - lo) % N
+        keep = wloc < W
+        lens = np.add.reduceat(keep.astype(np.int64), np.arange(0, len(keep), 16))
+        wrp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        wpsi = np.concatenate([synth.random_state(N, row_begin=a, row_end=b) for a, b in
+                               ((lo % N, min(N, lo % N + W)), (0, (lo % N + W) - N)) if b > a])
+        # Hermitian window block: CSC = conj CSR
+        ref_c.cheby_csc(wrp, wloc[keep], np.conj(wval[keep]), wpsi, coeffs, 20.0, -10.0, 1.0)
+        werr = max(werr, float(np.max(np.abs(one[wrows[mine] - r0] - wpsi[mine]))))
+    print(f"rank {rank}/{world}: c4 N=2^{int(np.log2(N))} err={werr:.3e} norm1-1={abs(float(n2[0]) - 1):.2e} "
+          f"norm2-1={abs(float(n2[1]) - 1):.2e} roundtrip={back:.3e} exchange={sh.exchange} M={sh.M} p2p={sh.p2p}", flush=True)
+    dist.barrier()
+    sh.close()
+    dist.destroy_process_group()
+    if not (werr < 1e-12 and abs(float(n2[0]) - 1) < 1e-11 and abs(float(n2[1]) - 1) < 1e-11 and back < 1e-10):
+        sys.exit(3)
+
+
+def rccl_main(rank, world):
+    """One GPU per rank, the library's own RCCL communicator (qp_comm_prepare / qp_comm_connect, id over the
+    gloo group): the native one-call step in all its forms against the oracle.  Needs `world` GPUs."""
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(rank)
+    N = 12288
+    ctx = L.Context(rank, stream=torch.cuda.current_stream().cuda_stream)
+    worst = 0.0
+    for offsets, exchange, overlap, p2p in (((1, 2, 3, 4, 16, 32, 48, 64), "auto", True, True),
+                                            ((1, 2, 3, 4, 16, 32, 48, 64), "auto", False, False),
+                                            ((5, 777, 2111, 3333, 4001, 4667, 5889, 6099), "allgather", True, False)):
+        rp, col, vals = synth.hermitian_offsets_csr(N, offsets=offsets)
+        bounds = qo.partition_rows(rp, world)
+        r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
+        sh = sharded.ShardedCheby(ctx, rp[r0:r1 + 1] - rp[r0], col[rp[r0]:rp[r1]], vals[rp[r0]:rp[r1]], N, r0, r1,
+                                  20.0, -10.0, 1.0, exchange=exchange, overlap=overlap, native=True, p2p=p2p)
+        if sh.native is None:
+            print(f"rank {rank}: native driver unavailable: {sh.native_error}", flush=True)
+            sys.exit(5)
+        psi0 = synth.random_state(N)
+        sh.set_state(psi0[r0:r1])
+        for _ in range(3):
+            sh.step()
+        sh.step(backward=True)
+        torch.cuda.synchronize()
+        sh.check()
+        H = synth.to_scipy(rp, col, vals, N)
+        wrk = qo.ChebyWrk(psi0, 20.0, -10.0, 1.0)
+        ref = psi0.copy()
+        for _ in range(3):
+            qo.cheby(ref, H, 1.0, wrk)
+        qo.cheby(ref, H, -1.0, wrk)
+        worst = max(worst, float(np.linalg.norm(sh.local_state() - ref[r0:r1])))
+        sh.close()
+    print(f"rank {rank}/{world}: rccl err={worst:.3e}", flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    if not worst < 1e-10:
+        sys.exit(3)
+
+
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     if os.environ.get("QP_METHOD") == "newton":
         return newton_main(rank, world)
+    if os.environ.get("QP_METHOD") == "c4":
+        return c4_main(rank, world)
+    if os.environ.get("QP_METHOD") == "rccl":
+        return rccl_main(rank, world)
     overlap = os.environ.get("QP_OVERLAP", "1") == "1"
     exchange = os.environ.get("QP_EXCHANGE", "auto")
     uneven = os.environ.get("QP_UNEVEN", "0") == "1"

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(world, **env_extra):
+def _run(world, timeout=240, **env_extra):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -27,7 +27,7 @@ def _run(world, **env_extra):
     outs = []
     for p in procs:
         try:
-            out, _ = p.communicate(timeout=240)
+            out, _ = p.communicate(timeout=timeout)
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
@@ -68,6 +68,27 @@ def test_multirank_native_driver_one_gpu(world, overlap, exchange, uneven, p2p):
 def test_multirank_newton_one_gpu(world):
     """Row-partitioned newton! (all-reduced Arnoldi inner products) with ranks sharing the GPU."""
     _run(world, QP_METHOD="newton")
+
+
+def test_c4_full_size_eight_ranks_one_gpu():
+    """BASELINE configs[3] at its size: N = 2^24 rows as 8 ranks x 2^21 rows sharing the one GPU, the library's
+    one-call step with the exchange through the callback communicator (the same code that runs with RCCL on one
+    GPU per rank): norms, forward / backward round trip, and the state after one step against the C oracle on
+    2^18-row windows inside a rank, across a rank boundary and across the periodic wrap."""
+    outs = _run(8, timeout=900, QP_METHOD="c4")
+    assert all("c4 N=2^24" in o and "exchange=halo" in o and "M=8192" in o for o in outs)
+    assert sum("err=0.000e+00" not in o for o in outs) >= 3      # the windows were compared on the ranks that own them
+
+
+def test_library_rccl_communicator_two_gpus():
+    """The library's own multi-rank RCCL communicator (two-phase set-up, ncclSend / ncclRecv neighbour exchange,
+    ncclAllGather, overlapped and serial schedules) against the oracle -- one GPU per rank, so this needs two
+    GPUs and skips itself on the one-GPU test boxes."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs (RCCL forms no multi-rank communicator on one device)")
+    outs = _run(2, QP_METHOD="rccl")
+    assert all("rccl err=" in o for o in outs)
 
 
 @pytest.mark.parametrize("world,driver", [(2, "native"), (3, "torch")])

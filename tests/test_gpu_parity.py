@@ -629,13 +629,13 @@ def test_full_size_properties(ctx):
 @pytest.mark.parametrize("window", [None, 1024])
 @pytest.mark.parametrize("fmt", [L.FMT_AUTO, L.FMT_HRB, L.FMT_RBCSR, L.FMT_CSR])
 def test_random_columns_matches_oracle(ctx, window, fmt):
-    """An irregular H -- columns drawn per row, globally or inside 1024-row windows, 14-16 entries per
+    """An irregular H -- columns drawn per row, globally or inside 1024-row windows, 12-16 entries per
     row (no translation invariance: no stencil blocks, per-entry indices) -- through every device
     format against the oracle, forward and backward, plus the bit-exact device round trip."""
     N = 1 << 14
     rp, col, vals = synth.random_columns_csr(N, window=window, seed=4242)
     H = synth.to_scipy(rp, col, vals, N)
-    assert abs(H - H.conj().T).max() == 0 and set(np.diff(rp)) <= {14, 15, 16}
+    assert abs(H - H.conj().T).max() == 0 and np.diff(rp).max() == 16 and np.diff(rp).min() >= 12
     Op = L.Operator(ctx, [L.Matrix(ctx, N, N, rp, col, vals)], 0, fmt)
     lay = Op.layout_info()
     if Op.format != L.FMT_CSR:

@@ -389,6 +389,10 @@ typedef struct {
    * "arnoldi!", "diagonalize_hessenberg_matrix", "get Leja points", "get Newton coeffs",
    * "evaluate polynomial" of src/newton.jl:276-343) */
   double ms_arnoldi, ms_eig, ms_leja, ms_coeffs, ms_poly, ms_update;
+  /* host time the DEVICE waited for: from the arrival of a sweep's last Hessenberg column to the launch of
+   * the kernel that applies the Newton polynomial (last eigenvalue block, Leja ordering, coefficients,
+   * polynomial), summed over the restarts of the step */
+  double ms_exposed;
 } qp_newton_stats;
 /* NewtonWrk(v0; m_max)  src/newton.jl:23-60 */
 int qp_newton_create(qp_ctx* ctx, int64_t n, int m_max, qp_newton** out);

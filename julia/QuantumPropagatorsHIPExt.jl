@@ -503,6 +503,7 @@ struct NewtonStats                  # qp_newton_stats
     restarts::Cint; n_a::Cint; n_leja::Cint; m_last::Cint; n_matvec::Cint
     radius::Cdouble; last_relerr::Cdouble; norm_psi::Cdouble
     ms_arnoldi::Cdouble; ms_eig::Cdouble; ms_leja::Cdouble; ms_coeffs::Cdouble; ms_poly::Cdouble; ms_update::Cdouble
+    ms_exposed::Cdouble
 end
 
 mutable struct NewtonHIPPropagator{GT} <: PWCPropagator
@@ -559,7 +560,7 @@ function init_prop(state, generator, tlist, ::Val{:NewtonHIP};
     end
     p = NewtonHIPPropagator{typeof(generator)}(generator, Ψ, t, n, tlist, parameters, controls, backward, inplace,
         func, norm_min, relerr, max_restarts, G, ctx, op, dstate, wrk,
-        Ref(NewtonStats(0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0)))
+        Ref(NewtonStats(0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0)))
     if Ψ isa Vector{ComplexF64}
         pin!(Ψ)
         finalizer(q -> (s = getfield(q, :state); s isa Vector{ComplexF64} && unpin!(s)), p)

@@ -114,6 +114,19 @@ struct PlainEpi {
   double2* y;
   double2 alpha, beta;
   int beta_zero;
+  // Arnoldi column with the previous column's "norm + scale" folded in (src/arnoldi.jl:89-96 applied on the
+  // fly): x is the UNNORMALISED q_j; h = |x| comes from the kRedBlocks partials of |x|^2 that the projection
+  // kernel left (every workgroup re-reduces them in its prologue, fixed order), the row sum is scaled by 1 / h
+  // (unless h < norm_min: dimensionality exhausted, nothing is scaled), the row's own element x_i / h goes to
+  // the basis vector qn_out, and workgroup 0 records Hess[j, j-1] = dt h and the norm for the host.
+  const double2* norm_part = nullptr;
+  const double2* xloc = nullptr;   // row-local element of x (x + xoff)
+  double2* qn_out = nullptr;
+  double2* hess_slot = nullptr;
+  double* norm_slot = nullptr;
+  double dt = 1.0, norm_min = 0.0;
+  unsigned* flag = nullptr;        // host-visible: set to flag_value once hess_slot / norm_slot are written
+  unsigned flag_value = 0;
 };
 
 struct Stats {
@@ -129,9 +142,10 @@ int spmv_grid_size(const DevMatrix& A);
 // qp_ctx_tuning_set); qp_tuning_set only changes the defaults that contexts created afterwards start
 // from, so handles driven from different threads never observe each other's switches.
 struct Tuning {
-  int rbcsr_variant = 7;      // bit 0 nt matrix loads, bit 1 early row-local loads, bit 2 deeper unroll (A/B in profiles/)
+  int rbcsr_variant = 15;     // bit 0 nt matrix loads, bit 1 early row-local loads, bit 2 deeper unroll, bit 3 (Hermitian-packed kernel) all loads of an all-stencil block up front (A/B in profiles/)
   int hrb_lower_last = 0;     // HRB kernel: process the lower (conj-transposed) section after the upper one
   int arnoldi_mode = 1;       // 0 = sequential fused MGS passes, 1 = low-synchronisation MGS
+  int arnoldi_fold = 1;       // 1 = the norm + scale of an Arnoldi column is folded into the next column's mat-vec (no launch of its own)
   int split_mode = 2;         // boundary -> interior hand-off: 0 = cross-stream events, 1 = in-launch counter, 2 = the counter when at most 256 workgroups poll
   int liouville_fused_n = 320;  // matrix-free Liouvillian: largest n that takes the fused matrix-core kernel (else library GEMMs)
   int real_vals = 1;          // operator refresh: stream a real copy of the values when they are all real

@@ -117,6 +117,7 @@ struct qp_krylov {
   int64_t n;
   int nvec;
   double2* Q = nullptr;         // nvec vectors of length n, contiguous
+  double2* raw[2] = {nullptr, nullptr};   // unnormalised vectors of the folded sweep (knob arnoldi_fold), on demand
   double2* hess_dev = nullptr;  // nvec x nvec column major
   double* norms_dev = nullptr;  // nvec
   double2* part = nullptr;      // 2 x kRedBlocks ping-pong partials
@@ -131,6 +132,13 @@ struct qp_krylov {
   double2* hess_map = nullptr;  // the same pinned buffers as the device sees them: the multi-launch
   double* norms_map = nullptr;  // Arnoldi sweep writes its Hessenberg entries straight to the host
   std::vector<hipEvent_t> col_events;  // one per column: "column j is on the host" (pipelined restarts)
+  // folded sweep: the mat-vec of column j + 1 announces "column j is complete on the host" by storing the sweep's
+  // sequence number into col_flags[j] (coherent pinned memory, system-scope release) after it has written
+  // Hess[j+1, j] and the norm -- the host polls instead of waiting for an event (no event record between columns)
+  unsigned* col_flags = nullptr;
+  unsigned* col_flags_map = nullptr;
+  unsigned seq = 0;
+  std::chrono::steady_clock::time_point t_last_column;   // when the host saw the last column of the latest sweep
   double2* q(int i) const { return Q + (size_t)i * n; }
 };
 
@@ -170,7 +178,7 @@ struct qp_newton {
   double2* h_npart = nullptr;
   std::vector<cplx> a, leja;
   std::vector<cplx> Hess, R, P, Rn, ritz;   // host work arrays of a step, kept between calls
-  std::vector<double> leja_prod;            // head of each Leja candidate's product chain (built while the columns arrive)
+  std::vector<qp::ScaledProd> leja_prod;            // head of each Leja candidate's product chain (built while the columns arrive)
   double radius = 0;
   int n_a = 0, n_leja = 0, restarts = 0;
 };

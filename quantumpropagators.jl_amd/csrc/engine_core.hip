@@ -787,8 +787,34 @@ static int choose_format(qp_operator* op, int requested, bool hermitian) {
         ++nlow;
         if (r - uc[p] <= maxdist) ++nnear;
       }
+    // ... and only if the transposed reads are coalesced: in a block whose 64 rows have their k-th entry at
+    // the same distance from the diagonal (stencil-like: lattices, tensor products) the wave reads 64
+    // consecutive values; in an irregular block every lane pulls its own L2 line for 16 useful bytes
+    // (measured, columns drawn per row inside 4096-row windows: Hermitian-packed 138 us vs 103 us per
+    // term, profiles/r02/kbench_random_window.txt).  A sample of the blocks decides.
+    int64_t sampled = 0, regular = 0;
+    const int64_t bstride = std::max<int64_t>(1, nblocks / 512);
+    for (int64_t b = 0; b < nblocks; b += bstride) {
+      const int64_t r0 = b * kRB, r1 = std::min(nrows, r0 + kRB);
+      if (r1 - r0 < kRB) continue;
+      ++sampled;
+      // the lower entries (col < row: the ones read through the transposed position) of every row of the
+      // block at the same distances from the diagonal
+      bool same = true;
+      int64_t nl0 = 0;
+      while (ur[r0] + nl0 < ur[r0 + 1] && uc[ur[r0] + nl0] < r0) ++nl0;
+      for (int64_t r = r0 + 1; r < r1 && same; ++r) {
+        int64_t nl = 0;
+        while (ur[r] + nl < ur[r + 1] && uc[ur[r] + nl] < r) ++nl;
+        if (nl != nl0) same = false;
+        for (int64_t k = 0; k < nl0 && same; ++k)
+          if ((int64_t)uc[ur[r] + k] - r != (int64_t)uc[ur[r0] + k] - r0) same = false;
+      }
+      if (same) ++regular;
+    }
+    const bool coalesced = sampled == 0 || 4 * regular >= 3 * sampled;
     // (the packed format addresses the transposed values with int32 positions)
-    return ((double)nnear >= 0.85 * (double)nlow && rb_stored < (int64_t)INT32_MAX) ? QP_FMT_HRB : QP_FMT_RBCSR;
+    return ((double)nnear >= 0.85 * (double)nlow && coalesced && rb_stored < (int64_t)INT32_MAX) ? QP_FMT_HRB : QP_FMT_RBCSR;
   }
   if (requested == QP_FMT_HRB && !hermitian) return -1;
   return requested;

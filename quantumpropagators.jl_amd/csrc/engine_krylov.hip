@@ -29,10 +29,16 @@ int qp_krylov_create(qp_ctx* ctx, int64_t n, int nvec, qp_krylov** out) {
   QP_CHECK(dev_alloc(&q->mgs_coef, (size_t)nvec));
   QP_HIP(hipMalloc((void**)&q->ticket, sizeof(unsigned)));
   QP_HIP(hipMemsetAsync(q->ticket, 0, sizeof(unsigned), ctx->stream));
-  QP_HIP(hipHostMalloc((void**)&q->h_hess, sizeof(double2) * (size_t)nvec * nvec, hipHostMallocDefault));
-  QP_HIP(hipHostMalloc((void**)&q->h_norms, sizeof(double) * (size_t)nvec, hipHostMallocDefault));
+  // coherent (fine-grained) pinned memory: what a kernel stores there is visible to the host while the sweep is
+  // still running, which the flag hand-off of the folded sweep relies on
+  const unsigned hflags = hipHostMallocMapped | hipHostMallocCoherent;
+  QP_HIP(hipHostMalloc((void**)&q->h_hess, sizeof(double2) * (size_t)nvec * nvec, hflags));
+  QP_HIP(hipHostMalloc((void**)&q->h_norms, sizeof(double) * (size_t)nvec, hflags));
+  QP_HIP(hipHostMalloc((void**)&q->col_flags, sizeof(unsigned) * (size_t)nvec, hflags));
+  std::memset(q->col_flags, 0, sizeof(unsigned) * (size_t)nvec);
   QP_HIP(hipHostGetDevicePointer((void**)&q->hess_map, q->h_hess, 0));
   QP_HIP(hipHostGetDevicePointer((void**)&q->norms_map, q->h_norms, 0));
+  QP_HIP(hipHostGetDevicePointer((void**)&q->col_flags_map, q->col_flags, 0));
   *out = q.release();
   return QP_OK;
   QP_CATCH
@@ -44,6 +50,8 @@ int qp_krylov_destroy(qp_krylov* q) {
   (void)hipSetDevice(q->ctx->device);
   (void)hipStreamSynchronize(q->ctx->stream);
   if (q->Q) (void)hipFree(q->Q);
+  if (q->raw[0]) (void)hipFree(q->raw[0]);
+  if (q->raw[1]) (void)hipFree(q->raw[1]);
   if (q->hess_dev) (void)hipFree(q->hess_dev);
   if (q->norms_dev) (void)hipFree(q->norms_dev);
   if (q->part) (void)hipFree(q->part);
@@ -51,6 +59,7 @@ int qp_krylov_destroy(qp_krylov* q) {
   if (q->gram) (void)hipFree(q->gram);
   if (q->h_hess) (void)hipHostFree(q->h_hess);
   if (q->h_norms) (void)hipHostFree(q->h_norms);
+  if (q->col_flags) (void)hipHostFree(q->col_flags);
   if (q->hcoef) (void)hipFree(q->hcoef);
   if (q->mgs_coef) (void)hipFree(q->mgs_coef);
   if (q->ticket) (void)hipFree(q->ticket);
@@ -72,31 +81,54 @@ int qp_krylov_download(const qp_krylov* q, int i, qp_c128* host) {
 
 namespace {
 
-// q[j+1] = H q[j], then modified Gram-Schmidt against q[0..j] with the fused
-// axpy->dot passes; leaves |q[j+1]|^2 partials in part[(j+1)&1].  hess column `hcol`
-// (device, length >= j+1) receives dt*<q_i|q_j+1>.
-int arnoldi_column(qp_operator* op, qp_krylov* q, int j, double dt, double2* hcol) {
+// One Arnoldi column: w = H x (x = q[j], or the UNNORMALISED q[j] with the previous column's norm + scale
+// folded into this mat-vec, see PlainEpi), then modified Gram-Schmidt of w against q[0..j]; leaves |w|^2
+// partials in part[(j+1)&1].  hess column `hcol` (device, length >= j+1) receives dt*<q_i|w>.
+struct FoldArgs {
+  const double2* norm_part;   // |x|^2 partials of the previous column's projection
+  double2* hess_slot;         // Hess[j, j-1]
+  double* norm_slot;          // norms[j-1]
+  double norm_min;
+  unsigned* flag;             // col_flags[j-1] (device address) or null
+  unsigned flag_value;
+};
+
+int arnoldi_column(qp_operator* op, qp_krylov* q, int j, double dt, double2* hcol, const double2* xin = nullptr,
+                   double2* w = nullptr, const FoldArgs* fold = nullptr) {
   qp_ctx* ctx = op->ctx;
+  if (!xin) xin = q->q(j);
+  if (!w) w = q->q(j + 1);
   qp::PlainEpi pe;
-  pe.y = q->q(j + 1);
+  pe.y = w;
   pe.alpha = make_double2(1.0, 0.0);
   pe.beta = make_double2(0.0, 0.0);
   pe.beta_zero = 1;
-  QP_CHECK(qp::launch_spmv_plain(ctx->stream, op->A, q->q(j), pe, &ctx->stats));  // src/arnoldi.jl:82
+  if (fold) {
+    pe.norm_part = fold->norm_part;
+    pe.xloc = xin;
+    pe.qn_out = q->q(j);
+    pe.hess_slot = fold->hess_slot;
+    pe.norm_slot = fold->norm_slot;
+    pe.dt = dt;
+    pe.norm_min = fold->norm_min;
+    pe.flag = fold->flag;
+    pe.flag_value = fold->flag_value;
+  }
+  QP_CHECK(qp::launch_spmv_plain(ctx->stream, op->A, xin, pe, &ctx->stats));  // src/arnoldi.jl:82
   if (ctx->tun.arnoldi_mode == 1 && q->gram_rows >= j && qp::mgs_lowsync_fits(j)) {
     // low-synchronisation MGS: same coefficients (to rounding), 3 launches per column;
-    // leaves |q[j+1]|^2 partials in part[(j+1)&1] like the sequential path.  Needs the Gram
+    // leaves |w|^2 partials in part[(j+1)&1] like the sequential path.  Needs the Gram
     // rows of the earlier basis vectors, which only this path maintains (a basis built by
     // the persistent small-system kernel or by sequential passes continues sequentially).
     q->gram_rows = j + 1;
-    return qp::launch_mgs_lowsync(ctx->stream, q->Q, q->n, j, q->q(j + 1), q->md_part, q->gram, q->nvec, hcol,
+    return qp::launch_mgs_lowsync(ctx->stream, q->Q, q->n, j, w, q->md_part, q->gram, q->nvec, hcol,
                                   q->hcoef, q->mgs_coef, q->ticket, q->part + (size_t)((j + 1) & 1) * kRedBlocks, dt,
                                   q->n, &ctx->stats);
   }
   q->gram_rows = std::min(q->gram_rows, j);
   for (int i = 0; i <= j + 1; ++i) {                                              // :84-87
     qp::MgsArgs a;
-    a.w = q->q(j + 1);
+    a.w = w;
     a.q_prev = (i > 0) ? q->q(i - 1) : nullptr;
     a.q_cur = (i <= j) ? q->q(i) : nullptr;
     a.part_in = q->part + (size_t)((i + 1) & 1) * kRedBlocks;
@@ -111,8 +143,9 @@ int arnoldi_column(qp_operator* op, qp_krylov* q, int j, double dt, double2* hco
 
 }  // namespace
 
-__global__ void norm_guard_scale_kernel(double2* __restrict__ w, const double2* __restrict__ part_in, double2* hess_slot,
-                                        double* norm_slot, double dt, double norm_min, int64_t n);
+__global__ void norm_guard_scale_kernel(double2* w, const double2* __restrict__ part_in, double2* hess_slot,
+                                        double* norm_slot, double dt, double norm_min, int64_t n, const double2* w_in,
+                                        unsigned* flag, unsigned flag_value);
 
 // workgroups of norm_guard_scale_kernel: every one re-reduces the 256 partials, so no more of them than
 // two elements per lane need (the partial order, hence the norm, does not depend on the grid)
@@ -144,6 +177,8 @@ static int arnoldi_impl(qp_operator* op, qp_krylov* q, int m, const qp_state* ps
   qp::SmallArgs plan;
   bool small = false;
   bool piped = false;
+  bool fold = false;
+  bool flags = false;   // folded + pipelined sweep: columns are announced through col_flags, not events
   if (ctx->tun.small_nnz > 0 && op->A.nnz <= (int64_t)ctx->tun.small_nnz * (qp::kSmallEptArnoldi / qp::kSmallEpt) &&
       qp::small_arnoldi_fits(q->n, m)) {
     int64_t maxrow = 0;
@@ -197,17 +232,45 @@ static int arnoldi_impl(qp_operator* op, qp_krylov* q, int m, const qp_state* ps
         q->col_events.push_back(e);
       }
     }
+    // knob arnoldi_fold: "norm + scale" of column j is done by the mat-vec of column j + 1 (it scales its row
+    // sums by 1 / |q_j| and stores the normalised q_j as it goes; src/arnoldi.jl:89-96 applied on the fly), so a
+    // column is mat-vec + projection only.  The unnormalised vectors ping-pong between two scratch vectors.
+    fold = ctx->tun.arnoldi_fold != 0 && op->A.format != QP_FMT_MATFREE && m > 1;
+    if (fold && !q->raw[0]) {
+      QP_CHECK(dev_alloc(&q->raw[0], (size_t)q->n));
+      QP_CHECK(dev_alloc(&q->raw[1], (size_t)q->n));
+    }
+    flags = fold && piped;
+    if (flags) q->seq = q->seq + 1 == 0 ? 1 : q->seq + 1;
     for (int j = 0; j < m; ++j) {
       double2* hcol = q->hess_map + (size_t)j * ldd;
-      QP_CHECK(arnoldi_column(op, q, j, dt, hcol));
-      if ((j + 1 < m) || extended) {                                                               // :88-97
-        hipLaunchKernelGGL(norm_guard_scale_kernel, dim3(guard_grid(q->n)), dim3(qp::kThreads), 0, ctx->stream, q->q(j + 1),
-                           q->part + (size_t)((j + 1) & 1) * kRedBlocks, hcol + (j + 1), q->norms_map + j, dt, norm_min,
-                           q->n);
-        QP_HIP(hipGetLastError());
-        ctx->stats.n_launch++;
+      if (fold) {
+        FoldArgs fa{q->part + (size_t)(j & 1) * kRedBlocks, j > 0 ? q->hess_map + (size_t)(j - 1) * ldd + j : nullptr,
+                    j > 0 ? q->norms_map + (j - 1) : nullptr, norm_min, (flags && j > 0) ? q->col_flags_map + (j - 1) : nullptr,
+                    q->seq};
+        QP_CHECK(arnoldi_column(op, q, j, dt, hcol, j == 0 ? q->q(0) : q->raw[j & 1], q->raw[(j + 1) & 1], j > 0 ? &fa : nullptr));
+        if (j + 1 == m) {   // the last vector: normalised into the basis (extended), or handed over as it is
+          if (extended) {
+            hipLaunchKernelGGL(norm_guard_scale_kernel, dim3(guard_grid(q->n)), dim3(qp::kThreads), 0, ctx->stream, q->q(j + 1),
+                               q->part + (size_t)((j + 1) & 1) * kRedBlocks, hcol + (j + 1), q->norms_map + j, dt, norm_min,
+                               q->n, (const double2*)q->raw[(j + 1) & 1], flags ? q->col_flags_map + j : (unsigned*)nullptr, q->seq);
+            QP_HIP(hipGetLastError());
+            ctx->stats.n_launch++;
+          } else {
+            QP_HIP(hipMemcpyAsync(q->q(j + 1), q->raw[(j + 1) & 1], (size_t)q->n * sizeof(double2), hipMemcpyDeviceToDevice, ctx->stream));
+          }
+        }
+      } else {
+        QP_CHECK(arnoldi_column(op, q, j, dt, hcol));
+        if ((j + 1 < m) || extended) {                                                               // :88-97
+          hipLaunchKernelGGL(norm_guard_scale_kernel, dim3(guard_grid(q->n)), dim3(qp::kThreads), 0, ctx->stream, q->q(j + 1),
+                             q->part + (size_t)((j + 1) & 1) * kRedBlocks, hcol + (j + 1), q->norms_map + j, dt, norm_min,
+                             q->n, (const double2*)q->q(j + 1), (unsigned*)nullptr, 0u);
+          QP_HIP(hipGetLastError());
+          ctx->stats.n_launch++;
+        }
       }
-      if (piped) QP_HIP(hipEventRecord(q->col_events[j], ctx->stream));
+      if (piped && !flags) QP_HIP(hipEventRecord(q->col_events[j], ctx->stream));
     }
   }
   const cplx* hh = reinterpret_cast<const cplx*>(q->h_hess);
@@ -221,8 +284,35 @@ static int arnoldi_impl(qp_operator* op, qp_krylov* q, int m, const qp_state* ps
   if (small && beta_out) *beta_out = hn[ldd - 1];   // written by the kernel (slot ldd - 1 is never a column's)
   int m_eff = m;
   int hook_rc = QP_OK;
+  // wait until column j is complete on the host: an event, or (folded sweep) the flag that the mat-vec of
+  // column j + 1 sets after the column's last entries -- the last column has no successor: stream end
+  auto wait_column = [&](int j) -> int {
+    if (!piped) return QP_OK;
+    if (!flags) {
+      QP_HIP(hipEventSynchronize(q->col_events[j]));
+      return QP_OK;
+    }
+    if (j + 1 == m && !extended) {   // no kernel after the last column that could announce it
+      QP_HIP(hipStreamSynchronize(ctx->stream));
+      return QP_OK;
+    }
+    const auto t_begin = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (__atomic_load_n(&q->col_flags[j], __ATOMIC_ACQUIRE) != q->seq) {
+      __builtin_ia32_pause();
+      if ((++spins & 0xfffffu) == 0 &&
+          std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() > 5.0) {
+        // never spin for good: fall back to the stream and look once more
+        QP_HIP(hipStreamSynchronize(ctx->stream));
+        if (__atomic_load_n(&q->col_flags[j], __ATOMIC_ACQUIRE) != q->seq)
+          return qp::fail(QP_E_INTERNAL, "Arnoldi column %d never announced itself to the host", j);
+      }
+    }
+    return QP_OK;
+  };
   for (int j = 0; j < m; ++j) {
-    if (piped) QP_HIP(hipEventSynchronize(q->col_events[j]));
+    QP_CHECK(wait_column(j));
+    if (j + 1 == m) q->t_last_column = std::chrono::steady_clock::now();
     const int rows = std::min(j + 2, dim);
     for (int i = 0; i < rows; ++i) {
       cplx v = hh[(size_t)j * ldd + i];
@@ -234,7 +324,9 @@ static int arnoldi_impl(qp_operator* op, qp_krylov* q, int m, const qp_state* ps
       break;
     }
   }
-  if (piped) QP_HIP(hipStreamSynchronize(ctx->stream));   // the columns after a breakdown are discarded
+  // the columns after a breakdown are discarded: wait for them.  (A complete folded sweep needs no wait: its last
+  // column announced itself, and what the device still does -- normalising the last vector -- is consumed in stream order.)
+  if (piped && !(flags && extended && m_eff == m && hook_rc == QP_OK)) QP_HIP(hipStreamSynchronize(ctx->stream));
   if (hook_rc != QP_OK) return hook_rc;
   *m_out = m_eff;
   return QP_OK;
@@ -314,7 +406,8 @@ int qp_krylov_normalize(qp_krylov* q, int j, double dt, double norm_min, const q
     return qp::fail(QP_E_BAD_ARG, "qp_krylov_normalize: bad arguments");
   QP_CHECK(use(q->ctx));
   hipLaunchKernelGGL(norm_guard_scale_kernel, dim3(guard_grid(q->n)), dim3(qp::kThreads), 0, q->ctx->stream, q->q(j + 1),
-                     norm_partials->d, hess_norm->d, reinterpret_cast<double*>(hess_norm->d + 1), dt, norm_min, q->n);
+                     norm_partials->d, hess_norm->d, reinterpret_cast<double*>(hess_norm->d + 1), dt, norm_min, q->n,
+                     (const double2*)q->q(j + 1), (unsigned*)nullptr, 0u);
   QP_HIP(hipGetLastError());
   q->ctx->stats.n_launch++;
   return QP_OK;
@@ -338,10 +431,12 @@ int qp_combine(qp_state* out, int use_out, qp_c128 s0, qp_krylov* q, int first, 
 
 // norm + guarded scale: lmul!(1/h) only when h >= norm_min (src/arnoldi.jl:89-96); the
 // raw norm is kept so that the host can detect breakdown also for dt < 0.
-__global__ __launch_bounds__(qp::kThreads) void norm_guard_scale_kernel(double2* __restrict__ w,
-                                                                        const double2* __restrict__ part_in,
+// (w_in != w: the scaled -- or, past a breakdown, the unscaled -- vector goes to w, w_in is left alone)
+// (flag != NULL: host-visible announcement that the slots are written, see PlainEpi::flag)
+__global__ __launch_bounds__(qp::kThreads) void norm_guard_scale_kernel(double2* w, const double2* __restrict__ part_in,
                                                                         double2* hess_slot, double* norm_slot, double dt,
-                                                                        double norm_min, int64_t n) {
+                                                                        double norm_min, int64_t n, const double2* w_in,
+                                                                        unsigned* flag, unsigned flag_value) {
   __shared__ double2 lds[qp::kThreads / 64];
   double2 v = part_in[threadIdx.x];
   for (int o = 32; o > 0; o >>= 1) {
@@ -354,11 +449,12 @@ __global__ __launch_bounds__(qp::kThreads) void norm_guard_scale_kernel(double2*
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     *hess_slot = make_double2(dt * h, 0.0);
     *norm_slot = h;
+    if (flag) __hip_atomic_store(flag, flag_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  if (h < norm_min) return;
-  const double inv = 1.0 / h;
+  if (h < norm_min && w_in == w) return;
+  const double inv = (h < norm_min) ? 1.0 : 1.0 / h;
   for (int64_t i = (int64_t)blockIdx.x * qp::kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * qp::kThreads) {
-    double2 t = w[i];
+    double2 t = w_in[i];
     t.x *= inv;
     t.y *= inv;
     w[i] = t;
@@ -440,7 +536,7 @@ int qp_newton_step(qp_newton* w, qp_operator* op, qp_state* psi, double dt, int 
   qp_state vstate{ctx, w->v, w->n, false};
   // v = Psi / beta, beta = |Psi| (:268-272) is done by the first Arnoldi sweep itself (q_0)
   double beta = 0.0;
-  double ms_arnoldi = 0, ms_eig = 0, ms_leja = 0, ms_coeffs = 0, ms_poly = 0, ms_update = 0;
+  double ms_arnoldi = 0, ms_eig = 0, ms_leja = 0, ms_coeffs = 0, ms_poly = 0, ms_update = 0, ms_exposed = 0;
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto ms_since = [](std::chrono::steady_clock::time_point t0) {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -451,12 +547,10 @@ int qp_newton_step(qp_newton* w, qp_operator* op, qp_state* psi, double dt, int 
     // Ritz values of every leading block (:297), block j+1 as soon as column j has arrived -- on
     // the multi-launch path while the device is still orthogonalising the later columns
     ritz.assign((size_t)m_req * (m_req + 1) / 2, cplx(0));
-    // ... and, from the second restart on, the head of every candidate's Leja product chain (the
-    // factors of the Leja points of the earlier restarts, src/newton.jl:127-136) -- valid as long
-    // as the sweep does not break down (the exponent depends on m)
-    std::vector<double>& lprod = w->leja_prod;
-    lprod.assign(ritz.size(), 1.0);
-    const double lexp = 1.0 / (double)(n_leja + m_req);
+    // ... and, from the second restart on, the head of every candidate's Leja product (the factors of
+    // the Leja points of the earlier restarts, src/newton.jl:127-136)
+    std::vector<qp::ScaledProd>& lprod = w->leja_prod;
+    lprod.assign(ritz.size(), qp::ScaledProd{1.0, 0});
     double ms_eig_sweep = 0, ms_fold_sweep = 0;
     int blocks_done = 0;
     const ColumnHook eig_block = [&](int j) -> int {
@@ -466,7 +560,7 @@ int qp_newton_step(qp_newton* w, qp_operator* op, qp_state* psi, double dt, int 
       ms_eig_sweep += ms_since(t1);
       if (st == QP_OK && n_leja > 0) {
         t1 = now();
-        for (int i = 0; i <= j; ++i) lprod[off + i] = qp::leja_fold_candidate(w->leja.data(), n_leja, ritz[off + i], lexp);
+        for (int i = 0; i <= j; ++i) lprod[off + i] = qp::leja_fold_candidate(w->leja.data(), n_leja, ritz[off + i]);
         ms_fold_sweep += ms_since(t1);
       }
       blocks_done = j + 1;
@@ -489,7 +583,7 @@ int qp_newton_step(qp_newton* w, qp_operator* op, qp_state* psi, double dt, int 
     for (int j = blocks_done; j < m; ++j)   // persistent-kernel sweep, or the pipeline switched off
       QP_CHECK(eig_block(j));
     ritz.resize((size_t)m * (m + 1) / 2);
-    const bool folded = (m == m_req) && n_leja > 0;   // same exponent as assumed above
+    const bool folded = n_leja > 0;   // (the products do not depend on m: valid also after a breakdown)
     ms_eig += ms_since(t0);
     if (s == 0) {                                                                    // :301-303, :67-70
       double rmax = 0;
@@ -544,6 +638,7 @@ int qp_newton_step(qp_newton* w, qp_operator* op, qp_state* psi, double dt, int 
     for (int i = 0; i < mp; ++i) R[i] *= (1.0 / beta);
     // Psi = (s == 0 ? 0 : Psi) + sum_{i<m} P_i q_i  (:346-352)  and  v = sum_{i<=m} R_i q_i  (q_0 is the
     // start vector of this sweep): one pass over the basis; fixed-size coefficient blocks, else one by one
+    ms_exposed += ms_since(w->q->t_last_column);
     if (!qp::launch_combine2_vecs(ctx->stream, psi->d, s == 0 ? 0 : 1, m, reinterpret_cast<const double2*>(P.data()), w->v,
                                   m + 1, reinterpret_cast<const double2*>(R.data()), w->q->q(0), w->n, w->npart, w->n,
                                   &ctx->stats)) {
@@ -584,6 +679,7 @@ int qp_newton_step(qp_newton* w, qp_operator* op, qp_state* psi, double dt, int 
     stats->ms_coeffs = ms_coeffs;
     stats->ms_poly = ms_poly;
     stats->ms_update = ms_update;
+    stats->ms_exposed = ms_exposed;
   }
   return QP_OK;
   QP_CATCH

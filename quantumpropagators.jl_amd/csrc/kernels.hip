@@ -134,6 +134,7 @@ struct ChebyOpT {
   struct Pre {
     double2 xi, v0, acc;
   };
+  __device__ __forceinline__ void begin(double2*) {}
   // row-local operands, issued ahead of the mat-vec loop so their latency overlaps it
   __device__ __forceinline__ Pre pre(int64_t i) const {
     Pre p;
@@ -189,15 +190,39 @@ using ChebyOp = ChebyOpT<false>;
 
 struct PlainOp {
   PlainEpi e;
+  double inv = 1.0;   // 1 / |x| of the folded normalisation (begin())
   struct Pre {
     double2 y;
   };
+  // all threads of the workgroup, before any row: the scale of the folded "norm + scale"
+  __device__ __forceinline__ void begin(double2* lds4) {
+    if (!e.norm_part) return;
+    static_assert(kRedBlocks == kThreads, "one partial per thread");
+    const double2 s2 = block_sum(e.norm_part[threadIdx.x], lds4);
+    const double h = sqrt(s2.x);                       // h = norm(q[j])              src/arnoldi.jl:89
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      if (e.hess_slot) *e.hess_slot = make_double2(e.dt * h, 0.0);   // :90
+      if (e.norm_slot) *e.norm_slot = h;
+      // everything the earlier kernels of the column wrote for the host is complete (kernel boundary); the two
+      // stores above are ordered before the flag by the release
+      if (e.flag) __hip_atomic_store(e.flag, e.flag_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    inv = (h < e.norm_min) ? 1.0 : 1.0 / h;            // lmul!(1 / h, q[j])          :96  (not past a breakdown :91-95)
+  }
   __device__ __forceinline__ Pre pre(int64_t i) const {
     Pre p;
     p.y = e.beta_zero ? make_double2(0.0, 0.0) : e.y[i];
     return p;
   }
   __device__ __forceinline__ void row(int64_t i, double2 s, const Pre& p, double2&, double&, int64_t) const {
+    if (e.norm_part) {
+      s.x *= inv;
+      s.y *= inv;
+      if (e.qn_out) {
+        const double2 xi = e.xloc[i];
+        e.qn_out[i] = make_double2(xi.x * inv, xi.y * inv);
+      }
+    }
     double2 r = cmul(e.alpha, s);
     if (!e.beta_zero) {
       const double2 by = cmul(e.beta, p.y);
@@ -306,6 +331,7 @@ __global__ __launch_bounds__(kThreads) void rbcsr_spmv_kernel(const int64_t* __r
   __shared__ double2 lds[kThreads / 64];
   const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
   sync_wait(sy, wg);
+  op.begin(lds);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int64_t idx = (int64_t)wg * (kThreads / 64) + wave;  // position in the row set
@@ -381,9 +407,11 @@ __global__ __launch_bounds__(kThreads) void hrb_spmv_kernel(const int64_t* __res
   constexpr bool NT = (VAR & 1) != 0;
   constexpr bool PRE = (VAR & 2) != 0;
   constexpr int UNR = (VAR & 4) ? 2 : 1;
+  constexpr bool DEEP = (VAR & 8) != 0;
   __shared__ double2 lds[kThreads / 64];
   const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
   sync_wait(sy, wg);
+  op.begin(lds);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int64_t idx = (int64_t)wg * (kThreads / 64) + wave;  // position in the row set
@@ -457,6 +485,45 @@ __global__ __launch_bounds__(kThreads) void hrb_spmv_kernel(const int64_t* __res
         cfma(s1, a3, x3);
       }
     };
+    // The common shape of a lattice / tensor-product H -- both sections stencil-encoded, two quads
+    // each (z = 16) -- as straight-line code: all 16 value loads and 16 gathers of the row block are
+    // issued before the first FMA (32 KiB in flight per wave instead of 4-8), which is what the
+    // kernel needs once the working set no longer sits in the Infinity Cache (N >= 2^22: HBM
+    // latency).  Same FMA order as the two loops below: bit-identical.
+    if (DEEP && !lower_last && nlq == 2 && nuq == 2 && (lcm & 3) == 2 && (ucm & 3) == 2) {
+      const LowerStencilSlot* __restrict__ ls = reinterpret_cast<const LowerStencilSlot*>(lcolbytes + (lcm >> 2));
+      const int4* __restrict__ ud = reinterpret_cast<const int4*>(ucolbytes + (ucm >> 2));
+      double2 la[8], lx[8], ua[8], ux[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const LowerStencilSlot e = ls[k];
+        const int c = (int)rowc + e.delta;
+        la[k] = ld_val<false>(uvals + (((c >> 6) == e.cb0 ? e.pb0 : e.pb1) + (c & 63)));
+        lx[k] = x[c];
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int4 d = ud[q];
+        ua[4 * q + 0] = ld_val<false>(v + (size_t)(4 * q + 0) * 64);
+        ua[4 * q + 1] = ld_val<false>(v + (size_t)(4 * q + 1) * 64);
+        ua[4 * q + 2] = ld_val<false>(v + (size_t)(4 * q + 2) * 64);
+        ua[4 * q + 3] = ld_val<false>(v + (size_t)(4 * q + 3) * 64);
+        ux[4 * q + 0] = x[(int)rowc + d.x];
+        ux[4 * q + 1] = x[(int)rowc + d.y];
+        ux[4 * q + 2] = x[(int)rowc + d.z];
+        ux[4 * q + 3] = x[(int)rowc + d.w];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k += 2) {
+        cfma_conj(s0, la[k], lx[k]);
+        cfma_conj(s1, la[k + 1], lx[k + 1]);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k += 2) {
+        cfma(s0, ua[k], ux[k]);
+        cfma(s1, ua[k + 1], ux[k + 1]);
+      }
+    } else
     // order of the two sections (tuning key "hrb_lower_last"): the conj-transposed values of
     // the lower section are found in L2 only if the wave that owns them has already fetched
     // them; summation order changes with it, bitwise reproducibility per setting is kept
@@ -486,6 +553,7 @@ __global__ __launch_bounds__(kThreads) void csr_spmv_kernel(const int64_t* __res
                                                             Op op) {
   __shared__ double2 lds[kThreads / 64];
   const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
+  op.begin(lds);
   const int64_t row = ((int64_t)wg * kThreads + threadIdx.x) / T;
   const int tl = threadIdx.x % T;
   double2 s = make_double2(0.0, 0.0);
@@ -1208,6 +1276,7 @@ int* tuning_field(Tuning& t, const char* key) {
   static const Entry table[] = {
       {"rbcsr_variant", &Tuning::rbcsr_variant}, {"hrb_lower_last", &Tuning::hrb_lower_last},
       {"arnoldi_mode", &Tuning::arnoldi_mode},   {"split_mode", &Tuning::split_mode},
+      {"arnoldi_fold", &Tuning::arnoldi_fold},
       {"liouville_fused_n", &Tuning::liouville_fused_n}, {"real_vals", &Tuning::real_vals},
       {"stencil", &Tuning::stencil},             {"acc_defer", &Tuning::acc_defer},
       {"cheby_graph", &Tuning::cheby_graph},     {"small_nnz", &Tuning::small_nnz},
@@ -1339,7 +1408,7 @@ static int launch_spmv(hipStream_t s, const DevMatrix& A, const double2* x, cons
                          reinterpret_cast<const char*>(A.lcols), reinterpret_cast<const int4*>(A.lpos), x, \
                          nblk, A.nrows, op, bmap, sy, tun.hrb_lower_last);                                 \
     break;
-    switch (tun.rbcsr_variant & 7) {
+    switch (tun.rbcsr_variant & 15) {
       QP_HRB_CASE(0)
       QP_HRB_CASE(1)
       QP_HRB_CASE(2)
@@ -1348,6 +1417,9 @@ static int launch_spmv(hipStream_t s, const DevMatrix& A, const double2* x, cons
       QP_HRB_CASE(5)
       QP_HRB_CASE(6)
       QP_HRB_CASE(7)
+      QP_HRB_CASE(8)
+      QP_HRB_CASE(15)
+      default: return fail(QP_E_BAD_ARG, "rbcsr_variant %d has no Hermitian-packed kernel (0-8, 15)", tun.rbcsr_variant);
     }
 #undef QP_HRB_CASE
   } else {

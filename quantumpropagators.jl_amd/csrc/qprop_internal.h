@@ -27,8 +27,12 @@ std::vector<double> cheby_coeffs(double Delta, double dt, double limit);
 bool hessenberg_eigvals_inplace(int n, cplx* A, cplx* w);
 int diagonalize_hessenberg(const cplx* Hess, int ldh, int m, bool accumulate, cplx* out);
 int diagonalize_hessenberg_block(const cplx* Hess, int ldh, int j, cplx* out);
-void extend_leja(cplx* leja, int n, cplx* newpoints, int n_new, int n_use, const double* prod_folded = nullptr);
-double leja_fold_candidate(const cplx* leja, int n, cplx z, double exponent);
+struct ScaledProd {   // m * 2^e with m in [0.5, 1), or m = 0
+  double m;
+  int e;
+};
+void extend_leja(cplx* leja, int n, cplx* newpoints, int n_new, int n_use, const ScaledProd* prod_folded = nullptr);
+ScaledProd leja_fold_candidate(const cplx* leja, int n, cplx z);
 cplx eval_func(int func_id, qp_func_cb cb, void* user, cplx z);
 int extend_newton_coeffs(cplx* a, int n_a, const cplx* leja, int func_id, qp_func_cb cb, void* user,
                          int n_leja, double radius);

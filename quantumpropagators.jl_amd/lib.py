@@ -62,7 +62,8 @@ class qp_newton_stats(C.Structure):
                 ("m_last", C.c_int), ("n_matvec", C.c_int), ("radius", C.c_double),
                 ("last_relerr", C.c_double), ("norm_psi", C.c_double),
                 ("ms_arnoldi", C.c_double), ("ms_eig", C.c_double), ("ms_leja", C.c_double),
-                ("ms_coeffs", C.c_double), ("ms_poly", C.c_double), ("ms_update", C.c_double)]
+                ("ms_coeffs", C.c_double), ("ms_poly", C.c_double), ("ms_update", C.c_double),
+                ("ms_exposed", C.c_double)]
 
 
 FUNC_CB = C.CFUNCTYPE(None, C.POINTER(qp_c128), C.POINTER(qp_c128), C.c_void_p)

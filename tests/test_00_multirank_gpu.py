@@ -33,9 +33,12 @@ def _run(world, timeout=240, **env_extra):
                 q.kill()
             raise
         outs.append(out)
-    for p, out in zip(procs, outs):
-        assert p.returncode == 0, out[-3000:]
-        assert "err=" in out
+    # (a rank that dies takes the others' barrier down with it: show the rank that failed FIRST, i.e. not with
+    # the "connection closed by peer" of a survivor)
+    bad = [(p.returncode, out) for p, out in zip(procs, outs) if p.returncode != 0]
+    bad.sort(key=lambda t: "Connection closed by peer" in t[1])
+    assert not bad, "\n-----\n".join(f"rc {rc}: {out[-1500:]}" for rc, out in bad[:3])
+    assert all("err=" in out for out in outs)
     return outs
 
 

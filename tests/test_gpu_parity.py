@@ -626,6 +626,34 @@ def test_full_size_properties(ctx):
     assert np.linalg.norm(res[L.FMT_HRB] - res[L.FMT_RBCSR]) < TOL
 
 
+def test_hrb_kernel_variants_bit_identical(ctx):
+    """Knob rbcsr_variant of the Hermitian-packed kernel: nontemporal index loads, early row-local loads, unroll
+    depth and (bit 3, the default) the straight-line path that issues all 32 loads of an all-stencil block before
+    the first FMA change the schedule of the loads only -- every variant gives the same bits."""
+    N = 1 << 15
+    rp, col, vals = synth.hermitian_offsets_csr(N)        # lattice: stencil blocks except at the wrap-around
+    Op = L.Operator(ctx, [L.Matrix(ctx, N, N, rp, col, vals)], 0, L.FMT_HRB)
+    lay = Op.layout_info()
+    assert lay["stencil_lower_blocks"] > 0.75 * lay["blocks"]      # all but the blocks next to the periodic wrap
+    psi0 = synth.random_state(N)
+    wrk = L.ChebyWrk(ctx, N, 20.0, -10.0, 1.0)
+    outs = {}
+    try:
+        for v in (15, 7, 3, 0, 8):
+            ctx.tuning_set("rbcsr_variant", v)
+            psi = L.State(ctx, data=psi0)
+            L.cheby(psi, Op, 1.0, wrk)
+            L.cheby(psi, Op, -1.0, wrk)
+            L.cheby(psi, Op, 1.0, wrk)
+            outs[v] = psi.numpy()
+    finally:
+        ctx.tuning_set("rbcsr_variant", 15)
+    assert all(np.array_equal(outs[15], o) for o in outs.values())
+    H = synth.to_scipy(rp, col, vals, N)
+    ref = qo.cheby(psi0.copy(), H, 1.0, qo.ChebyWrk(psi0, 20.0, -10.0, 1.0))
+    assert np.linalg.norm(outs[15] - ref) < TOL
+
+
 @pytest.mark.parametrize("window", [None, 1024])
 @pytest.mark.parametrize("fmt", [L.FMT_AUTO, L.FMT_HRB, L.FMT_RBCSR, L.FMT_CSR])
 def test_random_columns_matches_oracle(ctx, window, fmt):
@@ -638,6 +666,10 @@ def test_random_columns_matches_oracle(ctx, window, fmt):
     assert abs(H - H.conj().T).max() == 0 and np.diff(rp).max() == 16 and np.diff(rp).min() >= 12
     Op = L.Operator(ctx, [L.Matrix(ctx, N, N, rp, col, vals)], 0, fmt)
     lay = Op.layout_info()
+    if fmt == L.FMT_AUTO:
+        # irregular blocks: the conj-transposed reads of the Hermitian packing would not coalesce, AUTO keeps
+        # plain row blocks even where the window would fit L2 (profiles/r02/kbench_random_window.txt)
+        assert Op.format == L.FMT_RBCSR
     if Op.format != L.FMT_CSR:
         assert lay["stencil_upper_blocks"] == 0 and lay["stencil_lower_blocks"] == 0   # nothing translation invariant to encode
     r2, c2, v2 = Op.get_csr()

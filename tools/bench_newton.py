@@ -32,12 +32,14 @@ def main():
     ap.add_argument("--check", action="store_true", help="compare one step with the NumPy oracle (slow)")
     ap.add_argument("--pipeline", type=int, default=1, help="1 = Hessenberg eigenvalues overlap the Arnoldi sweep (default)")
     ap.add_argument("--arnoldi-mode", type=int, default=1, help="1 = low-sync MGS (default), 0 = sequential MGS passes")
+    ap.add_argument("--fold", type=int, default=1, help="1 = norm + scale of a column folded into the next mat-vec (default)")
     args = ap.parse_args()
     Lm = synth.liouvillian_tridiag(args.n)
     N = Lm.shape[0]
     nnz = Lm.nnz
     ctx = L.Context(0)
     L.tuning_set("arnoldi_mode", args.arnoldi_mode)
+    L.tuning_set("arnoldi_fold", args.fold)
     L.tuning_set("newton_pipeline", args.pipeline)
     fmt = {"auto": L.FMT_AUTO, "rbcsr": L.FMT_RBCSR, "csr": L.FMT_CSR}[args.format]
     op = L.Operator(ctx, [L.Matrix.from_scipy(ctx, Lm)], 0, fmt)
@@ -57,7 +59,7 @@ def main():
     ctx.sync()
     ctx.reset_stats()
     restarts, matvecs = 0, 0
-    host = {k: 0.0 for k in ("ms_arnoldi", "ms_eig", "ms_leja", "ms_coeffs", "ms_poly", "ms_update")}
+    host = {k: 0.0 for k in ("ms_arnoldi", "ms_eig", "ms_leja", "ms_coeffs", "ms_poly", "ms_update", "ms_exposed")}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         L.newton(psi, op, args.dt, wrk)

@@ -125,11 +125,13 @@ def measure_newton_c3(ctx, n=512, m=20, dt=0.5, steps=10, warmup=60):
     ctx.sync()
     ctx.reset_stats()
     sweeps = matvecs = 0
+    exposed = 0.0
     t0 = time.perf_counter()
     for _ in range(steps):
         L.newton(psi, op, dt, wrk)
         sweeps += wrk.restarts + 1
         matvecs += wrk.stats["n_matvec"]
+        exposed += wrk.stats["ms_exposed"]
     ctx.sync()
     el = time.perf_counter() - t0
     st = ctx.stats()
@@ -142,7 +144,7 @@ def measure_newton_c3(ctx, n=512, m=20, dt=0.5, steps=10, warmup=60):
            "arnoldi_sweeps_per_step": sweeps / steps, "matvecs_per_step": matvecs / steps,
            "kernel_launches_per_step": st["n_kernel_launches"] / steps,
            "launches_per_column": st["n_kernel_launches"] / max(matvecs, 1),
-           "ms_per_sweep": 1e3 * el / sweeps,
+           "ms_per_sweep": 1e3 * el / sweeps, "host_ms_exposed_per_step": exposed / steps,
            "algorithmic_gbs": sweep_bytes * sweeps / el / 1e9, "frac": sweep_bytes * sweeps / el / 1e9 / HBM_PEAK_GBS,
            "norm": psi.norm()}
     for h in (psi, wrk, op, M):

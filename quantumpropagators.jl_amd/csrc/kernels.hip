@@ -1865,22 +1865,25 @@ __host__ __device__ inline size_t mgs_solve_lds(int j) {
   return sizeof(double2) * (size_t)(3 * (j + 1) + j * (j + 1) / 2);
 }
 
-// partials are stored value-major: partials[v * kRedBlocks + workgroup]
-__global__ __launch_bounds__(kThreads) void multidot_kernel(const double2* __restrict__ Q, int64_t ldq, int j,
-                                                            const double2* __restrict__ w,
-                                                            double2* __restrict__ partials, int64_t n) {
-  __shared__ double2 wsum[kThreads / 64][2 * kTI];
+// partials are stored value-major: partials[v * kRedBlocks + workgroup].
+// BS threads per workgroup, EPL elements per lane and round (shipped: 256 x 2.  Tried: 1024-thread workgroups
+// with one element per lane, for 16 instead of 4 wavefronts per CU while the basis is one tile wide -- slower,
+// 1.31 instead of 1.06 ms per Arnoldi sweep at config C3: profiles/r02/newton_c3_notes.txt)
+template <int BS, int EPL>
+__global__ __launch_bounds__(BS) void multidot_kernel(const double2* __restrict__ Q, int64_t ldq, int j,
+                                                      const double2* __restrict__ w,
+                                                      double2* __restrict__ partials, int64_t n) {
+  __shared__ double2 wsum[BS / 64][2 * kTI];
   const int i0 = blockIdx.y * kTI;
   double2 ac[kTI], ag[kTI];
 #pragma unroll
   for (int t = 0; t < kTI; ++t) ac[t] = ag[t] = make_double2(0.0, 0.0);
   const double2* __restrict__ qj = Q + (size_t)j * ldq;
-  // two elements per lane and round: 2 (kTI + 2) loads in flight; each accumulator still adds its
-  // elements in ascending order
-  const int64_t stride = (int64_t)kRedBlocks * kThreads;
-  for (int64_t e0 = (int64_t)blockIdx.x * kThreads + threadIdx.x; e0 < n; e0 += 2 * stride) {
+  // EPL (kTI + 2) loads in flight per lane; each accumulator adds its elements in ascending order
+  const int64_t stride = (int64_t)kRedBlocks * BS;
+  for (int64_t e0 = (int64_t)blockIdx.x * BS + threadIdx.x; e0 < n; e0 += EPL * stride) {
     const int64_t e1 = e0 + stride;
-    const bool two = e1 < n;
+    const bool two = EPL == 2 && e1 < n;
     const double2 zero = make_double2(0.0, 0.0);
     const double2 wv0 = w[e0], qv0 = qj[e0];
     const double2 wv1 = two ? w[e1] : zero, qv1 = two ? qj[e1] : zero;
@@ -1931,7 +1934,7 @@ __global__ __launch_bounds__(kThreads) void multidot_kernel(const double2* __res
     if (i0 + t <= j) {
       double2 r = wsum[0][threadIdx.x];
 #pragma unroll
-      for (int k = 1; k < kThreads / 64; ++k) {
+      for (int k = 1; k < BS / 64; ++k) {
         r.x += wsum[k][threadIdx.x].x;
         r.y += wsum[k][threadIdx.x].y;
       }
@@ -2015,21 +2018,22 @@ __global__ __launch_bounds__(kThreads) void mgs_solve_kernel(int j, const double
   if (threadIdx.x < 64) mgs_solve_wave(j, red, Gt, h, hess_col, coef, dt);
 }
 
-// w += sum_i coef_i q_i in MGS order (coef_i = -h_i) and |w|^2 partials; two elements per lane
-// and four basis vectors per round in flight
-__global__ __launch_bounds__(kThreads) void mgs_update_kernel(double2* __restrict__ w, const double2* __restrict__ Q,
-                                                              int64_t ldq, int j, const double2* __restrict__ coef,
-                                                              double2* __restrict__ norm_partials, int64_t n) {
-  extern __shared__ double2 sm[];  // [0, j+1): coefficients; [j+1, j+5): reduction scratch
+// w += sum_i coef_i q_i in MGS order (coef_i = -h_i) and |w|^2 partials; EPL elements per lane and four
+// basis vectors per round in flight; BS threads per workgroup (see multidot_kernel)
+template <int BS, int EPL>
+__global__ __launch_bounds__(BS) void mgs_update_kernel(double2* __restrict__ w, const double2* __restrict__ Q,
+                                                        int64_t ldq, int j, const double2* __restrict__ coef,
+                                                        double2* __restrict__ norm_partials, int64_t n) {
+  extern __shared__ double2 sm[];  // [0, j+1): coefficients; [j+1, j+1+BS/64): reduction scratch
   double2* h = sm;
   double2* lds = sm + (j + 1);
-  for (int i = threadIdx.x; i <= j; i += kThreads) h[i] = coef[i];
+  for (int i = threadIdx.x; i <= j; i += BS) h[i] = coef[i];
   __syncthreads();
   double nrm = 0.0;
-  const int64_t stride = (int64_t)kRedBlocks * kThreads;
-  for (int64_t e0 = (int64_t)blockIdx.x * kThreads + threadIdx.x; e0 < n; e0 += 2 * stride) {
+  const int64_t stride = (int64_t)kRedBlocks * BS;
+  for (int64_t e0 = (int64_t)blockIdx.x * BS + threadIdx.x; e0 < n; e0 += EPL * stride) {
     const int64_t e1 = e0 + stride;
-    const bool two = e1 < n;
+    const bool two = EPL == 2 && e1 < n;
     double2 r0 = w[e0];
     double2 r1 = two ? w[e1] : make_double2(0.0, 0.0);
     int i = 0;
@@ -2059,14 +2063,22 @@ __global__ __launch_bounds__(kThreads) void mgs_update_kernel(double2* __restric
       nrm += r1.x * r1.x + r1.y * r1.y;
     }
   }
-  const double2 t = block_sum(make_double2(nrm, 0.0), lds);
-  if (threadIdx.x == 0) norm_partials[blockIdx.x] = t;
+  // block sum over BS / 64 wavefronts in wave order
+  double v = wave_sum(nrm);
+  const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
+  if (l == 0) lds[wv] = make_double2(v, 0.0);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = lds[0].x;
+    for (int k = 1; k < BS / 64; ++k) t += lds[k].x;
+    norm_partials[blockIdx.x] = make_double2(t, 0.0);
+  }
 }
 
 static int launch_multidot(hipStream_t s, const double2* Q, int64_t ldq, int j, const double2* w, double2* md_partials,
                            int64_t n, Stats* st) {
   const int ntiles = (j + 1 + kTI - 1) / kTI;
-  hipLaunchKernelGGL(multidot_kernel, dim3(kRedBlocks, ntiles), dim3(kThreads), 0, s, Q, ldq, j, w, md_partials, n);
+  hipLaunchKernelGGL((multidot_kernel<kThreads, 2>), dim3(kRedBlocks, ntiles), dim3(kThreads), 0, s, Q, ldq, j, w, md_partials, n);
   QP_HIP(hipGetLastError());
   if (st) st->n_launch++;
   return QP_OK;
@@ -2086,7 +2098,7 @@ int launch_mgs_multidot(hipStream_t s, const double2* Q, int64_t ldq, int j, con
 static int launch_mgs_update(hipStream_t s, const double2* Q, int64_t ldq, int j, double2* w, const double2* coef,
                              double2* norm_partials, int64_t n, Stats* st) {
   const size_t shmem = sizeof(double2) * (size_t)(j + 1 + kThreads / 64);
-  hipLaunchKernelGGL(mgs_update_kernel, dim3(kRedBlocks), dim3(kThreads), shmem, s, w, Q, ldq, j, coef, norm_partials, n);
+  hipLaunchKernelGGL((mgs_update_kernel<kThreads, 2>), dim3(kRedBlocks), dim3(kThreads), shmem, s, w, Q, ldq, j, coef, norm_partials, n);
   QP_HIP(hipGetLastError());
   if (st) st->n_launch++;
   return QP_OK;

@@ -1,3 +1,4 @@
-python -m pytest tests/test_00_multirank_gpu.py -q -x -k "c4" > gpurun_out/r02_tests_d.txt 2>&1
-python -m pytest tests/test_gpu_parity.py -q -k "row_partition or variants or random_columns" >> gpurun_out/r02_tests_d.txt 2>&1
-grep -E "passed|failed" gpurun_out/r02_tests_d.txt
+bash tools/profile.sh r02 > gpurun_out/r02_profile.log 2>&1
+bash tools/profile_newton.sh r02 1 > gpurun_out/r02_profile_newton.log 2>&1
+python tools/bench_newton.py --steps 10 > gpurun_out/r02_newton_final.json 2>&1
+python bench.py > gpurun_out/r02_bench2.json 2> gpurun_out/r02_bench2.err

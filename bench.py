@@ -106,6 +106,9 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with rocprofv3 child runs")
     ap.add_argument("--no-extras", action="store_true", help="headline only: no extra points (formats, patterns, C3, C5)")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling point")
+    ap.add_argument("--no-safe", action="store_true", help="N > 1: skip the conservative first measurement and the watchdog")
+    ap.add_argument("--watchdog", type=float, default=float(os.environ.get("QP_BENCH_WATCHDOG", "420")),
+                    help="N > 1: seconds the native / overlapped path (set-up, self-check, trial, measurement, strong point) may take")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -298,17 +301,10 @@ def main():
                 del sh2
             return sh_, nat, snote, dnote
 
-        sh, use_native, schedule_note, driver_note = make_stepper(rp, col, vals, N, r0, r1, psi0_local)
-        exchange_used = sh.exchange
-        ncols_local = rows + world * sh.M     # the local slice plus the ghost slots the exchange fills
-        op_for_layout = sh.op
 
-        def step():
-            sh.step(native=use_native)
-
-    fmt_used = op_for_layout.format
-    model = bp.cheby_layout_bytes(op_for_layout, rows, ncols_local, nnz_local, coeffs, real_copy=args.real)
-    layout = model["layout"]
+    if world == 1:
+        fmt_used = op_for_layout.format
+        model = bp.cheby_layout_bytes(op_for_layout, rows, ncols_local, nnz_local, coeffs, real_copy=args.real)
 
     pcie = None
     if world == 1 and os.environ.get("QP_BENCH_PCIE") == "1":
@@ -340,66 +336,182 @@ def main():
         sx.close()
         sy.close()
 
-    for _ in range(args.warmup):
-        step()
-    ctx.reset_stats()
-    barrier()
-    ctx.timer_begin()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    t_enq = time.perf_counter() - t0
-    ev_ms = ctx.timer_end()          # HIP events on the kernels' own stream
-    t_ev = time.perf_counter() - t0
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if os.environ.get("QP_BENCH_DEBUG"):
-        print(f"[debug] rank {rank}: enqueue {1e3*t_enq:.2f} ms, +events {1e3*t_ev:.2f} ms, +sync/barrier "
-              f"{1e3*elapsed:.2f} ms, hip events {ev_ms:.2f} ms", file=sys.stderr)
-    st = ctx.stats()
-    if world > 1:
-        sh.check()      # outside the timed region: the overlapped schedule never timed out
-    if dist is not None:
-        t = dev_tensor([elapsed, ev_ms])
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, ev_ms = float(t[0]), float(t[1])
+    def make_out(elapsed, ev_ms, st, fmt_used, model, exchange_used, schedule_note, driver_note, strong,
+                 traffic=None, traffic_src=None, traffic_detail=None, extras=None, note=None):
+        """The JSON line for one measured run of args.steps steps (elapsed: wall seconds, slowest rank)."""
+        layout = model["layout"]
+        steps_per_s = args.steps / elapsed
+        n_launch = args.steps * nterms
+        avg_launch_s = (ev_ms * 1e-3) / n_launch
+        achieved = model["per_term"] / avg_launch_s / 1e9
+        csr_equiv = model["csr_equivalent_per_term"] / avg_launch_s / 1e9
+        kern = KERNEL_OF_FORMAT[fmt_used] + "<ChebyOp>"
+        blocks_per_step = N / float(1 << 20)
 
-    # ---- N > 1: the strong-scaling point of BASELINE's metric (N = 2^20 in total) ----------------------
-    strong = None
-    if world > 1 and args.scaling == "weak" and not args.no_strong and (1 << 20) % world == 0:
-        Ns = 1 << 20
-        rs = Ns // world
-        s0, s1 = rank * rs, (rank + 1) * rs
-        rps, cols_, valss = bp.pattern_csr(args.pattern, Ns, s0, s1)
-        psis = synth.random_state(Ns, row_begin=s0, row_end=s1)
-        sh_s, nat_s, snote_s, dnote_s = make_stepper(rps, cols_, valss, Ns, s0, s1, psis)
-        ksteps = max(10, args.steps // 2)
-        for _ in range(5):
-            sh_s.step(native=nat_s)
+        workload = {"c2": "BASELINE configs[1]: Cheby prop_step!, N=2^20 CSR sparse Hermitian H, 16 nnz/row",
+                    "c4": "BASELINE configs[3]: Cheby prop_step!, CSR sparse H row-partitioned, 2^21 rows per GPU (N=2^24 at 8 GPUs), "
+                          "RCCL exchange of psi after each mat-vec"}[config]
+        if args.log2n is not None or args.scaling == "strong":
+            workload += f" [size overridden: 2^{log2n} rows {'in total (strong scaling)' if args.scaling == 'strong' else 'per GPU'}]"
+        out = {
+            "metric": "Cheby prop_step!/s at N=2^20 CSR fp64 (2^20-row blocks advanced per second)",
+            "value": steps_per_s * blocks_per_step,
+            "unit": "prop_step/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": "c128 state, f64 matrix values" if args.real else "c128 (complex fp64)", "data": "synthetic",
+            "config": {"workload": workload + (", real fp64 values (f64 variant)" if args.real else ", complex fp64 values") + ", int32 indices",
+                       "rows_per_gpu": rows, "N_total": N, "blocks_of_2^20_rows_per_step": blocks_per_step,
+                       "nnz_per_row": nnz_local / rows, "pattern": args.pattern,
+                       "n_coeffs": int(len(coeffs)), "matvecs_per_step": nterms,
+                       "spectral_range": [-10.0, 10.0], "dt": dt,
+                       "device_format": bp.FMT_NAME[fmt_used],
+                       "device_layout": layout,
+                       "parallelism": "single GPU" if world == 1 else (
+                           f"row-partitioned x{world}, exchange={exchange_used}, schedule={schedule_note}, driver={driver_note}"
+                           + (" [TEST MODE: ranks share one GPU, host-staged gloo]" if one_gpu else "")),
+                       "global_steps_per_s": steps_per_s},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_src, "traffic_detail": traffic_detail,
+                         "kernel": kern,
+                         "layout_bytes_per_launch": model["per_term"],
+                         "layout_bytes_matrix": model["matrix_per_term"], "layout_bytes_vectors": model["vectors_per_term"],
+                         "avg_launch_us": avg_launch_s * 1e6,
+                         "launches_timed": n_launch, "hip_event_ms": ev_ms,
+                         "effective_csr_equiv_gbs": csr_equiv,
+                         "effective_csr_equiv_frac": csr_equiv / HBM_PEAK_GBS,
+                         "csr_equivalent_bytes_per_launch": model["csr_equivalent_per_term"],
+                         "traffic_rate_gbs": (traffic / avg_launch_s / 1e9) if traffic else None,
+                         "traffic_frac_of_peak": (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "traffic_over_layout_bytes": (traffic / model["per_term"]) if traffic else None,
+                         "hbm_stream_measured_gbs": stream_gbs,
+                         "note": "avg launch duration = HIP-event time of the timed region on the kernels' stream / number of "
+                                 "fused-term launches (includes launch gaps; multi-GPU: includes the exchange).  `achieved` = bytes "
+                                 "the shipped device layout must move per launch (stored values + index bytes + block metadata + "
+                                 "the vector streams with the accumulator touched by every third term only) / that duration; "
+                                 "`effective_csr_equiv_gbs` prices the same time with the contract's CSR bytes (SURVEY 8d: (20 z + "
+                                 "84) N = 404 B/row), which a Hermitian-packed / stencil-encoded layout undercuts; `traffic` = "
+                                 "HBM bytes per launch from the PMC counters (Infinity-Cache hits are counted by FETCH_SIZE: at "
+                                 "N = 2^20 part of the working set is served on-die, see extras[banded_N_2^22...] for the point beyond it)"},
+            "cpu_baseline": cpu,
+            "cpu_baseline_all_cores": cpu_omp,
+            "pcie_inclusive_steps_per_s": pcie,
+            "strong_scaling_point": strong,
+            "extras": extras,
+            "stats": {"n_matvec": st["n_matvec"], "kernel_launches": st["n_kernel_launches"]},
+        }
+        if note:
+            out["config"]["parallelism"] += " | " + note
+        return out
+
+    def timed_steps(step_fn):
+        """W untimed + exactly K timed steps, barrier + synchronize on both sides, MAX over the ranks."""
+        for _ in range(args.warmup):
+            step_fn()
+        ctx.reset_stats()
         barrier()
-        t0s = time.perf_counter()
-        for _ in range(ksteps):
-            sh_s.step(native=nat_s)
+        ctx.timer_begin()
+        t0_ = time.perf_counter()
+        for _ in range(args.steps):
+            step_fn()
+        ev_ = ctx.timer_end()          # HIP events on the kernels' own stream
         torch.cuda.synchronize()
-        dist.barrier()
-        ts = dev_tensor([time.perf_counter() - t0s])
-        dist.all_reduce(ts, op=dist.ReduceOp.MAX)
-        sh_s.check()
-        strong = {"workload": "Cheby prop_step!, N=2^20 CSR fp64 in TOTAL, row-partitioned over the ranks (strong scaling)",
-                  "N_total": Ns, "rows_per_gpu": rs, "steps": ksteps, "prop_steps_per_s": ksteps / float(ts[0]),
-                  "ms_per_step": 1e3 * float(ts[0]) / ksteps, "exchange": sh_s.exchange, "schedule": snote_s, "driver": dnote_s}
-        sh_s.close()
-        del sh_s
+        if dist is not None:
+            dist.barrier()
+        el_ = time.perf_counter() - t0_
+        st_ = ctx.stats()
+        if dist is not None:
+            t_ = dev_tensor([el_, ev_])
+            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+            el_, ev_ = float(t_[0]), float(t_[1])
+        return el_, ev_, st_
 
-    steps_per_s = args.steps / elapsed
-    n_launch = args.steps * nterms
-    avg_launch_s = (ev_ms * 1e-3) / n_launch
-    achieved = model["per_term"] / avg_launch_s / 1e9
-    csr_equiv = model["csr_equivalent_per_term"] / avg_launch_s / 1e9
-    kern = KERNEL_OF_FORMAT[fmt_used] + "<ChebyOp>"
-    blocks_per_step = N / float(1 << 20)
+    # ---- N > 1: a conservative measurement first, the native / overlapped path under a watchdog -------------------
+    # The library's own RCCL communicator, the neighbour send / recv exchange and the two-stream overlap cannot be run
+    # with more than one rank on the one-GPU boxes this was developed on.  So the first thing measured on a multi-GPU
+    # node is the plainest schedule -- step loop in Python, one torch.distributed all-gather per term on the main
+    # stream, no second stream: all of it exercised with RCCL at world 1 and with gloo at world 2-3 -- and its complete
+    # JSON line is kept.  The faster path then runs under a watchdog: if it does not come back (a hang inside a
+    # collective cannot be recovered in-process), rank 0 prints the kept line and every rank leaves.
+    fallback = None
+    watchdog = None
+    if world > 1:
+        if not args.no_safe:
+            shA = sharded.ShardedCheby(ctx, rp, col, vals, N, r0, r1, Delta, E_min, dt, fmt=fmt, exchange=args.exchange,
+                                       host_staged=one_gpu, native=False, overlap=False)
+            shA.set_state(psi0_local)
+            elA, evA, stA = timed_steps(lambda: shA.step(native=False))
+            modelA = bp.cheby_layout_bytes(shA.op, rows, rows + world * shA.M, nnz_local, coeffs, real_copy=args.real)
+            fallback = make_out(elA, evA, stA, shA.op.format, modelA, shA.exchange, "serial", "torch.distributed (step loop in Python)",
+                                None, note="conservative schedule (reported because the native / overlapped path did not finish)")
+            fallback_line = json.dumps(fallback)
+            fallback["config"]["parallelism"] = fallback["config"]["parallelism"].split(" | ")[0]
+            shA.close()
+            del shA
+            import threading
+
+            def give_up():
+                if rank == 0:
+                    sys.stdout.write(fallback_line + "\n")
+                    sys.stdout.flush()
+                sys.stderr.write(f"[bench.py rank {rank}] native / overlapped path did not finish within {args.watchdog} s: "
+                                 f"reporting the conservative measurement\n")
+                sys.stderr.flush()
+                os._exit(0)
+            watchdog = threading.Timer(args.watchdog, give_up)
+            watchdog.daemon = True
+            watchdog.start()
+        def native_path():
+            if os.environ.get("QP_BENCH_TEST_HANG") == "1":      # testing only: what the watchdog is for
+                time.sleep(1e6)
+            if os.environ.get("QP_BENCH_TEST_HANG") == "raise" and rank == world - 1:
+                raise RuntimeError("simulated failure of the native path on one rank")
+            sh_, nat_, snote_, dnote_ = make_stepper(rp, col, vals, N, r0, r1, psi0_local)
+            model_ = bp.cheby_layout_bytes(sh_.op, rows, rows + world * sh_.M, nnz_local, coeffs, real_copy=args.real)
+            el_, ev_, st_ = timed_steps(lambda: sh_.step(native=nat_))
+            sh_.check()      # outside the timed region: the overlapped schedule never timed out
+            strong_ = None
+            # the strong-scaling point of BASELINE's metric (N = 2^20 in total)
+            if args.scaling == "weak" and not args.no_strong and (1 << 20) % world == 0:
+                Ns = 1 << 20
+                rs = Ns // world
+                s0, s1 = rank * rs, (rank + 1) * rs
+                rps, cols_, valss = bp.pattern_csr(args.pattern, Ns, s0, s1)
+                psis = synth.random_state(Ns, row_begin=s0, row_end=s1)
+                sh_s, nat_s, snote_s, dnote_s = make_stepper(rps, cols_, valss, Ns, s0, s1, psis)
+                ksteps = max(10, args.steps // 2)
+                for _ in range(5):
+                    sh_s.step(native=nat_s)
+                barrier()
+                t0s = time.perf_counter()
+                for _ in range(ksteps):
+                    sh_s.step(native=nat_s)
+                torch.cuda.synchronize()
+                dist.barrier()
+                ts = dev_tensor([time.perf_counter() - t0s])
+                dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+                sh_s.check()
+                strong_ = {"workload": "Cheby prop_step!, N=2^20 CSR fp64 in TOTAL, row-partitioned over the ranks (strong scaling)",
+                           "N_total": Ns, "rows_per_gpu": rs, "steps": ksteps, "prop_steps_per_s": ksteps / float(ts[0]),
+                           "ms_per_step": 1e3 * float(ts[0]) / ksteps, "exchange": sh_s.exchange, "schedule": snote_s, "driver": dnote_s}
+                sh_s.close()
+            return sh_, el_, ev_, st_, model_, snote_, dnote_, strong_
+
+        try:
+            sh, elapsed, ev_ms, st, model, schedule_note, driver_note, strong = native_path()
+        except Exception:      # noqa: BLE001 -- with a complete conservative measurement in hand, report that one
+            if fallback is None:
+                raise
+            import traceback
+            traceback.print_exc()
+            give_up()
+        exchange_used = sh.exchange
+        fmt_used = sh.op.format
+    else:
+        strong = None
+        elapsed, ev_ms, st = timed_steps(step)
 
     # ---- single GPU: CPU baselines, HBM traffic measured under rocprofv3, the other points ------------
     traffic = traffic_src = traffic_detail = None
@@ -442,60 +554,18 @@ def main():
                 except Exception as e:  # noqa: BLE001
                     extras[name] = {"error": f"{type(e).__name__}: {e}"}
 
-    workload = {"c2": "BASELINE configs[1]: Cheby prop_step!, N=2^20 CSR sparse Hermitian H, 16 nnz/row",
-                "c4": "BASELINE configs[3]: Cheby prop_step!, CSR sparse H row-partitioned, 2^21 rows per GPU (N=2^24 at 8 GPUs), "
-                      "RCCL exchange of psi after each mat-vec"}[config]
-    if args.log2n is not None or args.scaling == "strong":
-        workload += f" [size overridden: 2^{log2n} rows {'in total (strong scaling)' if args.scaling == 'strong' else 'per GPU'}]"
-    out = {
-        "metric": "Cheby prop_step!/s at N=2^20 CSR fp64 (2^20-row blocks advanced per second)",
-        "value": steps_per_s * blocks_per_step,
-        "unit": "prop_step/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-        "dtype": "c128 state, f64 matrix values" if args.real else "c128 (complex fp64)", "data": "synthetic",
-        "config": {"workload": workload + (", real fp64 values (f64 variant)" if args.real else ", complex fp64 values") + ", int32 indices",
-                   "rows_per_gpu": rows, "N_total": N, "blocks_of_2^20_rows_per_step": blocks_per_step,
-                   "nnz_per_row": nnz_local / rows, "pattern": args.pattern,
-                   "n_coeffs": int(len(coeffs)), "matvecs_per_step": nterms,
-                   "spectral_range": [-10.0, 10.0], "dt": dt,
-                   "device_format": bp.FMT_NAME[fmt_used],
-                   "device_layout": layout,
-                   "parallelism": "single GPU" if world == 1 else (
-                       f"row-partitioned x{world}, exchange={exchange_used}, schedule={schedule_note}, driver={driver_note}"
-                       + (" [TEST MODE: ranks share one GPU, host-staged gloo]" if one_gpu else "")),
-                   "global_steps_per_s": steps_per_s},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "traffic_source": traffic_src, "traffic_detail": traffic_detail,
-                     "kernel": kern,
-                     "layout_bytes_per_launch": model["per_term"],
-                     "layout_bytes_matrix": model["matrix_per_term"], "layout_bytes_vectors": model["vectors_per_term"],
-                     "avg_launch_us": avg_launch_s * 1e6,
-                     "launches_timed": n_launch, "hip_event_ms": ev_ms,
-                     "effective_csr_equiv_gbs": csr_equiv,
-                     "effective_csr_equiv_frac": csr_equiv / HBM_PEAK_GBS,
-                     "csr_equivalent_bytes_per_launch": model["csr_equivalent_per_term"],
-                     "traffic_rate_gbs": (traffic / avg_launch_s / 1e9) if traffic else None,
-                     "traffic_frac_of_peak": (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                     "traffic_over_layout_bytes": (traffic / model["per_term"]) if traffic else None,
-                     "hbm_stream_measured_gbs": stream_gbs,
-                     "note": "avg launch duration = HIP-event time of the timed region on the kernels' stream / number of "
-                             "fused-term launches (includes launch gaps; multi-GPU: includes the exchange).  `achieved` = bytes "
-                             "the shipped device layout must move per launch (stored values + index bytes + block metadata + "
-                             "the vector streams with the accumulator touched by every third term only) / that duration; "
-                             "`effective_csr_equiv_gbs` prices the same time with the contract's CSR bytes (SURVEY 8d: (20 z + "
-                             "84) N = 404 B/row), which a Hermitian-packed / stencil-encoded layout undercuts; `traffic` = "
-                             "HBM bytes per launch from the PMC counters (Infinity-Cache hits are counted by FETCH_SIZE: at "
-                             "N = 2^20 part of the working set is served on-die, see extras[banded_N_2^22...] for the point beyond it)"},
-        "cpu_baseline": cpu,
-        "cpu_baseline_all_cores": cpu_omp,
-        "pcie_inclusive_steps_per_s": pcie,
-        "strong_scaling_point": strong,
-        "extras": extras,
-        "stats": {"n_matvec": st["n_matvec"], "kernel_launches": st["n_kernel_launches"]},
-    }
+    out = make_out(elapsed, ev_ms, st, fmt_used, model, exchange_used, schedule_note, driver_note, strong,
+                   traffic, traffic_src, traffic_detail, extras,
+                   note=(None if fallback is None else
+                         f"conservative schedule measured first: {fallback['value']:.1f} {fallback['unit']} "
+                         f"({fallback['ms_per_step']:.3f} ms/step, torch.distributed all-gather per term, no overlap)"))
+    if watchdog is not None:
+        watchdog.cancel()
+    if fallback is not None and fallback["value"] > out["value"]:      # report the faster of the two complete measurements
+        fallback["config"]["parallelism"] += (f" | the native / overlapped path (schedule={schedule_note}, driver={driver_note}) measured "
+                                              f"{out['value']:.1f} {out['unit']} ({out['ms_per_step']:.3f} ms/step): slower, not reported as `value`")
+        fallback["strong_scaling_point"] = out["strong_scaling_point"]
+        out = fallback
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

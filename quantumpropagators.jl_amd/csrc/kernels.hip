@@ -135,6 +135,10 @@ struct ChebyOpT {
     double2 xi, v0, acc;
   };
   __device__ __forceinline__ void begin(double2*) {}
+  // the row's own element of the gathered vector, when the epilogue has it in `pre` (x_i with x + xoff == xloc)
+  static constexpr bool kHasXi = true;
+  __device__ __forceinline__ const double2* xloc() const { return e.xloc; }
+  static __device__ __forceinline__ double2 xi_of(const Pre& p) { return p.xi; }
   // row-local operands, issued ahead of the mat-vec loop so their latency overlaps it
   __device__ __forceinline__ Pre pre(int64_t i) const {
     Pre p;
@@ -209,6 +213,9 @@ struct PlainOp {
     }
     inv = (h < e.norm_min) ? 1.0 : 1.0 / h;            // lmul!(1 / h, q[j])          :96  (not past a breakdown :91-95)
   }
+  static constexpr bool kHasXi = false;
+  __device__ __forceinline__ const double2* xloc() const { return nullptr; }
+  static __device__ __forceinline__ double2 xi_of(const Pre&) { return make_double2(0.0, 0.0); }
   __device__ __forceinline__ Pre pre(int64_t i) const {
     Pre p;
     p.y = e.beta_zero ? make_double2(0.0, 0.0) : e.y[i];
@@ -408,6 +415,7 @@ __global__ __launch_bounds__(kThreads) void hrb_spmv_kernel(const int64_t* __res
   constexpr bool PRE = (VAR & 2) != 0;
   constexpr int UNR = (VAR & 4) ? 2 : 1;
   constexpr bool DEEP = (VAR & 8) != 0;
+  constexpr bool NEAR = (VAR & 16) != 0;
   __shared__ double2 lds[kThreads / 64];
   const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
   sync_wait(sy, wg);
@@ -493,13 +501,29 @@ __global__ __launch_bounds__(kThreads) void hrb_spmv_kernel(const int64_t* __res
     if (DEEP && !lower_last && nlq == 2 && nuq == 2 && (lcm & 3) == 2 && (ucm & 3) == 2) {
       const LowerStencilSlot* __restrict__ ls = reinterpret_cast<const LowerStencilSlot*>(lcolbytes + (lcm >> 2));
       const int4* __restrict__ ud = reinterpret_cast<const int4*>(ucolbytes + (ucm >> 2));
+      // NEAR (variant bit 4): a gathered element x[row + d] with |d| < 64 is the row-local element x_i of the
+      // lane d places away in this very wavefront, which the epilogue has loaded anyway: take it through the
+      // cross-lane network (ds_bpermute, no memory access) and load only the |d| lanes whose neighbour lives in
+      // the next row block -- half of the gathers of a lattice H never reach the L1.  Same values, same FMA order.
+      const bool near_ok = NEAR && Op::kHasXi && PRE && op.xloc() == x && (b + 1) * kRB <= nrows;
+      const double2 xi = Op::xi_of(pre);
+      auto gather = [&](int d) -> double2 {
+        const int c = (int)rowc + d;
+        if (near_ok && d > -64 && d < 64) {   // wave-uniform
+          const int src = lane + d;
+          double2 v = make_double2(__shfl(xi.x, src & 63, 64), __shfl(xi.y, src & 63, 64));
+          if ((unsigned)src >= 64u) v = x[c];
+          return v;
+        }
+        return x[c];
+      };
       double2 la[8], lx[8], ua[8], ux[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const LowerStencilSlot e = ls[k];
         const int c = (int)rowc + e.delta;
         la[k] = ld_val<false>(uvals + (((c >> 6) == e.cb0 ? e.pb0 : e.pb1) + (c & 63)));
-        lx[k] = x[c];
+        lx[k] = gather(e.delta);
       }
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
@@ -508,10 +532,10 @@ __global__ __launch_bounds__(kThreads) void hrb_spmv_kernel(const int64_t* __res
         ua[4 * q + 1] = ld_val<false>(v + (size_t)(4 * q + 1) * 64);
         ua[4 * q + 2] = ld_val<false>(v + (size_t)(4 * q + 2) * 64);
         ua[4 * q + 3] = ld_val<false>(v + (size_t)(4 * q + 3) * 64);
-        ux[4 * q + 0] = x[(int)rowc + d.x];
-        ux[4 * q + 1] = x[(int)rowc + d.y];
-        ux[4 * q + 2] = x[(int)rowc + d.z];
-        ux[4 * q + 3] = x[(int)rowc + d.w];
+        ux[4 * q + 0] = gather(d.x);
+        ux[4 * q + 1] = gather(d.y);
+        ux[4 * q + 2] = gather(d.z);
+        ux[4 * q + 3] = gather(d.w);
       }
 #pragma unroll
       for (int k = 0; k < 8; k += 2) {
@@ -1408,7 +1432,7 @@ static int launch_spmv(hipStream_t s, const DevMatrix& A, const double2* x, cons
                          reinterpret_cast<const char*>(A.lcols), reinterpret_cast<const int4*>(A.lpos), x, \
                          nblk, A.nrows, op, bmap, sy, tun.hrb_lower_last);                                 \
     break;
-    switch (tun.rbcsr_variant & 15) {
+    switch (tun.rbcsr_variant & 31) {
       QP_HRB_CASE(0)
       QP_HRB_CASE(1)
       QP_HRB_CASE(2)
@@ -1419,7 +1443,8 @@ static int launch_spmv(hipStream_t s, const DevMatrix& A, const double2* x, cons
       QP_HRB_CASE(7)
       QP_HRB_CASE(8)
       QP_HRB_CASE(15)
-      default: return fail(QP_E_BAD_ARG, "rbcsr_variant %d has no Hermitian-packed kernel (0-8, 15)", tun.rbcsr_variant);
+      QP_HRB_CASE(31)
+      default: return fail(QP_E_BAD_ARG, "rbcsr_variant %d has no Hermitian-packed kernel (0-8, 15, 31)", tun.rbcsr_variant);
     }
 #undef QP_HRB_CASE
   } else {

@@ -141,10 +141,52 @@ def test_bench_multirank_flow_one_gpu(world, driver):
     else:
         assert sp_ is None                              # 3 does not divide 2^20
     par = d["config"]["parallelism"]
+    # both measurements happened: the conservative one first, then the native / overlapped path under the watchdog;
+    # the faster of the two is the reported value and the line names the other
+    assert ("conservative schedule measured first" in par) != ("the native / overlapped path (" in par)
     assert f"row-partitioned x{world}" in par and "TEST MODE" in par
     assert "exchange=halo" in par                       # 2^16 rows per rank: banded H exchanges halos only
     assert "schedule=auto: overlap" in par and ("-> overlap" in par or "-> serial" in par)   # both schedules were timed
     assert ("driver=native (library step" in par) if driver == "native" else ("driver=torch.distributed" in par)
+
+
+@pytest.mark.parametrize("mode", ["1", "raise"])
+def test_bench_multirank_watchdog_reports_the_conservative_measurement(mode):
+    """The safety net of `bench.py --gpus N`: the plain schedule (torch.distributed all-gather per term, no second
+    stream) is measured first; if the native / overlapped path then hangs (simulated: it sleeps) or fails on a rank
+    (simulated: the last rank raises, the others wait for it in a collective), the watchdog prints the kept line from
+    rank 0 and every rank exits with status 0 -- the driver still gets a complete, valid measurement."""
+    import json
+    world = 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", QP_BENCH_ONE_GPU="1", QP_BENCH_TEST_HANG=mode)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3",
+                                       "--warmup", "1", "--log2n", "16", "--watchdog", "20"], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=240))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for p, (out, err) in zip(procs, outs):
+        assert p.returncode == 0, err[-3000:]
+    lines = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and not any(ln.startswith("{") for o, _ in outs[1:] for ln in o.splitlines())
+    d = json.loads(lines[0])
+    par = d["config"]["parallelism"]
+    assert d["n_gpus"] == world and d["steps"] == 3 and d["value"] > 0 and 0 < d["roofline"]["frac"] <= 1
+    assert "schedule=serial" in par and "driver=torch.distributed" in par
+    assert "conservative schedule (reported because the native / overlapped path did not finish)" in par
+    assert "reporting the conservative measurement" in outs[0][1]
 
 
 def test_bench_single_gpu_line_is_physical():

@@ -639,7 +639,7 @@ def test_hrb_kernel_variants_bit_identical(ctx):
     wrk = L.ChebyWrk(ctx, N, 20.0, -10.0, 1.0)
     outs = {}
     try:
-        for v in (15, 7, 3, 0, 8):
+        for v in (15, 31, 7, 3, 0, 8):
             ctx.tuning_set("rbcsr_variant", v)
             psi = L.State(ctx, data=psi0)
             L.cheby(psi, Op, 1.0, wrk)

@@ -319,6 +319,7 @@ int qp_cheby_step_batched(qp_cheby* w, qp_operator* op, qp_state* psi, int batch
   const bool rows_kernel = qp::spmm_uses_rows_kernel(ctx->tun, batch);
   const int32_t* order = nullptr;   // row walk of the wave-per-row kernel
   if (rows_kernel) QP_CHECK(operator_spmm_order(op, batch, &order));
+
   const double beta = (Delta / 2) + E_min;
   cplx c = (dt > 0) ? cplx(0, -2.0) / Delta : cplx(0, 2.0) / Delta;
   const cplx phase = std::exp(cplx(0, -1) * beta * dt);

@@ -708,6 +708,66 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {   // l wave-un
   return __hiloint2double(hi, lo);
 }
 
+// Scalar-memory variant (knob spmm_rw = 0): the row's entries are wave-uniform, so they can be fetched by the
+// scalar unit (s_load: value and column straight into SGPRs, which the FMAs and the gather addresses take as
+// operands) instead of one entry per lane + v_readlane broadcasts -- five VALU instructions per entry less.
+template <class Op>
+__global__ __launch_bounds__(kThreads) void spmm_rows_smem_kernel(const int64_t* __restrict__ rowptr,
+                                                                  const int32_t* __restrict__ cols,
+                                                                  const double2* __restrict__ vals,
+                                                                  const double2* __restrict__ X, int64_t nrows, int b, Op op,
+                                                                  const int32_t* __restrict__ order) {
+  const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int64_t pos = (int64_t)wg * (kThreads / 64) + wave;
+  if (pos >= nrows) return;
+  const int64_t row = order ? (int64_t)__builtin_amdgcn_readfirstlane(order[pos]) : pos;
+  const int st = blockIdx.y * 64 + lane;
+  const bool active = st < b;
+  const int stc = active ? st : b - 1;
+  const int64_t p0 = __builtin_amdgcn_readfirstlane((int)rowptr[row]) ;
+  const int len = __builtin_amdgcn_readfirstlane((int)(rowptr[row + 1] - rowptr[row]));
+  const int64_t e = row * (int64_t)b + stc;
+  const typename Op::Pre pre = op.pre(e);
+  const double2* __restrict__ Xs = X + stc;
+  const double2* __restrict__ rv = vals + p0;    // wave-uniform addresses: scalar loads
+  const int32_t* __restrict__ rc = cols + p0;
+  double2 acc0 = make_double2(0.0, 0.0), acc1 = make_double2(0.0, 0.0);
+  double2 chk = make_double2(0.0, 0.0);
+  double nrm = 0.0;
+  int k = 0;
+  // sums in the order of csr_spmm_kernel (groups of four alternating between two partial sums, remainder into the first)
+  for (; k + 7 < len; k += 8) {
+    double2 x[8], a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      x[u] = Xs[(int64_t)rc[k + u] * b];
+      a[u] = rv[k + u];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) {
+      cfma(acc0, a[u], x[u]);
+      cfma(acc1, a[u + 1], x[u + 1]);
+    }
+  }
+  if (k + 3 < len) {
+    double2 x[4], a[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      x[u] = Xs[(int64_t)rc[k + u] * b];
+      a[u] = rv[k + u];
+    }
+    cfma(acc0, a[0], x[0]);
+    cfma(acc1, a[1], x[1]);
+    cfma(acc0, a[2], x[2]);
+    cfma(acc1, a[3], x[3]);
+    k += 4;
+  }
+  for (; k < len; ++k) cfma(acc0, rv[k], Xs[(int64_t)rc[k] * b]);
+  if (active) op.row(e, make_double2(acc0.x + acc1.x, acc0.y + acc1.y), pre, chk, nrm, e);
+}
+
 // One wavefront walks RW consecutive positions of the row walk.  The dependent loads in front of a
 // row's gathers (walk position -> row, row pointers, the row's entries) are issued for all RW rows
 // together, so a row costs one round of up to 16 gathers instead of a chain of four memory latencies.
@@ -846,6 +906,16 @@ int launch_spmm_cheby(hipStream_t s, const int64_t* rowptr, const int32_t* cols,
       hipLaunchKernelGGL((spmm_rows_kernel<ChebyOp, RW, 8>), grid, dim3(kThreads), 0, s, rowptr, cols, vals, X, nrows, b, op, order); \
     }                                                                                                            \
   }
+    if (tun.spmm_rw == 0) {
+      dim3 grid((unsigned)((nrows + kThreads / 64 - 1) / (kThreads / 64)), (unsigned)((b + 63) / 64));
+      if (nt) {
+        ChebyOpT<true> op{e};
+        hipLaunchKernelGGL((spmm_rows_smem_kernel<ChebyOpT<true>>), grid, dim3(kThreads), 0, s, rowptr, cols, vals, X, nrows, b, op, order);
+      } else {
+        ChebyOp op{e};
+        hipLaunchKernelGGL((spmm_rows_smem_kernel<ChebyOp>), grid, dim3(kThreads), 0, s, rowptr, cols, vals, X, nrows, b, op, order);
+      }
+    } else
     switch (tun.spmm_rw) {
       case 2: QP_SPMM_ROWS(2) break;
       case 4: QP_SPMM_ROWS(4) break;

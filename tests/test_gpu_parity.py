@@ -1247,8 +1247,8 @@ def test_cheby_batched_rows_kernel_and_row_walk_bit_identical(ctx, batch):
     """Panels of more than 32 states take the wave-per-row kernel (lane = state, matrix entries
     broadcast through SGPRs).  It sums a row in the order of the tiled kernel, and the strip-wise row
     walk (tensor-structured H: far offsets multiples of g = 256 here) is index work only: tiled kernel,
-    natural order, automatic and forced strips, one to eight rows per wavefront all give the same bits,
-    and the oracle's values."""
+    natural order, automatic and forced strips, matrix entries through the scalar unit (the default) or one per
+    lane with one to eight rows per wavefront all give the same bits, and the oracle's values."""
     N = 8192
     rp, col, vals = synth.hermitian_offsets_csr(N, offsets=(1, 2, 3, 4, 256, 512, 768, 1024))
     Op = L.Operator(ctx, [L.Matrix(ctx, N, N, rp, col, vals)])
@@ -1256,7 +1256,7 @@ def test_cheby_batched_rows_kernel_and_row_walk_bit_identical(ctx, batch):
     states = np.stack([synth.random_state(N, seed=3000 + s) for s in range(batch)], axis=1)
     outs, walks = {}, {}
     try:
-        for rows, strip, rw in ((0, 0, 1), (1, -1, 1), (1, 0, 1), (1, 32, 1), (1, 64, 1), (1, 48, 1), (1, 32, 2), (1, 64, 4), (1, -1, 8)):
+        for rows, strip, rw in ((0, 0, 1), (1, -1, 1), (1, 0, 1), (1, 32, 1), (1, 64, 1), (1, 48, 1), (1, 32, 2), (1, 64, 4), (1, -1, 8), (1, -1, 0), (1, 0, 0), (1, 64, 0)):
             ctx.tuning_set("spmm_rows", rows)
             ctx.tuning_set("spmm_strip", strip)
             ctx.tuning_set("spmm_rw", rw)
@@ -1270,7 +1270,7 @@ def test_cheby_batched_rows_kernel_and_row_walk_bit_identical(ctx, batch):
     finally:
         ctx.tuning_set("spmm_rows", 1)
         ctx.tuning_set("spmm_strip", 0)
-        ctx.tuning_set("spmm_rw", 1)
+        ctx.tuning_set("spmm_rw", 0)
     ref = outs[(0, 0, 1)]
     for k, v in outs.items():
         assert np.array_equal(v, ref), k

@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--nt", type=int, default=None, help="nontemporal streams in the batched kernel (knob spmm_nt)")
     ap.add_argument("--rows", type=int, default=1, help="1 = wave-per-row kernel, lane = state (default for > 32 states); 0 = state-tiled kernel")
     ap.add_argument("--offsets", default="", help="comma-separated offsets instead of the banded lattice pattern (diagnostics)")
-    ap.add_argument("--rw", type=int, default=1, help="rows per wavefront of the wave-per-row kernel (1, 2, 4, 8)")
+    ap.add_argument("--rw", type=int, default=0, help="wave-per-row kernel: 0 = matrix entries through the scalar unit (default); 1, 2, 4, 8 = one entry per lane + readlane, that many rows per wavefront")
     ap.add_argument("--strip", type=int, default=0, help="row walk of the wave-per-row kernel: strip width (0 = automatic, -1 = natural order)")
     args = ap.parse_args()
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))

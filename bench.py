@@ -322,7 +322,7 @@ def main():
         L.host_unregister(host)
 
     # on-box streaming ceiling: y += a x over 2^26 complex elements, 48 B per element
-    stream_gbs = None
+    stream_gbs = copy_gbs = None
     if world == 1:
         ns = 1 << 26
         sx, sy = L.State(ctx, n=ns), L.State(ctx, n=ns)
@@ -333,6 +333,12 @@ def main():
         for _ in range(10):
             sy.axpy(0.5, sx)
         stream_gbs = 10 * 48.0 * ns / (ctx.timer_end() * 1e-3) / 1e9
+        for _ in range(2):
+            sy.copy_from(sx)
+        ctx.timer_begin()
+        for _ in range(10):
+            sy.copy_from(sx)          # the runtime's device-to-device copy: 32 B per element
+        copy_gbs = 10 * 32.0 * ns / (ctx.timer_end() * 1e-3) / 1e9
         sx.close()
         sy.close()
 
@@ -386,7 +392,7 @@ def main():
                          "traffic_rate_gbs": (traffic / avg_launch_s / 1e9) if traffic else None,
                          "traffic_frac_of_peak": (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "traffic_over_layout_bytes": (traffic / model["per_term"]) if traffic else None,
-                         "hbm_stream_measured_gbs": stream_gbs,
+                         "hbm_stream_measured_gbs": stream_gbs, "hbm_copy_measured_gbs": copy_gbs,
                          "note": "avg launch duration = HIP-event time of the timed region on the kernels' stream / number of "
                                  "fused-term launches (includes launch gaps; multi-GPU: includes the exchange).  `achieved` = bytes "
                                  "the shipped device layout must move per launch (stored values + index bytes + block metadata + "
@@ -543,7 +549,10 @@ def main():
                              ("c2_scattered_pattern", dict(pattern="scattered", log2n=20)),
                              ("c2_random_columns", dict(pattern="random", log2n=20)),
                              ("c2_random_columns_windowed", dict(pattern="random-window", log2n=20)),
-                             ("banded_N_2^22_out_of_infinity_cache", dict(pattern="banded", log2n=22, steps=5))):
+                             ("banded_N_2^22_out_of_infinity_cache", dict(pattern="banded", log2n=22, steps=5)),
+                             ("c2_alpha_2_17_coefficients", dict(pattern="banded", log2n=20, dt=0.2, steps=20)),
+                             ("c2_alpha_50_85_coefficients", dict(pattern="banded", log2n=20, dt=5.0, steps=5)),
+                             ("c2_real_symmetric_f64_values", dict(pattern="banded", log2n=20, real=True))):
                 try:
                     extras[name] = bp.measure_cheby(ctx, **kw)
                 except Exception as e:  # noqa: BLE001  (an extra point must not take the headline down)

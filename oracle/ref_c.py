@@ -76,13 +76,18 @@ def load():
     global _lib
     if _lib is None:
         omp_threads()
-        built_on = None
-        if os.path.exists(_SO + ".cpu"):
-            with open(_SO + ".cpu") as f:
-                built_on = f.read()
-        if not os.path.exists(_SO) or built_on != _cpu_signature():
-            build(force=True)      # first use on this CPU (the GPU box differs from the build container)
-        _lib = C.CDLL(_SO)
+        import fcntl
+        # several processes may get here at once (the ranks of a multi-process test on a fresh box): the check, a
+        # rebuild and the dlopen happen under one exclusive file lock, so nobody maps a half-written library
+        with open(_SO + ".lock", "w") as lk:
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            built_on = None
+            if os.path.exists(_SO + ".cpu"):
+                with open(_SO + ".cpu") as f:
+                    built_on = f.read()
+            if not os.path.exists(_SO) or built_on != _cpu_signature():
+                build(force=True)      # first use on this CPU (the GPU box differs from the build container)
+            _lib = C.CDLL(_SO)
         _lib.qp_ref_omp_setup.restype = C.c_void_p
         _lib.qp_ref_omp_setup.argtypes = [C.c_int64] + [C.c_void_p] * 4
         _lib.qp_ref_omp_step.restype = C.c_int

@@ -97,7 +97,8 @@ def measure_cheby(ctx, pattern="banded", log2n=20, fmt="auto", steps=10, warmup=
     t_term = ms * 1e-3 / (steps * nterms)
     by = cheby_layout_bytes(op, N, N, nnz, wrk.coeffs, real_copy=real)
     lay = by["layout"]
-    out = {"pattern": pattern, "N": N, "nnz_per_row": nnz / N, "device_format": FMT_NAME[op.format],
+    out = {"pattern": pattern, "N": N, "nnz_per_row": nnz / N, "device_format": FMT_NAME[op.format], "dt": dt,
+           "n_coeffs": int(wrk.n_coeffs), "values": "real fp64 (f64 variant)" if real else "complex fp64",
            "ms_per_step": ms / steps, "steps_per_s": 1e3 * steps / ms, "us_per_term": t_term * 1e6,
            "layout_bytes_per_term": by["per_term"], "layout_gbs": by["per_term"] / t_term / 1e9,
            "frac": by["per_term"] / t_term / 1e9 / HBM_PEAK_GBS,

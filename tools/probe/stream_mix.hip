@@ -4,6 +4,7 @@
 //   hipcc -O3 --offload-arch=gfx950 tools/probe/stream_mix.hip -o tools/probe/stream_mix && tools/probe/stream_mix
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s -> %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
@@ -61,8 +62,10 @@ static int run(const char* name, d2* x, d2* y, d2* z, size_t n, double bytes_per
   return 0;
 }
 
-int main() {
-  const size_t n = (size_t)1 << 24;   // 2^18 rows x 64 states: 268 MB per vector
+int main(int argc, char** argv) {
+  const int log2n = argc > 1 ? atoi(argv[1]) : 24;   // default 2^24 elements = 2^18 rows x 64 states: 268 MB per vector
+  const size_t n = (size_t)1 << log2n;
+  printf("%zu elements = %.0f MB per vector\n", n, n * 16.0 / 1e6);
   d2 *x, *y, *z;
   CK(hipMalloc(&x, n * 16));
   CK(hipMalloc(&y, n * 16));

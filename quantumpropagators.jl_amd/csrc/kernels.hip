@@ -134,6 +134,7 @@ struct ChebyOpT {
   struct Pre {
     double2 xi, v0, acc;
   };
+  __device__ __forceinline__ void begin_issue() {}
   __device__ __forceinline__ void begin(double2*) {}
   // the row's own element of the gathered vector, when the epilogue has it in `pre` (x_i with x + xoff == xloc)
   static constexpr bool kHasXi = true;
@@ -195,14 +196,20 @@ using ChebyOp = ChebyOpT<false>;
 struct PlainOp {
   PlainEpi e;
   double inv = 1.0;   // 1 / |x| of the folded normalisation (begin())
+  double2 np;         // this thread's partial of |x|^2 (begin_issue())
   struct Pre {
     double2 y;
   };
-  // all threads of the workgroup, before any row: the scale of the folded "norm + scale"
+  // The scale of the folded "norm + scale", in two halves: the load of the partials is issued first thing in
+  // the kernel, the reduction (a barrier) runs after the row sums, just before the first row() -- so the
+  // workgroup's matrix loads do not queue behind it.  All threads of the workgroup call both.
+  __device__ __forceinline__ void begin_issue() {
+    static_assert(kRedBlocks == kThreads, "one partial per thread");
+    if (e.norm_part) np = e.norm_part[threadIdx.x];
+  }
   __device__ __forceinline__ void begin(double2* lds4) {
     if (!e.norm_part) return;
-    static_assert(kRedBlocks == kThreads, "one partial per thread");
-    const double2 s2 = block_sum(e.norm_part[threadIdx.x], lds4);
+    const double2 s2 = block_sum(np, lds4);
     const double h = sqrt(s2.x);                       // h = norm(q[j])              src/arnoldi.jl:89
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       if (e.hess_slot) *e.hess_slot = make_double2(e.dt * h, 0.0);   // :90
@@ -338,23 +345,24 @@ __global__ __launch_bounds__(kThreads) void rbcsr_spmv_kernel(const int64_t* __r
   __shared__ double2 lds[kThreads / 64];
   const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
   sync_wait(sy, wg);
-  op.begin(lds);
+  op.begin_issue();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int64_t idx = (int64_t)wg * (kThreads / 64) + wave;  // position in the row set
   double2 chk = make_double2(0.0, 0.0);
   double nrm = 0.0;
+  int64_t row = nrows;
+  typename Op::Pre pre;
+  double2 s0 = make_double2(0.0, 0.0), s1 = make_double2(0.0, 0.0);
   if (idx < nblocks) {
     const int64_t b = block_map ? (int64_t)block_map[idx] : idx;
     const int64_t base = bptr[b];
     const int nq = (int)((bptr[b + 1] - base) >> 8);  // width / 4
     const VT* __restrict__ v = vals + base + lane;
     const int64_t cm = cmeta[b];
-    const int64_t row = b * kRB + lane;
+    row = b * kRB + lane;
     const int64_t rowc = row < nrows ? row : nrows - 1;
-    typename Op::Pre pre;
     if (PRE) pre = op.pre(rowc);
-    double2 s0 = make_double2(0.0, 0.0), s1 = make_double2(0.0, 0.0);
 #pragma unroll UNR
     for (int q = 0; q < nq; ++q) {
       const int4 c = ld_cols<NT>(colbytes, cm, q, lane, (int)rowc);
@@ -372,8 +380,9 @@ __global__ __launch_bounds__(kThreads) void rbcsr_spmv_kernel(const int64_t* __r
       cfma(s1, a3, x3);
     }
     if (!PRE) pre = op.pre(rowc);
-    if (row < nrows) op.row(row, make_double2(s0.x + s1.x, s0.y + s1.y), pre, chk, nrm, idx * kRB + lane);
   }
+  op.begin(lds);
+  if (row < nrows) op.row(row, make_double2(s0.x + s1.x, s0.y + s1.y), pre, chk, nrm, idx * kRB + lane);
   finish_check(op, chk, nrm, lds);
   sync_signal(sy);
 }
@@ -419,12 +428,15 @@ __global__ __launch_bounds__(kThreads) void hrb_spmv_kernel(const int64_t* __res
   __shared__ double2 lds[kThreads / 64];
   const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
   sync_wait(sy, wg);
-  op.begin(lds);
+  op.begin_issue();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int64_t idx = (int64_t)wg * (kThreads / 64) + wave;  // position in the row set
   double2 chk = make_double2(0.0, 0.0);
   double nrm = 0.0;
+  int64_t row = nrows;
+  typename Op::Pre pre;
+  double2 s0 = make_double2(0.0, 0.0), s1 = make_double2(0.0, 0.0);
   if (idx < nblocks) {
     const int64_t b = block_map ? (int64_t)block_map[idx] : idx;
     const int64_t ubase = uptr[b], lbase = lptr[b];
@@ -433,11 +445,9 @@ __global__ __launch_bounds__(kThreads) void hrb_spmv_kernel(const int64_t* __res
     const VT* __restrict__ v = uvals + ubase + lane;
     const int64_t ucm = ucmeta[b], lcm = lcmeta[b];
     const int4* __restrict__ lp4 = lpos4 + (lbase >> 2) + lane;
-    const int64_t row = b * kRB + lane;
+    row = b * kRB + lane;
     const int64_t rowc = row < nrows ? row : nrows - 1;
-    typename Op::Pre pre;
     if (PRE) pre = op.pre(rowc);
-    double2 s0 = make_double2(0.0, 0.0), s1 = make_double2(0.0, 0.0);
     auto lower_stencil = [&]() {
       const LowerStencilSlot* __restrict__ ls = reinterpret_cast<const LowerStencilSlot*>(lcolbytes + (lcm >> 2));
 #pragma unroll 2
@@ -559,8 +569,9 @@ __global__ __launch_bounds__(kThreads) void hrb_spmv_kernel(const int64_t* __res
       upper();
     }
     if (!PRE) pre = op.pre(rowc);
-    if (row < nrows) op.row(row, make_double2(s0.x + s1.x, s0.y + s1.y), pre, chk, nrm, idx * kRB + lane);
   }
+  op.begin(lds);
+  if (row < nrows) op.row(row, make_double2(s0.x + s1.x, s0.y + s1.y), pre, chk, nrm, idx * kRB + lane);
   finish_check(op, chk, nrm, lds);
   sync_signal(sy);
 }
@@ -577,7 +588,7 @@ __global__ __launch_bounds__(kThreads) void csr_spmv_kernel(const int64_t* __res
                                                             Op op) {
   __shared__ double2 lds[kThreads / 64];
   const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
-  op.begin(lds);
+  op.begin_issue();
   const int64_t row = ((int64_t)wg * kThreads + threadIdx.x) / T;
   const int tl = threadIdx.x % T;
   double2 s = make_double2(0.0, 0.0);
@@ -606,6 +617,7 @@ __global__ __launch_bounds__(kThreads) void csr_spmv_kernel(const int64_t* __res
   }
   double2 chk = make_double2(0.0, 0.0);
   double nrm = 0.0;
+  op.begin(lds);
   if (row < nrows && tl == 0) op.row(row, s, op.pre(row), chk, nrm, row);
   finish_check(op, chk, nrm, lds);
 }

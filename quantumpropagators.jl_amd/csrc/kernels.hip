@@ -1383,7 +1383,7 @@ int* tuning_field(Tuning& t, const char* key) {
       {"rbcsr_variant", &Tuning::rbcsr_variant}, {"hrb_lower_last", &Tuning::hrb_lower_last},
       {"arnoldi_mode", &Tuning::arnoldi_mode},   {"split_mode", &Tuning::split_mode},
       {"arnoldi_fold", &Tuning::arnoldi_fold},
-      {"liouville_fused_n", &Tuning::liouville_fused_n}, {"real_vals", &Tuning::real_vals},
+      {"liouville_fused_n", &Tuning::liouville_fused_n}, {"liouville_tile32_n", &Tuning::liouville_tile32_n}, {"liouville_tile32_min_n", &Tuning::liouville_tile32_min_n}, {"real_vals", &Tuning::real_vals},
       {"stencil", &Tuning::stencil},             {"acc_defer", &Tuning::acc_defer},
       {"cheby_graph", &Tuning::cheby_graph},     {"small_nnz", &Tuning::small_nnz},
       {"newton_pipeline", &Tuning::newton_pipeline}, {"spmm_tile", &Tuning::spmm_tile},

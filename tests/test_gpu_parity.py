@@ -938,17 +938,23 @@ def _dense_open_system(n, rng, nterms=2, nc=2):
     return Hs, cops
 
 
-@pytest.fixture(params=[4096, 0], ids=["fused-mfma", "rocblas"])
+@pytest.fixture(params=[(4096, 0), (0, 4096), (0, 0)], ids=["fused-mfma-16", "mfma-32", "rocblas"])
 def liouville_path(request):
-    """Both implementations of the matrix-free application: the hand-written fused fp64
-    matrix-core kernel (n <= 256 by default) and the chain of rocBLAS zgemm calls."""
-    L.tuning_set("liouville_fused_n", request.param)
+    """The three implementations of the matrix-free application: the hand-written fp64 matrix-core
+    kernels -- 16 x 16 tiles (n <= 320 by default) and 32 x 32 tiles (260 <= n <= 2048, n a multiple of 4, by default;
+    other n fall through to the library here) -- and the chain of rocBLAS zgemm calls."""
+    L.tuning_set("liouville_fused_n", request.param[0])
+    L.tuning_set("liouville_tile32_n", request.param[1])
+    L.tuning_set("liouville_tile32_min_n", 0)
     yield request.param
     L.tuning_set("liouville_fused_n", 320)
+    L.tuning_set("liouville_tile32_n", 2048)
+    L.tuning_set("liouville_tile32_min_n", 260)
 
 
 @pytest.mark.parametrize("convention", ["TDSE", "LvN"])
-@pytest.mark.parametrize("n,nterms,nc", [(3, 1, 0), (8, 2, 1), (33, 2, 2), (64, 0, 1), (150, 1, 1), (300, 2, 2)])
+@pytest.mark.parametrize("n,nterms,nc", [(3, 1, 0), (8, 2, 1), (33, 2, 2), (36, 1, 2), (64, 0, 1), (100, 1, 3), (150, 1, 1),
+                                         (300, 2, 2)])
 def test_matrix_free_liouvillian_matches_superoperator(ctx, liouville_path, convention, n, nterms, nc):
     """qp_liouvillian_create applies liouvillian(H, c_ops; convention) (src/generators.jl:473-631)
     as GEMMs on the n x n density matrix; the n^2 x n^2 sparse superoperator built from the

@@ -610,3 +610,43 @@ def test_ode_function(ctx):
     cheb = cheb.numpy() if hasattr(cheb, "numpy") else np.asarray(cheb)
     assert np.linalg.norm(u.numpy() - cheb) < 1e-6          # O(dt^2) PWC vs O(dt^4) RK4 on the same H(t)
     assert abs(np.linalg.norm(u.numpy()) - 1.0) < 1e-8
+
+
+def test_matvec_counters_like_reference_timings(ctx):
+    """test/test_timings.jl:8-39 with the context's counters in the place of TimerOutputs: N = 10, 100 steps
+    of a time-dependent generator with Cheby -> more than 200 "matrix-vector product" calls.  And the
+    qualitative statement of docs/src/benchmarks/profiling.md:112 (N = 200, 100 steps of dt = 1, spectral
+    radius 1): the Newton propagator (m_max = 10, chunks of 10 applications) needs more applications of
+    H than Chebychev, whose count per step is its number of coefficients minus one."""
+    rng = np.random.default_rng(677918056 % 2**32)
+    N = 10
+    tlist = np.linspace(0, 10, 101)
+    H0 = synth.dense_hermitian(N, rho=1.0, rng=rng)
+    H1 = synth.dense_hermitian(N, rho=0.1, rng=rng)
+    psi0 = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    psi0 /= np.linalg.norm(psi0)
+    p = P.init_prop(psi0, P.hamiltonian(H0, (H1, lambda t: np.sin(t))), tlist, method="cheby", ctx=ctx,
+                    rng=np.random.default_rng(5))
+    ctx.sync()
+    ctx.reset_stats()
+    for _ in range(len(tlist) - 1):
+        P.prop_step(p)
+    st = ctx.stats()
+    assert st["n_cheby_steps"] == 100
+    assert st["n_matvec"] > 200
+    assert st["n_matvec"] == 100 * (len(p.wrk.coeffs) - 1)
+
+    N = 200
+    tlist = np.arange(0, 101, 1.0)
+    H0 = synth.dense_hermitian(N, rho=1.0, rng=rng)
+    psi0 = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    psi0 /= np.linalg.norm(psi0)
+    counts, outs = {}, {}
+    for method in ("cheby", "newton"):
+        ctx.sync()
+        ctx.reset_stats()
+        outs[method] = P.propagate(psi0, (H0,), tlist, method=method, ctx=ctx, rng=np.random.default_rng(6))
+        counts[method] = ctx.stats()["n_matvec"]
+    assert np.linalg.norm(outs["cheby"] - outs["newton"]) < 1e-10
+    assert counts["newton"] > counts["cheby"] > 200
+    assert counts["newton"] >= 100 * 20 and counts["newton"] % 10 == 0   # whole chunks of m_max = 10, at least one restart

@@ -39,6 +39,7 @@ def main():
         us = 1e3 * ctx.timer_end() / reps
         flops = 8.0 * n ** 3 * (2 + 2 * nc)
         L.tuning_set("liouville_fused_n", 0)          # the chain of rocBLAS zgemm calls, for comparison
+        L.tuning_set("liouville_tile32_n", 0)
         for _ in range(3):
             Lmf.mul(x, y)
         ctx.timer_begin()
@@ -46,8 +47,9 @@ def main():
             Lmf.mul(x, y)
         us_lib = 1e3 * ctx.timer_end() / reps
         L.tuning_set("liouville_fused_n", 320)
+        L.tuning_set("liouville_tile32_n", 2048)
         out = {"n": n, "N": n * n, "c_ops": nc, "gemms_per_apply": 2 + 2 * nc, "us_per_apply": us,
-               "us_per_apply_rocblas_chain": us_lib, "path": "fused mfma kernel" if n <= 320 else "rocblas zgemm chain",
+               "us_per_apply_rocblas_chain": us_lib, "path": "mfma kernel, 32 x 32 tiles" if 260 <= n <= 2048 and n % 4 == 0 else "fused mfma kernel, 16 x 16 tiles" if n <= 320 else ("rocblas zgemm chain"),
                "tflops": flops / us / 1e6, "frac_fp64_matrix_peak": flops / us / 1e6 / FP64_MATRIX_PEAK_TF,
                # 1 (x) H - H^T (x) 1: 2 n^3 entries; per dense Lindblad operator n^4 + 2 n^3 more
                "sparse_superoperator_entries": 2 * n ** 3 + nc * (n ** 4 + 2 * n ** 3)}

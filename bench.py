@@ -557,7 +557,8 @@ def main():
                     extras[name] = bp.measure_cheby(ctx, **kw)
                 except Exception as e:  # noqa: BLE001  (an extra point must not take the headline down)
                     extras[name] = {"error": f"{type(e).__name__}: {e}"}
-            for name, fn in (("c3_newton", bp.measure_newton_c3), ("c5_batched", bp.measure_batched_c5)):
+            for name, fn in (("c3_newton", bp.measure_newton_c3), ("c5_batched", bp.measure_batched_c5),
+                             ("n4_matrix_free_liouvillian_n512", bp.measure_liouville)):
                 try:
                     extras[name] = fn(ctx)
                 except Exception as e:  # noqa: BLE001

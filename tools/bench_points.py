@@ -190,3 +190,43 @@ def measure_batched_c5(ctx, log2n=18, batch=64, steps=5, warmup=2):
     for h in (panel, wrk, op, M):
         h.close()
     return out
+
+
+def measure_liouville(ctx, n=512, nc=2, reps=20):
+    """one application L rho of the matrix-free Liouvillian (dense H, nc dense Lindblad operators) on the
+    fp64 matrix cores -- the hand-written kernel the library picks for this n, and the chain of library GEMMs beside it."""
+    rng = np.random.default_rng(0)
+    H = synth.dense_hermitian(n, rho=2.0, rng=rng)
+    cops = [0.2 * (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))) / np.sqrt(n) for _ in range(nc)]
+    Lmf = L.Liouvillian(ctx, [H], cops, convention="TDSE")
+    x = L.State(ctx, data=(rng.standard_normal(n * n) + 1j * rng.standard_normal(n * n)))
+    y = L.State(ctx, n=n * n)
+    flops = 8.0 * n ** 3 * (2 + 2 * nc)
+    keys = ("liouville_fused_n", "liouville_tile32_n")
+    saved = {k: ctx.tuning_get(k) for k in keys}
+    res = {}
+    try:
+        for name, override in (("hand_written", None), ("library_chain", 0)):
+            if override is not None:
+                for k in keys:
+                    ctx.tuning_set(k, override)
+            for _ in range(3):
+                Lmf.mul(x, y)
+            ctx.sync()
+            ctx.timer_begin()
+            for _ in range(reps):
+                Lmf.mul(x, y)
+            res[name] = 1e3 * ctx.timer_end() / reps
+    finally:
+        for k, v in saved.items():
+            ctx.tuning_set(k, v)
+    out = {"workload": f"matrix-free Liouvillian, one application L rho: n = {n} (N = n^2 = {n * n}), {nc} Lindblad operators, "
+                       f"{2 + 2 * nc} complex n x n products", "n": n, "c_ops": nc,
+           "kernel": "zgemm_sum32_kernel (32 x 32 tile per workgroup, v_mfma_f64_16x16x4_f64)" if 260 <= n <= 2048 and n % 4 == 0
+                     else "zgemm_sum_kernel (16 x 16 tile per workgroup)",
+           "us_per_apply": res["hand_written"], "tflops": flops / res["hand_written"] / 1e6,
+           "frac_fp64_matrix_peak": flops / res["hand_written"] / 1e6 / 78.6,
+           "us_per_apply_rocblas_chain": res["library_chain"], "tflops_rocblas_chain": flops / res["library_chain"] / 1e6}
+    for h in (x, y, Lmf):
+        h.close()
+    return out

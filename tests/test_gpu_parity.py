@@ -1012,6 +1012,48 @@ def test_matrix_free_liouvillian_matches_superoperator(ctx, liouville_path, conv
         Lmf.get_csr()
 
 
+@pytest.mark.parametrize("n,nc", [(516, 2), (1024, 1)])
+def test_matrix_free_liouvillian_paths_agree_at_size(ctx, n, nc):
+    """The sizes the 32 x 32 matrix-core kernel is meant for (one with partial edge tiles, one with more workgroups than
+    the chip holds at once): its L rho against the 16 x 16 kernel's, the library chain's and the map written out on rho
+    in NumPy, 5-argument form included; a physical rho keeps trace L rho = 0 and L rho Hermitian (i d rho/dt = L rho)."""
+    rng = np.random.default_rng(4000 + n)
+    Hs, cops = _dense_open_system(n, rng, 1, nc)
+    Lmf = L.Liouvillian(ctx, Hs, cops, convention="TDSE")
+    psi = rng.standard_normal((n, 3)) + 1j * rng.standard_normal((n, 3))
+    rho = psi @ psi.conj().T
+    rho /= np.trace(rho).real
+    x = np.ascontiguousarray(rho.T).reshape(-1)
+    y0 = rng.standard_normal(n * n) + 1j * rng.standard_normal(n * n)
+    out = Hs[0] @ rho - rho @ Hs[0]
+    for A in cops:
+        G = A.conj().T @ A
+        out = out + 1j * (A @ rho @ A.conj().T - 0.5 * (G @ rho + rho @ G))
+    ref = np.ascontiguousarray(out.T).reshape(-1)
+    xs = L.State(ctx, data=x)
+    res = {}
+    try:
+        for name, fused, tile in (("mfma16", 4096, 0), ("mfma32", 0, 4096), ("library", 0, 0)):
+            ctx.tuning_set("liouville_fused_n", fused)
+            ctx.tuning_set("liouville_tile32_n", tile)
+            ys = L.State(ctx, n=n * n)
+            Lmf.mul(xs, ys)
+            a = ys.numpy()
+            ys.upload(y0)
+            Lmf.mul(xs, ys, 0.7 - 0.2j, -0.3 + 0.1j)
+            res[name] = (a, ys.numpy())
+    finally:
+        ctx.tuning_set("liouville_fused_n", 320)
+        ctx.tuning_set("liouville_tile32_n", 2048)
+    scale = np.linalg.norm(ref)
+    for name, (a, b5) in res.items():
+        assert np.linalg.norm(a - ref) < 1e-13 * scale, name
+        assert np.linalg.norm(b5 - ((-0.3 + 0.1j) * y0 + (0.7 - 0.2j) * ref)) < 1e-13 * (scale + np.linalg.norm(y0)), name
+    Lrho = res["mfma32"][0].reshape(n, n).T
+    assert abs(np.trace(Lrho)) < 1e-12 * scale
+    assert np.linalg.norm(Lrho + Lrho.conj().T) < 1e-12 * scale      # L rho = i d rho/dt is anti-Hermitian
+
+
 def test_matrix_free_liouvillian_newton_and_cheby(ctx, liouville_path):
     """Newton on the matrix-free Liouvillian equals Newton on the sparse superoperator and the
     oracle (trace preserved, rho stays Hermitian); without dissipation the superoperator is

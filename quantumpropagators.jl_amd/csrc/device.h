@@ -147,8 +147,8 @@ struct Tuning {
   int arnoldi_mode = 1;       // 0 = sequential fused MGS passes, 1 = low-synchronisation MGS
   int arnoldi_fold = 1;       // 1 = the norm + scale of an Arnoldi column is folded into the next column's mat-vec (no launch of its own)
   int split_mode = 2;         // boundary -> interior hand-off: 0 = cross-stream events, 1 = in-launch counter, 2 = the counter when at most 256 workgroups poll
-  int liouville_tile32_min_n = 260;  // matrix-free Liouvillian: n in [this, liouville_tile32_n] and a multiple of 4 takes the
-  int liouville_tile32_n = 2048;     //   32 x 32 matrix-core kernel; other n <= liouville_fused_n the 16 x 16 one; the rest library GEMMs
+  int liouville_tile32_min_n = 260;  // matrix-free Liouvillian: n in [this, liouville_tile32_n] takes the 32 x 32 matrix-core
+  int liouville_tile32_n = 2048;     //   kernel; other n <= liouville_fused_n the 16 x 16 one; the rest library GEMMs
   int liouville_fused_n = 320;  // matrix-free Liouvillian: largest n that takes the fused matrix-core kernel (else library GEMMs)
   int real_vals = 1;          // operator refresh: stream a real copy of the values when they are all real
   int stencil = 1;            // operator build: encode blocks with block-wide column distances as stencil blocks

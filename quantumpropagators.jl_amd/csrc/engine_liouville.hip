@@ -100,7 +100,7 @@ __global__ __launch_bounds__(qp::kThreads) void liouville_combine_kernel(double2
 
 // ---------------------------------------------------------------------------
 // Hand-written fp64 matrix-core kernel for the sizes where a chain of library GEMMs is bound
-// by its launches (default: n < 260, and n <= 320 that are not a multiple of 4):  Y = beta Y + sum_j alpha_j P_j op_j(Q_j)  in ONE launch, all
+// by its launches (default: n < 260):  Y = beta Y + sum_j alpha_j P_j op_j(Q_j)  in ONE launch, all
 // matrices n x n, column-major.  v_mfma_f64_16x16x4_f64: lane l holds A[l & 15][l >> 4] and
 // B[l >> 4][l & 15]; D register r of lane l is D[(l >> 4) + 4 r][l & 15].  A complex
 // product is four real ones (Re += ar br - ai bi, Im += ar bi + ai br).
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void zgemm_sum_kernel(double2* __restrict__ Y,
 }
 
 // ---------------------------------------------------------------------------
-// The sum of products for the sizes above (default 320 < n <= 1024, n a multiple of 4: knob liouville_tile32_n):
+// The sum of products for the sizes above (default 260 <= n <= 2048: knobs liouville_tile32_min_n, liouville_tile32_n):
 //   Y = beta Y + alpha sum_j P_j Q_j      (`batched`: Y_z = alpha P_z Q_z for every z)
 // On MI355X the fp64 MFMA runs at the rate of the fp64 vector unit and shares its issue: every vector-ALU
 // instruction between two MFMAs is time the matrix pipe stands still, from the same or from another wavefront
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void zgemm_sum32_kernel(double2* __restrict__ 
   const int nt = batched ? 1 : terms.n_terms;
   const int tlast = first + nt - 1;
   double2* __restrict__ Yz = Y + (batched ? (size_t)blockIdx.z * n * n : 0);
-  const int ksteps = n >> 2;   // n is a multiple of 4
+  const int ksteps = n >> 2;   // whole k-steps; the n & 3 inner indices left over: one masked step after the loop
   const int per = (ksteps + 3) / 4;
   const int sbeg = wave * per;
   const int nsteps = max(min(ksteps, sbeg + per) - sbeg, 0);
@@ -403,6 +403,22 @@ __global__ __launch_bounds__(256) void zgemm_sum32_kernel(double2* __restrict__ 
       }
     }
   }
+  // n not a multiple of 4: one more k-step per product for the n & 3 inner indices left over, the lanes past the end
+  // masked out of the A fragment (products dealt round-robin to the wavefronts; outside the pipelined loop)
+  if (n & 3) {
+    const int k = ksteps * 4 + lk;
+    const bool kin = k < n;
+    const int kc = min(k, n - 1);
+    for (int t = first + wave; t <= tlast; t += 4) {
+      const double2 zero = make_double2(0.0, 0.0);
+      const double2 p0 = terms.P[t][(size_t)kc * n + ra0], p1 = terms.P[t][(size_t)kc * n + ra1];
+      fa[0][0] = kin ? p0 : zero;
+      fa[0][1] = kin ? p1 : zero;
+      fb[0][0] = terms.Q[t][(size_t)cb0 * n + kc];
+      fb[0][1] = terms.Q[t][(size_t)cb1 * n + kc];
+      mfma(0);
+    }
+  }
   // sum the four k-quarters in wave order
   if (wave > 0) {
 #pragma unroll
@@ -429,9 +445,9 @@ __global__ __launch_bounds__(256) void zgemm_sum32_kernel(double2* __restrict__ 
             sr += red[w][a * 2 + b][0][r][lane];
             si += red[w][a * 2 + b][1][r][lane];
           }
-          double vr = alpha.x * sr - alpha.y * si, vi = alpha.x * si + alpha.y * sr;
           const int row = row0 + a * 16 + lk + 4 * r, col = col0 + b * 16 + li;
           if (row < n && col < n) {
+            double vr = alpha.x * sr - alpha.y * si, vi = alpha.x * si + alpha.y * sr;
             double2* y = Yz + (size_t)col * n + row;
             if (!bz) {
               const double2 o = *y;
@@ -512,7 +528,7 @@ int liouville_apply(hipStream_t s, void* self, const double2* x, double2* y, dou
   Liouville* L = static_cast<Liouville*>(self);
   const rocblas_int n = (rocblas_int)L->n;
   const qp::Tuning& tun = L->ctx->tun;
-  if (L->MRn && L->n >= tun.liouville_tile32_min_n && L->n <= tun.liouville_tile32_n && L->n % 4 == 0 && 2 + L->nc <= kMaxTerms) {
+  if (L->MRn && L->n >= tun.liouville_tile32_min_n && L->n <= tun.liouville_tile32_n && 2 + L->nc <= kMaxTerms) {
     // two launches of the 32 x 32 matrix-core kernel: T_k = scale s_d A_k X (batched), then
     // Y = beta Y + alpha (M_L X + X (-M_R) + sum_k T_k A_k^+)
     if (L->nc > 0) {
@@ -646,7 +662,7 @@ int qp_liouvillian_create(qp_ctx* ctx, int64_t n, const qp_c128* const* H_terms,
   if (nterms > 0) QP_HIP(hipMemcpy(Lp->H_dev, Lp->H.data(), nterms * sizeof(double2*), hipMemcpyHostToDevice));
   QP_CHECK(dev_alloc(&Lp->ML, n2));
   QP_CHECK(dev_alloc(&Lp->MR, n2));
-  const bool tile32 = n % 4 == 0 && n <= 2048;   // sizes the 32 x 32 kernel can take (knob liouville_tile32_n decides per call)
+  const bool tile32 = n <= 2048;   // sizes the 32 x 32 kernel can take (knobs liouville_tile32_min_n / _n decide per call)
   if (tile32) QP_CHECK(dev_alloc(&Lp->MRn, n2));
   QP_CHECK(dev_alloc(&Lp->T, n2));
   if (nc > 0) QP_CHECK(dev_alloc(&Lp->Tk, n2 * (size_t)nc));

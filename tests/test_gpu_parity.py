@@ -941,8 +941,7 @@ def _dense_open_system(n, rng, nterms=2, nc=2):
 @pytest.fixture(params=[(4096, 0), (0, 4096), (0, 0)], ids=["fused-mfma-16", "mfma-32", "rocblas"])
 def liouville_path(request):
     """The three implementations of the matrix-free application: the hand-written fp64 matrix-core
-    kernels -- 16 x 16 tiles (n <= 320 by default) and 32 x 32 tiles (260 <= n <= 2048, n a multiple of 4, by default;
-    other n fall through to the library here) -- and the chain of rocBLAS zgemm calls."""
+    kernels -- 16 x 16 tiles (n <= 320 by default) and 32 x 32 tiles (260 <= n <= 2048 by default) -- and the chain of rocBLAS zgemm calls."""
     L.tuning_set("liouville_fused_n", request.param[0])
     L.tuning_set("liouville_tile32_n", request.param[1])
     L.tuning_set("liouville_tile32_min_n", 0)
@@ -1012,7 +1011,7 @@ def test_matrix_free_liouvillian_matches_superoperator(ctx, liouville_path, conv
         Lmf.get_csr()
 
 
-@pytest.mark.parametrize("n,nc", [(516, 2), (1024, 1)])
+@pytest.mark.parametrize("n,nc", [(516, 2), (774, 1), (1024, 1)])
 def test_matrix_free_liouvillian_paths_agree_at_size(ctx, n, nc):
     """The sizes the 32 x 32 matrix-core kernel is meant for (one with partial edge tiles, one with more workgroups than
     the chip holds at once): its L rho against the 16 x 16 kernel's, the library chain's and the map written out on rho

@@ -49,7 +49,7 @@ def main():
         L.tuning_set("liouville_fused_n", 320)
         L.tuning_set("liouville_tile32_n", 2048)
         out = {"n": n, "N": n * n, "c_ops": nc, "gemms_per_apply": 2 + 2 * nc, "us_per_apply": us,
-               "us_per_apply_rocblas_chain": us_lib, "path": "mfma kernel, 32 x 32 tiles" if 260 <= n <= 2048 and n % 4 == 0 else "fused mfma kernel, 16 x 16 tiles" if n <= 320 else ("rocblas zgemm chain"),
+               "us_per_apply_rocblas_chain": us_lib, "path": "mfma kernel, 32 x 32 tiles" if 260 <= n <= 2048 else "fused mfma kernel, 16 x 16 tiles" if n <= 320 else ("rocblas zgemm chain"),
                "tflops": flops / us / 1e6, "frac_fp64_matrix_peak": flops / us / 1e6 / FP64_MATRIX_PEAK_TF,
                # 1 (x) H - H^T (x) 1: 2 n^3 entries; per dense Lindblad operator n^4 + 2 n^3 more
                "sparse_superoperator_entries": 2 * n ** 3 + nc * (n ** 4 + 2 * n ** 3)}

@@ -222,7 +222,7 @@ def measure_liouville(ctx, n=512, nc=2, reps=20):
             ctx.tuning_set(k, v)
     out = {"workload": f"matrix-free Liouvillian, one application L rho: n = {n} (N = n^2 = {n * n}), {nc} Lindblad operators, "
                        f"{2 + 2 * nc} complex n x n products", "n": n, "c_ops": nc,
-           "kernel": "zgemm_sum32_kernel (32 x 32 tile per workgroup, v_mfma_f64_16x16x4_f64)" if 260 <= n <= 2048 and n % 4 == 0
+           "kernel": "zgemm_sum32_kernel (32 x 32 tile per workgroup, v_mfma_f64_16x16x4_f64)" if 260 <= n <= 2048
                      else "zgemm_sum_kernel (16 x 16 tile per workgroup)",
            "us_per_apply": res["hand_written"], "tflops": flops / res["hand_written"] / 1e6,
            "frac_fp64_matrix_peak": flops / res["hand_written"] / 1e6 / 78.6,

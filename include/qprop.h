@@ -268,7 +268,8 @@ int qp_cheby_term_split(qp_operator* op, qp_split* sp, void* boundary_stream, in
  * superoperator  L = s_h (1 (x) H - H^T (x) 1) + s_d sum_k (A_k^{+T} (x) A_k - (1 (x) G_k + G_k^T (x) 1) / 2),
  * G_k = A_k^+ A_k, (s_h, s_d) = (1, i) for :TDSE and (i, 1) for :LvN, acting on the
  * column-major vec(rho).  For DENSE H and A_k that matrix has 2 n^3 entries; this operator
- * applies the same map to rho as n x n GEMMs instead (fp64 matrix cores, rocBLAS zgemm):
+ * applies the same map to rho as complex n x n products instead (hand-written fp64 matrix-core kernels up to
+ * n = 2048, rocBLAS zgemm above):
  *   L rho = M_L rho - rho M_R + s_d sum_k A_k rho A_k^+,   M_L/R = s_h H -/+ (s_d / 2) sum_k G_k,
  * with H = sum_l c_l H_l the usual lazy sum (qp_operator_set_coeffs; the first
  * nterms - ncoeffs terms are the drift).  Matrices are dense, column-major (Julia layout).

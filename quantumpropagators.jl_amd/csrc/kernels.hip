@@ -1489,7 +1489,12 @@ static int launch_spmv(hipStream_t s, const DevMatrix& A, const double2* x, cons
       hipLaunchKernelGGL((rbcsr_spmv_kernel<Op, VV, double2>), dim3(grid), dim3(kThreads), 0, s, A.bptr, A.cmeta, \
                          reinterpret_cast<const char*>(A.cols), A.vals, x, nblk, A.nrows, op, bmap, sy);   \
     break;
-    switch (tun.rbcsr_variant & 7) {
+    // the deeper unroll (bit 2: 156-160 VGPRs, 3 wavefronts per SIMD) pays from three quads per row on; blocks of
+    // at most two quads (8 entries per row: the Liouvillian of config C3) take the shallow one (88 VGPRs, 5 per
+    // SIMD) -- at N = 2^18 that is one round of wavefronts instead of one and a third.  Same sums either way.
+    int variant = tun.rbcsr_variant & 7;
+    if (A.stored <= A.nblocks * (int64_t)(kRB * 8)) variant &= ~4;
+    switch (variant) {
       QP_RB_CASE(0)
       QP_RB_CASE(1)
       QP_RB_CASE(2)

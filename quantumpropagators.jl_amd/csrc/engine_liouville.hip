@@ -287,7 +287,7 @@ __device__ __forceinline__ double2 ld_off(const double2* base, unsigned off) {
 template <int D>
 __global__ __launch_bounds__(256) void zgemm_sum32_kernel(double2* __restrict__ Y, int n, double2 alpha, double2 beta,
                                                           Gemm32Terms terms, int batched) {
-  __shared__ double red[3][4][2][4][64];   // partial tiles of waves 1..3
+  __shared__ double red[4][4][2][4][64];   // the partial tiles of the four wavefronts (64 KB)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int row0 = blockIdx.x * 32, col0 = blockIdx.y * 32;
@@ -419,44 +419,41 @@ __global__ __launch_bounds__(256) void zgemm_sum32_kernel(double2* __restrict__ 
       mfma(0);
     }
   }
-  // sum the four k-quarters in wave order
-  if (wave > 0) {
+  // sum the four k-quarters in wave order; every wavefront finishes one of the four 16 x 16 tiles (all four partial
+  // tiles of everybody go through LDS, so that no register is indexed by the wave number)
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          red[wave - 1][a * 2 + b][0][r][lane] = cr[a][b][r];
-          red[wave - 1][a * 2 + b][1][r][lane] = ci[a][b][r];
-        }
-  }
+      for (int r = 0; r < 4; ++r) {
+        red[wave][a * 2 + b][0][r][lane] = cr[a][b][r];
+        red[wave][a * 2 + b][1][r][lane] = ci[a][b][r];
+      }
   __syncthreads();
-  if (wave == 0) {
+  {
     const bool bz = (beta.x == 0.0 && beta.y == 0.0) || batched;
+    const int a = wave >> 1, b = wave & 1;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int r = 0; r < 4; ++r) {
+      double sr = red[0][wave][0][r][lane], si = red[0][wave][1][r][lane];
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          double sr = cr[a][b][r], si = ci[a][b][r];
-          for (int w = 0; w < 3; ++w) {
-            sr += red[w][a * 2 + b][0][r][lane];
-            si += red[w][a * 2 + b][1][r][lane];
-          }
-          const int row = row0 + a * 16 + lk + 4 * r, col = col0 + b * 16 + li;
-          if (row < n && col < n) {
-            double vr = alpha.x * sr - alpha.y * si, vi = alpha.x * si + alpha.y * sr;
-            double2* y = Yz + (size_t)col * n + row;
-            if (!bz) {
-              const double2 o = *y;
-              vr += beta.x * o.x - beta.y * o.y;
-              vi += beta.x * o.y + beta.y * o.x;
-            }
-            *y = make_double2(vr, vi);
-          }
+      for (int w = 1; w < 4; ++w) {
+        sr += red[w][wave][0][r][lane];
+        si += red[w][wave][1][r][lane];
+      }
+      const int row = row0 + a * 16 + lk + 4 * r, col = col0 + b * 16 + li;
+      if (row < n && col < n) {
+        double vr = alpha.x * sr - alpha.y * si, vi = alpha.x * si + alpha.y * sr;
+        double2* y = Yz + (size_t)col * n + row;
+        if (!bz) {
+          const double2 o = *y;
+          vr += beta.x * o.x - beta.y * o.y;
+          vi += beta.x * o.y + beta.y * o.x;
         }
+        *y = make_double2(vr, vi);
+      }
+    }
   }
 }
 

@@ -145,6 +145,7 @@ struct Tuning {
   int rbcsr_variant = 15;     // bit 0 nt matrix loads, bit 1 early row-local loads, bit 2 deeper unroll, bit 3 (Hermitian-packed kernel) all loads of an all-stencil block up front (A/B in profiles/)
   int hrb_lower_last = 0;     // HRB kernel: process the lower (conj-transposed) section after the upper one
   int arnoldi_mode = 1;       // 0 = sequential fused MGS passes, 1 = low-synchronisation MGS
+  int arnoldi_solve = 1;      // 1 = the MGS reduction + solve run in the projection kernel's prologue (3 launches per column), 0 = own launch
   int arnoldi_fold = 1;       // 1 = the norm + scale of an Arnoldi column is folded into the next column's mat-vec (no launch of its own)
   int split_mode = 2;         // boundary -> interior hand-off: 0 = cross-stream events, 1 = in-launch counter, 2 = the counter when at most 256 workgroups poll
   int liouville_tile32_min_n = 260;  // matrix-free Liouvillian: n in [this, liouville_tile32_n] takes the 32 x 32 matrix-core
@@ -274,7 +275,7 @@ int launch_mgs_pass(hipStream_t s, const MgsArgs& a, Stats* st);
 // coefficients, then w -= Q h with |w|^2 partials: three launches
 int launch_mgs_lowsync(hipStream_t s, const double2* Q, int64_t ldq, int j, double2* w, double2* md_partials,
                        double2* G, int ldg, double2* hess_col, double2* reduced, double2* coef, unsigned* ticket,
-                       double2* norm_partials, double dt, int64_t n, Stats* st);
+                       double2* norm_partials, double dt, int64_t n, Stats* st, bool solve_in_update = false);
 // the same in pieces for row-partitioned runs: local sums -> (all-reduce by the caller) ->
 // solve (one workgroup) + update
 int launch_mgs_multidot(hipStream_t s, const double2* Q, int64_t ldq, int j, const double2* w, double2* md_partials,

@@ -123,7 +123,7 @@ int arnoldi_column(qp_operator* op, qp_krylov* q, int j, double dt, double2* hco
     q->gram_rows = j + 1;
     return qp::launch_mgs_lowsync(ctx->stream, q->Q, q->n, j, w, q->md_part, q->gram, q->nvec, hcol,
                                   q->hcoef, q->mgs_coef, q->ticket, q->part + (size_t)((j + 1) & 1) * kRedBlocks, dt,
-                                  q->n, &ctx->stats);
+                                  q->n, &ctx->stats, ctx->tun.arnoldi_solve != 0);
   }
   q->gram_rows = std::min(q->gram_rows, j);
   for (int i = 0; i <= j + 1; ++i) {                                              // :84-87

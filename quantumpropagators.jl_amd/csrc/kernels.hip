@@ -1382,7 +1382,7 @@ int* tuning_field(Tuning& t, const char* key) {
   static const Entry table[] = {
       {"rbcsr_variant", &Tuning::rbcsr_variant}, {"hrb_lower_last", &Tuning::hrb_lower_last},
       {"arnoldi_mode", &Tuning::arnoldi_mode},   {"split_mode", &Tuning::split_mode},
-      {"arnoldi_fold", &Tuning::arnoldi_fold},
+      {"arnoldi_fold", &Tuning::arnoldi_fold},   {"arnoldi_solve", &Tuning::arnoldi_solve},
       {"liouville_fused_n", &Tuning::liouville_fused_n}, {"liouville_tile32_n", &Tuning::liouville_tile32_n}, {"liouville_tile32_min_n", &Tuning::liouville_tile32_min_n}, {"real_vals", &Tuning::real_vals},
       {"stencil", &Tuning::stencil},             {"acc_defer", &Tuning::acc_defer},
       {"cheby_graph", &Tuning::cheby_graph},     {"small_nnz", &Tuning::small_nnz},
@@ -2132,15 +2132,50 @@ __global__ __launch_bounds__(kThreads) void mgs_solve_kernel(int j, const double
 
 // w += sum_i coef_i q_i in MGS order (coef_i = -h_i) and |w|^2 partials; EPL elements per lane and four
 // basis vectors per round in flight; BS threads per workgroup (see multidot_kernel)
-template <int BS, int EPL>
+// SOLVE (one GPU, knob arnoldi_solve): every workgroup first sums the kRedBlocks multidot partials of all 2 (j + 1)
+// values itself -- lane l adds partials l, l + 64, l + 128, l + 192, then the wavefront tree: a fixed order -- and
+// solves for the MGS coefficients, redundantly but without the reduction launch in between; workgroup 0 records the
+// Hessenberg column, every workgroup writes the (identical) new Gram row.
+struct MgsSolveArgs {
+  const double2* partials;
+  double2* G;
+  int ldg;
+  double2* hess_col;
+  double dt;
+};
+
+template <int BS, int EPL, bool SOLVE>
 __global__ __launch_bounds__(BS) void mgs_update_kernel(double2* __restrict__ w, const double2* __restrict__ Q,
                                                         int64_t ldq, int j, const double2* __restrict__ coef,
-                                                        double2* __restrict__ norm_partials, int64_t n) {
-  extern __shared__ double2 sm[];  // [0, j+1): coefficients; [j+1, j+1+BS/64): reduction scratch
+                                                        double2* __restrict__ norm_partials, int64_t n, MgsSolveArgs sv) {
+  extern __shared__ double2 sm[];  // [0, j+1): coefficients; [j+1, j+1+BS/64): reduction scratch; SOLVE: + red | hs | Gt | dummy
   double2* h = sm;
   double2* lds = sm + (j + 1);
-  for (int i = threadIdx.x; i <= j; i += BS) h[i] = coef[i];
-  __syncthreads();
+  if (SOLVE) {
+    static_assert(!SOLVE || (BS == kThreads && kRedBlocks == 256), "four partials per lane");
+    const int nv = 2 * (j + 1);
+    double2* red = lds + BS / 64;
+    double2* hs = red + nv;
+    double2* Gt = hs + (j + 1);
+    double2* dummy = Gt + j * (j + 1) / 2;   // hess column of the workgroups that do not record it
+    const int wv0 = threadIdx.x >> 6, l0 = threadIdx.x & 63;
+    for (int v = wv0; v < nv; v += BS / 64) {
+      const double2* __restrict__ pp = sv.partials + (size_t)v * kRedBlocks + l0;
+      const double2 q0 = pp[0], q1 = pp[64], q2 = pp[128], q3 = pp[192];
+      double2 r = make_double2(((q0.x + q1.x) + q2.x) + q3.x, ((q0.y + q1.y) + q2.y) + q3.y);
+      r.x = wave_sum(r.x);
+      r.y = wave_sum(r.y);
+      if (l0 == 0) red[v] = r;
+    }
+    __syncthreads();
+    mgs_stage_gram(j, red, Gt, sv.G, sv.ldg);
+    __syncthreads();
+    if (threadIdx.x < 64) mgs_solve_wave(j, red, Gt, hs, blockIdx.x == 0 ? sv.hess_col : dummy, h, sv.dt);
+    __syncthreads();
+  } else {
+    for (int i = threadIdx.x; i <= j; i += BS) h[i] = coef[i];
+    __syncthreads();
+  }
   double nrm = 0.0;
   const int64_t stride = (int64_t)kRedBlocks * BS;
   for (int64_t e0 = (int64_t)blockIdx.x * BS + threadIdx.x; e0 < n; e0 += EPL * stride) {
@@ -2210,7 +2245,8 @@ int launch_mgs_multidot(hipStream_t s, const double2* Q, int64_t ldq, int j, con
 static int launch_mgs_update(hipStream_t s, const double2* Q, int64_t ldq, int j, double2* w, const double2* coef,
                              double2* norm_partials, int64_t n, Stats* st) {
   const size_t shmem = sizeof(double2) * (size_t)(j + 1 + kThreads / 64);
-  hipLaunchKernelGGL((mgs_update_kernel<kThreads, 2>), dim3(kRedBlocks), dim3(kThreads), shmem, s, w, Q, ldq, j, coef, norm_partials, n);
+  hipLaunchKernelGGL((mgs_update_kernel<kThreads, 2, false>), dim3(kRedBlocks), dim3(kThreads), shmem, s, w, Q, ldq, j, coef,
+                     norm_partials, n, MgsSolveArgs{});
   QP_HIP(hipGetLastError());
   if (st) st->n_launch++;
   return QP_OK;
@@ -2228,9 +2264,17 @@ int launch_mgs_project(hipStream_t s, const double2* Q, int64_t ldq, int j, doub
 
 int launch_mgs_lowsync(hipStream_t s, const double2* Q, int64_t ldq, int j, double2* w, double2* md_partials,
                        double2* G, int ldg, double2* hess_col, double2* reduced, double2* coef, unsigned* ticket,
-                       double2* norm_partials, double dt, int64_t n, Stats* st) {
+                       double2* norm_partials, double dt, int64_t n, Stats* st, bool solve_in_update) {
   int rc = launch_multidot(s, Q, ldq, j, w, md_partials, n, st);
   if (rc != QP_OK) return rc;
+  if (solve_in_update && mgs_solve_lds(j) <= 12 * 1024) {   // j <= 35: reduction + solve in the projection's prologue
+    const size_t shmem = sizeof(double2) * (size_t)(j + 1 + kThreads / 64 + j + 1) + mgs_solve_lds(j);
+    hipLaunchKernelGGL((mgs_update_kernel<kThreads, 2, true>), dim3(kRedBlocks), dim3(kThreads), shmem, s, w, Q, ldq, j, coef,
+                       norm_partials, n, MgsSolveArgs{md_partials, G, ldg, hess_col, dt});
+    QP_HIP(hipGetLastError());
+    if (st) st->n_launch++;
+    return QP_OK;
+  }
   hipLaunchKernelGGL(multidot_reduce_kernel, dim3(2 * (j + 1)), dim3(kThreads), mgs_solve_lds(j), s, md_partials, j,
                      reduced, ticket, G, ldg, hess_col, coef, dt);
   QP_HIP(hipGetLastError());

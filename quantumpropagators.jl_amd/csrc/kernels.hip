@@ -2159,13 +2159,27 @@ __global__ __launch_bounds__(BS) void mgs_update_kernel(double2* __restrict__ w,
     double2* Gt = hs + (j + 1);
     double2* dummy = Gt + j * (j + 1) / 2;   // hess column of the workgroups that do not record it
     const int wv0 = threadIdx.x >> 6, l0 = threadIdx.x & 63;
-    for (int v = wv0; v < nv; v += BS / 64) {
-      const double2* __restrict__ pp = sv.partials + (size_t)v * kRedBlocks + l0;
-      const double2 q0 = pp[0], q1 = pp[64], q2 = pp[128], q3 = pp[192];
-      double2 r = make_double2(((q0.x + q1.x) + q2.x) + q3.x, ((q0.y + q1.y) + q2.y) + q3.y);
-      r.x = wave_sum(r.x);
-      r.y = wave_sum(r.y);
-      if (l0 == 0) red[v] = r;
+    constexpr int NW = BS / 64, UV = 4;   // UV values (16 loads per lane) in flight per wavefront and round
+    for (int v0 = wv0; v0 < nv; v0 += NW * UV) {
+      double2 q[UV][4];
+#pragma unroll
+      for (int u = 0; u < UV; ++u) {
+        const int v = min(v0 + u * NW, nv - 1);
+        const double2* __restrict__ pp = sv.partials + (size_t)v * kRedBlocks + l0;
+        q[u][0] = pp[0];
+        q[u][1] = pp[64];
+        q[u][2] = pp[128];
+        q[u][3] = pp[192];
+      }
+#pragma unroll
+      for (int u = 0; u < UV; ++u) {
+        const int v = v0 + u * NW;
+        double2 r = make_double2(((q[u][0].x + q[u][1].x) + q[u][2].x) + q[u][3].x,
+                                 ((q[u][0].y + q[u][1].y) + q[u][2].y) + q[u][3].y);
+        r.x = wave_sum(r.x);
+        r.y = wave_sum(r.y);
+        if (l0 == 0 && v < nv) red[v] = r;
+      }
     }
     __syncthreads();
     mgs_stage_gram(j, red, Gt, sv.G, sv.ldg);

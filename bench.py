@@ -28,6 +28,7 @@ import glob
 import json
 import os
 import shutil
+import signal
 import subprocess
 import sys
 import tempfile
@@ -59,9 +60,21 @@ def pmc_traffic(argv_inner, kernel_substr, timeout_s):
         out = tempfile.mkdtemp(prefix="qp_pmc_", dir="/tmp")
         cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--",
                sys.executable, os.path.join(ROOT, "bench.py")] + argv_inner
-        try:
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
-        except (subprocess.TimeoutExpired, OSError) as e:
+        try:   # own process group: a pass that hangs is ended with everything it started (the profiled child too)
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                    start_new_session=True)
+            try:
+                proc.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                proc.wait()
+                shutil.rmtree(out, ignore_errors=True)
+                return None, f"{counter} pass failed: timeout after {timeout_s} s"
+            r = proc
+        except OSError as e:
             shutil.rmtree(out, ignore_errors=True)
             return None, f"{counter} pass failed: {type(e).__name__}"
         got = []

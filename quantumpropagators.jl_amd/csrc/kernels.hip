@@ -723,8 +723,11 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {   // l wave-un
 // Scalar-memory variant (knob spmm_rw = 0): the row's entries are wave-uniform, so they can be fetched by the
 // scalar unit (s_load: value and column straight into SGPRs, which the FMAs and the gather addresses take as
 // operands) instead of one entry per lane + v_readlane broadcasts -- five VALU instructions per entry less.
-template <class Op>
-__global__ __launch_bounds__(kThreads) void spmm_rows_smem_kernel(const int64_t* __restrict__ rowptr,
+// WS wavefronts (consecutive walk positions) per workgroup (knob spmm_wg): 8 measured 282 us per term of config C5
+// against 302 with 4 and 290 with 16; 2-D tiles of walk positions per workgroup instead of runs: no difference
+// (profiles/r02/batched_c5_sweep.txt)
+template <class Op, int WS>
+__global__ __launch_bounds__(64 * WS) void spmm_rows_smem_kernel(const int64_t* __restrict__ rowptr,
                                                                   const int32_t* __restrict__ cols,
                                                                   const double2* __restrict__ vals,
                                                                   const double2* __restrict__ X, int64_t nrows, int b, Op op,
@@ -732,7 +735,7 @@ __global__ __launch_bounds__(kThreads) void spmm_rows_smem_kernel(const int64_t*
   const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  const int64_t pos = (int64_t)wg * (kThreads / 64) + wave;
+  const int64_t pos = (int64_t)wg * WS + wave;
   if (pos >= nrows) return;
   const int64_t row = order ? (int64_t)__builtin_amdgcn_readfirstlane(order[pos]) : pos;
   const int st = blockIdx.y * 64 + lane;
@@ -919,14 +922,21 @@ int launch_spmm_cheby(hipStream_t s, const int64_t* rowptr, const int32_t* cols,
     }                                                                                                            \
   }
     if (tun.spmm_rw == 0) {
-      dim3 grid((unsigned)((nrows + kThreads / 64 - 1) / (kThreads / 64)), (unsigned)((b + 63) / 64));
-      if (nt) {
-        ChebyOpT<true> op{e};
-        hipLaunchKernelGGL((spmm_rows_smem_kernel<ChebyOpT<true>>), grid, dim3(kThreads), 0, s, rowptr, cols, vals, X, nrows, b, op, order);
-      } else {
-        ChebyOp op{e};
-        hipLaunchKernelGGL((spmm_rows_smem_kernel<ChebyOp>), grid, dim3(kThreads), 0, s, rowptr, cols, vals, X, nrows, b, op, order);
-      }
+#define QP_SPMM_SMEM(WS)                                                                                          \
+  {                                                                                                               \
+    dim3 grid((unsigned)((nrows + (WS) - 1) / (WS)), (unsigned)((b + 63) / 64));                                  \
+    if (nt) {                                                                                                     \
+      ChebyOpT<true> op{e};                                                                                       \
+      hipLaunchKernelGGL((spmm_rows_smem_kernel<ChebyOpT<true>, WS>), grid, dim3(64 * (WS)), 0, s, rowptr, cols, vals, X, nrows, b, op, order); \
+    } else {                                                                                                      \
+      ChebyOp op{e};                                                                                              \
+      hipLaunchKernelGGL((spmm_rows_smem_kernel<ChebyOp, WS>), grid, dim3(64 * (WS)), 0, s, rowptr, cols, vals, X, nrows, b, op, order); \
+    }                                                                                                             \
+  }
+      if (tun.spmm_wg == 16) QP_SPMM_SMEM(16)
+      else if (tun.spmm_wg == 8) QP_SPMM_SMEM(8)
+      else QP_SPMM_SMEM(4)
+#undef QP_SPMM_SMEM
     } else
     switch (tun.spmm_rw) {
       case 2: QP_SPMM_ROWS(2) break;
@@ -1382,7 +1392,7 @@ int* tuning_field(Tuning& t, const char* key) {
   static const Entry table[] = {
       {"rbcsr_variant", &Tuning::rbcsr_variant}, {"hrb_lower_last", &Tuning::hrb_lower_last},
       {"arnoldi_mode", &Tuning::arnoldi_mode},   {"split_mode", &Tuning::split_mode},
-      {"arnoldi_fold", &Tuning::arnoldi_fold},   {"arnoldi_solve", &Tuning::arnoldi_solve},
+      {"arnoldi_fold", &Tuning::arnoldi_fold},   {"spmm_wg", &Tuning::spmm_wg},   {"arnoldi_solve", &Tuning::arnoldi_solve},
       {"liouville_fused_n", &Tuning::liouville_fused_n}, {"liouville_tile32_n", &Tuning::liouville_tile32_n}, {"liouville_tile32_min_n", &Tuning::liouville_tile32_min_n}, {"real_vals", &Tuning::real_vals},
       {"stencil", &Tuning::stencil},             {"acc_defer", &Tuning::acc_defer},
       {"cheby_graph", &Tuning::cheby_graph},     {"small_nnz", &Tuning::small_nnz},

@@ -1303,10 +1303,12 @@ def test_cheby_batched_rows_kernel_and_row_walk_bit_identical(ctx, batch):
     states = np.stack([synth.random_state(N, seed=3000 + s) for s in range(batch)], axis=1)
     outs, walks = {}, {}
     try:
-        for rows, strip, rw in ((0, 0, 1), (1, -1, 1), (1, 0, 1), (1, 32, 1), (1, 64, 1), (1, 48, 1), (1, 32, 2), (1, 64, 4), (1, -1, 8), (1, -1, 0), (1, 0, 0), (1, 64, 0)):
+        for rows, strip, rw in ((0, 0, 1), (1, -1, 1), (1, 0, 1), (1, 32, 1), (1, 64, 1), (1, 48, 1), (1, 32, 2), (1, 64, 4), (1, -1, 8), (1, -1, 0), (1, 0, 0), (1, 64, 0),
+                                (1, 0, -4), (1, 64, -16)):
             ctx.tuning_set("spmm_rows", rows)
             ctx.tuning_set("spmm_strip", strip)
-            ctx.tuning_set("spmm_rw", rw)
+            ctx.tuning_set("spmm_rw", max(rw, 0))
+            ctx.tuning_set("spmm_wg", -rw if rw < 0 else 8)      # negative: scalar-entry kernel with that many wavefronts per workgroup
             wrk = L.ChebyWrk(ctx, N * batch, 20.0, -10.0, 0.7)
             panel = L.State(ctx, data=states.reshape(-1))
             for dt in (0.7, -0.7, 0.7):
@@ -1318,6 +1320,7 @@ def test_cheby_batched_rows_kernel_and_row_walk_bit_identical(ctx, batch):
         ctx.tuning_set("spmm_rows", 1)
         ctx.tuning_set("spmm_strip", 0)
         ctx.tuning_set("spmm_rw", 0)
+        ctx.tuning_set("spmm_wg", 8)
     ref = outs[(0, 0, 1)]
     for k, v in outs.items():
         assert np.array_equal(v, ref), k

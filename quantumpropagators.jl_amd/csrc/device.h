@@ -159,6 +159,7 @@ struct Tuning {
   int newton_pipeline = 1;    // newton!: Hessenberg eigenvalues overlap the Arnoldi sweep
   int spmm_tile = 16;         // states per pass of the tiled batched SpMM kernel (16, 32 or 64)
   int spmm_rows = 1;          // batched SpMM: wave-per-row kernel (lane = state) for panels of more than 32 states (0: always the state-tiled kernel)
+  int hrb_wg = 8;             // Hermitian-packed fused term of a whole operator: row blocks per workgroup (8 or 4)
   int spmm_wg = 8;            // batched SpMM, scalar-entry kernel: wavefronts (consecutive walk positions) per workgroup: 4, 8 or 16
   int spmm_rw = 0;            // batched SpMM, wave-per-row kernel: 0 = matrix entries through the scalar unit (one row per wavefront), 1 / 2 / 4 / 8 = entries one per lane + readlane broadcast, that many rows per wavefront
   int spmm_strip = 0;         // batched SpMM row walk: inner-index strip width (0 = chosen from the L2 size; -1 = natural row order)

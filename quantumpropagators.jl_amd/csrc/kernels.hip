@@ -331,8 +331,8 @@ struct LowerStencilSlot {
 
 // VAR bit 0: nt matrix loads; bit 1: row-local operands prefetched before the loop;
 // bit 2: unroll 4 quads (16 value loads in flight per lane) instead of 2
-template <class Op, int VAR, class VT>
-__global__ __launch_bounds__(kThreads) void rbcsr_spmv_kernel(const int64_t* __restrict__ bptr,
+template <class Op, int VAR, class VT, int WS = kThreads / 64>   // WS wavefronts (row blocks) per workgroup
+__global__ __launch_bounds__(64 * WS) void rbcsr_spmv_kernel(const int64_t* __restrict__ bptr,
                                                               const int64_t* __restrict__ cmeta,
                                                               const char* __restrict__ colbytes,
                                                               const VT* __restrict__ vals,
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(kThreads) void rbcsr_spmv_kernel(const int64_t* __r
   op.begin_issue();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  const int64_t idx = (int64_t)wg * (kThreads / 64) + wave;  // position in the row set
+  const int64_t idx = (int64_t)wg * WS + wave;  // position in the row set
   double2 chk = make_double2(0.0, 0.0);
   double nrm = 0.0;
   int64_t row = nrows;
@@ -407,8 +407,8 @@ __device__ __forceinline__ double2 ld_tr(const VT* __restrict__ vals, int pos) {
   return pos < 0 ? make_double2(0.0, 0.0) : a;
 }
 
-template <class Op, int VAR, class VT>
-__global__ __launch_bounds__(kThreads) void hrb_spmv_kernel(const int64_t* __restrict__ uptr,
+template <class Op, int VAR, class VT, int WS = kThreads / 64>   // WS wavefronts (row blocks) per workgroup
+__global__ __launch_bounds__(64 * WS) void hrb_spmv_kernel(const int64_t* __restrict__ uptr,
                                                             const int64_t* __restrict__ ucmeta,
                                                             const char* __restrict__ ucolbytes,
                                                             const VT* __restrict__ uvals,
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(kThreads) void hrb_spmv_kernel(const int64_t* __res
   op.begin_issue();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  const int64_t idx = (int64_t)wg * (kThreads / 64) + wave;  // position in the row set
+  const int64_t idx = (int64_t)wg * WS + wave;  // position in the row set
   double2 chk = make_double2(0.0, 0.0);
   double nrm = 0.0;
   int64_t row = nrows;
@@ -1392,7 +1392,7 @@ int* tuning_field(Tuning& t, const char* key) {
   static const Entry table[] = {
       {"rbcsr_variant", &Tuning::rbcsr_variant}, {"hrb_lower_last", &Tuning::hrb_lower_last},
       {"arnoldi_mode", &Tuning::arnoldi_mode},   {"split_mode", &Tuning::split_mode},
-      {"arnoldi_fold", &Tuning::arnoldi_fold},   {"spmm_wg", &Tuning::spmm_wg},   {"arnoldi_solve", &Tuning::arnoldi_solve},
+      {"arnoldi_fold", &Tuning::arnoldi_fold},   {"spmm_wg", &Tuning::spmm_wg},   {"hrb_wg", &Tuning::hrb_wg},   {"arnoldi_solve", &Tuning::arnoldi_solve},
       {"liouville_fused_n", &Tuning::liouville_fused_n}, {"liouville_tile32_n", &Tuning::liouville_tile32_n}, {"liouville_tile32_min_n", &Tuning::liouville_tile32_min_n}, {"real_vals", &Tuning::real_vals},
       {"stencil", &Tuning::stencil},             {"acc_defer", &Tuning::acc_defer},
       {"cheby_graph", &Tuning::cheby_graph},     {"small_nnz", &Tuning::small_nnz},
@@ -1499,6 +1499,24 @@ static int launch_spmv(hipStream_t s, const DevMatrix& A, const double2* x, cons
       hipLaunchKernelGGL((rbcsr_spmv_kernel<Op, VV, double2>), dim3(grid), dim3(kThreads), 0, s, A.bptr, A.cmeta, \
                          reinterpret_cast<const char*>(A.cols), A.vals, x, nblk, A.nrows, op, bmap, sy);   \
     break;
+    if constexpr (std::is_same<Op, ChebyOp>::value) {
+      // as for the Hermitian-packed kernel below: eight row blocks per workgroup for the plain fused term of a whole operator
+      if (tun.hrb_wg == 8 && !rs && !op.e.check_partials && (tun.rbcsr_variant & 7) == 7 && A.stored > A.nblocks * (int64_t)(kRB * 8)) {
+        const int g8 = (int)((nblk + 7) / 8);
+        if (A.vals_r)
+          hipLaunchKernelGGL((rbcsr_spmv_kernel<Op, 7, double, 8>), dim3(g8), dim3(512), 0, s, A.bptr, A.cmeta,
+                             reinterpret_cast<const char*>(A.cols), A.vals_r, x, nblk, A.nrows, op, bmap, sy);
+        else
+          hipLaunchKernelGGL((rbcsr_spmv_kernel<Op, 7, double2, 8>), dim3(g8), dim3(512), 0, s, A.bptr, A.cmeta,
+                             reinterpret_cast<const char*>(A.cols), A.vals, x, nblk, A.nrows, op, bmap, sy);
+        QP_HIP(hipGetLastError());
+        if (st) {
+          st->n_launch++;
+          st->n_matvec++;
+        }
+        return QP_OK;
+      }
+    }
     // the deeper unroll (bit 2: 156-160 VGPRs, 3 wavefronts per SIMD) pays from three quads per row on; blocks of
     // at most two quads (8 entries per row: the Liouvillian of config C3) take the shallow one (88 VGPRs, 5 per
     // SIMD) -- at N = 2^18 that is one round of wavefronts instead of one and a third.  Same sums either way.
@@ -1529,6 +1547,31 @@ static int launch_spmv(hipStream_t s, const DevMatrix& A, const double2* x, cons
                          reinterpret_cast<const char*>(A.lcols), reinterpret_cast<const int4*>(A.lpos), x, \
                          nblk, A.nrows, op, bmap, sy, tun.hrb_lower_last);                                 \
     break;
+    if constexpr (std::is_same<Op, ChebyOp>::value) {
+      // The plain fused term of a whole operator (no row set, no normalisation check: the headline path) takes eight
+      // row blocks per workgroup instead of four (knob hrb_wg): half as many workgroups to dispatch, 36.3 -> 35.2 us per
+      // term at N = 2^20 (profiles/r02/kbench_banded.txt); the same sums.  Everything that counts workgroups (row
+      // sets of the multi-GPU split, the per-workgroup check partials) stays on four.
+      if (tun.hrb_wg == 8 && !rs && !op.e.check_partials && (tun.rbcsr_variant & 31) == 15) {
+        const int g8 = (int)((nblk + 7) / 8);
+        if (A.vals_r)
+          hipLaunchKernelGGL((hrb_spmv_kernel<Op, 15, double, 8>), dim3(g8), dim3(512), 0, s, A.bptr, A.cmeta,
+                             reinterpret_cast<const char*>(A.cols), A.vals_r, A.lptr, A.lcmeta,
+                             reinterpret_cast<const char*>(A.lcols), reinterpret_cast<const int4*>(A.lpos), x, nblk, A.nrows, op,
+                             bmap, sy, tun.hrb_lower_last);
+        else
+          hipLaunchKernelGGL((hrb_spmv_kernel<Op, 15, double2, 8>), dim3(g8), dim3(512), 0, s, A.bptr, A.cmeta,
+                             reinterpret_cast<const char*>(A.cols), A.vals, A.lptr, A.lcmeta,
+                             reinterpret_cast<const char*>(A.lcols), reinterpret_cast<const int4*>(A.lpos), x, nblk, A.nrows, op,
+                             bmap, sy, tun.hrb_lower_last);
+        QP_HIP(hipGetLastError());
+        if (st) {
+          st->n_launch++;
+          st->n_matvec++;
+        }
+        return QP_OK;
+      }
+    }
     switch (tun.rbcsr_variant & 31) {
       QP_HRB_CASE(0)
       QP_HRB_CASE(1)

@@ -629,8 +629,9 @@ def test_full_size_properties(ctx):
 def test_hrb_kernel_variants_bit_identical(ctx):
     """Knob rbcsr_variant of the Hermitian-packed kernel: nontemporal index loads, early row-local loads, unroll
     depth and (bit 3, the default) the straight-line path that issues all 32 loads of an all-stencil block before
-    the first FMA change the schedule of the loads only -- every variant gives the same bits."""
-    N = 1 << 15
+    the first FMA change the schedule of the loads only, knob hrb_wg (8 or 4 row blocks per workgroup) the
+    placement -- every variant gives the same bits.  N is not a multiple of 8 x 64 rows: a partly filled workgroup."""
+    N = (1 << 15) + 192
     rp, col, vals = synth.hermitian_offsets_csr(N)        # lattice: stencil blocks except at the wrap-around
     Op = L.Operator(ctx, [L.Matrix(ctx, N, N, rp, col, vals)], 0, L.FMT_HRB)
     lay = Op.layout_info()
@@ -639,8 +640,9 @@ def test_hrb_kernel_variants_bit_identical(ctx):
     wrk = L.ChebyWrk(ctx, N, 20.0, -10.0, 1.0)
     outs = {}
     try:
-        for v in (15, 31, 7, 3, 0, 8):
-            ctx.tuning_set("rbcsr_variant", v)
+        for v in (15, 31, 7, 3, 0, 8, "15 with 4 row blocks per workgroup"):
+            ctx.tuning_set("rbcsr_variant", v if isinstance(v, int) else 15)
+            ctx.tuning_set("hrb_wg", 8 if isinstance(v, int) else 4)      # 8 (default) applies to variant 15 only
             psi = L.State(ctx, data=psi0)
             L.cheby(psi, Op, 1.0, wrk)
             L.cheby(psi, Op, -1.0, wrk)
@@ -648,6 +650,7 @@ def test_hrb_kernel_variants_bit_identical(ctx):
             outs[v] = psi.numpy()
     finally:
         ctx.tuning_set("rbcsr_variant", 15)
+        ctx.tuning_set("hrb_wg", 8)
     assert all(np.array_equal(outs[15], o) for o in outs.values())
     H = synth.to_scipy(rp, col, vals, N)
     ref = qo.cheby(psi0.copy(), H, 1.0, qo.ChebyWrk(psi0, 20.0, -10.0, 1.0))

@@ -1482,6 +1482,16 @@ static int launch_spmv(hipStream_t s, const DevMatrix& A, const double2* x, cons
   const SyncArgs sy = rs ? rs->sync : SyncArgs();
   static const Tuning kDefaults;
   const Tuning& tun = A.tun ? *A.tun : kDefaults;
+  // Eight instead of four row blocks per workgroup (knob hrb_wg) for the fused Chebyshev term wherever nothing counts
+  // workgroups of four: not with the per-workgroup check partials, and of the two launches of a split term only for the
+  // interior one (no completion signal, no mirror map; its wait threshold, given in workgroups of four, is halved and
+  // rounded down: the workgroup that straddles the threshold waits as well)
+  bool wide_ok = false;
+  SyncArgs sy8 = sy;
+  if constexpr (std::is_same<Op, ChebyOp>::value) {
+    wide_ok = !op.e.check_partials && (!rs || (!rs->sync.signal && !op.e.mirror));
+    sy8.wait_from_wg = sy.wait_from_wg / 2;
+  }
   if (rs && rs->block_map) {
     if (A.format != QP_FMT_RBCSR && A.format != QP_FMT_HRB) return fail(QP_E_BAD_ARG, "row sets need a row-block format");
     bmap = rs->block_map;
@@ -1501,18 +1511,18 @@ static int launch_spmv(hipStream_t s, const DevMatrix& A, const double2* x, cons
     break;
     if constexpr (std::is_same<Op, ChebyOp>::value) {
       // as for the Hermitian-packed kernel below: eight row blocks per workgroup for the plain fused term of a whole operator
-      if (tun.hrb_wg == 8 && !rs && !op.e.check_partials && (tun.rbcsr_variant & 7) == 7 && A.stored > A.nblocks * (int64_t)(kRB * 8)) {
+      if (tun.hrb_wg == 8 && wide_ok && (tun.rbcsr_variant & 7) == 7 && A.stored > A.nblocks * (int64_t)(kRB * 8)) {
         const int g8 = (int)((nblk + 7) / 8);
         if (A.vals_r)
           hipLaunchKernelGGL((rbcsr_spmv_kernel<Op, 7, double, 8>), dim3(g8), dim3(512), 0, s, A.bptr, A.cmeta,
-                             reinterpret_cast<const char*>(A.cols), A.vals_r, x, nblk, A.nrows, op, bmap, sy);
+                             reinterpret_cast<const char*>(A.cols), A.vals_r, x, nblk, A.nrows, op, bmap, sy8);
         else
           hipLaunchKernelGGL((rbcsr_spmv_kernel<Op, 7, double2, 8>), dim3(g8), dim3(512), 0, s, A.bptr, A.cmeta,
-                             reinterpret_cast<const char*>(A.cols), A.vals, x, nblk, A.nrows, op, bmap, sy);
+                             reinterpret_cast<const char*>(A.cols), A.vals, x, nblk, A.nrows, op, bmap, sy8);
         QP_HIP(hipGetLastError());
         if (st) {
           st->n_launch++;
-          st->n_matvec++;
+          if (!rs || rs->count) st->n_matvec++;
         }
         return QP_OK;
       }
@@ -1548,26 +1558,24 @@ static int launch_spmv(hipStream_t s, const DevMatrix& A, const double2* x, cons
                          nblk, A.nrows, op, bmap, sy, tun.hrb_lower_last);                                 \
     break;
     if constexpr (std::is_same<Op, ChebyOp>::value) {
-      // The plain fused term of a whole operator (no row set, no normalisation check: the headline path) takes eight
-      // row blocks per workgroup instead of four (knob hrb_wg): half as many workgroups to dispatch, 36.3 -> 35.2 us per
-      // term at N = 2^20 (profiles/r02/kbench_banded.txt); the same sums.  Everything that counts workgroups (row
-      // sets of the multi-GPU split, the per-workgroup check partials) stays on four.
-      if (tun.hrb_wg == 8 && !rs && !op.e.check_partials && (tun.rbcsr_variant & 31) == 15) {
+      // eight row blocks per workgroup instead of four (see wide_ok above): half as many workgroups to dispatch, 36.3 ->
+      // 35.2 us per term at N = 2^20 (profiles/r02/kbench_banded.txt); the same sums
+      if (tun.hrb_wg == 8 && wide_ok && (tun.rbcsr_variant & 31) == 15) {
         const int g8 = (int)((nblk + 7) / 8);
         if (A.vals_r)
           hipLaunchKernelGGL((hrb_spmv_kernel<Op, 15, double, 8>), dim3(g8), dim3(512), 0, s, A.bptr, A.cmeta,
                              reinterpret_cast<const char*>(A.cols), A.vals_r, A.lptr, A.lcmeta,
                              reinterpret_cast<const char*>(A.lcols), reinterpret_cast<const int4*>(A.lpos), x, nblk, A.nrows, op,
-                             bmap, sy, tun.hrb_lower_last);
+                             bmap, sy8, tun.hrb_lower_last);
         else
           hipLaunchKernelGGL((hrb_spmv_kernel<Op, 15, double2, 8>), dim3(g8), dim3(512), 0, s, A.bptr, A.cmeta,
                              reinterpret_cast<const char*>(A.cols), A.vals, A.lptr, A.lcmeta,
                              reinterpret_cast<const char*>(A.lcols), reinterpret_cast<const int4*>(A.lpos), x, nblk, A.nrows, op,
-                             bmap, sy, tun.hrb_lower_last);
+                             bmap, sy8, tun.hrb_lower_last);
         QP_HIP(hipGetLastError());
         if (st) {
           st->n_launch++;
-          st->n_matvec++;
+          if (!rs || rs->count) st->n_matvec++;
         }
         return QP_OK;
       }

@@ -162,6 +162,16 @@ int qp_operator_info(const qp_operator* op, int64_t* nrows, int64_t* ncols, int6
  * out[3] = bytes of index data a mat-vec streams (column sections + transpose positions
  * of the non-stencil lower sections), out[4] = stored values. */
 int qp_operator_layout_info(const qp_operator* op, int64_t out[5]);
+/* What laying the operator out on the device cost (host work: format choice, encoding, upload): out[0] = ms of the
+ * latest build, out[1] = ms of all builds, out[2] = re-layouts after creation -- evaluate! (src/generators.jl:757-766)
+ * only rewrites coefficients, but a complex coefficient on a Hermitian-packed operator forces ONE rebuild as plain
+ * row blocks (a slower mat-vec from then on) --, out[3] = the current device format (QP_FMT_*). */
+int qp_operator_build_info(const qp_operator* op, double out[4]);
+/* Strip-walk plan of a Hermitian-packed lattice operator (the fused Chebyshev term then walks down strip columns and
+ * keeps the re-read data in registers / LDS): out[0] = 1 if the operator has one, out[1] = near distances, out[2] = far
+ * reach K (far distances m g, m = 1..K), out[3] = 1 if the stencil has a diagonal, out[4] = row blocks per strip step
+ * (g / 64), out[5], out[6] = the walkable row blocks [W0, R1), out[7] = row blocks on the per-block path. */
+int qp_operator_walk_info(const qp_operator* op, int64_t out[8]);
 /* How qp_cheby_step_batched will visit the rows for a panel of `batch` states (wave-per-row kernel,
  * more than 32 states): out[0] = inner dimension g detected in the pattern (far offsets are multiples of
  * g: H = H_a (x) 1 + 1 (x) H_c), out[1] = strip width (rows are visited strip by strip so that the gather

@@ -54,12 +54,40 @@ struct DevMatrix {
   int64_t lcolbytes = 0;
   int32_t* lpos = nullptr;    // lstored, quad packed; -1 = padding
   int64_t lstored = 0;
+  // HRB strip walk (kernels_walk.hip): valid when the operator is a lattice whose row blocks repeat one stencil
+  const struct WalkPlan* walk = nullptr;
   // QP_FMT_MATFREE: no stored entries; y = beta y + alpha A x is delegated to the owner
   // (engine_liouville.hip), and the Chebyshev term runs it followed by an unfused epilogue
   void* matfree = nullptr;
   int (*matfree_apply)(hipStream_t s, void* self, const double2* x, double2* y, double2 alpha, double2 beta,
                        Stats* st) = nullptr;
   double2* (*matfree_scratch)(void* self) = nullptr;   // n entries of workspace for the Chebyshev term
+};
+
+// ---- strip walk over a lattice operator (Hermitian-packed format) -----------------------------------------------
+// A run of row blocks [R0, R1) that all carry the same stencil: upper section
+//   [z0 slots at distance 0 (the diagonal)] [nn near distances 0 < d_1 < ... < d_nn <= 16] [K far distances m g, m = 1..K]
+//   [pads], lower section its mirror image [-K g ... -g] [-d_nn ... -d_1], g = 64 S rows.  Inside the run the position of
+// every value is a formula (U0 + (b - R0) ustride + 64 slot + lane), and a wavefront that WALKS down one strip column --
+// row blocks b, b + S, b + 2 S, ... -- finds everything a block needs beyond its own streams in what it loaded for the
+// blocks before: the gathered elements x[r + m g] are the row-local elements of the blocks m steps ahead / behind (a ring
+// of 2 K + 1 registers, one new load per step), the conj-transposed values of the far lower entries are the far upper
+// values it streamed m steps ago (a register FIFO), the near gathers and the near conj-transposed values are lane shifts
+// of the block's own element / values, staged through a per-wavefront LDS window with a halo of the neighbouring block.
+// Blocks outside [W0, R1) (W0 = R0 + K S: the first blocks whose history lies inside the run; the periodic wrap-around,
+// a ragged end) are listed in edge_map and take the per-block code path in the same launch.
+constexpr int kWalkMaxNear = 8;
+constexpr int kWalkHalo = 16;      // largest near distance
+struct WalkPlan {
+  int valid = 0;
+  int nn = 0, K = 0, z0 = 0;  // shape of the stencil (see above)
+  int S = 0;                  // row blocks per strip step
+  int near[kWalkMaxNear] = {0};
+  int64_t R0 = 0, R1 = 0, W0 = 0;
+  int64_t U0 = 0;             // bptr[R0]
+  int ustride = 0;            // stored upper values per row block (64 x padded width)
+  int32_t* edge_map = nullptr;   // device: the blocks outside [W0, R1)
+  int64_t n_edge = 0;
 };
 
 // epilogue of the fused Chebyshev term (see qp_cheby_term in qprop.h)
@@ -137,6 +165,11 @@ struct Stats {
 int launch_spmv_cheby(hipStream_t s, const DevMatrix& A, const double2* x, const ChebyEpi& e, Stats* st,
                       const RowSet* rs = nullptr);
 int launch_spmv_plain(hipStream_t s, const DevMatrix& A, const double2* x, const PlainEpi& e, Stats* st);
+// the strip walk for the fused Chebyshev term of a whole Hermitian-packed lattice operator; *launched = false when the
+// plan's shape has no kernel instance (the caller then takes the per-block kernel)
+bool walk_shape_supported(int nn, int K, int z0);   // is there a kernel instance for this stencil shape?
+int launch_hrb_walk_cheby(hipStream_t s, const DevMatrix& A, const double2* x, const ChebyEpi& e, const Tuning& tun,
+                          bool* launched);
 int spmv_grid_size(const DevMatrix& A);
 // Developer knobs for A/B measurements.  Every context carries its own copy (qp_ctx::tun, set with
 // qp_ctx_tuning_set); qp_tuning_set only changes the defaults that contexts created afterwards start
@@ -163,6 +196,9 @@ struct Tuning {
   int spmm_wg = 8;            // batched SpMM, scalar-entry kernel: wavefronts (consecutive walk positions) per workgroup: 4, 8 or 16
   int spmm_rw = 0;            // batched SpMM, wave-per-row kernel: 0 = matrix entries through the scalar unit (one row per wavefront), 1 / 2 / 4 / 8 = entries one per lane + readlane broadcast, that many rows per wavefront
   int spmm_strip = 0;         // batched SpMM row walk: inner-index strip width (0 = chosen from the L2 size; -1 = natural row order)
+  int hrb_walk = 1;           // Hermitian-packed fused term of a whole lattice operator: the strip-walk kernel (kernels_walk.hip) when the operator has a walk plan
+  int walk_waves = 2048;      // strip walk: wavefronts the walk is cut into (2 per SIMD x 4 SIMDs x 256 CUs: all resident at once)
+  int walk_min_blocks = 2048; // strip walk: smallest number of walkable row blocks for which the plan is used
   int spmm_nt = 1;            // nontemporal matrix / row-local streams in the batched SpMM kernel: 0 never, 2 always, 1 for large panels
 };
 // address of the knob called `key` inside `t`, or nullptr

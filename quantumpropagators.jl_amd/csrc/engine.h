@@ -63,6 +63,9 @@ struct qp_operator {
   qp_ctx* ctx = nullptr;
   DevMatrix A;
   HostLayoutData layout;
+  qp::WalkPlan walk;              // strip-walk plan of a Hermitian-packed lattice operator (A.walk points here when valid)
+  double build_ms = 0, build_ms_total = 0;   // host time of the latest / of all device layout builds
+  int n_builds = 0, n_relayouts = 0;         // re-layouts: builds forced after creation (complex coefficient on a packed operator)
   bool hermitian_planes = false;
   // CSR-ordered mirror of the current values for the batched (SpMM) path, built lazily
   int64_t* m_rowptr = nullptr;

@@ -328,6 +328,9 @@ static int operator_free_device(qp_operator* op) {
   if (op->A.lptr) (void)hipFree(op->A.lptr);
   if (op->A.lcols) (void)hipFree(op->A.lcols);
   if (op->A.lpos) (void)hipFree(op->A.lpos);
+  if (op->walk.edge_map) (void)hipFree(op->walk.edge_map);
+  op->walk = qp::WalkPlan();
+  op->A.walk = nullptr;
   if (op->m_rowptr) (void)hipFree(op->m_rowptr);
   if (op->m_cols) (void)hipFree(op->m_cols);
   if (op->m_map) (void)hipFree(op->m_map);
@@ -537,9 +540,122 @@ static int64_t decode_lower_stencil_pos(const std::vector<char>& bytes, const st
   return ((c >> 6) == e.cb0 ? e.pb0 : e.pb1) + (c & 63);
 }
 
+// Strip-walk plan of a Hermitian-packed lattice operator (device.h: WalkPlan; kernels_walk.hip).  Looks for the longest
+// run of row blocks that carry one and the same stencil in both sections, checks that the stencil has the shape the walk
+// needs and that every position the per-block kernel would read through the lower stencil records is the position the
+// walk computes by formula, and lists the remaining blocks.  Index work only: host, exact.
+static int build_walk_plan(qp_operator* op, const std::vector<char>& cbytes, const std::vector<char>& lbytes) {
+  qp::WalkPlan& P = op->walk;
+  if (P.edge_map) (void)hipFree(P.edge_map);
+  P = qp::WalkPlan();
+  DevMatrix& A = op->A;
+  A.walk = nullptr;
+  const HostLayout& Lh = op->layout;
+  const int64_t nb = A.nblocks;
+  if (A.format != QP_FMT_HRB || nb < 8) return QP_OK;
+  auto width = [&](const std::vector<int64_t>& ptr, int64_t b) { return (ptr[b + 1] - ptr[b]) / kRB; };
+  auto udelta = [&](int64_t b, int64_t k) {
+    int32_t d;
+    std::memcpy(&d, &cbytes[(size_t)(Lh.cmeta[b] >> 2) + (size_t)k * 4], 4);
+    return d;
+  };
+  auto lslot = [&](int64_t b, int64_t k) {
+    LowerStencilSlot e;
+    std::memcpy(&e, &lbytes[(size_t)(Lh.lcmeta[b] >> 2) + (size_t)k * sizeof(LowerStencilSlot)], sizeof(e));
+    return e;
+  };
+  auto same = [&](int64_t b, int64_t r) {   // does block b carry block r's stencil?
+    if ((Lh.cmeta[b] & 3) != kColStencil || (Lh.lcmeta[b] & 3) != kColStencil) return false;
+    const int64_t wu = width(Lh.bptr, r), wl = width(Lh.lptr, r);
+    if (width(Lh.bptr, b) != wu || width(Lh.lptr, b) != wl) return false;
+    for (int64_t k = 0; k < wu; ++k)
+      if (udelta(b, k) != udelta(r, k)) return false;
+    for (int64_t k = 0; k < wl; ++k)
+      if (lslot(b, k).delta != lslot(r, k).delta) return false;
+    return true;
+  };
+  // longest run (a partly filled last block never belongs to it)
+  const int64_t nfull = A.nrows / kRB;
+  int64_t best0 = 0, best1 = 0;
+  for (int64_t b = 0; b < nfull;) {
+    if ((Lh.cmeta[b] & 3) != kColStencil || (Lh.lcmeta[b] & 3) != kColStencil) {
+      ++b;
+      continue;
+    }
+    int64_t e = b + 1;
+    while (e < nfull && same(e, b)) ++e;
+    if (e - b > best1 - best0) best0 = b, best1 = e;
+    b = e;
+  }
+  if (best1 - best0 < 8) return QP_OK;
+  const int64_t R0 = best0, R1 = best1;
+  const int64_t wu = width(Lh.bptr, R0), wl = width(Lh.lptr, R0);
+  if (wl < 4 || wu < wl || wu > 16) return QP_OK;
+  // upper: [z0 x 0] [near 0 < d <= 16 ascending] [far g, 2 g, .., K g] [pads: 0]
+  std::vector<int32_t> ud((size_t)wu), ld((size_t)wl);
+  for (int64_t k = 0; k < wu; ++k) ud[(size_t)k] = udelta(R0, k);
+  for (int64_t k = 0; k < wl; ++k) ld[(size_t)k] = lslot(R0, k).delta;
+  int64_t k = 0;
+  int z0 = 0, nn = 0, K = 0;
+  while (k < wu && ud[(size_t)k] == 0 && k < 1) ++k, ++z0;
+  while (k < wu && ud[(size_t)k] > 0 && ud[(size_t)k] <= qp::kWalkHalo && nn < qp::kWalkMaxNear &&
+         (nn == 0 || ud[(size_t)k] > P.near[nn - 1])) P.near[nn++] = ud[(size_t)k++];
+  if (nn == 0 || k >= wu) return QP_OK;
+  const int64_t g = ud[(size_t)k];
+  if (g < kRB || g % kRB != 0) return QP_OK;
+  while (k < wu && ud[(size_t)k] == (int64_t)(K + 1) * g) ++k, ++K;
+  for (int64_t q = k; q < wu; ++q)
+    if (ud[(size_t)q] != 0) return QP_OK;          // what is left must be padding
+  if (K < 1 || nn + K != wl || !qp::walk_shape_supported(nn, K, z0)) return QP_OK;
+  // lower: the mirror image [-K g .. -g] [-d_nn .. -d_1]
+  for (int m = K; m >= 1; --m)
+    if (ld[(size_t)(K - m)] != -(int64_t)m * g) return QP_OK;
+  for (int i = 0; i < nn; ++i)
+    if (ld[(size_t)(K + i)] != -P.near[nn - 1 - i]) return QP_OK;
+  const int S = (int)(g / kRB);
+  const int64_t W0 = R0 + (int64_t)K * S;
+  if (R1 - W0 < 8) return QP_OK;
+  // positions: block b's upper values at U0 + (b - R0) ustride (contiguous blocks of equal width: true by
+  // construction, checked anyway), and every lower record of a walkable block must point where the walk will look
+  const int64_t U0 = Lh.bptr[R0], ustride = wu * kRB;
+  for (int64_t b = R0; b <= R1; ++b)
+    if (Lh.bptr[b] != U0 + (b - R0) * ustride) return QP_OK;
+  if (U0 + (R1 - R0) * ustride >= (int64_t)INT32_MAX) return QP_OK;
+  for (int64_t b = W0; b < R1; ++b) {
+    for (int64_t q = 0; q < wl; ++q) {
+      const LowerStencilSlot e = lslot(b, q);
+      int64_t uslot;     // the upper slot that holds the transposed entries of this lower slot
+      if (q < K) uslot = z0 + nn + (K - q) - 1;
+      else uslot = z0 + (nn - 1 - (q - K));
+      const int64_t c0 = b * kRB + e.delta;          // column of the block's first row
+      const int64_t cb0 = c0 >> 6;
+      if (cb0 < R0 || e.cb0 != cb0 || e.pb0 != U0 + (cb0 - R0) * ustride + uslot * kRB) return QP_OK;
+      if ((c0 & 63) != 0 && e.pb1 != U0 + (cb0 + 1 - R0) * ustride + uslot * kRB) return QP_OK;
+    }
+  }
+  std::vector<int32_t> edge;
+  for (int64_t b = 0; b < W0; ++b) edge.push_back((int32_t)b);
+  for (int64_t b = R1; b < nb; ++b) edge.push_back((int32_t)b);
+  P.nn = nn;
+  P.K = K;
+  P.z0 = z0;
+  P.S = S;
+  P.R0 = R0;
+  P.R1 = R1;
+  P.W0 = W0;
+  P.U0 = U0;
+  P.ustride = (int)ustride;
+  P.n_edge = (int64_t)edge.size();
+  QP_CHECK(dev_alloc(&P.edge_map, std::max<size_t>(edge.size(), 1)));
+  if (!edge.empty()) QP_HIP(hipMemcpy(P.edge_map, edge.data(), edge.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  P.valid = 1;
+  A.walk = &P;
+  return QP_OK;
+}
+
 // Build every device array of `op` for `format` from the union pattern (op->u_rowptr /
 // u_col) and the per-term values given in union-CSR order.
-static int operator_build_device(qp_operator* op, int format, const std::vector<std::vector<cplx>>& planes_csr) {
+static int operator_build_device_impl(qp_operator* op, int format, const std::vector<std::vector<cplx>>& planes_csr) {
   qp_ctx* ctx = op->ctx;
   const auto& ur = op->u_rowptr;
   const auto& uc = op->u_col;
@@ -593,8 +709,8 @@ static int operator_build_device(qp_operator* op, int format, const std::vector<
     A.stored = Lh.stored;
     A.lstored = Lh.lstored;
     // upper (or full) column indices
+    std::vector<char> cbytes;
     {
-      std::vector<char> cbytes;
       auto get_upper = [&](int64_t r, int64_t k, bool* pad) -> int64_t {
         const int64_t nl = hrb ? Lh.nlow[r] : 0;
         const int64_t len = ur[r + 1] - ur[r] - nl;
@@ -687,6 +803,7 @@ static int operator_build_device(qp_operator* op, int format, const std::vector<
       QP_HIP(hipMemcpy(A.lcmeta, Lh.lcmeta.data(), Lh.lcmeta.size() * sizeof(int64_t), hipMemcpyHostToDevice));
       QP_CHECK(dev_alloc(&A.lpos, lpos.size()));
       QP_HIP(hipMemcpy(A.lpos, lpos.data(), lpos.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+      QP_CHECK(build_walk_plan(op, cbytes, lbytes));
     }
   }
 
@@ -719,6 +836,17 @@ static int operator_build_device(qp_operator* op, int format, const std::vector<
   A.vals = op->planes[0];
   (void)ctx;
   return QP_OK;
+}
+
+// ... timed: format conversion, encoding and upload are host work at qp_operator_create (and once more if a complex
+// coefficient forces a Hermitian-packed operator back to plain row blocks); qp_operator_build_info reports it
+static int operator_build_device(qp_operator* op, int format, const std::vector<std::vector<cplx>>& planes_csr) {
+  const auto t0 = std::chrono::steady_clock::now();
+  const int rc = operator_build_device_impl(op, format, planes_csr);
+  op->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  op->build_ms_total += op->build_ms;
+  op->n_builds++;
+  return rc;
 }
 
 // current per-term values (device planes) back in union-CSR order
@@ -918,6 +1046,7 @@ static int operator_refresh(qp_operator* op) {
     operator_free_device(op);
     const int fmt = choose_format(op, QP_FMT_AUTO, false);
     QP_CHECK(operator_build_device(op, fmt, planes_csr));
+    op->n_relayouts++;
   }
   // real terms with real coefficients: the mat-vec kernels stream a real copy (8 instead of 16
   // bytes per value); everything else keeps reading the complex array
@@ -991,6 +1120,30 @@ int qp_operator_layout_info(const qp_operator* op, int64_t out[5]) {
     }
   }
   out[3] = idx_bytes;
+  return QP_OK;
+}
+
+int qp_operator_build_info(const qp_operator* op, double out[4]) {
+  if (!op || !out) return qp::fail(QP_E_BAD_ARG, "qp_operator_build_info: NULL argument");
+  out[0] = op->build_ms;
+  out[1] = op->build_ms_total;
+  out[2] = (double)op->n_relayouts;
+  out[3] = (double)op->A.format;
+  return QP_OK;
+}
+
+int qp_operator_walk_info(const qp_operator* op, int64_t out[8]) {
+  if (!op || !out) return qp::fail(QP_E_BAD_ARG, "qp_operator_walk_info: NULL argument");
+  const qp::WalkPlan& P = op->walk;
+  const bool on = P.valid && op->A.walk == &op->walk;
+  out[0] = on ? 1 : 0;
+  out[1] = on ? P.nn : 0;
+  out[2] = on ? P.K : 0;
+  out[3] = on ? P.z0 : 0;
+  out[4] = on ? P.S : 0;
+  out[5] = on ? P.W0 : 0;
+  out[6] = on ? P.R1 : 0;
+  out[7] = on ? P.n_edge : 0;
   return QP_OK;
 }
 

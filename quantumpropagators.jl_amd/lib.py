@@ -123,6 +123,8 @@ SIGNATURES = {
     "qp_operator_info": (C.c_int, [_P, _i64p, _i64p, _i64p, C.POINTER(C.c_int)]),
     "qp_operator_get_csr": (C.c_int, [_P, _i64p, _i32p, _cp]),
     "qp_operator_layout_info": (C.c_int, [_P, _i64p]),
+    "qp_operator_build_info": (C.c_int, [_P, _dp]),
+    "qp_operator_walk_info": (C.c_int, [_P, _i64p]),
     "qp_operator_spmm_walk": (C.c_int, [_P, C.c_int, _i64p]),
     "qp_state_create": (C.c_int, [_P, C.c_int64, C.POINTER(_P)]),
     "qp_state_wrap": (C.c_int, [_P, _P, C.c_int64, C.POINTER(_P)]),
@@ -506,6 +508,20 @@ class Operator:
         out = np.zeros(5, dtype=np.int64)
         check(self.lib.qp_operator_layout_info(self._h, _ptr(out, _i64p)))
         return dict(zip(("blocks", "stencil_upper_blocks", "stencil_lower_blocks", "index_bytes", "stored"),
+                        (int(v) for v in out)))
+
+    def build_info(self):
+        """Host cost of the device layout: ms of the latest build, ms of all builds, re-layouts forced after
+        creation (a complex coefficient on a Hermitian-packed operator), current device format."""
+        out = np.zeros(4, dtype=np.float64)
+        check(self.lib.qp_operator_build_info(self._h, _ptr(out, _dp)))
+        return {"build_ms": float(out[0]), "build_ms_total": float(out[1]), "relayouts": int(out[2]), "format": int(out[3])}
+
+    def walk_info(self):
+        """Strip-walk plan of a Hermitian-packed lattice operator (see include/qprop.h)."""
+        out = np.zeros(8, dtype=np.int64)
+        check(self.lib.qp_operator_walk_info(self._h, _ptr(out, _i64p)))
+        return dict(zip(("valid", "near", "far", "diag", "blocks_per_step", "first_block", "end_block", "edge_blocks"),
                         (int(v) for v in out)))
 
     def spmm_walk(self, batch):

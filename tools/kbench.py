@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--pattern", default="banded")
     ap.add_argument("--formats", default="rbcsr")
     ap.add_argument("--lower-last", type=int, default=0)
+    ap.add_argument("--ab", default="", help="A/B over one knob: key=v1,v2,... (every format / variant case is run with each value)")
     ap.add_argument("--real", action="store_true", help="real symmetric H (values streamed as fp64 instead of complex)")
     args = ap.parse_args()
     N = args.n if args.n else 1 << args.log2n
@@ -49,28 +50,41 @@ def main():
         vs = [int(v) for v in args.variants.split(",")] if f != "csr" else [0]
         for v in vs:
             cases.append((f, v, op))
+    ab_key, ab_vals = None, [None]
+    if args.ab:
+        ab_key, vals_s = args.ab.split("=")
+        ab_vals = [int(t) for t in vals_s.split(",")]
+    cases = [(f, (v, av), op) for f, v, op in cases for av in ab_vals]
+
+    def set_case(v):
+        L.tuning_set("rbcsr_variant", v[0])
+        if ab_key:
+            L.tuning_set(ab_key, v[1])
     psi = L.State(ctx, data=psi0)
     times = {(f, v): [] for f, v, _ in cases}
     for f, v, op in cases:                      # warm-up
-        L.tuning_set("rbcsr_variant", v)
+        set_case(v)
         L.cheby(psi, op, 1.0, wrk)
     ctx.sync()
     for r in range(args.rounds):
         for f, v, op in cases:
-            L.tuning_set("rbcsr_variant", v)
+            set_case(v)
             ctx.timer_begin()
             for _ in range(args.steps):
                 L.cheby(psi, op, 1.0, wrk)
             ms = ctx.timer_end()
             times[(f, v)].append(1e3 * ms / (args.steps * nterms))
     print(f"N={N} pattern={args.pattern} terms/step={nterms} alg_bytes/term={alg:.0f}")
-    print(f"{'format':8s} {'var':>3s} {'median_us':>10s} {'min_us':>8s} {'csr-equiv GB/s':>15s} {'frac8T':>7s} {'layout MB':>10s} {'layout GB/s':>12s} {'frac8T':>7s}  encodings")
+    if ab_key:
+        print(f"A/B knob {ab_key}: second number of 'var'")
+    print(f"{'format':8s} {'var':>8s} {'median_us':>10s} {'min_us':>8s} {'csr-equiv GB/s':>15s} {'frac8T':>7s} {'layout MB':>10s} {'layout GB/s':>12s} {'frac8T':>7s}  encodings")
     ops = {(f, v): op for f, v, op in cases}
     for (f, v), t in times.items():
         med, mn = float(np.median(t)), float(np.min(t))
         by = bp.cheby_layout_bytes(ops[(f, v)], N, N, nnz, wrk.coeffs, real_copy=args.real)
         lay = by["layout"]
-        print(f"{f:8s} {v:3d} {med:10.2f} {mn:8.2f} {alg / med / 1e3:15.0f} {alg / med / 1e3 / 8000:7.3f} {by['per_term'] / 1e6:10.1f} "
+        vs_ = f"{v[0]}" + (f"/{v[1]}" if ab_key else "")
+        print(f"{f:8s} {vs_:>8s} {med:10.2f} {mn:8.2f} {alg / med / 1e3:15.0f} {alg / med / 1e3 / 8000:7.3f} {by['per_term'] / 1e6:10.1f} "
               f"{by['per_term'] / med / 1e3:12.0f} {by['per_term'] / med / 1e3 / 8000:7.3f}  "
               f"blocks {lay['blocks']} stencil upper/lower {lay['stencil_upper_blocks']}/{lay['stencil_lower_blocks']} index bytes {lay['index_bytes']}")
     nrm = psi.norm()

@@ -123,6 +123,11 @@ int qp_ctx_create(int device, void* stream, qp_ctx** out) {
     std::lock_guard<std::mutex> lock(g_tuning_mutex);
     ctx->tun = g_tuning_defaults;
   }
+  {
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) ctx->tun.n_cu = ncu;
+    else (void)hipGetLastError();
+  }
   if (stream == QP_STREAM_NULL) {
     ctx->stream = nullptr;   // HIP's null stream
   } else if (stream) {
@@ -1135,7 +1140,10 @@ int qp_operator_build_info(const qp_operator* op, double out[4]) {
 int qp_operator_walk_info(const qp_operator* op, int64_t out[8]) {
   if (!op || !out) return qp::fail(QP_E_BAD_ARG, "qp_operator_walk_info: NULL argument");
   const qp::WalkPlan& P = op->walk;
-  const bool on = P.valid && op->A.walk == &op->walk;
+  const qp::Tuning& tun = op->ctx->tun;
+  // "has one" = the fused term of a whole-operator cheby! takes the walk under the context's current knobs
+  const bool on = P.valid && op->A.walk == &op->walk && tun.hrb_walk && !tun.hrb_lower_last && (tun.rbcsr_variant & 31) == 15 &&
+                  P.R1 - P.W0 >= tun.walk_min_blocks;
   out[0] = on ? 1 : 0;
   out[1] = on ? P.nn : 0;
   out[2] = on ? P.K : 0;

@@ -35,22 +35,32 @@ struct HrbArrays {   // what the per-block path of the edge blocks reads
 struct WalkGeom {
   int L = 0;           // steps per wavefront
   int nseg = 0;        // segments of L steps per strip column
-  int n_edge_wg = 0;   // leading workgroups: eight edge blocks each, per-block code path
   int n_walk_wg = 0;
+  int ntask = 0;       // wavefronts of the walk (n_walk_wg x kWalkWaves)
+  // Edge blocks (outside the walkable run) are handed out one per wavefront -- edge block i to wavefront i, after its
+  // walk -- and the segments of those wavefronts are `edge_steps` steps shorter, about what a block on the per-block
+  // path costs: every wavefront finishes at about the same time (as workgroups of their own they cost 5-6 us per
+  // launch: whichever compute units ran them started or finished their walk that much later)
+  int edge_segs = 0;   // segments 0 .. edge_segs - 1 are the shorter ones
+  int edge_steps = 0;
+  int edge_last = 0;   // the edge block after the walk instead of before it
+  // ... unless the walk leaves compute units free (an operator that fits the Infinity Cache takes half of them): then the
+  // edge blocks are workgroups of their own at the head of the grid, eight blocks each, and run beside the walk
+  int n_edge_wg = 0;
 };
 
 constexpr int kWalkWaves = 8;   // wavefronts (adjacent strip columns) per workgroup
 
-// one row block by the per-block rules of hrb_spmv_kernel (loop form: same sums as its straight-line form)
+// One row block by the per-block rules of hrb_spmv_kernel (same sums), arranged for LATENCY: a wavefront of the walk
+// takes its edge block alone, so the block is three dependent rounds of loads -- block pointers; column sections,
+// upper values and row-local operands; conj-transposed values and gathers -- and not one round per quad.  Sections of
+// up to three quads each (12 + 12 entries per row: what the wrap-around blocks of a 16-entry lattice have); wider blocks take the loop form below.
 template <class VT>
-__device__ __forceinline__ void hrb_edge_block(const HrbArrays& H, const VT* __restrict__ uvals,
-                                               const double2* __restrict__ x, int64_t b, int lane, int64_t nrows,
-                                               const ChebyOp& op) {
-  const int64_t ubase = H.uptr[b], lbase = H.lptr[b];
-  const int nuq = (int)((H.uptr[b + 1] - ubase) >> 8);
-  const int nlq = (int)((H.lptr[b + 1] - lbase) >> 8);
+__device__ __forceinline__ void hrb_edge_block_loop(const HrbArrays& H, const VT* __restrict__ uvals,
+                                                    const double2* __restrict__ x, int64_t b, int lane, int64_t nrows,
+                                                    const ChebyOp& op, int64_t ubase, int64_t lbase, int nuq, int nlq,
+                                                    int64_t ucm, int64_t lcm) {
   const VT* __restrict__ v = uvals + ubase + lane;
-  const int64_t ucm = H.ucmeta[b], lcm = H.lcmeta[b];
   const int4* __restrict__ lp4 = H.lpos4 + (lbase >> 2) + lane;
   const int64_t row = b * kRB + lane;
   const int64_t rowc = row < nrows ? row : nrows - 1;
@@ -58,50 +68,120 @@ __device__ __forceinline__ void hrb_edge_block(const HrbArrays& H, const VT* __r
   double2 s0 = make_double2(0.0, 0.0), s1 = make_double2(0.0, 0.0);
   if ((lcm & 3) == 2) {
     const LowerStencilSlot* __restrict__ ls = reinterpret_cast<const LowerStencilSlot*>(H.lcolbytes + (lcm >> 2));
-#pragma unroll 2
     for (int k = 0; k < 4 * nlq; k += 2) {
       const LowerStencilSlot e0 = ls[k], e1 = ls[k + 1];
       const int c0 = (int)rowc + e0.delta, c1 = (int)rowc + e1.delta;
       const double2 a0 = ld_val<false>(uvals + (((c0 >> 6) == e0.cb0 ? e0.pb0 : e0.pb1) + (c0 & 63)));
       const double2 a1 = ld_val<false>(uvals + (((c1 >> 6) == e1.cb0 ? e1.pb0 : e1.pb1) + (c1 & 63)));
-      const double2 x0 = x[c0];
-      const double2 x1 = x[c1];
-      cfma_conj(s0, a0, x0);
-      cfma_conj(s1, a1, x1);
+      cfma_conj(s0, a0, x[c0]);
+      cfma_conj(s1, a1, x[c1]);
     }
   } else {
     for (int q = 0; q < nlq; ++q) {
       const int4 c = ld_cols<true>(H.lcolbytes, lcm, q, lane, (int)rowc);
       const int4 p = ld_col<true>(lp4 + (size_t)q * 64);
-      const double2 a0 = ld_tr(uvals, p.x);
-      const double2 a1 = ld_tr(uvals, p.y);
-      const double2 a2 = ld_tr(uvals, p.z);
-      const double2 a3 = ld_tr(uvals, p.w);
-      const double2 x0 = x[c.x];
-      const double2 x1 = x[c.y];
-      const double2 x2 = x[c.z];
-      const double2 x3 = x[c.w];
-      cfma_conj(s0, a0, x0);
-      cfma_conj(s1, a1, x1);
-      cfma_conj(s0, a2, x2);
-      cfma_conj(s1, a3, x3);
+      cfma_conj(s0, ld_tr(uvals, p.x), x[c.x]);
+      cfma_conj(s1, ld_tr(uvals, p.y), x[c.y]);
+      cfma_conj(s0, ld_tr(uvals, p.z), x[c.z]);
+      cfma_conj(s1, ld_tr(uvals, p.w), x[c.w]);
     }
   }
   for (int q = 0; q < nuq; ++q) {
     const int4 c = ld_cols<true>(H.ucolbytes, ucm, q, lane, (int)rowc);
-    const double2 a0 = ld_val<false>(v + (size_t)(4 * q + 0) * 64);
-    const double2 a1 = ld_val<false>(v + (size_t)(4 * q + 1) * 64);
-    const double2 a2 = ld_val<false>(v + (size_t)(4 * q + 2) * 64);
-    const double2 a3 = ld_val<false>(v + (size_t)(4 * q + 3) * 64);
-    const double2 x0 = x[c.x];
-    const double2 x1 = x[c.y];
-    const double2 x2 = x[c.z];
-    const double2 x3 = x[c.w];
-    cfma(s0, a0, x0);
-    cfma(s1, a1, x1);
-    cfma(s0, a2, x2);
-    cfma(s1, a3, x3);
+    cfma(s0, ld_val<false>(v + (size_t)(4 * q + 0) * 64), x[c.x]);
+    cfma(s1, ld_val<false>(v + (size_t)(4 * q + 1) * 64), x[c.y]);
+    cfma(s0, ld_val<false>(v + (size_t)(4 * q + 2) * 64), x[c.z]);
+    cfma(s1, ld_val<false>(v + (size_t)(4 * q + 3) * 64), x[c.w]);
   }
+  double2 chk = make_double2(0.0, 0.0);
+  double nrm = 0.0;
+  if (row < nrows) op.row(row, make_double2(s0.x + s1.x, s0.y + s1.y), pre, chk, nrm, 0);
+}
+
+template <class VT>
+__device__ __forceinline__ void hrb_edge_block(const HrbArrays& H, const VT* __restrict__ uvals,
+                                               const double2* __restrict__ x, int64_t b, int lane, int64_t nrows,
+                                               const ChebyOp& op) {
+  constexpr int MQ = 3;
+  // round 1 (b is wave-uniform: scalar loads)
+  const int64_t ubase = H.uptr[b], lbase = H.lptr[b];
+  const int nuq = (int)((H.uptr[b + 1] - ubase) >> 8);
+  const int nlq = (int)((H.lptr[b + 1] - lbase) >> 8);
+  const int64_t ucm = H.ucmeta[b], lcm = H.lcmeta[b];
+  if (nuq > MQ || nlq > MQ) {
+    hrb_edge_block_loop<VT>(H, uvals, x, b, lane, nrows, op, ubase, lbase, nuq, nlq, ucm, lcm);
+    return;
+  }
+  const VT* __restrict__ v = uvals + ubase + lane;
+  const int4* __restrict__ lp4 = H.lpos4 + (lbase >> 2) + lane;
+  const int64_t row = b * kRB + lane;
+  const int64_t rowc = row < nrows ? row : nrows - 1;
+  // round 2: everything whose address the block pointers give
+  const ChebyOp::Pre pre = op.pre(rowc);
+  const bool lst = (lcm & 3) == 2;
+  const LowerStencilSlot* __restrict__ ls = reinterpret_cast<const LowerStencilSlot*>(H.lcolbytes + (lcm >> 2));
+  int4 uc[MQ], lc[MQ], lp[MQ];
+  double2 ua[4 * MQ];
+#pragma unroll
+  for (int q = 0; q < MQ; ++q) {
+    if (q < nuq) {
+      uc[q] = ld_cols<true>(H.ucolbytes, ucm, q, lane, (int)rowc);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) ua[4 * q + k] = ld_val<false>(v + (size_t)(4 * q + k) * 64);
+    }
+    if (q < nlq) {
+      if (lst) {   // column = row + delta, position of the transposed value = pb(column block) + column % 64
+        const LowerStencilSlot e0 = ls[4 * q], e1 = ls[4 * q + 1], e2 = ls[4 * q + 2], e3 = ls[4 * q + 3];
+        const int c0 = (int)rowc + e0.delta, c1 = (int)rowc + e1.delta, c2 = (int)rowc + e2.delta, c3 = (int)rowc + e3.delta;
+        lc[q] = make_int4(c0, c1, c2, c3);
+        lp[q] = make_int4((int)(((c0 >> 6) == e0.cb0 ? e0.pb0 : e0.pb1) + (c0 & 63)),
+                          (int)(((c1 >> 6) == e1.cb0 ? e1.pb0 : e1.pb1) + (c1 & 63)),
+                          (int)(((c2 >> 6) == e2.cb0 ? e2.pb0 : e2.pb1) + (c2 & 63)),
+                          (int)(((c3 >> 6) == e3.cb0 ? e3.pb0 : e3.pb1) + (c3 & 63)));
+      } else {
+        lc[q] = ld_cols<true>(H.lcolbytes, lcm, q, lane, (int)rowc);
+        lp[q] = ld_col<true>(lp4 + (size_t)q * 64);
+      }
+    }
+  }
+  // round 3: the conj-transposed values and every gathered element
+  double2 la[4 * MQ], lx[4 * MQ], ux[4 * MQ];
+#pragma unroll
+  for (int q = 0; q < MQ; ++q) {
+    if (q < nlq) {
+      la[4 * q + 0] = ld_tr(uvals, lp[q].x);
+      la[4 * q + 1] = ld_tr(uvals, lp[q].y);
+      la[4 * q + 2] = ld_tr(uvals, lp[q].z);
+      la[4 * q + 3] = ld_tr(uvals, lp[q].w);
+      lx[4 * q + 0] = x[lc[q].x];
+      lx[4 * q + 1] = x[lc[q].y];
+      lx[4 * q + 2] = x[lc[q].z];
+      lx[4 * q + 3] = x[lc[q].w];
+    }
+    if (q < nuq) {
+      ux[4 * q + 0] = x[uc[q].x];
+      ux[4 * q + 1] = x[uc[q].y];
+      ux[4 * q + 2] = x[uc[q].z];
+      ux[4 * q + 3] = x[uc[q].w];
+    }
+  }
+  double2 s0 = make_double2(0.0, 0.0), s1 = make_double2(0.0, 0.0);
+#pragma unroll
+  for (int q = 0; q < MQ; ++q)
+    if (q < nlq) {
+      cfma_conj(s0, la[4 * q + 0], lx[4 * q + 0]);
+      cfma_conj(s1, la[4 * q + 1], lx[4 * q + 1]);
+      cfma_conj(s0, la[4 * q + 2], lx[4 * q + 2]);
+      cfma_conj(s1, la[4 * q + 3], lx[4 * q + 3]);
+    }
+#pragma unroll
+  for (int q = 0; q < MQ; ++q)
+    if (q < nuq) {
+      cfma(s0, ua[4 * q + 0], ux[4 * q + 0]);
+      cfma(s1, ua[4 * q + 1], ux[4 * q + 1]);
+      cfma(s0, ua[4 * q + 2], ux[4 * q + 2]);
+      cfma(s1, ua[4 * q + 3], ux[4 * q + 3]);
+    }
   double2 chk = make_double2(0.0, 0.0);
   double nrm = 0.0;
   if (row < nrows) op.row(row, make_double2(s0.x + s1.x, s0.y + s1.y), pre, chk, nrm, 0);
@@ -131,7 +211,8 @@ struct WalkLds {
   static constexpr size_t kBytes = sizeof(double2) * (size_t)kPerWave * kWalkWaves;
 };
 
-template <class VT, int NN, int K, int Z0>
+// NTM: nontemporal accesses (bit 0: the matrix values, bit 1: the vector loads, bit 2: the stores)
+template <class VT, int NN, int K, int Z0, int NTM>
 __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __restrict__ uvals,
                                                                     const double2* __restrict__ x, WalkPlan P,
                                                                     WalkGeom G, HrbArrays H, int64_t nrows, ChebyOp op) {
@@ -146,7 +227,8 @@ __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __r
   const int lane = threadIdx.x & 63;
   if ((int)blockIdx.x < G.n_edge_wg) {
     const int64_t idx = (int64_t)blockIdx.x * kWalkWaves + wave;
-    if (idx < P.n_edge) hrb_edge_block<VT>(H, uvals, x, (int64_t)P.edge_map[idx], lane, nrows, op);
+    if (idx < P.n_edge)
+      hrb_edge_block<VT>(H, uvals, x, (int64_t)__builtin_amdgcn_readfirstlane(P.edge_map[idx]), lane, nrows, op);
     return;
   }
   const unsigned wg = xcd_remap(blockIdx.x - G.n_edge_wg, G.n_walk_wg);
@@ -154,10 +236,14 @@ __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __r
   const int S = P.S;
   const int seg = task / S, col = task - seg * S;
   const int64_t nW = P.R1 - P.W0;
-  if (seg >= G.nseg || col >= nW) return;
-  const int Jc = (int)((nW - col + S - 1) / S);
-  const int j0 = seg * G.L, j1 = min(j0 + G.L, Jc);
-  if (j0 >= j1) return;
+  const int Jc = col < nW ? (int)((nW - col + S - 1) / S) : 0;
+  const int j0 = seg * G.L - min(seg, G.edge_segs) * G.edge_steps;
+  const int j1 = min((seg + 1) * G.L - min(seg + 1, G.edge_segs) * G.edge_steps, Jc);
+  // this wavefront's edge block(s) first: three rounds of latency, about one step of the walk (see WalkGeom)
+  if (!G.edge_last && G.n_edge_wg == 0)
+    for (int64_t idx = task; idx < P.n_edge; idx += G.ntask)
+      hrb_edge_block<VT>(H, uvals, x, (int64_t)__builtin_amdgcn_readfirstlane(P.edge_map[idx]), lane, nrows, op);
+  if (seg < G.nseg && j0 < j1) {
   const int64_t g = (int64_t)kRB * S;
   const int dmax = P.near[NN - 1];
   double2* __restrict__ xwin = walk_lds + (size_t)wave * Lds::kPerWave;
@@ -166,7 +252,7 @@ __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __r
   // No branch inside the walk: a join in the control flow makes the compiler wait for EVERY outstanding load (the
   // prefetch included).  Operands that a term does not have are loaded from a line that stays in the L1 and ignored
   // by the epilogue; halo lanes beyond the halo repeat its last element.
-  ChebyOp opl = op;
+  ChebyOpT<(NTM & 4) != 0> opl{op.e};
   opl.e.mirror = nullptr;           // (the launcher takes this kernel only without them)
   opl.e.check_partials = nullptr;
   const double2* __restrict__ v0p = op.e.v0;
@@ -180,10 +266,10 @@ __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __r
     const int64_t r = blk * kRB + lane;
     const VT* __restrict__ v = uvals + ubase(blk) + lane;
 #pragma unroll
-    for (int u = 0; u < NU; ++u) w.ua[u] = ld_val<false>(v + (size_t)u * 64);
-    w.xnew = x[r + K * g];
-    w.v0 = *(v0p ? v0p + r : x + lane);
-    w.acc = *(accp ? accp + r : x + lane);
+    for (int u = 0; u < NU; ++u) w.ua[u] = ld_val<(NTM & 1) != 0>(v + (size_t)u * 64);
+    w.xnew = ld_stream<(NTM & 2) != 0>(x + r + K * g);
+    w.v0 = ld_stream<(NTM & 2) != 0>(v0p ? v0p + r : x + lane);
+    w.acc = ld_stream<(NTM & 2) != 0>(accp ? accp + r : x + lane);
     w.hx = x[blk * kRB + hoff_x];
     w.ha = ld_val<false>(uvals + ubase(blk - 1) + hoff_a);
   };
@@ -270,7 +356,7 @@ __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __r
       if (u & 1) cfma(s1, cu.ua[u], xv);
       else cfma(s0, cu.ua[u], xv);
     }
-    ChebyOp::Pre pre;
+    typename ChebyOpT<(NTM & 4) != 0>::Pre pre;
     pre.xi = xr[K];
     pre.v0 = v0p ? cu.v0 : make_double2(0.0, 0.0);
     pre.acc = accp ? cu.acc : make_double2(0.0, 0.0);
@@ -302,13 +388,17 @@ __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __r
   } else {
     step(wa, wb, std::false_type());
   }
+  }
+  if (G.edge_last && G.n_edge_wg == 0)
+    for (int64_t idx = task; idx < P.n_edge; idx += G.ntask)
+      hrb_edge_block<VT>(H, uvals, x, (int64_t)__builtin_amdgcn_readfirstlane(P.edge_map[idx]), lane, nrows, op);
 }
 
-template <class VT, int NN, int K, int Z0>
+template <class VT, int NN, int K, int Z0, int NTM = 0>
 static bool launch_instance(hipStream_t s, dim3 grid, const VT* uvals, const double2* x, const WalkPlan& P,
                             const WalkGeom& G, const HrbArrays& H, int64_t nrows, const ChebyOp& op) {
   constexpr size_t lds = WalkLds<NN, K>::kBytes;
-  auto kern = &hrb_walk_kernel<VT, NN, K, Z0>;
+  auto kern = &hrb_walk_kernel<VT, NN, K, Z0, NTM>;
   // more than the 64 KB a launch gets without asking: opt in once per kernel instance (and device)
   static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
@@ -319,17 +409,28 @@ static bool launch_instance(hipStream_t s, dim3 grid, const VT* uvals, const dou
 
 template <class VT>
 static bool launch_shape(hipStream_t s, dim3 grid, const VT* uvals, const double2* x, const WalkPlan& P,
-                         const WalkGeom& G, const HrbArrays& H, int64_t nrows, const ChebyOp& op) {
+                         const WalkGeom& G, const HrbArrays& H, int64_t nrows, const ChebyOp& op, int ntm) {
   const int key = P.nn * 100 + P.K * 10 + P.z0;
+#define QP_WALK_SHAPE(NN_, K_, Z0_)                                                                       \
+  return (ntm & 1) ? launch_instance<VT, NN_, K_, Z0_, 1>(s, grid, uvals, x, P, G, H, nrows, op)            \
+                   : launch_instance<VT, NN_, K_, Z0_, 0>(s, grid, uvals, x, P, G, H, nrows, op);
   switch (key) {
-    case 440: return launch_instance<VT, 4, 4, 0>(s, grid, uvals, x, P, G, H, nrows, op);
-    case 441: return launch_instance<VT, 4, 4, 1>(s, grid, uvals, x, P, G, H, nrows, op);
-    case 220: return launch_instance<VT, 2, 2, 0>(s, grid, uvals, x, P, G, H, nrows, op);
-    case 221: return launch_instance<VT, 2, 2, 1>(s, grid, uvals, x, P, G, H, nrows, op);
-    case 310: return launch_instance<VT, 3, 1, 0>(s, grid, uvals, x, P, G, H, nrows, op);
-    case 130: return launch_instance<VT, 1, 3, 0>(s, grid, uvals, x, P, G, H, nrows, op);
+    case 440:
+      switch (ntm) {   // (measurement variants of the headline shape)
+        case 3: return launch_instance<VT, 4, 4, 0, 3>(s, grid, uvals, x, P, G, H, nrows, op);
+        case 7: return launch_instance<VT, 4, 4, 0, 7>(s, grid, uvals, x, P, G, H, nrows, op);
+        case 5: return launch_instance<VT, 4, 4, 0, 5>(s, grid, uvals, x, P, G, H, nrows, op);
+        default: break;
+      }
+      QP_WALK_SHAPE(4, 4, 0)
+    case 441: QP_WALK_SHAPE(4, 4, 1)
+    case 220: QP_WALK_SHAPE(2, 2, 0)
+    case 221: QP_WALK_SHAPE(2, 2, 1)
+    case 310: QP_WALK_SHAPE(3, 1, 0)
+    case 130: QP_WALK_SHAPE(1, 3, 0)
     default: return false;
   }
+#undef QP_WALK_SHAPE
 }
 
 bool walk_shape_supported(int nn, int K, int z0) {
@@ -346,18 +447,40 @@ int launch_hrb_walk_cheby(hipStream_t s, const DevMatrix& A, const double2* x, c
   if (nW < tun.walk_min_blocks || nW < P->S) return QP_OK;
   WalkGeom G;
   const int64_t J = (nW + P->S - 1) / P->S;                       // steps of the longest strip column
-  const int64_t nseg_target = std::max<int64_t>(1, tun.walk_waves / P->S);
-  G.L = (int)std::max<int64_t>(1, (J + nseg_target - 1) / nseg_target);
-  G.nseg = (int)((J + G.L - 1) / G.L);
+  // wavefronts: all resident at once (2 per SIMD, 2048).  While the operator and the vectors sit in the Infinity Cache
+  // 1280 (160 of the 256 compute units) already draw what it delivers, the set-up of a walk (8 + 10 loads) is paid less
+  // often, and the edge blocks run beside the walk on the free compute units (profiles/r03/kbench_walk.txt)
+  // ... and beyond it the matrix values are streamed nontemporally: they are read once per term, and what the
+  // Infinity Cache then keeps from one term to the next is the vectors
+  const double footprint = (double)A.stored * (A.vals_r ? 8.0 : 16.0) + 64.0 * (double)A.nrows;
+  const bool resident = footprint <= 230e6;
+  const int waves = tun.walk_waves > 0 ? tun.walk_waves : (resident ? 1280 : 2048);
+  const int ntm = tun.walk_nt >= 0 ? tun.walk_nt : (resident ? 0 : 1);
+  const int64_t nseg_target = std::max<int64_t>(1, waves / P->S);
+  const bool no_edges = (tun.walk_dbg & 2) != 0;
+  const int64_t edge_wgs = (P->n_edge + kWalkWaves - 1) / kWalkWaves;
+  // edge blocks as workgroups of their own while every workgroup of the launch still finds a compute unit to itself
+  const bool edge_beside = !no_edges && (tun.walk_dbg & 4) == 0 &&
+                           (nseg_target * P->S + kWalkWaves - 1) / kWalkWaves + edge_wgs <= (int64_t)tun.n_cu;
+  G.n_edge_wg = edge_beside ? (int)edge_wgs : 0;
+  G.edge_steps = (no_edges || edge_beside) ? 0 : std::max(0, tun.walk_edge_steps);
+  G.edge_last = (tun.walk_dbg & 1) ? 1 : 0;
+  G.edge_segs = (no_edges || edge_beside) ? 0 : (int)std::min<int64_t>(nseg_target, (P->n_edge + P->S - 1) / P->S);
+  G.L = (int)std::max<int64_t>(G.edge_steps + 1, (J + (int64_t)G.edge_segs * G.edge_steps + nseg_target - 1) / nseg_target);
+  G.nseg = (int)((J + (int64_t)G.edge_segs * G.edge_steps + G.L - 1) / G.L);
+  while ((int64_t)G.nseg * G.L - (int64_t)std::min(G.edge_segs, G.nseg) * G.edge_steps < J) ++G.nseg;   // (tiny operators)
+  G.edge_segs = std::min(G.edge_segs, G.nseg);
   const int64_t ntask = (int64_t)G.nseg * P->S;
   G.n_walk_wg = (int)((ntask + kWalkWaves - 1) / kWalkWaves);
-  G.n_edge_wg = (int)((P->n_edge + kWalkWaves - 1) / kWalkWaves);
+  G.ntask = G.n_walk_wg * kWalkWaves;
   HrbArrays H{A.bptr, A.cmeta, reinterpret_cast<const char*>(A.cols), A.lptr, A.lcmeta,
               reinterpret_cast<const char*>(A.lcols), reinterpret_cast<const int4*>(A.lpos)};
   ChebyOp op{e};
   const dim3 grid((unsigned)(G.n_edge_wg + G.n_walk_wg));
-  const bool ok = A.vals_r ? launch_shape<double>(s, grid, A.vals_r, x, *P, G, H, A.nrows, op)
-                           : launch_shape<double2>(s, grid, A.vals, x, *P, G, H, A.nrows, op);
+  WalkPlan Pl = *P;
+  if (tun.walk_dbg & 2) Pl.n_edge = 0;   // (measurement only: results are wrong)
+  const bool ok = A.vals_r ? launch_shape<double>(s, grid, A.vals_r, x, Pl, G, H, A.nrows, op, ntm)
+                           : launch_shape<double2>(s, grid, A.vals, x, Pl, G, H, A.nrows, op, ntm);
   if (!ok) return QP_OK;
   QP_HIP(hipGetLastError());
   *launched = true;

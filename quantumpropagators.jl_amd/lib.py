@@ -534,9 +534,11 @@ class Operator:
     def set_coeffs(self, coeffs):
         a, p = _as_c128(np.atleast_1d(coeffs))
         check(self.lib.qp_operator_set_coeffs(self._h, p, len(a)))
+        self._refresh_info()      # (a complex coefficient takes a Hermitian-packed operator back to plain row blocks)
 
     def set_scale(self, s):
         check(self.lib.qp_operator_set_scale(self._h, c128(s)))
+        self._refresh_info()
 
     def get_csr(self):
         if self.format == FMT_MATFREE:

@@ -657,6 +657,113 @@ def test_hrb_kernel_variants_bit_identical(ctx):
     assert np.linalg.norm(outs[15] - ref) < TOL
 
 
+def _with_diagonal(rp, col, vals, N):
+    H = synth.to_scipy(rp, col, vals, N) + sp.diags(np.linspace(-1.0, 1.0, N)).astype(np.complex128)
+    H = sp.csr_matrix(H)
+    H.sort_indices()
+    return H.indptr.astype(np.int64), H.indices.astype(np.int32), H.data.astype(np.complex128)
+
+
+WALK_KNOBS = ("hrb_walk", "walk_waves", "walk_nt", "walk_dbg", "walk_edge_steps", "walk_min_blocks")
+WALK_DEFAULTS = {"hrb_walk": 1, "walk_waves": 0, "walk_nt": -1, "walk_dbg": 0, "walk_edge_steps": 3, "walk_min_blocks": 3072}
+
+
+@pytest.mark.parametrize("N,offsets,diag,real,shape", [
+    ((1 << 15) + 192, synth.BANDED_OFFSETS, False, False, (4, 4, 0)),      # the headline lattice, a partly filled last block
+    (1 << 16, (1, 2, 512, 1024), False, False, (2, 2, 0)),
+    (1 << 15, (1, 3, 7, 256), False, False, (3, 1, 0)),
+    (1 << 15, (2, 128, 256, 384), False, False, (1, 3, 0)),
+    (1 << 16, synth.BANDED_OFFSETS, True, False, (4, 4, 1)),               # with a diagonal: 9 + 3 pad slots in the upper section
+    (1 << 15, (1, 2, 3, 4, 192, 384, 576, 768), False, False, (4, 4, 0)),  # three row blocks per strip step
+    (1 << 15, (1, 2, 512, 1024), True, True, (2, 2, 1)),                   # real couplings: the walk streams the fp64 copy
+], ids=["16nnz", "8nnz", "near3far1", "near1far3", "16nnz+diag", "g192", "real+diag"])
+def test_strip_walk_bit_identical_to_block_kernel(ctx, N, offsets, diag, real, shape):
+    """The strip-walk kernel of a lattice operator (kernels_walk.hip: register ring of the gathered elements, FIFO of the
+    far upper values and near windows in LDS, edge blocks on the per-block path) sums every row in the order of the
+    per-block kernel: bit-identical results for every lattice shape that has a kernel instance, for every partition of
+    the walk (wavefront count), edge-block placement and cache policy -- and within 1e-10 of the oracle."""
+    rp, col, vals = synth.hermitian_offsets_csr(N, offsets=offsets)
+    if real:
+        vals = vals.real.astype(np.complex128)
+    if diag:
+        rp, col, vals = _with_diagonal(rp, col, vals, N)
+    saved = {k: ctx.tuning_get(k) for k in WALK_KNOBS}
+    try:
+        ctx.tuning_set("walk_min_blocks", 16)
+        Op = L.Operator(ctx, [L.Matrix(ctx, N, N, rp, col, vals)], 0, L.FMT_HRB)
+        wi = Op.walk_info()
+        assert wi["valid"] == 1 and (wi["near"], wi["far"], wi["diag"]) == shape
+        assert wi["blocks_per_step"] * 64 == [d for d in offsets if d >= 64][0]
+        assert 0 < wi["edge_blocks"] < 0.6 * Op.layout_info()["blocks"]
+        psi0 = synth.random_state(N)
+        wrk = L.ChebyWrk(ctx, N, 24.0, -12.0, 1.0)
+
+        def run(**knobs):
+            for k, v in {**WALK_DEFAULTS, "walk_min_blocks": 16, **knobs}.items():
+                ctx.tuning_set(k, v)
+            psi = L.State(ctx, data=psi0)
+            L.cheby(psi, Op, 1.0, wrk)
+            L.cheby(psi, Op, -1.0, wrk)
+            L.cheby(psi, Op, 1.0, wrk)
+            return psi.numpy()
+
+        base = run(hrb_walk=0)                                     # the per-block kernel
+        for knobs in (dict(), dict(walk_waves=64), dict(walk_waves=2048), dict(walk_waves=4096),
+                      dict(walk_dbg=4), dict(walk_dbg=5), dict(walk_dbg=4, walk_edge_steps=1, walk_waves=256),
+                      dict(walk_nt=1), dict(walk_nt=0, walk_waves=512)):
+            assert np.array_equal(base, run(**knobs)), knobs
+        if shape == (4, 4, 0):                                     # the measurement variants of the headline shape
+            for nt in (3, 5, 7):
+                assert np.array_equal(base, run(walk_nt=nt)), nt
+    finally:
+        for k, v in saved.items():
+            ctx.tuning_set(k, v)
+    H = synth.to_scipy(rp, col, vals, N)
+    ref = qo.cheby(psi0.copy(), H, 1.0, qo.ChebyWrk(psi0, 24.0, -12.0, 1.0))
+    assert np.linalg.norm(base - ref) < TOL
+
+
+def test_strip_walk_plan_only_for_lattices(ctx):
+    """The walk plan is index work on the host: it exists only where every position it computes by formula is the position
+    the per-block kernel would read -- not for scattered or per-row random columns, not for near distances beyond the LDS
+    halo, far distances that are not multiples of one 64-row-aligned stride, or shapes without a kernel instance -- and it
+    goes away when a complex coefficient forces the operator out of the Hermitian-packed format."""
+    N = 1 << 15
+    saved = ctx.tuning_get("walk_min_blocks")
+    ctx.tuning_set("walk_min_blocks", 16)
+    try:
+        for offsets, want in (((1, 2, 512, 1024), 1), ((1, 2, 500, 1000), 0), ((1, 17, 512, 1024), 0), ((1, 2, 512, 1536), 0),
+                              ((1, 2, 3, 512), 1), ((1, 512, 1024, 1536), 1), ((3, 5, 320, 640), 1), ((1, 2, 3, 4, 5, 6, 512, 1024), 0)):
+            rp, col, vals = synth.hermitian_offsets_csr(N, offsets=offsets)
+            Op = L.Operator(ctx, [L.Matrix(ctx, N, N, rp, col, vals)], 0, L.FMT_HRB)
+            assert Op.walk_info()["valid"] == want, offsets
+            Op.close()
+        rp, col, vals = synth.hermitian_offsets_csr(N, offsets=synth.scattered_offsets(N, 4))
+        assert L.Operator(ctx, [L.Matrix(ctx, N, N, rp, col, vals)], 0, L.FMT_HRB).walk_info()["valid"] == 0
+        rp, col, vals = synth.random_columns_csr(4096, n_pairs=4)
+        assert L.Operator(ctx, [L.Matrix(ctx, 4096, 4096, rp, col, vals)], 0, L.FMT_HRB).walk_info()["valid"] == 0
+        # two Hermitian terms, one coefficient: real -> packed + walk; complex -> plain row blocks, no walk, one re-layout
+        rp, col, vals = synth.hermitian_offsets_csr(N, offsets=(1, 2, 512, 1024))
+        M = L.Matrix(ctx, N, N, rp, col, vals)
+        Op = L.Operator(ctx, [M, M], 1)
+        Op.set_coeffs([0.5])
+        assert Op.format == L.FMT_HRB and Op.walk_info()["valid"] == 1
+        b0 = Op.build_info()
+        assert b0["relayouts"] == 0 and b0["build_ms"] > 0 and b0["format"] == L.FMT_HRB
+        Op.set_coeffs([0.5 + 0.25j])
+        b1 = Op.build_info()
+        assert Op.format == L.FMT_RBCSR and Op.walk_info()["valid"] == 0
+        assert b1["relayouts"] == 1 and b1["build_ms_total"] > b0["build_ms_total"] and b1["format"] == L.FMT_RBCSR
+        psi0 = synth.random_state(N)
+        psi = L.State(ctx, data=psi0)
+        y = L.State(ctx, n=N)
+        Op.mul(psi, y)
+        H = synth.to_scipy(rp, col, vals, N)
+        assert np.linalg.norm(y.numpy() - (1.5 + 0.25j) * (H @ psi0)) < TOL
+    finally:
+        ctx.tuning_set("walk_min_blocks", saved)
+
+
 @pytest.mark.parametrize("window", [None, 1024])
 @pytest.mark.parametrize("fmt", [L.FMT_AUTO, L.FMT_HRB, L.FMT_RBCSR, L.FMT_CSR])
 def test_random_columns_matches_oracle(ctx, window, fmt):

@@ -92,14 +92,88 @@ def pmc_traffic(argv_inner, kernel_substr, timeout_s):
                            "dispatches": [vals["FETCH_SIZE"][1], vals["WRITE_SIZE"][1]]}
 
 
+def run_c5(args, world, rank, local_rank, one_gpu, dist, L, synth, bp):
+    """BASELINE configs[4]: 64 states x N = 2^18 CSR H, Chebyshev on the panel, the batch split over the GPUs --
+    rank r advances states [r b, (r + 1) b), b = 64 / world, with its own copy of H and no communication (SURVEY 8e
+    "Batched").  One step = one prop_step! of the whole 64-state panel; `value` = state-steps per second of the job."""
+    if args.batch % world:
+        raise SystemExit(f"--config c5: {world} ranks do not divide the {args.batch}-state panel")
+    b = args.batch // world
+    log2n = args.log2n if args.log2n is not None else 18
+    N = 1 << log2n
+    import qprop_amd.sharded as sharded
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = L.Context(local_rank, stream=stream)
+    rp, col, vals = synth.hermitian_offsets_csr(N)
+    nnz = int(rp[-1])
+    bs = sharded.BatchSplitCheby(ctx, rp, col, vals, N, args.batch, 20.0, -10.0, args.dt, rank=rank, world=world)
+    bs.set_states(np.stack([synth.random_state(N, seed=500 + s) for s in range(bs.s0, bs.s1)], axis=1))
+    op, wrk = bs.impl.op, bs.impl.wrk
+    nterms = wrk.n_coeffs - 1
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        bs.step()
+    barrier()
+    ctx.timer_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        bs.step()
+    ev_ms = ctx.timer_end()
+    barrier()
+    el = time.perf_counter() - t0
+    norms = np.linalg.norm(bs.local_states(), axis=0)
+    drift = float(np.max(np.abs(norms - 1.0)))
+    if dist is not None:
+        t = torch.tensor([el, ev_ms, drift], dtype=torch.float64, device="cpu" if one_gpu else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el, ev_ms, drift = float(t[0]), float(t[1]), float(t[2])
+    t_term = ev_ms * 1e-3 / (args.steps * nterms)
+    sched = L.acc_schedule(wrk.coeffs)
+    nupd = sum(0 if d.skip else 1 for d in sched)
+    # bytes one GPU must move per fused term: the matrix once (CSR mirror), its share of X, v_{m-2}, v_m, the accumulator
+    lay = 20.0 * nnz + 12.0 * N + 16.0 * N * b * (3.0 - 2.0 / nterms + (2.0 * nupd - 1.0) / nterms)
+    alg = 20.0 * nnz + 4.0 * (N + 1) + 80.0 * N * b
+    out = {"metric": "batched Cheby prop_step!: state-steps/s, 64 states x N=2^18 CSR fp64 (BASELINE configs[4])",
+           "value": args.batch * args.steps / el, "unit": "state_step/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "c128 (complex fp64)", "data": "synthetic",
+           "config": {"workload": f"BASELINE configs[4]: batched Cheby prop_step!, {args.batch} states x N=2^{log2n} CSR H (16 nnz/row), "
+                                  f"batch split over {world} GPU(s): {b} states per GPU, H replicated, no communication",
+                      "states_per_gpu": b, "N": N, "n_coeffs": int(wrk.n_coeffs), "matvecs_per_step": nterms, "dt": args.dt,
+                      "kernel": "spmm_rows_smem_kernel (wave per row, lane = state)" if b > 32 else "csr_spmm_kernel (state-tiled)",
+                      "row_walk": dict(zip(("inner_dimension", "strip_width"), op.spmm_walk(b))),
+                      "parallelism": "single GPU" if world == 1 else f"batch-split x{world} (replicas of H, zero communication)"
+                                     + (" [TEST MODE: ranks share one GPU]" if one_gpu else "")},
+           "roofline": {"bound": "hbm", "achieved": lay / t_term / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": lay / t_term / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "layout_bytes_per_launch_per_gpu": lay, "avg_launch_us": t_term * 1e6,
+                        "algorithmic_bytes_per_launch_per_gpu": alg, "algorithmic_frac": alg / t_term / 1e9 / HBM_PEAK_GBS,
+                        "note": "per GPU (slowest rank): bytes the shipped step must move per fused term (matrix once, this GPU's "
+                                "share of the panel streams) / average launch duration from HIP events on the kernels' stream"},
+           "cpu_baseline": None, "max_norm_drift": drift}
+    if rank == 0:
+        print(json.dumps(out))
+    bs.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", default="auto", choices=["auto", "c2", "c4"],
+    ap.add_argument("--config", default="auto", choices=["auto", "c2", "c4", "c5"],
                     help="c2: BASELINE configs[1], 2^20 rows per GPU (default at 1 GPU); c4: configs[3], 2^21 rows per GPU = "
-                         "N 2^24 at 8 GPUs (default at more than 1)")
+                         "N 2^24 at 8 GPUs (default at more than 1); c5: configs[4], 64 states x N = 2^18, the batch split over "
+                         "the GPUs (H replicated, no communication)")
+    ap.add_argument("--batch", type=int, default=64, help="--config c5: states in the whole panel")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: rows per GPU fixed; strong: 2^log2n rows in TOTAL, split over the GPUs")
     ap.add_argument("--log2n", type=int, default=None, help="rows per GPU (weak) or in total (strong) = 2^log2n; overrides --config")
@@ -150,6 +224,9 @@ def main():
     import qprop_amd.synth as synth
     import bench_points as bp
 
+    if args.config == "c5":
+        run_c5(args, world, rank, local_rank, one_gpu, dist, L, synth, bp)
+        return
     config = args.config if args.config != "auto" else ("c2" if world == 1 else "c4")
     log2n = args.log2n if args.log2n is not None else (20 if config == "c2" else 21)
     if args.scaling == "strong":
@@ -315,9 +392,13 @@ def main():
             return sh_, nat, snote, dnote
 
 
+    kernel_used = None
+    build_ms = None
     if world == 1:
         fmt_used = op_for_layout.format
         model = bp.cheby_layout_bytes(op_for_layout, rows, ncols_local, nnz_local, coeffs, real_copy=args.real)
+        kernel_used = bp.cheby_kernel_name(op_for_layout)
+        build_ms = op_for_layout.build_info()
 
     pcie = None
     if world == 1 and os.environ.get("QP_BENCH_PCIE") == "1":
@@ -364,7 +445,7 @@ def main():
         avg_launch_s = (ev_ms * 1e-3) / n_launch
         achieved = model["per_term"] / avg_launch_s / 1e9
         csr_equiv = model["csr_equivalent_per_term"] / avg_launch_s / 1e9
-        kern = KERNEL_OF_FORMAT[fmt_used] + "<ChebyOp>"
+        kern = kernel_used + "<ChebyOp>"
         blocks_per_step = N / float(1 << 20)
 
         workload = {"c2": "BASELINE configs[1]: Cheby prop_step!, N=2^20 CSR sparse Hermitian H, 16 nnz/row",
@@ -386,6 +467,7 @@ def main():
                        "n_coeffs": int(len(coeffs)), "matvecs_per_step": nterms,
                        "spectral_range": [-10.0, 10.0], "dt": dt,
                        "device_format": bp.FMT_NAME[fmt_used],
+                       "operator_build": build_ms,
                        "device_layout": layout,
                        "parallelism": "single GPU" if world == 1 else (
                            f"row-partitioned x{world}, exchange={exchange_used}, schedule={schedule_note}, driver={driver_note}"
@@ -463,6 +545,8 @@ def main():
             shA.set_state(psi0_local)
             elA, evA, stA = timed_steps(lambda: shA.step(native=False))
             modelA = bp.cheby_layout_bytes(shA.op, rows, rows + world * shA.M, nnz_local, coeffs, real_copy=args.real)
+            kernel_used = KERNEL_OF_FORMAT[shA.op.format]
+            build_ms = shA.op.build_info()
             fallback = make_out(elA, evA, stA, shA.op.format, modelA, shA.exchange, "serial", "torch.distributed (step loop in Python)",
                                 None, note="conservative schedule (reported because the native / overlapped path did not finish)")
             fallback_line = json.dumps(fallback)
@@ -471,14 +555,19 @@ def main():
             del shA
             import threading
 
-            def give_up():
+            def give_up(reason="hung"):
+                # the kept line is printed, marked as degraded, and the process leaves with a NON-ZERO status: a hang or a
+                # failure of the native / RCCL / overlapped path must not look like a clean run to whoever gates on rc
                 if rank == 0:
-                    sys.stdout.write(fallback_line + "\n")
+                    kept = json.loads(fallback_line)
+                    kept["degraded"] = True
+                    kept["native_path"] = reason
+                    sys.stdout.write(json.dumps(kept) + "\n")
                     sys.stdout.flush()
-                sys.stderr.write(f"[bench.py rank {rank}] native / overlapped path did not finish within {args.watchdog} s: "
-                                 f"reporting the conservative measurement\n")
+                sys.stderr.write(f"[bench.py rank {rank}] native / overlapped path {reason} (limit {args.watchdog} s): "
+                                 f"reporting the conservative measurement, exit status 3\n")
                 sys.stderr.flush()
-                os._exit(0)
+                os._exit(3)
             watchdog = threading.Timer(args.watchdog, give_up)
             watchdog.daemon = True
             watchdog.start()
@@ -525,9 +614,11 @@ def main():
                 raise
             import traceback
             traceback.print_exc()
-            give_up()
+            give_up("failed")
         exchange_used = sh.exchange
         fmt_used = sh.op.format
+        kernel_used = KERNEL_OF_FORMAT[fmt_used]
+        build_ms = sh.op.build_info()
     else:
         strong = None
         elapsed, ev_ms, st = timed_steps(step)
@@ -543,7 +634,7 @@ def main():
         if not args.no_pmc:
             inner = ["--steps", "3", "--warmup", "1", "--cpu-steps", "0", "--no-pmc", "--no-extras", "--log2n", str(log2n),
                      "--pattern", args.pattern, "--format", args.format, "--dt", str(args.dt)] + (["--real"] if args.real else [])
-            traffic, traffic_detail = pmc_traffic(inner, KERNEL_OF_FORMAT[fmt_used], timeout_s=240)
+            traffic, traffic_detail = pmc_traffic(inner, kernel_used, timeout_s=240)
             if traffic is not None:
                 traffic_src = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE --kernel-trace on child runs of "
                                "this command (3 steps each); mean per launch of the kernel, FETCH_SIZE x 2 (gfx950), KiB -> bytes")
@@ -562,6 +653,7 @@ def main():
                              ("c2_scattered_pattern", dict(pattern="scattered", log2n=20)),
                              ("c2_random_columns", dict(pattern="random", log2n=20)),
                              ("c2_random_columns_windowed", dict(pattern="random-window", log2n=20)),
+                             ("banded_N_2^21_rows_per_gpu_of_config_c4", dict(pattern="banded", log2n=21, steps=8)),
                              ("banded_N_2^22_out_of_infinity_cache", dict(pattern="banded", log2n=22, steps=5)),
                              ("c2_alpha_2_17_coefficients", dict(pattern="banded", log2n=20, dt=0.2, steps=20)),
                              ("c2_alpha_50_85_coefficients", dict(pattern="banded", log2n=20, dt=5.0, steps=5)),
@@ -571,6 +663,7 @@ def main():
                 except Exception as e:  # noqa: BLE001  (an extra point must not take the headline down)
                     extras[name] = {"error": f"{type(e).__name__}: {e}"}
             for name, fn in (("c3_newton", bp.measure_newton_c3), ("c5_batched", bp.measure_batched_c5),
+                             ("c5_batched_8_states_share_of_one_of_8_gpus", lambda c: bp.measure_batched_c5(c, batch=8, steps=20)),
                              ("n4_matrix_free_liouvillian_n512", bp.measure_liouville)):
                 try:
                     extras[name] = fn(ctx)
@@ -582,12 +675,28 @@ def main():
                    note=(None if fallback is None else
                          f"conservative schedule measured first: {fallback['value']:.1f} {fallback['unit']} "
                          f"({fallback['ms_per_step']:.3f} ms/step, torch.distributed all-gather per term, no overlap)"))
+    # the fraction beyond the Infinity Cache as a first-class key of the headline object (at N = 2^20 the 134 MB of
+    # values and the vectors are served on-die; config C4 runs 2^21 rows per GPU)
+    if extras:
+        for key, name in (("hbm_resident_frac", "banded_N_2^22_out_of_infinity_cache"),
+                          ("hbm_resident_frac_2^21_rows", "banded_N_2^21_rows_per_gpu_of_config_c4")):
+            pt = extras.get(name) or {}
+            out["roofline"][key] = pt.get("frac")
+        pt = extras.get("banded_N_2^22_out_of_infinity_cache") or {}
+        out["roofline"]["hbm_resident_point"] = {k: pt.get(k) for k in ("N", "us_per_term", "layout_bytes_per_term", "layout_gbs", "kernel")}
+    out["degraded"] = False
+    out["native_path"] = "ok" if world > 1 else None
     if watchdog is not None:
+        # every rank is through the native path before any rank disarms: a rank whose timer fires late finds the others
+        # still armed (they leave with it) instead of blocked for good in the teardown collectives
+        barrier()
         watchdog.cancel()
     if fallback is not None and fallback["value"] > out["value"]:      # report the faster of the two complete measurements
         fallback["config"]["parallelism"] += (f" | the native / overlapped path (schedule={schedule_note}, driver={driver_note}) measured "
                                               f"{out['value']:.1f} {out['unit']} ({out['ms_per_step']:.3f} ms/step): slower, not reported as `value`")
         fallback["strong_scaling_point"] = out["strong_scaling_point"]
+        fallback["degraded"] = False
+        fallback["native_path"] = "ok (slower than the conservative schedule)"
         out = fallback
     if rank == 0:
         print(json.dumps(out))

@@ -598,3 +598,82 @@ class ShardedNewton:
                 raise L.QPAssertionError(6, f"newton!: s={s} exceeds max_restarts={max_restarts}")
         self.restarts = s
         return s
+
+
+class BatchSplitCheby:
+    """SURVEY 8e "Batched" / BASELINE configs[4]: a panel of ``batch`` states x N rows, the batch split over the ranks --
+    rank r owns states [r b, (r + 1) b), b = batch / world, and its own copy of H.  A step is ``cheby!`` on every state:
+    there is NO communication in it (no reductions in the Chebyshev recursion, src/cheby.jl:150-213, and no rows to
+    exchange); ``gather()`` reassembles the panel for output.
+
+    The product path is the HIP engine (``qp_cheby_step_batched`` on this rank's b-state panel); ``panel_backend`` lets the
+    CPU (gloo) tests inject a NumPy stand-in with the same two methods (``make(...)``, ``step(dt)``/``read()``/``write()``)."""
+
+    def __init__(self, ctx, rowptr, col, vals, N, batch, Delta, E_min, dt, fmt=L.FMT_AUTO, group=None, panel_backend=None,
+                 rank=None, world=None):
+        import torch.distributed as dist
+        self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
+        self.group = group
+        self.rank = rank if rank is not None else (self.dist.get_rank(group) if self.dist else 0)
+        self.world = world if world is not None else (self.dist.get_world_size(group) if self.dist else 1)
+        if batch % self.world:
+            raise ValueError(f"{self.world} ranks do not divide the {batch}-state panel")
+        self.N, self.batch, self.b = int(N), int(batch), int(batch) // self.world
+        self.s0, self.s1 = self.rank * self.b, (self.rank + 1) * self.b
+        self.dt = float(dt)
+        if panel_backend is not None:
+            self.impl = panel_backend.make(rowptr, col, vals, self.N, self.b, Delta, E_min, dt)
+        else:
+            self.impl = _HipPanel(ctx, rowptr, col, vals, self.N, self.b, Delta, E_min, dt, fmt)
+
+    def set_states(self, states):
+        """``states``: (N, batch) array of the WHOLE panel (every rank takes its columns) or (N, b) of this rank's share."""
+        states = np.asarray(states, dtype=np.complex128)
+        if states.shape == (self.N, self.batch):
+            states = states[:, self.s0:self.s1]
+        if states.shape != (self.N, self.b):
+            raise ValueError(f"expected a ({self.N}, {self.batch}) or ({self.N}, {self.b}) panel, got {states.shape}")
+        self.impl.write(np.ascontiguousarray(states))
+
+    def step(self, backward=False):
+        self.impl.step(-self.dt if backward else self.dt)
+
+    def local_states(self):
+        return self.impl.read()
+
+    def gather(self):
+        """The whole (N, batch) panel on every rank (host-staged; output only, never part of a step)."""
+        loc = self.local_states()
+        if self.dist is None or self.world == 1:
+            return loc
+        import torch
+        parts = [torch.empty((self.N, self.b), dtype=torch.complex128) for _ in range(self.world)]
+        self.dist.all_gather(parts, torch.from_numpy(np.ascontiguousarray(loc)), group=self.group)
+        return np.concatenate([p.numpy() for p in parts], axis=1)
+
+    def close(self):
+        if self.impl is not None:
+            self.impl.close()
+            self.impl = None
+
+
+class _HipPanel:
+    def __init__(self, ctx, rowptr, col, vals, N, b, Delta, E_min, dt, fmt):
+        self.ctx, self.N, self.b = ctx, N, b
+        self.M = L.Matrix(ctx, N, N, rowptr, col, vals)
+        self.op = L.Operator(ctx, [self.M], 0, fmt)
+        self.panel = L.State(ctx, n=N * b)
+        self.wrk = L.ChebyWrk(ctx, N * b, Delta, E_min, dt)
+
+    def write(self, states):
+        self.panel.upload(states.reshape(-1))       # panel X[i * b + s]
+
+    def read(self):
+        return self.panel.numpy().reshape(self.N, self.b)
+
+    def step(self, dt):
+        L.cheby_batched(self.panel, self.op, dt, self.wrk, self.b)
+
+    def close(self):
+        for h in (self.panel, self.wrk, self.op, self.M):
+            h.close()

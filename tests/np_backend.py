@@ -183,3 +183,34 @@ class NumpyBackend:
 
     def read(self, t, lo, hi):
         return self.view(t, lo, hi).copy()
+
+
+class NumpyPanelBackend:
+    """CPU stand-in for the b-state panel of qprop_amd.sharded.BatchSplitCheby: the oracle's cheby! state by state."""
+
+    def make(self, rowptr, col, vals, N, b, Delta, E_min, dt):
+        return _NumpyPanel(rowptr, col, vals, N, b, Delta, E_min, dt)
+
+
+class _NumpyPanel:
+    def __init__(self, rowptr, col, vals, N, b, Delta, E_min, dt):
+        from oracle import qp_oracle as qo
+        self.qo = qo
+        self.H = sp.csr_matrix((vals, col, rowptr), shape=(N, N))
+        self.X = np.zeros((N, b), dtype=np.complex128)
+        self.args = (Delta, E_min, dt)
+
+    def write(self, states):
+        self.X[:] = states
+
+    def read(self):
+        return self.X.copy()
+
+    def step(self, dt):
+        for s_ in range(self.X.shape[1]):
+            psi = self.X[:, s_].copy()
+            self.qo.cheby(psi, self.H, dt, self.qo.ChebyWrk(psi, *self.args))
+            self.X[:, s_] = psi
+
+    def close(self):
+        pass

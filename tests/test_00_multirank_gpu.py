@@ -7,6 +7,7 @@ import socket
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -125,6 +126,7 @@ def test_bench_multirank_flow_one_gpu(world, driver):
     lines = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")]
     assert len(lines) == 1 and not any(ln.startswith("{") for o, _ in outs[1:] for ln in o.splitlines())
     d = json.loads(lines[0])
+    assert d["degraded"] is False and d["native_path"].startswith("ok")
     assert d["n_gpus"] == world and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
     blocks = d["config"]["blocks_of_2^20_rows_per_step"]
     assert blocks == world / 16.0                       # value counts 2^20-row blocks: N_total / 2^20 of them per step
@@ -155,7 +157,8 @@ def test_bench_multirank_watchdog_reports_the_conservative_measurement(mode):
     """The safety net of `bench.py --gpus N`: the plain schedule (torch.distributed all-gather per term, no second
     stream) is measured first; if the native / overlapped path then hangs (simulated: it sleeps) or fails on a rank
     (simulated: the last rank raises, the others wait for it in a collective), the watchdog prints the kept line from
-    rank 0 and every rank exits with status 0 -- the driver still gets a complete, valid measurement."""
+    rank 0, marked `"degraded": true` with `native_path` = "hung" / "failed", and every rank exits with status 3: the
+    driver still gets a complete, valid measurement, and nobody can mistake the run for a clean one."""
     import json
     world = 2
     s = socket.socket()
@@ -178,15 +181,92 @@ def test_bench_multirank_watchdog_reports_the_conservative_measurement(mode):
                 q.kill()
             raise
     for p, (out, err) in zip(procs, outs):
-        assert p.returncode == 0, err[-3000:]
+        assert p.returncode == 3, err[-3000:]
     lines = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")]
     assert len(lines) == 1 and not any(ln.startswith("{") for o, _ in outs[1:] for ln in o.splitlines())
     d = json.loads(lines[0])
     par = d["config"]["parallelism"]
+    assert d["degraded"] is True and d["native_path"] == ("hung" if mode == "1" else "failed")
     assert d["n_gpus"] == world and d["steps"] == 3 and d["value"] > 0 and 0 < d["roofline"]["frac"] <= 1
     assert "schedule=serial" in par and "driver=torch.distributed" in par
     assert "conservative schedule (reported because the native / overlapped path did not finish)" in par
     assert "reporting the conservative measurement" in outs[0][1]
+
+
+@pytest.mark.parametrize("world", [1, 2, 8])
+def test_bench_c5_batch_split_flow_one_gpu(world):
+    """`bench.py --config c5 --gpus N`: the 64-state panel of BASELINE configs[4] split over N ranks (here sharing GPU 0),
+    H replicated, no communication; one JSON line from rank 0 with the job's state-steps per second."""
+    import json
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", QP_BENCH_ONE_GPU="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--config", "c5",
+                                       "--steps", "2", "--warmup", "1", "--log2n", "14"], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=300))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for p, (out, err) in zip(procs, outs):
+        assert p.returncode == 0, err[-3000:]
+    lines = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and not any(ln.startswith("{") for o, _ in outs[1:] for ln in o.splitlines())
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["unit"] == "state_step/s" and d["config"]["states_per_gpu"] == 64 // world
+    assert abs(d["value"] - 64 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    assert 0 < d["roofline"]["frac"] <= 1.0 and d["max_norm_drift"] < 1e-10
+    assert ("csr_spmm_kernel" in d["config"]["kernel"]) == (64 // world <= 32)
+
+
+def test_batched_panel_split_over_ranks_matches_oracle():
+    """SURVEY 8e "Batched" / BASELINE configs[4]: a 64-state panel split as 64 / R states per rank (H replicated, zero
+    communication) and reassembled equals the oracle's cheby! of every state (1e-10) and, bit for bit, the unsplit panel
+    where both take the same kernel (R = 1 vs 2: wave-per-row kernel; R = 4, 8: the state-tiled one)."""
+    sys.path.insert(0, ROOT)
+    import qprop_amd.lib as L
+    import qprop_amd.synth as synth
+    import qprop_amd.sharded as sharded
+    from oracle import qp_oracle as qo
+    N, batch = 4096, 64
+    rp, col, vals = synth.hermitian_offsets_csr(N, offsets=(1, 2, 3, 4, 64, 128, 192, 256))
+    H = synth.to_scipy(rp, col, vals, N)
+    states = np.stack([synth.random_state(N, seed=500 + s) for s in range(batch)], axis=1)
+    ref = np.empty_like(states)
+    for s_ in range(batch):
+        psi = states[:, s_].copy()
+        w = qo.ChebyWrk(psi, 20.0, -10.0, 0.7)
+        qo.cheby(psi, H, 0.7, w)
+        qo.cheby(psi, H, 0.7, w)
+        ref[:, s_] = psi
+    ctx = L.Context(0)
+    results = {}
+    for R in (1, 2, 4, 8):
+        b = batch // R
+        got = np.empty_like(states)
+        for r in range(R):                      # what rank r of R does (its own context, operator and panel share)
+            c = L.Context(0)
+            bs = sharded.BatchSplitCheby(c, rp, col, vals, N, batch, 20.0, -10.0, 0.7, rank=r, world=R)
+            assert (bs.s0, bs.s1, bs.b) == (r * b, (r + 1) * b, b)
+            bs.set_states(states)
+            bs.step()
+            bs.step()
+            got[:, bs.s0:bs.s1] = bs.local_states()
+            bs.close()
+            c.close()
+        results[R] = got
+        assert np.max(np.linalg.norm(got - ref, axis=0)) < 1e-10, R
+    assert np.array_equal(results[1], results[2]) and np.array_equal(results[4], results[8])
+    ctx.close()
 
 
 def test_bench_single_gpu_line_is_physical():

@@ -836,23 +836,44 @@ def test_newton_c3_full_size(ctx):
     owrk = qo.NewtonWrk(rho0, m_max=20)
     ref = qo.newton(rho0.copy(), Lm, 0.5, owrk)
     assert np.linalg.norm(rho.numpy() - ref) < TOL
-    assert abs(wrk.restarts - owrk.restarts) <= 1
+    # SURVEY 7 allows the convergence test to fire one restart apart; on this fixed input it does not, and a systematic
+    # extra restart (50 % more sweeps) must not pass unnoticed
+    assert wrk.restarts == owrk.restarts, (wrk.restarts, owrk.restarts)
 
 
 def test_batched_c5_full_size_properties(ctx):
-    """BASELINE configs[4] at full size: 64 states x N = 2^18.  Every state of the panel must
-    equal the single-state kernel's result for that state (different kernel, same operator),
-    norms are conserved and a backward step undoes a forward one."""
+    """BASELINE configs[4] at full size: 64 states x N = 2^18.  Three columns of the panel against the C restatement of
+    the reference's serial CSC path (oracle/cheby_ref.c, ~0.15 s of one core each) -- the oracle DIRECTLY at the full
+    size, for the wave-per-row kernel and, with 8 states (one GPU's share of the panel split over 8), for the
+    state-tiled kernel; every state must also equal the single-state kernel's result for that state (different
+    kernel, same operator), norms are conserved and a backward step undoes a forward one."""
+    from oracle import ref_c
     N, b = 1 << 18, 64
     rp, col, vals = synth.hermitian_offsets_csr(N)
     Op = L.Operator(ctx, [L.Matrix(ctx, N, N, rp, col, vals)])
-    del rp, col, vals
     states = np.stack([synth.random_state(N, seed=500 + s) for s in range(b)], axis=1)
+    coeffs = L.ChebyWrk(ctx, N, 20.0, -10.0, 1.0).coeffs
+    cref = {}
+    for s in (0, 5, 17, 63):                 # Hermitian H: CSC(H) = conj CSR(H)
+        c = states[:, s].copy()
+        ref_c.cheby_csc(rp, col.astype(np.int64), np.conj(vals), c, coeffs, 20.0, -10.0, 1.0)
+        cref[s] = c
+    del rp, col, vals
+    p8 = L.State(ctx, data=np.ascontiguousarray(states[:, :8]).reshape(-1))       # 8 states: csr_spmm_kernel
+    w8 = L.ChebyWrk(ctx, N * 8, 20.0, -10.0, 1.0)
+    L.cheby_batched(p8, Op, 1.0, w8, 8)
+    out8 = p8.numpy().reshape(N, 8)
+    for s in (0, 5):
+        assert np.linalg.norm(out8[:, s] - cref[s]) < TOL, s
+    p8.close()
+    w8.close()
     panel = L.State(ctx, data=states.reshape(-1))
     wrk = L.ChebyWrk(ctx, N * b, 20.0, -10.0, 1.0)
     L.cheby_batched(panel, Op, 1.0, wrk, b)
     out = panel.numpy().reshape(N, b)
     assert np.max(np.abs(np.linalg.norm(out, axis=0) - 1.0)) < 1e-11
+    for s in (0, 17, 63):                    # the oracle at the full size, panel kernel (more than 32 states)
+        assert np.linalg.norm(out[:, s] - cref[s]) < TOL, s
     w1 = L.ChebyWrk(ctx, N, 20.0, -10.0, 1.0)
     for s in (0, 17, 63):
         single = L.State(ctx, data=states[:, s].copy())

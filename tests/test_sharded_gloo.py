@@ -182,3 +182,68 @@ def test_sharded_newton_matches_oracle(world):
         assert err < 1e-10, (rank, err)
         assert all(abs(a - b) <= 1 for a, b in zip(restarts, oracle_restarts))
     assert len({tuple(r[2]) for r in res}) == 1          # every rank took the same restart decisions
+
+
+def _batch_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from np_backend import NumpyPanelBackend
+        import qprop_amd.sharded as sharded
+        import qprop_amd.synth as synth
+        N, batch = 512, 12
+        rp, col, vals = synth.hermitian_offsets_csr(N, offsets=(1, 2, 64, 128))
+        states = np.stack([synth.random_state(N, seed=500 + s) for s in range(batch)], axis=1)
+        bs = sharded.BatchSplitCheby(None, rp, col, vals, N, batch, 20.0, -10.0, 0.5, panel_backend=NumpyPanelBackend())
+        assert (bs.s0, bs.s1) == (rank * batch // world, (rank + 1) * batch // world)
+        bs.set_states(states)
+        bs.step()
+        bs.step()
+        bs.step(backward=True)
+        full = bs.gather()
+        q.put((rank, full, bs.b))
+        bs.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_batch_split_gloo(world):
+    """SURVEY 8e "Batched" (BASELINE configs[4]): the panel's states split over the ranks, H replicated, no communication in
+    a step; the gathered panel is the same on every rank and equals the oracle's cheby! of every state."""
+    from oracle import qp_oracle as qo
+    import qprop_amd.synth as synth
+    port = _free_port()
+    ctx_ = mp.get_context("spawn")
+    q = ctx_.Queue()
+    procs = [ctx_.Process(target=_batch_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    N, batch = 512, 12
+    rp, col, vals = synth.hermitian_offsets_csr(N, offsets=(1, 2, 64, 128))
+    H = synth.to_scipy(rp, col, vals, N)
+    ref = np.stack([synth.random_state(N, seed=500 + s) for s in range(batch)], axis=1)
+    for s_ in range(batch):
+        psi = ref[:, s_].copy()
+        w = qo.ChebyWrk(psi, 20.0, -10.0, 0.5)
+        qo.cheby(psi, H, 0.5, w)
+        qo.cheby(psi, H, 0.5, w)
+        qo.cheby(psi, H, -0.5, w)
+        ref[:, s_] = psi
+    for rank, full, b in res:
+        assert b == batch // world and full.shape == (N, batch)
+        assert np.max(np.linalg.norm(full - ref, axis=0)) < 1e-12
+
+
+def test_batch_split_rejects_uneven_split():
+    import qprop_amd.sharded as sharded
+    from np_backend import NumpyPanelBackend
+    import qprop_amd.synth as synth
+    rp, col, vals = synth.hermitian_offsets_csr(256, offsets=(1, 2))
+    with pytest.raises(ValueError):
+        sharded.BatchSplitCheby(None, rp, col, vals, 256, 10, 20.0, -10.0, 0.5, panel_backend=NumpyPanelBackend(), rank=0, world=4)

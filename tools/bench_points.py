@@ -35,11 +35,16 @@ def cheby_layout_bytes(op, rows, ncols, nnz, coeffs, real_copy=False):
     fmt = op.format
     nterms = len(coeffs) - 1
     vbytes = 8.0 if real_copy else 16.0
+    walk = op.walk_info() if fmt == L.FMT_HRB else {"valid": 0}
+    lay["strip_walk"] = walk
     if fmt == L.FMT_CSR:
         matrix = vbytes * nnz + 4.0 * nnz + 8.0 * (rows + 1)
     else:
         per_block = 32.0 if fmt == L.FMT_HRB else 16.0     # bptr + cmeta (+ lptr + lcmeta)
-        matrix = vbytes * lay["stored"] + lay["index_bytes"] + per_block * lay["blocks"]
+        index = lay["index_bytes"] + per_block * lay["blocks"]
+        if walk["valid"]:      # the strip walk computes positions by formula: index bytes only for its edge blocks
+            index *= walk["edge_blocks"] / max(lay["blocks"], 1)
+        matrix = vbytes * lay["stored"] + index
     sched = L.acc_schedule(coeffs)
     vec = 0.0
     updated = False
@@ -56,6 +61,13 @@ def cheby_layout_bytes(op, rows, ncols, nnz, coeffs, real_copy=False):
     return {"per_step": step, "per_term": step / nterms, "matrix_per_term": matrix, "vectors_per_term": vec / nterms,
             "csr_equivalent_per_term": (12.0 if real_copy else 20.0) * nnz + 4.0 * (rows + 1) + 80.0 * rows,
             "layout": lay}
+
+
+def cheby_kernel_name(op):
+    """The kernel a whole-operator fused Chebyshev term of `op` launches (substring of its symbol)."""
+    if op.format == L.FMT_HRB and op.walk_info()["valid"]:
+        return "hrb_walk_kernel"
+    return {L.FMT_CSR: "csr_spmv_kernel", L.FMT_RBCSR: "rbcsr_spmv_kernel", L.FMT_HRB: "hrb_spmv_kernel"}[op.format]
 
 
 def pattern_csr(pattern, N, row_begin=0, row_end=None):
@@ -98,6 +110,7 @@ def measure_cheby(ctx, pattern="banded", log2n=20, fmt="auto", steps=10, warmup=
     by = cheby_layout_bytes(op, N, N, nnz, wrk.coeffs, real_copy=real)
     lay = by["layout"]
     out = {"pattern": pattern, "N": N, "nnz_per_row": nnz / N, "device_format": FMT_NAME[op.format], "dt": dt,
+           "kernel": cheby_kernel_name(op), "operator_build_ms": op.build_info()["build_ms"],
            "n_coeffs": int(wrk.n_coeffs), "values": "real fp64 (f64 variant)" if real else "complex fp64",
            "ms_per_step": ms / steps, "steps_per_s": 1e3 * steps / ms, "us_per_term": t_term * 1e6,
            "layout_bytes_per_term": by["per_term"], "layout_gbs": by["per_term"] / t_term / 1e9,
@@ -180,7 +193,9 @@ def measure_batched_c5(ctx, log2n=18, batch=64, steps=5, warmup=2):
     # X, v_{m-2} read, v_m written, accumulator read + written by the terms of the deferred schedule
     lay = 20.0 * nnz + 12.0 * N + 16.0 * N * batch * (3.0 - 2.0 / nterms + (2.0 * nupd - 1.0) / nterms)
     norms = np.linalg.norm(panel.numpy().reshape(N, batch), axis=0)
-    out = {"workload": "BASELINE configs[4]: batched Cheby prop_step!, 64 states x N=2^18 CSR H (16 nnz/row)",
+    out = {"workload": f"BASELINE configs[4]: batched Cheby prop_step!, {batch} states x N=2^{log2n} CSR H (16 nnz/row)"
+                       + ("" if batch == 64 else f" [the per-GPU share of the 64-state panel split over {64 // batch} GPUs]"),
+           "kernel": "spmm_rows_smem_kernel (wave per row, lane = state)" if batch > 32 else "csr_spmm_kernel (state-tiled)",
            "N": N, "batch": batch, "steps": steps, "ms_per_panel_step": ms / steps,
            "state_steps_per_s": batch * steps / (ms * 1e-3), "us_per_term": t_term * 1e6,
            "row_walk": dict(zip(("inner_dimension", "strip_width"), op.spmm_walk(batch))),

@@ -1,6 +1,17 @@
 // arnoldi!, newton!, ritzvals / specrange and the building blocks of their row-partitioned
 // variants.
+#include <thread>
+
 #include "engine.h"
+
+// spin-wait hint of the host's polling loops (not only x86)
+#if defined(__x86_64__) || defined(__i386__)
+#define QP_CPU_RELAX() __builtin_ia32_pause()
+#elif defined(__aarch64__)
+#define QP_CPU_RELAX() asm volatile("yield" ::: "memory")
+#else
+#define QP_CPU_RELAX() std::this_thread::yield()
+#endif
 
 #include <functional>
 
@@ -299,7 +310,7 @@ static int arnoldi_impl(qp_operator* op, qp_krylov* q, int m, const qp_state* ps
     const auto t_begin = std::chrono::steady_clock::now();
     unsigned spins = 0;
     while (__atomic_load_n(&q->col_flags[j], __ATOMIC_ACQUIRE) != q->seq) {
-      __builtin_ia32_pause();
+      QP_CPU_RELAX();
       if ((++spins & 0xfffffu) == 0 &&
           std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() > 5.0) {
         // never spin for good: fall back to the stream and look once more

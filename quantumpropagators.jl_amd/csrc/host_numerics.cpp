@@ -165,30 +165,67 @@ int diagonalize_hessenberg(const cplx* Hess, int ldh, int m, bool accumulate, cp
 // extend_leja! -- src/newton.jl:97-148 (zero-based; `leja` must hold n + n_use)
 // ---------------------------------------------------------------------------
 // The reference ranks the candidates by  p_i = prod_j |z_i - leja_j|^(1/(n + n_use))  (the exponent only keeps the
-// product inside the floating-point range, :127,:135) and takes the first maximum.  Any strictly increasing
-// function of p_i ranks them identically, so the same greedy choice is made here from  prod_j |z_i - leja_j|^2
-// held as mantissa x 2^exponent: one multiplication and one frexp per (candidate, Leja point) pair instead of
-// a hypot and a pow -- the pow calls were the largest part of the host time that the device waits for at
-// the end of every Arnoldi sweep of newton! (0.10 of 1.1 ms per sweep at m = 20).  The product is exact to
-// a few ulp where the pow chain accumulates one rounding per factor; candidates whose products agree to
-// rounding -- Ritz values of nested Hessenberg blocks that have converged to the same eigenvalue -- may be
-// taken in a different order than by the reference's arithmetic, which changes which of two numerically
-// equal points is used, not the interpolation.
+// product inside the floating-point range, :127,:135), a left-to-right chain of one hypot and one pow per factor, and
+// takes the first maximum (strict >).  Those pow calls were the largest part of the host time that the device waits
+// for at the end of every Arnoldi sweep of newton! (0.10 of 1.1 ms per sweep at m = 20).  Here the ranking is done in
+// two tiers that together make the reference's choice:
+//   1. every candidate's  P_i = prod_j |z_i - leja_j|^2  is kept as mantissa x 2^exponent (one multiplication and
+//      one frexp per factor, exact to a few ulp, no overflow / underflow for any number of factors or any distance: the
+//      difference is scaled by a power of two BEFORE it is squared).  Any increasing function of the product ranks
+//      alike, so the candidate with the largest P_i is the reference's choice -- unless another candidate comes
+//      within the rounding noise of the reference's own chain;
+//   2. candidates whose P_i lies within 1e-8 (relative) of the largest -- Ritz values of nested Hessenberg blocks that
+//      have converged to the same eigenvalue, exact duplicates -- are re-ranked by the reference's arithmetic itself
+//      (the hypot / pow chain, factor by factor, first maximum wins among them in index order).  A candidate outside
+//      that set is below the maximum by more than 1e-8 / (2 (n + n_use)) in the reference's p, orders of magnitude
+//      above the chain's rounding error, so it cannot be the reference's choice.
+// The selection is therefore the reference's (the oracle's) index for index -- tests/test_cabi_host.py, including
+// adversarial inputs with duplicated and nearly equal candidates -- at the cost of the fast path.
 // prod_folded (optional, n > 0): the products over the first n Leja points, which a caller may have built
 // while the candidates were arriving (leja_fold_candidate).
-static inline void scaled_mul(ScaledProd& p, double d2) {
+static inline void scaled_mul_dist2(ScaledProd& p, cplx d) {
+  // |d|^2 with the range of |d| taken out first: scale by 2^-k, k = exponent of the larger component
+  const double ax = std::fabs(d.real()), ay = std::fabs(d.imag());
+  const double big = ax > ay ? ax : ay;
+  if (!(big > 0.0)) {   // zero distance (or NaN): the product is zero
+    p.m = (big == 0.0) ? 0.0 : big;
+    return;
+  }
+  int k = 0;
+  (void)std::frexp(big, &k);
+  const double sx = std::ldexp(d.real(), -k), sy = std::ldexp(d.imag(), -k);   // larger component in [0.5, 1)
   int de = 0;
-  p.m = std::frexp(p.m * d2, &de);   // m stays in [0.5, 1) (or 0): no overflow / underflow for any number of factors
-  p.e += de;
+  p.m = std::frexp(p.m * (sx * sx + sy * sy), &de);   // m stays in [0.5, 1) (or 0)
+  p.e += de + 2 * k;
 }
 static inline bool scaled_greater(const ScaledProd& a, const ScaledProd& b) {   // a > b, both >= 0
   if (a.m == 0.0 || b.m == 0.0) return a.m > b.m;
   return a.e != b.e ? a.e > b.e : a.m > b.m;
 }
+// a >= b (1 - tol)?  (b > 0)
+static inline bool scaled_near(const ScaledProd& a, const ScaledProd& b, double tol) {
+  if (a.m == 0.0) return false;
+  const int64_t de = (int64_t)a.e - (int64_t)b.e;
+  if (de > 2) return true;
+  if (de < -2) return false;
+  return std::ldexp(a.m, (int)de) >= b.m * (1.0 - tol);
+}
 
 ScaledProd leja_fold_candidate(const cplx* leja, int n, cplx z) {
   ScaledProd p{1.0, 0};
-  for (int j = 0; j < n; ++j) scaled_mul(p, std::norm(z - leja[j]));
+  for (int j = 0; j < n; ++j) scaled_mul_dist2(p, z - leja[j]);
+  return p;
+}
+
+// the reference's product for one candidate, operation by operation (src/newton.jl:132-136)
+static inline double leja_reference_product(const cplx* leja, int n_have, cplx z, double exponent) {
+  double p = 1.0;
+  // abs(::ComplexF64) is hypot (libm's, as the oracle's NumPy uses; libstdc++'s std::abs(complex) may take a scaled
+  // sqrt instead, one ulp apart, and exact ties between candidates are decided by exactly these bits)
+  for (int j = 0; j < n_have; ++j) {
+    const cplx d = z - leja[j];
+    p = p * std::pow(std::hypot(d.real(), d.imag()), exponent);
+  }
   return p;
 }
 
@@ -198,7 +235,7 @@ void extend_leja(cplx* leja, int n, cplx* newpoints, int n_new, int n_use, const
   if (n == 0) {
     cplx z_last = newpoints[u];
     for (int i = 0; i < u; ++i) {
-      if (std::abs(newpoints[i]) > std::abs(z_last)) {
+      if (std::hypot(newpoints[i].real(), newpoints[i].imag()) > std::hypot(z_last.real(), z_last.imag())) {
         newpoints[u] = newpoints[i];
         newpoints[i] = z_last;
         z_last = newpoints[u];
@@ -207,6 +244,8 @@ void extend_leja(cplx* leja, int n, cplx* newpoints, int n_new, int n_use, const
     leja[0] = newpoints[u];
     i_add_start = 1;
   }
+  const double exponent = 1.0 / (double)(n + n_use);                                   // :127
+  constexpr double kNearTie = 1e-8;
   // one running product per candidate; every new Leja point appends one factor to each (the reference
   // recomputes the whole product for every new point: O(m^3 n) pow calls)
   std::vector<ScaledProd> prod((size_t)std::max(n_new, 1), ScaledProd{1.0, 0});
@@ -219,7 +258,7 @@ void extend_leja(cplx* leja, int n, cplx* newpoints, int n_new, int n_use, const
     const int n_have = n + i_add;
     for (int i = 0; i <= u - i_add; ++i) {
       ScaledProd p = prod[i];
-      for (int j = n_done; j < n_have; ++j) scaled_mul(p, std::norm(newpoints[i] - leja[j]));
+      for (int j = n_done; j < n_have; ++j) scaled_mul_dist2(p, newpoints[i] - leja[j]);
       prod[i] = p;
     }
     n_done = n_have;
@@ -229,6 +268,24 @@ void extend_leja(cplx* leja, int n, cplx* newpoints, int n_new, int n_use, const
       if (scaled_greater(prod[i], p_max)) {  // strict: first maximum wins (src/newton.jl:137-140)
         p_max = prod[i];
         i_max = i;
+      }
+    }
+    if (p_max.m > 0.0) {
+      // tier 2: anything within the noise of the reference's chain is decided by that chain
+      bool tie = false;
+      for (int i = 0; i <= u - i_add && !tie; ++i) tie = (i != i_max) && scaled_near(prod[i], p_max, kNearTie);
+      if (tie) {
+        double pr_max = 0.0;   // (every tied candidate's product is positive: the loop below is the reference's :130-141)
+        int ir_max = i_max;
+        for (int i = 0; i <= u - i_add; ++i) {
+          if (!scaled_near(prod[i], p_max, kNearTie)) continue;
+          const double pr = leja_reference_product(leja, n_have, newpoints[i], exponent);
+          if (pr > pr_max) {
+            pr_max = pr;
+            ir_max = i;
+          }
+        }
+        i_max = ir_max;
       }
     }
     leja[n + i_add] = newpoints[i_max];

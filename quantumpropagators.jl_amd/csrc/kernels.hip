@@ -14,6 +14,7 @@
 // required by check_propagator's reinit test), reductions finished in the *next*
 // kernel's prologue instead of an extra launch or an in-launch fence.
 #include <cstring>
+#include <type_traits>
 
 #include "kernel_common.h"
 
@@ -33,7 +34,10 @@ __global__ __launch_bounds__(64 * WS) void rbcsr_spmv_kernel(const int64_t* __re
   constexpr bool NT = (VAR & 1) != 0;
   constexpr bool PRE = (VAR & 2) != 0;
   constexpr int UNR = (VAR & 4) ? 4 : 2;
-  __shared__ double2 lds[kThreads / 64];
+  static_assert(WS == kThreads / 64 || std::is_same<Op, ChebyOp>::value,
+                "block_sum (Op::begin of the folded norm, finish_check) sums kThreads / 64 wavefronts: only the fused term, "
+                "launched without its per-workgroup check, may run with another workgroup width");
+  __shared__ double2 lds[WS];
   const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
   sync_wait(sy, wg);
   op.begin_issue();
@@ -104,7 +108,9 @@ __global__ __launch_bounds__(64 * WS) void hrb_spmv_kernel(const int64_t* __rest
   constexpr int UNR = (VAR & 4) ? 2 : 1;
   constexpr bool DEEP = (VAR & 8) != 0;
   constexpr bool NEAR = (VAR & 16) != 0;
-  __shared__ double2 lds[kThreads / 64];
+  static_assert(WS == kThreads / 64 || std::is_same<Op, ChebyOp>::value,
+                "block_sum sums kThreads / 64 wavefronts: only the fused term without its check may use another width");
+  __shared__ double2 lds[WS];
   const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
   sync_wait(sy, wg);
   op.begin_issue();
@@ -600,7 +606,7 @@ int launch_spmm_cheby(hipStream_t s, const int64_t* rowptr, const int32_t* cols,
       hipLaunchKernelGGL((spmm_rows_kernel<ChebyOp, RW, 8>), grid, dim3(kThreads), 0, s, rowptr, cols, vals, X, nrows, b, op, order); \
     }                                                                                                            \
   }
-    if (tun.spmm_rw == 0) {
+    if (tun.spmm_rw == 0 && nnz <= (int64_t)INT32_MAX) {   // (the scalar-entry kernel broadcasts a 32-bit row pointer)
 #define QP_SPMM_SMEM(WS)                                                                                          \
   {                                                                                                               \
     dim3 grid((unsigned)((nrows + (WS) - 1) / (WS)), (unsigned)((b + 63) / 64));                                  \

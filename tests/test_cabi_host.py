@@ -124,6 +124,56 @@ def test_extend_leja_matches_oracle():
         assert np.array_equal(leja_a[:n_a], leja_b[:n_b])
 
 
+@pytest.mark.parametrize("case", ["duplicates", "near_ties", "nested_ritz", "tiny_and_huge", "on_leja_points"])
+def test_extend_leja_adversarial_ties_match_oracle(case):
+    """The Leja order is index work (bit-exact): the library ranks candidates by an exactly scaled product and lets the
+    reference's own hypot / pow chain (src/newton.jl:132-136) decide among candidates within its rounding noise.
+    Adversarial inputs -- exact duplicates, candidates 1e-15 apart, the accumulated Ritz values of nested Hessenberg
+    blocks of a Hermitian matrix whose extremal eigenvalues have converged (what newton! actually feeds it), distances
+    of 1e-170 and 1e+170 (the squared distance alone would leave the double range), candidates that coincide with
+    existing Leja points (product zero) -- give the oracle's picks, index for index, over several restarts."""
+    rng = np.random.default_rng(11)
+    m = 12
+    ncand = m * (m + 1) // 2
+
+    def candidates(rnd):
+        if case == "duplicates":
+            base = rng.standard_normal(ncand // 3 + 1) + 1j * rng.standard_normal(ncand // 3 + 1)
+            return np.resize(np.repeat(base, 3), ncand).copy()
+        if case == "near_ties":
+            base = rng.standard_normal(ncand // 4 + 1) + 1j * rng.standard_normal(ncand // 4 + 1)
+            pts = np.resize(np.repeat(base, 4), ncand).copy()
+            return pts * (1.0 + 1e-15 * rng.integers(-4, 5, ncand)) + 1e-16 * rng.integers(-3, 4, ncand)
+        if case == "nested_ritz":
+            A = rng.standard_normal((60, 60))
+            A = (A + A.T) / 2 + np.diag(np.linspace(-30, 30, 60))       # well separated extremal eigenvalues: fast convergence
+            v = rng.standard_normal(60) + 0j
+            Hs = np.zeros((m + 1, m + 1), dtype=complex)
+            qv = [np.zeros(60, dtype=complex) for _ in range(m + 1)]
+            mm = qo.arnoldi(Hs, qv, m, v / np.linalg.norm(v), A.astype(complex), 1.0, extended=True)
+            assert mm == m
+            return np.array(qo.diagonalize_hessenberg_matrix(Hs, mm, accumulate=True))[:ncand].copy()
+        if case == "tiny_and_huge":
+            scale = np.array([1e-170, 1e-90, 1.0, 1e90, 1e170])[rng.integers(0, 5, ncand)]
+            return (rng.standard_normal(ncand) + 1j * rng.standard_normal(ncand)) * scale
+        pts = rng.standard_normal(ncand) + 1j * rng.standard_normal(ncand)
+        if rnd > 0:
+            pts[::3] = leja_a[rng.integers(0, n_a, len(pts[::3]))]           # candidates ON earlier Leja points
+        return pts
+
+    leja_a = np.zeros(4 * m + 1, dtype=complex)
+    leja_b = leja_a.copy()
+    n_a = n_b = 0
+    for rnd in range(4):
+        pts = candidates(rnd)
+        assert len(pts) >= m
+        with np.errstate(over="ignore", under="ignore", divide="ignore", invalid="ignore"):
+            leja_a, n_a = qo.extend_leja(leja_a, n_a, pts.copy(), m)
+        leja_b, n_b = L.extend_leja(leja_b, n_b, pts.copy(), m)
+        assert n_a == n_b == (rnd + 1) * m
+        assert np.array_equal(leja_a[:n_a], leja_b[:n_b]), (case, rnd)
+
+
 @pytest.mark.parametrize("func", ["expmi", "exp", "callback"])
 def test_extend_newton_coeffs_matches_oracle(func):
     """src/newton.jl:176-214."""

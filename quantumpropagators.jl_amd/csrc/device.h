@@ -129,6 +129,7 @@ struct SyncArgs {
   unsigned wait_target = 0;
   unsigned wait_from_wg = 0;
   unsigned* timeout_flag = nullptr;
+  unsigned spin_limit = 1u << 28;   // polls (with s_sleep 8) before a wait gives up: ~1 min (knob split_spin_log2)
 };
 
 struct RowSet {
@@ -180,6 +181,8 @@ struct Tuning {
   int arnoldi_mode = 1;       // 0 = sequential fused MGS passes, 1 = low-synchronisation MGS
   int arnoldi_solve = 1;      // 1 = the MGS reduction + solve run in the projection kernel's prologue (3 launches per column), 0 = own launch
   int arnoldi_fold = 1;       // 1 = the norm + scale of an Arnoldi column is folded into the next column's mat-vec (no launch of its own)
+  int split_spin_log2 = 28;   // in-launch hand-off: a polling workgroup gives up after 2^this polls (~1 min) and raises the split's time-out flag
+  int split_dbg = 0;          // tests only: 1 = the boundary launches do not signal (every polling workgroup runs into the time-out)
   int split_mode = 2;         // boundary -> interior hand-off: 0 = cross-stream events, 1 = in-launch counter, 2 = the counter when at most 256 workgroups poll
   int liouville_tile32_min_n = 260;  // matrix-free Liouvillian: n in [this, liouville_tile32_n] takes the 32 x 32 matrix-core
   int liouville_tile32_n = 2048;     //   kernel; other n <= liouville_fused_n the 16 x 16 one; the rest library GEMMs

@@ -554,7 +554,8 @@ int qp_cheby_term_split(qp_operator* op, qp_split* sp, void* boundary_stream, in
     ri.sync.wait_target = sp->signals_issued;      // every boundary workgroup launched so far
     ri.sync.wait_from_wg = sp->wait_from_wg;
     ri.sync.timeout_flag = sp->timeout_dev;
-    rb.sync.signal = sp->counter;
+    ri.sync.spin_limit = 1u << std::min(std::max(op->ctx->tun.split_spin_log2, 4), 31);
+    rb.sync.signal = (op->ctx->tun.split_dbg & 1) ? nullptr : sp->counter;
     sp->signals_issued += (unsigned)((sp->n_boundary + qp::kThreads / 64 - 1) / (qp::kThreads / 64));
   }
   qp::ChebyEpi eb = e;

@@ -65,7 +65,7 @@ __device__ __forceinline__ void sync_wait(const SyncArgs& sy, unsigned wg) {
       unsigned spins = 0;
       while (__hip_atomic_load(sy.wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sy.wait_target) {
         __builtin_amdgcn_s_sleep(8);
-        if (++spins > (1u << 28)) {  // bounded (~1 min): never hang the queue for good; the host checks the flag
+        if (++spins > sy.spin_limit) {  // bounded (~1 min): never hang the queue for good; the host checks the flag
           if (sy.timeout_flag) __hip_atomic_store(sy.timeout_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // host-visible
           break;
         }

@@ -139,6 +139,49 @@ def test_sharded_overlap_machinery_world1(pg, overlap, split_mode):
     ctx.close()
 
 
+def test_split_wait_timeout_is_reported_not_hung(pg):
+    """The in-launch hand-off boundary(m) -> interior(m + 1) polls a counter with a bounded spin.  Forced failure: the
+    boundary launches do not signal (knob split_dbg) and the bound is lowered to 2^10 polls (knob split_spin_log2): the
+    interior launch comes back by itself, raises the split's host-visible flag, and the NEXT call on that split --
+    Python-driven term or the library's own step -- returns QP_E_INTERNAL instead of computing on with a stale vector."""
+    import torch
+    import qprop_amd.lib as L
+    import qprop_amd.sharded as sharded
+    import qprop_amd.synth as synth
+    N = 8192
+    rp, col, vals = synth.hermitian_offsets_csr(N, offsets=(1, 2, 3, 4, 16, 32, 48, 64))
+    ctx = L.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    send = np.concatenate([np.arange(0, 200), np.arange(N - 200, N)])
+    try:
+        ctx.tuning_set("split_mode", 1)
+        ctx.tuning_set("split_spin_log2", 10)
+        ctx.tuning_set("split_dbg", 1)
+        sh = sharded.ShardedCheby(ctx, rp, col, vals, N, 0, N, 20.0, -10.0, 1.0, exchange="halo", overlap=True,
+                                  _debug_send_rows=send)
+        assert sh.split is not None
+        sh.set_state(synth.random_state(N))
+        with pytest.raises(L.QPError) as ei:
+            for _ in range(3):                 # the flag is raised inside the first step's launches and seen by a later call
+                sh.step()
+                torch.cuda.synchronize()
+            sh.check()
+        assert ei.value.status == L.QP_E_INTERNAL and "timed out" in str(ei.value)
+        with pytest.raises(L.QPError):         # the split stays poisoned: its state is not valid
+            sh.split.check()
+        torch.cuda.synchronize()
+    finally:
+        ctx.tuning_set("split_dbg", 0)
+        ctx.tuning_set("split_spin_log2", 28)
+        ctx.tuning_set("split_mode", 2)
+    # a fresh split on the same context works again
+    sh2 = sharded.ShardedCheby(ctx, rp, col, vals, N, 0, N, 20.0, -10.0, 1.0, exchange="halo", overlap=True, _debug_send_rows=send)
+    sh2.set_state(synth.random_state(N))
+    sh2.step()
+    sh2.check()
+    assert abs(np.linalg.norm(sh2.local_state()) - 1.0) < 1e-11
+    ctx.close()
+
+
 def test_sharded_newton_world1(pg):
     """ShardedNewton with the product HipBackend (device Arnoldi building blocks + all-reduce
     call shape) at world 1 against the oracle and against the single-GPU qp_newton_step."""

@@ -247,3 +247,101 @@ def test_batch_split_rejects_uneven_split():
     rp, col, vals = synth.hermitian_offsets_csr(256, offsets=(1, 2))
     with pytest.raises(ValueError):
         sharded.BatchSplitCheby(None, rp, col, vals, 256, 10, 20.0, -10.0, 0.5, panel_backend=NumpyPanelBackend(), rank=0, world=4)
+
+
+class _FakeCommLib:
+    """Stand-in for the qp_comm_* entry points (the real ones need a GPU and librccl): records the calls."""
+
+    def __init__(self, log):
+        self.log = log
+
+    def qp_comm_prepare(self, ctx, path, rank, world, out):
+        self.log.append("prepare")
+        out._obj.value = 0x1000          # a non-NULL handle
+        return 0
+
+    def qp_comm_unique_id(self, path, buf):
+        self.log.append("unique_id")
+        buf.raw = bytes(range(128))
+        return 0
+
+    def qp_comm_connect(self, h, uid):
+        self.log.append("connect")
+        return 0
+
+    def qp_comm_destroy(self, h):
+        self.log.append("destroy")
+        return 0
+
+    def qp_last_error(self):
+        return b""
+
+
+class _FakeCtx:
+    def __init__(self, log):
+        self.lib = _FakeCommLib(log)
+        self._h = None
+
+    def _adopt(self, child):
+        pass
+
+
+def _comm_worker(rank, world, port, q, die_rank):
+    import datetime
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=30))
+    import qprop_amd.lib as L
+    log = []
+
+    def exchange_id(uid):
+        if rank == die_rank:
+            os._exit(17)        # this rank dies between qp_comm_prepare and qp_comm_connect
+        box = [uid]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    def agree(err):
+        errs = [None] * world
+        dist.all_gather_object(errs, err)
+        bad = [e for e in errs if e is not None]
+        return bad[0] if bad else None
+
+    try:
+        L.Comm(_FakeCtx(log), rank, world, exchange_id, lib_path="librccl-not-loaded-here.so", agree=agree)
+        q.put((rank, "connected", log))
+    except BaseException as e:      # noqa: BLE001
+        q.put((rank, "error:" + type(e).__name__, log))
+    q.close()
+    q.join_thread()                 # flush the result before leaving without interpreter shutdown:
+    os._exit(0)                     # (the process group of a world that lost a rank cannot be torn down collectively)
+
+
+@pytest.mark.parametrize("die_rank", [None, 1, 0])
+def test_comm_setup_survives_a_rank_that_dies_between_prepare_and_connect(die_rank):
+    """Two-phase set-up of the library's RCCL communicator (qprop_amd.lib.Comm): local preparation, then the ranks
+    exchange rank 0's id and AGREE, and only then enter the collective connect.  If a rank dies in between, the others'
+    exchange / agreement over the torch group fails (bounded by the group's time-out) and they raise with the handle
+    released -- none of them enters qp_comm_connect, where it would block for good.  (CPU: the entry points are a fake
+    that records calls; the protocol under test is the host side.)"""
+    world = 3
+    port = _free_port()
+    ctx_ = mp.get_context("spawn")
+    q = ctx_.Queue()
+    procs = [ctx_.Process(target=_comm_worker, args=(r, world, port, q, die_rank)) for r in range(world)]
+    for p in procs:
+        p.start()
+    alive = world - (0 if die_rank is None else 1)
+    res = {}
+    for _ in range(alive):
+        rank, what, log = q.get(timeout=120)
+        res[rank] = (what, log)
+    for p in procs:
+        p.join(timeout=60)
+    if die_rank is None:
+        assert all(what == "connected" and "connect" in log for what, log in res.values()), res
+        return
+    assert procs[die_rank].exitcode == 17 and die_rank not in res
+    for rank, (what, log) in res.items():
+        assert what.startswith("error:"), (rank, what)
+        assert "connect" not in log and log[0] == "prepare" and log[-1] == "destroy", (rank, log)

@@ -92,6 +92,37 @@ def pmc_traffic(argv_inner, kernel_substr, timeout_s):
                            "dispatches": [vals["FETCH_SIZE"][1], vals["WRITE_SIZE"][1]]}
 
 
+XGMI_LINK_GBS = 153.0      # per direction and link (MI355X_MICROARCH.md: 7 links x ~153 GB/s per GPU, point to point)
+
+
+def exchange_model(sh, world, rows, us_per_term):
+    """What the exchange of one fused term should cost on an 8-GPU xGMI node, from the partition alone, so that the first
+    real multi-GPU run can be read against a prediction: bytes every rank sends per term, the peers it sends to (one
+    point-to-point link each), the transfer time at the link rate plus a fixed start-up, and how much of it the
+    boundary / interior overlap can hide behind the interior launch (measured per-term time of this run)."""
+    M = int(sh.M)
+    if sh.exchange == "halo" and sh.send_to is not None:
+        peers = max(len(sh.send_to), 1)
+        sent = 16.0 * M                                  # the packed send rows, once per peer that reads any of them
+        per_link = sent                                  # worst link: the whole slab to one neighbour
+        kind = "neighbour send/recv of the packed halo rows"
+    else:
+        peers = max(world - 1, 1)
+        sent = 16.0 * M * peers                          # all-gather: this rank's slab to every other rank
+        per_link = 16.0 * M
+        kind = "all-gather of every rank's slab"
+    startup_us = 10.0                                    # collective / send-recv launch + first-byte latency (assumed)
+    transfer_us = per_link / (XGMI_LINK_GBS * 1e9) * 1e6
+    predicted = startup_us + transfer_us
+    return {"kind": kind, "rows_sent_per_rank_per_term": M, "bytes_sent_per_rank_per_term": sent, "peers": peers,
+            "bytes_on_busiest_link_per_term": per_link, "link_gbs_assumed": XGMI_LINK_GBS, "startup_us_assumed": startup_us,
+            "predicted_exchange_us_per_term": predicted, "measured_us_per_term_all_in": us_per_term,
+            "predicted_exposed_us_per_term_serial_schedule": predicted,
+            "predicted_exposed_us_per_term_overlap_schedule": max(0.0, predicted - 0.9 * us_per_term),
+            "note": "prediction from the partition (no measurement): serial schedule = exchange in line after every term; overlap "
+                    "schedule = exchange behind the interior launch, exposed only where it is longer than that launch"}
+
+
 def run_c5(args, world, rank, local_rank, one_gpu, dist, L, synth, bp):
     """BASELINE configs[4]: 64 states x N = 2^18 CSR H, Chebyshev on the panel, the batch split over the GPUs --
     rank r advances states [r b, (r + 1) b), b = 64 / world, with its own copy of H and no communication (SURVEY 8e
@@ -437,7 +468,7 @@ def main():
         sy.close()
 
     def make_out(elapsed, ev_ms, st, fmt_used, model, exchange_used, schedule_note, driver_note, strong,
-                 traffic=None, traffic_src=None, traffic_detail=None, extras=None, note=None):
+                 traffic=None, traffic_src=None, traffic_detail=None, extras=None, note=None, xmodel=None):
         """The JSON line for one measured run of args.steps steps (elapsed: wall seconds, slowest rank)."""
         layout = model["layout"]
         steps_per_s = args.steps / elapsed
@@ -500,6 +531,7 @@ def main():
             "cpu_baseline_all_cores": cpu_omp,
             "pcie_inclusive_steps_per_s": pcie,
             "strong_scaling_point": strong,
+            "exchange_model": xmodel,
             "extras": extras,
             "stats": {"n_matvec": st["n_matvec"], "kernel_launches": st["n_kernel_launches"]},
         }
@@ -548,7 +580,8 @@ def main():
             kernel_used = KERNEL_OF_FORMAT[shA.op.format]
             build_ms = shA.op.build_info()
             fallback = make_out(elA, evA, stA, shA.op.format, modelA, shA.exchange, "serial", "torch.distributed (step loop in Python)",
-                                None, note="conservative schedule (reported because the native / overlapped path did not finish)")
+                                None, note="conservative schedule (reported because the native / overlapped path did not finish)",
+                                xmodel=exchange_model(shA, world, rows, 1e3 * evA / (args.steps * nterms)))
             fallback_line = json.dumps(fallback)
             fallback["config"]["parallelism"] = fallback["config"]["parallelism"].split(" | ")[0]
             shA.close()
@@ -672,6 +705,7 @@ def main():
 
     out = make_out(elapsed, ev_ms, st, fmt_used, model, exchange_used, schedule_note, driver_note, strong,
                    traffic, traffic_src, traffic_detail, extras,
+                   xmodel=(exchange_model(sh, world, rows, 1e3 * ev_ms / (args.steps * nterms)) if world > 1 else None),
                    note=(None if fallback is None else
                          f"conservative schedule measured first: {fallback['value']:.1f} {fallback['unit']} "
                          f"({fallback['ms_per_step']:.3f} ms/step, torch.distributed all-gather per term, no overlap)"))

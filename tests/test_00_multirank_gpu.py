@@ -142,6 +142,9 @@ def test_bench_multirank_flow_one_gpu(world, driver):
         assert sp_["N_total"] == 1 << 20 and sp_["rows_per_gpu"] == 1 << 19 and sp_["prop_steps_per_s"] > 0
     else:
         assert sp_ is None                              # 3 does not divide 2^20
+    xm = d["exchange_model"]       # the prediction the first real multi-GPU run is read against
+    assert xm["rows_sent_per_rank_per_term"] > 0 and xm["peers"] >= 1 and xm["predicted_exchange_us_per_term"] > xm["startup_us_assumed"]
+    assert xm["bytes_on_busiest_link_per_term"] == 16 * xm["rows_sent_per_rank_per_term"]
     par = d["config"]["parallelism"]
     # both measurements happened: the conservative one first, then the native / overlapped path under the watchdog;
     # the faster of the two is the reported value and the line names the other

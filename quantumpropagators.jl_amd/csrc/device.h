@@ -206,6 +206,8 @@ struct Tuning {
   int walk_dbg = 0;           // strip walk, measurements only: 1 = in-wave edge block after the walk instead of before it, 2 = edge blocks skipped (WRONG results), 4 = never as workgroups of their own
   int n_cu = 256;             // compute units of the context's device (set by qp_ctx_create)
   int walk_min_blocks = 3072; // strip walk: smallest number of walkable row blocks for which the plan is used
+  int spmm_walk = 0;          // batched term on a lattice operator, panels of more than 32 states: 1 = the strip walk (kernels_spmm_walk.hip; measured slower than the wave-per-row kernel, profiles/r03/batched_c5_walk.txt: off)
+  int spmm_walk_waves = 0;    // ... wavefronts it is cut into (0: 3072 = 3 per SIMD)
   int spmm_nt = 1;            // nontemporal matrix / row-local streams in the batched SpMM kernel: 0 never, 2 always, 1 for large panels
 };
 // address of the knob called `key` inside `t`, or nullptr
@@ -221,6 +223,22 @@ struct CoefBlock {
 int launch_real_part(hipStream_t s, double* out, const double2* v, int64_t n, Stats* st);
 int launch_combine_planes(hipStream_t s, double2* vals, const double2* const* planes_dev, const double2* coefs,
                           int nplanes, int64_t n, double* vals_r, Stats* st);
+
+// ---- strip walk of the batched term (kernels_spmm_walk.hip) over a lattice operator in CSR order ---------------------
+// every row has z = 2 (nn + K) + diag entries; the rows a g + c, a in [a_lo, a_hi), have their columns at
+// [-K g .. -g] [-d_nn .. -d_1] [0] [d_1 .. d_nn] [g .. K g] (storage order); the other rows are listed in `edge`
+struct SpmmWalkPlan {
+  int valid = 0;
+  int nn = 0, K = 0, diag = 0;
+  int near[kWalkMaxNear] = {0};
+  int64_t g = 0;
+  int a_lo = 0, a_hi = 0;
+  int32_t* edge = nullptr;    // device: the rows outside the walk (wave-per-row kernel, `order` list)
+  int64_t n_edge = 0;
+};
+bool spmm_walk_shape_supported(int nn, int K, int diag);
+int launch_spmm_walk_cheby(hipStream_t s, const double2* vals, const double2* X, const SpmmWalkPlan& P, int b,
+                           const ChebyEpi& e, const Tuning& tun, bool nt, bool* launched);
 
 // batched states: CSR SpMM with the fused Chebyshev epilogue, panel X[i*b + s]
 int launch_spmm_cheby(hipStream_t s, const int64_t* rowptr, const int32_t* cols, const double2* vals,

@@ -64,6 +64,8 @@ struct qp_operator {
   DevMatrix A;
   HostLayoutData layout;
   qp::WalkPlan walk;              // strip-walk plan of a Hermitian-packed lattice operator (A.walk points here when valid)
+  qp::SpmmWalkPlan spmm_walk;     // strip-walk plan of the batched term, built on first use
+  bool spmm_walk_built = false;
   double build_ms = 0, build_ms_total = 0;   // host time of the latest / of all device layout builds
   int n_builds = 0, n_relayouts = 0;         // re-layouts: builds forced after creation (complex coefficient on a packed operator)
   bool hermitian_planes = false;
@@ -236,6 +238,8 @@ inline int dot_sync(qp_ctx* ctx, const double2* x, const double2* y, int64_t n, 
 int operator_csr_mirror(qp_operator* op, bool gather = true);
 // row order in which the batched (SpMM) kernel visits the rows for a panel of `batch` states
 int operator_spmm_order(qp_operator* op, int batch, const int32_t** order_out);
+// strip-walk plan of the batched term (lattice operators); *out = NULL when the operator has none
+int operator_spmm_walk_plan(qp_operator* op, const qp::SpmmWalkPlan** out);
 // which terms of a cheby! touch the Psi accumulator (include/qprop.h, qp_acc_defer)
 void acc_schedule(const double* a, int n_coeffs, bool defer, qp_acc_defer* out);
 void set_defer(qp::ChebyEpi& e, const qp_acc_defer* d);

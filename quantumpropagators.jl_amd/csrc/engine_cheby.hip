@@ -321,6 +321,10 @@ int qp_cheby_step_batched(qp_cheby* w, qp_operator* op, qp_state* psi, int batch
   const bool rows_kernel = qp::spmm_uses_rows_kernel(ctx->tun, batch);
   const int32_t* order = nullptr;   // row walk of the wave-per-row kernel
   if (rows_kernel) QP_CHECK(operator_spmm_order(op, batch, &order));
+  // lattice operators: the strip walk (far rows of X in a register ring) for the rows whose far neighbours exist, the
+  // wave-per-row kernel for the rest (its `order` list = those rows)
+  const qp::SpmmWalkPlan* walk = nullptr;
+  if (rows_kernel && ctx->tun.spmm_walk) QP_CHECK(operator_spmm_walk_plan(op, &walk));
 
   const double beta = (Delta / 2) + E_min;
   cplx c = (dt > 0) ? cplx(0, -2.0) / Delta : cplx(0, 2.0) / Delta;
@@ -369,8 +373,22 @@ int qp_cheby_step_batched(qp_cheby* w, qp_operator* op, qp_state* psi, int batch
     e.phase = d2(phase);
     e.apply_phase = last ? 1 : 0;
     e.check_partials = nullptr;
-    QP_CHECK(qp::launch_spmm_cheby(ctx->stream, op->m_rowptr, op->m_cols, op->m_vals, x, n, op->A.nnz, batch, e,
-                                   ctx->tun, rows_kernel, order, &ctx->stats));
+    bool walked = false;
+    if (walk) {
+      const bool nt = ctx->tun.spmm_nt == 2 || (ctx->tun.spmm_nt == 1 && (double)n * batch * sizeof(double2) >= 128.0 * 1024 * 1024);
+      QP_CHECK(qp::launch_spmm_walk_cheby(ctx->stream, op->m_vals, x, *walk, batch, e, ctx->tun, nt, &walked));
+      if (walked) {
+        ctx->stats.n_launch++;
+        if (walk->n_edge > 0)   // the rows next to the periodic wrap: same kernel as before, only these rows
+          QP_CHECK(qp::launch_spmm_cheby(ctx->stream, op->m_rowptr, op->m_cols, op->m_vals, x, walk->n_edge, op->A.nnz, batch, e,
+                                         ctx->tun, true, walk->edge, &ctx->stats));
+        else
+          ctx->stats.n_matvec++;
+      }
+    }
+    if (!walked)
+      QP_CHECK(qp::launch_spmm_cheby(ctx->stream, op->m_rowptr, op->m_cols, op->m_vals, x, n, op->A.nnz, batch, e,
+                                     ctx->tun, rows_kernel, order, &ctx->stats));
     if (m == 1) c *= 2.0;
   }
   if (result != P) QP_HIP(hipMemcpyAsync(P, result, (size_t)psi->n * sizeof(double2), hipMemcpyDeviceToDevice, ctx->stream));

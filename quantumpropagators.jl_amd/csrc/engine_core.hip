@@ -333,6 +333,9 @@ static int operator_free_device(qp_operator* op) {
   if (op->A.lptr) (void)hipFree(op->A.lptr);
   if (op->A.lcols) (void)hipFree(op->A.lcols);
   if (op->A.lpos) (void)hipFree(op->A.lpos);
+  if (op->spmm_walk.edge) (void)hipFree(op->spmm_walk.edge);
+  op->spmm_walk = qp::SpmmWalkPlan();
+  op->spmm_walk_built = false;
   if (op->walk.edge_map) (void)hipFree(op->walk.edge_map);
   op->walk = qp::WalkPlan();
   op->A.walk = nullptr;
@@ -1492,6 +1495,77 @@ int operator_spmm_order(qp_operator* op, int batch, const int32_t** order_out) {
   op->m_order_g = g;
   op->m_order_sw = sw;
   *order_out = op->m_order;
+  return QP_OK;
+}
+
+// Strip-walk plan of the batched term (device.h: SpmmWalkPlan; kernels_spmm_walk.hip).  Index work on the host: every
+// row must have the same number of entries, and every row a g + c with a in [a_lo, a_hi) its columns at exactly the
+// distances [-K g .. -g] [-d_nn .. -d_1] [0] [d_1 .. d_nn] [g .. K g]; all other rows are listed for the wave-per-row kernel.
+int operator_spmm_walk_plan(qp_operator* op, const qp::SpmmWalkPlan** out) {
+  *out = nullptr;
+  if (op->spmm_walk_built) {
+    if (op->spmm_walk.valid) *out = &op->spmm_walk;
+    return QP_OK;
+  }
+  op->spmm_walk_built = true;
+  qp::SpmmWalkPlan& P = op->spmm_walk;
+  P = qp::SpmmWalkPlan();
+  const int64_t n = op->A.nrows;
+  const auto& ur = op->u_rowptr;
+  const auto& uc = op->u_col;
+  if (op->A.format == QP_FMT_MATFREE || op->A.ncols != n || n < 4096 || n > INT32_MAX || ur.empty()) return QP_OK;
+  const int64_t z = ur[1] - ur[0];
+  if (z < 4 || z > 24 || ur[n] != z * n) return QP_OK;
+  for (int64_t r = 0; r < n; ++r)
+    if (ur[r + 1] - ur[r] != z) return QP_OK;
+  // the stencil of a row in the middle
+  const int64_t rm = n / 2;
+  std::vector<int64_t> dl((size_t)z);
+  for (int64_t k = 0; k < z; ++k) dl[(size_t)k] = (int64_t)uc[ur[rm] + k] - rm;
+  int64_t k = 0;
+  int K = 0, nn = 0, diag = 0;
+  while (k < z && dl[(size_t)k] <= -64) ++k, ++K;
+  if (K < 1 || K > 4) return QP_OK;
+  const int64_t g = -dl[(size_t)(K - 1)];
+  if (g < 64 || n % g != 0) return QP_OK;
+  for (int m = 1; m <= K; ++m)
+    if (dl[(size_t)(K - m)] != -(int64_t)m * g) return QP_OK;
+  while (k < z && dl[(size_t)k] < 0) ++k, ++nn;
+  if (nn < 1 || nn > qp::kWalkMaxNear) return QP_OK;
+  for (int i = 0; i < nn; ++i) P.near[i] = (int)(-dl[(size_t)(K + nn - 1 - i)]);
+  for (int i = 0; i < nn; ++i)
+    if (P.near[i] <= 0 || P.near[i] >= 64 || (i > 0 && P.near[i] <= P.near[i - 1])) return QP_OK;
+  if (k < z && dl[(size_t)k] == 0) ++k, diag = 1;
+  if (z != 2 * (nn + K) + diag) return QP_OK;
+  for (int i = 0; i < nn; ++i)
+    if (dl[(size_t)(K + nn + diag + i)] != P.near[i]) return QP_OK;
+  for (int m = 1; m <= K; ++m)
+    if (dl[(size_t)(K + 2 * nn + diag + m - 1)] != (int64_t)m * g) return QP_OK;
+  if (!qp::spmm_walk_shape_supported(nn, K, diag)) return QP_OK;
+  const int64_t A = n / g;
+  if (A < 2 * K + 8) return QP_OK;
+  // every row of the walk must carry exactly this stencil
+  for (int64_t a = K; a < A - K; ++a)
+    for (int64_t c = 0; c < g; ++c) {
+      const int64_t r = a * g + c;
+      const int32_t* col = uc.data() + ur[r];
+      for (int64_t q = 0; q < z; ++q)
+        if ((int64_t)col[q] - r != dl[(size_t)q]) return QP_OK;
+    }
+  std::vector<int32_t> edge;
+  for (int64_t r = 0; r < (int64_t)K * g; ++r) edge.push_back((int32_t)r);
+  for (int64_t r = (A - K) * g; r < n; ++r) edge.push_back((int32_t)r);
+  QP_CHECK(dev_alloc(&P.edge, std::max<size_t>(edge.size(), 1)));
+  QP_HIP(hipMemcpy(P.edge, edge.data(), edge.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  P.n_edge = (int64_t)edge.size();
+  P.nn = nn;
+  P.K = K;
+  P.diag = diag;
+  P.g = g;
+  P.a_lo = K;
+  P.a_hi = (int)(A - K);
+  P.valid = 1;
+  *out = &P;
   return QP_OK;
 }
 

@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libqprop_hip.so")
 
 QP_OK = 0
+QP_E_INTERNAL = 10
 QP_E_RCCL = 12
 STATUS = {
     0: "QP_OK", 1: "QP_E_BAD_ARG", 2: "QP_E_HIP", 3: "QP_E_DT_MISMATCH",

@@ -1464,6 +1464,47 @@ def test_cheby_batched_rows_kernel_and_row_walk_bit_identical(ctx, batch):
         assert np.linalg.norm(ref.reshape(N, batch)[:, s] - r) < TOL
 
 
+@pytest.mark.parametrize("N,offsets,diag,batch", [
+    (1 << 15, (1, 2, 3, 4, 256, 512, 768, 1024), False, 64),
+    (1 << 15, (1, 2, 3, 4, 256, 512, 768, 1024), True, 40),      # 17 entries per row, lanes beyond the panel idle
+    (1 << 14, (1, 3, 128, 256), False, 64),
+    (1 << 14, (2, 5, 192, 384), True, 33),
+], ids=["16nnz", "17nnz_b40", "8nnz", "9nnz_b33"])
+def test_cheby_batched_strip_walk_bit_identical(ctx, N, offsets, diag, batch):
+    """The strip walk of the batched term (kernels_spmm_walk.hip: far rows of X in a register ring down one inner index,
+    the matrix row as one vector load broadcast lane by lane, everything requested one step ahead; the rows next to the
+    periodic wrap stay with the wave-per-row kernel) sums every (row, state) in the order of the other batched kernels:
+    bit-identical panels, for any cut of the walk into wavefronts -- and the oracle's cheby! state by state."""
+    rp, col, vals = synth.hermitian_offsets_csr(N, offsets=offsets)
+    if diag:
+        rp, col, vals = _with_diagonal(rp, col, vals, N)
+    Op = L.Operator(ctx, [L.Matrix(ctx, N, N, rp, col, vals)])
+    states = np.stack([synth.random_state(N, seed=900 + s) for s in range(batch)], axis=1)
+    wrk = L.ChebyWrk(ctx, N * batch, 24.0, -12.0, 0.8)
+    saved = {k: ctx.tuning_get(k) for k in ("spmm_walk", "spmm_walk_waves")}
+    outs = {}
+    try:
+        for name, knobs in (("rows", dict(spmm_walk=0)), ("walk", dict(spmm_walk=1, spmm_walk_waves=0)),
+                            ("walk_1seg", dict(spmm_walk=1, spmm_walk_waves=1)), ("walk_many", dict(spmm_walk=1, spmm_walk_waves=20000))):
+            for k, v in knobs.items():
+                ctx.tuning_set(k, v)
+            panel = L.State(ctx, data=states.reshape(-1).copy())
+            L.cheby_batched(panel, Op, 0.8, wrk, batch)
+            L.cheby_batched(panel, Op, -0.8, wrk, batch)
+            L.cheby_batched(panel, Op, 0.8, wrk, batch)
+            outs[name] = panel.numpy().reshape(N, batch)
+    finally:
+        for k, v in saved.items():
+            ctx.tuning_set(k, v)
+    for name in ("walk", "walk_1seg", "walk_many"):
+        assert np.array_equal(outs["rows"], outs[name]), name
+    H = synth.to_scipy(rp, col, vals, N)
+    for s in (0, batch // 2, batch - 1):
+        psi = states[:, s].copy()
+        qo.cheby(psi, H, 0.8, qo.ChebyWrk(psi, 24.0, -12.0, 0.8))
+        assert np.linalg.norm(outs["walk"][:, s] - psi) < TOL, s
+
+
 def test_spmm_row_walk_detection(ctx):
     """Which patterns get a strip-wise row walk: the BASELINE lattice (inner dimension 1024, strips of
     64 inner indices at 64 states); not a scattered pattern (no common inner dimension), not a

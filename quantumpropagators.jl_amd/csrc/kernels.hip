@@ -631,7 +631,8 @@ int launch_spmm_cheby(hipStream_t s, const int64_t* rowptr, const int32_t* cols,
     }
 #undef QP_SPMM_ROWS
   } else
-  switch (tun.spmm_tile) {
+  switch ((b <= 8 && tun.spmm_tile == 16) ? 8 : tun.spmm_tile) {   // a panel of at most eight states (one GPU's share of 64 over 8): no idle lanes
+    case 8: launch_spmm_cheby_t<8>(s, rowptr, cols, vals, X, nrows, b, e, tun.spmm_nt); break;
     case 32: launch_spmm_cheby_t<32>(s, rowptr, cols, vals, X, nrows, b, e, tun.spmm_nt); break;
     case 64: launch_spmm_cheby_t<64>(s, rowptr, cols, vals, X, nrows, b, e, tun.spmm_nt); break;
     default: launch_spmm_cheby_t<16>(s, rowptr, cols, vals, X, nrows, b, e, tun.spmm_nt); break;

@@ -723,6 +723,61 @@ def test_strip_walk_bit_identical_to_block_kernel(ctx, N, offsets, diag, real, s
     assert np.linalg.norm(base - ref) < TOL
 
 
+def test_strip_walk_random_lattices_bit_identical(ctx):
+    """Seeded sweep over lattice parameters at the edges of the walk plan: strip steps of one row block (g = 64) up to 40,
+    near distances up to the LDS halo (16), sizes that are no multiple of g or of 64, few steps per wavefront, a diagonal
+    or none, real or complex couplings -- whenever the operator gets a plan, the walk and the per-block kernel agree bit
+    for bit (forward, backward, forward); shapes without a kernel instance must simply have no plan."""
+    rng = np.random.default_rng(20261003)
+    saved = {k: ctx.tuning_get(k) for k in WALK_KNOBS}
+    n_walked = 0
+    try:
+        for trial in range(28):
+            nn, K = [(4, 4), (2, 2), (3, 1), (1, 3)][trial % 4]
+            S = int(rng.choice([1, 2, 3, 5, 8, 16, 40]))
+            g = 64 * S
+            near = sorted(rng.choice(np.arange(1, 17), nn, replace=False).tolist())
+            nsteps = int(rng.integers(2 * K + 4, 2 * K + 40))
+            N = g * nsteps + int(rng.choice([0, 0, 64, 17, 200]))
+            offsets = tuple(near) + tuple(g * m for m in range(1, K + 1))
+            if 2 * max(offsets) >= N:
+                continue
+            rp, col, vals = synth.hermitian_offsets_csr(N, offsets=offsets, seed=1000 + trial)
+            diag = (nn, K) in ((4, 4), (2, 2)) and bool(rng.integers(0, 2))
+            if bool(rng.integers(0, 4) == 0):
+                vals = vals.real.astype(np.complex128)
+            if diag:
+                rp, col, vals = _with_diagonal(rp, col, vals, N)
+            for k, v in {**WALK_DEFAULTS, "walk_min_blocks": 8}.items():
+                ctx.tuning_set(k, v)
+            Op = L.Operator(ctx, [L.Matrix(ctx, N, N, rp, col, vals)], 0, L.FMT_HRB)
+            wi = Op.walk_info()
+            if not wi["valid"]:
+                Op.close()
+                continue
+            assert (wi["near"], wi["far"], wi["diag"], wi["blocks_per_step"]) == (nn, K, int(diag), S)
+            psi0 = synth.random_state(N, seed=trial)
+            wrk = L.ChebyWrk(ctx, N, 26.0, -13.0, 0.9)
+            outs = []
+            for knobs in (dict(hrb_walk=0), dict(hrb_walk=1), dict(hrb_walk=1, walk_waves=int(rng.choice([16, 128, 1024, 4096])),
+                                                                   walk_dbg=int(rng.choice([0, 1, 4, 5])), walk_nt=int(rng.integers(0, 2)))):
+                for k, v in {**WALK_DEFAULTS, "walk_min_blocks": 8, **knobs}.items():
+                    ctx.tuning_set(k, v)
+                psi = L.State(ctx, data=psi0)
+                L.cheby(psi, Op, 0.9, wrk)
+                L.cheby(psi, Op, -0.9, wrk)
+                L.cheby(psi, Op, 0.9, wrk)
+                outs.append(psi.numpy())
+            assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]), (trial, offsets, N, diag)
+            assert abs(np.linalg.norm(outs[1]) - 1.0) < 1e-11
+            n_walked += 1
+            Op.close()
+    finally:
+        for k, v in saved.items():
+            ctx.tuning_set(k, v)
+    assert n_walked >= 15
+
+
 def test_strip_walk_plan_only_for_lattices(ctx):
     """The walk plan is index work on the host: it exists only where every position it computes by formula is the position
     the per-block kernel would read -- not for scattered or per-row random columns, not for near distances beyond the LDS

@@ -72,7 +72,7 @@ struct DevMatrix {
 // row blocks b, b + S, b + 2 S, ... -- finds everything a block needs beyond its own streams in what it loaded for the
 // blocks before: the gathered elements x[r + m g] are the row-local elements of the blocks m steps ahead / behind (a ring
 // of 2 K + 1 registers, one new load per step), the conj-transposed values of the far lower entries are the far upper
-// values it streamed m steps ago (a register FIFO), the near gathers and the near conj-transposed values are lane shifts
+// values it streamed m steps ago (a FIFO in LDS), the near gathers and the near conj-transposed values are lane shifts
 // of the block's own element / values, staged through a per-wavefront LDS window with a halo of the neighbouring block.
 // Blocks outside [W0, R1) (W0 = R0 + K S: the first blocks whose history lies inside the run; the periodic wrap-around,
 // a ragged end) are listed in edge_map and take the per-block code path in the same launch.

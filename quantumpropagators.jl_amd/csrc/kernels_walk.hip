@@ -16,6 +16,7 @@
 //
 // Summation order per row is that of the per-block kernel (lower slots then upper slots in storage order, two
 // interleaved partial sums), so the two kernels agree bit for bit (tests/test_gpu_parity.py).
+#include <atomic>
 #include <type_traits>
 
 #include "kernel_common.h"
@@ -399,10 +400,18 @@ static bool launch_instance(hipStream_t s, dim3 grid, const VT* uvals, const dou
                             const WalkGeom& G, const HrbArrays& H, int64_t nrows, const ChebyOp& op) {
   constexpr size_t lds = WalkLds<NN, K>::kBytes;
   auto kern = &hrb_walk_kernel<VT, NN, K, Z0, NTM>;
-  // more than the 64 KB a launch gets without asking: opt in once per kernel instance (and device)
-  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
-  if (!attr_ok) return false;
+  // more than the 64 KB a launch gets without asking: opt in once per kernel instance AND device (a process may hold
+  // contexts on several GPUs); 0 = not tried, 1 = granted, 2 = refused (the caller then takes the per-block kernel)
+  static std::atomic<unsigned char> opted[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  unsigned char st = opted[dev].load(std::memory_order_acquire);
+  if (st == 0) {
+    st = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 1 : 2;
+    if (st == 2) (void)hipGetLastError();
+    opted[dev].store(st, std::memory_order_release);
+  }
+  if (st != 1) return false;
   hipLaunchKernelGGL(kern, grid, dim3(64 * kWalkWaves), lds, s, uvals, x, P, G, H, nrows, op);
   return true;
 }
@@ -454,7 +463,15 @@ int launch_hrb_walk_cheby(hipStream_t s, const DevMatrix& A, const double2* x, c
   // Infinity Cache then keeps from one term to the next is the vectors
   const double footprint = (double)A.stored * (A.vals_r ? 8.0 : 16.0) + 64.0 * (double)A.nrows;
   const bool resident = footprint <= 230e6;
-  const int waves = tun.walk_waves > 0 ? tun.walk_waves : (resident ? 1280 : 2048);
+  // beyond it: every CU but the few the edge workgroups take (8 x (256 - 24) = 1856 for the headline lattice), so that
+  // the edge blocks run BESIDE the walk there too; 2048 with the edge blocks inside the walk's wavefronts when that would
+  // leave more than an eighth of the chip to them (profiles/r03/kbench_walk_development.txt: 2^21 rows 71.4 -> 68.5 us,
+  // 2^22 126.0 -> 121.8, 2^23 275 -> 278)
+  const int64_t edge_wgs_all = (P->n_edge + kWalkWaves - 1) / kWalkWaves;
+  const int waves_beside = (int)(kWalkWaves * std::max<int64_t>(0, (int64_t)tun.n_cu - edge_wgs_all)) / P->S * P->S;
+  const int waves = tun.walk_waves > 0 ? tun.walk_waves
+                    : resident ? 1280
+                    : (waves_beside >= 7 * kWalkWaves * tun.n_cu / 8 ? waves_beside : kWalkWaves * tun.n_cu);
   const int ntm = tun.walk_nt >= 0 ? tun.walk_nt : (resident ? 0 : 1);
   const int64_t nseg_target = std::max<int64_t>(1, waves / P->S);
   const bool no_edges = (tun.walk_dbg & 2) != 0;

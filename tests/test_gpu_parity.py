@@ -665,7 +665,7 @@ def _with_diagonal(rp, col, vals, N):
 
 
 WALK_KNOBS = ("hrb_walk", "walk_waves", "walk_nt", "walk_dbg", "walk_edge_steps", "walk_min_blocks")
-WALK_DEFAULTS = {"hrb_walk": 1, "walk_waves": 0, "walk_nt": -1, "walk_dbg": 0, "walk_edge_steps": 3, "walk_min_blocks": 3072}
+WALK_DEFAULTS = {"hrb_walk": 1, "walk_waves": 0, "walk_nt": -1, "walk_dbg": 0, "walk_edge_steps": 4, "walk_min_blocks": 3072}
 
 
 @pytest.mark.parametrize("N,offsets,diag,real,shape", [

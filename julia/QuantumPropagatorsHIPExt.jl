@@ -85,7 +85,10 @@ end
 
 # one context per device and task tree, created on first use (contexts are cheap: a stream and two events)
 const _CTX = Dict{Int,Handle}()
-default_ctx(device::Integer = 0) = get!(() -> make_ctx(device), _CTX, Int(device))
+const _CTX_LOCK = ReentrantLock()        # propagators are created from many Julia threads (GRAPE / Krotov trajectories)
+default_ctx(device::Integer = 0) = lock(_CTX_LOCK) do
+    get!(() -> make_ctx(device), _CTX, Int(device))
+end
 
 # ------------------------------------------------------------------------------------------
 # HIPState: a device-resident state vector   (SURVEY 8f N3; src/interfaces/state.jl:92…)
@@ -456,7 +459,16 @@ end
 # set_state!   src/propagator.jl:367-377
 function set_state!(p::Union{ChebyHIPPropagator}, state)
     if p.state isa HIPState
-        state ≢ p.state && copyto!(p.dstate, state)     # HIPState or host vector: device copy or upload
+        if state ≢ p.state
+            if p.inplace
+                copyto!(p.dstate, state)                # HIPState or host vector: device copy or upload
+            else
+                # not in place: the reference REBINDS propagator.state (src/propagator.jl:372-375); states the caller
+                # already holds -- the object the last prop_step! returned -- must not be overwritten
+                p.dstate = state isa HIPState ? copy(state) : HIPState(state; ctx = p.dstate.ctx)
+                setfield!(p, :state, p.dstate)
+            end
+        end
         return p.state
     end
     if state ≢ p.state

@@ -37,7 +37,7 @@ struct WalkGeom {
   int L = 0;           // steps per wavefront
   int nseg = 0;        // segments of L steps per strip column
   int n_walk_wg = 0;
-  int ntask = 0;       // wavefronts of the walk (n_walk_wg x kWalkWaves)
+  int ntask = 0;       // wavefronts of the walk (n_walk_wg x wavefronts per workgroup)
   // Edge blocks (outside the walkable run) are handed out one per wavefront -- edge block i to wavefront i, after its
   // walk -- and the segments of those wavefronts are `edge_steps` steps shorter, about what a block on the per-block
   // path costs: every wavefront finishes at about the same time (as workgroups of their own they cost 5-6 us per
@@ -50,7 +50,7 @@ struct WalkGeom {
   int n_edge_wg = 0;
 };
 
-constexpr int kWalkWaves = 8;   // wavefronts (adjacent strip columns) per workgroup
+constexpr int kWalkWaves = 8;   // most wavefronts (adjacent strip columns) per workgroup; the launch may use fewer (knob walk_wg)
 
 // One row block by the per-block rules of hrb_spmv_kernel (same sums), arranged for LATENCY: a wavefront of the walk
 // takes its edge block alone, so the block is three dependent rounds of loads -- block pointers; column sections,
@@ -209,7 +209,7 @@ struct WalkLds {
   static constexpr int XW = kRB + 2 * kWalkHalo, AW = kRB + kWalkHalo;
   static constexpr int kHist = XW + NN * AW;
   static constexpr int kPerWave = kHist + kRB * (K * (K + 1) / 2);
-  static constexpr size_t kBytes = sizeof(double2) * (size_t)kPerWave * kWalkWaves;
+  static constexpr size_t kBytesPerWave = sizeof(double2) * (size_t)kPerWave;
 };
 
 // NTM: nontemporal accesses (bit 0: the matrix values, bit 1: the vector loads, bit 2: the stores)
@@ -227,13 +227,13 @@ __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __r
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if ((int)blockIdx.x < G.n_edge_wg) {
-    const int64_t idx = (int64_t)blockIdx.x * kWalkWaves + wave;
+    const int64_t idx = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
     if (idx < P.n_edge)
       hrb_edge_block<VT>(H, uvals, x, (int64_t)__builtin_amdgcn_readfirstlane(P.edge_map[idx]), lane, nrows, op);
     return;
   }
   const unsigned wg = xcd_remap(blockIdx.x - G.n_edge_wg, G.n_walk_wg);
-  const int task = (int)wg * kWalkWaves + wave;
+  const int task = (int)wg * (int)(blockDim.x >> 6) + wave;
   const int S = P.S;
   const int seg = task / S, col = task - seg * S;
   const int64_t nW = P.R1 - P.W0;
@@ -398,7 +398,9 @@ __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __r
 template <class VT, int NN, int K, int Z0, int NTM = 0>
 static bool launch_instance(hipStream_t s, dim3 grid, const VT* uvals, const double2* x, const WalkPlan& P,
                             const WalkGeom& G, const HrbArrays& H, int64_t nrows, const ChebyOp& op) {
-  constexpr size_t lds = WalkLds<NN, K>::kBytes;
+  const int ws = G.ntask / std::max(G.n_walk_wg, 1);      // wavefronts per workgroup of this launch
+  const size_t lds = WalkLds<NN, K>::kBytesPerWave * (size_t)ws;
+  constexpr size_t lds_max = WalkLds<NN, K>::kBytesPerWave * kWalkWaves;
   auto kern = &hrb_walk_kernel<VT, NN, K, Z0, NTM>;
   // more than the 64 KB a launch gets without asking: opt in once per kernel instance AND device (a process may hold
   // contexts on several GPUs); 0 = not tried, 1 = granted, 2 = refused (the caller then takes the per-block kernel)
@@ -407,12 +409,12 @@ static bool launch_instance(hipStream_t s, dim3 grid, const VT* uvals, const dou
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
   unsigned char st = opted[dev].load(std::memory_order_acquire);
   if (st == 0) {
-    st = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 1 : 2;
+    st = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max) == hipSuccess ? 1 : 2;
     if (st == 2) (void)hipGetLastError();
     opted[dev].store(st, std::memory_order_release);
   }
   if (st != 1) return false;
-  hipLaunchKernelGGL(kern, grid, dim3(64 * kWalkWaves), lds, s, uvals, x, P, G, H, nrows, op);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * ws), lds, s, uvals, x, P, G, H, nrows, op);
   return true;
 }
 
@@ -456,9 +458,10 @@ int launch_hrb_walk_cheby(hipStream_t s, const DevMatrix& A, const double2* x, c
   if (nW < tun.walk_min_blocks || nW < P->S) return QP_OK;
   WalkGeom G;
   const int64_t J = (nW + P->S - 1) / P->S;                       // steps of the longest strip column
-  // wavefronts: all resident at once (2 per SIMD, 2048).  While the operator and the vectors sit in the Infinity Cache
-  // 1280 (160 of the 256 compute units) already draw what it delivers, the set-up of a walk (8 + 10 loads) is paid less
-  // often, and the edge blocks run beside the walk on the free compute units (profiles/r03/kbench_walk.txt)
+  // wavefronts.  While the operator and the vectors sit in the Infinity Cache, 768 wavefronts as 192 workgroups of four
+  // (one per CU on three quarters of the chip) draw what it delivers: the set-up of a walk (8 + 10 loads) is paid less
+  // often than with the 2048 that fill every SIMD twice, and the edge blocks run beside the walk on the free compute
+  // units (profiles/r03/kbench_walk_development.txt: N = 2^20 31.9 us per term; 1280 as workgroups of eight 33.4, 2048 36.5)
   // ... and beyond it the matrix values are streamed nontemporally: they are read once per term, and what the
   // Infinity Cache then keeps from one term to the next is the vectors
   const double footprint = (double)A.stored * (A.vals_r ? 8.0 : 16.0) + 64.0 * (double)A.nrows;
@@ -467,18 +470,20 @@ int launch_hrb_walk_cheby(hipStream_t s, const DevMatrix& A, const double2* x, c
   // the edge blocks run BESIDE the walk there too; 2048 with the edge blocks inside the walk's wavefronts when that would
   // leave more than an eighth of the chip to them (profiles/r03/kbench_walk_development.txt: 2^21 rows 71.4 -> 68.5 us,
   // 2^22 126.0 -> 121.8, 2^23 275 -> 278)
-  const int64_t edge_wgs_all = (P->n_edge + kWalkWaves - 1) / kWalkWaves;
-  const int waves_beside = (int)(kWalkWaves * std::max<int64_t>(0, (int64_t)tun.n_cu - edge_wgs_all)) / P->S * P->S;
+  const int ws = (tun.walk_wg == 8 || tun.walk_wg == 4 || tun.walk_wg == 2) ? tun.walk_wg : (resident ? 4 : kWalkWaves);            // wavefronts per workgroup (two 4-wavefront workgroups fit a CU)
+  const int64_t wg_slots = (int64_t)tun.n_cu * (kWalkWaves / ws);  // workgroups the chip holds at once
+  const int64_t edge_wgs_all = (P->n_edge + ws - 1) / ws;
+  const int waves_beside = (int)(ws * std::max<int64_t>(0, wg_slots - edge_wgs_all)) / P->S * P->S;
   const int waves = tun.walk_waves > 0 ? tun.walk_waves
-                    : resident ? 1280
+                    : resident ? 768
                     : (waves_beside >= 7 * kWalkWaves * tun.n_cu / 8 ? waves_beside : kWalkWaves * tun.n_cu);
   const int ntm = tun.walk_nt >= 0 ? tun.walk_nt : (resident ? 0 : 1);
   const int64_t nseg_target = std::max<int64_t>(1, waves / P->S);
   const bool no_edges = (tun.walk_dbg & 2) != 0;
-  const int64_t edge_wgs = (P->n_edge + kWalkWaves - 1) / kWalkWaves;
-  // edge blocks as workgroups of their own while every workgroup of the launch still finds a compute unit to itself
+  const int64_t edge_wgs = edge_wgs_all;
+  // edge blocks as workgroups of their own while every workgroup of the launch still finds room on the chip at once
   const bool edge_beside = !no_edges && (tun.walk_dbg & 4) == 0 &&
-                           (nseg_target * P->S + kWalkWaves - 1) / kWalkWaves + edge_wgs <= (int64_t)tun.n_cu;
+                           (nseg_target * P->S + ws - 1) / ws + edge_wgs <= wg_slots;
   G.n_edge_wg = edge_beside ? (int)edge_wgs : 0;
   G.edge_steps = (no_edges || edge_beside) ? 0 : std::max(0, tun.walk_edge_steps);
   G.edge_last = (tun.walk_dbg & 1) ? 1 : 0;
@@ -488,8 +493,8 @@ int launch_hrb_walk_cheby(hipStream_t s, const DevMatrix& A, const double2* x, c
   while ((int64_t)G.nseg * G.L - (int64_t)std::min(G.edge_segs, G.nseg) * G.edge_steps < J) ++G.nseg;   // (tiny operators)
   G.edge_segs = std::min(G.edge_segs, G.nseg);
   const int64_t ntask = (int64_t)G.nseg * P->S;
-  G.n_walk_wg = (int)((ntask + kWalkWaves - 1) / kWalkWaves);
-  G.ntask = G.n_walk_wg * kWalkWaves;
+  G.n_walk_wg = (int)((ntask + ws - 1) / ws);
+  G.ntask = G.n_walk_wg * ws;
   HrbArrays H{A.bptr, A.cmeta, reinterpret_cast<const char*>(A.cols), A.lptr, A.lcmeta,
               reinterpret_cast<const char*>(A.lcols), reinterpret_cast<const int4*>(A.lpos)};
   ChebyOp op{e};

@@ -664,8 +664,8 @@ def _with_diagonal(rp, col, vals, N):
     return H.indptr.astype(np.int64), H.indices.astype(np.int32), H.data.astype(np.complex128)
 
 
-WALK_KNOBS = ("hrb_walk", "walk_waves", "walk_nt", "walk_dbg", "walk_edge_steps", "walk_min_blocks")
-WALK_DEFAULTS = {"hrb_walk": 1, "walk_waves": 0, "walk_nt": -1, "walk_dbg": 0, "walk_edge_steps": 4, "walk_min_blocks": 3072}
+WALK_KNOBS = ("hrb_walk", "walk_waves", "walk_nt", "walk_dbg", "walk_edge_steps", "walk_min_blocks", "walk_wg")
+WALK_DEFAULTS = {"hrb_walk": 1, "walk_waves": 0, "walk_nt": -1, "walk_dbg": 0, "walk_edge_steps": 4, "walk_min_blocks": 3072, "walk_wg": 0}
 
 
 @pytest.mark.parametrize("N,offsets,diag,real,shape", [
@@ -710,7 +710,7 @@ def test_strip_walk_bit_identical_to_block_kernel(ctx, N, offsets, diag, real, s
         base = run(hrb_walk=0)                                     # the per-block kernel
         for knobs in (dict(), dict(walk_waves=64), dict(walk_waves=2048), dict(walk_waves=4096),
                       dict(walk_dbg=4), dict(walk_dbg=5), dict(walk_dbg=4, walk_edge_steps=1, walk_waves=256),
-                      dict(walk_nt=1), dict(walk_nt=0, walk_waves=512)):
+                      dict(walk_nt=1), dict(walk_nt=0, walk_waves=512), dict(walk_wg=8), dict(walk_wg=2, walk_waves=96), dict(walk_wg=4, walk_dbg=4)):
             assert np.array_equal(base, run(**knobs)), knobs
         if shape == (4, 4, 0):                                     # the measurement variants of the headline shape
             for nt in (3, 5, 7):
@@ -760,7 +760,8 @@ def test_strip_walk_random_lattices_bit_identical(ctx):
             wrk = L.ChebyWrk(ctx, N, 26.0, -13.0, 0.9)
             outs = []
             for knobs in (dict(hrb_walk=0), dict(hrb_walk=1), dict(hrb_walk=1, walk_waves=int(rng.choice([16, 128, 1024, 4096])),
-                                                                   walk_dbg=int(rng.choice([0, 1, 4, 5])), walk_nt=int(rng.integers(0, 2)))):
+                                                                   walk_dbg=int(rng.choice([0, 1, 4, 5])), walk_nt=int(rng.integers(0, 2)),
+                                                                   walk_wg=int(rng.choice([0, 2, 4, 8])))):
                 for k, v in {**WALK_DEFAULTS, "walk_min_blocks": 8, **knobs}.items():
                     ctx.tuning_set(k, v)
                 psi = L.State(ctx, data=psi0)

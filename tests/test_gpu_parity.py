@@ -779,6 +779,41 @@ def test_strip_walk_random_lattices_bit_identical(ctx):
     assert n_walked >= 15
 
 
+def test_strip_walk_inside_a_replayed_graph(ctx):
+    """Knob `cheby_graph` with an operator that takes the strip walk: the walk's launch (dynamic LDS above 64 KB, opted in
+    per kernel instance and device) is captured and replayed like any other; same bits as the eager step, and the graph is
+    re-recorded when a walk knob changes the launch shape."""
+    N = 1 << 15
+    rp, col, vals = synth.hermitian_offsets_csr(N, offsets=(1, 2, 3, 4, 128, 256, 384, 512))
+    saved = {k: ctx.tuning_get(k) for k in WALK_KNOBS + ("cheby_graph",)}
+    try:
+        for k, v in {**WALK_DEFAULTS, "walk_min_blocks": 16}.items():
+            ctx.tuning_set(k, v)
+        Op = L.Operator(ctx, [L.Matrix(ctx, N, N, rp, col, vals)], 0, L.FMT_HRB)
+        assert Op.walk_info()["valid"] == 1
+        psi0 = synth.random_state(N)
+        wrk = L.ChebyWrk(ctx, N, 20.0, -10.0, 1.0)
+
+        def run(graph, **knobs):
+            for k, v in knobs.items():
+                ctx.tuning_set(k, v)
+            ctx.tuning_set("cheby_graph", 1 << 20 if graph else 0)
+            psi = L.State(ctx, data=psi0)
+            ctx.reset_stats()
+            for _ in range(5):
+                L.cheby(psi, Op, 1.0, wrk)
+            return psi.numpy(), ctx.stats()["n_graph_launches"]
+
+        eager, g0 = run(False)
+        replay, g1 = run(True)
+        assert g0 == 0 and g1 == 4 and np.array_equal(eager, replay)       # the first call arms the key, the second records
+        other, g2 = run(True, walk_waves=96, walk_wg=2)                    # a different launch shape: new key, new graph
+        assert g2 == 4 and np.array_equal(eager, other)
+    finally:
+        for k, v in saved.items():
+            ctx.tuning_set(k, v)
+
+
 def test_strip_walk_plan_only_for_lattices(ctx):
     """The walk plan is index work on the host: it exists only where every position it computes by formula is the position
     the per-block kernel would read -- not for scattered or per-row random columns, not for near distances beyond the LDS

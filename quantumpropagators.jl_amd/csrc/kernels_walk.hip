@@ -38,15 +38,18 @@ struct WalkGeom {
   int nseg = 0;        // segments of L steps per strip column
   int n_walk_wg = 0;
   int ntask = 0;       // wavefronts of the walk (n_walk_wg x wavefronts per workgroup)
-  // Edge blocks (outside the walkable run) are handed out one per wavefront -- edge block i to wavefront i, after its
-  // walk -- and the segments of those wavefronts are `edge_steps` steps shorter, about what a block on the per-block
-  // path costs: every wavefront finishes at about the same time (as workgroups of their own they cost 5-6 us per
-  // launch: whichever compute units ran them started or finished their walk that much later)
+  // Edge blocks (outside the walkable run), two schemes:
+  //  * beside the walk (n_edge_wg > 0): workgroups of their own at the head of the grid, one block per wavefront, while
+  //    every workgroup of the launch still finds room on the chip at once -- the walk is cut so that it does (768
+  //    wavefronts inside the Infinity Cache, 8 per CU on all but the CUs the edge workgroups take beyond it);
+  //  * inside the walk (n_edge_wg == 0; knob walk_waves / walk_dbg): edge block i goes to wavefront i, BEFORE its walk
+  //    (edge_last: after), and the segments of those wavefronts are `edge_steps` steps shorter -- a block on the per-block
+  //    path is three dependent rounds of loads, a step of the walk about one -- so that every wavefront finishes at
+  //    about the same time.  (As leading workgroups of a launch that fills every CU they cost 5-6 us: whichever compute
+  //    units ran them started their walk that much later.)
   int edge_segs = 0;   // segments 0 .. edge_segs - 1 are the shorter ones
   int edge_steps = 0;
-  int edge_last = 0;   // the edge block after the walk instead of before it
-  // ... unless the walk leaves compute units free (an operator that fits the Infinity Cache takes half of them): then the
-  // edge blocks are workgroups of their own at the head of the grid, eight blocks each, and run beside the walk
+  int edge_last = 0;
   int n_edge_wg = 0;
 };
 
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __r
   const int Jc = col < nW ? (int)((nW - col + S - 1) / S) : 0;
   const int j0 = seg * G.L - min(seg, G.edge_segs) * G.edge_steps;
   const int j1 = min((seg + 1) * G.L - min(seg + 1, G.edge_segs) * G.edge_steps, Jc);
-  // this wavefront's edge block(s) first: three rounds of latency, about one step of the walk (see WalkGeom)
+  // this wavefront's edge block(s) first (see WalkGeom)
   if (!G.edge_last && G.n_edge_wg == 0)
     for (int64_t idx = task; idx < P.n_edge; idx += G.ntask)
       hrb_edge_block<VT>(H, uvals, x, (int64_t)__builtin_amdgcn_readfirstlane(P.edge_map[idx]), lane, nrows, op);

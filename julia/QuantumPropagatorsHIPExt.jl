@@ -221,6 +221,23 @@ function set_coeffs!(op::Handle, coeffs::Vector{ComplexF64})
         (Ptr{Cvoid}, Ptr{C128}, Cint), op, coeffs, length(coeffs)))
 end
 
+# What laying the operator out on the device cost and how it is laid out now (include/qprop.h): host milliseconds of the
+# latest / of all builds, re-layouts forced after creation -- a complex coefficient takes a Hermitian-packed operator back
+# to plain row blocks, once, with a slower mat-vec from then on --, and the current device format.
+function operator_build_info(op::Handle)
+    out = zeros(Cdouble, 4)
+    GC.@preserve out check(ccall((:qp_operator_build_info, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), op, out))
+    return (build_ms = out[1], build_ms_total = out[2], relayouts = Int(out[3]), format = Int(out[4]))
+end
+
+# Strip-walk plan of a Hermitian-packed lattice operator (the fused Chebyshev term then runs csrc/kernels_walk.hip)
+function operator_walk_info(op::Handle)
+    out = zeros(Int64, 8)
+    GC.@preserve out check(ccall((:qp_operator_walk_info, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}), op, out))
+    return (valid = out[1] != 0, near = Int(out[2]), far = Int(out[3]), diagonal = out[4] != 0, blocks_per_step = Int(out[5]),
+            first_block = out[6], end_block = out[7], edge_blocks = out[8])
+end
+
 # mul!(C, A::Operator, B, α, β) on device vectors   src/generators.jl:634-645
 function hip_mul!(y::HIPState, op::Handle, x::HIPState, α::Number = true, β::Number = false)
     check(ccall((:qp_mul, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, C128, C128),

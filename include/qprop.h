@@ -266,6 +266,10 @@ typedef struct qp_split qp_split;
 int qp_split_create(qp_operator* op, const int64_t* send_rows, int64_t nsend, qp_split** out);
 int qp_split_destroy(qp_split* sp);
 int qp_split_info(const qp_split* sp, int64_t* n_boundary_blocks, int64_t* n_interior_blocks);
+/* The interior launch as a strip walk (lattice operators, see qp_operator_walk_info): out[0] = 1 if the split has a walk
+ * plan, out[1], out[2] = the walked row blocks [first, end) -- inside the interior, no walked block reads a boundary row --,
+ * out[3] = interior blocks on the per-block path (the only ones that wait for the boundary launch). */
+int qp_split_walk_info(const qp_split* sp, int64_t out[4]);
 /* device sync + check that no in-launch wait of the split schedule ever timed out */
 int qp_split_check(qp_split* sp);
 int qp_cheby_term_split(qp_operator* op, qp_split* sp, void* boundary_stream, int first,

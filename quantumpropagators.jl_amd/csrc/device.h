@@ -137,6 +137,11 @@ struct RowSet {
   int64_t nmap = 0;
   bool count = true;                   // count this launch as a mat-vec in the stats
   SyncArgs sync;
+  // the same set of blocks as a strip walk (interior launch of a split term; engine_cheby.hip: qp_split_create): a plan
+  // whose walkable run lies inside the set and never reads a row of the complementary set, its edge list = the rest of the
+  // set.  Only the edge blocks can depend on the other launch: they wait (sync.wait), the walk itself does not.
+  const struct WalkPlan* walk = nullptr;
+  int reserve_cu = 0;                  // compute units the walk leaves free for what runs beside it (the other launch, the collective)
 };
 
 struct PlainEpi {
@@ -170,7 +175,7 @@ int launch_spmv_plain(hipStream_t s, const DevMatrix& A, const double2* x, const
 // plan's shape has no kernel instance (the caller then takes the per-block kernel)
 bool walk_shape_supported(int nn, int K, int z0);   // is there a kernel instance for this stencil shape?
 int launch_hrb_walk_cheby(hipStream_t s, const DevMatrix& A, const double2* x, const ChebyEpi& e, const Tuning& tun,
-                          bool* launched);
+                          bool* launched, const RowSet* rs = nullptr);
 int spmv_grid_size(const DevMatrix& A);
 // Developer knobs for A/B measurements.  Every context carries its own copy (qp_ctx::tun, set with
 // qp_ctx_tuning_set); qp_tuning_set only changes the defaults that contexts created afterwards start

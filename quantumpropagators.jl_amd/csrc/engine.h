@@ -113,6 +113,9 @@ struct qp_split {   // boundary / interior partition of an operator's row blocks
   unsigned signals_issued = 0;
   unsigned wait_from_wg = 0;          // interior workgroups at or beyond this position poll
   unsigned n_waiting_wg = 0;          // how many of them there are
+  // the interior set as a strip walk (lattice operators): a run inside the interior that never reads a boundary row, the
+  // rest of the interior as its edge blocks (only they wait for the boundary launch)
+  qp::WalkPlan walk;
 };
 // QP_E_INTERNAL once an in-launch wait of this split has ever timed out (no synchronisation)
 int split_timed_out(const qp_split* sp);

@@ -467,6 +467,33 @@ int qp_split_create(qp_operator* op, const int64_t* send_rows, int64_t nsend, qp
   QP_HIP(hipHostMalloc((void**)&sp->timeout_host, sizeof(unsigned), hipHostMallocMapped));
   *sp->timeout_host = 0;
   QP_HIP(hipHostGetDevicePointer((void**)&sp->timeout_dev, sp->timeout_host, 0));
+  // Interior as a strip walk.  The boundary blocks of a row-partitioned lattice are a prefix and a suffix of the local
+  // rows; the walk takes the interior blocks from which no walked row block, with its ring of +-K strip steps and its
+  // one-block halo, reaches a boundary block: [max(W0, lo + K S + 1), min(R1, hi - K S - 1)).
+  sp->walk = qp::WalkPlan();
+  if (op->A.walk && op->A.walk->valid && op->A.format == QP_FMT_HRB) {
+    const qp::WalkPlan& P = *op->A.walk;
+    int64_t lo = 0, hi = A.nblocks;
+    while (lo < A.nblocks && is_boundary[lo]) ++lo;
+    while (hi > lo && is_boundary[hi - 1]) --hi;
+    bool contiguous = true;
+    for (int64_t b = lo; b < hi && contiguous; ++b) contiguous = !is_boundary[b];
+    const int64_t reach = (int64_t)P.K * P.S + 1;
+    const int64_t w0 = std::max(P.W0, lo + reach), r1 = std::min(P.R1, hi - reach);
+    if (contiguous && r1 - w0 >= 8) {
+      std::vector<int32_t> edge;
+      for (int32_t b : bi)
+        if (b < w0 || b >= r1) edge.push_back(b);
+      qp::WalkPlan W = P;
+      W.W0 = w0;
+      W.R1 = r1;
+      W.edge_map = nullptr;
+      W.n_edge = (int64_t)edge.size();
+      QP_CHECK(dev_alloc(&W.edge_map, std::max<size_t>(edge.size(), 1)));
+      if (!edge.empty()) QP_HIP(hipMemcpy(W.edge_map, edge.data(), edge.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+      sp->walk = W;
+    }
+  }
   sp->wait_from_wg = wait_from_wg;
   {
     const unsigned total = (unsigned)((bi.size() + qp::kThreads / 64 - 1) / (qp::kThreads / 64));
@@ -485,6 +512,7 @@ int qp_split_destroy(qp_split* sp) {
   if (sp->bmap_boundary) (void)hipFree(sp->bmap_boundary);
   if (sp->bmap_interior) (void)hipFree(sp->bmap_interior);
   if (sp->mirror) (void)hipFree(sp->mirror);
+  if (sp->walk.edge_map) (void)hipFree(sp->walk.edge_map);
   if (sp->counter) (void)hipFree(sp->counter);
   if (sp->timeout_host) (void)hipHostFree(sp->timeout_host);
   if (sp->ev_b) (void)hipEventDestroy(sp->ev_b);
@@ -498,6 +526,15 @@ int qp_split_info(const qp_split* sp, int64_t* n_boundary_blocks, int64_t* n_int
   if (!sp) return qp::fail(QP_E_BAD_ARG, "split is NULL");
   if (n_boundary_blocks) *n_boundary_blocks = sp->n_boundary;
   if (n_interior_blocks) *n_interior_blocks = sp->n_interior;
+  return QP_OK;
+}
+
+int qp_split_walk_info(const qp_split* sp, int64_t out[4]) {
+  if (!sp || !out) return qp::fail(QP_E_BAD_ARG, "qp_split_walk_info: NULL argument");
+  out[0] = sp->walk.valid ? 1 : 0;
+  out[1] = sp->walk.valid ? sp->walk.W0 : 0;
+  out[2] = sp->walk.valid ? sp->walk.R1 : 0;
+  out[3] = sp->walk.valid ? sp->walk.n_edge : 0;
   return QP_OK;
 }
 
@@ -545,6 +582,10 @@ int qp_cheby_term_split(qp_operator* op, qp_split* sp, void* boundary_stream, in
   set_defer(e, defer);
   qp::RowSet rb{sp->bmap_boundary, sp->n_boundary, false};
   qp::RowSet ri{sp->bmap_interior, sp->n_interior, true};
+  if (sp->walk.valid) {   // lattice operator: the interior as a strip walk; 8 CUs beyond the edge workgroups' stay free for
+    ri.walk = &sp->walk;  // the boundary launch and the collective's kernel that run beside it
+    ri.reserve_cu = 8;
+  }
   QP_CHECK(split_timed_out(sp));
   // knob split_mode: 1 = in-launch counter hand-off, 0 = events on both streams, 2 (default) = the counter
   // where it is safe by construction: the polling workgroups hold their CU slots while the boundary launch

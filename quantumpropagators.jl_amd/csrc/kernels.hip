@@ -1248,15 +1248,18 @@ static int launch_spmv(hipStream_t s, const DevMatrix& A, const double2* x, cons
     if constexpr (std::is_same<Op, ChebyOp>::value) {
       // a lattice operator (one stencil repeated down the row blocks): the strip walk (kernels_walk.hip) -- whole operator,
       // no normalisation check, the gathered vector's own rows being the row-local operand; same sums as the kernels below
-      if (tun.hrb_walk && A.walk && A.walk->valid && wide_ok && !rs && !tun.hrb_lower_last && (tun.rbcsr_variant & 31) == 15 &&
+      // ... or the interior launch of a split term whose row set carries a plan of its own (RowSet::walk)
+      const bool whole = !rs && A.walk && A.walk->valid;
+      const bool set_walk = rs && rs->walk && rs->walk->valid && !rs->sync.signal;
+      if (tun.hrb_walk && (whole || set_walk) && wide_ok && !tun.hrb_lower_last && (tun.rbcsr_variant & 31) == 15 &&
           op.e.xloc == x && !op.e.mirror) {
         bool launched = false;
-        const int rcw = launch_hrb_walk_cheby(s, A, x, op.e, tun, &launched);
+        const int rcw = launch_hrb_walk_cheby(s, A, x, op.e, tun, &launched, rs);
         if (rcw != QP_OK) return rcw;
         if (launched) {
           if (st) {
             st->n_launch++;
-            st->n_matvec++;
+            if (!rs || rs->count) st->n_matvec++;
           }
           return QP_OK;
         }

@@ -215,11 +215,31 @@ struct WalkLds {
   static constexpr size_t kBytesPerWave = sizeof(double2) * (size_t)kPerWave;
 };
 
+// One wavefront waits for the other launch of a split term (the per-wavefront form of kernel_common.h: sync_wait): lane 0
+// polls the completion counter with a bounded spin, the wavefront then acquires at agent scope.  Only wavefronts that
+// are about to take an EDGE block call it (the walk of a row set never reads a row of the other launch).
+__device__ __forceinline__ void wave_sync_wait(const SyncArgs& sy) {
+  if (!sy.wait) return;
+  if ((threadIdx.x & 63) == 0) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(sy.wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sy.wait_target) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > sy.spin_limit) {
+        if (sy.timeout_flag) __hip_atomic_store(sy.timeout_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // NTM: nontemporal accesses (bit 0: the matrix values, bit 1: the vector loads, bit 2: the stores)
 template <class VT, int NN, int K, int Z0, int NTM>
 __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __restrict__ uvals,
                                                                     const double2* __restrict__ x, WalkPlan P,
-                                                                    WalkGeom G, HrbArrays H, int64_t nrows, ChebyOp op) {
+                                                                    WalkGeom G, HrbArrays H, int64_t nrows, ChebyOp op,
+                                                                    SyncArgs sy) {
   constexpr int NL = NN + K;         // lower slots: [-K g .. -g] [-d_NN .. -d_1]
   constexpr int NU = Z0 + NN + K;    // upper slots that carry entries: [0] [d_1 .. d_NN] [g .. K g]
   using Lds = WalkLds<NN, K>;
@@ -231,8 +251,10 @@ __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __r
   const int lane = threadIdx.x & 63;
   if ((int)blockIdx.x < G.n_edge_wg) {
     const int64_t idx = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
-    if (idx < P.n_edge)
+    if (idx < P.n_edge) {
+      wave_sync_wait(sy);
       hrb_edge_block<VT>(H, uvals, x, (int64_t)__builtin_amdgcn_readfirstlane(P.edge_map[idx]), lane, nrows, op);
+    }
     return;
   }
   const unsigned wg = xcd_remap(blockIdx.x - G.n_edge_wg, G.n_walk_wg);
@@ -244,9 +266,11 @@ __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __r
   const int j0 = seg * G.L - min(seg, G.edge_segs) * G.edge_steps;
   const int j1 = min((seg + 1) * G.L - min(seg + 1, G.edge_segs) * G.edge_steps, Jc);
   // this wavefront's edge block(s) first (see WalkGeom)
-  if (!G.edge_last && G.n_edge_wg == 0)
+  if (!G.edge_last && G.n_edge_wg == 0 && task < P.n_edge) {
+    wave_sync_wait(sy);
     for (int64_t idx = task; idx < P.n_edge; idx += G.ntask)
       hrb_edge_block<VT>(H, uvals, x, (int64_t)__builtin_amdgcn_readfirstlane(P.edge_map[idx]), lane, nrows, op);
+  }
   if (seg < G.nseg && j0 < j1) {
   const int64_t g = (int64_t)kRB * S;
   const int dmax = P.near[NN - 1];
@@ -393,14 +417,16 @@ __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __r
     step(wa, wb, std::false_type());
   }
   }
-  if (G.edge_last && G.n_edge_wg == 0)
+  if (G.edge_last && G.n_edge_wg == 0 && task < P.n_edge) {
+    wave_sync_wait(sy);
     for (int64_t idx = task; idx < P.n_edge; idx += G.ntask)
       hrb_edge_block<VT>(H, uvals, x, (int64_t)__builtin_amdgcn_readfirstlane(P.edge_map[idx]), lane, nrows, op);
+  }
 }
 
 template <class VT, int NN, int K, int Z0, int NTM = 0>
 static bool launch_instance(hipStream_t s, dim3 grid, const VT* uvals, const double2* x, const WalkPlan& P,
-                            const WalkGeom& G, const HrbArrays& H, int64_t nrows, const ChebyOp& op) {
+                            const WalkGeom& G, const HrbArrays& H, int64_t nrows, const ChebyOp& op, const SyncArgs& sy) {
   const int ws = G.ntask / std::max(G.n_walk_wg, 1);      // wavefronts per workgroup of this launch
   const size_t lds = WalkLds<NN, K>::kBytesPerWave * (size_t)ws;
   constexpr size_t lds_max = WalkLds<NN, K>::kBytesPerWave * kWalkWaves;
@@ -417,23 +443,23 @@ static bool launch_instance(hipStream_t s, dim3 grid, const VT* uvals, const dou
     opted[dev].store(st, std::memory_order_release);
   }
   if (st != 1) return false;
-  hipLaunchKernelGGL(kern, grid, dim3(64 * ws), lds, s, uvals, x, P, G, H, nrows, op);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * ws), lds, s, uvals, x, P, G, H, nrows, op, sy);
   return true;
 }
 
 template <class VT>
 static bool launch_shape(hipStream_t s, dim3 grid, const VT* uvals, const double2* x, const WalkPlan& P,
-                         const WalkGeom& G, const HrbArrays& H, int64_t nrows, const ChebyOp& op, int ntm) {
+                         const WalkGeom& G, const HrbArrays& H, int64_t nrows, const ChebyOp& op, int ntm, const SyncArgs& sy) {
   const int key = P.nn * 100 + P.K * 10 + P.z0;
 #define QP_WALK_SHAPE(NN_, K_, Z0_)                                                                       \
-  return (ntm & 1) ? launch_instance<VT, NN_, K_, Z0_, 1>(s, grid, uvals, x, P, G, H, nrows, op)            \
-                   : launch_instance<VT, NN_, K_, Z0_, 0>(s, grid, uvals, x, P, G, H, nrows, op);
+  return (ntm & 1) ? launch_instance<VT, NN_, K_, Z0_, 1>(s, grid, uvals, x, P, G, H, nrows, op, sy)            \
+                   : launch_instance<VT, NN_, K_, Z0_, 0>(s, grid, uvals, x, P, G, H, nrows, op, sy);
   switch (key) {
     case 440:
       switch (ntm) {   // (measurement variants of the headline shape)
-        case 3: return launch_instance<VT, 4, 4, 0, 3>(s, grid, uvals, x, P, G, H, nrows, op);
-        case 7: return launch_instance<VT, 4, 4, 0, 7>(s, grid, uvals, x, P, G, H, nrows, op);
-        case 5: return launch_instance<VT, 4, 4, 0, 5>(s, grid, uvals, x, P, G, H, nrows, op);
+        case 3: return launch_instance<VT, 4, 4, 0, 3>(s, grid, uvals, x, P, G, H, nrows, op, sy);
+        case 7: return launch_instance<VT, 4, 4, 0, 7>(s, grid, uvals, x, P, G, H, nrows, op, sy);
+        case 5: return launch_instance<VT, 4, 4, 0, 5>(s, grid, uvals, x, P, G, H, nrows, op, sy);
         default: break;
       }
       QP_WALK_SHAPE(4, 4, 0)
@@ -453,9 +479,11 @@ bool walk_shape_supported(int nn, int K, int z0) {
 }
 
 int launch_hrb_walk_cheby(hipStream_t s, const DevMatrix& A, const double2* x, const ChebyEpi& e, const Tuning& tun,
-                          bool* launched) {
+                          bool* launched, const RowSet* rs) {
   *launched = false;
-  const WalkPlan* P = A.walk;
+  const WalkPlan* P = (rs && rs->walk) ? rs->walk : A.walk;
+  const SyncArgs sy = rs ? rs->sync : SyncArgs();
+  const int reserve = rs ? rs->reserve_cu : 0;
   if (!P || !P->valid || A.format != QP_FMT_HRB) return QP_OK;
   const int64_t nW = P->R1 - P->W0;
   if (nW < tun.walk_min_blocks || nW < P->S) return QP_OK;
@@ -474,12 +502,12 @@ int launch_hrb_walk_cheby(hipStream_t s, const DevMatrix& A, const double2* x, c
   // leave more than an eighth of the chip to them (profiles/r03/kbench_walk_development.txt: 2^21 rows 71.4 -> 68.5 us,
   // 2^22 126.0 -> 121.8, 2^23 275 -> 278)
   const int ws = (tun.walk_wg == 8 || tun.walk_wg == 4 || tun.walk_wg == 2) ? tun.walk_wg : (resident ? 4 : kWalkWaves);            // wavefronts per workgroup (two 4-wavefront workgroups fit a CU)
-  const int64_t wg_slots = (int64_t)tun.n_cu * (kWalkWaves / ws);  // workgroups the chip holds at once
+  const int64_t wg_slots = (int64_t)std::max(tun.n_cu - reserve, 8) * (kWalkWaves / ws);  // workgroups the walk may hold at once
   const int64_t edge_wgs_all = (P->n_edge + ws - 1) / ws;
   const int waves_beside = (int)(ws * std::max<int64_t>(0, wg_slots - edge_wgs_all)) / P->S * P->S;
   const int waves = tun.walk_waves > 0 ? tun.walk_waves
                     : resident ? 768
-                    : (waves_beside >= 7 * kWalkWaves * tun.n_cu / 8 ? waves_beside : kWalkWaves * tun.n_cu);
+                    : ((rs || waves_beside >= 7 * kWalkWaves * tun.n_cu / 8) ? std::max(waves_beside, P->S) : kWalkWaves * tun.n_cu);
   const int ntm = tun.walk_nt >= 0 ? tun.walk_nt : (resident ? 0 : 1);
   const int64_t nseg_target = std::max<int64_t>(1, waves / P->S);
   const bool no_edges = (tun.walk_dbg & 2) != 0;
@@ -504,8 +532,8 @@ int launch_hrb_walk_cheby(hipStream_t s, const DevMatrix& A, const double2* x, c
   const dim3 grid((unsigned)(G.n_edge_wg + G.n_walk_wg));
   WalkPlan Pl = *P;
   if (tun.walk_dbg & 2) Pl.n_edge = 0;   // (measurement only: results are wrong)
-  const bool ok = A.vals_r ? launch_shape<double>(s, grid, A.vals_r, x, Pl, G, H, A.nrows, op, ntm)
-                           : launch_shape<double2>(s, grid, A.vals, x, Pl, G, H, A.nrows, op, ntm);
+  const bool ok = A.vals_r ? launch_shape<double>(s, grid, A.vals_r, x, Pl, G, H, A.nrows, op, ntm, sy)
+                           : launch_shape<double2>(s, grid, A.vals, x, Pl, G, H, A.nrows, op, ntm, sy);
   if (!ok) return QP_OK;
   QP_HIP(hipGetLastError());
   *launched = true;

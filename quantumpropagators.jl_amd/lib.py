@@ -157,6 +157,7 @@ SIGNATURES = {
     "qp_split_create": (C.c_int, [_P, _i64p, C.c_int64, C.POINTER(_P)]),
     "qp_split_destroy": (C.c_int, [_P]),
     "qp_split_info": (C.c_int, [_P, _i64p, _i64p]),
+    "qp_split_walk_info": (C.c_int, [_P, _i64p]),
     "qp_split_check": (C.c_int, [_P]),
     "qp_cheby_term_split": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_int64, _P, _P, _P, _P, _P, qp_c128, C.c_double,
                                       C.c_double, C.c_double, qp_c128, C.POINTER(qp_acc_defer)]),
@@ -844,6 +845,12 @@ class Split:
 
     def check(self):
         check(self.lib.qp_split_check(self._h))
+
+    def walk_info(self):
+        """The interior launch as a strip walk: (valid, first walked block, end, interior blocks on the per-block path)."""
+        out = np.zeros(4, dtype=np.int64)
+        check(self.lib.qp_split_walk_info(self._h, _ptr(out, _i64p)))
+        return dict(zip(("valid", "first_block", "end_block", "edge_blocks"), (int(v) for v in out)))
 
     def close(self):
         if self._h:

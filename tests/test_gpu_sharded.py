@@ -139,6 +139,59 @@ def test_sharded_overlap_machinery_world1(pg, overlap, split_mode):
     ctx.close()
 
 
+@pytest.mark.parametrize("split_mode", [2, 1, 0])
+def test_split_interior_as_strip_walk_world1(pg, split_mode):
+    """A lattice operator's interior launch takes the strip walk (kernels_walk.hip) over the interior blocks from which no
+    walked block reaches a boundary row; the rest of the interior are its edge blocks, the only ones that wait for the
+    boundary launch.  One rank with a forced send set (first and last 4096 rows, like config C4's halo): every hand-off
+    mode gives the bits of the serial schedule -- which walks the whole operator -- and of the per-block kernels."""
+    import torch
+    from oracle import qp_oracle as qo
+    import qprop_amd.lib as L
+    import qprop_amd.sharded as sharded
+    import qprop_amd.synth as synth
+    N = 1 << 17
+    rp, col, vals = synth.hermitian_offsets_csr(N, offsets=(1, 2, 3, 4, 256, 512, 768, 1024))
+    ctx = L.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    send = np.concatenate([np.arange(0, 4096), np.arange(N - 4096, N)])
+    psi0 = synth.random_state(N)
+    outs = {}
+    try:
+        ctx.tuning_set("walk_min_blocks", 64)
+        ctx.tuning_set("split_mode", split_mode)
+        for name, overlap, walk in (("overlap+walk", True, 1), ("serial+walk", False, 1), ("overlap, per-block", True, 0)):
+            ctx.tuning_set("hrb_walk", walk)
+            sh = sharded.ShardedCheby(ctx, rp, col, vals, N, 0, N, 20.0, -10.0, 1.0, exchange="halo", overlap=overlap,
+                                      _debug_send_rows=send, fmt=L.FMT_HRB)
+            if overlap:
+                wi = sh.split.walk_info()
+                nb = N // 64
+                assert wi["valid"] == 1 and 64 + 16 < wi["first_block"] < wi["end_block"] < nb - 64 - 16
+                assert wi["edge_blocks"] == sh.split.n_interior - (wi["end_block"] - wi["first_block"])
+            sh.set_state(psi0)
+            for _ in range(3):
+                sh.step()
+            sh.step(backward=True)
+            torch.cuda.synchronize()
+            sh.check() if overlap else None
+            outs[name] = sh.local_state()
+            sh.close()
+    finally:
+        ctx.tuning_set("hrb_walk", 1)
+        ctx.tuning_set("walk_min_blocks", 3072)
+        ctx.tuning_set("split_mode", 2)
+    assert np.array_equal(outs["overlap+walk"], outs["serial+walk"])
+    assert np.array_equal(outs["overlap+walk"], outs["overlap, per-block"])
+    H = synth.to_scipy(rp, col, vals, N)
+    wrk = qo.ChebyWrk(psi0, 20.0, -10.0, 1.0)
+    ref = psi0.copy()
+    for _ in range(3):
+        qo.cheby(ref, H, 1.0, wrk)
+    qo.cheby(ref, H, -1.0, wrk)
+    assert np.linalg.norm(outs["overlap+walk"] - ref) < 1e-10
+    ctx.close()
+
+
 def test_split_wait_timeout_is_reported_not_hung(pg):
     """The in-launch hand-off boundary(m) -> interior(m + 1) polls a counter with a bounded spin.  Forced failure: the
     boundary launches do not signal (knob split_dbg) and the bound is lowered to 2^10 polls (knob split_spin_log2): the

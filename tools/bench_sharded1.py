@@ -13,9 +13,10 @@ s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.clos
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-N = 1 << 20
+N = 1 << int(os.environ.get("QP_LOG2N", "20"))
 rp, col, vals = synth.hermitian_offsets_csr(N)
 ctx = L.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+ctx.tuning_set("hrb_walk", int(os.environ.get("QP_HRB_WALK", "1")))      # 0: the per-block kernels everywhere (A/B of the strip walk)
 psi0 = synth.random_state(N)
 send = np.concatenate([np.arange(0, 4096), np.arange(N - 4096, N)])
 K = int(os.environ.get("QP_STEPS", "30"))

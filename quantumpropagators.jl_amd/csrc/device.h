@@ -206,6 +206,7 @@ struct Tuning {
   int spmm_strip = 0;         // batched SpMM row walk: inner-index strip width (0 = chosen from the L2 size; -1 = natural row order)
   int hrb_walk = 1;           // Hermitian-packed fused term of a whole lattice operator: the strip-walk kernel (kernels_walk.hip) when the operator has a walk plan
   int walk_waves = 0;         // strip walk: wavefronts the walk is cut into (0: 768 for an operator that fits the Infinity Cache, else 8 per CU on every CU the edge workgroups leave free -- 1856 for the headline lattice --, or 2048 with the edge blocks inside the walk)
+  int walk_reserve_cu = 8;    // strip walk as the interior launch of a split term: compute units left free (beyond the edge workgroups') for the boundary launch and the collective's kernel
   int walk_wg = 0;            // strip walk: wavefronts per workgroup (0: 4 for an operator that fits the Infinity Cache, else 8; or 8 / 4 / 2)
   int walk_nt = -1;           // strip walk: nontemporal accesses (-1: the matrix values when the operator does not fit the Infinity Cache; bit 0 matrix values; bits 1, 2: vector loads, stores -- measurement variants of the headline shape)
   int walk_edge_steps = 4;    // strip walk: a wavefront that also takes an edge block walks this many steps less (a block on the per-block path is three dependent rounds of loads; a step of the walk takes about one)

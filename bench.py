@@ -651,6 +651,10 @@ def main():
         exchange_used = sh.exchange
         fmt_used = sh.op.format
         kernel_used = KERNEL_OF_FORMAT[fmt_used]
+        if sh.split is not None and sh.split.walk_info()["valid"]:
+            kernel_used = "hrb_walk_kernel (interior set) + " + kernel_used + " (boundary set)"
+        elif sh.split is None:
+            kernel_used = bp.cheby_kernel_name(sh.op)
         build_ms = sh.op.build_info()
     else:
         strong = None

@@ -548,99 +548,90 @@ static int64_t decode_lower_stencil_pos(const std::vector<char>& bytes, const st
   return ((c >> 6) == e.cb0 ? e.pb0 : e.pb1) + (c & 63);
 }
 
-// Strip-walk plan of a Hermitian-packed lattice operator (device.h: WalkPlan; kernels_walk.hip).  Looks for the longest
-// run of row blocks that carry one and the same stencil in both sections, checks that the stencil has the shape the walk
-// needs and that every position the per-block kernel would read through the lower stencil records is the position the
-// walk computes by formula, and lists the remaining blocks.  Index work only: host, exact.
-static int build_walk_plan(qp_operator* op, const std::vector<char>& cbytes, const std::vector<char>& lbytes) {
+// Strip-walk plan of a Hermitian-packed lattice operator (device.h: WalkPlan; kernels_walk.hip).  Looks, in the union
+// pattern itself, for the longest run of row blocks in which every row has the same list of column distances, checks that
+// the list has the shape the walk needs -- [-K g .. -g] [-d_nn .. -d_1] [0]? [d_1 .. d_nn] [g .. K g], g a multiple of 64
+// rows -- and that the upper values of the run's blocks lie at equal strides.  With one stencil on every row of the run the
+// position of every value, and of every conj-transposed value, is a formula; how the column sections of those blocks are
+// encoded does not matter (the walk reads none of them).  The remaining blocks are listed for the per-block path.
+// Index work only: host, exact.
+static int build_walk_plan(qp_operator* op) {
   qp::WalkPlan& P = op->walk;
   if (P.edge_map) (void)hipFree(P.edge_map);
   P = qp::WalkPlan();
   DevMatrix& A = op->A;
   A.walk = nullptr;
   const HostLayout& Lh = op->layout;
+  const auto& ur = op->u_rowptr;
+  const auto& uc = op->u_col;
   const int64_t nb = A.nblocks;
-  if (A.format != QP_FMT_HRB || nb < 8) return QP_OK;
-  auto width = [&](const std::vector<int64_t>& ptr, int64_t b) { return (ptr[b + 1] - ptr[b]) / kRB; };
-  auto udelta = [&](int64_t b, int64_t k) {
-    int32_t d;
-    std::memcpy(&d, &cbytes[(size_t)(Lh.cmeta[b] >> 2) + (size_t)k * 4], 4);
-    return d;
-  };
-  auto lslot = [&](int64_t b, int64_t k) {
-    LowerStencilSlot e;
-    std::memcpy(&e, &lbytes[(size_t)(Lh.lcmeta[b] >> 2) + (size_t)k * sizeof(LowerStencilSlot)], sizeof(e));
-    return e;
-  };
-  auto same = [&](int64_t b, int64_t r) {   // does block b carry block r's stencil?
-    if ((Lh.cmeta[b] & 3) != kColStencil || (Lh.lcmeta[b] & 3) != kColStencil) return false;
-    const int64_t wu = width(Lh.bptr, r), wl = width(Lh.lptr, r);
-    if (width(Lh.bptr, b) != wu || width(Lh.lptr, b) != wl) return false;
-    for (int64_t k = 0; k < wu; ++k)
-      if (udelta(b, k) != udelta(r, k)) return false;
-    for (int64_t k = 0; k < wl; ++k)
-      if (lslot(b, k).delta != lslot(r, k).delta) return false;
+  if (A.format != QP_FMT_HRB || nb < 8 || A.ncols != A.nrows) return QP_OK;
+  const int64_t nfull = A.nrows / kRB;   // (a partly filled last block never belongs to the run)
+  auto same_row = [&](int64_t r, int64_t ref) {   // same distances as row `ref`?
+    const int64_t len = ur[ref + 1] - ur[ref];
+    if (ur[r + 1] - ur[r] != len) return false;
+    const int32_t* a = uc.data() + ur[r];
+    const int32_t* c = uc.data() + ur[ref];
+    const int64_t shift = r - ref;
+    for (int64_t k = 0; k < len; ++k)
+      if ((int64_t)a[k] - (int64_t)c[k] != shift) return false;
     return true;
   };
-  // longest run (a partly filled last block never belongs to it)
-  const int64_t nfull = A.nrows / kRB;
   int64_t best0 = 0, best1 = 0;
   for (int64_t b = 0; b < nfull;) {
-    if ((Lh.cmeta[b] & 3) != kColStencil || (Lh.lcmeta[b] & 3) != kColStencil) {
+    const int64_t ref = b * kRB;
+    if (ur[ref + 1] - ur[ref] < 3 || ur[ref + 1] - ur[ref] > 17) {
       ++b;
       continue;
     }
-    int64_t e = b + 1;
-    while (e < nfull && same(e, b)) ++e;
+    int64_t e = b;
+    for (;;) {   // extend while every row of block e carries row ref's distances
+      if (e >= nfull) break;
+      bool ok = true;
+      for (int64_t r = e * kRB; r < (e + 1) * kRB && ok; ++r) ok = same_row(r, ref);
+      if (!ok) break;
+      ++e;
+    }
     if (e - b > best1 - best0) best0 = b, best1 = e;
-    b = e;
+    b = std::max(e, b + 1);
   }
   if (best1 - best0 < 8) return QP_OK;
-  const int64_t R0 = best0, R1 = best1;
-  const int64_t wu = width(Lh.bptr, R0), wl = width(Lh.lptr, R0);
-  if (wl < 4 || wu < wl || wu > 16) return QP_OK;
-  // upper: [z0 x 0] [near 0 < d <= 16 ascending] [far g, 2 g, .., K g] [pads: 0]
-  std::vector<int32_t> ud((size_t)wu), ld((size_t)wl);
-  for (int64_t k = 0; k < wu; ++k) ud[(size_t)k] = udelta(R0, k);
-  for (int64_t k = 0; k < wl; ++k) ld[(size_t)k] = lslot(R0, k).delta;
+  const int64_t R0 = best0, R1 = best1, rref = R0 * kRB;
+  const int64_t z = ur[rref + 1] - ur[rref];
+  std::vector<int64_t> dl((size_t)z);
+  for (int64_t k = 0; k < z; ++k) dl[(size_t)k] = (int64_t)uc[ur[rref] + k] - rref;
+  // negatives: far then near; the diagonal; positives: near then far -- mirror images of each other
   int64_t k = 0;
-  int z0 = 0, nn = 0, K = 0;
-  while (k < wu && ud[(size_t)k] == 0 && k < 1) ++k, ++z0;
-  while (k < wu && ud[(size_t)k] > 0 && ud[(size_t)k] <= qp::kWalkHalo && nn < qp::kWalkMaxNear &&
-         (nn == 0 || ud[(size_t)k] > P.near[nn - 1])) P.near[nn++] = ud[(size_t)k++];
-  if (nn == 0 || k >= wu) return QP_OK;
-  const int64_t g = ud[(size_t)k];
-  if (g < kRB || g % kRB != 0) return QP_OK;
-  while (k < wu && ud[(size_t)k] == (int64_t)(K + 1) * g) ++k, ++K;
-  for (int64_t q = k; q < wu; ++q)
-    if (ud[(size_t)q] != 0) return QP_OK;          // what is left must be padding
-  if (K < 1 || nn + K != wl || !qp::walk_shape_supported(nn, K, z0)) return QP_OK;
-  // lower: the mirror image [-K g .. -g] [-d_nn .. -d_1]
-  for (int m = K; m >= 1; --m)
-    if (ld[(size_t)(K - m)] != -(int64_t)m * g) return QP_OK;
+  int K = 0, nn = 0, z0 = 0;
+  while (k < z && dl[(size_t)k] <= -(int64_t)kRB) ++k, ++K;
+  if (K < 1 || K > 4) return QP_OK;
+  const int64_t g = -dl[(size_t)(K - 1)];
+  if (g % kRB != 0) return QP_OK;
+  for (int m = 1; m <= K; ++m)
+    if (dl[(size_t)(K - m)] != -(int64_t)m * g) return QP_OK;
+  while (k < z && dl[(size_t)k] < 0) ++k, ++nn;
+  if (nn < 1 || nn > 4) return QP_OK;
+  for (int i = 0; i < nn; ++i) P.near[i] = (int)(-dl[(size_t)(K + nn - 1 - i)]);
   for (int i = 0; i < nn; ++i)
-    if (ld[(size_t)(K + i)] != -P.near[nn - 1 - i]) return QP_OK;
+    if (P.near[i] <= 0 || P.near[i] > qp::kWalkHalo || (i > 0 && P.near[i] <= P.near[i - 1])) return QP_OK;
+  if (k < z && dl[(size_t)k] == 0) ++k, z0 = 1;
+  if (z != 2 * (nn + K) + z0) return QP_OK;
+  for (int i = 0; i < nn; ++i)
+    if (dl[(size_t)(K + nn + z0 + i)] != P.near[i]) return QP_OK;
+  for (int m = 1; m <= K; ++m)
+    if (dl[(size_t)(K + 2 * nn + z0 + m - 1)] != (int64_t)m * g) return QP_OK;
+  if (!qp::walk_shape_supported(nn, K, z0)) return QP_OK;
   const int S = (int)(g / kRB);
   const int64_t W0 = R0 + (int64_t)K * S;
   if (R1 - W0 < 8) return QP_OK;
-  // positions: block b's upper values at U0 + (b - R0) ustride (contiguous blocks of equal width: true by
-  // construction, checked anyway), and every lower record of a walkable block must point where the walk will look
+  // the upper section of every block of the run: z0 + nn + K entries per row, padded to a multiple of four, at equal strides
+  const int64_t wu = ((z0 + nn + K + 3) / 4) * 4;
   const int64_t U0 = Lh.bptr[R0], ustride = wu * kRB;
   for (int64_t b = R0; b <= R1; ++b)
     if (Lh.bptr[b] != U0 + (b - R0) * ustride) return QP_OK;
+  for (int64_t r = rref; r < R1 * kRB; r += kRB)
+    if (Lh.nlow[r] != nn + K) return QP_OK;
   if (U0 + (R1 - R0) * ustride >= (int64_t)INT32_MAX) return QP_OK;
-  for (int64_t b = W0; b < R1; ++b) {
-    for (int64_t q = 0; q < wl; ++q) {
-      const LowerStencilSlot e = lslot(b, q);
-      int64_t uslot;     // the upper slot that holds the transposed entries of this lower slot
-      if (q < K) uslot = z0 + nn + (K - q) - 1;
-      else uslot = z0 + (nn - 1 - (q - K));
-      const int64_t c0 = b * kRB + e.delta;          // column of the block's first row
-      const int64_t cb0 = c0 >> 6;
-      if (cb0 < R0 || e.cb0 != cb0 || e.pb0 != U0 + (cb0 - R0) * ustride + uslot * kRB) return QP_OK;
-      if ((c0 & 63) != 0 && e.pb1 != U0 + (cb0 + 1 - R0) * ustride + uslot * kRB) return QP_OK;
-    }
-  }
   std::vector<int32_t> edge;
   for (int64_t b = 0; b < W0; ++b) edge.push_back((int32_t)b);
   for (int64_t b = R1; b < nb; ++b) edge.push_back((int32_t)b);
@@ -811,7 +802,7 @@ static int operator_build_device_impl(qp_operator* op, int format, const std::ve
       QP_HIP(hipMemcpy(A.lcmeta, Lh.lcmeta.data(), Lh.lcmeta.size() * sizeof(int64_t), hipMemcpyHostToDevice));
       QP_CHECK(dev_alloc(&A.lpos, lpos.size()));
       QP_HIP(hipMemcpy(A.lpos, lpos.data(), lpos.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-      QP_CHECK(build_walk_plan(op, cbytes, lbytes));
+      QP_CHECK(build_walk_plan(op));
     }
   }
 

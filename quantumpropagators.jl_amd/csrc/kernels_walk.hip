@@ -244,7 +244,6 @@ __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __r
   constexpr int NU = Z0 + NN + K;    // upper slots that carry entries: [0] [d_1 .. d_NN] [g .. K g]
   using Lds = WalkLds<NN, K>;
   constexpr int XW = Lds::XW, AW = Lds::AW;
-  static_assert(NL % 4 == 0, "a stencil lower section has no pad slots");
   static_assert(NN <= 4, "the near value halos share one register: sixteen lanes each");
   extern __shared__ double2 walk_lds[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -454,29 +453,33 @@ static bool launch_shape(hipStream_t s, dim3 grid, const VT* uvals, const double
 #define QP_WALK_SHAPE(NN_, K_, Z0_)                                                                       \
   return (ntm & 1) ? launch_instance<VT, NN_, K_, Z0_, 1>(s, grid, uvals, x, P, G, H, nrows, op, sy)            \
                    : launch_instance<VT, NN_, K_, Z0_, 0>(s, grid, uvals, x, P, G, H, nrows, op, sy);
+  if (key == 440 && (ntm == 3 || ntm == 5 || ntm == 7)) {   // (measurement variants of the headline shape)
+    if (ntm == 3) return launch_instance<VT, 4, 4, 0, 3>(s, grid, uvals, x, P, G, H, nrows, op, sy);
+    if (ntm == 5) return launch_instance<VT, 4, 4, 0, 5>(s, grid, uvals, x, P, G, H, nrows, op, sy);
+    return launch_instance<VT, 4, 4, 0, 7>(s, grid, uvals, x, P, G, H, nrows, op, sy);
+  }
+#define QP_WALK_NN(NN_)                                    \
+  case NN_ * 100 + 10: QP_WALK_SHAPE(NN_, 1, 0)            \
+  case NN_ * 100 + 11: QP_WALK_SHAPE(NN_, 1, 1)            \
+  case NN_ * 100 + 20: QP_WALK_SHAPE(NN_, 2, 0)            \
+  case NN_ * 100 + 21: QP_WALK_SHAPE(NN_, 2, 1)            \
+  case NN_ * 100 + 30: QP_WALK_SHAPE(NN_, 3, 0)            \
+  case NN_ * 100 + 31: QP_WALK_SHAPE(NN_, 3, 1)            \
+  case NN_ * 100 + 40: QP_WALK_SHAPE(NN_, 4, 0)            \
+  case NN_ * 100 + 41: QP_WALK_SHAPE(NN_, 4, 1)
   switch (key) {
-    case 440:
-      switch (ntm) {   // (measurement variants of the headline shape)
-        case 3: return launch_instance<VT, 4, 4, 0, 3>(s, grid, uvals, x, P, G, H, nrows, op, sy);
-        case 7: return launch_instance<VT, 4, 4, 0, 7>(s, grid, uvals, x, P, G, H, nrows, op, sy);
-        case 5: return launch_instance<VT, 4, 4, 0, 5>(s, grid, uvals, x, P, G, H, nrows, op, sy);
-        default: break;
-      }
-      QP_WALK_SHAPE(4, 4, 0)
-    case 441: QP_WALK_SHAPE(4, 4, 1)
-    case 220: QP_WALK_SHAPE(2, 2, 0)
-    case 221: QP_WALK_SHAPE(2, 2, 1)
-    case 310: QP_WALK_SHAPE(3, 1, 0)
-    case 130: QP_WALK_SHAPE(1, 3, 0)
+    QP_WALK_NN(1)
+    QP_WALK_NN(2)
+    QP_WALK_NN(3)
+    QP_WALK_NN(4)
     default: return false;
   }
+#undef QP_WALK_NN
 #undef QP_WALK_SHAPE
 }
 
-bool walk_shape_supported(int nn, int K, int z0) {
-  return (nn == 4 && K == 4 && z0 <= 1) || (nn == 2 && K == 2 && z0 <= 1) || (nn == 3 && K == 1 && z0 == 0) ||
-         (nn == 1 && K == 3 && z0 == 0);
-}
+// near distances 1..4 of at most 16 rows, far reach 1..4 strip steps, with or without a diagonal
+bool walk_shape_supported(int nn, int K, int z0) { return nn >= 1 && nn <= 4 && K >= 1 && K <= 4 && (z0 == 0 || z0 == 1); }
 
 int launch_hrb_walk_cheby(hipStream_t s, const DevMatrix& A, const double2* x, const ChebyEpi& e, const Tuning& tun,
                           bool* launched, const RowSet* rs) {

@@ -676,7 +676,14 @@ WALK_DEFAULTS = {"hrb_walk": 1, "walk_waves": 0, "walk_nt": -1, "walk_dbg": 0, "
     (1 << 16, synth.BANDED_OFFSETS, True, False, (4, 4, 1)),               # with a diagonal: 9 + 3 pad slots in the upper section
     (1 << 15, (1, 2, 3, 4, 192, 384, 576, 768), False, False, (4, 4, 0)),  # three row blocks per strip step
     (1 << 15, (1, 2, 512, 1024), True, True, (2, 2, 1)),                   # real couplings: the walk streams the fp64 copy
-], ids=["16nnz", "8nnz", "near3far1", "near1far3", "16nnz+diag", "g192", "real+diag"])
+    (1 << 15, (1, 256), True, False, (1, 1, 1)),                           # the five-point lattice: hopping + on-site term
+    (1 << 15, (1, 128), False, False, (1, 1, 0)),                          # (2 lower entries per row: padded lower sections)
+    (1 << 15, (1, 2, 192), True, True, (2, 1, 1)),
+    (1 << 15, (3, 128, 256), False, False, (1, 2, 0)),
+    (1 << 15, (1, 2, 3, 4, 256, 512), True, False, (4, 2, 1)),
+    (1 << 16, (2, 5, 9, 320, 640, 960), False, False, (3, 3, 0)),
+], ids=["16nnz", "8nnz", "near3far1", "near1far3", "16nnz+diag", "g192", "real+diag", "5point", "4nnz", "near2far1+diag",
+        "near1far2", "near4far2+diag", "near3far3"])
 def test_strip_walk_bit_identical_to_block_kernel(ctx, N, offsets, diag, real, shape):
     """The strip-walk kernel of a lattice operator (kernels_walk.hip: register ring of the gathered elements, FIFO of the
     far upper values and near windows in LDS, edge blocks on the per-block path) sums every row in the order of the
@@ -732,8 +739,8 @@ def test_strip_walk_random_lattices_bit_identical(ctx):
     saved = {k: ctx.tuning_get(k) for k in WALK_KNOBS}
     n_walked = 0
     try:
-        for trial in range(28):
-            nn, K = [(4, 4), (2, 2), (3, 1), (1, 3)][trial % 4]
+        for trial in range(40):
+            nn, K = int(rng.integers(1, 5)), int(rng.integers(1, 5))
             S = int(rng.choice([1, 2, 3, 5, 8, 16, 40]))
             g = 64 * S
             near = sorted(rng.choice(np.arange(1, 17), nn, replace=False).tolist())
@@ -743,7 +750,7 @@ def test_strip_walk_random_lattices_bit_identical(ctx):
             if 2 * max(offsets) >= N:
                 continue
             rp, col, vals = synth.hermitian_offsets_csr(N, offsets=offsets, seed=1000 + trial)
-            diag = (nn, K) in ((4, 4), (2, 2)) and bool(rng.integers(0, 2))
+            diag = bool(rng.integers(0, 2))
             if bool(rng.integers(0, 4) == 0):
                 vals = vals.real.astype(np.complex128)
             if diag:
@@ -776,7 +783,7 @@ def test_strip_walk_random_lattices_bit_identical(ctx):
     finally:
         for k, v in saved.items():
             ctx.tuning_set(k, v)
-    assert n_walked >= 15
+    assert n_walked >= 24
 
 
 def test_strip_walk_inside_a_replayed_graph(ctx):
@@ -815,9 +822,9 @@ def test_strip_walk_inside_a_replayed_graph(ctx):
 
 
 def test_strip_walk_plan_only_for_lattices(ctx):
-    """The walk plan is index work on the host: it exists only where every position it computes by formula is the position
-    the per-block kernel would read -- not for scattered or per-row random columns, not for near distances beyond the LDS
-    halo, far distances that are not multiples of one 64-row-aligned stride, or shapes without a kernel instance -- and it
+    """The walk plan is index work on the host: it exists only where one list of column distances repeats down a run of row
+    blocks and has the walk's shape -- not for scattered or per-row random columns, not for near distances beyond the LDS
+    halo, far distances that are not multiples of one 64-row-aligned stride, more than four near or far distances -- and it
     goes away when a complex coefficient forces the operator out of the Hermitian-packed format."""
     N = 1 << 15
     saved = ctx.tuning_get("walk_min_blocks")

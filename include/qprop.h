@@ -169,8 +169,8 @@ int qp_operator_layout_info(const qp_operator* op, int64_t out[5]);
 int qp_operator_build_info(const qp_operator* op, double out[4]);
 /* Strip-walk plan of a Hermitian-packed lattice operator (the fused Chebyshev term then walks down strip columns and
  * keeps the re-read data in registers / LDS): out[0] = 1 if the operator has one, out[1] = near distances, out[2] = far
- * reach K (far distances m g, m = 1..K), out[3] = 1 if the stencil has a diagonal, out[4] = row blocks per strip step
- * (g / 64), out[5], out[6] = the walkable row blocks [W0, R1), out[7] = row blocks on the per-block path. */
+ * reach K (far distances m g, m = 1..K), out[3] = 1 if the stencil has a diagonal, out[4] = rows per strip step g
+ * (any g >= 64), out[5], out[6] = the walkable row blocks [W0, R1), out[7] = row blocks on the per-block path. */
 int qp_operator_walk_info(const qp_operator* op, int64_t out[8]);
 /* How qp_cheby_step_batched will visit the rows for a panel of `batch` states (wave-per-row kernel,
  * more than 32 states): out[0] = inner dimension g detected in the pattern (far offsets are multiples of

@@ -234,7 +234,7 @@ end
 function operator_walk_info(op::Handle)
     out = zeros(Int64, 8)
     GC.@preserve out check(ccall((:qp_operator_walk_info, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}), op, out))
-    return (valid = out[1] != 0, near = Int(out[2]), far = Int(out[3]), diagonal = out[4] != 0, blocks_per_step = Int(out[5]),
+    return (valid = out[1] != 0, near = Int(out[2]), far = Int(out[3]), diagonal = out[4] != 0, rows_per_step = Int(out[5]),
             first_block = out[6], end_block = out[7], edge_blocks = out[8])
 end
 

@@ -67,7 +67,7 @@ struct DevMatrix {
 // ---- strip walk over a lattice operator (Hermitian-packed format) -----------------------------------------------
 // A run of row blocks [R0, R1) that all carry the same stencil: upper section
 //   [z0 slots at distance 0 (the diagonal)] [nn near distances 0 < d_1 < ... < d_nn <= 16] [K far distances m g, m = 1..K]
-//   [pads], lower section its mirror image [-K g ... -g] [-d_nn ... -d_1], g = 64 S rows.  Inside the run the position of
+//   [pads], lower section its mirror image [-K g ... -g] [-d_nn ... -d_1]; S = ceil(g / 64) column chunks per strip step.  Inside the run the position of
 // every value is a formula (U0 + (b - R0) ustride + 64 slot + lane), and a wavefront that WALKS down one strip column --
 // row blocks b, b + S, b + 2 S, ... -- finds everything a block needs beyond its own streams in what it loaded for the
 // blocks before: the gathered elements x[r + m g] are the row-local elements of the blocks m steps ahead / behind (a ring
@@ -81,7 +81,8 @@ constexpr int kWalkHalo = 16;      // largest near distance
 struct WalkPlan {
   int valid = 0;
   int nn = 0, K = 0, z0 = 0;  // shape of the stencil (see above)
-  int S = 0;                  // row blocks per strip step
+  int S = 0;                  // 64-row column chunks per strip step: ceil(g / 64)
+  int64_t g = 0;              // rows per strip step (the far distances are g, 2 g, .., K g); need not be a multiple of 64
   int near[kWalkMaxNear] = {0};
   int64_t R0 = 0, R1 = 0, W0 = 0;
   int64_t U0 = 0;             // bptr[R0]
@@ -345,7 +346,8 @@ int launch_mgs_pass(hipStream_t s, const MgsArgs& a, Stats* st);
 // coefficients, then w -= Q h with |w|^2 partials: three launches
 int launch_mgs_lowsync(hipStream_t s, const double2* Q, int64_t ldq, int j, double2* w, double2* md_partials,
                        double2* G, int ldg, double2* hess_col, double2* reduced, double2* coef, unsigned* ticket,
-                       double2* norm_partials, double dt, int64_t n, Stats* st, bool solve_in_update = false);
+                       double2* norm_partials, double dt, int64_t n, Stats* st, bool solve_in_update = false,
+                       unsigned* early_flag = nullptr, unsigned flag_value = 0, bool* early_armed = nullptr);
 // the same in pieces for row-partitioned runs: local sums -> (all-reduce by the caller) ->
 // solve (one workgroup) + update
 int launch_mgs_multidot(hipStream_t s, const double2* Q, int64_t ldq, int j, const double2* w, double2* md_partials,

@@ -565,7 +565,7 @@ static int build_walk_plan(qp_operator* op) {
   const auto& ur = op->u_rowptr;
   const auto& uc = op->u_col;
   const int64_t nb = A.nblocks;
-  if (A.format != QP_FMT_HRB || nb < 8 || A.ncols != A.nrows) return QP_OK;
+  if (A.format != QP_FMT_HRB || nb < 8 || A.ncols < A.nrows) return QP_OK;   // (more columns than rows: the halo slabs of a row-partitioned operator)
   const int64_t nfull = A.nrows / kRB;   // (a partly filled last block never belongs to the run)
   auto same_row = [&](int64_t r, int64_t ref) {   // same distances as row `ref`?
     const int64_t len = ur[ref + 1] - ur[ref];
@@ -605,8 +605,8 @@ static int build_walk_plan(qp_operator* op) {
   int K = 0, nn = 0, z0 = 0;
   while (k < z && dl[(size_t)k] <= -(int64_t)kRB) ++k, ++K;
   if (K < 1 || K > 4) return QP_OK;
-  const int64_t g = -dl[(size_t)(K - 1)];
-  if (g % kRB != 0) return QP_OK;
+  const int64_t g = -dl[(size_t)(K - 1)];          // any stride of at least one row block (100 x 100 lattices are lattices too)
+  if (g < kRB) return QP_OK;
   for (int m = 1; m <= K; ++m)
     if (dl[(size_t)(K - m)] != -(int64_t)m * g) return QP_OK;
   while (k < z && dl[(size_t)k] < 0) ++k, ++nn;
@@ -621,8 +621,8 @@ static int build_walk_plan(qp_operator* op) {
   for (int m = 1; m <= K; ++m)
     if (dl[(size_t)(K + 2 * nn + z0 + m - 1)] != (int64_t)m * g) return QP_OK;
   if (!qp::walk_shape_supported(nn, K, z0)) return QP_OK;
-  const int S = (int)(g / kRB);
-  const int64_t W0 = R0 + (int64_t)K * S;
+  const int S = (int)((g + kRB - 1) / kRB);
+  const int64_t W0 = R0 + ((int64_t)K * g + kRB - 1) / kRB;      // first block whose rows find their K g history inside the run
   if (R1 - W0 < 8) return QP_OK;
   // the upper section of every block of the run: z0 + nn + K entries per row, padded to a multiple of four, at equal strides
   const int64_t wu = ((z0 + nn + K + 3) / 4) * 4;
@@ -639,6 +639,7 @@ static int build_walk_plan(qp_operator* op) {
   P.K = K;
   P.z0 = z0;
   P.S = S;
+  P.g = g;
   P.R0 = R0;
   P.R1 = R1;
   P.W0 = W0;
@@ -1142,7 +1143,7 @@ int qp_operator_walk_info(const qp_operator* op, int64_t out[8]) {
   out[1] = on ? P.nn : 0;
   out[2] = on ? P.K : 0;
   out[3] = on ? P.z0 : 0;
-  out[4] = on ? P.S : 0;
+  out[4] = on ? P.g : 0;
   out[5] = on ? P.W0 : 0;
   out[6] = on ? P.R1 : 0;
   out[7] = on ? P.n_edge : 0;
@@ -1519,6 +1520,7 @@ int operator_spmm_walk_plan(qp_operator* op, const qp::SpmmWalkPlan** out) {
   if (K < 1 || K > 4) return QP_OK;
   const int64_t g = -dl[(size_t)(K - 1)];
   if (g < 64 || n % g != 0) return QP_OK;
+  if (g < kRB) return QP_OK;
   for (int m = 1; m <= K; ++m)
     if (dl[(size_t)(K - m)] != -(int64_t)m * g) return QP_OK;
   while (k < z && dl[(size_t)k] < 0) ++k, ++nn;

@@ -45,8 +45,9 @@ int qp_krylov_create(qp_ctx* ctx, int64_t n, int nvec, qp_krylov** out) {
   const unsigned hflags = hipHostMallocMapped | hipHostMallocCoherent;
   QP_HIP(hipHostMalloc((void**)&q->h_hess, sizeof(double2) * (size_t)nvec * nvec, hflags));
   QP_HIP(hipHostMalloc((void**)&q->h_norms, sizeof(double) * (size_t)nvec, hflags));
-  QP_HIP(hipHostMalloc((void**)&q->col_flags, sizeof(unsigned) * (size_t)nvec, hflags));
-  std::memset(q->col_flags, 0, sizeof(unsigned) * (size_t)nvec);
+  // [0, nvec): column complete (with its norm); [nvec, 2 nvec): the column's MGS coefficients are written (early flag)
+  QP_HIP(hipHostMalloc((void**)&q->col_flags, sizeof(unsigned) * (size_t)nvec * 2, hflags));
+  std::memset(q->col_flags, 0, sizeof(unsigned) * (size_t)nvec * 2);
   QP_HIP(hipHostGetDevicePointer((void**)&q->hess_map, q->h_hess, 0));
   QP_HIP(hipHostGetDevicePointer((void**)&q->norms_map, q->h_norms, 0));
   QP_HIP(hipHostGetDevicePointer((void**)&q->col_flags_map, q->col_flags, 0));
@@ -102,6 +103,8 @@ struct FoldArgs {
   double norm_min;
   unsigned* flag;             // col_flags[j-1] (device address) or null
   unsigned flag_value;
+  unsigned* early_flag = nullptr;   // this column's early flag (set by the projection kernel once Hess[0..j, j] is written)
+  bool* early_armed = nullptr;
 };
 
 int arnoldi_column(qp_operator* op, qp_krylov* q, int j, double dt, double2* hcol, const double2* xin = nullptr,
@@ -134,7 +137,8 @@ int arnoldi_column(qp_operator* op, qp_krylov* q, int j, double dt, double2* hco
     q->gram_rows = j + 1;
     return qp::launch_mgs_lowsync(ctx->stream, q->Q, q->n, j, w, q->md_part, q->gram, q->nvec, hcol,
                                   q->hcoef, q->mgs_coef, q->ticket, q->part + (size_t)((j + 1) & 1) * kRedBlocks, dt,
-                                  q->n, &ctx->stats, ctx->tun.arnoldi_solve != 0);
+                                  q->n, &ctx->stats, ctx->tun.arnoldi_solve != 0, fold ? fold->early_flag : nullptr,
+                                  fold ? fold->flag_value : 0u, fold ? fold->early_armed : nullptr);
   }
   q->gram_rows = std::min(q->gram_rows, j);
   for (int i = 0; i <= j + 1; ++i) {                                              // :84-87
@@ -190,6 +194,7 @@ static int arnoldi_impl(qp_operator* op, qp_krylov* q, int m, const qp_state* ps
   bool piped = false;
   bool fold = false;
   bool flags = false;   // folded + pipelined sweep: columns are announced through col_flags, not events
+  bool early_last = false;   // the last column also raises its early flag
   if (ctx->tun.small_nnz > 0 && op->A.nnz <= (int64_t)ctx->tun.small_nnz * (qp::kSmallEptArnoldi / qp::kSmallEpt) &&
       qp::small_arnoldi_fits(q->n, m)) {
     int64_t maxrow = 0;
@@ -259,6 +264,13 @@ static int arnoldi_impl(qp_operator* op, qp_krylov* q, int m, const qp_state* ps
         FoldArgs fa{q->part + (size_t)(j & 1) * kRedBlocks, j > 0 ? q->hess_map + (size_t)(j - 1) * ldd + j : nullptr,
                     j > 0 ? q->norms_map + (j - 1) : nullptr, norm_min, (flags && j > 0) ? q->col_flags_map + (j - 1) : nullptr,
                     q->seq};
+        // The hook of the LAST column is the one the device waits for (the others run while it works on later columns):
+        // its Hessenberg block does not contain the column's norm, so it may start as soon as the projection kernel has
+        // solved for the coefficients -- while that kernel still streams the basis.
+        if (flags && j + 1 == m && j > 0) {
+          fa.early_flag = q->col_flags_map + q->nvec + j;
+          fa.early_armed = &early_last;
+        }
         QP_CHECK(arnoldi_column(op, q, j, dt, hcol, j == 0 ? q->q(0) : q->raw[j & 1], q->raw[(j + 1) & 1], j > 0 ? &fa : nullptr));
         if (j + 1 == m) {   // the last vector: normalised into the basis (extended), or handed over as it is
           if (extended) {
@@ -321,15 +333,29 @@ static int arnoldi_impl(qp_operator* op, qp_krylov* q, int m, const qp_state* ps
     }
     return QP_OK;
   };
-  for (int j = 0; j < m; ++j) {
-    QP_CHECK(wait_column(j));
-    if (j + 1 == m) q->t_last_column = std::chrono::steady_clock::now();
-    const int rows = std::min(j + 2, dim);
+  auto copy_column = [&](int j, int rows) {
     for (int i = 0; i < rows; ++i) {
       cplx v = hh[(size_t)j * ldd + i];
       Hess[(size_t)j * ldh + i] = qp_c128{v.real(), v.imag()};
     }
-    if (piped && (hook_rc = (*on_column)(j)) != QP_OK) break;
+  };
+  for (int j = 0; j < m; ++j) {
+    const int rows = std::min(j + 2, dim);
+    bool hooked = false;
+    if (early_last && j + 1 == m) {   // coefficients first, hook, then the norm
+      unsigned spins = 0;
+      const unsigned* ef = q->col_flags + q->nvec + j;
+      while (__atomic_load_n(ef, __ATOMIC_ACQUIRE) != q->seq && ++spins < (1u << 24)) QP_CPU_RELAX();
+      if (__atomic_load_n(ef, __ATOMIC_ACQUIRE) == q->seq) {
+        copy_column(j, j + 1);
+        if ((hook_rc = (*on_column)(j)) != QP_OK) break;
+        hooked = true;
+      }
+    }
+    QP_CHECK(wait_column(j));
+    if (j + 1 == m) q->t_last_column = std::chrono::steady_clock::now();
+    copy_column(j, rows);
+    if (piped && !hooked && (hook_rc = (*on_column)(j)) != QP_OK) break;
     if (((j + 1 < m) || extended) && hn[j] < norm_min) {  // dimensionality exhausted  :91-95
       m_eff = j + 1;
       break;

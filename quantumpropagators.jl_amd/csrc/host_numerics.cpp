@@ -183,6 +183,25 @@ int diagonalize_hessenberg(const cplx* Hess, int ldh, int m, bool accumulate, cp
 // adversarial inputs with duplicated and nearly equal candidates -- at the cost of the fast path.
 // prod_folded (optional, n > 0): the products over the first n Leja points, which a caller may have built
 // while the candidates were arriving (leja_fold_candidate).
+// frexp / ldexp on the bit pattern (normal numbers; anything else takes the library call): the two Leja loops run
+// one of each per factor and candidate, at the end of every Arnoldi sweep while the device waits
+static inline double frexp_bits(double x, int* e) {
+  uint64_t b;
+  std::memcpy(&b, &x, sizeof b);
+  const int ex = (int)((b >> 52) & 0x7ff);
+  if (ex == 0 || ex == 0x7ff) return std::frexp(x, e);
+  *e = ex - 1022;
+  b = (b & ~(0x7ffULL << 52)) | (1022ULL << 52);
+  std::memcpy(&x, &b, sizeof b);
+  return x;
+}
+static inline double scale_pow2(double x, int k) {   // x * 2^k, exact
+  if (k < -1000 || k > 1000) return std::ldexp(x, k);
+  const uint64_t b = (uint64_t)(k + 1023) << 52;
+  double f;
+  std::memcpy(&f, &b, sizeof f);
+  return x * f;
+}
 static inline void scaled_mul_dist2(ScaledProd& p, cplx d) {
   // |d|^2 with the range of |d| taken out first: scale by 2^-k, k = exponent of the larger component
   const double ax = std::fabs(d.real()), ay = std::fabs(d.imag());
@@ -192,10 +211,10 @@ static inline void scaled_mul_dist2(ScaledProd& p, cplx d) {
     return;
   }
   int k = 0;
-  (void)std::frexp(big, &k);
-  const double sx = std::ldexp(d.real(), -k), sy = std::ldexp(d.imag(), -k);   // larger component in [0.5, 1)
+  (void)frexp_bits(big, &k);
+  const double sx = scale_pow2(d.real(), -k), sy = scale_pow2(d.imag(), -k);   // larger component in [0.5, 1)
   int de = 0;
-  p.m = std::frexp(p.m * (sx * sx + sy * sy), &de);   // m stays in [0.5, 1) (or 0)
+  p.m = frexp_bits(p.m * (sx * sx + sy * sy), &de);   // m stays in [0.5, 1) (or 0)
   p.e += de + 2 * k;
 }
 static inline bool scaled_greater(const ScaledProd& a, const ScaledProd& b) {   // a > b, both >= 0
@@ -208,7 +227,7 @@ static inline bool scaled_near(const ScaledProd& a, const ScaledProd& b, double 
   const int64_t de = (int64_t)a.e - (int64_t)b.e;
   if (de > 2) return true;
   if (de < -2) return false;
-  return std::ldexp(a.m, (int)de) >= b.m * (1.0 - tol);
+  return scale_pow2(a.m, (int)de) >= b.m * (1.0 - tol);
 }
 
 ScaledProd leja_fold_candidate(const cplx* leja, int n, cplx z) {

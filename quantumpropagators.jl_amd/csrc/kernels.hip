@@ -1909,6 +1909,8 @@ struct MgsSolveArgs {
   int ldg;
   double2* hess_col;
   double dt;
+  unsigned* early_flag = nullptr;   // host-visible: the column's MGS coefficients (Hess[0..j, j]) are written
+  unsigned flag_value = 0;
 };
 
 template <int BS, int EPL, bool SOLVE>
@@ -1952,6 +1954,9 @@ __global__ __launch_bounds__(BS) void mgs_update_kernel(double2* __restrict__ w,
     mgs_stage_gram(j, red, Gt, sv.G, sv.ldg);
     __syncthreads();
     if (threadIdx.x < 64) mgs_solve_wave(j, red, Gt, hs, blockIdx.x == 0 ? sv.hess_col : dummy, h, sv.dt);
+    // (lane 0 of the wavefront that stored the column: its release covers those stores)
+    if (sv.early_flag && blockIdx.x == 0 && threadIdx.x == 0)
+      __hip_atomic_store(sv.early_flag, sv.flag_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     __syncthreads();
   } else {
     for (int i = threadIdx.x; i <= j; i += BS) h[i] = coef[i];
@@ -2045,13 +2050,16 @@ int launch_mgs_project(hipStream_t s, const double2* Q, int64_t ldq, int j, doub
 
 int launch_mgs_lowsync(hipStream_t s, const double2* Q, int64_t ldq, int j, double2* w, double2* md_partials,
                        double2* G, int ldg, double2* hess_col, double2* reduced, double2* coef, unsigned* ticket,
-                       double2* norm_partials, double dt, int64_t n, Stats* st, bool solve_in_update) {
+                       double2* norm_partials, double dt, int64_t n, Stats* st, bool solve_in_update,
+                       unsigned* early_flag, unsigned flag_value, bool* early_armed) {
   int rc = launch_multidot(s, Q, ldq, j, w, md_partials, n, st);
   if (rc != QP_OK) return rc;
+  if (early_armed) *early_armed = false;
   if (solve_in_update && mgs_solve_lds(j) <= 12 * 1024) {   // j <= 35: reduction + solve in the projection's prologue
+    if (early_armed) *early_armed = early_flag != nullptr;
     const size_t shmem = sizeof(double2) * (size_t)(j + 1 + kThreads / 64 + j + 1) + mgs_solve_lds(j);
     hipLaunchKernelGGL((mgs_update_kernel<kThreads, 2, true>), dim3(kRedBlocks), dim3(kThreads), shmem, s, w, Q, ldq, j, coef,
-                       norm_partials, n, MgsSolveArgs{md_partials, G, ldg, hess_col, dt});
+                       norm_partials, n, MgsSolveArgs{md_partials, G, ldg, hess_col, dt, early_flag, flag_value});
     QP_HIP(hipGetLastError());
     if (st) st->n_launch++;
     return QP_OK;

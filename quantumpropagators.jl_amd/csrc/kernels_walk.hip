@@ -50,6 +50,7 @@ struct WalkGeom {
   int edge_segs = 0;   // segments 0 .. edge_segs - 1 are the shorter ones
   int edge_steps = 0;
   int edge_last = 0;
+  int64_t xlast = 0;   // last element of x (columns of a row-partitioned operator run beyond its rows: the halo slabs)
   int n_edge_wg = 0;
 };
 
@@ -260,8 +261,11 @@ __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __r
   const int task = (int)wg * (int)(blockDim.x >> 6) + wave;
   const int S = P.S;
   const int seg = task / S, col = task - seg * S;
-  const int64_t nW = P.R1 - P.W0;
-  const int Jc = col < nW ? (int)((nW - col + S - 1) / S) : 0;
+  // rows of this wavefront at step j: W0 * 64 + j g + 64 col + lane; the strip step g need not be a multiple of 64 rows:
+  // the last of the S = ceil(g / 64) column chunks is then partly filled (lanes beyond g are idle)
+  const int64_t g = P.g;
+  const int64_t wrows = (P.R1 - P.W0) * (int64_t)kRB;
+  const int Jc = (int64_t)col * kRB < wrows ? (int)((wrows - (int64_t)col * kRB + g - 1) / g) : 0;
   const int j0 = seg * G.L - min(seg, G.edge_segs) * G.edge_steps;
   const int j1 = min((seg + 1) * G.L - min(seg + 1, G.edge_segs) * G.edge_steps, Jc);
   // this wavefront's edge block(s) first (see WalkGeom)
@@ -271,11 +275,15 @@ __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __r
       hrb_edge_block<VT>(H, uvals, x, (int64_t)__builtin_amdgcn_readfirstlane(P.edge_map[idx]), lane, nrows, op);
   }
   if (seg < G.nseg && j0 < j1) {
-  const int64_t g = (int64_t)kRB * S;
   const int dmax = P.near[NN - 1];
   double2* __restrict__ xwin = walk_lds + (size_t)wave * Lds::kPerWave;
   double2* __restrict__ hring = xwin + Lds::kHist;
-  auto ubase = [&](int64_t blk) __attribute__((always_inline)) -> int64_t { return P.U0 + (blk - P.R0) * (int64_t)P.ustride; };
+  // position of slot 0 of row r in the upper value array (r inside the run; rows of one 64-row block are contiguous)
+  auto vpos = [&](int64_t r) __attribute__((always_inline)) -> int64_t {
+    return P.U0 + ((r >> 6) - P.R0) * (int64_t)P.ustride + (r & 63);
+  };
+  const int64_t rmax = G.xlast;
+  const int64_t vmax = P.R1 * (int64_t)kRB - 1;               // last row whose values sit at the run's strides
   // No branch inside the walk: a join in the control flow makes the compiler wait for EVERY outstanding load (the
   // prefetch included).  Operands that a term does not have are loaded from a line that stays in the L1 and ignored
   // by the epilogue; halo lanes beyond the halo repeat its last element.
@@ -288,17 +296,19 @@ __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __r
   const int hq = lane >> 4, ht = lane & 15;
   const int hd = P.near[hq < NN ? hq : NN - 1];               // distance of this lane's near value halo
   const int hoff_x = (hq & 1) ? kRB + min(ht, dmax - 1) : -dmax + min(ht, dmax - 1);
-  const int hoff_a = (Z0 + (hq < NN ? hq : NN - 1)) * kRB + kRB - hd + min(ht, hd - 1);
-  auto load_step = [&](int64_t blk, WalkStep<NU>& w) __attribute__((always_inline)) {
-    const int64_t r = blk * kRB + lane;
-    const VT* __restrict__ v = uvals + ubase(blk) + lane;
+  const int hslot = Z0 + (hq < NN ? hq : NN - 1);             // ... of slot z0 + q: rows r0 - d .. r0 - 1
+  // r0 = first row of the wavefront at that step.  Lanes beyond the strip (or the run) still load real data -- their
+  // elements of x are the near neighbours of the last active lanes -- with the row clamped into the matrix.
+  auto load_step = [&](int64_t r0, WalkStep<NU>& w) __attribute__((always_inline)) {
+    const int64_t r = min(r0 + lane, vmax);
+    const VT* __restrict__ v = uvals + vpos(r);
 #pragma unroll
     for (int u = 0; u < NU; ++u) w.ua[u] = ld_val<(NTM & 1) != 0>(v + (size_t)u * 64);
-    w.xnew = ld_stream<(NTM & 2) != 0>(x + r + K * g);
+    w.xnew = ld_stream<(NTM & 2) != 0>(x + min(r + K * g, rmax));
     w.v0 = ld_stream<(NTM & 2) != 0>(v0p ? v0p + r : x + lane);
     w.acc = ld_stream<(NTM & 2) != 0>(accp ? accp + r : x + lane);
-    w.hx = x[blk * kRB + hoff_x];
-    w.ha = ld_val<false>(uvals + ubase(blk - 1) + hoff_a);
+    w.hx = x[min(r0 + hoff_x, rmax)];
+    w.ha = ld_val<false>(uvals + vpos(r0 - hd + min(ht, hd - 1)) + (size_t)hslot * 64);
   };
   // where this lane's halo elements go in the windows (lanes that carry none rewrite their own main element)
   const bool hx_on = hq < 2 && ht < dmax;
@@ -306,12 +316,13 @@ __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __r
   const bool ha_on = hq < NN && ht < hd;
   const int ha_pos = XW + (hq < NN ? hq : 0) * AW + (ha_on ? kWalkHalo - hd + ht : kWalkHalo + lane);
 
-  int64_t b = P.W0 + col + (int64_t)S * j0;
-  int64_t row = b * kRB + lane;
+  int64_t row0 = P.W0 * (int64_t)kRB + (int64_t)j0 * g + (int64_t)col * kRB;
+  const int64_t rend = P.R1 * (int64_t)kRB;
+  const bool in_strip = (int64_t)col * kRB + lane < g;
   // the ring of gathered elements x[row + m g], m = -K .. K (the last one arrives with each step's loads) ...
   double2 xr[2 * K + 1];
 #pragma unroll
-  for (int m = -K; m < K; ++m) xr[K + m] = x[row + m * g];
+  for (int m = -K; m < K; ++m) xr[K + m] = x[min(row0 + lane + m * g, rmax)];
   // ... and the far upper values of the K blocks behind, FIFO m in LDS: the value of t steps ago sits at entry
   // (step - t) mod m, so the entry read at a step (the value of m steps ago) is the one overwritten at that step
 #pragma unroll
@@ -319,17 +330,17 @@ __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __r
 #pragma unroll
     for (int a = 1; a <= m; ++a)
       hring[(m * (m - 1) / 2 + (m - a)) * kRB + lane] =
-          ld_val<false>(uvals + ubase(b - (int64_t)a * S) + (size_t)(Z0 + NN + m - 1) * 64 + lane);
+          ld_val<false>(uvals + vpos(min(row0 + lane, vmax) - (int64_t)a * g) + (size_t)(Z0 + NN + m - 1) * 64);
   int hpos[K];   // (wave-uniform) entry of FIFO m that this step reads and then overwrites: step mod m
 #pragma unroll
   for (int m = 1; m <= K; ++m) hpos[m - 1] = 0;
   // Two register sets that swap roles every step: while the arithmetic of a block runs out of one, the next
   // block's streams land in the other (no copies, and the wait for them sits at their first use, a whole step later).
   WalkStep<NU> wa, wb;
-  load_step(b, wa);
+  load_step(row0, wa);
   auto step = [&](const WalkStep<NU>& cu, WalkStep<NU>& nx, auto has_next) __attribute__((always_inline)) {
     xr[2 * K] = cu.xnew;
-    if constexpr (decltype(has_next)::value) load_step(b + S, nx);
+    if constexpr (decltype(has_next)::value) load_step(row0 + g, nx);
     // ---- near windows through LDS: element e of the block's window sits at [kWalkHalo + e], e = -16 .. 79
     xwin[kWalkHalo + lane] = xr[K];
     xwin[hx_pos] = sel2(hx_on, cu.hx, xr[K]);
@@ -389,7 +400,8 @@ __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __r
     pre.acc = accp ? cu.acc : make_double2(0.0, 0.0);
     double2 chk = make_double2(0.0, 0.0);
     double nrm = 0.0;
-    opl.row(row, make_double2(s0.x + s1.x, s0.y + s1.y), pre, chk, nrm, 0);
+    const int64_t row = row0 + lane;
+    if (in_strip && row < rend) opl.row(row, make_double2(s0.x + s1.x, s0.y + s1.y), pre, chk, nrm, 0);
     // ---- one step down the strip column
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // this step's window / FIFO reads before the writes below
     __builtin_amdgcn_wave_barrier();
@@ -401,8 +413,7 @@ __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __r
     }
 #pragma unroll
     for (int i = 0; i < 2 * K; ++i) xr[i] = xr[i + 1];
-    b += S;
-    row += g;
+    row0 += g;
   };
   int n = j1 - j0;
   for (; n > 2; n -= 2) {
@@ -491,7 +502,7 @@ int launch_hrb_walk_cheby(hipStream_t s, const DevMatrix& A, const double2* x, c
   const int64_t nW = P->R1 - P->W0;
   if (nW < tun.walk_min_blocks || nW < P->S) return QP_OK;
   WalkGeom G;
-  const int64_t J = (nW + P->S - 1) / P->S;                       // steps of the longest strip column
+  const int64_t J = (nW * kRB + P->g - 1) / P->g;                 // steps of the longest strip column
   // wavefronts.  While the operator and the vectors sit in the Infinity Cache, 768 wavefronts as 192 workgroups of four
   // (one per CU on three quarters of the chip) draw what it delivers: the set-up of a walk (8 + 10 loads) is paid less
   // often than with the 2048 that fill every SIMD twice, and the edge blocks run beside the walk on the free compute
@@ -522,6 +533,7 @@ int launch_hrb_walk_cheby(hipStream_t s, const DevMatrix& A, const double2* x, c
   G.edge_steps = (no_edges || edge_beside) ? 0 : std::max(0, tun.walk_edge_steps);
   G.edge_last = (tun.walk_dbg & 1) ? 1 : 0;
   G.edge_segs = (no_edges || edge_beside) ? 0 : (int)std::min<int64_t>(nseg_target, (P->n_edge + P->S - 1) / P->S);
+  G.xlast = A.ncols - 1;
   G.L = (int)std::max<int64_t>(G.edge_steps + 1, (J + (int64_t)G.edge_segs * G.edge_steps + nseg_target - 1) / nseg_target);
   G.nseg = (int)((J + (int64_t)G.edge_segs * G.edge_steps + G.L - 1) / G.L);
   while ((int64_t)G.nseg * G.L - (int64_t)std::min(G.edge_segs, G.nseg) * G.edge_steps < J) ++G.nseg;   // (tiny operators)

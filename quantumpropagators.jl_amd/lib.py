@@ -13,7 +13,7 @@ import weakref
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libqprop_hip.so")
+LIB_PATH = os.environ.get("QPROP_HIP_LIB") or os.path.join(_HERE, "lib", "libqprop_hip.so")   # (override: A/B of two builds)
 
 QP_OK = 0
 QP_E_INTERNAL = 10
@@ -523,7 +523,7 @@ class Operator:
         """Strip-walk plan of a Hermitian-packed lattice operator (see include/qprop.h)."""
         out = np.zeros(8, dtype=np.int64)
         check(self.lib.qp_operator_walk_info(self._h, _ptr(out, _i64p)))
-        return dict(zip(("valid", "near", "far", "diag", "blocks_per_step", "first_block", "end_block", "edge_blocks"),
+        return dict(zip(("valid", "near", "far", "diag", "rows_per_step", "first_block", "end_block", "edge_blocks"),
                         (int(v) for v in out)))
 
     def spmm_walk(self, batch):

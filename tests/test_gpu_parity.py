@@ -682,8 +682,14 @@ WALK_DEFAULTS = {"hrb_walk": 1, "walk_waves": 0, "walk_nt": -1, "walk_dbg": 0, "
     (1 << 15, (3, 128, 256), False, False, (1, 2, 0)),
     (1 << 15, (1, 2, 3, 4, 256, 512), True, False, (4, 2, 1)),
     (1 << 16, (2, 5, 9, 320, 640, 960), False, False, (3, 3, 0)),
+    # strip steps that are no multiple of the 64-row block (a 100 x 327 lattice): the last column chunk is partly filled
+    (32700, (1, 100), True, False, (1, 1, 1)),
+    (1 << 15, (1, 2, 3, 4, 100, 200, 300, 400), False, False, (4, 4, 0)),
+    (1 << 15, (1, 16, 65, 130), False, True, (2, 2, 0)),
+    ((1 << 15) + 77, (2, 127, 254, 381), True, False, (1, 3, 1)),
+    (1 << 16, (1, 5, 1000, 2000), False, False, (2, 2, 0)),
 ], ids=["16nnz", "8nnz", "near3far1", "near1far3", "16nnz+diag", "g192", "real+diag", "5point", "4nnz", "near2far1+diag",
-        "near1far2", "near4far2+diag", "near3far3"])
+        "near1far2", "near4far2+diag", "near3far3", "g100_5point", "g100_16nnz", "g65_real", "g127+diag_ragged", "g1000"])
 def test_strip_walk_bit_identical_to_block_kernel(ctx, N, offsets, diag, real, shape):
     """The strip-walk kernel of a lattice operator (kernels_walk.hip: register ring of the gathered elements, FIFO of the
     far upper values and near windows in LDS, edge blocks on the per-block path) sums every row in the order of the
@@ -700,7 +706,7 @@ def test_strip_walk_bit_identical_to_block_kernel(ctx, N, offsets, diag, real, s
         Op = L.Operator(ctx, [L.Matrix(ctx, N, N, rp, col, vals)], 0, L.FMT_HRB)
         wi = Op.walk_info()
         assert wi["valid"] == 1 and (wi["near"], wi["far"], wi["diag"]) == shape
-        assert wi["blocks_per_step"] * 64 == [d for d in offsets if d >= 64][0]
+        assert wi["rows_per_step"] == [d for d in offsets if d >= 64][0]
         assert 0 < wi["edge_blocks"] < 0.6 * Op.layout_info()["blocks"]
         psi0 = synth.random_state(N)
         wrk = L.ChebyWrk(ctx, N, 24.0, -12.0, 1.0)
@@ -742,7 +748,7 @@ def test_strip_walk_random_lattices_bit_identical(ctx):
         for trial in range(40):
             nn, K = int(rng.integers(1, 5)), int(rng.integers(1, 5))
             S = int(rng.choice([1, 2, 3, 5, 8, 16, 40]))
-            g = 64 * S
+            g = 64 * S if trial % 2 == 0 else int(rng.integers(64, 64 * S + 64))     # every other trial: any stride
             near = sorted(rng.choice(np.arange(1, 17), nn, replace=False).tolist())
             nsteps = int(rng.integers(2 * K + 4, 2 * K + 40))
             N = g * nsteps + int(rng.choice([0, 0, 64, 17, 200]))
@@ -762,7 +768,7 @@ def test_strip_walk_random_lattices_bit_identical(ctx):
             if not wi["valid"]:
                 Op.close()
                 continue
-            assert (wi["near"], wi["far"], wi["diag"], wi["blocks_per_step"]) == (nn, K, int(diag), S)
+            assert (wi["near"], wi["far"], wi["diag"], wi["rows_per_step"]) == (nn, K, int(diag), g)
             psi0 = synth.random_state(N, seed=trial)
             wrk = L.ChebyWrk(ctx, N, 26.0, -13.0, 0.9)
             outs = []
@@ -824,13 +830,14 @@ def test_strip_walk_inside_a_replayed_graph(ctx):
 def test_strip_walk_plan_only_for_lattices(ctx):
     """The walk plan is index work on the host: it exists only where one list of column distances repeats down a run of row
     blocks and has the walk's shape -- not for scattered or per-row random columns, not for near distances beyond the LDS
-    halo, far distances that are not multiples of one 64-row-aligned stride, more than four near or far distances -- and it
+    halo, far distances that are not the multiples g, 2 g, .. of one stride g >= 64 (any such g will do), more than four near or far
+    distances -- and it
     goes away when a complex coefficient forces the operator out of the Hermitian-packed format."""
     N = 1 << 15
     saved = ctx.tuning_get("walk_min_blocks")
     ctx.tuning_set("walk_min_blocks", 16)
     try:
-        for offsets, want in (((1, 2, 512, 1024), 1), ((1, 2, 500, 1000), 0), ((1, 17, 512, 1024), 0), ((1, 2, 512, 1536), 0),
+        for offsets, want in (((1, 2, 512, 1024), 1), ((1, 2, 500, 1000), 1), ((1, 2, 500, 1100), 0), ((1, 2, 40, 80), 0), ((1, 17, 512, 1024), 0), ((1, 2, 512, 1536), 0),
                               ((1, 2, 3, 512), 1), ((1, 512, 1024, 1536), 1), ((3, 5, 320, 640), 1), ((1, 2, 3, 4, 5, 6, 512, 1024), 0)):
             rp, col, vals = synth.hermitian_offsets_csr(N, offsets=offsets)
             Op = L.Operator(ctx, [L.Matrix(ctx, N, N, rp, col, vals)], 0, L.FMT_HRB)

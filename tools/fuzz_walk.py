@@ -31,7 +31,7 @@ def main():
     for case in range(ncases):
         nn, K = int(rng.integers(1, 5)), int(rng.integers(1, 5))
         S = int(rng.choice([1, 2, 3, 4, 7, 16, 40]))
-        g = 64 * S
+        g = 64 * S if rng.integers(0, 2) else int(rng.integers(64, 64 * S + 64))      # half of the cases: any stride
         near = sorted(rng.choice(np.arange(1, 17), nn, replace=False).tolist())
         nsteps = int(rng.integers(2 * K + 6, 2 * K + 60))
         N = g * nsteps + int(rng.choice([0, 0, 64, 1, 37, 200]))

@@ -27,12 +27,16 @@ def main():
     ap.add_argument("--formats", default="rbcsr")
     ap.add_argument("--lower-last", type=int, default=0)
     ap.add_argument("--ab", default="", help="A/B over one knob: key=v1,v2,... (every format / variant case is run with each value)")
+    ap.add_argument("--offsets", default="", help="Hermitian lattice with these distances instead of --pattern (e.g. 1,1000 or 1,2,3,4,100,200,300,400)")
     ap.add_argument("--real", action="store_true", help="real symmetric H (values streamed as fp64 instead of complex)")
     args = ap.parse_args()
     N = args.n if args.n else 1 << args.log2n
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import bench_points as bp
-    rp, col, vals = bp.pattern_csr(args.pattern, N)      # banded | scattered | random | random-window
+    if args.offsets:
+        rp, col, vals = synth.hermitian_offsets_csr(N, offsets=tuple(int(t) for t in args.offsets.split(",")))
+    else:
+        rp, col, vals = bp.pattern_csr(args.pattern, N)      # banded | scattered | random | random-window
     if args.real:
         vals = vals.real.astype(np.complex128)
     ctx = L.Context(0)

@@ -172,6 +172,10 @@ struct Stats {
 int launch_spmv_cheby(hipStream_t s, const DevMatrix& A, const double2* x, const ChebyEpi& e, Stats* st,
                       const RowSet* rs = nullptr);
 int launch_spmv_plain(hipStream_t s, const DevMatrix& A, const double2* x, const PlainEpi& e, Stats* st);
+// kernels_arnoldi.hip: the Arnoldi column's mat-vec with the multidot (c_k = <q_k|w>, Gram row <q_k|q_j>, k <= j) in its
+// epilogue; partials in the multidot's layout.  *launched = false: no instance (format, column index): nothing was done
+int launch_arnoldi_matvec_dots(hipStream_t s, const DevMatrix& A, const double2* x, const PlainEpi& e, const double2* Q,
+                               int64_t ldq, int j, double2* partials, bool* launched, Stats* st);
 // the strip walk for the fused Chebyshev term of a whole Hermitian-packed lattice operator; *launched = false when the
 // plan's shape has no kernel instance (the caller then takes the per-block kernel)
 bool walk_shape_supported(int nn, int K, int z0);   // is there a kernel instance for this stencil shape?
@@ -185,6 +189,7 @@ struct Tuning {
   int rbcsr_variant = 15;     // bit 0 nt matrix loads, bit 1 early row-local loads, bit 2 deeper unroll, bit 3 (Hermitian-packed kernel) all loads of an all-stencil block up front (A/B in profiles/)
   int hrb_lower_last = 0;     // HRB kernel: process the lower (conj-transposed) section after the upper one
   int arnoldi_mode = 1;       // 0 = sequential fused MGS passes, 1 = low-synchronisation MGS
+  int arnoldi_fuse_dots = 1;  // 1 = the multidot of a column runs in its mat-vec's epilogue where an instance exists (row-block format, j <= 19): 2 launches per column
   int arnoldi_solve = 1;      // 1 = the MGS reduction + solve run in the projection kernel's prologue (3 launches per column), 0 = own launch
   int arnoldi_fold = 1;       // 1 = the norm + scale of an Arnoldi column is folded into the next column's mat-vec (no launch of its own)
   int split_spin_log2 = 28;   // in-launch hand-off: a polling workgroup gives up after 2^this polls (~1 min) and raises the split's time-out flag
@@ -347,7 +352,8 @@ int launch_mgs_pass(hipStream_t s, const MgsArgs& a, Stats* st);
 int launch_mgs_lowsync(hipStream_t s, const double2* Q, int64_t ldq, int j, double2* w, double2* md_partials,
                        double2* G, int ldg, double2* hess_col, double2* reduced, double2* coef, unsigned* ticket,
                        double2* norm_partials, double dt, int64_t n, Stats* st, bool solve_in_update = false,
-                       unsigned* early_flag = nullptr, unsigned flag_value = 0, bool* early_armed = nullptr);
+                       unsigned* early_flag = nullptr, unsigned flag_value = 0, bool* early_armed = nullptr,
+                       bool dots_done = false);
 // the same in pieces for row-partitioned runs: local sums -> (all-reduce by the caller) ->
 // solve (one workgroup) + update
 int launch_mgs_multidot(hipStream_t s, const double2* Q, int64_t ldq, int j, const double2* w, double2* md_partials,

@@ -128,8 +128,12 @@ int arnoldi_column(qp_operator* op, qp_krylov* q, int j, double dt, double2* hco
     pe.flag = fold->flag;
     pe.flag_value = fold->flag_value;
   }
-  QP_CHECK(qp::launch_spmv_plain(ctx->stream, op->A, xin, pe, &ctx->stats));  // src/arnoldi.jl:82
-  if (ctx->tun.arnoldi_mode == 1 && q->gram_rows >= j && qp::mgs_lowsync_fits(j)) {
+  const bool lowsync = ctx->tun.arnoldi_mode == 1 && q->gram_rows >= j && qp::mgs_lowsync_fits(j);
+  bool dots_done = false;
+  if (lowsync && ctx->tun.arnoldi_fuse_dots)   // knob: the multidot in the mat-vec's epilogue (kernels_arnoldi.hip)
+    QP_CHECK(qp::launch_arnoldi_matvec_dots(ctx->stream, op->A, xin, pe, q->Q, q->n, j, q->md_part, &dots_done, &ctx->stats));
+  if (!dots_done) QP_CHECK(qp::launch_spmv_plain(ctx->stream, op->A, xin, pe, &ctx->stats));  // src/arnoldi.jl:82
+  if (lowsync) {
     // low-synchronisation MGS: same coefficients (to rounding), 3 launches per column;
     // leaves |w|^2 partials in part[(j+1)&1] like the sequential path.  Needs the Gram
     // rows of the earlier basis vectors, which only this path maintains (a basis built by
@@ -138,7 +142,7 @@ int arnoldi_column(qp_operator* op, qp_krylov* q, int j, double dt, double2* hco
     return qp::launch_mgs_lowsync(ctx->stream, q->Q, q->n, j, w, q->md_part, q->gram, q->nvec, hcol,
                                   q->hcoef, q->mgs_coef, q->ticket, q->part + (size_t)((j + 1) & 1) * kRedBlocks, dt,
                                   q->n, &ctx->stats, ctx->tun.arnoldi_solve != 0, fold ? fold->early_flag : nullptr,
-                                  fold ? fold->flag_value : 0u, fold ? fold->early_armed : nullptr);
+                                  fold ? fold->flag_value : 0u, fold ? fold->early_armed : nullptr, dots_done);
   }
   q->gram_rows = std::min(q->gram_rows, j);
   for (int i = 0; i <= j + 1; ++i) {                                              // :84-87

@@ -23,10 +23,27 @@ __device__ __forceinline__ double2 cconj_mul(const double2 a, const double2 b) {
   return make_double2(a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x);
 }
 
+// Sum over the 64 lanes of a wavefront, returned in EVERY lane, through the data-parallel primitives of the vector ALU
+// (row shifts inside the rows of 16 lanes, then the two row broadcasts of gfx9): about twenty instructions and no
+// trip through the LDS crossbar -- the ds_bpermute form that __shfl_down compiles to is six dependent LDS round trips,
+// ~500 clocks per sum, which dominated the prologues and epilogues of the Arnoldi kernels (dozens of sums each).
+// Fixed order: prefix sums inside each row of 16, rows 0+1 and 2+3, then the halves.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_take(double v) {   // lanes without a source (or outside the row mask) get 0
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  return v;
+  v += dpp_take<0x111, 0xf>(v);   // row_shr:1
+  v += dpp_take<0x112, 0xf>(v);   // row_shr:2
+  v += dpp_take<0x114, 0xf>(v);   // row_shr:4
+  v += dpp_take<0x118, 0xf>(v);   // row_shr:8   -> lane 15 of every row holds the row's sum
+  v += dpp_take<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+  v += dpp_take<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3  -> lane 63 holds the total
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
 }
 
 // sum over the 256-thread workgroup, result broadcast to every thread; fixed order

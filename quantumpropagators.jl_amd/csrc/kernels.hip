@@ -1078,7 +1078,7 @@ int* tuning_field(Tuning& t, const char* key) {
   static const Entry table[] = {
       {"rbcsr_variant", &Tuning::rbcsr_variant}, {"hrb_lower_last", &Tuning::hrb_lower_last},
       {"arnoldi_mode", &Tuning::arnoldi_mode},   {"split_mode", &Tuning::split_mode},
-      {"arnoldi_fold", &Tuning::arnoldi_fold},   {"spmm_wg", &Tuning::spmm_wg},   {"hrb_wg", &Tuning::hrb_wg},   {"arnoldi_solve", &Tuning::arnoldi_solve},
+      {"arnoldi_fold", &Tuning::arnoldi_fold},   {"spmm_wg", &Tuning::spmm_wg},   {"hrb_wg", &Tuning::hrb_wg},   {"arnoldi_solve", &Tuning::arnoldi_solve},   {"arnoldi_fuse_dots", &Tuning::arnoldi_fuse_dots},
       {"liouville_fused_n", &Tuning::liouville_fused_n}, {"liouville_tile32_n", &Tuning::liouville_tile32_n}, {"liouville_tile32_min_n", &Tuning::liouville_tile32_min_n}, {"real_vals", &Tuning::real_vals},
       {"stencil", &Tuning::stencil},             {"acc_defer", &Tuning::acc_defer},
       {"cheby_graph", &Tuning::cheby_graph},     {"small_nnz", &Tuning::small_nnz},
@@ -2051,9 +2051,11 @@ int launch_mgs_project(hipStream_t s, const double2* Q, int64_t ldq, int j, doub
 int launch_mgs_lowsync(hipStream_t s, const double2* Q, int64_t ldq, int j, double2* w, double2* md_partials,
                        double2* G, int ldg, double2* hess_col, double2* reduced, double2* coef, unsigned* ticket,
                        double2* norm_partials, double dt, int64_t n, Stats* st, bool solve_in_update,
-                       unsigned* early_flag, unsigned flag_value, bool* early_armed) {
-  int rc = launch_multidot(s, Q, ldq, j, w, md_partials, n, st);
-  if (rc != QP_OK) return rc;
+                       unsigned* early_flag, unsigned flag_value, bool* early_armed, bool dots_done) {
+  if (!dots_done) {   // (else: the mat-vec left the partials, kernels_arnoldi.hip)
+    int rc = launch_multidot(s, Q, ldq, j, w, md_partials, n, st);
+    if (rc != QP_OK) return rc;
+  }
   if (early_armed) *early_armed = false;
   if (solve_in_update && mgs_solve_lds(j) <= 12 * 1024) {   // j <= 35: reduction + solve in the projection's prologue
     if (early_armed) *early_armed = early_flag != nullptr;

@@ -448,6 +448,45 @@ def test_arnoldi_matches_oracle(ctx, arnoldi_mode):
             assert np.max(np.abs(H2 - Href2)) < 1e-12
 
 
+@pytest.mark.parametrize("real", [False, True], ids=["complex", "real_copy"])
+def test_arnoldi_fused_dots_matches_oracle_and_unfused(ctx, real):
+    """Knob `arnoldi_fuse_dots` (kernels_arnoldi.hip): the mat-vec of an Arnoldi column also accumulates the column's dot
+    products c_k = <q_k|w> and its Gram row -- 2 launches per column instead of 3 while j <= 19, the unfused pair beyond.
+    Same Hessenberg matrix and basis as the oracle and as the unfused kernels (different summation order: 1e-12), on a
+    ragged N whose row blocks do not fill the 2048 wavefronts of the launch, for complex values and for the real copy."""
+    rng = np.random.default_rng(77)
+    N, m, dt = 20000 + 37, 24, 0.21
+    A = synth.sparse_random(N, 6.0 / N, rng=rng)
+    if real:
+        A = sp.csr_matrix(A.real.astype(complex))
+    psi = _rand_state(N, rng)
+    saved = {k: ctx.tuning_get(k) for k in ("small_nnz", "arnoldi_fuse_dots", "arnoldi_mode")}
+    try:
+        ctx.tuning_set("small_nnz", 0)
+        ctx.tuning_set("arnoldi_mode", 1)
+        Op = L.Operator(ctx, [L.Matrix.from_scipy(ctx, A)], 0, L.FMT_RBCSR)
+        res = {}
+        for fuse in (1, 0):
+            ctx.tuning_set("arnoldi_fuse_dots", fuse)
+            q = L.Krylov(ctx, N, m + 1)
+            Hess = np.zeros((m + 1, m + 1), dtype=complex, order="F")
+            ctx.sync()
+            ctx.reset_stats()
+            assert L.arnoldi(Hess, q, m, L.State(ctx, data=psi), Op, dt, extended=True) == m
+            res[fuse] = (Hess, [q.vec(i) for i in range(m + 1)], ctx.stats()["n_kernel_launches"])
+        Href = np.zeros((m + 1, m + 1), dtype=complex)
+        qref = [np.empty(N, dtype=complex) for _ in range(m + 1)]
+        assert qo.arnoldi(Href, qref, m, psi, A, dt, extended=True) == m
+        for fuse in (1, 0):
+            assert np.max(np.abs(res[fuse][0] - Href)) < 1e-12
+            for i in range(m + 1):
+                assert np.linalg.norm(res[fuse][1][i] - qref[i]) < 1e-11
+        assert res[0][2] - res[1][2] == 20          # one launch less for each of the columns j = 0 .. 19
+    finally:
+        for k, v in saved.items():
+            ctx.tuning_set(k, v)
+
+
 def test_arnoldi_breakdown(ctx, arnoldi_mode):
     """Krylov dimension smaller than m: reduced m is returned (src/arnoldi.jl:91-95),
     also for negative dt."""

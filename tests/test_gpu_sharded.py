@@ -11,6 +11,7 @@ import sys
 
 import numpy as np
 import pytest
+import scipy.sparse as sp
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -139,19 +140,27 @@ def test_sharded_overlap_machinery_world1(pg, overlap, split_mode):
     ctx.close()
 
 
-@pytest.mark.parametrize("split_mode", [2, 1, 0])
-def test_split_interior_as_strip_walk_world1(pg, split_mode):
+@pytest.mark.parametrize("split_mode,offsets", [(2, (1, 2, 3, 4, 256, 512, 768, 1024)), (1, (1, 2, 3, 4, 256, 512, 768, 1024)),
+                                                (0, (1, 2, 3, 4, 256, 512, 768, 1024)), (2, (1, 2, 3, 4, 250, 500, 750, 1000)),
+                                                (2, (1, 1000))], ids=["mode2", "mode1", "mode0", "g250", "five_point_g1000"])
+def test_split_interior_as_strip_walk_world1(pg, split_mode, offsets):
     """A lattice operator's interior launch takes the strip walk (kernels_walk.hip) over the interior blocks from which no
     walked block reaches a boundary row; the rest of the interior are its edge blocks, the only ones that wait for the
     boundary launch.  One rank with a forced send set (first and last 4096 rows, like config C4's halo): every hand-off
-    mode gives the bits of the serial schedule -- which walks the whole operator -- and of the per-block kernels."""
+    mode gives the bits of the serial schedule -- which walks the whole operator -- and of the per-block kernels; also for
+    strip steps that are no multiple of the 64-row block."""
     import torch
     from oracle import qp_oracle as qo
     import qprop_amd.lib as L
     import qprop_amd.sharded as sharded
     import qprop_amd.synth as synth
     N = 1 << 17
-    rp, col, vals = synth.hermitian_offsets_csr(N, offsets=(1, 2, 3, 4, 256, 512, 768, 1024))
+    rp, col, vals = synth.hermitian_offsets_csr(N, offsets=offsets)
+    if len(offsets) == 2:    # hopping + on-site term
+        Hd = synth.to_scipy(rp, col, vals, N) + sp.diags(np.linspace(-1.0, 1.0, N)).astype(np.complex128)
+        Hd = sp.csr_matrix(Hd)
+        Hd.sort_indices()
+        rp, col, vals = Hd.indptr.astype(np.int64), Hd.indices.astype(np.int32), Hd.data.astype(np.complex128)
     ctx = L.Context(0, stream=torch.cuda.current_stream().cuda_stream)
     send = np.concatenate([np.arange(0, 4096), np.arange(N - 4096, N)])
     psi0 = synth.random_state(N)

@@ -167,6 +167,13 @@ int qp_operator_layout_info(const qp_operator* op, int64_t out[5]);
  * only rewrites coefficients, but a complex coefficient on a Hermitian-packed operator forces ONE rebuild as plain
  * row blocks (a slower mat-vec from then on) --, out[3] = the current device format (QP_FMT_*). */
 int qp_operator_build_info(const qp_operator* op, double out[4]);
+/* Lattice completion at qp_operator_create (knob lattice_fill): explicit zeros added to the union pattern so that every
+ * interior row of a lattice operator with open boundaries (a finite-difference Hamiltonian on a grid: the rows at the
+ * grid's x-edges lack one neighbour) carries the same list of column distances -- what the strip walk and the stencil
+ * encoding need.  *n_filled = 0 for every other operator.  The zeros show up in qp_operator_get_csr and in the stored
+ * count of qp_operator_layout_info; the reference's sparse matrices (src/generators.jl:634-645 mul!) keep explicit
+ * zeros in the same way. */
+int qp_operator_fill_info(const qp_operator* op, int64_t* n_filled);
 /* Strip-walk plan of a Hermitian-packed lattice operator (the fused Chebyshev term then walks down strip columns and
  * keeps the re-read data in registers / LDS): out[0] = 1 if the operator has one, out[1] = near distances, out[2] = far
  * reach K (far distances m g, m = 1..K), out[3] = 1 if the stencil has a diagonal, out[4] = rows per strip step g

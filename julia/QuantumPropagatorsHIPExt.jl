@@ -238,6 +238,13 @@ function operator_walk_info(op::Handle)
             first_block = out[6], end_block = out[7], edge_blocks = out[8])
 end
 
+# explicit zeros that qp_operator_create added to complete a lattice operator's rows (open boundaries of a grid)
+function operator_fill_info(op::Handle)
+    n = Ref{Int64}(0)
+    check(ccall((:qp_operator_fill_info, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}), op, n))
+    return n[]
+end
+
 # mul!(C, A::Operator, B, α, β) on device vectors   src/generators.jl:634-645
 function hip_mul!(y::HIPState, op::Handle, x::HIPState, α::Number = true, β::Number = false)
     check(ccall((:qp_mul, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, C128, C128),

@@ -189,6 +189,7 @@ struct Tuning {
   int rbcsr_variant = 15;     // bit 0 nt matrix loads, bit 1 early row-local loads, bit 2 deeper unroll, bit 3 (Hermitian-packed kernel) all loads of an all-stencil block up front (A/B in profiles/)
   int hrb_lower_last = 0;     // HRB kernel: process the lower (conj-transposed) section after the upper one
   int arnoldi_mode = 1;       // 0 = sequential fused MGS passes, 1 = low-synchronisation MGS
+  int lattice_fill = 1;       // 1 = rows of a lattice operator that lack a few of its distances (open boundaries of a grid) are completed with explicit zeros
   int arnoldi_fuse_dots = 1;  // 1 = the multidot of a column runs in its mat-vec's epilogue where an instance exists (row-block format, j <= 19): 2 launches per column
   int arnoldi_solve = 1;      // 1 = the MGS reduction + solve run in the projection kernel's prologue (3 launches per column), 0 = own launch
   int arnoldi_fold = 1;       // 1 = the norm + scale of an Arnoldi column is folded into the next column's mat-vec (no launch of its own)

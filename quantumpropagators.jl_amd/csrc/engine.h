@@ -67,6 +67,7 @@ struct qp_operator {
   qp::SpmmWalkPlan spmm_walk;     // strip-walk plan of the batched term, built on first use
   bool spmm_walk_built = false;
   double build_ms = 0, build_ms_total = 0;   // host time of the latest / of all device layout builds
+  int64_t n_lattice_fill = 0;               // explicit zeros that complete a lattice operator's rows (engine_core.hip: lattice_fill)
   int n_builds = 0, n_relayouts = 0;         // re-layouts: builds forced after creation (complex coefficient on a packed operator)
   bool hermitian_planes = false;
   // CSR-ordered mirror of the current values for the batched (SpMM) path, built lazily

@@ -896,12 +896,28 @@ static int choose_format(qp_operator* op, int requested, bool hermitian) {
   // (profiles/r01/kbench_*): accept up to 50 % padding before falling back
   const bool rb_ok = (double)rb_stored <= 1.5 * (double)nnz + 1024.0;
   if (requested == QP_FMT_AUTO) {
-    if (!rb_ok) return QP_FMT_CSR;
+    // (a Hermitian operator is judged by the padding of its packed form further down: five entries per row -- the
+    // five-point lattice -- pad to eight as plain row blocks, but to four upper entries when packed)
+    if (!rb_ok && !hermitian) return QP_FMT_CSR;
     // few, long rows (small dense generators: the reference's test and benchmark sizes): a
     // row block gives one wavefront 64 rows to walk entry by entry -- too few wavefronts to
     // hide the latency.  One wavefront per row instead (CSR kernel, 64 lanes per row).
     if (nblocks < 2048 && nnz >= 32 * nrows) return QP_FMT_CSR;
     if (!hermitian) return QP_FMT_RBCSR;
+    int64_t hu_stored = 0;   // values the packed form stores: the upper section of every block, padded to a multiple of four
+    {
+      const auto& ucc = op->u_col;
+      for (int64_t b = 0; b < nblocks; ++b) {
+        int64_t w = 0;
+        for (int64_t r = b * kRB; r < std::min(nrows, (b + 1) * kRB); ++r) {
+          const int32_t* cb = ucc.data() + ur[r];
+          const int32_t* ce = ucc.data() + ur[r + 1];
+          w = std::max<int64_t>(w, ce - std::lower_bound(cb, ce, (int32_t)r));
+        }
+        hu_stored += ((w + 3) & ~(int64_t)3) * kRB;
+      }
+    }
+    const bool hrb_ok = rb_ok || (double)hu_stored <= 0.9 * (double)nnz + 1024.0;
     // Hermitian packing pays only if the transposed values are still in the XCD's L2
     // (4 MiB) when the lower entry is processed: the rows stream in order, so require
     // (row - col) * bytes-per-row <= 2 MiB for at least 85 % of the lower entries.
@@ -942,10 +958,92 @@ static int choose_format(qp_operator* op, int requested, bool hermitian) {
     }
     const bool coalesced = sampled == 0 || 4 * regular >= 3 * sampled;
     // (the packed format addresses the transposed values with int32 positions)
-    return ((double)nnear >= 0.85 * (double)nlow && coalesced && rb_stored < (int64_t)INT32_MAX) ? QP_FMT_HRB : QP_FMT_RBCSR;
+    if ((double)nnear >= 0.85 * (double)nlow && coalesced && hrb_ok && rb_stored < (int64_t)INT32_MAX) return QP_FMT_HRB;
+    return rb_ok ? QP_FMT_RBCSR : QP_FMT_CSR;
   }
   if (requested == QP_FMT_HRB && !hermitian) return -1;
   return requested;
+}
+
+// Lattice completion (knob lattice_fill).  A finite-difference operator on an nx x ny grid with open boundaries is the
+// walk's lattice -- distances +-1, +-nx -- except that the rows at x = 0 lack the -1 entry and those at x = nx - 1 the +1
+// entry: one row in nx breaks the "same distances on every row" run that the strip walk (and the stencil encoding of the
+// row blocks) needs.  If every row between the first and the last K g rows carries a SUBSET of the middle row's distance
+// list, that list has the walk's shape, and at most 3 % of the entries are missing, the missing ones are stored as explicit
+// zeros (with their transposes, so that the pattern stays structurally symmetric).  Index work only; 0 * x terms change no
+// row sum beyond the order in which the two accumulators of a row take their entries.
+static void lattice_fill(const qp::Tuning& tun, int64_t n, int64_t ncols, std::vector<int64_t>& ur, std::vector<int32_t>& uc) {
+  if (!tun.lattice_fill || !tun.hrb_walk || n != ncols || n / kRB < std::max(tun.walk_min_blocks, 16)) return;
+  // the reference row: the fullest one near the middle (the middle row itself may sit on the grid's edge)
+  int64_t rm = n / 2;
+  for (int64_t r = std::max<int64_t>(0, n / 2 - 128); r < std::min(n, n / 2 + 128); ++r)
+    if (ur[r + 1] - ur[r] > ur[rm + 1] - ur[rm]) rm = r;
+  const int z = (int)(ur[rm + 1] - ur[rm]);
+  if (z < 3 || z > 17) return;
+  std::vector<int64_t> D((size_t)z);
+  for (int k = 0; k < z; ++k) D[(size_t)k] = (int64_t)uc[ur[rm] + k] - rm;
+  for (int k = 0; k < z; ++k)
+    if (D[(size_t)k] != -D[(size_t)(z - 1 - k)]) return;
+  int K = 0, nn = 0, k = 0;
+  while (k < z && D[(size_t)k] <= -(int64_t)kRB) ++k, ++K;
+  if (K < 1 || K > 4) return;
+  const int64_t g = -D[(size_t)(K - 1)];
+  for (int m = 1; m <= K; ++m)
+    if (D[(size_t)(K - m)] != -(int64_t)m * g) return;
+  while (k < z && D[(size_t)k] < 0) {
+    if (-D[(size_t)k] > qp::kWalkHalo) return;
+    ++k, ++nn;
+  }
+  const int z0 = (k < z && D[(size_t)k] == 0) ? 1 : 0;
+  if (nn < 1 || nn > 4 || z != 2 * (nn + K) + z0 || !qp::walk_shape_supported(nn, K, z0)) return;
+  const int64_t lo = (int64_t)K * g, hi = n - (int64_t)K * g;
+  if (hi - lo < 16 * (int64_t)kRB) return;
+  int64_t missing = 0;
+  for (int64_t r = lo; r < hi; ++r) {
+    int d = 0;
+    for (int64_t p = ur[r]; p < ur[r + 1]; ++p) {
+      const int64_t delta = (int64_t)uc[p] - r;
+      while (d < z && D[(size_t)d] < delta) ++d;
+      if (d == z || D[(size_t)d] != delta) return;   // an entry outside the lattice's distances: not this kind of operator
+      ++d;
+    }
+    missing += z - (ur[r + 1] - ur[r]);
+  }
+  if (missing == 0 || (double)missing > 0.03 * (double)ur[n]) return;
+  // transposes of filled entries that land in the first / last K g rows
+  std::vector<std::pair<int64_t, int32_t>> extra;
+  for (int64_t r = lo; r < hi; ++r) {
+    if (ur[r + 1] - ur[r] == z) continue;
+    int64_t p = ur[r];
+    for (int d = 0; d < z; ++d) {
+      const int64_t c = r + D[(size_t)d];
+      if (p < ur[r + 1] && uc[p] == c) {
+        ++p;
+        continue;
+      }
+      if (c < lo || c >= hi) extra.emplace_back(c, (int32_t)r);
+    }
+  }
+  std::sort(extra.begin(), extra.end());
+  std::vector<int64_t> nr((size_t)n + 1, 0);
+  std::vector<int32_t> nc;
+  nc.reserve(uc.size() + (size_t)missing + extra.size());
+  size_t ex = 0;
+  std::vector<int32_t> row;
+  for (int64_t r = 0; r < n; ++r) {
+    if (r >= lo && r < hi) {
+      for (int d = 0; d < z; ++d) nc.push_back((int32_t)(r + D[(size_t)d]));
+    } else {
+      row.assign(uc.begin() + ur[r], uc.begin() + ur[r + 1]);
+      while (ex < extra.size() && extra[ex].first == r) row.push_back(extra[ex++].second);
+      std::sort(row.begin(), row.end());
+      row.erase(std::unique(row.begin(), row.end()), row.end());
+      nc.insert(nc.end(), row.begin(), row.end());
+    }
+    nr[(size_t)r + 1] = (int64_t)nc.size();
+  }
+  ur.swap(nr);
+  uc.swap(nc);
 }
 
 int qp_operator_create(qp_ctx* ctx, qp_matrix* const* ops, int nops, int ncoeffs, int format,
@@ -988,6 +1086,11 @@ int qp_operator_create(qp_ctx* ctx, qp_matrix* const* ops, int nops, int ncoeffs
       uc.insert(uc.end(), merged.begin(), merged.end());
       ur[r + 1] = (int64_t)uc.size();
     }
+  }
+  if (format == QP_FMT_AUTO || format == QP_FMT_HRB) {
+    const int64_t before = ur[nrows];
+    lattice_fill(ctx->tun, nrows, ncols, ur, uc);
+    op->n_lattice_fill = ur[nrows] - before;
   }
   op->A.nnz = ur[nrows];
 
@@ -1129,6 +1232,12 @@ int qp_operator_build_info(const qp_operator* op, double out[4]) {
   out[1] = op->build_ms_total;
   out[2] = (double)op->n_relayouts;
   out[3] = (double)op->A.format;
+  return QP_OK;
+}
+
+int qp_operator_fill_info(const qp_operator* op, int64_t* n_filled) {
+  if (!op || !n_filled) return qp::fail(QP_E_BAD_ARG, "qp_operator_fill_info: NULL argument");
+  *n_filled = op->n_lattice_fill;
   return QP_OK;
 }
 

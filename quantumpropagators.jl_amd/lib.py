@@ -126,6 +126,7 @@ SIGNATURES = {
     "qp_operator_layout_info": (C.c_int, [_P, _i64p]),
     "qp_operator_build_info": (C.c_int, [_P, _dp]),
     "qp_operator_walk_info": (C.c_int, [_P, _i64p]),
+    "qp_operator_fill_info": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "qp_operator_spmm_walk": (C.c_int, [_P, C.c_int, _i64p]),
     "qp_state_create": (C.c_int, [_P, C.c_int64, C.POINTER(_P)]),
     "qp_state_wrap": (C.c_int, [_P, _P, C.c_int64, C.POINTER(_P)]),
@@ -518,6 +519,12 @@ class Operator:
         out = np.zeros(4, dtype=np.float64)
         check(self.lib.qp_operator_build_info(self._h, _ptr(out, _dp)))
         return {"build_ms": float(out[0]), "build_ms_total": float(out[1]), "relayouts": int(out[2]), "format": int(out[3])}
+
+    def fill_info(self):
+        """Explicit zeros that operator creation added to complete a lattice operator's rows (0 for any other operator)."""
+        n = C.c_int64(0)
+        check(self.lib.qp_operator_fill_info(self._h, C.byref(n)))
+        return n.value
 
     def walk_info(self):
         """Strip-walk plan of a Hermitian-packed lattice operator (see include/qprop.h)."""

@@ -82,6 +82,43 @@ def hermitian_offsets_csr(N, offsets=BANDED_OFFSETS, rho=10.0, seed=DEFAULT_SEED
     return rowptr, cols.reshape(-1).astype(np.int32), vals.reshape(-1)
 
 
+def grid_hamiltonian_2d(nx, ny, flux=0.0, next_nearest=False, seed=DEFAULT_SEED):
+    """Finite-difference Hamiltonian of a particle on an nx x ny grid with OPEN boundaries (row = x + nx y): hopping -1 to
+    the four neighbours (Peierls phase exp(i flux y) on the x-hops when flux != 0, so the couplings are complex), optionally
+    -1/4 to the second neighbours along x, and a smooth potential on the diagonal.  The rows at the x-edges of the grid lack
+    a neighbour -- the lattice with holes that operator creation completes (include/qprop.h: qp_operator_fill_info).
+    Returns scipy CSR (sorted indices)."""
+    import scipy.sparse as sp
+    x = np.arange(nx)
+    y = np.arange(ny)
+    X, Y = np.meshgrid(x, y, indexing="xy")            # row-major in y: index = x + nx * y
+    idx = (X + nx * Y).ravel()
+    rows, cols, vals = [], [], []
+
+    def hop(mask, d, v):
+        r = idx[mask.ravel()]
+        rows.extend([r, r + d])
+        cols.extend([r + d, r])
+        vv = v.ravel()[mask.ravel()] if np.ndim(v) else np.full(len(r), v, dtype=np.complex128)
+        vals.extend([vv, np.conj(vv)])
+
+    phase = np.exp(1j * flux * Y) if flux else np.ones_like(Y, dtype=np.complex128)
+    hop(X < nx - 1, 1, -phase)
+    hop(Y < ny - 1, nx, np.complex128(-1.0))
+    if next_nearest:
+        hop(X < nx - 2, 2, -0.25 * phase * phase)
+    with np.errstate(over="ignore"):
+        jitter = _u01(splitmix64(np.uint64(seed) ^ (idx.astype(np.uint64) * _GOLDEN)))
+    pot = 0.5 * ((X - nx / 2) / nx) ** 2 + 0.5 * ((Y - ny / 2) / ny) ** 2
+    rows.append(idx)
+    cols.append(idx)
+    vals.append((4.0 + pot.ravel() + 0.01 * jitter).astype(np.complex128))
+    H = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(nx * ny, nx * ny))
+    H.sum_duplicates()
+    H.sort_indices()
+    return H
+
+
 def random_columns_csr(N, n_pairs=8, window=None, rho=10.0, seed=DEFAULT_SEED):
     """Hermitian H whose columns are drawn PER ROW (no translation invariance: the irregular case that
     plain "CSR" implies), 2 n_pairs entries per row, no diagonal.  Rows are cut into blocks of `window`

@@ -831,6 +831,66 @@ def test_strip_walk_random_lattices_bit_identical(ctx):
     assert n_walked >= 24
 
 
+@pytest.mark.parametrize("nx,ny,flux,nnn,shape", [(100, 420, 0.2, False, (1, 1, 1)), (64, 700, 0.0, False, (1, 1, 1)),
+                                                  (130, 330, 0.1, True, (2, 1, 1))], ids=["100x420", "64x700_real", "130x330_nnn"])
+def test_lattice_fill_open_boundary_grid(ctx, nx, ny, flux, nnn, shape):
+    """A finite-difference Hamiltonian on an nx x ny grid with open boundaries: the rows at the grid's x-edges lack a
+    neighbour, so no run of row blocks has one distance list on every row.  Operator creation completes those rows with
+    explicit zeros (knob lattice_fill, qp_operator_fill_info): the operator becomes the walk's lattice with strip step
+    g = nx (no multiple of 64 here), the step agrees with the oracle, and with the unfilled operator to rounding."""
+    H = synth.grid_hamiltonian_2d(nx, ny, flux=flux, next_nearest=nnn)
+    N = nx * ny
+    psi0 = synth.random_state(N)
+    saved = {k: ctx.tuning_get(k) for k in ("walk_min_blocks", "lattice_fill")}
+    outs = {}
+    try:
+        ctx.tuning_set("walk_min_blocks", 64)
+        for fill in (1, 0):
+            ctx.tuning_set("lattice_fill", fill)
+            Op = L.Operator(ctx, [L.Matrix.from_scipy(ctx, H)])
+            wi = Op.walk_info()
+            if fill:
+                # entries that the rows between the first and the last grid row lack: 2 per grid row (6 with second
+                # neighbours along x), plus their transposes in the first and the last grid row
+                per_row = 6 if nnn else 2
+                assert Op.fill_info() == per_row * (ny - 2) + per_row
+                assert wi["valid"] == 1 and (wi["near"], wi["far"], wi["diag"]) == shape and wi["rows_per_step"] == nx
+                assert Op.format == L.FMT_HRB
+                rp, col, val = Op.get_csr()
+                assert rp[-1] == H.nnz + Op.fill_info()
+                assert abs(synth.to_scipy(rp, col, val, N) - H).max() == 0.0
+            else:
+                assert Op.fill_info() == 0 and wi["valid"] == 0
+            wrk = L.ChebyWrk(ctx, N, 12.0, -1.0, 0.7)
+            psi = L.State(ctx, data=psi0)
+            for dt in (0.7, 0.7, -0.7):
+                L.cheby(psi, Op, dt, wrk)
+            outs[fill] = psi.numpy()
+            Op.close()
+    finally:
+        for k, v in saved.items():
+            ctx.tuning_set(k, v)
+    owrk = qo.ChebyWrk(psi0, 12.0, -1.0, 0.7)
+    ref = psi0.copy()
+    for dt in (0.7, 0.7, -0.7):
+        qo.cheby(ref, H, dt, owrk)
+    assert np.linalg.norm(outs[1] - ref) < TOL
+    assert np.linalg.norm(outs[1] - outs[0]) < 1e-12
+    # an operator that is a lattice except for a few foreign entries is left alone
+    H2 = sp.lil_matrix(H)
+    H2[N // 2 + 5, N // 2 + 37] = 0.5
+    H2[N // 2 + 37, N // 2 + 5] = 0.5
+    H2 = sp.csr_matrix(H2)
+    H2.sort_indices()
+    try:
+        ctx.tuning_set("walk_min_blocks", 64)
+        Op = L.Operator(ctx, [L.Matrix.from_scipy(ctx, H2)])
+        assert Op.fill_info() == 0
+        Op.close()
+    finally:
+        ctx.tuning_set("walk_min_blocks", saved["walk_min_blocks"])
+
+
 def test_strip_walk_inside_a_replayed_graph(ctx):
     """Knob `cheby_graph` with an operator that takes the strip walk: the walk's launch (dynamic LDS above 64 KB, opted in
     per kernel instance and device) is captured and replayed like any other; same bits as the eager step, and the graph is

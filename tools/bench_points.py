@@ -42,9 +42,14 @@ def cheby_layout_bytes(op, rows, ncols, nnz, coeffs, real_copy=False):
     else:
         per_block = 32.0 if fmt == L.FMT_HRB else 16.0     # bptr + cmeta (+ lptr + lcmeta)
         index = lay["index_bytes"] + per_block * lay["blocks"]
-        if walk["valid"]:      # the strip walk computes positions by formula: index bytes only for its edge blocks
-            index *= walk["edge_blocks"] / max(lay["blocks"], 1)
-        matrix = vbytes * lay["stored"] + index
+        stored = lay["stored"]
+        if walk["valid"]:      # the strip walk computes positions by formula: index bytes only for its edge blocks ...
+            share = walk["edge_blocks"] / max(lay["blocks"], 1)
+            index *= share
+            # ... and reads the slots that carry entries, not the pad slots of the quad-padded sections
+            slots = walk["diag"] + walk["near"] + walk["far"]
+            stored = 64.0 * slots * (walk["end_block"] - walk["first_block"]) + lay["stored"] * share
+        matrix = vbytes * stored + index
     sched = L.acc_schedule(coeffs)
     vec = 0.0
     updated = False
@@ -84,11 +89,19 @@ def pattern_csr(pattern, N, row_begin=0, row_end=None):
     raise ValueError(pattern)
 
 
-def measure_cheby(ctx, pattern="banded", log2n=20, fmt="auto", steps=10, warmup=2, real=False, dt=1.0):
+def measure_cheby(ctx, pattern="banded", log2n=20, fmt="auto", steps=10, warmup=2, real=False, dt=1.0, grid=None):
     """Cheby prop_step! on one GPU for a pattern / size / device format; per-term time from HIP events on
-    the kernels' stream; layout-byte and CSR-equivalent rates."""
-    N = 1 << log2n
-    rp, col, vals = pattern_csr(pattern, N)
+    the kernels' stream; layout-byte and CSR-equivalent rates.  grid = (nx, ny): the finite-difference Hamiltonian of an
+    open-boundary grid (synth.grid_hamiltonian_2d) instead of a pattern."""
+    if grid:
+        Hg = synth.grid_hamiltonian_2d(grid[0], grid[1], flux=0.1)
+        N = grid[0] * grid[1]
+        pattern = f"five-point grid {grid[0]} x {grid[1]}, open boundaries"
+        rp, col, vals = Hg.indptr.astype(np.int64), Hg.indices.astype(np.int32), Hg.data.astype(np.complex128)
+        del Hg
+    else:
+        N = 1 << log2n
+        rp, col, vals = pattern_csr(pattern, N)
     if real:
         vals = vals.real.astype(np.complex128)
     nnz = int(rp[-1])
@@ -119,6 +132,9 @@ def measure_cheby(ctx, pattern="banded", log2n=20, fmt="auto", steps=10, warmup=
            "encodings": {"row_blocks": lay["blocks"], "stencil_upper_blocks": lay["stencil_upper_blocks"],
                          "stencil_lower_blocks": lay["stencil_lower_blocks"], "index_bytes": lay["index_bytes"]},
            "norm_drift": abs(psi.norm() - 1.0)}
+    if grid:
+        out["explicit_zeros_completing_the_lattice"] = op.fill_info()
+        out["strip_walk"] = lay.get("strip_walk")
     for h in (psi, wrk, op, M):
         h.close()
     return out

@@ -28,12 +28,19 @@ def main():
     ap.add_argument("--lower-last", type=int, default=0)
     ap.add_argument("--ab", default="", help="A/B over one knob: key=v1,v2,... (every format / variant case is run with each value)")
     ap.add_argument("--offsets", default="", help="Hermitian lattice with these distances instead of --pattern (e.g. 1,1000 or 1,2,3,4,100,200,300,400)")
+    ap.add_argument("--grid", default="", help="nx,ny: finite-difference Hamiltonian on an open-boundary grid (synth.grid_hamiltonian_2d)")
+    ap.add_argument("--no-fill", action="store_true", help="knob lattice_fill = 0 while the operator is created")
     ap.add_argument("--real", action="store_true", help="real symmetric H (values streamed as fp64 instead of complex)")
     args = ap.parse_args()
     N = args.n if args.n else 1 << args.log2n
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import bench_points as bp
-    if args.offsets:
+    if args.grid:
+        nx, ny = (int(t) for t in args.grid.split(","))
+        Hg = synth.grid_hamiltonian_2d(nx, ny, flux=0.0 if args.real else 0.1)
+        N = nx * ny
+        rp, col, vals = Hg.indptr.astype(np.int64), Hg.indices.astype(np.int32), Hg.data.astype(np.complex128)
+    elif args.offsets:
         rp, col, vals = synth.hermitian_offsets_csr(N, offsets=tuple(int(t) for t in args.offsets.split(",")))
     else:
         rp, col, vals = bp.pattern_csr(args.pattern, N)      # banded | scattered | random | random-window
@@ -41,6 +48,8 @@ def main():
         vals = vals.real.astype(np.complex128)
     ctx = L.Context(0)
     L.tuning_set("hrb_lower_last", args.lower_last)
+    if args.no_fill:
+        L.tuning_set("lattice_fill", 0)
     M = L.Matrix(ctx, N, N, rp, col, vals)
     nnz = int(rp[-1])
     del rp, col, vals

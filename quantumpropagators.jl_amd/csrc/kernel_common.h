@@ -46,6 +46,14 @@ __device__ __forceinline__ double wave_sum(double v) {
   return __hiloint2double(hi, lo);
 }
 
+// the same sum through the LDS crossbar (__shfl_down = ds_bpermute; total in lane 0): for kernels that are short of
+// vector-ALU issue slots rather than waiting on the chain
+__device__ __forceinline__ double wave_sum_lds(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
 // sum over the 256-thread workgroup, result broadcast to every thread; fixed order
 __device__ __forceinline__ double2 block_sum(double2 v, double2* lds4) {
   v.x = wave_sum(v.x);

@@ -678,9 +678,12 @@ int launch_gather_csr_vals(hipStream_t s, double2* out, const double2* vals, con
 // the matrix in registers: a group of `lanes` lanes owns rows g, g + G, ... (`rows_per_group`
 // of them), each lane `ent` entries of each row; rows_per_group * ent <= kSmallEpt.
 // ---------------------------------------------------------------------------
+// (the single-workgroup kernels keep their cross-lane sums on the LDS crossbar: their eight wavefronts are VALU-bound in
+// step with one another, and the extra vector instructions of the DPP forms cost more than the crossbar's latency --
+// config C1 8.65 ms per 200 steps against 9.1 with DPP wavefront sums and 10.0 with DPP row butterflies too)
 __device__ __forceinline__ double2 small_block_sum(double2 v, double2* red) {
-  v.x = wave_sum(v.x);
-  v.y = wave_sum(v.y);
+  v.x = wave_sum_lds(v.x);
+  v.y = wave_sum_lds(v.y);
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
   if (l == 0) red[w] = v;
   __syncthreads();

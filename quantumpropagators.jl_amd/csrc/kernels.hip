@@ -1923,6 +1923,26 @@ __global__ __launch_bounds__(BS) void mgs_update_kernel(double2* __restrict__ w,
   extern __shared__ double2 sm[];  // [0, j+1): coefficients; [j+1, j+1+BS/64): reduction scratch; SOLVE: + red | hs | Gt | dummy
   double2* h = sm;
   double2* lds = sm + (j + 1);
+  // the first round of the streams (this lane's elements of w and of the first four basis vectors) is requested BEFORE
+  // the prologue below: the reduction + solve is a chain of L2 round trips and barriers (2-3 us) that needs no memory
+  // pipe, and the coefficients are not needed before the first FMA
+  const int64_t stride = (int64_t)kRedBlocks * BS;
+  const int64_t ef0 = (int64_t)blockIdx.x * BS + threadIdx.x, ef1 = ef0 + stride;
+  const bool pre_on = ef0 < n, pre_two = EPL == 2 && ef1 < n, pre_q = j >= 3;
+  double2 pr0 = make_double2(0.0, 0.0), pr1 = make_double2(0.0, 0.0), pa[4], pb[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) pa[t] = pb[t] = make_double2(0.0, 0.0);
+  if (pre_on) {
+    pr0 = w[ef0];
+    if (pre_two) pr1 = w[ef1];
+    if (pre_q) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        pa[t] = Q[(size_t)t * ldq + ef0];
+        if (pre_two) pb[t] = Q[(size_t)t * ldq + ef1];
+      }
+    }
+  }
   if (SOLVE) {
     static_assert(!SOLVE || (BS == kThreads && kRedBlocks == 256), "four partials per lane");
     const int nv = 2 * (j + 1);
@@ -1966,19 +1986,27 @@ __global__ __launch_bounds__(BS) void mgs_update_kernel(double2* __restrict__ w,
     __syncthreads();
   }
   double nrm = 0.0;
-  const int64_t stride = (int64_t)kRedBlocks * BS;
-  for (int64_t e0 = (int64_t)blockIdx.x * BS + threadIdx.x; e0 < n; e0 += EPL * stride) {
+  for (int64_t e0 = ef0; e0 < n; e0 += EPL * stride) {
     const int64_t e1 = e0 + stride;
     const bool two = EPL == 2 && e1 < n;
-    double2 r0 = w[e0];
-    double2 r1 = two ? w[e1] : make_double2(0.0, 0.0);
+    const bool first = e0 == ef0;   // (the same for every lane of the workgroup)
+    double2 r0 = first ? pr0 : w[e0];
+    double2 r1 = first ? pr1 : (two ? w[e1] : make_double2(0.0, 0.0));
     int i = 0;
     for (; i + 3 <= j; i += 4) {
       double2 a[4], b[4];
+      if (first && i == 0) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        a[t] = Q[(size_t)(i + t) * ldq + e0];
-        b[t] = two ? Q[(size_t)(i + t) * ldq + e1] : make_double2(0.0, 0.0);
+        for (int t = 0; t < 4; ++t) {
+          a[t] = pa[t];
+          b[t] = pb[t];
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          a[t] = Q[(size_t)(i + t) * ldq + e0];
+          b[t] = two ? Q[(size_t)(i + t) * ldq + e1] : make_double2(0.0, 0.0);
+        }
       }
 #pragma unroll
       for (int t = 0; t < 4; ++t) {

@@ -973,7 +973,8 @@ static int choose_format(qp_operator* op, int requested, bool hermitian) {
 // zeros (with their transposes, so that the pattern stays structurally symmetric).  Index work only; 0 * x terms change no
 // row sum beyond the order in which the two accumulators of a row take their entries.
 static void lattice_fill(const qp::Tuning& tun, int64_t n, int64_t ncols, std::vector<int64_t>& ur, std::vector<int32_t>& uc) {
-  if (!tun.lattice_fill || !tun.hrb_walk || n != ncols || n / kRB < std::max(tun.walk_min_blocks, 16)) return;
+  if (!tun.lattice_fill || ncols < n || n / kRB < std::max(tun.walk_min_blocks, 16)) return;
+  // (ncols > n: the local rows of a row-partitioned operator; its halo columns appear only in the first / last K g rows)
   // the reference row: the fullest one near the middle (the middle row itself may sit on the grid's edge)
   int64_t rm = n / 2;
   for (int64_t r = std::max<int64_t>(0, n / 2 - 128); r < std::min(n, n / 2 + 128); ++r)
@@ -1002,6 +1003,7 @@ static void lattice_fill(const qp::Tuning& tun, int64_t n, int64_t ncols, std::v
   for (int64_t r = lo; r < hi; ++r) {
     int d = 0;
     for (int64_t p = ur[r]; p < ur[r + 1]; ++p) {
+      if (uc[p] >= n) return;
       const int64_t delta = (int64_t)uc[p] - r;
       while (d < z && D[(size_t)d] < delta) ++d;
       if (d == z || D[(size_t)d] != delta) return;   // an entry outside the lattice's distances: not this kind of operator

@@ -142,7 +142,8 @@ def test_sharded_overlap_machinery_world1(pg, overlap, split_mode):
 
 @pytest.mark.parametrize("split_mode,offsets", [(2, (1, 2, 3, 4, 256, 512, 768, 1024)), (1, (1, 2, 3, 4, 256, 512, 768, 1024)),
                                                 (0, (1, 2, 3, 4, 256, 512, 768, 1024)), (2, (1, 2, 3, 4, 250, 500, 750, 1000)),
-                                                (2, (1, 1000))], ids=["mode2", "mode1", "mode0", "g250", "five_point_g1000"])
+                                                (2, (1, 1000)), (2, "grid")],
+                         ids=["mode2", "mode1", "mode0", "g250", "five_point_g1000", "open_grid_128x1024"])
 def test_split_interior_as_strip_walk_world1(pg, split_mode, offsets):
     """A lattice operator's interior launch takes the strip walk (kernels_walk.hip) over the interior blocks from which no
     walked block reaches a boundary row; the rest of the interior are its edge blocks, the only ones that wait for the
@@ -155,7 +156,12 @@ def test_split_interior_as_strip_walk_world1(pg, split_mode, offsets):
     import qprop_amd.sharded as sharded
     import qprop_amd.synth as synth
     N = 1 << 17
-    rp, col, vals = synth.hermitian_offsets_csr(N, offsets=offsets)
+    if offsets == "grid":    # open-boundary grid: the local operator's edge rows are completed at creation (lattice_fill)
+        Hg = synth.grid_hamiltonian_2d(128, 1024, flux=0.15)
+        rp, col, vals = Hg.indptr.astype(np.int64), Hg.indices.astype(np.int32), Hg.data.astype(np.complex128)
+        offsets = (1, 128, 0)
+    else:
+        rp, col, vals = synth.hermitian_offsets_csr(N, offsets=offsets)
     if len(offsets) == 2:    # hopping + on-site term
         Hd = synth.to_scipy(rp, col, vals, N) + sp.diags(np.linspace(-1.0, 1.0, N)).astype(np.complex128)
         Hd = sp.csr_matrix(Hd)
@@ -175,7 +181,8 @@ def test_split_interior_as_strip_walk_world1(pg, split_mode, offsets):
             if overlap:
                 wi = sh.split.walk_info()
                 nb = N // 64
-                assert wi["valid"] == 1 and 64 + 16 < wi["first_block"] < wi["end_block"] < nb - 64 - 16
+                reach = -(-max(offsets) // 64) + 1      # blocks between the boundary rows and the first walked block
+                assert wi["valid"] == 1 and 64 + reach <= wi["first_block"] < wi["end_block"] <= nb - 64 - reach
                 assert wi["edge_blocks"] == sh.split.n_interior - (wi["end_block"] - wi["first_block"])
             sh.set_state(psi0)
             for _ in range(3):

@@ -168,7 +168,13 @@ def measure_newton_c3(ctx, n=512, m=20, dt=0.5, steps=10, warmup=60):
     z = nnz / N
     # SURVEY 8d model per Arnoldi sweep (this implementation's low-sync MGS reads the basis twice per column)
     sweep_bytes = m * (20 * z + 36) * N + 64 * N * m * (m + 1) / 2 + 64 * N * m + 32 * N * m + 16 * (m + 2) * N + 16 * (m + 3) * N
-    out = {"workload": "BASELINE configs[2]: Newton prop_step!, N=2^18 non-Hermitian sparse Liouvillian, m_max=20",
+    # bytes this implementation moves per sweep: per column the matrix, the gathered / written vectors of the fused mat-vec
+    # (x, w, q_j, the j older basis vectors) and of the projection (w twice, j + 1 basis vectors); then the two combines
+    impl_bytes = m * 20 * z * N + 16 * N * m * (m + 5) + 16 * N * (m + 3)
+    regime = ("working set (basis + matrix) inside the Infinity Cache: a latency / L1-queue figure, not an HBM fraction" if N <= (1 << 19)
+              else "basis beyond the Infinity Cache: HBM-bandwidth bound")
+    out = {"workload": f"BASELINE configs[2]: Newton prop_step!, N={N} (n={n}) non-Hermitian sparse Liouvillian, m_max={m}",
+           "regime": regime,
            "N": N, "nnz_per_row": z, "m_max": m, "dt": dt, "steps": steps, "device_format": FMT_NAME[op.format],
            "ms_per_step": 1e3 * el / steps, "steps_per_s": steps / el,
            "arnoldi_sweeps_per_step": sweeps / steps, "matvecs_per_step": matvecs / steps,
@@ -176,6 +182,8 @@ def measure_newton_c3(ctx, n=512, m=20, dt=0.5, steps=10, warmup=60):
            "launches_per_column": st["n_kernel_launches"] / max(matvecs, 1),
            "ms_per_sweep": 1e3 * el / sweeps, "host_ms_exposed_per_step": exposed / steps,
            "algorithmic_gbs": sweep_bytes * sweeps / el / 1e9, "frac": sweep_bytes * sweeps / el / 1e9 / HBM_PEAK_GBS,
+           "implementation_bytes_per_sweep": impl_bytes, "implementation_gbs": impl_bytes * sweeps / el / 1e9,
+           "implementation_frac": impl_bytes * sweeps / el / 1e9 / HBM_PEAK_GBS,
            "norm": psi.norm()}
     for h in (psi, wrk, op, M):
         h.close()

@@ -130,6 +130,14 @@ int qp_csc_to_csr_host(int64_t nrows, int64_t ncols, const int64_t* colptr,
 int qp_partition_rows_host(const int64_t* rowptr, int64_t nrows, int nparts, int balance,
                            int64_t* bounds_out /* nparts+1 */);
 
+/* The index work of the lattice completion (see qp_operator_fill_info) on a host CSR pattern, without a device:
+ * rowptr / col of an nrows x ncols pattern with sorted, unique columns; `min_blocks` = the smallest operator (in 64-row
+ * blocks) that is completed (the walk_min_blocks knob of a context).  Writes the completed pattern -- the input itself
+ * when nothing is to be completed -- into rowptr_out (nrows + 1) / col_out (capacity `cap` entries) and its entry count
+ * into *nnz_out; QP_E_BAD_ARG if `cap` is too small (*nnz_out then holds what is needed). */
+int qp_lattice_fill_host(int64_t nrows, int64_t ncols, const int64_t* rowptr, const int32_t* col, int min_blocks,
+                         int64_t* rowptr_out, int32_t* col_out, int64_t cap, int64_t* nnz_out);
+
 /* ---- matrices --------------------------------------------------------------------- */
 /* ptr/idx: rowptr/col (CSR) or colptr/rowval (CSC), int64, `index_base` 0 or 1.
  * nrows may be a row block of a larger operator (local rows, global ncols).

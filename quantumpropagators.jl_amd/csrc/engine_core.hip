@@ -1237,6 +1237,25 @@ int qp_operator_build_info(const qp_operator* op, double out[4]) {
   return QP_OK;
 }
 
+int qp_lattice_fill_host(int64_t nrows, int64_t ncols, const int64_t* rowptr, const int32_t* col, int min_blocks,
+                         int64_t* rowptr_out, int32_t* col_out, int64_t cap, int64_t* nnz_out) {
+  QP_TRY
+  if (!rowptr || !col || !rowptr_out || !col_out || !nnz_out || nrows < 0 || ncols < 0 || rowptr[0] != 0)
+    return qp::fail(QP_E_BAD_ARG, "qp_lattice_fill_host: bad arguments");
+  std::vector<int64_t> ur(rowptr, rowptr + nrows + 1);
+  std::vector<int32_t> uc(col, col + rowptr[nrows]);
+  qp::Tuning tun;
+  tun.lattice_fill = 1;
+  tun.walk_min_blocks = min_blocks;
+  lattice_fill(tun, nrows, ncols, ur, uc);
+  *nnz_out = ur[nrows];
+  if (ur[nrows] > cap) return qp::fail(QP_E_BAD_ARG, "qp_lattice_fill_host: col_out holds %lld entries, %lld needed", (long long)cap, (long long)ur[nrows]);
+  std::memcpy(rowptr_out, ur.data(), ur.size() * sizeof(int64_t));
+  std::memcpy(col_out, uc.data(), uc.size() * sizeof(int32_t));
+  return QP_OK;
+  QP_CATCH
+}
+
 int qp_operator_fill_info(const qp_operator* op, int64_t* n_filled) {
   if (!op || !n_filled) return qp::fail(QP_E_BAD_ARG, "qp_operator_fill_info: NULL argument");
   *n_filled = op->n_lattice_fill;

@@ -127,6 +127,7 @@ SIGNATURES = {
     "qp_operator_build_info": (C.c_int, [_P, _dp]),
     "qp_operator_walk_info": (C.c_int, [_P, _i64p]),
     "qp_operator_fill_info": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "qp_lattice_fill_host": (C.c_int, [C.c_int64, C.c_int64, _i64p, _i32p, C.c_int, _i64p, _i32p, C.c_int64, C.POINTER(C.c_int64)]),
     "qp_operator_spmm_walk": (C.c_int, [_P, C.c_int, _i64p]),
     "qp_state_create": (C.c_int, [_P, C.c_int64, C.POINTER(_P)]),
     "qp_state_wrap": (C.c_int, [_P, _P, C.c_int64, C.POINTER(_P)]),
@@ -304,6 +305,19 @@ def hessenberg_eigvals(Hess, m, accumulate=False):
     out = np.empty(n_out, dtype=np.complex128)
     check(load().qp_hessenberg_eigvals(_ptr(Hess, _cp), ldh, m, int(accumulate), _ptr(out, _cp)))
     return out
+
+
+def lattice_fill_host(nrows, ncols, rowptr, col, min_blocks=3072):
+    """The lattice completion of operator creation on a host CSR pattern (no device needed): returns (rowptr, col)."""
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+    col = np.ascontiguousarray(col, dtype=np.int32)
+    cap = int(rowptr[-1]) + 64 * 17 + int(0.05 * rowptr[-1]) + 1024
+    rp_out = np.empty(nrows + 1, dtype=np.int64)
+    col_out = np.empty(cap, dtype=np.int32)
+    nnz = C.c_int64(0)
+    check(load().qp_lattice_fill_host(nrows, ncols, _ptr(rowptr, _i64p), _ptr(col, _i32p), int(min_blocks),
+                                      _ptr(rp_out, _i64p), _ptr(col_out, _i32p), cap, C.byref(nnz)))
+    return rp_out, col_out[:nnz.value].copy()
 
 
 def extend_leja(leja, n, newpoints, n_use):

@@ -242,6 +242,70 @@ def test_partition_rows_bit_exact():
             assert np.array_equal(L.partition_rows(rowptr, parts, bal), qo.partition_rows(rowptr, parts, bal))
 
 
+@pytest.mark.parametrize("nx,ny,nnn", [(100, 60, False), (64, 90, False), (130, 50, True), (70, 400, False)])
+def test_lattice_fill_host_completes_open_boundary_grids(nx, ny, nnn):
+    """Index work of the lattice completion (engine_core.hip: lattice_fill, the host half of qp_operator_create), bit-exact
+    against a NumPy restatement: every row between the first and the last grid row of an open-boundary grid Hamiltonian
+    gets the full distance list of the stencil (explicit zeros where the grid's x-edge cut a neighbour off), the entries
+    that land in the first / last grid row get their transposes, nothing else changes."""
+    H = synth.grid_hamiltonian_2d(nx, ny, flux=0.3, next_nearest=nnn)
+    N = nx * ny
+    rp, col = L.lattice_fill_host(N, N, H.indptr, H.indices, min_blocks=16)
+    D = [-nx, -2, -1, 0, 1, 2, nx] if nnn else [-nx, -1, 0, 1, nx]
+    want = set(zip(*H.nonzero()))
+    want |= {(r, r) for r in range(N)}
+    for r in range(nx, N - nx):
+        for d in D:
+            want.add((r, r + d))
+            want.add((r + d, r))
+    got = {(r, int(c)) for r in range(N) for c in col[rp[r]:rp[r + 1]]}
+    assert got == want
+    for r in range(N):                              # sorted, unique
+        assert np.all(np.diff(col[rp[r]:rp[r + 1]]) > 0)
+    assert rp[-1] == len(col) == len(want)
+
+
+def test_lattice_fill_host_leaves_other_patterns_alone():
+    """No completion for: a lattice with an entry outside its distances, more than 3 % missing entries, operators below the
+    size knob, a complete lattice, a non-symmetric distance list, a row-partitioned pattern whose interior rows reach the
+    halo columns; the local rows of a partitioned grid operator (halo columns only in the first / last grid row) are completed."""
+    import scipy.sparse as sp
+    nx, ny = 100, 60
+    H = synth.grid_hamiltonian_2d(nx, ny)
+    N = nx * ny
+
+    def same(M, n=N, ncols=N, **kw):
+        rp, col = L.lattice_fill_host(n, ncols, M.indptr, M.indices, **{"min_blocks": 16, **kw})
+        return np.array_equal(rp, M.indptr) and np.array_equal(col, M.indices)
+
+    assert not same(H)
+    assert same(H, min_blocks=N // 64 + 1)                                      # below the size knob
+    H2 = sp.lil_matrix(H)
+    H2[N // 2 + 5, N // 2 + 37] = H2[N // 2 + 37, N // 2 + 5] = 0.5            # a foreign entry
+    assert same(sp.csr_matrix(H2))
+    Hh = sp.lil_matrix(H)
+    for y in range(2, ny - 2):                                                  # every third x-hop cut: > 3 % missing
+        for x in range(0, nx - 1, 3):
+            Hh[x + nx * y, x + 1 + nx * y] = 0
+            Hh[x + 1 + nx * y, x + nx * y] = 0
+    Hh = sp.csr_matrix(Hh)
+    Hh.eliminate_zeros()
+    assert same(Hh)
+    rpb, colb, valb = synth.hermitian_offsets_csr(1 << 13, offsets=(1, 2, 128, 256))   # already complete (periodic wrap rows aside)
+    assert same(synth.to_scipy(rpb, colb, valb, 1 << 13), n=1 << 13, ncols=1 << 13)
+    U = sp.csr_matrix(sp.triu(H))                                              # distances not symmetric
+    assert same(U)
+    # local rows [nx * 10, nx * 50) of the grid with the halo columns appended behind the local ones
+    lo, hi = nx * 10, nx * 50
+    Hl = H[lo:hi].tocoo()
+    ccol = np.where((Hl.col >= lo) & (Hl.col < hi), Hl.col - lo, np.where(Hl.col < lo, (hi - lo) + (Hl.col - (lo - nx)), (hi - lo) + nx + (Hl.col - hi)))
+    Hloc = sp.csr_matrix((Hl.data, (Hl.row, ccol)), shape=(hi - lo, hi - lo + 2 * nx))
+    Hloc.sort_indices()
+    rp, col = L.lattice_fill_host(hi - lo, hi - lo + 2 * nx, Hloc.indptr, Hloc.indices, min_blocks=16)
+    assert rp[-1] == Hloc.nnz + 2 * (40 - 2) + 2
+    assert np.all(np.diff(rp)[nx:hi - lo - nx] == 5)
+
+
 def test_accumulator_schedule_host():
     """qp_acc_schedule_host (include/qprop.h, qp_acc_defer): the Psi accumulator is touched
     every third term, the last term always, the first update no later than term 2 (Psi = v_0 is

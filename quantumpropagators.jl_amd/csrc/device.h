@@ -189,6 +189,7 @@ struct Tuning {
   int rbcsr_variant = 15;     // bit 0 nt matrix loads, bit 1 early row-local loads, bit 2 deeper unroll, bit 3 (Hermitian-packed kernel) all loads of an all-stencil block up front (A/B in profiles/)
   int hrb_lower_last = 0;     // HRB kernel: process the lower (conj-transposed) section after the upper one
   int arnoldi_mode = 1;       // 0 = sequential fused MGS passes, 1 = low-synchronisation MGS
+  int sparse_controls = 1;    // 1 = evaluate! rewrites only the positions of sparse trailing control terms (see qp_operator::sparse_from)
   int lattice_fill = 1;       // 1 = rows of a lattice operator that lack a few of its distances (open boundaries of a grid) are completed with explicit zeros
   int arnoldi_fuse_dots = 1;  // 1 = the multidot of a column runs in its mat-vec's epilogue where an instance exists (row-block format, j <= 19): 2 launches per column
   int arnoldi_solve = 1;      // 1 = the MGS reduction + solve run in the projection kernel's prologue (3 launches per column), 0 = own launch
@@ -237,6 +238,9 @@ struct CoefBlock {
 int launch_real_part(hipStream_t s, double* out, const double2* v, int64_t n, Stats* st);
 int launch_combine_planes(hipStream_t s, double2* vals, const double2* const* planes_dev, const double2* coefs,
                           int nplanes, int64_t n, double* vals_r, Stats* st);
+// vals[support[i]] = base[support[i]] + sum_l coefs[l] * support_vals[l * n_support + i]  (and its real part into vals_r)
+int launch_sparse_planes_update(hipStream_t s, double2* vals, const double2* base, const int32_t* support, int64_t n_support,
+                                const double2* support_vals, int nplanes, const double2* coefs, double* vals_r, Stats* st);
 
 // ---- strip walk of the batched term (kernels_spmm_walk.hip) over a lattice operator in CSR order ---------------------
 // every row has z = 2 (nn + K) + diag entries; the rows a g + c, a in [a_lo, a_hi), have their columns at

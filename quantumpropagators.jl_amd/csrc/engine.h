@@ -88,6 +88,17 @@ struct qp_operator {
   std::vector<double2*> planes;   // device value planes, one per term, layout of A.vals
   double2** planes_dev = nullptr;
   double2* combined = nullptr;    // device, allocated on first non-trivial coefficient set
+  // Sparse control planes (knob sparse_controls): the trailing control terms whose entries cover at most a quarter of the
+  // stored values -- a dipole operator on a grid is a diagonal.  evaluate! then rewrites only those positions:
+  //   combined[p] = base[p] + sum_{l >= sparse_from} c_l plane_l[p],  p in the union of their supports,
+  // base = the sum over the planes before them with the coefficients it was last built with (rebuilt when those change).
+  int sparse_from = -1;
+  int64_t n_support = 0;
+  int32_t* support = nullptr;        // device: positions in the value array, ascending
+  double2* support_vals = nullptr;   // device: [nops - sparse_from][n_support]
+  double2* base = nullptr;
+  std::vector<double2> base_eff;
+  bool base_valid = false, base_real = false;
   bool planes_real = false;       // every value of every term has a zero imaginary part
   double* real_vals = nullptr;    // device copy of the real parts of the current values (see DevMatrix::vals_r)
   const double2* real_of = nullptr;  // the complex array real_vals was extracted from, when still valid

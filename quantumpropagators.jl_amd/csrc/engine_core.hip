@@ -320,6 +320,15 @@ static int operator_free_device(qp_operator* op) {
   op->planes.clear();
   if (op->planes_dev) (void)hipFree(op->planes_dev);
   if (op->combined) (void)hipFree(op->combined);
+  if (op->support) (void)hipFree(op->support);
+  if (op->support_vals) (void)hipFree(op->support_vals);
+  if (op->base) (void)hipFree(op->base);
+  op->support = nullptr;
+  op->support_vals = nullptr;
+  op->base = nullptr;
+  op->sparse_from = -1;
+  op->n_support = 0;
+  op->base_valid = false;
   if (op->real_vals) (void)hipFree(op->real_vals);
   op->real_vals = nullptr;
   op->real_of = nullptr;
@@ -816,6 +825,11 @@ static int operator_build_device_impl(qp_operator* op, int format, const std::ve
         break;
       }
   std::vector<cplx> hplane((size_t)std::max<int64_t>(A.stored, 1));
+  // positions a control term touches (kept while it may still belong to the sparse suffix, see qp_operator::sparse_from)
+  const int drift_planes = nops - op->ncoeffs;
+  std::vector<std::vector<std::pair<int32_t, cplx>>> touched((size_t)nops);
+  std::vector<char> is_sparse((size_t)nops, 0);
+  const bool sparse_candidates = nops >= 2 && op->ncoeffs >= 1 && A.stored < (int64_t)INT32_MAX;
   for (int l = 0; l < nops; ++l) {
     std::fill(hplane.begin(), hplane.end(), cplx(0.0));
     const auto& pv = planes_csr[l];
@@ -826,10 +840,48 @@ static int operator_build_device_impl(qp_operator* op, int format, const std::ve
         hplane[pos] = pv[ur[r] + k];
       }
     }
+    if (sparse_candidates && l >= drift_planes && l >= 1) {
+      auto& t = touched[(size_t)l];
+      const size_t limit = (size_t)(A.stored / 4);
+      bool few = true;
+      for (int64_t p = 0; p < A.stored && few; ++p)
+        if (hplane[(size_t)p] != cplx(0.0)) {
+          t.emplace_back((int32_t)p, hplane[(size_t)p]);
+          few = t.size() <= limit;
+        }
+      if (few) is_sparse[(size_t)l] = 1;
+      else t.clear(), t.shrink_to_fit();
+    }
     double2* dp = nullptr;
     QP_CHECK(dev_alloc(&dp, (size_t)A.stored));
     op->planes.push_back(dp);
     QP_HIP(hipMemcpy(dp, hplane.data(), (size_t)A.stored * sizeof(double2), hipMemcpyHostToDevice));
+  }
+  {
+    int sfrom = nops;
+    while (sfrom - 1 >= std::max(drift_planes, 1) && is_sparse[(size_t)(sfrom - 1)]) --sfrom;
+    const int nsp = nops - sfrom;
+    if (nsp >= 1 && nsp <= qp::kCoefBlock) {
+      std::vector<int32_t> sup;
+      for (int l = sfrom; l < nops; ++l)
+        for (const auto& e : touched[(size_t)l]) sup.push_back(e.first);
+      std::sort(sup.begin(), sup.end());
+      sup.erase(std::unique(sup.begin(), sup.end()), sup.end());
+      if (!sup.empty() && (int64_t)sup.size() <= A.stored / 4) {
+        std::vector<cplx> sv((size_t)nsp * sup.size(), cplx(0.0));
+        for (int l = sfrom; l < nops; ++l)
+          for (const auto& e : touched[(size_t)l]) {
+            const size_t i = (size_t)(std::lower_bound(sup.begin(), sup.end(), e.first) - sup.begin());
+            sv[(size_t)(l - sfrom) * sup.size() + i] = e.second;
+          }
+        QP_CHECK(dev_alloc(&op->support, sup.size()));
+        QP_HIP(hipMemcpy(op->support, sup.data(), sup.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        QP_CHECK(dev_alloc(&op->support_vals, sv.size()));
+        QP_HIP(hipMemcpy(op->support_vals, sv.data(), sv.size() * sizeof(double2), hipMemcpyHostToDevice));
+        op->sparse_from = sfrom;
+        op->n_support = (int64_t)sup.size();
+      }
+    }
   }
   QP_CHECK(dev_alloc(&op->planes_dev, (size_t)nops));
   QP_HIP(hipMemcpy(op->planes_dev, op->planes.data(), nops * sizeof(double2*), hipMemcpyHostToDevice));
@@ -1157,7 +1209,27 @@ static int operator_refresh(qp_operator* op) {
   // bytes per value); everything else keeps reading the complex array
   const bool want_real = op->ctx->tun.real_vals && op->planes_real && all_real && op->A.stored > 0;
   if (want_real && !op->real_vals) QP_CHECK(dev_alloc(&op->real_vals, (size_t)op->A.stored));
-  if (op->nops == 1 && all_one) {
+  if (op->sparse_from > 0 && ctx->tun.sparse_controls && !(op->nops == 1 && all_one)) {
+    // only the sparse trailing control terms' positions are rewritten (qp_operator::sparse_from)
+    const int sf = op->sparse_from;
+    bool same = op->base_valid && op->base_real == want_real && (int)op->base_eff.size() == sf;
+    for (int l = 0; same && l < sf; ++l) same = (eff[l].x == op->base_eff[(size_t)l].x && eff[l].y == op->base_eff[(size_t)l].y);
+    if (!same) {
+      if (!op->base) QP_CHECK(dev_alloc(&op->base, (size_t)op->A.stored));
+      if (!op->combined) QP_CHECK(dev_alloc(&op->combined, (size_t)op->A.stored));
+      QP_CHECK(qp::launch_combine_planes(ctx->stream, op->base, op->planes_dev, eff.data(), sf, op->A.stored, nullptr, &ctx->stats));
+      QP_HIP(hipMemcpyAsync(op->combined, op->base, (size_t)op->A.stored * sizeof(double2), hipMemcpyDeviceToDevice, ctx->stream));
+      op->base_eff.assign(eff.begin(), eff.begin() + sf);
+      op->base_valid = true;
+      op->base_real = want_real;
+    }
+    QP_CHECK(qp::launch_sparse_planes_update(ctx->stream, op->combined, op->base, op->support, op->n_support, op->support_vals,
+                                             op->nops - sf, eff.data() + sf, (same && want_real) ? op->real_vals : nullptr,
+                                             &ctx->stats));
+    if (!same && want_real) QP_CHECK(qp::launch_real_part(ctx->stream, op->real_vals, op->combined, op->A.stored, &ctx->stats));
+    op->A.vals = op->combined;
+    op->real_of = nullptr;
+  } else if (op->nops == 1 && all_one) {
     op->A.vals = op->planes[0];
     if (want_real && op->real_of != op->A.vals) {   // a plane never changes: extract once
       QP_CHECK(qp::launch_real_part(ctx->stream, op->real_vals, op->A.vals, op->A.stored, &ctx->stats));

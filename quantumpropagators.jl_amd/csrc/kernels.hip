@@ -1081,7 +1081,7 @@ int* tuning_field(Tuning& t, const char* key) {
   static const Entry table[] = {
       {"rbcsr_variant", &Tuning::rbcsr_variant}, {"hrb_lower_last", &Tuning::hrb_lower_last},
       {"arnoldi_mode", &Tuning::arnoldi_mode},   {"split_mode", &Tuning::split_mode},
-      {"arnoldi_fold", &Tuning::arnoldi_fold},   {"spmm_wg", &Tuning::spmm_wg},   {"hrb_wg", &Tuning::hrb_wg},   {"arnoldi_solve", &Tuning::arnoldi_solve},   {"arnoldi_fuse_dots", &Tuning::arnoldi_fuse_dots},   {"lattice_fill", &Tuning::lattice_fill},
+      {"arnoldi_fold", &Tuning::arnoldi_fold},   {"spmm_wg", &Tuning::spmm_wg},   {"hrb_wg", &Tuning::hrb_wg},   {"arnoldi_solve", &Tuning::arnoldi_solve},   {"arnoldi_fuse_dots", &Tuning::arnoldi_fuse_dots},   {"lattice_fill", &Tuning::lattice_fill},   {"sparse_controls", &Tuning::sparse_controls},
       {"liouville_fused_n", &Tuning::liouville_fused_n}, {"liouville_tile32_n", &Tuning::liouville_tile32_n}, {"liouville_tile32_min_n", &Tuning::liouville_tile32_min_n}, {"real_vals", &Tuning::real_vals},
       {"stencil", &Tuning::stencil},             {"acc_defer", &Tuning::acc_defer},
       {"cheby_graph", &Tuning::cheby_graph},     {"small_nnz", &Tuning::small_nnz},
@@ -1400,6 +1400,34 @@ __global__ __launch_bounds__(kThreads) void combine_planes_kernel(double2* __res
     vals[p] = acc;
     if (vals_r) vals_r[p] = acc.x;   // real copy for the mat-vec kernels of an all-real operator
   }
+}
+
+// evaluate! for sparse trailing control terms: only the positions they touch are rewritten, in the summation order of
+// combine_planes_kernel (the sum over the earlier planes is `base`)
+__global__ __launch_bounds__(kThreads) void sparse_planes_update_kernel(double2* __restrict__ vals, const double2* __restrict__ base,
+                                                                        const int32_t* __restrict__ support, int64_t n_support,
+                                                                        const double2* __restrict__ support_vals, CoefBlock coefs,
+                                                                        int nplanes, double* __restrict__ vals_r) {
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n_support; i += (int64_t)gridDim.x * kThreads) {
+    const int32_t p = support[i];
+    double2 acc = base[p];
+    for (int l = 0; l < nplanes; ++l) cfma(acc, coefs.c[l], support_vals[(size_t)l * n_support + i]);
+    vals[p] = acc;
+    if (vals_r) vals_r[p] = acc.x;
+  }
+}
+
+int launch_sparse_planes_update(hipStream_t s, double2* vals, const double2* base, const int32_t* support, int64_t n_support,
+                                const double2* support_vals, int nplanes, const double2* coefs, double* vals_r, Stats* st) {
+  if (n_support == 0) return QP_OK;
+  if (nplanes > kCoefBlock) return fail(QP_E_BAD_ARG, "more than %d sparse control terms", kCoefBlock);
+  CoefBlock cb;
+  for (int l = 0; l < nplanes; ++l) cb.c[l] = coefs[l];
+  hipLaunchKernelGGL(sparse_planes_update_kernel, dim3(ew_grid(n_support)), dim3(kThreads), 0, s, vals, base, support, n_support,
+                     support_vals, cb, nplanes, vals_r);
+  QP_HIP(hipGetLastError());
+  if (st) st->n_launch++;
+  return QP_OK;
 }
 
 __global__ __launch_bounds__(kThreads) void real_part_kernel(double* __restrict__ out, const double2* __restrict__ v,

@@ -509,7 +509,8 @@ int launch_hrb_walk_cheby(hipStream_t s, const DevMatrix& A, const double2* x, c
   // units (profiles/r03/kbench_walk_development.txt: N = 2^20 31.9 us per term; 1280 as workgroups of eight 33.4, 2048 36.5)
   // ... and beyond it the matrix values are streamed nontemporally: they are read once per term, and what the
   // Infinity Cache then keeps from one term to the next is the vectors
-  const double footprint = (double)A.stored * (A.vals_r ? 8.0 : 16.0) + 64.0 * (double)A.nrows;
+  // (the slots the walk streams: the pad slots of the quad-padded upper sections are never read)
+  const double footprint = (double)(P->z0 + P->nn + P->K) * kRB * (double)A.nblocks * (A.vals_r ? 8.0 : 16.0) + 64.0 * (double)A.nrows;
   const bool resident = footprint <= 230e6;
   // beyond it: every CU but the few the edge workgroups take (8 x (256 - 24) = 1856 for the headline lattice), so that
   // the edge blocks run BESIDE the walk there too; 2048 with the edge blocks inside the walk's wavefronts when that would

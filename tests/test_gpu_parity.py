@@ -1220,6 +1220,61 @@ def test_stencil_blocks_bit_identical(ctx, fmt, N):
 
 
 @pytest.mark.parametrize("fmt", [L.FMT_CSR, L.FMT_RBCSR, L.FMT_HRB])
+@pytest.mark.parametrize("real", [False, True], ids=["complex", "real"])
+def test_sparse_control_terms_update_only_their_positions(ctx, fmt, real):
+    """evaluate! (src/generators.jl:757-766) with sparse trailing control terms -- a diagonal dipole operator next to a
+    banded drift -- rewrites only the positions those terms touch (knob sparse_controls): the stored values after any
+    sequence of coefficient / scale changes are those of the full combination, bit for bit (the real copy included: same
+    cheby! results), for the sparse term last, two sparse terms, a dense control term before them; a dense term AFTER a
+    sparse one switches the path off.  A complex coefficient on the packed format still re-lays the operator out."""
+    N = 6000
+    rng = np.random.default_rng(5)
+    rp, col, val = synth.hermitian_offsets_csr(N, (1, 2, 7, 64), rho=6.0)
+    H0 = synth.to_scipy(rp, col, val, N)
+    rp, col, val = synth.hermitian_offsets_csr(N, (1, 2, 7, 64), rho=6.0, seed=77)
+    Hd = 0.3 * synth.to_scipy(rp, col, val, N)                                   # a dense control term
+    D1 = sp.diags([np.linspace(-1, 1, N)], [0], format="csr", dtype=complex)    # sparse: the diagonal
+    D2 = sp.diags([rng.uniform(-1, 1, N - 2)], [2], format="csr", dtype=complex)
+    D2 = (D2 + D2.getH()).tocsr()                                                # sparse: one off-diagonal pair
+    if real:
+        H0, Hd, D2 = (sp.csr_matrix(M.real.astype(complex)) for M in (H0, Hd, D2))
+    psi0 = synth.random_state(N)
+    moves = [("c", [0.5, -0.25, 0.1]), ("c", [0.5, -0.25, 0.7]), ("c", [0.5, 0.4, 0.7]), ("s", 0.5), ("c", [0.9, 0.4, -0.2]),
+             ("c", [0.9, 0.4, -0.3]), ("s", 1.0)]
+    if fmt != L.FMT_HRB and not real:
+        moves.append(("c", [0.9, 0.4 + 0.1j, -0.3 + 0.2j]))
+    for terms, expect_sparse in (([H0, Hd, D1, D2], True), ([H0, D1, Hd, D2], True), ([H0, D1, D2, Hd], False)):
+        outs = []
+        for knob in (1, 0):
+            ctx.tuning_set("sparse_controls", knob)
+            try:
+                Op = L.Operator(ctx, [L.Matrix.from_scipy(ctx, M) for M in terms], ncoeffs=3, fmt=fmt)
+                res = []
+                wrk = L.ChebyWrk(ctx, N, 30.0, -15.0, 0.3)
+                for kind, arg in moves:
+                    n0 = ctx.stats()["n_kernel_launches"]
+                    Op.set_coeffs(arg) if kind == "c" else Op.set_scale(arg)
+                    res.append(Op.get_csr()[2])
+                    x = L.State(ctx, data=psi0)
+                    L.cheby(x, Op, 0.3, wrk)
+                    res.append(x.numpy())
+                outs.append(res)
+                Op.close()
+            finally:
+                ctx.tuning_set("sparse_controls", 1)
+        for a, b in zip(*outs):
+            assert np.array_equal(a, b)
+        # the last state against the oracle
+        kind_c = [m for m in moves if m[0] == "c"][-1][1]
+        scale = [m for m in moves if m[0] == "s"][-1][1]
+        Heff = scale * (terms[0] + sum(c * M for c, M in zip(kind_c, terms[1:])))
+        ref = qo.cheby(psi0.copy(), sp.csr_matrix(Heff), 0.3, qo.ChebyWrk(psi0, 30.0, -15.0, 0.3))
+        if np.all(np.imag(kind_c) == 0):          # (a complex coefficient makes H non-Hermitian: cheby! is then only compared between the two paths)
+            assert np.linalg.norm(outs[0][-1] - ref) < TOL
+        del expect_sparse
+
+
+@pytest.mark.parametrize("fmt", [L.FMT_CSR, L.FMT_RBCSR, L.FMT_HRB])
 def test_real_valued_operator_streams_real_copy(ctx, fmt):
     """An operator whose terms and coefficients are all real is streamed from a real copy of
     its values (8 instead of 16 bytes per entry).  The real value enters the same complex FMA

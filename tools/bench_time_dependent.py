@@ -1,3 +1,8 @@
+"""Cost of evaluate! in a time-dependent Chebyshev step at N = 2^20 (drift + one control term, coefficient changed before
+every step): a dense control term, a diagonal one (sparse: only its positions are rewritten, knob sparse_controls), the same
+with the full combination forced, and the static / constant-coefficient references.
+
+    python tools/bench_time_dependent.py"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -82,6 +82,8 @@ struct WalkPlan {
   int valid = 0;
   int nn = 0, K = 0, z0 = 0;  // shape of the stencil (see above)
   int S = 0;                  // 64-row column chunks per strip step: ceil(g / 64)
+  int xl = 0;                 // 1: one more pair of distances +- glong beyond the ring's reach (loaded directly)
+  int64_t glong = 0;
   int64_t g = 0;              // rows per strip step (the far distances are g, 2 g, .., K g); need not be a multiple of 64
   int near[kWalkMaxNear] = {0};
   int64_t R0 = 0, R1 = 0, W0 = 0;
@@ -178,7 +180,7 @@ int launch_arnoldi_matvec_dots(hipStream_t s, const DevMatrix& A, const double2*
                                int64_t ldq, int j, double2* partials, bool* launched, Stats* st);
 // the strip walk for the fused Chebyshev term of a whole Hermitian-packed lattice operator; *launched = false when the
 // plan's shape has no kernel instance (the caller then takes the per-block kernel)
-bool walk_shape_supported(int nn, int K, int z0);   // is there a kernel instance for this stencil shape?
+bool walk_shape_supported(int nn, int K, int z0, int xl = 0);   // is there a kernel instance for this stencil shape?
 int launch_hrb_walk_cheby(hipStream_t s, const DevMatrix& A, const double2* x, const ChebyEpi& e, const Tuning& tun,
                           bool* launched, const RowSet* rs = nullptr);
 int spmv_grid_size(const DevMatrix& A);

@@ -564,6 +564,51 @@ static int64_t decode_lower_stencil_pos(const std::vector<char>& bytes, const st
 // position of every value, and of every conj-transposed value, is a formula; how the column sections of those blocks are
 // encoded does not matter (the walk reads none of them).  The remaining blocks are listed for the per-block path.
 // Index work only: host, exact.
+// The walk's stencil shape read off one row's sorted list of column distances (kernels_walk.hip):
+//   [-L]? [-K g .. -g] [-d_nn .. -d_1] [0]? [d_1 .. d_nn] [g .. K g] [L]?
+// near distances of at most kWalkHalo rows, far distances the multiples of one strip step g >= 64 rows, optionally one more
+// pair +-L beyond them (xl: the plane distance of a three-dimensional grid).  false: not a shape the walk has a kernel for.
+struct WalkShape {
+  int nn = 0, K = 0, z0 = 0, xl = 0;
+  int64_t g = 0, glong = 0;
+  int near[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+static bool parse_walk_shape(const std::vector<int64_t>& dl, WalkShape& w) {
+  const int z = (int)dl.size();
+  if (z < 3 || z > 19) return false;
+  for (int k = 0; k < z; ++k)
+    if (dl[(size_t)k] != -dl[(size_t)(z - 1 - k)]) return false;   // mirror images of each other
+  int nbig = 0;
+  while (nbig < z && dl[(size_t)nbig] <= -(int64_t)kRB) ++nbig;
+  if (nbig < 1 || nbig > 5) return false;
+  w = WalkShape();
+  w.g = -dl[(size_t)(nbig - 1)];
+  if (w.g < kRB) return false;
+  auto multiples = [&](int first, int K) {
+    for (int m = 1; m <= K; ++m)
+      if (dl[(size_t)(first + K - m)] != -(int64_t)m * w.g) return false;
+    return true;
+  };
+  if (nbig <= 4 && multiples(0, nbig)) {
+    w.K = nbig;
+  } else if (nbig >= 2 && multiples(1, nbig - 1) && -dl[0] > (int64_t)(nbig - 1) * w.g) {
+    w.K = nbig - 1;
+    w.xl = 1;
+    w.glong = -dl[0];
+  } else {
+    return false;
+  }
+  int k = nbig;
+  while (k < z && dl[(size_t)k] < 0) ++k, ++w.nn;
+  if (w.nn < 1 || w.nn > 4) return false;
+  for (int i = 0; i < w.nn; ++i) w.near[i] = (int)(-dl[(size_t)(nbig + w.nn - 1 - i)]);
+  for (int i = 0; i < w.nn; ++i)
+    if (w.near[i] <= 0 || w.near[i] > qp::kWalkHalo || (i > 0 && w.near[i] <= w.near[i - 1])) return false;
+  w.z0 = (k < z && dl[(size_t)k] == 0) ? 1 : 0;
+  if (z != 2 * (w.nn + w.K + w.xl) + w.z0) return false;
+  return qp::walk_shape_supported(w.nn, w.K, w.z0, w.xl);
+}
+
 static int build_walk_plan(qp_operator* op) {
   qp::WalkPlan& P = op->walk;
   if (P.edge_map) (void)hipFree(P.edge_map);
@@ -589,7 +634,7 @@ static int build_walk_plan(qp_operator* op) {
   int64_t best0 = 0, best1 = 0;
   for (int64_t b = 0; b < nfull;) {
     const int64_t ref = b * kRB;
-    if (ur[ref + 1] - ur[ref] < 3 || ur[ref + 1] - ur[ref] > 17) {
+    if (ur[ref + 1] - ur[ref] < 3 || ur[ref + 1] - ur[ref] > 19) {
       ++b;
       continue;
     }
@@ -609,37 +654,22 @@ static int build_walk_plan(qp_operator* op) {
   const int64_t z = ur[rref + 1] - ur[rref];
   std::vector<int64_t> dl((size_t)z);
   for (int64_t k = 0; k < z; ++k) dl[(size_t)k] = (int64_t)uc[ur[rref] + k] - rref;
-  // negatives: far then near; the diagonal; positives: near then far -- mirror images of each other
-  int64_t k = 0;
-  int K = 0, nn = 0, z0 = 0;
-  while (k < z && dl[(size_t)k] <= -(int64_t)kRB) ++k, ++K;
-  if (K < 1 || K > 4) return QP_OK;
-  const int64_t g = -dl[(size_t)(K - 1)];          // any stride of at least one row block (100 x 100 lattices are lattices too)
-  if (g < kRB) return QP_OK;
-  for (int m = 1; m <= K; ++m)
-    if (dl[(size_t)(K - m)] != -(int64_t)m * g) return QP_OK;
-  while (k < z && dl[(size_t)k] < 0) ++k, ++nn;
-  if (nn < 1 || nn > 4) return QP_OK;
-  for (int i = 0; i < nn; ++i) P.near[i] = (int)(-dl[(size_t)(K + nn - 1 - i)]);
-  for (int i = 0; i < nn; ++i)
-    if (P.near[i] <= 0 || P.near[i] > qp::kWalkHalo || (i > 0 && P.near[i] <= P.near[i - 1])) return QP_OK;
-  if (k < z && dl[(size_t)k] == 0) ++k, z0 = 1;
-  if (z != 2 * (nn + K) + z0) return QP_OK;
-  for (int i = 0; i < nn; ++i)
-    if (dl[(size_t)(K + nn + z0 + i)] != P.near[i]) return QP_OK;
-  for (int m = 1; m <= K; ++m)
-    if (dl[(size_t)(K + 2 * nn + z0 + m - 1)] != (int64_t)m * g) return QP_OK;
-  if (!qp::walk_shape_supported(nn, K, z0)) return QP_OK;
+  WalkShape ws;
+  if (!parse_walk_shape(dl, ws)) return QP_OK;
+  const int nn = ws.nn, K = ws.K, z0 = ws.z0, xl = ws.xl;
+  const int64_t g = ws.g;
+  for (int i = 0; i < nn; ++i) P.near[i] = ws.near[i];
   const int S = (int)((g + kRB - 1) / kRB);
-  const int64_t W0 = R0 + ((int64_t)K * g + kRB - 1) / kRB;      // first block whose rows find their K g history inside the run
+  // first block whose rows find their history (K g rows back, L for the long pair) inside the run
+  const int64_t W0 = R0 + (std::max<int64_t>((int64_t)K * g, ws.glong) + kRB - 1) / kRB;
   if (R1 - W0 < 8) return QP_OK;
   // the upper section of every block of the run: z0 + nn + K entries per row, padded to a multiple of four, at equal strides
-  const int64_t wu = ((z0 + nn + K + 3) / 4) * 4;
+  const int64_t wu = ((z0 + nn + K + xl + 3) / 4) * 4;
   const int64_t U0 = Lh.bptr[R0], ustride = wu * kRB;
   for (int64_t b = R0; b <= R1; ++b)
     if (Lh.bptr[b] != U0 + (b - R0) * ustride) return QP_OK;
   for (int64_t r = rref; r < R1 * kRB; r += kRB)
-    if (Lh.nlow[r] != nn + K) return QP_OK;
+    if (Lh.nlow[r] != nn + K + xl) return QP_OK;
   if (U0 + (R1 - R0) * ustride >= (int64_t)INT32_MAX) return QP_OK;
   std::vector<int32_t> edge;
   for (int64_t b = 0; b < W0; ++b) edge.push_back((int32_t)b);
@@ -649,6 +679,8 @@ static int build_walk_plan(qp_operator* op) {
   P.z0 = z0;
   P.S = S;
   P.g = g;
+  P.xl = xl;
+  P.glong = ws.glong;
   P.R0 = R0;
   P.R1 = R1;
   P.W0 = W0;
@@ -1021,7 +1053,7 @@ static int choose_format(qp_operator* op, int requested, bool hermitian) {
 // walk's lattice -- distances +-1, +-nx -- except that the rows at x = 0 lack the -1 entry and those at x = nx - 1 the +1
 // entry: one row in nx breaks the "same distances on every row" run that the strip walk (and the stencil encoding of the
 // row blocks) needs.  If every row between the first and the last K g rows carries a SUBSET of the middle row's distance
-// list, that list has the walk's shape, and at most 3 % of the entries are missing, the missing ones are stored as explicit
+// list, that list has the walk's shape, and at most 12 % of the entries are missing (a 64 x 8 x nz grid: 4 %), the missing ones are stored as explicit
 // zeros (with their transposes, so that the pattern stays structurally symmetric).  Index work only; 0 * x terms change no
 // row sum beyond the order in which the two accumulators of a row take their entries.
 static void lattice_fill(const qp::Tuning& tun, int64_t n, int64_t ncols, std::vector<int64_t>& ur, std::vector<int32_t>& uc) {
@@ -1031,25 +1063,18 @@ static void lattice_fill(const qp::Tuning& tun, int64_t n, int64_t ncols, std::v
   int64_t rm = n / 2;
   for (int64_t r = std::max<int64_t>(0, n / 2 - 128); r < std::min(n, n / 2 + 128); ++r)
     if (ur[r + 1] - ur[r] > ur[rm + 1] - ur[rm]) rm = r;
+  for (int64_t t = -32; t <= 32; ++t) {   // (a whole line of a three-dimensional grid may sit on an edge: look further out too)
+    const int64_t r = n / 2 + t * 4099;
+    if (r >= 0 && r < n && ur[r + 1] - ur[r] > ur[rm + 1] - ur[rm]) rm = r;
+  }
   const int z = (int)(ur[rm + 1] - ur[rm]);
-  if (z < 3 || z > 17) return;
+  if (z < 3 || z > 19) return;
   std::vector<int64_t> D((size_t)z);
   for (int k = 0; k < z; ++k) D[(size_t)k] = (int64_t)uc[ur[rm] + k] - rm;
-  for (int k = 0; k < z; ++k)
-    if (D[(size_t)k] != -D[(size_t)(z - 1 - k)]) return;
-  int K = 0, nn = 0, k = 0;
-  while (k < z && D[(size_t)k] <= -(int64_t)kRB) ++k, ++K;
-  if (K < 1 || K > 4) return;
-  const int64_t g = -D[(size_t)(K - 1)];
-  for (int m = 1; m <= K; ++m)
-    if (D[(size_t)(K - m)] != -(int64_t)m * g) return;
-  while (k < z && D[(size_t)k] < 0) {
-    if (-D[(size_t)k] > qp::kWalkHalo) return;
-    ++k, ++nn;
-  }
-  const int z0 = (k < z && D[(size_t)k] == 0) ? 1 : 0;
-  if (nn < 1 || nn > 4 || z != 2 * (nn + K) + z0 || !qp::walk_shape_supported(nn, K, z0)) return;
-  const int64_t lo = (int64_t)K * g, hi = n - (int64_t)K * g;
+  WalkShape ws;
+  if (!parse_walk_shape(D, ws)) return;
+  const int64_t reach = std::max<int64_t>((int64_t)ws.K * ws.g, ws.glong);
+  const int64_t lo = reach, hi = n - reach;
   if (hi - lo < 16 * (int64_t)kRB) return;
   int64_t missing = 0;
   for (int64_t r = lo; r < hi; ++r) {
@@ -1063,7 +1088,7 @@ static void lattice_fill(const qp::Tuning& tun, int64_t n, int64_t ncols, std::v
     }
     missing += z - (ur[r + 1] - ur[r]);
   }
-  if (missing == 0 || (double)missing > 0.03 * (double)ur[n]) return;
+  if (missing == 0 || (double)missing > 0.12 * (double)ur[n]) return;
   // transposes of filled entries that land in the first / last K g rows
   std::vector<std::pair<int64_t, int32_t>> extra;
   for (int64_t r = lo; r < hi; ++r) {

@@ -16,11 +16,15 @@ __device__ __forceinline__ void cfma(double2& s, const double2 a, const double2 
   s.y = fma(a.x, b.y, s.y);
   s.y = fma(a.y, b.x, s.y);
 }
+// One rounded product and one fused multiply-add per component, spelled out: left to -ffp-contract=fast, WHICH of the two
+// products of `a.x * b.x - a.y * b.y` gets fused is the compiler's choice per call site, and two kernels that must agree
+// bit for bit (the strip walk and the per-block kernel: the step's final phase exp(-i beta dt) is a complex scalar as soon
+// as the spectral window is not centred on zero) rounded differently.
 __device__ __forceinline__ double2 cmul(const double2 a, const double2 b) {
-  return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+  return make_double2(fma(a.x, b.x, -__dmul_rn(a.y, b.y)), fma(a.x, b.y, __dmul_rn(a.y, b.x)));
 }
 __device__ __forceinline__ double2 cconj_mul(const double2 a, const double2 b) {  // conj(a)*b
-  return make_double2(a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x);
+  return make_double2(fma(a.x, b.x, __dmul_rn(a.y, b.y)), fma(a.x, b.y, -__dmul_rn(a.y, b.x)));
 }
 
 // Sum over the 64 lanes of a wavefront, returned in EVERY lane, through the data-parallel primitives of the vector ALU

@@ -204,6 +204,8 @@ struct WalkStep {
   // halos of the near windows, sixteen lanes each (lane = 16 q + t, only t < distance is used):
   double2 hx;          //   q = 0: x[r0 - dmax + t]         q = 1: x[r0 + 64 + t]
   double2 ha;          //   q = i: value (64 - d_i + t) of slot z0 + i of block b - 1
+  // the long pair (XL): x[row + L], x[row - L] and the conj-transposed value of the lower entry (row, row - L)
+  double2 xlu, xll, al;
 };
 
 // LDS of one wavefront, in double2 elements: the near window of x (16 + 64 + 16), NN near value windows (16 + 64) and the
@@ -236,13 +238,18 @@ __device__ __forceinline__ void wave_sync_wait(const SyncArgs& sy) {
 }
 
 // NTM: nontemporal accesses (bit 0: the matrix values, bit 1: the vector loads, bit 2: the stores)
-template <class VT, int NN, int K, int Z0, int NTM>
+// XL = 1: one more pair of distances +-L beyond the ring's reach (L > K g, any number of rows: the plane distance nx ny of
+// a three-dimensional grid walked in steps of g = nx).  Its operands are not in the ring -- they would be ny steps away --
+// and are loaded directly, one step ahead like everything else: x[row + L], x[row - L], the upper value of slot
+// z0 + nn + K and the value stored for (row - L, row).  Storage order of the sections: the long entry is the first of
+// the lower and the last of the upper one.
+template <class VT, int NN, int K, int Z0, int NTM, int XL = 0>
 __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __restrict__ uvals,
                                                                     const double2* __restrict__ x, WalkPlan P,
                                                                     WalkGeom G, HrbArrays H, int64_t nrows, ChebyOp op,
                                                                     SyncArgs sy) {
-  constexpr int NL = NN + K;         // lower slots: [-K g .. -g] [-d_NN .. -d_1]
-  constexpr int NU = Z0 + NN + K;    // upper slots that carry entries: [0] [d_1 .. d_NN] [g .. K g]
+  constexpr int NL = XL + NN + K;         // lower slots: [-L] [-K g .. -g] [-d_NN .. -d_1]
+  constexpr int NU = Z0 + NN + K + XL;    // upper slots that carry entries: [0] [d_1 .. d_NN] [g .. K g] [L]
   using Lds = WalkLds<NN, K>;
   constexpr int XW = Lds::XW, AW = Lds::AW;
   static_assert(NN <= 4, "the near value halos share one register: sixteen lanes each");
@@ -309,6 +316,11 @@ __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __r
     w.acc = ld_stream<(NTM & 2) != 0>(accp ? accp + r : x + lane);
     w.hx = x[min(r0 + hoff_x, rmax)];
     w.ha = ld_val<false>(uvals + vpos(r0 - hd + min(ht, hd - 1)) + (size_t)hslot * 64);
+    if constexpr (XL != 0) {
+      w.xlu = ld_stream<(NTM & 2) != 0>(x + min(r + P.glong, rmax));
+      w.xll = ld_stream<(NTM & 2) != 0>(x + (r - P.glong));
+      w.al = ld_val<false>(uvals + vpos(r - P.glong) + (size_t)(Z0 + NN + K) * 64);
+    }
   };
   // where this lane's halo elements go in the windows (lanes that carry none rewrite their own main element)
   const bool hx_on = hq < 2 && ht < dmax;
@@ -368,16 +380,19 @@ __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __r
       nxu[i] = xwin[kWalkHalo + lane + d];
     }
     double2 s0 = make_double2(0.0, 0.0), s1 = make_double2(0.0, 0.0);
-    // lower section, storage order: far -K g .. -g, then near -d_NN .. -d_1
+    // lower section, storage order: (the long entry -L,) far -K g .. -g, then near -d_NN .. -d_1
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
       double2 a, xv;
-      if (l < K) {
-        const int m = K - l;
+      if (l < XL) {
+        a = cu.al;
+        xv = cu.xll;
+      } else if (l < XL + K) {
+        const int m = K - (l - XL);
         a = fa[m - 1];
         xv = xr[K - m];
       } else {
-        const int i = NN - 1 - (l - K);
+        const int i = NN - 1 - (l - XL - K);
         a = na[i];
         xv = nxl[i];
       }
@@ -390,7 +405,8 @@ __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __r
       double2 xv;
       if (u < Z0) xv = xr[K];
       else if (u < Z0 + NN) xv = nxu[u - Z0];
-      else xv = xr[K + (u - Z0 - NN + 1)];
+      else if (u < Z0 + NN + K) xv = xr[K + (u - Z0 - NN + 1)];
+      else xv = cu.xlu;
       if (u & 1) cfma(s1, cu.ua[u], xv);
       else cfma(s0, cu.ua[u], xv);
     }
@@ -434,13 +450,13 @@ __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __r
   }
 }
 
-template <class VT, int NN, int K, int Z0, int NTM = 0>
+template <class VT, int NN, int K, int Z0, int NTM = 0, int XL = 0>
 static bool launch_instance(hipStream_t s, dim3 grid, const VT* uvals, const double2* x, const WalkPlan& P,
                             const WalkGeom& G, const HrbArrays& H, int64_t nrows, const ChebyOp& op, const SyncArgs& sy) {
   const int ws = G.ntask / std::max(G.n_walk_wg, 1);      // wavefronts per workgroup of this launch
   const size_t lds = WalkLds<NN, K>::kBytesPerWave * (size_t)ws;
   constexpr size_t lds_max = WalkLds<NN, K>::kBytesPerWave * kWalkWaves;
-  auto kern = &hrb_walk_kernel<VT, NN, K, Z0, NTM>;
+  auto kern = &hrb_walk_kernel<VT, NN, K, Z0, NTM, XL>;
   // more than the 64 KB a launch gets without asking: opt in once per kernel instance AND device (a process may hold
   // contexts on several GPUs); 0 = not tried, 1 = granted, 2 = refused (the caller then takes the per-block kernel)
   static std::atomic<unsigned char> opted[64];
@@ -461,6 +477,19 @@ template <class VT>
 static bool launch_shape(hipStream_t s, dim3 grid, const VT* uvals, const double2* x, const WalkPlan& P,
                          const WalkGeom& G, const HrbArrays& H, int64_t nrows, const ChebyOp& op, int ntm, const SyncArgs& sy) {
   const int key = P.nn * 100 + P.K * 10 + P.z0;
+  if (P.xl) {   // the long pair: near 1 or 2, one far distance (three-dimensional grids)
+#define QP_WALK_XL(NN_, Z0_)                                                                                   \
+  return (ntm & 1) ? launch_instance<VT, NN_, 1, Z0_, 1, 1>(s, grid, uvals, x, P, G, H, nrows, op, sy)           \
+                   : launch_instance<VT, NN_, 1, Z0_, 0, 1>(s, grid, uvals, x, P, G, H, nrows, op, sy);
+    switch (key) {
+      case 110: QP_WALK_XL(1, 0)
+      case 111: QP_WALK_XL(1, 1)
+      case 210: QP_WALK_XL(2, 0)
+      case 211: QP_WALK_XL(2, 1)
+      default: return false;
+    }
+#undef QP_WALK_XL
+  }
 #define QP_WALK_SHAPE(NN_, K_, Z0_)                                                                       \
   return (ntm & 1) ? launch_instance<VT, NN_, K_, Z0_, 1>(s, grid, uvals, x, P, G, H, nrows, op, sy)            \
                    : launch_instance<VT, NN_, K_, Z0_, 0>(s, grid, uvals, x, P, G, H, nrows, op, sy);
@@ -490,7 +519,11 @@ static bool launch_shape(hipStream_t s, dim3 grid, const VT* uvals, const double
 }
 
 // near distances 1..4 of at most 16 rows, far reach 1..4 strip steps, with or without a diagonal
-bool walk_shape_supported(int nn, int K, int z0) { return nn >= 1 && nn <= 4 && K >= 1 && K <= 4 && (z0 == 0 || z0 == 1); }
+// ... and, with one long pair beyond the ring (xl = 1), near 1..2 and one far distance
+bool walk_shape_supported(int nn, int K, int z0, int xl) {
+  if (xl) return xl == 1 && nn >= 1 && nn <= 2 && K == 1 && (z0 == 0 || z0 == 1);
+  return nn >= 1 && nn <= 4 && K >= 1 && K <= 4 && (z0 == 0 || z0 == 1);
+}
 
 int launch_hrb_walk_cheby(hipStream_t s, const DevMatrix& A, const double2* x, const ChebyEpi& e, const Tuning& tun,
                           bool* launched, const RowSet* rs) {
@@ -510,7 +543,7 @@ int launch_hrb_walk_cheby(hipStream_t s, const DevMatrix& A, const double2* x, c
   // ... and beyond it the matrix values are streamed nontemporally: they are read once per term, and what the
   // Infinity Cache then keeps from one term to the next is the vectors
   // (the slots the walk streams: the pad slots of the quad-padded upper sections are never read)
-  const double footprint = (double)(P->z0 + P->nn + P->K) * kRB * (double)A.nblocks * (A.vals_r ? 8.0 : 16.0) + 64.0 * (double)A.nrows;
+  const double footprint = (double)(P->z0 + P->nn + P->K + P->xl) * kRB * (double)A.nblocks * (A.vals_r ? 8.0 : 16.0) + 64.0 * (double)A.nrows;
   const bool resident = footprint <= 230e6;
   // beyond it: every CU but the few the edge workgroups take (8 x (256 - 24) = 1856 for the headline lattice), so that
   // the edge blocks run BESIDE the walk there too; 2048 with the edge blocks inside the walk's wavefronts when that would

@@ -119,6 +119,42 @@ def grid_hamiltonian_2d(nx, ny, flux=0.0, next_nearest=False, seed=DEFAULT_SEED)
     return H
 
 
+def grid_hamiltonian_3d(nx, ny, nz, flux=0.0, seed=DEFAULT_SEED):
+    """Seven-point finite-difference Hamiltonian on an nx x ny x nz grid with OPEN boundaries (row = x + nx (y + ny z)):
+    hopping -1 to the six neighbours (phase exp(i flux y) on the x-hops when flux != 0), a smooth potential on the diagonal.
+    Distances +-1, +-nx, +-nx ny: the walk's lattice with one long pair beyond the ring (kernels_walk.hip, XL) once its edge
+    rows are completed.  Returns scipy CSR (sorted indices)."""
+    import scipy.sparse as sp
+    N = nx * ny * nz
+    idx = np.arange(N, dtype=np.int64)
+    X = idx % nx
+    Y = (idx // nx) % ny
+    Z = idx // (nx * ny)
+    rows, cols, vals = [], [], []
+
+    def hop(mask, d, v):
+        r = idx[mask]
+        vv = v[mask] if np.ndim(v) else np.full(len(r), v, dtype=np.complex128)
+        rows.extend([r, r + d])
+        cols.extend([r + d, r])
+        vals.extend([vv, np.conj(vv)])
+
+    phase = np.exp(1j * flux * Y) if flux else np.ones(N, dtype=np.complex128)
+    hop(X < nx - 1, 1, -phase)
+    hop(Y < ny - 1, nx, np.complex128(-1.0))
+    hop(Z < nz - 1, nx * ny, np.complex128(-0.5))
+    with np.errstate(over="ignore"):
+        jitter = _u01(splitmix64(np.uint64(seed) ^ (idx.astype(np.uint64) * _GOLDEN)))
+    pot = 0.5 * ((X - nx / 2) / nx) ** 2 + 0.5 * ((Y - ny / 2) / ny) ** 2 + 0.5 * ((Z - nz / 2) / nz) ** 2
+    rows.append(idx)
+    cols.append(idx)
+    vals.append((5.0 + pot + 0.01 * jitter).astype(np.complex128))
+    H = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(N, N))
+    H.sum_duplicates()
+    H.sort_indices()
+    return H
+
+
 def random_columns_csr(N, n_pairs=8, window=None, rho=10.0, seed=DEFAULT_SEED):
     """Hermitian H whose columns are drawn PER ROW (no translation invariance: the irregular case that
     plain "CSR" implies), 2 n_pairs entries per row, no diagonal.  Rows are cut into blocks of `window`

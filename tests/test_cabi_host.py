@@ -266,7 +266,7 @@ def test_lattice_fill_host_completes_open_boundary_grids(nx, ny, nnn):
 
 
 def test_lattice_fill_host_leaves_other_patterns_alone():
-    """No completion for: a lattice with an entry outside its distances, more than 3 % missing entries, operators below the
+    """No completion for: a lattice with an entry outside its distances, more than 12 % missing entries, operators below the
     size knob, a complete lattice, a non-symmetric distance list, a row-partitioned pattern whose interior rows reach the
     halo columns; the local rows of a partitioned grid operator (halo columns only in the first / last grid row) are completed."""
     import scipy.sparse as sp
@@ -284,8 +284,8 @@ def test_lattice_fill_host_leaves_other_patterns_alone():
     H2[N // 2 + 5, N // 2 + 37] = H2[N // 2 + 37, N // 2 + 5] = 0.5            # a foreign entry
     assert same(sp.csr_matrix(H2))
     Hh = sp.lil_matrix(H)
-    for y in range(2, ny - 2):                                                  # every third x-hop cut: > 3 % missing
-        for x in range(0, nx - 1, 3):
+    for y in range(2, ny - 2):                                                  # every second x-hop cut: 20 % missing
+        for x in range(0, nx - 1, 2):
             Hh[x + nx * y, x + 1 + nx * y] = 0
             Hh[x + 1 + nx * y, x + nx * y] = 0
     Hh = sp.csr_matrix(Hh)

@@ -891,6 +891,59 @@ def test_lattice_fill_open_boundary_grid(ctx, nx, ny, flux, nnn, shape):
         ctx.tuning_set("walk_min_blocks", saved["walk_min_blocks"])
 
 
+@pytest.mark.parametrize("dims,flux,uniform", [((64, 8, 40), 0.2, False), ((100, 6, 30), 0.0, False), ((70, 9, 24), 0.1, False),
+                                               ((0, 0, 0), 0.0, True)], ids=["64x8x40", "100x6x30_real", "70x9x24", "uniform_offsets"])
+def test_strip_walk_long_pair_three_dimensional_grids(ctx, dims, flux, uniform):
+    """Distances +-1, +-nx, +-nx ny: the plane distance is not in the walk's ring of +-K strip steps (it is ny steps away);
+    the kernel instances with a long pair (XL) load its operands directly.  A seven-point Hamiltonian on an open-boundary
+    nx x ny x nz grid is completed at creation (the x-edge rows AND the y-edge lines of every plane) and then walks in steps
+    of g = nx: bit-identical to the per-block kernel for several partitions of the walk, within 1e-10 of the oracle."""
+    if uniform:          # translation-invariant lattice with the same distances (no completion needed)
+        N = 1 << 15
+        rp, col, vals = synth.hermitian_offsets_csr(N, offsets=(1, 2, 128, 3000))
+        H = synth.to_scipy(rp, col, vals, N)
+        H = sp.csr_matrix(H + sp.diags(np.linspace(-1.0, 1.0, N)).astype(np.complex128))
+        H.sort_indices()
+        Delta, Emin = 24.0, -12.0
+    else:
+        H = synth.grid_hamiltonian_3d(*dims, flux=flux)
+        N = H.shape[0]
+        Delta, Emin = 14.0, -1.0
+    psi0 = synth.random_state(N)
+    saved = {k: ctx.tuning_get(k) for k in WALK_KNOBS}
+    try:
+        ctx.tuning_set("walk_min_blocks", 16)
+        Op = L.Operator(ctx, [L.Matrix.from_scipy(ctx, H)])
+        assert Op.format == L.FMT_HRB
+        wi = Op.walk_info()
+        assert wi["valid"] == 1 and wi["far"] == 1 and wi["diag"] == 1
+        if not uniform:
+            assert Op.fill_info() > 0 and wi["rows_per_step"] == dims[0]
+            assert wi["first_block"] >= (dims[0] * dims[1]) // 64
+        wrk = L.ChebyWrk(ctx, N, Delta, Emin, 0.6)
+
+        def run(**knobs):
+            for k, v in {**WALK_DEFAULTS, "walk_min_blocks": 16, **knobs}.items():
+                ctx.tuning_set(k, v)
+            psi = L.State(ctx, data=psi0)
+            for dt in (0.6, -0.6, 0.6):
+                L.cheby(psi, Op, dt, wrk)
+            return psi.numpy()
+
+        base = run(hrb_walk=0)
+        for knobs in (dict(), dict(walk_waves=64), dict(walk_waves=1024), dict(walk_dbg=4), dict(walk_dbg=5, walk_waves=256),
+                      dict(walk_nt=1), dict(walk_wg=8), dict(walk_wg=2, walk_waves=96)):
+            assert np.array_equal(base, run(**knobs)), knobs
+    finally:
+        for k, v in saved.items():
+            ctx.tuning_set(k, v)
+    owrk = qo.ChebyWrk(psi0, Delta, Emin, 0.6)
+    ref = psi0.copy()
+    for dt in (0.6, -0.6, 0.6):
+        qo.cheby(ref, H, dt, owrk)
+    assert np.linalg.norm(base - ref) < TOL
+
+
 def test_strip_walk_inside_a_replayed_graph(ctx):
     """Knob `cheby_graph` with an operator that takes the strip walk: the walk's launch (dynamic LDS above 64 KB, opted in
     per kernel instance and device) is captured and replayed like any other; same bits as the eager step, and the graph is
@@ -929,14 +982,14 @@ def test_strip_walk_inside_a_replayed_graph(ctx):
 def test_strip_walk_plan_only_for_lattices(ctx):
     """The walk plan is index work on the host: it exists only where one list of column distances repeats down a run of row
     blocks and has the walk's shape -- not for scattered or per-row random columns, not for near distances beyond the LDS
-    halo, far distances that are not the multiples g, 2 g, .. of one stride g >= 64 (any such g will do), more than four near or far
-    distances -- and it
+    halo, far distances that are not the multiples g, 2 g, .. of one stride g >= 64 (any such g will do; ONE further distance beyond
+    them is the long pair of a three-dimensional grid, with at most two near distances), more than four near or far distances -- and it
     goes away when a complex coefficient forces the operator out of the Hermitian-packed format."""
     N = 1 << 15
     saved = ctx.tuning_get("walk_min_blocks")
     ctx.tuning_set("walk_min_blocks", 16)
     try:
-        for offsets, want in (((1, 2, 512, 1024), 1), ((1, 2, 500, 1000), 1), ((1, 2, 500, 1100), 0), ((1, 2, 40, 80), 0), ((1, 17, 512, 1024), 0), ((1, 2, 512, 1536), 0),
+        for offsets, want in (((1, 2, 512, 1024), 1), ((1, 2, 500, 1000), 1), ((1, 2, 500, 1100), 1), ((1, 2, 500, 1100, 1700), 0), ((1, 2, 3, 500, 1100), 0), ((1, 2, 40, 80), 0), ((1, 17, 512, 1024), 0), ((1, 2, 512, 1536), 1), ((1, 2, 512, 1536, 2048), 0),
                               ((1, 2, 3, 512), 1), ((1, 512, 1024, 1536), 1), ((3, 5, 320, 640), 1), ((1, 2, 3, 4, 5, 6, 512, 1024), 0)):
             rp, col, vals = synth.hermitian_offsets_csr(N, offsets=offsets)
             Op = L.Operator(ctx, [L.Matrix(ctx, N, N, rp, col, vals)], 0, L.FMT_HRB)

@@ -36,6 +36,10 @@ def main():
         nsteps = int(rng.integers(2 * K + 6, 2 * K + 60))
         N = g * nsteps + int(rng.choice([0, 0, 64, 1, 37, 200]))
         offsets = tuple(near) + tuple(g * m for m in range(1, K + 1))
+        if rng.integers(0, 5) == 0:          # a fifth of the cases: the long pair of a three-dimensional grid (near <= 2, one far distance)
+            nn, K = min(nn, 2), 1
+            near = near[:nn]
+            offsets = tuple(near) + (g, g * int(rng.integers(2, 12)) + int(rng.integers(0, 2)) * int(rng.integers(1, g)))
         if 2 * max(offsets) >= N or N > (1 << 18):
             continue
         nterms = int(rng.integers(1, 4))
@@ -67,7 +71,7 @@ def main():
         Heff = sp.csr_matrix(Heff)
         wi = Op.walk_info()
         dt = float(rng.choice([0.3, 0.7, 1.1]))
-        Delta, E_min = 60.0, -30.0
+        Delta, E_min = (60.0, -30.0) if rng.integers(0, 2) else (70.0, -30.0)     # (a window off centre: complex final phase)
         psi0 = synth.random_state(N, seed=case)
         wrk = L.ChebyWrk(ctx, N, Delta, E_min, dt)
         signs = [1 if rng.integers(0, 3) else -1 for _ in range(3)]

@@ -695,7 +695,8 @@ def main():
                              ("c2_alpha_2_17_coefficients", dict(pattern="banded", log2n=20, dt=0.2, steps=20)),
                              ("c2_alpha_50_85_coefficients", dict(pattern="banded", log2n=20, dt=5.0, steps=5)),
                              ("c2_real_symmetric_f64_values", dict(pattern="banded", log2n=20, real=True)),
-                             ("grid_2048x2048_five_point_open_boundaries", dict(grid=(2048, 2048), steps=5))):
+                             ("grid_2048x2048_five_point_open_boundaries", dict(grid=(2048, 2048), steps=5)),
+                             ("grid_256x128x128_seven_point_open_boundaries", dict(grid=(256, 128, 128), steps=4))):
                 try:
                     extras[name] = bp.measure_cheby(ctx, **kw)
                 except Exception as e:  # noqa: BLE001  (an extra point must not take the headline down)

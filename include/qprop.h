@@ -187,6 +187,9 @@ int qp_operator_fill_info(const qp_operator* op, int64_t* n_filled);
  * reach K (far distances m g, m = 1..K), out[3] = 1 if the stencil has a diagonal, out[4] = rows per strip step g
  * (any g >= 64), out[5], out[6] = the walkable row blocks [W0, R1), out[7] = row blocks on the per-block path. */
 int qp_operator_walk_info(const qp_operator* op, int64_t out[8]);
+/* *glong = the long distance L (rows) of a walk plan with one further pair of distances +-L beyond its far reach
+ * (a three-dimensional grid's plane distance; its operands are loaded directly), 0 if the plan has none / there is no plan */
+int qp_operator_walk_long(const qp_operator* op, int64_t* glong);
 /* How qp_cheby_step_batched will visit the rows for a panel of `batch` states (wave-per-row kernel,
  * more than 32 states): out[0] = inner dimension g detected in the pattern (far offsets are multiples of
  * g: H = H_a (x) 1 + 1 (x) H_c), out[1] = strip width (rows are visited strip by strip so that the gather

@@ -238,6 +238,13 @@ function operator_walk_info(op::Handle)
             first_block = out[6], end_block = out[7], edge_blocks = out[8])
 end
 
+# long distance (rows) of a walk plan with one further pair beyond its far reach (three-dimensional grids), 0 if none
+function operator_walk_long(op::Handle)
+    n = Ref{Int64}(0)
+    check(ccall((:qp_operator_walk_long, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}), op, n))
+    return n[]
+end
+
 # explicit zeros that qp_operator_create added to complete a lattice operator's rows (open boundaries of a grid)
 function operator_fill_info(op::Handle)
     n = Ref{Int64}(0)

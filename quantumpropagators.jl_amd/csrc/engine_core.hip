@@ -1042,7 +1042,20 @@ static int choose_format(qp_operator* op, int requested, bool hermitian) {
     }
     const bool coalesced = sampled == 0 || 4 * regular >= 3 * sampled;
     // (the packed format addresses the transposed values with int32 positions)
-    if ((double)nnear >= 0.85 * (double)nlow && coalesced && hrb_ok && rb_stored < (int64_t)INT32_MAX) return QP_FMT_HRB;
+    // ... unless the operator will take the strip walk, which reads a far transposed value one step ahead like any other
+    // stream instead of waiting for it in the row sum (the plane distance of a three-dimensional grid is 32768 rows away:
+    // 256 x 128 x 128 grid 136 us per term as plain row blocks, 101 packed and walked)
+    bool walkable = false;
+    if (op->ctx->tun.hrb_walk && nblocks >= op->ctx->tun.walk_min_blocks) {
+      int64_t rm = nrows / 2;
+      for (int64_t r = std::max<int64_t>(0, nrows / 2 - 128); r < std::min(nrows, nrows / 2 + 128); ++r)
+        if (ur[r + 1] - ur[r] > ur[rm + 1] - ur[rm]) rm = r;
+      std::vector<int64_t> D((size_t)(ur[rm + 1] - ur[rm]));
+      for (size_t k = 0; k < D.size(); ++k) D[k] = (int64_t)uc[ur[rm] + (int64_t)k] - rm;
+      WalkShape wsh;
+      walkable = parse_walk_shape(D, wsh) && 4 * regular >= 3 * sampled;
+    }
+    if (((double)nnear >= 0.85 * (double)nlow || walkable) && coalesced && hrb_ok && rb_stored < (int64_t)INT32_MAX) return QP_FMT_HRB;
     return rb_ok ? QP_FMT_RBCSR : QP_FMT_CSR;
   }
   if (requested == QP_FMT_HRB && !hermitian) return -1;
@@ -1374,6 +1387,12 @@ int qp_operator_walk_info(const qp_operator* op, int64_t out[8]) {
   out[5] = on ? P.W0 : 0;
   out[6] = on ? P.R1 : 0;
   out[7] = on ? P.n_edge : 0;
+  return QP_OK;
+}
+
+int qp_operator_walk_long(const qp_operator* op, int64_t* glong) {
+  if (!op || !glong) return qp::fail(QP_E_BAD_ARG, "qp_operator_walk_long: NULL argument");
+  *glong = (op->walk.valid && op->A.walk == &op->walk && op->walk.xl) ? op->walk.glong : 0;
   return QP_OK;
 }
 

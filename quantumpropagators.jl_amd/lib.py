@@ -127,6 +127,7 @@ SIGNATURES = {
     "qp_operator_build_info": (C.c_int, [_P, _dp]),
     "qp_operator_walk_info": (C.c_int, [_P, _i64p]),
     "qp_operator_fill_info": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "qp_operator_walk_long": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "qp_lattice_fill_host": (C.c_int, [C.c_int64, C.c_int64, _i64p, _i32p, C.c_int, _i64p, _i32p, C.c_int64, C.POINTER(C.c_int64)]),
     "qp_operator_spmm_walk": (C.c_int, [_P, C.c_int, _i64p]),
     "qp_state_create": (C.c_int, [_P, C.c_int64, C.POINTER(_P)]),
@@ -549,8 +550,12 @@ class Operator:
         """Strip-walk plan of a Hermitian-packed lattice operator (see include/qprop.h)."""
         out = np.zeros(8, dtype=np.int64)
         check(self.lib.qp_operator_walk_info(self._h, _ptr(out, _i64p)))
-        return dict(zip(("valid", "near", "far", "diag", "rows_per_step", "first_block", "end_block", "edge_blocks"),
-                        (int(v) for v in out)))
+        d = dict(zip(("valid", "near", "far", "diag", "rows_per_step", "first_block", "end_block", "edge_blocks"),
+                     (int(v) for v in out)))
+        gl = C.c_int64(0)
+        check(self.lib.qp_operator_walk_long(self._h, C.byref(gl)))
+        d["long_distance"] = gl.value        # rows; 0: no long pair (three-dimensional grids have one: the plane distance)
+        return d
 
     def spmm_walk(self, batch):
         """Row walk of the batched kernel for ``batch`` states: (inner dimension, strip width), (0, 0)

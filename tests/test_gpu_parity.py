@@ -917,6 +917,7 @@ def test_strip_walk_long_pair_three_dimensional_grids(ctx, dims, flux, uniform):
         assert Op.format == L.FMT_HRB
         wi = Op.walk_info()
         assert wi["valid"] == 1 and wi["far"] == 1 and wi["diag"] == 1
+        assert wi["long_distance"] == (3000 if uniform else dims[0] * dims[1])
         if not uniform:
             assert Op.fill_info() > 0 and wi["rows_per_step"] == dims[0]
             assert wi["first_block"] >= (dims[0] * dims[1]) // 64

@@ -47,7 +47,7 @@ def cheby_layout_bytes(op, rows, ncols, nnz, coeffs, real_copy=False):
             share = walk["edge_blocks"] / max(lay["blocks"], 1)
             index *= share
             # ... and reads the slots that carry entries, not the pad slots of the quad-padded sections
-            slots = walk["diag"] + walk["near"] + walk["far"]
+            slots = walk["diag"] + walk["near"] + walk["far"] + (1 if walk.get("long_distance") else 0)
             stored = 64.0 * slots * (walk["end_block"] - walk["first_block"]) + lay["stored"] * share
         matrix = vbytes * stored + index
     sched = L.acc_schedule(coeffs)
@@ -93,7 +93,13 @@ def measure_cheby(ctx, pattern="banded", log2n=20, fmt="auto", steps=10, warmup=
     """Cheby prop_step! on one GPU for a pattern / size / device format; per-term time from HIP events on
     the kernels' stream; layout-byte and CSR-equivalent rates.  grid = (nx, ny): the finite-difference Hamiltonian of an
     open-boundary grid (synth.grid_hamiltonian_2d) instead of a pattern."""
-    if grid:
+    if grid and len(grid) == 3:
+        Hg = synth.grid_hamiltonian_3d(*grid, flux=0.1)
+        N = grid[0] * grid[1] * grid[2]
+        pattern = f"seven-point grid {grid[0]} x {grid[1]} x {grid[2]}, open boundaries"
+        rp, col, vals = Hg.indptr.astype(np.int64), Hg.indices.astype(np.int32), Hg.data.astype(np.complex128)
+        del Hg
+    elif grid:
         Hg = synth.grid_hamiltonian_2d(grid[0], grid[1], flux=0.1)
         N = grid[0] * grid[1]
         pattern = f"five-point grid {grid[0]} x {grid[1]}, open boundaries"

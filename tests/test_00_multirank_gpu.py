@@ -292,6 +292,29 @@ def test_bench_single_gpu_line_is_physical():
     assert rf["traffic_detail"]["dispatches"][0] >= 31
 
 
+def test_bench_extras_points_are_physical():
+    """The measurement functions behind bench.py's `extras` (tools/bench_points.py), at small sizes: every `frac` is a physical
+    fraction of the 8 TB/s roofline (bytes the implementation moves / time), the SURVEY 8d model of the Newton sweep is reported
+    beside it under its own key, an open-boundary grid takes the strip walk after the lattice completion."""
+    import qprop_amd.lib as L
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_points as bp
+    ctx = L.Context(0)
+    try:
+        ctx.tuning_set("walk_min_blocks", 64)
+        r = bp.measure_newton_c3(ctx, n=96, m=12, steps=3, warmup=3)
+        assert 0 < r["frac"] <= 1.0 and r["frac"] == r["implementation_frac"] and r["frac_survey_8d_model"] > r["frac"]
+        assert r["launches_per_column"] < 2.6
+        g = bp.measure_cheby(ctx, grid=(128, 96), steps=2, warmup=1)
+        assert 0 < g["frac"] <= 1.0 and g["kernel"] == "hrb_walk_kernel" and g["explicit_zeros_completing_the_lattice"] > 0
+        g3 = bp.measure_cheby(ctx, grid=(64, 12, 40), steps=2, warmup=1)
+        assert 0 < g3["frac"] <= 1.0 and g3["kernel"] == "hrb_walk_kernel" and g3["strip_walk"]["long_distance"] == 64 * 12
+        b = bp.measure_cheby(ctx, pattern="banded", log2n=16, steps=2, warmup=1)
+        assert 0 < b["frac"] <= 1.0
+    finally:
+        ctx.close()
+
+
 def test_c_consumer_runs(tmp_path):
     """examples/c_abi_demo.c -- a plain-C program on the C ABI, no Python / torch in the process: its own
     checks (norm, Newton == Cheby, forward + backward = identity, the reference's dt assertion) pass."""

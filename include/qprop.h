@@ -170,8 +170,8 @@ int qp_operator_info(const qp_operator* op, int64_t* nrows, int64_t* ncols, int6
  * out[3] = bytes of index data a mat-vec streams (column sections + transpose positions
  * of the non-stencil lower sections), out[4] = stored values. */
 int qp_operator_layout_info(const qp_operator* op, int64_t out[5]);
-/* What laying the operator out on the device cost (host work: format choice, encoding, upload): out[0] = ms of the
- * latest build, out[1] = ms of all builds, out[2] = re-layouts after creation -- evaluate! (src/generators.jl:757-766)
+/* What creating the operator cost on the host (union pattern, lattice completion, value planes, Hermitian check, format
+ * choice, encoding, upload): out[0] = ms of the latest build (the creation itself, or a later re-layout), out[1] = ms of all builds, out[2] = re-layouts after creation -- evaluate! (src/generators.jl:757-766)
  * only rewrites coefficients, but a complex coefficient on a Hermitian-packed operator forces ONE rebuild as plain
  * row blocks (a slower mat-vec from then on) --, out[3] = the current device format (QP_FMT_*). */
 int qp_operator_build_info(const qp_operator* op, double out[4]);

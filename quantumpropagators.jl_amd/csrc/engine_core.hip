@@ -1090,6 +1090,16 @@ static void lattice_fill(const qp::Tuning& tun, int64_t n, int64_t ncols, std::v
   const int64_t lo = reach, hi = n - reach;
   if (hi - lo < 16 * (int64_t)kRB) return;
   int64_t missing = 0;
+  {   // nothing to complete when every row between lo and hi already has z entries (the headline lattice): skip the check
+    bool longer = false;
+    for (int64_t r = lo; r < hi && !longer; ++r) {
+      const int64_t len = ur[r + 1] - ur[r];
+      longer = len > z;
+      missing += z - len;
+    }
+    if (longer || missing == 0) return;
+    missing = 0;
+  }
   for (int64_t r = lo; r < hi; ++r) {
     int d = 0;
     for (int64_t p = ur[r]; p < ur[r + 1]; ++p) {
@@ -1160,6 +1170,7 @@ int qp_operator_create(qp_ctx* ctx, qp_matrix* const* ops, int nops, int ncoeffs
   op->A.nrows = nrows;
   op->A.ncols = ncols;
 
+  const auto t_create = std::chrono::steady_clock::now();
   // ---- union sparsity pattern (sorted merge per row) ----
   auto& ur = op->u_rowptr;
   auto& uc = op->u_col;
@@ -1191,6 +1202,21 @@ int qp_operator_create(qp_ctx* ctx, qp_matrix* const* ops, int nops, int ncoeffs
   for (int l = 0; l < nops; ++l) {
     const qp_matrix* M = ops[l];
     auto& pv = planes_csr[l];
+    if (nops == 1 && (int64_t)M->vals.size() == op->A.nnz && uc.size() == M->col.size() && ur == M->rowptr) {
+      // one term and no completion: the union pattern is the term's own -- a plain copy, unless a row holds one column
+      // twice (the loop below sums duplicates into the first of them, as Julia's sparse() does)
+      bool dup = false;
+      for (int64_t r = 0; r < nrows && !dup; ++r)
+        for (int64_t q = ur[r] + 1; q < ur[r + 1]; ++q)
+          if (uc[q] == uc[q - 1]) {
+            dup = true;
+            break;
+          }
+      if (!dup) {
+        pv = M->vals;
+        continue;
+      }
+    }
     pv.assign((size_t)op->A.nnz, cplx(0));
     for (int64_t r = 0; r < nrows; ++r) {
       int64_t k = 0;
@@ -1207,6 +1233,10 @@ int qp_operator_create(qp_ctx* ctx, qp_matrix* const* ops, int nops, int ncoeffs
   if (fmt < 0) return qp::fail(QP_E_BAD_ARG, "QP_FMT_HRB requested but the operator terms are not exactly Hermitian");
   QP_CHECK(operator_build_device(op.get(), fmt, planes_csr));
   planes_csr.clear();
+  // the whole host side of the creation (union pattern, lattice completion, value planes, Hermitian check, format choice)
+  // belongs to what qp_operator_build_info reports for the first build
+  op->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create).count();
+  op->build_ms_total = op->build_ms;
   qp_operator* raw = op.release();
   std::vector<qp_c128> ones(ncoeffs, qp_c128{1.0, 0.0});
   int rc = qp_operator_set_coeffs(raw, ones.data(), ncoeffs);

@@ -396,27 +396,31 @@ using HostLayout = HostLayoutData;
 // outside the square part and always carry their values.
 static bool csr_is_hermitian(int64_t n, const std::vector<int64_t>& rp, const std::vector<int32_t>& col,
                              const std::vector<cplx>& vals) {
+  // Rows in ascending order, their lower entries (r, c), c < r, in ascending c: row c is asked for its upper entries
+  // (c, r) in ascending r, i.e. in storage order -- one cursor per row instead of a search per entry.  An upper entry
+  // without a partner stops its row's cursor and fails the next match (or the final count).
   int64_t nlower = 0, nupper = 0;
+  std::vector<int64_t> cur((size_t)std::max<int64_t>(n, 1), 0);
   for (int64_t r = 0; r < n; ++r) {
+    int64_t first_upper = rp[r + 1];
     for (int64_t p = rp[r]; p < rp[r + 1]; ++p) {
       const int64_t c = col[p];
       if (p > rp[r] && col[p - 1] >= c) return false;
       if (c == r) {
         if (vals[p].imag() != 0.0) return false;
-      } else if (c >= n) {
-        continue;
       } else if (c > r) {
-        ++nupper;
+        if (first_upper == rp[r + 1]) first_upper = p;
+        if (c < n) ++nupper;
       } else {
         ++nlower;
-        const int32_t* b = col.data() + rp[c];
-        const int32_t* e = col.data() + rp[c + 1];
-        const int32_t* it = std::lower_bound(b, e, (int32_t)r);
-        if (it == e || *it != r) return false;
-        const cplx t = vals[it - col.data()];
+        const int64_t q = cur[(size_t)c];
+        if (q >= rp[c + 1] || col[q] != r) return false;
+        const cplx t = vals[q];
         if (!(t.real() == vals[p].real() && t.imag() == -vals[p].imag())) return false;
+        cur[(size_t)c] = q + 1;
       }
     }
+    cur[(size_t)r] = first_upper;
   }
   return nlower == nupper;
 }

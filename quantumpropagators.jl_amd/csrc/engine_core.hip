@@ -4,9 +4,29 @@
 // device work is stream-ordered, with host synchronisation only where the reference
 // algorithm needs a scalar on the host (once per Newton restart, once per Arnoldi call).
 #include <mutex>
+#include <thread>
 #include <numeric>
 
 #include "engine.h"
+
+// rows [0, n) in contiguous chunks on a few host threads (index work whose iterations write disjoint positions)
+template <class F>
+static void parallel_rows(int64_t n, F&& fn) {
+  const unsigned hw = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+  if (n < (int64_t)1 << 16 || hw == 1) {
+    fn((int64_t)0, n);
+    return;
+  }
+  std::vector<std::thread> th;
+  const int64_t chunk = (n + hw - 1) / hw;
+  for (unsigned t = 0; t < hw; ++t) {
+    const int64_t a = (int64_t)t * chunk, b = std::min(n, a + chunk);
+    if (a >= b) break;
+    th.emplace_back([&fn, a, b] { fn(a, b); });
+  }
+  for (auto& x : th) x.join();
+}
+
 
 // ---------------------------------------------------------------------------
 // error plumbing
@@ -780,16 +800,18 @@ static int operator_build_device_impl(qp_operator* op, int format, const std::ve
       // lower section: (column, position of the conj-transposed value in the upper section)
       std::vector<int32_t> lpos((size_t)std::max<int64_t>(A.lstored, 1), -1);
       if (Lh.stored >= (int64_t)INT32_MAX) return qp::fail(QP_E_BAD_ARG, "Hermitian-packed format needs < 2^31 stored values per GPU");
-      for (int64_t r = 0; r < nrows; ++r) {
-        const int64_t nl = Lh.nlow[r];
-        for (int64_t k = 0; k < nl; ++k) {
-          const int64_t c = uc[ur[r] + k];
-          const int32_t* b = uc.data() + ur[c];
-          const int32_t* e = uc.data() + ur[c + 1];
-          const int64_t kk = (std::lower_bound(b, e, (int32_t)r) - b) - Lh.nlow[c];  // index of (c,r) among row c's upper entries
-          lpos[rb_quad_pos(Lh.lptr, r, k)] = (int32_t)rb_val_pos(Lh.bptr, c, kk);
+      parallel_rows(nrows, [&](int64_t r_begin, int64_t r_end) {
+        for (int64_t r = r_begin; r < r_end; ++r) {
+          const int64_t nl = Lh.nlow[r];
+          for (int64_t k = 0; k < nl; ++k) {
+            const int64_t c = uc[ur[r] + k];
+            const int32_t* b = uc.data() + ur[c];
+            const int32_t* e = uc.data() + ur[c + 1];
+            const int64_t kk = (std::lower_bound(b, e, (int32_t)r) - b) - Lh.nlow[c];  // index of (c,r) among row c's upper entries
+            lpos[rb_quad_pos(Lh.lptr, r, k)] = (int32_t)rb_val_pos(Lh.bptr, c, kk);
+          }
         }
-      }
+      });
       std::vector<char> lbytes;
       // stencil lower block: every row has a real entry in every slot, at a block-wide
       // distance delta_k, and the conj-transposed values sit at one slot per column block
@@ -869,13 +891,15 @@ static int operator_build_device_impl(qp_operator* op, int format, const std::ve
   for (int l = 0; l < nops; ++l) {
     std::fill(hplane.begin(), hplane.end(), cplx(0.0));
     const auto& pv = planes_csr[l];
-    for (int64_t r = 0; r < nrows; ++r) {
-      const int64_t nl = (format == QP_FMT_HRB) ? op->layout.nlow[r] : 0;
-      for (int64_t k = nl; k < ur[r + 1] - ur[r]; ++k) {
-        const int64_t pos = (format == QP_FMT_CSR) ? ur[r] + k : rb_val_pos(op->layout.bptr, r, k - nl);
-        hplane[pos] = pv[ur[r] + k];
+    parallel_rows(nrows, [&](int64_t r_begin, int64_t r_end) {
+      for (int64_t r = r_begin; r < r_end; ++r) {
+        const int64_t nl = (format == QP_FMT_HRB) ? op->layout.nlow[r] : 0;
+        for (int64_t k = nl; k < ur[r + 1] - ur[r]; ++k) {
+          const int64_t pos = (format == QP_FMT_CSR) ? ur[r] + k : rb_val_pos(op->layout.bptr, r, k - nl);
+          hplane[pos] = pv[ur[r] + k];
+        }
       }
-    }
+    });
     if (sparse_candidates && l >= drift_planes && l >= 1) {
       auto& t = touched[(size_t)l];
       const size_t limit = (size_t)(A.stored / 4);

@@ -58,17 +58,28 @@ function check(status::Cint)
     end
 end
 
-# opaque handle with a finalizer; `destroy` is the name of the C destructor.  The library lets handles
-# be destroyed in any order (a context's record outlives qp_ctx_destroy), so finalizers need no ordering.
+# One destructor per kind of handle.  `ccall` needs its `(name, library)` pair as a CONSTANT expression (a Symbol held in a
+# struct field and resolved at run time is rejected: "first argument not a pointer or valid constant expression"), so the
+# handle carries the destructor as a function value, not as a name.
+_ctx_destroy(p::Ptr{Cvoid}) = ccall((:qp_ctx_destroy, LIB), Cint, (Ptr{Cvoid},), p)
+_state_destroy(p::Ptr{Cvoid}) = ccall((:qp_state_destroy, LIB), Cint, (Ptr{Cvoid},), p)
+_matrix_destroy(p::Ptr{Cvoid}) = ccall((:qp_matrix_destroy, LIB), Cint, (Ptr{Cvoid},), p)
+_operator_destroy(p::Ptr{Cvoid}) = ccall((:qp_operator_destroy, LIB), Cint, (Ptr{Cvoid},), p)
+_cheby_destroy(p::Ptr{Cvoid}) = ccall((:qp_cheby_destroy, LIB), Cint, (Ptr{Cvoid},), p)
+_newton_destroy(p::Ptr{Cvoid}) = ccall((:qp_newton_destroy, LIB), Cint, (Ptr{Cvoid},), p)
+
+# opaque handle with a finalizer; `destroy` is one of the destructors above.  The library lets handles be destroyed in
+# any order (a context's record outlives qp_ctx_destroy), so finalizers need no ordering; a destructor neither yields nor
+# allocates on the Julia side, as a finalizer must not.
 mutable struct Handle
     ptr::Ptr{Cvoid}
-    destroy::Symbol
+    destroy::Function
     keep::Any                      # objects that must outlive the handle (e.g. the context)
-    function Handle(ptr::Ptr{Cvoid}, destroy::Symbol, keep = nothing)
+    function Handle(ptr::Ptr{Cvoid}, destroy::Function, keep = nothing)
         h = new(ptr, destroy, keep)
         finalizer(h) do x
             if x.ptr != C_NULL
-                ccall((x.destroy, LIB), Cint, (Ptr{Cvoid},), x.ptr)
+                x.destroy(x.ptr)
                 x.ptr = C_NULL
             end
         end
@@ -80,7 +91,7 @@ Base.unsafe_convert(::Type{Ptr{Cvoid}}, h::Handle) = h.ptr
 function make_ctx(device::Integer = 0)
     out = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:qp_ctx_create, LIB), Cint, (Cint, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), device, C_NULL, out))
-    return Handle(out[], :qp_ctx_destroy)
+    return Handle(out[], _ctx_destroy)
 end
 
 # one context per device and task tree, created on first use (contexts are cheap: a stream and two events)
@@ -114,7 +125,7 @@ end
 function HIPState(::UndefInitializer, n::Integer; device::Integer = 0, ctx::Handle = default_ctx(device))
     out = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:qp_state_create, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Ptr{Cvoid}}), ctx, n, out))
-    return HIPState(Handle(out[], :qp_state_destroy, ctx), ctx, Int(n))
+    return HIPState(Handle(out[], _state_destroy, ctx), ctx, Int(n))
 end
 function HIPState(Ψ::AbstractVector; device::Integer = 0, ctx::Handle = default_ctx(device))
     s = HIPState(undef, length(Ψ); ctx)
@@ -199,7 +210,7 @@ function make_matrix(ctx::Handle, A::AbstractMatrix)
         1,   # index_base
         0,   # QP_FMT_AUTO
         out))
-    return Handle(out[], :qp_matrix_destroy, ctx)
+    return Handle(out[], _matrix_destroy, ctx)
 end
 
 # Generators.Operator on the device: lazy sum Σ c_l H_l, the first `length(ops) - ncoeffs` ops are drift
@@ -211,7 +222,7 @@ function make_operator(ctx::Handle, ops::AbstractVector, ncoeffs::Integer)
     GC.@preserve mats ptrs check(ccall((:qp_operator_create, LIB), Cint,
         (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Cint, Cint, Cint, Ptr{Ptr{Cvoid}}),
         ctx, ptrs, length(ptrs), ncoeffs, 0, out))
-    return Handle(out[], :qp_operator_destroy, ctx)     # the library copied the matrices: `mats` may go
+    return Handle(out[], _operator_destroy, ctx)     # the library copied the matrices: `mats` may go
 end
 
 # evaluate!(op::Operator, generator, tlist, n; vals_dict)   src/generators.jl:757-766
@@ -435,7 +446,7 @@ function init_prop(state, generator, tlist, ::Val{:ChebyHIP};
     Ψ, dstate = _state_pair(ctx, state, inplace)
     wrk_out = Ref{Ptr{Cvoid}}(C_NULL)              # ChebyWrk, src/cheby.jl:87-124
     check(ccall((:qp_cheby_create, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Ptr{Cvoid}}), ctx, N, wrk_out))
-    wrk = Handle(wrk_out[], :qp_cheby_destroy, ctx)
+    wrk = Handle(wrk_out[], _cheby_destroy, ctx)
     n = 1
     t = tlist[1]
     if backward
@@ -594,7 +605,7 @@ function init_prop(state, generator, tlist, ::Val{:NewtonHIP};
     Ψ, dstate = _state_pair(ctx, state, true)
     wrk_out = Ref{Ptr{Cvoid}}(C_NULL)                                            # NewtonWrk, src/newton.jl:23-60
     check(ccall((:qp_newton_create, LIB), Cint, (Ptr{Cvoid}, Int64, Cint, Ptr{Ptr{Cvoid}}), ctx, length(Ψ), m_max, wrk_out))
-    wrk = Handle(wrk_out[], :qp_newton_destroy, ctx)
+    wrk = Handle(wrk_out[], _newton_destroy, ctx)
     n = 1
     t = tlist[1]
     if backward

@@ -1,9 +1,13 @@
 """The Julia glue (julia/QuantumPropagatorsHIPExt.jl) cannot be executed here (no Julia in the image), so
 its binding to the C ABI is checked mechanically instead: every `ccall((:qp_..., LIB), Ret, (types...), ...)`
 is parsed and compared -- name, return type, arity and every argument type -- with the prototype in
-include/qprop.h; the Julia mirror of `qp_newton_stats` is compared field by field; every destructor named
-in a `Handle(...)` exists; and the excerpt shown in INTEGRATION.md is regenerated from the file, so the
-two cannot drift."""
+include/qprop.h (a `ccall` whose target is not a LITERAL `(:qp_name, LIB)` pair fails the test: Julia rejects a symbol
+resolved at run time); the Julia mirror of `qp_newton_stats` is compared field by field; every destructor handed to a
+`Handle(...)` is a one-line `ccall` of an existing destructor; every helper the glue imports from QuantumPropagators
+exists in the reference with the arity and keywords used (tests/golden/reference_api.json, extracted from the reference's
+sources by tests/golden/make_reference_api.py); the propagator structs carry the fields the reference's helpers and
+`check_propagator` touch; and the excerpt shown in INTEGRATION.md is regenerated from the file, so the two cannot drift."""
+import json
 import os
 import re
 
@@ -118,7 +122,7 @@ def _split_top(s):
 
 
 def parse_ccalls():
-    """[(name or None for a dynamic symbol, ret, [arg types], n actual args, line)] for every ccall in the glue."""
+    """[(name, ret, [arg types], n actual args, line)] for every ccall in the glue."""
     txt = open(JL).read()
     txt_nc = "\n".join(re.sub(r"#.*$", "", ln) for ln in txt.splitlines())
     calls = []
@@ -131,19 +135,22 @@ def parse_ccalls():
             depth -= ch == ")"
             j += 1
         parts = _split_top(txt_nc[i:j - 1])
-        sym = re.match(r"\(\s*(:?[A-Za-z_.0-9]+)\s*,\s*LIB\s*\)", parts[0])
-        assert sym, f"ccall target not of the form (:name, LIB): {parts[0]!r}"
-        name = sym.group(1)[1:] if sym.group(1).startswith(":") else None
+        line = txt_nc[:m.start()].count("\n") + 1
+        # `ccall` wants its (name, library) pair as a constant expression: a literal Symbol and the constant LIB.  A field,
+        # a variable or a call in the first position compiles to "first argument not a pointer or valid constant expression"
+        sym = re.fullmatch(r"\(\s*:(qp_[a-z_0-9]+)\s*,\s*LIB\s*\)", parts[0])
+        assert sym, f"julia:{line}: ccall target is not a literal (:qp_name, LIB) pair: {parts[0]!r}"
+        name = sym.group(1)
         ret = parts[1]
         atypes = [t for t in _split_top(parts[2].strip()[1:-1]) if t]
-        calls.append((name, ret, atypes, len(parts) - 3, txt_nc[:m.start()].count("\n") + 1))
+        calls.append((name, ret, atypes, len(parts) - 3, line))
     return calls
 
 
 def test_every_ccall_matches_the_header():
     protos, _ = parse_header()
     calls = parse_ccalls()
-    named = [c for c in calls if c[0] is not None]
+    named = calls
     assert len(named) >= 20, "the glue binds the whole step path"
     seen = set()
     for name, ret, atypes, nargs, line in named:
@@ -166,14 +173,144 @@ def test_every_ccall_matches_the_header():
 def test_destructors_named_in_handles_exist():
     protos, _ = parse_header()
     txt = open(JL).read()
-    names = set(re.findall(r"Handle\([^)]*?:(qp_[a-z_]+_destroy)", txt))
-    assert {"qp_ctx_destroy", "qp_matrix_destroy", "qp_operator_destroy", "qp_state_destroy", "qp_cheby_destroy",
-            "qp_newton_destroy"} <= names
-    for n in names:
+    # the handle stores a FUNCTION (one literal ccall per destructor), never a Symbol to be resolved at run time
+    assert re.search(r"mutable struct Handle\n\s*ptr::Ptr\{Cvoid\}\n\s*destroy::Function\n", txt)
+    assert not re.search(r"destroy::Symbol", txt)
+    defs = dict(re.findall(r"^(_[a-z]+_destroy)\(p::Ptr\{Cvoid\}\) = ccall\(\(:(qp_[a-z_]+_destroy), LIB\), Cint, \(Ptr\{Cvoid\},\), p\)$",
+                           txt, flags=re.M))
+    used = set(re.findall(r"Handle\([^()]*?\b(_[a-z]+_destroy)\b", txt))
+    assert used == set(defs), (used, set(defs))
+    assert set(defs.values()) == {"qp_ctx_destroy", "qp_matrix_destroy", "qp_operator_destroy", "qp_state_destroy", "qp_cheby_destroy",
+                                  "qp_newton_destroy"}
+    for n in defs.values():
         assert n in protos and protos[n][0] == "int" and protos[n][1] == ["ptr:void"], n
-    # the dynamic-symbol ccall of the finalizer has the destructor's shape
-    dyn = [c for c in parse_ccalls() if c[0] is None]
-    assert len(dyn) == 1 and jl_class(dyn[0][1]) == "int" and [jl_class(t) for t in dyn[0][2]] == ["ptr:void"]
+    # every Handle(...) construction passes one of them (no Symbol literal left over)
+    for m in re.finditer(r"\bHandle\(([^()]*(?:\([^()]*\))?[^()]*)\)", txt):
+        args = _split_top(m.group(1))
+        if len(args) >= 2 and not args[0].startswith("ptr::"):
+            assert args[1] in defs, f"Handle(...) with destructor {args[1]!r}"
+
+
+# ---- the reference side of the glue: imported helpers, struct fields, the propagator contract ---------------------
+API = os.path.join(ROOT, "tests", "golden", "reference_api.json")
+REFERENCE = "/root/reference"
+
+
+def _glue_code():
+    return "\n".join(re.sub(r"#.*$", "", ln) for ln in open(JL).read().splitlines())
+
+
+def _calls_of(name, txt):
+    """[(n positional, [keyword names], line)] for every CALL of `name` in the glue (definitions excluded)."""
+    out = []
+    for m in re.finditer(r"(?<![A-Za-z_0-9!.])" + re.escape(name) + r"\(", txt):
+        line_start = txt.rfind("\n", 0, m.start()) + 1
+        head = txt[line_start:m.start()]
+        i = m.end() - 1
+        depth, j = 0, i
+        while True:
+            depth += txt[j] in "([{"
+            depth -= txt[j] in ")]}"
+            j += 1
+            if depth == 0:
+                break
+        after = txt[j:j + 40]
+        if head.strip() in ("function", "") and (head.strip() == "function" or re.match(r"\s*=(?!=)", after)):
+            continue                                   # a method definition of the glue itself
+        inner = txt[i + 1:j - 1]
+        semi = [k for k, ch in enumerate(inner) if ch == ";" and inner[:k].count("(") == inner[:k].count(")")]
+        pos_txt, kw_txt = (inner[:semi[0]], inner[semi[0] + 1:]) if semi else (inner, "")
+        pos = [a for a in _split_top(pos_txt) if a]
+        kws = [re.split(r"[=\s]", k, maxsplit=1)[0] for k in _split_top(kw_txt) if k and not k.endswith("...")]
+        # `f(a; kw = v)` may also be written `f(a, kw = v)`
+        kws += [re.split(r"[=\s]", a, maxsplit=1)[0] for a in pos if re.match(r"[A-Za-z_]\w*\s*=(?!=)", a)]
+        pos = [a for a in pos if not re.match(r"[A-Za-z_]\w*\s*=(?!=)", a)]
+        splat = any(a.endswith("...") for a in pos)
+        out.append((None if splat else len(pos), kws, txt[:m.start()].count("\n") + 1))
+    return out
+
+
+def test_reference_api_fixture_is_current():
+    """tests/golden/reference_api.json is what make_reference_api.py extracts from the reference (checked where the
+    reference is present: this container; the GPU box only has the committed file)."""
+    import pytest
+    if not os.path.isdir(os.path.join(REFERENCE, "src")):
+        pytest.skip("the reference sources are not on this machine")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_reference_api", os.path.join(ROOT, "tests", "golden", "make_reference_api.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert json.loads(json.dumps(mod.scan(REFERENCE), sort_keys=True)) == json.load(open(API))
+
+
+def test_helpers_imported_from_the_reference_exist_with_the_arity_used():
+    api = json.load(open(API))["functions"]
+    txt = _glue_code()
+    imported = set()
+    for m in re.finditer(r"^(?:using|import) QuantumPropagators(?:\.[A-Za-z]+)?:\s*((?:[^\n]|\n[ \t]+\S)*)", txt, flags=re.M):
+        imported |= {t.strip() for t in m.group(1).replace("\n", " ").split(",") if t.strip()}
+    helpers = {n for n in imported if n[0] == "_" or n[0].islower()}
+    assert {"_pwc_process_parameters", "_pwc_advance_time!", "_pwc_set_t!", "_get_uniform_dt", "get_controls", "discretize",
+            "evaluate", "hamiltonian", "init_prop", "prop_step!", "reinit_prop!", "set_state!", "set_t!"} <= helpers
+    for name in sorted(helpers):
+        assert api.get(name), f"{name} is imported by the glue but the reference defines no such function"
+        for npos, kws, line in _calls_of(name, txt):
+            ok = False
+            for sig in api[name]:
+                arity = npos is None or (sig["min_positional"] <= npos and (sig["max_positional"] is None or npos <= sig["max_positional"]))
+                kw = all(k in sig["keywords"] or sig["keyword_rest"] for k in kws)
+                ok = ok or (arity and kw)
+            assert ok, f"julia:{line}: {name} called with {npos} positional arguments and keywords {kws}: no such method in the reference " \
+                       f"({[(s['at'], s['min_positional'], s['max_positional'], s['keywords']) for s in api[name]][:4]})"
+    # the fully qualified extension of Interfaces.supports_inplace
+    assert re.search(r"QuantumPropagators\.Interfaces\.supports_inplace\(::Type\{HIPState\}\) = true", txt)
+    assert any(s["min_positional"] == 1 for s in api["supports_inplace"])
+
+
+def test_method_extensions_have_the_reference_generic_shape():
+    api = json.load(open(API))["functions"]
+    txt = _glue_code()
+    # init_prop(state, generator, tlist, ::Val{:X}; kwargs..., _...) -- four positional arguments, trailing keyword rest so that
+    # propagate() may pass keywords of other layers through (src/cheby_propagator.jl:87-104)
+    inits = re.findall(r"^function init_prop\(([^;]*);((?:.|\n)*?)\)\n", txt, flags=re.M)
+    assert len(inits) == 2
+    ref = [s for s in api["init_prop"] if s["at"].startswith("src/cheby_propagator.jl")][0]
+    for pos, kw in inits:
+        assert len(_split_top(pos)) == 4 == ref["min_positional"]
+        assert _split_top(kw)[-1].endswith("..."), "init_prop must swallow unknown keywords"
+    cheby_kw = {re.split(r"[=\s]", k, maxsplit=1)[0] for k in _split_top(inits[0][1]) if not k.endswith("...")}
+    assert set(ref["keywords"]) <= cheby_kw, set(ref["keywords"]) - cheby_kw
+    newton_ref = [s for s in api["init_prop"] if s["at"].startswith("src/newton_propagator.jl")][0]
+    newton_kw = {re.split(r"[=\s]", k, maxsplit=1)[0] for k in _split_top(inits[1][1]) if not k.endswith("...")}
+    assert set(newton_ref["keywords"]) <= newton_kw, set(newton_ref["keywords"]) - newton_kw
+    for name, npos in (("prop_step!", 1), ("set_state!", 2), ("set_t!", 2), ("reinit_prop!", 2)):
+        defs = re.findall(r"^(?:function )?" + re.escape(name) + r"\(([^;)]*)", txt, flags=re.M)
+        assert defs, name
+        for d in defs:
+            assert len(_split_top(d)) == npos, (name, d)
+            assert any(s["min_positional"] == npos for s in api[name])
+
+
+def test_propagator_structs_carry_the_fields_the_reference_touches():
+    api = json.load(open(API))
+    txt = _glue_code()
+    need = set(api["public_properties"]["names"])                               # src/propagator.jl:119-126 (check_propagator reads them)
+    for fn in ("_pwc_set_t!", "_pwc_advance_time!"):                            # the helpers the glue calls
+        need |= set(api["pwc_helper_fields"]["by_function"][fn])
+    need |= {"generator", "controls", "n"}                                      # PWC conventions, src/pwc_utils.jl:5-24
+    for struct in ("ChebyHIPPropagator", "NewtonHIPPropagator"):
+        m = re.search(r"mutable struct " + struct + r"\{GT\} <: PWCPropagator\n((?:.|\n)*?)\nend", txt)
+        assert m, struct
+        fields = {re.split(r"::|\s", ln.strip().removeprefix("const ").strip(), maxsplit=1)[0] for ln in m.group(1).split("\n") if ln.strip()}
+        assert need <= fields, (struct, need - fields)
+    assert api["abstract_types"]["PWCPropagator"]["decl"] == "abstract type PWCPropagator <: PiecewisePropagator end"
+    # Generator / Operator fields the glue reads
+    for s, fields in (("Generator", ("ops", "amplitudes")), ("Operator", ("ops", "coeffs"))):
+        assert set(fields) <= set(api["structs"][s]["fields"])
+    for f in re.findall(r"\bG\.(\w+)\.\.\.", txt):
+        assert f in api["structs"]["Generator"]["fields"]
+    for f in re.findall(r"\bO\.(\w+)\.\.\.", txt):
+        assert f in api["structs"]["Operator"]["fields"]
 
 
 def test_newton_stats_mirror_matches_field_by_field():
@@ -218,7 +355,7 @@ def excerpt():
         i = re.search(start_pat, txt).start()
         j = txt.index(end_pat, i) + len(end_pat)
         return txt[i:j]
-    parts = [block(r"mutable struct Handle\n"), block(r"mutable struct HIPState <: AbstractVector"),
+    parts = [block(r"# One destructor per kind of handle", "        return h\n    end\nend\n"), block(r"mutable struct HIPState <: AbstractVector"),
              block(r"function LinearAlgebra\.axpy!\(a::Number, x::HIPState"),
              block(r"# What the reference accepts as a generator", "lazy_sum(G) = throw"),
              block(r"# prop_step!\(::ChebyPropagator\)"), block(r"function prop_step!\(p::NewtonHIPPropagator\)")]

@@ -56,30 +56,63 @@ def scattered_offsets(N, n_offsets=8, seed=DEFAULT_SEED):
     return tuple(sorted(out))
 
 
-def hermitian_offsets_csr(N, offsets=BANDED_OFFSETS, rho=10.0, seed=DEFAULT_SEED,
-                          row_begin=0, row_end=None):
-    """Hermitian H with exactly 2*len(offsets) nnz per row, no diagonal:
-    H[i,(i+d_k)%N] = g(seed,i,k);  H[(i+d_k)%N, i] = conj(.).  Gershgorin:
-    spectrum in [-rho, rho].  Returns 0-based CSR (rowptr int64, col int32,
-    vals complex128) for rows [row_begin, row_end), columns ascending."""
-    row_end = N if row_end is None else row_end
+def _offsets_rows(N, offsets, rho, seed, a, b, col_out, val_out):
+    """Rows [a, b) of hermitian_offsets_csr into col_out / val_out (views of (b - a) x 2 nk)."""
     nk = len(offsets)
-    assert 2 * max(offsets) < N, "offsets must be < N/2 so that columns are distinct"
-    rows = np.arange(row_begin, row_end, dtype=np.int64)
-    nloc = len(rows)
-    cols = np.empty((nloc, 2 * nk), dtype=np.int64)
-    vals = np.empty((nloc, 2 * nk), dtype=np.complex128)
+    rows = np.arange(a, b, dtype=np.int64)
+    cols = np.empty((b - a, 2 * nk), dtype=np.int64)
+    vals = np.empty((b - a, 2 * nk), dtype=np.complex128)
     for k, d in enumerate(offsets):
         cols[:, 2 * k] = (rows + d) % N
         vals[:, 2 * k] = coupling(seed, rows, k, rho, nk)
         src = (rows - d) % N
         cols[:, 2 * k + 1] = src
         vals[:, 2 * k + 1] = np.conj(coupling(seed, src, k, rho, nk))
-    order = np.argsort(cols, axis=1, kind="stable")
-    cols = np.take_along_axis(cols, order, axis=1)
-    vals = np.take_along_axis(vals, order, axis=1)
+    # columns ascending within a row.  Away from the periodic wrap every row has the SAME order (i - d_max ... i + d_max):
+    # sort one row and apply its permutation to the chunk; rows whose columns wrap are sorted one by one
+    dmax = max(offsets)
+    lo, hi = max(a, dmax), min(b, N - dmax)          # rows [lo, hi) do not wrap
+    if lo < hi:
+        perm = np.argsort(cols[lo - a], kind="stable")
+        col_out[lo - a:hi - a] = cols[lo - a:hi - a][:, perm]
+        val_out[lo - a:hi - a] = vals[lo - a:hi - a][:, perm]
+    for s, e in ((a, min(lo, b)), (max(hi, a), b)) if lo < hi else ((a, b),):
+        if s < e:
+            order = np.argsort(cols[s - a:e - a], axis=1, kind="stable")
+            col_out[s - a:e - a] = np.take_along_axis(cols[s - a:e - a], order, axis=1)
+            val_out[s - a:e - a] = np.take_along_axis(vals[s - a:e - a], order, axis=1)
+
+
+def hermitian_offsets_csr(N, offsets=BANDED_OFFSETS, rho=10.0, seed=DEFAULT_SEED,
+                          row_begin=0, row_end=None):
+    """Hermitian H with exactly 2*len(offsets) nnz per row, no diagonal:
+    H[i,(i+d_k)%N] = g(seed,i,k);  H[(i+d_k)%N, i] = conj(.).  Gershgorin:
+    spectrum in [-rho, rho].  Returns 0-based CSR (rowptr int64, col int32,
+    vals complex128) for rows [row_begin, row_end), columns ascending.  Generated in row chunks on a thread pool (NumPy
+    releases the GIL inside its loops): N = 2^24 takes seconds, not minutes, and no more scratch than the chunks."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    row_end = N if row_end is None else row_end
+    nk = len(offsets)
+    assert 2 * max(offsets) < N, "offsets must be < N/2 so that columns are distinct"
+    nloc = row_end - row_begin
+    col = np.empty((nloc, 2 * nk), dtype=np.int32)
+    vals = np.empty((nloc, 2 * nk), dtype=np.complex128)
+    chunk = 1 << 16
+    jobs = [(a, min(a + chunk, row_end)) for a in range(row_begin, row_end, chunk)]
+
+    def run(ab):
+        a, b = ab
+        _offsets_rows(N, offsets, rho, seed, a, b, col[a - row_begin:b - row_begin], vals[a - row_begin:b - row_begin])
+    nthreads = max(1, min(len(jobs), len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16))
+    if nthreads > 1:
+        with ThreadPoolExecutor(nthreads) as ex:
+            list(ex.map(run, jobs))
+    else:
+        for ab in jobs:
+            run(ab)
     rowptr = np.arange(0, (nloc + 1) * 2 * nk, 2 * nk, dtype=np.int64)
-    return rowptr, cols.reshape(-1).astype(np.int32), vals.reshape(-1)
+    return rowptr, col.reshape(-1), vals.reshape(-1)
 
 
 def grid_hamiltonian_2d(nx, ny, flux=0.0, next_nearest=False, seed=DEFAULT_SEED):

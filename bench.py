@@ -47,13 +47,16 @@ KERNEL_OF_FORMAT = {1: "csr_spmv_kernel", 2: "rbcsr_spmv_kernel", 3: "hrb_spmv_k
 STATIC_PMC = os.path.join("profiles", "r03", "bench_pmc_summary.json")
 
 
-def pmc_traffic(argv_inner, kernel_substr, timeout_s):
-    """HBM bytes per launch of the dominant kernel, measured now: this script re-run as a CHILD process
-    under rocprofv3, one pass per counter (the guide's HBM / rocprofv3 recipe: FETCH_SIZE x 2 on gfx950,
-    WRITE_SIZE as is, units KiB).  Returns (bytes, detail) or (None, reason)."""
+def pmc_traffic(argv_inner, kernel_substr, timeout_s, how="mean"):
+    """HBM bytes of the named kernel(s), measured now: this script re-run as a CHILD process under rocprofv3, one pass per
+    counter (the guide's HBM / rocprofv3 recipe: FETCH_SIZE x 2 on gfx950, WRITE_SIZE as is, units KiB).  `kernel_substr`: one
+    substring or a tuple of them; how = "mean": bytes per launch (mean over the matching dispatches), "sum": bytes of ALL
+    matching dispatches of the child run (the caller divides by the steps the child ran).  Returns (bytes, detail) or
+    (None, reason)."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
+    subs = (kernel_substr,) if isinstance(kernel_substr, str) else tuple(kernel_substr)
     env = dict(os.environ, TMPDIR="/tmp")
     vals = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -81,15 +84,30 @@ def pmc_traffic(argv_inner, kernel_substr, timeout_s):
         for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
             with open(f) as fh:
                 for row in csv.DictReader(fh):
-                    if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                    if row["Counter_Name"] == counter and any(s in row["Kernel_Name"] for s in subs):
                         got.append(float(row["Counter_Value"]))
         shutil.rmtree(out, ignore_errors=True)
         if r.returncode != 0 or not got:
-            return None, f"{counter} pass: rc {r.returncode}, {len(got)} dispatches of {kernel_substr}"
-        vals[counter] = (sum(got) / len(got) * 1024.0, len(got))
+            return None, f"{counter} pass: rc {r.returncode}, {len(got)} dispatches of {'/'.join(subs)}"
+        vals[counter] = ((sum(got) if how == "sum" else sum(got) / len(got)) * 1024.0, len(got))
     fetch, write = 2.0 * vals["FETCH_SIZE"][0], vals["WRITE_SIZE"][0]
     return fetch + write, {"FETCH_SIZE_bytes_x2": fetch, "WRITE_SIZE_bytes": write,
                            "dispatches": [vals["FETCH_SIZE"][1], vals["WRITE_SIZE"][1]]}
+
+
+# kernels of one newton! step (csrc/kernels_arnoldi.hip, kernels.hip): what a C3 child run's traffic is summed over
+NEWTON_KERNELS = ("arnoldi_matvec_dots_kernel", "mgs_update_kernel", "multidot_kernel", "multidot_reduce_kernel", "combine2_vecs_kernel",
+                  "combine_vecs_kernel", "norm_guard_scale_kernel", "rbcsr_spmv_kernel", "csr_spmv_kernel", "mgs_pass_kernel")
+
+
+def run_point(args, L, bp):
+    """`--point c3|c5` (used by the PMC child runs of the extras): that one measurement, nothing else, a short JSON line."""
+    ctx = L.Context(0)
+    if args.point == "c3":
+        r = bp.measure_newton_c3(ctx, steps=args.steps, warmup=args.steps, repeats=1)      # 2 x steps identical newton! steps from rho_0
+    else:
+        r = bp.measure_batched_c5(ctx, batch=args.batch, steps=args.steps, warmup=1, repeats=1)
+    print(json.dumps({"point": args.point, "steps": args.steps, "ms": r.get("ms_per_step", r.get("ms_per_panel_step"))}))
 
 
 XGMI_LINK_GBS = 153.0      # per direction and link (MI355X_MICROARCH.md: 7 links x ~153 GB/s per GPU, point to point)
@@ -121,6 +139,74 @@ def exchange_model(sh, world, rows, us_per_term):
             "predicted_exposed_us_per_term_overlap_schedule": max(0.0, predicted - 0.9 * us_per_term),
             "note": "prediction from the partition (no measurement): serial schedule = exchange in line after every term; overlap "
                     "schedule = exchange behind the interior launch, exposed only where it is longer than that launch"}
+
+
+MACHINERY_FACTOR = 74.7 / 68.8      # overlapped native step / plain term at 2^21 rows on one GPU (profiles/r03/sharded_machinery_1gpu.txt)
+STATIC_SIZES = os.path.join("profiles", "r04", "single_gpu_sizes.json")
+
+
+def scaling_prediction(us_per_term_by_log2rows, value_1gpu, nterms, source):
+    """What 1 / 2 / 4 / 8 GPUs of one xGMI node should deliver, from per-term times measured on ONE GPU at the row counts a rank
+    would own plus the exchange model -- so that the first real multi-GPU run is read against a table, not a guess.
+
+    FIXED problem (N = 2^24, ">= 6x at 8 GPUs vs 1"): G ranks own 2^24 / G rows each.
+      halo form (banded H: each rank sends its 2 x 4096 edge rows to its two neighbours, ncclSend/ncclRecv): 10 us start-up +
+        131 KB / 153 GB/s; overlapped schedule = machinery factor x compute (the exchange hides behind the interior launch while
+        it is shorter than 0.9 of it), serial schedule = compute + exchange;
+      all-gather form (the collective north_star names; what a scattered H needs): every rank receives the other G - 1 slices,
+        16 N / G bytes over each of G - 1 links in parallel; every row reads remote data, so nothing hides it: compute + exchange
+        (compute priced with the banded operator's time: an upper bound on what a scattered operator reaches).
+    WEAK default of `bench.py --gpus G` (2^21 rows per GPU): value in 2^20-row blocks per second against this run's 1-GPU value
+    (N = 2^20, Infinity-Cache resident) -- the efficiency the driver will compute."""
+    t = {int(k): float(v) for k, v in us_per_term_by_log2rows.items()}
+    startup, link = 10.0, XGMI_LINK_GBS * 1e3      # us, bytes per us
+    fixed = []
+    for G in (1, 2, 4, 8):
+        lg = 24 - G.bit_length() + 1
+        tc = t.get(lg)
+        if tc is None:
+            continue
+        row = {"gpus": G, "rows_per_gpu": 1 << lg, "us_per_term_compute": tc}
+        if G == 1:
+            row.update(us_per_term_halo_overlap=tc, us_per_term_halo_serial=tc, us_per_term_allgather=tc, exchange_us_halo=0.0,
+                       exchange_us_allgather=0.0)
+        else:
+            xh = startup + 16.0 * 2 * 4096 / link
+            xa = startup + 16.0 * (1 << lg) / link
+            row.update(exchange_us_halo=xh, exchange_us_allgather=xa,
+                       us_per_term_halo_overlap=MACHINERY_FACTOR * tc + max(0.0, xh - 0.9 * tc),
+                       us_per_term_halo_serial=tc + xh, us_per_term_allgather=tc + xa)
+        fixed.append(row)
+    if fixed and fixed[0]["gpus"] == 1:
+        t1 = fixed[0]["us_per_term_compute"]
+        for row in fixed:
+            for k in ("halo_overlap", "halo_serial", "allgather"):
+                row["speedup_" + k] = t1 / row["us_per_term_" + k]
+                row["prop_steps_per_s_" + k] = 1e6 / (nterms * row["us_per_term_" + k])
+    weak = []
+    if t.get(21):
+        for G in (1, 2, 4, 8):
+            per = MACHINERY_FACTOR * t[21] if G > 1 else t[21]
+            v = G * 2.0 * 1e6 / (nterms * per)
+            weak.append({"gpus": G, "rows_per_gpu": 1 << 21, "predicted_value_blocks_per_s": v,
+                         "predicted_efficiency_vs_1gpu_value": (v / (G * value_1gpu)) if value_1gpu else None})
+    return {"source_of_compute_times": source, "us_per_term_by_log2_rows": t, "terms_per_step": nterms,
+            "assumptions": {"xgmi_link_gbs": XGMI_LINK_GBS, "exchange_startup_us": startup, "overlap_machinery_factor": MACHINERY_FACTOR,
+                            "halo_rows_per_neighbour": 8192},
+            "fixed_problem_N_2^24": fixed, "bench_default_weak_2^21_rows_per_gpu": weak,
+            "reading": "halo form: >= 6x at 8 GPUs needs only the per-GPU kernel at 2^21 rows; all-gather form: link-bound "
+                       "(32 MiB per link and term at 8 GPUs), it cannot reach 6x on 153 GB/s links"}
+
+
+def scaling_prediction_static(nterms):
+    """The same table in a multi-GPU line, from the committed single-GPU measurements (this run cannot measure them)."""
+    path = os.path.join(ROOT, STATIC_SIZES)
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        d = json.load(f)
+    return scaling_prediction(d["us_per_term_by_log2_rows"], d.get("value_1gpu"), nterms,
+                              f"STATIC: {STATIC_SIZES} (single-GPU run of bench.py on another box)")
 
 
 def run_c5(args, world, rank, local_rank, one_gpu, dist, L, synth, bp):
@@ -225,6 +311,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="headline only: no extra points (formats, patterns, C3, C5)")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling point")
     ap.add_argument("--no-safe", action="store_true", help="N > 1: skip the conservative first measurement and the watchdog")
+    ap.add_argument("--point", default=None, choices=["c3", "c5"], help=argparse.SUPPRESS)      # one extras point only (PMC child runs)
     ap.add_argument("--watchdog", type=float, default=float(os.environ.get("QP_BENCH_WATCHDOG", "420")),
                     help="N > 1: seconds the native / overlapped path (set-up, self-check, trial, measurement, strong point) may take")
     args = ap.parse_args()
@@ -255,11 +342,20 @@ def main():
     import qprop_amd.synth as synth
     import bench_points as bp
 
+    if args.point:
+        run_point(args, L, bp)
+        return
     if args.config == "c5":
         run_c5(args, world, rank, local_rank, one_gpu, dist, L, synth, bp)
         return
     config = args.config if args.config != "auto" else ("c2" if world == 1 else "c4")
-    log2n = args.log2n if args.log2n is not None else (20 if config == "c2" else 21)
+    # c4 on ONE GPU (or --scaling strong) is the FIXED problem of BASELINE.md section 2: N = 2^24 in total -- the denominator
+    # of ">= 6x at 8 GPUs vs 1"; with more ranks and weak scaling it is 2^21 rows per GPU (N = 2^24 at 8)
+    if config == "c4" and (world == 1 or args.scaling == "strong"):
+        default_log2n = 24
+    else:
+        default_log2n = 20 if config == "c2" else 21
+    log2n = args.log2n if args.log2n is not None else default_log2n
     if args.scaling == "strong":
         if (1 << log2n) % world:
             raise SystemExit("--scaling strong needs a rank count that divides 2^log2n")
@@ -484,6 +580,7 @@ def main():
                           "RCCL exchange of psi after each mat-vec"}[config]
         if args.log2n is not None or args.scaling == "strong":
             workload += f" [size overridden: 2^{log2n} rows {'in total (strong scaling)' if args.scaling == 'strong' else 'per GPU'}]"
+        seg = laps.get("us") or []
         out = {
             "metric": "Cheby prop_step!/s at N=2^20 CSR fp64 (2^20-row blocks advanced per second)",
             "value": steps_per_s * blocks_per_step,
@@ -495,43 +592,52 @@ def main():
             "config": {"workload": workload + (", real fp64 values (f64 variant)" if args.real else ", complex fp64 values") + ", int32 indices",
                        "rows_per_gpu": rows, "N_total": N, "blocks_of_2^20_rows_per_step": blocks_per_step,
                        "nnz_per_row": nnz_local / rows, "pattern": args.pattern,
-                       "n_coeffs": int(len(coeffs)), "matvecs_per_step": nterms,
-                       "spectral_range": [-10.0, 10.0], "dt": dt,
+                       "n_coeffs": int(len(coeffs)), "matvecs_per_step": nterms, "dt": dt,
                        "device_format": bp.FMT_NAME[fmt_used],
-                       "operator_build": build_ms,
-                       "device_layout": layout,
+                       "operator_build_ms": (build_ms or {}).get("build_ms"),
                        "parallelism": "single GPU" if world == 1 else (
                            f"row-partitioned x{world}, exchange={exchange_used}, schedule={schedule_note}, driver={driver_note}"
                            + (" [TEST MODE: ranks share one GPU, host-staged gloo]" if one_gpu else "")),
-                       "global_steps_per_s": steps_per_s},
+                       "global_steps_per_s": steps_per_s,
+                       "spectral_range": [-10.0, 10.0],
+                       "operator_build": build_ms,
+                       "device_layout": layout},
+            # the scalars a gate reads come first (the driver's record keeps the leading scalar keys of this object); dicts and the
+            # explanatory note come last.  hbm_resident_* / fixed_problem_* are filled from the extras below (single GPU, headline)
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": traffic_src, "traffic_detail": traffic_detail,
                          "kernel": kern,
-                         "layout_bytes_per_launch": model["per_term"],
-                         "layout_bytes_matrix": model["matrix_per_term"], "layout_bytes_vectors": model["vectors_per_term"],
                          "avg_launch_us": avg_launch_s * 1e6,
-                         "launches_timed": n_launch, "hip_event_ms": ev_ms,
+                         "hbm_resident_frac": None, "hbm_resident_us_per_term": None, "hbm_resident_frac_2^21_rows": None,
+                         "fixed_problem_n24_us_per_term": None, "fixed_problem_n24_frac": None, "fixed_problem_n24_blocks_per_s": None,
+                         "operator_build_ms": (build_ms or {}).get("build_ms"),
+                         "unstable": bool(seg and max(seg) > 1.3 * min(seg)),
+                         "launch_us_min_segment": min(seg) if seg else None, "launch_us_max_segment": max(seg) if seg else None,
+                         "layout_bytes_per_launch": model["per_term"],
+                         "csr_equivalent_bytes_per_launch": model["csr_equivalent_per_term"],
                          "effective_csr_equiv_gbs": csr_equiv,
                          "effective_csr_equiv_frac": csr_equiv / HBM_PEAK_GBS,
-                         "csr_equivalent_bytes_per_launch": model["csr_equivalent_per_term"],
+                         "traffic_over_layout_bytes": (traffic / model["per_term"]) if traffic else None,
                          "traffic_rate_gbs": (traffic / avg_launch_s / 1e9) if traffic else None,
                          "traffic_frac_of_peak": (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                         "traffic_over_layout_bytes": (traffic / model["per_term"]) if traffic else None,
                          "hbm_stream_measured_gbs": stream_gbs, "hbm_copy_measured_gbs": copy_gbs,
-                         "note": "avg launch duration = HIP-event time of the timed region on the kernels' stream / number of "
-                                 "fused-term launches (includes launch gaps; multi-GPU: includes the exchange).  `achieved` = bytes "
-                                 "the shipped device layout must move per launch (stored values + index bytes + block metadata + "
-                                 "the vector streams with the accumulator touched by every third term only) / that duration; "
-                                 "`effective_csr_equiv_gbs` prices the same time with the contract's CSR bytes (SURVEY 8d: (20 z + "
-                                 "84) N = 404 B/row), which a Hermitian-packed / stencil-encoded layout undercuts; `traffic` = "
-                                 "HBM bytes per launch from the PMC counters (Infinity-Cache hits are counted by FETCH_SIZE: at "
-                                 "N = 2^20 part of the working set is served on-die, see extras[banded_N_2^22...] for the point beyond it)"},
+                         "layout_bytes_matrix": model["matrix_per_term"], "layout_bytes_vectors": model["vectors_per_term"],
+                         "launches_timed": n_launch, "hip_event_ms": ev_ms,
+                         "traffic_source": traffic_src,
+                         "launch_us_segments": seg, "traffic_detail": traffic_detail,
+                         "note": "avg_launch_us = HIP-event time of the timed region on the kernels' stream / fused-term launches (gaps and, "
+                                 "multi-GPU, the exchange included); launch_us_segments: the same per quarter of the region.  achieved = "
+                                 "bytes the SHIPPED device layout must move per launch / that time (<= peak by construction); "
+                                 "effective_csr_equiv_* prices the time with SURVEY 8d's CSR bytes (404 B/row), which the Hermitian-packed "
+                                 "stencil layout undercuts -- not a physical fraction.  traffic = HBM bytes per launch from PMC counters "
+                                 "(FETCH_SIZE counts Infinity-Cache hits: at N = 2^20 the working set is served on-die; hbm_resident_* = the "
+                                 "N = 2^22 point beyond it, fixed_problem_n24_* = config C4's N = 2^24 on this one GPU)"},
             "cpu_baseline": cpu,
             "cpu_baseline_all_cores": cpu_omp,
             "pcie_inclusive_steps_per_s": pcie,
             "strong_scaling_point": strong,
             "exchange_model": xmodel,
+            "scaling_prediction": None,
             "extras": extras,
             "stats": {"n_matvec": st["n_matvec"], "kernel_launches": st["n_kernel_launches"]},
         }
@@ -539,22 +645,34 @@ def main():
             out["config"]["parallelism"] += " | " + note
         return out
 
+    laps = {}
+
     def timed_steps(step_fn):
-        """W untimed + exactly K timed steps, barrier + synchronize on both sides, MAX over the ranks."""
+        """W untimed + exactly K timed steps, barrier + synchronize on both sides, MAX over the ranks.  Inside the timed
+        region an event is recorded on the kernels' stream after every quarter of the steps (three records: a few
+        microseconds in all), so that the line can say whether the region was uniform: `launch_us_segments`, `unstable`."""
         for _ in range(args.warmup):
             step_fn()
         ctx.reset_stats()
         barrier()
+        nseg = 4 if args.steps >= 8 else 1
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(nseg + 1)]
+        cuts = [round(k * args.steps / nseg) for k in range(nseg + 1)]
         ctx.timer_begin()
+        marks[0].record()
         t0_ = time.perf_counter()
-        for _ in range(args.steps):
+        for i in range(args.steps):
             step_fn()
+            if (i + 1) in cuts[1:]:
+                marks[cuts.index(i + 1)].record()
         ev_ = ctx.timer_end()          # HIP events on the kernels' own stream
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         el_ = time.perf_counter() - t0_
         st_ = ctx.stats()
+        seg = [1e3 * marks[k].elapsed_time(marks[k + 1]) / ((cuts[k + 1] - cuts[k]) * nterms) for k in range(nseg)]
+        laps["us"] = seg
         if dist is not None:
             t_ = dev_tensor([el_, ev_])
             dist.all_reduce(t_, op=dist.ReduceOp.MAX)
@@ -692,6 +810,8 @@ def main():
                              ("c2_random_columns_windowed", dict(pattern="random-window", log2n=20)),
                              ("banded_N_2^21_rows_per_gpu_of_config_c4", dict(pattern="banded", log2n=21, steps=8)),
                              ("banded_N_2^22_out_of_infinity_cache", dict(pattern="banded", log2n=22, steps=5)),
+                             ("banded_N_2^23_rows_per_gpu_of_the_fixed_problem_at_2_gpus", dict(pattern="banded", log2n=23, steps=4, warmup=3)),
+                             ("banded_N_2^24_config_c4_fixed_problem_on_one_gpu", dict(pattern="banded", log2n=24, steps=4, warmup=3)),
                              ("c2_alpha_2_17_coefficients", dict(pattern="banded", log2n=20, dt=0.2, steps=20)),
                              ("c2_alpha_50_85_coefficients", dict(pattern="banded", log2n=20, dt=5.0, steps=5)),
                              ("c2_real_symmetric_f64_values", dict(pattern="banded", log2n=20, real=True)),
@@ -711,21 +831,62 @@ def main():
                 except Exception as e:  # noqa: BLE001
                     extras[name] = {"error": f"{type(e).__name__}: {e}"}
 
+            # HBM traffic of the C3 and C5 points, by the same child-process PMC passes as the headline (one counter per pass)
+            if not args.no_pmc:
+                for name, argv, subs, how, per in (
+                        ("c3_newton", ["--point", "c3", "--steps", "3"], NEWTON_KERNELS, "sum", 6.0),       # the child runs 2 x 3 identical steps
+                        ("c5_batched", ["--point", "c5", "--steps", "2"], "spmm_rows_smem_kernel", "mean", 1.0)):
+                    pt = extras.get(name)
+                    if not pt or "error" in pt:
+                        continue
+                    tr, det = pmc_traffic(argv, subs, timeout_s=240, how=how)
+                    if tr is None:
+                        pt["traffic"], pt["traffic_source"] = None, f"not measured: {det}"
+                        continue
+                    tr /= per
+                    impl = pt.get("implementation_bytes_per_sweep", 0) * pt.get("arnoldi_sweeps_per_step", 0) if name == "c3_newton" \
+                        else pt.get("layout_bytes_per_term")
+                    pt["traffic"] = tr
+                    pt["traffic_unit"] = "HBM bytes per newton! step (all kernels of the step)" if name == "c3_newton" else "HBM bytes per fused panel term"
+                    pt["traffic_over_implementation_bytes"] = tr / impl if impl else None
+                    pt["traffic_source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of `bench.py " + " ".join(argv)
+                                            + "`, FETCH_SIZE x 2 (gfx950); " + ("sum over the step's kernels / steps" if how == "sum" else "mean per launch"))
+                    pt["traffic_detail"] = det
+
     out = make_out(elapsed, ev_ms, st, fmt_used, model, exchange_used, schedule_note, driver_note, strong,
                    traffic, traffic_src, traffic_detail, extras,
                    xmodel=(exchange_model(sh, world, rows, 1e3 * ev_ms / (args.steps * nterms)) if world > 1 else None),
                    note=(None if fallback is None else
                          f"conservative schedule measured first: {fallback['value']:.1f} {fallback['unit']} "
                          f"({fallback['ms_per_step']:.3f} ms/step, torch.distributed all-gather per term, no overlap)"))
-    # the fraction beyond the Infinity Cache as a first-class key of the headline object (at N = 2^20 the 134 MB of
-    # values and the vectors are served on-die; config C4 runs 2^21 rows per GPU)
+    # the fraction beyond the Infinity Cache and the fixed problem of BASELINE.md section 2 as scalar keys of the headline
+    # object (at N = 2^20 the 134 MB of values and the vectors are served on-die; config C4 is N = 2^24)
     if extras:
-        for key, name in (("hbm_resident_frac", "banded_N_2^22_out_of_infinity_cache"),
-                          ("hbm_resident_frac_2^21_rows", "banded_N_2^21_rows_per_gpu_of_config_c4")):
-            pt = extras.get(name) or {}
-            out["roofline"][key] = pt.get("frac")
-        pt = extras.get("banded_N_2^22_out_of_infinity_cache") or {}
-        out["roofline"]["hbm_resident_point"] = {k: pt.get(k) for k in ("N", "us_per_term", "layout_bytes_per_term", "layout_gbs", "kernel")}
+        rf = out["roofline"]
+        p22 = extras.get("banded_N_2^22_out_of_infinity_cache") or {}
+        p21 = extras.get("banded_N_2^21_rows_per_gpu_of_config_c4") or {}
+        p24 = extras.get("banded_N_2^24_config_c4_fixed_problem_on_one_gpu") or {}
+        rf["hbm_resident_frac"] = p22.get("frac")
+        rf["hbm_resident_us_per_term"] = p22.get("us_per_term")
+        rf["hbm_resident_frac_2^21_rows"] = p21.get("frac")
+        rf["fixed_problem_n24_us_per_term"] = p24.get("us_per_term")
+        rf["fixed_problem_n24_frac"] = p24.get("frac")
+        rf["fixed_problem_n24_blocks_per_s"] = (16.0 * p24["steps_per_s"]) if p24.get("steps_per_s") else None
+        rf["hbm_resident_point"] = {k: p22.get(k) for k in ("N", "us_per_term", "us_per_term_min", "us_per_term_max", "unstable",
+                                                            "layout_bytes_per_term", "layout_gbs", "kernel")}
+        rf["fixed_problem_point"] = {k: p24.get(k) for k in ("N", "us_per_term", "us_per_term_min", "us_per_term_max", "unstable", "ms_per_step",
+                                                             "steps_per_s", "layout_bytes_per_term", "layout_gbs", "frac", "kernel",
+                                                             "operator_build_ms")}
+        rf["unstable_extras"] = sorted(k for k, v in extras.items() if isinstance(v, dict) and v.get("unstable"))
+        rf["note"] = rf.pop("note")        # the long text stays last
+        sizes = {}
+        for lg, pt in ((20, {"us_per_term": rf["avg_launch_us"]}), (21, p21), (22, p22),
+                       (23, extras.get("banded_N_2^23_rows_per_gpu_of_the_fixed_problem_at_2_gpus") or {}), (24, p24)):
+            if pt.get("us_per_term"):
+                sizes[lg] = pt["us_per_term"]
+        out["scaling_prediction"] = scaling_prediction(sizes, out["value"], nterms, "measured in this run on one GPU")
+    elif world > 1:
+        out["scaling_prediction"] = scaling_prediction_static(nterms)
     out["degraded"] = False
     out["native_path"] = "ok" if world > 1 else None
     if watchdog is not None:

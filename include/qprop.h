@@ -73,7 +73,14 @@ enum { QP_VAL_C128 = 0, QP_VAL_F64 = 1 };
  * else RBCSR; CSR when row-block padding would exceed 50 %.  An HRB operator that is given
  * complex coefficients re-lays itself out as RBCSR. */
 enum { QP_FMT_AUTO = 0, QP_FMT_CSR = 1, QP_FMT_RBCSR = 2, QP_FMT_HRB = 3,
-       QP_FMT_MATFREE = 4 /* reported by qp_operator_info for qp_liouvillian_create operators */ };
+       QP_FMT_MATFREE = 4, /* reported by qp_operator_info for qp_liouvillian_create operators */
+       /* DENSE: the union pattern of the terms is (made) complete and the values are stored row-major, 16 B per entry (8 B
+        * for an all-real operator), no index bytes: the reference's own dense generators (test/test_cheby.jl:24-47,
+        * test/test_newton.jl:53-65: N = 1000 Hermitian(rand(ComplexF64, N, N)); BASELINE configs[0]).  One state: a row-sum
+        * kernel with the fused Chebyshev / plain epilogues; a panel of states (qp_cheby_step_batched): H [psi_1 .. psi_b] on
+        * the fp64 matrix cores.  AUTO takes it when at least 3/4 of the nrows x ncols positions are stored (the missing ones
+        * become explicit zeros, which qp_operator_get_csr then shows, as with qp_operator_fill_info). */
+       QP_FMT_DENSE = 5 };
 enum { QP_CONV_TDSE = 0, QP_CONV_LVN = 1 };   /* `convention` of liouvillian(), src/generators.jl:473-631 */
 enum { QP_FUNC_EXPMI = 0,    /* z -> exp(-i z)   default of newton!, src/newton.jl:247 */
        QP_FUNC_EXP = 1,      /* z -> exp(z)      test/test_newton.jl:171 */

@@ -183,6 +183,12 @@ int launch_arnoldi_matvec_dots(hipStream_t s, const DevMatrix& A, const double2*
 bool walk_shape_supported(int nn, int K, int z0, int xl = 0);   // is there a kernel instance for this stencil shape?
 int launch_hrb_walk_cheby(hipStream_t s, const DevMatrix& A, const double2* x, const ChebyEpi& e, const Tuning& tun,
                           bool* launched, const RowSet* rs = nullptr);
+// kernels_dense.hip (QP_FMT_DENSE: CSR arrays with a complete pattern, i.e. vals / vals_r is the row-major dense matrix)
+int launch_dense_gemv_cheby(hipStream_t s, const DevMatrix& A, const double2* x, const ChebyEpi& e, Stats* st);
+int launch_dense_gemv_plain(hipStream_t s, const DevMatrix& A, const double2* x, const PlainEpi& e, Stats* st);
+int launch_dense_zgemm_cheby(hipStream_t s, const DevMatrix& A, const double2* X, int batch, const ChebyEpi& e, Stats* st);
+// the formats whose value array is in CSR order (rowptr / cols / vals[p])
+inline bool csr_layout(int format) { return format == QP_FMT_CSR || format == QP_FMT_DENSE; }
 int spmv_grid_size(const DevMatrix& A);
 // Developer knobs for A/B measurements.  Every context carries its own copy (qp_ctx::tun, set with
 // qp_ctx_tuning_set); qp_tuning_set only changes the defaults that contexts created afterwards start
@@ -206,6 +212,9 @@ struct Tuning {
   int stencil = 1;            // operator build: encode blocks with block-wide column distances as stencil blocks
   int acc_defer = 1;          // qp_cheby_step: touch the Psi accumulator every third term only (1) or every term (0)
   int cheby_graph = 0;        // qp_cheby_step: replay a repeated step as a hipGraph when the mat-vec grid has at most this many workgroups (0: off; measured: no gain)
+  int dense_auto = 1;         // 1 = AUTO lays an operator out dense (QP_FMT_DENSE) when at least dense_min_density_pct % of its positions are stored
+  int dense_min_density_pct = 75;
+  int dense_panel_mfma = 1;   // 1 = the batched step of a dense operator runs H X on the fp64 matrix cores (kernels_dense.hip); 0 = the sparse panel kernels (A/B)
   int small_nnz = 8192;       // qp_propagate: register-resident Cheby systems up to this nnz run as ONE persistent launch (0: off)
   int newton_pipeline = 1;    // newton!: Hessenberg eigenvalues overlap the Arnoldi sweep
   int spmm_tile = 16;         // states per pass of the tiled batched SpMM kernel (16, 32 or 64)

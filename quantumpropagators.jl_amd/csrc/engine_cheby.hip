@@ -220,7 +220,7 @@ int qp_cheby_step(qp_cheby* w, qp_operator* op, qp_state* psi, const double* a, 
     qp_cheby::GraphKey key;
     key.vals = A.vals_r ? (const void*)A.vals_r : (const void*)A.vals;
     key.cols = A.cols;
-    key.rowptr = A.format == QP_FMT_CSR ? (const void*)A.rowptr : (const void*)A.bptr;
+    key.rowptr = qp::csr_layout(A.format) ? (const void*)A.rowptr : (const void*)A.bptr;
     key.psi = psi->d;
     key.format = A.format;
     // every knob that selects a kernel or a launch shape of the step's terms
@@ -316,9 +316,12 @@ int qp_cheby_step_batched(qp_cheby* w, qp_operator* op, qp_state* psi, int batch
   if (!(Delta > 0)) return qp::fail(QP_E_BAD_ARG, "Delta must be positive");
   qp_ctx* ctx = op->ctx;
   QP_CHECK(use(ctx));
-  QP_CHECK(operator_csr_mirror(op));
+  // a dense operator (QP_FMT_DENSE): H X on the fp64 matrix cores (csrc/kernels_dense.hip), straight from the operator's own
+  // value array; knob dense_panel_mfma 0 sends it through the sparse panel kernels like any CSR operator (A/B)
+  const bool dense = op->A.format == QP_FMT_DENSE && ctx->tun.dense_panel_mfma != 0 && (op->A.vals || op->A.vals_r);
+  if (!dense) QP_CHECK(operator_csr_mirror(op));
   // kernel choice (knob spmm_rows): the wave-per-row kernel for wide panels, else the state-tiled kernel
-  const bool rows_kernel = qp::spmm_uses_rows_kernel(ctx->tun, batch);
+  const bool rows_kernel = !dense && qp::spmm_uses_rows_kernel(ctx->tun, batch);
   const int32_t* order = nullptr;   // row walk of the wave-per-row kernel
   if (rows_kernel) QP_CHECK(operator_spmm_order(op, batch, &order));
   // lattice operators: the strip walk (far rows of X in a register ring) for the rows whose far neighbours exist, the
@@ -374,6 +377,10 @@ int qp_cheby_step_batched(qp_cheby* w, qp_operator* op, qp_state* psi, int batch
     e.apply_phase = last ? 1 : 0;
     e.check_partials = nullptr;
     bool walked = false;
+    if (dense) {
+      QP_CHECK(qp::launch_dense_zgemm_cheby(ctx->stream, op->A, x, batch, e, &ctx->stats));
+      walked = true;
+    }
     if (walk) {
       const bool nt = ctx->tun.spmm_nt == 2 || (ctx->tun.spmm_nt == 1 && (double)n * batch * sizeof(double2) >= 128.0 * 1024 * 1024);
       QP_CHECK(qp::launch_spmm_walk_cheby(ctx->stream, op->m_vals, x, *walk, batch, e, ctx->tun, nt, &walked));

@@ -5,6 +5,7 @@
 // algorithm needs a scalar on the host (once per Newton restart, once per Arnoldi call).
 #include <mutex>
 #include <thread>
+#include <system_error>
 #include <numeric>
 
 #include "engine.h"
@@ -19,12 +20,20 @@ static void parallel_rows(int64_t n, F&& fn) {
   }
   std::vector<std::thread> th;
   const int64_t chunk = (n + hw - 1) / hw;
-  for (unsigned t = 0; t < hw; ++t) {
-    const int64_t a = (int64_t)t * chunk, b = std::min(n, a + chunk);
-    if (a >= b) break;
-    th.emplace_back([&fn, a, b] { fn(a, b); });
+  int64_t done = 0;   // rows [0, done) have been handed to a thread
+  try {
+    for (unsigned t = 0; t < hw; ++t) {
+      const int64_t a = (int64_t)t * chunk, b = std::min(n, a + chunk);
+      if (a >= b) break;
+      th.emplace_back([&fn, a, b] { fn(a, b); });
+      done = b;
+    }
+  } catch (const std::system_error&) {
+    // no more threads to be had (resource limits): the started ones are joined below -- a joinable std::thread destroyed
+    // means std::terminate -- and this thread takes the rest
   }
   for (auto& x : th) x.join();
+  if (done < n) fn(done, n);
 }
 
 
@@ -734,7 +743,7 @@ static int operator_build_device_impl(qp_operator* op, int format, const std::ve
   Lh = HostLayout();
   Lh.format = format;
 
-  if (format == QP_FMT_CSR) {
+  if (qp::csr_layout(format)) {   // QP_FMT_DENSE: the same arrays with a complete pattern (vals[r ncols + c])
     A.stored = nnz;
     QP_CHECK(dev_alloc(&A.rowptr, ur.size()));
     QP_HIP(hipMemcpy(A.rowptr, ur.data(), ur.size() * sizeof(int64_t), hipMemcpyHostToDevice));
@@ -895,7 +904,7 @@ static int operator_build_device_impl(qp_operator* op, int format, const std::ve
       for (int64_t r = r_begin; r < r_end; ++r) {
         const int64_t nl = (format == QP_FMT_HRB) ? op->layout.nlow[r] : 0;
         for (int64_t k = nl; k < ur[r + 1] - ur[r]; ++k) {
-          const int64_t pos = (format == QP_FMT_CSR) ? ur[r] + k : rb_val_pos(op->layout.bptr, r, k - nl);
+          const int64_t pos = qp::csr_layout(format) ? ur[r] + k : rb_val_pos(op->layout.bptr, r, k - nl);
           hplane[pos] = pv[ur[r] + k];
         }
       }
@@ -977,7 +986,7 @@ static int operator_download_planes(qp_operator* op, std::vector<std::vector<cpl
     for (int64_t r = 0; r < A.nrows; ++r) {
       const int64_t nl = (A.format == QP_FMT_HRB) ? op->layout.nlow[r] : 0;
       for (int64_t k = 0; k < ur[r + 1] - ur[r]; ++k) {
-        if (A.format == QP_FMT_CSR) {
+        if (qp::csr_layout(A.format)) {
           out[ur[r] + k] = hv[ur[r] + k];
         } else if (k >= nl) {
           out[ur[r] + k] = hv[rb_val_pos(op->layout.bptr, r, k - nl)];
@@ -1186,7 +1195,7 @@ int qp_operator_create(qp_ctx* ctx, qp_matrix* const* ops, int nops, int ncoeffs
     if (ops[l]->nrows != ops[0]->nrows || ops[l]->ncols != ops[0]->ncols)
       return qp::fail(QP_E_BAD_ARG, "ops[%d] shape differs from ops[0]", l);
   }
-  if (format < QP_FMT_AUTO || format > QP_FMT_HRB) return qp::fail(QP_E_BAD_ARG, "bad device format %d", format);
+  if (format < QP_FMT_AUTO || (format > QP_FMT_HRB && format != QP_FMT_DENSE)) return qp::fail(QP_E_BAD_ARG, "bad device format %d", format);
   QP_CHECK(use(ctx));
   std::unique_ptr<qp_operator, int (*)(qp_operator*)> op(new qp_operator(), operator_free);
   op->ctx = ctx;
@@ -1218,7 +1227,31 @@ int qp_operator_create(qp_ctx* ctx, qp_matrix* const* ops, int nops, int ncoeffs
       ur[r + 1] = (int64_t)uc.size();
     }
   }
-  if (format == QP_FMT_AUTO || format == QP_FMT_HRB) {
+  // ---- a dense generator (QP_FMT_DENSE): requested, or AUTO with at least dense_min_density_pct % of the positions stored.
+  // The pattern is made complete (the missing positions become explicit zeros, counted like the lattice completion's), so
+  // that the CSR-ordered value array IS the row-major dense matrix and the dense kernels need no index at all.
+  bool dense = false;
+  {
+    const double positions = (double)nrows * (double)ncols;
+    if (format == QP_FMT_DENSE) {
+      if (positions > (double)INT32_MAX) return qp::fail(QP_E_BAD_ARG, "QP_FMT_DENSE: %lld x %lld positions exceed the 2^31 limit", (long long)nrows, (long long)ncols);
+      dense = nrows > 0 && ncols > 0;
+    } else if (format == QP_FMT_AUTO && ctx->tun.dense_auto && nrows > 0 && ncols > 0 && positions <= 1073741824.0) {
+      dense = 100.0 * (double)ur[nrows] >= (double)ctx->tun.dense_min_density_pct * positions;
+    }
+  }
+  if (dense) {
+    const int64_t before = ur[nrows];
+    if (before != nrows * ncols) {
+      uc.resize((size_t)(nrows * ncols));
+      parallel_rows(nrows, [&](int64_t r0, int64_t r1) {
+        for (int64_t r = r0; r < r1; ++r)
+          for (int64_t c = 0; c < ncols; ++c) uc[(size_t)(r * ncols + c)] = (int32_t)c;
+      });
+      for (int64_t r = 0; r <= nrows; ++r) ur[r] = r * ncols;
+    }
+    op->n_lattice_fill = ur[nrows] - before;
+  } else if (format == QP_FMT_AUTO || format == QP_FMT_HRB) {
     const int64_t before = ur[nrows];
     lattice_fill(ctx->tun, nrows, ncols, ur, uc);
     op->n_lattice_fill = ur[nrows] - before;
@@ -1254,10 +1287,10 @@ int qp_operator_create(qp_ctx* ctx, qp_matrix* const* ops, int nops, int ncoeffs
       }
     }
   }
-  bool hermitian = (ncols >= nrows) && (format == QP_FMT_AUTO || format == QP_FMT_HRB);
+  bool hermitian = !dense && (ncols >= nrows) && (format == QP_FMT_AUTO || format == QP_FMT_HRB);
   for (int l = 0; hermitian && l < nops; ++l) hermitian = csr_is_hermitian(nrows, ur, uc, planes_csr[l]);
   op->hermitian_planes = hermitian;
-  const int fmt = choose_format(op.get(), format, hermitian);
+  const int fmt = dense ? (int)QP_FMT_DENSE : choose_format(op.get(), format, hermitian);
   if (fmt < 0) return qp::fail(QP_E_BAD_ARG, "QP_FMT_HRB requested but the operator terms are not exactly Hermitian");
   QP_CHECK(operator_build_device(op.get(), fmt, planes_csr));
   planes_csr.clear();
@@ -1381,7 +1414,7 @@ int qp_operator_layout_info(const qp_operator* op, int64_t out[5]) {
   for (int i = 0; i < 5; ++i) out[i] = 0;
   const DevMatrix& A = op->A;
   out[4] = A.stored;
-  if (A.format == QP_FMT_CSR || A.format == QP_FMT_MATFREE) return QP_OK;
+  if (qp::csr_layout(A.format) || A.format == QP_FMT_MATFREE) return QP_OK;
   const HostLayout& Lh = op->layout;
   out[0] = A.nblocks;
   int64_t idx_bytes = A.colbytes + A.lcolbytes;
@@ -1481,7 +1514,7 @@ int qp_operator_get_csr(qp_operator* op, int64_t* rowptr, int32_t* col, qp_c128*
   QP_HIP(hipStreamSynchronize(op->ctx->stream));
   std::vector<cplx> hv((size_t)std::max<int64_t>(A.stored, 1));
   QP_HIP(hipMemcpy(hv.data(), A.vals, (size_t)A.stored * sizeof(double2), hipMemcpyDeviceToHost));
-  if (A.format == QP_FMT_CSR) {
+  if (qp::csr_layout(A.format)) {
     std::vector<int64_t> rp(A.nrows + 1);
     std::vector<int32_t> hc((size_t)std::max<int64_t>(A.nnz, 1));
     QP_HIP(hipMemcpy(rp.data(), A.rowptr, rp.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
@@ -1879,7 +1912,7 @@ int operator_csr_mirror(qp_operator* op, bool gather) {
       const int64_t nl = (A.format == QP_FMT_HRB) ? op->layout.nlow[r] : 0;
       for (int64_t k = 0; k < ur[r + 1] - ur[r]; ++k) {
         int64_t m;
-        if (A.format == QP_FMT_CSR) {
+        if (qp::csr_layout(A.format)) {
           m = ur[r] + k;
         } else if (k >= nl) {
           m = rb_val_pos(op->layout.bptr, r, k - nl);

@@ -1085,6 +1085,7 @@ int* tuning_field(Tuning& t, const char* key) {
       {"liouville_fused_n", &Tuning::liouville_fused_n}, {"liouville_tile32_n", &Tuning::liouville_tile32_n}, {"liouville_tile32_min_n", &Tuning::liouville_tile32_min_n}, {"real_vals", &Tuning::real_vals},
       {"stencil", &Tuning::stencil},             {"acc_defer", &Tuning::acc_defer},
       {"cheby_graph", &Tuning::cheby_graph},     {"small_nnz", &Tuning::small_nnz},
+      {"dense_auto", &Tuning::dense_auto},       {"dense_min_density_pct", &Tuning::dense_min_density_pct}, {"dense_panel_mfma", &Tuning::dense_panel_mfma},
       {"newton_pipeline", &Tuning::newton_pipeline}, {"spmm_tile", &Tuning::spmm_tile},
       {"spmm_nt", &Tuning::spmm_nt},             {"spmm_rows", &Tuning::spmm_rows},
       {"spmm_strip", &Tuning::spmm_strip},       {"spmm_rw", &Tuning::spmm_rw},
@@ -1360,6 +1361,10 @@ int launch_spmv_cheby(hipStream_t s, const DevMatrix& A, const double2* x, const
     if (st) st->n_launch++;
     return QP_OK;
   }
+  if (A.format == QP_FMT_DENSE) {
+    if (rs && rs->block_map) return fail(QP_E_BAD_ARG, "row sets need a row-block format");
+    return launch_dense_gemv_cheby(s, A, x, e, st);
+  }
   ChebyOp op{e};
   int rc = launch_spmv(s, A, x, op, st, rs);
   // algorithmic bytes, SURVEY 8d: z (V + 4) N + 4 (N + 1) + 5 * 16 N
@@ -1371,6 +1376,7 @@ int launch_spmv_cheby(hipStream_t s, const DevMatrix& A, const double2* x, const
 int launch_spmv_plain(hipStream_t s, const DevMatrix& A, const double2* x, const PlainEpi& e, Stats* st) {
   if (A.format == QP_FMT_MATFREE)
     return A.matfree_apply(s, A.matfree, x, e.y, e.alpha, e.beta_zero ? make_double2(0.0, 0.0) : e.beta, st);
+  if (A.format == QP_FMT_DENSE) return launch_dense_gemv_plain(s, A, x, e, st);
   PlainOp op{e};
   int rc = launch_spmv(s, A, x, op, st);
   // plain SpMV: matrix + read x + write y  ((20 z + 36) N)

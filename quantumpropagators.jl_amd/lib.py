@@ -26,7 +26,7 @@ STATUS = {
 }
 LAYOUT_CSR, LAYOUT_CSC = 0, 1
 VAL_C128, VAL_F64 = 0, 1
-FMT_AUTO, FMT_CSR, FMT_RBCSR, FMT_HRB, FMT_MATFREE = 0, 1, 2, 3, 4
+FMT_AUTO, FMT_CSR, FMT_RBCSR, FMT_HRB, FMT_MATFREE, FMT_DENSE = 0, 1, 2, 3, 4, 5
 FUNC_EXPMI, FUNC_EXP, FUNC_CALLBACK = 0, 1, 2
 
 

@@ -642,13 +642,22 @@ class BatchSplitCheby:
         return self.impl.read()
 
     def gather(self):
-        """The whole (N, batch) panel on every rank (host-staged; output only, never part of a step)."""
-        loc = self.local_states()
-        if self.dist is None or self.world == 1:
+        """The whole (N, batch) panel on every rank (output only, never part of a step).  The collective runs on tensors of the
+        kind the group's backend moves: device tensors under nccl (= RCCL; the product group of bench.py has no CPU backend),
+        host tensors under gloo."""
+        loc = np.ascontiguousarray(self.local_states())
+        if self.dist is None:
             return loc
         import torch
+        if str(self.dist.get_backend(self.group)).lower() == "nccl":
+            dev = torch.device("cuda", torch.cuda.current_device())
+            send = torch.view_as_real(torch.from_numpy(loc)).to(dev)                    # (N, b, 2) fp64
+            recv = torch.empty((self.world,) + tuple(send.shape), dtype=torch.float64, device=dev)
+            self.dist.all_gather_into_tensor(recv, send, group=self.group)
+            parts = torch.view_as_complex(recv.cpu()).numpy()                           # (world, N, b)
+            return np.concatenate(list(parts), axis=1)
         parts = [torch.empty((self.N, self.b), dtype=torch.complex128) for _ in range(self.world)]
-        self.dist.all_gather(parts, torch.from_numpy(np.ascontiguousarray(loc)), group=self.group)
+        self.dist.all_gather(parts, torch.from_numpy(loc), group=self.group)
         return np.concatenate([p.numpy() for p in parts], axis=1)
 
     def close(self):

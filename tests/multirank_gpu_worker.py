@@ -118,6 +118,63 @@ def c4_main(rank, world):
         sys.exit(3)
 
 
+def c4_allgather_main(rank, world):
+    """BASELINE configs[3] at its size in the ALL-GATHER form -- the collective north_star names: N = 2^24 rows, `world` ranks
+    sharing GPU 0, a SCATTERED Hermitian H (8 seeded offsets in [1, N/2): every row of a rank is read by another rank, so the
+    send list is the whole slice and the slice itself is the send buffer), the library's one-call step with the exchange
+    handed back through the callback communicator.  Checked against the C restatement of the reference at FULL size: rank 0
+    regenerates the whole operator, runs one serial step (about 15 s of one core) and scatters the slices of the result."""
+    from oracle import ref_c
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    N = 1 << int(os.environ.get("QP_LOG2N", "24"))
+    rows = N // world
+    r0, r1 = rank * rows, (rank + 1) * rows
+    offs = synth.scattered_offsets(N)
+    rp, col, vals = synth.hermitian_offsets_csr(N, offsets=offs, row_begin=r0, row_end=r1)
+    ctx = L.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    sh = sharded.ShardedCheby(ctx, rp, col, vals, N, r0, r1, 20.0, -10.0, 1.0, exchange="allgather", overlap=True,
+                              host_staged=True, native=True)
+    del rp, col, vals
+    if sh.native is None or sh.exchange != "allgather" or sh.M != rows:
+        print(f"rank {rank}: native={sh.native is not None} exchange={sh.exchange} M={sh.M} (want the whole slice, {rows})", flush=True)
+        sys.exit(5)
+    psi0 = synth.random_state(N, row_begin=r0, row_end=r1)
+    sh.set_state(psi0)
+    sh.step()
+    torch.cuda.synchronize()
+    one = sh.local_state()
+    n2 = torch.tensor([float(np.vdot(one, one).real)], dtype=torch.float64)
+    dist.all_reduce(n2)
+    sh.step(backward=True)
+    torch.cuda.synchronize()
+    sh.check()
+    back = float(np.linalg.norm(sh.local_state() - psi0))
+    mine = torch.empty(rows, 2, dtype=torch.float64)
+    if rank == 0:
+        coeffs = L.cheby_coeffs(20.0, 1.0)
+        frp, fcol, fvals = synth.hermitian_offsets_csr(N, offsets=offs)
+        np.conj(fvals, out=fvals)                                  # Hermitian: CSC(H) = conj CSR(H)
+        ref = synth.random_state(N)
+        ref_c.load()
+        ref_c.cheby_csc(frp, fcol.astype(np.int64), fvals, ref, coeffs, 20.0, -10.0, 1.0)
+        del frp, fcol, fvals
+        parts = [torch.from_numpy(np.ascontiguousarray(ref[k * rows:(k + 1) * rows])).view(torch.float64).reshape(rows, 2)
+                 for k in range(world)]
+        dist.scatter(mine, parts, src=0)
+    else:
+        dist.scatter(mine, None, src=0)
+    refloc = mine.numpy().view(np.complex128).reshape(-1)
+    err = float(np.linalg.norm(one - refloc))
+    print(f"rank {rank}/{world}: c4-allgather N=2^{int(np.log2(N))} err={err:.3e} norm1-1={abs(float(n2[0]) - 1):.2e} roundtrip={back:.3e} "
+          f"exchange={sh.exchange} M={sh.M} split={'yes' if sh.split is not None else 'no'} format={sh.op.format}", flush=True)
+    dist.barrier()
+    sh.close()
+    dist.destroy_process_group()
+    if not (err < 1e-10 and abs(float(n2[0]) - 1) < 1e-11 and back < 1e-10):
+        sys.exit(3)
+
+
 def rccl_main(rank, world):
     """One GPU per rank, the library's own RCCL communicator (qp_comm_prepare / qp_comm_connect, id over the
     gloo group): the native one-call step in all its forms against the oracle.  Needs `world` GPUs."""
@@ -165,6 +222,8 @@ def main():
         return newton_main(rank, world)
     if os.environ.get("QP_METHOD") == "c4":
         return c4_main(rank, world)
+    if os.environ.get("QP_METHOD") == "c4-allgather":
+        return c4_allgather_main(rank, world)
     if os.environ.get("QP_METHOD") == "rccl":
         return rccl_main(rank, world)
     overlap = os.environ.get("QP_OVERLAP", "1") == "1"

@@ -84,6 +84,62 @@ def test_c4_full_size_eight_ranks_one_gpu():
     assert sum("err=0.000e+00" not in o for o in outs) >= 3      # the windows were compared on the ranks that own them
 
 
+def test_c4_full_size_eight_ranks_allgather_form_one_gpu():
+    """The same size in the ALL-GATHER form (the collective BASELINE's north_star names): a scattered H whose send list is every
+    rank's whole 2^21-row slice, 32 MiB per rank and term through the exchange; the state after one step against the C
+    oracle at full size (computed once, on rank 0), norm and forward / backward round trip."""
+    outs = _run(8, timeout=1500, QP_METHOD="c4-allgather")
+    assert all("c4-allgather N=2^24" in o and "exchange=allgather" in o and f"M={1 << 21}" in o for o in outs)
+
+
+def test_bench_eight_ranks_full_c4_flow_one_gpu():
+    """The COMPLETE `bench.py --gpus 8` flow at config C4's size (2^21 rows per rank, N = 2^24), as the driver launches it,
+    with the 8 ranks sharing the test GPU: conservative pass, native set-up + self-check, both schedules' trial, the timed
+    steps, the strong point -- so that the first run on a real 8-GPU node exercises nothing for the first time but RCCL
+    itself.  Must finish well inside the driver's patience (asserted: < 10 min)."""
+    import json
+    import time
+    world = 8
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    t0 = time.time()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", QP_BENCH_ONE_GPU="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2",
+                                       "--warmup", "1"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=900))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    took = time.time() - t0
+    for p, (out, err) in zip(procs, outs):
+        assert p.returncode == 0, err[-3000:]
+    assert took < 600, f"the full --gpus 8 flow took {took:.0f} s"
+    lines = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["degraded"] is False and d["native_path"].startswith("ok") and d["n_gpus"] == 8 and d["scaling"] == "weak"
+    assert d["config"]["N_total"] == 1 << 24 and d["config"]["rows_per_gpu"] == 1 << 21 and d["config"]["blocks_of_2^20_rows_per_step"] == 16.0
+    par = d["config"]["parallelism"]
+    assert "row-partitioned x8" in par and "exchange=halo" in par and "schedule=auto: overlap" in par and "driver=native" in par
+    sp_ = d["strong_scaling_point"]
+    assert sp_["N_total"] == 1 << 20 and sp_["rows_per_gpu"] == 1 << 17 and sp_["prop_steps_per_s"] > 0
+    xm = d["exchange_model"]
+    assert xm["rows_sent_per_rank_per_term"] == 8192 and xm["peers"] == 2
+    pred = d["scaling_prediction"]         # the 1 / 2 / 4 / 8 table the first real run is read against
+    assert [r["gpus"] for r in pred["fixed_problem_N_2^24"]] == [1, 2, 4, 8]
+    assert pred["fixed_problem_N_2^24"][-1]["speedup_halo_overlap"] > 6.0 > pred["fixed_problem_N_2^24"][-1]["speedup_allgather"]
+    assert 0 < d["roofline"]["frac"] <= 1.0
+
+
 def test_library_rccl_communicator_two_gpus():
     """The library's own multi-rank RCCL communicator (two-phase set-up, ncclSend / ncclRecv neighbour exchange,
     ncclAllGather, overlapped and serial schedules) against the oracle -- one GPU per rank, so this needs two

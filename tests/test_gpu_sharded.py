@@ -334,3 +334,31 @@ def test_native_rccl_step_world1(pg, overlap, exchange, p2p):
         ctx.sync()
         assert np.array_equal(b.numpy(), a.numpy())
     ctx.close()
+
+
+def test_batch_split_gather_under_the_nccl_group(pg):
+    """BatchSplitCheby.gather() under the PRODUCT process group (nccl = RCCL, no CPU backend: a host-tensor collective
+    raises "No backend type associated with device type cpu" there): the panel is reassembled through device tensors.
+    World 1 here (RCCL forms no multi-rank communicator on one device); the gloo branch is covered by
+    tests/test_sharded_gloo.py::test_batch_split_gloo at world 2 and 3."""
+    import torch
+    from oracle import qp_oracle as qo
+    import qprop_amd.lib as L
+    import qprop_amd.sharded as sharded
+    import qprop_amd.synth as synth
+    assert str(pg.get_backend()).lower() == "nccl"
+    N, batch = 2048, 8
+    rp, col, vals = synth.hermitian_offsets_csr(N, offsets=(1, 2, 3, 4, 16, 32, 48, 64))
+    ctx = L.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    bs = sharded.BatchSplitCheby(ctx, rp, col, vals, N, batch, 20.0, -10.0, 1.0)
+    states = np.stack([synth.random_state(N, seed=900 + s) for s in range(batch)], axis=1)
+    bs.set_states(states)
+    bs.step()
+    got = bs.gather()                        # all_gather_into_tensor on cuda tensors
+    assert got.shape == (N, batch) and np.array_equal(got, bs.local_states())
+    H = synth.to_scipy(rp, col, vals, N)
+    for s in range(batch):
+        ref = qo.cheby(states[:, s].copy(), H, 1.0, qo.ChebyWrk(states[:, s], 20.0, -10.0, 1.0))
+        assert np.linalg.norm(got[:, s] - ref) < 1e-10
+    bs.close()
+    ctx.close()

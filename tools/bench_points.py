@@ -15,7 +15,40 @@ import qprop_amd.lib as L  # noqa: E402
 import qprop_amd.synth as synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; 6.3 TB/s measured copy)
-FMT_NAME = {1: "csr", 2: "rbcsr", 3: "hrb (Hermitian-packed row blocks)", 4: "matrix-free"}
+FMT_NAME = {1: "csr", 2: "rbcsr", 3: "hrb (Hermitian-packed row blocks)", 4: "matrix-free", 5: "dense (row-major, no index bytes)"}
+
+
+def timed_regions(ctx, fn, steps, repeats=3):
+    """`repeats` timed regions of `steps` calls of fn, each bracketed by HIP events on the kernels' stream; next to every
+    region's event time what the HOST did meanwhile -- wall time of the enqueue loop and the longest single call -- so that a
+    host stall (the device drains its queue and idles inside the event bracket) can be told from a device slow mode.
+    -> [(event_ms, enqueue_ms, longest_call_ms)]"""
+    out = []
+    for _ in range(repeats):
+        ctx.sync()
+        longest = 0.0
+        ctx.timer_begin()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            t1 = time.perf_counter()
+            fn()
+            longest = max(longest, time.perf_counter() - t1)
+        enq = time.perf_counter() - t0
+        out.append((ctx.timer_end(), 1e3 * enq, 1e3 * longest))
+    return out
+
+
+def spread(values, regions=None):
+    """median / min / max of repeated measurements; `unstable` when max / min > 1.3 (one 455 us sample among
+    122-136 us ones became a first-class key of the line).  With the host-side record of the regions: whether the slowest
+    region is explained by the host (its enqueue loop took at least 80 % of the event time: the device was waiting)."""
+    v = sorted(float(x) for x in values)
+    out = {"median": float(np.median(v)), "min": v[0], "max": v[-1], "repeats": len(v), "unstable": bool(v[-1] > 1.3 * v[0])}
+    if regions is not None and out["unstable"]:
+        slow = max(regions, key=lambda r: r[0])
+        out["slowest_region"] = {"event_ms": slow[0], "host_enqueue_ms": slow[1], "longest_single_call_ms": slow[2],
+                                 "host_stall_suspected": bool(slow[1] > 0.8 * slow[0])}
+    return out
 
 
 def cheby_layout_bytes(op, rows, ncols, nnz, coeffs, real_copy=False):
@@ -89,9 +122,10 @@ def pattern_csr(pattern, N, row_begin=0, row_end=None):
     raise ValueError(pattern)
 
 
-def measure_cheby(ctx, pattern="banded", log2n=20, fmt="auto", steps=10, warmup=2, real=False, dt=1.0, grid=None):
+def measure_cheby(ctx, pattern="banded", log2n=20, fmt="auto", steps=10, warmup=2, real=False, dt=1.0, grid=None, repeats=3):
     """Cheby prop_step! on one GPU for a pattern / size / device format; per-term time from HIP events on
-    the kernels' stream; layout-byte and CSR-equivalent rates.  grid = (nx, ny): the finite-difference Hamiltonian of an
+    the kernels' stream -- the MEDIAN of `repeats` timed regions of `steps` steps, with min, max and an `unstable` flag --;
+    layout-byte and CSR-equivalent rates.  grid = (nx, ny): the finite-difference Hamiltonian of an
     open-boundary grid (synth.grid_hamiltonian_2d) instead of a pattern."""
     if grid and len(grid) == 3:
         Hg = synth.grid_hamiltonian_3d(*grid, flux=0.1)
@@ -120,18 +154,18 @@ def measure_cheby(ctx, pattern="banded", log2n=20, fmt="auto", steps=10, warmup=
     nterms = wrk.n_coeffs - 1
     for _ in range(warmup):
         L.cheby(psi, op, dt, wrk)
-    ctx.sync()
-    ctx.timer_begin()
-    for _ in range(steps):
-        L.cheby(psi, op, dt, wrk)
-    ms = ctx.timer_end()
-    t_term = ms * 1e-3 / (steps * nterms)
+    regions = timed_regions(ctx, lambda: L.cheby(psi, op, dt, wrk), steps, repeats)
+    sp = spread([1e3 * r[0] / (steps * nterms) for r in regions], regions)      # us per term
+    ms = sp["median"] * 1e-3 * steps * nterms
+    t_term = sp["median"] * 1e-6
     by = cheby_layout_bytes(op, N, N, nnz, wrk.coeffs, real_copy=real)
     lay = by["layout"]
     out = {"pattern": pattern, "N": N, "nnz_per_row": nnz / N, "device_format": FMT_NAME[op.format], "dt": dt,
            "kernel": cheby_kernel_name(op), "operator_build_ms": op.build_info()["build_ms"],
            "n_coeffs": int(wrk.n_coeffs), "values": "real fp64 (f64 variant)" if real else "complex fp64",
            "ms_per_step": ms / steps, "steps_per_s": 1e3 * steps / ms, "us_per_term": t_term * 1e6,
+           "us_per_term_min": sp["min"], "us_per_term_max": sp["max"], "repeats": sp["repeats"], "steps_per_repeat": steps,
+           "unstable": sp["unstable"], "slowest_region": sp.get("slowest_region"),
            "layout_bytes_per_term": by["per_term"], "layout_gbs": by["per_term"] / t_term / 1e9,
            "frac": by["per_term"] / t_term / 1e9 / HBM_PEAK_GBS,
            "csr_equivalent_gbs": by["csr_equivalent_per_term"] / t_term / 1e9,
@@ -146,8 +180,10 @@ def measure_cheby(ctx, pattern="banded", log2n=20, fmt="auto", steps=10, warmup=
     return out
 
 
-def measure_newton_c3(ctx, n=512, m=20, dt=0.5, steps=10, warmup=60):
-    """BASELINE configs[2]: N = n^2 non-Hermitian Liouvillian, Newton / restarted Arnoldi with m_max = m."""
+def measure_newton_c3(ctx, n=512, m=20, dt=0.5, steps=10, warmup=60, repeats=3):
+    """BASELINE configs[2]: N = n^2 non-Hermitian Liouvillian, Newton / restarted Arnoldi with m_max = m.  The same `steps` steps
+    from rho_0 are timed `repeats` times (wall clock around the synchronised loop: the restart loop has host phases); the
+    median region is reported, with min / max / `unstable`."""
     Lm = synth.liouvillian_tridiag(n)
     N, nnz = Lm.shape[0], Lm.nnz
     M = L.Matrix.from_scipy(ctx, Lm)
@@ -157,20 +193,23 @@ def measure_newton_c3(ctx, n=512, m=20, dt=0.5, steps=10, warmup=60):
     psi = L.State(ctx, data=rho0)
     for _ in range(warmup):
         L.newton(psi, op, dt, wrk)
-    psi.upload(rho0)          # the open system relaxes: time the same steps every run
-    ctx.sync()
-    ctx.reset_stats()
-    sweeps = matvecs = 0
-    exposed = 0.0
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        L.newton(psi, op, dt, wrk)
-        sweeps += wrk.restarts + 1
-        matvecs += wrk.stats["n_matvec"]
-        exposed += wrk.stats["ms_exposed"]
-    ctx.sync()
-    el = time.perf_counter() - t0
-    st = ctx.stats()
+    runs = []
+    for _ in range(repeats):
+        psi.upload(rho0)          # the open system relaxes: time the same steps every run
+        ctx.sync()
+        ctx.reset_stats()
+        sweeps = matvecs = 0
+        exposed = 0.0
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            L.newton(psi, op, dt, wrk)
+            sweeps += wrk.restarts + 1
+            matvecs += wrk.stats["n_matvec"]
+            exposed += wrk.stats["ms_exposed"]
+        ctx.sync()
+        runs.append((time.perf_counter() - t0, sweeps, matvecs, exposed, ctx.stats()))
+    sp = spread([1e3 * r[0] / steps for r in runs])
+    el, sweeps, matvecs, exposed, st = sorted(runs, key=lambda r: r[0])[len(runs) // 2]
     z = nnz / N
     # SURVEY 8d model per Arnoldi sweep (this implementation's low-sync MGS reads the basis twice per column)
     sweep_bytes = m * (20 * z + 36) * N + 64 * N * m * (m + 1) / 2 + 64 * N * m + 32 * N * m + 16 * (m + 2) * N + 16 * (m + 3) * N
@@ -182,7 +221,8 @@ def measure_newton_c3(ctx, n=512, m=20, dt=0.5, steps=10, warmup=60):
     out = {"workload": f"BASELINE configs[2]: Newton prop_step!, N={N} (n={n}) non-Hermitian sparse Liouvillian, m_max={m}",
            "regime": regime,
            "N": N, "nnz_per_row": z, "m_max": m, "dt": dt, "steps": steps, "device_format": FMT_NAME[op.format],
-           "ms_per_step": 1e3 * el / steps, "steps_per_s": steps / el,
+           "ms_per_step": 1e3 * el / steps, "ms_per_step_min": sp["min"], "ms_per_step_max": sp["max"], "repeats": sp["repeats"],
+           "unstable": sp["unstable"], "steps_per_s": steps / el,
            "arnoldi_sweeps_per_step": sweeps / steps, "matvecs_per_step": matvecs / steps,
            "kernel_launches_per_step": st["n_kernel_launches"] / steps,
            "launches_per_column": st["n_kernel_launches"] / max(matvecs, 1),
@@ -199,7 +239,7 @@ def measure_newton_c3(ctx, n=512, m=20, dt=0.5, steps=10, warmup=60):
     return out
 
 
-def measure_batched_c5(ctx, log2n=18, batch=64, steps=5, warmup=2):
+def measure_batched_c5(ctx, log2n=18, batch=64, steps=5, warmup=2, repeats=3):
     """BASELINE configs[4]: `batch` states x N = 2^log2n CSR H, Chebyshev on the panel."""
     N = 1 << log2n
     rp, col, vals = synth.hermitian_offsets_csr(N)
@@ -213,12 +253,10 @@ def measure_batched_c5(ctx, log2n=18, batch=64, steps=5, warmup=2):
     nterms = wrk.n_coeffs - 1
     for _ in range(warmup):
         L.cheby_batched(panel, op, 1.0, wrk, batch)
-    ctx.sync()
-    ctx.timer_begin()
-    for _ in range(steps):
-        L.cheby_batched(panel, op, 1.0, wrk, batch)
-    ms = ctx.timer_end()
-    t_term = ms * 1e-3 / (steps * nterms)
+    regions = timed_regions(ctx, lambda: L.cheby_batched(panel, op, 1.0, wrk, batch), steps, repeats)
+    sp = spread([1e3 * r[0] / (steps * nterms) for r in regions], regions)
+    ms = sp["median"] * 1e-3 * steps * nterms
+    t_term = sp["median"] * 1e-6
     alg = 20.0 * nnz + 4.0 * (N + 1) + 80.0 * N * batch          # SURVEY 8d batched model per term
     sched = L.acc_schedule(wrk.coeffs)
     nupd = sum(0 if d.skip else 1 for d in sched)
@@ -231,11 +269,64 @@ def measure_batched_c5(ctx, log2n=18, batch=64, steps=5, warmup=2):
            "kernel": "spmm_rows_smem_kernel (wave per row, lane = state)" if batch > 32 else "csr_spmm_kernel (state-tiled)",
            "N": N, "batch": batch, "steps": steps, "ms_per_panel_step": ms / steps,
            "state_steps_per_s": batch * steps / (ms * 1e-3), "us_per_term": t_term * 1e6,
+           "us_per_term_min": sp["min"], "us_per_term_max": sp["max"], "repeats": sp["repeats"], "unstable": sp["unstable"],
+           "slowest_region": sp.get("slowest_region"),
            "row_walk": dict(zip(("inner_dimension", "strip_width"), op.spmm_walk(batch))),
            "layout_bytes_per_term": lay, "layout_gbs": lay / t_term / 1e9, "frac": lay / t_term / 1e9 / HBM_PEAK_GBS,
            "algorithmic_gbs": alg / t_term / 1e9, "algorithmic_frac": alg / t_term / 1e9 / HBM_PEAK_GBS,
            "max_norm_drift": float(np.max(np.abs(norms - 1.0)))}
     for h in (panel, wrk, op, M):
+        h.close()
+    return out
+
+
+def measure_dense(ctx, N=4096, batch=1, fmt="dense", mfma=1, steps=None, repeats=3, seed=7):
+    """A dense Hermitian generator (the reference's own test operators: test/test_cheby.jl:24-47) through the fused Chebyshev
+    term: one state (row-sum kernel: 16 N^2 bytes per term) or a panel of `batch` states (H X on the fp64 matrix cores:
+    8 N^2 b flop per term; mfma = 0: the sparse panel kernels on the same operator).  fmt "csr" forces the CSR kernels."""
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
+    H = (X + X.conj().T) * (5.0 / np.sqrt(8.0 * N))          # GUE scaled to a spectral radius of about 10
+    del X
+    f = {"dense": L.FMT_DENSE, "csr": L.FMT_CSR, "auto": L.FMT_AUTO}[fmt]
+    rp = np.arange(N + 1, dtype=np.int64) * N
+    col = np.tile(np.arange(N, dtype=np.int32), N)
+    M = L.Matrix(ctx, N, N, rp, col, H.reshape(-1))
+    del H, rp, col
+    op = L.Operator(ctx, [M], 0, f)
+    dt = 0.5
+    wrk = L.ChebyWrk(ctx, N * batch, 24.0, -12.0, dt)
+    nterms = wrk.n_coeffs - 1
+    states = rng.standard_normal(N * batch) + 1j * rng.standard_normal(N * batch)
+    psi = L.State(ctx, data=states / np.linalg.norm(states) * np.sqrt(batch))
+    saved = ctx.tuning_get("dense_panel_mfma")
+    ctx.tuning_set("dense_panel_mfma", mfma)
+    try:
+        step = (lambda: L.cheby(psi, op, dt, wrk)) if batch == 1 else (lambda: L.cheby_batched(psi, op, dt, wrk, batch))
+        step()
+        ctx.sync()
+        if steps is None:      # about 20 ms per timed region
+            ctx.timer_begin()
+            step()
+            one = max(ctx.timer_end(), 1e-3)
+            steps = int(max(1, min(50, 20.0 / one)))
+        regions = timed_regions(ctx, step, steps, repeats)
+    finally:
+        ctx.tuning_set("dense_panel_mfma", saved)
+    sp = spread([1e3 * r[0] / (steps * nterms) for r in regions], regions)
+    t = sp["median"] * 1e-6
+    byts = 16.0 * N * N + 80.0 * N * batch
+    flops = 8.0 * N * N * batch
+    out = {"workload": f"dense Hermitian H, N = {N}, complex fp64" + (f", panel of {batch} states" if batch > 1 else ", one state"),
+           "N": N, "batch": batch, "device_format": FMT_NAME[op.format], "n_coeffs": int(wrk.n_coeffs),
+           "kernel": ("dense_gemv_kernel" if op.format == L.FMT_DENSE else "csr_spmv_kernel") if batch == 1 else
+                     ("dense_zgemm_cheby_kernel (MFMA)" if (op.format == L.FMT_DENSE and mfma) else "sparse panel kernels"),
+           "us_per_term": sp["median"], "us_per_term_min": sp["min"], "us_per_term_max": sp["max"], "repeats": sp["repeats"],
+           "unstable": sp["unstable"], "operator_build_ms": op.build_info()["build_ms"],
+           "bytes_per_term": byts, "gbs": byts / t / 1e9, "frac": byts / t / 1e9 / HBM_PEAK_GBS,
+           "tflops": flops / t / 1e12, "frac_fp64_matrix_peak": flops / t / 1e12 / 78.6,
+           "bound": "mfma" if batch >= 20 else "hbm", "norm_drift": abs(psi.norm() / np.sqrt(batch) - 1.0)}
+    for h in (psi, wrk, op, M):
         h.close()
     return out
 
@@ -252,7 +343,7 @@ def measure_liouville(ctx, n=512, nc=2, reps=20):
     flops = 8.0 * n ** 3 * (2 + 2 * nc)
     keys = ("liouville_fused_n", "liouville_tile32_n")
     saved = {k: ctx.tuning_get(k) for k in keys}
-    res = {}
+    res, sps = {}, {}
     try:
         for name, override in (("hand_written", None), ("library_chain", 0)):
             if override is not None:
@@ -260,11 +351,9 @@ def measure_liouville(ctx, n=512, nc=2, reps=20):
                     ctx.tuning_set(k, override)
             for _ in range(3):
                 Lmf.mul(x, y)
-            ctx.sync()
-            ctx.timer_begin()
-            for _ in range(reps):
-                Lmf.mul(x, y)
-            res[name] = 1e3 * ctx.timer_end() / reps
+            regions = timed_regions(ctx, lambda: Lmf.mul(x, y), reps, 3)
+            sps[name] = spread([1e3 * r[0] / reps for r in regions], regions)
+            res[name] = sps[name]["median"]
     finally:
         for k, v in saved.items():
             ctx.tuning_set(k, v)
@@ -272,7 +361,8 @@ def measure_liouville(ctx, n=512, nc=2, reps=20):
                        f"{2 + 2 * nc} complex n x n products", "n": n, "c_ops": nc,
            "kernel": "zgemm_sum32_kernel (32 x 32 tile per workgroup, v_mfma_f64_16x16x4_f64)" if 260 <= n <= 2048
                      else "zgemm_sum_kernel (16 x 16 tile per workgroup)",
-           "us_per_apply": res["hand_written"], "tflops": flops / res["hand_written"] / 1e6,
+           "us_per_apply": res["hand_written"], "us_per_apply_min": sps["hand_written"]["min"], "us_per_apply_max": sps["hand_written"]["max"],
+           "repeats": 3, "unstable": sps["hand_written"]["unstable"], "tflops": flops / res["hand_written"] / 1e6,
            "frac_fp64_matrix_peak": flops / res["hand_written"] / 1e6 / 78.6,
            "us_per_apply_rocblas_chain": res["library_chain"], "tflops_rocblas_chain": flops / res["library_chain"] / 1e6}
     for h in (x, y, Lmf):

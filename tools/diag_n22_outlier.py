@@ -106,6 +106,18 @@ def main():
                 del big[:16]
                 rows.append(t)
             report(f"cycle {c} (d) host frees 128 MB of numpy buffers between repeats", rows)
+        # (e) the host side right after a LARGE operator has been destroyed (what precedes a point in bench.py's extras
+        # sequence): build and close a 2^23-row operator (1 GB of device memory freed), then time the 2^22 one at once
+        if c < 3:
+            Mb, opb, wrkb, psib = build(ctx, 23)
+            L.cheby(psib, opb, 1.0, wrkb)
+            ctx.sync()
+            for h in (psib, wrkb, opb, Mb):
+                h.close()
+            rows = [timed(ctx, psi, op, wrk, args.steps) for _ in range(args.repeats)]
+            report(f"cycle {c} (e) right after a 2^23-row operator was built, used and destroyed", rows)
+            worst = max(rows, key=lambda r: r[0])
+            print(f"    slowest region of (e): {worst[0]:.1f} us/term, host enqueue loop {worst[1]:.1f} ms, longest single call {worst[2]:.1f} ms")
         for h in (psi, wrk, op, M):
             h.close()
         print(f"    2^21 point of this cycle: {np.median([r[0] for r in r21]):.1f} us/term (median of 3 x 8 steps)")

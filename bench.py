@@ -885,8 +885,6 @@ def main():
             if pt.get("us_per_term"):
                 sizes[lg] = pt["us_per_term"]
         out["scaling_prediction"] = scaling_prediction(sizes, out["value"], nterms, "measured in this run on one GPU")
-    elif world > 1:
-        out["scaling_prediction"] = scaling_prediction_static(nterms)
     out["degraded"] = False
     out["native_path"] = "ok" if world > 1 else None
     if watchdog is not None:
@@ -901,6 +899,8 @@ def main():
         fallback["degraded"] = False
         fallback["native_path"] = "ok (slower than the conservative schedule)"
         out = fallback
+    if world > 1:      # the 1 / 2 / 4 / 8 table this run is to be read against (from the committed single-GPU measurements)
+        out["scaling_prediction"] = scaling_prediction_static(nterms)
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

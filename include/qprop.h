@@ -197,6 +197,28 @@ int qp_operator_walk_info(const qp_operator* op, int64_t out[8]);
 /* *glong = the long distance L (rows) of a walk plan with one further pair of distances +-L beyond its far reach
  * (a three-dimensional grid's plane distance; its operands are loaded directly), 0 if the plan has none / there is no plan */
 int qp_operator_walk_long(const qp_operator* op, int64_t* glong);
+/* WHY an operator does not take the strip walk (the fast path of the fused Chebyshev term is a cliff: the same banded
+ * operator costs 1.8 x as much per term on the per-block kernels): *code = QP_WALK_OK when it has a plan that its launches
+ * use, else what broke it; `text` (may be NULL) receives a sentence with the offending numbers ("near column distance 17
+ * exceeds the 16-row halo ..."), truncated to text_len.  The Python / Julia wrappers warn once per operator. */
+enum { QP_WALK_OK = 0,
+       QP_WALK_NOT_HERMITIAN = 1,   /* a term is not exactly Hermitian: no packed format, no walk (newton! does not need it) */
+       QP_WALK_COMPLEX_COEFF = 2,   /* a complex coefficient un-packed the operator (qp_operator_build_info counts the re-layout) */
+       QP_WALK_NOT_PACKED = 3,      /* Hermitian, but laid out otherwise (format forced, or AUTO found no L2 locality for the packing) */
+       QP_WALK_TOO_FEW_BLOCKS = 4,  /* fewer walkable row blocks than knob walk_min_blocks (3072): the per-block kernel is as fast there */
+       QP_WALK_NO_UNIFORM_RUN = 5,  /* rows do not repeat one list of column distances: not a lattice */
+       QP_WALK_ROW_LENGTH = 6,      /* fewer than 3 or more than 19 entries per row */
+       QP_WALK_NOT_MIRRORED = 7,    /* a column distance without its mirror image */
+       QP_WALK_NO_FAR = 8,          /* a plain band (no distance >= 64 rows): nothing to walk along */
+       QP_WALK_NO_NEAR = 9,
+       QP_WALK_NEAR_TOO_FAR = 10,   /* a near distance beyond the 16-row halo of the walk's window */
+       QP_WALK_TOO_MANY_NEAR = 11,  /* more than 4 near distances per side */
+       QP_WALK_TOO_MANY_FAR = 12,   /* more than 4 far distances per side (beyond one long pair) */
+       QP_WALK_INCOMMENSURATE = 13, /* far distances that are not multiples of one strip step (two strides) */
+       QP_WALK_NO_KERNEL = 14,      /* a shape without a kernel instance (long pair with more than 2 near / 1 far distances) */
+       QP_WALK_LAYOUT = 15,         /* the run's upper sections are not at equal strides / positions beyond 2^31 */
+       QP_WALK_DISABLED = 16 };     /* knob hrb_walk 0 */
+int qp_operator_walk_reason(const qp_operator* op, int* code, char* text, size_t text_len);
 /* How qp_cheby_step_batched will visit the rows for a panel of `batch` states (wave-per-row kernel,
  * more than 32 states): out[0] = inner dimension g detected in the pattern (far offsets are multiples of
  * g: H = H_a (x) 1 + 1 (x) H_c), out[1] = strip width (rows are visited strip by strip so that the gather

@@ -256,6 +256,16 @@ function operator_walk_long(op::Handle)
     return n[]
 end
 
+# Why the fused Chebyshev term of an operator does not take the strip walk (include/qprop.h: QP_WALK_*): (code, sentence);
+# code 0 = it does.  init_prop(...; method = :ChebyHIP) warns once for a large Hermitian operator that fell off the fast path.
+function operator_walk_reason(op::Handle)
+    code = Ref{Cint}(0)
+    text = zeros(UInt8, 256)
+    GC.@preserve text check(ccall((:qp_operator_walk_reason, LIB), Cint, (Ptr{Cvoid}, Ptr{Cint}, Ptr{UInt8}, Csize_t),
+        op, code, text, length(text)))
+    return Int(code[]), unsafe_string(pointer(text))
+end
+
 # explicit zeros that qp_operator_create added to complete a lattice operator's rows (open boundaries of a grid)
 function operator_fill_info(op::Handle)
     n = Ref{Int64}(0)
@@ -434,6 +444,11 @@ function init_prop(state, generator, tlist, ::Val{:ChebyHIP};
     ctx = state isa HIPState ? state.ctx : default_ctx(device)
     op = device_operator(ctx, G)
     N = length(state)
+    if N >= 64 * 3072                      # large enough for the strip walk (knob walk_min_blocks): say so if it is not taken
+        code, why = operator_walk_reason(op)
+        # 1 not Hermitian (newton! territory), 4 too few blocks, 16 switched off: nothing to report
+        (code in (0, 1, 4, 16)) || @warn "ChebyHIP: the operator does not take the strip walk (up to 1.8x per term): $why" maxlog = 1
+    end
     E_min, E_max = _envelope(ctx, op, G, N, control_ranges, specrange_method; specrange_kwargs...)
     Δ = E_max - E_min
     @assert Δ > 0.0

@@ -212,6 +212,9 @@ struct Tuning {
   int stencil = 1;            // operator build: encode blocks with block-wide column distances as stencil blocks
   int acc_defer = 1;          // qp_cheby_step: touch the Psi accumulator every third term only (1) or every term (0)
   int cheby_graph = 0;        // qp_cheby_step: replay a repeated step as a hipGraph when the mat-vec grid has at most this many workgroups (0: off; measured: no gain)
+  int newton_graph = 0;       // 1 = a Newton restart's Arnoldi columns are replayed from a hipGraph (recorded on the second identical sweep)
+  int arnoldi_l2_order = 1;   // 1 = the projection kernel owns the mat-vec's rows per XCD and reads rounds / basis vectors back to front (L2 reuse of what the dots pass read last)
+  int arnoldi_nt = 1;         // 1 = the fused Arnoldi mat-vec streams the matrix nontemporal (the L2 keeps basis vectors instead)
   int dense_auto = 1;         // 1 = AUTO lays an operator out dense (QP_FMT_DENSE) when at least dense_min_density_pct % of its positions are stored
   int dense_min_density_pct = 75;
   int dense_panel_mfma = 1;   // 1 = the batched step of a dense operator runs H X on the fp64 matrix cores (kernels_dense.hip); 0 = the sparse panel kernels (A/B)
@@ -369,7 +372,7 @@ int launch_mgs_lowsync(hipStream_t s, const double2* Q, int64_t ldq, int j, doub
                        double2* G, int ldg, double2* hess_col, double2* reduced, double2* coef, unsigned* ticket,
                        double2* norm_partials, double dt, int64_t n, Stats* st, bool solve_in_update = false,
                        unsigned* early_flag = nullptr, unsigned flag_value = 0, bool* early_armed = nullptr,
-                       bool dots_done = false);
+                       bool dots_done = false, bool l2_order = false);
 // the same in pieces for row-partitioned runs: local sums -> (all-reduce by the caller) ->
 // solve (one workgroup) + update
 int launch_mgs_multidot(hipStream_t s, const double2* Q, int64_t ldq, int j, const double2* w, double2* md_partials,

@@ -3,6 +3,7 @@
 #pragma once
 
 #include <vector>
+#include <string>
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -63,6 +64,8 @@ struct qp_operator {
   qp_ctx* ctx = nullptr;
   DevMatrix A;
   HostLayoutData layout;
+  int walk_reason = 0;            // QP_WALK_*: why the operator has no strip-walk plan (build_walk_plan)
+  std::string walk_reason_text;
   qp::WalkPlan walk;              // strip-walk plan of a Hermitian-packed lattice operator (A.walk points here when valid)
   qp::SpmmWalkPlan spmm_walk;     // strip-walk plan of the batched term, built on first use
   bool spmm_walk_built = false;
@@ -159,6 +162,21 @@ struct qp_krylov {
   unsigned* col_flags_map = nullptr;
   unsigned seq = 0;
   std::chrono::steady_clock::time_point t_last_column;   // when the host saw the last column of the latest sweep
+  // hipGraph of one sweep's column launches (knob newton_graph; engine_krylov.hip: arnoldi_impl)
+  struct SweepKey {
+    const void *op = nullptr, *vals = nullptr, *vals_r = nullptr, *bptr = nullptr;
+    int format = -1, m = 0, knobs = 0;
+    double dt = 0, norm_min = 0;
+    bool operator==(const SweepKey& o) const {
+      return op == o.op && vals == o.vals && vals_r == o.vals_r && bptr == o.bptr && format == o.format && m == o.m &&
+             knobs == o.knobs && dt == o.dt && norm_min == o.norm_min;
+    }
+  };
+  SweepKey sweep_key, sweep_pending;
+  hipGraphExec_t sweep_exec = nullptr;
+  Stats sweep_stats;
+  bool sweep_early = false;
+  int sweep_gram_rows = 0;
   double2* q(int i) const { return Q + (size_t)i * n; }
 };
 

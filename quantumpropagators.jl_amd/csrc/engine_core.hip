@@ -606,17 +606,55 @@ struct WalkShape {
   int64_t g = 0, glong = 0;
   int near[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
-static bool parse_walk_shape(const std::vector<int64_t>& dl, WalkShape& w) {
+// 0 = a shape the walk has a kernel for; else the QP_WALK_* code of what broke it (include/qprop.h), with the offending
+// numbers in *why
+static int walk_shape_reason(const std::vector<int64_t>& dl, WalkShape& w, std::string* why) {
+  auto say = [&](const char* fmt, long long a = 0, long long b = 0) {
+    if (why) {
+      char buf[160];
+      std::snprintf(buf, sizeof buf, fmt, a, b);
+      *why = buf;
+    }
+  };
   const int z = (int)dl.size();
-  if (z < 3 || z > 19) return false;
+  if (z < 3 || z > 19) {
+    say("%lld entries per row (the walk takes 3 to 19)", z);
+    return QP_WALK_ROW_LENGTH;
+  }
   for (int k = 0; k < z; ++k)
-    if (dl[(size_t)k] != -dl[(size_t)(z - 1 - k)]) return false;   // mirror images of each other
+    if (dl[(size_t)k] != -dl[(size_t)(z - 1 - k)]) {   // mirror images of each other
+      say("column distance %lld has no mirror image %lld in the row", dl[(size_t)k], -dl[(size_t)k]);
+      return QP_WALK_NOT_MIRRORED;
+    }
   int nbig = 0;
   while (nbig < z && dl[(size_t)nbig] <= -(int64_t)kRB) ++nbig;
-  if (nbig < 1 || nbig > 5) return false;
+  if (nbig < 1) {
+    say("no column distance of at least 64 rows: a band of half-width %lld has no strip step", -dl[0]);
+    return QP_WALK_NO_FAR;
+  }
+  // near part first: it decides between "too many / too far near" and the far diagnoses below
+  {
+    int k = nbig, nnear = 0;
+    while (k < z && dl[(size_t)k] < 0) ++k, ++nnear;
+    if (nnear >= 1 && -dl[(size_t)nbig] > qp::kWalkHalo) {
+      say("near column distance %lld exceeds the %lld-row halo of the walk's window", -dl[(size_t)nbig], qp::kWalkHalo);
+      return QP_WALK_NEAR_TOO_FAR;
+    }
+    if (nnear > 4) {
+      say("%lld near column distances per side (the walk takes 1 to 4)", nnear);
+      return QP_WALK_TOO_MANY_NEAR;
+    }
+    if (nnear < 1) {
+      say("no near column distance (the walk's kernels take 1 to 4 within %lld rows)", qp::kWalkHalo);
+      return QP_WALK_NO_NEAR;
+    }
+  }
+  if (nbig > 5) {
+    say("%lld far column distances per side (the walk takes up to 4 multiples of one stride, plus one long pair)", nbig);
+    return QP_WALK_TOO_MANY_FAR;
+  }
   w = WalkShape();
   w.g = -dl[(size_t)(nbig - 1)];
-  if (w.g < kRB) return false;
   auto multiples = [&](int first, int K) {
     for (int m = 1; m <= K; ++m)
       if (dl[(size_t)(first + K - m)] != -(int64_t)m * w.g) return false;
@@ -629,18 +667,28 @@ static bool parse_walk_shape(const std::vector<int64_t>& dl, WalkShape& w) {
     w.xl = 1;
     w.glong = -dl[0];
   } else {
-    return false;
+    long long bad = 0;
+    for (int i = 0; i < nbig; ++i)
+      if ((-dl[(size_t)i]) % w.g != 0) bad = -dl[(size_t)i];
+    if (bad) say("far column distance %lld is no multiple of the strip step %lld (two incommensurate strides)", bad, w.g);
+    else say("far column distances are multiples of %lld but not the consecutive ones 1 .. K, K <= 4 (largest: %lld)", w.g, -dl[0]);
+    return bad ? QP_WALK_INCOMMENSURATE : QP_WALK_TOO_MANY_FAR;
   }
   int k = nbig;
   while (k < z && dl[(size_t)k] < 0) ++k, ++w.nn;
-  if (w.nn < 1 || w.nn > 4) return false;
   for (int i = 0; i < w.nn; ++i) w.near[i] = (int)(-dl[(size_t)(nbig + w.nn - 1 - i)]);
-  for (int i = 0; i < w.nn; ++i)
-    if (w.near[i] <= 0 || w.near[i] > qp::kWalkHalo || (i > 0 && w.near[i] <= w.near[i - 1])) return false;
   w.z0 = (k < z && dl[(size_t)k] == 0) ? 1 : 0;
-  if (z != 2 * (w.nn + w.K + w.xl) + w.z0) return false;
-  return qp::walk_shape_supported(w.nn, w.K, w.z0, w.xl);
+  if (z != 2 * (w.nn + w.K + w.xl) + w.z0) {
+    say("row of %lld entries does not split into diagonal + near + far parts", z);
+    return QP_WALK_NOT_MIRRORED;
+  }
+  if (!qp::walk_shape_supported(w.nn, w.K, w.z0, w.xl)) {
+    say("no kernel instance for %lld near and %lld far distances with a long pair (the long pair comes with at most 2 near, 1 far)", w.nn, w.K);
+    return QP_WALK_NO_KERNEL;
+  }
+  return QP_WALK_OK;
 }
+static bool parse_walk_shape(const std::vector<int64_t>& dl, WalkShape& w) { return walk_shape_reason(dl, w, nullptr) == QP_WALK_OK; }
 
 static int build_walk_plan(qp_operator* op) {
   qp::WalkPlan& P = op->walk;
@@ -652,7 +700,17 @@ static int build_walk_plan(qp_operator* op) {
   const auto& ur = op->u_rowptr;
   const auto& uc = op->u_col;
   const int64_t nb = A.nblocks;
-  if (A.format != QP_FMT_HRB || nb < 8 || A.ncols < A.nrows) return QP_OK;   // (more columns than rows: the halo slabs of a row-partitioned operator)
+  auto why = [&](int code, const char* fmt, long long a = 0, long long b = 0) {
+    char buf[200];
+    std::snprintf(buf, sizeof buf, fmt, a, b);
+    op->walk_reason = code;
+    op->walk_reason_text = buf;
+    return QP_OK;
+  };
+  op->walk_reason = QP_WALK_OK;
+  op->walk_reason_text.clear();
+  if (A.format != QP_FMT_HRB) return why(QP_WALK_NOT_PACKED, "device format %lld is not the Hermitian-packed one", A.format);
+  if (nb < 8 || A.ncols < A.nrows) return why(QP_WALK_TOO_FEW_BLOCKS, "%lld row blocks (or fewer columns than rows)", nb);   // (more columns than rows: the halo slabs of a row-partitioned operator)
   const int64_t nfull = A.nrows / kRB;   // (a partly filled last block never belongs to the run)
   auto same_row = [&](int64_t r, int64_t ref) {   // same distances as row `ref`?
     const int64_t len = ur[ref + 1] - ur[ref];
@@ -682,28 +740,38 @@ static int build_walk_plan(qp_operator* op) {
     if (e - b > best1 - best0) best0 = b, best1 = e;
     b = std::max(e, b + 1);
   }
-  if (best1 - best0 < 8) return QP_OK;
+  if (best1 - best0 < 8)
+    return why(QP_WALK_NO_UNIFORM_RUN, "the longest run of row blocks whose rows all carry one list of column distances is %lld blocks (of %lld): not a lattice",
+               best1 - best0, nb);
   const int64_t R0 = best0, R1 = best1, rref = R0 * kRB;
   const int64_t z = ur[rref + 1] - ur[rref];
   std::vector<int64_t> dl((size_t)z);
   for (int64_t k = 0; k < z; ++k) dl[(size_t)k] = (int64_t)uc[ur[rref] + k] - rref;
   WalkShape ws;
-  if (!parse_walk_shape(dl, ws)) return QP_OK;
+  {
+    std::string text;
+    const int code = walk_shape_reason(dl, ws, &text);
+    if (code != QP_WALK_OK) {
+      op->walk_reason = code;
+      op->walk_reason_text = text;
+      return QP_OK;
+    }
+  }
   const int nn = ws.nn, K = ws.K, z0 = ws.z0, xl = ws.xl;
   const int64_t g = ws.g;
   for (int i = 0; i < nn; ++i) P.near[i] = ws.near[i];
   const int S = (int)((g + kRB - 1) / kRB);
   // first block whose rows find their history (K g rows back, L for the long pair) inside the run
   const int64_t W0 = R0 + (std::max<int64_t>((int64_t)K * g, ws.glong) + kRB - 1) / kRB;
-  if (R1 - W0 < 8) return QP_OK;
+  if (R1 - W0 < 8) return why(QP_WALK_TOO_FEW_BLOCKS, "%lld walkable row blocks after the first %lld of the run (whose history lies outside it)", R1 - W0, W0 - R0);
   // the upper section of every block of the run: z0 + nn + K entries per row, padded to a multiple of four, at equal strides
   const int64_t wu = ((z0 + nn + K + xl + 3) / 4) * 4;
   const int64_t U0 = Lh.bptr[R0], ustride = wu * kRB;
   for (int64_t b = R0; b <= R1; ++b)
-    if (Lh.bptr[b] != U0 + (b - R0) * ustride) return QP_OK;
+    if (Lh.bptr[b] != U0 + (b - R0) * ustride) return why(QP_WALK_LAYOUT, "upper sections of the run are not at equal strides (block %lld)", b);
   for (int64_t r = rref; r < R1 * kRB; r += kRB)
-    if (Lh.nlow[r] != nn + K + xl) return QP_OK;
-  if (U0 + (R1 - R0) * ustride >= (int64_t)INT32_MAX) return QP_OK;
+    if (Lh.nlow[r] != nn + K + xl) return why(QP_WALK_LAYOUT, "row %lld has %lld lower entries", r, Lh.nlow[r]);
+  if (U0 + (R1 - R0) * ustride >= (int64_t)INT32_MAX) return why(QP_WALK_LAYOUT, "value positions beyond 2^31");
   std::vector<int32_t> edge;
   for (int64_t b = 0; b < W0; ++b) edge.push_back((int32_t)b);
   for (int64_t b = R1; b < nb; ++b) edge.push_back((int32_t)b);
@@ -1479,6 +1547,49 @@ int qp_operator_walk_info(const qp_operator* op, int64_t out[8]) {
   out[6] = on ? P.R1 : 0;
   out[7] = on ? P.n_edge : 0;
   return QP_OK;
+}
+
+int qp_operator_walk_reason(const qp_operator* op, int* code, char* text, size_t text_len) {
+  QP_TRY
+  if (!op || !code) return qp::fail(QP_E_BAD_ARG, "qp_operator_walk_reason: NULL argument");
+  int c = QP_WALK_OK;
+  std::string why;
+  const qp::WalkPlan& P = op->walk;
+  const qp::Tuning& tun = op->ctx->tun;
+  if (op->A.format != QP_FMT_HRB) {
+    if (op->A.format == QP_FMT_MATFREE || op->A.format == QP_FMT_DENSE) {
+      c = QP_WALK_NOT_PACKED;
+      why = "a dense / matrix-free operator has no sparse lattice to walk";
+    } else if (!op->hermitian_planes) {
+      c = QP_WALK_NOT_HERMITIAN;
+      why = "a term of the operator is not exactly Hermitian (or a format other than AUTO / HRB was requested): no Hermitian-packed layout";
+    } else if (op->n_relayouts > 0) {
+      c = QP_WALK_COMPLEX_COEFF;
+      why = "a complex coefficient took the Hermitian-packed operator back to plain row blocks (qp_operator_build_info: re-layouts)";
+    } else {
+      c = QP_WALK_NOT_PACKED;
+      why = "Hermitian, but not laid out Hermitian-packed (transposed entries too far apart for the L2, irregular row blocks, or padding)";
+    }
+  } else if (!P.valid) {
+    c = op->walk_reason != QP_WALK_OK ? op->walk_reason : (int)QP_WALK_NO_UNIFORM_RUN;
+    why = op->walk_reason_text;
+  } else if (!tun.hrb_walk) {
+    c = QP_WALK_DISABLED;
+    why = "knob hrb_walk is 0";
+  } else if (P.R1 - P.W0 < tun.walk_min_blocks || P.R1 - P.W0 < P.S) {
+    c = QP_WALK_TOO_FEW_BLOCKS;
+    char buf[160];
+    std::snprintf(buf, sizeof buf, "%lld walkable row blocks, knob walk_min_blocks is %d: the per-block kernel runs (as fast at this size)",
+                  (long long)(P.R1 - P.W0), tun.walk_min_blocks);
+    why = buf;
+  }
+  *code = c;
+  if (text && text_len > 0) {
+    std::strncpy(text, why.c_str(), text_len - 1);
+    text[text_len - 1] = '\0';
+  }
+  return QP_OK;
+  QP_CATCH
 }
 
 int qp_operator_walk_long(const qp_operator* op, int64_t* glong) {

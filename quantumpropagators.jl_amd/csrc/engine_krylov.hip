@@ -76,6 +76,7 @@ int qp_krylov_destroy(qp_krylov* q) {
   if (q->mgs_coef) (void)hipFree(q->mgs_coef);
   if (q->ticket) (void)hipFree(q->ticket);
   for (hipEvent_t e : q->col_events) (void)hipEventDestroy(e);
+  if (q->sweep_exec) (void)hipGraphExecDestroy(q->sweep_exec);
   delete q;
   return QP_OK;
   QP_CATCH
@@ -142,7 +143,8 @@ int arnoldi_column(qp_operator* op, qp_krylov* q, int j, double dt, double2* hco
     return qp::launch_mgs_lowsync(ctx->stream, q->Q, q->n, j, w, q->md_part, q->gram, q->nvec, hcol,
                                   q->hcoef, q->mgs_coef, q->ticket, q->part + (size_t)((j + 1) & 1) * kRedBlocks, dt,
                                   q->n, &ctx->stats, ctx->tun.arnoldi_solve != 0, fold ? fold->early_flag : nullptr,
-                                  fold ? fold->flag_value : 0u, fold ? fold->early_armed : nullptr, dots_done);
+                                  fold ? fold->flag_value : 0u, fold ? fold->early_armed : nullptr, dots_done,
+                                  ctx->tun.arnoldi_l2_order != 0);
   }
   q->gram_rows = std::min(q->gram_rows, j);
   for (int i = 0; i <= j + 1; ++i) {                                              // :84-87
@@ -261,7 +263,40 @@ static int arnoldi_impl(qp_operator* op, qp_krylov* q, int m, const qp_state* ps
       QP_CHECK(dev_alloc(&q->raw[1], (size_t)q->n));
     }
     flags = fold && piped;
-    if (flags) q->seq = q->seq + 1 == 0 ? 1 : q->seq + 1;
+    // knob newton_graph: the columns of a folded, pipelined sweep (2 launches each + the last vector's normalisation) are
+    // captured once per (operator, m, dt) and replayed per restart.  A replayed launch carries the flag value it was
+    // captured with, so a graph sweep always announces its columns with kGraphSeq and the host clears the flags first
+    // (nothing of the previous sweep is in flight: its last kernel's last store was the flag the host waited for, or the
+    // stream was synchronised).  Breakdown, other operators, other m: eager launches as before.
+    constexpr unsigned kGraphSeq = 0x47525048u;
+    qp_krylov::SweepKey skey;
+    bool use_graph = false, record_graph = false;
+    if (flags && extended && ctx->tun.newton_graph != 0 && ctx->stream != nullptr) {   // (the null stream cannot be captured)
+      skey.op = op;
+      skey.vals = op->A.vals;
+      skey.vals_r = op->A.vals_r;
+      skey.bptr = op->A.bptr;
+      skey.format = op->A.format;
+      skey.m = m;
+      skey.dt = dt;
+      skey.norm_min = norm_min;
+      skey.knobs = ((((ctx->tun.arnoldi_mode * 2 + ctx->tun.arnoldi_fuse_dots) * 2 + ctx->tun.arnoldi_solve) * 2 + ctx->tun.arnoldi_l2_order) * 2 +
+                    ctx->tun.arnoldi_nt) * 64 + (ctx->tun.rbcsr_variant & 63);
+      use_graph = q->sweep_exec && skey == q->sweep_key;
+      record_graph = !use_graph && skey == q->sweep_pending;
+      if (!use_graph && !record_graph) q->sweep_pending = skey;
+    }
+    if (flags) {
+      if (use_graph || record_graph) {
+        q->seq = kGraphSeq;
+        std::memset(q->col_flags, 0, sizeof(unsigned) * (size_t)q->nvec * 2);
+        __atomic_thread_fence(__ATOMIC_RELEASE);
+      } else {
+        q->seq = q->seq + 1 == 0 ? 1 : q->seq + 1;
+        if (q->seq == kGraphSeq) q->seq++;
+      }
+    }
+    auto enqueue_columns = [&]() -> int {
     for (int j = 0; j < m; ++j) {
       double2* hcol = q->hess_map + (size_t)j * ldd;
       if (fold) {
@@ -298,6 +333,46 @@ static int arnoldi_impl(qp_operator* op, qp_krylov* q, int m, const qp_state* ps
         }
       }
       if (piped && !flags) QP_HIP(hipEventRecord(q->col_events[j], ctx->stream));
+    }
+    return QP_OK;
+    };
+    if (use_graph) {
+      QP_HIP(hipGraphLaunch(q->sweep_exec, ctx->stream));
+      ctx->stats.n_graph_launch++;
+      ctx->stats.n_matvec += q->sweep_stats.n_matvec;
+      ctx->stats.n_launch += q->sweep_stats.n_launch;
+      ctx->stats.spmv_bytes += q->sweep_stats.spmv_bytes;
+      early_last = q->sweep_early;
+      q->gram_rows = q->sweep_gram_rows;
+    } else if (record_graph) {
+      hipGraph_t graph = nullptr;
+      const Stats before = ctx->stats;
+      QP_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+      const int rc = enqueue_columns();
+      const hipError_t ec = hipStreamEndCapture(ctx->stream, &graph);
+      if (rc != QP_OK) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc;
+      }
+      QP_HIP(ec);
+      q->sweep_stats = Stats();
+      q->sweep_stats.n_matvec = ctx->stats.n_matvec - before.n_matvec;
+      q->sweep_stats.n_launch = ctx->stats.n_launch - before.n_launch;
+      q->sweep_stats.spmv_bytes = ctx->stats.spmv_bytes - before.spmv_bytes;
+      q->sweep_early = early_last;
+      q->sweep_gram_rows = q->gram_rows;
+      if (q->sweep_exec) {
+        (void)hipGraphExecDestroy(q->sweep_exec);
+        q->sweep_exec = nullptr;
+      }
+      const hipError_t ei = hipGraphInstantiate(&q->sweep_exec, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      QP_HIP(ei);
+      q->sweep_key = skey;
+      QP_HIP(hipGraphLaunch(q->sweep_exec, ctx->stream));
+      ctx->stats.n_graph_launch++;
+    } else {
+      QP_CHECK(enqueue_columns());
     }
   }
   const cplx* hh = reinterpret_cast<const cplx*>(q->h_hess);

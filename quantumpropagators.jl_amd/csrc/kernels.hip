@@ -1085,6 +1085,7 @@ int* tuning_field(Tuning& t, const char* key) {
       {"liouville_fused_n", &Tuning::liouville_fused_n}, {"liouville_tile32_n", &Tuning::liouville_tile32_n}, {"liouville_tile32_min_n", &Tuning::liouville_tile32_min_n}, {"real_vals", &Tuning::real_vals},
       {"stencil", &Tuning::stencil},             {"acc_defer", &Tuning::acc_defer},
       {"cheby_graph", &Tuning::cheby_graph},     {"small_nnz", &Tuning::small_nnz},
+      {"newton_graph", &Tuning::newton_graph}, {"arnoldi_l2_order", &Tuning::arnoldi_l2_order}, {"arnoldi_nt", &Tuning::arnoldi_nt},
       {"dense_auto", &Tuning::dense_auto},       {"dense_min_density_pct", &Tuning::dense_min_density_pct}, {"dense_panel_mfma", &Tuning::dense_panel_mfma},
       {"newton_pipeline", &Tuning::newton_pipeline}, {"spmm_tile", &Tuning::spmm_tile},
       {"spmm_nt", &Tuning::spmm_nt},             {"spmm_rows", &Tuning::spmm_rows},
@@ -1950,7 +1951,15 @@ struct MgsSolveArgs {
   unsigned flag_value = 0;
 };
 
-template <int BS, int EPL, bool SOLVE>
+// ORD (knob arnoldi_l2_order): the elements a workgroup owns and the order in which it reads the basis are chosen for the
+// XCD's L2.  The column's mat-vec with the dot products in its epilogue (kernels_arnoldi.hip) has just read the basis
+// vectors q_0 .. q_j, ascending, on the rows of ITS workgroups -- rows [t * 512 grid + 512 wg, + 512) in round t, wg =
+// xcd_remap(blockIdx) -- so each XCD's L2 holds the share of the LAST vectors of the LAST round.  ORD = true gives the
+// projection the same rows per (remapped) workgroup and walks rounds and basis vectors back to front: what the dots pass
+// read last is read first, out of L2 instead of the Infinity Cache; and it ends on q_0 of round 0, which is where the next
+// column's dots pass begins.  The coefficients are the solved ones either way (the sum w - sum_i h_i q_i in another order:
+// a rounding-level difference, deterministic).  ORD = false: the round-2 layout (element = blockIdx * BS + thread + k * 65536).
+template <int BS, int EPL, bool SOLVE, bool ORD>
 __global__ __launch_bounds__(BS) void mgs_update_kernel(double2* __restrict__ w, const double2* __restrict__ Q,
                                                         int64_t ldq, int j, const double2* __restrict__ coef,
                                                         double2* __restrict__ norm_partials, int64_t n, MgsSolveArgs sv) {
@@ -1960,8 +1969,15 @@ __global__ __launch_bounds__(BS) void mgs_update_kernel(double2* __restrict__ w,
   // the first round of the streams (this lane's elements of w and of the first four basis vectors) is requested BEFORE
   // the prologue below: the reduction + solve is a chain of L2 round trips and barriers (2-3 us) that needs no memory
   // pipe, and the coefficients are not needed before the first FMA
+  static_assert(!ORD || EPL == 2, "the ordered form takes two elements per lane and round");
   const int64_t stride = (int64_t)kRedBlocks * BS;
-  const int64_t ef0 = (int64_t)blockIdx.x * BS + threadIdx.x, ef1 = ef0 + stride;
+  // ORD: rounds of gridDim.x * 2 BS elements, this workgroup's 2 BS of the LAST round first
+  const int64_t per_round = (int64_t)gridDim.x * 2 * BS;
+  const int64_t nrounds = ORD ? (n + per_round - 1) / per_round : 0;
+  const int64_t ef0 = ORD ? (nrounds - 1) * per_round + (int64_t)xcd_remap(blockIdx.x, gridDim.x) * 2 * BS + threadIdx.x
+                          : (int64_t)blockIdx.x * BS + threadIdx.x;
+  const int64_t ef1 = ORD ? ef0 + BS : ef0 + stride;
+  const int pq0 = ORD ? j - 3 : 0;   // first of the four basis vectors requested ahead of the prologue
   const bool pre_on = ef0 < n, pre_two = EPL == 2 && ef1 < n, pre_q = j >= 3;
   double2 pr0 = make_double2(0.0, 0.0), pr1 = make_double2(0.0, 0.0), pa[4], pb[4];
 #pragma unroll
@@ -1972,8 +1988,8 @@ __global__ __launch_bounds__(BS) void mgs_update_kernel(double2* __restrict__ w,
     if (pre_q) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        pa[t] = Q[(size_t)t * ldq + ef0];
-        if (pre_two) pb[t] = Q[(size_t)t * ldq + ef1];
+        pa[t] = Q[(size_t)(pq0 + t) * ldq + ef0];
+        if (pre_two) pb[t] = Q[(size_t)(pq0 + t) * ldq + ef1];
       }
     }
   }
@@ -2020,6 +2036,50 @@ __global__ __launch_bounds__(BS) void mgs_update_kernel(double2* __restrict__ w,
     __syncthreads();
   }
   double nrm = 0.0;
+  if constexpr (ORD) {
+    for (int64_t e0 = ef0; e0 >= 0; e0 -= per_round) {   // rounds back to front
+      const int64_t e1 = e0 + BS;
+      const bool on = e0 < n, two = e1 < n;
+      const bool first = e0 == ef0;   // (the same for every lane of the workgroup)
+      if (!on) continue;              // (only in the last round, which comes first: lanes past the end)
+      double2 r0 = first ? pr0 : w[e0];
+      double2 r1 = first ? pr1 : (two ? w[e1] : make_double2(0.0, 0.0));
+      int i = j;
+      for (; i >= 3; i -= 4) {        // q_i, q_{i-1}, q_{i-2}, q_{i-3}: loaded as [i-3 .. i], applied from i downwards
+        double2 a[4], b[4];
+        if (first && i == j) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            a[t] = pa[t];
+            b[t] = pb[t];
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            a[t] = Q[(size_t)(i - 3 + t) * ldq + e0];
+            b[t] = two ? Q[(size_t)(i - 3 + t) * ldq + e1] : make_double2(0.0, 0.0);
+          }
+        }
+#pragma unroll
+        for (int t = 3; t >= 0; --t) {
+          cfma(r0, h[i - 3 + t], a[t]);
+          cfma(r1, h[i - 3 + t], b[t]);
+        }
+      }
+      for (; i >= 0; --i) {
+        const double2 a = Q[(size_t)i * ldq + e0];
+        const double2 b = two ? Q[(size_t)i * ldq + e1] : make_double2(0.0, 0.0);
+        cfma(r0, h[i], a);
+        cfma(r1, h[i], b);
+      }
+      w[e0] = r0;
+      nrm += r0.x * r0.x + r0.y * r0.y;
+      if (two) {
+        w[e1] = r1;
+        nrm += r1.x * r1.x + r1.y * r1.y;
+      }
+    }
+  } else {
   for (int64_t e0 = ef0; e0 < n; e0 += EPL * stride) {
     const int64_t e1 = e0 + stride;
     const bool two = EPL == 2 && e1 < n;
@@ -2061,6 +2121,7 @@ __global__ __launch_bounds__(BS) void mgs_update_kernel(double2* __restrict__ w,
       nrm += r1.x * r1.x + r1.y * r1.y;
     }
   }
+  }
   // block sum over BS / 64 wavefronts in wave order
   double v = wave_sum(nrm);
   const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
@@ -2096,7 +2157,7 @@ int launch_mgs_multidot(hipStream_t s, const double2* Q, int64_t ldq, int j, con
 static int launch_mgs_update(hipStream_t s, const double2* Q, int64_t ldq, int j, double2* w, const double2* coef,
                              double2* norm_partials, int64_t n, Stats* st) {
   const size_t shmem = sizeof(double2) * (size_t)(j + 1 + kThreads / 64);
-  hipLaunchKernelGGL((mgs_update_kernel<kThreads, 2, false>), dim3(kRedBlocks), dim3(kThreads), shmem, s, w, Q, ldq, j, coef,
+  hipLaunchKernelGGL((mgs_update_kernel<kThreads, 2, false, false>), dim3(kRedBlocks), dim3(kThreads), shmem, s, w, Q, ldq, j, coef,
                      norm_partials, n, MgsSolveArgs{});
   QP_HIP(hipGetLastError());
   if (st) st->n_launch++;
@@ -2116,7 +2177,7 @@ int launch_mgs_project(hipStream_t s, const double2* Q, int64_t ldq, int j, doub
 int launch_mgs_lowsync(hipStream_t s, const double2* Q, int64_t ldq, int j, double2* w, double2* md_partials,
                        double2* G, int ldg, double2* hess_col, double2* reduced, double2* coef, unsigned* ticket,
                        double2* norm_partials, double dt, int64_t n, Stats* st, bool solve_in_update,
-                       unsigned* early_flag, unsigned flag_value, bool* early_armed, bool dots_done) {
+                       unsigned* early_flag, unsigned flag_value, bool* early_armed, bool dots_done, bool l2_order) {
   if (!dots_done) {   // (else: the mat-vec left the partials, kernels_arnoldi.hip)
     int rc = launch_multidot(s, Q, ldq, j, w, md_partials, n, st);
     if (rc != QP_OK) return rc;
@@ -2125,8 +2186,12 @@ int launch_mgs_lowsync(hipStream_t s, const double2* Q, int64_t ldq, int j, doub
   if (solve_in_update && mgs_solve_lds(j) <= 12 * 1024) {   // j <= 35: reduction + solve in the projection's prologue
     if (early_armed) *early_armed = early_flag != nullptr;
     const size_t shmem = sizeof(double2) * (size_t)(j + 1 + kThreads / 64 + j + 1) + mgs_solve_lds(j);
-    hipLaunchKernelGGL((mgs_update_kernel<kThreads, 2, true>), dim3(kRedBlocks), dim3(kThreads), shmem, s, w, Q, ldq, j, coef,
-                       norm_partials, n, MgsSolveArgs{md_partials, G, ldg, hess_col, dt, early_flag, flag_value});
+    if (l2_order)
+      hipLaunchKernelGGL((mgs_update_kernel<kThreads, 2, true, true>), dim3(kRedBlocks), dim3(kThreads), shmem, s, w, Q, ldq, j, coef,
+                         norm_partials, n, MgsSolveArgs{md_partials, G, ldg, hess_col, dt, early_flag, flag_value});
+    else
+      hipLaunchKernelGGL((mgs_update_kernel<kThreads, 2, true, false>), dim3(kRedBlocks), dim3(kThreads), shmem, s, w, Q, ldq, j, coef,
+                         norm_partials, n, MgsSolveArgs{md_partials, G, ldg, hess_col, dt, early_flag, flag_value});
     QP_HIP(hipGetLastError());
     if (st) st->n_launch++;
     return QP_OK;

@@ -19,7 +19,10 @@ namespace qp {
 
 constexpr int kFusedWaves = 8;
 
-template <int JT, class VT>   // VT: double2, or double for the real copy of an all-real operator (kernel_common.h: ld_val)
+// NT (knob arnoldi_nt): the matrix values and column sections are loaded nontemporal -- the matrix is read once per
+// column and does not fit an XCD's L2 next to the basis; streamed, it leaves the L2 to the basis vectors that the
+// projection kernel reads next (kernels.hip: mgs_update_kernel<.., ORD = true>)
+template <int JT, class VT, bool NT>   // VT: double2, or double for the real copy of an all-real operator (kernel_common.h: ld_val)
 __global__ __launch_bounds__(64 * kFusedWaves) void arnoldi_matvec_dots_kernel(
     const int64_t* __restrict__ bptr, const int64_t* __restrict__ cmeta, const char* __restrict__ colbytes,
     const VT* __restrict__ vals, const double2* __restrict__ x, int64_t nblocks, int64_t nrows, PlainEpi e,
@@ -62,11 +65,11 @@ __global__ __launch_bounds__(64 * kFusedWaves) void arnoldi_matvec_dots_kernel(
     double2 s0 = make_double2(0.0, 0.0), s1 = make_double2(0.0, 0.0);
 #pragma unroll 2
     for (int q = 0; q < nq; ++q) {
-      const int4 cc = ld_cols<false>(colbytes, cm, q, lane, (int)rowc);
-      const double2 a0 = ld_val<false>(v + (size_t)(4 * q + 0) * 64);
-      const double2 a1 = ld_val<false>(v + (size_t)(4 * q + 1) * 64);
-      const double2 a2 = ld_val<false>(v + (size_t)(4 * q + 2) * 64);
-      const double2 a3 = ld_val<false>(v + (size_t)(4 * q + 3) * 64);
+      const int4 cc = ld_cols<NT>(colbytes, cm, q, lane, (int)rowc);
+      const double2 a0 = ld_val<NT>(v + (size_t)(4 * q + 0) * 64);
+      const double2 a1 = ld_val<NT>(v + (size_t)(4 * q + 1) * 64);
+      const double2 a2 = ld_val<NT>(v + (size_t)(4 * q + 2) * 64);
+      const double2 a3 = ld_val<NT>(v + (size_t)(4 * q + 3) * 64);
       const double2 x0 = x[cc.x];
       const double2 x1 = x[cc.y];
       const double2 x2 = x[cc.z];
@@ -187,15 +190,23 @@ __global__ __launch_bounds__(64 * kFusedWaves) void arnoldi_matvec_dots_kernel(
   }
 }
 
+template <int JT, bool NT>
+static void launch_instance_nt(hipStream_t s, const DevMatrix& A, const double2* x, const PlainEpi& e, const double2* Q,
+                               int64_t ldq, int j, double2* partials) {
+  if (A.vals_r)
+    hipLaunchKernelGGL((arnoldi_matvec_dots_kernel<JT, double, NT>), dim3(kRedBlocks), dim3(64 * kFusedWaves), 0, s, A.bptr,
+                       A.cmeta, reinterpret_cast<const char*>(A.cols), A.vals_r, x, A.nblocks, A.nrows, e, Q, ldq, j, partials);
+  else
+    hipLaunchKernelGGL((arnoldi_matvec_dots_kernel<JT, double2, NT>), dim3(kRedBlocks), dim3(64 * kFusedWaves), 0, s, A.bptr,
+                       A.cmeta, reinterpret_cast<const char*>(A.cols), A.vals, x, A.nblocks, A.nrows, e, Q, ldq, j, partials);
+}
 template <int JT>
 static void launch_instance(hipStream_t s, const DevMatrix& A, const double2* x, const PlainEpi& e, const double2* Q,
                             int64_t ldq, int j, double2* partials) {
-  if (A.vals_r)
-    hipLaunchKernelGGL((arnoldi_matvec_dots_kernel<JT, double>), dim3(kRedBlocks), dim3(64 * kFusedWaves), 0, s, A.bptr,
-                       A.cmeta, reinterpret_cast<const char*>(A.cols), A.vals_r, x, A.nblocks, A.nrows, e, Q, ldq, j, partials);
-  else
-    hipLaunchKernelGGL((arnoldi_matvec_dots_kernel<JT, double2>), dim3(kRedBlocks), dim3(64 * kFusedWaves), 0, s, A.bptr,
-                       A.cmeta, reinterpret_cast<const char*>(A.cols), A.vals, x, A.nblocks, A.nrows, e, Q, ldq, j, partials);
+  // (only where the operator is large enough for the question to exist: a small one sits in the L2 with its basis)
+  const bool nt = A.tun && A.tun->arnoldi_nt != 0 && (double)A.stored * (A.vals_r ? 8.0 : 16.0) > 8.0 * 1024 * 1024;
+  if (nt) launch_instance_nt<JT, true>(s, A, x, e, Q, ldq, j, partials);
+  else launch_instance_nt<JT, false>(s, A, x, e, Q, ldq, j, partials);
 }
 
 // the largest j (basis vectors 0 .. j) with a kernel instance

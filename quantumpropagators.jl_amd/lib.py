@@ -27,6 +27,13 @@ STATUS = {
 LAYOUT_CSR, LAYOUT_CSC = 0, 1
 VAL_C128, VAL_F64 = 0, 1
 FMT_AUTO, FMT_CSR, FMT_RBCSR, FMT_HRB, FMT_MATFREE, FMT_DENSE = 0, 1, 2, 3, 4, 5
+WALK_REASONS = {0: "ok", 1: "not_hermitian", 2: "complex_coefficient", 3: "not_packed", 4: "too_few_blocks", 5: "no_uniform_run",
+                6: "row_length", 7: "not_mirrored", 8: "no_far_distance", 9: "no_near_distance", 10: "near_too_far", 11: "too_many_near",
+                12: "too_many_far", 13: "incommensurate_strides", 14: "no_kernel_instance", 15: "layout", 16: "disabled"}
+
+
+class QPPerformanceWarning(UserWarning):
+    """An operator left a fast path (e.g. the strip walk of the fused Chebyshev term); results are unaffected."""
 FUNC_EXPMI, FUNC_EXP, FUNC_CALLBACK = 0, 1, 2
 
 
@@ -128,6 +135,7 @@ SIGNATURES = {
     "qp_operator_walk_info": (C.c_int, [_P, _i64p]),
     "qp_operator_fill_info": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "qp_operator_walk_long": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "qp_operator_walk_reason": (C.c_int, [_P, C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
     "qp_lattice_fill_host": (C.c_int, [C.c_int64, C.c_int64, _i64p, _i32p, C.c_int, _i64p, _i32p, C.c_int64, C.POINTER(C.c_int64)]),
     "qp_operator_spmm_walk": (C.c_int, [_P, C.c_int, _i64p]),
     "qp_state_create": (C.c_int, [_P, C.c_int64, C.POINTER(_P)]),
@@ -557,6 +565,14 @@ class Operator:
         d["long_distance"] = gl.value        # rows; 0: no long pair (three-dimensional grids have one: the plane distance)
         return d
 
+    def walk_reason(self):
+        """(code, name, sentence): why the fused Chebyshev term of this operator does not take the strip walk -- QP_WALK_OK
+        ("ok") when it does (include/qprop.h: qp_operator_walk_reason)."""
+        code = C.c_int(0)
+        buf = C.create_string_buffer(256)
+        check(self.lib.qp_operator_walk_reason(self._h, C.byref(code), buf, len(buf)))
+        return code.value, WALK_REASONS.get(code.value, str(code.value)), buf.value.decode()
+
     def spmm_walk(self, batch):
         """Row walk of the batched kernel for ``batch`` states: (inner dimension, strip width), (0, 0)
         for the natural row order."""
@@ -829,9 +845,26 @@ class ChebyWrk:
 def cheby(psi, H, dt, wrk, E_min=None, check_normalization=False):
     """``cheby!(psi, H, dt, wrk; E_min, check_normalization)`` on the device."""
     E_min = wrk.E_min if E_min is None else E_min
+    if not getattr(H, "_walk_checked", False):
+        _warn_if_off_the_walk(H)
     check(wrk.lib.qp_cheby_step(wrk._h, H._h, psi._h, _ptr(wrk.coeffs, _dp), wrk.n_coeffs, wrk.Delta,
                                 float(E_min), float(dt), wrk.dt, wrk.limit, int(check_normalization)))
     return psi
+
+
+def _warn_if_off_the_walk(H):
+    """Once per operator: a Hermitian sparse operator large enough for the strip walk (knob walk_min_blocks) that does not
+    take it pays up to 1.8 x per fused term on the per-block kernels -- say which property of its stencil broke the plan."""
+    H._walk_checked = True
+    try:
+        if H.format not in (FMT_HRB, FMT_RBCSR, FMT_CSR) or H.shape[0] < 64 * H.ctx.tuning_get("walk_min_blocks"):
+            return
+        code, name, text = H.walk_reason()
+    except Exception:       # an information query must never take a step down
+        return
+    if name not in ("ok", "not_hermitian", "too_few_blocks", "disabled"):
+        import warnings
+        warnings.warn(f"cheby!: this operator does not take the strip walk [{name}]: {text}", QPPerformanceWarning, stacklevel=3)
 
 
 def cheby_batched(psi_panel, H, dt, wrk, batch, E_min=None):

@@ -1099,6 +1099,42 @@ def test_newton_c3_full_size(ctx):
     assert wrk.restarts == owrk.restarts, (wrk.restarts, owrk.restarts)
 
 
+@pytest.mark.parametrize("l2_order,nt,graph", [(0, 0, 0), (1, 0, 0), (0, 1, 0), (1, 1, 0), (1, 1, 1), (0, 0, 1)])
+@pytest.mark.parametrize("n", [96, 200])
+def test_newton_sweep_knobs_match_oracle(ctx, l2_order, nt, graph, n):
+    """The round-4 forms of the Arnoldi sweep -- the projection kernel on the mat-vec's rows per XCD, reading rounds and
+    basis vectors back to front (arnoldi_l2_order), the matrix streamed nontemporal in the fused mat-vec (arnoldi_nt), the
+    columns of a restart replayed from a hipGraph (newton_graph: recorded on the second identical sweep, so several steps
+    are run) -- against the oracle: |delta psi| < 1e-10 after every step, the restart counts equal; n = 200 (N = 40000) has
+    two rounds of row blocks per workgroup with a partly filled last one."""
+    Lm = synth.liouvillian_tridiag(n)
+    N = Lm.shape[0]
+    rho0 = synth.random_state(N)
+    saved = {k: ctx.tuning_get(k) for k in ("arnoldi_l2_order", "arnoldi_nt", "newton_graph")}
+    try:
+        ctx.tuning_set("arnoldi_l2_order", l2_order)
+        ctx.tuning_set("arnoldi_nt", nt)
+        ctx.tuning_set("newton_graph", graph)
+        Op = L.Operator(ctx, [L.Matrix.from_scipy(ctx, Lm)])
+        wrk = L.NewtonWrk(ctx, N, m_max=12)
+        rho = L.State(ctx, data=rho0)
+        owrk = qo.NewtonWrk(rho0, m_max=12)
+        ref = rho0.copy()
+        ctx.reset_stats()
+        for step, dt in enumerate((0.5, 0.5, 0.5, -0.5, 0.3)):      # (another dt: another graph)
+            L.newton(rho, Op, dt, wrk)
+            qo.newton(ref, Lm, dt, owrk)
+            assert np.linalg.norm(rho.numpy() - ref) < TOL, step
+            assert wrk.restarts == owrk.restarts, (step, wrk.restarts, owrk.restarts)
+        if graph:
+            assert ctx.stats()["n_graph_launches"] >= 3
+        else:
+            assert ctx.stats()["n_graph_launches"] == 0
+    finally:
+        for k, v in saved.items():
+            ctx.tuning_set(k, v)
+
+
 def test_batched_c5_full_size_properties(ctx):
     """BASELINE configs[4] at full size: 64 states x N = 2^18.  Three columns of the panel against the C restatement of
     the reference's serial CSC path (oracle/cheby_ref.c, ~0.15 s of one core each) -- the oracle DIRECTLY at the full
@@ -1900,3 +1936,68 @@ def test_host_register_pinned_transfers(ctx):
         L.host_unregister(pinned)
     with pytest.raises(L.QPError):
         L.host_unregister(np.empty(16, dtype=np.complex128))     # was never registered
+
+
+def test_walk_reason_says_what_broke_the_plan(ctx):
+    """qp_operator_walk_reason: the fused term's fast path is a cliff; an operator that falls off it is told why, with the
+    offending numbers (VERDICT r03 weak #6).  One operator per way of falling, plus the ones that walk."""
+    import warnings
+    ctx.tuning_set("walk_min_blocks", 64)
+    try:
+        N = 1 << 14
+
+        def reason(offsets, fmt=L.FMT_AUTO, hermitian=True, coeff=None):
+            rp, col, vals = synth.hermitian_offsets_csr(N, offsets=offsets)
+            if not hermitian:
+                vals = vals * (1.0 + 0.5 * (np.arange(len(vals)) % 3 == 0))
+            op = L.Operator(ctx, [L.Matrix(ctx, N, N, rp, col, vals)], 1 if coeff is not None else 0, fmt)
+            if coeff is not None:
+                op.set_coeffs([coeff])
+            r = op.walk_reason()
+            return op, r
+
+        op, r = reason((1, 2, 3, 4, 256, 512, 768, 1024))
+        assert r[0] == 0 and r[1] == "ok" and op.walk_info()["valid"] == 1
+        op, r = reason((1, 17, 256))
+        assert r[1] == "near_too_far" and "17" in r[2] and op.walk_info()["valid"] == 0
+        op, r = reason((1, 2, 3, 4, 5, 256))
+        assert r[1] == "too_many_near" and "5 near" in r[2]
+        op, r = reason((1, 256, 512, 768, 1024, 1280))
+        assert r[1] == "too_many_far"
+        op, r = reason((1, 256, 600))
+        assert r[1] == "incommensurate_strides" and "600" in r[2] and "256" in r[2]
+        op, r = reason((1, 2, 3))
+        assert r[1] == "no_far_distance"
+        op, r = reason((256, 512))
+        assert r[1] == "no_near_distance"
+        op, r = reason((1, 2, 256), hermitian=False)
+        assert r[1] == "not_hermitian"
+        op, r = reason((1, 2, 256), fmt=L.FMT_RBCSR)
+        assert r[1] in ("not_hermitian", "not_packed")          # (a forced plain format is not checked for Hermiticity)
+        op, r = reason((1, 2, 256), coeff=1.0)
+        assert r[1] == "ok"
+        op.set_coeffs([1.0 + 0.5j])                              # a complex coefficient un-packs the operator
+        assert op.walk_reason()[1] == "complex_coefficient" and op.build_info()["relayouts"] == 1
+        ctx.tuning_set("walk_min_blocks", 3072)
+        op, r = reason((1, 2, 256))
+        assert r[1] == "too_few_blocks" and "3072" in r[2]
+        ctx.tuning_set("hrb_walk", 0)
+        ctx.tuning_set("walk_min_blocks", 64)
+        op, r = reason((1, 2, 256))
+        assert r[1] == "disabled"
+        ctx.tuning_set("hrb_walk", 1)
+        # the Python wrapper warns once, at the first cheby! of a large operator that fell off for a reason worth telling
+        N2 = 64 * 80
+        rp, col, vals = synth.hermitian_offsets_csr(N2, offsets=(1, 17, 256))
+        opw = L.Operator(ctx, [L.Matrix(ctx, N2, N2, rp, col, vals)])
+        wrk = L.ChebyWrk(ctx, N2, 20.0, -10.0, 0.1)
+        psi = L.State(ctx, data=synth.random_state(N2))
+        with warnings.catch_warnings(record=True) as got:
+            warnings.simplefilter("always")
+            L.cheby(psi, opw, 0.1, wrk)
+            L.cheby(psi, opw, 0.1, wrk)
+        msgs = [w for w in got if issubclass(w.category, L.QPPerformanceWarning)]
+        assert len(msgs) == 1 and "near_too_far" in str(msgs[0].message)
+    finally:
+        ctx.tuning_set("walk_min_blocks", 3072)
+        ctx.tuning_set("hrb_walk", 1)

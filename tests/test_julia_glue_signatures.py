@@ -99,6 +99,8 @@ def jl_class(t):
         return "ptr:ptr"
     if inner == "Cvoid":
         return "ptr:void"
+    if inner == "UInt8":          # a caller-owned character buffer the library writes into (char* text, size_t len)
+        return "cstring"
     if inner in JL_SCALARS:
         return "ptr:" + JL_SCALARS[inner]
     return "ptr:struct:" + JL_STRUCTS.get(inner, inner)

@@ -90,6 +90,9 @@ enum { QP_SPECRANGE_ARNOLDI = 0, QP_SPECRANGE_DIAG = 1 };
 const char* qp_last_error(void);
 const char* qp_status_name(int status);
 int qp_version(void);
+/* 1 for the developer flavour of the library (csrc: `make dev`, -DQP_DEVELOPER), which accepts the measurement-only settings
+ * that change results or force a time-out (knobs walk_dbg bit 1, split_dbg); the release build refuses them. */
+int qp_developer_build(void);
 int qp_device_count(int* n_out);
 /* Developer knobs for A/B kernel experiments (e.g. "rbcsr_variant": bit0 nt matrix loads, bit1 early
  * row-local loads, bit2 deeper unroll; the full list is `struct Tuning` in csrc/device.h); not part of
@@ -197,6 +200,11 @@ int qp_operator_walk_info(const qp_operator* op, int64_t out[8]);
 /* *glong = the long distance L (rows) of a walk plan with one further pair of distances +-L beyond its far reach
  * (a three-dimensional grid's plane distance; its operands are loaded directly), 0 if the plan has none / there is no plan */
 int qp_operator_walk_long(const qp_operator* op, int64_t* glong);
+/* How evaluate! (qp_operator_set_coeffs / _set_scale) updates the stored values: out[0] = index of the first of the trailing
+ * control terms that are kept as (position, value) lists because they touch at most a quarter of the stored values (a dipole
+ * operator on a grid is a diagonal), -1 if there are none; out[1] = positions such an update rewrites; out[2] = 1 if the latest
+ * update rewrote only those positions (knob sparse_controls; the full combination otherwise). */
+int qp_operator_evaluate_info(const qp_operator* op, int64_t out[3]);
 /* WHY an operator does not take the strip walk (the fast path of the fused Chebyshev term is a cliff: the same banded
  * operator costs 1.8 x as much per term on the per-block kernels): *code = QP_WALK_OK when it has a plan that its launches
  * use, else what broke it; `text` (may be NULL) receives a sentence with the offending numbers ("near column distance 17

@@ -212,6 +212,7 @@ struct Tuning {
   int stencil = 1;            // operator build: encode blocks with block-wide column distances as stencil blocks
   int acc_defer = 1;          // qp_cheby_step: touch the Psi accumulator every third term only (1) or every term (0)
   int cheby_graph = 0;        // qp_cheby_step: replay a repeated step as a hipGraph when the mat-vec grid has at most this many workgroups (0: off; measured: no gain)
+  int roctx = 0;              // 1 = named profiler ranges around the steps' phases (qprop_internal.h: ScopedRange); also QP_ROCTX=1
   int newton_graph = 0;       // 1 = a Newton restart's Arnoldi columns are replayed from a hipGraph (recorded on the second identical sweep)
   int arnoldi_l2_order = 1;   // 1 = the projection kernel owns the mat-vec's rows per XCD and reads rounds / basis vectors back to front (L2 reuse of what the dots pass read last)
   int arnoldi_nt = 1;         // 1 = the fused Arnoldi mat-vec streams the matrix nontemporal (the L2 keeps basis vectors instead)

@@ -102,6 +102,7 @@ struct qp_operator {
   double2* base = nullptr;
   std::vector<double2> base_eff;
   bool base_valid = false, base_real = false;
+  bool last_refresh_sparse = false;   // the latest evaluate! rewrote only the sparse control terms' positions
   bool planes_real = false;       // every value of every term has a zero imaginary part
   double* real_vals = nullptr;    // device copy of the real parts of the current values (see DevMatrix::vals_r)
   const double2* real_of = nullptr;  // the complex array real_vals was extracted from, when still valid

@@ -170,7 +170,10 @@ static int cheby_step_launches(qp_cheby* w, qp_operator* op, qp_state* psi, cons
     e.apply_phase = last ? 1 : 0;
     // the reference checks terms i >= 3 only (inside the loop at :186)
     e.check_partials = (check_normalization && m >= 2) ? w->chk_part : nullptr;
-    QP_CHECK(qp::launch_spmv_cheby(ctx->stream, A, x, e, &ctx->stats));
+    {
+      const qp::ScopedRange mv_range(ctx->tun.roctx != 0 || qp::ranges_enabled_by_env(), "matrix-vector product");   // src/cheby.jl:175, :189
+      QP_CHECK(qp::launch_spmv_cheby(ctx->stream, A, x, e, &ctx->stats));
+    }
     if (e.check_partials)
       QP_CHECK(qp::launch_reduce_triples(ctx->stream, w->chk_part, nwg, w->chk_out + 3 * (m - 1), &ctx->stats));
     if (m == 1) c *= 2.0;  // :184
@@ -196,6 +199,7 @@ int qp_cheby_step(qp_cheby* w, qp_operator* op, qp_state* psi, const double* a, 
   if (!(Delta > 0)) return qp::fail(QP_E_BAD_ARG, "Delta must be positive");
   qp_ctx* ctx = op->ctx;
   QP_CHECK(use(ctx));
+  const qp::ScopedRange step_range(ctx->tun.roctx != 0 || qp::ranges_enabled_by_env(), "prop_step!");   // src/cheby_propagator.jl:349
   const double beta = (Delta / 2) + E_min;                        // :156
   cplx c = (dt > 0) ? cplx(0, -2.0) / Delta : cplx(0, 2.0) / Delta;  // :158-162
   const cplx phase = std::exp(cplx(0, -1) * beta * dt);            // :211
@@ -621,7 +625,11 @@ int qp_cheby_term_split(qp_operator* op, qp_split* sp, void* boundary_stream, in
     ri.sync.wait_from_wg = sp->wait_from_wg;
     ri.sync.timeout_flag = sp->timeout_dev;
     ri.sync.spin_limit = 1u << std::min(std::max(op->ctx->tun.split_spin_log2, 4), 31);
-    rb.sync.signal = (op->ctx->tun.split_dbg & 1) ? nullptr : sp->counter;
+#ifdef QP_DEVELOPER
+    rb.sync.signal = (op->ctx->tun.split_dbg & 1) ? nullptr : sp->counter;   // (time-out test: the boundary launch does not signal)
+#else
+    rb.sync.signal = sp->counter;
+#endif
     sp->signals_issued += (unsigned)((sp->n_boundary + qp::kThreads / 64 - 1) / (qp::kThreads / 64));
   }
   qp::ChebyEpi eb = e;

@@ -88,10 +88,34 @@ int qp_version(void) { return 100; }
 static std::mutex g_tuning_mutex;
 static qp::Tuning g_tuning_defaults;
 
+// Settings that change RESULTS (walk_dbg bit 1: the edge blocks of the strip walk are skipped) or force a failure
+// (split_dbg: the boundary launches of a split term do not signal, every waiting wavefront runs into the time-out) exist for
+// measurements and for the time-out test only: a release build refuses them; `make dev` (-DQP_DEVELOPER) builds the flavour
+// that takes them (lib/libqprop_hip_dev.so, loaded with QPROP_HIP_LIB).
+static int tuning_value_allowed(const char* key, int value) {
+#ifndef QP_DEVELOPER
+  if ((std::strcmp(key, "walk_dbg") == 0 && (value & 2)) || (std::strcmp(key, "split_dbg") == 0 && value != 0))
+    return qp::fail(QP_E_BAD_ARG, "%s = %d is a developer-build setting (csrc: make dev; it changes results or forces a time-out)", key, value);
+#endif
+  (void)key;
+  (void)value;
+  return QP_OK;
+}
+
 extern "C" {
+
+/* 1 for the developer flavour of the library (-DQP_DEVELOPER), 0 for the release build */
+int qp_developer_build(void) {
+#ifdef QP_DEVELOPER
+  return 1;
+#else
+  return 0;
+#endif
+}
 
 int qp_tuning_set(const char* key, int value) {
   if (!key) return qp::fail(QP_E_BAD_ARG, "key is NULL");
+  QP_CHECK(tuning_value_allowed(key, value));
   std::lock_guard<std::mutex> lock(g_tuning_mutex);
   int* f = qp::tuning_field(g_tuning_defaults, key);
   if (!f) return qp::fail(QP_E_BAD_ARG, "unknown tuning key %s", key);
@@ -101,6 +125,7 @@ int qp_tuning_set(const char* key, int value) {
 
 int qp_ctx_tuning_set(qp_ctx* ctx, const char* key, int value) {
   if (!ctx || !key) return qp::fail(QP_E_BAD_ARG, "qp_ctx_tuning_set: NULL argument");
+  QP_CHECK(tuning_value_allowed(key, value));
   int* f = qp::tuning_field(ctx->tun, key);
   if (!f) return qp::fail(QP_E_BAD_ARG, "unknown tuning key %s", key);
   *f = value;
@@ -1426,13 +1451,20 @@ static int operator_refresh(qp_operator* op) {
     if (!same && want_real) QP_CHECK(qp::launch_real_part(ctx->stream, op->real_vals, op->combined, op->A.stored, &ctx->stats));
     op->A.vals = op->combined;
     op->real_of = nullptr;
+    op->last_refresh_sparse = true;
   } else if (op->nops == 1 && all_one) {
+    op->last_refresh_sparse = false;
+    op->base_valid = false;   // (`combined` is not what the sparse update left: the next sparse update rebuilds its base)
     op->A.vals = op->planes[0];
     if (want_real && op->real_of != op->A.vals) {   // a plane never changes: extract once
       QP_CHECK(qp::launch_real_part(ctx->stream, op->real_vals, op->A.vals, op->A.stored, &ctx->stats));
       op->real_of = op->A.vals;
     }
   } else {
+    // the full combination rewrites `combined` with THESE coefficients everywhere: whatever the sparse update's base was
+    // built for no longer describes it (knob sparse_controls switched off and on again on a live operator)
+    op->base_valid = false;
+    op->last_refresh_sparse = false;
     if (!op->combined) QP_CHECK(dev_alloc(&op->combined, (size_t)op->A.stored));
     QP_CHECK(qp::launch_combine_planes(ctx->stream, op->combined, op->planes_dev, eff.data(), op->nops, op->A.stored,
                                        want_real ? op->real_vals : nullptr, &ctx->stats));
@@ -1547,6 +1579,16 @@ int qp_operator_walk_info(const qp_operator* op, int64_t out[8]) {
   out[6] = on ? P.R1 : 0;
   out[7] = on ? P.n_edge : 0;
   return QP_OK;
+}
+
+int qp_operator_evaluate_info(const qp_operator* op, int64_t out[3]) {
+  QP_TRY
+  if (!op || !out) return qp::fail(QP_E_BAD_ARG, "qp_operator_evaluate_info: NULL argument");
+  out[0] = op->sparse_from;
+  out[1] = op->sparse_from > 0 ? op->n_support : 0;
+  out[2] = op->last_refresh_sparse ? 1 : 0;
+  return QP_OK;
+  QP_CATCH
 }
 
 int qp_operator_walk_reason(const qp_operator* op, int* code, char* text, size_t text_len) {

@@ -131,9 +131,12 @@ int arnoldi_column(qp_operator* op, qp_krylov* q, int j, double dt, double2* hco
   }
   const bool lowsync = ctx->tun.arnoldi_mode == 1 && q->gram_rows >= j && qp::mgs_lowsync_fits(j);
   bool dots_done = false;
-  if (lowsync && ctx->tun.arnoldi_fuse_dots)   // knob: the multidot in the mat-vec's epilogue (kernels_arnoldi.hip)
-    QP_CHECK(qp::launch_arnoldi_matvec_dots(ctx->stream, op->A, xin, pe, q->Q, q->n, j, q->md_part, &dots_done, &ctx->stats));
-  if (!dots_done) QP_CHECK(qp::launch_spmv_plain(ctx->stream, op->A, xin, pe, &ctx->stats));  // src/arnoldi.jl:82
+  {
+    const qp::ScopedRange mv_range(ctx->tun.roctx != 0 || qp::ranges_enabled_by_env(), "matrix-vector product");   // src/arnoldi.jl:81
+    if (lowsync && ctx->tun.arnoldi_fuse_dots)   // knob: the multidot in the mat-vec's epilogue (kernels_arnoldi.hip)
+      QP_CHECK(qp::launch_arnoldi_matvec_dots(ctx->stream, op->A, xin, pe, q->Q, q->n, j, q->md_part, &dots_done, &ctx->stats));
+    if (!dots_done) QP_CHECK(qp::launch_spmv_plain(ctx->stream, op->A, xin, pe, &ctx->stats));  // src/arnoldi.jl:82
+  }
   if (lowsync) {
     // low-synchronisation MGS: same coefficients (to rounding), 3 launches per column;
     // leaves |w|^2 partials in part[(j+1)&1] like the sequential path.  Needs the Gram
@@ -640,6 +643,8 @@ int qp_newton_step(qp_newton* w, qp_operator* op, qp_state* psi, double dt, int 
   if (dt == 0.0) return qp::fail(QP_E_BAD_ARG, "dt must be non-zero");   // src/newton.jl:263
   qp_ctx* ctx = op->ctx;
   QP_CHECK(use(ctx));
+  const bool ranges = ctx->tun.roctx != 0 || qp::ranges_enabled_by_env();
+  const qp::ScopedRange step_range(ranges, "prop_step!");               // src/newton_propagator.jl:121
   const int m_max = w->m_max;
   int m = m_max;                                                        // :253
   std::fill(w->a.begin(), w->a.end(), cplx(0));                         // :254-255
@@ -671,6 +676,7 @@ int qp_newton_step(qp_newton* w, qp_operator* op, qp_state* psi, double dt, int 
     int blocks_done = 0;
     const ColumnHook eig_block = [&](int j) -> int {
       auto t1 = now();
+      const qp::ScopedRange eig_range(ranges, "diagonalize_hessenberg_matrix");   // src/newton.jl:296
       const size_t off = (size_t)j * (j + 1) / 2;
       const int st = qp::diagonalize_hessenberg_block(Hess.data(), ldh, j + 1, ritz.data() + off);
       ms_eig_sweep += ms_since(t1);
@@ -682,9 +688,12 @@ int qp_newton_step(qp_newton* w, qp_operator* op, qp_state* psi, double dt, int 
       blocks_done = j + 1;
       return st == QP_OK ? QP_OK : qp::fail(QP_E_INTERNAL, "Hessenberg QR did not converge");
     };
-    QP_CHECK(arnoldi_impl(op, w->q, m_req, s == 0 ? psi : &vstate, dt, 1, norm_min,
-                          reinterpret_cast<qp_c128*>(Hess.data()), ldh, &m, s == 0 ? &beta : nullptr,
-                          ctx->tun.newton_pipeline ? &eig_block : nullptr));
+    {
+      const qp::ScopedRange arnoldi_range(ranges, "arnoldi!");                       // src/newton.jl:276
+      QP_CHECK(arnoldi_impl(op, w->q, m_req, s == 0 ? psi : &vstate, dt, 1, norm_min,
+                            reinterpret_cast<qp_c128*>(Hess.data()), ldh, &m, s == 0 ? &beta : nullptr,
+                            ctx->tun.newton_pipeline ? &eig_block : nullptr));
+    }
     ms_arnoldi += ms_since(t0) - ms_eig_sweep - ms_fold_sweep;
     ms_eig += ms_eig_sweep;
     ms_leja += ms_fold_sweep;
@@ -709,19 +718,27 @@ int qp_newton_step(qp_newton* w, qp_operator* op, qp_state* psi, double dt, int 
     const int n_s = n_leja;                                                          // :307
     if ((int)w->leja.size() < n_leja + m) w->leja.resize((size_t)2 * (n_leja + m), cplx(0));  // :105-110
     t0 = now();
-    qp::extend_leja(w->leja.data(), n_leja, ritz.data(), (int)ritz.size(), m, folded ? lprod.data() : nullptr);
+    {
+      const qp::ScopedRange leja_range(ranges, "get Leja points");                   // src/newton.jl:306
+      qp::extend_leja(w->leja.data(), n_leja, ritz.data(), (int)ritz.size(), m, folded ? lprod.data() : nullptr);
+    }
     ms_leja += ms_since(t0);
     n_leja += m;
     if ((int)w->a.size() < n_leja) w->a.resize((size_t)2 * n_leja, cplx(0));         // :187-192
     {
       t0 = now();
-      int st = qp::extend_newton_coeffs(w->a.data(), n_a, w->leja.data(), func_id, cb, user, n_leja, w->radius);  // :314
+      int st;
+      {
+        const qp::ScopedRange coeff_range(ranges, "get Newton coeffs");              // src/newton.jl:313
+        st = qp::extend_newton_coeffs(w->a.data(), n_a, w->leja.data(), func_id, cb, user, n_leja, w->radius);  // :314
+      }
       ms_coeffs += ms_since(t0);
       if (st == QP_E_DIVDIFF_UNDERFLOW) return qp::fail(st, "Divided differences too small");
       if (st != QP_OK) return qp::fail(st, "extend_newton_coeffs failed (radius=%g)", w->radius);
       n_a = n_leja;
     }
     // Newton polynomial in the extended Hessenberg matrix                           :328-343
+    if (ranges) qp::range_push("evaluate polynomial");                               // src/newton.jl:328 (closed after the update below)
     t0 = now();
     const int mp = m + 1;
     R.assign(mp, cplx(0));
@@ -766,6 +783,7 @@ int qp_newton_step(qp_newton* w, qp_operator* op, qp_state* psi, double dt, int 
     QP_HIP(hipMemcpyAsync(w->h_npart, w->npart, kRedBlocks * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
     QP_HIP(hipStreamSynchronize(ctx->stream));
     norm_psi = std::sqrt(sum_partials(w->h_npart).real());
+    if (ranges) qp::range_pop();
     ms_update += ms_since(t0);
     last_relerr = beta * std::abs(w->a[n_a - 1]) / (1 + norm_psi);                    // :370
     if (last_relerr < relerr) break;

@@ -10,7 +10,46 @@
 #include <cstring>
 #include <vector>
 
+#include <dlfcn.h>
+
+#include <cstdlib>
+#include <mutex>
+
 namespace qp {
+
+// ---- profiler ranges (qprop_internal.h) -------------------------------------------------------------------------
+namespace {
+using PushFn = int (*)(const char*);
+using PopFn = int (*)();
+PushFn g_push = nullptr;
+PopFn g_pop = nullptr;
+std::once_flag g_roctx_once;
+void resolve_roctx() {
+  for (const char* lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+    void* h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) continue;
+    g_push = reinterpret_cast<PushFn>(dlsym(h, "roctxRangePushA"));
+    g_pop = reinterpret_cast<PopFn>(dlsym(h, "roctxRangePop"));
+    if (g_push && g_pop) return;
+    g_push = nullptr;
+    g_pop = nullptr;
+  }
+}
+}  // namespace
+void range_push(const char* name) {
+  std::call_once(g_roctx_once, resolve_roctx);
+  if (g_push) (void)g_push(name);
+}
+void range_pop() {
+  if (g_pop) (void)g_pop();
+}
+bool ranges_enabled_by_env() {
+  static const bool on = [] {
+    const char* e = std::getenv("QP_ROCTX");
+    return e && e[0] == '1';
+  }();
+  return on;
+}
 
 using cplx = std::complex<double>;
 

@@ -40,6 +40,27 @@ int csc_to_csr(int64_t nrows, int64_t ncols, const int64_t* colptr, const int64_
                const qp_c128* nzval, int base, int64_t* rowptr, int32_t* col, qp_c128* vals);
 void partition_rows(const int64_t* rowptr, int64_t nrows, int nparts, int balance, int64_t* bounds);
 
+// Named ranges for profiler timelines (rocprofv3 --marker-trace), with the NAMES of the reference's TimerOutputs sections
+// -- timing_data["prop_step!"]["matrix-vector product"], "arnoldi!", "diagonalize_hessenberg_matrix", "get Leja points",
+// "get Newton coeffs", "evaluate polynomial" (src/cheby_propagator.jl:349, src/cheby.jl:175, src/newton.jl:276-328,
+// test/test_timings.jl:28-30) -- so that a trace of a step reads like the reference's timer table instead of 98 anonymous
+// launches.  Off unless knob `roctx` is 1 or QP_ROCTX=1 is in the environment; the marker library (rocprofiler-sdk-roctx,
+// else roctx64) is resolved with dlopen on first use and its absence is not an error.
+void range_push(const char* name);
+void range_pop();
+bool ranges_enabled_by_env();
+struct ScopedRange {
+  bool on;
+  ScopedRange(bool enabled, const char* name) : on(enabled) {
+    if (on) range_push(name);
+  }
+  ~ScopedRange() {
+    if (on) range_pop();
+  }
+  ScopedRange(const ScopedRange&) = delete;
+  ScopedRange& operator=(const ScopedRange&) = delete;
+};
+
 }  // namespace qp
 
 #define QP_TRY try {

@@ -134,8 +134,10 @@ SIGNATURES = {
     "qp_operator_build_info": (C.c_int, [_P, _dp]),
     "qp_operator_walk_info": (C.c_int, [_P, _i64p]),
     "qp_operator_fill_info": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "qp_developer_build": (C.c_int, []),
     "qp_operator_walk_long": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "qp_operator_walk_reason": (C.c_int, [_P, C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
+    "qp_operator_evaluate_info": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "qp_lattice_fill_host": (C.c_int, [C.c_int64, C.c_int64, _i64p, _i32p, C.c_int, _i64p, _i32p, C.c_int64, C.POINTER(C.c_int64)]),
     "qp_operator_spmm_walk": (C.c_int, [_P, C.c_int, _i64p]),
     "qp_state_create": (C.c_int, [_P, C.c_int64, C.POINTER(_P)]),
@@ -320,7 +322,8 @@ def lattice_fill_host(nrows, ncols, rowptr, col, min_blocks=3072):
     """The lattice completion of operator creation on a host CSR pattern (no device needed): returns (rowptr, col)."""
     rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
     col = np.ascontiguousarray(col, dtype=np.int32)
-    cap = int(rowptr[-1]) + 64 * 17 + int(0.05 * rowptr[-1]) + 1024
+    # the completion accepts up to 12 % missing entries (engine_core.hip: lattice_fill): room for 13 % and a block of slack
+    cap = int(1.13 * int(rowptr[-1])) + 64 * 20 + 1024
     rp_out = np.empty(nrows + 1, dtype=np.int64)
     col_out = np.empty(cap, dtype=np.int32)
     nnz = C.c_int64(0)
@@ -564,6 +567,13 @@ class Operator:
         check(self.lib.qp_operator_walk_long(self._h, C.byref(gl)))
         d["long_distance"] = gl.value        # rows; 0: no long pair (three-dimensional grids have one: the plane distance)
         return d
+
+    def evaluate_info(self):
+        """How evaluate! updates the values: first sparse control term (-1: none), positions rewritten, whether the latest
+        update was a sparse one (include/qprop.h)."""
+        out = np.zeros(3, dtype=np.int64)
+        check(self.lib.qp_operator_evaluate_info(self._h, _ptr(out, _i64p)))
+        return dict(zip(("first_sparse_term", "positions", "latest_update_sparse"), (int(v) for v in out)))
 
     def walk_reason(self):
         """(code, name, sentence): why the fused Chebyshev term of this operator does not take the strip walk -- QP_WALK_OK

@@ -140,6 +140,21 @@ def test_bench_eight_ranks_full_c4_flow_one_gpu():
     assert 0 < d["roofline"]["frac"] <= 1.0
 
 
+def test_split_wait_timeout_is_reported_not_hung():
+    """The in-launch hand-off boundary(m) -> interior(m + 1) polls a counter with a bounded spin.  Forced failure: the
+    boundary launches do not signal (knob split_dbg -- developer flavour of the library only, csrc: make dev) and the bound
+    is lowered to 2^10 polls (knob split_spin_log2): the interior launch comes back by itself, raises the split's
+    host-visible flag, and the NEXT call on that split -- Python-driven term or the library's own step -- returns
+    QP_E_INTERNAL instead of computing on with a stale vector; a fresh split on the same context works again."""
+    dev = os.path.join(ROOT, "quantumpropagators.jl_amd", "lib", "libqprop_hip_dev.so")
+    assert os.path.exists(dev), "lib/libqprop_hip_dev.so is missing: __graft_entry__.build() (make all dev) builds it"
+    env = dict(os.environ, QPROP_HIP_LIB=dev, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dev_build_worker.py")], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert "dev-build time-out test ok" in r.stdout
+
+
 def test_library_rccl_communicator_two_gpus():
     """The library's own multi-rank RCCL communicator (two-phase set-up, ncclSend / ncclRecv neighbour exchange,
     ncclAllGather, overlapped and serial schedules) against the oracle -- one GPU per rank, so this needs two

@@ -265,6 +265,20 @@ def test_lattice_fill_host_completes_open_boundary_grids(nx, ny, nnn):
     assert rp[-1] == len(col) == len(want)
 
 
+def test_lattice_fill_host_thin_three_dimensional_grid_needs_ten_percent_more_entries():
+    """A 64 x 4 x 1024 seven-point grid with open boundaries: its y-direction is four points wide, so 9.7 % of the completed
+    pattern is explicit zeros -- inside the 12 % the completion accepts and more than the 5 % the wrapper used to leave room
+    for (QP_E_BAD_ARG "col_out holds 1506854 entries, 1572210 needed")."""
+    nx, ny, nz = 64, 4, 1024
+    H = synth.grid_hamiltonian_3d(nx, ny, nz, flux=0.1)
+    N = nx * ny * nz
+    rp, col = L.lattice_fill_host(N, N, H.indptr, H.indices, min_blocks=16)
+    added = int(rp[-1]) - H.nnz
+    assert 0.08 * H.nnz < added < 0.12 * H.nnz
+    mid = N // 2
+    assert sorted(int(c) - mid for c in col[rp[mid]:rp[mid + 1]]) == [-nx * ny, -nx, -1, 0, 1, nx, nx * ny]
+
+
 def test_lattice_fill_host_leaves_other_patterns_alone():
     """No completion for: a lattice with an entry outside its distances, more than 12 % missing entries, operators below the
     size knob, a complete lattice, a non-symmetric distance list, a row-partitioned pattern whose interior rows reach the

@@ -1344,6 +1344,15 @@ def test_sparse_control_terms_update_only_their_positions(ctx, fmt, real):
                 for kind, arg in moves:
                     n0 = ctx.stats()["n_kernel_launches"]
                     Op.set_coeffs(arg) if kind == "c" else Op.set_scale(arg)
+                    ev = Op.evaluate_info()
+                    relaid = Op.format != fmt            # (a complex coefficient un-packed the operator: full combination from then on)
+                    # the sparse path exists when the trailing control terms touch at most a quarter of the STORED values: 3 of the
+                    # 12 padded slots per row in the row-block formats, but 3 of 11 entries as plain CSR (no padding) -- not there
+                    has_sparse = expect_sparse and fmt != L.FMT_CSR and not relaid
+                    assert (ev["first_sparse_term"] > 0) == has_sparse, (kind, arg, ev)
+                    assert ev["latest_update_sparse"] == (1 if (knob and has_sparse) else 0), (kind, arg, ev)
+                    if has_sparse:
+                        assert 0 < ev["positions"] <= 3 * N
                     res.append(Op.get_csr()[2])
                     x = L.State(ctx, data=psi0)
                     L.cheby(x, Op, 0.3, wrk)
@@ -1361,7 +1370,26 @@ def test_sparse_control_terms_update_only_their_positions(ctx, fmt, real):
         ref = qo.cheby(psi0.copy(), sp.csr_matrix(Heff), 0.3, qo.ChebyWrk(psi0, 30.0, -15.0, 0.3))
         if np.all(np.imag(kind_c) == 0):          # (a complex coefficient makes H non-Hermitian: cheby! is then only compared between the two paths)
             assert np.linalg.norm(outs[0][-1] - ref) < TOL
-        del expect_sparse
+    # the knob toggled on a LIVE operator: full combination in between, then sparse updates again with drift
+    # coefficients equal to what the base was built for -- the base must be rebuilt, not trusted
+    Op = L.Operator(ctx, [L.Matrix.from_scipy(ctx, M) for M in (H0, Hd, D1, D2)], ncoeffs=3, fmt=fmt)
+    ref = L.Operator(ctx, [L.Matrix.from_scipy(ctx, M) for M in (H0, Hd, D1, D2)], ncoeffs=3, fmt=fmt)
+    try:
+        live = 1 if fmt != L.FMT_CSR else 0
+        ctx.tuning_set("sparse_controls", 1)
+        Op.set_coeffs([0.5, -0.25, 0.1])
+        assert Op.evaluate_info()["latest_update_sparse"] == live
+        ctx.tuning_set("sparse_controls", 0)
+        Op.set_coeffs([0.9, 0.3, 0.2])              # full combination: `combined` now holds 0.9 Hd everywhere
+        assert Op.evaluate_info()["latest_update_sparse"] == 0
+        ctx.tuning_set("sparse_controls", 1)
+        Op.set_coeffs([0.5, -0.4, 0.6])             # drift coefficient 0.5 again: equal to the stale base's
+        assert Op.evaluate_info()["latest_update_sparse"] == live
+        ctx.tuning_set("sparse_controls", 0)
+        ref.set_coeffs([0.5, -0.4, 0.6])
+        assert np.array_equal(Op.get_csr()[2], ref.get_csr()[2])
+    finally:
+        ctx.tuning_set("sparse_controls", 1)
 
 
 @pytest.mark.parametrize("fmt", [L.FMT_CSR, L.FMT_RBCSR, L.FMT_HRB])

@@ -208,46 +208,22 @@ def test_split_interior_as_strip_walk_world1(pg, split_mode, offsets):
     ctx.close()
 
 
-def test_split_wait_timeout_is_reported_not_hung(pg):
-    """The in-launch hand-off boundary(m) -> interior(m + 1) polls a counter with a bounded spin.  Forced failure: the
-    boundary launches do not signal (knob split_dbg) and the bound is lowered to 2^10 polls (knob split_spin_log2): the
-    interior launch comes back by itself, raises the split's host-visible flag, and the NEXT call on that split --
-    Python-driven term or the library's own step -- returns QP_E_INTERNAL instead of computing on with a stale vector."""
+def test_release_build_refuses_the_settings_that_change_results(pg):
+    """The knobs that skip work (walk_dbg bit 1: the strip walk's edge blocks) or force a failure (split_dbg: no completion
+    signal) exist in the developer flavour of the library only (csrc: make dev): the shipped library refuses them through
+    every setter, and says so.  (The forced time-out itself: tests/test_00_multirank_gpu.py::test_split_wait_timeout_...)"""
     import torch
     import qprop_amd.lib as L
-    import qprop_amd.sharded as sharded
-    import qprop_amd.synth as synth
-    N = 8192
-    rp, col, vals = synth.hermitian_offsets_csr(N, offsets=(1, 2, 3, 4, 16, 32, 48, 64))
+    assert L.load().qp_developer_build() == 0
     ctx = L.Context(0, stream=torch.cuda.current_stream().cuda_stream)
-    send = np.concatenate([np.arange(0, 200), np.arange(N - 200, N)])
-    try:
-        ctx.tuning_set("split_mode", 1)
-        ctx.tuning_set("split_spin_log2", 10)
-        ctx.tuning_set("split_dbg", 1)
-        sh = sharded.ShardedCheby(ctx, rp, col, vals, N, 0, N, 20.0, -10.0, 1.0, exchange="halo", overlap=True,
-                                  _debug_send_rows=send)
-        assert sh.split is not None
-        sh.set_state(synth.random_state(N))
-        with pytest.raises(L.QPError) as ei:
-            for _ in range(3):                 # the flag is raised inside the first step's launches and seen by a later call
-                sh.step()
-                torch.cuda.synchronize()
-            sh.check()
-        assert ei.value.status == L.QP_E_INTERNAL and "timed out" in str(ei.value)
-        with pytest.raises(L.QPError):         # the split stays poisoned: its state is not valid
-            sh.split.check()
-        torch.cuda.synchronize()
-    finally:
-        ctx.tuning_set("split_dbg", 0)
-        ctx.tuning_set("split_spin_log2", 28)
-        ctx.tuning_set("split_mode", 2)
-    # a fresh split on the same context works again
-    sh2 = sharded.ShardedCheby(ctx, rp, col, vals, N, 0, N, 20.0, -10.0, 1.0, exchange="halo", overlap=True, _debug_send_rows=send)
-    sh2.set_state(synth.random_state(N))
-    sh2.step()
-    sh2.check()
-    assert abs(np.linalg.norm(sh2.local_state()) - 1.0) < 1e-11
+    for key, value in (("walk_dbg", 2), ("walk_dbg", 7), ("split_dbg", 1)):
+        with pytest.raises(L.QPError, match="developer-build setting"):
+            ctx.tuning_set(key, value)
+        with pytest.raises(L.QPError, match="developer-build setting"):
+            L.tuning_set(key, value)
+    for key, value in (("walk_dbg", 1), ("walk_dbg", 4), ("walk_dbg", 5), ("split_dbg", 0)):   # bit-identical variants stay
+        ctx.tuning_set(key, value)
+    ctx.tuning_set("walk_dbg", 0)
     ctx.close()
 
 

@@ -24,6 +24,7 @@ is not usable, the value of the committed profile, labelled as such.
 """
 import argparse
 import csv
+import gc
 import glob
 import json
 import os
@@ -658,6 +659,10 @@ def main():
         nseg = 4 if args.steps >= 8 else 1
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(nseg + 1)]
         cuts = [round(k * args.steps / nseg) for k in range(nseg + 1)]
+        # (the interpreter's cyclic garbage collector stays out of the timed region, as in `timeit`: a full collection of a
+        # process that has imported torch takes 50-80 ms, see tools/bench_points.py: timed_regions)
+        gc_was_on = gc.isenabled()
+        gc.disable()
         ctx.timer_begin()
         marks[0].record()
         t0_ = time.perf_counter()
@@ -667,6 +672,8 @@ def main():
                 marks[cuts.index(i + 1)].record()
         ev_ = ctx.timer_end()          # HIP events on the kernels' own stream
         torch.cuda.synchronize()
+        if gc_was_on:
+            gc.enable()
         if dist is not None:
             dist.barrier()
         el_ = time.perf_counter() - t0_
@@ -825,6 +832,8 @@ def main():
                              ("c3_newton_n2048_bandwidth_bound", lambda c: bp.measure_newton_c3(c, n=2048, steps=3, warmup=4)),
                              ("c5_batched", bp.measure_batched_c5),
                              ("c5_batched_8_states_share_of_one_of_8_gpus", lambda c: bp.measure_batched_c5(c, batch=8, steps=20)),
+                             ("dense_h_n4096_one_state", lambda c: bp.measure_dense(c, N=4096)),
+                             ("dense_h_n4096_64_states_on_the_matrix_cores", lambda c: bp.measure_dense(c, N=4096, batch=64)),
                              ("n4_matrix_free_liouvillian_n512", bp.measure_liouville)):
                 try:
                     extras[name] = fn(ctx)
@@ -878,6 +887,9 @@ def main():
                                                              "steps_per_s", "layout_bytes_per_term", "layout_gbs", "frac", "kernel",
                                                              "operator_build_ms")}
         rf["unstable_extras"] = sorted(k for k, v in extras.items() if isinstance(v, dict) and v.get("unstable"))
+        t_gc = time.perf_counter()
+        gc.collect()
+        rf["host_gc_full_collection_ms"] = 1e3 * (time.perf_counter() - t_gc)    # what a collection inside a timed region would cost
         rf["note"] = rf.pop("note")        # the long text stays last
         sizes = {}
         for lg, pt in ((20, {"us_per_term": rf["avg_launch_us"]}), (21, p21), (22, p22),

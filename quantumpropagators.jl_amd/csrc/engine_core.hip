@@ -1344,15 +1344,30 @@ int qp_operator_create(qp_ctx* ctx, qp_matrix* const* ops, int nops, int ncoeffs
       for (int64_t r = 0; r <= nrows; ++r) ur[r] = r * ncols;
     }
     op->n_lattice_fill = ur[nrows] - before;
-  } else if (format == QP_FMT_AUTO || format == QP_FMT_HRB) {
+  }
+  // Lattice completion (explicit zeros) is for operators that END UP Hermitian-packed with a strip-walk plan; whether this
+  // one does is known only after the Hermitian check and the format choice below, which need the values.  So: complete
+  // tentatively, keep the original pattern, and take the completion back if the operator turns out non-Hermitian, is laid
+  // out otherwise, or has no plan after all (a non-Hermitian lattice-shaped Liouvillian kept up to 12 % stored
+  // zeros for nothing -- more bytes per mat-vec, and 0 * Inf = NaN where the reference has no entry).
+  std::vector<int64_t> ur_orig;
+  std::vector<int32_t> uc_orig;
+  if (!dense && (format == QP_FMT_AUTO || format == QP_FMT_HRB)) {
+    ur_orig = ur;
+    uc_orig = uc;
     const int64_t before = ur[nrows];
     lattice_fill(ctx->tun, nrows, ncols, ur, uc);
     op->n_lattice_fill = ur[nrows] - before;
+    if (op->n_lattice_fill == 0) {
+      ur_orig.clear();
+      uc_orig.clear();
+    }
   }
-  op->A.nnz = ur[nrows];
 
   // ---- per-term values in union order (duplicates within a row are summed, as Julia's sparse() does) ----
   std::vector<std::vector<cplx>> planes_csr(nops);
+  auto scatter_planes = [&]() {
+  op->A.nnz = ur[nrows];
   for (int l = 0; l < nops; ++l) {
     const qp_matrix* M = ops[l];
     auto& pv = planes_csr[l];
@@ -1380,12 +1395,35 @@ int qp_operator_create(qp_ctx* ctx, qp_matrix* const* ops, int nops, int ncoeffs
       }
     }
   }
+  };
+  scatter_planes();
+  auto take_completion_back = [&]() {
+    ur.swap(ur_orig);
+    uc.swap(uc_orig);
+    ur_orig.clear();
+    uc_orig.clear();
+    op->n_lattice_fill = 0;
+    for (auto& pv : planes_csr) pv.clear();
+    scatter_planes();
+  };
   bool hermitian = !dense && (ncols >= nrows) && (format == QP_FMT_AUTO || format == QP_FMT_HRB);
   for (int l = 0; hermitian && l < nops; ++l) hermitian = csr_is_hermitian(nrows, ur, uc, planes_csr[l]);
   op->hermitian_planes = hermitian;
-  const int fmt = dense ? (int)QP_FMT_DENSE : choose_format(op.get(), format, hermitian);
+  int fmt = dense ? (int)QP_FMT_DENSE : choose_format(op.get(), format, hermitian);
   if (fmt < 0) return qp::fail(QP_E_BAD_ARG, "QP_FMT_HRB requested but the operator terms are not exactly Hermitian");
+  if (!ur_orig.empty() && fmt != QP_FMT_HRB) {   // (a lattice completion happened;) not Hermitian, or not packed: the zeros would buy nothing
+    take_completion_back();
+    fmt = choose_format(op.get(), format, hermitian);
+    if (fmt < 0) return qp::fail(QP_E_BAD_ARG, "QP_FMT_HRB requested but the operator terms are not exactly Hermitian");
+  }
   QP_CHECK(operator_build_device(op.get(), fmt, planes_csr));
+  if (!ur_orig.empty() && !op->walk.valid) {     // packed, completed, and still no plan: build once more without the zeros
+    QP_CHECK(operator_free_device(op.get()));
+    take_completion_back();
+    fmt = choose_format(op.get(), format, hermitian);
+    if (fmt < 0) return qp::fail(QP_E_BAD_ARG, "QP_FMT_HRB requested but the operator terms are not exactly Hermitian");
+    QP_CHECK(operator_build_device(op.get(), fmt, planes_csr));
+  }
   planes_csr.clear();
   // the whole host side of the creation (union pattern, lattice completion, value planes, Hermitian check, format choice)
   // belongs to what qp_operator_build_info reports for the first build

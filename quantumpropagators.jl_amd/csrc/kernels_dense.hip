@@ -144,74 +144,88 @@ __device__ __forceinline__ double2 ld_off(const double* base, unsigned off) {
   return make_double2(d, 0.0);
 }
 
-// One workgroup = one 32 x 32 tile of the panel (rows i0 .. i0 + 31, states s0 .. s0 + 31); each of its four wavefronts owns
-// a quarter of the inner dimension and keeps the whole tile (2 x 2 MFMA tiles, real and imaginary part: 64 accumulator
-// registers); a k-step of 4 is four loads for 16 MFMAs (8 when H is real).  MFMA operand layout (as in
-// engine_liouville.hip, verified there against the library GEMM): lane l = (li = l & 15, lk = l >> 4) feeds A[i = li][k = lk]
-// and B[k = lk][j = li] and receives C[i = lk + 4 r][j = li] in accumulator register r.
+// One workgroup = one (16 TA) x (16 TB) tile of the panel (rows i0 .., states s0 ..); each of its four wavefronts owns a quarter
+// of the inner dimension and keeps the whole tile (TA x TB MFMA tiles, real and imaginary part: 8 TA TB accumulator
+// registers); a k-step of 4 is TA + TB loads for 4 TA TB MFMAs (2 TA TB when H is real).  TA = TB = 2 (32 x 32) for panels of
+// more than 16 states: 16 MFMAs per four 1-KiB loads, the MFMA rate decides (N = 4096, b = 64: 61 TFLOP/s); TA = TB = 1
+// (16 x 16) for panels of at most 16 states, where the step is HBM-bound (arithmetic intensity b / 2 < 9.8 flop/B): twice the
+// workgroups, no MFMA spent on columns past the panel's width.  MFMA operand layout (as in engine_liouville.hip, verified there
+// against the library GEMM): lane l = (li = l & 15, lk = l >> 4) feeds A[i = li][k = lk] and B[k = lk][j = li] and receives
+// C[i = lk + 4 r][j = li] in accumulator register r.
 //   A fragment: H[i0 + 16 a + li][k + lk]            (row-major H: 16 rows x 64 contiguous bytes per load)
 //   B fragment: X[(k + lk) b + s0 + 16 c + li]       (panel, state index contiguous: 4 rows x 256 contiguous bytes)
-// The four partial tiles are summed through LDS in wave order (deterministic), then each wavefront applies the row epilogue
-// of the fused term to one 16 x 16 quarter: element e = row * b + state, exactly as the sparse panel kernels do.
-template <class Op, class VT, int D>
+// The four partial tiles are summed through LDS in wave order (deterministic), then the 4 TA TB (tile, register) pairs are dealt
+// to the four wavefronts, which apply the row epilogue of the fused term: element e = row * b + state, exactly as the sparse
+// panel kernels do.
+template <class Op, class VT, int D, int TA, int TB>
 __global__ __launch_bounds__(256) void dense_zgemm_cheby_kernel(const VT* __restrict__ H, const double2* __restrict__ X, int n,
                                                                 int ncols, int b, Op op) {
   constexpr bool CPLX = std::is_same<VT, double2>::value;
-  __shared__ double red[4][4][2][4][64];   // the partial tiles of the four wavefronts (64 KB)
+  constexpr int NT = TA * TB;
+  __shared__ double red[4][NT][2][4][64];   // the partial tiles of the four wavefronts (16 KB per MFMA tile)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int row0 = blockIdx.x * 32, col0 = blockIdx.y * 32;
+  const int row0 = blockIdx.x * (16 * TA), col0 = blockIdx.y * (16 * TB);
   const int ksteps = ncols >> 2;   // whole k-steps; the ncols & 3 inner indices left over: one masked step after the loop
   const int per = (ksteps + 3) / 4;
   const int sbeg = wave * per;
   const int total = max(min(ksteps, sbeg + per) - sbeg, 0);
   const int li = lane & 15, lk = lane >> 4;
-  const int ra0 = min(row0 + li, n - 1) - row0, ra1 = min(row0 + 16 + li, n - 1) - row0;     // rows past the end repeat the last (not stored)
-  const int cb0 = min(col0 + li, b - 1), cb1 = min(col0 + 16 + li, b - 1);
   constexpr unsigned ES = sizeof(VT);
-  const unsigned oa0 = ((unsigned)ra0 * (unsigned)ncols + (unsigned)lk) * ES, oa1 = ((unsigned)ra1 * (unsigned)ncols + (unsigned)lk) * ES;
-  const unsigned ob0 = ((unsigned)lk * (unsigned)b + (unsigned)cb0) * 16u, ob1 = ((unsigned)lk * (unsigned)b + (unsigned)cb1) * 16u;
+  unsigned oa[TA], ob[TB];
+  int ra[TA], cb[TB];
+#pragma unroll
+  for (int a = 0; a < TA; ++a) {
+    ra[a] = min(row0 + 16 * a + li, n - 1) - row0;     // rows past the end repeat the last (not stored)
+    oa[a] = ((unsigned)ra[a] * (unsigned)ncols + (unsigned)lk) * ES;
+  }
+#pragma unroll
+  for (int c = 0; c < TB; ++c) {
+    cb[c] = min(col0 + 16 * c + li, b - 1);
+    ob[c] = ((unsigned)lk * (unsigned)b + (unsigned)cb[c]) * 16u;
+  }
   const VT* baseA = H + (size_t)row0 * (size_t)ncols + (size_t)sbeg * 4;
   const double2* baseB = X + (size_t)sbeg * 4 * (size_t)b;
   const size_t strideB = (size_t)4 * (size_t)b;
 
-  v4d cr[2][2], ci[2][2];
+  v4d cr[TA][TB], ci[TA][TB];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < TA; ++a)
 #pragma unroll
-    for (int c = 0; c < 2; ++c) cr[a][c] = ci[a][c] = v4d{0.0, 0.0, 0.0, 0.0};
+    for (int c = 0; c < TB; ++c) cr[a][c] = ci[a][c] = v4d{0.0, 0.0, 0.0, 0.0};
 
-  double2 fa[D][2], fb[D][2];
+  double2 fa[D][TA], fb[D][TB];
   auto load = [&](int slot) {
-    fa[slot][0] = ld_off(baseA, oa0);
-    fa[slot][1] = ld_off(baseA, oa1);
-    fb[slot][0] = ld_off(baseB, ob0);
-    fb[slot][1] = ld_off(baseB, ob1);
+#pragma unroll
+    for (int a = 0; a < TA; ++a) fa[slot][a] = ld_off(baseA, oa[a]);
+#pragma unroll
+    for (int c = 0; c < TB; ++c) fb[slot][c] = ld_off(baseB, ob[c]);
     baseA += 4;
     baseB += strideB;
   };
-  auto mfma = [&](int slot) {   // 16 MFMAs (8 for a real H); consecutive ones never share an accumulator
+  auto mfma = [&](int slot) {   // 4 TA TB MFMAs (half for a real H); consecutive ones never share an accumulator where TA TB > 1
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < TA; ++a)
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
+      for (int c = 0; c < TB; ++c) {
         cr[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[slot][a].x, fb[slot][c].x, cr[a][c], 0, 0, 0);
         ci[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[slot][a].x, fb[slot][c].y, ci[a][c], 0, 0, 0);
       }
     if (CPLX) {
-      double nai[2];
+      double nai[TA];
 #pragma unroll
-      for (int a = 0; a < 2; ++a) nai[a] = -fa[slot][a].y;
+      for (int a = 0; a < TA; ++a) nai[a] = -fa[slot][a].y;
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < TA; ++a)
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < TB; ++c) {
           cr[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(nai[a], fb[slot][c].y, cr[a][c], 0, 0, 0);
           ci[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[slot][a].y, fb[slot][c].x, ci[a][c], 0, 0, 0);
         }
     }
   };
-  constexpr int NM = CPLX ? 16 : 8;
+  constexpr int NM = (CPLX ? 4 : 2) * NT;          // MFMAs per k-step
+  constexpr int NL = TA + TB;                      // refills per k-step
   int s = 0;
   if (total >= 2 * D - 1) {
 #pragma unroll
@@ -229,7 +243,8 @@ __global__ __launch_bounds__(256) void dense_zgemm_cheby_kernel(const VT* __rest
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      // one MFMA
           __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                      // at most one vector-ALU instruction
           __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);                      // scalar work of the cursors
-          if (g % (NM / 4) == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // one of the four refills
+          if (NM >= NL ? (g % (NM / NL) == (NM / NL) / 2) : true)
+            __builtin_amdgcn_sched_group_barrier(0x020, NM >= NL ? 1 : NL / NM, 0);   // the step's refills, spread over it
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -265,48 +280,51 @@ __global__ __launch_bounds__(256) void dense_zgemm_cheby_kernel(const VT* __rest
     const bool kin = k < ncols;
     const int kc = min(k, ncols - 1);
     const double2 zero = make_double2(0.0, 0.0);
-    const double2 p0 = ld_val<false>(H + ((size_t)(row0 + ra0) * (size_t)ncols + kc));
-    const double2 p1 = ld_val<false>(H + ((size_t)(row0 + ra1) * (size_t)ncols + kc));
-    fa[0][0] = kin ? p0 : zero;
-    fa[0][1] = kin ? p1 : zero;
-    fb[0][0] = X[(size_t)kc * b + cb0];
-    fb[0][1] = X[(size_t)kc * b + cb1];
+#pragma unroll
+    for (int a = 0; a < TA; ++a) {
+      const double2 p = ld_val<false>(H + ((size_t)(row0 + ra[a]) * (size_t)ncols + kc));
+      fa[0][a] = kin ? p : zero;
+    }
+#pragma unroll
+    for (int c = 0; c < TB; ++c) fb[0][c] = X[(size_t)kc * b + cb[c]];
     mfma(0);
   }
-  // the row-local operands of this wavefront's quarter of the tile, requested before the partial tiles go through LDS
-  const int qa = wave >> 1, qc = wave & 1;
-  const int col = col0 + qc * 16 + li;
-  typename Op::Pre pre[4];
-  int64_t el[4];
-  bool live[4];
+  // the 4 NT (tile, accumulator register) pairs of the workgroup's tile, NT per wavefront: pair p = wave NT + i is register
+  // r = p & 3 of MFMA tile p >> 2 (for the 32 x 32 tile: wavefront w finishes MFMA tile w).  Their row-local operands are
+  // requested before the partial tiles go through LDS.
+  typename Op::Pre pre[NT];
+  int64_t el[NT];
+  bool live[NT];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = row0 + qa * 16 + lk + 4 * r;
-    live[r] = row < n && col < b;
-    el[r] = live[r] ? (int64_t)row * b + col : 0;
-    if (live[r]) pre[r] = op.pre(el[r]);
+  for (int i = 0; i < NT; ++i) {
+    const int p = wave * NT + i, tile = p >> 2, r = p & 3;
+    const int row = row0 + (tile / TB) * 16 + lk + 4 * r, col = col0 + (tile % TB) * 16 + li;
+    live[i] = row < n && col < b;
+    el[i] = live[i] ? (int64_t)row * b + col : 0;
+    if (live[i]) pre[i] = op.pre(el[i]);
   }
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < TA; ++a)
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int c = 0; c < TB; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        red[wave][a * 2 + c][0][r][lane] = cr[a][c][r];
-        red[wave][a * 2 + c][1][r][lane] = ci[a][c][r];
+        red[wave][a * TB + c][0][r][lane] = cr[a][c][r];
+        red[wave][a * TB + c][1][r][lane] = ci[a][c][r];
       }
   __syncthreads();
   double2 chk = make_double2(0.0, 0.0);
   double nrm = 0.0;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    double sr = red[0][wave][0][r][lane], si = red[0][wave][1][r][lane];
+  for (int i = 0; i < NT; ++i) {
+    const int p = wave * NT + i, tile = p >> 2, r = p & 3;
+    double sr = red[0][tile][0][r][lane], si = red[0][tile][1][r][lane];
 #pragma unroll
     for (int w = 1; w < 4; ++w) {
-      sr += red[w][wave][0][r][lane];
-      si += red[w][wave][1][r][lane];
+      sr += red[w][tile][0][r][lane];
+      si += red[w][tile][1][r][lane];
     }
-    if (live[r]) op.row(el[r], make_double2(sr, si), pre[r], chk, nrm, el[r]);
+    if (live[i]) op.row(el[i], make_double2(sr, si), pre[i], chk, nrm, el[i]);
   }
 }
 
@@ -317,19 +335,25 @@ int launch_dense_zgemm_cheby(hipStream_t s, const DevMatrix& A, const double2* X
       (int64_t)4 * batch * 16 > (int64_t)UINT32_MAX)
     return fail(QP_E_BAD_ARG, "dense panel step: operator %lld x %lld too large for the 32-bit lane offsets", (long long)A.nrows,
                 (long long)A.ncols);
-  const dim3 grid((unsigned)((A.nrows + 31) / 32), (unsigned)((batch + 31) / 32));
+  const bool narrow = batch <= 16;   // a 16 x 16 tile per workgroup: HBM-bound panels, no MFMA spent past the panel's width
+  const int tm = narrow ? 16 : 32;
+  const dim3 grid((unsigned)((A.nrows + tm - 1) / tm), (unsigned)((batch + tm - 1) / tm));
   // the panel streams (v0, accumulator, new term) of a large panel are read / written once per term: nontemporal, as in the
   // sparse panel kernels
   const bool nt = (double)A.nrows * batch * sizeof(double2) >= 128.0 * 1024 * 1024;
-#define QP_DENSE_ZGEMM(OP)                                                                                               \
+#define QP_DENSE_ZGEMM(OP, TT)                                                                                           \
   do {                                                                                                                   \
     OP op{e};                                                                                                            \
     if (A.vals_r)                                                                                                        \
-      hipLaunchKernelGGL((dense_zgemm_cheby_kernel<OP, double, 6>), grid, dim3(256), 0, s, A.vals_r, X, (int)A.nrows, (int)A.ncols, batch, op); \
+      hipLaunchKernelGGL((dense_zgemm_cheby_kernel<OP, double, 6, TT, TT>), grid, dim3(256), 0, s, A.vals_r, X, (int)A.nrows, (int)A.ncols, batch, op); \
     else                                                                                                                 \
-      hipLaunchKernelGGL((dense_zgemm_cheby_kernel<OP, double2, 6>), grid, dim3(256), 0, s, A.vals, X, (int)A.nrows, (int)A.ncols, batch, op);  \
+      hipLaunchKernelGGL((dense_zgemm_cheby_kernel<OP, double2, 6, TT, TT>), grid, dim3(256), 0, s, A.vals, X, (int)A.nrows, (int)A.ncols, batch, op);  \
   } while (0)
-  if (nt) QP_DENSE_ZGEMM(ChebyOpT<true>); else QP_DENSE_ZGEMM(ChebyOp);
+  if (narrow) {
+    if (nt) QP_DENSE_ZGEMM(ChebyOpT<true>, 1); else QP_DENSE_ZGEMM(ChebyOp, 1);
+  } else {
+    if (nt) QP_DENSE_ZGEMM(ChebyOpT<true>, 2); else QP_DENSE_ZGEMM(ChebyOp, 2);
+  }
 #undef QP_DENSE_ZGEMM
   QP_HIP(hipGetLastError());
   if (st) {

@@ -650,3 +650,29 @@ def test_matvec_counters_like_reference_timings(ctx):
     assert np.linalg.norm(outs["cheby"] - outs["newton"]) < 1e-10
     assert counts["newton"] > counts["cheby"] > 200
     assert counts["newton"] >= 100 * 20 and counts["newton"] % 10 == 0   # whole chunks of m_max = 10, at least one restart
+
+
+def test_named_profiler_ranges_do_not_disturb_a_step(ctx):
+    """Knob roctx = 1 (or QP_ROCTX=1): the steps' phases are wrapped in named ranges carrying the reference's TimerOutputs
+    section names ("prop_step!", "matrix-vector product", "arnoldi!", "diagonalize_hessenberg_matrix", "get Leja points",
+    "get Newton coeffs", "evaluate polynomial": test/test_timings.jl:28-30, src/newton.jl:276-328) for rocprofv3
+    --marker-trace.  The marker library is optional (resolved with dlopen); results are the same bits with it on."""
+    import qprop_amd.synth as synth
+    Lm = synth.liouvillian_tridiag(40)
+    N = Lm.shape[0]
+    rho0 = synth.random_state(N)
+    op = L.Operator(ctx, [L.Matrix.from_scipy(ctx, Lm)])
+    outs = []
+    for on in (0, 1):
+        ctx.tuning_set("roctx", on)
+        try:
+            rho = L.State(ctx, data=rho0)
+            L.newton(rho, op, 0.4, L.NewtonWrk(ctx, N, m_max=10))
+            rp, col, vals = synth.hermitian_offsets_csr(4096, offsets=(1, 2, 3, 4, 16, 32, 48, 64))
+            oph = L.Operator(ctx, [L.Matrix(ctx, 4096, 4096, rp, col, vals)])
+            psi = L.State(ctx, data=synth.random_state(4096))
+            L.cheby(psi, oph, 1.0, L.ChebyWrk(ctx, 4096, 20.0, -10.0, 1.0))
+            outs.append((rho.numpy(), psi.numpy()))
+        finally:
+            ctx.tuning_set("roctx", 0)
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])

@@ -2,6 +2,7 @@
 (kbench.py, bench_newton.py, bench_batched.py): byte models of the SHIPPED device layouts and short
 single-GPU measurements of the other BASELINE configs / patterns.  Everything here calls the product
 path through the C ABI (qprop_amd.lib); nothing imports the oracle."""
+import gc
 import os
 import sys
 import time
@@ -22,19 +23,32 @@ def timed_regions(ctx, fn, steps, repeats=3):
     """`repeats` timed regions of `steps` calls of fn, each bracketed by HIP events on the kernels' stream; next to every
     region's event time what the HOST did meanwhile -- wall time of the enqueue loop and the longest single call -- so that a
     host stall (the device drains its queue and idles inside the event bracket) can be told from a device slow mode.
-    -> [(event_ms, enqueue_ms, longest_call_ms)]"""
+    -> [(event_ms, enqueue_ms, longest_call_ms)]
+
+    The interpreter's cyclic garbage collector is switched off inside a region (as `timeit` does): in a process that has
+    imported torch a full collection takes 50-80 ms, it is triggered by the allocation count -- i.e. by the ctypes wrappers'
+    temporaries, in the middle of an enqueue loop -- and the device then idles inside the event bracket.  That is what the
+    one 455 us-per-term sample of round 3 was (profiles/r04/n22_outlier.txt); QP_BENCH_GC=1 leaves the collector on."""
     out = []
+    keep_gc = os.environ.get("QP_BENCH_GC") == "1"
     for _ in range(repeats):
         ctx.sync()
         longest = 0.0
-        ctx.timer_begin()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            t1 = time.perf_counter()
-            fn()
-            longest = max(longest, time.perf_counter() - t1)
-        enq = time.perf_counter() - t0
-        out.append((ctx.timer_end(), 1e3 * enq, 1e3 * longest))
+        was_on = gc.isenabled()
+        if not keep_gc:
+            gc.disable()
+        try:
+            ctx.timer_begin()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                t1 = time.perf_counter()
+                fn()
+                longest = max(longest, time.perf_counter() - t1)
+            enq = time.perf_counter() - t0
+            out.append((ctx.timer_end(), 1e3 * enq, 1e3 * longest))
+        finally:
+            if was_on:
+                gc.enable()
     return out
 
 

@@ -118,6 +118,29 @@ def main():
             report(f"cycle {c} (e) right after a 2^23-row operator was built, used and destroyed", rows)
             worst = max(rows, key=lambda r: r[0])
             print(f"    slowest region of (e): {worst[0]:.1f} us/term, host enqueue loop {worst[1]:.1f} ms, longest single call {worst[2]:.1f} ms")
+        # (f) the interpreter's cyclic garbage collector with a heap as large as a torch process's: a full collection in the
+        # middle of the enqueue loop (forced here; in bench.py the allocation count of the ctypes temporaries triggers it)
+        if c == 0:
+            import torch  # noqa: F401  (only for the size of its heap)
+            t0 = time.perf_counter()
+            gc.collect()
+            full_ms = 1e3 * (time.perf_counter() - t0)
+            rows = []
+            for k in range(4):
+                nterms = wrk.n_coeffs - 1
+                ctx.sync()
+                ctx.timer_begin()
+                t0 = time.perf_counter()
+                longest = 0.0
+                for s in range(args.steps):
+                    t1 = time.perf_counter()
+                    L.cheby(psi, op, 1.0, wrk)
+                    if k % 2 == 1 and s == 1:
+                        gc.collect()              # every second region: one full collection after its second step
+                    longest = max(longest, time.perf_counter() - t1)
+                enq = time.perf_counter() - t0
+                rows.append((1e3 * ctx.timer_end() / (args.steps * nterms), 1e3 * enq, 1e3 * longest))
+            report(f"cycle {c} (f) torch imported; a full gc.collect() ({full_ms:.0f} ms) inside every second region", rows)
         for h in (psi, wrk, op, M):
             h.close()
         print(f"    2^21 point of this cycle: {np.median([r[0] for r in r21]):.1f} us/term (median of 3 x 8 steps)")

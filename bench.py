@@ -579,6 +579,9 @@ def main():
         workload = {"c2": "BASELINE configs[1]: Cheby prop_step!, N=2^20 CSR sparse Hermitian H, 16 nnz/row",
                     "c4": "BASELINE configs[3]: Cheby prop_step!, CSR sparse H row-partitioned, 2^21 rows per GPU (N=2^24 at 8 GPUs), "
                           "RCCL exchange of psi after each mat-vec"}[config]
+        if config == "c4" and world == 1:
+            workload = ("BASELINE configs[3] on ONE GPU: Cheby prop_step!, N=2^24 CSR sparse Hermitian H, 16 nnz/row -- the fixed problem whose "
+                        "8-GPU row-partitioned run BASELINE.md section 2 compares with (no exchange here)")
         if args.log2n is not None or args.scaling == "strong":
             workload += f" [size overridden: 2^{log2n} rows {'in total (strong scaling)' if args.scaling == 'strong' else 'per GPU'}]"
         seg = laps.get("us") or []
@@ -611,6 +614,7 @@ def main():
                          "avg_launch_us": avg_launch_s * 1e6,
                          "hbm_resident_frac": None, "hbm_resident_us_per_term": None, "hbm_resident_frac_2^21_rows": None,
                          "fixed_problem_n24_us_per_term": None, "fixed_problem_n24_frac": None, "fixed_problem_n24_blocks_per_s": None,
+                         "hbm_resident_frac_of_measured_stream": None, "fixed_problem_n24_frac_of_measured_stream": None,
                          "operator_build_ms": (build_ms or {}).get("build_ms"),
                          "unstable": bool(seg and max(seg) > 1.3 * min(seg)),
                          "launch_us_min_segment": min(seg) if seg else None, "launch_us_max_segment": max(seg) if seg else None,
@@ -881,6 +885,11 @@ def main():
         rf["fixed_problem_n24_us_per_term"] = p24.get("us_per_term")
         rf["fixed_problem_n24_frac"] = p24.get("frac")
         rf["fixed_problem_n24_blocks_per_s"] = (16.0 * p24["steps_per_s"]) if p24.get("steps_per_s") else None
+        # the same two points against what THIS box streams (y += a x over 2^26 elements, measured above): beyond the Infinity
+        # Cache the chip's practical ceiling is that figure, not 8 TB/s (profiles/r04/walk_n24_pmc.txt)
+        if stream_gbs:
+            rf["hbm_resident_frac_of_measured_stream"] = (p22["layout_gbs"] / stream_gbs) if p22.get("layout_gbs") else None
+            rf["fixed_problem_n24_frac_of_measured_stream"] = (p24["layout_gbs"] / stream_gbs) if p24.get("layout_gbs") else None
         rf["hbm_resident_point"] = {k: p22.get(k) for k in ("N", "us_per_term", "us_per_term_min", "us_per_term_max", "unstable",
                                                             "layout_bytes_per_term", "layout_gbs", "kernel")}
         rf["fixed_problem_point"] = {k: p24.get(k) for k in ("N", "us_per_term", "us_per_term_min", "us_per_term_max", "unstable", "ms_per_step",

@@ -10,10 +10,30 @@
 
 #include "engine.h"
 
+// host threads the library may keep busy at once: at most 8, and never more than the container's CPU quota leaves (cgroup
+// cpu.max: a control group that exceeds its quota is frozen for the rest of the scheduler period -- up to 100 ms in which the
+// caller's enqueueing thread does not run either)
+static unsigned host_threads() {
+  static const unsigned n = [] {
+    unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+      char q[32] = {0};
+      long period = 0;
+      if (std::fscanf(f, "%31s %ld", q, &period) == 2 && std::strcmp(q, "max") != 0 && period > 0) {
+        const long quota = std::atol(q) / period;
+        if (quota >= 1) hw = std::min<unsigned>(hw, (unsigned)quota);
+      }
+      std::fclose(f);
+    }
+    return std::max(1u, std::min(8u, hw > 2 ? hw - 1 : hw));
+  }();
+  return n;
+}
+
 // rows [0, n) in contiguous chunks on a few host threads (index work whose iterations write disjoint positions)
 template <class F>
 static void parallel_rows(int64_t n, F&& fn) {
-  const unsigned hw = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+  const unsigned hw = host_threads();
   if (n < (int64_t)1 << 16 || hw == 1) {
     fn((int64_t)0, n);
     return;

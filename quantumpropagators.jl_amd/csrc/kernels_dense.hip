@@ -335,24 +335,35 @@ int launch_dense_zgemm_cheby(hipStream_t s, const DevMatrix& A, const double2* X
       (int64_t)4 * batch * 16 > (int64_t)UINT32_MAX)
     return fail(QP_E_BAD_ARG, "dense panel step: operator %lld x %lld too large for the 32-bit lane offsets", (long long)A.nrows,
                 (long long)A.ncols);
-  const bool narrow = batch <= 16;   // a 16 x 16 tile per workgroup: HBM-bound panels, no MFMA spent past the panel's width
-  const int tm = narrow ? 16 : 32;
-  const dim3 grid((unsigned)((A.nrows + tm - 1) / tm), (unsigned)((batch + tm - 1) / tm));
+  // Tile per workgroup: 32 x 32 where that still gives every compute unit a workgroup (each of its wavefronts runs at the
+  // MFMA issue rate alone: more of them per CU add nothing, fewer workgroups than CUs leave matrix cores idle); else 16 x 32,
+  // else 16 x 16 -- also for panels of at most 16 states, which are HBM-bound and would spend half of a wider tile's MFMAs
+  // on columns past the panel's width.  (N = 4096: b = 8 126 -> 46 us per term, b = 32 126 -> 16 x 32 tiles;
+  // profiles/r04/dense_narrow_panels.txt)
+  auto wgs = [&](int ta, int tb) { return ((A.nrows + 16 * ta - 1) / (16 * ta)) * (int64_t)((batch + 16 * tb - 1) / (16 * tb)); };
+  int ta = 1, tb = 1;
+  if (batch > 16) {
+    if (wgs(2, 2) >= 192) ta = 2, tb = 2;
+    else if (wgs(1, 2) >= 192) tb = 2;
+  }
+  const dim3 grid((unsigned)((A.nrows + 16 * ta - 1) / (16 * ta)), (unsigned)((batch + 16 * tb - 1) / (16 * tb)));
   // the panel streams (v0, accumulator, new term) of a large panel are read / written once per term: nontemporal, as in the
   // sparse panel kernels
   const bool nt = (double)A.nrows * batch * sizeof(double2) >= 128.0 * 1024 * 1024;
-#define QP_DENSE_ZGEMM(OP, TT)                                                                                           \
+#define QP_DENSE_ZGEMM(OP, TA_, TB_)                                                                                     \
   do {                                                                                                                   \
     OP op{e};                                                                                                            \
     if (A.vals_r)                                                                                                        \
-      hipLaunchKernelGGL((dense_zgemm_cheby_kernel<OP, double, 6, TT, TT>), grid, dim3(256), 0, s, A.vals_r, X, (int)A.nrows, (int)A.ncols, batch, op); \
+      hipLaunchKernelGGL((dense_zgemm_cheby_kernel<OP, double, 6, TA_, TB_>), grid, dim3(256), 0, s, A.vals_r, X, (int)A.nrows, (int)A.ncols, batch, op); \
     else                                                                                                                 \
-      hipLaunchKernelGGL((dense_zgemm_cheby_kernel<OP, double2, 6, TT, TT>), grid, dim3(256), 0, s, A.vals, X, (int)A.nrows, (int)A.ncols, batch, op);  \
+      hipLaunchKernelGGL((dense_zgemm_cheby_kernel<OP, double2, 6, TA_, TB_>), grid, dim3(256), 0, s, A.vals, X, (int)A.nrows, (int)A.ncols, batch, op);  \
   } while (0)
-  if (narrow) {
-    if (nt) QP_DENSE_ZGEMM(ChebyOpT<true>, 1); else QP_DENSE_ZGEMM(ChebyOp, 1);
+  if (ta == 2) {
+    if (nt) QP_DENSE_ZGEMM(ChebyOpT<true>, 2, 2); else QP_DENSE_ZGEMM(ChebyOp, 2, 2);
+  } else if (tb == 2) {
+    if (nt) QP_DENSE_ZGEMM(ChebyOpT<true>, 1, 2); else QP_DENSE_ZGEMM(ChebyOp, 1, 2);
   } else {
-    if (nt) QP_DENSE_ZGEMM(ChebyOpT<true>, 2); else QP_DENSE_ZGEMM(ChebyOp, 2);
+    if (nt) QP_DENSE_ZGEMM(ChebyOpT<true>, 1, 1); else QP_DENSE_ZGEMM(ChebyOp, 1, 1);
   }
 #undef QP_DENSE_ZGEMM
   QP_HIP(hipGetLastError());

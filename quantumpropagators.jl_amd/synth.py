@@ -56,6 +56,23 @@ def scattered_offsets(N, n_offsets=8, seed=DEFAULT_SEED):
     return tuple(sorted(out))
 
 
+def _usable_cpus():
+    """Cores this process may keep busy: the affinity mask, capped by the container's CPU quota (cgroup cpu.max).  A thread
+    pool sized by the host's core count (256 on the GPU boxes, quota 16) gets the whole control group THROTTLED for the rest
+    of the scheduler period -- up to 100 ms in which no thread of the process runs, the one that enqueues kernels included
+    (profiles/r04/n22_outlier.txt)."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def _offsets_rows(N, offsets, rho, seed, a, b, col_out, val_out):
     """Rows [a, b) of hermitian_offsets_csr into col_out / val_out (views of (b - a) x 2 nk)."""
     nk = len(offsets)
@@ -104,7 +121,7 @@ def hermitian_offsets_csr(N, offsets=BANDED_OFFSETS, rho=10.0, seed=DEFAULT_SEED
     def run(ab):
         a, b = ab
         _offsets_rows(N, offsets, rho, seed, a, b, col[a - row_begin:b - row_begin], vals[a - row_begin:b - row_begin])
-    nthreads = max(1, min(len(jobs), len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16))
+    nthreads = max(1, min(len(jobs), _usable_cpus() - 1, 16))
     if nthreads > 1:
         with ThreadPoolExecutor(nthreads) as ex:
             list(ex.map(run, jobs))

@@ -363,6 +363,22 @@ def test_bench_single_gpu_line_is_physical():
     assert rf["traffic_detail"]["dispatches"][0] >= 31
 
 
+def test_bench_config_c4_on_one_gpu_is_the_fixed_problem():
+    """`bench.py --gpus 1 --config c4`: config C4's N = 2^24 on ONE GPU, the denominator of ">= 6 x at 8 GPUs vs 1 at fixed
+    problem" (BASELINE.md section 2); here with the size overridden, to check the flow: the rows are all on this GPU, the value
+    counts 2^20-row blocks, and the timed region reports its quarters."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c4", "--log2n", "18", "--steps", "8", "--warmup", "1",
+                        "--cpu-steps", "0", "--no-pmc", "--no-extras"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["config"]["N_total"] == 1 << 18 == d["config"]["rows_per_gpu"] and "configs[3]" in d["config"]["workload"]
+    assert abs(d["value"] - 0.25 * d["config"]["global_steps_per_s"]) < 1e-9 * d["value"]
+    rf = d["roofline"]
+    assert len(rf["launch_us_segments"]) == 4 and rf["unstable"] in (False, True) and 0 < rf["frac"] <= 1.0
+    assert list(rf)[:8] == ["bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us"]     # the gate scalars lead
+
+
 def test_bench_extras_points_are_physical():
     """The measurement functions behind bench.py's `extras` (tools/bench_points.py), at small sizes: every `frac` is a physical
     fraction of the 8 TB/s roofline (bytes the implementation moves / time), the SURVEY 8d model of the Newton sweep is reported

@@ -192,13 +192,14 @@ def test_dense_c1_fixture(ctx):
             k += 1
 
 
-@pytest.mark.parametrize("N,batch", [(33, 1), (33, 8), (128, 31), (128, 64), (1000, 64), (515, 40), (1000, 96)])
+@pytest.mark.parametrize("N,batch", [(33, 1), (33, 8), (128, 31), (128, 64), (1000, 64), (515, 40), (1000, 96), (2050, 40), (3203, 64)])
 @pytest.mark.parametrize("real", [False, True])
 def test_dense_batched_cheby_on_the_matrix_cores(ctx, N, batch, real):
     """qp_cheby_step_batched of a dense operator: H [psi_1 .. psi_b] as a dense panel contraction on the fp64 matrix cores
     (v_mfma_f64_16x16x4_f64), recurrence + accumulate in the tile's epilogue; every state against the oracle's cheby!,
     forward and backward; ragged N (tile edges, inner dimension not a multiple of 4) and panel widths that do not fill
-    a tile."""
+    a tile.  The three tile shapes of the kernel are all taken: 16 x 16 (narrow panels, or too few rows for wider tiles to
+    fill the chip), 16 x 32 (N = 2050, b = 40) and 32 x 32 (N = 3203, b = 64)."""
     rng = np.random.default_rng(N + batch)
     H = synth.dense_hermitian(N, rho=4.0, rng=rng)
     if real:
@@ -215,7 +216,8 @@ def test_dense_batched_cheby_on_the_matrix_cores(ctx, N, batch, real):
     st = ctx.stats()
     assert st["n_matvec"] == wrk.n_coeffs - 1 and st["n_kernel_launches"] <= wrk.n_coeffs     # one launch per term (+ a copy)
     got = panel.numpy().reshape(N, batch)
-    for s in range(batch):
+    checked = range(batch) if N <= 1000 else sorted({0, 15, 16, 17, 31, 32, batch - 1} & set(range(batch)))   # (the oracle is O(N^2) per state and term)
+    for s in checked:
         ref = qo.cheby(states[:, s].copy(), H, dt, qo.ChebyWrk(states[:, s], Delta, E_min, dt))
         assert np.linalg.norm(got[:, s] - ref) < TOL, s
     # the sparse panel kernels on the same operator (knob dense_panel_mfma 0): same states to 1e-12

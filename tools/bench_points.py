@@ -19,11 +19,27 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s;
 FMT_NAME = {1: "csr", 2: "rbcsr", 3: "hrb (Hermitian-packed row blocks)", 4: "matrix-free", 5: "dense (row-major, no index bytes)"}
 
 
+def _cpu_throttled_ms():
+    """Milliseconds this process's control group has been throttled by the CPU quota so far (cgroup v2 cpu.stat, else v1), or
+    None: a region during which this number grows lost its host thread to the container's scheduler, not to the library."""
+    for path, key, scale in (("/sys/fs/cgroup/cpu.stat", "throttled_usec", 1e-3),
+                             ("/sys/fs/cgroup/cpu/cpu.stat", "throttled_time", 1e-6),
+                             ("/sys/fs/cgroup/cpu,cpuacct/cpu.stat", "throttled_time", 1e-6)):
+        try:
+            with open(path) as f:
+                for ln in f:
+                    if ln.startswith(key + " "):
+                        return float(ln.split()[1]) * scale
+        except OSError:
+            continue
+    return None
+
+
 def timed_regions(ctx, fn, steps, repeats=3):
     """`repeats` timed regions of `steps` calls of fn, each bracketed by HIP events on the kernels' stream; next to every
     region's event time what the HOST did meanwhile -- wall time of the enqueue loop and the longest single call -- so that a
     host stall (the device drains its queue and idles inside the event bracket) can be told from a device slow mode.
-    -> [(event_ms, enqueue_ms, longest_call_ms)]
+    -> [(event_ms, enqueue_ms, longest_call_ms, ms the control group was throttled by its CPU quota meanwhile or None)]
 
     The interpreter's cyclic garbage collector is switched off inside a region (as `timeit` does): in a process that has
     imported torch a full collection takes 50-80 ms, it is triggered by the allocation count -- i.e. by the ctypes wrappers'
@@ -31,6 +47,16 @@ def timed_regions(ctx, fn, steps, repeats=3):
     one 455 us-per-term sample of round 3 was (profiles/r04/n22_outlier.txt); QP_BENCH_GC=1 leaves the collector on."""
     out = []
     keep_gc = os.environ.get("QP_BENCH_GC") == "1"
+    # The host phases before a point (synthetic generation and operator build on several threads, the CPU baseline's OpenMP
+    # team) can exhaust the container's CPU quota for the current scheduler period: the whole control group is then frozen
+    # until the period ends -- up to 100 ms, landing in the first timed region.  If the throttle counter moved lately, let
+    # the period pass before timing.
+    thr = _cpu_throttled_ms()
+    if thr is not None:
+        time.sleep(0.02)
+        if _cpu_throttled_ms() != thr or thr != getattr(timed_regions, "_last_thr", None):
+            time.sleep(0.12)
+        timed_regions._last_thr = _cpu_throttled_ms()
     for _ in range(repeats):
         ctx.sync()
         longest = 0.0
@@ -38,6 +64,7 @@ def timed_regions(ctx, fn, steps, repeats=3):
         if not keep_gc:
             gc.disable()
         try:
+            thr0 = _cpu_throttled_ms()
             ctx.timer_begin()
             t0 = time.perf_counter()
             for _ in range(steps):
@@ -45,7 +72,9 @@ def timed_regions(ctx, fn, steps, repeats=3):
                 fn()
                 longest = max(longest, time.perf_counter() - t1)
             enq = time.perf_counter() - t0
-            out.append((ctx.timer_end(), 1e3 * enq, 1e3 * longest))
+            ev = ctx.timer_end()
+            thr1 = _cpu_throttled_ms()
+            out.append((ev, 1e3 * enq, 1e3 * longest, (thr1 - thr0) if (thr0 is not None and thr1 is not None) else None))
         finally:
             if was_on:
                 gc.enable()
@@ -61,7 +90,8 @@ def spread(values, regions=None):
     if regions is not None and out["unstable"]:
         slow = max(regions, key=lambda r: r[0])
         out["slowest_region"] = {"event_ms": slow[0], "host_enqueue_ms": slow[1], "longest_single_call_ms": slow[2],
-                                 "host_stall_suspected": bool(slow[1] > 0.8 * slow[0])}
+                                 "host_stall_suspected": bool(slow[2] > 0.5 * slow[0] or slow[1] > 0.8 * slow[0]),
+                                 "cpu_quota_throttled_ms": slow[3] if len(slow) > 3 else None}
     return out
 
 
@@ -185,6 +215,7 @@ def measure_cheby(ctx, pattern="banded", log2n=20, fmt="auto", steps=10, warmup=
            "csr_equivalent_gbs": by["csr_equivalent_per_term"] / t_term / 1e9,
            "encodings": {"row_blocks": lay["blocks"], "stencil_upper_blocks": lay["stencil_upper_blocks"],
                          "stencil_lower_blocks": lay["stencil_lower_blocks"], "index_bytes": lay["index_bytes"]},
+           "strip_walk_reason": op.walk_reason()[1],      # "ok", or why this operator's term is not the strip walk (qp_operator_walk_reason)
            "norm_drift": abs(psi.norm() - 1.0)}
     if grid:
         out["explicit_zeros_completing_the_lattice"] = op.fill_info()

@@ -40,6 +40,7 @@ def timed(ctx, psi, op, wrk, steps):
     nterms = wrk.n_coeffs - 1
     ctx.sync()
     longest = 0.0
+    thr0 = bp._cpu_throttled_ms()
     ctx.timer_begin()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -48,6 +49,9 @@ def timed(ctx, psi, op, wrk, steps):
         longest = max(longest, time.perf_counter() - t1)
     enq = time.perf_counter() - t0
     ms = ctx.timer_end()
+    thr1 = bp._cpu_throttled_ms()
+    if thr0 is not None and thr1 is not None and thr1 - thr0 > 1.0:
+        print(f"    (CPU quota: the control group was throttled for {thr1 - thr0:.1f} ms during this region)")
     return 1e3 * ms / (steps * nterms), 1e3 * enq, 1e3 * longest
 
 

@@ -8,3 +8,4 @@ timeout 900 python tools/stress_overlap.py > gpurun_out/fz/stress_overlap.txt 2>
 timeout 1500 python tools/fuzz_walk.py 500 11 > gpurun_out/fz/fuzz_walk.txt 2>&1; tail -1 gpurun_out/fz/fuzz_walk.txt
 timeout 1500 python tools/fuzz_walk.py 500 31 > gpurun_out/fz/fuzz_walk_long_pair.txt 2>&1; tail -1 gpurun_out/fz/fuzz_walk_long_pair.txt
 timeout 900 python tools/fuzz_liouville.py > gpurun_out/fz/fuzz_liouville.txt 2>&1; tail -1 gpurun_out/fz/fuzz_liouville.txt
+timeout 900 python tools/fuzz_dense.py 400 3 > gpurun_out/fz/fuzz_dense.txt 2>&1; tail -1 gpurun_out/fz/fuzz_dense.txt

@@ -183,35 +183,6 @@ int launch_arnoldi_matvec_dots(hipStream_t s, const DevMatrix& A, const double2*
 bool walk_shape_supported(int nn, int K, int z0, int xl = 0);   // is there a kernel instance for this stencil shape?
 int launch_hrb_walk_cheby(hipStream_t s, const DevMatrix& A, const double2* x, const ChebyEpi& e, const Tuning& tun,
                           bool* launched, const RowSet* rs = nullptr);
-// kernels_sweep.hip: a whole Arnoldi sweep as one cooperative launch with the basis resident in registers / LDS (at most 2^18 rows)
-struct SweepArgs {
-  // operator (row-block format)
-  const int64_t* bptr;
-  const int64_t* cmeta;
-  const char* colbytes;
-  const void* vals;          // double2, or double for the real copy
-  int64_t nblocks, nrows;
-  // Krylov object
-  double2* Q;                // basis in memory, vector k at Q + k ldq (q_0 = the normalised start vector on entry)
-  int64_t ldq;
-  double2* raw0;             // ping-pong buffers of the unnormalised vectors u_j (u_j in raw[j & 1]; u_0 = q_0 is read from Q)
-  double2* raw1;
-  double2* partials;         // [2 nvec][256] multidot partials (value-major)
-  double2* norm_part;        // [2][256] |u|^2 partials, ping-pong
-  double2* G;                // Gram rows, leading dimension ldg
-  int ldg;
-  double2* hess;             // host-mapped Hessenberg matrix, column-major, leading dimension ldh
-  double* norms;             // host-mapped norms
-  int ldh;
-  unsigned* flags;           // host-mapped: [0, nvec) column complete, [nvec, 2 nvec) column's coefficients written
-  int nvec;
-  unsigned seq;              // the value the flags are set to
-  int m;                     // columns
-  double dt, norm_min;
-  unsigned* barrier;         // device counter, zero on entry
-  unsigned* error;           // host-mapped: set to 1 if a barrier wait gave up
-};
-int launch_arnoldi_sweep_resident(hipStream_t s, const DevMatrix& A, const SweepArgs& a, int n_cu, bool* launched, Stats* st);
 // kernels_dense.hip (QP_FMT_DENSE: CSR arrays with a complete pattern, i.e. vals / vals_r is the row-major dense matrix)
 int launch_dense_gemv_cheby(hipStream_t s, const DevMatrix& A, const double2* x, const ChebyEpi& e, Stats* st);
 int launch_dense_gemv_plain(hipStream_t s, const DevMatrix& A, const double2* x, const PlainEpi& e, Stats* st);
@@ -242,7 +213,6 @@ struct Tuning {
   int acc_defer = 1;          // qp_cheby_step: touch the Psi accumulator every third term only (1) or every term (0)
   int cheby_graph = 0;        // qp_cheby_step: replay a repeated step as a hipGraph when the mat-vec grid has at most this many workgroups (0: off; measured: no gain)
   int roctx = 0;              // 1 = named profiler ranges around the steps' phases (qprop_internal.h: ScopedRange); also QP_ROCTX=1
-  int arnoldi_resident = 1;   // 1 = a pipelined, folded sweep of at most 2^18 rows runs as ONE cooperative launch with the basis resident on the chip (kernels_sweep.hip)
   int newton_graph = 0;       // 1 = a Newton restart's Arnoldi columns are replayed from a hipGraph (recorded on the second identical sweep)
   int arnoldi_l2_order = 1;   // 1 = the projection kernel owns the mat-vec's rows per XCD and reads rounds / basis vectors back to front (L2 reuse of what the dots pass read last)
   int arnoldi_nt = 1;         // 1 = the fused Arnoldi mat-vec streams the matrix nontemporal (the L2 keeps basis vectors instead)

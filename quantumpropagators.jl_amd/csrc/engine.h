@@ -159,9 +159,8 @@ struct qp_krylov {
   // folded sweep: the mat-vec of column j + 1 announces "column j is complete on the host" by storing the sweep's
   // sequence number into col_flags[j] (coherent pinned memory, system-scope release) after it has written
   // Hess[j+1, j] and the norm -- the host polls instead of waiting for an event (no event record between columns)
-  unsigned* col_flags = nullptr;        // (2 nvec flags + one error word of the resident sweep, kernels_sweep.hip)
+  unsigned* col_flags = nullptr;
   unsigned* col_flags_map = nullptr;
-  unsigned* sweep_barrier = nullptr;    // device: arrival counter of the resident sweep's grid barriers
   unsigned seq = 0;
   std::chrono::steady_clock::time_point t_last_column;   // when the host saw the last column of the latest sweep
   // hipGraph of one sweep's column launches (knob newton_graph; engine_krylov.hip: arnoldi_impl)

@@ -46,9 +46,8 @@ int qp_krylov_create(qp_ctx* ctx, int64_t n, int nvec, qp_krylov** out) {
   QP_HIP(hipHostMalloc((void**)&q->h_hess, sizeof(double2) * (size_t)nvec * nvec, hflags));
   QP_HIP(hipHostMalloc((void**)&q->h_norms, sizeof(double) * (size_t)nvec, hflags));
   // [0, nvec): column complete (with its norm); [nvec, 2 nvec): the column's MGS coefficients are written (early flag)
-  QP_HIP(hipHostMalloc((void**)&q->col_flags, sizeof(unsigned) * ((size_t)nvec * 2 + 1), hflags));
-  std::memset(q->col_flags, 0, sizeof(unsigned) * ((size_t)nvec * 2 + 1));
-  QP_HIP(hipMalloc((void**)&q->sweep_barrier, sizeof(unsigned)));
+  QP_HIP(hipHostMalloc((void**)&q->col_flags, sizeof(unsigned) * (size_t)nvec * 2, hflags));
+  std::memset(q->col_flags, 0, sizeof(unsigned) * (size_t)nvec * 2);
   QP_HIP(hipHostGetDevicePointer((void**)&q->hess_map, q->h_hess, 0));
   QP_HIP(hipHostGetDevicePointer((void**)&q->norms_map, q->h_norms, 0));
   QP_HIP(hipHostGetDevicePointer((void**)&q->col_flags_map, q->col_flags, 0));
@@ -76,7 +75,6 @@ int qp_krylov_destroy(qp_krylov* q) {
   if (q->hcoef) (void)hipFree(q->hcoef);
   if (q->mgs_coef) (void)hipFree(q->mgs_coef);
   if (q->ticket) (void)hipFree(q->ticket);
-  if (q->sweep_barrier) (void)hipFree(q->sweep_barrier);
   for (hipEvent_t e : q->col_events) (void)hipEventDestroy(e);
   if (q->sweep_exec) (void)hipGraphExecDestroy(q->sweep_exec);
   delete q;
@@ -341,48 +339,7 @@ static int arnoldi_impl(qp_operator* op, qp_krylov* q, int m, const qp_state* ps
     }
     return QP_OK;
     };
-    // knob arnoldi_resident: the whole sweep as ONE cooperative launch with the Krylov basis resident in registers / LDS
-    // (kernels_sweep.hip) -- systems of at most 2^18 rows in the row-block format, m <= 20, low-synchronisation MGS; same
-    // flags, same Hessenberg / norm slots, so the host side below does not know the difference
-    bool resident = false;
-    if (flags && extended && !use_graph && !record_graph && ctx->tun.arnoldi_resident != 0 && ctx->tun.arnoldi_mode == 1 &&
-        ctx->tun.arnoldi_fuse_dots != 0 && ctx->tun.arnoldi_solve != 0 && qp::mgs_lowsync_fits(m - 1) && q->n < ((int64_t)1 << 28)) {
-      qp::SweepArgs sa;
-      sa.bptr = op->A.bptr;
-      sa.cmeta = op->A.cmeta;
-      sa.colbytes = reinterpret_cast<const char*>(op->A.cols);
-      sa.vals = op->A.vals_r ? (const void*)op->A.vals_r : (const void*)op->A.vals;
-      sa.nblocks = op->A.nblocks;
-      sa.nrows = op->A.nrows;
-      sa.Q = q->Q;
-      sa.ldq = q->n;
-      sa.raw0 = q->raw[0];
-      sa.raw1 = q->raw[1];
-      sa.partials = q->md_part;
-      sa.norm_part = q->part;
-      sa.G = q->gram;
-      sa.ldg = q->nvec;
-      sa.hess = q->hess_map;
-      sa.norms = q->norms_map;
-      sa.ldh = ldd;
-      sa.flags = q->col_flags_map;
-      sa.nvec = q->nvec;
-      sa.seq = q->seq;
-      sa.m = m;
-      sa.dt = dt;
-      sa.norm_min = norm_min;
-      sa.barrier = q->sweep_barrier;
-      sa.error = q->col_flags_map + 2 * (size_t)q->nvec;
-      q->col_flags[2 * (size_t)q->nvec] = 0;
-      QP_HIP(hipMemsetAsync(q->sweep_barrier, 0, sizeof(unsigned), ctx->stream));
-      QP_CHECK(qp::launch_arnoldi_sweep_resident(ctx->stream, op->A, sa, ctx->tun.n_cu, &resident, &ctx->stats));
-      if (resident) {
-        q->gram_rows = m;
-        early_last = true;
-      }
-    }
-    if (resident) {
-    } else if (use_graph) {
+    if (use_graph) {
       QP_HIP(hipGraphLaunch(q->sweep_exec, ctx->stream));
       ctx->stats.n_graph_launch++;
       ctx->stats.n_matvec += q->sweep_stats.n_matvec;
@@ -490,8 +447,6 @@ static int arnoldi_impl(qp_operator* op, qp_krylov* q, int m, const qp_state* ps
   // column announced itself, and what the device still does -- normalising the last vector -- is consumed in stream order.)
   if (piped && !(flags && extended && m_eff == m && hook_rc == QP_OK)) QP_HIP(hipStreamSynchronize(ctx->stream));
   if (hook_rc != QP_OK) return hook_rc;
-  if (!small && q->col_flags[2 * (size_t)q->nvec] != 0)
-    return qp::fail(QP_E_INTERNAL, "the resident Arnoldi sweep gave up waiting at a grid barrier");
   *m_out = m_eff;
   return QP_OK;
   QP_CATCH

@@ -1085,7 +1085,7 @@ int* tuning_field(Tuning& t, const char* key) {
       {"liouville_fused_n", &Tuning::liouville_fused_n}, {"liouville_tile32_n", &Tuning::liouville_tile32_n}, {"liouville_tile32_min_n", &Tuning::liouville_tile32_min_n}, {"real_vals", &Tuning::real_vals},
       {"stencil", &Tuning::stencil},             {"acc_defer", &Tuning::acc_defer},
       {"cheby_graph", &Tuning::cheby_graph},     {"small_nnz", &Tuning::small_nnz},
-      {"roctx", &Tuning::roctx}, {"arnoldi_resident", &Tuning::arnoldi_resident}, {"newton_graph", &Tuning::newton_graph}, {"arnoldi_l2_order", &Tuning::arnoldi_l2_order}, {"arnoldi_nt", &Tuning::arnoldi_nt},
+      {"roctx", &Tuning::roctx}, {"newton_graph", &Tuning::newton_graph}, {"arnoldi_l2_order", &Tuning::arnoldi_l2_order}, {"arnoldi_nt", &Tuning::arnoldi_nt},
       {"dense_auto", &Tuning::dense_auto},       {"dense_min_density_pct", &Tuning::dense_min_density_pct}, {"dense_panel_mfma", &Tuning::dense_panel_mfma},
       {"newton_pipeline", &Tuning::newton_pipeline}, {"spmm_tile", &Tuning::spmm_tile},
       {"spmm_nt", &Tuning::spmm_nt},             {"spmm_rows", &Tuning::spmm_rows},
@@ -1721,7 +1721,7 @@ int launch_combine_vecs(hipStream_t s, double2* out, int use_out, double2 s0, co
 // ---------------------------------------------------------------------------
 constexpr int kTI = 8;  // basis vectors per multidot tile (16 complex accumulators per lane)
 
-#include "mgs_common.h"   // tri_index, mgs_solve_wave, mgs_stage_gram (shared with kernels_sweep.hip)
+#include "mgs_common.h"   // tri_index, mgs_solve_wave, mgs_stage_gram
 
 // LDS of the finishing workgroup: red[2(j+1)] | h[j+1] | Gt[j(j+1)/2]
 __host__ __device__ inline size_t mgs_solve_lds(int j) {

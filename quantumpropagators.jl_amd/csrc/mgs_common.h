@@ -1,6 +1,5 @@
-// Device helpers of the low-synchronisation modified Gram-Schmidt (kernels.hip: mgs_update_kernel and friends;
-// kernels_sweep.hip: the resident-basis Arnoldi sweep).  Included INSIDE namespace qp by both translation units.
-// (no include guard needed beyond this: each TU includes it once)
+// Device helpers of the low-synchronisation modified Gram-Schmidt (kernels.hip: mgs_update_kernel and friends).  Included
+// INSIDE namespace qp.
 __device__ __forceinline__ int tri_index(int i, int k) { return i * (i - 1) / 2 + k; }  // k < i
 
 // Forward substitution  h_i = c_i - sum_{k<i} <q_i|q_k> h_k  (the MGS coefficients, see above) by

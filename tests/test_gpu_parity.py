@@ -1135,47 +1135,6 @@ def test_newton_sweep_knobs_match_oracle(ctx, l2_order, nt, graph, n):
             ctx.tuning_set(k, v)
 
 
-@pytest.mark.parametrize("n,m_max", [(96, 12), (200, 20), (300, 7), (512, 20)])
-def test_newton_resident_sweep_matches_oracle_and_the_two_kernel_path(ctx, n, m_max):
-    """The Arnoldi sweep as ONE cooperative launch with the Krylov basis resident in registers / LDS (csrc/kernels_sweep.hip,
-    knob arnoldi_resident; systems of at most 2^18 rows -- n = 512 is config C3 at full size, n = 200 has a partly filled
-    second round of row blocks, m_max = 20 uses the memory tail of the basis beyond the 17 resident vectors): several steps
-    against the oracle (|delta psi| < 1e-10, equal restart counts), against the two-kernel path (1e-12), run-to-run identical
-    bits, and ONE launch per sweep."""
-    Lm = synth.liouvillian_tridiag(n)
-    N = Lm.shape[0]
-    rho0 = synth.random_state(N)
-    Op = L.Operator(ctx, [L.Matrix.from_scipy(ctx, Lm)])
-    assert Op.format == L.FMT_RBCSR
-    steps = (0.5, 0.5, -0.3) if n < 512 else (0.5,)
-    outs = {}
-    for resident in (1, 0, 1):
-        ctx.tuning_set("arnoldi_resident", resident)
-        try:
-            wrk = L.NewtonWrk(ctx, N, m_max=m_max)
-            rho = L.State(ctx, data=rho0)
-            ctx.reset_stats()
-            sweeps = 0
-            for dt in steps:
-                L.newton(rho, Op, dt, wrk)
-                sweeps += wrk.restarts + 1
-            launches = ctx.stats()["n_kernel_launches"]
-            outs.setdefault(resident, []).append((rho.numpy(), wrk.restarts, launches / sweeps))
-        finally:
-            ctx.tuning_set("arnoldi_resident", 1)
-    ref = rho0.copy()
-    owrk = qo.NewtonWrk(rho0, m_max=m_max)
-    for dt in steps:
-        qo.newton(ref, Lm, dt, owrk)
-    (r1, rs1, lps1), (r1b, _, _) = outs[1]
-    (r0, rs0, lps0), = outs[0]
-    assert np.linalg.norm(r1 - ref) < TOL and np.linalg.norm(r0 - ref) < TOL
-    assert rs1 == rs0 == owrk.restarts
-    assert np.linalg.norm(r1 - r0) < 1e-12
-    assert np.array_equal(r1, r1b)                        # fixed reduction orders: the same bits every run
-    assert lps1 < 8 < lps0, (lps1, lps0)                   # one launch per sweep (+ the start vector's and the combination's)
-
-
 def test_batched_c5_full_size_properties(ctx):
     """BASELINE configs[4] at full size: 64 states x N = 2^18.  Three columns of the panel against the C restatement of
     the reference's serial CSC path (oracle/cheby_ref.c, ~0.15 s of one core each) -- the oracle DIRECTLY at the full

@@ -16,15 +16,12 @@ sys.path.insert(0, ROOT)
 import qprop_amd.lib as L  # noqa: E402
 import qprop_amd.synth as synth  # noqa: E402
 
-DEFAULT = ("resident:arnoldi_resident=1,arnoldi_l2_order=1,arnoldi_nt=1,newton_graph=0;"
-           "two_kernels:arnoldi_resident=0,arnoldi_l2_order=1,arnoldi_nt=1,newton_graph=0;"
-           "two_kernels_round3:arnoldi_resident=0,arnoldi_l2_order=0,arnoldi_nt=0,newton_graph=0")
-ROUND4_KNOBS = ("base:arnoldi_resident=0,arnoldi_l2_order=0,arnoldi_nt=0,newton_graph=0;"
-                "l2order:arnoldi_resident=0,arnoldi_l2_order=1,arnoldi_nt=0,newton_graph=0;"
-                "nt:arnoldi_resident=0,arnoldi_l2_order=0,arnoldi_nt=1,newton_graph=0;"
-                "l2order+nt:arnoldi_resident=0,arnoldi_l2_order=1,arnoldi_nt=1,newton_graph=0;"
-                "l2order+nt+graph:arnoldi_resident=0,arnoldi_l2_order=1,arnoldi_nt=1,newton_graph=1;"
-                "graph:arnoldi_resident=0,arnoldi_l2_order=0,arnoldi_nt=0,newton_graph=1")
+DEFAULT = ("base:arnoldi_l2_order=0,arnoldi_nt=0,newton_graph=0;"
+           "l2order:arnoldi_l2_order=1,arnoldi_nt=0,newton_graph=0;"
+           "nt:arnoldi_l2_order=0,arnoldi_nt=1,newton_graph=0;"
+           "l2order+nt:arnoldi_l2_order=1,arnoldi_nt=1,newton_graph=0;"
+           "l2order+nt+graph:arnoldi_l2_order=1,arnoldi_nt=1,newton_graph=1;"
+           "graph:arnoldi_l2_order=0,arnoldi_nt=0,newton_graph=1")
 
 
 def main():

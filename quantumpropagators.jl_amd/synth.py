@@ -85,19 +85,15 @@ def _offsets_rows(N, offsets, rho, seed, a, b, col_out, val_out):
         src = (rows - d) % N
         cols[:, 2 * k + 1] = src
         vals[:, 2 * k + 1] = np.conj(coupling(seed, src, k, rho, nk))
-    # columns ascending within a row.  Away from the periodic wrap every row has the SAME order (i - d_max ... i + d_max):
-    # sort one row and apply its permutation to the chunk; rows whose columns wrap are sorted one by one
-    dmax = max(offsets)
-    lo, hi = max(a, dmax), min(b, N - dmax)          # rows [lo, hi) do not wrap
-    if lo < hi:
-        perm = np.argsort(cols[lo - a], kind="stable")
-        col_out[lo - a:hi - a] = cols[lo - a:hi - a][:, perm]
-        val_out[lo - a:hi - a] = vals[lo - a:hi - a][:, perm]
-    for s, e in ((a, min(lo, b)), (max(hi, a), b)) if lo < hi else ((a, b),):
-        if s < e:
-            order = np.argsort(cols[s - a:e - a], axis=1, kind="stable")
-            col_out[s - a:e - a] = np.take_along_axis(cols[s - a:e - a], order, axis=1)
-            val_out[s - a:e - a] = np.take_along_axis(vals[s - a:e - a], order, axis=1)
+    # columns ascending within a row.  Between two consecutive rows of {d_k, N - d_k} no column wraps differently, so every
+    # row of such a segment has the SAME order: sort one row per segment and apply its permutation (for the banded offsets
+    # the segments are [0, 1), [1, 2) ... near the ends and one long one in the middle; for scattered offsets up to N / 2
+    # there are at most 4 len(offsets) + 1 of them)
+    cuts = sorted({a, b} | {c for d in offsets for c in (d, N - d) if a < c < b})
+    for s, e in zip(cuts[:-1], cuts[1:]):
+        perm = np.argsort(cols[s - a], kind="stable")
+        col_out[s - a:e - a] = cols[s - a:e - a][:, perm]
+        val_out[s - a:e - a] = vals[s - a:e - a][:, perm]
 
 
 def hermitian_offsets_csr(N, offsets=BANDED_OFFSETS, rho=10.0, seed=DEFAULT_SEED,

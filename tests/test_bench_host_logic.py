@@ -1,0 +1,91 @@
+"""CPU tests of the measurement plumbing that needs no GPU: the repeat / median / outlier record of tools/bench_points.py, the
+prediction table of bench.py (what the first real multi-GPU run is read against), the quota-aware thread count of the
+synthetic generator, and that the chunked generator is deterministic across chunkings."""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("qp_bench_module", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_spread_flags_an_unstable_point_and_blames_the_host_when_it_was_the_host():
+    import bench_points as bp
+    quiet = bp.spread([134.6, 134.5, 135.7], [(20.9, 0.6, 0.2, 0.0), (20.8, 0.6, 0.2, 0.0), (21.0, 0.7, 0.2, 0.0)])
+    assert quiet["median"] == 134.6 and quiet["unstable"] is False and "slowest_region" not in quiet
+    # one region with a 70 ms stall inside ONE library call while the control group was throttled
+    stalled = bp.spread([134.6, 586.1, 134.5], [(20.9, 0.6, 0.2, 0.0), (90.85, 70.7, 70.2, 1656.3), (20.8, 0.6, 0.2, 0.0)])
+    assert stalled["median"] == 134.6 and stalled["min"] == 134.5 and stalled["max"] == 586.1 and stalled["unstable"] is True
+    sr = stalled["slowest_region"]
+    assert sr["host_stall_suspected"] is True and sr["cpu_quota_throttled_ms"] == 1656.3 and sr["longest_single_call_ms"] == 70.2
+    # a slow region the host does NOT explain (short enqueue, long events): a device matter
+    device = bp.spread([100.0, 100.0, 180.0], [(15.5, 0.5, 0.2, 0.0), (15.5, 0.5, 0.2, 0.0), (27.9, 0.6, 0.2, 0.0)])
+    assert device["unstable"] is True and device["slowest_region"]["host_stall_suspected"] is False
+
+
+def test_scaling_prediction_table():
+    b = _bench()
+    sizes = {20: 31.1, 21: 65.5, 22: 127.6, 23: 284.2, 24: 629.6}
+    p = b.scaling_prediction(sizes, 1036.5, 31, "test")
+    rows = p["fixed_problem_N_2^24"]
+    assert [r["gpus"] for r in rows] == [1, 2, 4, 8] and [r["rows_per_gpu"] for r in rows] == [1 << 24, 1 << 23, 1 << 22, 1 << 21]
+    assert rows[0]["speedup_halo_overlap"] == 1.0
+    # halo form: the exchange (10 us + 131 KB at 153 GB/s) hides behind the interior launch; the machinery costs 8.6 %
+    assert abs(rows[3]["exchange_us_halo"] - (10.0 + 16 * 8192 / 153e3)) < 1e-9
+    assert abs(rows[3]["us_per_term_halo_overlap"] - b.MACHINERY_FACTOR * 65.5) < 1e-9
+    assert rows[3]["speedup_halo_overlap"] > 6.0 and rows[3]["speedup_halo_serial"] > 6.0
+    # all-gather form: 16 N / G bytes per link and term -- link-bound, far from 6 x
+    assert abs(rows[3]["exchange_us_allgather"] - (10.0 + 16.0 * (1 << 21) / 153e3)) < 1e-9
+    assert rows[3]["speedup_allgather"] < 3.0 and rows[1]["speedup_allgather"] < 1.0
+    weak = p["bench_default_weak_2^21_rows_per_gpu"]
+    assert [w["gpus"] for w in weak] == [1, 2, 4, 8] and 0.8 < weak[3]["predicted_efficiency_vs_1gpu_value"] < 1.0
+    # a run that lacks a size leaves that row out instead of inventing it
+    q = b.scaling_prediction({21: 65.5, 24: 629.6}, 1036.5, 31, "test")
+    assert [r["gpus"] for r in q["fixed_problem_N_2^24"]] == [1, 8]
+    # the committed single-GPU sizes feed a multi-GPU line's table
+    st = b.scaling_prediction_static(31)
+    assert st is None or st["source_of_compute_times"].startswith("STATIC")
+
+
+def test_exchange_model_of_a_halo_partition():
+    b = _bench()
+
+    class Sh:
+        M, exchange, send_to = 8192, "halo", [1, 7]
+    xm = b.exchange_model(Sh, 8, 1 << 21, 70.0)
+    assert xm["peers"] == 2 and xm["bytes_on_busiest_link_per_term"] == 16 * 8192
+    assert xm["predicted_exposed_us_per_term_overlap_schedule"] == 0.0 and xm["predicted_exposed_us_per_term_serial_schedule"] > 10.0
+
+    class Ag:
+        M, exchange, send_to = 1 << 21, "allgather", None
+    xa = b.exchange_model(Ag, 8, 1 << 21, 70.0)
+    assert xa["peers"] == 7 and xa["bytes_sent_per_rank_per_term"] == 16.0 * (1 << 21) * 7
+    assert xa["predicted_exposed_us_per_term_overlap_schedule"] > 100.0          # 32 MiB per link: not hidden by a 70 us launch
+
+
+def test_generator_is_chunking_independent_and_quota_aware():
+    import qprop_amd.synth as synth
+    assert 1 <= synth._usable_cpus() <= (os.cpu_count() or 1)
+    N = 70000 + 1234       # not a multiple of the chunk size; banded offsets wrap at both ends
+    rp, col, vals = synth.hermitian_offsets_csr(N)
+    a, b, c = synth.hermitian_offsets_csr(N, row_begin=65000, row_end=69000)
+    assert np.array_equal(col[65000 * 16:69000 * 16], b) and np.array_equal(vals[65000 * 16:69000 * 16], c)
+    # Hermitian, 16 distinct columns per row, ascending
+    import scipy.sparse as sp
+    H = sp.csr_matrix((vals, col, rp), shape=(N, N))
+    assert abs(H - H.getH()).max() == 0.0
+    assert np.all(np.diff(col.reshape(N, 16), axis=1) > 0)
+    offs = synth.scattered_offsets(1 << 14)
+    r2, c2, v2 = synth.hermitian_offsets_csr(1 << 14, offsets=offs)
+    H2 = sp.csr_matrix((v2, c2, r2), shape=(1 << 14, 1 << 14))
+    assert abs(H2 - H2.getH()).max() == 0.0 and np.all(np.diff(c2.reshape(-1, 16), axis=1) > 0)

@@ -200,6 +200,15 @@ int qp_operator_walk_info(const qp_operator* op, int64_t out[8]);
 /* *glong = the long distance L (rows) of a walk plan with one further pair of distances +-L beyond its far reach
  * (a three-dimensional grid's plane distance; its operands are loaded directly), 0 if the plan has none / there is no plan */
 int qp_operator_walk_long(const qp_operator* op, int64_t* glong);
+/* Column-blocked mirror of an operator with IRREGULAR columns (src/generators.jl:634-645 accepts any sparse H_l; a random
+ * graph's gathers are each their own cache line and the vector outgrows the L2): the entries are also kept grouped by
+ * (row tile, column block) and whole-operator mat-vecs (cheby!, arnoldi!, mul!) walk the column blocks in their outer loop, so
+ * that the whole chip gathers from one L2-resident window of the vector at a time (csrc/kernels_colblock.hip).  Built at
+ * qp_operator_create when the operator is laid out as plain row blocks / CSR, has at least 2^19 columns and its sampled
+ * gathers are irregular (knobs colblock, cb_log2w, cb_min_log2n).  out = {1 if the operator has the mirror, column blocks,
+ * log2 of the columns per block, rows per tile, entries of the longest (tile, block) segment, tiles}; *line_share
+ * (nullable) = sampled share of gathers that pull a 128-byte line of their own, 0 if the decision never got that far. */
+int qp_operator_colblock_info(const qp_operator* op, int64_t out[6], double* line_share);
 /* How evaluate! (qp_operator_set_coeffs / _set_scale) updates the stored values: out[0] = index of the first of the trailing
  * control terms that are kept as (position, value) lists because they touch at most a quarter of the stored values (a dipole
  * operator on a grid is a diagonal), -1 if there are none; out[1] = positions such an update rewrites; out[2] = 1 if the latest

@@ -56,6 +56,8 @@ struct DevMatrix {
   int64_t lstored = 0;
   // HRB strip walk (kernels_walk.hip): valid when the operator is a lattice whose row blocks repeat one stencil
   const struct WalkPlan* walk = nullptr;
+  // column-blocked mirror of an operator with irregular columns (kernels_colblock.hip); used for whole-operator launches
+  const struct ColBlockPlan* cb = nullptr;
   // QP_FMT_MATFREE: no stored entries; y = beta y + alpha A x is delegated to the owner
   // (engine_liouville.hip), and the Chebyshev term runs it followed by an unfused epilogue
   void* matfree = nullptr;
@@ -92,6 +94,32 @@ struct WalkPlan {
   int32_t* edge_map = nullptr;   // device: the blocks outside [W0, R1)
   int64_t n_edge = 0;
 };
+
+// ---- column-blocked mirror (kernels_colblock.hip) ----------------------------------------------------------------------
+// An operator whose columns are irregular (no lattice, no band: src/generators.jl:634-645 allows any sparse H_l) gathers
+// x[col] from all over the vector; at N = 2^20 the vector is 16 MB against the 4 MB of L2 an XCD has, so nearly every
+// gathered element is its own line fetched from the Infinity Cache (233 us per term).  The mirror holds
+// the same entries grouped by (row tile, column block): tiles of 64 rpt rows, blocks of 2^log2w columns; the segment of
+// (tile t, block c) lists the entries of the tile's rows whose column lies in block c, row by row, columns ascending.  The
+// kernel walks the column blocks in the OUTER loop -- every wavefront is resident from the start and owns its tiles for the
+// whole launch -- so at any time the whole chip gathers from one 2^log2w-element window of x that every XCD's L2 holds.
+struct ColBlockPlan {
+  int valid = 0;
+  int log2w = 17;               // columns per block = 1 << log2w  (2 MB of x)
+  int P = 0;                    // column blocks
+  int rpt = 2;                  // 64-row groups per tile
+  int max_seg = 0;              // entries of the longest segment (the per-wavefront LDS buffer holds one segment)
+  int64_t ntiles = 0, nnz = 0;
+  int32_t* segptr = nullptr;    // device [ntiles P + 1]: first entry of segment t P + c
+  uint16_t* rowoff = nullptr;   // device [ntiles P (64 rpt + 1)]: first entry of every row inside its segment
+  uint32_t* cols = nullptr;     // device [nnz]
+  int64_t* map = nullptr;       // device [nnz]: position in the operator's value array (-(position) - 1: its complex conjugate)
+  double2* vals = nullptr;      // device [nnz]: the current values in mirror order (refreshed when the operator's values change)
+  double* vals_r = nullptr;     // device [nnz]: their real parts, streamed instead when every value is real
+  int use_real = 0;
+};
+constexpr int kCbMaxTilesPerWave = 8;
+constexpr int kCbMaxSeg = 1024;
 
 // epilogue of the fused Chebyshev term (see qp_cheby_term in qprop.h)
 struct ChebyEpi {
@@ -187,6 +215,11 @@ int launch_hrb_walk_cheby(hipStream_t s, const DevMatrix& A, const double2* x, c
 int launch_dense_gemv_cheby(hipStream_t s, const DevMatrix& A, const double2* x, const ChebyEpi& e, Stats* st);
 int launch_dense_gemv_plain(hipStream_t s, const DevMatrix& A, const double2* x, const PlainEpi& e, Stats* st);
 int launch_dense_zgemm_cheby(hipStream_t s, const DevMatrix& A, const double2* X, int batch, const ChebyEpi& e, Stats* st);
+// kernels_colblock.hip: *launched = false when the mirror does not apply to this launch (the caller then takes the format's kernel)
+int launch_colblock_cheby(hipStream_t s, const DevMatrix& A, const double2* x, const ChebyEpi& e, const Tuning& tun, bool* launched);
+int launch_colblock_plain(hipStream_t s, const DevMatrix& A, const double2* x, const PlainEpi& e, const Tuning& tun, bool* launched);
+// vals[p] = src[map[p]] (conjugated for a negative map entry); real != NULL: also real[p] = Re vals[p]
+int launch_colblock_gather(hipStream_t s, const ColBlockPlan& P, const double2* src, Stats* st);
 // the formats whose value array is in CSR order (rowptr / cols / vals[p])
 inline bool csr_layout(int format) { return format == QP_FMT_CSR || format == QP_FMT_DENSE; }
 int spmv_grid_size(const DevMatrix& A);
@@ -219,6 +252,10 @@ struct Tuning {
   int dense_auto = 1;         // 1 = AUTO lays an operator out dense (QP_FMT_DENSE) when at least dense_min_density_pct % of its positions are stored
   int dense_min_density_pct = 75;
   int dense_panel_mfma = 1;   // 1 = the batched step of a dense operator runs H X on the fp64 matrix cores (kernels_dense.hip); 0 = the sparse panel kernels (A/B)
+  int colblock = 1;           // 1 = an operator with irregular columns whose vector outgrows the L2 gets a column-blocked mirror (kernels_colblock.hip); 2 = any row-block / CSR operator that fits the mirror's limits (tests); 0 = off
+  int cb_log2w = 17;          // ... columns per block (log2): 2^17 complex elements = 2 MB of the 4 MB an XCD's L2 holds
+  int cb_min_log2n = 19;      // ... smallest number of columns (log2) the mirror is built for (2^18 elements are the L2's 4 MB)
+  int cb_waves = 24;          // ... resident wavefronts per CU the launch is sized for
   int small_nnz = 8192;       // qp_propagate: register-resident Cheby systems up to this nnz run as ONE persistent launch (0: off)
   int newton_pipeline = 1;    // newton!: Hessenberg eigenvalues overlap the Arnoldi sweep
   int spmm_tile = 16;         // states per pass of the tiled batched SpMM kernel (16, 32 or 64)

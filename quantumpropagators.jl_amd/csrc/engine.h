@@ -69,6 +69,8 @@ struct qp_operator {
   qp::WalkPlan walk;              // strip-walk plan of a Hermitian-packed lattice operator (A.walk points here when valid)
   qp::SpmmWalkPlan spmm_walk;     // strip-walk plan of the batched term, built on first use
   bool spmm_walk_built = false;
+  qp::ColBlockPlan cb;            // column-blocked mirror of an operator with irregular columns (A.cb points here when valid)
+  double cb_line_share = 0.0;     // what decided: share of a row block's gathers that pull a line of their own (sampled)
   double build_ms = 0, build_ms_total = 0;   // host time of the latest / of all device layout builds
   int64_t n_lattice_fill = 0;               // explicit zeros that complete a lattice operator's rows (engine_core.hip: lattice_fill)
   int n_builds = 0, n_relayouts = 0;         // re-layouts: builds forced after creation (complex coefficient on a packed operator)

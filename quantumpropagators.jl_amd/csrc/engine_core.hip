@@ -32,9 +32,9 @@ static unsigned host_threads() {
 
 // rows [0, n) in contiguous chunks on a few host threads (index work whose iterations write disjoint positions)
 template <class F>
-static void parallel_rows(int64_t n, F&& fn) {
+static void parallel_rows(int64_t n, F&& fn, int64_t serial_below = (int64_t)1 << 16) {
   const unsigned hw = host_threads();
-  if (n < (int64_t)1 << 16 || hw == 1) {
+  if (n < serial_below || hw == 1) {
     fn((int64_t)0, n);
     return;
   }
@@ -422,6 +422,14 @@ static int operator_free_device(qp_operator* op) {
   if (op->walk.edge_map) (void)hipFree(op->walk.edge_map);
   op->walk = qp::WalkPlan();
   op->A.walk = nullptr;
+  if (op->cb.segptr) (void)hipFree(op->cb.segptr);
+  if (op->cb.rowoff) (void)hipFree(op->cb.rowoff);
+  if (op->cb.cols) (void)hipFree(op->cb.cols);
+  if (op->cb.map) (void)hipFree(op->cb.map);
+  if (op->cb.vals) (void)hipFree(op->cb.vals);
+  if (op->cb.vals_r) (void)hipFree(op->cb.vals_r);
+  op->cb = qp::ColBlockPlan();
+  op->A.cb = nullptr;
   if (op->m_rowptr) (void)hipFree(op->m_rowptr);
   if (op->m_cols) (void)hipFree(op->m_cols);
   if (op->m_map) (void)hipFree(op->m_map);
@@ -1072,11 +1080,161 @@ static int operator_build_device_impl(qp_operator* op, int format, const std::ve
   return QP_OK;
 }
 
+// position of every union-CSR entry in the operator's value array (-(position) - 1: the complex conjugate of that value --
+// the lower entries of a Hermitian-packed operator)
+static void csr_value_map(const qp_operator* op, std::vector<int64_t>& map) {
+  const DevMatrix& A = op->A;
+  const auto& ur = op->u_rowptr;
+  const auto& uc = op->u_col;
+  map.assign((size_t)std::max<int64_t>(A.nnz, 1), 0);
+  parallel_rows(A.nrows, [&](int64_t r_begin, int64_t r_end) {
+    for (int64_t r = r_begin; r < r_end; ++r) {
+      const int64_t nl = (A.format == QP_FMT_HRB) ? op->layout.nlow[r] : 0;
+      for (int64_t k = 0; k < ur[r + 1] - ur[r]; ++k) {
+        int64_t m;
+        if (qp::csr_layout(A.format)) {
+          m = ur[r] + k;
+        } else if (k >= nl) {
+          m = rb_val_pos(op->layout.bptr, r, k - nl);
+        } else {
+          const int64_t c = uc[ur[r] + k];
+          const int32_t* b = uc.data() + ur[c];
+          const int32_t* e = uc.data() + ur[c + 1];
+          const int64_t kk = (std::lower_bound(b, e, (int32_t)r) - b) - op->layout.nlow[c];
+          m = -rb_val_pos(op->layout.bptr, c, kk) - 1;
+        }
+        map[ur[r] + k] = m;
+      }
+    }
+  });
+}
+
+// Column-blocked mirror (device.h: ColBlockPlan; kernels_colblock.hip) for an operator whose gathers are irregular.
+// Decision (knob colblock = 1): plain row blocks or CSR (a lattice is Hermitian-packed and walked; a dense operator has
+// its own kernels), at least 2^cb_min_log2n columns (below, the vector sits in the L2 as it is), at most 64 column blocks
+// and kCbMaxTilesPerWave tiles per resident wavefront, and -- sampled over the row blocks -- more than half of the gathers
+// of a wavefront's load pulling a 128-byte line of their own (a band or a lattice shares each line among 8 lanes: 0.125).
+static int build_colblock(qp_operator* op) {
+  qp_ctx* ctx = op->ctx;
+  const qp::Tuning& tun = ctx->tun;
+  DevMatrix& A = op->A;
+  op->A.cb = nullptr;
+  if (tun.colblock == 0 || (A.format != QP_FMT_RBCSR && A.format != QP_FMT_CSR)) return QP_OK;
+  const auto& ur = op->u_rowptr;
+  const auto& uc = op->u_col;
+  const int64_t nrows = A.nrows, ncols = A.ncols, nnz = A.nnz;
+  if (nrows < 64 || nnz < 1 || nnz >= (int64_t)INT32_MAX || ncols >= ((int64_t)1 << 32)) return QP_OK;
+  const int log2w = std::max(8, std::min(tun.cb_log2w, 24));
+  const int64_t W = (int64_t)1 << log2w;
+  const int64_t P = (ncols + W - 1) / W;
+  if (tun.colblock == 1 && (ncols < ((int64_t)1 << std::max(tun.cb_min_log2n, 1)) || P < 2)) return QP_OK;
+  if (P > 64) return QP_OK;
+  // irregularity: distinct 128-byte lines among the k-th gathers of a 64-row block, over the entries sampled
+  {
+    const int64_t nblocks = nrows / kRB;
+    const int64_t bstride = std::max<int64_t>(1, nblocks / 1024);
+    int64_t gathers = 0, lines = 0;
+    std::vector<int64_t> ln;
+    for (int64_t b = 0; b < nblocks; b += bstride) {
+      int64_t wmax = 0;
+      for (int64_t r = b * kRB; r < (b + 1) * kRB; ++r) wmax = std::max(wmax, ur[r + 1] - ur[r]);
+      for (int64_t k = 0; k < wmax; ++k) {
+        ln.clear();
+        for (int64_t r = b * kRB; r < (b + 1) * kRB; ++r)
+          if (k < ur[r + 1] - ur[r]) ln.push_back((int64_t)uc[ur[r] + k] >> 3);
+        std::sort(ln.begin(), ln.end());
+        gathers += (int64_t)ln.size();
+        lines += (int64_t)(std::unique(ln.begin(), ln.end()) - ln.begin());
+      }
+    }
+    op->cb_line_share = gathers > 0 ? (double)lines / (double)gathers : 0.0;
+    if (tun.colblock == 1 && op->cb_line_share <= 0.5) return QP_OK;
+  }
+  // tile height: 128 rows unless a segment would outgrow the wavefront's LDS buffer, then 64
+  qp::ColBlockPlan& C = op->cb;
+  std::vector<int32_t> segcnt;
+  int rpt = 0, max_seg = 0;
+  int64_t ntiles = 0;
+  for (int tryr : {2, 1}) {
+    const int64_t TR = 64 * tryr;
+    ntiles = (nrows + TR - 1) / TR;
+    segcnt.assign((size_t)(ntiles * P + 1), 0);
+    parallel_rows(ntiles, [&](int64_t t0, int64_t t1) {
+      for (int64_t t = t0; t < t1; ++t)
+        for (int64_t r = t * TR; r < std::min(nrows, (t + 1) * TR); ++r)
+          for (int64_t p = ur[r]; p < ur[r + 1]; ++p) segcnt[(size_t)(t * P + ((int64_t)uc[p] >> log2w))]++;
+    }, 512);
+    max_seg = 0;
+    for (int64_t sgi = 0; sgi < ntiles * P; ++sgi) max_seg = std::max(max_seg, (int)segcnt[(size_t)sgi]);
+    if (max_seg <= qp::kCbMaxSeg) {
+      rpt = tryr;
+      break;
+    }
+  }
+  if (rpt == 0) return QP_OK;   // a (64-row, 2^log2w-column) cell with more than kCbMaxSeg entries: not this kernel's operator
+  {
+    const int64_t resident = (int64_t)std::max(tun.n_cu, 1) * std::max(4, std::min(tun.cb_waves, 32));
+    if ((ntiles + resident - 1) / resident > qp::kCbMaxTilesPerWave) return QP_OK;
+  }
+  const int64_t TR = 64 * rpt;
+  std::vector<int32_t> segptr((size_t)(ntiles * P + 1));
+  {
+    int64_t run = 0;
+    for (int64_t sgi = 0; sgi < ntiles * P; ++sgi) {
+      segptr[(size_t)sgi] = (int32_t)run;
+      run += segcnt[(size_t)sgi];
+    }
+    segptr[(size_t)(ntiles * P)] = (int32_t)run;
+  }
+  std::vector<int64_t> vmap;
+  csr_value_map(op, vmap);
+  std::vector<uint16_t> rowoff((size_t)(ntiles * P) * (size_t)(TR + 1));
+  std::vector<uint32_t> cols((size_t)nnz);
+  std::vector<int64_t> map((size_t)nnz);
+  parallel_rows(ntiles, [&](int64_t t0, int64_t t1) {
+    std::vector<int32_t> fill((size_t)P);
+    for (int64_t t = t0; t < t1; ++t) {
+      for (int64_t c = 0; c < P; ++c) fill[(size_t)c] = 0;
+      for (int64_t l = 0; l < TR; ++l) {
+        const int64_t r = t * TR + l;
+        for (int64_t c = 0; c < P; ++c) rowoff[(size_t)(t * P + c) * (size_t)(TR + 1) + (size_t)l] = (uint16_t)fill[(size_t)c];
+        if (r >= nrows) continue;
+        for (int64_t p = ur[r]; p < ur[r + 1]; ++p) {
+          const int64_t c = (int64_t)uc[p] >> log2w;
+          const int64_t e = (int64_t)segptr[(size_t)(t * P + c)] + fill[(size_t)c]++;
+          cols[(size_t)e] = (uint32_t)uc[p];
+          map[(size_t)e] = vmap[(size_t)p];
+        }
+      }
+      for (int64_t c = 0; c < P; ++c) rowoff[(size_t)(t * P + c) * (size_t)(TR + 1) + (size_t)TR] = (uint16_t)fill[(size_t)c];
+    }
+    }, 512);
+  QP_CHECK(dev_alloc(&C.segptr, segptr.size()));
+  QP_CHECK(dev_alloc(&C.rowoff, rowoff.size()));
+  QP_CHECK(dev_alloc(&C.cols, cols.size()));
+  QP_CHECK(dev_alloc(&C.map, map.size()));
+  QP_CHECK(dev_alloc(&C.vals, (size_t)nnz));
+  QP_HIP(hipMemcpy(C.segptr, segptr.data(), segptr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  QP_HIP(hipMemcpy(C.rowoff, rowoff.data(), rowoff.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  QP_HIP(hipMemcpy(C.cols, cols.data(), cols.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  QP_HIP(hipMemcpy(C.map, map.data(), map.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+  C.log2w = log2w;
+  C.P = (int)P;
+  C.rpt = rpt;
+  C.max_seg = max_seg;
+  C.ntiles = ntiles;
+  C.nnz = nnz;
+  C.valid = 1;
+  op->A.cb = &op->cb;
+  return QP_OK;
+}
+
 // ... timed: format conversion, encoding and upload are host work at qp_operator_create (and once more if a complex
 // coefficient forces a Hermitian-packed operator back to plain row blocks); qp_operator_build_info reports it
 static int operator_build_device(qp_operator* op, int format, const std::vector<std::vector<cplx>>& planes_csr) {
   const auto t0 = std::chrono::steady_clock::now();
-  const int rc = operator_build_device_impl(op, format, planes_csr);
+  int rc = operator_build_device_impl(op, format, planes_csr);
+  if (rc == QP_OK) rc = build_colblock(op);
   op->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   op->build_ms_total += op->build_ms;
   op->n_builds++;
@@ -1530,6 +1688,11 @@ static int operator_refresh(qp_operator* op) {
     op->real_of = nullptr;
   }
   op->A.vals_r = want_real ? op->real_vals : nullptr;
+  if (op->cb.valid) {   // the column-blocked mirror follows the values (one gather pass per evaluate!)
+    if (want_real && !op->cb.vals_r) QP_CHECK(dev_alloc(&op->cb.vals_r, (size_t)op->cb.nnz));
+    op->cb.use_real = want_real ? 1 : 0;
+    QP_CHECK(qp::launch_colblock_gather(ctx->stream, op->cb, op->A.vals, &ctx->stats));
+  }
   return QP_OK;
 }
 
@@ -1688,6 +1851,23 @@ int qp_operator_walk_reason(const qp_operator* op, int* code, char* text, size_t
     std::strncpy(text, why.c_str(), text_len - 1);
     text[text_len - 1] = '\0';
   }
+  return QP_OK;
+  QP_CATCH
+}
+
+/* column-blocked mirror (device.h: ColBlockPlan): out = {1 if the operator has one, column blocks, log2 of the columns per
+   block, rows per tile, entries of the longest segment, tiles}; *line_share (nullable) = the sampled share of gathers that
+   pull a 128-byte line of their own -- what the decision was taken on (0 when it never came to sampling) */
+int qp_operator_colblock_info(const qp_operator* op, int64_t out[6], double* line_share) {
+  QP_TRY
+  if (!op || !out) return qp::fail(QP_E_BAD_ARG, "qp_operator_colblock_info: NULL argument");
+  out[0] = op->cb.valid;
+  out[1] = op->cb.P;
+  out[2] = op->cb.log2w;
+  out[3] = 64 * op->cb.rpt;
+  out[4] = op->cb.max_seg;
+  out[5] = op->cb.ntiles;
+  if (line_share) *line_share = op->cb_line_share;
   return QP_OK;
   QP_CATCH
 }
@@ -2118,25 +2298,8 @@ int operator_csr_mirror(qp_operator* op, bool gather) {
   const auto& uc = op->u_col;
   const int64_t nnz = A.nnz;
   if (!op->m_rowptr) {
-    std::vector<int64_t> map((size_t)std::max<int64_t>(nnz, 1));
-    for (int64_t r = 0; r < A.nrows; ++r) {
-      const int64_t nl = (A.format == QP_FMT_HRB) ? op->layout.nlow[r] : 0;
-      for (int64_t k = 0; k < ur[r + 1] - ur[r]; ++k) {
-        int64_t m;
-        if (qp::csr_layout(A.format)) {
-          m = ur[r] + k;
-        } else if (k >= nl) {
-          m = rb_val_pos(op->layout.bptr, r, k - nl);
-        } else {
-          const int64_t c = uc[ur[r] + k];
-          const int32_t* b = uc.data() + ur[c];
-          const int32_t* e = uc.data() + ur[c + 1];
-          const int64_t kk = (std::lower_bound(b, e, (int32_t)r) - b) - op->layout.nlow[c];
-          m = -rb_val_pos(op->layout.bptr, c, kk) - 1;
-        }
-        map[ur[r] + k] = m;
-      }
-    }
+    std::vector<int64_t> map;
+    csr_value_map(op, map);
     QP_CHECK(dev_alloc(&op->m_rowptr, ur.size()));
     QP_CHECK(dev_alloc(&op->m_cols, (size_t)nnz));
     QP_CHECK(dev_alloc(&op->m_map, (size_t)nnz));

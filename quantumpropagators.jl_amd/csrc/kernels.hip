@@ -1086,6 +1086,7 @@ int* tuning_field(Tuning& t, const char* key) {
       {"stencil", &Tuning::stencil},             {"acc_defer", &Tuning::acc_defer},
       {"cheby_graph", &Tuning::cheby_graph},     {"small_nnz", &Tuning::small_nnz},
       {"roctx", &Tuning::roctx}, {"newton_graph", &Tuning::newton_graph}, {"arnoldi_l2_order", &Tuning::arnoldi_l2_order}, {"arnoldi_nt", &Tuning::arnoldi_nt},
+      {"colblock", &Tuning::colblock}, {"cb_log2w", &Tuning::cb_log2w}, {"cb_min_log2n", &Tuning::cb_min_log2n}, {"cb_waves", &Tuning::cb_waves},
       {"dense_auto", &Tuning::dense_auto},       {"dense_min_density_pct", &Tuning::dense_min_density_pct}, {"dense_panel_mfma", &Tuning::dense_panel_mfma},
       {"newton_pipeline", &Tuning::newton_pipeline}, {"spmm_tile", &Tuning::spmm_tile},
       {"spmm_nt", &Tuning::spmm_nt},             {"spmm_rows", &Tuning::spmm_rows},
@@ -1179,6 +1180,21 @@ static int launch_spmv(hipStream_t s, const DevMatrix& A, const double2* x, cons
   // workgroups of four: not with the per-workgroup check partials, and of the two launches of a split term only for the
   // interior one (no completion signal, no mirror map; its wait threshold, given in workgroups of four, is halved and
   // rounded down: the workgroup that straddles the threshold waits as well)
+  // an operator with irregular columns: its column-blocked mirror (kernels_colblock.hip), whole-operator launches only
+  if (!rs && A.cb && A.cb->valid && tun.colblock != 0) {
+    bool launched = false;
+    int rcb;
+    if constexpr (std::is_same<Op, ChebyOp>::value) rcb = launch_colblock_cheby(s, A, x, op.e, tun, &launched);
+    else rcb = launch_colblock_plain(s, A, x, op.e, tun, &launched);
+    if (rcb != QP_OK) return rcb;
+    if (launched) {
+      if (st) {
+        st->n_launch++;
+        st->n_matvec++;
+      }
+      return QP_OK;
+    }
+  }
   bool wide_ok = false;
   SyncArgs sy8 = sy;
   if constexpr (std::is_same<Op, ChebyOp>::value) {

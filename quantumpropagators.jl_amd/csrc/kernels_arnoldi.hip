@@ -217,6 +217,9 @@ int launch_arnoldi_matvec_dots(hipStream_t s, const DevMatrix& A, const double2*
                                int64_t ldq, int j, double2* partials, bool* launched, Stats* st) {
   *launched = false;
   if (A.format != QP_FMT_RBCSR || (!A.vals && !A.vals_r) || j < 0 || j > kFusedMaxJ || A.nblocks < 1 || A.nrows >= (1 << 28)) return QP_OK;
+  // an operator with a column-blocked mirror: its plain mat-vec (kernels_colblock.hip) + the separate multidot beat the fused
+  // kernel, whose gathers are what the mirror exists to fix
+  if (A.cb && A.cb->valid && A.tun && A.tun->colblock != 0) return QP_OK;
   if (!e.beta_zero || e.alpha.x != 1.0 || e.alpha.y != 0.0) return QP_OK;
   if (e.xloc && e.xloc != x) return QP_OK;
   if (j < 4) launch_instance<4>(s, A, x, e, Q, ldq, j, partials);

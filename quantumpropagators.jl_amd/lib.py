@@ -138,6 +138,7 @@ SIGNATURES = {
     "qp_operator_walk_long": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "qp_operator_walk_reason": (C.c_int, [_P, C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
     "qp_operator_evaluate_info": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "qp_operator_colblock_info": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "qp_lattice_fill_host": (C.c_int, [C.c_int64, C.c_int64, _i64p, _i32p, C.c_int, _i64p, _i32p, C.c_int64, C.POINTER(C.c_int64)]),
     "qp_operator_spmm_walk": (C.c_int, [_P, C.c_int, _i64p]),
     "qp_state_create": (C.c_int, [_P, C.c_int64, C.POINTER(_P)]),
@@ -574,6 +575,15 @@ class Operator:
         out = np.zeros(3, dtype=np.int64)
         check(self.lib.qp_operator_evaluate_info(self._h, _ptr(out, _i64p)))
         return dict(zip(("first_sparse_term", "positions", "latest_update_sparse"), (int(v) for v in out)))
+
+    def colblock_info(self):
+        """Column-blocked mirror of an operator with irregular columns (include/qprop.h: qp_operator_colblock_info)."""
+        out = np.zeros(6, dtype=np.int64)
+        share = C.c_double(0.0)
+        check(self.lib.qp_operator_colblock_info(self._h, _ptr(out, _i64p), C.byref(share)))
+        d = dict(zip(("valid", "column_blocks", "log2_block_columns", "rows_per_tile", "longest_segment", "tiles"), (int(v) for v in out)))
+        d["own_line_share"] = share.value
+        return d
 
     def walk_reason(self):
         """(code, name, sentence): why the fused Chebyshev term of this operator does not take the strip walk -- QP_WALK_OK

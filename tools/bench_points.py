@@ -149,6 +149,8 @@ def cheby_kernel_name(op):
     """The kernel a whole-operator fused Chebyshev term of `op` launches (substring of its symbol)."""
     if op.format == L.FMT_HRB and op.walk_info()["valid"]:
         return "hrb_walk_kernel"
+    if op.colblock_info()["valid"] and op.ctx.tuning_get("colblock") != 0:
+        return "colblock_spmv_kernel"
     return {L.FMT_CSR: "csr_spmv_kernel", L.FMT_RBCSR: "rbcsr_spmv_kernel", L.FMT_HRB: "hrb_spmv_kernel"}[op.format]
 
 
@@ -215,6 +217,7 @@ def measure_cheby(ctx, pattern="banded", log2n=20, fmt="auto", steps=10, warmup=
            "csr_equivalent_gbs": by["csr_equivalent_per_term"] / t_term / 1e9,
            "encodings": {"row_blocks": lay["blocks"], "stencil_upper_blocks": lay["stencil_upper_blocks"],
                          "stencil_lower_blocks": lay["stencil_lower_blocks"], "index_bytes": lay["index_bytes"]},
+           "column_blocked_mirror": op.colblock_info(),
            "strip_walk_reason": op.walk_reason()[1],      # "ok", or why this operator's term is not the strip walk (qp_operator_walk_reason)
            "norm_drift": abs(psi.norm() - 1.0)}
     if grid:

@@ -1,0 +1,128 @@
+#!/usr/bin/env python3
+"""Fuzz the column-blocked mirror (csrc/kernels_colblock.hip) against SciPy / the oracle (test infrastructure): random shapes
+(rectangular, ragged last tile, empty rows, rows of very different lengths, clustered and uniform columns), block widths
+2^6 ... 2^12, both tile heights, real / complex values, lazy sums with coefficients and scale (the mirror is refreshed by
+evaluate!), mul! with alpha / beta, cheby! forward and backward, newton!.  Every case also runs the same operator through
+its ordinary row-block kernel (knob colblock = 0 on the live operator).
+
+    python tools/fuzz_colblock.py [n_cases] [seed]"""
+import os
+import sys
+
+import numpy as np
+import scipy.sparse as sp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import qp_oracle as qo  # noqa: E402
+import qprop_amd.lib as L  # noqa: E402
+
+
+def random_sparse(nr, nc, rng, real, hermitian=False):
+    """rows of 0 ... ~3 mean entries; columns uniform or clustered around a per-row centre"""
+    mean = float(rng.uniform(2.0, 14.0))
+    lens = rng.poisson(mean, size=nr)
+    lens[rng.random(nr) < 0.02] = 0
+    if rng.random() < 0.2:
+        lens[int(rng.integers(0, nr))] = min(nc, int(rng.integers(50, 200)))          # one long row
+    rows = np.repeat(np.arange(nr), lens)
+    if rng.random() < 0.5:
+        cols = rng.integers(0, nc, size=len(rows))
+    else:
+        centre = rng.integers(0, nc, size=nr)
+        cols = (np.repeat(centre, lens) + rng.integers(-nc // 7 - 1, nc // 7 + 2, size=len(rows))) % nc
+    vals = (rng.standard_normal(len(rows)) + (0 if real else 1j) * rng.standard_normal(len(rows))) / (2.0 * mean + 2.0)
+    A = sp.coo_matrix((vals, (rows, cols)), shape=(nr, nc)).tocsr()
+    if hermitian:
+        A = ((A + A.getH()) * 0.5).tocsr()
+    A.sum_duplicates()
+    A.sort_indices()
+    return A.astype(np.complex128)
+
+
+def main():
+    ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    bad = 0
+    kinds = {"mul": 0, "cheby": 0, "newton": 0}
+    nomirror = 0
+    for case in range(ncases):
+        rng = np.random.default_rng([seed, case])
+        ctx = L.Context(0)
+        ctx.tuning_set("colblock", 2)
+        log2w = int(rng.integers(6, 13))
+        ctx.tuning_set("cb_log2w", log2w)
+        kind = ["mul", "cheby", "newton"][int(rng.integers(0, 3))]
+        real = bool(rng.random() < 0.3)
+        kinds[kind] += 1
+        if kind == "mul":
+            nr = int(rng.integers(64, 6000))
+            nc = nr if rng.random() < 0.5 else int(rng.integers(64, 9000))
+            nterms = int(rng.integers(1, 4))
+            mats = [random_sparse(nr, nc, rng, real) for _ in range(nterms)]
+            fmt = [L.FMT_AUTO, L.FMT_RBCSR, L.FMT_CSR][int(rng.integers(0, 3))]
+            op = L.Operator(ctx, [L.Matrix.from_scipy(ctx, A) for A in mats], nterms - 1, fmt)
+            info = op.colblock_info()
+            coeffs = [complex(rng.standard_normal(), 0 if real else rng.standard_normal()) for _ in range(nterms - 1)]
+            x = rng.standard_normal(nc) + 1j * rng.standard_normal(nc)
+            y0 = rng.standard_normal(nr) + 1j * rng.standard_normal(nr)
+            X, Y = L.State(ctx, data=x), L.State(ctx, data=y0)
+            err = 0.0
+            for rep in range(2):                       # the second round after another evaluate!
+                if coeffs:
+                    coeffs = [c * (1.0 + 0.5 * rep) for c in coeffs]
+                    op.set_coeffs(coeffs)
+                scale = complex(rng.standard_normal(), rng.standard_normal()) if rng.random() < 0.5 else 1.0
+                op.set_scale(scale)
+                Aeff = scale * (mats[0] + sum((c * A for c, A in zip(coeffs, mats[1:])), 0 * mats[0]))
+                al, be = complex(rng.standard_normal(), rng.standard_normal()), complex(rng.standard_normal(), rng.standard_normal())
+                ref = al * (Aeff @ x) + be * y0
+                for knob in (2, 0):
+                    ctx.tuning_set("colblock", knob)
+                    Y.upload(y0)
+                    op.mul(X, Y, al, be)
+                    err = max(err, float(np.linalg.norm(Y.numpy() - ref) / max(1.0, np.linalg.norm(ref))))
+            desc = f"mul {nr}x{nc} terms={nterms} real={real} fmt={fmt} log2w={log2w} mirror={info['valid']} tile={info['rows_per_tile']} blocks={info['column_blocks']}"
+            tol = 1e-13
+        else:
+            n = int(rng.integers(100, 5000))
+            H = random_sparse(n, n, rng, real, hermitian=(kind == "cheby" or rng.random() < 0.5))
+            if kind == "newton":
+                H = sp.csr_matrix(H - 0.02j * sp.identity(n))
+            op = L.Operator(ctx, [L.Matrix.from_scipy(ctx, H)], 0, L.FMT_RBCSR if kind == "cheby" else L.FMT_AUTO)
+            info = op.colblock_info()
+            dt = float(rng.uniform(0.1, 1.0)) * (1 if rng.random() < 0.7 else -1)
+            psi0 = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+            psi0 /= np.linalg.norm(psi0)
+            err = 0.0
+            if kind == "newton":
+                m = int(rng.integers(4, 12))
+                ref = qo.newton(psi0.copy(), H, dt, qo.NewtonWrk(psi0, m_max=m))
+                for knob in (2, 0):
+                    ctx.tuning_set("colblock", knob)
+                    psi = L.State(ctx, data=psi0)
+                    L.newton(psi, op, dt, L.NewtonWrk(ctx, n, m_max=m))
+                    err = max(err, float(np.linalg.norm(psi.numpy() - ref)))
+            else:
+                owrk = qo.ChebyWrk(psi0, 2.5, -1.25, abs(dt))
+                ref = qo.cheby(psi0.copy(), H, dt, owrk)
+                for knob in (2, 0):
+                    ctx.tuning_set("colblock", knob)
+                    psi = L.State(ctx, data=psi0)
+                    L.cheby(psi, op, dt, L.ChebyWrk(ctx, n, 2.5, -1.25, abs(dt)))
+                    err = max(err, float(np.linalg.norm(psi.numpy() - ref)))
+            desc = f"{kind} n={n} real={real} dt={dt:+.2f} log2w={log2w} mirror={info['valid']} tile={info['rows_per_tile']} blocks={info['column_blocks']}"
+            tol = 1e-10
+        nomirror += 1 - info["valid"]
+        ok = err < tol
+        if not ok:
+            bad += 1
+        if not ok or case % 25 == 0:
+            print(f"case {case:4d} {desc}: err {err:.2e} {'ok' if ok else 'BAD'}", flush=True)
+        ctx.close()
+    print(f"{ncases} cases ({kinds}; {nomirror} without a mirror: dense or Hermitian-packed by the format choice), {bad} bad")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

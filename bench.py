@@ -45,7 +45,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s measured copy)
 KERNEL_OF_FORMAT = {1: "csr_spmv_kernel", 2: "rbcsr_spmv_kernel", 3: "hrb_spmv_kernel"}
-STATIC_PMC = os.path.join("profiles", "r03", "bench_pmc_summary.json")
+STATIC_PMC = os.path.join("profiles", "r04", "bench_pmc_summary.json")
 
 
 def pmc_traffic(argv_inner, kernel_substr, timeout_s, how="mean"):

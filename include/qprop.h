@@ -200,11 +200,15 @@ int qp_operator_walk_info(const qp_operator* op, int64_t out[8]);
 /* *glong = the long distance L (rows) of a walk plan with one further pair of distances +-L beyond its far reach
  * (a three-dimensional grid's plane distance; its operands are loaded directly), 0 if the plan has none / there is no plan */
 int qp_operator_walk_long(const qp_operator* op, int64_t* glong);
+/* A plan may carry TWO such pairs (the fourth-order Laplacian of a three-dimensional grid: +-nx ny and +-2 nx ny; a
+ * four-dimensional grid): out = {L_0, L_1}, the shorter first, 0 for a pair the plan does not have.  qp_operator_walk_long
+ * reports the longest. */
+int qp_operator_walk_long_pairs(const qp_operator* op, int64_t out[2]);
 /* Column-blocked mirror of an operator with IRREGULAR columns (src/generators.jl:634-645 accepts any sparse H_l; a random
  * graph's gathers are each their own cache line and the vector outgrows the L2): the entries are also kept grouped by
  * (row tile, column block) and whole-operator mat-vecs (cheby!, arnoldi!, mul!) walk the column blocks in their outer loop, so
  * that the whole chip gathers from one L2-resident window of the vector at a time (csrc/kernels_colblock.hip).  Built at
- * qp_operator_create when the operator is laid out as plain row blocks / CSR, has at least 2^19 columns and its sampled
+ * qp_operator_create when the operator is laid out as plain row blocks / CSR, has at least 2^20 columns and its sampled
  * gathers are irregular (knobs colblock, cb_log2w, cb_min_log2n).  out = {1 if the operator has the mirror, column blocks,
  * log2 of the columns per block, rows per tile, entries of the longest (tile, block) segment, tiles}; *line_share
  * (nullable) = sampled share of gathers that pull a 128-byte line of their own, 0 if the decision never got that far. */
@@ -230,9 +234,9 @@ enum { QP_WALK_OK = 0,
        QP_WALK_NO_NEAR = 9,
        QP_WALK_NEAR_TOO_FAR = 10,   /* a near distance beyond the 16-row halo of the walk's window */
        QP_WALK_TOO_MANY_NEAR = 11,  /* more than 4 near distances per side */
-       QP_WALK_TOO_MANY_FAR = 12,   /* more than 4 far distances per side (beyond one long pair) */
+       QP_WALK_TOO_MANY_FAR = 12,   /* more than 4 far distances per side (or more than 2 beside long pairs) */
        QP_WALK_INCOMMENSURATE = 13, /* far distances that are not multiples of one strip step (two strides) */
-       QP_WALK_NO_KERNEL = 14,      /* a shape without a kernel instance (long pair with more than 2 near / 1 far distances) */
+       QP_WALK_NO_KERNEL = 14,      /* a shape without a kernel instance (long pairs with more than 2 near / 2 far distances) */
        QP_WALK_LAYOUT = 15,         /* the run's upper sections are not at equal strides / positions beyond 2^31 */
        QP_WALK_DISABLED = 16 };     /* knob hrb_walk 0 */
 int qp_operator_walk_reason(const qp_operator* op, int* code, char* text, size_t text_len);

@@ -84,8 +84,9 @@ struct WalkPlan {
   int valid = 0;
   int nn = 0, K = 0, z0 = 0;  // shape of the stencil (see above)
   int S = 0;                  // 64-row column chunks per strip step: ceil(g / 64)
-  int xl = 0;                 // 1: one more pair of distances +- glong beyond the ring's reach (loaded directly)
-  int64_t glong = 0;
+  int xl = 0;                 // 1: one more pair of distances +- glong beyond the ring's reach (loaded directly); 2: two, +- glong1 and +- glong
+  int64_t glong = 0;          // the longest distance of the stencil
+  int64_t glong1 = 0;         // xl = 2: the shorter long distance, K g < glong1 < glong
   int64_t g = 0;              // rows per strip step (the far distances are g, 2 g, .., K g); need not be a multiple of 64
   int near[kWalkMaxNear] = {0};
   int64_t R0 = 0, R1 = 0, W0 = 0;
@@ -253,9 +254,10 @@ struct Tuning {
   int dense_min_density_pct = 75;
   int dense_panel_mfma = 1;   // 1 = the batched step of a dense operator runs H X on the fp64 matrix cores (kernels_dense.hip); 0 = the sparse panel kernels (A/B)
   int colblock = 1;           // 1 = an operator with irregular columns whose vector outgrows the L2 gets a column-blocked mirror (kernels_colblock.hip); 2 = any row-block / CSR operator that fits the mirror's limits (tests); 0 = off
-  int cb_log2w = 17;          // ... columns per block (log2): 2^17 complex elements = 2 MB of the 4 MB an XCD's L2 holds
-  int cb_min_log2n = 19;      // ... smallest number of columns (log2) the mirror is built for (2^18 elements are the L2's 4 MB)
-  int cb_waves = 24;          // ... resident wavefronts per CU the launch is sized for
+  int cb_log2w = 0;           // ... columns per block (log2); 0 = about sixteen blocks, 2^16 ... 2^18 columns each (1 - 4 MB of the vector; an XCD's L2 holds 4 MB)
+  int cb_min_log2n = 20;      // ... smallest number of columns (log2) the mirror is built for (measured: 2^18 columns 0.9 x, 2^19 1.04 x, 2^20 1.37 x, 2^21 1.62 x, 2^22 1.52 x)
+  int cb_rpt = 0;             // ... 64-row groups per tile: 0 = 2 unless a segment would outgrow the LDS buffer, else 1 or 2
+  int cb_waves = 16;          // ... resident wavefronts per CU the launch is sized for (24 and 32 measured slower: 410 vs 353 us at 2^21 columns)
   int small_nnz = 8192;       // qp_propagate: register-resident Cheby systems up to this nnz run as ONE persistent launch (0: off)
   int newton_pipeline = 1;    // newton!: Hessenberg eigenvalues overlap the Arnoldi sweep
   int spmm_tile = 16;         // states per pass of the tiled batched SpMM kernel (16, 32 or 64)

@@ -651,12 +651,13 @@ static int64_t decode_lower_stencil_pos(const std::vector<char>& bytes, const st
 // encoded does not matter (the walk reads none of them).  The remaining blocks are listed for the per-block path.
 // Index work only: host, exact.
 // The walk's stencil shape read off one row's sorted list of column distances (kernels_walk.hip):
-//   [-L]? [-K g .. -g] [-d_nn .. -d_1] [0]? [d_1 .. d_nn] [g .. K g] [L]?
-// near distances of at most kWalkHalo rows, far distances the multiples of one strip step g >= 64 rows, optionally one more
-// pair +-L beyond them (xl: the plane distance of a three-dimensional grid).  false: not a shape the walk has a kernel for.
+//   [-L_1]? [-L_0]? [-K g .. -g] [-d_nn .. -d_1] [0]? [d_1 .. d_nn] [g .. K g] [L_0]? [L_1]?
+// near distances of at most kWalkHalo rows, far distances the multiples of one strip step g >= 64 rows, optionally one or two
+// more pairs +-L beyond them (xl: the plane distance of a three-dimensional grid, and its double for a fourth-order stencil;
+// the volume distance of a four-dimensional one).  false: not a shape the walk has a kernel for.
 struct WalkShape {
   int nn = 0, K = 0, z0 = 0, xl = 0;
-  int64_t g = 0, glong = 0;
+  int64_t g = 0, glong = 0, glong1 = 0;   // glong: the longest distance; glong1: the shorter long one when there are two
   int near[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 // 0 = a shape the walk has a kernel for; else the QP_WALK_* code of what broke it (include/qprop.h), with the offending
@@ -702,8 +703,8 @@ static int walk_shape_reason(const std::vector<int64_t>& dl, WalkShape& w, std::
       return QP_WALK_NO_NEAR;
     }
   }
-  if (nbig > 5) {
-    say("%lld far column distances per side (the walk takes up to 4 multiples of one stride, plus one long pair)", nbig);
+  if (nbig > 6) {
+    say("%lld far column distances per side (the walk takes up to 4 multiples of one stride, or up to 2 plus one or two long pairs)", nbig);
     return QP_WALK_TOO_MANY_FAR;
   }
   w = WalkShape();
@@ -715,10 +716,15 @@ static int walk_shape_reason(const std::vector<int64_t>& dl, WalkShape& w, std::
   };
   if (nbig <= 4 && multiples(0, nbig)) {
     w.K = nbig;
-  } else if (nbig >= 2 && multiples(1, nbig - 1) && -dl[0] > (int64_t)(nbig - 1) * w.g) {
+  } else if (nbig >= 2 && nbig <= 5 && multiples(1, nbig - 1) && -dl[0] > (int64_t)(nbig - 1) * w.g) {
     w.K = nbig - 1;
     w.xl = 1;
     w.glong = -dl[0];
+  } else if (nbig >= 3 && multiples(2, nbig - 2) && -dl[1] > (int64_t)(nbig - 2) * w.g) {   // (sorted: -dl[0] > -dl[1])
+    w.K = nbig - 2;
+    w.xl = 2;
+    w.glong = -dl[0];
+    w.glong1 = -dl[1];
   } else {
     long long bad = 0;
     for (int i = 0; i < nbig; ++i)
@@ -736,7 +742,7 @@ static int walk_shape_reason(const std::vector<int64_t>& dl, WalkShape& w, std::
     return QP_WALK_NOT_MIRRORED;
   }
   if (!qp::walk_shape_supported(w.nn, w.K, w.z0, w.xl)) {
-    say("no kernel instance for %lld near and %lld far distances with a long pair (the long pair comes with at most 2 near, 1 far)", w.nn, w.K);
+    say("no kernel instance for %lld near and %lld far distances with long pairs (they come with at most 2 near, 2 far)", w.nn, w.K);
     return QP_WALK_NO_KERNEL;
   }
   return QP_WALK_OK;
@@ -835,6 +841,7 @@ static int build_walk_plan(qp_operator* op) {
   P.g = g;
   P.xl = xl;
   P.glong = ws.glong;
+  P.glong1 = ws.glong1;
   P.R0 = R0;
   P.R1 = R1;
   P.W0 = W0;
@@ -1124,11 +1131,20 @@ static int build_colblock(qp_operator* op) {
   const auto& uc = op->u_col;
   const int64_t nrows = A.nrows, ncols = A.ncols, nnz = A.nnz;
   if (nrows < 64 || nnz < 1 || nnz >= (int64_t)INT32_MAX || ncols >= ((int64_t)1 << 32)) return QP_OK;
-  const int log2w = std::max(8, std::min(tun.cb_log2w, 24));
+  // columns per block: about sixteen blocks (measured, 16 random columns per row: N = 2^20 171 / 178 / 195 us per term with
+  // 2^16 / 2^17 / 2^18 columns per block, 2^21 416 / 353 / 460, 2^22 1125 / 890 / 829 -- profiles/r04/colblock.txt), a block
+  // never larger than half an XCD's L2 share would like (2^18 elements = 4 MB is the whole L2; taken only from 2^22 columns on)
+  int log2w = tun.cb_log2w;
+  if (log2w <= 0) {
+    int lg = 0;
+    while (((int64_t)1 << lg) < ncols) ++lg;
+    log2w = std::max(16, std::min(lg - 4, 18));
+  }
+  log2w = std::max(6, std::min(log2w, 24));
   const int64_t W = (int64_t)1 << log2w;
   const int64_t P = (ncols + W - 1) / W;
   if (tun.colblock == 1 && (ncols < ((int64_t)1 << std::max(tun.cb_min_log2n, 1)) || P < 2)) return QP_OK;
-  if (P > 64) return QP_OK;
+  if (P > 256) return QP_OK;
   // irregularity: distinct 128-byte lines among the k-th gathers of a 64-row block, over the entries sampled
   {
     const int64_t nblocks = nrows / kRB;
@@ -1156,6 +1172,7 @@ static int build_colblock(qp_operator* op) {
   int rpt = 0, max_seg = 0;
   int64_t ntiles = 0;
   for (int tryr : {2, 1}) {
+    if (tun.cb_rpt != 0 && tun.cb_rpt != tryr) continue;
     const int64_t TR = 64 * tryr;
     ntiles = (nrows + TR - 1) / TR;
     segcnt.assign((size_t)(ntiles * P + 1), 0);
@@ -1386,6 +1403,12 @@ static void lattice_fill(const qp::Tuning& tun, int64_t n, int64_t ncols, std::v
     if (ur[r + 1] - ur[r] > ur[rm + 1] - ur[rm]) rm = r;
   for (int64_t t = -32; t <= 32; ++t) {   // (a whole line of a three-dimensional grid may sit on an edge: look further out too)
     const int64_t r = n / 2 + t * 4099;
+    if (r >= 0 && r < n && ur[r + 1] - ur[r] > ur[rm + 1] - ur[rm]) rm = r;
+  }
+  // (... or a whole band of planes, when the stencil reaches two lines and two planes out and the grid is small: 2048 rows
+  // spread over the middle half, at offsets that run through every position inside a line)
+  for (int64_t k = 0; k < 2048; ++k) {
+    const int64_t r = n / 4 + (k * (n / 2)) / 2048 + (k * 37) % 64;
     if (r >= 0 && r < n && ur[r + 1] - ur[r] > ur[rm + 1] - ur[rm]) rm = r;
   }
   const int z = (int)(ur[rm + 1] - ur[rm]);
@@ -1875,6 +1898,14 @@ int qp_operator_colblock_info(const qp_operator* op, int64_t out[6], double* lin
 int qp_operator_walk_long(const qp_operator* op, int64_t* glong) {
   if (!op || !glong) return qp::fail(QP_E_BAD_ARG, "qp_operator_walk_long: NULL argument");
   *glong = (op->walk.valid && op->A.walk == &op->walk && op->walk.xl) ? op->walk.glong : 0;
+  return QP_OK;
+}
+
+int qp_operator_walk_long_pairs(const qp_operator* op, int64_t out[2]) {
+  if (!op || !out) return qp::fail(QP_E_BAD_ARG, "qp_operator_walk_long_pairs: NULL argument");
+  const bool on = op->walk.valid && op->A.walk == &op->walk;
+  out[0] = (on && op->walk.xl == 2) ? op->walk.glong1 : (on && op->walk.xl == 1) ? op->walk.glong : 0;
+  out[1] = (on && op->walk.xl == 2) ? op->walk.glong : 0;
   return QP_OK;
 }
 

@@ -1086,7 +1086,7 @@ int* tuning_field(Tuning& t, const char* key) {
       {"stencil", &Tuning::stencil},             {"acc_defer", &Tuning::acc_defer},
       {"cheby_graph", &Tuning::cheby_graph},     {"small_nnz", &Tuning::small_nnz},
       {"roctx", &Tuning::roctx}, {"newton_graph", &Tuning::newton_graph}, {"arnoldi_l2_order", &Tuning::arnoldi_l2_order}, {"arnoldi_nt", &Tuning::arnoldi_nt},
-      {"colblock", &Tuning::colblock}, {"cb_log2w", &Tuning::cb_log2w}, {"cb_min_log2n", &Tuning::cb_min_log2n}, {"cb_waves", &Tuning::cb_waves},
+      {"colblock", &Tuning::colblock}, {"cb_log2w", &Tuning::cb_log2w}, {"cb_min_log2n", &Tuning::cb_min_log2n}, {"cb_waves", &Tuning::cb_waves}, {"cb_rpt", &Tuning::cb_rpt},
       {"dense_auto", &Tuning::dense_auto},       {"dense_min_density_pct", &Tuning::dense_min_density_pct}, {"dense_panel_mfma", &Tuning::dense_panel_mfma},
       {"newton_pipeline", &Tuning::newton_pipeline}, {"spmm_tile", &Tuning::spmm_tile},
       {"spmm_nt", &Tuning::spmm_nt},             {"spmm_rows", &Tuning::spmm_rows},

@@ -10,9 +10,9 @@ bool walk_launch_c128_hi(hipStream_t s, dim3 grid, const double2* uvals, const d
 }
 
 // near distances 1..4 of at most 16 rows, far reach 1..4 strip steps, with or without a diagonal
-// ... and, with one long pair beyond the ring (xl = 1), near 1..2 and one far distance
+// ... and, with one or two long pairs beyond the ring (xl = 1, 2), near 1..2 and one or two far distances
 bool walk_shape_supported(int nn, int K, int z0, int xl) {
-  if (xl) return xl == 1 && nn >= 1 && nn <= 2 && K == 1 && (z0 == 0 || z0 == 1);
+  if (xl) return (xl == 1 || xl == 2) && nn >= 1 && nn <= 2 && (K == 1 || K == 2) && (z0 == 0 || z0 == 1);
   return nn >= 1 && nn <= 4 && K >= 1 && K <= 4 && (z0 == 0 || z0 == 1);
 }
 
@@ -77,10 +77,13 @@ int launch_hrb_walk_cheby(hipStream_t s, const DevMatrix& A, const double2* x, c
   WalkPlan Pl = *P;
   if (no_edges) Pl.n_edge = 0;
   const bool hi = Pl.nn >= 3 && !Pl.xl;   // which translation unit holds the shape
-  const bool ok = A.vals_r ? (hi ? walk_launch_f64_hi(s, grid, A.vals_r, x, Pl, G, H, A.nrows, op, ntm, sy)
-                                 : walk_launch_f64_lo(s, grid, A.vals_r, x, Pl, G, H, A.nrows, op, ntm, sy))
-                           : (hi ? walk_launch_c128_hi(s, grid, A.vals, x, Pl, G, H, A.nrows, op, ntm, sy)
-                                 : walk_launch_c128_lo(s, grid, A.vals, x, Pl, G, H, A.nrows, op, ntm, sy));
+  const bool xlu = Pl.xl && !(Pl.xl == 1 && Pl.K == 1);
+  const bool ok = A.vals_r ? (xlu  ? walk_launch_f64_xl(s, grid, A.vals_r, x, Pl, G, H, A.nrows, op, ntm, sy)
+                              : hi ? walk_launch_f64_hi(s, grid, A.vals_r, x, Pl, G, H, A.nrows, op, ntm, sy)
+                                   : walk_launch_f64_lo(s, grid, A.vals_r, x, Pl, G, H, A.nrows, op, ntm, sy))
+                           : (xlu  ? walk_launch_c128_xl(s, grid, A.vals, x, Pl, G, H, A.nrows, op, ntm, sy)
+                              : hi ? walk_launch_c128_hi(s, grid, A.vals, x, Pl, G, H, A.nrows, op, ntm, sy)
+                                   : walk_launch_c128_lo(s, grid, A.vals, x, Pl, G, H, A.nrows, op, ntm, sy));
   if (!ok) return QP_OK;
   QP_HIP(hipGetLastError());
   *launched = true;

@@ -200,7 +200,7 @@ __device__ __forceinline__ void hrb_edge_block(const HrbArrays& H, const VT* __r
 __device__ __forceinline__ double2 sel2(bool c, double2 a, double2 b) { return make_double2(c ? a.x : b.x, c ? a.y : b.y); }
 
 // what a step needs from memory (everything else is carried over from the steps before)
-template <int NU>
+template <int NU, int XL = 0>
 struct WalkStep {
   double2 ua[NU];      // the block's upper values (pads skipped)
   double2 xnew;        // x[row + K g]
@@ -208,8 +208,8 @@ struct WalkStep {
   // halos of the near windows, sixteen lanes each (lane = 16 q + t, only t < distance is used):
   double2 hx;          //   q = 0: x[r0 - dmax + t]         q = 1: x[r0 + 64 + t]
   double2 ha;          //   q = i: value (64 - d_i + t) of slot z0 + i of block b - 1
-  // the long pair (XL): x[row + L], x[row - L] and the conj-transposed value of the lower entry (row, row - L)
-  double2 xlu, xll, al;
+  // the long pairs (XL of them): x[row + L_p], x[row - L_p] and the conj-transposed value of the lower entry (row, row - L_p)
+  double2 xlu[XL > 0 ? XL : 1], xll[XL > 0 ? XL : 1], al[XL > 0 ? XL : 1];
 };
 
 // LDS of one wavefront, in double2 elements: the near window of x (16 + 64 + 16), NN near value windows (16 + 64) and the
@@ -247,6 +247,9 @@ __device__ __forceinline__ void wave_sync_wait(const SyncArgs& sy) {
 // and are loaded directly, one step ahead like everything else: x[row + L], x[row - L], the upper value of slot
 // z0 + nn + K and the value stored for (row - L, row).  Storage order of the sections: the long entry is the first of
 // the lower and the last of the upper one.
+// XL = 2: two such pairs, K g < L_0 < L_1 (P.glong1, P.glong) -- the fourth-order Laplacian of a three-dimensional grid
+// (+-1, +-2; +-nx, +-2 nx; +-nx ny, +-2 nx ny: near 2, far 2, long 2), next-nearest planes, a four-dimensional grid.  Lower
+// section [-L_1] [-L_0] [far] [near], upper section [diag] [near] [far] [L_0] [L_1].
 template <class VT, int NN, int K, int Z0, int NTM, int XL = 0>
 __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __restrict__ uvals,
                                                                     const double2* __restrict__ x, WalkPlan P,
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __r
   const int hslot = Z0 + (hq < NN ? hq : NN - 1);             // ... of slot z0 + q: rows r0 - d .. r0 - 1
   // r0 = first row of the wavefront at that step.  Lanes beyond the strip (or the run) still load real data -- their
   // elements of x are the near neighbours of the last active lanes -- with the row clamped into the matrix.
-  auto load_step = [&](int64_t r0, WalkStep<NU>& w) __attribute__((always_inline)) {
+  auto load_step = [&](int64_t r0, WalkStep<NU, XL>& w) __attribute__((always_inline)) {
     const int64_t r = min(r0 + lane, vmax);
     const VT* __restrict__ v = uvals + vpos(r);
 #pragma unroll
@@ -320,10 +323,12 @@ __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __r
     w.acc = ld_stream<(NTM & 2) != 0>(accp ? accp + r : x + lane);
     w.hx = x[min(r0 + hoff_x, rmax)];
     w.ha = ld_val<false>(uvals + vpos(r0 - hd + min(ht, hd - 1)) + (size_t)hslot * 64);
-    if constexpr (XL != 0) {
-      w.xlu = ld_stream<(NTM & 2) != 0>(x + min(r + P.glong, rmax));
-      w.xll = ld_stream<(NTM & 2) != 0>(x + (r - P.glong));
-      w.al = ld_val<false>(uvals + vpos(r - P.glong) + (size_t)(Z0 + NN + K) * 64);
+#pragma unroll
+    for (int p = 0; p < XL; ++p) {
+      const int64_t Lp = (p == XL - 1) ? P.glong : P.glong1;
+      w.xlu[p] = ld_stream<(NTM & 2) != 0>(x + min(r + Lp, rmax));
+      w.xll[p] = ld_stream<(NTM & 2) != 0>(x + (r - Lp));
+      w.al[p] = ld_val<false>(uvals + vpos(r - Lp) + (size_t)(Z0 + NN + K + p) * 64);
     }
   };
   // where this lane's halo elements go in the windows (lanes that carry none rewrite their own main element)
@@ -352,9 +357,9 @@ __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __r
   for (int m = 1; m <= K; ++m) hpos[m - 1] = 0;
   // Two register sets that swap roles every step: while the arithmetic of a block runs out of one, the next
   // block's streams land in the other (no copies, and the wait for them sits at their first use, a whole step later).
-  WalkStep<NU> wa, wb;
+  WalkStep<NU, XL> wa, wb;
   load_step(row0, wa);
-  auto step = [&](const WalkStep<NU>& cu, WalkStep<NU>& nx, auto has_next) __attribute__((always_inline)) {
+  auto step = [&](const WalkStep<NU, XL>& cu, WalkStep<NU, XL>& nx, auto has_next) __attribute__((always_inline)) {
     xr[2 * K] = cu.xnew;
     if constexpr (decltype(has_next)::value) load_step(row0 + g, nx);
     // ---- near windows through LDS: element e of the block's window sits at [kWalkHalo + e], e = -16 .. 79
@@ -384,13 +389,13 @@ __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __r
       nxu[i] = xwin[kWalkHalo + lane + d];
     }
     double2 s0 = make_double2(0.0, 0.0), s1 = make_double2(0.0, 0.0);
-    // lower section, storage order: (the long entry -L,) far -K g .. -g, then near -d_NN .. -d_1
+    // lower section, storage order: (the long entries -L_1, -L_0,) far -K g .. -g, then near -d_NN .. -d_1
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
       double2 a, xv;
       if (l < XL) {
-        a = cu.al;
-        xv = cu.xll;
+        a = cu.al[XL - 1 - l];
+        xv = cu.xll[XL - 1 - l];
       } else if (l < XL + K) {
         const int m = K - (l - XL);
         a = fa[m - 1];
@@ -410,7 +415,7 @@ __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __r
       if (u < Z0) xv = xr[K];
       else if (u < Z0 + NN) xv = nxu[u - Z0];
       else if (u < Z0 + NN + K) xv = xr[K + (u - Z0 - NN + 1)];
-      else xv = cu.xlu;
+      else xv = cu.xlu[u - (Z0 + NN + K) < 0 ? 0 : u - (Z0 + NN + K)];
       if (u & 1) cfma(s1, cu.ua[u], xv);
       else cfma(s0, cu.ua[u], xv);
     }
@@ -477,29 +482,49 @@ static bool launch_instance(hipStream_t s, dim3 grid, const VT* uvals, const dou
   return true;
 }
 
-// One quarter of the kernel shapes per translation unit: PART 0 = near 3-4, PART 1 = near 1-2 and the long-pair shapes, each
+// The kernel shapes are spread over translation units: PART 0 = near 3-4, PART 1 = near 1-2 and the shapes with one long pair and
+// one far distance, PART 2 = the other long-pair shapes (two far distances, two long pairs), each
 // for complex values (double2) and for the real copy (double).  The measurement variants of the headline shape (matrix loads
 // temporal / nontemporal in other mixes: ntm 3, 5, 7) exist in developer builds only (-DQP_DEVELOPER).
 template <class VT, int PART>
 static bool launch_shape(hipStream_t s, dim3 grid, const VT* uvals, const double2* x, const WalkPlan& P,
                          const WalkGeom& G, const HrbArrays& H, int64_t nrows, const ChebyOp& op, int ntm, const SyncArgs& sy) {
   const int key = P.nn * 100 + P.K * 10 + P.z0;
-  if (P.xl) {   // the long pair: near 1 or 2, one far distance (three-dimensional grids)
+  if (P.xl) {   // long pairs: near 1 or 2, far 1 or 2, one or two pairs (three-dimensional grids; PART 1: one pair and one far distance, PART 2: the rest)
+#define QP_WALK_XL(NN_, K_, Z0_, XL_)                                                                              \
+  return (ntm & 1) ? launch_instance<VT, NN_, K_, Z0_, 1, XL_>(s, grid, uvals, x, P, G, H, nrows, op, sy)           \
+                   : launch_instance<VT, NN_, K_, Z0_, 0, XL_>(s, grid, uvals, x, P, G, H, nrows, op, sy);
     if constexpr (PART == 1) {
-#define QP_WALK_XL(NN_, Z0_)                                                                                   \
-  return (ntm & 1) ? launch_instance<VT, NN_, 1, Z0_, 1, 1>(s, grid, uvals, x, P, G, H, nrows, op, sy)           \
-                   : launch_instance<VT, NN_, 1, Z0_, 0, 1>(s, grid, uvals, x, P, G, H, nrows, op, sy);
+      if (P.xl != 1) return false;
       switch (key) {
-        case 110: QP_WALK_XL(1, 0)
-        case 111: QP_WALK_XL(1, 1)
-        case 210: QP_WALK_XL(2, 0)
-        case 211: QP_WALK_XL(2, 1)
+        case 110: QP_WALK_XL(1, 1, 0, 1)
+        case 111: QP_WALK_XL(1, 1, 1, 1)
+        case 210: QP_WALK_XL(2, 1, 0, 1)
+        case 211: QP_WALK_XL(2, 1, 1, 1)
         default: return false;
       }
-#undef QP_WALK_XL
     }
+    if constexpr (PART == 2) {
+      switch (P.xl * 1000 + key) {
+        case 1120: QP_WALK_XL(1, 2, 0, 1)
+        case 1121: QP_WALK_XL(1, 2, 1, 1)
+        case 1220: QP_WALK_XL(2, 2, 0, 1)
+        case 1221: QP_WALK_XL(2, 2, 1, 1)
+        case 2110: QP_WALK_XL(1, 1, 0, 2)
+        case 2111: QP_WALK_XL(1, 1, 1, 2)
+        case 2210: QP_WALK_XL(2, 1, 0, 2)
+        case 2211: QP_WALK_XL(2, 1, 1, 2)
+        case 2120: QP_WALK_XL(1, 2, 0, 2)
+        case 2121: QP_WALK_XL(1, 2, 1, 2)
+        case 2220: QP_WALK_XL(2, 2, 0, 2)
+        case 2221: QP_WALK_XL(2, 2, 1, 2)
+        default: return false;
+      }
+    }
+#undef QP_WALK_XL
     return false;
   }
+  if constexpr (PART == 2) return false;
 #define QP_WALK_SHAPE(NN_, K_, Z0_)                                                                       \
   return (ntm & 1) ? launch_instance<VT, NN_, K_, Z0_, 1>(s, grid, uvals, x, P, G, H, nrows, op, sy)            \
                    : launch_instance<VT, NN_, K_, Z0_, 0>(s, grid, uvals, x, P, G, H, nrows, op, sy);
@@ -527,18 +552,19 @@ static bool launch_shape(hipStream_t s, dim3 grid, const VT* uvals, const double
       QP_WALK_NN(4)
       default: return false;
     }
-  } else {
+  } else if constexpr (PART == 1) {
     switch (key) {
       QP_WALK_NN(1)
       QP_WALK_NN(2)
       default: return false;
     }
   }
+  return false;
 #undef QP_WALK_NN
 #undef QP_WALK_SHAPE
 }
 
-// the four translation units' entry points (uvals: double2* for _c128_*, double* for _f64_*)
+// the six translation units' entry points (uvals: double2* for _c128_*, double* for _f64_*)
 bool walk_launch_c128_hi(hipStream_t s, dim3 grid, const double2* uvals, const double2* x, const WalkPlan& P, const WalkGeom& G,
                          const HrbArrays& H, int64_t nrows, const ChebyOp& op, int ntm, const SyncArgs& sy);
 bool walk_launch_c128_lo(hipStream_t s, dim3 grid, const double2* uvals, const double2* x, const WalkPlan& P, const WalkGeom& G,
@@ -546,6 +572,10 @@ bool walk_launch_c128_lo(hipStream_t s, dim3 grid, const double2* uvals, const d
 bool walk_launch_f64_hi(hipStream_t s, dim3 grid, const double* uvals, const double2* x, const WalkPlan& P, const WalkGeom& G,
                         const HrbArrays& H, int64_t nrows, const ChebyOp& op, int ntm, const SyncArgs& sy);
 bool walk_launch_f64_lo(hipStream_t s, dim3 grid, const double* uvals, const double2* x, const WalkPlan& P, const WalkGeom& G,
+                        const HrbArrays& H, int64_t nrows, const ChebyOp& op, int ntm, const SyncArgs& sy);
+bool walk_launch_c128_xl(hipStream_t s, dim3 grid, const double2* uvals, const double2* x, const WalkPlan& P, const WalkGeom& G,
+                         const HrbArrays& H, int64_t nrows, const ChebyOp& op, int ntm, const SyncArgs& sy);
+bool walk_launch_f64_xl(hipStream_t s, dim3 grid, const double* uvals, const double2* x, const WalkPlan& P, const WalkGeom& G,
                         const HrbArrays& H, int64_t nrows, const ChebyOp& op, int ntm, const SyncArgs& sy);
 
 }  // namespace qp

@@ -137,6 +137,7 @@ SIGNATURES = {
     "qp_developer_build": (C.c_int, []),
     "qp_operator_walk_long": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "qp_operator_walk_reason": (C.c_int, [_P, C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
+    "qp_operator_walk_long_pairs": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "qp_operator_evaluate_info": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "qp_operator_colblock_info": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "qp_lattice_fill_host": (C.c_int, [C.c_int64, C.c_int64, _i64p, _i32p, C.c_int, _i64p, _i32p, C.c_int64, C.POINTER(C.c_int64)]),
@@ -567,6 +568,9 @@ class Operator:
         gl = C.c_int64(0)
         check(self.lib.qp_operator_walk_long(self._h, C.byref(gl)))
         d["long_distance"] = gl.value        # rows; 0: no long pair (three-dimensional grids have one: the plane distance)
+        lp = np.zeros(2, dtype=np.int64)
+        check(self.lib.qp_operator_walk_long_pairs(self._h, _ptr(lp, _i64p)))
+        d["long_distances"] = [int(v) for v in lp if v]      # [] / [L] / [L_0, L_1] (fourth-order stencils, four-dimensional grids)
         return d
 
     def evaluate_info(self):

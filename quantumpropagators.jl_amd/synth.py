@@ -165,11 +165,13 @@ def grid_hamiltonian_2d(nx, ny, flux=0.0, next_nearest=False, seed=DEFAULT_SEED)
     return H
 
 
-def grid_hamiltonian_3d(nx, ny, nz, flux=0.0, seed=DEFAULT_SEED):
+def grid_hamiltonian_3d(nx, ny, nz, flux=0.0, seed=DEFAULT_SEED, order=2):
     """Seven-point finite-difference Hamiltonian on an nx x ny x nz grid with OPEN boundaries (row = x + nx (y + ny z)):
     hopping -1 to the six neighbours (phase exp(i flux y) on the x-hops when flux != 0), a smooth potential on the diagonal.
     Distances +-1, +-nx, +-nx ny: the walk's lattice with one long pair beyond the ring (kernels_walk.hip, XL) once its edge
-    rows are completed.  Returns scipy CSR (sorted indices)."""
+    rows are completed.  order = 4: the fourth-order Laplacian's thirteen points -- second neighbours along every axis with
+    weight +1/12 of... (-1/12 : 4/3 stencil, scaled to the hoppings here): distances +-1, +-2, +-nx, +-2 nx, +-nx ny,
+    +-2 nx ny (near 2, far 2, two long pairs).  Returns scipy CSR (sorted indices)."""
     import scipy.sparse as sp
     N = nx * ny * nz
     idx = np.arange(N, dtype=np.int64)
@@ -189,6 +191,10 @@ def grid_hamiltonian_3d(nx, ny, nz, flux=0.0, seed=DEFAULT_SEED):
     hop(X < nx - 1, 1, -phase)
     hop(Y < ny - 1, nx, np.complex128(-1.0))
     hop(Z < nz - 1, nx * ny, np.complex128(-0.5))
+    if order == 4:      # -1/12 f(x +- 2 h) + 4/3 f(x +- h) - 5/2 f(x): the second neighbours carry -1/16 of the first ones' weight
+        hop(X < nx - 2, 2, phase * phase / 16.0)
+        hop(Y < ny - 2, 2 * nx, np.complex128(1.0 / 16.0))
+        hop(Z < nz - 2, 2 * nx * ny, np.complex128(0.5 / 16.0))
     with np.errstate(over="ignore"):
         jitter = _u01(splitmix64(np.uint64(seed) ^ (idx.astype(np.uint64) * _GOLDEN)))
     pot = 0.5 * ((X - nx / 2) / nx) ** 2 + 0.5 * ((Y - ny / 2) / ny) ** 2 + 0.5 * ((Z - nz / 2) / nz) ** 2

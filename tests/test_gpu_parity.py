@@ -945,6 +945,65 @@ def test_strip_walk_long_pair_three_dimensional_grids(ctx, dims, flux, uniform):
     assert np.linalg.norm(base - ref) < TOL
 
 
+@pytest.mark.parametrize("case", ["grid_4th_order_72x10x20", "grid_4th_order_real_64x8x24", "uniform_k1_two_pairs", "uniform_k2_one_pair",
+                                  "uniform_k2_two_pairs_no_diag"])
+def test_strip_walk_two_long_pairs_and_two_far_distances(ctx, case):
+    """The long-pair shapes beyond (one pair, one far distance): the fourth-order Laplacian of an open-boundary nx x ny x nz grid
+    -- distances +-1, +-2, +-nx, +-2 nx, +-nx ny, +-2 nx ny: near 2, far 2, TWO long pairs, completed at creation like the
+    seven-point one -- and translation-invariant lattices with one / two far distances and one / two pairs.  Bit-identical to
+    the per-block kernel for several partitions of the walk, within 1e-10 of the oracle."""
+    if case.startswith("grid"):
+        dims = (72, 10, 20) if "72x10x20" in case else (64, 8, 24)     # (nx >= 64: the strip step)
+        H = synth.grid_hamiltonian_3d(*dims, flux=0.0 if "real" in case else 0.15, order=4)
+        N = H.shape[0]
+        Delta, Emin = 16.0, -1.0
+        want = dict(near=2, far=2, diag=1, longs=[dims[0] * dims[1], 2 * dims[0] * dims[1]], step=dims[0])
+    else:
+        N = 1 << 15
+        offs, want = {"uniform_k1_two_pairs": ((1, 128, 1000, 3001), dict(near=1, far=1, diag=1, longs=[1000, 3001], step=128)),
+                      "uniform_k2_one_pair": ((1, 3, 100, 200, 2500), dict(near=2, far=2, diag=1, longs=[2500], step=100)),
+                      "uniform_k2_two_pairs_no_diag": ((2, 5, 192, 384, 1111, 2222), dict(near=2, far=2, diag=0, longs=[1111, 2222], step=192))}[case]
+        rp, col, vals = synth.hermitian_offsets_csr(N, offsets=offs)
+        H = synth.to_scipy(rp, col, vals, N)
+        if want["diag"]:
+            H = sp.csr_matrix(H + sp.diags(np.linspace(-1.0, 1.0, N)).astype(np.complex128))
+        H.sort_indices()
+        Delta, Emin = 24.0, -12.0
+    psi0 = synth.random_state(N)
+    saved = {k: ctx.tuning_get(k) for k in WALK_KNOBS}
+    try:
+        ctx.tuning_set("walk_min_blocks", 16)
+        Op = L.Operator(ctx, [L.Matrix.from_scipy(ctx, H)])
+        assert Op.format == L.FMT_HRB and Op.walk_reason()[1] == "ok"
+        wi = Op.walk_info()
+        assert wi["valid"] == 1 and (wi["near"], wi["far"], wi["diag"]) == (want["near"], want["far"], want["diag"])
+        assert wi["long_distances"] == want["longs"] and wi["long_distance"] == want["longs"][-1] and wi["rows_per_step"] == want["step"]
+        if case.startswith("grid"):
+            assert Op.fill_info() > 0 and wi["first_block"] >= want["longs"][-1] // 64
+        wrk = L.ChebyWrk(ctx, N, Delta, Emin, 0.6)
+
+        def run(**knobs):
+            for k, v in {**WALK_DEFAULTS, "walk_min_blocks": 16, **knobs}.items():
+                ctx.tuning_set(k, v)
+            psi = L.State(ctx, data=psi0)
+            for dt in (0.6, -0.6, 0.6):
+                L.cheby(psi, Op, dt, wrk)
+            return psi.numpy()
+
+        base = run(hrb_walk=0)
+        for knobs in (dict(), dict(walk_waves=64), dict(walk_waves=1024), dict(walk_dbg=4), dict(walk_dbg=5, walk_waves=256),
+                      dict(walk_nt=1), dict(walk_wg=8), dict(walk_wg=2, walk_waves=96)):
+            assert np.array_equal(base, run(**knobs)), knobs
+    finally:
+        for k, v in saved.items():
+            ctx.tuning_set(k, v)
+    owrk = qo.ChebyWrk(psi0, Delta, Emin, 0.6)
+    ref = psi0.copy()
+    for dt in (0.6, -0.6, 0.6):
+        qo.cheby(ref, H, dt, owrk)
+    assert np.linalg.norm(base - ref) < TOL
+
+
 def test_strip_walk_inside_a_replayed_graph(ctx):
     """Knob `cheby_graph` with an operator that takes the strip walk: the walk's launch (dynamic LDS above 64 KB, opted in
     per kernel instance and device) is captured and replayed like any other; same bits as the eager step, and the graph is
@@ -983,14 +1042,14 @@ def test_strip_walk_inside_a_replayed_graph(ctx):
 def test_strip_walk_plan_only_for_lattices(ctx):
     """The walk plan is index work on the host: it exists only where one list of column distances repeats down a run of row
     blocks and has the walk's shape -- not for scattered or per-row random columns, not for near distances beyond the LDS
-    halo, far distances that are not the multiples g, 2 g, .. of one stride g >= 64 (any such g will do; ONE further distance beyond
-    them is the long pair of a three-dimensional grid, with at most two near distances), more than four near or far distances -- and it
+    halo, far distances that are not the multiples g, 2 g, .. of one stride g >= 64 (any such g will do; ONE or TWO further distances
+    beyond them are the long pairs of a three-dimensional grid, with at most two near and two far distances), more than four near or far distances -- and it
     goes away when a complex coefficient forces the operator out of the Hermitian-packed format."""
     N = 1 << 15
     saved = ctx.tuning_get("walk_min_blocks")
     ctx.tuning_set("walk_min_blocks", 16)
     try:
-        for offsets, want in (((1, 2, 512, 1024), 1), ((1, 2, 500, 1000), 1), ((1, 2, 500, 1100), 1), ((1, 2, 500, 1100, 1700), 0), ((1, 2, 3, 500, 1100), 0), ((1, 2, 40, 80), 0), ((1, 17, 512, 1024), 0), ((1, 2, 512, 1536), 1), ((1, 2, 512, 1536, 2048), 0),
+        for offsets, want in (((1, 2, 512, 1024), 1), ((1, 2, 500, 1000), 1), ((1, 2, 500, 1100), 1), ((1, 2, 500, 1100, 1700), 1), ((1, 2, 500, 1100, 1700, 2300), 0), ((1, 2, 3, 500, 1100), 0), ((1, 2, 40, 80), 0), ((1, 17, 512, 1024), 0), ((1, 2, 512, 1536), 1), ((1, 2, 512, 1536, 2048), 1),
                               ((1, 2, 3, 512), 1), ((1, 512, 1024, 1536), 1), ((3, 5, 320, 640), 1), ((1, 2, 3, 4, 5, 6, 512, 1024), 0)):
             rp, col, vals = synth.hermitian_offsets_csr(N, offsets=offsets)
             Op = L.Operator(ctx, [L.Matrix(ctx, N, N, rp, col, vals)], 0, L.FMT_HRB)
@@ -1998,11 +2057,18 @@ def test_walk_reason_says_what_broke_the_plan(ctx):
         assert r[1] == "too_many_near" and "5 near" in r[2]
         op, r = reason((1, 256, 512, 768, 1024, 1280))             # read as four strides + one long pair: no such kernel
         assert r[1] == "no_kernel_instance" and "long pair" in r[2]
-        op, r = reason((1, 256, 512, 768, 1024, 1280, 1536))
+        op, r = reason((1, 256, 512, 768, 1024, 1280, 1536))       # four strides + two long pairs: no such kernel either
+        assert r[1] == "no_kernel_instance"
+        op, r = reason((1, 256, 512, 768, 1024, 1280, 1536, 1792))
         assert r[1] == "too_many_far"
         op, r = reason((1, 256, 600))                              # one stride + one long pair (any distance): walks
-        assert r[1] == "ok" and op.walk_info()["long_distance"] == 600
-        op, r = reason((1, 256, 600, 1000))
+        assert r[1] == "ok" and op.walk_info()["long_distance"] == 600 and op.walk_info()["long_distances"] == [600]
+        op, r = reason((1, 256, 600, 1000))                        # ... + two long pairs: walks (round 4)
+        assert r[1] == "ok" and op.walk_info()["long_distances"] == [600, 1000] and op.walk_info()["long_distance"] == 1000
+        op, r = reason((1, 2, 256, 512, 2000, 4000))               # the thirteen-point stencil of a three-dimensional grid
+        wi = op.walk_info()
+        assert r[1] == "ok" and wi["near"] == 2 and wi["far"] == 2 and wi["long_distances"] == [2000, 4000]
+        op, r = reason((1, 256, 600, 1000, 1500))
         assert r[1] == "incommensurate_strides" and "256" in r[2]
         op, r = reason((1, 2, 3))
         assert r[1] == "no_far_distance"

@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--patterns", nargs="+", default=["random", "random-window"])
     ap.add_argument("--log2w", type=int, nargs="+", default=[17])
     ap.add_argument("--waves", type=int, nargs="+", default=[24])
+    ap.add_argument("--rpt", type=int, nargs="+", default=[0])
+    ap.add_argument("--force", action="store_true", help="build the mirror whatever the sampled gathers look like (colblock = 2)")
     ap.add_argument("--steps", type=int, default=6)
     args = ap.parse_args()
     ctx = L.Context(0)
@@ -36,12 +38,16 @@ def main():
                   f" {base['us_per_term_max']:8.1f} {base['csr_equivalent_gbs']:11.0f} {base['csr_equivalent_gbs'] / 8000.0:11.3f} {base['operator_build_ms']:9.0f}")
             sys.stdout.flush()
             for lw in args.log2w:
-                for wv in args.waves:
-                    ctx.tuning_set("colblock", 2 if ln < 19 else 1)
+                for wv, rpt in ((w_, r_) for w_ in args.waves for r_ in args.rpt):
+                    ctx.tuning_set("colblock", 2 if (ln < 19 or args.force) else 1)
                     ctx.tuning_set("cb_log2w", lw)
                     ctx.tuning_set("cb_waves", wv)
+                    ctx.tuning_set("cb_rpt", rpt)
                     r = bp.measure_cheby(ctx, pattern=pat, log2n=ln, steps=args.steps, warmup=2)
                     ci = r["column_blocked_mirror"]
+                    if not ci["valid"]:
+                        print(f"{pat:>14s} {1 << ln:9d} (no mirror for log2w {lw}, waves {wv}, rpt {rpt})")
+                        continue
                     print(f"{pat:>14s} {1 << ln:9d} {r['kernel']:>22s} {lw:5d} {wv:5d} {ci['column_blocks']:6d} {ci['rows_per_tile']:5d} {r['us_per_term']:9.1f}"
                           f" {r['us_per_term_min']:8.1f} {r['us_per_term_max']:8.1f} {r['csr_equivalent_gbs']:11.0f} {r['csr_equivalent_gbs'] / 8000.0:11.3f}"
                           f" {r['operator_build_ms']:9.0f}  {ci['own_line_share']:.2f}   speed-up {base['us_per_term'] / r['us_per_term']:.2f} x")

@@ -97,7 +97,12 @@ def main():
             err = 0.0
             if kind == "newton":
                 m = int(rng.integers(4, 12))
-                ref = qo.newton(psi0.copy(), H, dt, qo.NewtonWrk(psi0, m_max=m))
+                try:
+                    ref = qo.newton(psi0.copy(), H, dt, qo.NewtonWrk(psi0, m_max=m))
+                except AssertionError:      # (the oracle itself runs out of restarts for this dt / m_max: not a case)
+                    kinds[kind] -= 1
+                    ctx.close()
+                    continue
                 for knob in (2, 0):
                     ctx.tuning_set("colblock", knob)
                     psi = L.State(ctx, data=psi0)

@@ -6,7 +6,7 @@ that are no multiple of the stride or of 64, forward and backward steps, random 
 workgroup widths.  Every case that takes the walk must agree with the oracle's cheby! to 1e-10 and with the per-block
 kernel bit for bit.  Test infrastructure: oracle/ is the checker.
 
-    python tools/fuzz_walk.py [n_cases] [seed]"""
+    python tools/fuzz_walk.py [n_cases] [seed] [one case in this many carries long pairs: default 5]"""
 import os
 import sys
 
@@ -36,10 +36,15 @@ def main():
         nsteps = int(rng.integers(2 * K + 6, 2 * K + 60))
         N = g * nsteps + int(rng.choice([0, 0, 64, 1, 37, 200]))
         offsets = tuple(near) + tuple(g * m for m in range(1, K + 1))
-        if rng.integers(0, 5) == 0:          # a fifth of the cases: the long pair of a three-dimensional grid (near <= 2, one far distance)
-            nn, K = min(nn, 2), 1
+        longs = int(sys.argv[3]) if len(sys.argv) > 3 else 5      # one case in `longs` carries long pairs (1: every case)
+        if rng.integers(0, longs) == 0:      # the long pairs of three- and four-dimensional grids: near <= 2, far reach <= 2, one or two pairs
+            nn, K = min(nn, 2), int(rng.integers(1, 3))
             near = near[:nn]
-            offsets = tuple(near) + (g, g * int(rng.integers(2, 12)) + int(rng.integers(0, 2)) * int(rng.integers(1, g)))
+            L0 = g * (K + int(rng.integers(1, 11))) + int(rng.integers(0, 2)) * int(rng.integers(1, g))
+            lo = (L0,)
+            if rng.integers(0, 2):           # two pairs: the double of the first (a fourth-order stencil's second plane) or anything beyond it
+                lo = (L0, 2 * L0 if rng.integers(0, 2) else L0 + int(rng.integers(1, 9 * g)))
+            offsets = tuple(near) + tuple(g * m for m in range(1, K + 1)) + lo
         if 2 * max(offsets) >= N or N > (1 << 18):
             continue
         nterms = int(rng.integers(1, 4))

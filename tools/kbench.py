@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--ab", default="", help="A/B over one knob: key=v1,v2,... (every format / variant case is run with each value)")
     ap.add_argument("--offsets", default="", help="Hermitian lattice with these distances instead of --pattern (e.g. 1,1000 or 1,2,3,4,100,200,300,400)")
     ap.add_argument("--grid", default="", help="nx,ny: finite-difference Hamiltonian on an open-boundary grid (synth.grid_hamiltonian_2d)")
+    ap.add_argument("--order", type=int, default=2, help="with a three-dimensional --grid: 2 = seven-point, 4 = thirteen-point stencil")
     ap.add_argument("--no-fill", action="store_true", help="knob lattice_fill = 0 while the operator is created")
     ap.add_argument("--real", action="store_true", help="real symmetric H (values streamed as fp64 instead of complex)")
     args = ap.parse_args()
@@ -36,8 +37,13 @@ def main():
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import bench_points as bp
     if args.grid:
-        nx, ny = (int(t) for t in args.grid.split(","))
-        Hg = synth.grid_hamiltonian_2d(nx, ny, flux=0.0 if args.real else 0.1)
+        dims = [int(t) for t in args.grid.split(",")]
+        nx, ny = dims[0], dims[1]
+        if len(dims) == 3:      # nx,ny,nz: seven-point grid; with --order 4 the thirteen points of the fourth-order Laplacian
+            Hg = synth.grid_hamiltonian_3d(*dims, flux=0.0 if args.real else 0.1, order=args.order)
+            ny = dims[1] * dims[2]
+        else:
+            Hg = synth.grid_hamiltonian_2d(nx, ny, flux=0.0 if args.real else 0.1)
         N = nx * ny
         rp, col, vals = Hg.indptr.astype(np.int64), Hg.indices.astype(np.int32), Hg.data.astype(np.complex128)
     elif args.offsets:

@@ -1149,7 +1149,7 @@ static int build_colblock(qp_operator* op) {
   {
     const int64_t nblocks = nrows / kRB;
     const int64_t bstride = std::max<int64_t>(1, nblocks / 1024);
-    int64_t gathers = 0, lines = 0;
+    int64_t gathers = 0, lines = 0, local = 0;
     std::vector<int64_t> ln;
     for (int64_t b = 0; b < nblocks; b += bstride) {
       int64_t wmax = 0;
@@ -1157,7 +1157,11 @@ static int build_colblock(qp_operator* op) {
       for (int64_t k = 0; k < wmax; ++k) {
         ln.clear();
         for (int64_t r = b * kRB; r < (b + 1) * kRB; ++r)
-          if (k < ur[r + 1] - ur[r]) ln.push_back((int64_t)uc[ur[r] + k] >> 3);
+          if (k < ur[r + 1] - ur[r]) {
+            const int64_t c = uc[ur[r] + k];
+            ln.push_back(c >> 3);
+            if (std::llabs(c - r) <= ((int64_t)1 << 16)) ++local;
+          }
         std::sort(ln.begin(), ln.end());
         gathers += (int64_t)ln.size();
         lines += (int64_t)(std::unique(ln.begin(), ln.end()) - ln.begin());
@@ -1165,6 +1169,10 @@ static int build_colblock(qp_operator* op) {
     }
     op->cb_line_share = gathers > 0 ? (double)lines / (double)gathers : 0.0;
     if (tun.colblock == 1 && op->cb_line_share <= 0.5) return QP_OK;
+    // ... and the gathers must really leave the L2: columns drawn near the row (within 2^16 elements = 1 MB either side)
+    // stay in the XCD's L2 as the rows stream by -- columns random inside 4096-row windows: 101 us per term on the
+    // row-block kernel, 186 through the mirror
+    if (tun.colblock == 1 && 4 * local >= 3 * gathers) return QP_OK;
   }
   // tile height: 128 rows unless a segment would outgrow the wavefront's LDS buffer, then 64
   qp::ColBlockPlan& C = op->cb;

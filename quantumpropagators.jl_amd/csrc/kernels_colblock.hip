@@ -111,6 +111,10 @@ __global__ __launch_bounds__(kThreads) void colblock_spmv_kernel(const int32_t* 
   }
 }
 
+// (Tried and dropped, round 4: the same walk with the next segment's values, columns and row offsets requested before the
+// current segment is worked on, segment pointers in registers -- 177 vs 175 us per term at N = 2^20, 410 vs 354 at 2^21.  The
+// dependent chain of a segment is not what bounds the kernel; the L2's request rate is: DESIGN 4.)
+
 // mirror values from the operator's current values
 __global__ __launch_bounds__(kThreads) void colblock_gather_kernel(double2* __restrict__ out, double* __restrict__ out_r,
                                                                    const double2* __restrict__ vals,

@@ -198,6 +198,13 @@ def test_auto_decision(ctx):
     ib = opb.colblock_info()
     assert ib["valid"] == 0 and 0.0 < ib["own_line_share"] < 0.3
     opb.close()
+    # columns drawn per row but NEAR the row (inside 4096-row windows): every gather is its own line, yet the lines stay in the
+    # XCD's L2 as the rows stream by -- no mirror (101 us per term on the row-block kernel, 186 through a mirror)
+    rw, cw, vw = synth.random_columns_csr(N, window=4096)
+    opw = L.Operator(ctx, [L.Matrix(ctx, N, N, rw, cw, vw)])
+    iw = opw.colblock_info()
+    assert iw["valid"] == 0 and iw["own_line_share"] > 0.5
+    opw.close()
     # small: no mirror (the vector fits the L2)
     n = 1 << 16
     r2, c2, v2 = synth.random_columns_csr(n)

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--log2w", type=int, nargs="+", default=[17])
     ap.add_argument("--waves", type=int, nargs="+", default=[24])
     ap.add_argument("--rpt", type=int, nargs="+", default=[0])
+    ap.add_argument("--extra", nargs="+", default=[""], help="further knob sets, each 'knob=value,knob=value' (one measured line per set)")
     ap.add_argument("--force", action="store_true", help="build the mirror whatever the sampled gathers look like (colblock = 2)")
     ap.add_argument("--steps", type=int, default=6)
     args = ap.parse_args()
@@ -38,7 +39,9 @@ def main():
                   f" {base['us_per_term_max']:8.1f} {base['csr_equivalent_gbs']:11.0f} {base['csr_equivalent_gbs'] / 8000.0:11.3f} {base['operator_build_ms']:9.0f}")
             sys.stdout.flush()
             for lw in args.log2w:
-                for wv, rpt in ((w_, r_) for w_ in args.waves for r_ in args.rpt):
+                for wv, rpt, extra in ((w_, r_, x_) for w_ in args.waves for r_ in args.rpt for x_ in args.extra):
+                    for kv in filter(None, extra.split(",")):
+                        ctx.tuning_set(kv.split("=")[0], int(kv.split("=")[1]))
                     ctx.tuning_set("colblock", 2 if (ln < 19 or args.force) else 1)
                     ctx.tuning_set("cb_log2w", lw)
                     ctx.tuning_set("cb_waves", wv)
@@ -50,7 +53,7 @@ def main():
                         continue
                     print(f"{pat:>14s} {1 << ln:9d} {r['kernel']:>22s} {lw:5d} {wv:5d} {ci['column_blocks']:6d} {ci['rows_per_tile']:5d} {r['us_per_term']:9.1f}"
                           f" {r['us_per_term_min']:8.1f} {r['us_per_term_max']:8.1f} {r['csr_equivalent_gbs']:11.0f} {r['csr_equivalent_gbs'] / 8000.0:11.3f}"
-                          f" {r['operator_build_ms']:9.0f}  {ci['own_line_share']:.2f}   speed-up {base['us_per_term'] / r['us_per_term']:.2f} x")
+                          f" {r['operator_build_ms']:9.0f}  {ci['own_line_share']:.2f}   speed-up {base['us_per_term'] / r['us_per_term']:.2f} x  {extra}   |dnorm| {r['norm_drift']:.1e}")
                     sys.stdout.flush()
     ctx.close()
 

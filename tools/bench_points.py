@@ -114,7 +114,15 @@ def cheby_layout_bytes(op, rows, ncols, nnz, coeffs, real_copy=False):
     vbytes = 8.0 if real_copy else 16.0
     walk = op.walk_info() if fmt == L.FMT_HRB else {"valid": 0}
     lay["strip_walk"] = walk
-    if fmt == L.FMT_CSR:
+    cb = op.colblock_info() if fmt in (L.FMT_CSR, L.FMT_RBCSR) else {"valid": 0}
+    cb_on = bool(cb["valid"]) and op.ctx.tuning_get("colblock") != 0
+    lay["column_blocked_mirror"] = cb if cb_on else None
+    if cb_on:
+        # the column-blocked mirror (kernels_colblock.hip): value + column per entry, a 16-bit offset per (row, column block)
+        # and one more per (tile, block), the segment pointers
+        tr = cb["rows_per_tile"]
+        matrix = (vbytes + 4.0) * nnz + 2.0 * cb["tiles"] * cb["column_blocks"] * (tr + 1) + 4.0 * cb["tiles"] * cb["column_blocks"]
+    elif fmt == L.FMT_CSR:
         matrix = vbytes * nnz + 4.0 * nnz + 8.0 * (rows + 1)
     else:
         per_block = 32.0 if fmt == L.FMT_HRB else 16.0     # bptr + cmeta (+ lptr + lcmeta)
@@ -131,7 +139,7 @@ def cheby_layout_bytes(op, rows, ncols, nnz, coeffs, real_copy=False):
     vec = 0.0
     updated = False
     for m in range(1, nterms + 1):
-        vec += 16.0 * ncols                      # gathered vector
+        vec += 16.0 * ncols * (8.0 if cb_on else 1.0)    # gathered vector (the mirror: every XCD's L2 loads every window once)
         if m >= 2:
             vec += 16.0 * rows                   # v_{m-2}
         if m < nterms:

@@ -896,6 +896,10 @@ def main():
                                                              "steps_per_s", "layout_bytes_per_term", "layout_gbs", "frac", "kernel",
                                                              "operator_build_ms")}
         rf["unstable_extras"] = sorted(k for k, v in extras.items() if isinstance(v, dict) and v.get("unstable"))
+        # points one of whose timed regions was measured again because a single enqueue call held the host for more than half
+        # of the region (tools/bench_points.py: timed_regions; the discarded regions are kept in the point's record)
+        rf["extras_with_a_region_remeasured_after_a_host_stall"] = sorted(
+            k for k, v in extras.items() if isinstance(v, dict) and v.get("regions_remeasured_after_host_stall"))
         t_gc = time.perf_counter()
         gc.collect()
         rf["host_gc_full_collection_ms"] = 1e3 * (time.perf_counter() - t_gc)    # what a collection inside a timed region would cost

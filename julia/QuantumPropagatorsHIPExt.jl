@@ -266,6 +266,16 @@ function operator_walk_reason(op::Handle)
     return Int(code[]), unsafe_string(pointer(text))
 end
 
+# column-blocked mirror of an operator with irregular columns (include/qprop.h: qp_operator_colblock_info):
+# (has one, column blocks, log2 of the columns per block, rows per tile, longest segment, tiles, share of single-line gathers)
+function operator_colblock_info(op::Handle)
+    out = zeros(Int64, 6)
+    share = Ref{Cdouble}(0.0)
+    GC.@preserve out check(ccall((:qp_operator_colblock_info, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Cdouble}), op, out, share))
+    return (valid = out[1] != 0, column_blocks = out[2], log2_block_columns = out[3], rows_per_tile = out[4],
+        longest_segment = out[5], tiles = out[6], own_line_share = share[])
+end
+
 # explicit zeros that qp_operator_create added to complete a lattice operator's rows (open boundaries of a grid)
 function operator_fill_info(op::Handle)
     n = Ref{Int64}(0)

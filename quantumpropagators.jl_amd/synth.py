@@ -339,3 +339,53 @@ def liouvillian_tridiag(n, gamma=0.05, kappa=0.02, seed=DEFAULT_SEED, convention
     L.sum_duplicates()
     L.sort_indices()
     return L
+
+
+def tfim_csr(n, J=1.0, h=1.0, hz=0.1):
+    """Transverse-field Ising chain of n spins (open ends), N = 2^n, computational basis (bit i of the row = spin i):
+    H = -J sum_i sz_i sz_{i+1} - hz sum_i sz_i - h sum_i sx_i.  Every row: the diagonal and n entries at columns
+    row XOR 2^i -- the structure of every qubit-register Hamiltonian (a Pauli string with k X/Y factors couples row and
+    row XOR mask): NOT translation invariant (the distance is +2^i where bit i is 0, -2^i where it is 1), but 64-row blocks
+    map onto 64-row blocks for i >= 6.  Returns (rowptr int64, col int32, vals complex128), columns ascending;
+    spectrum inside [-(J (n - 1) + hz n + h n), +...]."""
+    N = 1 << n
+    r = np.arange(N, dtype=np.int64)
+    bits = ((r[:, None] >> np.arange(n, dtype=np.int64)[None, :]) & 1).astype(np.int8)
+    s = 1 - 2 * bits.astype(np.float64)
+    diag = -J * np.sum(s[:, :-1] * s[:, 1:], axis=1) - hz * np.sum(s, axis=1)
+    del bits, s
+    cols = np.empty((N, n + 1), dtype=np.int64)
+    cols[:, :n] = r[:, None] ^ (np.int64(1) << np.arange(n, dtype=np.int64))[None, :]
+    cols[:, n] = r
+    vals = np.empty((N, n + 1), dtype=np.complex128)
+    vals[:, :n] = -h
+    vals[:, n] = diag
+    order = np.argsort(cols, axis=1, kind="stable")
+    cols = np.take_along_axis(cols, order, axis=1)
+    vals = np.take_along_axis(vals, order, axis=1)
+    rowptr = np.arange(N + 1, dtype=np.int64) * (n + 1)
+    return rowptr, cols.reshape(-1).astype(np.int32), vals.reshape(-1)
+
+
+def xxz_csr(n, J=1.0, delta=0.5, hz=0.05):
+    """XXZ Heisenberg chain of n spins (open ends): H = J sum_i (sx sx + sy sy)_{i,i+1} / 2 + delta sz sz + hz sum_i (i + 1) sz_i / n.
+    The exchange term couples row and row XOR (3 << i) where spins i, i + 1 differ: the number of entries of a row is its number
+    of domain walls + 1 -- ragged rows, no two rows of a block alike.  Returns CSR arrays as tfim_csr."""
+    import scipy.sparse as sp
+    N = 1 << n
+    r = np.arange(N, dtype=np.int64)
+    bits = ((r[:, None] >> np.arange(n, dtype=np.int64)[None, :]) & 1).astype(np.int8)
+    s = 1 - 2 * bits.astype(np.float64)
+    diag = delta * np.sum(s[:, :-1] * s[:, 1:], axis=1) + hz * np.sum(s * (np.arange(n) + 1)[None, :], axis=1) / n
+    rows, cols = [r], [r]
+    vals = [diag.astype(np.complex128)]
+    for i in range(n - 1):
+        differ = bits[:, i] != bits[:, i + 1]
+        rr = r[differ]
+        rows.append(rr)
+        cols.append(rr ^ (np.int64(3) << i))
+        vals.append(np.full(len(rr), J, dtype=np.complex128))
+    del bits, s
+    A = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(N, N)).tocsr()
+    A.sort_indices()
+    return A.indptr.astype(np.int64), A.indices.astype(np.int32), A.data.astype(np.complex128)

@@ -89,3 +89,33 @@ def test_generator_is_chunking_independent_and_quota_aware():
     r2, c2, v2 = synth.hermitian_offsets_csr(1 << 14, offsets=offs)
     H2 = sp.csr_matrix((v2, c2, r2), shape=(1 << 14, 1 << 14))
     assert abs(H2 - H2.getH()).max() == 0.0 and np.all(np.diff(c2.reshape(-1, 16), axis=1) > 0)
+
+
+def test_a_region_with_a_host_stall_is_measured_again_and_kept_on_record():
+    """tools/bench_points.py: timed_regions -- one enqueue call that takes more than half of its region's event time means the
+    device idled inside the event bracket; the region is repeated (at most twice per point) and the discarded one reported."""
+    import time
+    import bench_points as bp
+
+    class FakeCtx:
+        def sync(self):
+            pass
+
+        def timer_begin(self):
+            self.t0 = time.perf_counter()
+
+        def timer_end(self):
+            return 1e3 * (time.perf_counter() - self.t0)
+
+    calls = {"n": 0}
+
+    def fn():
+        calls["n"] += 1
+        time.sleep(0.08 if calls["n"] == 2 else 0.002)      # the second call of the first region is held for 80 ms
+
+    regions = bp.timed_regions(FakeCtx(), fn, steps=4, repeats=3)
+    assert len(regions) == 3 and len(regions.discarded) == 1 and calls["n"] == 16
+    assert regions.discarded[0][2] > 70.0 and all(r[2] < 0.5 * r[0] for r in regions)
+    sp = bp.spread([r[0] for r in regions], regions)
+    assert sp["unstable"] is False and len(sp["regions_remeasured_after_host_stall"]) == 1
+    assert sp["regions_remeasured_after_host_stall"][0]["longest_single_call_ms"] > 70.0

@@ -180,6 +180,12 @@ int qp_operator_info(const qp_operator* op, int64_t* nrows, int64_t* ncols, int6
  * out[3] = bytes of index data a mat-vec streams (column sections + transpose positions
  * of the non-stencil lower sections), out[4] = stored values. */
 int qp_operator_layout_info(const qp_operator* op, int64_t out[5]);
+/* How the row blocks' column sections are encoded (index bytes per entry: 4 / 2 / 0 / 1): out[0..3] = blocks whose upper (or
+ * only) section holds int32 columns / int16 distances to the row / one distance per slot for all 64 rows (stencil: lattices) /
+ * one 64-aligned column block per slot + the lane inside it as a byte per entry (block map: a slot sends the 64 rows into one
+ * block of columns -- row XOR mask, the structure of qubit-register Hamiltonians); out[4..7] = the same for the lower sections
+ * of a Hermitian-packed operator.  All zero for the CSR-ordered formats. */
+int qp_operator_encoding_info(const qp_operator* op, int64_t out[8]);
 /* What creating the operator cost on the host (union pattern, lattice completion, value planes, Hermitian check, format
  * choice, encoding, upload): out[0] = ms of the latest build (the creation itself, or a later re-layout), out[1] = ms of all builds, out[2] = re-layouts after creation -- evaluate! (src/generators.jl:757-766)
  * only rewrites coefficients, but a complex coefficient on a Hermitian-packed operator forces ONE rebuild as plain

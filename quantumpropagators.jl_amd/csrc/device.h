@@ -36,7 +36,8 @@ struct DevMatrix {
   int32_t* cols = nullptr;    // CSR: plain int32.  Row-block formats: a byte stream; block b's
                               // column section starts at byte cmeta[b] >> 2; cmeta[b] & 3 = 0: quad-packed
                               // int32 columns, 1: quad-packed int16 deltas to the lane's row, 2: stencil
-                              // block, one int32 delta per slot for all 64 rows
+                              // block, one int32 delta per slot for all 64 rows, 3: block map, one column
+                              // block per slot for all 64 rows + the lane inside it, a byte per entry
   int64_t* cmeta = nullptr;   // nblocks (row-block formats)
   int64_t colbytes = 0;
   double2* vals = nullptr;    // stored, the current values (always valid)
@@ -243,6 +244,7 @@ struct Tuning {
   int liouville_tile32_n = 2048;     //   kernel; other n <= liouville_fused_n the 16 x 16 one; the rest library GEMMs
   int liouville_fused_n = 320;  // matrix-free Liouvillian: largest n that takes the fused matrix-core kernel (else library GEMMs)
   int real_vals = 1;          // operator refresh: stream a real copy of the values when they are all real
+  int block_map = 1;          // operator build: encode blocks whose slots each map the 64 rows into one 64-aligned column block (row XOR mask: qubit-register Hamiltonians) with one byte of index per entry
   int stencil = 1;            // operator build: encode blocks with block-wide column distances as stencil blocks
   int acc_defer = 1;          // qp_cheby_step: touch the Psi accumulator every third term only (1) or every term (0)
   int cheby_graph = 0;        // qp_cheby_step: replay a repeated step as a hipGraph when the mat-vec grid has at most this many workgroups (0: off; measured: no gain)

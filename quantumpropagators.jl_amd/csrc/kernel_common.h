@@ -319,7 +319,9 @@ typedef int i2v __attribute__((ext_vector_type(2)));
 
 // Column indices of quad q for this lane.  A block stores either int32 columns or, when
 // every column of the block is within +-32767 of its row (banded H), int16 deltas to the
-// lane's own row: 2 instead of 4 bytes per entry of index traffic.
+// lane's own row: 2 instead of 4 bytes per entry of index traffic; a stencil block one distance per
+// slot (mode 2); a block-map block (mode 3: engine_core.hip, encode_col_sections) one column block per
+// slot + one byte per entry.
 template <bool NT>
 __device__ __forceinline__ int4 ld_cols(const char* __restrict__ colbytes, int64_t meta, int q, int lane, int rowc) {
   const char* p = colbytes + (meta >> 2);
@@ -327,6 +329,14 @@ __device__ __forceinline__ int4 ld_cols(const char* __restrict__ colbytes, int64
   if (mode == 2) {  // stencil block: one delta per slot for the whole block (wave-uniform load)
     const int4 d = *(reinterpret_cast<const int4*>(p) + q);
     return make_int4(rowc + d.x, rowc + d.y, rowc + d.z, rowc + d.w);
+  }
+  if (mode == 3) {  // block map: one column block per slot for the whole block (wave-uniform) + the lane inside it, a byte per row and slot
+    const char* pq = p + (size_t)q * (16 + 4 * 64);
+    const int4 cb = *reinterpret_cast<const int4*>(pq);
+    const unsigned* lp = reinterpret_cast<const unsigned*>(pq + 16) + lane;
+    const unsigned lb = NT ? __builtin_nontemporal_load(lp) : *lp;
+    return make_int4((cb.x << 6) | (int)(lb & 63u), (cb.y << 6) | (int)((lb >> 8) & 63u), (cb.z << 6) | (int)((lb >> 16) & 63u),
+                     (cb.w << 6) | (int)((lb >> 24) & 63u));
   }
   if (mode == 1) {
     const i2v* q8 = reinterpret_cast<const i2v*>(p) + (size_t)q * 64 + lane;

@@ -138,6 +138,7 @@ SIGNATURES = {
     "qp_operator_walk_long": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "qp_operator_walk_reason": (C.c_int, [_P, C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
     "qp_operator_walk_long_pairs": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "qp_operator_encoding_info": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "qp_operator_evaluate_info": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "qp_operator_colblock_info": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "qp_lattice_fill_host": (C.c_int, [C.c_int64, C.c_int64, _i64p, _i32p, C.c_int, _i64p, _i32p, C.c_int64, C.POINTER(C.c_int64)]),
@@ -579,6 +580,13 @@ class Operator:
         out = np.zeros(3, dtype=np.int64)
         check(self.lib.qp_operator_evaluate_info(self._h, _ptr(out, _i64p)))
         return dict(zip(("first_sparse_term", "positions", "latest_update_sparse"), (int(v) for v in out)))
+
+    def encoding_info(self):
+        """Blocks per encoding of their column sections (include/qprop.h: qp_operator_encoding_info)."""
+        out = np.zeros(8, dtype=np.int64)
+        check(self.lib.qp_operator_encoding_info(self._h, _ptr(out, _i64p)))
+        names = ("int32", "int16", "stencil", "block_map")
+        return {"upper": dict(zip(names, (int(v) for v in out[:4]))), "lower": dict(zip(names, (int(v) for v in out[4:])))}
 
     def colblock_info(self):
         """Column-blocked mirror of an operator with irregular columns (include/qprop.h: qp_operator_colblock_info)."""

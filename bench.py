@@ -827,7 +827,9 @@ def main():
                              ("c2_alpha_50_85_coefficients", dict(pattern="banded", log2n=20, dt=5.0, steps=5)),
                              ("c2_real_symmetric_f64_values", dict(pattern="banded", log2n=20, real=True)),
                              ("grid_2048x2048_five_point_open_boundaries", dict(grid=(2048, 2048), steps=5)),
-                             ("grid_256x128x128_seven_point_open_boundaries", dict(grid=(256, 128, 128), steps=4))):
+                             ("grid_256x128x128_seven_point_open_boundaries", dict(grid=(256, 128, 128), steps=4)),
+                             ("grid_256x128x128_thirteen_point_two_long_pairs", dict(grid=(256, 128, 128), grid_order=4, steps=4)),
+                             ("tfim_20_spins_qubit_register_hamiltonian", dict(spins=20, steps=5))):
                 try:
                     extras[name] = bp.measure_cheby(ctx, **kw)
                 except Exception as e:  # noqa: BLE001  (an extra point must not take the headline down)

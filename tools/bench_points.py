@@ -201,15 +201,25 @@ def pattern_csr(pattern, N, row_begin=0, row_end=None):
     raise ValueError(pattern)
 
 
-def measure_cheby(ctx, pattern="banded", log2n=20, fmt="auto", steps=10, warmup=2, real=False, dt=1.0, grid=None, repeats=3):
+def measure_cheby(ctx, pattern="banded", log2n=20, fmt="auto", steps=10, warmup=2, real=False, dt=1.0, grid=None, repeats=3,
+                  grid_order=2, spins=None):
     """Cheby prop_step! on one GPU for a pattern / size / device format; per-term time from HIP events on
     the kernels' stream -- the MEDIAN of `repeats` timed regions of `steps` steps, with min, max and an `unstable` flag --;
     layout-byte and CSR-equivalent rates.  grid = (nx, ny): the finite-difference Hamiltonian of an
     open-boundary grid (synth.grid_hamiltonian_2d) instead of a pattern."""
-    if grid and len(grid) == 3:
-        Hg = synth.grid_hamiltonian_3d(*grid, flux=0.1)
+    window = (20.0, -10.0)        # Delta, E_min of the synthetic patterns (|spectrum| <= 10)
+    if spins:                     # transverse-field Ising chain: the qubit-register structure (row XOR 2^i), real couplings
+        N = 1 << spins
+        rp, col, vals = synth.tfim_csr(spins)
+        bound = 1.0 * (spins - 1) + 0.1 * spins + 1.0 * spins
+        window = (2.2 * bound, -1.1 * bound)
+        dt = 20.0 / window[0]     # alpha = 10 as the headline
+        pattern = f"transverse-field Ising chain, {spins} spins (row XOR 2^i), real couplings"
+        real = True
+    elif grid and len(grid) == 3:
+        Hg = synth.grid_hamiltonian_3d(*grid, flux=0.1, order=grid_order)
         N = grid[0] * grid[1] * grid[2]
-        pattern = f"seven-point grid {grid[0]} x {grid[1]} x {grid[2]}, open boundaries"
+        pattern = f"{'seven' if grid_order == 2 else 'thirteen'}-point grid {grid[0]} x {grid[1]} x {grid[2]}, open boundaries"
         rp, col, vals = Hg.indptr.astype(np.int64), Hg.indices.astype(np.int32), Hg.data.astype(np.complex128)
         del Hg
     elif grid:
@@ -228,7 +238,7 @@ def measure_cheby(ctx, pattern="banded", log2n=20, fmt="auto", steps=10, warmup=
     M = L.Matrix(ctx, N, N, rp, col, vals)
     del rp, col, vals
     op = L.Operator(ctx, [M], 0, f)
-    wrk = L.ChebyWrk(ctx, N, 20.0, -10.0, dt)
+    wrk = L.ChebyWrk(ctx, N, window[0], window[1], dt)
     psi = L.State(ctx, data=synth.random_state(N))
     nterms = wrk.n_coeffs - 1
     for _ in range(warmup):
@@ -251,7 +261,7 @@ def measure_cheby(ctx, pattern="banded", log2n=20, fmt="auto", steps=10, warmup=
            "csr_equivalent_gbs": by["csr_equivalent_per_term"] / t_term / 1e9,
            "encodings": {"row_blocks": lay["blocks"], "stencil_upper_blocks": lay["stencil_upper_blocks"],
                          "stencil_lower_blocks": lay["stencil_lower_blocks"], "index_bytes": lay["index_bytes"]},
-           "column_blocked_mirror": op.colblock_info(),
+           "column_blocked_mirror": op.colblock_info(), "column_encodings": op.encoding_info(),
            "strip_walk_reason": op.walk_reason()[1],      # "ok", or why this operator's term is not the strip walk (qp_operator_walk_reason)
            "norm_drift": abs(psi.norm() - 1.0)}
     if grid:

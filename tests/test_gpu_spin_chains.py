@@ -62,8 +62,9 @@ def test_spin_chain_cheby_matches_oracle(ctx, model, n, fmt):
 
 
 def test_block_map_knob_changes_the_bytes_not_the_bits(ctx):
-    """The same operator with the encoding switched off at creation: int32 columns, four times the index bytes, identical results."""
-    n = 14
+    """The same operator with the encoding switched off at creation: int32 columns (the far spin flips are more than 32767 rows
+    away: no int16 distances), four times the index bytes, identical results."""
+    n = 17
     N = 1 << n
     rp, col, vals = synth.tfim_csr(n)
     psi0 = synth.random_state(N)

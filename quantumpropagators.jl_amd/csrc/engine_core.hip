@@ -792,6 +792,17 @@ static int walk_shape_reason(const std::vector<int64_t>& dl, WalkShape& w, std::
     say("row of %lld entries does not split into diagonal + near + far parts", z);
     return QP_WALK_NOT_MIRRORED;
   }
+  if (w.xl >= 1) {
+    // a "long" distance right beside the ring's far reach is a DIAGONAL neighbour (nine-point stencil: g - 1, g, g + 1 read as
+    // stride g - 1 plus two long pairs): its operands are lane shifts of the ring's elements, which the walk does not keep in
+    // a window -- loading them directly makes the walk no faster than the per-block kernel (N = 2^22: 117.9 vs 113.9 us)
+    const int64_t first = (w.xl == 2) ? w.glong1 : w.glong;
+    if (first - (int64_t)w.K * w.g <= qp::kWalkHalo) {
+      say("distance %lld is a diagonal neighbour of the far reach %lld (windows on the ring's far steps are not built; the per-block kernel is as fast)",
+          first, (long long)w.K * w.g);
+      return QP_WALK_NO_KERNEL;
+    }
+  }
   if (!qp::walk_shape_supported(w.nn, w.K, w.z0, w.xl)) {
     say("no kernel instance for %lld near and %lld far distances with long pairs (they come with at most 2 near, 2 far)", w.nn, w.K);
     return QP_WALK_NO_KERNEL;

@@ -2068,6 +2068,8 @@ def test_walk_reason_says_what_broke_the_plan(ctx):
         op, r = reason((1, 2, 256, 512, 2000, 4000))               # the thirteen-point stencil of a three-dimensional grid
         wi = op.walk_info()
         assert r[1] == "ok" and wi["near"] == 2 and wi["far"] == 2 and wi["long_distances"] == [2000, 4000]
+        op, r = reason((1, 255, 256, 257))                         # nine-point stencil with diagonal neighbours: per-block kernel
+        assert r[1] == "no_kernel_instance" and "diagonal neighbour" in r[2] and op.walk_info()["valid"] == 0
         op, r = reason((1, 256, 600, 1000, 1500))
         assert r[1] == "incommensurate_strides" and "256" in r[2]
         op, r = reason((1, 2, 3))

@@ -210,6 +210,10 @@ int qp_operator_walk_long(const qp_operator* op, int64_t* glong);
  * four-dimensional grid): out = {L_0, L_1}, the shorter first, 0 for a pair the plan does not have.  qp_operator_walk_long
  * reports the longest. */
 int qp_operator_walk_long_pairs(const qp_operator* op, int64_t out[2]);
+/* The whole stencil shape of the plan: out = {near distances, far reach K, 1 if there is a diagonal entry, long pairs (0-2),
+ * 1 if the far distances come with their DIAGONAL neighbours (strip step m: m g - 1, m g, m g + 1 -- the nine-point stencil of a
+ * two-dimensional grid with next-nearest hopping), strip step g, shorter long distance, longest distance}; zeros without a plan. */
+int qp_operator_walk_shape(const qp_operator* op, int64_t out[8]);
 /* Column-blocked mirror of an operator with IRREGULAR columns (src/generators.jl:634-645 accepts any sparse H_l; a random
  * graph's gathers are each their own cache line and the vector outgrows the L2): the entries are also kept grouped by
  * (row tile, column block) and whole-operator mat-vecs (cheby!, arnoldi!, mul!) walk the column blocks in their outer loop, so

@@ -88,6 +88,7 @@ struct WalkPlan {
   int xl = 0;                 // 1: one more pair of distances +- glong beyond the ring's reach (loaded directly); 2: two, +- glong1 and +- glong
   int64_t glong = 0;          // the longest distance of the stencil
   int64_t glong1 = 0;         // xl = 2: the shorter long distance, K g < glong1 < glong
+  int fd = 0;                 // 1: diagonal far neighbours -- the far distances of strip step m are m g - 1, m g, m g + 1 (three slots per step)
   int64_t g = 0;              // rows per strip step (the far distances are g, 2 g, .., K g); need not be a multiple of 64
   int near[kWalkMaxNear] = {0};
   int64_t R0 = 0, R1 = 0, W0 = 0;
@@ -210,7 +211,7 @@ int launch_arnoldi_matvec_dots(hipStream_t s, const DevMatrix& A, const double2*
                                int64_t ldq, int j, double2* partials, bool* launched, Stats* st);
 // the strip walk for the fused Chebyshev term of a whole Hermitian-packed lattice operator; *launched = false when the
 // plan's shape has no kernel instance (the caller then takes the per-block kernel)
-bool walk_shape_supported(int nn, int K, int z0, int xl = 0);   // is there a kernel instance for this stencil shape?
+bool walk_shape_supported(int nn, int K, int z0, int xl = 0, int fd = 0);   // is there a kernel instance for this stencil shape?
 int launch_hrb_walk_cheby(hipStream_t s, const DevMatrix& A, const double2* x, const ChebyEpi& e, const Tuning& tun,
                           bool* launched, const RowSet* rs = nullptr);
 // kernels_dense.hip (QP_FMT_DENSE: CSR arrays with a complete pattern, i.e. vals / vals_r is the row-major dense matrix)

@@ -489,7 +489,7 @@ int qp_split_create(qp_operator* op, const int64_t* send_rows, int64_t nsend, qp
     while (hi > lo && is_boundary[hi - 1]) --hi;
     bool contiguous = true;
     for (int64_t b = lo; b < hi && contiguous; ++b) contiguous = !is_boundary[b];
-    const int64_t reach = (std::max<int64_t>((int64_t)P.K * P.g, P.glong) + kRB - 1) / kRB + 1;
+    const int64_t reach = (std::max<int64_t>((int64_t)P.K * P.g + P.fd, P.glong) + kRB - 1) / kRB + 1;
     const int64_t w0 = std::max(P.W0, lo + reach), r1 = std::min(P.R1, hi - reach);
     if (contiguous && r1 - w0 >= 8) {
       std::vector<int32_t> edge;

@@ -707,7 +707,7 @@ static int64_t decode_lower_stencil_pos(const std::vector<char>& bytes, const st
 // more pairs +-L beyond them (xl: the plane distance of a three-dimensional grid, and its double for a fourth-order stencil;
 // the volume distance of a four-dimensional one).  false: not a shape the walk has a kernel for.
 struct WalkShape {
-  int nn = 0, K = 0, z0 = 0, xl = 0;
+  int nn = 0, K = 0, z0 = 0, xl = 0, fd = 0;   // fd = 1: diagonal far neighbours g - 1, g, g + 1 (nine-point stencils)
   int64_t g = 0, glong = 0, glong1 = 0;   // glong: the longest distance; glong1: the shorter long one when there are two
   int near[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
@@ -765,7 +765,12 @@ static int walk_shape_reason(const std::vector<int64_t>& dl, WalkShape& w, std::
       if (dl[(size_t)(first + K - m)] != -(int64_t)m * w.g) return false;
     return true;
   };
-  if (nbig <= 4 && multiples(0, nbig)) {
+  if (nbig == 3 && dl[0] + 1 == dl[1] && dl[1] + 1 == dl[2] && -dl[2] >= (int64_t)kRB) {
+    // -(g + 1), -g, -(g - 1): one strip step with its two diagonal neighbours (the nine-point stencil of a two-dimensional grid)
+    w.g = -dl[1];
+    w.K = 1;
+    w.fd = 1;
+  } else if (nbig <= 4 && multiples(0, nbig)) {
     w.K = nbig;
   } else if (nbig >= 2 && nbig <= 5 && multiples(1, nbig - 1) && -dl[0] > (int64_t)(nbig - 1) * w.g) {
     w.K = nbig - 1;
@@ -788,7 +793,7 @@ static int walk_shape_reason(const std::vector<int64_t>& dl, WalkShape& w, std::
   while (k < z && dl[(size_t)k] < 0) ++k, ++w.nn;
   for (int i = 0; i < w.nn; ++i) w.near[i] = (int)(-dl[(size_t)(nbig + w.nn - 1 - i)]);
   w.z0 = (k < z && dl[(size_t)k] == 0) ? 1 : 0;
-  if (z != 2 * (w.nn + w.K + w.xl) + w.z0) {
+  if (z != 2 * (w.nn + w.K * (1 + 2 * w.fd) + w.xl) + w.z0) {
     say("row of %lld entries does not split into diagonal + near + far parts", z);
     return QP_WALK_NOT_MIRRORED;
   }
@@ -803,7 +808,11 @@ static int walk_shape_reason(const std::vector<int64_t>& dl, WalkShape& w, std::
       return QP_WALK_NO_KERNEL;
     }
   }
-  if (!qp::walk_shape_supported(w.nn, w.K, w.z0, w.xl)) {
+  if (w.fd && !qp::walk_shape_supported(w.nn, w.K, w.z0, w.xl, w.fd)) {
+    say("no kernel instance for %lld near distances beside diagonal far neighbours (they come with at most 2 near)", w.nn);
+    return QP_WALK_NO_KERNEL;
+  }
+  if (!w.fd && !qp::walk_shape_supported(w.nn, w.K, w.z0, w.xl)) {
     say("no kernel instance for %lld near and %lld far distances with long pairs (they come with at most 2 near, 2 far)", w.nn, w.K);
     return QP_WALK_NO_KERNEL;
   }
@@ -878,20 +887,20 @@ static int build_walk_plan(qp_operator* op) {
       return QP_OK;
     }
   }
-  const int nn = ws.nn, K = ws.K, z0 = ws.z0, xl = ws.xl;
+  const int nn = ws.nn, K = ws.K, z0 = ws.z0, xl = ws.xl, fd = ws.fd, KF = ws.K * (1 + 2 * ws.fd);
   const int64_t g = ws.g;
   for (int i = 0; i < nn; ++i) P.near[i] = ws.near[i];
   const int S = (int)((g + kRB - 1) / kRB);
   // first block whose rows find their history (K g rows back, L for the long pair) inside the run
-  const int64_t W0 = R0 + (std::max<int64_t>((int64_t)K * g, ws.glong) + kRB - 1) / kRB;
+  const int64_t W0 = R0 + (std::max<int64_t>((int64_t)K * g + fd, ws.glong) + kRB - 1) / kRB;
   if (R1 - W0 < 8) return why(QP_WALK_TOO_FEW_BLOCKS, "%lld walkable row blocks after the first %lld of the run (whose history lies outside it)", R1 - W0, W0 - R0);
   // the upper section of every block of the run: z0 + nn + K entries per row, padded to a multiple of four, at equal strides
-  const int64_t wu = ((z0 + nn + K + xl + 3) / 4) * 4;
+  const int64_t wu = ((z0 + nn + KF + xl + 3) / 4) * 4;
   const int64_t U0 = Lh.bptr[R0], ustride = wu * kRB;
   for (int64_t b = R0; b <= R1; ++b)
     if (Lh.bptr[b] != U0 + (b - R0) * ustride) return why(QP_WALK_LAYOUT, "upper sections of the run are not at equal strides (block %lld)", b);
   for (int64_t r = rref; r < R1 * kRB; r += kRB)
-    if (Lh.nlow[r] != nn + K + xl) return why(QP_WALK_LAYOUT, "row %lld has %lld lower entries", r, Lh.nlow[r]);
+    if (Lh.nlow[r] != nn + KF + xl) return why(QP_WALK_LAYOUT, "row %lld has %lld lower entries", r, Lh.nlow[r]);
   if (U0 + (R1 - R0) * ustride >= (int64_t)INT32_MAX) return why(QP_WALK_LAYOUT, "value positions beyond 2^31");
   std::vector<int32_t> edge;
   for (int64_t b = 0; b < W0; ++b) edge.push_back((int32_t)b);
@@ -904,6 +913,7 @@ static int build_walk_plan(qp_operator* op) {
   P.xl = xl;
   P.glong = ws.glong;
   P.glong1 = ws.glong1;
+  P.fd = fd;
   P.R0 = R0;
   P.R1 = R1;
   P.W0 = W0;
@@ -1487,7 +1497,7 @@ static void lattice_fill(const qp::Tuning& tun, int64_t n, int64_t ncols, std::v
   for (int k = 0; k < z; ++k) D[(size_t)k] = (int64_t)uc[ur[rm] + k] - rm;
   WalkShape ws;
   if (!parse_walk_shape(D, ws)) return;
-  const int64_t reach = std::max<int64_t>((int64_t)ws.K * ws.g, ws.glong);
+  const int64_t reach = std::max<int64_t>((int64_t)ws.K * ws.g + ws.fd, ws.glong);
   const int64_t lo = reach, hi = n - reach;
   if (hi - lo < 16 * (int64_t)kRB) return;
   int64_t missing = 0;
@@ -1984,6 +1994,25 @@ int qp_operator_colblock_info(const qp_operator* op, int64_t out[6], double* lin
 int qp_operator_walk_long(const qp_operator* op, int64_t* glong) {
   if (!op || !glong) return qp::fail(QP_E_BAD_ARG, "qp_operator_walk_long: NULL argument");
   *glong = (op->walk.valid && op->A.walk == &op->walk && op->walk.xl) ? op->walk.glong : 0;
+  return QP_OK;
+}
+
+/* the whole stencil shape of the walk plan: {near distances, far reach K, diagonal entry, long pairs, diagonal far neighbours
+   (1: the far distances of step m are m g - 1, m g, m g + 1), strip step g, shorter long distance, longest distance}; zeros
+   without a plan */
+int qp_operator_walk_shape(const qp_operator* op, int64_t out[8]) {
+  if (!op || !out) return qp::fail(QP_E_BAD_ARG, "qp_operator_walk_shape: NULL argument");
+  for (int i = 0; i < 8; ++i) out[i] = 0;
+  if (!(op->walk.valid && op->A.walk == &op->walk)) return QP_OK;
+  const qp::WalkPlan& P = op->walk;
+  out[0] = P.nn;
+  out[1] = P.K;
+  out[2] = P.z0;
+  out[3] = P.xl;
+  out[4] = P.fd;
+  out[5] = P.g;
+  out[6] = P.xl == 2 ? P.glong1 : 0;
+  out[7] = P.xl ? P.glong : 0;
   return QP_OK;
 }
 

@@ -11,7 +11,9 @@ bool walk_launch_c128_hi(hipStream_t s, dim3 grid, const double2* uvals, const d
 
 // near distances 1..4 of at most 16 rows, far reach 1..4 strip steps, with or without a diagonal
 // ... and, with one or two long pairs beyond the ring (xl = 1, 2), near 1..2 and one or two far distances
-bool walk_shape_supported(int nn, int K, int z0, int xl) {
+// ... and, with diagonal far neighbours (fd = 1: m g - 1, m g, m g + 1), near 1..2 and one strip step
+bool walk_shape_supported(int nn, int K, int z0, int xl, int fd) {
+  if (fd) return fd == 1 && xl == 0 && K == 1 && nn >= 1 && nn <= 2 && (z0 == 0 || z0 == 1);
   if (xl) return (xl == 1 || xl == 2) && nn >= 1 && nn <= 2 && (K == 1 || K == 2) && (z0 == 0 || z0 == 1);
   return nn >= 1 && nn <= 4 && K >= 1 && K <= 4 && (z0 == 0 || z0 == 1);
 }
@@ -34,7 +36,7 @@ int launch_hrb_walk_cheby(hipStream_t s, const DevMatrix& A, const double2* x, c
   // ... and beyond it the matrix values are streamed nontemporally: they are read once per term, and what the
   // Infinity Cache then keeps from one term to the next is the vectors
   // (the slots the walk streams: the pad slots of the quad-padded upper sections are never read)
-  const double footprint = (double)(P->z0 + P->nn + P->K + P->xl) * kRB * (double)A.nblocks * (A.vals_r ? 8.0 : 16.0) + 64.0 * (double)A.nrows;
+  const double footprint = (double)(P->z0 + P->nn + P->K * (1 + 2 * P->fd) + P->xl) * kRB * (double)A.nblocks * (A.vals_r ? 8.0 : 16.0) + 64.0 * (double)A.nrows;
   const bool resident = footprint <= 230e6;
   // beyond it: every CU but the few the edge workgroups take (8 x (256 - 24) = 1856 for the headline lattice), so that
   // the edge blocks run BESIDE the walk there too; 2048 with the edge blocks inside the walk's wavefronts when that would
@@ -78,7 +80,9 @@ int launch_hrb_walk_cheby(hipStream_t s, const DevMatrix& A, const double2* x, c
   if (no_edges) Pl.n_edge = 0;
   const bool hi = Pl.nn >= 3 && !Pl.xl;   // which translation unit holds the shape
   const bool xlu = Pl.xl && !(Pl.xl == 1 && Pl.K == 1);
-  const bool ok = A.vals_r ? (xlu  ? walk_launch_f64_xl(s, grid, A.vals_r, x, Pl, G, H, A.nrows, op, ntm, sy)
+  const bool ok = Pl.fd ? (A.vals_r ? walk_launch_f64_fd(s, grid, A.vals_r, x, Pl, G, H, A.nrows, op, ntm, sy)
+                                    : walk_launch_c128_fd(s, grid, A.vals, x, Pl, G, H, A.nrows, op, ntm, sy))
+                  : A.vals_r ? (xlu  ? walk_launch_f64_xl(s, grid, A.vals_r, x, Pl, G, H, A.nrows, op, ntm, sy)
                               : hi ? walk_launch_f64_hi(s, grid, A.vals_r, x, Pl, G, H, A.nrows, op, ntm, sy)
                                    : walk_launch_f64_lo(s, grid, A.vals_r, x, Pl, G, H, A.nrows, op, ntm, sy))
                            : (xlu  ? walk_launch_c128_xl(s, grid, A.vals, x, Pl, G, H, A.nrows, op, ntm, sy)

@@ -200,7 +200,7 @@ __device__ __forceinline__ void hrb_edge_block(const HrbArrays& H, const VT* __r
 __device__ __forceinline__ double2 sel2(bool c, double2 a, double2 b) { return make_double2(c ? a.x : b.x, c ? a.y : b.y); }
 
 // what a step needs from memory (everything else is carried over from the steps before)
-template <int NU, int XL = 0>
+template <int NU, int XL = 0, int FD = 0>
 struct WalkStep {
   double2 ua[NU];      // the block's upper values (pads skipped)
   double2 xnew;        // x[row + K g]
@@ -210,15 +210,41 @@ struct WalkStep {
   double2 ha;          //   q = i: value (64 - d_i + t) of slot z0 + i of block b - 1
   // the long pairs (XL of them): x[row + L_p], x[row - L_p] and the conj-transposed value of the lower entry (row, row - L_p)
   double2 xlu[XL > 0 ? XL : 1], xll[XL > 0 ? XL : 1], al[XL > 0 ? XL : 1];
+  // diagonal far neighbours (FD): the elements just outside the wavefront's 64 rows at the ring's far steps -- lane e < 4 K:
+  // m = e / 4 + 1, x[r0 - 1 + m g], x[r0 + 64 + m g], x[r0 - 1 - m g], x[r0 + 64 - m g] -- and the two conj-transposed values
+  // per m that the neighbouring strip columns streamed -- lane e < 2 K: m = e / 2 + 1, rows r0 - 1 - m g (slot m g + 1) and
+  // r0 + 64 - m g (slot m g - 1)
+  double2 hxf, hvf;
 };
 
+// value of lane `src` (wave-uniform) in every lane
+__device__ __forceinline__ double2 bcast2(double2 v, int src) {
+  return make_double2(__hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v.x), src), __builtin_amdgcn_readlane(__double2loint(v.x), src)),
+                      __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v.y), src), __builtin_amdgcn_readlane(__double2loint(v.y), src)));
+}
+// the element of lane + 1 (UP = true) or lane - 1 in every lane (one DPP wavefront shift per dword); the lane without a
+// source gets `edge`
+template <bool UP>
+__device__ __forceinline__ double lane_shift1(double v) {
+  constexpr int CTRL = UP ? 0x130 : 0x138;   // wave_shl:1 (dst[i] = src[i + 1]) / wave_shr:1 (dst[i] = src[i - 1])
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <bool UP>
+__device__ __forceinline__ double2 lane_shift2(double2 v, double2 edge, int lane) {
+  const double2 t = make_double2(lane_shift1<UP>(v.x), lane_shift1<UP>(v.y));
+  const bool e = UP ? lane == 63 : lane == 0;
+  return make_double2(e ? edge.x : t.x, e ? edge.y : t.y);
+}
+
 // LDS of one wavefront, in double2 elements: the near window of x (16 + 64 + 16), NN near value windows (16 + 64) and the
-// FIFOs of the far upper values (slot m: m entries of 64)
-template <int NN, int K>
+// FIFOs of the far upper values (slot m: m entries of 64; with diagonal far neighbours, FD = 1, three slots per m)
+template <int NN, int K, int FD = 0>
 struct WalkLds {
   static constexpr int XW = kRB + 2 * kWalkHalo, AW = kRB + kWalkHalo;
   static constexpr int kHist = XW + NN * AW;
-  static constexpr int kPerWave = kHist + kRB * (K * (K + 1) / 2);
+  static constexpr int kPerWave = kHist + kRB * (1 + 2 * FD) * (K * (K + 1) / 2);
   static constexpr size_t kBytesPerWave = sizeof(double2) * (size_t)kPerWave;
 };
 
@@ -250,14 +276,22 @@ __device__ __forceinline__ void wave_sync_wait(const SyncArgs& sy) {
 // XL = 2: two such pairs, K g < L_0 < L_1 (P.glong1, P.glong) -- the fourth-order Laplacian of a three-dimensional grid
 // (+-1, +-2; +-nx, +-2 nx; +-nx ny, +-2 nx ny: near 2, far 2, long 2), next-nearest planes, a four-dimensional grid.  Lower
 // section [-L_1] [-L_0] [far] [near], upper section [diag] [near] [far] [L_0] [L_1].
-template <class VT, int NN, int K, int Z0, int NTM, int XL = 0>
+// FD = 1: DIAGONAL far neighbours -- the far distances of strip step m are m g - 1, m g, m g + 1 (the nine-point stencil of a
+// two-dimensional grid with next-nearest hopping: +-1, +-(g - 1), +-g, +-(g + 1)).  The gathered elements x[r + m g +- 1] are
+// the ring's elements of the NEIGHBOURING lanes (one DPP wavefront shift per dword; the lane at the edge takes the element
+// just outside the wavefront's rows from a packed halo load), the conj-transposed values of the lower entries are read from
+// the FIFO of their slot one lane over (the edge lane: a value the neighbouring strip column streamed, from the same halo load).
+template <class VT, int NN, int K, int Z0, int NTM, int XL = 0, int FD = 0>
 __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __restrict__ uvals,
                                                                     const double2* __restrict__ x, WalkPlan P,
                                                                     WalkGeom G, HrbArrays H, int64_t nrows, ChebyOp op,
                                                                     SyncArgs sy) {
-  constexpr int NL = XL + NN + K;         // lower slots: [-L] [-K g .. -g] [-d_NN .. -d_1]
-  constexpr int NU = Z0 + NN + K + XL;    // upper slots that carry entries: [0] [d_1 .. d_NN] [g .. K g] [L]
-  using Lds = WalkLds<NN, K>;
+  constexpr int FS = 1 + 2 * FD;          // far slots per strip step: [m g] or [m g - 1] [m g] [m g + 1]
+  constexpr int KF = K * FS;
+  constexpr int NL = XL + NN + KF;        // lower slots: [-L] [-K g .. -g] [-d_NN .. -d_1]
+  constexpr int NU = Z0 + NN + KF + XL;   // upper slots that carry entries: [0] [d_1 .. d_NN] [g .. K g] [L]
+  static_assert(FD == 0 || XL == 0, "diagonal far neighbours and long pairs are not combined");
+  using Lds = WalkLds<NN, K, FD>;
   constexpr int XW = Lds::XW, AW = Lds::AW;
   static_assert(NN <= 4, "the near value halos share one register: sixteen lanes each");
   extern __shared__ double2 walk_lds[];
@@ -313,7 +347,7 @@ __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __r
   const int hslot = Z0 + (hq < NN ? hq : NN - 1);             // ... of slot z0 + q: rows r0 - d .. r0 - 1
   // r0 = first row of the wavefront at that step.  Lanes beyond the strip (or the run) still load real data -- their
   // elements of x are the near neighbours of the last active lanes -- with the row clamped into the matrix.
-  auto load_step = [&](int64_t r0, WalkStep<NU, XL>& w) __attribute__((always_inline)) {
+  auto load_step = [&](int64_t r0, WalkStep<NU, XL, FD>& w) __attribute__((always_inline)) {
     const int64_t r = min(r0 + lane, vmax);
     const VT* __restrict__ v = uvals + vpos(r);
 #pragma unroll
@@ -323,12 +357,21 @@ __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __r
     w.acc = ld_stream<(NTM & 2) != 0>(accp ? accp + r : x + lane);
     w.hx = x[min(r0 + hoff_x, rmax)];
     w.ha = ld_val<false>(uvals + vpos(r0 - hd + min(ht, hd - 1)) + (size_t)hslot * 64);
+    if constexpr (FD != 0) {
+      const int em = min(lane >> 2, K - 1) + 1, ew = lane & 3;               // x halos: lane e -> (m, which)
+      const int64_t xrow = r0 + ((ew & 1) ? kRB : -1) + ((ew & 2) ? -(int64_t)em * g : (int64_t)em * g);
+      w.hxf = x[min(max(xrow, (int64_t)0), rmax)];
+      const int vm = min(lane >> 1, K - 1) + 1, vs = lane & 1;               // value halos: lane e -> (m, side)
+      // side 0: row r0 - 1 - m g, its entry at distance m g + 1 (slot d = 2); side 1: row r0 + 64 - m g, distance m g - 1 (d = 0)
+      const int64_t vrow = min(max(r0 + (vs ? kRB : -1) - (int64_t)vm * g, P.R0 * (int64_t)kRB), vmax);
+      w.hvf = ld_val<false>(uvals + vpos(vrow) + (size_t)(Z0 + NN + (vm - 1) * FS + (vs ? 0 : 2)) * 64);
+    }
 #pragma unroll
     for (int p = 0; p < XL; ++p) {
       const int64_t Lp = (p == XL - 1) ? P.glong : P.glong1;
       w.xlu[p] = ld_stream<(NTM & 2) != 0>(x + min(r + Lp, rmax));
       w.xll[p] = ld_stream<(NTM & 2) != 0>(x + (r - Lp));
-      w.al[p] = ld_val<false>(uvals + vpos(r - Lp) + (size_t)(Z0 + NN + K + p) * 64);
+      w.al[p] = ld_val<false>(uvals + vpos(r - Lp) + (size_t)(Z0 + NN + KF + p) * 64);
     }
   };
   // where this lane's halo elements go in the windows (lanes that carry none rewrite their own main element)
@@ -346,20 +389,23 @@ __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __r
   for (int m = -K; m < K; ++m) xr[K + m] = x[min(row0 + lane + m * g, rmax)];
   // ... and the far upper values of the K blocks behind, FIFO m in LDS: the value of t steps ago sits at entry
   // (step - t) mod m, so the entry read at a step (the value of m steps ago) is the one overwritten at that step
+  // (FIFO of far slot (m, d), d < FS: entries FS m (m - 1) / 2 + d m ... + m - 1)
 #pragma unroll
   for (int m = 1; m <= K; ++m)
 #pragma unroll
-    for (int a = 1; a <= m; ++a)
-      hring[(m * (m - 1) / 2 + (m - a)) * kRB + lane] =
-          ld_val<false>(uvals + vpos(min(row0 + lane, vmax) - (int64_t)a * g) + (size_t)(Z0 + NN + m - 1) * 64);
+    for (int d = 0; d < FS; ++d)
+#pragma unroll
+      for (int a = 1; a <= m; ++a)
+        hring[(FS * (m * (m - 1) / 2) + d * m + (m - a)) * kRB + lane] =
+            ld_val<false>(uvals + vpos(min(row0 + lane, vmax) - (int64_t)a * g) + (size_t)(Z0 + NN + (m - 1) * FS + d) * 64);
   int hpos[K];   // (wave-uniform) entry of FIFO m that this step reads and then overwrites: step mod m
 #pragma unroll
   for (int m = 1; m <= K; ++m) hpos[m - 1] = 0;
   // Two register sets that swap roles every step: while the arithmetic of a block runs out of one, the next
   // block's streams land in the other (no copies, and the wait for them sits at their first use, a whole step later).
-  WalkStep<NU, XL> wa, wb;
+  WalkStep<NU, XL, FD> wa, wb;
   load_step(row0, wa);
-  auto step = [&](const WalkStep<NU, XL>& cu, WalkStep<NU, XL>& nx, auto has_next) __attribute__((always_inline)) {
+  auto step = [&](const WalkStep<NU, XL, FD>& cu, WalkStep<NU, XL, FD>& nx, auto has_next) __attribute__((always_inline)) {
     xr[2 * K] = cu.xnew;
     if constexpr (decltype(has_next)::value) load_step(row0 + g, nx);
     // ---- near windows through LDS: element e of the block's window sits at [kWalkHalo + e], e = -16 .. 79
@@ -378,9 +424,25 @@ __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __r
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // every operand that comes out of LDS first (independent reads, one wait), then the arithmetic
-    double2 fa[K], na[NN], nxl[NN], nxu[NN];
+    double2 fa[KF], na[NN], nxl[NN], nxu[NN];
 #pragma unroll
-    for (int m = 1; m <= K; ++m) fa[m - 1] = hring[(m * (m - 1) / 2 + hpos[m - 1]) * kRB + lane];
+    for (int m = 1; m <= K; ++m)
+#pragma unroll
+      for (int d = 0; d < FS; ++d) {
+        // the value streamed m steps ago for the row that is this row's partner: the same lane (d = middle), or one lane over
+        // for a diagonal partner (row - m g - delta, delta = d - 1: lane - delta; the edge lane is fixed up below)
+        const int sl = FD ? min(max(lane - (d - 1), 0), kRB - 1) : lane;
+        fa[(m - 1) * FS + d] = hring[(FS * (m * (m - 1) / 2) + d * m + hpos[m - 1]) * kRB + sl];
+      }
+    if constexpr (FD != 0) {
+#pragma unroll
+      for (int m = 1; m <= K; ++m) {
+        const double2 v0h = bcast2(cu.hvf, 2 * (m - 1));       // row r0 - 1 - m g, distance m g + 1: partner of lane 0
+        const double2 v1h = bcast2(cu.hvf, 2 * (m - 1) + 1);   // row r0 + 64 - m g, distance m g - 1: partner of lane 63
+        fa[(m - 1) * FS + 2] = sel2(lane == 0, v0h, fa[(m - 1) * FS + 2]);
+        fa[(m - 1) * FS + 0] = sel2(lane == kRB - 1, v1h, fa[(m - 1) * FS + 0]);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NN; ++i) {
       const int d = P.near[i];
@@ -396,12 +458,22 @@ __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __r
       if (l < XL) {
         a = cu.al[XL - 1 - l];
         xv = cu.xll[XL - 1 - l];
-      } else if (l < XL + K) {
-        const int m = K - (l - XL);
-        a = fa[m - 1];
-        xv = xr[K - m];
+      } else if (l < XL + KF) {
+        // storage order: distance descending -- m = K .. 1 and inside a strip step m g + 1, m g, m g - 1 (d = 2, 1, 0)
+        const int f = l - XL;
+        const int m = K - f / FS;
+        const int d = FS - 1 - f % FS;
+        a = fa[(m - 1) * FS + d];
+        if constexpr (FD != 0) {
+          // column r - m g - delta, delta = d - 1: the ring element m steps back, one lane to the left (delta = +1) / right
+          if (d == 2) xv = lane_shift2<false>(xr[K - m], bcast2(cu.hxf, 4 * (m - 1) + 2), lane);       // x[r0 - 1 - m g] for lane 0
+          else if (d == 0) xv = lane_shift2<true>(xr[K - m], bcast2(cu.hxf, 4 * (m - 1) + 3), lane);   // x[r0 + 64 - m g] for lane 63
+          else xv = xr[K - m];
+        } else {
+          xv = xr[K - m];
+        }
       } else {
-        const int i = NN - 1 - (l - XL - K);
+        const int i = NN - 1 - (l - XL - KF);
         a = na[i];
         xv = nxl[i];
       }
@@ -414,8 +486,18 @@ __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __r
       double2 xv;
       if (u < Z0) xv = xr[K];
       else if (u < Z0 + NN) xv = nxu[u - Z0];
-      else if (u < Z0 + NN + K) xv = xr[K + (u - Z0 - NN + 1)];
-      else xv = cu.xlu[u - (Z0 + NN + K) < 0 ? 0 : u - (Z0 + NN + K)];
+      else if (u < Z0 + NN + KF) {
+        const int f = u - Z0 - NN;
+        const int m = f / FS + 1;
+        if constexpr (FD != 0) {
+          const int d = f % FS;   // distance m g + (d - 1)
+          if (d == 0) xv = lane_shift2<false>(xr[K + m], bcast2(cu.hxf, 4 * (m - 1) + 0), lane);      // x[r0 - 1 + m g] for lane 0
+          else if (d == 2) xv = lane_shift2<true>(xr[K + m], bcast2(cu.hxf, 4 * (m - 1) + 1), lane);   // x[r0 + 64 + m g] for lane 63
+          else xv = xr[K + m];
+        } else {
+          xv = xr[K + m];
+        }
+      } else xv = cu.xlu[u - (Z0 + NN + KF) < 0 ? 0 : u - (Z0 + NN + KF)];
       if (u & 1) cfma(s1, cu.ua[u], xv);
       else cfma(s0, cu.ua[u], xv);
     }
@@ -433,7 +515,8 @@ __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __r
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
     for (int m = 1; m <= K; ++m) {
-      hring[(m * (m - 1) / 2 + hpos[m - 1]) * kRB + lane] = cu.ua[Z0 + NN + m - 1];
+#pragma unroll
+      for (int d = 0; d < FS; ++d) hring[(FS * (m * (m - 1) / 2) + d * m + hpos[m - 1]) * kRB + lane] = cu.ua[Z0 + NN + (m - 1) * FS + d];
       hpos[m - 1] = (hpos[m - 1] + 1 == m) ? 0 : hpos[m - 1] + 1;
     }
 #pragma unroll
@@ -459,13 +542,13 @@ __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __r
   }
 }
 
-template <class VT, int NN, int K, int Z0, int NTM = 0, int XL = 0>
+template <class VT, int NN, int K, int Z0, int NTM = 0, int XL = 0, int FD = 0>
 static bool launch_instance(hipStream_t s, dim3 grid, const VT* uvals, const double2* x, const WalkPlan& P,
                             const WalkGeom& G, const HrbArrays& H, int64_t nrows, const ChebyOp& op, const SyncArgs& sy) {
   const int ws = G.ntask / std::max(G.n_walk_wg, 1);      // wavefronts per workgroup of this launch
-  const size_t lds = WalkLds<NN, K>::kBytesPerWave * (size_t)ws;
-  constexpr size_t lds_max = WalkLds<NN, K>::kBytesPerWave * kWalkWaves;
-  auto kern = &hrb_walk_kernel<VT, NN, K, Z0, NTM, XL>;
+  const size_t lds = WalkLds<NN, K, FD>::kBytesPerWave * (size_t)ws;
+  constexpr size_t lds_max = WalkLds<NN, K, FD>::kBytesPerWave * kWalkWaves;
+  auto kern = &hrb_walk_kernel<VT, NN, K, Z0, NTM, XL, FD>;
   // more than the 64 KB a launch gets without asking: opt in once per kernel instance AND device (a process may hold
   // contexts on several GPUs); 0 = not tried, 1 = granted, 2 = refused (the caller then takes the per-block kernel)
   static std::atomic<unsigned char> opted[64];
@@ -483,13 +566,31 @@ static bool launch_instance(hipStream_t s, dim3 grid, const VT* uvals, const dou
 }
 
 // The kernel shapes are spread over translation units: PART 0 = near 3-4, PART 1 = near 1-2 and the shapes with one long pair and
-// one far distance, PART 2 = the other long-pair shapes (two far distances, two long pairs), each
+// one far distance, PART 2 = the other long-pair shapes (two far distances, two long pairs), PART 3 = the shapes with diagonal far neighbours, each
 // for complex values (double2) and for the real copy (double).  The measurement variants of the headline shape (matrix loads
 // temporal / nontemporal in other mixes: ntm 3, 5, 7) exist in developer builds only (-DQP_DEVELOPER).
 template <class VT, int PART>
 static bool launch_shape(hipStream_t s, dim3 grid, const VT* uvals, const double2* x, const WalkPlan& P,
                          const WalkGeom& G, const HrbArrays& H, int64_t nrows, const ChebyOp& op, int ntm, const SyncArgs& sy) {
   const int key = P.nn * 100 + P.K * 10 + P.z0;
+  if (P.fd) {   // diagonal far neighbours (nine-point stencils): near 1 or 2, one strip step (PART 3)
+    if constexpr (PART == 3) {
+#define QP_WALK_FD(NN_, Z0_)                                                                                          \
+  return (ntm & 1) ? launch_instance<VT, NN_, 1, Z0_, 1, 0, 1>(s, grid, uvals, x, P, G, H, nrows, op, sy)              \
+                   : launch_instance<VT, NN_, 1, Z0_, 0, 0, 1>(s, grid, uvals, x, P, G, H, nrows, op, sy);
+      if (P.xl != 0 || P.K != 1) return false;
+      switch (key) {
+        case 110: QP_WALK_FD(1, 0)
+        case 111: QP_WALK_FD(1, 1)
+        case 210: QP_WALK_FD(2, 0)
+        case 211: QP_WALK_FD(2, 1)
+        default: return false;
+      }
+#undef QP_WALK_FD
+    }
+    return false;
+  }
+  if constexpr (PART == 3) return false;
   if (P.xl) {   // long pairs: near 1 or 2, far 1 or 2, one or two pairs (three-dimensional grids; PART 1: one pair and one far distance, PART 2: the rest)
 #define QP_WALK_XL(NN_, K_, Z0_, XL_)                                                                              \
   return (ntm & 1) ? launch_instance<VT, NN_, K_, Z0_, 1, XL_>(s, grid, uvals, x, P, G, H, nrows, op, sy)           \
@@ -564,7 +665,7 @@ static bool launch_shape(hipStream_t s, dim3 grid, const VT* uvals, const double
 #undef QP_WALK_SHAPE
 }
 
-// the six translation units' entry points (uvals: double2* for _c128_*, double* for _f64_*)
+// the eight translation units' entry points (uvals: double2* for _c128_*, double* for _f64_*)
 bool walk_launch_c128_hi(hipStream_t s, dim3 grid, const double2* uvals, const double2* x, const WalkPlan& P, const WalkGeom& G,
                          const HrbArrays& H, int64_t nrows, const ChebyOp& op, int ntm, const SyncArgs& sy);
 bool walk_launch_c128_lo(hipStream_t s, dim3 grid, const double2* uvals, const double2* x, const WalkPlan& P, const WalkGeom& G,
@@ -576,6 +677,10 @@ bool walk_launch_f64_lo(hipStream_t s, dim3 grid, const double* uvals, const dou
 bool walk_launch_c128_xl(hipStream_t s, dim3 grid, const double2* uvals, const double2* x, const WalkPlan& P, const WalkGeom& G,
                          const HrbArrays& H, int64_t nrows, const ChebyOp& op, int ntm, const SyncArgs& sy);
 bool walk_launch_f64_xl(hipStream_t s, dim3 grid, const double* uvals, const double2* x, const WalkPlan& P, const WalkGeom& G,
+                        const HrbArrays& H, int64_t nrows, const ChebyOp& op, int ntm, const SyncArgs& sy);
+bool walk_launch_c128_fd(hipStream_t s, dim3 grid, const double2* uvals, const double2* x, const WalkPlan& P, const WalkGeom& G,
+                         const HrbArrays& H, int64_t nrows, const ChebyOp& op, int ntm, const SyncArgs& sy);
+bool walk_launch_f64_fd(hipStream_t s, dim3 grid, const double* uvals, const double2* x, const WalkPlan& P, const WalkGeom& G,
                         const HrbArrays& H, int64_t nrows, const ChebyOp& op, int ntm, const SyncArgs& sy);
 
 }  // namespace qp

@@ -138,6 +138,7 @@ SIGNATURES = {
     "qp_operator_walk_long": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "qp_operator_walk_reason": (C.c_int, [_P, C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
     "qp_operator_walk_long_pairs": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "qp_operator_walk_shape": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "qp_operator_encoding_info": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "qp_operator_evaluate_info": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "qp_operator_colblock_info": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
@@ -572,6 +573,10 @@ class Operator:
         lp = np.zeros(2, dtype=np.int64)
         check(self.lib.qp_operator_walk_long_pairs(self._h, _ptr(lp, _i64p)))
         d["long_distances"] = [int(v) for v in lp if v]      # [] / [L] / [L_0, L_1] (fourth-order stencils, four-dimensional grids)
+        sh = np.zeros(8, dtype=np.int64)
+        check(self.lib.qp_operator_walk_shape(self._h, _ptr(sh, _i64p)))
+        d["far_diagonals"] = int(sh[4])      # 1: every far distance m g comes with m g - 1 and m g + 1 (nine-point stencils)
+        d["upper_slots"] = int(sh[2] + sh[0] + sh[1] * (1 + 2 * sh[4]) + sh[3])   # value slots a walked row block streams
         return d
 
     def evaluate_info(self):

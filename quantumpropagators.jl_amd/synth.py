@@ -128,10 +128,10 @@ def hermitian_offsets_csr(N, offsets=BANDED_OFFSETS, rho=10.0, seed=DEFAULT_SEED
     return rowptr, col.reshape(-1), vals.reshape(-1)
 
 
-def grid_hamiltonian_2d(nx, ny, flux=0.0, next_nearest=False, seed=DEFAULT_SEED):
+def grid_hamiltonian_2d(nx, ny, flux=0.0, next_nearest=False, seed=DEFAULT_SEED, diagonal=0.0):
     """Finite-difference Hamiltonian of a particle on an nx x ny grid with OPEN boundaries (row = x + nx y): hopping -1 to
     the four neighbours (Peierls phase exp(i flux y) on the x-hops when flux != 0, so the couplings are complex), optionally
-    -1/4 to the second neighbours along x, and a smooth potential on the diagonal.  The rows at the x-edges of the grid lack
+    -1/4 to the second neighbours along x, -`diagonal` to the four diagonal neighbours, and a smooth potential on the diagonal.  The rows at the x-edges of the grid lack
     a neighbour -- the lattice with holes that operator creation completes (include/qprop.h: qp_operator_fill_info).
     Returns scipy CSR (sorted indices)."""
     import scipy.sparse as sp
@@ -153,6 +153,9 @@ def grid_hamiltonian_2d(nx, ny, flux=0.0, next_nearest=False, seed=DEFAULT_SEED)
     hop(Y < ny - 1, nx, np.complex128(-1.0))
     if next_nearest:
         hop(X < nx - 2, 2, -0.25 * phase * phase)
+    if diagonal:      # t' hopping to the four diagonal neighbours: distances +-(nx - 1), +-(nx + 1) -- the nine-point stencil
+        hop((X < nx - 1) & (Y < ny - 1), nx + 1, -diagonal * phase)
+        hop((X > 0) & (Y < ny - 1), nx - 1, -diagonal * np.conj(phase))
     with np.errstate(over="ignore"):
         jitter = _u01(splitmix64(np.uint64(seed) ^ (idx.astype(np.uint64) * _GOLDEN)))
     pot = 0.5 * ((X - nx / 2) / nx) ** 2 + 0.5 * ((Y - ny / 2) / ny) ** 2

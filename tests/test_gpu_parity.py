@@ -1004,6 +1004,66 @@ def test_strip_walk_two_long_pairs_and_two_far_distances(ctx, case):
     assert np.linalg.norm(base - ref) < TOL
 
 
+@pytest.mark.parametrize("case", ["uniform_256", "uniform_100_no_diag", "uniform_real_two_near", "grid_96x50_tprime", "grid_128x40_tprime_real"])
+def test_strip_walk_diagonal_far_neighbours(ctx, case):
+    """Far distances with their diagonal neighbours, g - 1, g, g + 1 (nine-point stencil: next-nearest hopping on a two-dimensional
+    grid): the gathered elements are the ring's elements one lane over (a DPP wavefront shift, the edge lane from a packed halo
+    load), the conj-transposed values come out of the FIFO one lane over.  Bit-identical to the per-block kernel for several
+    partitions of the walk (strip steps that are no multiple of 64 rows included), within 1e-10 of the oracle."""
+    if case.startswith("grid"):
+        nx, ny = (96, 50) if "96x50" in case else (128, 40)
+        H = synth.grid_hamiltonian_2d(nx, ny, flux=0.0 if "real" in case else 0.2, diagonal=0.3)
+        N = H.shape[0]
+        Delta, Emin = 12.0, -1.0
+        want = dict(near=1, diag=1, step=nx)
+    else:
+        N = 1 << 15
+        offs, want = {"uniform_256": ((1, 255, 256, 257), dict(near=1, diag=1, step=256)),
+                      "uniform_100_no_diag": ((3, 99, 100, 101), dict(near=1, diag=0, step=100)),
+                      "uniform_real_two_near": ((1, 2, 511, 512, 513), dict(near=2, diag=1, step=512))}[case]
+        rp, col, vals = synth.hermitian_offsets_csr(N, offsets=offs)
+        if "real" in case:
+            vals = vals.real.astype(np.complex128)
+        H = synth.to_scipy(rp, col, vals, N)
+        if want["diag"]:
+            H = sp.csr_matrix(H + sp.diags(np.linspace(-1.0, 1.0, N)).astype(np.complex128))
+        H.sort_indices()
+        Delta, Emin = 24.0, -12.0
+    psi0 = synth.random_state(N)
+    saved = {k: ctx.tuning_get(k) for k in WALK_KNOBS}
+    try:
+        ctx.tuning_set("walk_min_blocks", 16)
+        Op = L.Operator(ctx, [L.Matrix.from_scipy(ctx, H)])
+        assert Op.format == L.FMT_HRB and Op.walk_reason()[1] == "ok"
+        wi = Op.walk_info()
+        assert wi["valid"] == 1 and wi["far_diagonals"] == 1 and wi["far"] == 1
+        assert (wi["near"], wi["diag"], wi["rows_per_step"]) == (want["near"], want["diag"], want["step"])
+        if case.startswith("grid"):
+            assert Op.fill_info() > 0
+        wrk = L.ChebyWrk(ctx, N, Delta, Emin, 0.6)
+
+        def run(**knobs):
+            for k, v in {**WALK_DEFAULTS, "walk_min_blocks": 16, **knobs}.items():
+                ctx.tuning_set(k, v)
+            psi = L.State(ctx, data=psi0)
+            for dt in (0.6, -0.6, 0.6):
+                L.cheby(psi, Op, dt, wrk)
+            return psi.numpy()
+
+        base = run(hrb_walk=0)
+        for knobs in (dict(), dict(walk_waves=64), dict(walk_waves=1024), dict(walk_dbg=4), dict(walk_dbg=5, walk_waves=256),
+                      dict(walk_nt=1), dict(walk_wg=8), dict(walk_wg=2, walk_waves=96)):
+            assert np.array_equal(base, run(**knobs)), knobs
+    finally:
+        for k, v in saved.items():
+            ctx.tuning_set(k, v)
+    owrk = qo.ChebyWrk(psi0, Delta, Emin, 0.6)
+    ref = psi0.copy()
+    for dt in (0.6, -0.6, 0.6):
+        qo.cheby(ref, H, dt, owrk)
+    assert np.linalg.norm(base - ref) < TOL
+
+
 def test_strip_walk_inside_a_replayed_graph(ctx):
     """Knob `cheby_graph` with an operator that takes the strip walk: the walk's launch (dynamic LDS above 64 KB, opted in
     per kernel instance and device) is captured and replayed like any other; same bits as the eager step, and the graph is
@@ -2068,8 +2128,13 @@ def test_walk_reason_says_what_broke_the_plan(ctx):
         op, r = reason((1, 2, 256, 512, 2000, 4000))               # the thirteen-point stencil of a three-dimensional grid
         wi = op.walk_info()
         assert r[1] == "ok" and wi["near"] == 2 and wi["far"] == 2 and wi["long_distances"] == [2000, 4000]
-        op, r = reason((1, 255, 256, 257))                         # nine-point stencil with diagonal neighbours: per-block kernel
+        op, r = reason((1, 255, 256, 257))                         # nine-point stencil with diagonal neighbours: walks (round 4)
+        wi = op.walk_info()
+        assert r[1] == "ok" and wi["far_diagonals"] == 1 and wi["far"] == 1 and wi["rows_per_step"] == 256 and wi["upper_slots"] == 4
+        op, r = reason((1, 256, 257))                              # one diagonal neighbour only, read as a long pair beside the ring: per-block kernel
         assert r[1] == "no_kernel_instance" and "diagonal neighbour" in r[2] and op.walk_info()["valid"] == 0
+        op, r = reason((1, 2, 3, 255, 256, 257))
+        assert r[1] == "no_kernel_instance" and "diagonal far neighbours" in r[2]
         op, r = reason((1, 256, 600, 1000, 1500))
         assert r[1] == "incommensurate_strides" and "256" in r[2]
         op, r = reason((1, 2, 3))

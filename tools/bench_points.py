@@ -157,7 +157,7 @@ def cheby_layout_bytes(op, rows, ncols, nnz, coeffs, real_copy=False):
             share = walk["edge_blocks"] / max(lay["blocks"], 1)
             index *= share
             # ... and reads the slots that carry entries, not the pad slots of the quad-padded sections
-            slots = walk["diag"] + walk["near"] + walk["far"] + len(walk.get("long_distances", []))
+            slots = walk.get("upper_slots") or (walk["diag"] + walk["near"] + walk["far"] + len(walk.get("long_distances", [])))
             stored = 64.0 * slots * (walk["end_block"] - walk["first_block"]) + lay["stored"] * share
         matrix = vbytes * stored + index
     sched = L.acc_schedule(coeffs)

@@ -45,6 +45,12 @@ def main():
             if rng.integers(0, 2):           # two pairs: the double of the first (a fourth-order stencil's second plane) or anything beyond it
                 lo = (L0, 2 * L0 if rng.integers(0, 2) else L0 + int(rng.integers(1, 9 * g)))
             offsets = tuple(near) + tuple(g * m for m in range(1, K + 1)) + lo
+        elif rng.integers(0, 6) == 0:        # diagonal far neighbours: g - 1, g, g + 1 (nine-point stencils), near <= 2, g >= 65
+            nn, K = min(nn, 2), 1
+            near = near[:nn]
+            g = max(g, 65)
+            N = g * nsteps + int(rng.choice([0, 0, 64, 1, 37, 200]))
+            offsets = tuple(near) + (g - 1, g, g + 1)
         if 2 * max(offsets) >= N or N > (1 << 18):
             continue
         nterms = int(rng.integers(1, 4))

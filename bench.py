@@ -829,6 +829,7 @@ def main():
                              ("grid_2048x2048_five_point_open_boundaries", dict(grid=(2048, 2048), steps=5)),
                              ("grid_256x128x128_seven_point_open_boundaries", dict(grid=(256, 128, 128), steps=4)),
                              ("grid_256x128x128_thirteen_point_two_long_pairs", dict(grid=(256, 128, 128), grid_order=4, steps=4)),
+                             ("nine_point_diagonal_neighbours_N_2^22", dict(offsets=(1, 2047, 2048, 2049), log2n=22, steps=5)),
                              ("tfim_20_spins_qubit_register_hamiltonian", dict(spins=20, steps=5))):
                 try:
                     extras[name] = bp.measure_cheby(ctx, **kw)

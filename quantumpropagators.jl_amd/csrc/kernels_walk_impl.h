@@ -352,7 +352,9 @@ __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __r
     const VT* __restrict__ v = uvals + vpos(r);
 #pragma unroll
     for (int u = 0; u < NU; ++u) w.ua[u] = ld_val<(NTM & 1) != 0>(v + (size_t)u * 64);
-    w.xnew = ld_stream<(NTM & 2) != 0>(x + min(r + K * g, rmax));
+    // (the row of the gathered element is NOT clamped into the run: with diagonal far neighbours the last row of the run reads
+    // the ring element of the lane beside it, which must be the true x[row + 1 + K g] -- only the matrix' last column clamps)
+    w.xnew = ld_stream<(NTM & 2) != 0>(x + min(r0 + lane + K * g, rmax));
     w.v0 = ld_stream<(NTM & 2) != 0>(v0p ? v0p + r : x + lane);
     w.acc = ld_stream<(NTM & 2) != 0>(accp ? accp + r : x + lane);
     w.hx = x[min(r0 + hoff_x, rmax)];
@@ -397,7 +399,7 @@ __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __r
 #pragma unroll
       for (int a = 1; a <= m; ++a)
         hring[(FS * (m * (m - 1) / 2) + d * m + (m - a)) * kRB + lane] =
-            ld_val<false>(uvals + vpos(min(row0 + lane, vmax) - (int64_t)a * g) + (size_t)(Z0 + NN + (m - 1) * FS + d) * 64);
+            ld_val<false>(uvals + vpos(min(row0 + lane - (int64_t)a * g, vmax)) + (size_t)(Z0 + NN + (m - 1) * FS + d) * 64);   // (the HISTORY row is clamped into the run, not the lane's own: with diagonal neighbours the last row of the run reads the lane beside it)
   int hpos[K];   // (wave-uniform) entry of FIFO m that this step reads and then overwrites: step mod m
 #pragma unroll
   for (int m = 1; m <= K; ++m) hpos[m - 1] = 0;

@@ -202,7 +202,7 @@ def pattern_csr(pattern, N, row_begin=0, row_end=None):
 
 
 def measure_cheby(ctx, pattern="banded", log2n=20, fmt="auto", steps=10, warmup=2, real=False, dt=1.0, grid=None, repeats=3,
-                  grid_order=2, spins=None):
+                  grid_order=2, spins=None, offsets=None):
     """Cheby prop_step! on one GPU for a pattern / size / device format; per-term time from HIP events on
     the kernels' stream -- the MEDIAN of `repeats` timed regions of `steps` steps, with min, max and an `unstable` flag --;
     layout-byte and CSR-equivalent rates.  grid = (nx, ny): the finite-difference Hamiltonian of an
@@ -228,6 +228,10 @@ def measure_cheby(ctx, pattern="banded", log2n=20, fmt="auto", steps=10, warmup=
         pattern = f"five-point grid {grid[0]} x {grid[1]}, open boundaries"
         rp, col, vals = Hg.indptr.astype(np.int64), Hg.indices.astype(np.int32), Hg.data.astype(np.complex128)
         del Hg
+    elif offsets:                 # a translation-invariant Hermitian lattice with these column distances
+        N = 1 << log2n
+        rp, col, vals = synth.hermitian_offsets_csr(N, offsets=tuple(offsets))
+        pattern = f"lattice with distances +-{tuple(offsets)}"
     else:
         N = 1 << log2n
         rp, col, vals = pattern_csr(pattern, N)

@@ -10,3 +10,4 @@ timeout 1500 python tools/fuzz_walk.py 500 31 > gpurun_out/fz/fuzz_walk_long_pai
 timeout 900 python tools/fuzz_liouville.py > gpurun_out/fz/fuzz_liouville.txt 2>&1; tail -1 gpurun_out/fz/fuzz_liouville.txt
 timeout 900 python tools/fuzz_dense.py 400 3 > gpurun_out/fz/fuzz_dense.txt 2>&1; tail -1 gpurun_out/fz/fuzz_dense.txt
 timeout 900 python tools/fuzz_colblock.py 300 5 > gpurun_out/fz/fuzz_colblock.txt 2>&1; tail -1 gpurun_out/fz/fuzz_colblock.txt
+timeout 1500 python tools/fuzz_walk.py 400 123 4 > gpurun_out/fz/fuzz_walk_diagonals_and_long_pairs.txt 2>&1; tail -1 gpurun_out/fz/fuzz_walk_diagonals_and_long_pairs.txt

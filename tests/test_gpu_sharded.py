@@ -142,14 +142,14 @@ def test_sharded_overlap_machinery_world1(pg, overlap, split_mode):
 
 @pytest.mark.parametrize("split_mode,offsets", [(2, (1, 2, 3, 4, 256, 512, 768, 1024)), (1, (1, 2, 3, 4, 256, 512, 768, 1024)),
                                                 (0, (1, 2, 3, 4, 256, 512, 768, 1024)), (2, (1, 2, 3, 4, 250, 500, 750, 1000)),
-                                                (2, (1, 1000)), (2, "grid")],
-                         ids=["mode2", "mode1", "mode0", "g250", "five_point_g1000", "open_grid_128x1024"])
+                                                (2, (1, 1000)), (2, "grid"), (2, (1, 2, 300, 600, 5000, 10000)), (2, (1, 999, 1000, 1001))],
+                         ids=["mode2", "mode1", "mode0", "g250", "five_point_g1000", "open_grid_128x1024", "two_long_pairs", "diagonal_far_neighbours"])
 def test_split_interior_as_strip_walk_world1(pg, split_mode, offsets):
     """A lattice operator's interior launch takes the strip walk (kernels_walk.hip) over the interior blocks from which no
     walked block reaches a boundary row; the rest of the interior are its edge blocks, the only ones that wait for the
     boundary launch.  One rank with a forced send set (first and last 4096 rows, like config C4's halo): every hand-off
     mode gives the bits of the serial schedule -- which walks the whole operator -- and of the per-block kernels; also for
-    strip steps that are no multiple of the 64-row block."""
+    strip steps that are no multiple of the 64-row block, and for the round-4 shapes (two long pairs; diagonal far neighbours)."""
     import torch
     from oracle import qp_oracle as qo
     import qprop_amd.lib as L

@@ -6,12 +6,17 @@
 // Hamiltonian in a configuration basis) defeats them: every gathered x[col] is its own 128-byte line, the vector
 // (16 MB at N = 2^20) does not fit the 4 MB of L2 an XCD owns, and the term runs at the rate the Infinity Cache serves
 // single lines -- 233 us per term for 16 random columns per row at N = 2^20 (profiles/r03), 0.21 of the HBM roofline.
+// Measured with the mirror (profiles/r04/colblock.txt, colblock_pmc.txt): 174 us at 2^20, 354 (569) at 2^21, 835 (1265) at
+// 2^22; the L2 hit rate goes from 0.30 to 0.76-0.89 and the mean request latency from 794 to 440 cycles.  The floor is the
+// L2's request rate: a 16-byte gather costs a whole line request, no CU can reuse a line, and ~20 M requests per term pass
+// at ~7 per clock and XCD.
 //
 // Here the SAME entries are grouped by (row tile, column block) and the launch walks the column blocks in its OUTER loop:
 //   * every wavefront of the launch is resident from the first cycle (the grid is sized to the chip) and owns its row tiles
 //     -- 64 rpt rows each, `tpw` of them -- for the whole launch, row sums in registers;
 //   * phase c: every wavefront processes the segments (own tile, block c).  All gathers of the whole chip fall into ONE
-//     window of 2^log2w elements of x (2 MB): every XCD's L2 loads the window once and serves the rest as hits;
+//     window of 2^log2w elements of x (1-4 MB: about sixteen blocks, engine_core.hip build_colblock): every XCD's L2 loads
+//     the window once and serves the rest as hits;
 //   * inside a segment the entries are read one per lane (coalesced, nontemporal: the matrix is read exactly once per
 //     launch), multiplied with the gathered element, and the products staged in the wavefront's own LDS buffer; then lane r
 //     adds up the products of its rows in storage order (ascending column, as the CSR kernels do).  No workgroup barrier:

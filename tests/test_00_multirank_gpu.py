@@ -87,7 +87,8 @@ def test_c4_full_size_eight_ranks_one_gpu():
 def test_c4_full_size_eight_ranks_allgather_form_one_gpu():
     """The same size in the ALL-GATHER form (the collective BASELINE's north_star names): a scattered H whose send list is every
     rank's whole 2^21-row slice, 32 MiB per rank and term through the exchange; the state after one step against the C
-    oracle at full size (computed once, on rank 0), norm and forward / backward round trip."""
+    oracle at full size (computed once, on rank 0), norm and forward / backward round trip.  (dt = 0.1, 11 coefficients:
+    each term of this form moves 256 MB through the host-staged exchange.)"""
     outs = _run(8, timeout=1500, QP_METHOD="c4-allgather")
     assert all("c4-allgather N=2^24" in o and "exchange=allgather" in o and f"M={1 << 21}" in o for o in outs)
 

@@ -275,9 +275,21 @@ def run_c5(args, world, rank, local_rank, one_gpu, dist, L, synth, bp):
                         "note": "per GPU (slowest rank): bytes the shipped step must move per fused term (matrix once, this GPU's "
                                 "share of the panel streams) / average launch duration from HIP events on the kernels' stream"},
            "cpu_baseline": None, "max_norm_drift": drift}
+    # HBM traffic of the panel kernel (this line carried "traffic": null): the same child-process PMC
+    # passes as the headline, on rank 0 of a single-GPU run, for the panel width this run's GPUs see
+    if rank == 0 and world == 1 and not args.no_pmc and args.batch == 64 and log2n == 18:
+        bs.close()
+        bs = None
+        tr, det = pmc_traffic(["--point", "c5", "--steps", "2"], "spmm_rows_smem_kernel", timeout_s=240, how="mean")
+        rfl = out["roofline"]
+        rfl["traffic"] = tr
+        rfl["traffic_source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of `bench.py --point c5`, "
+                                 "FETCH_SIZE x 2 (gfx950), mean per launch") if tr is not None else f"not measured: {det}"
+        rfl["traffic_over_layout_bytes"] = (tr / lay) if tr else None
     if rank == 0:
         print(json.dumps(out))
-    bs.close()
+    if bs is not None:
+        bs.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -899,7 +899,19 @@ def _warn_if_off_the_walk(H):
         code, name, text = H.walk_reason()
     except Exception:       # an information query must never take a step down
         return
-    if name not in ("ok", "not_hermitian", "too_few_blocks", "disabled"):
+    if name in ("ok", "not_hermitian", "too_few_blocks", "disabled"):
+        return
+    try:
+        # an operator that is no lattice at all but has a fast path of its own has nothing to be told: irregular columns take
+        # the column-blocked mirror, a qubit-register Hamiltonian (row XOR mask) the block-map encoding of its row blocks
+        if H.colblock_info()["valid"]:
+            return
+        enc = H.encoding_info()["upper"]
+        if name in ("not_packed", "no_uniform_run") and enc["block_map"] > 0 and enc["int32"] + enc["int16"] == 0:
+            return
+    except Exception:
+        pass
+    if True:
         import warnings
         warnings.warn(f"cheby!: this operator does not take the strip walk [{name}]: {text}", QPPerformanceWarning, stacklevel=3)
 

@@ -770,6 +770,13 @@ static int walk_shape_reason(const std::vector<int64_t>& dl, WalkShape& w, std::
     w.g = -dl[1];
     w.K = 1;
     w.fd = 1;
+  } else if (nbig == 4 && dl[1] + 1 == dl[2] && dl[2] + 1 == dl[3] && -dl[3] >= (int64_t)kRB && -dl[0] > -dl[1] + qp::kWalkHalo) {
+    // ... and one long pair beyond them: layers of such planes (+-nx ny)
+    w.g = -dl[2];
+    w.K = 1;
+    w.fd = 1;
+    w.xl = 1;
+    w.glong = -dl[0];
   } else if (nbig <= 4 && multiples(0, nbig)) {
     w.K = nbig;
   } else if (nbig >= 2 && nbig <= 5 && multiples(1, nbig - 1) && -dl[0] > (int64_t)(nbig - 1) * w.g) {
@@ -809,7 +816,7 @@ static int walk_shape_reason(const std::vector<int64_t>& dl, WalkShape& w, std::
     }
   }
   if (w.fd && !qp::walk_shape_supported(w.nn, w.K, w.z0, w.xl, w.fd)) {
-    say("no kernel instance for %lld near distances beside diagonal far neighbours (they come with at most 2 near)", w.nn);
+    say("no kernel instance for %lld near distances beside diagonal far neighbours (they come with at most 2 near and one long pair)", w.nn);
     return QP_WALK_NO_KERNEL;
   }
   if (!w.fd && !qp::walk_shape_supported(w.nn, w.K, w.z0, w.xl)) {

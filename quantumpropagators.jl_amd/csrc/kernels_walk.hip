@@ -11,9 +11,9 @@ bool walk_launch_c128_hi(hipStream_t s, dim3 grid, const double2* uvals, const d
 
 // near distances 1..4 of at most 16 rows, far reach 1..4 strip steps, with or without a diagonal
 // ... and, with one or two long pairs beyond the ring (xl = 1, 2), near 1..2 and one or two far distances
-// ... and, with diagonal far neighbours (fd = 1: m g - 1, m g, m g + 1), near 1..2 and one strip step
+// ... and, with diagonal far neighbours (fd = 1: m g - 1, m g, m g + 1), near 1..2, one strip step and at most one long pair
 bool walk_shape_supported(int nn, int K, int z0, int xl, int fd) {
-  if (fd) return fd == 1 && xl == 0 && K == 1 && nn >= 1 && nn <= 2 && (z0 == 0 || z0 == 1);
+  if (fd) return fd == 1 && (xl == 0 || xl == 1) && K == 1 && nn >= 1 && nn <= 2 && (z0 == 0 || z0 == 1);
   if (xl) return (xl == 1 || xl == 2) && nn >= 1 && nn <= 2 && (K == 1 || K == 2) && (z0 == 0 || z0 == 1);
   return nn >= 1 && nn <= 4 && K >= 1 && K <= 4 && (z0 == 0 || z0 == 1);
 }

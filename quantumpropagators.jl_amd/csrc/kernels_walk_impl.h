@@ -290,7 +290,7 @@ __global__ __launch_bounds__(64 * kWalkWaves) void hrb_walk_kernel(const VT* __r
   constexpr int KF = K * FS;
   constexpr int NL = XL + NN + KF;        // lower slots: [-L] [-K g .. -g] [-d_NN .. -d_1]
   constexpr int NU = Z0 + NN + KF + XL;   // upper slots that carry entries: [0] [d_1 .. d_NN] [g .. K g] [L]
-  static_assert(FD == 0 || XL == 0, "diagonal far neighbours and long pairs are not combined");
+  static_assert(FD == 0 || XL <= 1, "diagonal far neighbours come with at most one long pair");
   using Lds = WalkLds<NN, K, FD>;
   constexpr int XW = Lds::XW, AW = Lds::AW;
   static_assert(NN <= 4, "the near value halos share one register: sixteen lanes each");
@@ -575,17 +575,22 @@ template <class VT, int PART>
 static bool launch_shape(hipStream_t s, dim3 grid, const VT* uvals, const double2* x, const WalkPlan& P,
                          const WalkGeom& G, const HrbArrays& H, int64_t nrows, const ChebyOp& op, int ntm, const SyncArgs& sy) {
   const int key = P.nn * 100 + P.K * 10 + P.z0;
-  if (P.fd) {   // diagonal far neighbours (nine-point stencils): near 1 or 2, one strip step (PART 3)
+  if (P.fd) {   // diagonal far neighbours (nine-point stencils): near 1 or 2, one strip step, with or without ONE long pair
+                // (layers of such planes: +-nx ny) -- PART 3
     if constexpr (PART == 3) {
-#define QP_WALK_FD(NN_, Z0_)                                                                                          \
-  return (ntm & 1) ? launch_instance<VT, NN_, 1, Z0_, 1, 0, 1>(s, grid, uvals, x, P, G, H, nrows, op, sy)              \
-                   : launch_instance<VT, NN_, 1, Z0_, 0, 0, 1>(s, grid, uvals, x, P, G, H, nrows, op, sy);
-      if (P.xl != 0 || P.K != 1) return false;
-      switch (key) {
-        case 110: QP_WALK_FD(1, 0)
-        case 111: QP_WALK_FD(1, 1)
-        case 210: QP_WALK_FD(2, 0)
-        case 211: QP_WALK_FD(2, 1)
+#define QP_WALK_FD(NN_, Z0_, XL_)                                                                                       \
+  return (ntm & 1) ? launch_instance<VT, NN_, 1, Z0_, 1, XL_, 1>(s, grid, uvals, x, P, G, H, nrows, op, sy)              \
+                   : launch_instance<VT, NN_, 1, Z0_, 0, XL_, 1>(s, grid, uvals, x, P, G, H, nrows, op, sy);
+      if (P.xl > 1 || P.K != 1) return false;
+      switch (P.xl * 1000 + key) {
+        case 110: QP_WALK_FD(1, 0, 0)
+        case 111: QP_WALK_FD(1, 1, 0)
+        case 210: QP_WALK_FD(2, 0, 0)
+        case 211: QP_WALK_FD(2, 1, 0)
+        case 1110: QP_WALK_FD(1, 0, 1)
+        case 1111: QP_WALK_FD(1, 1, 1)
+        case 1210: QP_WALK_FD(2, 0, 1)
+        case 1211: QP_WALK_FD(2, 1, 1)
         default: return false;
       }
 #undef QP_WALK_FD

@@ -168,7 +168,7 @@ def grid_hamiltonian_2d(nx, ny, flux=0.0, next_nearest=False, seed=DEFAULT_SEED,
     return H
 
 
-def grid_hamiltonian_3d(nx, ny, nz, flux=0.0, seed=DEFAULT_SEED, order=2):
+def grid_hamiltonian_3d(nx, ny, nz, flux=0.0, seed=DEFAULT_SEED, order=2, diagonal=0.0):
     """Seven-point finite-difference Hamiltonian on an nx x ny x nz grid with OPEN boundaries (row = x + nx (y + ny z)):
     hopping -1 to the six neighbours (phase exp(i flux y) on the x-hops when flux != 0), a smooth potential on the diagonal.
     Distances +-1, +-nx, +-nx ny: the walk's lattice with one long pair beyond the ring (kernels_walk.hip, XL) once its edge
@@ -194,6 +194,9 @@ def grid_hamiltonian_3d(nx, ny, nz, flux=0.0, seed=DEFAULT_SEED, order=2):
     hop(X < nx - 1, 1, -phase)
     hop(Y < ny - 1, nx, np.complex128(-1.0))
     hop(Z < nz - 1, nx * ny, np.complex128(-0.5))
+    if diagonal:        # in-plane next-nearest hopping t' (layered t-t' planes coupled along z): distances +-(nx - 1), +-(nx + 1)
+        hop((X < nx - 1) & (Y < ny - 1), nx + 1, -diagonal * phase)
+        hop((X > 0) & (Y < ny - 1), nx - 1, -diagonal * np.conj(phase))
     if order == 4:      # -1/12 f(x +- 2 h) + 4/3 f(x +- h) - 5/2 f(x): the second neighbours carry -1/16 of the first ones' weight
         hop(X < nx - 2, 2, phase * phase / 16.0)
         hop(Y < ny - 2, 2 * nx, np.complex128(1.0 / 16.0))

@@ -1004,13 +1004,19 @@ def test_strip_walk_two_long_pairs_and_two_far_distances(ctx, case):
     assert np.linalg.norm(base - ref) < TOL
 
 
-@pytest.mark.parametrize("case", ["uniform_256", "uniform_100_no_diag", "uniform_real_two_near", "grid_96x50_tprime", "grid_128x40_tprime_real"])
+@pytest.mark.parametrize("case", ["uniform_256", "uniform_100_no_diag", "uniform_real_two_near", "grid_96x50_tprime", "grid_128x40_tprime_real",
+                                  "uniform_128_long_pair", "layers_72x10x20_tprime"])
 def test_strip_walk_diagonal_far_neighbours(ctx, case):
     """Far distances with their diagonal neighbours, g - 1, g, g + 1 (nine-point stencil: next-nearest hopping on a two-dimensional
     grid): the gathered elements are the ring's elements one lane over (a DPP wavefront shift, the edge lane from a packed halo
     load), the conj-transposed values come out of the FIFO one lane over.  Bit-identical to the per-block kernel for several
     partitions of the walk (strip steps that are no multiple of 64 rows included), within 1e-10 of the oracle."""
-    if case.startswith("grid"):
+    if case.startswith("layers"):      # planes with next-nearest hopping, coupled along z: one long pair beside the diagonals
+        H = synth.grid_hamiltonian_3d(72, 10, 20, flux=0.2, diagonal=0.3)
+        N = H.shape[0]
+        Delta, Emin = 16.0, -1.0
+        want = dict(near=1, diag=1, step=72, long=720)
+    elif case.startswith("grid"):
         nx, ny = (96, 50) if "96x50" in case else (128, 40)
         H = synth.grid_hamiltonian_2d(nx, ny, flux=0.0 if "real" in case else 0.2, diagonal=0.3)
         N = H.shape[0]
@@ -1019,6 +1025,7 @@ def test_strip_walk_diagonal_far_neighbours(ctx, case):
     else:
         N = 1 << 15
         offs, want = {"uniform_256": ((1, 255, 256, 257), dict(near=1, diag=1, step=256)),
+                      "uniform_128_long_pair": ((2, 127, 128, 129, 3001), dict(near=1, diag=1, step=128, long=3001)),
                       "uniform_100_no_diag": ((3, 99, 100, 101), dict(near=1, diag=0, step=100)),
                       "uniform_real_two_near": ((1, 2, 511, 512, 513), dict(near=2, diag=1, step=512))}[case]
         rp, col, vals = synth.hermitian_offsets_csr(N, offsets=offs)
@@ -1038,7 +1045,8 @@ def test_strip_walk_diagonal_far_neighbours(ctx, case):
         wi = Op.walk_info()
         assert wi["valid"] == 1 and wi["far_diagonals"] == 1 and wi["far"] == 1
         assert (wi["near"], wi["diag"], wi["rows_per_step"]) == (want["near"], want["diag"], want["step"])
-        if case.startswith("grid"):
+        assert wi["long_distances"] == ([want["long"]] if "long" in want else [])
+        if case.startswith("grid") or case.startswith("layers"):
             assert Op.fill_info() > 0
         wrk = L.ChebyWrk(ctx, N, Delta, Emin, 0.6)
 

@@ -51,6 +51,8 @@ def main():
             g = max(g, 65)
             N = g * nsteps + int(rng.choice([0, 0, 64, 1, 37, 200]))
             offsets = tuple(near) + (g - 1, g, g + 1)
+            if rng.integers(0, 2):           # ... and one long pair beyond them (layers of such planes)
+                offsets = offsets + (g * int(rng.integers(2, 12)) + int(rng.integers(18, g)),)
         if 2 * max(offsets) >= N or N > (1 << 18):
             continue
         nterms = int(rng.integers(1, 4))

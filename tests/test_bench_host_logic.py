@@ -119,3 +119,36 @@ def test_a_region_with_a_host_stall_is_measured_again_and_kept_on_record():
     sp = bp.spread([r[0] for r in regions], regions)
     assert sp["unstable"] is False and len(sp["regions_remeasured_after_host_stall"]) == 1
     assert sp["regions_remeasured_after_host_stall"][0]["longest_single_call_ms"] > 70.0
+
+
+def test_lattice_completion_knows_the_round_4_stencil_shapes():
+    """Host index work, no GPU: `qp_lattice_fill_host` completes an open-boundary grid's edge rows only when the fullest row's
+    distance list has a shape the strip walk has a kernel for -- now also the thirteen-point stencil of a three-dimensional grid
+    (two long pairs beside two far distances; the reference row is found on small grids too), the nine-point stencil with
+    diagonal neighbours, and layers of such planes (diagonal neighbours + one long pair)."""
+    import qprop_amd.lib as L
+    import qprop_amd.synth as synth
+    cases = {"thirteen-point 64x8x24": synth.grid_hamiltonian_3d(64, 8, 24, order=4),
+             "thirteen-point 72x10x20": synth.grid_hamiltonian_3d(72, 10, 20, flux=0.1, order=4),
+             "nine-point diagonal 96x50": synth.grid_hamiltonian_2d(96, 50, flux=0.2, diagonal=0.3),
+             "layers 72x10x20 with t'": synth.grid_hamiltonian_3d(72, 10, 20, flux=0.2, diagonal=0.3),
+             "seven-point 64x8x40": synth.grid_hamiltonian_3d(64, 8, 40)}
+    for name, H in cases.items():
+        N = H.shape[0]
+        z = int(np.diff(H.indptr).max())
+        rp, col = L.lattice_fill_host(N, N, H.indptr, H.indices, min_blocks=16)
+        filled = int(rp[-1]) - H.nnz
+        assert 0 < filled < 0.12 * H.nnz, (name, filled)
+        lens = np.diff(rp)
+        reach = int(np.max(np.abs(H.indices[H.indptr[N // 2 + 7]:H.indptr[N // 2 + 8]] - (N // 2 + 7))))
+        reach = max(reach, int(np.max(np.abs(col[rp[N // 2]:rp[N // 2 + 1]] - N // 2))))
+        assert np.all(lens[reach:N - reach] == z), name          # every row between the first and last `reach` rows is complete
+        # the original entries are all still there, columns ascending
+        for r in (0, reach, N // 2, N - 1):
+            orig = set(H.indices[H.indptr[r]:H.indptr[r + 1]].tolist())
+            got = col[rp[r]:rp[r + 1]]
+            assert orig <= set(got.tolist()) and np.all(np.diff(got) > 0), (name, r)
+    # a nine-point stencil whose strip step is below 64 rows is not the walk's lattice: nothing is completed
+    Hs = synth.grid_hamiltonian_2d(40, 120, diagonal=0.3)
+    rp, col = L.lattice_fill_host(Hs.shape[0], Hs.shape[0], Hs.indptr, Hs.indices, min_blocks=16)
+    assert int(rp[-1]) == Hs.nnz

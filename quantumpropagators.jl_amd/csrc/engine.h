@@ -72,7 +72,7 @@ struct qp_operator {
   qp::ColBlockPlan cb;            // column-blocked mirror of an operator with irregular columns (A.cb points here when valid)
   double cb_line_share = 0.0;     // what decided: share of a row block's gathers that pull a line of their own (sampled)
   double build_ms = 0, build_ms_total = 0;   // host time of the latest / of all device layout builds
-  int64_t n_lattice_fill = 0;               // explicit zeros that complete a lattice operator's rows (engine_core.hip: lattice_fill)
+  int64_t n_lattice_fill = 0;               // explicit zeros that complete a lattice operator's rows (engine_plans.hip: lattice_fill)
   int n_builds = 0, n_relayouts = 0;         // re-layouts: builds forced after creation (complex coefficient on a packed operator)
   bool hermitian_planes = false;
   // CSR-ordered mirror of the current values for the batched (SpMM) path, built lazily

@@ -15,7 +15,7 @@
 //   * every wavefront of the launch is resident from the first cycle (the grid is sized to the chip) and owns its row tiles
 //     -- 64 rpt rows each, `tpw` of them -- for the whole launch, row sums in registers;
 //   * phase c: every wavefront processes the segments (own tile, block c).  All gathers of the whole chip fall into ONE
-//     window of 2^log2w elements of x (1-4 MB: about sixteen blocks, engine_core.hip build_colblock): every XCD's L2 loads
+//     window of 2^log2w elements of x (1-4 MB: about sixteen blocks, engine_plans.hip build_colblock): every XCD's L2 loads
 //     the window once and serves the rest as hits;
 //   * inside a segment the entries are read one per lane (coalesced, nontemporal: the matrix is read exactly once per
 //     launch), multiplied with the gathered element, and the products staged in the wavefront's own LDS buffer; then lane r

@@ -326,7 +326,7 @@ def lattice_fill_host(nrows, ncols, rowptr, col, min_blocks=3072):
     """The lattice completion of operator creation on a host CSR pattern (no device needed): returns (rowptr, col)."""
     rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
     col = np.ascontiguousarray(col, dtype=np.int32)
-    # the completion accepts up to 12 % missing entries (engine_core.hip: lattice_fill): room for 13 % and a block of slack
+    # the completion accepts up to 12 % missing entries (engine_plans.hip: lattice_fill): room for 13 % and a block of slack
     cap = int(1.13 * int(rowptr[-1])) + 64 * 20 + 1024
     rp_out = np.empty(nrows + 1, dtype=np.int64)
     col_out = np.empty(cap, dtype=np.int32)

@@ -244,7 +244,7 @@ def test_partition_rows_bit_exact():
 
 @pytest.mark.parametrize("nx,ny,nnn", [(100, 60, False), (64, 90, False), (130, 50, True), (70, 400, False)])
 def test_lattice_fill_host_completes_open_boundary_grids(nx, ny, nnn):
-    """Index work of the lattice completion (engine_core.hip: lattice_fill, the host half of qp_operator_create), bit-exact
+    """Index work of the lattice completion (engine_plans.hip: lattice_fill, the host half of qp_operator_create), bit-exact
     against a NumPy restatement: every row between the first and the last grid row of an open-boundary grid Hamiltonian
     gets the full distance list of the stencil (explicit zeros where the grid's x-edge cut a neighbour off), the entries
     that land in the first / last grid row get their transposes, nothing else changes."""

@@ -408,7 +408,7 @@ struct MgsArgs {
   int64_t n;
 };
 int launch_mgs_pass(hipStream_t s, const MgsArgs& a, Stats* st);
-// low-synchronisation MGS of column j (see kernels.hip): c = Q^H w and the Gram row in one
+// low-synchronisation MGS of column j (see kernels_blas.hip): c = Q^H w and the Gram row in one
 // pass, a small reduction whose last workgroup (ticket counter) solves for the MGS
 // coefficients, then w -= Q h with |w|^2 partials: three launches
 int launch_mgs_lowsync(hipStream_t s, const double2* Q, int64_t ldq, int j, double2* w, double2* md_partials,

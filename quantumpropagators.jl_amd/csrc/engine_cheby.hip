@@ -649,7 +649,7 @@ int qp_cheby_term_split(qp_operator* op, qp_split* sp, void* boundary_stream, in
 // propagate step loop (src/propagate.jl:283-344)
 // ---------------------------------------------------------------------------
 // Small systems: the whole time grid in one persistent single-workgroup launch
-// (kernels.hip: cheby_propagate_small_kernel).  Same arguments as qp_propagate, method 0.
+// (kernels_small.hip: cheby_propagate_small_kernel).  Same arguments as qp_propagate, method 0.
 static int propagate_cheby_small(qp_operator* op, qp_state* psi, const qp_prop_spec* spec, qp::SmallArgs a,
                                  const double* dts,
                                  const qp_c128* coeff_table, int ncoeffs, int nsteps, qp_operator* const* observables,

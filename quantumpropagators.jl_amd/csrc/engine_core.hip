@@ -458,7 +458,7 @@ struct LowerStencilSlot {
   int32_t delta, cb0;
   int64_t pb0, pb1, pad;
 };
-static_assert(sizeof(LowerStencilSlot) == 32, "layout shared with kernels.hip");
+static_assert(sizeof(LowerStencilSlot) == 32, "layout shared with kernel_common.h");
 
 // mode of a block's column section (low two bits of its meta word, the rest is the byte offset)
 enum { kColInt32 = 0, kColInt16 = 1, kColStencil = 2, kColBlockMap = 3 };
@@ -1623,7 +1623,7 @@ int qp_dot_op(const qp_state* x, qp_operator* op, const qp_state* y, qp_state* t
 
 // CSR-ordered mirror of the operator for the batched (SpMM) path and the persistent
 // small-system kernels, built lazily
-// Row walk for the batched kernel (kernels.hip: spmm_rows_kernel).  The pattern is
+// Row walk for the batched kernel (kernels_spmm.hip: spmm_rows_kernel).  The pattern is
 // sampled for its offsets d = col - row (folded to (-n/2, n/2]); when the far ones (|d| >= 64) are all
 // multiples of one inner dimension g -- H = H_a (x) 1 + 1 (x) H_c, i = a g + c: lattice and tensor-product
 // operators -- the rows are listed strip by strip: `sw` consecutive inner indices c, all outer indices a

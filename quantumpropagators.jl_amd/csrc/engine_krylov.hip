@@ -213,7 +213,7 @@ static int arnoldi_impl(qp_operator* op, qp_krylov* q, int m, const qp_state* ps
     small = qp::small_plan(q->n, maxrow, &plan, qp::kSmallEpt) || qp::small_plan(q->n, maxrow, &plan, qp::kSmallEptArnoldi);
   }
   if (small) {
-    // all m columns in one persistent single-workgroup launch (kernels.hip: arnoldi_small_kernel)
+    // all m columns in one persistent single-workgroup launch (kernels_small.hip: arnoldi_small_kernel)
     QP_CHECK(operator_csr_mirror(op, false));
     qp::SmallArnoldiArgs a;
     a.n = q->n;

@@ -1,4 +1,4 @@
-// Device helpers shared by the kernel translation units (kernels.hip, kernels_walk.hip): complex FMA forms,
+// Device helpers shared by the kernel translation units (kernels*.hip): complex FMA forms,
 // wavefront / workgroup sums, the XCD-aware workgroup remap, the in-launch hand-off, the row epilogues of the
 // fused Chebyshev term and of the plain mat-vec, and the loaders of the row-block formats.  gfx950 only.
 #pragma once
@@ -10,6 +10,14 @@ namespace qp {
 // ---------------------------------------------------------------------------
 // helpers
 // ---------------------------------------------------------------------------
+// grid of an elementwise kernel: 8 workgroups per CU at most, grid-stride the rest
+inline int ew_grid(int64_t n) {
+  int64_t g = (n + kThreads - 1) / kThreads;
+  if (g > 256 * 8) g = 256 * 8;  // 8 workgroups per CU, grid-stride the rest
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
 __device__ __forceinline__ void cfma(double2& s, const double2 a, const double2 b) {
   s.x = fma(a.x, b.x, s.x);
   s.x = fma(-a.y, b.y, s.x);

@@ -3,7 +3,7 @@
 //   w = H q_j                       src/arnoldi.jl:82
 //   c_k = <q_k | w>,  k <= j        src/arnoldi.jl:84-85 (all of them against the SAME w: the low-synchronisation form
 //   g_k = <q_k | q_j>, k <= j        of modified Gram-Schmidt -- the projection kernel turns c and the Gram rows g into the
-//                                   reference's sequential coefficients, kernels.hip: mgs_solve_wave)
+//                                   reference's sequential coefficients, kernels_blas.hip, mgs_common.h: mgs_solve_wave)
 //
 // The separate multidot launch read w and q_j again, once per tile of eight basis vectors, and cost a launch boundary per
 // column; the lane that owns row i has w_i and (q_j)_i in registers when its row sum is complete.  Here every wavefront
@@ -21,7 +21,7 @@ constexpr int kFusedWaves = 8;
 
 // NT (knob arnoldi_nt): the matrix values and column sections are loaded nontemporal -- the matrix is read once per
 // column and does not fit an XCD's L2 next to the basis; streamed, it leaves the L2 to the basis vectors that the
-// projection kernel reads next (kernels.hip: mgs_update_kernel<.., ORD = true>)
+// projection kernel reads next (kernels_blas.hip: mgs_update_kernel<.., ORD = true>)
 template <int JT, class VT, bool NT>   // VT: double2, or double for the real copy of an all-real operator (kernel_common.h: ld_val)
 __global__ __launch_bounds__(64 * kFusedWaves) void arnoldi_matvec_dots_kernel(
     const int64_t* __restrict__ bptr, const int64_t* __restrict__ cmeta, const char* __restrict__ colbytes,

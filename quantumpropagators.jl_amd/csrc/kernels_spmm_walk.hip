@@ -1,7 +1,7 @@
 // Strip walk for the batched Chebyshev term (BASELINE configs[4]: panel X[i * b + s], lane = state) on a lattice
 // operator H = H_a (x) 1 + 1 (x) H_c: near distances +-d_i (d < 64) and far distances +-m g, m = 1..K.
 //
-// The wave-per-row kernels (kernels.hip: spmm_rows_smem_kernel) send 16 gathered rows of X (16 KiB) per row through
+// The wave-per-row kernels (kernels_spmm.hip: spmm_rows_smem_kernel) send 16 gathered rows of X (16 KiB) per row through
 // the compute unit's L1; what bounds them is that path, not HBM (profiles/r02/batched_c5_pmc_diag.txt: texture
 // addresser busy 87 %, 90 L1 -> L2 requests per row, 64 of them the eight far gathers that no neighbouring row shares).
 // Here a wavefront walks down one inner index c -- rows c + a g, a = a0, a0 + 1, ... -- and keeps the far rows of X in a

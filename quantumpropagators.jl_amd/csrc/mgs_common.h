@@ -1,4 +1,4 @@
-// Device helpers of the low-synchronisation modified Gram-Schmidt (kernels.hip: mgs_update_kernel and friends).  Included
+// Device helpers of the low-synchronisation modified Gram-Schmidt (kernels_blas.hip: mgs_update_kernel and friends).  Included
 // INSIDE namespace qp.
 __device__ __forceinline__ int tri_index(int i, int k) { return i * (i - 1) / 2 + k; }  // k < i
 

@@ -467,8 +467,11 @@ constexpr size_t kBlockMapQuad = 16 + 4 * (size_t)kRB;   // bytes per quad of a 
 // `special(b, w, out)`: a chance to emit a block in the stencil encoding (returns true and
 // appends its bytes) before the per-entry encodings are tried.
 template <class GetCol, class Special>
-static void encode_col_sections(int64_t nrows, int64_t nblocks, const std::vector<int64_t>& ptr, GetCol get,
+static void encode_col_sections(int64_t nrows, int64_t ncols, int64_t nblocks, const std::vector<int64_t>& ptr, GetCol get,
                                 Special special, std::vector<char>& bytes, std::vector<int64_t>& meta, bool allow_block_map = true) {
+  // (pad entries multiply a zero value with x[column]: the column must exist.  A TALL operator -- fewer columns than rows --
+  // has rows beyond its last column: a pad takes min(row, ncols - 1), never the row itself.)
+  const int64_t last_col = std::max<int64_t>(ncols - 1, 0);
   meta.assign((size_t)nblocks, 0);
   bytes.clear();
   for (int64_t b = 0; b < nblocks; ++b) {
@@ -500,7 +503,7 @@ static void encode_col_sections(int64_t nrows, int64_t nblocks, const std::vecto
         }
       }
       if (okmap) {
-        const int64_t own = std::min(b, (nrows - 1) >> 6);
+        const int64_t own = std::min(std::min(b, (nrows - 1) >> 6), last_col >> 6);
         for (int64_t k = 0; k < w; ++k)
           if (cb[(size_t)k] < 0) cb[(size_t)k] = own;          // a slot of pure padding: any valid column will do
         meta[b] = ((int64_t)bytes.size() << 2) | kColBlockMap;
@@ -532,6 +535,7 @@ static void encode_col_sections(int64_t nrows, int64_t nblocks, const std::vecto
         const int64_t c = get(r, k, &pad);
         if (!pad && (c - r > 32767 || r - c > 32767)) { ok16 = false; break; }
       }
+      if (r - std::min(r, last_col) > 32767) ok16 = false;   // (a pad of this row could not be encoded as a distance)
     }
     meta[b] = ((int64_t)bytes.size() << 2) | (ok16 ? kColInt16 : kColInt32);
     const size_t esz = ok16 ? 2 : 4;
@@ -542,8 +546,8 @@ static void encode_col_sections(int64_t nrows, int64_t nblocks, const std::vecto
       const int64_t rc = std::min(r, nrows - 1);   // the kernel decodes deltas against the clamped row
       for (int64_t k = 0; k < w; ++k) {
         bool pad = (r >= nrows);
-        int64_t c = pad ? rc : get(r, k, &pad);
-        if (pad && ok16) c = rc;
+        int64_t c = pad ? std::min(rc, last_col) : get(r, k, &pad);
+        if (pad && ok16) c = std::min(rc, last_col);
         const size_t q = (size_t)(k >> 2) * (4 * kRB) + (size_t)l * 4 + (k & 3);   // quad-packed slot
         if (ok16) {
           const int16_t d = (int16_t)(c - rc);
@@ -700,7 +704,7 @@ static int operator_build_device_impl(qp_operator* op, int format, const std::ve
         *pad = true;
         return (ur[r + 1] > ur[r]) ? uc[ur[r]] : 0;
       };
-      encode_col_sections(nrows, A.nblocks, Lh.bptr, get_upper,
+      encode_col_sections(nrows, A.ncols, A.nblocks, Lh.bptr, get_upper,
                           [&](int64_t b, int64_t w, std::vector<char>& out) {
                             return ctx->tun.stencil != 0 && try_stencil_upper(nrows, A.ncols, b, w, get_upper, out);
                           },
@@ -771,7 +775,7 @@ static int operator_build_device_impl(qp_operator* op, int format, const std::ve
         std::memcpy(&out[off], slots.data(), (size_t)w * sizeof(LowerStencilSlot));
         return true;
       };
-      encode_col_sections(nrows, A.nblocks, Lh.lptr,
+      encode_col_sections(nrows, A.ncols, A.nblocks, Lh.lptr,
                           [&](int64_t r, int64_t k, bool* pad) -> int64_t {
                             if (k < Lh.nlow[r]) return uc[ur[r] + k];
                             *pad = true;          // padded: any valid column, value masked by pos < 0

@@ -55,6 +55,8 @@ def main():
         kind = ["mul", "cheby", "newton"][int(rng.integers(0, 3))]
         real = bool(rng.random() < 0.3)
         kinds[kind] += 1
+        if os.environ.get("QP_FUZZ_VERBOSE"):
+            print(f"[case {case}: {kind} real={real} log2w={log2w}]", flush=True)
         if kind == "mul":
             nr = int(rng.integers(64, 6000))
             nc = nr if rng.random() < 0.5 else int(rng.integers(64, 9000))
@@ -96,7 +98,10 @@ def main():
             psi0 /= np.linalg.norm(psi0)
             err = 0.0
             if kind == "newton":
-                m = int(rng.integers(4, 12))
+                # (m_max >= 6: with the 4 or 5 Krylov vectors this used to draw, newton! itself sits on the edge of convergence for
+                # some of these non-normal operators -- seed 22, case 221: the oracle needs 2 restarts at m_max = 4 and does not
+                # converge at all at m_max = 3; the library's variants then differ by rounding in WHETHER they converge)
+                m = int(rng.integers(6, 12))
                 try:
                     ref = qo.newton(psi0.copy(), H, dt, qo.NewtonWrk(psi0, m_max=m))
                 except AssertionError:      # (the oracle itself runs out of restarts for this dt / m_max: not a case)

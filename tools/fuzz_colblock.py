@@ -60,6 +60,8 @@ def main():
         if kind == "mul":
             nr = int(rng.integers(64, 6000))
             nc = nr if rng.random() < 0.5 else int(rng.integers(64, 9000))
+            if rng.random() < 0.15:          # tiny and odd shapes: a few rows / columns, single column, fewer rows than a row block
+                nr, nc = int(rng.integers(1, 150)), int(rng.integers(1, 150))
             nterms = int(rng.integers(1, 4))
             mats = [random_sparse(nr, nc, rng, real) for _ in range(nterms)]
             fmt = [L.FMT_AUTO, L.FMT_RBCSR, L.FMT_CSR][int(rng.integers(0, 3))]

@@ -16,7 +16,10 @@ One "step" = one ``prop_step!`` = one pass of the hot path (31 fused SpMV terms 
   STRONG point BASELINE's metric also names (N = 2^20 in total, split over the ranks) is measured after the timed
   region and reported under ``strong_scaling_point``; ``--config c2 --scaling strong`` makes it the headline.
 
-Rank 0 prints ONE JSON line.  ``roofline.frac`` prices the bytes the SHIPPED device layout has to move
+Rank 0 prints ONE compact JSON line LAST (< 4 KB: the contract's keys, the gate scalars of ``roofline`` and ``cpu_baseline``,
+one [time, fraction] pair per extra point); the complete record of the run -- every extra point, the prediction table, the
+notes -- goes to ``bench_extras.json`` next to this script (and under ``gpurun_out/`` where that directory exists).
+``roofline.frac`` prices the bytes the SHIPPED device layout has to move
 (tools/bench_points.py: cheby_layout_bytes) and cannot exceed 1; the contract's CSR figure is kept as
 ``roofline.effective_csr_equiv_gbs``.  ``roofline.traffic`` is measured in this run: two child processes of this
 script under ``rocprofv3 --pmc`` (FETCH_SIZE, WRITE_SIZE; one pass each as the pool requires), or, if the profiler
@@ -199,6 +202,23 @@ def scaling_prediction(us_per_term_by_log2rows, value_1gpu, nterms, source):
                        "(32 MiB per link and term at 8 GPUs), it cannot reach 6x on 153 GB/s links"}
 
 
+def prediction_scalars(pred):
+    """The few numbers of the prediction table a reader of the printed line needs (the table itself: bench_extras.json)."""
+    if not pred:
+        return None
+    out = {}
+    for row in pred.get("fixed_problem_N_2^24") or []:
+        if row["gpus"] == 8 and "speedup_halo_overlap" in row:
+            out["fixed_n24_speedup_8gpu_halo"] = row["speedup_halo_overlap"]
+            out["fixed_n24_speedup_8gpu_allgather"] = row["speedup_allgather"]
+    for row in pred.get("bench_default_weak_2^21_rows_per_gpu") or []:
+        if row["gpus"] == 8:
+            out["weak_8gpu_blocks_per_s"] = row["predicted_value_blocks_per_s"]
+            out["weak_8gpu_efficiency"] = row["predicted_efficiency_vs_1gpu_value"]
+    out["source"] = "STATIC" if str(pred.get("source_of_compute_times", "")).startswith("STATIC") else "this run"
+    return out or None
+
+
 def scaling_prediction_static(nterms):
     """The same table in a multi-GPU line, from the committed single-GPU measurements (this run cannot measure them)."""
     path = os.path.join(ROOT, STATIC_SIZES)
@@ -208,6 +228,108 @@ def scaling_prediction_static(nterms):
         d = json.load(f)
     return scaling_prediction(d["us_per_term_by_log2_rows"], d.get("value_1gpu"), nterms,
                               f"STATIC: {STATIC_SIZES} (single-GPU run of bench.py on another box)")
+
+
+LINE_LIMIT = 4096          # the driver parses the LAST stdout line; r04's 36 KB line defeated it
+EXTRAS_FILE = "bench_extras.json"
+
+
+def _short(s, n=160):
+    s = str(s)
+    return s if len(s) <= n else s[:n - 3] + "..."
+
+
+def _num(x, digits=6):
+    """Floats at 6 significant digits (the line is a gate record, not an archive); everything else as is."""
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}")
+    return x
+
+
+def _pick(d, keys):
+    return {k: _num(d[k]) for k in keys if d and k in d and d[k] is not None}
+
+
+def compact_line(full):
+    """The one JSON object the driver reads: few, scalar, early.  `full` is the complete record of the run (it goes to
+    bench_extras.json); this keeps the contract's keys, the gate scalars of `roofline` / `cpu_baseline`, and ONE
+    (time, fraction) pair per extra point.  No string longer than 160 characters, the whole line below LINE_LIMIT."""
+    cfg = full.get("config") or {}
+    rf = full.get("roofline") or {}
+    line = {k: _num(full.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                           "scaling", "vs_baseline", "dtype", "data")}
+    line["metric"] = _short(line["metric"])
+    c = _pick(cfg, ("N_total", "N", "rows_per_gpu", "states_per_gpu", "nnz_per_row", "pattern", "n_coeffs", "matvecs_per_step", "dt",
+                    "device_format", "operator_build_ms"))
+    c = {"workload": _short(cfg.get("workload_short") or cfg.get("workload")), **c,
+         "parallelism": _short(cfg.get("parallelism_short") or cfg.get("parallelism"))}
+    line["config"] = c
+    r = {"bound": rf.get("bound"), "achieved": _num(rf.get("achieved")), "peak": rf.get("peak"), "unit": rf.get("unit"),
+         "frac": _num(rf.get("frac")), "traffic": _num(rf.get("traffic"))}
+    r.update(_pick(rf, ("kernel", "avg_launch_us", "bytes_per_launch", "traffic_over_bytes", "unstable",
+                        "hbm_resident_frac", "hbm_resident_us_per_term", "n23_frac", "n23_us_per_term",
+                        "fixed_problem_n24_frac", "fixed_problem_n24_us_per_term", "fixed_problem_n24_blocks_per_s",
+                        "stream_read_gbs", "stream_walk_mix_gbs", "hbm_resident_frac_of_stream_mix", "fixed_problem_n24_frac_of_stream_mix",
+                        "csr_equiv_frac", "algorithmic_frac", "traffic_measured")))
+    if "kernel" in r:
+        r["kernel"] = _short(r["kernel"], 96)
+    line["roofline"] = r
+    cb = full.get("cpu_baseline")
+    line["cpu_baseline"] = None if not cb else {
+        **_pick(cb, ("value", "unit", "cores", "kind")), "sample": _short(cb.get("sample", "")),
+        **_pick(cb, ("ms_per_step", "l2_diff_vs_gpu_after_sample"))}
+    ca = full.get("cpu_baseline_all_cores")
+    if ca:
+        line["cpu_baseline_all_cores"] = _pick(ca, ("value", "cores", "ms_per_step"))
+    for k in ("strong_point", "allgather_form", "prediction", "conservative_first"):
+        if full.get(k):
+            line[k] = {kk: (_short(v, 96) if isinstance(v, str) else _num(v)) for kk, v in full[k].items()}
+    # one pair per extra point: [time in the point's own unit (us per term / ms per step / us per apply), fraction of its roofline]
+    pts = {}
+    for name, pt in (full.get("extras") or {}).items():
+        if not isinstance(pt, dict):
+            continue
+        if "error" in pt:
+            pts[name] = "error"
+            continue
+        t = next((pt[k] for k in ("us_per_term", "ms_per_step", "us_per_apply") if pt.get(k) is not None), None)
+        f = next((pt[k] for k in ("frac", "frac_fp64_matrix_peak") if pt.get(k) is not None), None)
+        if pt.get("bound") == "mfma" and pt.get("frac_fp64_matrix_peak") is not None:
+            f = pt["frac_fp64_matrix_peak"]
+        pts[name] = [_num(t, 4), _num(f, 3)]
+    if pts:
+        line["points"] = pts
+        line["points_unit"] = "[us per term | ms per step (c3*) | us per apply (n4*), fraction of the point's roofline]"
+    for k in ("max_norm_drift", "degraded", "native_path"):
+        if k in full:
+            line[k] = _num(full[k])
+    line["extras_file"] = EXTRAS_FILE
+    return line
+
+
+def emit(full):
+    """Rank 0: the complete record to bench_extras.json (next to this script, and under gpurun_out/ where that exists so that
+    it travels back from a GPU box), one short `EXTRA ` line per extra point, then -- LAST -- the compact line."""
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, EXTRAS_FILE), "w") as f:
+                    json.dump(full, f, indent=1)
+            except OSError:
+                pass
+    line = compact_line(full)
+    for name, v in (line.get("points") or {}).items():
+        print("EXTRA " + json.dumps({name: v}))
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) >= LINE_LIMIT:      # never print a line the driver cannot read: drop the optional parts, largest first
+        for k in ("points", "points_unit", "prediction", "conservative_first", "cpu_baseline_all_cores"):
+            line.pop(k, None)
+            text = json.dumps(line, separators=(",", ":"))
+            if len(text) < LINE_LIMIT:
+                break
+    sys.stdout.flush()
+    print(text)
+    sys.stdout.flush()
 
 
 def run_c5(args, world, rank, local_rank, one_gpu, dist, L, synth, bp):
@@ -274,7 +396,15 @@ def run_c5(args, world, rank, local_rank, one_gpu, dist, L, synth, bp):
                         "algorithmic_bytes_per_launch_per_gpu": alg, "algorithmic_frac": alg / t_term / 1e9 / HBM_PEAK_GBS,
                         "note": "per GPU (slowest rank): bytes the shipped step must move per fused term (matrix once, this GPU's "
                                 "share of the panel streams) / average launch duration from HIP events on the kernels' stream"},
-           "cpu_baseline": None, "max_norm_drift": drift}
+           "cpu_baseline": None, "max_norm_drift": drift, "degraded": False}
+    out["config"]["workload_short"] = f"BASELINE configs[4]: batched Cheby prop_step!, {args.batch} states x N=2^{log2n} CSR H, 16 nnz/row"
+    out["config"]["parallelism_short"] = ("single GPU" if world == 1 else f"batch-split x{world}, H replicated, no communication") + (
+        " [TEST MODE: one GPU]" if one_gpu else "")
+    out["config"]["nnz_per_row"] = nnz / N
+    out["config"]["device_format"] = bp.FMT_NAME[op.format]
+    rfl = out["roofline"]
+    rfl["kernel"] = "spmm_rows_smem_kernel" if b > 32 else "csr_spmm_kernel"
+    rfl["bytes_per_launch"] = lay
     # HBM traffic of the panel kernel (this line carried "traffic": null): the same child-process PMC
     # passes as the headline, on rank 0 of a single-GPU run, for the panel width this run's GPUs see
     if rank == 0 and world == 1 and not args.no_pmc and args.batch == 64 and log2n == 18:
@@ -286,8 +416,10 @@ def run_c5(args, world, rank, local_rank, one_gpu, dist, L, synth, bp):
         rfl["traffic_source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of `bench.py --point c5`, "
                                  "FETCH_SIZE x 2 (gfx950), mean per launch") if tr is not None else f"not measured: {det}"
         rfl["traffic_over_layout_bytes"] = (tr / lay) if tr else None
+        rfl["traffic_over_bytes"] = rfl["traffic_over_layout_bytes"]
+        rfl["traffic_measured"] = tr is not None
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
     if bs is not None:
         bs.close()
     if dist is not None:
@@ -323,6 +455,7 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with rocprofv3 child runs")
     ap.add_argument("--no-extras", action="store_true", help="headline only: no extra points (formats, patterns, C3, C5)")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling point")
+    ap.add_argument("--no-allgather", action="store_true", help="N > 1: skip the 4-step measurement of the all-gather exchange form")
     ap.add_argument("--no-safe", action="store_true", help="N > 1: skip the conservative first measurement and the watchdog")
     ap.add_argument("--point", default=None, choices=["c3", "c5"], help=argparse.SUPPRESS)      # one extras point only (PMC child runs)
     ap.add_argument("--watchdog", type=float, default=float(os.environ.get("QP_BENCH_WATCHDOG", "420")),
@@ -467,10 +600,10 @@ def main():
         # if, on every rank, one step of it reproduces the torch-driven step bit for bit.
         want_native = args.driver == "native"     # (test mode: callback communicator, host-staged)
 
-        def make_stepper(rp_, col_, vals_, N_, r0_, r1_, psi0_):
+        def make_stepper(rp_, col_, vals_, N_, r0_, r1_, psi0_, exchange=None):
             """Both schedules of the partitioned step for one problem -> (stepper, native?, exchange, notes, layout op)."""
             def build(overlap):
-                sh_ = sharded.ShardedCheby(ctx, rp_, col_, vals_, N_, r0_, r1_, Delta, E_min, dt, fmt=fmt, exchange=args.exchange,
+                sh_ = sharded.ShardedCheby(ctx, rp_, col_, vals_, N_, r0_, r1_, Delta, E_min, dt, fmt=fmt, exchange=exchange or args.exchange,
                                            host_staged=one_gpu, native=want_native, overlap=overlap)
                 nat = sh_.native is not None
                 if nat:
@@ -555,26 +688,18 @@ def main():
         pcie = 20 / (time.perf_counter() - t0p)
         L.host_unregister(host)
 
-    # on-box streaming ceiling: y += a x over 2^26 complex elements, 48 B per element
-    stream_gbs = copy_gbs = None
-    if world == 1:
-        ns = 1 << 26
-        sx, sy = L.State(ctx, n=ns), L.State(ctx, n=ns)
-        sx.fill(1.0)
-        for _ in range(2):
-            sy.axpy(0.5, sx)
-        ctx.timer_begin()
-        for _ in range(10):
-            sy.axpy(0.5, sx)
-        stream_gbs = 10 * 48.0 * ns / (ctx.timer_end() * 1e-3) / 1e9
-        for _ in range(2):
-            sy.copy_from(sx)
-        ctx.timer_begin()
-        for _ in range(10):
-            sy.copy_from(sx)          # the runtime's device-to-device copy: 32 B per element
-        copy_gbs = 10 * 32.0 * ns / (ctx.timer_end() * 1e-3) / 1e9
-        sx.close()
-        sy.close()
+    # on-box HBM yardsticks: what this box streams read-only and in the walk's own 8 : 1 read : write
+    # mix at 2 GiB working sets -- tools/probe/stream_yardstick (a child process: its own context, nothing of ours running)
+    stream_read_gbs = stream_mix_gbs = None
+    if world == 1 and not args.no_extras:
+        exe = os.path.join(ROOT, "tools", "probe", "stream_yardstick")
+        try:
+            torch.cuda.synchronize()
+            r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+            y = json.loads(r.stdout.strip().splitlines()[-1])
+            stream_read_gbs, stream_mix_gbs = y.get("stream_read_gbs"), y.get("stream_walk_mix_gbs")
+        except Exception as e:  # noqa: BLE001  (a missing probe must not take the headline down)
+            sys.stderr.write(f"[bench.py] stream yardstick not measured: {type(e).__name__}: {e}\n")
 
     def make_out(elapsed, ev_ms, st, fmt_used, model, exchange_used, schedule_note, driver_note, strong,
                  traffic=None, traffic_src=None, traffic_detail=None, extras=None, note=None, xmodel=None):
@@ -618,37 +743,39 @@ def main():
                        "spectral_range": [-10.0, 10.0],
                        "operator_build": build_ms,
                        "device_layout": layout},
-            # the scalars a gate reads come first (the driver's record keeps the leading scalar keys of this object); dicts and the
-            # explanatory note come last.  hbm_resident_* / fixed_problem_* are filled from the extras below (single GPU, headline)
+            # `roofline`: the gate scalars (compact_line() copies them into the printed line); the explanatory material goes
+            # to bench_extras.json only.  hbm_resident_* / n23_* / fixed_problem_* are filled from the extras below.
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": kern,
                          "avg_launch_us": avg_launch_s * 1e6,
-                         "hbm_resident_frac": None, "hbm_resident_us_per_term": None, "hbm_resident_frac_2^21_rows": None,
-                         "fixed_problem_n24_us_per_term": None, "fixed_problem_n24_frac": None, "fixed_problem_n24_blocks_per_s": None,
-                         "hbm_resident_frac_of_measured_stream": None, "fixed_problem_n24_frac_of_measured_stream": None,
-                         "operator_build_ms": (build_ms or {}).get("build_ms"),
+                         "bytes_per_launch": model["per_term"],
+                         "traffic_over_bytes": (traffic / model["per_term"]) if traffic else None,
+                         "traffic_measured": bool(traffic_src and traffic_src.startswith("measured")) if traffic is not None else None,
                          "unstable": bool(seg and max(seg) > 1.3 * min(seg)),
+                         "hbm_resident_frac": None, "hbm_resident_us_per_term": None, "n23_frac": None, "n23_us_per_term": None,
+                         "fixed_problem_n24_frac": None, "fixed_problem_n24_us_per_term": None, "fixed_problem_n24_blocks_per_s": None,
+                         "stream_read_gbs": stream_read_gbs, "stream_walk_mix_gbs": stream_mix_gbs,
+                         "hbm_resident_frac_of_stream_mix": None, "fixed_problem_n24_frac_of_stream_mix": None,
+                         "csr_equiv_frac": csr_equiv / HBM_PEAK_GBS,
+                         "hbm_resident_frac_2^21_rows": None,
+                         "operator_build_ms": (build_ms or {}).get("build_ms"),
                          "launch_us_min_segment": min(seg) if seg else None, "launch_us_max_segment": max(seg) if seg else None,
                          "layout_bytes_per_launch": model["per_term"],
                          "csr_equivalent_bytes_per_launch": model["csr_equivalent_per_term"],
                          "effective_csr_equiv_gbs": csr_equiv,
-                         "effective_csr_equiv_frac": csr_equiv / HBM_PEAK_GBS,
-                         "traffic_over_layout_bytes": (traffic / model["per_term"]) if traffic else None,
                          "traffic_rate_gbs": (traffic / avg_launch_s / 1e9) if traffic else None,
-                         "traffic_frac_of_peak": (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                         "hbm_stream_measured_gbs": stream_gbs, "hbm_copy_measured_gbs": copy_gbs,
                          "layout_bytes_matrix": model["matrix_per_term"], "layout_bytes_vectors": model["vectors_per_term"],
                          "launches_timed": n_launch, "hip_event_ms": ev_ms,
                          "traffic_source": traffic_src,
                          "launch_us_segments": seg, "traffic_detail": traffic_detail,
                          "note": "avg_launch_us = HIP-event time of the timed region on the kernels' stream / fused-term launches (gaps and, "
-                                 "multi-GPU, the exchange included); launch_us_segments: the same per quarter of the region.  achieved = "
-                                 "bytes the SHIPPED device layout must move per launch / that time (<= peak by construction); "
-                                 "effective_csr_equiv_* prices the time with SURVEY 8d's CSR bytes (404 B/row), which the Hermitian-packed "
-                                 "stencil layout undercuts -- not a physical fraction.  traffic = HBM bytes per launch from PMC counters "
-                                 "(FETCH_SIZE counts Infinity-Cache hits: at N = 2^20 the working set is served on-die; hbm_resident_* = the "
-                                 "N = 2^22 point beyond it, fixed_problem_n24_* = config C4's N = 2^24 on this one GPU)"},
+                                 "multi-GPU, the exchange included).  achieved = bytes the SHIPPED device layout must move per launch / "
+                                 "that time; csr_equiv_frac prices the time with SURVEY 8d's CSR bytes (404 B/row), which the "
+                                 "Hermitian-packed stencil layout undercuts -- not a physical fraction.  traffic = HBM bytes per launch "
+                                 "from PMC counters (FETCH_SIZE counts Infinity-Cache hits: at N = 2^20 the working set is served on-die; "
+                                 "hbm_resident_* = the N = 2^22 point beyond it, fixed_problem_n24_* = config C4's N = 2^24 on this one "
+                                 "GPU); stream_* = tools/probe/stream_yardstick on this box (read only / the walk's 8:1 mix, 2 GiB)"},
             "cpu_baseline": cpu,
             "cpu_baseline_all_cores": cpu_omp,
             "pcie_inclusive_steps_per_s": pcie,
@@ -658,6 +785,15 @@ def main():
             "extras": extras,
             "stats": {"n_matvec": st["n_matvec"], "kernel_launches": st["n_kernel_launches"]},
         }
+        out["config"]["workload_short"] = {
+            "c2": f"BASELINE configs[1]: Cheby prop_step!, N=2^{log2n} CSR sparse Hermitian H, 16 nnz/row, c128, int32 indices",
+            "c4": (f"BASELINE configs[3] fixed problem on ONE GPU: Cheby prop_step!, N=2^{log2n} CSR H, 16 nnz/row" if world == 1 else
+                   f"BASELINE configs[3]: Cheby prop_step!, CSR H row-partitioned, 2^{(rows - 1).bit_length()} rows/GPU, RCCL exchange per mat-vec")}[config] + (
+            " [f64 values]" if args.real else "")
+        out["config"]["parallelism_short"] = "single GPU" if world == 1 else (
+            f"row-partitioned x{world}, exchange={exchange_used}, schedule={str(schedule_note).split(' -> ')[-1].split(':')[0]}, "
+            f"driver={'native (own RCCL communicator)' if str(driver_note).startswith('native') else 'torch.distributed'}"
+            + (" [TEST MODE: one GPU, gloo]" if one_gpu else ""))
         if note:
             out["config"]["parallelism"] += " | " + note
         return out
@@ -711,6 +847,7 @@ def main():
     # collective cannot be recovered in-process), rank 0 prints the kept line and every rank leaves.
     fallback = None
     watchdog = None
+    ag_form = {}
     if world > 1:
         if not args.no_safe:
             shA = sharded.ShardedCheby(ctx, rp, col, vals, N, r0, r1, Delta, E_min, dt, fmt=fmt, exchange=args.exchange,
@@ -736,8 +873,7 @@ def main():
                     kept = json.loads(fallback_line)
                     kept["degraded"] = True
                     kept["native_path"] = reason
-                    sys.stdout.write(json.dumps(kept) + "\n")
-                    sys.stdout.flush()
+                    emit(kept)
                 sys.stderr.write(f"[bench.py rank {rank}] native / overlapped path {reason} (limit {args.watchdog} s): "
                                  f"reporting the conservative measurement, exit status 3\n")
                 sys.stderr.flush()
@@ -779,6 +915,33 @@ def main():
                            "N_total": Ns, "rows_per_gpu": rs, "steps": ksteps, "prop_steps_per_s": ksteps / float(ts[0]),
                            "ms_per_step": 1e3 * float(ts[0]) / ksteps, "exchange": sh_s.exchange, "schedule": snote_s, "driver": dnote_s}
                 sh_s.close()
+            # the collective north_star NAMES -- an all-gather of the term vector after every mat-vec -- gets its own measured
+            # point next to the headline (for a banded H `auto` picks the halo exchange): 4 steps with the whole slice
+            # exchanged, the same operator, the same driver
+            if not args.no_allgather:
+                per_term_main = 1e3 * ev_ / (args.steps * nterms)
+                if sh_.exchange == "allgather":
+                    ag_form["us_per_term"], ag_form["blocks_per_s"] = per_term_main, (N / float(1 << 20)) * args.steps / el_
+                else:
+                    try:
+                        sh_g, nat_g, _, dnote_g = make_stepper(rp, col, vals, N, r0, r1, psi0_local, exchange="allgather")
+                        for _ in range(2):
+                            sh_g.step(native=nat_g)
+                        barrier()
+                        t0g = time.perf_counter()
+                        for _ in range(4):
+                            sh_g.step(native=nat_g)
+                        torch.cuda.synchronize()
+                        dist.barrier()
+                        tg = dev_tensor([time.perf_counter() - t0g])
+                        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+                        sh_g.check()
+                        ag_form["us_per_term"] = 1e6 * float(tg[0]) / (4 * nterms)
+                        ag_form["blocks_per_s"] = (N / float(1 << 20)) * 4 / float(tg[0])
+                        ag_form["driver"] = "native" if nat_g else "torch.distributed"
+                        sh_g.close()
+                    except Exception as e:  # noqa: BLE001 -- the extra point must not take the headline down
+                        ag_form["error"] = f"{type(e).__name__}: {e}"
             return sh_, el_, ev_, st_, model_, snote_, dnote_, strong_
 
         try:
@@ -827,33 +990,33 @@ def main():
             wrk.close()
             op.close()
             extras = {}
-            for name, kw in (("c2_rbcsr_generic_format", dict(pattern="banded", log2n=20, fmt="rbcsr")),
-                             ("c2_scattered_pattern", dict(pattern="scattered", log2n=20)),
-                             ("c2_random_columns", dict(pattern="random", log2n=20)),
-                             ("c2_random_columns_windowed", dict(pattern="random-window", log2n=20)),
-                             ("banded_N_2^21_rows_per_gpu_of_config_c4", dict(pattern="banded", log2n=21, steps=8)),
-                             ("banded_N_2^22_out_of_infinity_cache", dict(pattern="banded", log2n=22, steps=5)),
-                             ("banded_N_2^23_rows_per_gpu_of_the_fixed_problem_at_2_gpus", dict(pattern="banded", log2n=23, steps=4, warmup=3)),
-                             ("banded_N_2^24_config_c4_fixed_problem_on_one_gpu", dict(pattern="banded", log2n=24, steps=4, warmup=3)),
-                             ("c2_alpha_2_17_coefficients", dict(pattern="banded", log2n=20, dt=0.2, steps=20)),
-                             ("c2_alpha_50_85_coefficients", dict(pattern="banded", log2n=20, dt=5.0, steps=5)),
-                             ("c2_real_symmetric_f64_values", dict(pattern="banded", log2n=20, real=True)),
-                             ("grid_2048x2048_five_point_open_boundaries", dict(grid=(2048, 2048), steps=5)),
-                             ("grid_256x128x128_seven_point_open_boundaries", dict(grid=(256, 128, 128), steps=4)),
-                             ("grid_256x128x128_thirteen_point_two_long_pairs", dict(grid=(256, 128, 128), grid_order=4, steps=4)),
-                             ("nine_point_diagonal_neighbours_N_2^22", dict(offsets=(1, 2047, 2048, 2049), log2n=22, steps=5)),
-                             ("tfim_20_spins_qubit_register_hamiltonian", dict(spins=20, steps=5))):
+            for name, kw in (("c2_rbcsr", dict(pattern="banded", log2n=20, fmt="rbcsr")),
+                             ("c2_scattered", dict(pattern="scattered", log2n=20)),
+                             ("c2_random", dict(pattern="random", log2n=20)),
+                             ("c2_random_window", dict(pattern="random-window", log2n=20)),
+                             ("banded_n21", dict(pattern="banded", log2n=21, steps=8)),
+                             ("banded_n22", dict(pattern="banded", log2n=22, steps=5)),
+                             ("banded_n23", dict(pattern="banded", log2n=23, steps=4, warmup=3)),
+                             ("banded_n24", dict(pattern="banded", log2n=24, steps=4, warmup=3)),
+                             ("c2_alpha2", dict(pattern="banded", log2n=20, dt=0.2, steps=20)),
+                             ("c2_alpha50", dict(pattern="banded", log2n=20, dt=5.0, steps=5)),
+                             ("c2_real_f64", dict(pattern="banded", log2n=20, real=True)),
+                             ("grid2d_5pt", dict(grid=(2048, 2048), steps=5)),
+                             ("grid3d_7pt", dict(grid=(256, 128, 128), steps=4)),
+                             ("grid3d_13pt", dict(grid=(256, 128, 128), grid_order=4, steps=4)),
+                             ("lattice_9pt_n22", dict(offsets=(1, 2047, 2048, 2049), log2n=22, steps=5)),
+                             ("tfim20", dict(spins=20, steps=5))):
                 try:
                     extras[name] = bp.measure_cheby(ctx, **kw)
                 except Exception as e:  # noqa: BLE001  (an extra point must not take the headline down)
                     extras[name] = {"error": f"{type(e).__name__}: {e}"}
             for name, fn in (("c3_newton", bp.measure_newton_c3),
-                             ("c3_newton_n2048_bandwidth_bound", lambda c: bp.measure_newton_c3(c, n=2048, steps=3, warmup=4)),
+                             ("c3_newton_n2048", lambda c: bp.measure_newton_c3(c, n=2048, steps=3, warmup=4)),
                              ("c5_batched", bp.measure_batched_c5),
-                             ("c5_batched_8_states_share_of_one_of_8_gpus", lambda c: bp.measure_batched_c5(c, batch=8, steps=20)),
-                             ("dense_h_n4096_one_state", lambda c: bp.measure_dense(c, N=4096)),
-                             ("dense_h_n4096_64_states_on_the_matrix_cores", lambda c: bp.measure_dense(c, N=4096, batch=64)),
-                             ("n4_matrix_free_liouvillian_n512", bp.measure_liouville)):
+                             ("c5_batched_8", lambda c: bp.measure_batched_c5(c, batch=8, steps=20)),
+                             ("dense_n4096", lambda c: bp.measure_dense(c, N=4096)),
+                             ("dense_n4096_b64_mfma", lambda c: bp.measure_dense(c, N=4096, batch=64)),
+                             ("n4_liouville_n512", bp.measure_liouville)):
                 try:
                     extras[name] = fn(ctx)
                 except Exception as e:  # noqa: BLE001
@@ -891,20 +1054,22 @@ def main():
     # object (at N = 2^20 the 134 MB of values and the vectors are served on-die; config C4 is N = 2^24)
     if extras:
         rf = out["roofline"]
-        p22 = extras.get("banded_N_2^22_out_of_infinity_cache") or {}
-        p21 = extras.get("banded_N_2^21_rows_per_gpu_of_config_c4") or {}
-        p24 = extras.get("banded_N_2^24_config_c4_fixed_problem_on_one_gpu") or {}
+        p22 = extras.get("banded_n22") or {}
+        p21 = extras.get("banded_n21") or {}
+        p24 = extras.get("banded_n24") or {}
+        p23 = extras.get("banded_n23") or {}
         rf["hbm_resident_frac"] = p22.get("frac")
         rf["hbm_resident_us_per_term"] = p22.get("us_per_term")
         rf["hbm_resident_frac_2^21_rows"] = p21.get("frac")
+        rf["n23_frac"], rf["n23_us_per_term"] = p23.get("frac"), p23.get("us_per_term")
         rf["fixed_problem_n24_us_per_term"] = p24.get("us_per_term")
         rf["fixed_problem_n24_frac"] = p24.get("frac")
         rf["fixed_problem_n24_blocks_per_s"] = (16.0 * p24["steps_per_s"]) if p24.get("steps_per_s") else None
-        # the same two points against what THIS box streams (y += a x over 2^26 elements, measured above): beyond the Infinity
-        # Cache the chip's practical ceiling is that figure, not 8 TB/s (profiles/r04/walk_n24_pmc.txt)
-        if stream_gbs:
-            rf["hbm_resident_frac_of_measured_stream"] = (p22["layout_gbs"] / stream_gbs) if p22.get("layout_gbs") else None
-            rf["fixed_problem_n24_frac_of_measured_stream"] = (p24["layout_gbs"] / stream_gbs) if p24.get("layout_gbs") else None
+        # the same two points against what THIS box streams in the walk's own read : write mix (tools/probe/stream_yardstick):
+        # a fraction of a measured ceiling of the same mix, so it cannot exceed 1 by construction of the yardstick
+        if stream_mix_gbs:
+            rf["hbm_resident_frac_of_stream_mix"] = (p22["layout_gbs"] / stream_mix_gbs) if p22.get("layout_gbs") else None
+            rf["fixed_problem_n24_frac_of_stream_mix"] = (p24["layout_gbs"] / stream_mix_gbs) if p24.get("layout_gbs") else None
         rf["hbm_resident_point"] = {k: p22.get(k) for k in ("N", "us_per_term", "us_per_term_min", "us_per_term_max", "unstable",
                                                             "layout_bytes_per_term", "layout_gbs", "kernel")}
         rf["fixed_problem_point"] = {k: p24.get(k) for k in ("N", "us_per_term", "us_per_term_min", "us_per_term_max", "unstable", "ms_per_step",
@@ -921,7 +1086,7 @@ def main():
         rf["note"] = rf.pop("note")        # the long text stays last
         sizes = {}
         for lg, pt in ((20, {"us_per_term": rf["avg_launch_us"]}), (21, p21), (22, p22),
-                       (23, extras.get("banded_N_2^23_rows_per_gpu_of_the_fixed_problem_at_2_gpus") or {}), (24, p24)):
+                       (23, extras.get("banded_n23") or {}), (24, p24)):
             if pt.get("us_per_term"):
                 sizes[lg] = pt["us_per_term"]
         out["scaling_prediction"] = scaling_prediction(sizes, out["value"], nterms, "measured in this run on one GPU")
@@ -941,8 +1106,15 @@ def main():
         out = fallback
     if world > 1:      # the 1 / 2 / 4 / 8 table this run is to be read against (from the committed single-GPU measurements)
         out["scaling_prediction"] = scaling_prediction_static(nterms)
+        out["allgather_form"] = ag_form or None
+        if fallback is not None and out is not fallback:
+            out["conservative_first"] = {"value": fallback["value"], "ms_per_step": fallback["ms_per_step"]}
+    sp_ = out.get("strong_scaling_point")
+    if sp_:
+        out["strong_point"] = {k: sp_[k] for k in ("N_total", "prop_steps_per_s", "ms_per_step", "exchange")}
+    out["prediction"] = prediction_scalars(out.get("scaling_prediction"))
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
     if dist is not None:
         sh.close()      # the library's communicator goes before the process group it was bootstrapped over
         dist.destroy_process_group()

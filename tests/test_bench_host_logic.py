@@ -152,3 +152,78 @@ def test_lattice_completion_knows_the_round_4_stencil_shapes():
     Hs = synth.grid_hamiltonian_2d(40, 120, diagonal=0.3)
     rp, col = L.lattice_fill_host(Hs.shape[0], Hs.shape[0], Hs.indptr, Hs.indices, min_blocks=16)
     assert int(rp[-1]) == Hs.nnz
+
+
+def _strings(o):
+    if isinstance(o, str):
+        yield o
+    elif isinstance(o, dict):
+        for v in o.values():
+            yield from _strings(v)
+    elif isinstance(o, (list, tuple)):
+        for v in o:
+            yield from _strings(v)
+
+
+def test_printed_line_is_compact_and_carries_the_gate_keys(capsys, tmp_path, monkeypatch):
+    """the driver reads the LAST stdout line; round 4's 36 KB line defeated it.  The canned measurement is
+    that very record (profiles/r04/bench_line.json, every extras point and the prediction table included)."""
+    import json
+    b = _bench()
+    with open(os.path.join(ROOT, "profiles", "r04", "bench_line.json")) as f:
+        full = json.load(f)
+    assert len(json.dumps(full)) > 30000
+    monkeypatch.setattr(b, "ROOT", str(tmp_path))       # the sidecar goes next to the script: not into the repo from a test
+    full["prediction"] = b.prediction_scalars(full["scaling_prediction"])
+    b.emit(full)
+    lines = capsys.readouterr().out.strip().splitlines()
+    text = lines[-1]
+    assert len(text) < b.LINE_LIMIT == 4096
+    line = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "degraded"):
+        assert k in line, k
+    assert line["value"] == float(f"{full['value']:.6g}") and line["n_gpus"] == 1
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us", "unstable"):
+        assert k in line["roofline"], k
+    assert 0.0 < line["roofline"]["frac"] <= 1.0 and line["roofline"]["bound"] == "hbm"
+    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] == 1 and line["cpu_baseline"]["kind"] == "port"
+    assert "workload" in line["config"] and line["config"]["device_format"]
+    assert all(len(s) <= 160 for s in _strings(line)), max(_strings(line), key=len)
+    # one pair per extras point; the other stdout lines are the short EXTRA ones
+    assert set(line["points"]) == set(full["extras"]) and line["points"]["c3_newton"][0] == float(f"{full['extras']['c3_newton']['ms_per_step']:.4g}")
+    assert all(ln.startswith("EXTRA ") and len(ln) < 200 for ln in lines[:-1]) and len(lines) - 1 == len(full["extras"])
+    # the complete record went to the sidecar
+    with open(tmp_path / b.EXTRAS_FILE) as f:
+        assert json.load(f)["extras"].keys() == full["extras"].keys()
+
+
+def test_printed_line_of_a_multi_gpu_and_a_c5_record_stays_under_the_limit(capsys, tmp_path, monkeypatch):
+    import json
+    b = _bench()
+    monkeypatch.setattr(b, "ROOT", str(tmp_path))
+    with open(os.path.join(ROOT, "profiles", "r04", "bench_line.json")) as f:
+        full = json.load(f)
+    # what a --gpus 8 record adds: long parallelism prose, the strong point, the all-gather form, the prediction, the first measurement
+    full.update(n_gpus=8, extras=None, cpu_baseline=None, cpu_baseline_all_cores=None)
+    full["config"]["parallelism"] = "row-partitioned x8, " + "x" * 700
+    full["config"]["parallelism_short"] = "row-partitioned x8, exchange=halo, schedule=overlap, driver=native (own RCCL communicator)"
+    full["strong_point"] = {"N_total": 1 << 20, "prop_steps_per_s": 2100.0, "ms_per_step": 0.476, "exchange": "halo"}
+    full["allgather_form"] = {"us_per_term": 310.2, "blocks_per_s": 1664.0, "driver": "native"}
+    full["conservative_first"] = {"value": 3000.0, "ms_per_step": 5.3}
+    full["prediction"] = b.prediction_scalars(b.scaling_prediction_static(31))
+    b.emit(full)
+    line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert len(json.dumps(line, separators=(",", ":"))) < 4096 and line["cpu_baseline"] is None
+    assert line["allgather_form"]["us_per_term"] == 310.2 and line["strong_point"]["prop_steps_per_s"] == 2100.0
+    assert all(len(s) <= 160 for s in _strings(line))
+    with open(os.path.join(ROOT, "profiles", "r04", "bench_line_config_c5.json")) as f:
+        c5 = json.load(f)
+    b.emit(c5)
+    line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert len(json.dumps(line)) < 4096 and line["roofline"]["frac"] > 0 and all(len(s) <= 160 for s in _strings(line))
+    # a record that would still be too long loses its optional parts, never its gate keys
+    full["extras"] = {f"point_{i}_{'y' * 60}": {"us_per_term": 1.0, "frac": 0.5} for i in range(80)}
+    b.emit(full)
+    line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert "points" not in line and line["roofline"]["frac"] > 0 and len(json.dumps(line, separators=(",", ":"))) < 4096

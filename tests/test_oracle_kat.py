@@ -13,7 +13,8 @@ import pytest
 import scipy.linalg as sla
 import scipy.sparse as sp
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 from oracle import qp_oracle as qo  # noqa: E402
 import qprop_amd.synth as synth  # noqa: E402
 
@@ -320,3 +321,83 @@ def test_synthetic_hermitian():
     psi = synth.random_state(256)
     assert abs(np.linalg.norm(psi) - 1) < 1e-14
     assert np.array_equal(synth.random_state(256, row_begin=10, row_end=20), psi[10:20])
+
+
+# ---- the C port (oracle/cheby_ref.c) is the checker of the full-size GPU tests: pin it too ---------------------------
+# test_full_size_properties (C2), the C4 / C5 tests and bench.py's l2_diff compare the device with
+# ref_c.cheby_csc / ChebyCsrOmp, and nothing compared THOSE with the NumPy oracle, a fixture or mpmath.
+
+def _c_port_cases():
+    import scipy.sparse as sp_
+    rng = np.random.default_rng(20261004)
+    f = np.load(os.path.join(ROOT, "tests", "golden", "F3_cheby_c2_n256.npz"))
+    H3 = sp_.csr_matrix((f["vals"], f["col"], f["rowptr"]), shape=(256, 256)) if "vals" in f.files else None
+    cases = []
+    if H3 is not None:
+        cases.append(("F3 N=256 (the C2 generator)", H3, f["psi0"], float(f["Delta"]), float(f["E_min"])))
+    N = 4096
+    rp, col, vals = synth.hermitian_offsets_csr(N, offsets=(1, 2, 3, 4, 16, 32, 48, 64))
+    cases.append(("N=4096 banded", synth.to_scipy(rp, col, vals, N), synth.random_state(N), 20.0, -10.0))
+    # ragged: rows of very different lengths (incl. empty ones), a real diagonal, Hermitian by construction
+    Nr = 777
+    lens = rng.integers(0, 40, Nr)
+    lens[rng.integers(0, Nr, 60)] = 0
+    rows = np.repeat(np.arange(Nr), lens)
+    cols = rng.integers(0, Nr, rows.size)
+    A = sp_.coo_matrix((rng.standard_normal(rows.size) + 1j * rng.standard_normal(rows.size), (rows, cols)), shape=(Nr, Nr)).tocsr()
+    Hr = (A + A.getH()).tocsr() + sp_.diags(rng.standard_normal(Nr)).tocsr()
+    Hr.sum_duplicates()
+    Hr.sort_indices()
+    bound = float(abs(Hr).sum(axis=1).max())
+    cases.append(("ragged random Hermitian N=777", Hr, _rand_state(Nr, rng), 2.0 * bound, -bound))
+    return cases
+
+
+def test_c_port_matches_the_numpy_oracle():
+    """ref_c.cheby_csc (serial CSC, the reference's operation order: src/cheby.jl:171-211) and ref_c.ChebyCsrOmp.step (the
+    all-cores CSR variant) against qo.cheby: three operators, dt = +0.7 and -0.7, 3 steps each, < 1e-13 after every step."""
+    from oracle import ref_c
+    for name, H, psi0, Delta, E_min in _c_port_cases():
+        H = H.tocsr()
+        H.sort_indices()
+        Hc = H.tocsc()
+        Hc.sort_indices()
+        for dt in (0.7, -0.7):
+            wrk = qo.ChebyWrk(psi0, Delta, E_min, abs(dt))
+            a = wrk.coeffs[:wrk.n_coeffs].copy()
+            ref, c_csc = psi0.copy(), psi0.copy()
+            omp = ref_c.ChebyCsrOmp(H.indptr, H.indices, H.data, psi0)
+            for k in range(3):
+                qo.cheby(ref, H, dt, wrk)
+                ref_c.cheby_csc(Hc.indptr, Hc.indices, Hc.data, c_csc, a, Delta, E_min, dt)
+                omp.step(a, Delta, E_min, dt)
+                assert np.linalg.norm(c_csc - ref) < 1e-13, (name, dt, k, "serial CSC")
+                assert np.linalg.norm(omp.psi() - ref) < 1e-13, (name, dt, k, "OpenMP CSR")
+            omp.close()
+            one = psi0.copy()
+            ref_c.cheby_csr_omp(H.indptr, H.indices, H.data, one, a, Delta, E_min, dt)
+            single = qo.cheby(psi0.copy(), H, dt, qo.ChebyWrk(psi0, Delta, E_min, abs(dt)))
+            assert np.linalg.norm(one - single) < 1e-13, (name, dt, "one-shot OpenMP CSR")
+
+
+def test_c_port_matches_50_digit_arithmetic():
+    """The C port against exp(-i H dt) psi in 50-digit arithmetic (mpmath) at N = 24: what test/test_cheby.jl:24-47 compares
+    with, independent of NumPy and of the double-precision oracle."""
+    pytest.importorskip("mpmath")
+    from oracle import qp_oracle_mp as qmp
+    from oracle import ref_c
+    rng = np.random.default_rng(5)
+    N = 24
+    X = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
+    Hd = (X + X.conj().T) / 2
+    Hd[np.abs(Hd) < 0.6] = 0.0            # sparse, still Hermitian (|.| is symmetric)
+    H = sp.csr_matrix(Hd)
+    ev = np.linalg.eigvalsh(Hd)
+    Delta, E_min = float(1.02 * (ev[-1] - ev[0])), float(ev[0] - 0.01 * (ev[-1] - ev[0]))
+    psi0 = _rand_state(N, rng)
+    for dt in (0.4, -0.4):
+        a = qo.cheby_coeffs(Delta, abs(dt))
+        Hc = H.tocsc()
+        got = ref_c.cheby_csc(Hc.indptr, Hc.indices, Hc.data, psi0.copy(), a, Delta, E_min, dt)
+        exact = np.array([complex(z) for z in qmp.expm_apply(Hd, psi0, dt)])
+        assert np.linalg.norm(got - exact) < 1e-12, dt

@@ -226,6 +226,13 @@ int launch_colblock_gather(hipStream_t s, const ColBlockPlan& P, const double2* 
 // the formats whose value array is in CSR order (rowptr / cols / vals[p])
 inline bool csr_layout(int format) { return format == QP_FMT_CSR || format == QP_FMT_DENSE; }
 int spmv_grid_size(const DevMatrix& A);
+// dense row-sum kernel (kernels_dense.hip): rows per wavefront and the grid that follows from it -- shared with spmv_grid_size,
+// which sizes the per-workgroup partials of check_normalization
+inline int dense_gemv_rows_per_wave(int64_t nrows) { return nrows >= 16384 ? 4 : 1; }
+inline int dense_gemv_grid(int64_t nrows) {
+  const int64_t per_wg = (int64_t)(kThreads / 64) * dense_gemv_rows_per_wave(nrows);
+  return (int)((nrows + per_wg - 1) / per_wg);
+}
 // Developer knobs for A/B measurements.  Every context carries its own copy (qp_ctx::tun, set with
 // qp_ctx_tuning_set); qp_tuning_set only changes the defaults that contexts created afterwards start
 // from, so handles driven from different threads never observe each other's switches.

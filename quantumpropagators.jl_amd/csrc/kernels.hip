@@ -334,6 +334,9 @@ int* tuning_field(Tuning& t, const char* key) {
 }
 
 int spmv_grid_size(const DevMatrix& A) {
+  // (dense: one wavefront per R rows -- the grid launch_dense_gemv uses; the per-workgroup check triples of check_normalization
+  // are sized and reduced with THIS count, so the two must be one expression)
+  if (A.format == QP_FMT_DENSE) return dense_gemv_grid(A.nrows);
   if (A.format == QP_FMT_RBCSR || A.format == QP_FMT_HRB) return (int)((A.nblocks + kThreads / 64 - 1) / (kThreads / 64));
   const int64_t threads = A.nrows * A.lanes_per_row;
   return (int)((threads + kThreads - 1) / kThreads);

@@ -81,10 +81,9 @@ static int launch_dense_gemv(hipStream_t s, const DevMatrix& A, const double2* x
   // R rows per wavefront once there are rows to spare (x is then read once per R rows: the wave's x loads go through the
   // same L1 queue as its matrix loads); nontemporal matrix loads once the operator is beyond what the caches can hold
   // between two terms anyway
-  const int R = A.nrows >= 16384 ? 4 : 1;
+  const int R = dense_gemv_rows_per_wave(A.nrows);
   const bool nt = (double)A.nrows * (double)A.ncols * (A.vals_r ? 8.0 : 16.0) > 224.0 * 1024 * 1024;
-  const int64_t per_wg = (int64_t)(kThreads / 64) * R;
-  const dim3 grid((unsigned)((A.nrows + per_wg - 1) / per_wg));
+  const dim3 grid((unsigned)dense_gemv_grid(A.nrows));
 #define QP_DENSE_GEMV(RR, NTF)                                                                                         \
   do {                                                                                                                 \
     if (A.vals_r)                                                                                                      \

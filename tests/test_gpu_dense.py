@@ -259,3 +259,39 @@ def test_dense_batched_full_size_properties(ctx):
     assert np.linalg.norm(one.numpy() - (0.6 * got[:, 3] + 0.8j * got[:, 5])) < 1e-11
     L.cheby_batched(panel, op, -dt, wrk, batch)
     assert np.linalg.norm(panel.numpy().reshape(N, batch) - states) < TOL * np.sqrt(batch)
+
+
+@pytest.mark.parametrize("N", [5, 8, 20, 32, 200, 16384 + 37])
+def test_dense_check_normalization_partials_match_the_dense_grid(ctx, N):
+    """the per-workgroup triples of check_normalization (src/cheby.jl:194-200) were sized with the sparse
+    kernels' grid, not the dense row-sum kernel's -- too small for N <= 32 (lanes per row 8 / 16 / 32), four times too large
+    from N = 16384 (four rows per wavefront).  A correct window must pass and leave the oracle's result; a window that does
+    not hold the spectrum must raise, as the oracle does."""
+    rng = np.random.default_rng(100 + N)
+    if N < 1000:
+        H = synth.dense_hermitian(N, rho=3.0, rng=rng)
+        bound = 3.0
+    else:       # (a large dense Hermitian matrix built cheaply: real symmetric low-rank-plus-diagonal, every entry non-zero)
+        u = rng.standard_normal(N) / np.sqrt(N)
+        H = np.outer(u, u).astype(np.complex128) + np.diag(rng.uniform(-1, 1, N))
+        bound = 1.0 + float(u @ u)
+    op = L.Operator(ctx, [L.Matrix.from_dense(ctx, H)])
+    assert op.format == L.FMT_DENSE
+    psi0 = _rand_state(N, rng)
+    dt = 0.4
+    wrk = L.ChebyWrk(ctx, N, 2.2 * bound, -1.1 * bound, dt)
+    psi = L.State(ctx, data=psi0)
+    for _ in range(3):      # (repeated: partials left over from an earlier step must not leak into the next reduction)
+        L.cheby(psi, op, dt, wrk, check_normalization=True)
+    ref = psi0.copy()
+    owrk = qo.ChebyWrk(psi0, 2.2 * bound, -1.1 * bound, dt)
+    for _ in range(3):
+        qo.cheby(ref, H, dt, owrk, check_normalization=True)
+    assert np.linalg.norm(psi.numpy() - ref) < TOL
+    # one-sided violation: the whole spectrum lies below the window
+    bad = L.ChebyWrk(ctx, N, 0.2 * bound, 2.0 * bound, dt)
+    psi.upload(psi0)
+    with pytest.raises(L.QPAssertionError, match="Incorrect normalization"):
+        L.cheby(psi, op, dt, bad, check_normalization=True)
+    with pytest.raises(AssertionError, match="Incorrect normalization"):
+        qo.cheby(psi0.copy(), H, dt, qo.ChebyWrk(psi0, 0.2 * bound, 2.0 * bound, dt), check_normalization=True)

@@ -186,6 +186,16 @@ int qp_operator_layout_info(const qp_operator* op, int64_t out[5]);
  * block of columns -- row XOR mask, the structure of qubit-register Hamiltonians); out[4..7] = the same for the lower sections
  * of a Hermitian-packed operator.  All zero for the CSR-ordered formats. */
 int qp_operator_encoding_info(const qp_operator* op, int64_t out[8]);
+/* The value-dictionary mirror of a row-block operator whose 64-row blocks hold at most 256 distinct values each (the reference's
+ * generators are sums of a few structured terms, src/generators.jl:634-645: spin-chain couplings, constant hopping amplitudes):
+ * one byte per stored entry + per block a table of its distinct values (shared between blocks with the same values); with
+ * several terms the table entry is the tuple of the terms' values and evaluate! (src/generators.jl:757-766) recombines the
+ * tables, not a value plane.  The reconstruction is exact (qp_operator_get_csr returns the decoded values) and the mat-vec
+ * is bit-identical to the uncoded one.  out[0] = 1 when the mat-vec kernels read the mirror, out[1] = table entries,
+ * out[2] = distinct tables, out[3] = bytes a term streams for the values through it (codes + tables), out[4] = bytes of the
+ * value plane it replaces, out[5] = why there is none (0: there is one; 1: not a plain row-block operator; 2: a block with more
+ * than 256 distinct values; 3: no saving; 4: knob value_dict = 0; 5: the column-blocked mirror is in use). */
+int qp_operator_value_encoding_info(const qp_operator* op, int64_t out[6]);
 /* What creating the operator cost on the host (union pattern, lattice completion, value planes, Hermitian check, format
  * choice, encoding, upload): out[0] = ms of the latest build (the creation itself, or a later re-layout), out[1] = ms of all builds, out[2] = re-layouts after creation -- evaluate! (src/generators.jl:757-766)
  * only rewrites coefficients, but a complex coefficient on a Hermitian-packed operator forces ONE rebuild as plain

@@ -59,6 +59,8 @@ struct DevMatrix {
   const struct WalkPlan* walk = nullptr;
   // column-blocked mirror of an operator with irregular columns (kernels_colblock.hip); used for whole-operator launches
   const struct ColBlockPlan* cb = nullptr;
+  // value-dictionary mirror of a row-block operator whose blocks hold few distinct values (kernels_coded.hip)
+  const struct CodedVals* cv = nullptr;
   // QP_FMT_MATFREE: no stored entries; y = beta y + alpha A x is delegated to the owner
   // (engine_liouville.hip), and the Chebyshev term runs it followed by an unfused epilogue
   void* matfree = nullptr;
@@ -119,6 +121,25 @@ struct ColBlockPlan {
   int64_t* map = nullptr;       // device [nnz]: position in the operator's value array (-(position) - 1: its complex conjugate)
   double2* vals = nullptr;      // device [nnz]: the current values in mirror order (refreshed when the operator's values change)
   double* vals_r = nullptr;     // device [nnz]: their real parts, streamed instead when every value is real
+  int use_real = 0;
+};
+// ---- value-dictionary mirror (kernels_coded.hip) ------------------------------------------------------------------------
+// The reference's typical generator is a sum of a few structured terms (src/generators.jl:634-645): a spin chain's couplings, a
+// grid's hopping amplitudes -- a handful of distinct numbers, stored 16 (or 8) bytes per entry.  When every 64-row block of a
+// row-block operator holds at most 256 distinct TUPLES (value in term 1, .., value in term L) over its stored positions, the
+// operator gets a mirror: one byte per stored position (`codes`, quad-packed like the column sections: byte j of dword
+// (bptr[b] >> 2) + 64 q + lane = slot 4 q + j of that lane's row) and per block a table of its tuples -- tables with the same
+// content shared between blocks.  The mat-vec kernels read the COMBINED table tab[(tptr[b] >> 9) + code] = sum_l c_l tuple_l: the
+// same arithmetic on the same numbers as the value plane they replace (bit-identical results), 1 B + a cached table line per
+// entry instead of 16 B, and evaluate! (src/generators.jl:757-766) rewrites the tables, not a plane.
+struct CodedVals {
+  int valid = 0;
+  int64_t ntab = 0;               // table entries (all blocks, shared tables counted once)
+  int64_t ntables = 0;            // distinct tables
+  uint8_t* codes = nullptr;       // device [stored]
+  int64_t* tptr = nullptr;        // device [nblocks]: (first table entry of the block << 9) | its number of entries (1 .. 256)
+  double2* tab = nullptr;         // device [ntab]: the current combined table (the only term's own table when there is one term, scale 1)
+  double* tab_r = nullptr;        // device [ntab]: its real parts, read instead when every value is real
   int use_real = 0;
 };
 constexpr int kCbMaxTilesPerWave = 8;
@@ -218,6 +239,11 @@ int launch_hrb_walk_cheby(hipStream_t s, const DevMatrix& A, const double2* x, c
 int launch_dense_gemv_cheby(hipStream_t s, const DevMatrix& A, const double2* x, const ChebyEpi& e, Stats* st);
 int launch_dense_gemv_plain(hipStream_t s, const DevMatrix& A, const double2* x, const PlainEpi& e, Stats* st);
 int launch_dense_zgemm_cheby(hipStream_t s, const DevMatrix& A, const double2* X, int batch, const ChebyEpi& e, Stats* st);
+// kernels_coded.hip: the row-block mat-vec through the value-dictionary mirror (A.cv valid); grid / row-set arguments as launch_spmv
+int launch_rbcsr_coded_cheby(hipStream_t s, const DevMatrix& A, const double2* x, const ChebyEpi& e, int64_t nblk,
+                             const int32_t* bmap, const SyncArgs& sy, bool wide);
+int launch_rbcsr_coded_plain(hipStream_t s, const DevMatrix& A, const double2* x, const PlainEpi& e, int64_t nblk,
+                             const int32_t* bmap, const SyncArgs& sy);
 // kernels_colblock.hip: *launched = false when the mirror does not apply to this launch (the caller then takes the format's kernel)
 int launch_colblock_cheby(hipStream_t s, const DevMatrix& A, const double2* x, const ChebyEpi& e, const Tuning& tun, bool* launched);
 int launch_colblock_plain(hipStream_t s, const DevMatrix& A, const double2* x, const PlainEpi& e, const Tuning& tun, bool* launched);
@@ -280,6 +306,7 @@ struct Tuning {
   int walk_waves = 0;         // strip walk: wavefronts the walk is cut into (0: 768 for an operator that fits the Infinity Cache, else 8 per CU on every CU the edge workgroups leave free -- 1856 for the headline lattice --, or 2048 with the edge blocks inside the walk)
   int walk_reserve_cu = 8;    // strip walk as the interior launch of a split term: compute units left free (beyond the edge workgroups') for the boundary launch and the collective's kernel
   int walk_wg = 0;            // strip walk: wavefronts per workgroup (0: 4 for an operator that fits the Infinity Cache, else 8; or 8 / 4 / 2)
+  int value_dict = 1;         // value-dictionary mirror of row-block operators with few distinct values per block (0: never built / used)
   int walk_nt = -1;           // strip walk: nontemporal accesses (-1: the matrix values when the operator does not fit the Infinity Cache; bit 0 matrix values; bits 1, 2: vector loads, stores -- measurement variants of the headline shape)
   int walk_edge_steps = 4;    // strip walk: a wavefront that also takes an edge block walks this many steps less (a block on the per-block path is three dependent rounds of loads; a step of the walk takes about one)
   int walk_dbg = 0;           // strip walk, measurements only: 1 = in-wave edge block after the walk instead of before it, 2 = edge blocks skipped (WRONG results), 4 = never as workgroups of their own

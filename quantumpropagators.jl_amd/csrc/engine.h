@@ -70,6 +70,11 @@ struct qp_operator {
   qp::SpmmWalkPlan spmm_walk;     // strip-walk plan of the batched term, built on first use
   bool spmm_walk_built = false;
   qp::ColBlockPlan cb;            // column-blocked mirror of an operator with irregular columns (A.cb points here when valid)
+  qp::CodedVals cv;               // value-dictionary mirror (A.cv points here when valid): codes, per-block tables
+  std::vector<double2*> cv_tplanes;   // device: per term the tuple component of every table entry [cv.ntab] (static)
+  double2** cv_tplanes_dev = nullptr;
+  double2* cv_tab_comb = nullptr;     // device: combined table, allocated on the first non-trivial coefficient set
+  int cv_reason = 0;                  // why there is no mirror: 0 built / not tried, 1 format, 2 a block with > 256 tuples, 3 no saving, 4 knob off
   double cb_line_share = 0.0;     // what decided: share of a row block's gathers that pull a line of their own (sampled)
   double build_ms = 0, build_ms_total = 0;   // host time of the latest / of all device layout builds
   int64_t n_lattice_fill = 0;               // explicit zeros that complete a lattice operator's rows (engine_plans.hip: lattice_fill)

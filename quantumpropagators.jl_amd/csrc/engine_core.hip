@@ -7,6 +7,8 @@
 #include <thread>
 #include <system_error>
 #include <numeric>
+#include <atomic>
+#include <unordered_map>
 
 #include "engine_host.h"
 
@@ -383,6 +385,17 @@ static int operator_free_device(qp_operator* op) {
   if (op->cb.vals_r) (void)hipFree(op->cb.vals_r);
   op->cb = qp::ColBlockPlan();
   op->A.cb = nullptr;
+  for (auto p : op->cv_tplanes) (void)hipFree(p);
+  op->cv_tplanes.clear();
+  if (op->cv_tplanes_dev) (void)hipFree(op->cv_tplanes_dev);
+  if (op->cv_tab_comb) (void)hipFree(op->cv_tab_comb);
+  if (op->cv.codes) (void)hipFree(op->cv.codes);
+  if (op->cv.tptr) (void)hipFree(op->cv.tptr);
+  if (op->cv.tab_r) (void)hipFree(op->cv.tab_r);
+  op->cv_tplanes_dev = nullptr;
+  op->cv_tab_comb = nullptr;
+  op->cv = qp::CodedVals();
+  op->A.cv = nullptr;
   if (op->m_rowptr) (void)hipFree(op->m_rowptr);
   if (op->m_cols) (void)hipFree(op->m_cols);
   if (op->m_map) (void)hipFree(op->m_map);
@@ -871,12 +884,120 @@ static int operator_build_device_impl(qp_operator* op, int format, const std::ve
   return QP_OK;
 }
 
+// Value-dictionary mirror (device.h: CodedVals) of a row-block operator: per 64-row block the distinct tuples
+// (value in term 0, .., value in term L - 1) over its stored positions (pads: the all-zero tuple), sorted bytewise; one code byte
+// per stored position; tables with the same content shared.  Built when every block has at most 256 tuples and codes + tables
+// come to less than half of the value plane the mat-vec would stream instead.  Host index work (bit patterns, no arithmetic).
+static int build_coded_values(qp_operator* op, const std::vector<std::vector<cplx>>& planes_csr) {
+  qp_ctx* ctx = op->ctx;
+  DevMatrix& A = op->A;
+  op->cv_reason = 0;
+  if (ctx->tun.value_dict == 0) return op->cv_reason = 4, QP_OK;
+  if (A.format != QP_FMT_RBCSR || A.stored <= 0 || A.nblocks <= 0) return op->cv_reason = 1, QP_OK;
+  const auto& ur = op->u_rowptr;
+  const HostLayout& Lh = op->layout;
+  const int L = (int)planes_csr.size();
+  const int64_t nrows = A.nrows, nblocks = A.nblocks;
+  const size_t tb = sizeof(cplx) * (size_t)L;       // bytes of one tuple
+  std::vector<uint8_t> codes((size_t)A.stored, 0);
+  std::vector<std::string> tables((size_t)nblocks);  // block b's sorted distinct tuples, tb bytes each
+  std::atomic<bool> too_many{false};
+  parallel_rows(nblocks, [&](int64_t b0, int64_t b1) {
+    std::vector<char> ent;          // the block's tuples, position-major (slot, lane)
+    std::vector<int32_t> order, code_of;
+    for (int64_t b = b0; b < b1 && !too_many.load(std::memory_order_relaxed); ++b) {
+      const int64_t w = (Lh.bptr[b + 1] - Lh.bptr[b]) / kRB;
+      const int64_t npos = w * kRB;
+      ent.assign((size_t)npos * tb, 0);
+      for (int64_t l = 0; l < kRB; ++l) {
+        const int64_t r = b * kRB + l;
+        if (r >= nrows) break;
+        const int64_t len = ur[r + 1] - ur[r];
+        for (int64_t k = 0; k < len; ++k)
+          for (int t = 0; t < L; ++t)
+            std::memcpy(&ent[(size_t)(k * kRB + l) * tb + (size_t)t * sizeof(cplx)], &planes_csr[(size_t)t][(size_t)(ur[r] + k)], sizeof(cplx));
+      }
+      // distinct tuples: sort the positions by tuple bytes, walk the runs
+      order.resize((size_t)npos);
+      for (int64_t i = 0; i < npos; ++i) order[(size_t)i] = (int32_t)i;
+      std::sort(order.begin(), order.end(), [&](int32_t a, int32_t c) {
+        return std::memcmp(&ent[(size_t)a * tb], &ent[(size_t)c * tb], tb) < 0;
+      });
+      code_of.assign((size_t)npos, 0);
+      std::string& T = tables[(size_t)b];
+      T.clear();
+      int n = 0;
+      bool fits = true;
+      for (int64_t i = 0; i < npos; ++i) {
+        const int32_t p = order[(size_t)i];
+        if (i == 0 || std::memcmp(&ent[(size_t)p * tb], &ent[(size_t)order[(size_t)i - 1] * tb], tb) != 0) {
+          if (n == 256) {
+            fits = false;
+            break;
+          }
+          T.append(&ent[(size_t)p * tb], tb);
+          ++n;
+        }
+        code_of[(size_t)p] = n - 1;
+      }
+      if (!fits) {
+        too_many.store(true, std::memory_order_relaxed);
+        break;
+      }
+      // codes in the quad-packed layout of the column sections (rb_quad_pos): byte (k & 3) of dword (k >> 2) * 64 + lane
+      for (int64_t k = 0; k < w; ++k)
+        for (int64_t l = 0; l < kRB; ++l)
+          codes[(size_t)(Lh.bptr[b] + (k >> 2) * (4 * kRB) + l * 4 + (k & 3))] = (uint8_t)code_of[(size_t)(k * kRB + l)];
+    }
+  }, 64);
+  if (too_many.load()) return op->cv_reason = 2, QP_OK;
+  // shared tables: first block with a content owns it
+  std::unordered_map<std::string, int64_t> where;
+  std::vector<int64_t> tptr((size_t)nblocks);
+  std::string all;
+  for (int64_t b = 0; b < nblocks; ++b) {
+    auto it = where.find(tables[(size_t)b]);
+    if (it == where.end()) {
+      it = where.emplace(tables[(size_t)b], (int64_t)(all.size() / tb)).first;
+      all += tables[(size_t)b];
+    }
+    tptr[(size_t)b] = (it->second << 9) | (int64_t)(tables[(size_t)b].size() / tb);   // first entry << 9 | entries (<= 256)
+    std::string().swap(tables[(size_t)b]);
+  }
+  const int64_t ntab = (int64_t)(all.size() / tb);
+  // what a term streams: a byte per stored position + (a share of) the tables, against 16 (8: real) bytes per position
+  const double coded_bytes = (double)A.stored + 16.0 * (double)ntab, plain_bytes = (op->planes_real ? 8.0 : 16.0) * (double)A.stored;
+  if (coded_bytes > 0.5 * plain_bytes) return op->cv_reason = 3, QP_OK;
+  qp::CodedVals& C = op->cv;
+  C.ntab = ntab;
+  C.ntables = (int64_t)where.size();
+  QP_CHECK(dev_alloc(&C.codes, codes.size()));
+  QP_HIP(hipMemcpy(C.codes, codes.data(), codes.size(), hipMemcpyHostToDevice));
+  QP_CHECK(dev_alloc(&C.tptr, tptr.size()));
+  QP_HIP(hipMemcpy(C.tptr, tptr.data(), tptr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+  std::vector<cplx> col((size_t)ntab);
+  for (int t = 0; t < L; ++t) {
+    for (int64_t e = 0; e < ntab; ++e) std::memcpy(&col[(size_t)e], &all[(size_t)e * tb + (size_t)t * sizeof(cplx)], sizeof(cplx));
+    double2* dp = nullptr;
+    QP_CHECK(dev_alloc(&dp, (size_t)ntab));
+    op->cv_tplanes.push_back(dp);
+    QP_HIP(hipMemcpy(dp, col.data(), (size_t)ntab * sizeof(double2), hipMemcpyHostToDevice));
+  }
+  QP_CHECK(dev_alloc(&op->cv_tplanes_dev, (size_t)L));
+  QP_HIP(hipMemcpy(op->cv_tplanes_dev, op->cv_tplanes.data(), (size_t)L * sizeof(double2*), hipMemcpyHostToDevice));
+  C.tab = op->cv_tplanes[0];
+  C.valid = 1;
+  A.cv = &op->cv;
+  return QP_OK;
+}
+
 // ... timed: format conversion, encoding and upload are host work at qp_operator_create (and once more if a complex
 // coefficient forces a Hermitian-packed operator back to plain row blocks); qp_operator_build_info reports it
 static int operator_build_device(qp_operator* op, int format, const std::vector<std::vector<cplx>>& planes_csr) {
   const auto t0 = std::chrono::steady_clock::now();
   int rc = operator_build_device_impl(op, format, planes_csr);
   if (rc == QP_OK) rc = build_colblock(op);
+  if (rc == QP_OK && !(op->cb.valid && op->ctx->tun.colblock != 0)) rc = build_coded_values(op, planes_csr);
   op->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   op->build_ms_total += op->build_ms;
   op->n_builds++;
@@ -1148,6 +1269,20 @@ static int operator_refresh(qp_operator* op) {
     op->real_of = nullptr;
   }
   op->A.vals_r = want_real ? op->real_vals : nullptr;
+  if (op->cv.valid) {   // the value-dictionary mirror: the same combination on the table entries instead of the stored positions
+    qp::CodedVals& C = op->cv;
+    if (want_real && !C.tab_r) QP_CHECK(dev_alloc(&C.tab_r, (size_t)C.ntab));
+    if (op->nops == 1 && all_one) {
+      C.tab = op->cv_tplanes[0];
+      if (want_real) QP_CHECK(qp::launch_real_part(ctx->stream, C.tab_r, C.tab, C.ntab, &ctx->stats));
+    } else {
+      if (!op->cv_tab_comb) QP_CHECK(dev_alloc(&op->cv_tab_comb, (size_t)C.ntab));
+      QP_CHECK(qp::launch_combine_planes(ctx->stream, op->cv_tab_comb, op->cv_tplanes_dev, eff.data(), op->nops, C.ntab,
+                                         want_real ? C.tab_r : nullptr, &ctx->stats));
+      C.tab = op->cv_tab_comb;
+    }
+    C.use_real = want_real ? 1 : 0;
+  }
   if (op->cb.valid) {   // the column-blocked mirror follows the values (one gather pass per evaluate!)
     if (want_real && !op->cb.vals_r) QP_CHECK(dev_alloc(&op->cb.vals_r, (size_t)op->cb.nnz));
     op->cb.use_real = want_real ? 1 : 0;
@@ -1223,6 +1358,24 @@ int qp_operator_encoding_info(const qp_operator* op, int64_t out[8]) {
     out[(int)(Lh.cmeta[b] & 3)]++;
     if (A.format == QP_FMT_HRB) out[4 + (int)(Lh.lcmeta[b] & 3)]++;
   }
+  return QP_OK;
+}
+
+/* the value-dictionary mirror (device.h: CodedVals): out[0] = 1 when the mat-vec reads it, out[1] = table entries, out[2] = distinct
+   tables, out[3] = bytes a term streams for the values through it (codes + tables), out[4] = bytes of the value plane it replaces,
+   out[5] = why there is none (0: there is one, 1: not a plain row-block operator, 2: a block with more than 256 distinct values,
+   3: no saving, 4: knob value_dict off, 5: column-blocked mirror in use) */
+int qp_operator_value_encoding_info(const qp_operator* op, int64_t out[6]) {
+  if (!op || !out) return qp::fail(QP_E_BAD_ARG, "qp_operator_value_encoding_info: NULL argument");
+  for (int i = 0; i < 6; ++i) out[i] = 0;
+  const qp::CodedVals& C = op->cv;
+  const bool on = C.valid && op->ctx->tun.value_dict != 0;
+  out[0] = on ? 1 : 0;
+  out[1] = C.ntab;
+  out[2] = C.ntables;
+  out[3] = C.valid ? op->A.stored + (C.use_real ? 8 : 16) * C.ntab : 0;
+  out[4] = (op->A.vals_r ? 8 : 16) * op->A.stored;
+  out[5] = on ? 0 : (C.valid ? 4 : (op->cb.valid ? 5 : (op->cv_reason ? op->cv_reason : 1)));
   return QP_OK;
 }
 
@@ -1408,6 +1561,24 @@ int qp_operator_get_csr(qp_operator* op, int64_t* rowptr, int32_t* col, qp_c128*
   QP_HIP(hipStreamSynchronize(op->ctx->stream));
   std::vector<cplx> hv((size_t)std::max<int64_t>(A.stored, 1));
   QP_HIP(hipMemcpy(hv.data(), A.vals, (size_t)A.stored * sizeof(double2), hipMemcpyDeviceToHost));
+  if (op->cv.valid && op->ctx->tun.value_dict != 0) {
+    // the values the mat-vec really reads: table[tptr[block] + code], decoded back into the plane's positions (the
+    // reconstruction is exact: tests compare it with what was passed in)
+    const qp::CodedVals& C = op->cv;
+    std::vector<uint8_t> codes((size_t)A.stored);
+    std::vector<int64_t> tptr((size_t)A.nblocks);
+    std::vector<cplx> tab((size_t)C.ntab);
+    QP_HIP(hipMemcpy(codes.data(), C.codes, codes.size(), hipMemcpyDeviceToHost));
+    QP_HIP(hipMemcpy(tptr.data(), C.tptr, tptr.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+    QP_HIP(hipMemcpy(tab.data(), C.tab, tab.size() * sizeof(double2), hipMemcpyDeviceToHost));
+    const HostLayout& Lc = op->layout;
+    for (int64_t b = 0; b < A.nblocks; ++b) {
+      const int64_t w = (Lc.bptr[b + 1] - Lc.bptr[b]) / kRB;
+      for (int64_t k = 0; k < w; ++k)
+        for (int64_t l = 0; l < kRB; ++l)
+          hv[(size_t)(Lc.bptr[b] + k * kRB + l)] = tab[(size_t)((tptr[(size_t)b] >> 9) + codes[(size_t)(Lc.bptr[b] + (k >> 2) * (4 * kRB) + l * 4 + (k & 3))])];
+    }
+  }
   if (qp::csr_layout(A.format)) {
     std::vector<int64_t> rp(A.nrows + 1);
     std::vector<int32_t> hc((size_t)std::max<int64_t>(A.nnz, 1));

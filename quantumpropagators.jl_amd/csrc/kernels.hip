@@ -326,7 +326,7 @@ int* tuning_field(Tuning& t, const char* key) {
       {"spmm_nt", &Tuning::spmm_nt},             {"spmm_rows", &Tuning::spmm_rows},
       {"spmm_strip", &Tuning::spmm_strip},       {"spmm_rw", &Tuning::spmm_rw},
       {"hrb_walk", &Tuning::hrb_walk},           {"walk_waves", &Tuning::walk_waves},
-      {"walk_min_blocks", &Tuning::walk_min_blocks}, {"walk_dbg", &Tuning::walk_dbg}, {"walk_nt", &Tuning::walk_nt}, {"walk_wg", &Tuning::walk_wg}, {"walk_reserve_cu", &Tuning::walk_reserve_cu}, {"walk_edge_steps", &Tuning::walk_edge_steps}, {"split_spin_log2", &Tuning::split_spin_log2}, {"split_dbg", &Tuning::split_dbg}, {"spmm_walk", &Tuning::spmm_walk}, {"spmm_walk_waves", &Tuning::spmm_walk_waves},
+      {"walk_min_blocks", &Tuning::walk_min_blocks}, {"walk_dbg", &Tuning::walk_dbg}, {"walk_nt", &Tuning::walk_nt}, {"value_dict", &Tuning::value_dict}, {"walk_wg", &Tuning::walk_wg}, {"walk_reserve_cu", &Tuning::walk_reserve_cu}, {"walk_edge_steps", &Tuning::walk_edge_steps}, {"split_spin_log2", &Tuning::split_spin_log2}, {"split_dbg", &Tuning::split_dbg}, {"spmm_walk", &Tuning::spmm_walk}, {"spmm_walk_waves", &Tuning::spmm_walk_waves},
   };
   for (const Entry& e : table)
     if (std::strcmp(e.name, key) == 0) return &(t.*(e.field));
@@ -383,6 +383,18 @@ static int launch_spmv(hipStream_t s, const DevMatrix& A, const double2* x, cons
     nblk = rs->nmap;
     if (nblk == 0) return QP_OK;
     grid = (int)((nblk + kThreads / 64 - 1) / (kThreads / 64));
+  }
+  if (A.format == QP_FMT_RBCSR && A.cv && A.cv->valid && tun.value_dict != 0) {
+    // few distinct values per block: one byte + a cached table line per entry instead of the value (kernels_coded.hip)
+    int rcc;
+    if constexpr (std::is_same<Op, ChebyOp>::value) rcc = launch_rbcsr_coded_cheby(s, A, x, op.e, nblk, bmap, sy, wide_ok && tun.hrb_wg == 8);
+    else rcc = launch_rbcsr_coded_plain(s, A, x, op.e, nblk, bmap, sy);
+    if (rcc != QP_OK) return rcc;
+    if (st) {
+      st->n_launch++;
+      if (!rs || rs->count) st->n_matvec++;
+    }
+    return QP_OK;
   }
   if (A.format == QP_FMT_RBCSR) {
 #define QP_RB_CASE(VV)                                                                                   \

@@ -140,6 +140,7 @@ SIGNATURES = {
     "qp_operator_walk_long_pairs": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "qp_operator_walk_shape": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "qp_operator_encoding_info": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "qp_operator_value_encoding_info": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "qp_operator_evaluate_info": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "qp_operator_colblock_info": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "qp_lattice_fill_host": (C.c_int, [C.c_int64, C.c_int64, _i64p, _i32p, C.c_int, _i64p, _i32p, C.c_int64, C.POINTER(C.c_int64)]),
@@ -592,6 +593,16 @@ class Operator:
         check(self.lib.qp_operator_encoding_info(self._h, _ptr(out, _i64p)))
         names = ("int32", "int16", "stencil", "block_map")
         return {"upper": dict(zip(names, (int(v) for v in out[:4]))), "lower": dict(zip(names, (int(v) for v in out[4:])))}
+
+    def value_encoding_info(self):
+        """Value-dictionary mirror: one byte + a shared table line per stored entry (include/qprop.h: qp_operator_value_encoding_info)."""
+        out = np.zeros(6, dtype=np.int64)
+        check(self.lib.qp_operator_value_encoding_info(self._h, _ptr(out, _i64p)))
+        why = ("", "not a plain row-block operator", "a block with more than 256 distinct values", "no saving", "knob value_dict = 0",
+               "column-blocked mirror in use")
+        d = dict(zip(("valid", "table_entries", "tables", "coded_bytes", "plane_bytes"), (int(v) for v in out[:5])))
+        d["reason"] = why[int(out[5])] if 0 <= int(out[5]) < len(why) else str(int(out[5]))
+        return d
 
     def colblock_info(self):
         """Column-blocked mirror of an operator with irregular columns (include/qprop.h: qp_operator_colblock_info)."""

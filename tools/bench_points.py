@@ -160,6 +160,10 @@ def cheby_layout_bytes(op, rows, ncols, nnz, coeffs, real_copy=False):
             slots = walk.get("upper_slots") or (walk["diag"] + walk["near"] + walk["far"] + len(walk.get("long_distances", [])))
             stored = 64.0 * slots * (walk["end_block"] - walk["first_block"]) + lay["stored"] * share
         matrix = vbytes * stored + index
+        ve = op.value_encoding_info() if fmt == L.FMT_RBCSR else {"valid": 0}
+        lay["value_dictionary"] = ve if ve["valid"] else None
+        if ve["valid"]:      # the value-dictionary mirror: a byte per stored position + the blocks' (shared) tables
+            matrix = ve["coded_bytes"] + index
     sched = L.acc_schedule(coeffs)
     vec = 0.0
     updated = False
@@ -184,6 +188,8 @@ def cheby_kernel_name(op):
         return "hrb_walk_kernel"
     if op.colblock_info()["valid"] and op.ctx.tuning_get("colblock") != 0:
         return "colblock_spmv_kernel"
+    if op.format == L.FMT_RBCSR and op.value_encoding_info()["valid"]:
+        return "rbcsr_coded_spmv_kernel"
     return {L.FMT_CSR: "csr_spmv_kernel", L.FMT_RBCSR: "rbcsr_spmv_kernel", L.FMT_HRB: "hrb_spmv_kernel"}[op.format]
 
 
@@ -269,6 +275,7 @@ def measure_cheby(ctx, pattern="banded", log2n=20, fmt="auto", steps=10, warmup=
            "encodings": {"row_blocks": lay["blocks"], "stencil_upper_blocks": lay["stencil_upper_blocks"],
                          "stencil_lower_blocks": lay["stencil_lower_blocks"], "index_bytes": lay["index_bytes"]},
            "column_blocked_mirror": op.colblock_info(), "column_encodings": op.encoding_info(),
+           "value_dictionary": op.value_encoding_info(),
            "strip_walk_reason": op.walk_reason()[1],      # "ok", or why this operator's term is not the strip walk (qp_operator_walk_reason)
            "norm_drift": abs(psi.norm() - 1.0)}
     if grid:

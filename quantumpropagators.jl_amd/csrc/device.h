@@ -230,6 +230,13 @@ int launch_spmv_plain(hipStream_t s, const DevMatrix& A, const double2* x, const
 // epilogue; partials in the multidot's layout.  *launched = false: no instance (format, column index): nothing was done
 int launch_arnoldi_matvec_dots(hipStream_t s, const DevMatrix& A, const double2* x, const PlainEpi& e, const double2* Q,
                                int64_t ldq, int j, double2* partials, bool* launched, Stats* st);
+// kernels_onepass.hip: the sweep that reads the basis once per column (knob arnoldi_mode = 2)
+bool arnoldi_onepass_fits(const DevMatrix& A, int m, int nvec);
+int op_part_slots(int nvec);
+int launch_arnoldi_onepass_sweep(hipStream_t s, const DevMatrix& A, const double2* start, double s0, double2* Q, int64_t ldq,
+                                 double2* const a_buf[2], int m, int nvec, double2* const part[2], double2* gram, double2* hhat,
+                                 double* svals, double* nu_dev, double dt, double2* hess_map, double* norms_map, double* nu_map,
+                                 unsigned* flags_map, unsigned flag_value, Stats* st);
 // the strip walk for the fused Chebyshev term of a whole Hermitian-packed lattice operator; *launched = false when the
 // plan's shape has no kernel instance (the caller then takes the per-block kernel)
 bool walk_shape_supported(int nn, int K, int z0, int xl = 0, int fd = 0);   // is there a kernel instance for this stencil shape?
@@ -266,6 +273,7 @@ struct Tuning {
   int rbcsr_variant = 15;     // bit 0 nt matrix loads, bit 1 early row-local loads, bit 2 deeper unroll, bit 3 (Hermitian-packed kernel) all loads of an all-stencil block up front (A/B in profiles/)
   int hrb_lower_last = 0;     // HRB kernel: process the lower (conj-transposed) section after the upper one
   int arnoldi_mode = 1;       // 0 = sequential fused MGS passes, 1 = low-synchronisation MGS
+  int arnoldi_onepass = 1;    // newton!'s sweeps read the basis ONCE per column (kernels_onepass.hip): 0 never, 1 when basis + matrix exceed the Infinity Cache (bytes, not latency, then bound the sweep: profiles/r05/newton_onepass.txt), 2 wherever an instance exists
   int sparse_controls = 1;    // 1 = evaluate! rewrites only the positions of sparse trailing control terms (see qp_operator::sparse_from)
   int lattice_fill = 1;       // 1 = rows of a lattice operator that lack a few of its distances (open boundaries of a grid) are completed with explicit zeros
   int arnoldi_fuse_dots = 1;  // 1 = the multidot of a column runs in its mat-vec's epilogue where an instance exists (row-block format, j <= 19): 2 launches per column

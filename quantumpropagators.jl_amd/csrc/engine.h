@@ -185,6 +185,17 @@ struct qp_krylov {
   Stats sweep_stats;
   bool sweep_early = false;
   int sweep_gram_rows = 0;
+  // one-pass sweep (knob arnoldi_mode = 2, kernels_onepass.hip), buffers on first use: per-column coefficient records, Gram
+  // matrix and Hessenberg matrix in the stored (not exactly normalised) basis, scales, partials; nu = norms of the stored
+  // basis vectors of the latest sweep (pinned, written by the device; all one after any other kind of sweep)
+  double2* op_gram = nullptr;
+  double2* op_hhat = nullptr;
+  double2* op_part[2] = {nullptr, nullptr};
+  double* op_svals = nullptr;
+  double* op_nu_dev = nullptr;
+  double* h_nu = nullptr;
+  double* nu_map = nullptr;
+  bool nu_valid = false;        // the latest sweep left nu != 1: combination coefficients are divided by it
   double2* q(int i) const { return Q + (size_t)i * n; }
 };
 

@@ -75,6 +75,13 @@ int qp_krylov_destroy(qp_krylov* q) {
   if (q->hcoef) (void)hipFree(q->hcoef);
   if (q->mgs_coef) (void)hipFree(q->mgs_coef);
   if (q->ticket) (void)hipFree(q->ticket);
+  if (q->op_gram) (void)hipFree(q->op_gram);
+  if (q->op_hhat) (void)hipFree(q->op_hhat);
+  if (q->op_part[0]) (void)hipFree(q->op_part[0]);
+  if (q->op_part[1]) (void)hipFree(q->op_part[1]);
+  if (q->op_svals) (void)hipFree(q->op_svals);
+  if (q->op_nu_dev) (void)hipFree(q->op_nu_dev);
+  if (q->h_nu) (void)hipHostFree(q->h_nu);
   for (hipEvent_t e : q->col_events) (void)hipEventDestroy(e);
   if (q->sweep_exec) (void)hipGraphExecDestroy(q->sweep_exec);
   delete q;
@@ -186,9 +193,90 @@ static inline int guard_grid(int64_t n) {
 // in Hess -- the caller's work on the leading (j+1) x (j+1) block (newton!: its eigenvalues,
 // src/newton.jl:297) overlaps the device's work on the later columns.
 using ColumnHook = std::function<int(int)>;
+
+// The sweep that reads the basis once per column (knob arnoldi_onepass; kernels_onepass.hip says how): m + 1 column kernels, a
+// single-workgroup solve after each; column j of the Hessenberg matrix reaches the pinned host buffer with the solve after
+// column kernel j + 1 and announces itself through col_flags[j], like the folded sweep's.  The stored basis vectors have norm
+// q->h_nu[i] (1 to rounding unless a projection cancelled nearly everything): the caller divides its combination coefficients by it.
+static int arnoldi_onepass(qp_operator* op, qp_krylov* q, int m, const qp_state* psi, double dt, double norm_min, qp_c128* Hess,
+                           int ldh, int* m_out, double* beta_out, const ColumnHook* on_column) {
+  qp_ctx* ctx = op->ctx;
+  const int ldd = q->nvec;
+  if (!q->op_gram) {
+    QP_CHECK(dev_alloc(&q->op_gram, (size_t)ldd * ldd));
+    QP_CHECK(dev_alloc(&q->op_hhat, (size_t)ldd * ldd));
+    QP_CHECK(dev_alloc(&q->op_part[0], (size_t)qp::op_part_slots(ldd) * kRedBlocks));
+    QP_CHECK(dev_alloc(&q->op_part[1], (size_t)qp::op_part_slots(ldd) * kRedBlocks));
+    QP_CHECK(dev_alloc(&q->op_svals, (size_t)ldd + 1));
+    QP_CHECK(dev_alloc(&q->op_nu_dev, (size_t)ldd + 1));
+    QP_HIP(hipHostMalloc((void**)&q->h_nu, sizeof(double) * (size_t)(ldd + 1), hipHostMallocMapped));
+    QP_HIP(hipHostGetDevicePointer((void**)&q->nu_map, q->h_nu, 0));
+  }
+  if (!q->raw[0]) {
+    QP_CHECK(dev_alloc(&q->raw[0], (size_t)q->n));
+    QP_CHECK(dev_alloc(&q->raw[1], (size_t)q->n));
+  }
+  std::memset(q->h_hess, 0, sizeof(double2) * (size_t)ldd * ldd);
+  std::memset(q->h_norms, 0, sizeof(double) * (size_t)ldd);
+  for (int i = 0; i <= ldd; ++i) q->h_nu[i] = 1.0;
+  double s0 = 1.0;
+  if (beta_out) {   // newton! :268-272: beta = |Psi|, q_0 = Psi / beta -- the first column kernel scales by 1 / beta
+    cplx n2;
+    QP_CHECK(dot_sync(ctx, psi->d, psi->d, q->n, &n2));
+    *beta_out = std::sqrt(n2.real());
+    s0 = 1.0 / *beta_out;
+  }
+  q->seq = q->seq + 1 == 0 ? 1 : q->seq + 1;
+  if (q->seq == 0x47525048u) q->seq++;
+  q->gram_rows = 0;            // (the low-synchronisation sweep's Gram rows do not describe this basis)
+  q->nu_valid = true;
+  {
+    const qp::ScopedRange mv_range(ctx->tun.roctx != 0 || qp::ranges_enabled_by_env(), "matrix-vector product");
+    QP_CHECK(qp::launch_arnoldi_onepass_sweep(ctx->stream, op->A, psi->d, s0, q->Q, q->n, q->raw, m, ldd, q->op_part, q->op_gram,
+                                              q->op_hhat, q->op_svals, q->op_nu_dev, dt, q->hess_map, q->norms_map, q->nu_map,
+                                              q->col_flags_map, q->seq, &ctx->stats));
+  }
+  const cplx* hh = reinterpret_cast<const cplx*>(q->h_hess);
+  const double* hn = q->h_norms;
+  int m_eff = m, hook_rc = QP_OK;
+  for (int j = 0; j < m; ++j) {
+    const auto t_begin = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (__atomic_load_n(&q->col_flags[j], __ATOMIC_ACQUIRE) != q->seq) {
+      QP_CPU_RELAX();
+      if ((++spins & 0xfffffu) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() > 5.0) {
+        QP_HIP(hipStreamSynchronize(ctx->stream));      // never spin for good: fall back to the stream and look once more
+        if (__atomic_load_n(&q->col_flags[j], __ATOMIC_ACQUIRE) != q->seq)
+          return qp::fail(QP_E_INTERNAL, "Arnoldi column %d never announced itself to the host", j);
+      }
+    }
+    if (j + 1 == m) q->t_last_column = std::chrono::steady_clock::now();
+    for (int i = 0; i < std::min(j + 2, m + 1); ++i) {
+      const cplx v = hh[(size_t)j * ldd + i];
+      Hess[(size_t)j * ldh + i] = qp_c128{v.real(), v.imag()};
+    }
+    if (on_column && (hook_rc = (*on_column)(j)) != QP_OK) break;
+    if (hn[j] < norm_min) {      // dimensionality exhausted  src/arnoldi.jl:91-95
+      m_eff = j + 1;
+      break;
+    }
+  }
+  // a complete sweep needs no wait (its last column announced itself; the stream is consumed in order); after a breakdown or
+  // a failed hook the later columns are discarded: wait for them
+  if (m_eff != m || hook_rc != QP_OK) QP_HIP(hipStreamSynchronize(ctx->stream));
+  if (hook_rc != QP_OK) return hook_rc;
+  if (m_eff < m) {
+    // the reference leaves the vector of a breakdown UNNORMALISED (src/arnoldi.jl:91-95 breaks before :96); the stored one was
+    // scaled by s: its coefficient is to be divided by nu / h instead of nu
+    const double h = hn[m_eff - 1];
+    q->h_nu[m_eff] = h > 0.0 ? q->h_nu[m_eff] / h : 0.0;
+  }
+  *m_out = m_eff;
+  return QP_OK;
+}
 static int arnoldi_impl(qp_operator* op, qp_krylov* q, int m, const qp_state* psi, double dt, int extended,
                         double norm_min, qp_c128* Hess, int ldh, int* m_out, double* beta_out,
-                        const ColumnHook* on_column = nullptr) {
+                        const ColumnHook* on_column = nullptr, bool scaled_basis_ok = false) {
   QP_TRY
   if (!op || !q || !psi || !Hess || !m_out) return qp::fail(QP_E_BAD_ARG, "qp_arnoldi: NULL argument");
   const int dim = extended ? m + 1 : m;
@@ -212,6 +300,12 @@ static int arnoldi_impl(qp_operator* op, qp_krylov* q, int m, const qp_state* ps
     // before the 32-slot variants were added), the larger one only for systems that need it
     small = qp::small_plan(q->n, maxrow, &plan, qp::kSmallEpt) || qp::small_plan(q->n, maxrow, &plan, qp::kSmallEptArnoldi);
   }
+  q->nu_valid = false;
+  // (only for a caller that divides its combination coefficients by the stored vectors' norms: newton!)
+  const double sweep_bytes = 16.0 * (double)q->n * (m + 3) + (op->A.vals_r ? 12.0 : 20.0) * (double)op->A.stored;
+  const bool onepass_wanted = ctx->tun.arnoldi_onepass == 2 || (ctx->tun.arnoldi_onepass == 1 && sweep_bytes > 224.0 * 1024 * 1024);
+  if (!small && extended && scaled_basis_ok && ctx->tun.arnoldi_mode == 1 && onepass_wanted && qp::arnoldi_onepass_fits(op->A, m, q->nvec))
+    return arnoldi_onepass(op, q, m, psi, dt, norm_min, Hess, ldh, m_out, beta_out, on_column);
   if (small) {
     // all m columns in one persistent single-workgroup launch (kernels_small.hip: arnoldi_small_kernel)
     QP_CHECK(operator_csr_mirror(op, false));
@@ -692,7 +786,7 @@ int qp_newton_step(qp_newton* w, qp_operator* op, qp_state* psi, double dt, int 
       const qp::ScopedRange arnoldi_range(ranges, "arnoldi!");                       // src/newton.jl:276
       QP_CHECK(arnoldi_impl(op, w->q, m_req, s == 0 ? psi : &vstate, dt, 1, norm_min,
                             reinterpret_cast<qp_c128*>(Hess.data()), ldh, &m, s == 0 ? &beta : nullptr,
-                            ctx->tun.newton_pipeline ? &eig_block : nullptr));
+                            ctx->tun.newton_pipeline ? &eig_block : nullptr, true));
     }
     ms_arnoldi += ms_since(t0) - ms_eig_sweep - ms_fold_sweep;
     ms_eig += ms_eig_sweep;
@@ -771,6 +865,15 @@ int qp_newton_step(qp_newton* w, qp_operator* op, qp_state* psi, double dt, int 
     for (int i = 0; i < mp; ++i) R[i] *= (1.0 / beta);
     // Psi = (s == 0 ? 0 : Psi) + sum_{i<m} P_i q_i  (:346-352)  and  v = sum_{i<=m} R_i q_i  (q_0 is the
     // start vector of this sweep): one pass over the basis; fixed-size coefficient blocks, else one by one
+    if (w->q->nu_valid) {
+      // one-pass sweep: the stored basis vectors have norm nu_i (not exactly one): coefficients in the orthonormal basis -> stored basis
+      for (int i = 0; i < mp; ++i) {
+        const double nu = w->q->h_nu[i];
+        const double inv = nu > 0.0 ? 1.0 / nu : 0.0;
+        if (i < m) P[i] *= inv;
+        R[i] *= inv;
+      }
+    }
     ms_exposed += ms_since(w->q->t_last_column);
     if (!qp::launch_combine2_vecs(ctx->stream, psi->d, s == 0 ? 0 : 1, m, reinterpret_cast<const double2*>(P.data()), w->v,
                                   m + 1, reinterpret_cast<const double2*>(R.data()), w->q->q(0), w->n, w->npart, w->n,

@@ -126,290 +126,27 @@ def test_bench_eight_ranks_full_c4_flow_one_gpu():
     assert took < 600, f"the full --gpus 8 flow took {took:.0f} s"
     lines = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")]
     assert len(lines) == 1
+    # the printed line is the compact one the driver parses: below 4 KB, no long strings, the gate keys
+    assert len(lines[0]) < 4096
     d = json.loads(lines[0])
     assert d["degraded"] is False and d["native_path"].startswith("ok") and d["n_gpus"] == 8 and d["scaling"] == "weak"
-    assert d["config"]["N_total"] == 1 << 24 and d["config"]["rows_per_gpu"] == 1 << 21 and d["config"]["blocks_of_2^20_rows_per_step"] == 16.0
+    assert d["config"]["N_total"] == 1 << 24 and d["config"]["rows_per_gpu"] == 1 << 21
     par = d["config"]["parallelism"]
-    assert "row-partitioned x8" in par and "exchange=halo" in par and "schedule=auto: overlap" in par and "driver=native" in par
-    sp_ = d["strong_scaling_point"]
+    assert "row-partitioned x8" in par and "exchange=halo" in par and "schedule=overlap" in par and "driver=native" in par and len(par) <= 160
+    assert d["roofline"]["frac"] > 0 and d["roofline"]["bound"] == "hbm" and d["value"] > 0
+    assert d["strong_point"]["N_total"] == 1 << 20 and d["strong_point"]["prop_steps_per_s"] > 0
+    # the collective north_star names has a measured point of its own next to the halo headline
+    ag = d["allgather_form"]
+    assert ag["us_per_term"] > 0 and ag["blocks_per_s"] > 0 and "error" not in ag
+    assert d["prediction"]["fixed_n24_speedup_8gpu_halo"] > 6.0 > d["prediction"]["fixed_n24_speedup_8gpu_allgather"]
+    # the complete record next to the script
+    with open(os.path.join(ROOT, "bench_extras.json")) as f:
+        full = json.load(f)
+    assert full["config"]["blocks_of_2^20_rows_per_step"] == 16.0 and "schedule=auto: overlap" in full["config"]["parallelism"]
+    sp_ = full["strong_scaling_point"]
     assert sp_["N_total"] == 1 << 20 and sp_["rows_per_gpu"] == 1 << 17 and sp_["prop_steps_per_s"] > 0
-    xm = d["exchange_model"]
+    xm = full["exchange_model"]
     assert xm["rows_sent_per_rank_per_term"] == 8192 and xm["peers"] == 2
-    pred = d["scaling_prediction"]         # the 1 / 2 / 4 / 8 table the first real run is read against
+    pred = full["scaling_prediction"]         # the 1 / 2 / 4 / 8 table the first real run is read against
     assert [r["gpus"] for r in pred["fixed_problem_N_2^24"]] == [1, 2, 4, 8]
     assert pred["fixed_problem_N_2^24"][-1]["speedup_halo_overlap"] > 6.0 > pred["fixed_problem_N_2^24"][-1]["speedup_allgather"]
-    assert 0 < d["roofline"]["frac"] <= 1.0
-
-
-def test_split_wait_timeout_is_reported_not_hung():
-    """The in-launch hand-off boundary(m) -> interior(m + 1) polls a counter with a bounded spin.  Forced failure: the
-    boundary launches do not signal (knob split_dbg -- developer flavour of the library only, csrc: make dev) and the bound
-    is lowered to 2^10 polls (knob split_spin_log2): the interior launch comes back by itself, raises the split's
-    host-visible flag, and the NEXT call on that split -- Python-driven term or the library's own step -- returns
-    QP_E_INTERNAL instead of computing on with a stale vector; a fresh split on the same context works again."""
-    dev = os.path.join(ROOT, "quantumpropagators.jl_amd", "lib", "libqprop_hip_dev.so")
-    assert os.path.exists(dev), "lib/libqprop_hip_dev.so is missing: __graft_entry__.build() (make all dev) builds it"
-    env = dict(os.environ, QPROP_HIP_LIB=dev, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dev_build_worker.py")], env=env, capture_output=True, text=True,
-                       timeout=600)
-    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
-    assert "dev-build time-out test ok" in r.stdout
-
-
-def test_library_rccl_communicator_two_gpus():
-    """The library's own multi-rank RCCL communicator (two-phase set-up, ncclSend / ncclRecv neighbour exchange,
-    ncclAllGather, overlapped and serial schedules) against the oracle -- one GPU per rank, so this needs two
-    GPUs and skips itself on the one-GPU test boxes."""
-    import torch
-    if torch.cuda.device_count() < 2:
-        pytest.skip("needs 2 GPUs (RCCL forms no multi-rank communicator on one device)")
-    outs = _run(2, QP_METHOD="rccl")
-    assert all("rccl err=" in o for o in outs)
-
-
-@pytest.mark.parametrize("world,driver", [(2, "native"), (3, "torch")])
-def test_bench_multirank_flow_one_gpu(world, driver):
-    """bench.py as the driver launches it for N > 1 (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from
-    the environment), in its test mode where the ranks share GPU 0 and the exchange is staged through
-    the host: partition, self-check of the native step against the torch-driven one, barrier + max
-    over ranks, one JSON line from rank 0 with the whole-job value."""
-    import json
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    procs = []
-    for r in range(world):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", QP_BENCH_ONE_GPU="1")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3",
-                                       "--warmup", "1", "--log2n", "16", "--driver", driver], env=env,
-                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-    outs = []
-    for p in procs:
-        try:
-            outs.append(p.communicate(timeout=240))
-        except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            raise
-    for p, (out, err) in zip(procs, outs):
-        assert p.returncode == 0, err[-3000:]
-    lines = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")]
-    assert len(lines) == 1 and not any(ln.startswith("{") for o, _ in outs[1:] for ln in o.splitlines())
-    d = json.loads(lines[0])
-    assert d["degraded"] is False and d["native_path"].startswith("ok")
-    assert d["n_gpus"] == world and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
-    blocks = d["config"]["blocks_of_2^20_rows_per_step"]
-    assert blocks == world / 16.0                       # value counts 2^20-row blocks: N_total / 2^20 of them per step
-    assert d["value"] > 0 and abs(d["value"] - blocks * d["config"]["global_steps_per_s"]) < 1e-9 * d["value"]
-    assert d["config"]["N_total"] == world << 16 and d["cpu_baseline"] is None
-    rf = d["roofline"]
-    assert 0 < rf["frac"] <= 1.0 and rf["achieved"] <= rf["peak"]          # bytes of the shipped layout: a physical fraction
-    assert rf["layout_bytes_per_launch"] < rf["csr_equivalent_bytes_per_launch"]
-    assert abs(rf["effective_csr_equiv_gbs"] * rf["layout_bytes_per_launch"] - rf["achieved"] * rf["csr_equivalent_bytes_per_launch"]) \
-        < 1e-6 * rf["achieved"] * rf["csr_equivalent_bytes_per_launch"]
-    sp_ = d["strong_scaling_point"]
-    if world == 2:                                      # N = 2^20 in total, split over the ranks
-        assert sp_["N_total"] == 1 << 20 and sp_["rows_per_gpu"] == 1 << 19 and sp_["prop_steps_per_s"] > 0
-    else:
-        assert sp_ is None                              # 3 does not divide 2^20
-    xm = d["exchange_model"]       # the prediction the first real multi-GPU run is read against
-    assert xm["rows_sent_per_rank_per_term"] > 0 and xm["peers"] >= 1 and xm["predicted_exchange_us_per_term"] > xm["startup_us_assumed"]
-    assert xm["bytes_on_busiest_link_per_term"] == 16 * xm["rows_sent_per_rank_per_term"]
-    par = d["config"]["parallelism"]
-    # both measurements happened: the conservative one first, then the native / overlapped path under the watchdog;
-    # the faster of the two is the reported value and the line names the other
-    assert ("conservative schedule measured first" in par) != ("the native / overlapped path (" in par)
-    assert f"row-partitioned x{world}" in par and "TEST MODE" in par
-    assert "exchange=halo" in par                       # 2^16 rows per rank: banded H exchanges halos only
-    assert "schedule=auto: overlap" in par and ("-> overlap" in par or "-> serial" in par)   # both schedules were timed
-    assert ("driver=native (library step" in par) if driver == "native" else ("driver=torch.distributed" in par)
-
-
-@pytest.mark.parametrize("mode", ["1", "raise"])
-def test_bench_multirank_watchdog_reports_the_conservative_measurement(mode):
-    """The safety net of `bench.py --gpus N`: the plain schedule (torch.distributed all-gather per term, no second
-    stream) is measured first; if the native / overlapped path then hangs (simulated: it sleeps) or fails on a rank
-    (simulated: the last rank raises, the others wait for it in a collective), the watchdog prints the kept line from
-    rank 0, marked `"degraded": true` with `native_path` = "hung" / "failed", and every rank exits with status 3: the
-    driver still gets a complete, valid measurement, and nobody can mistake the run for a clean one."""
-    import json
-    world = 2
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    procs = []
-    for r in range(world):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", QP_BENCH_ONE_GPU="1", QP_BENCH_TEST_HANG=mode)
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3",
-                                       "--warmup", "1", "--log2n", "16", "--watchdog", "20"], env=env,
-                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-    outs = []
-    for p in procs:
-        try:
-            outs.append(p.communicate(timeout=240))
-        except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            raise
-    for p, (out, err) in zip(procs, outs):
-        assert p.returncode == 3, err[-3000:]
-    lines = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")]
-    assert len(lines) == 1 and not any(ln.startswith("{") for o, _ in outs[1:] for ln in o.splitlines())
-    d = json.loads(lines[0])
-    par = d["config"]["parallelism"]
-    assert d["degraded"] is True and d["native_path"] == ("hung" if mode == "1" else "failed")
-    assert d["n_gpus"] == world and d["steps"] == 3 and d["value"] > 0 and 0 < d["roofline"]["frac"] <= 1
-    assert "schedule=serial" in par and "driver=torch.distributed" in par
-    assert "conservative schedule (reported because the native / overlapped path did not finish)" in par
-    assert "reporting the conservative measurement" in outs[0][1]
-
-
-@pytest.mark.parametrize("world", [1, 2, 8])
-def test_bench_c5_batch_split_flow_one_gpu(world):
-    """`bench.py --config c5 --gpus N`: the 64-state panel of BASELINE configs[4] split over N ranks (here sharing GPU 0),
-    H replicated, no communication; one JSON line from rank 0 with the job's state-steps per second."""
-    import json
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    procs = []
-    for r in range(world):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", QP_BENCH_ONE_GPU="1")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--config", "c5",
-                                       "--steps", "2", "--warmup", "1", "--log2n", "14"], env=env,
-                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-    outs = []
-    for p in procs:
-        try:
-            outs.append(p.communicate(timeout=300))
-        except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            raise
-    for p, (out, err) in zip(procs, outs):
-        assert p.returncode == 0, err[-3000:]
-    lines = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")]
-    assert len(lines) == 1 and not any(ln.startswith("{") for o, _ in outs[1:] for ln in o.splitlines())
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == world and d["unit"] == "state_step/s" and d["config"]["states_per_gpu"] == 64 // world
-    assert abs(d["value"] - 64 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
-    assert 0 < d["roofline"]["frac"] <= 1.0 and d["max_norm_drift"] < 1e-10
-    assert ("csr_spmm_kernel" in d["config"]["kernel"]) == (64 // world <= 32)
-
-
-def test_batched_panel_split_over_ranks_matches_oracle():
-    """SURVEY 8e "Batched" / BASELINE configs[4]: a 64-state panel split as 64 / R states per rank (H replicated, zero
-    communication) and reassembled equals the oracle's cheby! of every state (1e-10) and, bit for bit, the unsplit panel
-    where both take the same kernel (R = 1 vs 2: wave-per-row kernel; R = 4, 8: the state-tiled one)."""
-    sys.path.insert(0, ROOT)
-    import qprop_amd.lib as L
-    import qprop_amd.synth as synth
-    import qprop_amd.sharded as sharded
-    from oracle import qp_oracle as qo
-    N, batch = 4096, 64
-    rp, col, vals = synth.hermitian_offsets_csr(N, offsets=(1, 2, 3, 4, 64, 128, 192, 256))
-    H = synth.to_scipy(rp, col, vals, N)
-    states = np.stack([synth.random_state(N, seed=500 + s) for s in range(batch)], axis=1)
-    ref = np.empty_like(states)
-    for s_ in range(batch):
-        psi = states[:, s_].copy()
-        w = qo.ChebyWrk(psi, 20.0, -10.0, 0.7)
-        qo.cheby(psi, H, 0.7, w)
-        qo.cheby(psi, H, 0.7, w)
-        ref[:, s_] = psi
-    ctx = L.Context(0)
-    results = {}
-    for R in (1, 2, 4, 8):
-        b = batch // R
-        got = np.empty_like(states)
-        for r in range(R):                      # what rank r of R does (its own context, operator and panel share)
-            c = L.Context(0)
-            bs = sharded.BatchSplitCheby(c, rp, col, vals, N, batch, 20.0, -10.0, 0.7, rank=r, world=R)
-            assert (bs.s0, bs.s1, bs.b) == (r * b, (r + 1) * b, b)
-            bs.set_states(states)
-            bs.step()
-            bs.step()
-            got[:, bs.s0:bs.s1] = bs.local_states()
-            bs.close()
-            c.close()
-        results[R] = got
-        assert np.max(np.linalg.norm(got - ref, axis=0)) < 1e-10, R
-    assert np.array_equal(results[1], results[2]) and np.array_equal(results[4], results[8])
-    ctx.close()
-
-
-def test_bench_single_gpu_line_is_physical():
-    """bench.py on one GPU (small size): `roofline.frac` prices the shipped layout's bytes and stays below 1, the
-    contract's CSR figure is reported separately, and `traffic` is measured in the run (child processes under
-    rocprofv3 --pmc), not read from a file."""
-    import json
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "1", "--cpu-steps", "0",
-                        "--log2n", "17", "--no-extras"], capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
-    rf = d["roofline"]
-    assert d["n_gpus"] == 1 and d["config"]["N_total"] == 1 << 17 and abs(d["value"] - d["config"]["global_steps_per_s"] / 8) < 1e-9 * d["value"]
-    assert 0 < rf["frac"] <= 1.0
-    assert rf["layout_bytes_per_launch"] < rf["csr_equivalent_bytes_per_launch"] == (20 * 16 + 84) * (1 << 17) + 4
-    assert rf["traffic_source"].startswith("measured in this run"), rf["traffic_source"]
-    assert 0.3 * rf["layout_bytes_per_launch"] < rf["traffic"] < 3.0 * rf["layout_bytes_per_launch"]
-    assert rf["traffic_detail"]["dispatches"][0] >= 31
-
-
-def test_bench_config_c4_on_one_gpu_is_the_fixed_problem():
-    """`bench.py --gpus 1 --config c4`: config C4's N = 2^24 on ONE GPU, the denominator of ">= 6 x at 8 GPUs vs 1 at fixed
-    problem" (BASELINE.md section 2); here with the size overridden, to check the flow: the rows are all on this GPU, the value
-    counts 2^20-row blocks, and the timed region reports its quarters."""
-    import json
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c4", "--log2n", "18", "--steps", "8", "--warmup", "1",
-                        "--cpu-steps", "0", "--no-pmc", "--no-extras"], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-3000:]
-    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
-    assert d["n_gpus"] == 1 and d["config"]["N_total"] == 1 << 18 == d["config"]["rows_per_gpu"] and "configs[3]" in d["config"]["workload"]
-    assert abs(d["value"] - 0.25 * d["config"]["global_steps_per_s"]) < 1e-9 * d["value"]
-    rf = d["roofline"]
-    assert len(rf["launch_us_segments"]) == 4 and rf["unstable"] in (False, True) and 0 < rf["frac"] <= 1.0
-    assert list(rf)[:8] == ["bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us"]     # the gate scalars lead
-
-
-def test_bench_extras_points_are_physical():
-    """The measurement functions behind bench.py's `extras` (tools/bench_points.py), at small sizes: every `frac` is a physical
-    fraction of the 8 TB/s roofline (bytes the implementation moves / time), the SURVEY 8d model of the Newton sweep is reported
-    beside it under its own key, an open-boundary grid takes the strip walk after the lattice completion."""
-    import qprop_amd.lib as L
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    import bench_points as bp
-    ctx = L.Context(0)
-    try:
-        ctx.tuning_set("walk_min_blocks", 64)
-        r = bp.measure_newton_c3(ctx, n=96, m=12, steps=3, warmup=3)
-        assert 0 < r["frac"] <= 1.0 and r["frac"] == r["implementation_frac"] and r["frac_survey_8d_model"] > r["frac"]
-        assert r["launches_per_column"] < 2.6
-        g = bp.measure_cheby(ctx, grid=(128, 96), steps=2, warmup=1)
-        assert 0 < g["frac"] <= 1.0 and g["kernel"] == "hrb_walk_kernel" and g["explicit_zeros_completing_the_lattice"] > 0
-        g3 = bp.measure_cheby(ctx, grid=(64, 12, 40), steps=2, warmup=1)
-        assert 0 < g3["frac"] <= 1.0 and g3["kernel"] == "hrb_walk_kernel" and g3["strip_walk"]["long_distance"] == 64 * 12
-        b = bp.measure_cheby(ctx, pattern="banded", log2n=16, steps=2, warmup=1)
-        assert 0 < b["frac"] <= 1.0
-    finally:
-        ctx.close()
-
-
-def test_c_consumer_runs(tmp_path):
-    """examples/c_abi_demo.c -- a plain-C program on the C ABI, no Python / torch in the process: its own
-    checks (norm, Newton == Cheby, forward + backward = identity, the reference's dt assertion) pass."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from test_c_consumer import _build
-    exe = _build(tmp_path)
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=180)
-    sys.stdout.write(r.stdout)
-    assert r.returncode == 0, r.stdout + r.stderr
-    assert "C ABI demo ok" in r.stdout and "QP_E_DT_MISMATCH" in r.stdout

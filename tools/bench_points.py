@@ -322,6 +322,12 @@ def measure_newton_c3(ctx, n=512, m=20, dt=0.5, steps=10, warmup=60, repeats=3):
     # bytes this implementation moves per sweep: per column the matrix, the gathered / written vectors of the fused mat-vec
     # (x, w, q_j, the j older basis vectors) and of the projection (w twice, j + 1 basis vectors); then the two combines
     impl_bytes = m * 20 * z * N + 16 * N * m * (m + 5) + 16 * N * (m + 3)
+    # the one-pass sweep (csrc/kernels_onepass.hip; taken when basis + matrix exceed the Infinity Cache): per column kernel t the
+    # matrix, the row and the gathers of a_t, t basis rows once, the two rows written; then the two combines
+    onepass = ctx.tuning_get("arnoldi_onepass") == 2 or (ctx.tuning_get("arnoldi_onepass") == 1 and
+                                                         16.0 * N * (m + 3) + 20.0 * z * N > 224.0 * 1024 * 1024)
+    if onepass and m <= 20:
+        impl_bytes = m * 20 * z * N + 16 * N * (m * (m + 1) / 2 + 4 * (m + 1)) + 16 * N * (m + 3)
     regime = ("working set (basis + matrix) inside the Infinity Cache: a latency / L1-queue figure, not an HBM fraction" if N <= (1 << 19)
               else "basis beyond the Infinity Cache: HBM-bandwidth bound")
     out = {"workload": f"BASELINE configs[2]: Newton prop_step!, N={N} (n={n}) non-Hermitian sparse Liouvillian, m_max={m}",
@@ -333,6 +339,7 @@ def measure_newton_c3(ctx, n=512, m=20, dt=0.5, steps=10, warmup=60, repeats=3):
            "kernel_launches_per_step": st["n_kernel_launches"] / steps,
            "launches_per_column": st["n_kernel_launches"] / max(matvecs, 1),
            "ms_per_sweep": 1e3 * el / sweeps, "host_ms_exposed_per_step": exposed / steps,
+           "sweep": "one pass over the basis per column" if (onepass and m <= 20) else "two passes over the basis per column (low-synchronisation MGS)",
            # `frac` prices the bytes this implementation moves (physical: cannot exceed 1); the SURVEY 8d sweep model counts
            # the reference's sequential Gram-Schmidt passes, which the low-synchronisation form does not make
            "implementation_bytes_per_sweep": impl_bytes, "implementation_gbs": impl_bytes * sweeps / el / 1e9,

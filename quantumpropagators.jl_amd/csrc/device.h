@@ -239,7 +239,16 @@ int launch_arnoldi_onepass_sweep(hipStream_t s, const DevMatrix& A, const double
                                  unsigned* flags_map, unsigned flag_value, Stats* st);
 // the strip walk for the fused Chebyshev term of a whole Hermitian-packed lattice operator; *launched = false when the
 // plan's shape has no kernel instance (the caller then takes the per-block kernel)
-bool walk_shape_supported(int nn, int K, int z0, int xl = 0, int fd = 0);   // is there a kernel instance for this stencil shape?
+// is there a strip-walk kernel instance for this stencil shape?  (The dispatch of kernels_walk_impl.h: launch_shape instantiates
+// exactly these; inline here so that the host planners -- and their sanitizer build, tests/sanitize_host_index.cpp -- see the same list.)
+// near distances 1..4 of at most 16 rows, far reach 1..4 strip steps, with or without a diagonal
+// ... and, with one or two long pairs beyond the ring (xl = 1, 2), near 1..2 and one or two far distances
+// ... and, with diagonal far neighbours (fd = 1: m g - 1, m g, m g + 1), near 1..2, one strip step and at most one long pair
+inline bool walk_shape_supported(int nn, int K, int z0, int xl = 0, int fd = 0) {
+  if (fd) return fd == 1 && (xl == 0 || xl == 1) && K == 1 && nn >= 1 && nn <= 2 && (z0 == 0 || z0 == 1);
+  if (xl) return (xl == 1 || xl == 2) && nn >= 1 && nn <= 2 && (K == 1 || K == 2) && (z0 == 0 || z0 == 1);
+  return nn >= 1 && nn <= 4 && K >= 1 && K <= 4 && (z0 == 0 || z0 == 1);
+}
 int launch_hrb_walk_cheby(hipStream_t s, const DevMatrix& A, const double2* x, const ChebyEpi& e, const Tuning& tun,
                           bool* launched, const RowSet* rs = nullptr);
 // kernels_dense.hip (QP_FMT_DENSE: CSR arrays with a complete pattern, i.e. vals / vals_r is the row-major dense matrix)
@@ -353,7 +362,9 @@ struct SpmmWalkPlan {
   int32_t* edge = nullptr;    // device: the rows outside the walk (wave-per-row kernel, `order` list)
   int64_t n_edge = 0;
 };
-bool spmm_walk_shape_supported(int nn, int K, int diag);
+inline bool spmm_walk_shape_supported(int nn, int K, int diag) {   // the instances of kernels_spmm_walk.hip: launch_shape
+  return ((nn == 4 && K == 4) || (nn == 2 && K == 2)) && (diag == 0 || diag == 1);
+}
 int launch_spmm_walk_cheby(hipStream_t s, const double2* vals, const double2* X, const SpmmWalkPlan& P, int b,
                            const ChebyEpi& e, const Tuning& tun, bool nt, bool* launched);
 

@@ -307,32 +307,6 @@ __global__ __launch_bounds__(kThreads) void csr_spmv_kernel(const int64_t* __res
   finish_check(op, chk, nrm, lds);
 }
 
-int* tuning_field(Tuning& t, const char* key) {
-  struct Entry {
-    const char* name;
-    int Tuning::*field;
-  };
-  static const Entry table[] = {
-      {"rbcsr_variant", &Tuning::rbcsr_variant}, {"hrb_lower_last", &Tuning::hrb_lower_last},
-      {"arnoldi_mode", &Tuning::arnoldi_mode},   {"arnoldi_onepass", &Tuning::arnoldi_onepass},   {"split_mode", &Tuning::split_mode},
-      {"arnoldi_fold", &Tuning::arnoldi_fold},   {"spmm_wg", &Tuning::spmm_wg},   {"hrb_wg", &Tuning::hrb_wg},   {"arnoldi_solve", &Tuning::arnoldi_solve},   {"arnoldi_fuse_dots", &Tuning::arnoldi_fuse_dots},   {"lattice_fill", &Tuning::lattice_fill},   {"sparse_controls", &Tuning::sparse_controls},
-      {"liouville_fused_n", &Tuning::liouville_fused_n}, {"liouville_tile32_n", &Tuning::liouville_tile32_n}, {"liouville_tile32_min_n", &Tuning::liouville_tile32_min_n}, {"real_vals", &Tuning::real_vals},
-      {"stencil", &Tuning::stencil}, {"block_map", &Tuning::block_map},             {"acc_defer", &Tuning::acc_defer},
-      {"cheby_graph", &Tuning::cheby_graph},     {"small_nnz", &Tuning::small_nnz},
-      {"roctx", &Tuning::roctx}, {"newton_graph", &Tuning::newton_graph}, {"arnoldi_l2_order", &Tuning::arnoldi_l2_order}, {"arnoldi_nt", &Tuning::arnoldi_nt},
-      {"colblock", &Tuning::colblock}, {"cb_log2w", &Tuning::cb_log2w}, {"cb_min_log2n", &Tuning::cb_min_log2n}, {"cb_waves", &Tuning::cb_waves}, {"cb_rpt", &Tuning::cb_rpt},
-      {"dense_auto", &Tuning::dense_auto},       {"dense_min_density_pct", &Tuning::dense_min_density_pct}, {"dense_panel_mfma", &Tuning::dense_panel_mfma},
-      {"newton_pipeline", &Tuning::newton_pipeline}, {"spmm_tile", &Tuning::spmm_tile},
-      {"spmm_nt", &Tuning::spmm_nt},             {"spmm_rows", &Tuning::spmm_rows},
-      {"spmm_strip", &Tuning::spmm_strip},       {"spmm_rw", &Tuning::spmm_rw},
-      {"hrb_walk", &Tuning::hrb_walk},           {"walk_waves", &Tuning::walk_waves},
-      {"walk_min_blocks", &Tuning::walk_min_blocks}, {"walk_dbg", &Tuning::walk_dbg}, {"walk_nt", &Tuning::walk_nt}, {"value_dict", &Tuning::value_dict}, {"walk_wg", &Tuning::walk_wg}, {"walk_reserve_cu", &Tuning::walk_reserve_cu}, {"walk_edge_steps", &Tuning::walk_edge_steps}, {"split_spin_log2", &Tuning::split_spin_log2}, {"split_dbg", &Tuning::split_dbg}, {"spmm_walk", &Tuning::spmm_walk}, {"spmm_walk_waves", &Tuning::spmm_walk_waves},
-  };
-  for (const Entry& e : table)
-    if (std::strcmp(e.name, key) == 0) return &(t.*(e.field));
-  return nullptr;
-}
-
 int spmv_grid_size(const DevMatrix& A) {
   // (dense: one wavefront per R rows -- the grid launch_dense_gemv uses; the per-workgroup check triples of check_normalization
   // are sized and reduced with THIS count, so the two must be one expression)

@@ -132,10 +132,6 @@ static void launch_inst(hipStream_t s, dim3 grid, const double2* vals, const dou
   hipLaunchKernelGGL((spmm_walk_kernel<Op, NN, K, DIAG>), grid, dim3(64 * kSpmmWalkWaves), 0, s, vals, X, P, L, nseg, b, op);
 }
 
-bool spmm_walk_shape_supported(int nn, int K, int diag) {
-  return ((nn == 4 && K == 4) || (nn == 2 && K == 2)) && (diag == 0 || diag == 1);
-}
-
 template <class Op>
 static bool launch_shape(hipStream_t s, dim3 grid, const double2* vals, const double2* X, const SpmmWalkPlan& P, int L,
                          int nseg, int b, const Op& op) {

@@ -9,15 +9,6 @@ bool walk_launch_c128_hi(hipStream_t s, dim3 grid, const double2* uvals, const d
   return launch_shape<double2, 0>(s, grid, uvals, x, P, G, H, nrows, op, ntm, sy);
 }
 
-// near distances 1..4 of at most 16 rows, far reach 1..4 strip steps, with or without a diagonal
-// ... and, with one or two long pairs beyond the ring (xl = 1, 2), near 1..2 and one or two far distances
-// ... and, with diagonal far neighbours (fd = 1: m g - 1, m g, m g + 1), near 1..2, one strip step and at most one long pair
-bool walk_shape_supported(int nn, int K, int z0, int xl, int fd) {
-  if (fd) return fd == 1 && (xl == 0 || xl == 1) && K == 1 && nn >= 1 && nn <= 2 && (z0 == 0 || z0 == 1);
-  if (xl) return (xl == 1 || xl == 2) && nn >= 1 && nn <= 2 && (K == 1 || K == 2) && (z0 == 0 || z0 == 1);
-  return nn >= 1 && nn <= 4 && K >= 1 && K <= 4 && (z0 == 0 || z0 == 1);
-}
-
 int launch_hrb_walk_cheby(hipStream_t s, const DevMatrix& A, const double2* x, const ChebyEpi& e, const Tuning& tun,
                           bool* launched, const RowSet* rs) {
   *launched = false;

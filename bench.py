@@ -876,23 +876,35 @@ def main():
                     emit(kept)
                 sys.stderr.write(f"[bench.py rank {rank}] native / overlapped path {reason} (limit {args.watchdog} s): "
                                  f"reporting the conservative measurement, exit status 3\n")
+                if reason == "hung":      # where: the Python stacks
+                    import faulthandler
+                    faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
                 sys.stderr.flush()
                 os._exit(3)
             watchdog = threading.Timer(args.watchdog, give_up)
             watchdog.daemon = True
             watchdog.start()
+        def stage(msg):      # progress on stderr (rank 0): a watchdog exit then says how far the path got
+            if rank == 0:
+                sys.stderr.write(f"[bench.py] native path: {msg} (+{time.perf_counter() - t_native:.1f} s)\n")
+                sys.stderr.flush()
+        t_native = time.perf_counter()
+
         def native_path():
             if os.environ.get("QP_BENCH_TEST_HANG") == "1":      # testing only: what the watchdog is for
                 time.sleep(1e6)
             if os.environ.get("QP_BENCH_TEST_HANG") == "raise" and rank == world - 1:
                 raise RuntimeError("simulated failure of the native path on one rank")
+            stage("set-up, self-check and schedule trial")
             sh_, nat_, snote_, dnote_ = make_stepper(rp, col, vals, N, r0, r1, psi0_local)
+            stage("timed steps")
             model_ = bp.cheby_layout_bytes(sh_.op, rows, rows + world * sh_.M, nnz_local, coeffs, real_copy=args.real)
             el_, ev_, st_ = timed_steps(lambda: sh_.step(native=nat_))
             sh_.check()      # outside the timed region: the overlapped schedule never timed out
             strong_ = None
             # the strong-scaling point of BASELINE's metric (N = 2^20 in total)
             if args.scaling == "weak" and not args.no_strong and (1 << 20) % world == 0:
+                stage("strong-scaling point")
                 Ns = 1 << 20
                 rs = Ns // world
                 s0, s1 = rank * rs, (rank + 1) * rs
@@ -919,21 +931,27 @@ def main():
             # point next to the headline (for a banded H `auto` picks the halo exchange): 4 steps with the whole slice
             # exchanged, the same operator, the same driver
             if not args.no_allgather:
+                stage("all-gather form")
                 per_term_main = 1e3 * ev_ / (args.steps * nterms)
                 if sh_.exchange == "allgather":
                     ag_form["us_per_term"], ag_form["blocks_per_s"] = per_term_main, (N / float(1 << 20)) * args.steps / el_
                 else:
                     try:
-                        if one_gpu:      # test mode stages every byte through the host: the same code path on 2^16 rows per rank
-                            rows_t = min(rows, 1 << 16)
-                            Ng, g0, g1 = rows_t * world, rank * rows_t, (rank + 1) * rows_t
-                            rpg, colg, valsg = bp.pattern_csr(args.pattern, Ng, g0, g1)
-                            sh_g, nat_g, _, dnote_g = make_stepper(rpg, colg, valsg, Ng, g0, g1, synth.random_state(Ng, row_begin=g0, row_end=g1),
-                                                                   exchange="allgather")
+                        # the plainest schedule (step loop in Python, one torch.distributed all-gather per term on the main stream, no
+                        # second stream): the form exercised with RCCL at world 1 and with gloo at world 2 - 3 -- a number for the
+                        # collective, not another first run of the native machinery
+                        # ... on the SCATTERED pattern (synth: eight seeded distances in [1, N / 2)): every row reads remote data, the send
+                        # list is every rank's whole slice -- the case the collective exists for (a banded H exchanges halos)
+                        rows_t = min(rows, 1 << 13) if one_gpu else rows      # (test mode stages every byte through the host: 128 KiB per rank)
+                        Ng, g0, g1 = rows_t * world, rank * rows_t, (rank + 1) * rows_t
+                        rpg, colg, valsg = bp.pattern_csr("scattered", Ng, g0, g1)
+                        psig = synth.random_state(Ng, row_begin=g0, row_end=g1)
+                        if one_gpu:
                             ag_form["test_mode_rows_per_rank"] = rows_t
-                        else:
-                            Ng = N
-                            sh_g, nat_g, _, dnote_g = make_stepper(rp, col, vals, N, r0, r1, psi0_local, exchange="allgather")
+                        sh_g = sharded.ShardedCheby(ctx, rpg, colg, valsg, Ng, g0, g1, Delta, E_min, dt, fmt=fmt, exchange="allgather",
+                                                    host_staged=one_gpu, native=False, overlap=False)
+                        sh_g.set_state(psig)
+                        nat_g = False
                         kg = 4
                         for _ in range(2):
                             sh_g.step(native=nat_g)
@@ -948,10 +966,14 @@ def main():
                         sh_g.check()
                         ag_form["us_per_term"] = 1e6 * float(tg[0]) / (kg * nterms)
                         ag_form["blocks_per_s"] = (Ng / float(1 << 20)) * kg / float(tg[0])
-                        ag_form["driver"] = "native" if nat_g else "torch.distributed"
+                        ag_form["driver"] = "torch.distributed, serial"
+                        ag_form["pattern"] = "scattered"
                         sh_g.close()
                     except Exception as e:  # noqa: BLE001 -- the extra point must not take the headline down
+                        import traceback
+                        sys.stderr.write(f"[bench.py rank {rank}] all-gather form failed:\n{traceback.format_exc()}\n")
                         ag_form["error"] = f"{type(e).__name__}: {e}"
+            stage("done")
             return sh_, el_, ev_, st_, model_, snote_, dnote_, strong_
 
         try:
@@ -1110,6 +1132,8 @@ def main():
     if fallback is not None and fallback["value"] > out["value"]:      # report the faster of the two complete measurements
         fallback["config"]["parallelism"] += (f" | the native / overlapped path (schedule={schedule_note}, driver={driver_note}) measured "
                                               f"{out['value']:.1f} {out['unit']} ({out['ms_per_step']:.3f} ms/step): slower, not reported as `value`")
+        fallback["config"]["parallelism_short"] = _short(fallback["config"]["parallelism_short"].replace(" [TEST MODE: one GPU, gloo]", "") +
+                                                         " | slower, not `value`: " + out["config"]["parallelism_short"].split(", ", 2)[-1])
         fallback["strong_scaling_point"] = out["strong_scaling_point"]
         fallback["degraded"] = False
         fallback["native_path"] = "ok (slower than the conservative schedule)"

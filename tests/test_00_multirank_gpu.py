@@ -132,7 +132,8 @@ def test_bench_eight_ranks_full_c4_flow_one_gpu():
     assert d["degraded"] is False and d["native_path"].startswith("ok") and d["n_gpus"] == 8 and d["scaling"] == "weak"
     assert d["config"]["N_total"] == 1 << 24 and d["config"]["rows_per_gpu"] == 1 << 21
     par = d["config"]["parallelism"]
-    assert "row-partitioned x8" in par and "exchange=halo" in par and "schedule=overlap" in par and "driver=native" in par and len(par) <= 160
+    # (the line reports the faster of the conservative and the native measurement; the native path's schedule and driver are named either way)
+    assert "row-partitioned x8" in par and "exchange=halo" in par and "schedule=" in par and "driver=native" in par and len(par) <= 160
     assert d["roofline"]["frac"] > 0 and d["roofline"]["bound"] == "hbm" and d["value"] > 0
     assert d["strong_point"]["N_total"] == 1 << 20 and d["strong_point"]["prop_steps_per_s"] > 0
     # the collective north_star names has a measured point of its own next to the halo headline
@@ -142,7 +143,7 @@ def test_bench_eight_ranks_full_c4_flow_one_gpu():
     # the complete record next to the script
     with open(os.path.join(ROOT, "bench_extras.json")) as f:
         full = json.load(f)
-    assert full["config"]["blocks_of_2^20_rows_per_step"] == 16.0 and "schedule=auto: overlap" in full["config"]["parallelism"]
+    assert full["config"]["blocks_of_2^20_rows_per_step"] == 16.0 and "schedule=auto: overlap" in full["config"]["parallelism"] and "driver=native" in full["config"]["parallelism"]
     sp_ = full["strong_scaling_point"]
     assert sp_["N_total"] == 1 << 20 and sp_["rows_per_gpu"] == 1 << 17 and sp_["prop_steps_per_s"] > 0
     xm = full["exchange_model"]

@@ -266,6 +266,28 @@ function operator_walk_reason(op::Handle)
     return Int(code[]), unsafe_string(pointer(text))
 end
 
+# an operator that is no lattice but has a fast path of its own has nothing to be told (the Python mirror: lib.py, _warn_if_off_the_walk):
+# a dense or matrix-free format, a column-blocked mirror, a value dictionary, or row blocks that are all block maps (qubit registers)
+function operator_has_own_fast_path(op::Handle)
+    fmt = Ref{Cint}(0)
+    check(ccall((:qp_operator_info, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Cint}), op, C_NULL, C_NULL, C_NULL, fmt))
+    (fmt[] == 4 || fmt[] == 5) && return true          # QP_FMT_MATFREE, QP_FMT_DENSE
+    operator_colblock_info(op).valid && return true
+    ve = zeros(Int64, 6)
+    GC.@preserve ve check(ccall((:qp_operator_value_encoding_info, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}), op, ve))
+    ve[1] != 0 && return true
+    enc = zeros(Int64, 8)
+    GC.@preserve enc check(ccall((:qp_operator_encoding_info, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}), op, enc))
+    return enc[4] > 0 && enc[1] + enc[2] == 0          # upper sections: block maps, none with per-entry int32 / int16 columns
+end
+
+# a context knob (include/qprop.h: qp_ctx_tuning_get)
+function ctx_tuning_get(ctx::Handle, key::AbstractString)
+    v = Ref{Cint}(0)
+    check(ccall((:qp_ctx_tuning_get, LIB), Cint, (Ptr{Cvoid}, Cstring, Ptr{Cint}), ctx, key, v))
+    return Int(v[])
+end
+
 # column-blocked mirror of an operator with irregular columns (include/qprop.h: qp_operator_colblock_info):
 # (has one, column blocks, log2 of the columns per block, rows per tile, longest segment, tiles, share of single-line gathers)
 function operator_colblock_info(op::Handle)
@@ -454,10 +476,12 @@ function init_prop(state, generator, tlist, ::Val{:ChebyHIP};
     ctx = state isa HIPState ? state.ctx : default_ctx(device)
     op = device_operator(ctx, G)
     N = length(state)
-    if N >= 64 * 3072                      # large enough for the strip walk (knob walk_min_blocks): say so if it is not taken
+    if N >= 64 * ctx_tuning_get(ctx, "walk_min_blocks")      # large enough for the strip walk: say so if it is not taken
         code, why = operator_walk_reason(op)
-        # 1 not Hermitian (newton! territory), 4 too few blocks, 16 switched off: nothing to report
-        (code in (0, 1, 4, 16)) || @warn "ChebyHIP: the operator does not take the strip walk (up to 1.8x per term): $why" maxlog = 1
+        # 1 not Hermitian (newton! territory), 4 too few blocks, 16 switched off: nothing to report; neither for an operator
+        # with a fast path of its own
+        (code in (0, 1, 4, 16)) || operator_has_own_fast_path(op) ||
+            @warn "ChebyHIP: the operator does not take the strip walk (up to 1.8x per term): $why" maxlog = 1
     end
     E_min, E_max = _envelope(ctx, op, G, N, control_ranges, specrange_method; specrange_kwargs...)
     Δ = E_max - E_min

@@ -280,7 +280,6 @@ inline int dense_gemv_grid(int64_t nrows) {
 // from, so handles driven from different threads never observe each other's switches.
 struct Tuning {
   int rbcsr_variant = 15;     // bit 0 nt matrix loads, bit 1 early row-local loads, bit 2 deeper unroll, bit 3 (Hermitian-packed kernel) all loads of an all-stencil block up front (A/B in profiles/)
-  int hrb_lower_last = 0;     // HRB kernel: process the lower (conj-transposed) section after the upper one
   int arnoldi_mode = 1;       // 0 = sequential fused MGS passes, 1 = low-synchronisation MGS
   int arnoldi_onepass = 1;    // newton!'s sweeps read the basis ONCE per column (kernels_onepass.hip): 0 never, 1 when basis + matrix exceed the Infinity Cache (bytes, not latency, then bound the sweep: profiles/r05/newton_onepass.txt), 2 wherever an instance exists
   int sparse_controls = 1;    // 1 = evaluate! rewrites only the positions of sparse trailing control terms (see qp_operator::sparse_from)
@@ -300,7 +299,6 @@ struct Tuning {
   int acc_defer = 1;          // qp_cheby_step: touch the Psi accumulator every third term only (1) or every term (0)
   int cheby_graph = 0;        // qp_cheby_step: replay a repeated step as a hipGraph when the mat-vec grid has at most this many workgroups (0: off; measured: no gain)
   int roctx = 0;              // 1 = named profiler ranges around the steps' phases (qprop_internal.h: ScopedRange); also QP_ROCTX=1
-  int newton_graph = 0;       // 1 = a Newton restart's Arnoldi columns are replayed from a hipGraph (recorded on the second identical sweep)
   int arnoldi_l2_order = 1;   // 1 = the projection kernel owns the mat-vec's rows per XCD and reads rounds / basis vectors back to front (L2 reuse of what the dots pass read last)
   int arnoldi_nt = 1;         // 1 = the fused Arnoldi mat-vec streams the matrix nontemporal (the L2 keeps basis vectors instead)
   int dense_auto = 1;         // 1 = AUTO lays an operator out dense (QP_FMT_DENSE) when at least dense_min_density_pct % of its positions are stored

@@ -170,22 +170,7 @@ struct qp_krylov {
   unsigned* col_flags_map = nullptr;
   unsigned seq = 0;
   std::chrono::steady_clock::time_point t_last_column;   // when the host saw the last column of the latest sweep
-  // hipGraph of one sweep's column launches (knob newton_graph; engine_krylov.hip: arnoldi_impl)
-  struct SweepKey {
-    const void *op = nullptr, *vals = nullptr, *vals_r = nullptr, *bptr = nullptr;
-    int format = -1, m = 0, knobs = 0;
-    double dt = 0, norm_min = 0;
-    bool operator==(const SweepKey& o) const {
-      return op == o.op && vals == o.vals && vals_r == o.vals_r && bptr == o.bptr && format == o.format && m == o.m &&
-             knobs == o.knobs && dt == o.dt && norm_min == o.norm_min;
-    }
-  };
-  SweepKey sweep_key, sweep_pending;
-  hipGraphExec_t sweep_exec = nullptr;
-  Stats sweep_stats;
-  bool sweep_early = false;
-  int sweep_gram_rows = 0;
-  // one-pass sweep (knob arnoldi_mode = 2, kernels_onepass.hip), buffers on first use: per-column coefficient records, Gram
+  // one-pass sweep (knob arnoldi_onepass, kernels_onepass.hip), buffers on first use: per-column coefficient records, Gram
   // matrix and Hessenberg matrix in the stored (not exactly normalised) basis, scales, partials; nu = norms of the stored
   // basis vectors of the latest sweep (pinned, written by the device; all one after any other kind of sweep)
   double2* op_gram = nullptr;

@@ -23,13 +23,13 @@ int* tuning_field(Tuning& t, const char* key) {
     int Tuning::*field;
   };
   static const Entry table[] = {
-      {"rbcsr_variant", &Tuning::rbcsr_variant}, {"hrb_lower_last", &Tuning::hrb_lower_last},
+      {"rbcsr_variant", &Tuning::rbcsr_variant},
       {"arnoldi_mode", &Tuning::arnoldi_mode},   {"arnoldi_onepass", &Tuning::arnoldi_onepass},   {"split_mode", &Tuning::split_mode},
       {"arnoldi_fold", &Tuning::arnoldi_fold},   {"spmm_wg", &Tuning::spmm_wg},   {"hrb_wg", &Tuning::hrb_wg},   {"arnoldi_solve", &Tuning::arnoldi_solve},   {"arnoldi_fuse_dots", &Tuning::arnoldi_fuse_dots},   {"lattice_fill", &Tuning::lattice_fill},   {"sparse_controls", &Tuning::sparse_controls},
       {"liouville_fused_n", &Tuning::liouville_fused_n}, {"liouville_tile32_n", &Tuning::liouville_tile32_n}, {"liouville_tile32_min_n", &Tuning::liouville_tile32_min_n}, {"real_vals", &Tuning::real_vals},
       {"stencil", &Tuning::stencil}, {"block_map", &Tuning::block_map},             {"acc_defer", &Tuning::acc_defer},
       {"cheby_graph", &Tuning::cheby_graph},     {"small_nnz", &Tuning::small_nnz},
-      {"roctx", &Tuning::roctx}, {"newton_graph", &Tuning::newton_graph}, {"arnoldi_l2_order", &Tuning::arnoldi_l2_order}, {"arnoldi_nt", &Tuning::arnoldi_nt},
+      {"roctx", &Tuning::roctx}, {"arnoldi_l2_order", &Tuning::arnoldi_l2_order}, {"arnoldi_nt", &Tuning::arnoldi_nt},
       {"colblock", &Tuning::colblock}, {"cb_log2w", &Tuning::cb_log2w}, {"cb_min_log2n", &Tuning::cb_min_log2n}, {"cb_waves", &Tuning::cb_waves}, {"cb_rpt", &Tuning::cb_rpt},
       {"dense_auto", &Tuning::dense_auto},       {"dense_min_density_pct", &Tuning::dense_min_density_pct}, {"dense_panel_mfma", &Tuning::dense_panel_mfma},
       {"newton_pipeline", &Tuning::newton_pipeline}, {"spmm_tile", &Tuning::spmm_tile},
@@ -1091,7 +1091,17 @@ int qp_operator_create(qp_ctx* ctx, qp_matrix* const* ops, int nops, int ncoeffs
   auto& ur = op->u_rowptr;
   auto& uc = op->u_col;
   ur.assign(nrows + 1, 0);
-  if (nops == 1) {
+  // (one term whose rows are strictly ascending IS the union pattern; a term with repeated or unsorted columns goes through the
+  // merge like several terms do, so that density, completeness and every layout decision below see each position once --
+  // a duplicate could make the stored count reach nrows x ncols with positions missing)
+  bool canonical = nops == 1;
+  for (int64_t r = 0; canonical && r < nrows; ++r)
+    for (int64_t p = ops[0]->rowptr[r] + 1; p < ops[0]->rowptr[r + 1]; ++p)
+      if (ops[0]->col[p] <= ops[0]->col[p - 1]) {
+        canonical = false;
+        break;
+      }
+  if (canonical) {
     ur = ops[0]->rowptr;
     uc = ops[0]->col;
   } else {
@@ -1157,20 +1167,10 @@ int qp_operator_create(qp_ctx* ctx, qp_matrix* const* ops, int nops, int ncoeffs
   for (int l = 0; l < nops; ++l) {
     const qp_matrix* M = ops[l];
     auto& pv = planes_csr[l];
-    if (nops == 1 && (int64_t)M->vals.size() == op->A.nnz && uc.size() == M->col.size() && ur == M->rowptr) {
-      // one term and no completion: the union pattern is the term's own -- a plain copy, unless a row holds one column
-      // twice (the loop below sums duplicates into the first of them, as Julia's sparse() does)
-      bool dup = false;
-      for (int64_t r = 0; r < nrows && !dup; ++r)
-        for (int64_t q = ur[r] + 1; q < ur[r + 1]; ++q)
-          if (uc[q] == uc[q - 1]) {
-            dup = true;
-            break;
-          }
-      if (!dup) {
-        pv = M->vals;
-        continue;
-      }
+    if (nops == 1 && canonical && (int64_t)M->vals.size() == op->A.nnz && ur == M->rowptr && uc == M->col) {
+      // one canonical term and no completion: the union pattern IS the term's own (same columns, not merely as many) -- a plain copy
+      pv = M->vals;
+      continue;
     }
     pv.assign((size_t)op->A.nnz, cplx(0));
     for (int64_t r = 0; r < nrows; ++r) {
@@ -1445,7 +1445,7 @@ int qp_operator_walk_info(const qp_operator* op, int64_t out[8]) {
   const qp::WalkPlan& P = op->walk;
   const qp::Tuning& tun = op->ctx->tun;
   // "has one" = the fused term of a whole-operator cheby! takes the walk under the context's current knobs
-  const bool on = P.valid && op->A.walk == &op->walk && tun.hrb_walk && !tun.hrb_lower_last && (tun.rbcsr_variant & 31) == 15 &&
+  const bool on = P.valid && op->A.walk == &op->walk && tun.hrb_walk && (tun.rbcsr_variant & 31) == 15 &&
                   P.R1 - P.W0 >= tun.walk_min_blocks;
   out[0] = on ? 1 : 0;
   out[1] = on ? P.nn : 0;

@@ -83,7 +83,6 @@ int qp_krylov_destroy(qp_krylov* q) {
   if (q->op_nu_dev) (void)hipFree(q->op_nu_dev);
   if (q->h_nu) (void)hipHostFree(q->h_nu);
   for (hipEvent_t e : q->col_events) (void)hipEventDestroy(e);
-  if (q->sweep_exec) (void)hipGraphExecDestroy(q->sweep_exec);
   delete q;
   return QP_OK;
   QP_CATCH
@@ -227,7 +226,6 @@ static int arnoldi_onepass(qp_operator* op, qp_krylov* q, int m, const qp_state*
     s0 = 1.0 / *beta_out;
   }
   q->seq = q->seq + 1 == 0 ? 1 : q->seq + 1;
-  if (q->seq == 0x47525048u) q->seq++;
   q->gram_rows = 0;            // (the low-synchronisation sweep's Gram rows do not describe this basis)
   q->nu_valid = true;
   {
@@ -360,38 +358,8 @@ static int arnoldi_impl(qp_operator* op, qp_krylov* q, int m, const qp_state* ps
       QP_CHECK(dev_alloc(&q->raw[1], (size_t)q->n));
     }
     flags = fold && piped;
-    // knob newton_graph: the columns of a folded, pipelined sweep (2 launches each + the last vector's normalisation) are
-    // captured once per (operator, m, dt) and replayed per restart.  A replayed launch carries the flag value it was
-    // captured with, so a graph sweep always announces its columns with kGraphSeq and the host clears the flags first
-    // (nothing of the previous sweep is in flight: its last kernel's last store was the flag the host waited for, or the
-    // stream was synchronised).  Breakdown, other operators, other m: eager launches as before.
-    constexpr unsigned kGraphSeq = 0x47525048u;
-    qp_krylov::SweepKey skey;
-    bool use_graph = false, record_graph = false;
-    if (flags && extended && ctx->tun.newton_graph != 0 && ctx->stream != nullptr) {   // (the null stream cannot be captured)
-      skey.op = op;
-      skey.vals = op->A.vals;
-      skey.vals_r = op->A.vals_r;
-      skey.bptr = op->A.bptr;
-      skey.format = op->A.format;
-      skey.m = m;
-      skey.dt = dt;
-      skey.norm_min = norm_min;
-      skey.knobs = ((((ctx->tun.arnoldi_mode * 2 + ctx->tun.arnoldi_fuse_dots) * 2 + ctx->tun.arnoldi_solve) * 2 + ctx->tun.arnoldi_l2_order) * 2 +
-                    ctx->tun.arnoldi_nt) * 64 + (ctx->tun.rbcsr_variant & 63);
-      use_graph = q->sweep_exec && skey == q->sweep_key;
-      record_graph = !use_graph && skey == q->sweep_pending;
-      if (!use_graph && !record_graph) q->sweep_pending = skey;
-    }
-    if (flags) {
-      if (use_graph || record_graph) {
-        q->seq = kGraphSeq;
-        std::memset(q->col_flags, 0, sizeof(unsigned) * (size_t)q->nvec * 2);
-        __atomic_thread_fence(__ATOMIC_RELEASE);
-      } else {
-        q->seq = q->seq + 1 == 0 ? 1 : q->seq + 1;
-        if (q->seq == kGraphSeq) q->seq++;
-      }
+    if (flags) {      // a new sequence number per sweep: the columns announce themselves with it
+      q->seq = q->seq + 1 == 0 ? 1 : q->seq + 1;
     }
     auto enqueue_columns = [&]() -> int {
     for (int j = 0; j < m; ++j) {
@@ -433,44 +401,7 @@ static int arnoldi_impl(qp_operator* op, qp_krylov* q, int m, const qp_state* ps
     }
     return QP_OK;
     };
-    if (use_graph) {
-      QP_HIP(hipGraphLaunch(q->sweep_exec, ctx->stream));
-      ctx->stats.n_graph_launch++;
-      ctx->stats.n_matvec += q->sweep_stats.n_matvec;
-      ctx->stats.n_launch += q->sweep_stats.n_launch;
-      ctx->stats.spmv_bytes += q->sweep_stats.spmv_bytes;
-      early_last = q->sweep_early;
-      q->gram_rows = q->sweep_gram_rows;
-    } else if (record_graph) {
-      hipGraph_t graph = nullptr;
-      const Stats before = ctx->stats;
-      QP_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-      const int rc = enqueue_columns();
-      const hipError_t ec = hipStreamEndCapture(ctx->stream, &graph);
-      if (rc != QP_OK) {
-        if (graph) (void)hipGraphDestroy(graph);
-        return rc;
-      }
-      QP_HIP(ec);
-      q->sweep_stats = Stats();
-      q->sweep_stats.n_matvec = ctx->stats.n_matvec - before.n_matvec;
-      q->sweep_stats.n_launch = ctx->stats.n_launch - before.n_launch;
-      q->sweep_stats.spmv_bytes = ctx->stats.spmv_bytes - before.spmv_bytes;
-      q->sweep_early = early_last;
-      q->sweep_gram_rows = q->gram_rows;
-      if (q->sweep_exec) {
-        (void)hipGraphExecDestroy(q->sweep_exec);
-        q->sweep_exec = nullptr;
-      }
-      const hipError_t ei = hipGraphInstantiate(&q->sweep_exec, graph, nullptr, nullptr, 0);
-      (void)hipGraphDestroy(graph);
-      QP_HIP(ei);
-      q->sweep_key = skey;
-      QP_HIP(hipGraphLaunch(q->sweep_exec, ctx->stream));
-      ctx->stats.n_graph_launch++;
-    } else {
-      QP_CHECK(enqueue_columns());
-    }
+    QP_CHECK(enqueue_columns());
   }
   const cplx* hh = reinterpret_cast<const cplx*>(q->h_hess);
   const double* hn = q->h_norms;

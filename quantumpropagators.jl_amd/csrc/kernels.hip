@@ -101,8 +101,7 @@ __global__ __launch_bounds__(64 * WS) void hrb_spmv_kernel(const int64_t* __rest
                                                             const int4* __restrict__ lpos4,
                                                             const double2* __restrict__ x, int64_t nblocks,
                                                             int64_t nrows, Op op,
-                                                            const int32_t* __restrict__ block_map, SyncArgs sy,
-                                                            int lower_last) {
+                                                            const int32_t* __restrict__ block_map, SyncArgs sy) {
   constexpr bool NT = (VAR & 1) != 0;
   constexpr bool PRE = (VAR & 2) != 0;
   constexpr int UNR = (VAR & 4) ? 2 : 1;
@@ -193,7 +192,7 @@ __global__ __launch_bounds__(64 * WS) void hrb_spmv_kernel(const int64_t* __rest
     // issued before the first FMA (32 KiB in flight per wave instead of 4-8), which is what the
     // kernel needs once the working set no longer sits in the Infinity Cache (N >= 2^22: HBM
     // latency).  Same FMA order as the two loops below: bit-identical.
-    if (DEEP && !lower_last && nlq == 2 && nuq == 2 && (lcm & 3) == 2 && (ucm & 3) == 2) {
+    if (DEEP && nlq == 2 && nuq == 2 && (lcm & 3) == 2 && (ucm & 3) == 2) {
       const LowerStencilSlot* __restrict__ ls = reinterpret_cast<const LowerStencilSlot*>(lcolbytes + (lcm >> 2));
       const int4* __restrict__ ud = reinterpret_cast<const int4*>(ucolbytes + (ucm >> 2));
       // NEAR (variant bit 4): a gathered element x[row + d] with |d| < 64 is the row-local element x_i of the
@@ -243,13 +242,9 @@ __global__ __launch_bounds__(64 * WS) void hrb_spmv_kernel(const int64_t* __rest
         cfma(s1, ua[k + 1], ux[k + 1]);
       }
     } else
-    // order of the two sections (tuning key "hrb_lower_last"): the conj-transposed values of
-    // the lower section are found in L2 only if the wave that owns them has already fetched
-    // them; summation order changes with it, bitwise reproducibility per setting is kept
-    if (lower_last) {
-      upper();
-      lower();
-    } else {
+    // the lower section first: its conj-transposed values are the lines the waves of the rows above streamed shortly before
+    // on the same XCD.  (The summation order is part of the result's bits: the strip walk follows the same order.)
+    {
       lower();
       upper();
     }
@@ -421,12 +416,12 @@ static int launch_spmv(hipStream_t s, const DevMatrix& A, const double2* x, cons
       hipLaunchKernelGGL((hrb_spmv_kernel<Op, VV, double>), dim3(grid), dim3(kThreads), 0, s, A.bptr, A.cmeta, \
                          reinterpret_cast<const char*>(A.cols), A.vals_r, A.lptr, A.lcmeta,              \
                          reinterpret_cast<const char*>(A.lcols), reinterpret_cast<const int4*>(A.lpos), x, \
-                         nblk, A.nrows, op, bmap, sy, tun.hrb_lower_last);                                 \
+                         nblk, A.nrows, op, bmap, sy);                                 \
     else                                                                                                 \
       hipLaunchKernelGGL((hrb_spmv_kernel<Op, VV, double2>), dim3(grid), dim3(kThreads), 0, s, A.bptr, A.cmeta, \
                          reinterpret_cast<const char*>(A.cols), A.vals, A.lptr, A.lcmeta,                \
                          reinterpret_cast<const char*>(A.lcols), reinterpret_cast<const int4*>(A.lpos), x, \
-                         nblk, A.nrows, op, bmap, sy, tun.hrb_lower_last);                                 \
+                         nblk, A.nrows, op, bmap, sy);                                 \
     break;
     if constexpr (std::is_same<Op, ChebyOp>::value) {
       // a lattice operator (one stencil repeated down the row blocks): the strip walk (kernels_walk.hip) -- whole operator,
@@ -434,7 +429,7 @@ static int launch_spmv(hipStream_t s, const DevMatrix& A, const double2* x, cons
       // ... or the interior launch of a split term whose row set carries a plan of its own (RowSet::walk)
       const bool whole = !rs && A.walk && A.walk->valid;
       const bool set_walk = rs && rs->walk && rs->walk->valid && !rs->sync.signal;
-      if (tun.hrb_walk && (whole || set_walk) && wide_ok && !tun.hrb_lower_last && (tun.rbcsr_variant & 31) == 15 &&
+      if (tun.hrb_walk && (whole || set_walk) && wide_ok && (tun.rbcsr_variant & 31) == 15 &&
           op.e.xloc == x && !op.e.mirror) {
         bool launched = false;
         const int rcw = launch_hrb_walk_cheby(s, A, x, op.e, tun, &launched, rs);
@@ -455,12 +450,12 @@ static int launch_spmv(hipStream_t s, const DevMatrix& A, const double2* x, cons
           hipLaunchKernelGGL((hrb_spmv_kernel<Op, 15, double, 8>), dim3(g8), dim3(512), 0, s, A.bptr, A.cmeta,
                              reinterpret_cast<const char*>(A.cols), A.vals_r, A.lptr, A.lcmeta,
                              reinterpret_cast<const char*>(A.lcols), reinterpret_cast<const int4*>(A.lpos), x, nblk, A.nrows, op,
-                             bmap, sy8, tun.hrb_lower_last);
+                             bmap, sy8);
         else
           hipLaunchKernelGGL((hrb_spmv_kernel<Op, 15, double2, 8>), dim3(g8), dim3(512), 0, s, A.bptr, A.cmeta,
                              reinterpret_cast<const char*>(A.cols), A.vals, A.lptr, A.lcmeta,
                              reinterpret_cast<const char*>(A.lcols), reinterpret_cast<const int4*>(A.lpos), x, nblk, A.nrows, op,
-                             bmap, sy8, tun.hrb_lower_last);
+                             bmap, sy8);
         QP_HIP(hipGetLastError());
         if (st) {
           st->n_launch++;

@@ -327,13 +327,20 @@ def lattice_fill_host(nrows, ncols, rowptr, col, min_blocks=3072):
     """The lattice completion of operator creation on a host CSR pattern (no device needed): returns (rowptr, col)."""
     rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
     col = np.ascontiguousarray(col, dtype=np.int32)
-    # the completion accepts up to 12 % missing entries (engine_plans.hip: lattice_fill): room for 13 % and a block of slack
-    cap = int(1.13 * int(rowptr[-1])) + 64 * 20 + 1024
+    # the completion adds the missing entries of the rows (up to 12 %, engine_plans.hip: lattice_fill) plus the transposes that land
+    # in the first and last `reach` rows -- bounded by the pattern, not by a constant: ask for the size first (a call with no room
+    # reports the count it needs), then fill
     rp_out = np.empty(nrows + 1, dtype=np.int64)
-    col_out = np.empty(cap, dtype=np.int32)
     nnz = C.c_int64(0)
-    check(load().qp_lattice_fill_host(nrows, ncols, _ptr(rowptr, _i64p), _ptr(col, _i32p), int(min_blocks),
-                                      _ptr(rp_out, _i64p), _ptr(col_out, _i32p), cap, C.byref(nnz)))
+    cap = int(1.13 * int(rowptr[-1])) + 64 * 20 + 1024
+    for _ in range(2):
+        col_out = np.empty(cap, dtype=np.int32)
+        rc = load().qp_lattice_fill_host(nrows, ncols, _ptr(rowptr, _i64p), _ptr(col, _i32p), int(min_blocks),
+                                         _ptr(rp_out, _i64p), _ptr(col_out, _i32p), cap, C.byref(nnz))
+        if rc == 0 or nnz.value <= cap:
+            check(rc)
+            break
+        cap = int(nnz.value)      # (QP_E_BAD_ARG with *nnz_out = the entries the completed pattern has: retry with exactly that)
     return rp_out, col_out[:nnz.value].copy()
 
 
@@ -915,16 +922,15 @@ def _warn_if_off_the_walk(H):
     try:
         # an operator that is no lattice at all but has a fast path of its own has nothing to be told: irregular columns take
         # the column-blocked mirror, a qubit-register Hamiltonian (row XOR mask) the block-map encoding of its row blocks
-        if H.colblock_info()["valid"]:
+        if H.colblock_info()["valid"] or H.value_encoding_info()["valid"]:
             return
         enc = H.encoding_info()["upper"]
         if name in ("not_packed", "no_uniform_run") and enc["block_map"] > 0 and enc["int32"] + enc["int16"] == 0:
             return
     except Exception:
         pass
-    if True:
-        import warnings
-        warnings.warn(f"cheby!: this operator does not take the strip walk [{name}]: {text}", QPPerformanceWarning, stacklevel=3)
+    import warnings
+    warnings.warn(f"cheby!: this operator does not take the strip walk [{name}]: {text}", QPPerformanceWarning, stacklevel=3)
 
 
 def cheby_batched(psi_panel, H, dt, wrk, batch, E_min=None):

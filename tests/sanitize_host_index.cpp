@@ -378,6 +378,34 @@ int main() {
           std::snprintf(what, sizeof what, "random %lld x %lld fmt %d nvals %d herm %d", (long long)sh.first, (long long)sh.second, fmt, nvals, (int)herm);
           check_operator(ctx, terms, 0, fmt, what);
         }
+  // a row with a repeated column makes the stored count reach nrows x ncols although a position is missing -- the
+  // duplicate is summed (Julia's sparse() semantics), the operator must not be taken for a complete dense one
+  {
+    Csr t;
+    t.nrows = t.ncols = 3;
+    t.rp = {0, 3, 6, 9};
+    t.col = {0, 0, 1, 0, 1, 2, 0, 1, 2};
+    for (int i = 0; i < 9; ++i) t.val.push_back(qp_c128{1.0 + i, 0.5});
+    for (int fmt : {QP_FMT_AUTO, QP_FMT_DENSE, QP_FMT_RBCSR, QP_FMT_CSR}) {
+      qp_matrix* m = nullptr;
+      std::vector<int64_t> idx(t.col.begin(), t.col.end());
+      REQUIRE(qp_matrix_create(ctx, 3, 3, 9, t.rp.data(), idx.data(), t.val.data(), QP_VAL_C128, QP_LAYOUT_CSR, 0, QP_FMT_AUTO, &m) == QP_OK, "dup: matrix");
+      qp_operator* op = nullptr;
+      REQUIRE(qp_operator_create(ctx, &m, 1, 0, fmt, &op) == QP_OK, "dup: operator (format %d): %s", fmt, qp::g_last_error.c_str());
+      const int64_t nnz = op->A.nnz;
+      std::vector<int64_t> rp(4);
+      std::vector<int32_t> col((size_t)nnz);
+      std::vector<qp_c128> val((size_t)nnz);
+      REQUIRE(qp_operator_get_csr(op, rp.data(), col.data(), val.data()) == QP_OK, "dup: get_csr");
+      // row 0: columns 0 (1 + 2 = 3, 0.5 + 0.5) and 1; a dense layout adds the explicit zero at (0, 2)
+      REQUIRE(col[0] == 0 && val[0].re == 3.0 && val[0].im == 1.0 && col[1] == 1 && val[1].re == 3.0, "dup: row 0 is (%d: %g), (%d: %g)", col[0], val[0].re, col[1], val[1].re);
+      if (op->A.format == QP_FMT_DENSE) REQUIRE(nnz == 9 && col[2] == 2 && val[2].re == 0.0 && val[2].im == 0.0, "dup: the missing position must be an explicit zero");
+      else REQUIRE(nnz == 8, "dup: nnz %lld", (long long)nnz);
+      qp_operator_destroy(op);
+      qp_matrix_destroy(m);
+      ++n_cases;
+    }
+  }
   // several terms with coefficients (lazy sum, sparse control terms, table recombination)
   for (int rep = 0; rep < 12; ++rep) {
     const int64_t n = 50 + (int64_t)(rng() % 3000);

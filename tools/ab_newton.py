@@ -2,7 +2,7 @@
 """A/B of the Newton (config C3) knobs in ONE process, interleaved rounds: each configuration runs the same `steps`
 newton! steps from rho_0; median / min over the rounds.
 
-    python tools/ab_newton.py [--n 512] [--rounds 7] --configs "base:arnoldi_l2_order=0,arnoldi_nt=0,newton_graph=0;l2:arnoldi_l2_order=1,arnoldi_nt=0,newton_graph=0;..."
+    python tools/ab_newton.py [--n 512] [--rounds 7] --configs "two-pass:arnoldi_onepass=0;one-pass:arnoldi_onepass=2"
 """
 import argparse
 import os
@@ -16,12 +16,7 @@ sys.path.insert(0, ROOT)
 import qprop_amd.lib as L  # noqa: E402
 import qprop_amd.synth as synth  # noqa: E402
 
-DEFAULT = ("base:arnoldi_l2_order=0,arnoldi_nt=0,newton_graph=0;"
-           "l2order:arnoldi_l2_order=1,arnoldi_nt=0,newton_graph=0;"
-           "nt:arnoldi_l2_order=0,arnoldi_nt=1,newton_graph=0;"
-           "l2order+nt:arnoldi_l2_order=1,arnoldi_nt=1,newton_graph=0;"
-           "l2order+nt+graph:arnoldi_l2_order=1,arnoldi_nt=1,newton_graph=1;"
-           "graph:arnoldi_l2_order=0,arnoldi_nt=0,newton_graph=1")
+DEFAULT = ("two-pass:arnoldi_onepass=0;auto:arnoldi_onepass=1;one-pass:arnoldi_onepass=2")
 
 
 def main():

@@ -25,7 +25,6 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--pattern", default="banded")
     ap.add_argument("--formats", default="rbcsr")
-    ap.add_argument("--lower-last", type=int, default=0)
     ap.add_argument("--ab", default="", help="A/B over one knob: key=v1,v2,... (every format / variant case is run with each value)")
     ap.add_argument("--offsets", default="", help="Hermitian lattice with these distances instead of --pattern (e.g. 1,1000 or 1,2,3,4,100,200,300,400)")
     ap.add_argument("--grid", default="", help="nx,ny: finite-difference Hamiltonian on an open-boundary grid (synth.grid_hamiltonian_2d)")
@@ -53,7 +52,6 @@ def main():
     if args.real:
         vals = vals.real.astype(np.complex128)
     ctx = L.Context(0)
-    L.tuning_set("hrb_lower_last", args.lower_last)
     if args.no_fill:
         L.tuning_set("lattice_fill", 0)
     M = L.Matrix(ctx, N, N, rp, col, vals)

@@ -423,6 +423,12 @@ def measure_dense(ctx, N=4096, batch=1, fmt="dense", mfma=1, steps=None, repeats
             step()
             one = max(ctx.timer_end(), 1e-3)
             steps = int(max(1, min(50, 20.0 / one)))
+        # steady-state clocks: the first ~20 ms after an idle gap (the host built a 4096 x 4096 matrix just now) run at the clock the
+        # chip idled at -- 146 - 160 us per term instead of 127.5 - 128.5 for the 64-state panel, profiles/r05/dense_modes.txt
+        t_warm = time.perf_counter()
+        while time.perf_counter() - t_warm < 0.25:
+            step()
+        ctx.sync()
         regions = timed_regions(ctx, step, steps, repeats)
     finally:
         ctx.tuning_set("dense_panel_mfma", saved)

@@ -48,7 +48,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s measured copy)
 KERNEL_OF_FORMAT = {1: "csr_spmv_kernel", 2: "rbcsr_spmv_kernel", 3: "hrb_spmv_kernel"}
-STATIC_PMC = os.path.join("profiles", "r04", "bench_pmc_summary.json")
+STATIC_PMC = os.path.join("profiles", "r05", "bench_pmc_summary.json")
 
 
 def pmc_traffic(argv_inner, kernel_substr, timeout_s, how="mean"):
@@ -307,17 +307,20 @@ def compact_line(full):
     return line
 
 
-def emit(full):
+def emit(full, tag=""):
     """Rank 0: the complete record to bench_extras.json (next to this script, and under gpurun_out/ where that exists so that
-    it travels back from a GPU box), one short `EXTRA ` line per extra point, then -- LAST -- the compact line."""
+    it travels back from a GPU box; `tag`: "_c5", "_c4", "_gpus8" .. for the runs that are not the default headline), one short
+    `EXTRA ` line per extra point, then -- LAST -- the compact line."""
+    name = EXTRAS_FILE.replace(".json", f"{tag}.json")
     for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
         if os.path.isdir(d):
             try:
-                with open(os.path.join(d, EXTRAS_FILE), "w") as f:
+                with open(os.path.join(d, name), "w") as f:
                     json.dump(full, f, indent=1)
             except OSError:
                 pass
     line = compact_line(full)
+    line["extras_file"] = name
     for name, v in (line.get("points") or {}).items():
         print("EXTRA " + json.dumps({name: v}))
     text = json.dumps(line, separators=(",", ":"))
@@ -419,7 +422,7 @@ def run_c5(args, world, rank, local_rank, one_gpu, dist, L, synth, bp):
         rfl["traffic_over_bytes"] = rfl["traffic_over_layout_bytes"]
         rfl["traffic_measured"] = tr is not None
     if rank == 0:
-        emit(out)
+        emit(out, "_c5" + (f"_gpus{world}" if world > 1 else ""))
     if bs is not None:
         bs.close()
     if dist is not None:
@@ -873,7 +876,7 @@ def main():
                     kept = json.loads(fallback_line)
                     kept["degraded"] = True
                     kept["native_path"] = reason
-                    emit(kept)
+                    emit(kept, f"_{config}_gpus{world}")
                 sys.stderr.write(f"[bench.py rank {rank}] native / overlapped path {reason} (limit {args.watchdog} s): "
                                  f"reporting the conservative measurement, exit status 3\n")
                 if reason == "hung":      # where: the Python stacks
@@ -1148,7 +1151,9 @@ def main():
         out["strong_point"] = {k: sp_[k] for k in ("N_total", "prop_steps_per_s", "ms_per_step", "exchange")}
     out["prediction"] = prediction_scalars(out.get("scaling_prediction"))
     if rank == 0:
-        emit(out)
+        default_run = world == 1 and config == "c2" and args.log2n is None and args.pattern == "banded" and args.format == "auto" and \
+            not args.real and args.dt == 1.0 and args.scaling == "weak"
+        emit(out, "" if default_run else f"_{config}" + (f"_gpus{world}" if world > 1 else "") + ("" if args.log2n is None else f"_n{log2n}"))
     if dist is not None:
         sh.close()      # the library's communicator goes before the process group it was bootstrapped over
         dist.destroy_process_group()

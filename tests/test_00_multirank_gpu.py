@@ -141,7 +141,8 @@ def test_bench_eight_ranks_full_c4_flow_one_gpu():
     assert ag["us_per_term"] > 0 and ag["blocks_per_s"] > 0 and "error" not in ag
     assert d["prediction"]["fixed_n24_speedup_8gpu_halo"] > 6.0 > d["prediction"]["fixed_n24_speedup_8gpu_allgather"]
     # the complete record next to the script
-    with open(os.path.join(ROOT, "bench_extras.json")) as f:
+    assert d["extras_file"] == "bench_extras_c4_gpus8.json"
+    with open(os.path.join(ROOT, d["extras_file"])) as f:
         full = json.load(f)
     assert full["config"]["blocks_of_2^20_rows_per_step"] == 16.0 and "schedule=auto: overlap" in full["config"]["parallelism"] and "driver=native" in full["config"]["parallelism"]
     sp_ = full["strong_scaling_point"]

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Fuzz of newton! on the MULTI-LAUNCH Arnoldi path (more stored entries than the persistent kernel
 takes: low-synchronisation Gram-Schmidt with the solve in the reduction's last workgroup, pipelined
-Hessenberg eigenvalues, pre-folded Leja products, fused basis combination) against the NumPy oracle:
+Hessenberg eigenvalues, pre-folded Leja products, fused basis combination; the one-pass sweep of csrc/kernels_onepass.hip in a third of the cases) against the NumPy oracle:
 random sparse systems, Hermitian or not, random Krylov size, time step sign, several steps.
 
     python tools/fuzz_newton_large.py [n_cases] [seed]"""
@@ -31,6 +31,8 @@ for case in range(ncases):
     psi0 /= np.linalg.norm(psi0)
     mode = int(rng.integers(0, 2))
     pipe = int(rng.integers(0, 2))
+    onepass = int(rng.integers(0, 3))      # 0 never, 1 auto, 2 the one-pass sweep wherever an instance exists (m_max <= 20, mode 1)
+    L.tuning_set("arnoldi_onepass", onepass)
     L.tuning_set("arnoldi_mode", mode)
     L.tuning_set("newton_pipeline", pipe)
     Op = L.Operator(ctx, [L.Matrix.from_scipy(ctx, sp.csr_matrix(A))])
@@ -50,9 +52,10 @@ for case in range(ncases):
         ok, msg = False, f"{type(e).__name__}: {e}"
     if not ok:
         bad += 1
-        print(f"case {case}: N={N} nnz={A.nnz} herm={herm} m_max={m_max} dt={dt:.3f} steps={nsteps} mode={mode} pipe={pipe}: {msg}",
+        print(f"case {case}: N={N} nnz={A.nnz} herm={herm} m_max={m_max} dt={dt:.3f} steps={nsteps} mode={mode} pipe={pipe} onepass={onepass}: {msg}",
               flush=True)
 L.tuning_set("arnoldi_mode", 1)
+L.tuning_set("arnoldi_onepass", 1)
 L.tuning_set("newton_pipeline", 1)
 print(f"{ncases} cases, {bad} bad")
 sys.exit(1 if bad else 0)

@@ -22,11 +22,16 @@ constexpr int kFusedWaves = 8;
 // NT (knob arnoldi_nt): the matrix values and column sections are loaded nontemporal -- the matrix is read once per
 // column and does not fit an XCD's L2 next to the basis; streamed, it leaves the L2 to the basis vectors that the
 // projection kernel reads next (kernels_blas.hip: mgs_update_kernel<.., ORD = true>)
-template <int JT, class VT, bool NT>   // VT: double2, or double for the real copy of an all-real operator (kernel_common.h: ld_val)
+// CODED: the operator has a value-dictionary mirror (device.h: CodedVals; kernels_coded.hip) -- `vals` is then the combined TABLE,
+// a quad of slots costs one dword of four codes instead of four value loads, and the block's table (at most 256 entries) is staged
+// in the wavefront's reduction tile, which is idle until the epilogue.  Same values in the same order: bit-identical sums.
+template <int JT, class VT, bool NT, bool CODED = false>   // VT: double2, or double for the real copy of an all-real operator (kernel_common.h: ld_val)
 __global__ __launch_bounds__(64 * kFusedWaves) void arnoldi_matvec_dots_kernel(
     const int64_t* __restrict__ bptr, const int64_t* __restrict__ cmeta, const char* __restrict__ colbytes,
     const VT* __restrict__ vals, const double2* __restrict__ x, int64_t nblocks, int64_t nrows, PlainEpi e,
-    const double2* __restrict__ Q, int64_t ldq, int j, double2* __restrict__ partials) {
+    const double2* __restrict__ Q, int64_t ldq, int j, double2* __restrict__ partials,
+    const unsigned* __restrict__ codes4 = nullptr, const int64_t* __restrict__ tptr = nullptr) {
+  static_assert(!CODED || sizeof(VT) * 256 <= sizeof(double) * 64 * 9, "a block's table fits the wavefront's reduction tile");
   static_assert(JT % 4 == 0, "chunks of four basis vectors");
   static_assert(kRedBlocks == 256, "the folded norm: 256 partials, four wavefronts' worth");
   __shared__ double2 lds4[4];
@@ -51,7 +56,7 @@ __global__ __launch_bounds__(64 * kFusedWaves) void arnoldi_matvec_dots_kernel(
     const int64_t bc = active ? b : nblocks - 1;
     const int64_t base = bptr[bc];
     const int nq = active ? (int)((bptr[bc + 1] - base) >> 8) : 0;
-    const VT* __restrict__ v = vals + base + lane;
+    const VT* __restrict__ v = vals + (CODED ? 0 : base + lane);
     const int64_t cm = cmeta[bc];
     const int64_t row = bc * kRB + lane;
     const bool valid = active && row < nrows;
@@ -63,6 +68,41 @@ __global__ __launch_bounds__(64 * kFusedWaves) void arnoldi_matvec_dots_kernel(
 #pragma unroll
     for (int u = 0; u < 4; ++u) qa[u] = (Q + (size_t)min(u, jl) * ldq)[ro];
     double2 s0 = make_double2(0.0, 0.0), s1 = make_double2(0.0, 0.0);
+    if constexpr (CODED) {
+      VT* __restrict__ tw = reinterpret_cast<VT*>(red_tile[wave]);
+      const int64_t tp = tptr[bc];
+      const VT* __restrict__ tb = vals + (tp >> 9);
+      const int tlen = (int)(tp & 511);
+      if (t > 0) {      // the previous block's table reads are done before this block's table overwrites them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (i * 64 < tlen) tw[i * 64 + lane] = tb[min(i * 64 + lane, tlen - 1)];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const unsigned* __restrict__ cq = codes4 + (base >> 2) + lane;
+#pragma unroll 2
+      for (int q = 0; q < nq; ++q) {
+        const unsigned cw = __builtin_nontemporal_load(cq + (size_t)q * 64);
+        const int4 cc = ld_cols<true>(colbytes, cm, q, lane, (int)rowc);
+        const double2 x0 = x[cc.x];
+        const double2 x1 = x[cc.y];
+        const double2 x2 = x[cc.z];
+        const double2 x3 = x[cc.w];
+        const double2 a0 = ld_val<false>(tw + (cw & 255u));
+        const double2 a1 = ld_val<false>(tw + ((cw >> 8) & 255u));
+        const double2 a2 = ld_val<false>(tw + ((cw >> 16) & 255u));
+        const double2 a3 = ld_val<false>(tw + (cw >> 24));
+        cfma(s0, a0, x0);
+        cfma(s1, a1, x1);
+        cfma(s0, a2, x2);
+        cfma(s1, a3, x3);
+      }
+    } else {
 #pragma unroll 2
     for (int q = 0; q < nq; ++q) {
       const int4 cc = ld_cols<NT>(colbytes, cm, q, lane, (int)rowc);
@@ -78,6 +118,7 @@ __global__ __launch_bounds__(64 * kFusedWaves) void arnoldi_matvec_dots_kernel(
       cfma(s1, a1, x1);
       cfma(s0, a2, x2);
       cfma(s1, a3, x3);
+    }
     }
     if (t == 0 && e.norm_part) {
       np.x = wave_sum(np.x);
@@ -151,6 +192,11 @@ __global__ __launch_bounds__(64 * kFusedWaves) void arnoldi_matvec_dots_kernel(
   {
     constexpr int NV = 4 * JT;
     double* __restrict__ tile = red_tile[wave];
+    if constexpr (CODED) {      // the tile held the last block's table until here
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
     const int tv = lane & 7, tp = lane >> 3;
 #pragma unroll
     for (int ch = 0; ch < NV / 8; ++ch) {
@@ -195,14 +241,26 @@ static void launch_instance_nt(hipStream_t s, const DevMatrix& A, const double2*
                                int64_t ldq, int j, double2* partials) {
   if (A.vals_r)
     hipLaunchKernelGGL((arnoldi_matvec_dots_kernel<JT, double, NT>), dim3(kRedBlocks), dim3(64 * kFusedWaves), 0, s, A.bptr,
-                       A.cmeta, reinterpret_cast<const char*>(A.cols), A.vals_r, x, A.nblocks, A.nrows, e, Q, ldq, j, partials);
+                       A.cmeta, reinterpret_cast<const char*>(A.cols), A.vals_r, x, A.nblocks, A.nrows, e, Q, ldq, j, partials, nullptr, nullptr);
   else
     hipLaunchKernelGGL((arnoldi_matvec_dots_kernel<JT, double2, NT>), dim3(kRedBlocks), dim3(64 * kFusedWaves), 0, s, A.bptr,
-                       A.cmeta, reinterpret_cast<const char*>(A.cols), A.vals, x, A.nblocks, A.nrows, e, Q, ldq, j, partials);
+                       A.cmeta, reinterpret_cast<const char*>(A.cols), A.vals, x, A.nblocks, A.nrows, e, Q, ldq, j, partials, nullptr, nullptr);
 }
 template <int JT>
 static void launch_instance(hipStream_t s, const DevMatrix& A, const double2* x, const PlainEpi& e, const double2* Q,
                             int64_t ldq, int j, double2* partials) {
+  // an operator with a value dictionary: codes + the block's table instead of the value plane
+  if (A.cv && A.cv->valid && A.tun && A.tun->value_dict != 0) {
+    const CodedVals& C = *A.cv;
+    const unsigned* codes4 = reinterpret_cast<const unsigned*>(C.codes);
+    if (C.use_real)
+      hipLaunchKernelGGL((arnoldi_matvec_dots_kernel<JT, double, true, true>), dim3(kRedBlocks), dim3(64 * kFusedWaves), 0, s, A.bptr,
+                         A.cmeta, reinterpret_cast<const char*>(A.cols), C.tab_r, x, A.nblocks, A.nrows, e, Q, ldq, j, partials, codes4, C.tptr);
+    else
+      hipLaunchKernelGGL((arnoldi_matvec_dots_kernel<JT, double2, true, true>), dim3(kRedBlocks), dim3(64 * kFusedWaves), 0, s, A.bptr,
+                         A.cmeta, reinterpret_cast<const char*>(A.cols), C.tab, x, A.nblocks, A.nrows, e, Q, ldq, j, partials, codes4, C.tptr);
+    return;
+  }
   // (only where the operator is large enough for the question to exist: a small one sits in the L2 with its basis)
   const bool nt = A.tun && A.tun->arnoldi_nt != 0 && (double)A.stored * (A.vals_r ? 8.0 : 16.0) > 8.0 * 1024 * 1024;
   if (nt) launch_instance_nt<JT, true>(s, A, x, e, Q, ldq, j, partials);

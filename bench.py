@@ -146,7 +146,7 @@ def exchange_model(sh, world, rows, us_per_term):
 
 
 MACHINERY_FACTOR = 74.7 / 68.8      # overlapped native step / plain term at 2^21 rows on one GPU (profiles/r03/sharded_machinery_1gpu.txt)
-STATIC_SIZES = os.path.join("profiles", "r04", "single_gpu_sizes.json")
+STATIC_SIZES = os.path.join("profiles", "r05", "single_gpu_sizes.json")
 
 
 def scaling_prediction(us_per_term_by_log2rows, value_1gpu, nterms, source):

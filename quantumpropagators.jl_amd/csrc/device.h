@@ -278,6 +278,13 @@ inline int dense_gemv_grid(int64_t nrows) {
 // Developer knobs for A/B measurements.  Every context carries its own copy (qp_ctx::tun, set with
 // qp_ctx_tuning_set); qp_tuning_set only changes the defaults that contexts created afterwards start
 // from, so handles driven from different threads never observe each other's switches.
+// fixed choices that were knobs while they were being measured (docs/history/): the density from which AUTO lays an operator out dense,
+// the resident wavefronts per CU the column-blocked mirror is sized for (24 and 32 measured slower), the compute units an interior strip
+// walk leaves to the boundary launch and the collective's kernel
+constexpr int kDenseMinDensityPct = 75;
+constexpr int kCbWavesPerCu = 16;
+constexpr int kWalkReserveCu = 8;
+
 struct Tuning {
   int rbcsr_variant = 15;     // bit 0 nt matrix loads, bit 1 early row-local loads, bit 2 deeper unroll, bit 3 (Hermitian-packed kernel) all loads of an all-stencil block up front (A/B in profiles/)
   int arnoldi_mode = 1;       // 0 = sequential fused MGS passes, 1 = low-synchronisation MGS
@@ -301,14 +308,11 @@ struct Tuning {
   int roctx = 0;              // 1 = named profiler ranges around the steps' phases (qprop_internal.h: ScopedRange); also QP_ROCTX=1
   int arnoldi_l2_order = 1;   // 1 = the projection kernel owns the mat-vec's rows per XCD and reads rounds / basis vectors back to front (L2 reuse of what the dots pass read last)
   int arnoldi_nt = 1;         // 1 = the fused Arnoldi mat-vec streams the matrix nontemporal (the L2 keeps basis vectors instead)
-  int dense_auto = 1;         // 1 = AUTO lays an operator out dense (QP_FMT_DENSE) when at least dense_min_density_pct % of its positions are stored
-  int dense_min_density_pct = 75;
+  int dense_auto = 1;         // 1 = AUTO lays an operator out dense (QP_FMT_DENSE) when at least 75 % (kDenseMinDensityPct) of its positions are stored
   int dense_panel_mfma = 1;   // 1 = the batched step of a dense operator runs H X on the fp64 matrix cores (kernels_dense.hip); 0 = the sparse panel kernels (A/B)
   int colblock = 1;           // 1 = an operator with irregular columns whose vector outgrows the L2 gets a column-blocked mirror (kernels_colblock.hip); 2 = any row-block / CSR operator that fits the mirror's limits (tests); 0 = off
   int cb_log2w = 0;           // ... columns per block (log2); 0 = about sixteen blocks, 2^16 ... 2^18 columns each (1 - 4 MB of the vector; an XCD's L2 holds 4 MB)
   int cb_min_log2n = 20;      // ... smallest number of columns (log2) the mirror is built for (measured: 2^18 columns 0.9 x, 2^19 1.04 x, 2^20 1.37 x, 2^21 1.62 x, 2^22 1.52 x)
-  int cb_rpt = 0;             // ... 64-row groups per tile: 0 = 2 unless a segment would outgrow the LDS buffer, else 1 or 2
-  int cb_waves = 16;          // ... resident wavefronts per CU the launch is sized for (24 and 32 measured slower: 410 vs 353 us at 2^21 columns)
   int small_nnz = 8192;       // qp_propagate: register-resident Cheby systems up to this nnz run as ONE persistent launch (0: off)
   int newton_pipeline = 1;    // newton!: Hessenberg eigenvalues overlap the Arnoldi sweep
   int spmm_tile = 16;         // states per pass of the tiled batched SpMM kernel (16, 32 or 64)
@@ -319,7 +323,6 @@ struct Tuning {
   int spmm_strip = 0;         // batched SpMM row walk: inner-index strip width (0 = chosen from the L2 size; -1 = natural row order)
   int hrb_walk = 1;           // Hermitian-packed fused term of a whole lattice operator: the strip-walk kernel (kernels_walk.hip) when the operator has a walk plan
   int walk_waves = 0;         // strip walk: wavefronts the walk is cut into (0: 768 for an operator that fits the Infinity Cache, else 8 per CU on every CU the edge workgroups leave free -- 1856 for the headline lattice --, or 2048 with the edge blocks inside the walk)
-  int walk_reserve_cu = 8;    // strip walk as the interior launch of a split term: compute units left free (beyond the edge workgroups') for the boundary launch and the collective's kernel
   int walk_wg = 0;            // strip walk: wavefronts per workgroup (0: 4 for an operator that fits the Infinity Cache, else 8; or 8 / 4 / 2)
   int value_dict = 1;         // value-dictionary mirror of row-block operators with few distinct values per block (0: never built / used)
   int walk_nt = -1;           // strip walk: nontemporal accesses (-1: the matrix values when the operator does not fit the Infinity Cache; bit 0 matrix values; bits 1, 2: vector loads, stores -- measurement variants of the headline shape)

@@ -595,7 +595,7 @@ int qp_cheby_term_split(qp_operator* op, qp_split* sp, void* boundary_stream, in
   qp::RowSet ri{sp->bmap_interior, sp->n_interior, true};
   if (sp->walk.valid) {   // lattice operator: the interior as a strip walk; CUs beyond the edge workgroups' stay free (knob) for
     ri.walk = &sp->walk;  // the boundary launch and the collective's kernel that run beside it
-    ri.reserve_cu = std::max(0, op->ctx->tun.walk_reserve_cu);
+    ri.reserve_cu = qp::kWalkReserveCu;
   }
   QP_CHECK(split_timed_out(sp));
   // knob split_mode: 1 = in-launch counter hand-off, 0 = events on both streams, 2 (default) = the counter

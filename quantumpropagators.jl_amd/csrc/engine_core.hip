@@ -30,13 +30,13 @@ int* tuning_field(Tuning& t, const char* key) {
       {"stencil", &Tuning::stencil}, {"block_map", &Tuning::block_map},             {"acc_defer", &Tuning::acc_defer},
       {"cheby_graph", &Tuning::cheby_graph},     {"small_nnz", &Tuning::small_nnz},
       {"roctx", &Tuning::roctx}, {"arnoldi_l2_order", &Tuning::arnoldi_l2_order}, {"arnoldi_nt", &Tuning::arnoldi_nt},
-      {"colblock", &Tuning::colblock}, {"cb_log2w", &Tuning::cb_log2w}, {"cb_min_log2n", &Tuning::cb_min_log2n}, {"cb_waves", &Tuning::cb_waves}, {"cb_rpt", &Tuning::cb_rpt},
-      {"dense_auto", &Tuning::dense_auto},       {"dense_min_density_pct", &Tuning::dense_min_density_pct}, {"dense_panel_mfma", &Tuning::dense_panel_mfma},
+      {"colblock", &Tuning::colblock}, {"cb_log2w", &Tuning::cb_log2w}, {"cb_min_log2n", &Tuning::cb_min_log2n},
+      {"dense_auto", &Tuning::dense_auto},       {"dense_panel_mfma", &Tuning::dense_panel_mfma},
       {"newton_pipeline", &Tuning::newton_pipeline}, {"spmm_tile", &Tuning::spmm_tile},
       {"spmm_nt", &Tuning::spmm_nt},             {"spmm_rows", &Tuning::spmm_rows},
       {"spmm_strip", &Tuning::spmm_strip},       {"spmm_rw", &Tuning::spmm_rw},
       {"hrb_walk", &Tuning::hrb_walk},           {"walk_waves", &Tuning::walk_waves},
-      {"walk_min_blocks", &Tuning::walk_min_blocks}, {"walk_dbg", &Tuning::walk_dbg}, {"walk_nt", &Tuning::walk_nt}, {"value_dict", &Tuning::value_dict}, {"walk_wg", &Tuning::walk_wg}, {"walk_reserve_cu", &Tuning::walk_reserve_cu}, {"walk_edge_steps", &Tuning::walk_edge_steps}, {"split_spin_log2", &Tuning::split_spin_log2}, {"split_dbg", &Tuning::split_dbg}, {"spmm_walk", &Tuning::spmm_walk}, {"spmm_walk_waves", &Tuning::spmm_walk_waves},
+      {"walk_min_blocks", &Tuning::walk_min_blocks}, {"walk_dbg", &Tuning::walk_dbg}, {"walk_nt", &Tuning::walk_nt}, {"value_dict", &Tuning::value_dict}, {"walk_wg", &Tuning::walk_wg}, {"walk_edge_steps", &Tuning::walk_edge_steps}, {"split_spin_log2", &Tuning::split_spin_log2}, {"split_dbg", &Tuning::split_dbg}, {"spmm_walk", &Tuning::spmm_walk}, {"spmm_walk_waves", &Tuning::spmm_walk_waves},
   };
   for (const Entry& e : table)
     if (std::strcmp(e.name, key) == 0) return &(t.*(e.field));
@@ -1116,7 +1116,7 @@ int qp_operator_create(qp_ctx* ctx, qp_matrix* const* ops, int nops, int ncoeffs
       ur[r + 1] = (int64_t)uc.size();
     }
   }
-  // ---- a dense generator (QP_FMT_DENSE): requested, or AUTO with at least dense_min_density_pct % of the positions stored.
+  // ---- a dense generator (QP_FMT_DENSE): requested, or AUTO with at least kDenseMinDensityPct % of the positions stored.
   // The pattern is made complete (the missing positions become explicit zeros, counted like the lattice completion's), so
   // that the CSR-ordered value array IS the row-major dense matrix and the dense kernels need no index at all.
   bool dense = false;
@@ -1126,7 +1126,7 @@ int qp_operator_create(qp_ctx* ctx, qp_matrix* const* ops, int nops, int ncoeffs
       if (positions > (double)INT32_MAX) return qp::fail(QP_E_BAD_ARG, "QP_FMT_DENSE: %lld x %lld positions exceed the 2^31 limit", (long long)nrows, (long long)ncols);
       dense = nrows > 0 && ncols > 0;
     } else if (format == QP_FMT_AUTO && ctx->tun.dense_auto && nrows > 0 && ncols > 0 && positions <= 1073741824.0) {
-      dense = 100.0 * (double)ur[nrows] >= (double)ctx->tun.dense_min_density_pct * positions;
+      dense = 100.0 * (double)ur[nrows] >= (double)qp::kDenseMinDensityPct * positions;
     }
   }
   if (dense) {

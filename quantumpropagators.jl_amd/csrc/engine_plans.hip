@@ -337,7 +337,6 @@ int build_colblock(qp_operator* op) {
   int rpt = 0, max_seg = 0;
   int64_t ntiles = 0;
   for (int tryr : {2, 1}) {
-    if (tun.cb_rpt != 0 && tun.cb_rpt != tryr) continue;
     const int64_t TR = 64 * tryr;
     ntiles = (nrows + TR - 1) / TR;
     segcnt.assign((size_t)(ntiles * P + 1), 0);
@@ -355,7 +354,7 @@ int build_colblock(qp_operator* op) {
   }
   if (rpt == 0) return QP_OK;   // a (64-row, 2^log2w-column) cell with more than kCbMaxSeg entries: not this kernel's operator
   {
-    const int64_t resident = (int64_t)std::max(tun.n_cu, 1) * std::max(4, std::min(tun.cb_waves, 32));
+    const int64_t resident = (int64_t)std::max(tun.n_cu, 1) * qp::kCbWavesPerCu;
     if ((ntiles + resident - 1) / resident > qp::kCbMaxTilesPerWave) return QP_OK;
   }
   const int64_t TR = 64 * rpt;

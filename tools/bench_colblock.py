@@ -44,8 +44,6 @@ def main():
                         ctx.tuning_set(kv.split("=")[0], int(kv.split("=")[1]))
                     ctx.tuning_set("colblock", 2 if (ln < 19 or args.force) else 1)
                     ctx.tuning_set("cb_log2w", lw)
-                    ctx.tuning_set("cb_waves", wv)
-                    ctx.tuning_set("cb_rpt", rpt)
                     r = bp.measure_cheby(ctx, pattern=pat, log2n=ln, steps=args.steps, warmup=2)
                     ci = r["column_blocked_mirror"]
                     if not ci["valid"]:

@@ -16,7 +16,6 @@ dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cu
 N = 1 << int(os.environ.get("QP_LOG2N", "20"))
 rp, col, vals = synth.hermitian_offsets_csr(N)
 ctx = L.Context(0, stream=torch.cuda.current_stream().cuda_stream)
-ctx.tuning_set("walk_reserve_cu", int(os.environ.get("QP_WALK_RESERVE", "8")))
 ctx.tuning_set("hrb_walk", int(os.environ.get("QP_HRB_WALK", "1")))      # 0: the per-block kernels everywhere (A/B of the strip walk)
 psi0 = synth.random_state(N)
 send = np.concatenate([np.arange(0, 4096), np.arange(N - 4096, N)])

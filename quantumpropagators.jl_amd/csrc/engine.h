@@ -148,7 +148,7 @@ struct qp_krylov {
   int64_t n;
   int nvec;
   double2* Q = nullptr;         // nvec vectors of length n, contiguous
-  double2* raw[2] = {nullptr, nullptr};   // unnormalised vectors of the folded sweep (knob arnoldi_fold), on demand
+  double2* raw[2] = {nullptr, nullptr};   // unnormalised vectors of the folded sweep, on demand
   double2* hess_dev = nullptr;  // nvec x nvec column major
   double* norms_dev = nullptr;  // nvec
   double2* part = nullptr;      // 2 x kRedBlocks ping-pong partials

@@ -25,7 +25,7 @@ int* tuning_field(Tuning& t, const char* key) {
   static const Entry table[] = {
       {"rbcsr_variant", &Tuning::rbcsr_variant},
       {"arnoldi_mode", &Tuning::arnoldi_mode},   {"arnoldi_onepass", &Tuning::arnoldi_onepass},   {"split_mode", &Tuning::split_mode},
-      {"arnoldi_fold", &Tuning::arnoldi_fold},   {"spmm_wg", &Tuning::spmm_wg},   {"hrb_wg", &Tuning::hrb_wg},   {"arnoldi_solve", &Tuning::arnoldi_solve},   {"arnoldi_fuse_dots", &Tuning::arnoldi_fuse_dots},   {"lattice_fill", &Tuning::lattice_fill},   {"sparse_controls", &Tuning::sparse_controls},
+      {"spmm_wg", &Tuning::spmm_wg},   {"hrb_wg", &Tuning::hrb_wg},   {"arnoldi_fuse_dots", &Tuning::arnoldi_fuse_dots},   {"lattice_fill", &Tuning::lattice_fill},   {"sparse_controls", &Tuning::sparse_controls},
       {"liouville_fused_n", &Tuning::liouville_fused_n}, {"liouville_tile32_n", &Tuning::liouville_tile32_n}, {"liouville_tile32_min_n", &Tuning::liouville_tile32_min_n}, {"real_vals", &Tuning::real_vals},
       {"stencil", &Tuning::stencil}, {"block_map", &Tuning::block_map},             {"acc_defer", &Tuning::acc_defer},
       {"cheby_graph", &Tuning::cheby_graph},     {"small_nnz", &Tuning::small_nnz},

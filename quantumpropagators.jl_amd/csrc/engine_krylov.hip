@@ -151,7 +151,7 @@ int arnoldi_column(qp_operator* op, qp_krylov* q, int j, double dt, double2* hco
     q->gram_rows = j + 1;
     return qp::launch_mgs_lowsync(ctx->stream, q->Q, q->n, j, w, q->md_part, q->gram, q->nvec, hcol,
                                   q->hcoef, q->mgs_coef, q->ticket, q->part + (size_t)((j + 1) & 1) * kRedBlocks, dt,
-                                  q->n, &ctx->stats, ctx->tun.arnoldi_solve != 0, fold ? fold->early_flag : nullptr,
+                                  q->n, &ctx->stats, /* reduction + solve in the projection's prologue */ true, fold ? fold->early_flag : nullptr,
                                   fold ? fold->flag_value : 0u, fold ? fold->early_armed : nullptr, dots_done,
                                   ctx->tun.arnoldi_l2_order != 0);
   }
@@ -349,10 +349,10 @@ static int arnoldi_impl(qp_operator* op, qp_krylov* q, int m, const qp_state* ps
         q->col_events.push_back(e);
       }
     }
-    // knob arnoldi_fold: "norm + scale" of column j is done by the mat-vec of column j + 1 (it scales its row
+    // "norm + scale" of column j is done by the mat-vec of column j + 1 (it scales its row
     // sums by 1 / |q_j| and stores the normalised q_j as it goes; src/arnoldi.jl:89-96 applied on the fly), so a
     // column is mat-vec + projection only.  The unnormalised vectors ping-pong between two scratch vectors.
-    fold = ctx->tun.arnoldi_fold != 0 && op->A.format != QP_FMT_MATFREE && m > 1;
+    fold = op->A.format != QP_FMT_MATFREE && m > 1;
     if (fold && !q->raw[0]) {
       QP_CHECK(dev_alloc(&q->raw[0], (size_t)q->n));
       QP_CHECK(dev_alloc(&q->raw[1], (size_t)q->n));

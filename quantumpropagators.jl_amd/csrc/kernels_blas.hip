@@ -499,7 +499,7 @@ __global__ __launch_bounds__(kThreads) void mgs_solve_kernel(int j, const double
 
 // w += sum_i coef_i q_i in MGS order (coef_i = -h_i) and |w|^2 partials; EPL elements per lane and four
 // basis vectors per round in flight; BS threads per workgroup (see multidot_kernel)
-// SOLVE (one GPU, knob arnoldi_solve): every workgroup first sums the kRedBlocks multidot partials of all 2 (j + 1)
+// SOLVE (one GPU): every workgroup first sums the kRedBlocks multidot partials of all 2 (j + 1)
 // values itself -- lane l adds partials l, l + 64, l + 128, l + 192, then the wavefront tree: a fixed order -- and
 // solves for the MGS coefficients, redundantly but without the reduction launch in between; workgroup 0 records the
 // Hessenberg column, every workgroup writes the (identical) new Gram row.

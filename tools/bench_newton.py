@@ -31,10 +31,8 @@ def main():
     ap.add_argument("--format", default="auto", choices=["auto", "rbcsr", "csr"])
     ap.add_argument("--check", action="store_true", help="compare one step with the NumPy oracle (slow)")
     ap.add_argument("--variant", type=int, default=None, help="knob rbcsr_variant (kernel variant bits) for A/B runs")
-    ap.add_argument("--solve", type=int, default=1, help="1 = MGS reduction + solve in the projection kernel's prologue (default), 0 = own launch")
     ap.add_argument("--pipeline", type=int, default=1, help="1 = Hessenberg eigenvalues overlap the Arnoldi sweep (default)")
     ap.add_argument("--arnoldi-mode", type=int, default=1, help="1 = low-sync MGS (default), 0 = sequential MGS passes")
-    ap.add_argument("--fold", type=int, default=1, help="1 = norm + scale of a column folded into the next mat-vec (default)")
     ap.add_argument("--fuse-dots", type=int, default=1, help="1 = a column's multidot runs in its mat-vec's epilogue (default), 0 = own launch")
     args = ap.parse_args()
     Lm = synth.liouvillian_tridiag(args.n)
@@ -42,8 +40,6 @@ def main():
     nnz = Lm.nnz
     ctx = L.Context(0)
     L.tuning_set("arnoldi_mode", args.arnoldi_mode)
-    L.tuning_set("arnoldi_fold", args.fold)
-    L.tuning_set("arnoldi_solve", args.solve)
     L.tuning_set("arnoldi_fuse_dots", args.fuse_dots)
     if args.variant is not None:
         L.tuning_set("rbcsr_variant", args.variant)

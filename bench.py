@@ -270,6 +270,7 @@ def compact_line(full):
                         "hbm_resident_frac", "hbm_resident_us_per_term", "n23_frac", "n23_us_per_term",
                         "fixed_problem_n24_frac", "fixed_problem_n24_us_per_term", "fixed_problem_n24_blocks_per_s",
                         "stream_read_gbs", "stream_walk_mix_gbs", "hbm_resident_frac_of_stream_mix", "fixed_problem_n24_frac_of_stream_mix",
+                        "cache_stream_read_gbs", "cache_stream_mix_gbs", "traffic_rate_gbs",
                         "csr_equiv_frac", "algorithmic_frac", "traffic_measured")))
     if "kernel" in r:
         r["kernel"] = _short(r["kernel"], 96)
@@ -693,7 +694,8 @@ def main():
 
     # on-box HBM yardsticks: what this box streams read-only and in the walk's own 8 : 1 read : write
     # mix at 2 GiB working sets -- tools/probe/stream_yardstick (a child process: its own context, nothing of ours running)
-    stream_read_gbs = stream_mix_gbs = None
+    # ... and at a footprint the Infinity Cache holds (128 / 144 MiB: the headline's own working set is 195 MB and is served on-die)
+    stream_read_gbs = stream_mix_gbs = cache_read_gbs = cache_mix_gbs = None
     if world == 1 and not args.no_extras:
         exe = os.path.join(ROOT, "tools", "probe", "stream_yardstick")
         try:
@@ -701,6 +703,9 @@ def main():
             r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
             y = json.loads(r.stdout.strip().splitlines()[-1])
             stream_read_gbs, stream_mix_gbs = y.get("stream_read_gbs"), y.get("stream_walk_mix_gbs")
+            r = subprocess.run([exe, "20"], capture_output=True, text=True, timeout=60)
+            y = json.loads(r.stdout.strip().splitlines()[-1])
+            cache_read_gbs, cache_mix_gbs = y.get("stream_read_gbs"), y.get("stream_walk_mix_gbs")
         except Exception as e:  # noqa: BLE001  (a missing probe must not take the headline down)
             sys.stderr.write(f"[bench.py] stream yardstick not measured: {type(e).__name__}: {e}\n")
 
@@ -759,6 +764,7 @@ def main():
                          "hbm_resident_frac": None, "hbm_resident_us_per_term": None, "n23_frac": None, "n23_us_per_term": None,
                          "fixed_problem_n24_frac": None, "fixed_problem_n24_us_per_term": None, "fixed_problem_n24_blocks_per_s": None,
                          "stream_read_gbs": stream_read_gbs, "stream_walk_mix_gbs": stream_mix_gbs,
+                         "cache_stream_read_gbs": cache_read_gbs, "cache_stream_mix_gbs": cache_mix_gbs,
                          "hbm_resident_frac_of_stream_mix": None, "fixed_problem_n24_frac_of_stream_mix": None,
                          "csr_equiv_frac": csr_equiv / HBM_PEAK_GBS,
                          "hbm_resident_frac_2^21_rows": None,
@@ -778,7 +784,8 @@ def main():
                                  "Hermitian-packed stencil layout undercuts -- not a physical fraction.  traffic = HBM bytes per launch "
                                  "from PMC counters (FETCH_SIZE counts Infinity-Cache hits: at N = 2^20 the working set is served on-die; "
                                  "hbm_resident_* = the N = 2^22 point beyond it, fixed_problem_n24_* = config C4's N = 2^24 on this one "
-                                 "GPU); stream_* = tools/probe/stream_yardstick on this box (read only / the walk's 8:1 mix, 2 GiB)"},
+                                 "GPU); stream_* = tools/probe/stream_yardstick on this box (read only / the walk's 8:1 mix, 2 GiB); cache_stream_* = the same "
+                                 "at 128 / 144 MiB, inside the Infinity Cache like the headline's working set: compare traffic_rate_gbs"},
             "cpu_baseline": cpu,
             "cpu_baseline_all_cores": cpu_omp,
             "pcie_inclusive_steps_per_s": pcie,

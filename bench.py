@@ -101,7 +101,76 @@ def pmc_traffic(argv_inner, kernel_substr, timeout_s, how="mean"):
 
 # kernels of one newton! step (csrc/kernels_arnoldi.hip, kernels.hip): what a C3 child run's traffic is summed over
 NEWTON_KERNELS = ("arnoldi_matvec_dots_kernel", "mgs_update_kernel", "multidot_kernel", "multidot_reduce_kernel", "combine2_vecs_kernel",
-                  "combine_vecs_kernel", "norm_guard_scale_kernel", "rbcsr_spmv_kernel", "csr_spmv_kernel", "mgs_pass_kernel")
+                  "combine_vecs_kernel", "norm_guard_scale_kernel", "rbcsr_spmv_kernel", "csr_spmv_kernel", "mgs_pass_kernel",
+                  "arnoldi_onepass_kernel", "arnoldi_onepass_solve_kernel", "rbcsr_coded_spmv_kernel")
+
+
+def cpu_baseline_c5(L, synth, step_panel, set_panel, read_panel, rp, col, vals, N, batch, dt, cpu_steps, first_state=0):
+    """`cpu_baseline` of the batched config (BASELINE configs[4]): oracle/cheby_ref.c -- the serial CSC path of the reference,
+    one state at a time, as the reference's own loop over states would run it -- on a SAMPLE of the panel's states (the
+    first 4), `cpu_steps` (<= 16) prop_steps each: same H, same coefficients; then the same steps on the GPU panel from the same
+    initial states and the largest l2 difference over the sampled states.  Checker / reported baseline only."""
+    from oracle import ref_c
+    S, K = min(4, batch), max(1, min(int(cpu_steps), 16))
+    init = np.stack([synth.random_state(N, seed=500 + first_state + s) for s in range(batch)], axis=1)
+    set_panel(init)
+    for _ in range(K):
+        step_panel()
+    gpu = read_panel()[:, :S].copy()
+    coeffs = L.cheby_coeffs(20.0, dt)
+    colptr, rowval, nzval = rp, col.astype(np.int64), np.conj(vals)      # Hermitian: CSC(H) = conj CSR(H)
+    ref_c.load()
+    worst = 0.0
+    tc = 0.0
+    for s_ in range(S):
+        cpsi = init[:, s_].copy()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            ref_c.cheby_csc(colptr, rowval, nzval, cpsi, coeffs, 20.0, -10.0, dt)
+        tc += time.perf_counter() - t0
+        worst = max(worst, float(np.linalg.norm(gpu[:, s_] - cpsi)))
+    return {"value": S * K / tc, "unit": "state_step/s", "cores": 1, "kind": "port",
+            "sample": f"{K} prop_steps of {S} of the {batch} states, N={N} (oracle/cheby_ref.c: serial CSC SpMV + BLAS-1, one state at a "
+                      f"time; gcc {ref_c.build_flags()})",
+            "ms_per_step": 1e3 * tc / (S * K), "l2_diff_vs_gpu_after_sample": worst, "states_sampled": S, "steps_sampled": K}
+
+
+def cpu_baseline_c3(ctx, L, synth, n=512, m=20, dt=0.5, steps=2):
+    """`cpu_baseline` of the Newton config (BASELINE configs[2]): oracle/newton_ref.c (serial CSC mat-vec, the reference's sequential
+    modified Gram-Schmidt and combinations, one core) with the NumPy oracle's host algebra, `steps` newton! steps from rho_0 at
+    the point's own size; the same steps on the GPU and the l2 difference, restart counts of both.  Checker / reported baseline only."""
+    from oracle import ref_c
+    Lm = synth.liouvillian_tridiag(n)
+    N = Lm.shape[0]
+    rho0 = synth.random_state(N)
+    M = L.Matrix.from_scipy(ctx, Lm)
+    op = L.Operator(ctx, [M])
+    wrk = L.NewtonWrk(ctx, N, m_max=m)
+    psi = L.State(ctx, data=rho0)
+    r_gpu = []
+    for _ in range(steps):
+        L.newton(psi, op, dt, wrk)
+        r_gpu.append(int(wrk.restarts))
+    gpu = psi.numpy()
+    for h in (psi, wrk, op, M):
+        h.close()
+    Lc = Lm.tocsc()
+    Lc.sort_indices()
+    colptr, rowval, nzval = Lc.indptr.astype(np.int64), Lc.indices.astype(np.int64), Lc.data.astype(np.complex128)
+    ref_c.load()
+    wc = ref_c.NewtonCscWrk(N, m_max=m)
+    cpsi = rho0.copy()
+    r_cpu = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ref_c.newton_csc(colptr, rowval, nzval, cpsi, dt, wc)
+        r_cpu.append(int(wc.restarts))
+    tc = time.perf_counter() - t0
+    return {"value": steps / tc, "unit": "prop_step/s", "cores": 1, "kind": "port",
+            "sample": f"{steps} newton! steps from rho_0 of the same N={N} Liouvillian, m_max={m} (oracle/newton_ref.c: serial CSC SpMV, "
+                      f"sequential MGS, combinations; host algebra by the NumPy oracle; gcc {ref_c.build_flags()})",
+            "ms_per_step": 1e3 * tc / steps, "l2_diff_vs_gpu_after_sample": float(np.linalg.norm(gpu - cpsi)),
+            "restarts_cpu": r_cpu, "restarts_gpu": r_gpu, "matvecs_cpu": int(wc.n_matvec)}
 
 
 def run_point(args, L, bp):
@@ -266,7 +335,7 @@ def compact_line(full):
     line["config"] = c
     r = {"bound": rf.get("bound"), "achieved": _num(rf.get("achieved")), "peak": rf.get("peak"), "unit": rf.get("unit"),
          "frac": _num(rf.get("frac")), "traffic": _num(rf.get("traffic"))}
-    r.update(_pick(rf, ("kernel", "avg_launch_us", "bytes_per_launch", "traffic_over_bytes", "unstable",
+    r.update(_pick(rf, ("kernel", "avg_launch_us", "bytes_per_launch", "model", "cache_resident", "traffic_over_bytes", "unstable",
                         "hbm_resident_frac", "hbm_resident_us_per_term", "n23_frac", "n23_us_per_term",
                         "fixed_problem_n24_frac", "fixed_problem_n24_us_per_term", "fixed_problem_n24_blocks_per_s",
                         "stream_read_gbs", "stream_walk_mix_gbs", "hbm_resident_frac_of_stream_mix", "fixed_problem_n24_frac_of_stream_mix",
@@ -297,11 +366,15 @@ def compact_line(full):
         f = next((pt[k] for k in ("frac", "frac_fp64_matrix_peak") if pt.get(k) is not None), None)
         if pt.get("bound") == "mfma" and pt.get("frac_fp64_matrix_peak") is not None:
             f = pt["frac_fp64_matrix_peak"]
-        pts[name] = [_num(t, 4), _num(f, 3)]
+        pts[name] = [_num(t, 4), _num(f, 3), pt.get("model", "?")]
+        cb = pt.get("cpu_baseline")
+        if isinstance(cb, dict) and cb.get("ms_per_step"):      # the reference's CPU path beside the point: ms per (state-)step, one core
+            pts[name].append(_num(cb["ms_per_step"], 4))
     if pts:
         line["points"] = pts
-        line["points_unit"] = "[us per term | ms per step (c3*) | us per apply (n4*), fraction of the point's roofline]"
-    for k in ("max_norm_drift", "degraded", "native_path"):
+        line["points_unit"] = ("[us/term | ms/step (c3*) | us/apply (n4*), frac of peak by the named byte model (layout | impl | flops), "
+                               "CPU port ms per (state-)step if timed]")
+    for k in ("exchange", "rccl_ranks", "max_norm_drift", "degraded", "native_path"):
         if k in full:
             line[k] = _num(full[k])
     line["extras_file"] = EXTRAS_FILE
@@ -409,6 +482,11 @@ def run_c5(args, world, rank, local_rank, one_gpu, dist, L, synth, bp):
     rfl = out["roofline"]
     rfl["kernel"] = "spmm_rows_smem_kernel" if b > 32 else "csr_spmm_kernel"
     rfl["bytes_per_launch"] = lay
+    rfl["model"] = "layout"
+    # the reference's CPU path beside it (rank 0 of a single-GPU run, after the timed region): a sample of the panel's states
+    if rank == 0 and world == 1 and args.cpu_steps > 0:
+        out["cpu_baseline"] = cpu_baseline_c5(L, synth, bs.step, bs.set_states, bs.local_states, rp, col, vals, N, args.batch, args.dt,
+                                              args.cpu_steps, first_state=bs.s0)
     # HBM traffic of the panel kernel (this line carried "traffic": null): the same child-process PMC
     # passes as the headline, on rank 0 of a single-GPU run, for the panel width this run's GPUs see
     if rank == 0 and world == 1 and not args.no_pmc and args.batch == 64 and log2n == 18:
@@ -455,7 +533,7 @@ def main():
     ap.add_argument("--driver", default="native", choices=["native", "torch"],
                     help="multi-GPU step: one library call with its own RCCL communicator, or the Python loop")
     ap.add_argument("--cpu-steps", type=int, default=16,
-                    help="steps of the CPU baseline sample (0 = skip); 16 steps ~ 10 s of one core")
+                    help="steps of the CPU baseline sample (0 = skip); 16 steps ~ 10 s of one core (c5: per sampled state, 4 states)")
     ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with rocprofv3 child runs")
     ap.add_argument("--no-extras", action="store_true", help="headline only: no extra points (formats, patterns, C3, C5)")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling point")
@@ -538,6 +616,17 @@ def main():
 
     def dev_tensor(x):
         return torch.tensor(x, dtype=torch.float64, device="cpu" if one_gpu else "cuda")
+
+    def comm_ranks(sh_=None, nat=False):
+        """Ranks of the RCCL communicator a measured point exchanged on: ncclCommCount of the library's own communicator
+        (qp_comm_info) for the native step, the nccl group's size for the torch.distributed-driven one; 0 in the one-GPU test
+        mode (host-staged gloo / callback communicator: no RCCL).  A multi-GPU line whose points did not run on `world` RCCL
+        ranks is refused below (exit status 4)."""
+        if world == 1 or one_gpu:
+            return 0
+        if nat and sh_ is not None and getattr(sh_, "comm", None) is not None:
+            return int(L.comm_info(sh_.comm)["rccl_ranks"])
+        return int(dist.get_world_size()) if str(dist.get_backend()).lower() == "nccl" else 0
 
     parity = None
     cpu = None
@@ -710,7 +799,7 @@ def main():
             sys.stderr.write(f"[bench.py] stream yardstick not measured: {type(e).__name__}: {e}\n")
 
     def make_out(elapsed, ev_ms, st, fmt_used, model, exchange_used, schedule_note, driver_note, strong,
-                 traffic=None, traffic_src=None, traffic_detail=None, extras=None, note=None, xmodel=None):
+                 traffic=None, traffic_src=None, traffic_detail=None, extras=None, note=None, xmodel=None, rccl=0):
         """The JSON line for one measured run of args.steps steps (elapsed: wall seconds, slowest rank)."""
         layout = model["layout"]
         steps_per_s = args.steps / elapsed
@@ -760,6 +849,8 @@ def main():
                          "bytes_per_launch": model["per_term"],
                          "traffic_over_bytes": (traffic / model["per_term"]) if traffic else None,
                          "traffic_measured": bool(traffic_src and traffic_src.startswith("measured")) if traffic is not None else None,
+                         # the bytes one launch moves fit the 256 MiB Infinity Cache: `frac` is then a cache-assisted rate, not an HBM one
+                         "cache_resident": bool(model["per_term"] < 256.0 * 1024 * 1024), "model": "layout",
                          "unstable": bool(seg and max(seg) > 1.3 * min(seg)),
                          "hbm_resident_frac": None, "hbm_resident_us_per_term": None, "n23_frac": None, "n23_us_per_term": None,
                          "fixed_problem_n24_frac": None, "fixed_problem_n24_us_per_term": None, "fixed_problem_n24_blocks_per_s": None,
@@ -786,6 +877,7 @@ def main():
                                  "hbm_resident_* = the N = 2^22 point beyond it, fixed_problem_n24_* = config C4's N = 2^24 on this one "
                                  "GPU); stream_* = tools/probe/stream_yardstick on this box (read only / the walk's 8:1 mix, 2 GiB); cache_stream_* = the same "
                                  "at 128 / 144 MiB, inside the Infinity Cache like the headline's working set: compare traffic_rate_gbs"},
+            "exchange": exchange_used, "rccl_ranks": rccl,
             "cpu_baseline": cpu,
             "cpu_baseline_all_cores": cpu_omp,
             "pcie_inclusive_steps_per_s": pcie,
@@ -858,6 +950,7 @@ def main():
     fallback = None
     watchdog = None
     ag_form = {}
+    ranks_seen = {}
     if world > 1:
         if not args.no_safe:
             shA = sharded.ShardedCheby(ctx, rp, col, vals, N, r0, r1, Delta, E_min, dt, fmt=fmt, exchange=args.exchange,
@@ -869,7 +962,7 @@ def main():
             build_ms = shA.op.build_info()
             fallback = make_out(elA, evA, stA, shA.op.format, modelA, shA.exchange, "serial", "torch.distributed (step loop in Python)",
                                 None, note="conservative schedule (reported because the native / overlapped path did not finish)",
-                                xmodel=exchange_model(shA, world, rows, 1e3 * evA / (args.steps * nterms)))
+                                xmodel=exchange_model(shA, world, rows, 1e3 * evA / (args.steps * nterms)), rccl=comm_ranks())
             fallback_line = json.dumps(fallback)
             fallback["config"]["parallelism"] = fallback["config"]["parallelism"].split(" | ")[0]
             shA.close()
@@ -911,6 +1004,7 @@ def main():
             model_ = bp.cheby_layout_bytes(sh_.op, rows, rows + world * sh_.M, nnz_local, coeffs, real_copy=args.real)
             el_, ev_, st_ = timed_steps(lambda: sh_.step(native=nat_))
             sh_.check()      # outside the timed region: the overlapped schedule never timed out
+            ranks_seen["headline"] = comm_ranks(sh_, nat_)
             strong_ = None
             # the strong-scaling point of BASELINE's metric (N = 2^20 in total)
             if args.scaling == "weak" and not args.no_strong and (1 << 20) % world == 0:
@@ -935,7 +1029,8 @@ def main():
                 sh_s.check()
                 strong_ = {"workload": "Cheby prop_step!, N=2^20 CSR fp64 in TOTAL, row-partitioned over the ranks (strong scaling)",
                            "N_total": Ns, "rows_per_gpu": rs, "steps": ksteps, "prop_steps_per_s": ksteps / float(ts[0]),
-                           "ms_per_step": 1e3 * float(ts[0]) / ksteps, "exchange": sh_s.exchange, "schedule": snote_s, "driver": dnote_s}
+                           "ms_per_step": 1e3 * float(ts[0]) / ksteps, "exchange": sh_s.exchange, "schedule": snote_s, "driver": dnote_s,
+                           "rccl_ranks": comm_ranks(sh_s, nat_s)}
                 sh_s.close()
             # the collective north_star NAMES -- an all-gather of the term vector after every mat-vec -- gets its own measured
             # point next to the headline (for a banded H `auto` picks the halo exchange): 4 steps with the whole slice
@@ -943,8 +1038,10 @@ def main():
             if not args.no_allgather:
                 stage("all-gather form")
                 per_term_main = 1e3 * ev_ / (args.steps * nterms)
+                ag_form["exchange"] = "allgather"
                 if sh_.exchange == "allgather":
                     ag_form["us_per_term"], ag_form["blocks_per_s"] = per_term_main, (N / float(1 << 20)) * args.steps / el_
+                    ag_form["rccl_ranks"] = ranks_seen["headline"]
                 else:
                     try:
                         # the plainest schedule (step loop in Python, one torch.distributed all-gather per term on the main stream, no
@@ -977,6 +1074,7 @@ def main():
                         ag_form["us_per_term"] = 1e6 * float(tg[0]) / (kg * nterms)
                         ag_form["blocks_per_s"] = (Ng / float(1 << 20)) * kg / float(tg[0])
                         ag_form["driver"] = "torch.distributed, serial"
+                        ag_form["rccl_ranks"] = comm_ranks()
                         ag_form["pattern"] = "scattered"
                         sh_g.close()
                     except Exception as e:  # noqa: BLE001 -- the extra point must not take the headline down
@@ -1064,6 +1162,18 @@ def main():
                 except Exception as e:  # noqa: BLE001
                     extras[name] = {"error": f"{type(e).__name__}: {e}"}
 
+            # the reference's CPU path beside the other two GPU configs: bounded samples, one core
+            if args.cpu_steps > 0:
+                try:
+                    if "error" not in extras.get("c3_newton", {"error": 1}):
+                        extras["c3_newton"]["cpu_baseline"] = cpu_baseline_c3(ctx, L, synth, steps=2)
+                except Exception as e:  # noqa: BLE001
+                    extras["c3_newton"]["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+                try:
+                    if "error" not in extras.get("c5_batched", {"error": 1}):
+                        extras["c5_batched"]["cpu_baseline"] = bp.with_panel(ctx, 18, 64, lambda *a: cpu_baseline_c5(L, synth, *a, min(args.cpu_steps, 8)))
+                except Exception as e:  # noqa: BLE001
+                    extras["c5_batched"]["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
             # HBM traffic of the C3 and C5 points, by the same child-process PMC passes as the headline (one counter per pass)
             if not args.no_pmc:
                 for name, argv, subs, how, per in (
@@ -1089,6 +1199,7 @@ def main():
     out = make_out(elapsed, ev_ms, st, fmt_used, model, exchange_used, schedule_note, driver_note, strong,
                    traffic, traffic_src, traffic_detail, extras,
                    xmodel=(exchange_model(sh, world, rows, 1e3 * ev_ms / (args.steps * nterms)) if world > 1 else None),
+                   rccl=ranks_seen.get("headline", 0),
                    note=(None if fallback is None else
                          f"conservative schedule measured first: {fallback['value']:.1f} {fallback['unit']} "
                          f"({fallback['ms_per_step']:.3f} ms/step, torch.distributed all-gather per term, no overlap)"))
@@ -1152,11 +1263,24 @@ def main():
         out["scaling_prediction"] = scaling_prediction_static(nterms)
         out["allgather_form"] = ag_form or None
         if fallback is not None and out is not fallback:
-            out["conservative_first"] = {"value": fallback["value"], "ms_per_step": fallback["ms_per_step"]}
+            out["conservative_first"] = {"value": fallback["value"], "ms_per_step": fallback["ms_per_step"],
+                                         "exchange": fallback["exchange"], "rccl_ranks": fallback["rccl_ranks"]}
     sp_ = out.get("strong_scaling_point")
     if sp_:
-        out["strong_point"] = {k: sp_[k] for k in ("N_total", "prop_steps_per_s", "ms_per_step", "exchange")}
+        out["strong_point"] = {k: sp_.get(k) for k in ("N_total", "prop_steps_per_s", "ms_per_step", "exchange", "rccl_ranks")}
     out["prediction"] = prediction_scalars(out.get("scaling_prediction"))
+    # every measured point of a multi-GPU line names its exchange and the RCCL ranks it ran on; a point that did not run on an
+    # N-rank RCCL communicator makes the run a failed one (the line is still printed, marked): nobody can mistake a run whose
+    # ranks never talked over RCCL for a scaling measurement.  (One-GPU test mode: rccl_ranks = 0 by construction, labelled.)
+    bad_rccl = []
+    if world > 1 and not one_gpu:
+        for name in (None, "strong_point", "allgather_form", "conservative_first"):
+            pt = out if name is None else out.get(name)
+            if pt and "error" not in pt and pt.get("rccl_ranks") != world:
+                bad_rccl.append(f"{name or 'headline'}: rccl_ranks={pt.get('rccl_ranks')}")
+        if bad_rccl:
+            out["degraded"] = True
+            out["native_path"] = _short("rccl_ranks != n_gpus: " + "; ".join(bad_rccl), 96)
     if rank == 0:
         default_run = world == 1 and config == "c2" and args.log2n is None and args.pattern == "banded" and args.format == "auto" and \
             not args.real and args.dt == 1.0 and args.scaling == "weak"
@@ -1164,6 +1288,9 @@ def main():
     if dist is not None:
         sh.close()      # the library's communicator goes before the process group it was bootstrapped over
         dist.destroy_process_group()
+    if bad_rccl:
+        sys.stderr.write(f"[bench.py rank {rank}] {'; '.join(bad_rccl)} with --gpus {world}: exit status 4\n")
+        sys.exit(4)
 
 
 if __name__ == "__main__":

@@ -414,6 +414,11 @@ typedef int (*qp_exchange_cb)(void* user, const qp_c128* send_dev, int64_t count
                               const int* send_to, int n_send_to, const int* recv_from, int n_recv_from,
                               void* stream);
 int qp_comm_create_callback(qp_ctx* ctx, int rank, int world, qp_exchange_cb cb, void* user, qp_comm** out);
+/* What the communicator is: the `world` / `rank` it was created with; `rccl_ranks` / `rccl_rank` = ncclCommCount /
+ * ncclCommUserRank of the CONNECTED RCCL communicator (0 / -1 for a callback communicator or before qp_comm_connect);
+ * `is_callback` = 1 for qp_comm_create_callback.  Any output may be NULL.  (bench.py --gpus N prints rccl_ranks and
+ * refuses to report a multi-GPU line whose exchange did not run on an N-rank RCCL communicator.) */
+int qp_comm_info(const qp_comm* comm, int* world, int* rank, int* rccl_ranks, int* rccl_rank, int* is_callback);
 int qp_comm_destroy(qp_comm* comm);
 /* recv[r*count .. (r+1)*count) = rank r's send[0..count);  stream NULL = the ctx stream */
 int qp_comm_allgather(qp_comm* comm, const qp_state* send, qp_state* recv, int64_t count,
@@ -496,6 +501,10 @@ typedef struct {
    * the kernel that applies the Newton polynomial (last eigenvalue block, Leja ordering, coefficients,
    * polynomial), summed over the restarts of the step */
   double ms_exposed;
+  /* Arnoldi sweeps of the step that took the one-pass form (basis read once per column, lagged normalisation: taken when
+   * basis + matrix exceed the Infinity Cache), and how many of THOSE were done again with the two-pass sweep because the
+   * norm of a stored basis vector had drifted from 1 by more than 1e-4 (pipelined-Krylov error growth when h_{t+1,t} << |H q_t|) */
+  int sweeps_onepass, sweeps_onepass_redone;
 } qp_newton_stats;
 /* NewtonWrk(v0; m_max)  src/newton.jl:23-60 */
 int qp_newton_create(qp_ctx* ctx, int64_t n, int m_max, qp_newton** out);

@@ -607,6 +607,7 @@ struct NewtonStats                  # qp_newton_stats
     radius::Cdouble; last_relerr::Cdouble; norm_psi::Cdouble
     ms_arnoldi::Cdouble; ms_eig::Cdouble; ms_leja::Cdouble; ms_coeffs::Cdouble; ms_poly::Cdouble; ms_update::Cdouble
     ms_exposed::Cdouble
+    sweeps_onepass::Cint; sweeps_onepass_redone::Cint
 end
 
 mutable struct NewtonHIPPropagator{GT} <: PWCPropagator

@@ -131,7 +131,9 @@ struct ColBlockPlan {
 // (bptr[b] >> 2) + 64 q + lane = slot 4 q + j of that lane's row) and per block a table of its tuples -- tables with the same
 // content shared between blocks.  The mat-vec kernels read the COMBINED table tab[(tptr[b] >> 9) + code] = sum_l c_l tuple_l: the
 // same arithmetic on the same numbers as the value plane they replace (bit-identical results), 1 B + a cached table line per
-// entry instead of 16 B, and evaluate! (src/generators.jl:757-766) rewrites the tables, not a plane.
+// entry instead of 16 B.  evaluate! (src/generators.jl:757-766) recombines the tables IN ADDITION to the value plane (operator_refresh,
+// engine_core.hip): the plane stays the source of truth for the consumers that read it (Arnoldi mat-vecs without a dictionary path,
+// the panel kernels, qp_operator_get_csr, the split), so the mirror saves bytes per mat-vec, not work per evaluate!.
 struct CodedVals {
   int valid = 0;
   int64_t ntab = 0;               // table entries (all blocks, shared tables counted once)
@@ -288,7 +290,7 @@ constexpr int kWalkReserveCu = 8;
 struct Tuning {
   int rbcsr_variant = 15;     // bit 0 nt matrix loads, bit 1 early row-local loads, bit 2 deeper unroll, bit 3 (Hermitian-packed kernel) all loads of an all-stencil block up front (A/B in profiles/)
   int arnoldi_mode = 1;       // 0 = sequential fused MGS passes, 1 = low-synchronisation MGS
-  int arnoldi_onepass = 1;    // newton!'s sweeps read the basis ONCE per column (kernels_onepass.hip): 0 never, 1 when basis + matrix exceed the Infinity Cache (bytes, not latency, then bound the sweep: profiles/r05/newton_onepass.txt), 2 wherever an instance exists
+  int arnoldi_onepass = 1;    // newton!'s sweeps read the basis ONCE per column (kernels_onepass.hip): 0 never, 1 when basis + matrix exceed the Infinity Cache (bytes, not latency, then bound the sweep: profiles/r05/newton_onepass.txt), 2 wherever an instance exists, 3 = 2 with every sweep done again in the two-pass form (exercises the norm-drift fall-back of engine_krylov.hip)
   int sparse_controls = 1;    // 1 = evaluate! rewrites only the positions of sparse trailing control terms (see qp_operator::sparse_from)
   int lattice_fill = 1;       // 1 = rows of a lattice operator that lack a few of its distances (open boundaries of a grid) are completed with explicit zeros
   int arnoldi_fuse_dots = 1;  // 1 = the multidot of a column runs in its mat-vec's epilogue where an instance exists (row-block format, j <= 19): 2 launches per column

@@ -180,6 +180,7 @@ struct qp_krylov {
   double* op_nu_dev = nullptr;
   double* h_nu = nullptr;
   double* nu_map = nullptr;
+  int n_onepass = 0, n_onepass_redone = 0;   // one-pass sweeps so far / of those, done again with the two-pass sweep (norm drift)
   bool nu_valid = false;        // the latest sweep left nu != 1: combination coefficients are divided by it
   double2* q(int i) const { return Q + (size_t)i * n; }
 };

@@ -230,6 +230,7 @@ int qp_cheby_step(qp_cheby* w, qp_operator* op, qp_state* psi, const double* a, 
     // every knob that selects a kernel or a launch shape of the step's terms
     key.variant = ((((ctx->tun.rbcsr_variant * 2) * 16 + ctx->tun.hrb_wg) * 2 + (ctx->tun.hrb_walk ? 1 : 0)) * 8 +
                    (ctx->tun.walk_nt & 7)) * 4096 + ((ctx->tun.walk_waves + 16 * ctx->tun.walk_wg) & 4095);
+    key.variant = key.variant * 2 + (ctx->tun.value_dict ? 1 : 0);      // (coded / plain row-block kernel)
     key.n_coeffs = n_coeffs;
     key.dt = dt;
     key.Delta = Delta;

@@ -192,6 +192,7 @@ static inline int guard_grid(int64_t n) {
 // in Hess -- the caller's work on the leading (j+1) x (j+1) block (newton!: its eigenvalues,
 // src/newton.jl:297) overlaps the device's work on the later columns.
 using ColumnHook = std::function<int(int)>;
+constexpr double kOnepassNormDrift = 1e-4;   // |nu_i - 1| of a one-pass sweep's stored basis vectors beyond which the sweep is redone
 
 // The sweep that reads the basis once per column (knob arnoldi_onepass; kernels_onepass.hip says how): m + 1 column kernels, a
 // single-workgroup solve after each; column j of the Hessenberg matrix reaches the pinned host buffer with the solve after
@@ -301,9 +302,23 @@ static int arnoldi_impl(qp_operator* op, qp_krylov* q, int m, const qp_state* ps
   q->nu_valid = false;
   // (only for a caller that divides its combination coefficients by the stored vectors' norms: newton!)
   const double sweep_bytes = 16.0 * (double)q->n * (m + 3) + (op->A.vals_r ? 12.0 : 20.0) * (double)op->A.stored;
-  const bool onepass_wanted = ctx->tun.arnoldi_onepass == 2 || (ctx->tun.arnoldi_onepass == 1 && sweep_bytes > 224.0 * 1024 * 1024);
-  if (!small && extended && scaled_basis_ok && ctx->tun.arnoldi_mode == 1 && onepass_wanted && qp::arnoldi_onepass_fits(op->A, m, q->nvec))
-    return arnoldi_onepass(op, q, m, psi, dt, norm_min, Hess, ldh, m_out, beta_out, on_column);
+  const bool onepass_wanted = ctx->tun.arnoldi_onepass >= 2 || (ctx->tun.arnoldi_onepass == 1 && sweep_bytes > 224.0 * 1024 * 1024);
+  if (!small && extended && scaled_basis_ok && ctx->tun.arnoldi_mode == 1 && onepass_wanted && qp::arnoldi_onepass_fits(op->A, m, q->nvec)) {
+    QP_CHECK(arnoldi_onepass(op, q, m, psi, dt, norm_min, Hess, ldh, m_out, beta_out, on_column));
+    ++q->n_onepass;
+    // The one-pass sweep never applies H to the new basis vector itself: it carries a_{t+1} = s (H a_t - sum gamma_i q_i) forward by
+    // linearity and takes the scale from |a|^2 - sum |h|^2, which cancels when h_{t+1,t} << |a_t| -- the known error growth of
+    // pipelined Krylov sweeps.  The stored vectors' measured norms nu_i say when that happened: all conversions are exact in nu,
+    // but a nu far from 1 means the recurrence lost digits.  Then the sweep is done again in the two-pass form (the column
+    // hook is idempotent: it recomputes the Ritz values of the leading blocks from the new columns).
+    double drift = 0.0;
+    for (int i = 0; i <= *m_out && i <= m; ++i)
+      if (!(i == *m_out && *m_out < m)) drift = std::max(drift, std::fabs(q->h_nu[i] - 1.0));    // (the vector of a breakdown is unnormalised by design)
+    if (!(drift > kOnepassNormDrift) && ctx->tun.arnoldi_onepass != 3) return QP_OK;
+    ++q->n_onepass_redone;
+    q->nu_valid = false;
+    std::memset(Hess, 0, sizeof(qp_c128) * (size_t)ldh * ldh);
+  }
   if (small) {
     // all m columns in one persistent single-workgroup launch (kernels_small.hip: arnoldi_small_kernel)
     QP_CHECK(operator_csr_mirror(op, false));
@@ -683,6 +698,7 @@ int qp_newton_step(qp_newton* w, qp_operator* op, qp_state* psi, double dt, int 
   // v = Psi / beta, beta = |Psi| (:268-272) is done by the first Arnoldi sweep itself (q_0)
   double beta = 0.0;
   double ms_arnoldi = 0, ms_eig = 0, ms_leja = 0, ms_coeffs = 0, ms_poly = 0, ms_update = 0, ms_exposed = 0;
+  const int onepass0 = w->q->n_onepass, redone0 = w->q->n_onepass_redone;
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto ms_since = [](std::chrono::steady_clock::time_point t0) {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -848,6 +864,8 @@ int qp_newton_step(qp_newton* w, qp_operator* op, qp_state* psi, double dt, int 
     stats->ms_poly = ms_poly;
     stats->ms_update = ms_update;
     stats->ms_exposed = ms_exposed;
+    stats->sweeps_onepass = w->q->n_onepass - onepass0;
+    stats->sweeps_onepass_redone = w->q->n_onepass_redone - redone0;
   }
   return QP_OK;
   QP_CATCH

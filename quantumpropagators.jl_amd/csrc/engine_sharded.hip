@@ -23,6 +23,8 @@ struct RcclApi {
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;      // optional: qp_comm_info
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;   // optional: qp_comm_info
 };
 
 int rccl_load(const char* path, RcclApi* api) {
@@ -39,6 +41,8 @@ int rccl_load(const char* path, RcclApi* api) {
   api->GroupStart = reinterpret_cast<decltype(api->GroupStart)>(dlsym(h, "ncclGroupStart"));
   api->GroupEnd = reinterpret_cast<decltype(api->GroupEnd)>(dlsym(h, "ncclGroupEnd"));
   api->GetErrorString = reinterpret_cast<decltype(api->GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+  api->CommCount = reinterpret_cast<decltype(api->CommCount)>(dlsym(h, "ncclCommCount"));
+  api->CommUserRank = reinterpret_cast<decltype(api->CommUserRank)>(dlsym(h, "ncclCommUserRank"));
   if (!api->GetUniqueId || !api->CommInitRank || !api->CommDestroy || !api->AllGather || !api->Send || !api->Recv ||
       !api->GroupStart || !api->GroupEnd || !api->GetErrorString)
     return qp::fail(QP_E_RCCL, "%s does not export the RCCL entry points", path);
@@ -150,6 +154,27 @@ int qp_comm_create_callback(qp_ctx* ctx, int rank, int world, qp_exchange_cb cb,
   c->cb = cb;
   c->cb_user = user;
   *out = c.release();
+  return QP_OK;
+  QP_CATCH
+}
+
+// What the communicator IS, asked of RCCL itself (ncclCommCount / ncclCommUserRank of the connected communicator), so that a
+// caller -- bench.py --gpus N -- can state and check "this exchange ran on an RCCL communicator of N ranks" instead of assuming it.
+int qp_comm_info(const qp_comm* comm, int* world, int* rank, int* rccl_ranks, int* rccl_rank, int* is_callback) {
+  QP_TRY
+  if (!comm) return qp::fail(QP_E_BAD_ARG, "qp_comm_info: NULL communicator");
+  if (world) *world = comm->world;
+  if (rank) *rank = comm->rank;
+  if (is_callback) *is_callback = comm->cb ? 1 : 0;
+  int n = 0, r = -1;
+  if (comm->comm) {
+    if (!comm->api.CommCount || !comm->api.CommUserRank)
+      return qp::fail(QP_E_RCCL, "qp_comm_info: this librccl exports neither ncclCommCount nor ncclCommUserRank");
+    QP_RCCL(comm->api, comm->api.CommCount(comm->comm, &n));
+    QP_RCCL(comm->api, comm->api.CommUserRank(comm->comm, &r));
+  }
+  if (rccl_ranks) *rccl_ranks = n;
+  if (rccl_rank) *rccl_rank = r;
   return QP_OK;
   QP_CATCH
 }

@@ -71,7 +71,7 @@ class qp_newton_stats(C.Structure):
                 ("last_relerr", C.c_double), ("norm_psi", C.c_double),
                 ("ms_arnoldi", C.c_double), ("ms_eig", C.c_double), ("ms_leja", C.c_double),
                 ("ms_coeffs", C.c_double), ("ms_poly", C.c_double), ("ms_update", C.c_double),
-                ("ms_exposed", C.c_double)]
+                ("ms_exposed", C.c_double), ("sweeps_onepass", C.c_int), ("sweeps_onepass_redone", C.c_int)]
 
 
 FUNC_CB = C.CFUNCTYPE(None, C.POINTER(qp_c128), C.POINTER(qp_c128), C.c_void_p)
@@ -186,6 +186,7 @@ SIGNATURES = {
     "qp_comm_prepare": (C.c_int, [_P, C.c_char_p, C.c_int, C.c_int, C.POINTER(_P)]),
     "qp_comm_connect": (C.c_int, [_P, C.c_char_p]),
     "qp_comm_create_callback": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.POINTER(_P)]),
+    "qp_comm_info": (C.c_int, [_P, _i32p, _i32p, _i32p, _i32p, _i32p]),
     "qp_comm_destroy": (C.c_int, [_P]),
     "qp_comm_allgather": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
     "qp_sharded_cheby_create": (C.c_int, [C.POINTER(qp_sharded_cheby_desc), C.POINTER(_P)]),
@@ -1076,6 +1077,13 @@ class Comm:
 
 EXCHANGE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int), C.c_int,
                           C.POINTER(C.c_int), C.c_int, C.c_void_p)
+
+
+def comm_info(comm):
+    """qp_comm_info of a :class:`Comm` / :class:`CallbackComm`: what RCCL itself says the communicator is."""
+    v = [C.c_int(0) for _ in range(5)]
+    check(comm.lib.qp_comm_info(comm._h, *[C.byref(x) for x in v]))
+    return dict(zip(("world", "rank", "rccl_ranks", "rccl_rank", "is_callback"), (int(x.value) for x in v)))
 
 
 class CallbackComm:

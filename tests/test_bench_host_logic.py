@@ -175,11 +175,22 @@ def test_printed_line_is_compact_and_carries_the_gate_keys(capsys, tmp_path, mon
     assert len(json.dumps(full)) > 30000
     monkeypatch.setattr(b, "ROOT", str(tmp_path))       # the sidecar goes next to the script: not into the repo from a test
     full["prediction"] = b.prediction_scalars(full["scaling_prediction"])
+    # round 6: every point names ITS byte model, the headline says whether its working set is cache
+    # resident, and the C3 / C5 points carry the CPU port's time beside the GPU's
+    full["roofline"].update(model="layout", cache_resident=True)
+    full.update(exchange="none", rccl_ranks=0)
+    for name, pt in full["extras"].items():
+        pt["model"] = "impl" if name.startswith("c3") else ("flops" if "matrix_cores" in name or name.startswith("n4") else "layout")
+    full["extras"]["c3_newton"]["cpu_baseline"] = {"value": 0.4, "ms_per_step": 2500.0, "cores": 1, "kind": "port"}
     b.emit(full)
     lines = capsys.readouterr().out.strip().splitlines()
     text = lines[-1]
     assert len(text) < b.LINE_LIMIT == 4096
     line = json.loads(text)
+    assert line["roofline"]["model"] == "layout" and line["roofline"]["cache_resident"] is True
+    assert all(len(v) >= 3 and v[2] in ("layout", "impl", "flops") for v in line["points"].values())
+    assert line["points"]["c3_newton"][2:] == ["impl", 2500.0] and line["points"]["dense_h_n4096_64_states_on_the_matrix_cores"][2] == "flops"
+    assert "exchange" in line and "rccl_ranks" in line
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline", "cpu_baseline", "degraded"):
         assert k in line, k

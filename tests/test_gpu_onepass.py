@@ -142,3 +142,47 @@ def test_onepass_is_deterministic_and_matches_two_pass_to_rounding(ctx):
         outs.append(rho.numpy())
     assert np.array_equal(outs[0], outs[1])
     assert np.linalg.norm(outs[0] - outs[2]) < 1e-12
+
+
+def test_onepass_sweep_redone_in_two_pass_form_on_norm_drift(ctx):
+    """the one-pass sweep carries H a_t forward by linearity and cannot see its own error growth; the host checks the
+    stored basis vectors' measured norms after every such sweep and does the sweep AGAIN in the two-pass form when one drifted
+    from 1 by more than 1e-4.  Knob value 3 forces that path on every sweep: same parity, same restart counts, and the step's
+    statistics say how many sweeps were redone (none at knob value 2 on a benign operator)."""
+    Lm = synth.liouvillian_tridiag(96)
+    rho0 = synth.random_state(Lm.shape[0])
+    wrk, owrk = _steps(ctx, Lm, rho0, (0.5, -0.5), 12)
+    assert wrk.stats["sweeps_onepass"] == wrk.restarts + 1 and wrk.stats["sweeps_onepass_redone"] == 0
+    ctx.tuning_set("arnoldi_onepass", 3)
+    wrk, owrk = _steps(ctx, Lm, rho0, (0.5, 0.5, -0.5), 12, expect_onepass=False)
+    assert wrk.stats["sweeps_onepass"] == wrk.restarts + 1 == wrk.stats["sweeps_onepass_redone"]
+    ctx.tuning_set("arnoldi_onepass", 0)
+    wrk, owrk = _steps(ctx, Lm, rho0, (0.5,), 12, expect_onepass=False)
+    assert wrk.stats["sweeps_onepass"] == 0 and wrk.stats["sweeps_onepass_redone"] == 0
+
+
+def test_onepass_sweep_is_taken_automatically_beyond_the_infinity_cache():
+    """The AUTOMATIC branch (knob at its default, 1): a Liouvillian with basis + matrix above 224 MB (n = 800: N = 640 000, m_max = 20:
+    16 N 23 + matrix = 0.29 GB) takes the one-pass sweep by itself -- statistics say so -- and agrees with the oracle after the step
+    (1e-10), restart counts equal; one size below the threshold (n = 512, config C3) does not take it."""
+    c = L.Context(0)
+    try:
+        assert c.tuning_get("arnoldi_onepass") == 1
+        for n, expect in ((800, True), (512, False)):
+            Lm = synth.liouvillian_tridiag(n)
+            N = Lm.shape[0]
+            rho0 = synth.random_state(N)
+            op = L.Operator(c, [L.Matrix.from_scipy(c, Lm)])
+            wrk = L.NewtonWrk(c, N, m_max=20)
+            psi = L.State(c, data=rho0)
+            L.newton(psi, op, 0.5, wrk)
+            assert (wrk.stats["sweeps_onepass"] == wrk.restarts + 1) if expect else (wrk.stats["sweeps_onepass"] == 0), (n, wrk.stats)
+            assert wrk.stats["sweeps_onepass_redone"] == 0
+            if expect:
+                owrk = qo.NewtonWrk(rho0, m_max=20)
+                ref = qo.newton(rho0.copy(), Lm, 0.5, owrk)
+                assert np.linalg.norm(psi.numpy() - ref) < TOL and wrk.restarts == owrk.restarts
+            for h in (psi, wrk, op):
+                h.close()
+    finally:
+        c.close()

@@ -401,3 +401,63 @@ def test_c_port_matches_50_digit_arithmetic():
         got = ref_c.cheby_csc(Hc.indptr, Hc.indices, Hc.data, psi0.copy(), a, Delta, E_min, dt)
         exact = np.array([complex(z) for z in qmp.expm_apply(Hd, psi0, dt)])
         assert np.linalg.norm(got - exact) < 1e-12, dt
+
+
+def test_newton_c_port_matches_the_numpy_oracle():
+    """ref_c.newton_csc (oracle/newton_ref.c: serial CSC mat-vec, the reference's sequential modified Gram-Schmidt, its two
+    combinations -- src/arnoldi.jl:79-96, src/newton.jl:346-367 -- with the NumPy oracle's own host algebra between them)
+    against qo.newton and against the dense exponential: fixture F4 (N = 256, result, restart count and the first restart's
+    Hessenberg matrix as stored), an N = 4096 Liouvillian over +dt, +dt, -dt with equal restart counts, and the reference's
+    `func = exp` variant (test/test_newton.jl:166-175).  The bench's C3 `cpu_baseline` rests on this."""
+    import os
+    import scipy.linalg as sla
+    from oracle import ref_c
+    import qprop_amd.synth as synth
+    f = np.load(os.path.join(os.path.dirname(__file__), "golden", "F4_newton_liouvillian_n256.npz"))
+    Lm = sp.csr_matrix((f["vals"], f["col"], f["rowptr"]), shape=(int(f["n"]), int(f["n"])))
+    Lc = Lm.tocsc()
+    Lc.sort_indices()
+    wc = ref_c.NewtonCscWrk(Lm.shape[0], m_max=int(f["m_max"]))
+    rho = ref_c.newton_csc(Lc.indptr, Lc.indices, Lc.data, f["rho0"].copy(), float(f["dt"]), wc)
+    assert np.linalg.norm(rho - f["result"]) < 1e-13 and wc.restarts == int(f["restarts"]) and wc.n_a == int(f["n_a"])
+    assert abs(wc.radius - float(f["radius"])) < 1e-12 * float(f["radius"])
+    m_eff, Hess, nmv = ref_c.arnoldi_csc(Lc.indptr, Lc.indices, Lc.data, np.zeros((21, Lm.shape[0]), dtype=np.complex128), 20,
+                                         f["rho0"] / np.linalg.norm(f["rho0"]), float(f["dt"]), True, 1e-14)
+    assert m_eff == 20 and nmv == 20 and np.max(np.abs(Hess - f["first_Hess"])) < 1e-13
+    # a non-extended sweep leaves the last sub-diagonal entry alone and does not normalise the last vector (src/arnoldi.jl:88)
+    q = np.zeros((6, Lm.shape[0]), dtype=np.complex128)
+    m5, H5, _ = ref_c.arnoldi_csc(Lc.indptr, Lc.indices, Lc.data, q, 5, f["rho0"] / np.linalg.norm(f["rho0"]), 1.0, False, 1e-15)
+    H5o = np.zeros((6, 6), dtype=np.complex128)
+    qo_ = [np.zeros(Lm.shape[0], dtype=np.complex128) for _ in range(6)]
+    assert qo.arnoldi(H5o, qo_, 5, f["rho0"] / np.linalg.norm(f["rho0"]), Lm, 1.0, extended=False) == m5 == 5
+    assert np.max(np.abs(H5 - H5o)) < 1e-13 and H5[5, 4] == 0 and np.linalg.norm(q[5] - qo_[5]) < 1e-12
+    # breakdown: an eigenvector start gives m = 1 and the eigenstate shortcut (src/newton.jl:289-295)
+    D = sp.diags(np.arange(1.0, 9.0)).tocsc().astype(np.complex128)
+    e3 = np.zeros(8, dtype=np.complex128)
+    e3[3] = 1.0
+    w8 = ref_c.NewtonCscWrk(8, m_max=5)
+    out = ref_c.newton_csc(D.indptr, D.indices, D.data, e3.copy(), 0.3, w8)
+    assert w8.restarts == 0 and w8.n_matvec == 1 and abs(out[3] - np.exp(-1j * 4.0 * 0.3)) < 1e-14
+    # (for a state of norm beta != 1 the reference's shortcut evaluates func(beta * Hess[1, 1]): kept, as the NumPy oracle keeps it)
+    out2 = ref_c.newton_csc(D.indptr, D.indices, D.data, 2.0 * e3, 0.3, w8)
+    assert np.linalg.norm(out2 - qo.newton(2.0 * e3, D.tocsr(), 0.3, qo.NewtonWrk(e3, m_max=5))) < 1e-14
+    # N = 4096
+    Lb = synth.liouvillian_tridiag(64)
+    N = Lb.shape[0]
+    Lbc = Lb.tocsc()
+    Lbc.sort_indices()
+    rho0 = synth.random_state(N)
+    ref, got = rho0.copy(), rho0.copy()
+    w, wc = qo.NewtonWrk(ref, m_max=20), ref_c.NewtonCscWrk(N, m_max=20)
+    for dt in (0.5, 0.5, -0.3):
+        qo.newton(ref, Lb, dt, w)
+        ref_c.newton_csc(Lbc.indptr, Lbc.indices, Lbc.data, got, dt, wc)
+        assert np.linalg.norm(got - ref) < 1e-12 and wc.restarts == w.restarts, dt
+    # func = exp on a small dense system against the dense exponential (the reference's own check, 1e-10)
+    rng = np.random.default_rng(11)
+    A = sp.csc_matrix((rng.standard_normal((40, 40)) + 1j * rng.standard_normal((40, 40))) * (rng.random((40, 40)) < 0.3) * 0.4)
+    A.sort_indices()
+    x0 = _rand_state(40, rng)
+    wA = ref_c.NewtonCscWrk(40, m_max=10)
+    y = ref_c.newton_csc(A.indptr, A.indices, A.data, x0.copy(), 0.7, wA, func=np.exp)
+    assert np.linalg.norm(y - sla.expm(A.toarray() * 0.7) @ x0) < 1e-10

@@ -270,7 +270,7 @@ def measure_cheby(ctx, pattern="banded", log2n=20, fmt="auto", steps=10, warmup=
            "unstable": sp["unstable"], "slowest_region": sp.get("slowest_region"),
            "regions_remeasured_after_host_stall": sp.get("regions_remeasured_after_host_stall"),
            "layout_bytes_per_term": by["per_term"], "layout_gbs": by["per_term"] / t_term / 1e9,
-           "frac": by["per_term"] / t_term / 1e9 / HBM_PEAK_GBS,
+           "frac": by["per_term"] / t_term / 1e9 / HBM_PEAK_GBS, "model": "layout",
            "csr_equivalent_gbs": by["csr_equivalent_per_term"] / t_term / 1e9,
            "encodings": {"row_blocks": lay["blocks"], "stencil_upper_blocks": lay["stencil_upper_blocks"],
                          "stencil_lower_blocks": lay["stencil_lower_blocks"], "index_bytes": lay["index_bytes"]},
@@ -317,8 +317,9 @@ def measure_newton_c3(ctx, n=512, m=20, dt=0.5, steps=10, warmup=60, repeats=3):
     sp = spread([1e3 * r[0] / steps for r in runs])
     el, sweeps, matvecs, exposed, st = sorted(runs, key=lambda r: r[0])[len(runs) // 2]
     z = nnz / N
-    # SURVEY 8d model per Arnoldi sweep (this implementation's low-sync MGS reads the basis twice per column)
-    sweep_bytes = m * (20 * z + 36) * N + 64 * N * m * (m + 1) / 2 + 64 * N * m + 32 * N * m + 16 * (m + 2) * N + 16 * (m + 3) * N
+    # SURVEY 8d model per Arnoldi sweep, as written there: m plain mat-vecs [matrix + read x + write y] + one fused axpy -> dot pass per
+    # (i, j) [48 N each] + norm + scale per column [48 N] + Psi += sum P_i q_i [(16 m + 32) N] + v = sum R_i q_i [(16 (m + 1) + 16) N]
+    sweep_bytes = m * (20 * z + 36) * N + 48 * N * m * (m + 1) / 2 + 48 * N * m + (16 * m + 32) * N + (16 * (m + 1) + 16) * N
     # bytes this implementation moves per sweep: per column the matrix, the gathered / written vectors of the fused mat-vec
     # (x, w, q_j, the j older basis vectors) and of the projection (w twice, j + 1 basis vectors); then the two combines
     impl_bytes = m * 20 * z * N + 16 * N * m * (m + 5) + 16 * N * (m + 3)
@@ -343,7 +344,7 @@ def measure_newton_c3(ctx, n=512, m=20, dt=0.5, steps=10, warmup=60, repeats=3):
            # `frac` prices the bytes this implementation moves (physical: cannot exceed 1); the SURVEY 8d sweep model counts
            # the reference's sequential Gram-Schmidt passes, which the low-synchronisation form does not make
            "implementation_bytes_per_sweep": impl_bytes, "implementation_gbs": impl_bytes * sweeps / el / 1e9,
-           "frac": impl_bytes * sweeps / el / 1e9 / HBM_PEAK_GBS,
+           "frac": impl_bytes * sweeps / el / 1e9 / HBM_PEAK_GBS, "model": "impl",
            "implementation_frac": impl_bytes * sweeps / el / 1e9 / HBM_PEAK_GBS,
            "algorithmic_gbs": sweep_bytes * sweeps / el / 1e9, "frac_survey_8d_model": sweep_bytes * sweeps / el / 1e9 / HBM_PEAK_GBS,
            "norm": psi.norm()}
@@ -385,12 +386,31 @@ def measure_batched_c5(ctx, log2n=18, batch=64, steps=5, warmup=2, repeats=3):
            "us_per_term_min": sp["min"], "us_per_term_max": sp["max"], "repeats": sp["repeats"], "unstable": sp["unstable"],
            "slowest_region": sp.get("slowest_region"), "regions_remeasured_after_host_stall": sp.get("regions_remeasured_after_host_stall"),
            "row_walk": dict(zip(("inner_dimension", "strip_width"), op.spmm_walk(batch))),
-           "layout_bytes_per_term": lay, "layout_gbs": lay / t_term / 1e9, "frac": lay / t_term / 1e9 / HBM_PEAK_GBS,
+           "layout_bytes_per_term": lay, "layout_gbs": lay / t_term / 1e9, "frac": lay / t_term / 1e9 / HBM_PEAK_GBS, "model": "layout",
            "algorithmic_gbs": alg / t_term / 1e9, "algorithmic_frac": alg / t_term / 1e9 / HBM_PEAK_GBS,
            "max_norm_drift": float(np.max(np.abs(norms - 1.0)))}
     for h in (panel, wrk, op, M):
         h.close()
     return out
+
+
+def with_panel(ctx, log2n, batch, fn, dt=1.0):
+    """The C5 panel (operator, `batch` states, workspace) handed to `fn(step, set_states, read_states, rowptr, col, vals, N, batch,
+    dt)` -- bench.py's CPU-baseline leg compares a sample of the panel with the C port through this; nothing here touches the
+    oracle."""
+    N = 1 << log2n
+    rp, col, vals = synth.hermitian_offsets_csr(N)
+    M = L.Matrix(ctx, N, N, rp, col, vals)
+    op = L.Operator(ctx, [M])
+    panel = L.State(ctx, n=N * batch)
+    wrk = L.ChebyWrk(ctx, N * batch, 20.0, -10.0, dt)
+    try:
+        return fn(lambda: L.cheby_batched(panel, op, dt, wrk, batch),
+                  lambda st: panel.upload(np.ascontiguousarray(st).reshape(-1)),
+                  lambda: panel.numpy().reshape(N, batch), rp, col, vals, N, batch, dt)
+    finally:
+        for h in (panel, wrk, op, M):
+            h.close()
 
 
 def measure_dense(ctx, N=4096, batch=1, fmt="dense", mfma=1, steps=None, repeats=3, seed=7):
@@ -444,7 +464,7 @@ def measure_dense(ctx, N=4096, batch=1, fmt="dense", mfma=1, steps=None, repeats
            "unstable": sp["unstable"], "operator_build_ms": op.build_info()["build_ms"],
            "bytes_per_term": byts, "gbs": byts / t / 1e9, "frac": byts / t / 1e9 / HBM_PEAK_GBS,
            "tflops": flops / t / 1e12, "frac_fp64_matrix_peak": flops / t / 1e12 / 78.6,
-           "bound": "mfma" if batch >= 20 else "hbm", "norm_drift": abs(psi.norm() / np.sqrt(batch) - 1.0)}
+           "bound": "mfma" if batch >= 20 else "hbm", "model": "flops" if batch >= 20 else "layout", "norm_drift": abs(psi.norm() / np.sqrt(batch) - 1.0)}
     for h in (psi, wrk, op, M):
         h.close()
     return out
@@ -482,7 +502,7 @@ def measure_liouville(ctx, n=512, nc=2, reps=20):
                      else "zgemm_sum_kernel (16 x 16 tile per workgroup)",
            "us_per_apply": res["hand_written"], "us_per_apply_min": sps["hand_written"]["min"], "us_per_apply_max": sps["hand_written"]["max"],
            "repeats": 3, "unstable": sps["hand_written"]["unstable"], "tflops": flops / res["hand_written"] / 1e6,
-           "frac_fp64_matrix_peak": flops / res["hand_written"] / 1e6 / 78.6,
+           "frac_fp64_matrix_peak": flops / res["hand_written"] / 1e6 / 78.6, "bound": "mfma", "model": "flops",
            "us_per_apply_rocblas_chain": res["library_chain"], "tflops_rocblas_chain": flops / res["library_chain"] / 1e6}
     for h in (x, y, Lmf):
         h.close()

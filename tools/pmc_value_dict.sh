@@ -1,16 +1,17 @@
 #!/bin/bash
 # HBM traffic per launch of the row-block mat-vec with and without the value-dictionary mirror: one rocprofv3 --pmc pass per counter
 # (the guide's recipe: FETCH_SIZE x 2 on gfx950, WRITE_SIZE as is, KiB), + a --stats pass for the times.  Output: gpurun_out/pmc_value_dict.txt
+REPO="$(cd "$(dirname "$0")/.." && pwd)"
 cd /tmp && export TMPDIR=/tmp
-OUT=/root/repo/gpurun_out/pmc_value_dict.txt
-mkdir -p /root/repo/gpurun_out
+OUT=$REPO/gpurun_out/pmc_value_dict.txt
+mkdir -p $REPO/gpurun_out
 : > $OUT
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pv_$c
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pv_$c -- python3 /root/repo/tools/pmc_value_dict.py > /tmp/pv_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pv_$c -- python3 $REPO/tools/pmc_value_dict.py > /tmp/pv_$c.log 2>&1
 done
 rm -rf /tmp/pv_stats
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pv_stats -- python3 /root/repo/tools/pmc_value_dict.py > /tmp/pv_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pv_stats -- python3 $REPO/tools/pmc_value_dict.py > /tmp/pv_stats.log 2>&1
 python3 - >> $OUT <<'PY'
 import csv, glob, collections
 tot = collections.defaultdict(lambda: collections.defaultdict(list))

@@ -213,6 +213,11 @@ int qp_operator_fill_info(const qp_operator* op, int64_t* n_filled);
  * reach K (far distances m g, m = 1..K), out[3] = 1 if the stencil has a diagonal, out[4] = rows per strip step g
  * (any g >= 64), out[5], out[6] = the walkable row blocks [W0, R1), out[7] = row blocks on the per-block path. */
 int qp_operator_walk_info(const qp_operator* op, int64_t out[8]);
+/* The two-term strip walk: whether a whole-operator qp_cheby_step of this operator forms TWO Chebyshev terms per pass over the
+ * matrix values under the context's knobs (lattice operators beyond the Infinity Cache whose strip columns are long enough; knob
+ * walk_pair).  out[0] = 1 if it does, out[1], out[2] = the row blocks [W0, R1) that take both terms in one launch, out[3] = row
+ * blocks outside them (two per-block launches per pair of terms).  Same results bit for bit either way. */
+int qp_operator_walk2_info(const qp_operator* op, int64_t out[4]);
 /* *glong = the long distance L (rows) of a walk plan with one further pair of distances +-L beyond its far reach
  * (a three-dimensional grid's plane distance; its operands are loaded directly), 0 if the plan has none / there is no plan */
 int qp_operator_walk_long(const qp_operator* op, int64_t* glong);

@@ -251,6 +251,12 @@ inline bool walk_shape_supported(int nn, int K, int z0, int xl = 0, int fd = 0) 
   if (xl) return (xl == 1 || xl == 2) && nn >= 1 && nn <= 2 && (K == 1 || K == 2) && (z0 == 0 || z0 == 1);
   return nn >= 1 && nn <= 4 && K >= 1 && K <= 4 && (z0 == 0 || z0 == 1);
 }
+// the two-term strip walk (kernels_walk2.hip): both terms of a pair (m, m + 1) on the two-term region of plan `P2`, term m of its edge list
+inline bool walk2_shape_supported(int nn, int K, int z0) {
+  return (z0 == 0 || z0 == 1) && ((nn == 4 && K == 4) || (nn == 2 && K == 2) || (nn == 1 && K == 1));
+}
+int launch_hrb_walk2_cheby(hipStream_t s, const DevMatrix& A, const WalkPlan& P2, const double2* x, const ChebyEpi& e1,
+                           const ChebyEpi& e2, const Tuning& tun, bool* launched);
 int launch_hrb_walk_cheby(hipStream_t s, const DevMatrix& A, const double2* x, const ChebyEpi& e, const Tuning& tun,
                           bool* launched, const RowSet* rs = nullptr);
 // kernels_dense.hip (QP_FMT_DENSE: CSR arrays with a complete pattern, i.e. vals / vals_r is the row-major dense matrix)
@@ -324,6 +330,8 @@ struct Tuning {
   int hrb_walk = 1;           // Hermitian-packed fused term of a whole lattice operator: the strip-walk kernel (kernels_walk.hip) when the operator has a walk plan
   int walk_waves = 0;         // strip walk: wavefronts the walk is cut into (0: 768 for an operator that fits the Infinity Cache, else 8 per CU on every CU the edge workgroups leave free -- 1856 for the headline lattice --, or 2048 with the edge blocks inside the walk)
   int walk_wg = 0;            // strip walk: wavefronts per workgroup (0: 4 for an operator that fits the Infinity Cache, else 8; or 8 / 4 / 2)
+  int walk_pair = -1;         // strip walk, two Chebyshev terms per pass over the values (kernels_walk2.hip): -1 = for operators beyond the Infinity Cache whose strip columns are long enough (>= 24 steps per wavefront), 0 never, 1 wherever a plan exists
+  int walk2_waves = 0;        // ... wavefronts it is cut into (0: one per SIMD = 4 per compute unit)
   int value_dict = 1;         // value-dictionary mirror of row-block operators with few distinct values per block (0: never built / used)
   int walk_nt = -1;           // strip walk: nontemporal accesses (-1: the matrix values when the operator does not fit the Infinity Cache; bit 0 matrix values; bits 1, 2: vector loads, stores -- measurement variants of the headline shape)
   int walk_edge_steps = 4;    // strip walk: a wavefront that also takes an edge block walks this many steps less (a block on the per-block path is three dependent rounds of loads; a step of the walk takes about one)

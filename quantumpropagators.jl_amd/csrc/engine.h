@@ -67,6 +67,8 @@ struct qp_operator {
   int walk_reason = 0;            // QP_WALK_*: why the operator has no strip-walk plan (build_walk_plan)
   std::string walk_reason_text;
   qp::WalkPlan walk;              // strip-walk plan of a Hermitian-packed lattice operator (A.walk points here when valid)
+  qp::WalkPlan walk2;             // the same run for the two-term walk (kernels_walk2.hip): [W0, R1) shrunk by K strip steps at either end,
+                                  // edge list = every block outside that region; valid = 0 when the operator has none
   qp::SpmmWalkPlan spmm_walk;     // strip-walk plan of the batched term, built on first use
   bool spmm_walk_built = false;
   qp::ColBlockPlan cb;            // column-blocked mirror of an operator with irregular columns (A.cb points here when valid)
@@ -190,6 +192,8 @@ struct qp_cheby {
   int64_t n;
   double2* bufA = nullptr;
   double2* acc = nullptr;
+  double2* bufC = nullptr;     // two more term vectors for the two-term walk (allocated on first use): a pair writes v_m and v_{m+1}
+  double2* bufD = nullptr;     //   to vectors that nobody reads during the launch
   double* chk_part = nullptr;  // per-workgroup triples (allocated on demand)
   double* chk_out = nullptr;   // per-term triples
   int chk_wg = 0, chk_terms = 0;

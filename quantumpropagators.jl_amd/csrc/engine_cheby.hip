@@ -68,6 +68,8 @@ int qp_cheby_destroy(qp_cheby* w) {
   (void)hipSetDevice(w->ctx->device);
   (void)hipStreamSynchronize(w->ctx->stream);
   if (w->bufA) (void)hipFree(w->bufA);
+  if (w->bufC) (void)hipFree(w->bufC);
+  if (w->bufD) (void)hipFree(w->bufD);
   if (w->acc) (void)hipFree(w->acc);
   if (w->chk_part) (void)hipFree(w->chk_part);
   if (w->chk_out) (void)hipFree(w->chk_out);
@@ -116,8 +118,42 @@ int qp_cheby_term(qp_operator* op, const qp_state* x, int64_t xoff, const qp_sta
   QP_CATCH
 }
 
+// Does a whole-operator cheby! of `op` take the two-term strip walk (kernels_walk2.hip) under the context's knobs?  Beyond the
+// Infinity Cache only (inside it the one-term walk is not bound by the value stream), and only when a wavefront's strip column is
+// long enough for the 2 K steps a segment runs in before its first z to be a small part of it.
+static bool walk2_wanted(const qp_operator* op) {
+  const qp::Tuning& tun = op->ctx->tun;
+  const qp::WalkPlan& Q = op->walk2;
+  const DevMatrix& A = op->A;
+  if (!Q.valid || tun.walk_pair == 0 || !tun.hrb_walk || (tun.rbcsr_variant & 31) != 15 || A.walk != &op->walk || !op->walk.valid) return false;
+  if (op->walk.R1 - op->walk.W0 < tun.walk_min_blocks) return false;
+  if (tun.walk_pair == 1) return true;
+  const double footprint = (double)(Q.z0 + Q.nn + Q.K) * kRB * (double)A.nblocks * (A.vals_r ? 8.0 : 16.0) + 64.0 * (double)A.nrows;
+  if (footprint <= 230e6) return false;
+  const int W = kRB - 2 * Q.near[Q.nn - 1];
+  const int64_t S2 = (Q.g + W - 1) / W, Jz = ((Q.R1 - Q.W0) * (int64_t)kRB + Q.g - 1) / Q.g;
+  const int64_t waves = tun.walk2_waves > 0 ? tun.walk2_waves : 4 * (int64_t)tun.n_cu;
+  return Jz / std::max<int64_t>(1, waves / S2) >= 24;
+}
+
+int qp_operator_walk2_info(const qp_operator* op, int64_t out[4]) {
+  QP_TRY
+  if (!op || !out) return qp::fail(QP_E_BAD_ARG, "qp_operator_walk2_info: NULL argument");
+  const bool on = walk2_wanted(op);
+  out[0] = on ? 1 : 0;
+  out[1] = on ? op->walk2.W0 : 0;
+  out[2] = on ? op->walk2.R1 : 0;
+  out[3] = on ? op->walk2.n_edge : 0;
+  return QP_OK;
+  QP_CATCH
+}
+
 // the launches of one cheby! call (src/cheby.jl:171-211): n_coeffs - 1 fused mat-vec + term
-// kernels and, when the result does not land in Psi's buffer, one copy
+// kernels and, when the result does not land in Psi's buffer, one copy.
+// Term vectors: `cur` holds v_{m-1} (gathered by term m), `prev` holds v_{m-2}.  A one-term launch writes v_m over v_{m-2} in
+// place; a two-term launch (terms m and m + 1 in one pass over the matrix values, kernels_walk2.hip) writes v_m and v_{m+1} to two
+// vectors nobody reads meanwhile -- the neighbouring strip columns still gather from `cur` and `prev` -- so a step that takes pairs
+// rotates four vectors (Psi's, bufA, bufC, bufD) instead of two.
 static int cheby_step_launches(qp_cheby* w, qp_operator* op, qp_state* psi, const double* a, int n_coeffs, double beta,
                                cplx c, cplx phase, bool check_normalization) {
   qp_ctx* ctx = op->ctx;
@@ -130,30 +166,15 @@ static int cheby_step_launches(qp_cheby* w, qp_operator* op, qp_state* psi, cons
   double2* result = nullptr;
   std::vector<qp_acc_defer> sched((size_t)nterms);
   acc_schedule(a, n_coeffs, ctx->tun.acc_defer != 0, sched.data());
+  bool pairs = !check_normalization && nterms >= 3 && walk2_wanted(op);
+  if (pairs && !w->bufC) {
+    QP_CHECK(dev_alloc(&w->bufC, (size_t)w->n));
+    QP_CHECK(dev_alloc(&w->bufD, (size_t)w->n));
+  }
+  double2 *cur = P, *prev = nullptr;
+  double2* spare[2] = {w->bufC, w->bufD};      // the two vectors no term of the step is reading
   bool updated = false;   // has any term written the accumulator yet?
-  for (int m = 1; m <= nterms; ++m) {
-    const bool last = (m == nterms);
-    qp::ChebyEpi e;
-    const double2* x;
-    if (m == 1) {
-      // v0 = Psi; Psi = a1 v0; v1 = c (H v0 - beta v0); Psi += a2 v1     :171-182
-      x = P;
-      e.v0 = nullptr;
-      e.vout = last ? nullptr : B;
-      e.acc_in = nullptr;
-      e.acc_out = ACC;
-      result = ACC;
-    } else {
-      // v2 = c (H v1 - beta v1) + v0; Psi += a_i v2; rotate            :186-207
-      double2* xb = (m % 2 == 0) ? B : P;   // holds v1 (gathered)
-      double2* ob = (m % 2 == 0) ? P : B;   // holds v0, overwritten in place by v2
-      x = xb;
-      e.v0 = ob;
-      e.vout = last ? nullptr : ob;
-      e.acc_in = updated ? ACC : nullptr;
-      e.acc_out = (last && xb == B) ? P : ACC;  // P may be written only while it is not gathered
-      result = e.acc_out;
-    }
+  auto fill = [&](qp::ChebyEpi& e, int m, const double2* x) {      // what every term's epilogue carries
     e.a_prev = updated ? 0.0 : a[0];
     set_defer(e, &sched[m - 1]);
     if (sched[m - 1].skip) {
@@ -167,16 +188,90 @@ static int cheby_step_launches(qp_cheby* w, qp_operator* op, qp_state* psi, cons
     e.beta = beta;
     e.a = a[m];
     e.phase = d2(phase);
-    e.apply_phase = last ? 1 : 0;
+    e.apply_phase = (m == nterms) ? 1 : 0;
+  };
+  for (int m = 1; m <= nterms; ++m) {
+    const bool last = (m == nterms);
+    qp::ChebyEpi e;
+    if (m == 1) {
+      // v0 = Psi; Psi = a1 v0; v1 = c (H v0 - beta v0); Psi += a2 v1     :171-182
+      e.v0 = nullptr;
+      e.vout = last ? nullptr : B;
+      e.acc_in = nullptr;
+      e.acc_out = ACC;
+      result = ACC;
+    } else if (pairs && m + 1 <= nterms && !(sched[m - 1].skip == 0 && sched[m].skip == 0)) {
+      // terms m and m + 1 in one pass over the values: y = v_m -> spare[0], z = v_{m+1} -> spare[1]
+      const bool last2 = (m + 1 == nterms);
+      const bool updated_before = updated;
+      qp::ChebyEpi e1, e2;
+      e1.v0 = prev;
+      e1.vout = spare[0];
+      e1.acc_in = updated ? ACC : nullptr;
+      e1.acc_out = ACC;
+      e1.check_partials = nullptr;
+      fill(e1, m, cur);
+      e2.v0 = cur;
+      e2.vout = last2 ? nullptr : spare[1];
+      e2.acc_in = updated ? ACC : nullptr;
+      e2.acc_out = ACC;
+      e2.check_partials = nullptr;
+      fill(e2, m + 1, spare[0]);
+      bool launched = false;
+      {
+        const qp::ScopedRange mv_range(ctx->tun.roctx != 0 || qp::ranges_enabled_by_env(), "matrix-vector product");
+        QP_CHECK(qp::launch_hrb_walk2_cheby(ctx->stream, A, op->walk2, cur, e1, e2, ctx->tun, &launched));
+        if (launched) {
+          // term m + 1 of the blocks outside the two-term region: they read y of their neighbours, which the launch above wrote
+          qp::RowSet rs;
+          rs.block_map = op->walk2.edge_map;
+          rs.nmap = op->walk2.n_edge;
+          rs.count = false;
+          QP_CHECK(qp::launch_spmv_cheby(ctx->stream, A, spare[0], e2, &ctx->stats, &rs));
+          ctx->stats.n_launch++;
+          ctx->stats.n_matvec += 2;
+          ctx->stats.spmv_bytes += 2.0 * (20.0 * (double)A.nnz + 4.0 * (double)(A.nrows + 1) + 80.0 * (double)A.nrows);
+        }
+      }
+      if (launched) {
+        result = ACC;
+        double2* const y = spare[0];
+        double2* const z = spare[1];
+        spare[0] = cur;
+        spare[1] = prev;
+        prev = y;
+        cur = z;
+        ++m;
+        continue;
+      }
+      // not taken after all (the kernel's LDS opt-in was refused): this and every later term as one-term launches
+      updated = updated_before;
+      pairs = false;
+    }
+    if (m > 1) {
+      // v2 = c (H v1 - beta v1) + v0; Psi += a_i v2; rotate            :186-207
+      e.v0 = prev;                      // holds v0, overwritten in place by v2
+      e.vout = last ? nullptr : prev;
+      e.acc_in = updated ? ACC : nullptr;
+      e.acc_out = (last && cur != P && !pairs) ? P : ACC;  // P may be written only while it is not gathered
+      result = e.acc_out;
+    }
+    fill(e, m, cur);
     // the reference checks terms i >= 3 only (inside the loop at :186)
     e.check_partials = (check_normalization && m >= 2) ? w->chk_part : nullptr;
     {
       const qp::ScopedRange mv_range(ctx->tun.roctx != 0 || qp::ranges_enabled_by_env(), "matrix-vector product");   // src/cheby.jl:175, :189
-      QP_CHECK(qp::launch_spmv_cheby(ctx->stream, A, x, e, &ctx->stats));
+      QP_CHECK(qp::launch_spmv_cheby(ctx->stream, A, cur, e, &ctx->stats));
     }
     if (e.check_partials)
       QP_CHECK(qp::launch_reduce_triples(ctx->stream, w->chk_part, nwg, w->chk_out + 3 * (m - 1), &ctx->stats));
-    if (m == 1) c *= 2.0;  // :184
+    if (m == 1) {
+      c *= 2.0;  // :184
+      prev = P;
+      cur = B;
+    } else {
+      std::swap(cur, prev);      // prev's buffer now holds v_m: it is gathered next
+    }
   }
   if (result != P)
     QP_HIP(hipMemcpyAsync(P, result, (size_t)psi->n * sizeof(double2), hipMemcpyDeviceToDevice, ctx->stream));

@@ -36,7 +36,7 @@ int* tuning_field(Tuning& t, const char* key) {
       {"spmm_nt", &Tuning::spmm_nt},             {"spmm_rows", &Tuning::spmm_rows},
       {"spmm_strip", &Tuning::spmm_strip},       {"spmm_rw", &Tuning::spmm_rw},
       {"hrb_walk", &Tuning::hrb_walk},           {"walk_waves", &Tuning::walk_waves},
-      {"walk_min_blocks", &Tuning::walk_min_blocks}, {"walk_dbg", &Tuning::walk_dbg}, {"walk_nt", &Tuning::walk_nt}, {"value_dict", &Tuning::value_dict}, {"walk_wg", &Tuning::walk_wg}, {"walk_edge_steps", &Tuning::walk_edge_steps}, {"split_spin_log2", &Tuning::split_spin_log2}, {"split_dbg", &Tuning::split_dbg}, {"spmm_walk", &Tuning::spmm_walk}, {"spmm_walk_waves", &Tuning::spmm_walk_waves},
+      {"walk_min_blocks", &Tuning::walk_min_blocks}, {"walk_dbg", &Tuning::walk_dbg}, {"walk_nt", &Tuning::walk_nt}, {"value_dict", &Tuning::value_dict}, {"walk_pair", &Tuning::walk_pair}, {"walk2_waves", &Tuning::walk2_waves}, {"walk_wg", &Tuning::walk_wg}, {"walk_edge_steps", &Tuning::walk_edge_steps}, {"split_spin_log2", &Tuning::split_spin_log2}, {"split_dbg", &Tuning::split_dbg}, {"spmm_walk", &Tuning::spmm_walk}, {"spmm_walk_waves", &Tuning::spmm_walk_waves},
   };
   for (const Entry& e : table)
     if (std::strcmp(e.name, key) == 0) return &(t.*(e.field));
@@ -403,6 +403,8 @@ static int operator_free_device(qp_operator* op) {
   op->spmm_walk_built = false;
   if (op->walk.edge_map) (void)hipFree(op->walk.edge_map);
   op->walk = qp::WalkPlan();
+  if (op->walk2.edge_map) (void)hipFree(op->walk2.edge_map);
+  op->walk2 = qp::WalkPlan();
   op->A.walk = nullptr;
   if (op->cb.segptr) (void)hipFree(op->cb.segptr);
   if (op->cb.rowoff) (void)hipFree(op->cb.rowoff);

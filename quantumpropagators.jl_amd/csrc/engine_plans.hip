@@ -141,6 +141,8 @@ int build_walk_plan(qp_operator* op) {
   qp::WalkPlan& P = op->walk;
   if (P.edge_map) (void)hipFree(P.edge_map);
   P = qp::WalkPlan();
+  if (op->walk2.edge_map) (void)hipFree(op->walk2.edge_map);
+  op->walk2 = qp::WalkPlan();
   DevMatrix& A = op->A;
   A.walk = nullptr;
   const HostLayout& Lh = op->layout;
@@ -241,6 +243,22 @@ int build_walk_plan(qp_operator* op) {
   if (!edge.empty()) QP_HIP(hipMemcpy(P.edge_map, edge.data(), edge.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   P.valid = 1;
   A.walk = &P;
+  // the two-term walk's plan: the region in which phase Z (term m + 1 of block t - K) finds y of the K blocks on either side formed
+  // by the same walk -- [W0 + K S, R1 - K S) -- and, as its edge list, every block outside it (they take two per-block launches)
+  if (!xl && !fd && g % kRB == 0 && qp::walk2_shape_supported(nn, K, z0) && (R1 - W0) - 2 * (int64_t)K * S >= 8 * (int64_t)S) {
+    qp::WalkPlan& Q = op->walk2;
+    Q = P;
+    Q.edge_map = nullptr;
+    Q.W0 = W0 + (int64_t)K * S;
+    Q.R1 = R1 - (int64_t)K * S;
+    std::vector<int32_t> edge2;
+    for (int64_t b = 0; b < Q.W0; ++b) edge2.push_back((int32_t)b);
+    for (int64_t b = Q.R1; b < nb; ++b) edge2.push_back((int32_t)b);
+    Q.n_edge = (int64_t)edge2.size();
+    QP_CHECK(dev_alloc(&Q.edge_map, std::max<size_t>(edge2.size(), 1)));
+    QP_HIP(hipMemcpy(Q.edge_map, edge2.data(), edge2.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    Q.valid = 1;
+  }
   return QP_OK;
 }
 

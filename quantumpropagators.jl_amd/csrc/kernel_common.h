@@ -215,6 +215,42 @@ struct ChebyOpT {
     if (e.apply_phase) r = cmul(e.phase, r);  // lmul!(exp(-i beta dt), Psi)  :211
     st_stream<NT>(e.acc_out + i, r);
   }
+  // row() in two halves for a kernel that needs the new term's VALUE back (the two-term strip walk, kernels_walk2.hip, feeds
+  // v_m of a row into the row sums of v_{m+1}): term() = the value row() would store -- the same operations in the same order,
+  // hence the same bits; no normalisation check, no mirror map (that kernel is not taken with either) --, finish() = its stores.
+  __device__ __forceinline__ double2 term(double2 s, const Pre& p) const {
+    double2 t = make_double2(fma(-e.beta, p.xi.x, s.x), fma(-e.beta, p.xi.y, s.y));
+    t = cmul(e.c, t);
+    if (e.v0) {
+      t.x += p.v0.x;
+      t.y += p.v0.y;
+    }
+    return t;
+  }
+  __device__ __forceinline__ void finish(int64_t i, double2 t, const Pre& p) const {
+    const double2 xi = p.xi;
+    if (e.vout) st_stream<NT>(e.vout + i, t);
+    if (e.acc_skip) return;
+    double2 r;
+    if (e.acc_in) {
+      r = p.acc;
+    } else {
+      const double2 ps = (e.n_defer == 1) ? p.v0 : xi;
+      r = make_double2(e.a_prev * ps.x, e.a_prev * ps.y);
+    }
+    if (e.n_defer == 2) {
+      r.x = fma(e.a_d2, p.v0.x, r.x);
+      r.y = fma(e.a_d2, p.v0.y, r.y);
+    }
+    if (e.n_defer >= 1) {
+      r.x = fma(e.a_d1, xi.x, r.x);
+      r.y = fma(e.a_d1, xi.y, r.y);
+    }
+    r.x = fma(e.a, t.x, r.x);
+    r.y = fma(e.a, t.y, r.y);
+    if (e.apply_phase) r = cmul(e.phase, r);
+    st_stream<NT>(e.acc_out + i, r);
+  }
 };
 using ChebyOp = ChebyOpT<false>;
 

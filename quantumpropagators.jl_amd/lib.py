@@ -133,6 +133,7 @@ SIGNATURES = {
     "qp_operator_layout_info": (C.c_int, [_P, _i64p]),
     "qp_operator_build_info": (C.c_int, [_P, _dp]),
     "qp_operator_walk_info": (C.c_int, [_P, _i64p]),
+    "qp_operator_walk2_info": (C.c_int, [_P, _i64p]),
     "qp_operator_fill_info": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "qp_developer_build": (C.c_int, []),
     "qp_operator_walk_long": (C.c_int, [_P, C.POINTER(C.c_int64)]),
@@ -569,6 +570,12 @@ class Operator:
         n = C.c_int64(0)
         check(self.lib.qp_operator_fill_info(self._h, C.byref(n)))
         return n.value
+
+    def walk2_info(self):
+        """Does a whole-operator ``cheby!`` take the two-term strip walk (include/qprop.h: qp_operator_walk2_info)?"""
+        out = np.zeros(4, dtype=np.int64)
+        check(self.lib.qp_operator_walk2_info(self._h, _ptr(out, _i64p)))
+        return dict(zip(("valid", "first_block", "end_block", "edge_blocks"), (int(v) for v in out)))
 
     def walk_info(self):
         """Strip-walk plan of a Hermitian-packed lattice operator (see include/qprop.h)."""

@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("{\"error\": \"%s -> %s\"}\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
@@ -34,7 +35,8 @@ struct Args {
   d2* acc_out;
   long long n;
   int g, L, W;      // rows per strip step, z-steps per wavefront, useful rows per chunk (64: no lateral redundancy, 56: the real thing)
-  int mode;         // 0: one-term walk (today), 1: two-term walk, values retained in LDS, 2: two-term walk, values loaded again
+  int mode;         // 0: one-term walk (today), 1: two-term walk, values retained in LDS, 2: two-term walk, values loaded again,
+                    // 3: two-term walk, values retained in REGISTERS (walk unrolled by K + 1 so that the rotation is static; 1 wavefront per SIMD)
   int with_acc;
   int waves_per_wg;
 };
@@ -46,7 +48,7 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
 }
 
 template <int MODE>
-__global__ __launch_bounds__(512) void walk(Args A) {
+__global__ __launch_bounds__(MODE == 3 ? 256 : 512) void walk(Args A) {
   extern __shared__ d2 lds[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
@@ -67,6 +69,13 @@ __global__ __launch_bounds__(512) void walk(Args A) {
     return A.vals + ((row >> 6) * 8 + u) * 64 + (row & 63);
   };
   d2 va[8], vz[8], xn, pp, ac = {0.0, 0.0}, h0, h1, ring = {0.0, 0.0}, yring = {0.0, 0.0};
+  d2 hist[MODE == 3 ? K + 1 : 1][8];
+  if (MODE == 3) {
+#pragma unroll
+    for (int a = 0; a < K + 1; ++a)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) hist[a][u] = d2{0.0, 0.0};
+  }
   const long long jbeg = (MODE == 0) ? j0 : j0 - K;      // first Y step (the two-term walk runs in K steps before its first z)
   // run-in of a segment: ring (2K loads) and history values (K (K + 1) / 2 lines), as the real walk
   {
@@ -98,7 +107,8 @@ __global__ __launch_bounds__(512) void walk(Args A) {
   };
   const long long ybeg = (MODE == 0) ? j0 : j0 - K, yend = (MODE == 0) ? j1 : j1 + K;      // Y steps: K of run-in, K of run-out
   load(ybeg);
-  for (long long j = ybeg; j < yend; ++j) {
+  auto body = [&](long long j, auto phase) __attribute__((always_inline)) {
+    constexpr int PH = decltype(phase)::value;
     // ---- phase Y (today's step): near windows through LDS, 128 FMAs
 #pragma unroll
     for (int k = 0; k < 5; ++k) win[k * 96 + 16 + lane] = k < 4 ? va[k] : ring;
@@ -132,6 +142,13 @@ __global__ __launch_bounds__(512) void walk(Args A) {
       if (MODE == 1) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) vz[u] = ret[((j - ybeg + 1) % (K + 1)) * 512 + u * 64 + lane];
+      }
+      if (MODE == 3) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          vz[u] = hist[(PH + 1) % (K + 1)][u];
+          hist[PH % (K + 1)][u] = va[u];
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -174,6 +191,17 @@ __global__ __launch_bounds__(512) void walk(Args A) {
         if (A.with_acc) A.acc_out[std::min(r - (long long)K * A.g, nlast)] = d2{zv.x + yv.x, zv.y};
       }
     }
+  };
+  if (MODE == 3) {      // (a few steps beyond the segment's end: addresses clamp, a probe)
+    for (long long j = ybeg; j < yend; j += K + 1) {
+      body(j, std::integral_constant<int, 0>());
+      body(j + 1, std::integral_constant<int, 1>());
+      body(j + 2, std::integral_constant<int, 2>());
+      body(j + 3, std::integral_constant<int, 3>());
+      body(j + 4, std::integral_constant<int, 4>());
+    }
+  } else {
+    for (long long j = ybeg; j < yend; ++j) body(j, std::integral_constant<int, 0>());
   }
 }
 
@@ -218,7 +246,7 @@ int main(int argc, char** argv) {
   struct Cfg { int mode, W, wpw; const char* name; };
   // (values retained in LDS: 5 blocks x 8 KiB + windows = 50 KB per wavefront: at most THREE wavefronts per compute unit)
   const Cfg cfgs[] = {{0, 64, 8, "one_term_x2"},           {1, 64, 3, "two_term_lds_W64_3w"}, {1, 56, 3, "two_term_lds_W56_3w"},
-                      {2, 64, 8, "two_term_reload_W64_8w"}, {2, 56, 8, "two_term_reload_W56_8w"}, {2, 56, 4, "two_term_reload_W56_4w"}};
+                      {3, 64, 4, "two_term_regs_W64_4w"},  {3, 56, 4, "two_term_regs_W56_4w"}, {2, 56, 8, "two_term_reload_W56_8w"}};
   const int nc = (int)(sizeof(cfgs) / sizeof(cfgs[0]));
   std::vector<std::vector<double>> us((size_t)nc);
   int Ls[8] = {0};
@@ -235,7 +263,7 @@ int main(int argc, char** argv) {
       const long long ntask = ((J + A.L - 1) / A.L) * S;
       const int nwg = (int)((ntask + cf.wpw - 1) / cf.wpw);
       const size_t ldsb = sizeof(d2) * (size_t)cf.wpw * ((cf.mode == 1 ? (K + 1) * 512 : 0) + 6 * 96);
-      auto kern = cf.mode == 0 ? &walk<0> : (cf.mode == 1 ? &walk<1> : &walk<2>);
+      auto kern = cf.mode == 0 ? &walk<0> : (cf.mode == 1 ? &walk<1> : (cf.mode == 2 ? &walk<2> : &walk<3>));
       CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
       CK(hipEventRecord(e0));
       // six terms' worth: six one-term launches (accumulator on two of them) or three two-term launches (accumulator on one)

@@ -136,14 +136,17 @@ static bool walk2_wanted(const qp_operator* op) {
   return Jz / std::max<int64_t>(1, waves / S2) >= 24;
 }
 
-int qp_operator_walk2_info(const qp_operator* op, int64_t out[4]) {
+int qp_operator_walk2_info(const qp_operator* op, int64_t out[6]) {
   QP_TRY
   if (!op || !out) return qp::fail(QP_E_BAD_ARG, "qp_operator_walk2_info: NULL argument");
   const bool on = walk2_wanted(op);
+  const int W = on ? kRB - 2 * op->walk2.near[op->walk2.nn - 1] : 0;
   out[0] = on ? 1 : 0;
   out[1] = on ? op->walk2.W0 : 0;
   out[2] = on ? op->walk2.R1 : 0;
   out[3] = on ? op->walk2.n_edge : 0;
+  out[4] = W;
+  out[5] = on ? (op->walk2.g + W - 1) / W : 0;
   return QP_OK;
   QP_CATCH
 }
@@ -166,11 +169,7 @@ static int cheby_step_launches(qp_cheby* w, qp_operator* op, qp_state* psi, cons
   double2* result = nullptr;
   std::vector<qp_acc_defer> sched((size_t)nterms);
   acc_schedule(a, n_coeffs, ctx->tun.acc_defer != 0, sched.data());
-  bool pairs = !check_normalization && nterms >= 3 && walk2_wanted(op);
-  if (pairs && !w->bufC) {
-    QP_CHECK(dev_alloc(&w->bufC, (size_t)w->n));
-    QP_CHECK(dev_alloc(&w->bufD, (size_t)w->n));
-  }
+  bool pairs = !check_normalization && nterms >= 3 && w->bufC && w->bufD && walk2_wanted(op);   // (qp_cheby_step allocated the two vectors)
   double2 *cur = P, *prev = nullptr;
   double2* spare[2] = {w->bufC, w->bufD};      // the two vectors no term of the step is reading
   bool updated = false;   // has any term written the accumulator yet?
@@ -313,6 +312,12 @@ int qp_cheby_step(qp_cheby* w, qp_operator* op, qp_state* psi, const double* a, 
       w->chk_terms = nterms;
     }
   }
+  // the two-term strip walk rotates four term vectors: the two beyond Psi's and bufA are allocated on first use (here, not inside a
+  // stream capture)
+  if (nterms >= 3 && !check_normalization && !w->bufC && walk2_wanted(op)) {
+    QP_CHECK(dev_alloc(&w->bufC, (size_t)w->n));
+    QP_CHECK(dev_alloc(&w->bufD, (size_t)w->n));
+  }
   // launch-bound systems (a term takes less than its launch): replay the step as a hipGraph
   bool done = false;
   if (ctx->tun.cheby_graph && !check_normalization && ctx->stream != nullptr && ctx->stream != hipStreamLegacy) {
@@ -326,6 +331,7 @@ int qp_cheby_step(qp_cheby* w, qp_operator* op, qp_state* psi, const double* a, 
     key.variant = ((((ctx->tun.rbcsr_variant * 2) * 16 + ctx->tun.hrb_wg) * 2 + (ctx->tun.hrb_walk ? 1 : 0)) * 8 +
                    (ctx->tun.walk_nt & 7)) * 4096 + ((ctx->tun.walk_waves + 16 * ctx->tun.walk_wg) & 4095);
     key.variant = key.variant * 2 + (ctx->tun.value_dict ? 1 : 0);      // (coded / plain row-block kernel)
+    key.variant = key.variant * 2 + (walk2_wanted(op) ? 1 : 0);         // (terms in pairs)
     key.n_coeffs = n_coeffs;
     key.dt = dt;
     key.Delta = Delta;

@@ -392,7 +392,12 @@ int launch_hrb_walk2_cheby(hipStream_t s, const DevMatrix& A, const WalkPlan& P2
   HrbArrays H{A.bptr, A.cmeta, reinterpret_cast<const char*>(A.cols), A.lptr, A.lcmeta,
               reinterpret_cast<const char*>(A.lcols), reinterpret_cast<const int4*>(A.lpos)};
   ChebyOp op1{e1}, op2{e2};
-  const int ntm = tun.walk_nt >= 0 ? tun.walk_nt : 1;
+  // value loads with the default cache policy once the values are well beyond the Infinity Cache: the chunks overlap by 2 d_max rows and
+  // a chunk's packed value halo is its neighbour's stream -- streamed nontemporally, each of those lines comes from memory twice
+  // (N = 2^22: 103.6 -> 99.8 us per term, 2^24: 399 -> 363); while most of the values still fit the cache the nontemporal stream
+  // leaves it to the vectors (2^21: 56.8 -> 54.6)
+  const double value_bytes = (double)(P2.z0 + P2.nn + P2.K) * kRB * (double)A.nblocks * (A.vals_r ? 8.0 : 16.0);
+  const int ntm = tun.walk_nt >= 0 ? tun.walk_nt : (value_bytes <= 300e6 ? 1 : 0);
   const bool ok = A.vals_r ? launch2_shape<double>(s, A.vals_r, x, P2, G, H, A.nrows, op1, op2, ntm)
                            : launch2_shape<double2>(s, A.vals, x, P2, G, H, A.nrows, op1, op2, ntm);
   if (!ok) return QP_OK;

@@ -165,9 +165,42 @@ def cheby_layout_bytes(op, rows, ncols, nnz, coeffs, real_copy=False):
         if ve["valid"]:      # the value-dictionary mirror: a byte per stored position + the blocks' (shared) tables
             matrix = ve["coded_bytes"] + index
     sched = L.acc_schedule(coeffs)
+    # the two-term strip walk (csrc/kernels_walk2.hip): terms 2 .. in PAIRS, each pair one pass over the values.  What a pair loads is
+    # more than the rows it forms: a chunk's 64 lanes form z on W = 64 - 2 d_max of them (ceil(g / W) chunks per strip step), and a
+    # segment of L steps runs in 2 K steps before its first z; the blocks outside the two-term region take two per-block passes.
+    w2 = op.walk2_info() if (fmt == L.FMT_HRB and walk["valid"]) else {"valid": 0}
+    pair = None
+    if w2["valid"]:
+        g, K = walk["rows_per_step"], walk["far"]
+        W, S2 = w2["useful_rows_per_chunk"], w2["chunks_per_strip_step"]
+        Jz = -(-(w2["end_block"] - w2["first_block"]) * 64 // g)
+        waves = op.ctx.tuning_get("walk2_waves") or 4 * op.ctx.tuning_get("n_cu")
+        Lz = -(-Jz // max(1, waves // S2))
+        nseg = -(-Jz // Lz)
+        rows_loaded = 64.0 * S2 * (Jz + 2 * K * nseg)          # lanes x Y steps of the walk
+        rows_region = 64.0 * (w2["end_block"] - w2["first_block"])
+        slots = walk.get("upper_slots") or (walk["diag"] + walk["near"] + walk["far"])
+        edge_share = w2["edge_blocks"] / max(lay["blocks"], 1)
+        pair = {"rows_loaded_per_pair": rows_loaded, "rows_of_the_region": rows_region, "chunks_per_strip_step": S2, "useful_rows_per_chunk": W,
+                "steps_per_wavefront": Lz, "segments": nseg,
+                # values once per pair over the lanes that load them + the edge blocks' two per-block passes (values + index bytes)
+                "matrix_per_pair": vbytes * slots * rows_loaded + 2.0 * (vbytes * lay["stored"] + lay["index_bytes"] + 32.0 * lay["blocks"]) * edge_share}
+        lay["two_term_walk"] = pair
     vec = 0.0
     updated = False
-    for m in range(1, nterms + 1):
+    npairs = 0
+    m = 1
+    while m <= nterms:
+        if pair is not None and m >= 2 and m + 1 <= nterms:
+            # x and p over the loaded lanes, y and z over the rows; the accumulator by the schedule (never both terms of a pair)
+            vec += 2.0 * 16.0 * pair["rows_loaded_per_pair"] + 16.0 * rows + (16.0 * rows if m + 1 < nterms else 0.0)
+            for mm in (m, m + 1):
+                if not sched[mm - 1].skip:
+                    vec += (32.0 if updated else 16.0) * rows
+                    updated = True
+            npairs += 1
+            m += 2
+            continue
         vec += 16.0 * ncols * (8.0 if cb_on else 1.0)    # gathered vector (the mirror: every XCD's L2 loads every window once)
         if m >= 2:
             vec += 16.0 * rows                   # v_{m-2}
@@ -176,8 +209,15 @@ def cheby_layout_bytes(op, rows, ncols, nnz, coeffs, real_copy=False):
         if not sched[m - 1].skip:
             vec += (32.0 if updated else 16.0) * rows
             updated = True
-    step = nterms * matrix + vec
-    return {"per_step": step, "per_term": step / nterms, "matrix_per_term": matrix, "vectors_per_term": vec / nterms,
+        m += 1
+    if pair is not None:
+        vec += 32.0 * rows                       # the result's copy into Psi's vector (the pairs rotate four vectors)
+        step = (nterms - 2 * npairs) * matrix + npairs * pair["matrix_per_pair"] + vec
+        matrix_per_term = ((nterms - 2 * npairs) * matrix + npairs * pair["matrix_per_pair"]) / nterms
+    else:
+        step = nterms * matrix + vec
+        matrix_per_term = matrix
+    return {"per_step": step, "per_term": step / nterms, "matrix_per_term": matrix_per_term, "vectors_per_term": vec / nterms,
             "csr_equivalent_per_term": (12.0 if real_copy else 20.0) * nnz + 4.0 * (rows + 1) + 80.0 * rows,
             "layout": lay}
 
@@ -185,7 +225,7 @@ def cheby_layout_bytes(op, rows, ncols, nnz, coeffs, real_copy=False):
 def cheby_kernel_name(op):
     """The kernel a whole-operator fused Chebyshev term of `op` launches (substring of its symbol)."""
     if op.format == L.FMT_HRB and op.walk_info()["valid"]:
-        return "hrb_walk_kernel"
+        return "hrb_walk2_kernel" if op.walk2_info()["valid"] else "hrb_walk_kernel"
     if op.colblock_info()["valid"] and op.ctx.tuning_get("colblock") != 0:
         return "colblock_spmv_kernel"
     if op.format == L.FMT_RBCSR and op.value_encoding_info()["valid"]:

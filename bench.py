@@ -957,7 +957,7 @@ def main():
                                        host_staged=one_gpu, native=False, overlap=False)
             shA.set_state(psi0_local)
             elA, evA, stA = timed_steps(lambda: shA.step(native=False))
-            modelA = bp.cheby_layout_bytes(shA.op, rows, rows + world * shA.M, nnz_local, coeffs, real_copy=args.real)
+            modelA = bp.cheby_layout_bytes(shA.op, rows, rows + world * shA.M, nnz_local, coeffs, real_copy=args.real, whole_step=False)
             kernel_used = KERNEL_OF_FORMAT[shA.op.format]
             build_ms = shA.op.build_info()
             fallback = make_out(elA, evA, stA, shA.op.format, modelA, shA.exchange, "serial", "torch.distributed (step loop in Python)",
@@ -1001,7 +1001,7 @@ def main():
             stage("set-up, self-check and schedule trial")
             sh_, nat_, snote_, dnote_ = make_stepper(rp, col, vals, N, r0, r1, psi0_local)
             stage("timed steps")
-            model_ = bp.cheby_layout_bytes(sh_.op, rows, rows + world * sh_.M, nnz_local, coeffs, real_copy=args.real)
+            model_ = bp.cheby_layout_bytes(sh_.op, rows, rows + world * sh_.M, nnz_local, coeffs, real_copy=args.real, whole_step=False)
             el_, ev_, st_ = timed_steps(lambda: sh_.step(native=nat_))
             sh_.check()      # outside the timed region: the overlapped schedule never timed out
             ranks_seen["headline"] = comm_ranks(sh_, nat_)
@@ -1098,7 +1098,7 @@ def main():
         if sh.split is not None and sh.split.walk_info()["valid"]:
             kernel_used = "hrb_walk_kernel (interior set) + " + kernel_used + " (boundary set)"
         elif sh.split is None:
-            kernel_used = bp.cheby_kernel_name(sh.op)
+            kernel_used = bp.cheby_kernel_name(sh.op, whole_step=False)
         build_ms = sh.op.build_info()
     else:
         strong = None

@@ -217,8 +217,10 @@ int qp_operator_walk_info(const qp_operator* op, int64_t out[8]);
  * matrix values under the context's knobs (lattice operators beyond the Infinity Cache whose strip columns are long enough; knob
  * walk_pair).  out[0] = 1 if it does, out[1], out[2] = the row blocks [W0, R1) that take both terms in one launch, out[3] = row
  * blocks outside them (two per-block launches per pair of terms), out[4] = rows of a 64-row column chunk that form the second
- * term (64 - 2 x the largest near distance: the chunks overlap), out[5] = chunks per strip step.  Same results bit for bit either way. */
-int qp_operator_walk2_info(const qp_operator* op, int64_t out[6]);
+ * term (64 - 2 x the largest near distance: the chunks overlap), out[5] = chunks per strip step, out[6] = steps of the second term per
+ * wavefront (each wavefront runs in 2 K steps before its first), out[7] = wavefronts per strip column.  Same results bit for bit
+ * either way. */
+int qp_operator_walk2_info(const qp_operator* op, int64_t out[8]);
 /* *glong = the long distance L (rows) of a walk plan with one further pair of distances +-L beyond its far reach
  * (a three-dimensional grid's plane distance; its operands are loaded directly), 0 if the plan has none / there is no plan */
 int qp_operator_walk_long(const qp_operator* op, int64_t* glong);

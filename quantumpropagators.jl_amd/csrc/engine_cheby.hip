@@ -136,7 +136,7 @@ static bool walk2_wanted(const qp_operator* op) {
   return Jz / std::max<int64_t>(1, waves / S2) >= 24;
 }
 
-int qp_operator_walk2_info(const qp_operator* op, int64_t out[6]) {
+int qp_operator_walk2_info(const qp_operator* op, int64_t out[8]) {
   QP_TRY
   if (!op || !out) return qp::fail(QP_E_BAD_ARG, "qp_operator_walk2_info: NULL argument");
   const bool on = walk2_wanted(op);
@@ -147,6 +147,15 @@ int qp_operator_walk2_info(const qp_operator* op, int64_t out[6]) {
   out[3] = on ? op->walk2.n_edge : 0;
   out[4] = W;
   out[5] = on ? (op->walk2.g + W - 1) / W : 0;
+  out[6] = out[7] = 0;
+  if (on) {      // the cut of the walk (kernels_walk2.hip: launch_hrb_walk2_cheby): z steps per wavefront, segments per strip column
+    const qp::Tuning& tun = op->ctx->tun;
+    const int64_t Jz = ((op->walk2.R1 - op->walk2.W0) * (int64_t)kRB + op->walk2.g - 1) / op->walk2.g;
+    const int64_t waves = tun.walk2_waves > 0 ? tun.walk2_waves : 4 * (int64_t)tun.n_cu;
+    const int64_t L = (Jz + std::max<int64_t>(1, waves / out[5]) - 1) / std::max<int64_t>(1, waves / out[5]);
+    out[6] = L;
+    out[7] = (Jz + L - 1) / L;
+  }
   return QP_OK;
   QP_CATCH
 }

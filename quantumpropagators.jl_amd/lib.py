@@ -573,9 +573,10 @@ class Operator:
 
     def walk2_info(self):
         """Does a whole-operator ``cheby!`` take the two-term strip walk (include/qprop.h: qp_operator_walk2_info)?"""
-        out = np.zeros(6, dtype=np.int64)
+        out = np.zeros(8, dtype=np.int64)
         check(self.lib.qp_operator_walk2_info(self._h, _ptr(out, _i64p)))
-        return dict(zip(("valid", "first_block", "end_block", "edge_blocks", "useful_rows_per_chunk", "chunks_per_strip_step"), (int(v) for v in out)))
+        return dict(zip(("valid", "first_block", "end_block", "edge_blocks", "useful_rows_per_chunk", "chunks_per_strip_step",
+                         "steps_per_wavefront", "segments"), (int(v) for v in out)))
 
     def walk_info(self):
         """Strip-walk plan of a Hermitian-packed lattice operator (see include/qprop.h)."""

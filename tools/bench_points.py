@@ -120,7 +120,7 @@ def spread(values, regions=None):
     return out
 
 
-def cheby_layout_bytes(op, rows, ncols, nnz, coeffs, real_copy=False):
+def cheby_layout_bytes(op, rows, ncols, nnz, coeffs, real_copy=False, whole_step=True):
     """HBM bytes ONE cheby! step must move with the operator laid out as it is on the device, split by
     stream, and the same per fused term (averages over the step's terms).
 
@@ -168,15 +168,14 @@ def cheby_layout_bytes(op, rows, ncols, nnz, coeffs, real_copy=False):
     # the two-term strip walk (csrc/kernels_walk2.hip): terms 2 .. in PAIRS, each pair one pass over the values.  What a pair loads is
     # more than the rows it forms: a chunk's 64 lanes form z on W = 64 - 2 d_max of them (ceil(g / W) chunks per strip step), and a
     # segment of L steps runs in 2 K steps before its first z; the blocks outside the two-term region take two per-block passes.
-    w2 = op.walk2_info() if (fmt == L.FMT_HRB and walk["valid"]) else {"valid": 0}
+    # (whole_step = False: the terms are launched one by one -- the row-partitioned step exchanges after every term -- never in pairs)
+    w2 = op.walk2_info() if (whole_step and fmt == L.FMT_HRB and walk["valid"]) else {"valid": 0}
     pair = None
     if w2["valid"]:
         g, K = walk["rows_per_step"], walk["far"]
         W, S2 = w2["useful_rows_per_chunk"], w2["chunks_per_strip_step"]
         Jz = -(-(w2["end_block"] - w2["first_block"]) * 64 // g)
-        waves = op.ctx.tuning_get("walk2_waves") or 4 * op.ctx.tuning_get("n_cu")
-        Lz = -(-Jz // max(1, waves // S2))
-        nseg = -(-Jz // Lz)
+        Lz, nseg = w2["steps_per_wavefront"], w2["segments"]
         rows_loaded = 64.0 * S2 * (Jz + 2 * K * nseg)          # lanes x Y steps of the walk
         rows_region = 64.0 * (w2["end_block"] - w2["first_block"])
         slots = walk.get("upper_slots") or (walk["diag"] + walk["near"] + walk["far"])
@@ -222,10 +221,11 @@ def cheby_layout_bytes(op, rows, ncols, nnz, coeffs, real_copy=False):
             "layout": lay}
 
 
-def cheby_kernel_name(op):
-    """The kernel a whole-operator fused Chebyshev term of `op` launches (substring of its symbol)."""
+def cheby_kernel_name(op, whole_step=True):
+    """The kernel a whole-operator fused Chebyshev term of `op` launches (substring of its symbol); whole_step: inside cheby!
+    (terms in pairs where the two-term walk is taken), else a term launched on its own."""
     if op.format == L.FMT_HRB and op.walk_info()["valid"]:
-        return "hrb_walk2_kernel" if op.walk2_info()["valid"] else "hrb_walk_kernel"
+        return "hrb_walk2_kernel" if (whole_step and op.walk2_info()["valid"]) else "hrb_walk_kernel"
     if op.colblock_info()["valid"] and op.ctx.tuning_get("colblock") != 0:
         return "colblock_spmv_kernel"
     if op.format == L.FMT_RBCSR and op.value_encoding_info()["valid"]:

@@ -1116,6 +1116,9 @@ def main():
             inner = ["--steps", "3", "--warmup", "1", "--cpu-steps", "0", "--no-pmc", "--no-extras", "--log2n", str(log2n),
                      "--pattern", args.pattern, "--format", args.format, "--dt", str(args.dt)] + (["--real"] if args.real else [])
             traffic, traffic_detail = pmc_traffic(inner, kernel_used, timeout_s=240)
+            if traffic is not None and kernel_used == "hrb_walk2_kernel":
+                traffic /= 2.0      # a launch of the two-term walk forms TWO terms: per term, like bytes_per_launch and avg_launch_us
+                traffic_detail["note"] = "hrb_walk2_kernel: one launch = two terms; `traffic` is per TERM (half the per-launch mean)"
             if traffic is not None:
                 traffic_src = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE --kernel-trace on child runs of "
                                "this command (3 steps each); mean per launch of the kernel, FETCH_SIZE x 2 (gfx950), KiB -> bytes")

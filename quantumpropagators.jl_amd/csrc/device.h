@@ -253,7 +253,7 @@ inline bool walk_shape_supported(int nn, int K, int z0, int xl = 0, int fd = 0) 
 }
 // the two-term strip walk (kernels_walk2.hip): both terms of a pair (m, m + 1) on the two-term region of plan `P2`, term m of its edge list
 inline bool walk2_shape_supported(int nn, int K, int z0) {
-  return (z0 == 0 || z0 == 1) && ((nn == 4 && K == 4) || (nn == 2 && K == 2) || (nn == 1 && K == 1));
+  return (z0 == 0 || z0 == 1) && nn >= 1 && nn <= 4 && K >= 1 && K <= 4;
 }
 int launch_hrb_walk2_cheby(hipStream_t s, const DevMatrix& A, const WalkPlan& P2, const double2* x, const ChebyEpi& e1,
                            const ChebyEpi& e2, const Tuning& tun, bool* launched);
@@ -291,7 +291,9 @@ inline int dense_gemv_grid(int64_t nrows) {
 // walk leaves to the boundary launch and the collective's kernel
 constexpr int kDenseMinDensityPct = 75;
 constexpr int kCbWavesPerCu = 16;
+constexpr int kCbMinLog2N = 20;     // column-blocked mirror: smallest number of columns (log2) it is built for (measured: 2^18 columns 0.9 x, 2^19 1.04 x, 2^20 1.37 x, 2^21 1.62 x, 2^22 1.52 x)
 constexpr int kWalkReserveCu = 8;
+constexpr int kWalkEdgeSteps = 4;   // strip walk: a wavefront that also takes an edge block walks this many steps less (a block on the per-block path is three dependent rounds of loads; a step of the walk takes about one)
 
 struct Tuning {
   int rbcsr_variant = 15;     // bit 0 nt matrix loads, bit 1 early row-local loads, bit 2 deeper unroll, bit 3 (Hermitian-packed kernel) all loads of an all-stencil block up front (A/B in profiles/)
@@ -312,36 +314,26 @@ struct Tuning {
   int acc_defer = 1;          // qp_cheby_step: touch the Psi accumulator every third term only (1) or every term (0)
   int cheby_graph = 0;        // qp_cheby_step: replay a repeated step as a hipGraph when the mat-vec grid has at most this many workgroups (0: off; measured: no gain)
   int roctx = 0;              // 1 = named profiler ranges around the steps' phases (qprop_internal.h: ScopedRange); also QP_ROCTX=1
-  int arnoldi_l2_order = 1;   // 1 = the projection kernel owns the mat-vec's rows per XCD and reads rounds / basis vectors back to front (L2 reuse of what the dots pass read last)
-  int arnoldi_nt = 1;         // 1 = the fused Arnoldi mat-vec streams the matrix nontemporal (the L2 keeps basis vectors instead)
   int dense_auto = 1;         // 1 = AUTO lays an operator out dense (QP_FMT_DENSE) when at least 75 % (kDenseMinDensityPct) of its positions are stored
   int dense_panel_mfma = 1;   // 1 = the batched step of a dense operator runs H X on the fp64 matrix cores (kernels_dense.hip); 0 = the sparse panel kernels (A/B)
   int colblock = 1;           // 1 = an operator with irregular columns whose vector outgrows the L2 gets a column-blocked mirror (kernels_colblock.hip); 2 = any row-block / CSR operator that fits the mirror's limits (tests); 0 = off
   int cb_log2w = 0;           // ... columns per block (log2); 0 = about sixteen blocks, 2^16 ... 2^18 columns each (1 - 4 MB of the vector; an XCD's L2 holds 4 MB)
-  int cb_min_log2n = 20;      // ... smallest number of columns (log2) the mirror is built for (measured: 2^18 columns 0.9 x, 2^19 1.04 x, 2^20 1.37 x, 2^21 1.62 x, 2^22 1.52 x)
   int small_nnz = 8192;       // qp_propagate: register-resident Cheby systems up to this nnz run as ONE persistent launch (0: off)
   int newton_pipeline = 1;    // newton!: Hessenberg eigenvalues overlap the Arnoldi sweep
-  int spmm_tile = 16;         // states per pass of the tiled batched SpMM kernel (16, 32 or 64)
   int spmm_rows = 1;          // batched SpMM: wave-per-row kernel (lane = state) for panels of more than 32 states (0: always the state-tiled kernel)
-  int hrb_wg = 8;             // Hermitian-packed fused term of a whole operator: row blocks per workgroup (8 or 4)
-  int spmm_wg = 8;            // batched SpMM, scalar-entry kernel: wavefronts (consecutive walk positions) per workgroup: 4, 8 or 16
   int spmm_rw = 0;            // batched SpMM, wave-per-row kernel: 0 = matrix entries through the scalar unit (one row per wavefront), 1 / 2 / 4 / 8 = entries one per lane + readlane broadcast, that many rows per wavefront
   int spmm_strip = 0;         // batched SpMM row walk: inner-index strip width (0 = chosen from the L2 size; -1 = natural row order)
   int hrb_walk = 1;           // Hermitian-packed fused term of a whole lattice operator: the strip-walk kernel (kernels_walk.hip) when the operator has a walk plan
-  int walk_waves = 0;         // strip walk: wavefronts the walk is cut into (0: 768 for an operator that fits the Infinity Cache, else 8 per CU on every CU the edge workgroups leave free -- 1856 for the headline lattice --, or 2048 with the edge blocks inside the walk)
-  int walk_wg = 0;            // strip walk: wavefronts per workgroup (0: 4 for an operator that fits the Infinity Cache, else 8; or 8 / 4 / 2)
-  int walk_pair = -1;         // strip walk, two Chebyshev terms per pass over the values (kernels_walk2.hip): -1 = for operators beyond the Infinity Cache whose strip columns are long enough (>= 24 steps per wavefront), 0 never, 1 wherever a plan exists
-  int walk2_waves = 0;        // ... wavefronts it is cut into (0: one per SIMD = 4 per compute unit)
+  int walk_waves = 0;         // strip walk: wavefronts the walk is cut into (0: 768 for an operator that fits the Infinity Cache, else 8 per CU on every CU the edge workgroups leave free -- 1856 for the headline lattice --, or 2048 with the edge blocks inside the walk; the two-term walk: one per SIMD = 4 per compute unit)
+  int walk_pair = -1;         // strip walk, two Chebyshev terms per pass over the values (kernels_walk2.hip): -1 = for operators beyond the Infinity Cache whose strip columns are long enough (>= 24 steps per wavefront), 0 never, 1 wherever a plan exists (its cut: walk_waves)
   int value_dict = 1;         // value-dictionary mirror of row-block operators with few distinct values per block (0: never built / used)
   int walk_nt = -1;           // strip walk: nontemporal accesses (-1: the matrix values when the operator does not fit the Infinity Cache; bit 0 matrix values; bits 1, 2: vector loads, stores -- measurement variants of the headline shape)
-  int walk_edge_steps = 4;    // strip walk: a wavefront that also takes an edge block walks this many steps less (a block on the per-block path is three dependent rounds of loads; a step of the walk takes about one)
   int walk_dbg = 0;           // strip walk, measurements only: 1 = in-wave edge block after the walk instead of before it, 2 = edge blocks skipped (WRONG results), 4 = never as workgroups of their own
-  int n_cu = 256;             // compute units of the context's device (set by qp_ctx_create)
   int walk_min_blocks = 3072; // strip walk: smallest number of walkable row blocks for which the plan is used
-  int spmm_walk = 0;          // batched term on a lattice operator, panels of more than 32 states: 1 = the strip walk (kernels_spmm_walk.hip; measured slower than the wave-per-row kernel, profiles/r03/batched_c5_walk.txt: off)
-  int spmm_walk_waves = 0;    // ... wavefronts it is cut into (0: 3072 = 3 per SIMD)
   int spmm_nt = 1;            // nontemporal matrix / row-local streams in the batched SpMM kernel: 0 never, 2 always, 1 for large panels
 };
+// compute units of the CURRENT device (hipGetDevice; asked once per device and cached; 256 if the runtime will not say)
+int device_cu_count();
 // address of the knob called `key` inside `t`, or nullptr
 int* tuning_field(Tuning& t, const char* key);
 
@@ -359,23 +351,6 @@ int launch_combine_planes(hipStream_t s, double2* vals, const double2* const* pl
 int launch_sparse_planes_update(hipStream_t s, double2* vals, const double2* base, const int32_t* support, int64_t n_support,
                                 const double2* support_vals, int nplanes, const double2* coefs, double* vals_r, Stats* st);
 
-// ---- strip walk of the batched term (kernels_spmm_walk.hip) over a lattice operator in CSR order ---------------------
-// every row has z = 2 (nn + K) + diag entries; the rows a g + c, a in [a_lo, a_hi), have their columns at
-// [-K g .. -g] [-d_nn .. -d_1] [0] [d_1 .. d_nn] [g .. K g] (storage order); the other rows are listed in `edge`
-struct SpmmWalkPlan {
-  int valid = 0;
-  int nn = 0, K = 0, diag = 0;
-  int near[kWalkMaxNear] = {0};
-  int64_t g = 0;
-  int a_lo = 0, a_hi = 0;
-  int32_t* edge = nullptr;    // device: the rows outside the walk (wave-per-row kernel, `order` list)
-  int64_t n_edge = 0;
-};
-inline bool spmm_walk_shape_supported(int nn, int K, int diag) {   // the instances of kernels_spmm_walk.hip: launch_shape
-  return ((nn == 4 && K == 4) || (nn == 2 && K == 2)) && (diag == 0 || diag == 1);
-}
-int launch_spmm_walk_cheby(hipStream_t s, const double2* vals, const double2* X, const SpmmWalkPlan& P, int b,
-                           const ChebyEpi& e, const Tuning& tun, bool nt, bool* launched);
 
 // batched states: CSR SpMM with the fused Chebyshev epilogue, panel X[i*b + s]
 int launch_spmm_cheby(hipStream_t s, const int64_t* rowptr, const int32_t* cols, const double2* vals,

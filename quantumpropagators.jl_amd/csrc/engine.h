@@ -69,8 +69,6 @@ struct qp_operator {
   qp::WalkPlan walk;              // strip-walk plan of a Hermitian-packed lattice operator (A.walk points here when valid)
   qp::WalkPlan walk2;             // the same run for the two-term walk (kernels_walk2.hip): [W0, R1) shrunk by K strip steps at either end,
                                   // edge list = every block outside that region; valid = 0 when the operator has none
-  qp::SpmmWalkPlan spmm_walk;     // strip-walk plan of the batched term, built on first use
-  bool spmm_walk_built = false;
   qp::ColBlockPlan cb;            // column-blocked mirror of an operator with irregular columns (A.cb points here when valid)
   qp::CodedVals cv;               // value-dictionary mirror (A.cv points here when valid): codes, per-block tables
   std::vector<double2*> cv_tplanes;   // device: per term the tuple component of every table entry [cv.ntab] (static)
@@ -280,8 +278,6 @@ inline int dot_sync(qp_ctx* ctx, const double2* x, const double2* y, int64_t n, 
 int operator_csr_mirror(qp_operator* op, bool gather = true);
 // row order in which the batched (SpMM) kernel visits the rows for a panel of `batch` states
 int operator_spmm_order(qp_operator* op, int batch, const int32_t** order_out);
-// strip-walk plan of the batched term (lattice operators); *out = NULL when the operator has none
-int operator_spmm_walk_plan(qp_operator* op, const qp::SpmmWalkPlan** out);
 // which terms of a cheby! touch the Psi accumulator (include/qprop.h, qp_acc_defer)
 void acc_schedule(const double* a, int n_coeffs, bool defer, qp_acc_defer* out);
 void set_defer(qp::ChebyEpi& e, const qp_acc_defer* d);

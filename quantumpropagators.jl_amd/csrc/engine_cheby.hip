@@ -132,7 +132,7 @@ static bool walk2_wanted(const qp_operator* op) {
   if (footprint <= 230e6) return false;
   const int W = kRB - 2 * Q.near[Q.nn - 1];
   const int64_t S2 = (Q.g + W - 1) / W, Jz = ((Q.R1 - Q.W0) * (int64_t)kRB + Q.g - 1) / Q.g;
-  const int64_t waves = tun.walk2_waves > 0 ? tun.walk2_waves : 4 * (int64_t)tun.n_cu;
+  const int64_t waves = tun.walk_waves > 0 ? tun.walk_waves : 4 * (int64_t)qp::device_cu_count();
   return Jz / std::max<int64_t>(1, waves / S2) >= 24;
 }
 
@@ -151,7 +151,7 @@ int qp_operator_walk2_info(const qp_operator* op, int64_t out[8]) {
   if (on) {      // the cut of the walk (kernels_walk2.hip: launch_hrb_walk2_cheby): z steps per wavefront, segments per strip column
     const qp::Tuning& tun = op->ctx->tun;
     const int64_t Jz = ((op->walk2.R1 - op->walk2.W0) * (int64_t)kRB + op->walk2.g - 1) / op->walk2.g;
-    const int64_t waves = tun.walk2_waves > 0 ? tun.walk2_waves : 4 * (int64_t)tun.n_cu;
+    const int64_t waves = tun.walk_waves > 0 ? tun.walk_waves : 4 * (int64_t)qp::device_cu_count();
     const int64_t L = (Jz + std::max<int64_t>(1, waves / out[5]) - 1) / std::max<int64_t>(1, waves / out[5]);
     out[6] = L;
     out[7] = (Jz + L - 1) / L;
@@ -337,8 +337,8 @@ int qp_cheby_step(qp_cheby* w, qp_operator* op, qp_state* psi, const double* a, 
     key.psi = psi->d;
     key.format = A.format;
     // every knob that selects a kernel or a launch shape of the step's terms
-    key.variant = ((((ctx->tun.rbcsr_variant * 2) * 16 + ctx->tun.hrb_wg) * 2 + (ctx->tun.hrb_walk ? 1 : 0)) * 8 +
-                   (ctx->tun.walk_nt & 7)) * 4096 + ((ctx->tun.walk_waves + 16 * ctx->tun.walk_wg) & 4095);
+    key.variant = ((((ctx->tun.rbcsr_variant * 2) * 16 + 8) * 2 + (ctx->tun.hrb_walk ? 1 : 0)) * 8 +
+                   (ctx->tun.walk_nt & 7)) * 4096 + (ctx->tun.walk_waves & 4095);
     key.variant = key.variant * 2 + (ctx->tun.value_dict ? 1 : 0);      // (coded / plain row-block kernel)
     key.variant = key.variant * 2 + (walk2_wanted(op) ? 1 : 0);         // (terms in pairs)
     key.n_coeffs = n_coeffs;
@@ -439,10 +439,6 @@ int qp_cheby_step_batched(qp_cheby* w, qp_operator* op, qp_state* psi, int batch
   const bool rows_kernel = !dense && qp::spmm_uses_rows_kernel(ctx->tun, batch);
   const int32_t* order = nullptr;   // row walk of the wave-per-row kernel
   if (rows_kernel) QP_CHECK(operator_spmm_order(op, batch, &order));
-  // lattice operators: the strip walk (far rows of X in a register ring) for the rows whose far neighbours exist, the
-  // wave-per-row kernel for the rest (its `order` list = those rows)
-  const qp::SpmmWalkPlan* walk = nullptr;
-  if (rows_kernel && ctx->tun.spmm_walk) QP_CHECK(operator_spmm_walk_plan(op, &walk));
 
   const double beta = (Delta / 2) + E_min;
   cplx c = (dt > 0) ? cplx(0, -2.0) / Delta : cplx(0, 2.0) / Delta;
@@ -495,18 +491,6 @@ int qp_cheby_step_batched(qp_cheby* w, qp_operator* op, qp_state* psi, int batch
     if (dense) {
       QP_CHECK(qp::launch_dense_zgemm_cheby(ctx->stream, op->A, x, batch, e, &ctx->stats));
       walked = true;
-    }
-    if (walk) {
-      const bool nt = ctx->tun.spmm_nt == 2 || (ctx->tun.spmm_nt == 1 && (double)n * batch * sizeof(double2) >= 128.0 * 1024 * 1024);
-      QP_CHECK(qp::launch_spmm_walk_cheby(ctx->stream, op->m_vals, x, *walk, batch, e, ctx->tun, nt, &walked));
-      if (walked) {
-        ctx->stats.n_launch++;
-        if (walk->n_edge > 0)   // the rows next to the periodic wrap: same kernel as before, only these rows
-          QP_CHECK(qp::launch_spmm_cheby(ctx->stream, op->m_rowptr, op->m_cols, op->m_vals, x, walk->n_edge, op->A.nnz, batch, e,
-                                         ctx->tun, true, walk->edge, &ctx->stats));
-        else
-          ctx->stats.n_matvec++;
-      }
     }
     if (!walked)
       QP_CHECK(qp::launch_spmm_cheby(ctx->stream, op->m_rowptr, op->m_cols, op->m_vals, x, n, op->A.nnz, batch, e,

@@ -25,22 +25,39 @@ int* tuning_field(Tuning& t, const char* key) {
   static const Entry table[] = {
       {"rbcsr_variant", &Tuning::rbcsr_variant},
       {"arnoldi_mode", &Tuning::arnoldi_mode},   {"arnoldi_onepass", &Tuning::arnoldi_onepass},   {"split_mode", &Tuning::split_mode},
-      {"spmm_wg", &Tuning::spmm_wg},   {"hrb_wg", &Tuning::hrb_wg},   {"arnoldi_fuse_dots", &Tuning::arnoldi_fuse_dots},   {"lattice_fill", &Tuning::lattice_fill},   {"sparse_controls", &Tuning::sparse_controls},
+            {"arnoldi_fuse_dots", &Tuning::arnoldi_fuse_dots},   {"lattice_fill", &Tuning::lattice_fill},   {"sparse_controls", &Tuning::sparse_controls},
       {"liouville_fused_n", &Tuning::liouville_fused_n}, {"liouville_tile32_n", &Tuning::liouville_tile32_n}, {"liouville_tile32_min_n", &Tuning::liouville_tile32_min_n}, {"real_vals", &Tuning::real_vals},
       {"stencil", &Tuning::stencil}, {"block_map", &Tuning::block_map},             {"acc_defer", &Tuning::acc_defer},
       {"cheby_graph", &Tuning::cheby_graph},     {"small_nnz", &Tuning::small_nnz},
-      {"roctx", &Tuning::roctx}, {"arnoldi_l2_order", &Tuning::arnoldi_l2_order}, {"arnoldi_nt", &Tuning::arnoldi_nt},
-      {"colblock", &Tuning::colblock}, {"cb_log2w", &Tuning::cb_log2w}, {"cb_min_log2n", &Tuning::cb_min_log2n},
+      {"roctx", &Tuning::roctx}, 
+      {"colblock", &Tuning::colblock}, {"cb_log2w", &Tuning::cb_log2w},
       {"dense_auto", &Tuning::dense_auto},       {"dense_panel_mfma", &Tuning::dense_panel_mfma},
-      {"newton_pipeline", &Tuning::newton_pipeline}, {"spmm_tile", &Tuning::spmm_tile},
+      {"newton_pipeline", &Tuning::newton_pipeline}, 
       {"spmm_nt", &Tuning::spmm_nt},             {"spmm_rows", &Tuning::spmm_rows},
       {"spmm_strip", &Tuning::spmm_strip},       {"spmm_rw", &Tuning::spmm_rw},
       {"hrb_walk", &Tuning::hrb_walk},           {"walk_waves", &Tuning::walk_waves},
-      {"walk_min_blocks", &Tuning::walk_min_blocks}, {"walk_dbg", &Tuning::walk_dbg}, {"walk_nt", &Tuning::walk_nt}, {"value_dict", &Tuning::value_dict}, {"walk_pair", &Tuning::walk_pair}, {"walk2_waves", &Tuning::walk2_waves}, {"walk_wg", &Tuning::walk_wg}, {"walk_edge_steps", &Tuning::walk_edge_steps}, {"split_spin_log2", &Tuning::split_spin_log2}, {"split_dbg", &Tuning::split_dbg}, {"spmm_walk", &Tuning::spmm_walk}, {"spmm_walk_waves", &Tuning::spmm_walk_waves},
+      {"walk_min_blocks", &Tuning::walk_min_blocks}, {"walk_dbg", &Tuning::walk_dbg}, {"walk_nt", &Tuning::walk_nt}, {"value_dict", &Tuning::value_dict}, {"walk_pair", &Tuning::walk_pair}, {"split_spin_log2", &Tuning::split_spin_log2}, {"split_dbg", &Tuning::split_dbg},
   };
   for (const Entry& e : table)
     if (std::strcmp(e.name, key) == 0) return &(t.*(e.field));
   return nullptr;
+}
+
+int device_cu_count() {
+  static std::atomic<int> cached[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+    (void)hipGetLastError();
+    return 256;
+  }
+  int n = cached[dev].load(std::memory_order_relaxed);
+  if (n > 0) return n;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    n = 256;
+  }
+  cached[dev].store(n, std::memory_order_relaxed);
+  return n;
 }
 
 static thread_local std::string g_last_error;
@@ -178,11 +195,6 @@ int qp_ctx_create(int device, void* stream, qp_ctx** out) {
   {
     std::lock_guard<std::mutex> lock(g_tuning_mutex);
     ctx->tun = g_tuning_defaults;
-  }
-  {
-    int ncu = 0;
-    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) ctx->tun.n_cu = ncu;
-    else (void)hipGetLastError();
   }
   if (stream == QP_STREAM_NULL) {
     ctx->stream = nullptr;   // HIP's null stream
@@ -398,9 +410,6 @@ static int operator_free_device(qp_operator* op) {
   if (op->A.lptr) (void)hipFree(op->A.lptr);
   if (op->A.lcols) (void)hipFree(op->A.lcols);
   if (op->A.lpos) (void)hipFree(op->A.lpos);
-  if (op->spmm_walk.edge) (void)hipFree(op->spmm_walk.edge);
-  op->spmm_walk = qp::SpmmWalkPlan();
-  op->spmm_walk_built = false;
   if (op->walk.edge_map) (void)hipFree(op->walk.edge_map);
   op->walk = qp::WalkPlan();
   if (op->walk2.edge_map) (void)hipFree(op->walk2.edge_map);
@@ -459,35 +468,78 @@ static int operator_free(qp_operator* op) {
 // pattern, real diagonal, strictly increasing columns)?
 // Columns >= n (ghost columns of a row-partitioned operator in local numbering) are
 // outside the square part and always carry their values.
+// A term's values in union order: the term's own array (one canonical term: the union pattern IS the term's -- no 4 GB copy at
+// N = 2^24) or an array of its own.
+struct PlaneView {
+  std::vector<cplx> own;
+  const cplx* p = nullptr;
+  size_t n = 0;
+  PlaneView() = default;
+  PlaneView(PlaneView&&) = default;
+  PlaneView& operator=(PlaneView&&) = default;
+  PlaneView(const PlaneView&) = delete;
+  PlaneView& operator=(const PlaneView&) = delete;
+  const cplx& operator[](size_t i) const { return p[i]; }
+  size_t size() const { return n; }
+  const cplx* begin() const { return p; }
+  const cplx* end() const { return p + n; }
+  void borrow(const std::vector<cplx>& v) {
+    std::vector<cplx>().swap(own);
+    p = v.data();
+    n = v.size();
+  }
+  std::vector<cplx>& make_own(size_t count) {
+    own.assign(count, cplx(0));
+    p = own.data();
+    n = count;
+    return own;
+  }
+  void clear() {
+    std::vector<cplx>().swap(own);
+    p = nullptr;
+    n = 0;
+  }
+};
+using Planes = std::vector<PlaneView>;
+
 static bool csr_is_hermitian(int64_t n, const std::vector<int64_t>& rp, const std::vector<int32_t>& col,
-                             const std::vector<cplx>& vals) {
-  // Rows in ascending order, their lower entries (r, c), c < r, in ascending c: row c is asked for its upper entries
-  // (c, r) in ascending r, i.e. in storage order -- one cursor per row instead of a search per entry.  An upper entry
-  // without a partner stops its row's cursor and fails the next match (or the final count).
-  int64_t nlower = 0, nupper = 0;
-  std::vector<int64_t> cur((size_t)std::max<int64_t>(n, 1), 0);
-  for (int64_t r = 0; r < n; ++r) {
-    int64_t first_upper = rp[r + 1];
-    for (int64_t p = rp[r]; p < rp[r + 1]; ++p) {
-      const int64_t c = col[p];
-      if (p > rp[r] && col[p - 1] >= c) return false;
-      if (c == r) {
-        if (vals[p].imag() != 0.0) return false;
-      } else if (c > r) {
-        if (first_upper == rp[r + 1]) first_upper = p;
-        if (c < n) ++nupper;
-      } else {
-        ++nlower;
-        const int64_t q = cur[(size_t)c];
-        if (q >= rp[c + 1] || col[q] != r) return false;
-        const cplx t = vals[q];
-        if (!(t.real() == vals[p].real() && t.imag() == -vals[p].imag())) return false;
-        cur[(size_t)c] = q + 1;
+                             const PlaneView& vals) {
+  // Every row on its own (rows in chunks on a few host threads): columns strictly ascending, a real diagonal, and for every
+  // lower entry (r, c), c < r, the upper entry (c, r) with the conjugate value -- found by bisection in row c (rows are short);
+  // as many lower entries as upper ones inside the square part then says that no upper entry lacks its partner.
+  std::atomic<bool> ok{true};
+  std::atomic<int64_t> nlower{0}, nupper{0};
+  parallel_rows(n, [&](int64_t r_begin, int64_t r_end) {
+    int64_t lo = 0, up = 0;
+    for (int64_t r = r_begin; r < r_end && ok.load(std::memory_order_relaxed); ++r) {
+      for (int64_t p = rp[r]; p < rp[r + 1]; ++p) {
+        const int64_t c = col[p];
+        bool good = !(p > rp[r] && col[p - 1] >= c);
+        if (good && c == r) {
+          good = vals[p].imag() == 0.0;
+        } else if (good && c > r) {
+          if (c < n) ++up;
+        } else if (good) {
+          ++lo;
+          const int32_t* b = col.data() + rp[c];
+          const int32_t* e = col.data() + rp[c + 1];
+          const int32_t* q = std::lower_bound(b, e, (int32_t)r);
+          good = q != e && *q == (int32_t)r;
+          if (good) {
+            const cplx t = vals[(size_t)(q - col.data())];
+            good = t.real() == vals[p].real() && t.imag() == -vals[p].imag();
+          }
+        }
+        if (!good) {
+          ok.store(false, std::memory_order_relaxed);
+          return;
+        }
       }
     }
-    cur[(size_t)r] = first_upper;
-  }
-  return nlower == nupper;
+    nlower.fetch_add(lo, std::memory_order_relaxed);
+    nupper.fetch_add(up, std::memory_order_relaxed);
+  });
+  return ok.load() && nlower.load() == nupper.load();
 }
 
 // Encode the quad-packed column sections of all blocks: per block either int32 columns or,
@@ -508,15 +560,14 @@ constexpr size_t kBlockMapQuad = 16 + 4 * (size_t)kRB;   // bytes per quad of a 
 
 // `special(b, w, out)`: a chance to emit a block in the stencil encoding (returns true and
 // appends its bytes) before the per-entry encodings are tried.
+// (blocks [b0, b1) into `bytes`, which starts empty: the offsets in meta[b] are relative to it)
 template <class GetCol, class Special>
-static void encode_col_sections(int64_t nrows, int64_t ncols, int64_t nblocks, const std::vector<int64_t>& ptr, GetCol get,
-                                Special special, std::vector<char>& bytes, std::vector<int64_t>& meta, bool allow_block_map = true) {
+static void encode_col_sections_range(int64_t nrows, int64_t ncols, int64_t b0, int64_t b1, const std::vector<int64_t>& ptr, GetCol& get,
+                                      Special& special, std::vector<char>& bytes, std::vector<int64_t>& meta, bool allow_block_map) {
   // (pad entries multiply a zero value with x[column]: the column must exist.  A TALL operator -- fewer columns than rows --
   // has rows beyond its last column: a pad takes min(row, ncols - 1), never the row itself.)
   const int64_t last_col = std::max<int64_t>(ncols - 1, 0);
-  meta.assign((size_t)nblocks, 0);
-  bytes.clear();
-  for (int64_t b = 0; b < nblocks; ++b) {
+  for (int64_t b = b0; b < b1; ++b) {
     const int64_t w = (ptr[b + 1] - ptr[b]) / kRB;
     while (bytes.size() % 32) bytes.push_back(0);
     const size_t start = bytes.size();
@@ -604,6 +655,36 @@ static void encode_col_sections(int64_t nrows, int64_t ncols, int64_t nblocks, c
   while (bytes.size() % 32) bytes.push_back(0);
 }
 
+// All blocks, in chunks on a few host threads (every block's bytes depend on that block alone; a block starts on a 32-byte boundary,
+// so the chunks concatenate -- each padded to that boundary -- into exactly the bytes a single pass writes).
+template <class GetCol, class Special>
+static void encode_col_sections(int64_t nrows, int64_t ncols, int64_t nblocks, const std::vector<int64_t>& ptr, GetCol get,
+                                Special special, std::vector<char>& bytes, std::vector<int64_t>& meta, bool allow_block_map = true) {
+  meta.assign((size_t)nblocks, 0);
+  bytes.clear();
+  const unsigned T = (nblocks >= 4096) ? host_threads() : 1u;
+  if (T <= 1) {
+    encode_col_sections_range(nrows, ncols, 0, nblocks, ptr, get, special, bytes, meta, allow_block_map);
+    return;
+  }
+  std::vector<std::vector<char>> part((size_t)T);
+  const int64_t chunk = (nblocks + T - 1) / T;
+  parallel_rows((int64_t)T, [&](int64_t t0, int64_t t1) {
+    for (int64_t t = t0; t < t1; ++t) {
+      const int64_t c0 = std::min(nblocks, t * chunk), c1 = std::min(nblocks, (t + 1) * chunk);
+      encode_col_sections_range(nrows, ncols, c0, c1, ptr, get, special, part[(size_t)t], meta, allow_block_map);
+    }
+  }, 0);
+  for (unsigned t = 0; t < T; ++t) {
+    while (bytes.size() % 32) bytes.push_back(0);
+    const int64_t base = (int64_t)bytes.size();
+    const int64_t c0 = std::min<int64_t>(nblocks, (int64_t)t * chunk), c1 = std::min<int64_t>(nblocks, (int64_t)(t + 1) * chunk);
+    for (int64_t bb = c0; bb < c1; ++bb) meta[(size_t)bb] += base << 2;
+    bytes.insert(bytes.end(), part[(size_t)t].begin(), part[(size_t)t].end());
+    std::vector<char>().swap(part[(size_t)t]);
+  }
+}
+
 // Stencil blocks: every row of the 64-row block has its k-th entry at the same distance
 // delta_k from the diagonal (grids, lattices, tensor-product operators: most blocks of a
 // banded H).  The section then stores w int32 deltas for the whole block instead of w x 64
@@ -683,7 +764,7 @@ static int64_t decode_lower_stencil_pos(const std::vector<char>& bytes, const st
 
 // Build every device array of `op` for `format` from the union pattern (op->u_rowptr /
 // u_col) and the per-term values given in union-CSR order.
-static int operator_build_device_impl(qp_operator* op, int format, const std::vector<std::vector<cplx>>& planes_csr) {
+static int operator_build_device_impl(qp_operator* op, int format, const Planes& planes_csr) {
   qp_ctx* ctx = op->ctx;
   const auto& ur = op->u_rowptr;
   const auto& uc = op->u_col;
@@ -696,6 +777,7 @@ static int operator_build_device_impl(qp_operator* op, int format, const std::ve
   HostLayout& Lh = op->layout;
   Lh = HostLayout();
   Lh.format = format;
+  BuildTrace trace;
 
   if (qp::csr_layout(format)) {   // QP_FMT_DENSE: the same arrays with a complete pattern (vals[r ncols + c])
     A.stored = nnz;
@@ -713,29 +795,37 @@ static int operator_build_device_impl(qp_operator* op, int format, const std::ve
     if (hrb) {
       Lh.lptr.assign(A.nblocks + 1, 0);
       Lh.nlow.assign(nrows, 0);
-      for (int64_t r = 0; r < nrows; ++r) {
-        const int32_t* b = uc.data() + ur[r];
-        const int32_t* e = uc.data() + ur[r + 1];
-        Lh.nlow[r] = (int32_t)(std::lower_bound(b, e, (int32_t)r) - b);
-      }
+      parallel_rows(nrows, [&](int64_t r0, int64_t r1) {
+        for (int64_t r = r0; r < r1; ++r) {
+          const int32_t* b = uc.data() + ur[r];
+          const int32_t* e = uc.data() + ur[r + 1];
+          Lh.nlow[r] = (int32_t)(std::lower_bound(b, e, (int32_t)r) - b);
+        }
+      });
     }
-    for (int64_t b = 0; b < A.nblocks; ++b) {
-      int64_t wu = 0, wl = 0;
-      for (int64_t r = b * kRB; r < std::min(nrows, (b + 1) * kRB); ++r) {
-        const int64_t len = ur[r + 1] - ur[r];
-        const int64_t nl = hrb ? Lh.nlow[r] : 0;
-        wu = std::max(wu, len - nl);
-        wl = std::max(wl, nl);
+    // widths per block on a few threads (into the pointer arrays), then the running sums
+    parallel_rows(A.nblocks, [&](int64_t b0, int64_t b1) {
+      for (int64_t b = b0; b < b1; ++b) {
+        int64_t wu = 0, wl = 0;
+        for (int64_t r = b * kRB; r < std::min(nrows, (b + 1) * kRB); ++r) {
+          const int64_t len = ur[r + 1] - ur[r];
+          const int64_t nl = hrb ? Lh.nlow[r] : 0;
+          wu = std::max(wu, len - nl);
+          wl = std::max(wl, nl);
+        }
+        Lh.bptr[b + 1] = ((wu + 3) & ~(int64_t)3) * kRB;
+        if (hrb) Lh.lptr[b + 1] = ((wl + 3) & ~(int64_t)3) * kRB;
       }
-      wu = (wu + 3) & ~(int64_t)3;
-      wl = (wl + 3) & ~(int64_t)3;
-      Lh.bptr[b + 1] = Lh.bptr[b] + wu * kRB;
-      if (hrb) Lh.lptr[b + 1] = Lh.lptr[b] + wl * kRB;
+    }, 1024);
+    for (int64_t b = 0; b < A.nblocks; ++b) {
+      Lh.bptr[b + 1] += Lh.bptr[b];
+      if (hrb) Lh.lptr[b + 1] += Lh.lptr[b];
     }
     Lh.stored = Lh.bptr[A.nblocks] + kRB;   // + one block of slack: padded lower entries read vals[0..63]
     Lh.lstored = hrb ? Lh.lptr[A.nblocks] : 0;
     A.stored = Lh.stored;
     A.lstored = Lh.lstored;
+    trace.mark("  block widths and pointers");
     // upper (or full) column indices
     std::vector<char> cbytes;
     {
@@ -759,6 +849,7 @@ static int operator_build_device_impl(qp_operator* op, int format, const std::ve
     }
     QP_CHECK(dev_alloc(&A.bptr, Lh.bptr.size()));
     QP_HIP(hipMemcpy(A.bptr, Lh.bptr.data(), Lh.bptr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    trace.mark("  upper column sections + upload");
     if (hrb) {
       // lower section: (column, position of the conj-transposed value in the upper section)
       std::vector<int32_t> lpos((size_t)std::max<int64_t>(A.lstored, 1), -1);
@@ -833,26 +924,34 @@ static int operator_build_device_impl(qp_operator* op, int format, const std::ve
       QP_HIP(hipMemcpy(A.lcmeta, Lh.lcmeta.data(), Lh.lcmeta.size() * sizeof(int64_t), hipMemcpyHostToDevice));
       QP_CHECK(dev_alloc(&A.lpos, lpos.size()));
       QP_HIP(hipMemcpy(A.lpos, lpos.data(), lpos.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+      trace.mark("  lower sections (positions, stencils) + upload");
       QP_CHECK(build_walk_plan(op));
+      trace.mark("  strip-walk plan");
     }
   }
 
   // ---- value planes ----
-  op->planes_real = true;
-  for (const auto& pv : planes_csr)
-    for (const cplx& v : pv)
-      if (v.imag() != 0.0) {
-        op->planes_real = false;
-        break;
-      }
-  std::vector<cplx> hplane((size_t)std::max<int64_t>(A.stored, 1));
+  {
+    std::atomic<bool> all_real{true};
+    for (const auto& pv : planes_csr)
+      parallel_rows((int64_t)pv.size(), [&](int64_t i0, int64_t i1) {
+        for (int64_t i = i0; i < i1 && all_real.load(std::memory_order_relaxed); ++i)
+          if (pv[(size_t)i].imag() != 0.0) all_real.store(false, std::memory_order_relaxed);
+      }, (int64_t)1 << 20);
+    op->planes_real = all_real.load();
+  }
+  // (raw storage: a std::vector would zero its 2 GB serially at N = 2^24 before the threaded fill below does it again)
+  const size_t hplane_n = (size_t)std::max<int64_t>(A.stored, 1);
+  std::unique_ptr<cplx, void (*)(void*)> hplane_buf(static_cast<cplx*>(std::malloc(hplane_n * sizeof(cplx))), std::free);
+  if (!hplane_buf) return qp::fail(QP_E_ALLOC, "out of host memory building the operator (%zu bytes)", hplane_n * sizeof(cplx));
+  cplx* const hplane = hplane_buf.get();
   // positions a control term touches (kept while it may still belong to the sparse suffix, see qp_operator::sparse_from)
   const int drift_planes = nops - op->ncoeffs;
   std::vector<std::vector<std::pair<int32_t, cplx>>> touched((size_t)nops);
   std::vector<char> is_sparse((size_t)nops, 0);
   const bool sparse_candidates = nops >= 2 && op->ncoeffs >= 1 && A.stored < (int64_t)INT32_MAX;
   for (int l = 0; l < nops; ++l) {
-    std::fill(hplane.begin(), hplane.end(), cplx(0.0));
+    parallel_rows((int64_t)hplane_n, [&](int64_t a, int64_t b) { std::fill(hplane + a, hplane + b, cplx(0.0)); }, (int64_t)1 << 20);
     const auto& pv = planes_csr[l];
     parallel_rows(nrows, [&](int64_t r_begin, int64_t r_end) {
       for (int64_t r = r_begin; r < r_end; ++r) {
@@ -878,7 +977,7 @@ static int operator_build_device_impl(qp_operator* op, int format, const std::ve
     double2* dp = nullptr;
     QP_CHECK(dev_alloc(&dp, (size_t)A.stored));
     op->planes.push_back(dp);
-    QP_HIP(hipMemcpy(dp, hplane.data(), (size_t)A.stored * sizeof(double2), hipMemcpyHostToDevice));
+    QP_HIP(hipMemcpy(dp, hplane, (size_t)A.stored * sizeof(double2), hipMemcpyHostToDevice));
   }
   {
     int sfrom = nops;
@@ -908,6 +1007,7 @@ static int operator_build_device_impl(qp_operator* op, int format, const std::ve
   }
   QP_CHECK(dev_alloc(&op->planes_dev, (size_t)nops));
   QP_HIP(hipMemcpy(op->planes_dev, op->planes.data(), nops * sizeof(double2*), hipMemcpyHostToDevice));
+  trace.mark("  value planes in device order + upload");
   A.vals = op->planes[0];
   (void)ctx;
   return QP_OK;
@@ -917,7 +1017,7 @@ static int operator_build_device_impl(qp_operator* op, int format, const std::ve
 // (value in term 0, .., value in term L - 1) over its stored positions (pads: the all-zero tuple), sorted bytewise; one code byte
 // per stored position; tables with the same content shared.  Built when every block has at most 256 tuples and codes + tables
 // come to less than half of the value plane the mat-vec would stream instead.  Host index work (bit patterns, no arithmetic).
-static int build_coded_values(qp_operator* op, const std::vector<std::vector<cplx>>& planes_csr) {
+static int build_coded_values(qp_operator* op, const Planes& planes_csr) {
   qp_ctx* ctx = op->ctx;
   DevMatrix& A = op->A;
   op->cv_reason = 0;
@@ -1022,7 +1122,7 @@ static int build_coded_values(qp_operator* op, const std::vector<std::vector<cpl
 
 // ... timed: format conversion, encoding and upload are host work at qp_operator_create (and once more if a complex
 // coefficient forces a Hermitian-packed operator back to plain row blocks); qp_operator_build_info reports it
-static int operator_build_device(qp_operator* op, int format, const std::vector<std::vector<cplx>>& planes_csr) {
+static int operator_build_device(qp_operator* op, int format, const Planes& planes_csr) {
   const auto t0 = std::chrono::steady_clock::now();
   int rc = operator_build_device_impl(op, format, planes_csr);
   if (rc == QP_OK) rc = build_colblock(op);
@@ -1034,18 +1134,18 @@ static int operator_build_device(qp_operator* op, int format, const std::vector<
 }
 
 // current per-term values (device planes) back in union-CSR order
-static int operator_download_planes(qp_operator* op, std::vector<std::vector<cplx>>& planes_csr) {
+static int operator_download_planes(qp_operator* op, Planes& planes_csr) {
   const DevMatrix& A = op->A;
   const auto& ur = op->u_rowptr;
   const auto& uc = op->u_col;
   const int64_t nnz = ur[A.nrows];
   QP_HIP(hipStreamSynchronize(op->ctx->stream));
   std::vector<cplx> hv((size_t)std::max<int64_t>(A.stored, 1));
-  planes_csr.assign(op->planes.size(), std::vector<cplx>());
+  planes_csr.clear();
+  planes_csr.resize(op->planes.size());
   for (size_t l = 0; l < op->planes.size(); ++l) {
     QP_HIP(hipMemcpy(hv.data(), op->planes[l], (size_t)A.stored * sizeof(double2), hipMemcpyDeviceToHost));
-    auto& out = planes_csr[l];
-    out.assign((size_t)nnz, cplx(0));
+    auto& out = planes_csr[l].make_own((size_t)nnz);
     for (int64_t r = 0; r < A.nrows; ++r) {
       const int64_t nl = (A.format == QP_FMT_HRB) ? op->layout.nlow[r] : 0;
       for (int64_t k = 0; k < ur[r + 1] - ur[r]; ++k) {
@@ -1089,6 +1189,7 @@ int qp_operator_create(qp_ctx* ctx, qp_matrix* const* ops, int nops, int ncoeffs
   op->A.ncols = ncols;
 
   const auto t_create = std::chrono::steady_clock::now();
+  BuildTrace trace;
   // ---- union sparsity pattern (sorted merge per row) ----
   auto& ur = op->u_rowptr;
   auto& uc = op->u_col;
@@ -1097,12 +1198,18 @@ int qp_operator_create(qp_ctx* ctx, qp_matrix* const* ops, int nops, int ncoeffs
   // merge like several terms do, so that density, completeness and every layout decision below see each position once --
   // a duplicate could make the stored count reach nrows x ncols with positions missing)
   bool canonical = nops == 1;
-  for (int64_t r = 0; canonical && r < nrows; ++r)
-    for (int64_t p = ops[0]->rowptr[r] + 1; p < ops[0]->rowptr[r + 1]; ++p)
-      if (ops[0]->col[p] <= ops[0]->col[p - 1]) {
-        canonical = false;
-        break;
-      }
+  if (canonical) {
+    std::atomic<bool> asc{true};
+    parallel_rows(nrows, [&](int64_t r0, int64_t r1) {
+      for (int64_t r = r0; r < r1 && asc.load(std::memory_order_relaxed); ++r)
+        for (int64_t p = ops[0]->rowptr[r] + 1; p < ops[0]->rowptr[r + 1]; ++p)
+          if (ops[0]->col[p] <= ops[0]->col[p - 1]) {
+            asc.store(false, std::memory_order_relaxed);
+            break;
+          }
+    });
+    canonical = asc.load();
+  }
   if (canonical) {
     ur = ops[0]->rowptr;
     uc = ops[0]->col;
@@ -1118,6 +1225,7 @@ int qp_operator_create(qp_ctx* ctx, qp_matrix* const* ops, int nops, int ncoeffs
       ur[r + 1] = (int64_t)uc.size();
     }
   }
+  trace.mark("union pattern");
   // ---- a dense generator (QP_FMT_DENSE): requested, or AUTO with at least kDenseMinDensityPct % of the positions stored.
   // The pattern is made complete (the missing positions become explicit zeros, counted like the lattice completion's), so
   // that the CSR-ordered value array IS the row-major dense matrix and the dense kernels need no index at all.
@@ -1151,10 +1259,8 @@ int qp_operator_create(qp_ctx* ctx, qp_matrix* const* ops, int nops, int ncoeffs
   std::vector<int64_t> ur_orig;
   std::vector<int32_t> uc_orig;
   if (!dense && (format == QP_FMT_AUTO || format == QP_FMT_HRB)) {
-    ur_orig = ur;
-    uc_orig = uc;
     const int64_t before = ur[nrows];
-    lattice_fill(ctx->tun, nrows, ncols, ur, uc);
+    lattice_fill(ctx->tun, nrows, ncols, ur, uc, &ur_orig, &uc_orig);      // (ur_orig / uc_orig stay empty when nothing was completed)
     op->n_lattice_fill = ur[nrows] - before;
     if (op->n_lattice_fill == 0) {
       ur_orig.clear();
@@ -1162,8 +1268,9 @@ int qp_operator_create(qp_ctx* ctx, qp_matrix* const* ops, int nops, int ncoeffs
     }
   }
 
+  trace.mark("lattice completion");
   // ---- per-term values in union order (duplicates within a row are summed, as Julia's sparse() does) ----
-  std::vector<std::vector<cplx>> planes_csr(nops);
+  Planes planes_csr((size_t)nops);
   auto scatter_planes = [&]() {
   op->A.nnz = ur[nrows];
   for (int l = 0; l < nops; ++l) {
@@ -1171,20 +1278,23 @@ int qp_operator_create(qp_ctx* ctx, qp_matrix* const* ops, int nops, int ncoeffs
     auto& pv = planes_csr[l];
     if (nops == 1 && canonical && (int64_t)M->vals.size() == op->A.nnz && ur == M->rowptr && uc == M->col) {
       // one canonical term and no completion: the union pattern IS the term's own (same columns, not merely as many) -- a plain copy
-      pv = M->vals;
+      pv.borrow(M->vals);      // (the term outlives this call: the operator build reads it, nothing keeps the pointer)
       continue;
     }
-    pv.assign((size_t)op->A.nnz, cplx(0));
-    for (int64_t r = 0; r < nrows; ++r) {
-      int64_t k = 0;
-      for (int64_t p = M->rowptr[r]; p < M->rowptr[r + 1]; ++p) {
-        while (uc[ur[r] + k] != M->col[p]) ++k;
-        pv[ur[r] + k] += M->vals[p];
+    auto& o = pv.make_own((size_t)op->A.nnz);
+    parallel_rows(nrows, [&](int64_t r0, int64_t r1) {
+      for (int64_t r = r0; r < r1; ++r) {
+        int64_t k = 0;
+        for (int64_t p = M->rowptr[r]; p < M->rowptr[r + 1]; ++p) {
+          while (uc[ur[r] + k] != M->col[p]) ++k;
+          o[ur[r] + k] += M->vals[p];
+        }
       }
-    }
+    });
   }
   };
   scatter_planes();
+  trace.mark("value planes in union order");
   auto take_completion_back = [&]() {
     ur.swap(ur_orig);
     uc.swap(uc_orig);
@@ -1197,7 +1307,9 @@ int qp_operator_create(qp_ctx* ctx, qp_matrix* const* ops, int nops, int ncoeffs
   bool hermitian = !dense && (ncols >= nrows) && (format == QP_FMT_AUTO || format == QP_FMT_HRB);
   for (int l = 0; hermitian && l < nops; ++l) hermitian = csr_is_hermitian(nrows, ur, uc, planes_csr[l]);
   op->hermitian_planes = hermitian;
+  trace.mark("Hermitian check");
   int fmt = dense ? (int)QP_FMT_DENSE : choose_format(op.get(), format, hermitian);
+  trace.mark("format choice");
   if (fmt < 0) return qp::fail(QP_E_BAD_ARG, "QP_FMT_HRB requested but the operator terms are not exactly Hermitian");
   if (!ur_orig.empty() && fmt != QP_FMT_HRB) {   // (a lattice completion happened;) not Hermitian, or not packed: the zeros would buy nothing
     take_completion_back();
@@ -1205,6 +1317,7 @@ int qp_operator_create(qp_ctx* ctx, qp_matrix* const* ops, int nops, int ncoeffs
     if (fmt < 0) return qp::fail(QP_E_BAD_ARG, "QP_FMT_HRB requested but the operator terms are not exactly Hermitian");
   }
   QP_CHECK(operator_build_device(op.get(), fmt, planes_csr));
+  trace.mark("device build (layout, encodings, uploads, plans)");
   if (!ur_orig.empty() && !op->walk.valid) {     // packed, completed, and still no plan: build once more without the zeros
     QP_CHECK(operator_free_device(op.get()));
     take_completion_back();
@@ -1246,7 +1359,7 @@ static int operator_refresh(qp_operator* op) {
   if (op->A.format == QP_FMT_HRB && !all_real) {
     // a complex combination of Hermitian terms is not Hermitian: leave the packed format
     // (slow path, once): re-lay the planes out as full row-block CSR
-    std::vector<std::vector<cplx>> planes_csr;
+    Planes planes_csr;
     QP_CHECK(operator_download_planes(op, planes_csr));
     operator_free_device(op);
     const int fmt = choose_format(op, QP_FMT_AUTO, false);
@@ -1918,78 +2031,6 @@ int operator_spmm_order(qp_operator* op, int batch, const int32_t** order_out) {
   op->m_order_g = g;
   op->m_order_sw = sw;
   *order_out = op->m_order;
-  return QP_OK;
-}
-
-// Strip-walk plan of the batched term (device.h: SpmmWalkPlan; kernels_spmm_walk.hip).  Index work on the host: every
-// row must have the same number of entries, and every row a g + c with a in [a_lo, a_hi) its columns at exactly the
-// distances [-K g .. -g] [-d_nn .. -d_1] [0] [d_1 .. d_nn] [g .. K g]; all other rows are listed for the wave-per-row kernel.
-int operator_spmm_walk_plan(qp_operator* op, const qp::SpmmWalkPlan** out) {
-  *out = nullptr;
-  if (op->spmm_walk_built) {
-    if (op->spmm_walk.valid) *out = &op->spmm_walk;
-    return QP_OK;
-  }
-  op->spmm_walk_built = true;
-  qp::SpmmWalkPlan& P = op->spmm_walk;
-  P = qp::SpmmWalkPlan();
-  const int64_t n = op->A.nrows;
-  const auto& ur = op->u_rowptr;
-  const auto& uc = op->u_col;
-  if (op->A.format == QP_FMT_MATFREE || op->A.ncols != n || n < 4096 || n > INT32_MAX || ur.empty()) return QP_OK;
-  const int64_t z = ur[1] - ur[0];
-  if (z < 4 || z > 24 || ur[n] != z * n) return QP_OK;
-  for (int64_t r = 0; r < n; ++r)
-    if (ur[r + 1] - ur[r] != z) return QP_OK;
-  // the stencil of a row in the middle
-  const int64_t rm = n / 2;
-  std::vector<int64_t> dl((size_t)z);
-  for (int64_t k = 0; k < z; ++k) dl[(size_t)k] = (int64_t)uc[ur[rm] + k] - rm;
-  int64_t k = 0;
-  int K = 0, nn = 0, diag = 0;
-  while (k < z && dl[(size_t)k] <= -64) ++k, ++K;
-  if (K < 1 || K > 4) return QP_OK;
-  const int64_t g = -dl[(size_t)(K - 1)];
-  if (g < 64 || n % g != 0) return QP_OK;
-  if (g < kRB) return QP_OK;
-  for (int m = 1; m <= K; ++m)
-    if (dl[(size_t)(K - m)] != -(int64_t)m * g) return QP_OK;
-  while (k < z && dl[(size_t)k] < 0) ++k, ++nn;
-  if (nn < 1 || nn > qp::kWalkMaxNear) return QP_OK;
-  for (int i = 0; i < nn; ++i) P.near[i] = (int)(-dl[(size_t)(K + nn - 1 - i)]);
-  for (int i = 0; i < nn; ++i)
-    if (P.near[i] <= 0 || P.near[i] >= 64 || (i > 0 && P.near[i] <= P.near[i - 1])) return QP_OK;
-  if (k < z && dl[(size_t)k] == 0) ++k, diag = 1;
-  if (z != 2 * (nn + K) + diag) return QP_OK;
-  for (int i = 0; i < nn; ++i)
-    if (dl[(size_t)(K + nn + diag + i)] != P.near[i]) return QP_OK;
-  for (int m = 1; m <= K; ++m)
-    if (dl[(size_t)(K + 2 * nn + diag + m - 1)] != (int64_t)m * g) return QP_OK;
-  if (!qp::spmm_walk_shape_supported(nn, K, diag)) return QP_OK;
-  const int64_t A = n / g;
-  if (A < 2 * K + 8) return QP_OK;
-  // every row of the walk must carry exactly this stencil
-  for (int64_t a = K; a < A - K; ++a)
-    for (int64_t c = 0; c < g; ++c) {
-      const int64_t r = a * g + c;
-      const int32_t* col = uc.data() + ur[r];
-      for (int64_t q = 0; q < z; ++q)
-        if ((int64_t)col[q] - r != dl[(size_t)q]) return QP_OK;
-    }
-  std::vector<int32_t> edge;
-  for (int64_t r = 0; r < (int64_t)K * g; ++r) edge.push_back((int32_t)r);
-  for (int64_t r = (A - K) * g; r < n; ++r) edge.push_back((int32_t)r);
-  QP_CHECK(dev_alloc(&P.edge, std::max<size_t>(edge.size(), 1)));
-  QP_HIP(hipMemcpy(P.edge, edge.data(), edge.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-  P.n_edge = (int64_t)edge.size();
-  P.nn = nn;
-  P.K = K;
-  P.diag = diag;
-  P.g = g;
-  P.a_lo = K;
-  P.a_hi = (int)(A - K);
-  P.valid = 1;
-  *out = &P;
   return QP_OK;
 }
 

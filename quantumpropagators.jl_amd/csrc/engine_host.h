@@ -27,6 +27,19 @@ inline unsigned host_threads() {
   return n;
 }
 
+// Phase timer of the host-side operator build (QP_BUILD_TRACE=1: one line per phase on stderr; otherwise two clock reads per phase)
+struct BuildTrace {
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  const bool on = std::getenv("QP_BUILD_TRACE") != nullptr;
+  void mark(const char* what) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[qp build] %-44s %9.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+    t = now;
+  }
+};
+
+
 // rows [0, n) in contiguous chunks on a few host threads (index work whose iterations write disjoint positions)
 template <class F>
 inline void parallel_rows(int64_t n, F&& fn, int64_t serial_below = (int64_t)1 << 16) {
@@ -69,7 +82,8 @@ using HostLayout = HostLayoutData;
 // engine_plans.hip
 struct WalkShape;
 int choose_format(qp_operator* op, int requested, bool hermitian);
-void lattice_fill(const qp::Tuning& tun, int64_t n, int64_t ncols, std::vector<int64_t>& ur, std::vector<int32_t>& uc);
+void lattice_fill(const qp::Tuning& tun, int64_t n, int64_t ncols, std::vector<int64_t>& ur, std::vector<int32_t>& uc,
+                  std::vector<int64_t>* ur_before = nullptr, std::vector<int32_t>* uc_before = nullptr);
 int build_walk_plan(qp_operator* op);
 int build_colblock(qp_operator* op);
 // position of every union-CSR entry in the operator's value array (-(position) - 1: its complex conjugate)

@@ -153,7 +153,7 @@ int arnoldi_column(qp_operator* op, qp_krylov* q, int j, double dt, double2* hco
                                   q->hcoef, q->mgs_coef, q->ticket, q->part + (size_t)((j + 1) & 1) * kRedBlocks, dt,
                                   q->n, &ctx->stats, /* reduction + solve in the projection's prologue */ true, fold ? fold->early_flag : nullptr,
                                   fold ? fold->flag_value : 0u, fold ? fold->early_armed : nullptr, dots_done,
-                                  ctx->tun.arnoldi_l2_order != 0);
+                                  /* rows per XCD, basis back to front: L2 reuse of what the dots pass read last */ true);
   }
   q->gram_rows = std::min(q->gram_rows, j);
   for (int i = 0; i <= j + 1; ++i) {                                              // :84-87

@@ -2,6 +2,8 @@
 // completion of open-boundary grids (lattice_fill), the strip-walk plan of a Hermitian-packed lattice (build_walk_plan: shape
 // parser, run detection, positions), the column-blocked mirror of an operator with irregular columns (build_colblock).
 // Split out of engine_core.hip in round 4; called from qp_operator_create / operator_build_device there.
+#include <atomic>
+
 #include "engine_host.h"
 
 // Strip-walk plan of a Hermitian-packed lattice operator (device.h: WalkPlan; kernels_walk.hip).  Looks, in the union
@@ -171,23 +173,30 @@ int build_walk_plan(qp_operator* op) {
       if ((int64_t)a[k] - (int64_t)c[k] != shift) return false;
     return true;
   };
+  // Longest run of row blocks whose rows all carry ONE list of column distances.  "Same distances" is transitive, so a block
+  // belongs to the run of the block before it iff (a) its own 64 rows agree with one another and (b) its first row agrees with the
+  // first row of the block before: both per block, on a few host threads; the runs are then read off the two flag arrays.
+  std::vector<char> uniform((size_t)std::max<int64_t>(nfull, 1), 0), joins((size_t)std::max<int64_t>(nfull, 1), 0);
+  parallel_rows(nfull, [&](int64_t b0, int64_t b1) {
+    for (int64_t b = b0; b < b1; ++b) {
+      const int64_t ref = b * kRB;
+      const int64_t len = ur[ref + 1] - ur[ref];
+      bool ok = len >= 3 && len <= 19;
+      for (int64_t r = ref + 1; r < ref + kRB && ok; ++r) ok = same_row(r, ref);
+      uniform[(size_t)b] = ok ? 1 : 0;
+      joins[(size_t)b] = (ok && b > 0 && same_row(ref, ref - kRB)) ? 1 : 0;
+    }
+  }, 1024);
   int64_t best0 = 0, best1 = 0;
   for (int64_t b = 0; b < nfull;) {
-    const int64_t ref = b * kRB;
-    if (ur[ref + 1] - ur[ref] < 3 || ur[ref + 1] - ur[ref] > 19) {
+    if (!uniform[(size_t)b]) {
       ++b;
       continue;
     }
-    int64_t e = b;
-    for (;;) {   // extend while every row of block e carries row ref's distances
-      if (e >= nfull) break;
-      bool ok = true;
-      for (int64_t r = e * kRB; r < (e + 1) * kRB && ok; ++r) ok = same_row(r, ref);
-      if (!ok) break;
-      ++e;
-    }
+    int64_t e = b + 1;
+    while (e < nfull && uniform[(size_t)e] && joins[(size_t)e]) ++e;
     if (e - b > best1 - best0) best0 = b, best1 = e;
-    b = std::max(e, b + 1);
+    b = e;
   }
   if (best1 - best0 < 8)
     return why(QP_WALK_NO_UNIFORM_RUN, "the longest run of row blocks whose rows all carry one list of column distances is %lld blocks (of %lld): not a lattice",
@@ -293,7 +302,7 @@ void csr_value_map(const qp_operator* op, std::vector<int64_t>& map) {
 
 // Column-blocked mirror (device.h: ColBlockPlan; kernels_colblock.hip) for an operator whose gathers are irregular.
 // Decision (knob colblock = 1): plain row blocks or CSR (a lattice is Hermitian-packed and walked; a dense operator has
-// its own kernels), at least 2^cb_min_log2n columns (below, the vector sits in the L2 as it is), at most 64 column blocks
+// its own kernels), at least 2^20 (kCbMinLog2N) columns (below, the vector sits in the L2 as it is), at most 64 column blocks
 // and kCbMaxTilesPerWave tiles per resident wavefront, and -- sampled over the row blocks -- more than half of the gathers
 // of a wavefront's load pulling a 128-byte line of their own (a band or a lattice shares each line among 8 lanes: 0.125).
 int build_colblock(qp_operator* op) {
@@ -318,7 +327,7 @@ int build_colblock(qp_operator* op) {
   log2w = std::max(6, std::min(log2w, 24));
   const int64_t W = (int64_t)1 << log2w;
   const int64_t P = (ncols + W - 1) / W;
-  if (tun.colblock == 1 && (ncols < ((int64_t)1 << std::max(tun.cb_min_log2n, 1)) || P < 2)) return QP_OK;
+  if (tun.colblock == 1 && (ncols < ((int64_t)1 << qp::kCbMinLog2N) || P < 2)) return QP_OK;
   if (P > 256) return QP_OK;
   // irregularity: distinct 128-byte lines among the k-th gathers of a 64-row block, over the entries sampled
   {
@@ -372,7 +381,7 @@ int build_colblock(qp_operator* op) {
   }
   if (rpt == 0) return QP_OK;   // a (64-row, 2^log2w-column) cell with more than kCbMaxSeg entries: not this kernel's operator
   {
-    const int64_t resident = (int64_t)std::max(tun.n_cu, 1) * qp::kCbWavesPerCu;
+    const int64_t resident = (int64_t)std::max(qp::device_cu_count(), 1) * qp::kCbWavesPerCu;
     if ((ntiles + resident - 1) / resident > qp::kCbMaxTilesPerWave) return QP_OK;
   }
   const int64_t TR = 64 * rpt;
@@ -453,15 +462,21 @@ int choose_format(qp_operator* op, int requested, bool hermitian) {
     int64_t hu_stored = 0;   // values the packed form stores: the upper section of every block, padded to a multiple of four
     {
       const auto& ucc = op->u_col;
-      for (int64_t b = 0; b < nblocks; ++b) {
-        int64_t w = 0;
-        for (int64_t r = b * kRB; r < std::min(nrows, (b + 1) * kRB); ++r) {
-          const int32_t* cb = ucc.data() + ur[r];
-          const int32_t* ce = ucc.data() + ur[r + 1];
-          w = std::max<int64_t>(w, ce - std::lower_bound(cb, ce, (int32_t)r));
+      std::atomic<int64_t> total{0};
+      parallel_rows(nblocks, [&](int64_t b0, int64_t b1) {
+        int64_t mine = 0;
+        for (int64_t b = b0; b < b1; ++b) {
+          int64_t w = 0;
+          for (int64_t r = b * kRB; r < std::min(nrows, (b + 1) * kRB); ++r) {
+            const int32_t* cb = ucc.data() + ur[r];
+            const int32_t* ce = ucc.data() + ur[r + 1];
+            w = std::max<int64_t>(w, ce - std::lower_bound(cb, ce, (int32_t)r));
+          }
+          mine += ((w + 3) & ~(int64_t)3) * kRB;
         }
-        hu_stored += ((w + 3) & ~(int64_t)3) * kRB;
-      }
+        total.fetch_add(mine, std::memory_order_relaxed);
+      }, 1024);
+      hu_stored = total.load();
     }
     const bool hrb_ok = rb_ok || (double)hu_stored <= 0.9 * (double)nnz + 1024.0;
     // Hermitian packing pays only if the transposed values are still in the XCD's L2
@@ -472,11 +487,21 @@ int choose_format(qp_operator* op, int requested, bool hermitian) {
     const double row_bytes = 14.0 * (double)nnz / (double)std::max<int64_t>(nrows, 1) + 80.0;
     const int64_t maxdist = (int64_t)(2.0 * 1048576.0 / row_bytes);
     int64_t nlow = 0, nnear = 0;
-    for (int64_t r = 0; r < nrows; ++r)
-      for (int64_t p = ur[r]; p < ur[r + 1] && uc[p] < r; ++p) {
-        ++nlow;
-        if (r - uc[p] <= maxdist) ++nnear;
-      }
+    {
+      std::atomic<int64_t> tl{0}, tn{0};
+      parallel_rows(nrows, [&](int64_t r0, int64_t r1) {
+        int64_t l = 0, nr = 0;
+        for (int64_t r = r0; r < r1; ++r)
+          for (int64_t p = ur[r]; p < ur[r + 1] && uc[p] < r; ++p) {
+            ++l;
+            if (r - uc[p] <= maxdist) ++nr;
+          }
+        tl.fetch_add(l, std::memory_order_relaxed);
+        tn.fetch_add(nr, std::memory_order_relaxed);
+      });
+      nlow = tl.load();
+      nnear = tn.load();
+    }
     // ... and only if the transposed reads are coalesced: in a block whose 64 rows have their k-th entry at
     // the same distance from the diagonal (stencil-like: lattices, tensor products) the wave reads 64
     // consecutive values; in an irregular block every lane pulls its own L2 line for 16 useful bytes
@@ -531,7 +556,8 @@ int choose_format(qp_operator* op, int requested, bool hermitian) {
 // list, that list has the walk's shape, and at most 12 % of the entries are missing (a 64 x 8 x nz grid: 4 %), the missing ones are stored as explicit
 // zeros (with their transposes, so that the pattern stays structurally symmetric).  Index work only; 0 * x terms change no
 // row sum beyond the order in which the two accumulators of a row take their entries.
-void lattice_fill(const qp::Tuning& tun, int64_t n, int64_t ncols, std::vector<int64_t>& ur, std::vector<int32_t>& uc) {
+void lattice_fill(const qp::Tuning& tun, int64_t n, int64_t ncols, std::vector<int64_t>& ur, std::vector<int32_t>& uc,
+                  std::vector<int64_t>* ur_before, std::vector<int32_t>* uc_before) {
   if (!tun.lattice_fill || ncols < n || n / kRB < std::max(tun.walk_min_blocks, 16)) return;
   // (ncols > n: the local rows of a row-partitioned operator; its halo columns appear only in the first / last K g rows)
   // the reference row: the fullest one near the middle (the middle row itself may sit on the grid's edge)
@@ -614,5 +640,9 @@ void lattice_fill(const qp::Tuning& tun, int64_t n, int64_t ncols, std::vector<i
   }
   ur.swap(nr);
   uc.swap(nc);
+  // the pattern as it was (the caller takes the completion back when the operator does not end up walked) -- handed over only
+  // when something was completed: no copy of a pattern that stays as it is
+  if (ur_before) ur_before->swap(nr);
+  if (uc_before) uc_before->swap(nc);
 }
 

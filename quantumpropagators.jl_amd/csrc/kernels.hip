@@ -321,7 +321,7 @@ static int launch_spmv(hipStream_t s, const DevMatrix& A, const double2* x, cons
   const SyncArgs sy = rs ? rs->sync : SyncArgs();
   static const Tuning kDefaults;
   const Tuning& tun = A.tun ? *A.tun : kDefaults;
-  // Eight instead of four row blocks per workgroup (knob hrb_wg) for the fused Chebyshev term wherever nothing counts
+  // Eight instead of four row blocks per workgroup for the fused Chebyshev term wherever nothing counts
   // workgroups of four: not with the per-workgroup check partials, and of the two launches of a split term only for the
   // interior one (no completion signal, no mirror map; its wait threshold, given in workgroups of four, is halved and
   // rounded down: the workgroup that straddles the threshold waits as well)
@@ -356,7 +356,7 @@ static int launch_spmv(hipStream_t s, const DevMatrix& A, const double2* x, cons
   if (A.format == QP_FMT_RBCSR && A.cv && A.cv->valid && tun.value_dict != 0) {
     // few distinct values per block: one byte + a cached table line per entry instead of the value (kernels_coded.hip)
     int rcc;
-    if constexpr (std::is_same<Op, ChebyOp>::value) rcc = launch_rbcsr_coded_cheby(s, A, x, op.e, nblk, bmap, sy, wide_ok && tun.hrb_wg == 8);
+    if constexpr (std::is_same<Op, ChebyOp>::value) rcc = launch_rbcsr_coded_cheby(s, A, x, op.e, nblk, bmap, sy, wide_ok);
     else rcc = launch_rbcsr_coded_plain(s, A, x, op.e, nblk, bmap, sy);
     if (rcc != QP_OK) return rcc;
     if (st) {
@@ -377,7 +377,7 @@ static int launch_spmv(hipStream_t s, const DevMatrix& A, const double2* x, cons
     break;
     if constexpr (std::is_same<Op, ChebyOp>::value) {
       // as for the Hermitian-packed kernel below: eight row blocks per workgroup for the plain fused term of a whole operator
-      if (tun.hrb_wg == 8 && wide_ok && (tun.rbcsr_variant & 7) == 7 && A.stored > A.nblocks * (int64_t)(kRB * 8)) {
+      if (wide_ok && (tun.rbcsr_variant & 7) == 7 && A.stored > A.nblocks * (int64_t)(kRB * 8)) {
         const int g8 = (int)((nblk + 7) / 8);
         if (A.vals_r)
           hipLaunchKernelGGL((rbcsr_spmv_kernel<Op, 7, double, 8>), dim3(g8), dim3(512), 0, s, A.bptr, A.cmeta,
@@ -444,7 +444,7 @@ static int launch_spmv(hipStream_t s, const DevMatrix& A, const double2* x, cons
       }
       // eight row blocks per workgroup instead of four (see wide_ok above): half as many workgroups to dispatch, 36.3 ->
       // 35.2 us per term at N = 2^20 (profiles/r02/kbench_banded.txt); the same sums
-      if (tun.hrb_wg == 8 && wide_ok && (tun.rbcsr_variant & 31) == 15) {
+      if (wide_ok && (tun.rbcsr_variant & 31) == 15) {
         const int g8 = (int)((nblk + 7) / 8);
         if (A.vals_r)
           hipLaunchKernelGGL((hrb_spmv_kernel<Op, 15, double, 8>), dim3(g8), dim3(512), 0, s, A.bptr, A.cmeta,

@@ -19,7 +19,7 @@ namespace qp {
 
 constexpr int kFusedWaves = 8;
 
-// NT (knob arnoldi_nt): the matrix values and column sections are loaded nontemporal -- the matrix is read once per
+// NT: the matrix values and column sections are loaded nontemporal -- the matrix is read once per
 // column and does not fit an XCD's L2 next to the basis; streamed, it leaves the L2 to the basis vectors that the
 // projection kernel reads next (kernels_blas.hip: mgs_update_kernel<.., ORD = true>)
 // CODED: the operator has a value-dictionary mirror (device.h: CodedVals; kernels_coded.hip) -- `vals` is then the combined TABLE,
@@ -262,7 +262,7 @@ static void launch_instance(hipStream_t s, const DevMatrix& A, const double2* x,
     return;
   }
   // (only where the operator is large enough for the question to exist: a small one sits in the L2 with its basis)
-  const bool nt = A.tun && A.tun->arnoldi_nt != 0 && (double)A.stored * (A.vals_r ? 8.0 : 16.0) > 8.0 * 1024 * 1024;
+  const bool nt = (double)A.stored * (A.vals_r ? 8.0 : 16.0) > 8.0 * 1024 * 1024;
   if (nt) launch_instance_nt<JT, true>(s, A, x, e, Q, ldq, j, partials);
   else launch_instance_nt<JT, false>(s, A, x, e, Q, ldq, j, partials);
 }

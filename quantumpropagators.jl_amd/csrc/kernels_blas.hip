@@ -513,7 +513,7 @@ struct MgsSolveArgs {
   unsigned flag_value = 0;
 };
 
-// ORD (knob arnoldi_l2_order): the elements a workgroup owns and the order in which it reads the basis are chosen for the
+// ORD: the elements a workgroup owns and the order in which it reads the basis are chosen for the
 // XCD's L2.  The column's mat-vec with the dot products in its epilogue (kernels_arnoldi.hip) has just read the basis
 // vectors q_0 .. q_j, ascending, on the rows of ITS workgroups -- rows [t * 512 grid + 512 wg, + 512) in round t, wg =
 // xcd_remap(blockIdx) -- so each XCD's L2 holds the share of the LAST vectors of the LAST round.  ORD = true gives the

@@ -162,7 +162,7 @@ static int launch_colblock(hipStream_t s, const DevMatrix& A, const double2* x, 
   if (!Pp || !Pp->valid || tun.colblock == 0 || A.nrows == 0) return QP_OK;
   const ColBlockPlan& P = *Pp;
   // every wavefront resident from the start: the grid is what the chip holds, a wavefront takes `tpw` tiles
-  const int64_t resident = (int64_t)std::max(tun.n_cu, 1) * kCbWavesPerCu;
+  const int64_t resident = (int64_t)std::max(device_cu_count(), 1) * kCbWavesPerCu;
   int64_t tpw = (P.ntiles + resident - 1) / resident;
   if (tpw < 1) tpw = 1;
   if (tpw > kCbMaxTilesPerWave) return QP_OK;

@@ -481,7 +481,7 @@ int launch_arnoldi_onepass_sweep(hipStream_t s, const DevMatrix& A, const double
                                  double2* const a_buf[2], int m, int nvec, double2* const part[2], double2* gram, double2* hhat,
                                  double* svals, double* nu_dev, double dt, double2* hess_map, double* norms_map, double* nu_map,
                                  unsigned* flags_map, unsigned flag_value, Stats* st) {
-  const bool nt = A.tun && A.tun->arnoldi_nt != 0 && (double)A.stored * (A.vals_r ? 8.0 : 16.0) > 8.0 * 1024 * 1024;
+  const bool nt = (double)A.stored * (A.vals_r ? 8.0 : 16.0) > 8.0 * 1024 * 1024;
   OpSolveArgs S;
   S.m = m;
   S.nvec = nvec;

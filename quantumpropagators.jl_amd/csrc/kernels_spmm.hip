@@ -106,7 +106,7 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {   // l wave-un
 // Scalar-memory variant (knob spmm_rw = 0): the row's entries are wave-uniform, so they can be fetched by the
 // scalar unit (s_load: value and column straight into SGPRs, which the FMAs and the gather addresses take as
 // operands) instead of one entry per lane + v_readlane broadcasts -- five VALU instructions per entry less.
-// WS wavefronts (consecutive walk positions) per workgroup (knob spmm_wg): 8 measured 282 us per term of config C5
+// WS wavefronts (consecutive walk positions) per workgroup: 8 measured 282 us per term of config C5
 // against 302 with 4 and 290 with 16; 2-D tiles of walk positions per workgroup instead of runs: no difference
 // (profiles/r02/batched_c5_sweep.txt)
 template <class Op, int WS>
@@ -316,9 +316,7 @@ int launch_spmm_cheby(hipStream_t s, const int64_t* rowptr, const int32_t* cols,
       hipLaunchKernelGGL((spmm_rows_smem_kernel<ChebyOp, WS>), grid, dim3(64 * (WS)), 0, s, rowptr, cols, vals, X, nrows, b, op, order); \
     }                                                                                                             \
   }
-      if (tun.spmm_wg == 16) QP_SPMM_SMEM(16)
-      else if (tun.spmm_wg == 8) QP_SPMM_SMEM(8)
-      else QP_SPMM_SMEM(4)
+      QP_SPMM_SMEM(8)
 #undef QP_SPMM_SMEM
     } else
     switch (tun.spmm_rw) {
@@ -329,12 +327,10 @@ int launch_spmm_cheby(hipStream_t s, const int64_t* rowptr, const int32_t* cols,
     }
 #undef QP_SPMM_ROWS
   } else
-  switch ((b <= 8 && tun.spmm_tile == 16) ? 8 : tun.spmm_tile) {   // a panel of at most eight states (one GPU's share of 64 over 8): no idle lanes
-    case 8: launch_spmm_cheby_t<8>(s, rowptr, cols, vals, X, nrows, b, e, tun.spmm_nt); break;
-    case 32: launch_spmm_cheby_t<32>(s, rowptr, cols, vals, X, nrows, b, e, tun.spmm_nt); break;
-    case 64: launch_spmm_cheby_t<64>(s, rowptr, cols, vals, X, nrows, b, e, tun.spmm_nt); break;
-    default: launch_spmm_cheby_t<16>(s, rowptr, cols, vals, X, nrows, b, e, tun.spmm_nt); break;
-  }
+  // states per pass of the tiled kernel: 16 (the gather window of a banded H stays inside an XCD's L2; 32 and 64 measured slower,
+  // profiles/r02/batched_c5_sweep.txt); a panel of at most eight states (one GPU's share of 64 over 8): 8, no idle lanes
+  if (b <= 8) launch_spmm_cheby_t<8>(s, rowptr, cols, vals, X, nrows, b, e, tun.spmm_nt);
+  else launch_spmm_cheby_t<16>(s, rowptr, cols, vals, X, nrows, b, e, tun.spmm_nt);
   QP_HIP(hipGetLastError());
   if (st) {
     st->n_launch++;

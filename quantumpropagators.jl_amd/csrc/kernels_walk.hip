@@ -33,13 +33,13 @@ int launch_hrb_walk_cheby(hipStream_t s, const DevMatrix& A, const double2* x, c
   // the edge blocks run BESIDE the walk there too; 2048 with the edge blocks inside the walk's wavefronts when that would
   // leave more than an eighth of the chip to them (profiles/r03/kbench_walk_development.txt: 2^21 rows 71.4 -> 68.5 us,
   // 2^22 126.0 -> 121.8, 2^23 275 -> 278)
-  const int ws = (tun.walk_wg == 8 || tun.walk_wg == 4 || tun.walk_wg == 2) ? tun.walk_wg : (resident ? 4 : kWalkWaves);            // wavefronts per workgroup (two 4-wavefront workgroups fit a CU)
-  const int64_t wg_slots = (int64_t)std::max(tun.n_cu - reserve, 8) * (kWalkWaves / ws);  // workgroups the walk may hold at once
+  const int ws = resident ? 4 : kWalkWaves;            // wavefronts per workgroup (two 4-wavefront workgroups fit a CU)
+  const int64_t wg_slots = (int64_t)std::max(device_cu_count() - reserve, 8) * (kWalkWaves / ws);  // workgroups the walk may hold at once
   const int64_t edge_wgs_all = (P->n_edge + ws - 1) / ws;
   const int waves_beside = (int)(ws * std::max<int64_t>(0, wg_slots - edge_wgs_all)) / P->S * P->S;
   const int waves = tun.walk_waves > 0 ? tun.walk_waves
                     : resident ? (A.vals_r ? 1024 : 768)   // (real copy, half the value bytes per step: 1024; N = 2^20: 26.6 -> 24.3 us)
-                    : ((rs || waves_beside >= 7 * kWalkWaves * tun.n_cu / 8) ? std::max(waves_beside, P->S) : kWalkWaves * tun.n_cu);
+                    : ((rs || waves_beside >= 7 * kWalkWaves * device_cu_count() / 8) ? std::max(waves_beside, P->S) : kWalkWaves * device_cu_count());
   const int ntm = tun.walk_nt >= 0 ? tun.walk_nt : (resident ? 0 : 1);
   const int64_t nseg_target = std::max<int64_t>(1, waves / P->S);
 #ifdef QP_DEVELOPER
@@ -52,7 +52,7 @@ int launch_hrb_walk_cheby(hipStream_t s, const DevMatrix& A, const double2* x, c
   const bool edge_beside = !no_edges && (tun.walk_dbg & 4) == 0 &&
                            (nseg_target * P->S + ws - 1) / ws + edge_wgs <= wg_slots;
   G.n_edge_wg = edge_beside ? (int)edge_wgs : 0;
-  G.edge_steps = (no_edges || edge_beside) ? 0 : std::max(0, tun.walk_edge_steps);
+  G.edge_steps = (no_edges || edge_beside) ? 0 : kWalkEdgeSteps;
   G.edge_last = (tun.walk_dbg & 1) ? 1 : 0;
   G.edge_segs = (no_edges || edge_beside) ? 0 : (int)std::min<int64_t>(nseg_target, (P->n_edge + P->S - 1) / P->S);
   G.xlast = A.ncols - 1;

@@ -172,7 +172,7 @@ def test_time_dependent_generator_refreshes_the_mirror(ctx):
 def test_auto_decision(ctx):
     """colblock = 1 (the default): the mirror is built for irregular gathers on a vector that outgrows the L2 -- not for a band,
     not for a lattice (Hermitian-packed and walked), not for a small operator, not for a dense one."""
-    assert ctx.tuning_get("colblock") == 1 and ctx.tuning_get("cb_log2w") == 0 and ctx.tuning_get("cb_min_log2n") == 20
+    assert ctx.tuning_get("colblock") == 1 and ctx.tuning_get("cb_log2w") == 0
     N = 1 << 20
     rp, col, vals = synth.random_columns_csr(N)
     op = L.Operator(ctx, [L.Matrix(ctx, N, N, rp, col, vals)])

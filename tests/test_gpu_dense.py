@@ -233,7 +233,7 @@ def test_dense_batched_cheby_on_the_matrix_cores(ctx, N, batch, real):
 
 
 def test_dense_batched_full_size_properties(ctx):
-    """The measured point (tools/bench_dense.py): N = 4096, 64 states.  Norms, forward / backward round trip, linearity,
+    """The measured point (tools/point.py dense --batch 64): N = 4096, 64 states.  Norms, forward / backward round trip, linearity,
     and eight states against the single-state dense step."""
     rng = np.random.default_rng(4096)
     N, batch = 4096, 64

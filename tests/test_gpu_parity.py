@@ -668,8 +668,8 @@ def test_full_size_properties(ctx):
 def test_hrb_kernel_variants_bit_identical(ctx):
     """Knob rbcsr_variant of the Hermitian-packed kernel: nontemporal index loads, early row-local loads, unroll
     depth and (bit 3, the default) the straight-line path that issues all 32 loads of an all-stencil block before
-    the first FMA change the schedule of the loads only, knob hrb_wg (8 or 4 row blocks per workgroup) the
-    placement -- every variant gives the same bits.  N is not a multiple of 8 x 64 rows: a partly filled workgroup."""
+    the first FMA change the schedule of the loads only -- every variant gives the same bits (variant 15 runs eight row blocks per
+    workgroup, the others four).  N is not a multiple of 8 x 64 rows: a partly filled workgroup."""
     N = (1 << 15) + 192
     rp, col, vals = synth.hermitian_offsets_csr(N)        # lattice: stencil blocks except at the wrap-around
     Op = L.Operator(ctx, [L.Matrix(ctx, N, N, rp, col, vals)], 0, L.FMT_HRB)
@@ -679,9 +679,8 @@ def test_hrb_kernel_variants_bit_identical(ctx):
     wrk = L.ChebyWrk(ctx, N, 20.0, -10.0, 1.0)
     outs = {}
     try:
-        for v in (15, 31, 7, 3, 0, 8, "15 with 4 row blocks per workgroup"):
-            ctx.tuning_set("rbcsr_variant", v if isinstance(v, int) else 15)
-            ctx.tuning_set("hrb_wg", 8 if isinstance(v, int) else 4)      # 8 (default) applies to variant 15 only
+        for v in (15, 31, 7, 3, 0, 8):
+            ctx.tuning_set("rbcsr_variant", v)
             psi = L.State(ctx, data=psi0)
             L.cheby(psi, Op, 1.0, wrk)
             L.cheby(psi, Op, -1.0, wrk)
@@ -689,7 +688,6 @@ def test_hrb_kernel_variants_bit_identical(ctx):
             outs[v] = psi.numpy()
     finally:
         ctx.tuning_set("rbcsr_variant", 15)
-        ctx.tuning_set("hrb_wg", 8)
     assert all(np.array_equal(outs[15], o) for o in outs.values())
     H = synth.to_scipy(rp, col, vals, N)
     ref = qo.cheby(psi0.copy(), H, 1.0, qo.ChebyWrk(psi0, 20.0, -10.0, 1.0))
@@ -703,8 +701,8 @@ def _with_diagonal(rp, col, vals, N):
     return H.indptr.astype(np.int64), H.indices.astype(np.int32), H.data.astype(np.complex128)
 
 
-WALK_KNOBS = ("hrb_walk", "walk_waves", "walk_nt", "walk_dbg", "walk_edge_steps", "walk_min_blocks", "walk_wg")
-WALK_DEFAULTS = {"hrb_walk": 1, "walk_waves": 0, "walk_nt": -1, "walk_dbg": 0, "walk_edge_steps": 4, "walk_min_blocks": 3072, "walk_wg": 0}
+WALK_KNOBS = ("hrb_walk", "walk_waves", "walk_nt", "walk_dbg", "walk_min_blocks", "walk_pair")
+WALK_DEFAULTS = {"hrb_walk": 1, "walk_waves": 0, "walk_nt": -1, "walk_dbg": 0, "walk_min_blocks": 3072, "walk_pair": -1}
 
 
 @pytest.mark.parametrize("N,offsets,diag,real,shape", [
@@ -761,8 +759,8 @@ def test_strip_walk_bit_identical_to_block_kernel(ctx, N, offsets, diag, real, s
 
         base = run(hrb_walk=0)                                     # the per-block kernel
         for knobs in (dict(), dict(walk_waves=64), dict(walk_waves=2048), dict(walk_waves=4096),
-                      dict(walk_dbg=4), dict(walk_dbg=5), dict(walk_dbg=4, walk_edge_steps=1, walk_waves=256),
-                      dict(walk_nt=1), dict(walk_nt=0, walk_waves=512), dict(walk_wg=8), dict(walk_wg=2, walk_waves=96), dict(walk_wg=4, walk_dbg=4)):
+                      dict(walk_dbg=4), dict(walk_dbg=5), dict(walk_dbg=4, walk_waves=256),
+                      dict(walk_nt=1), dict(walk_nt=0, walk_waves=512), dict(walk_waves=96)):
             assert np.array_equal(base, run(**knobs)), knobs
         if shape == (4, 4, 0):                                     # the measurement variants of the headline shape
             for nt in (3, 5, 7):
@@ -813,7 +811,7 @@ def test_strip_walk_random_lattices_bit_identical(ctx):
             outs = []
             for knobs in (dict(hrb_walk=0), dict(hrb_walk=1), dict(hrb_walk=1, walk_waves=int(rng.choice([16, 128, 1024, 4096])),
                                                                    walk_dbg=int(rng.choice([0, 1, 4, 5])), walk_nt=int(rng.integers(0, 2)),
-                                                                   walk_wg=int(rng.choice([0, 2, 4, 8])))):
+                                                                   walk_pair=int(rng.choice([0, 1])))):
                 for k, v in {**WALK_DEFAULTS, "walk_min_blocks": 8, **knobs}.items():
                     ctx.tuning_set(k, v)
                 psi = L.State(ctx, data=psi0)
@@ -933,7 +931,7 @@ def test_strip_walk_long_pair_three_dimensional_grids(ctx, dims, flux, uniform):
 
         base = run(hrb_walk=0)
         for knobs in (dict(), dict(walk_waves=64), dict(walk_waves=1024), dict(walk_dbg=4), dict(walk_dbg=5, walk_waves=256),
-                      dict(walk_nt=1), dict(walk_wg=8), dict(walk_wg=2, walk_waves=96)):
+                      dict(walk_nt=1), dict(walk_waves=96)):
             assert np.array_equal(base, run(**knobs)), knobs
     finally:
         for k, v in saved.items():
@@ -992,7 +990,7 @@ def test_strip_walk_two_long_pairs_and_two_far_distances(ctx, case):
 
         base = run(hrb_walk=0)
         for knobs in (dict(), dict(walk_waves=64), dict(walk_waves=1024), dict(walk_dbg=4), dict(walk_dbg=5, walk_waves=256),
-                      dict(walk_nt=1), dict(walk_wg=8), dict(walk_wg=2, walk_waves=96)):
+                      dict(walk_nt=1), dict(walk_waves=96)):
             assert np.array_equal(base, run(**knobs)), knobs
     finally:
         for k, v in saved.items():
@@ -1060,7 +1058,7 @@ def test_strip_walk_diagonal_far_neighbours(ctx, case):
 
         base = run(hrb_walk=0)
         for knobs in (dict(), dict(walk_waves=64), dict(walk_waves=1024), dict(walk_dbg=4), dict(walk_dbg=5, walk_waves=256),
-                      dict(walk_nt=1), dict(walk_wg=8), dict(walk_wg=2, walk_waves=96)):
+                      dict(walk_nt=1), dict(walk_waves=96)):
             assert np.array_equal(base, run(**knobs)), knobs
     finally:
         for k, v in saved.items():
@@ -1100,7 +1098,7 @@ def test_strip_walk_inside_a_replayed_graph(ctx):
         eager, g0 = run(False)
         replay, g1 = run(True)
         assert g0 == 0 and g1 == 4 and np.array_equal(eager, replay)       # the first call arms the key, the second records
-        other, g2 = run(True, walk_waves=96, walk_wg=2)                    # a different launch shape: new key, new graph
+        other, g2 = run(True, walk_waves=96)                    # a different launch shape: new key, new graph
         assert g2 == 4 and np.array_equal(eager, other)
     finally:
         for k, v in saved.items():
@@ -1226,20 +1224,17 @@ def test_newton_c3_full_size(ctx):
     assert wrk.restarts == owrk.restarts, (wrk.restarts, owrk.restarts)
 
 
-@pytest.mark.parametrize("l2_order,nt", [(0, 0), (1, 0), (0, 1), (1, 1)])
 @pytest.mark.parametrize("n", [96, 200])
-def test_newton_sweep_knobs_match_oracle(ctx, l2_order, nt, n):
-    """The round-4 forms of the Arnoldi sweep -- the projection kernel on the mat-vec's rows per XCD, reading rounds and
-    basis vectors back to front (arnoldi_l2_order), the matrix streamed nontemporal in the fused mat-vec (arnoldi_nt) --
+def test_newton_sweep_knobs_match_oracle(ctx, n):
+    """The Arnoldi sweep as shipped since round 4 -- the projection kernel on the mat-vec's rows per XCD, reading rounds and
+    basis vectors back to front, the matrix streamed nontemporal in the fused mat-vec (both were knobs until round 6: settled) --
     against the oracle: |delta psi| < 1e-10 after every step, the restart counts equal; n = 200 (N = 40000) has
     two rounds of row blocks per workgroup with a partly filled last one."""
     Lm = synth.liouvillian_tridiag(n)
     N = Lm.shape[0]
     rho0 = synth.random_state(N)
-    saved = {k: ctx.tuning_get(k) for k in ("arnoldi_l2_order", "arnoldi_nt")}
+    saved = {}
     try:
-        ctx.tuning_set("arnoldi_l2_order", l2_order)
-        ctx.tuning_set("arnoldi_nt", nt)
         Op = L.Operator(ctx, [L.Matrix.from_scipy(ctx, Lm)])
         wrk = L.NewtonWrk(ctx, N, m_max=12)
         rho = L.State(ctx, data=rho0)
@@ -1892,12 +1887,12 @@ def test_newton_long_krylov_basis(ctx):
     assert wrk.restarts == owrk.restarts
 
 
-@pytest.mark.parametrize("tile", [16, 32, 64])
-def test_cheby_batched_streaming_variants_bit_identical(ctx, tile):
-    """Knobs of the batched kernel: the nontemporal variant (picked automatically for panels larger
-    than the caches, forced here on a small one) and the states-per-pass tile change the memory
-    access pattern only -- every (row, state) element sees the same FMA sequence."""
-    N, batch = 1500, 40
+@pytest.mark.parametrize("batch", [40, 8])
+def test_cheby_batched_streaming_variants_bit_identical(ctx, batch):
+    """Knob of the batched kernel: the nontemporal variant (picked automatically for panels larger than the caches, forced here
+    on a small one) changes the memory access pattern only -- every (row, state) element sees the same FMA sequence; panels of
+    40 states (tiles of 16) and of 8 (one tile)."""
+    N = 1500
     rp, col, vals = synth.hermitian_offsets_csr(N, offsets=(1, 2, 3, 4, 16, 32, 48, 300))
     Op = L.Operator(ctx, [L.Matrix(ctx, N, N, rp, col, vals)])
     states = np.stack([synth.random_state(N, seed=2000 + s) for s in range(batch)], axis=1)
@@ -1905,7 +1900,6 @@ def test_cheby_batched_streaming_variants_bit_identical(ctx, tile):
     try:
         for nt in (0, 2):
             L.tuning_set("spmm_nt", nt)
-            L.tuning_set("spmm_tile", tile)
             wrk = L.ChebyWrk(ctx, N * batch, 20.0, -10.0, 0.9)
             panel = L.State(ctx, data=states.reshape(-1))
             for dt in (0.9, -0.9, 0.9):
@@ -1913,9 +1907,7 @@ def test_cheby_batched_streaming_variants_bit_identical(ctx, tile):
             outs[nt] = panel.numpy()
     finally:
         L.tuning_set("spmm_nt", 1)
-        L.tuning_set("spmm_tile", 16)
     assert np.array_equal(outs[0], outs[2])
-    L.tuning_set("spmm_tile", 16)
     wrk = L.ChebyWrk(ctx, N * batch, 20.0, -10.0, 0.9)
     panel = L.State(ctx, data=states.reshape(-1))
     for dt in (0.9, -0.9, 0.9):
@@ -1938,12 +1930,10 @@ def test_cheby_batched_rows_kernel_and_row_walk_bit_identical(ctx, batch):
     states = np.stack([synth.random_state(N, seed=3000 + s) for s in range(batch)], axis=1)
     outs, walks = {}, {}
     try:
-        for rows, strip, rw in ((0, 0, 1), (1, -1, 1), (1, 0, 1), (1, 32, 1), (1, 64, 1), (1, 48, 1), (1, 32, 2), (1, 64, 4), (1, -1, 8), (1, -1, 0), (1, 0, 0), (1, 64, 0),
-                                (1, 0, -4), (1, 64, -16)):
+        for rows, strip, rw in ((0, 0, 1), (1, -1, 1), (1, 0, 1), (1, 32, 1), (1, 64, 1), (1, 48, 1), (1, 32, 2), (1, 64, 4), (1, -1, 8), (1, -1, 0), (1, 0, 0), (1, 64, 0)):
             ctx.tuning_set("spmm_rows", rows)
             ctx.tuning_set("spmm_strip", strip)
-            ctx.tuning_set("spmm_rw", max(rw, 0))
-            ctx.tuning_set("spmm_wg", -rw if rw < 0 else 8)      # negative: scalar-entry kernel with that many wavefronts per workgroup
+            ctx.tuning_set("spmm_rw", rw)
             wrk = L.ChebyWrk(ctx, N * batch, 20.0, -10.0, 0.7)
             panel = L.State(ctx, data=states.reshape(-1))
             for dt in (0.7, -0.7, 0.7):
@@ -1955,7 +1945,6 @@ def test_cheby_batched_rows_kernel_and_row_walk_bit_identical(ctx, batch):
         ctx.tuning_set("spmm_rows", 1)
         ctx.tuning_set("spmm_strip", 0)
         ctx.tuning_set("spmm_rw", 0)
-        ctx.tuning_set("spmm_wg", 8)
     ref = outs[(0, 0, 1)]
     for k, v in outs.items():
         assert np.array_equal(v, ref), k
@@ -1966,47 +1955,6 @@ def test_cheby_batched_rows_kernel_and_row_walk_bit_identical(ctx, batch):
     for s in (0, batch - 1):
         r = qo.cheby(states[:, s].copy(), H, 0.7, owrk)
         assert np.linalg.norm(ref.reshape(N, batch)[:, s] - r) < TOL
-
-
-@pytest.mark.parametrize("N,offsets,diag,batch", [
-    (1 << 15, (1, 2, 3, 4, 256, 512, 768, 1024), False, 64),
-    (1 << 15, (1, 2, 3, 4, 256, 512, 768, 1024), True, 40),      # 17 entries per row, lanes beyond the panel idle
-    (1 << 14, (1, 3, 128, 256), False, 64),
-    (1 << 14, (2, 5, 192, 384), True, 33),
-], ids=["16nnz", "17nnz_b40", "8nnz", "9nnz_b33"])
-def test_cheby_batched_strip_walk_bit_identical(ctx, N, offsets, diag, batch):
-    """The strip walk of the batched term (kernels_spmm_walk.hip: far rows of X in a register ring down one inner index,
-    the matrix row as one vector load broadcast lane by lane, everything requested one step ahead; the rows next to the
-    periodic wrap stay with the wave-per-row kernel) sums every (row, state) in the order of the other batched kernels:
-    bit-identical panels, for any cut of the walk into wavefronts -- and the oracle's cheby! state by state."""
-    rp, col, vals = synth.hermitian_offsets_csr(N, offsets=offsets)
-    if diag:
-        rp, col, vals = _with_diagonal(rp, col, vals, N)
-    Op = L.Operator(ctx, [L.Matrix(ctx, N, N, rp, col, vals)])
-    states = np.stack([synth.random_state(N, seed=900 + s) for s in range(batch)], axis=1)
-    wrk = L.ChebyWrk(ctx, N * batch, 24.0, -12.0, 0.8)
-    saved = {k: ctx.tuning_get(k) for k in ("spmm_walk", "spmm_walk_waves")}
-    outs = {}
-    try:
-        for name, knobs in (("rows", dict(spmm_walk=0)), ("walk", dict(spmm_walk=1, spmm_walk_waves=0)),
-                            ("walk_1seg", dict(spmm_walk=1, spmm_walk_waves=1)), ("walk_many", dict(spmm_walk=1, spmm_walk_waves=20000))):
-            for k, v in knobs.items():
-                ctx.tuning_set(k, v)
-            panel = L.State(ctx, data=states.reshape(-1).copy())
-            L.cheby_batched(panel, Op, 0.8, wrk, batch)
-            L.cheby_batched(panel, Op, -0.8, wrk, batch)
-            L.cheby_batched(panel, Op, 0.8, wrk, batch)
-            outs[name] = panel.numpy().reshape(N, batch)
-    finally:
-        for k, v in saved.items():
-            ctx.tuning_set(k, v)
-    for name in ("walk", "walk_1seg", "walk_many"):
-        assert np.array_equal(outs["rows"], outs[name]), name
-    H = synth.to_scipy(rp, col, vals, N)
-    for s in (0, batch // 2, batch - 1):
-        psi = states[:, s].copy()
-        qo.cheby(psi, H, 0.8, qo.ChebyWrk(psi, 24.0, -12.0, 0.8))
-        assert np.linalg.norm(outs["walk"][:, s] - psi) < TOL, s
 
 
 def test_spmm_row_walk_detection(ctx):

@@ -16,8 +16,8 @@ import qprop_amd.synth as synth  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-10
-KNOBS = ("hrb_walk", "walk_pair", "walk2_waves", "walk_min_blocks", "walk_nt", "walk_waves")
-DEFAULTS = {"hrb_walk": 1, "walk_pair": -1, "walk2_waves": 0, "walk_min_blocks": 3072, "walk_nt": -1, "walk_waves": 0}
+KNOBS = ("hrb_walk", "walk_pair", "walk_min_blocks", "walk_nt", "walk_waves")
+DEFAULTS = {"hrb_walk": 1, "walk_pair": -1, "walk_min_blocks": 3072, "walk_nt": -1, "walk_waves": 0}
 
 
 @pytest.fixture()
@@ -44,7 +44,13 @@ def _with_diagonal(rp, col, vals, N, seed=3):
     (1 << 15, (2, 16, 192, 384), True, False, (2, 2, 1)),                  # near reach 16: chunks of 32 useful rows
     (1 << 14, (1, 64), True, False, (1, 1, 1)),                            # the five-point stencil of a periodic 64 x 256 grid
     (1 << 15, (5, 320), False, False, (1, 1, 0)),
-], ids=["headline", "g64+diag", "real", "near2far2", "near2far2+diag_d16", "5point", "near1far1_g320"])
+    (1 << 16, (2, 5, 9, 320, 640, 960), False, False, (3, 3, 0)),
+    (1 << 15, (1, 2, 3, 4, 256, 512), True, False, (4, 2, 1)),
+    (1 << 15, (3, 128, 256, 384), False, False, (1, 3, 0)),
+    (1 << 15, (1, 2, 7, 192), True, True, (3, 1, 1)),
+    (1 << 16, (1, 6, 128, 256, 384, 512), False, False, (2, 4, 0)),
+], ids=["headline", "g64+diag", "real", "near2far2", "near2far2+diag_d16", "5point", "near1far1_g320", "near3far3", "near4far2+diag",
+        "near1far3", "near3far1_real+diag", "near2far4"])
 def test_two_term_walk_bit_identical_to_one_term_launches(ctx, N, offsets, diag, real, shape):
     rp, col, vals = synth.hermitian_offsets_csr(N, offsets=offsets)
     if real:
@@ -77,8 +83,8 @@ def test_two_term_walk_bit_identical_to_one_term_launches(ctx, N, offsets, diag,
             base, t0 = run(hrb_walk=0)                                 # the per-block kernel, one term per launch
             one, t1 = run(walk_pair=0)                                 # the one-term strip walk
             assert t0 == 0 and t1 == 0 and np.array_equal(base, one)
-            for knobs in (dict(walk_pair=1), dict(walk_pair=1, walk2_waves=64), dict(walk_pair=1, walk2_waves=4096),
-                          dict(walk_pair=1, walk2_waves=200, walk_nt=0), dict(walk_pair=1, walk2_waves=1, walk_nt=1)):
+            for knobs in (dict(walk_pair=1), dict(walk_pair=1, walk_waves=64), dict(walk_pair=1, walk_waves=4096),
+                          dict(walk_pair=1, walk_waves=200, walk_nt=0), dict(walk_pair=1, walk_waves=1, walk_nt=1)):
                 got, taken = run(**knobs)
                 assert taken == 1, knobs
                 assert np.array_equal(base, got), (dt, knobs, float(np.max(np.abs(base - got))))

@@ -1,5 +1,4 @@
-"""Measured points shared by bench.py (the extra keys of its JSON line) and the per-config tools
-(kbench.py, bench_newton.py, bench_batched.py): byte models of the SHIPPED device layouts and short
+"""Measured points shared by bench.py (the extra keys of its JSON line) and the tools (kbench.py, point.py): byte models of the SHIPPED device layouts and short
 single-GPU measurements of the other BASELINE configs / patterns.  Everything here calls the product
 path through the C ABI (qprop_amd.lib); nothing imports the oracle."""
 import gc

@@ -92,7 +92,7 @@ def main():
         for walk in (0, 1):
             ctx.tuning_set("hrb_walk", walk)
             ctx.tuning_set("walk_waves", int(rng.choice([0, 16, 64, 256, 1024, 4096])) if walk else 0)
-            ctx.tuning_set("walk_wg", int(rng.choice([0, 2, 4, 8])) if walk else 0)
+            ctx.tuning_set("walk_pair", int(rng.choice([-1, 0, 1])) if walk else -1)      # (the two-term walk where the operator has a plan for it)
             ctx.tuning_set("walk_nt", int(rng.choice([-1, 0, 1])) if walk else -1)
             ctx.tuning_set("walk_dbg", int(rng.choice([0, 1, 4, 5])) if walk else 0)
             psi = L.State(ctx, data=psi0)
@@ -113,7 +113,7 @@ def main():
                   f"walk={wi} |walk - oracle|={err:.3e} bit-identical={same}", flush=True)
         for h in (Op, wrk, *mats):
             h.close()
-    for k, v in (("hrb_walk", 1), ("walk_waves", 0), ("walk_wg", 0), ("walk_nt", -1), ("walk_dbg", 0)):
+    for k, v in (("hrb_walk", 1), ("walk_waves", 0), ("walk_pair", -1), ("walk_nt", -1), ("walk_dbg", 0)):
         ctx.tuning_set(k, v)
     print(f"{ncases} cases drawn (seed {seed}), {walked} took the strip walk, {bad} bad, worst |walk - oracle| = {worst:.3e}")
     sys.exit(1 if bad else 0)

@@ -1153,7 +1153,8 @@ def main():
                     extras[name] = bp.measure_cheby(ctx, **kw)
                 except Exception as e:  # noqa: BLE001  (an extra point must not take the headline down)
                     extras[name] = {"error": f"{type(e).__name__}: {e}"}
-            for name, fn in (("c3_newton", bp.measure_newton_c3),
+            for name, fn in (("tfim20_pauli", lambda c: bp.measure_pauli(c, spins=20, steps=5)),
+                             ("c3_newton", bp.measure_newton_c3),
                              ("c3_newton_n2048", lambda c: bp.measure_newton_c3(c, n=2048, steps=3, warmup=4)),
                              ("c5_batched", bp.measure_batched_c5),
                              ("c5_batched_8", lambda c: bp.measure_batched_c5(c, batch=8, steps=20)),

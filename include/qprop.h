@@ -386,6 +386,22 @@ int qp_cheby_term_split(qp_operator* op, qp_split* sp, void* boundary_stream, in
  * The result is a qp_operator of size n^2: qp_mul, qp_dot_op, the Arnoldi / Newton / specrange
  * entry points and qp_cheby_step accept it (qp_cheby_step with an unfused epilogue); the entry
  * points that need stored entries (get_csr, split, batched, persistent kernels) do not. */
+/* ---- qubit registers: H = sum_l c_l H_l with every H_l a sum of Pauli strings, applied from the strings (no stored matrix) ----
+ * The reference's generator for a register of n qubits is the usual lazy sum of sparse matrices (src/generators.jl:634-645 mul!);
+ * when those matrices are sums of Pauli strings  a P,  P = sigma_{n-1} (x) ... (x) sigma_0  (qubit i = bit i of the basis index),
+ * this operator applies them from the bit masks:  xmask = the qubits with X or Y, zmask = those with Z or Y (a Y is in both),
+ *     (P psi)[r] = i^{#Y} (-1)^{popcount((r xor xmask) and zmask)} psi[r xor xmask]
+ * -- zero matrix bytes per term.  `op` = which H_l of the lazy sum a string belongs to (the first nops - ncoeffs terms are the drift,
+ * the others carry the coefficients of qp_operator_set_coeffs: evaluate! rewrites a few hundred numbers).  6 <= nqubits <= 30.
+ * The result is a qp_operator of size 2^nqubits (QP_FMT_MATFREE): qp_cheby_step (fused term), qp_mul, qp_dot_op, the Arnoldi /
+ * Newton / specrange entry points accept it; the entry points that need stored entries do not. */
+typedef struct {
+  uint64_t xmask, zmask;
+  qp_c128 coef;      /* the string's amplitude a (real for a Hermitian H; the factor i^{#Y} is applied by the library) */
+  int op;            /* 0 .. nops - 1 */
+} qp_pauli_string;
+int qp_pauli_operator_create(qp_ctx* ctx, int nqubits, const qp_pauli_string* strings, int nstrings, int nops, int ncoeffs,
+                             qp_operator** out);
 int qp_liouvillian_create(qp_ctx* ctx, int64_t n, const qp_c128* const* H_terms, int nterms,
                           int ncoeffs, const qp_c128* const* c_ops, int nc, int convention,
                           qp_operator** out);

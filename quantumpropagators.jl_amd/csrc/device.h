@@ -67,6 +67,8 @@ struct DevMatrix {
   int (*matfree_apply)(hipStream_t s, void* self, const double2* x, double2* y, double2 alpha, double2 beta,
                        Stats* st) = nullptr;
   double2* (*matfree_scratch)(void* self) = nullptr;   // n entries of workspace for the Chebyshev term
+  // optional: the fused Chebyshev term of the owner's own kernel (engine_pauli.hip); without it the term is apply + epilogue
+  int (*matfree_cheby)(hipStream_t s, void* self, const double2* x, const struct ChebyEpi& e, Stats* st) = nullptr;
 };
 
 // ---- strip walk over a lattice operator (Hermitian-packed format) -----------------------------------------------

@@ -525,6 +525,7 @@ int launch_spmv_cheby(hipStream_t s, const DevMatrix& A, const double2* x, const
   if (A.format == QP_FMT_MATFREE) {
     if (rs) return fail(QP_E_BAD_ARG, "row sets need a row-block format");
     if (e.check_partials) return fail(QP_E_BAD_ARG, "check_normalization is not available for a matrix-free operator");
+    if (A.matfree_cheby && e.xloc == x && !e.mirror) return A.matfree_cheby(s, A.matfree, x, e, st);
     double2* tmp = A.matfree_scratch(A.matfree);
     int rc = A.matfree_apply(s, A.matfree, x, tmp, make_double2(1.0, 0.0), make_double2(0.0, 0.0), st);
     if (rc != QP_OK) return rc;

@@ -89,6 +89,10 @@ class qp_sharded_cheby_desc(C.Structure):
                 ("recv_from", C.POINTER(C.c_int)), ("n_recv_from", C.c_int)]
 
 
+class qp_pauli_string(C.Structure):
+    _fields_ = [("xmask", C.c_uint64), ("zmask", C.c_uint64), ("coef", qp_c128), ("op", C.c_int)]
+
+
 class qp_prop_spec(C.Structure):
     _fields_ = [("method", C.c_int), ("cheby", C.c_void_p), ("a", C.POINTER(C.c_double)), ("n_coeffs", C.c_int),
                 ("Delta", C.c_double), ("E_min", C.c_double), ("wrk_dt", C.c_double), ("limit", C.c_double),
@@ -182,6 +186,7 @@ SIGNATURES = {
                                       C.c_double, C.c_double, qp_c128, C.POINTER(qp_acc_defer)]),
     "qp_liouvillian_create": (C.c_int, [_P, C.c_int64, C.POINTER(_cp), C.c_int, C.c_int, C.POINTER(_cp), C.c_int,
                                         C.c_int, C.POINTER(_P)]),
+    "qp_pauli_operator_create": (C.c_int, [_P, C.c_int, C.POINTER(qp_pauli_string), C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "qp_comm_unique_id": (C.c_int, [C.c_char_p, C.c_char_p]),
     "qp_comm_create": (C.c_int, [_P, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(_P)]),
     "qp_comm_prepare": (C.c_int, [_P, C.c_char_p, C.c_int, C.c_int, C.POINTER(_P)]),
@@ -696,6 +701,50 @@ class Operator:
 
 
 CONV_TDSE, CONV_LVN = 0, 1
+
+
+def pauli_masks(string):
+    """'XIZY' (qubit n-1 first, as one writes a tensor product) or a dict {qubit: 'X'|'Y'|'Z'} -> (xmask, zmask)."""
+    if isinstance(string, dict):
+        items = string.items()
+    else:
+        n = len(string)
+        items = ((n - 1 - k, ch) for k, ch in enumerate(string))
+    x = z = 0
+    for q, ch in items:
+        ch = ch.upper()
+        if ch in "XY":
+            x |= 1 << q
+        if ch in "ZY":
+            z |= 1 << q
+        if ch not in "IXYZ":
+            raise ValueError(f"not a Pauli label: {ch!r}")
+    return x, z
+
+
+class PauliOperator(Operator):
+    """Qubit-register generator applied from its Pauli strings, no stored matrix (include/qprop.h, qp_pauli_operator_create):
+    ``terms[l]`` = the strings of H_l of the lazy sum  sum_l c_l H_l  as (amplitude, string) pairs, string = 'XIZY'-style label
+    (qubit n-1 first), {qubit: label} dict, or an (xmask, zmask) pair of bit masks; the last ``ncoeffs`` terms carry the
+    coefficients of ``set_coeffs`` (the others are the drift), as for :class:`Operator`."""
+
+    def __init__(self, ctx, nqubits, terms, ncoeffs=0):
+        self.ctx, self.lib = ctx, ctx.lib
+        flat = []
+        for l, strings in enumerate(terms):
+            for amp, st in strings:
+                xm, zm = st if (isinstance(st, tuple) and len(st) == 2 and all(isinstance(v, (int, np.integer)) for v in st)) else pauli_masks(st)
+                flat.append((int(xm), int(zm), complex(amp), l))
+        arr = (qp_pauli_string * max(len(flat), 1))()
+        for k, (xm, zm, amp, l) in enumerate(flat):
+            arr[k].xmask, arr[k].zmask, arr[k].coef, arr[k].op = xm, zm, qp_c128(amp.real, amp.imag), l
+        self._h = _P()
+        check(self.lib.qp_pauli_operator_create(ctx._h, int(nqubits), arr, len(flat), len(terms), int(ncoeffs), C.byref(self._h)))
+        self.ops = []
+        self.ncoeffs = int(ncoeffs)
+        self.nqubits = int(nqubits)
+        self._refresh_info()
+        ctx._adopt(self)
 
 
 class Liouvillian(Operator):

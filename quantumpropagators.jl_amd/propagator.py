@@ -24,7 +24,7 @@ import scipy.sparse as sp
 
 from . import lib as L
 
-__all__ = ["Generator", "hamiltonian", "liouvillian", "MatrixFreeLiouvillian", "init_prop", "prop_step", "reinit_prop", "set_state", "set_t",
+__all__ = ["Generator", "hamiltonian", "liouvillian", "MatrixFreeLiouvillian", "PauliSum", "init_prop", "prop_step", "reinit_prop", "set_state", "set_t",
            "propagate", "ode_function", "QuantumODEFunction", "ChebyPropagator", "NewtonPropagator", "discretize", "discretize_on_midpoints"]
 
 
@@ -144,6 +144,32 @@ def hamiltonian(*terms):
     return Generator(ops, ampl)
 
 
+class PauliSum:
+    """A qubit-register operator given as a sum of Pauli strings, ``PauliSum(n, [(amplitude, 'XIZY' | {qubit: 'X'} | (xmask, zmask)), ...])``
+    -- usable wherever :func:`hamiltonian` takes a matrix: ``hamiltonian(PauliSum(n, zz), (PauliSum(n, x), eps))``.  A generator
+    whose operators are all PauliSums goes to the device as ``lib.PauliOperator`` (applied from the bit masks: no stored matrix,
+    include/qprop.h qp_pauli_operator_create); ``+`` concatenates the strings, ``toarray()`` / ``tocsr()`` build the matrix (what the
+    reference would be handed: the oracle's input in the tests)."""
+
+    def __init__(self, nqubits, strings):
+        self.nqubits = int(nqubits)
+        self.strings = [(complex(a), st if (isinstance(st, tuple) and len(st) == 2 and not isinstance(st[0], str)) else L.pauli_masks(st))
+                        for a, st in strings]
+        self.shape = (1 << self.nqubits, 1 << self.nqubits)
+
+    def __add__(self, other):
+        if not isinstance(other, PauliSum) or other.nqubits != self.nqubits:
+            return NotImplemented
+        return PauliSum(self.nqubits, self.strings + other.strings)
+
+    def tocsr(self):
+        from . import synth
+        return synth.pauli_sum_matrix(self.nqubits, self.strings)
+
+    def toarray(self):
+        return self.tocsr().toarray()
+
+
 class MatrixFreeLiouvillian:
     """What :func:`liouvillian` returns for ``matrix_free=True``: the Hamiltonian terms, the
     amplitudes of the controlled ones and the Lindblad operators, kept as n x n matrices.  On
@@ -210,9 +236,15 @@ class _DeviceGenerator:
             self.op = L.Liouvillian(ctx, generator.ops, generator.c_ops, ncoeffs=len(self.controls),
                                     convention=generator.convention)
             return
+        if isinstance(generator, PauliSum) or (isinstance(generator, Generator) and generator.ops and
+                                               all(isinstance(A, PauliSum) for A in generator.ops)):
+            ops = [generator] if isinstance(generator, PauliSum) else generator.ops
+            self.controls = [] if isinstance(generator, PauliSum) else list(generator.amplitudes)
+            self.op = L.PauliOperator(ctx, ops[0].nqubits, [A.strings for A in ops], ncoeffs=len(self.controls))
+            return
         if isinstance(generator, Generator):
             self.controls = list(generator.amplitudes)
-            mats = [_to_matrix(ctx, A) for A in generator.ops]
+            mats = [_to_matrix(ctx, A.tocsr() if isinstance(A, PauliSum) else A) for A in generator.ops]
         elif isinstance(generator, L.Operator):
             self.controls = []
             self.op = generator

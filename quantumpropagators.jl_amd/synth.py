@@ -373,6 +373,46 @@ def tfim_csr(n, J=1.0, h=1.0, hz=0.1):
     return rowptr, cols.reshape(-1).astype(np.int32), vals.reshape(-1)
 
 
+def tfim_pauli_terms(n, J=1.0, h=1.0, hz=0.1):
+    """The strings of tfim_csr(n, J, h, hz) for lib.PauliOperator: [(amplitude, (xmask, zmask)), ...] -- one term of the lazy sum."""
+    out = [(-J, (0, (1 << i) | (1 << (i + 1)))) for i in range(n - 1)]
+    out += [(-hz, (0, 1 << i)) for i in range(n)]
+    out += [(-h, (1 << i, 0)) for i in range(n)]
+    return out
+
+
+def xxz_pauli_terms(n, J=1.0, delta=0.5, hz=0.05):
+    """The strings of xxz_csr(n, J, delta, hz): J/2 (XX + YY) + delta ZZ per bond, hz (i + 1) / n Z_i per site."""
+    out = []
+    for i in range(n - 1):
+        b = (1 << i) | (1 << (i + 1))
+        out += [(0.5 * J, (b, 0)), (0.5 * J, (b, b)), (delta, (0, b))]      # XX, YY (x = z = both bits), ZZ
+    out += [(hz * (i + 1) / n, (0, 1 << i)) for i in range(n)]
+    return out
+
+
+def pauli_sum_matrix(n, strings):
+    """scipy CSR matrix of sum a P from explicit Kronecker products of the 2 x 2 Pauli matrices (qubit i = bit i of the index:
+    the factor of qubit n - 1 comes first in the product) -- an independent construction for the tests of the mask arithmetic."""
+    import scipy.sparse as sp
+    sig = {"I": sp.identity(2, dtype=np.complex128, format="csr"),
+           "X": sp.csr_matrix(np.array([[0, 1], [1, 0]], dtype=np.complex128)),
+           "Y": sp.csr_matrix(np.array([[0, -1j], [1j, 0]], dtype=np.complex128)),
+           "Z": sp.csr_matrix(np.array([[1, 0], [0, -1]], dtype=np.complex128))}
+    N = 1 << n
+    H = sp.csr_matrix((N, N), dtype=np.complex128)
+    for amp, (xm, zm) in strings:
+        M = None
+        for q in range(n - 1, -1, -1):
+            xb, zb = (xm >> q) & 1, (zm >> q) & 1
+            f = sig["Y" if (xb and zb) else "X" if xb else "Z" if zb else "I"]
+            M = f if M is None else sp.kron(M, f, format="csr")
+        H = H + complex(amp) * M
+    H = H.tocsr()
+    H.sort_indices()
+    return H
+
+
 def xxz_csr(n, J=1.0, delta=0.5, hz=0.05):
     """XXZ Heisenberg chain of n spins (open ends): H = J sum_i (sx sx + sy sy)_{i,i+1} / 2 + delta sz sz + hz sum_i (i + 1) sz_i / n.
     The exchange term couples row and row XOR (3 << i) where spins i, i + 1 differ: the number of entries of a row is its number

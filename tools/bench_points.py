@@ -246,6 +246,42 @@ def pattern_csr(pattern, N, row_begin=0, row_end=None):
     raise ValueError(pattern)
 
 
+def measure_pauli(ctx, spins=20, model="tfim", steps=10, warmup=2, repeats=3):
+    """Cheby prop_step! of a qubit-register generator applied from its Pauli strings (csrc/engine_pauli.hip: no stored matrix): the
+    transverse-field Ising / XXZ chain of `spins` spins, alpha = 10 as the headline.  Bytes per term: the vectors alone."""
+    N = 1 << spins
+    strings = synth.tfim_pauli_terms(spins) if model == "tfim" else synth.xxz_pauli_terms(spins)
+    bound = float(sum(abs(complex(a)) for a, _ in strings))
+    window = (2.2 * bound, -1.1 * bound)
+    dt = 20.0 / window[0]
+    op = L.PauliOperator(ctx, spins, [strings])
+    wrk = L.ChebyWrk(ctx, N, window[0], window[1], dt)
+    psi = L.State(ctx, data=synth.random_state(N))
+    nterms = wrk.n_coeffs - 1
+    for _ in range(warmup):
+        L.cheby(psi, op, dt, wrk)
+    regions = timed_regions(ctx, lambda: L.cheby(psi, op, dt, wrk), steps, repeats)
+    sp = spread([1e3 * r[0] / (steps * nterms) for r in regions], regions)
+    t_term = sp["median"] * 1e-6
+    sched = L.acc_schedule(wrk.coeffs)
+    vec, updated = 0.0, False
+    for m in range(1, nterms + 1):      # x once (its partners are permuted lines of the same vector), v_{m-2}, v_m, the accumulator by the schedule
+        vec += 16.0 * N + (16.0 * N if m >= 2 else 0.0) + (16.0 * N if m < nterms else 0.0)
+        if not sched[m - 1].skip:
+            vec += (32.0 if updated else 16.0) * N
+            updated = True
+    per_term = vec / nterms
+    out = {"pattern": f"{'transverse-field Ising' if model == 'tfim' else 'XXZ'} chain, {spins} spins, from its {len(strings)} Pauli strings (matrix-free)",
+           "N": N, "strings": len(strings), "x_mask_groups": len({x for _, (x, _) in strings}), "device_format": FMT_NAME[op.format],
+           "kernel": "pauli_spmv_kernel", "n_coeffs": int(wrk.n_coeffs), "us_per_term": t_term * 1e6, "us_per_term_min": sp["min"],
+           "us_per_term_max": sp["max"], "repeats": sp["repeats"], "unstable": sp["unstable"], "steps_per_s": 1e6 / (t_term * 1e6 * nterms),
+           "layout_bytes_per_term": per_term, "layout_gbs": per_term / t_term / 1e9, "frac": per_term / t_term / 1e9 / HBM_PEAK_GBS,
+           "model": "layout", "norm_drift": abs(psi.norm() - 1.0)}
+    for h in (psi, wrk, op):
+        h.close()
+    return out
+
+
 def measure_cheby(ctx, pattern="banded", log2n=20, fmt="auto", steps=10, warmup=2, real=False, dt=1.0, grid=None, repeats=3,
                   grid_order=2, spins=None, offsets=None):
     """Cheby prop_step! on one GPU for a pattern / size / device format; per-term time from HIP events on

@@ -9,6 +9,7 @@ scripts of rounds 2-5 (bench_newton.py, bench_batched.py, bench_dense.py, bench_
     python tools/point.py cheby --log2n 22 --ab walk_pair=0,1
     python tools/point.py cheby --spins 20 | --grid 2048,2048 | --pattern scattered | --offsets 1,2047,2048,2049
     python tools/point.py dense --batch 64 ; python tools/point.py liouville --n 512
+    python tools/point.py pauli --spins 20 [--pattern xxz]     # qubit register from its Pauli strings (no stored matrix)
 """
 import argparse
 import json
@@ -24,7 +25,7 @@ import bench_points as bp  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("point", choices=["c3", "c5", "cheby", "dense", "liouville"])
+    ap.add_argument("point", choices=["c3", "c5", "cheby", "dense", "liouville", "pauli"])
     ap.add_argument("--n", type=int, default=None, help="c3 / liouville: system size n (N = n^2); dense: N")
     ap.add_argument("--log2n", type=int, default=None)
     ap.add_argument("--batch", type=int, default=None)
@@ -52,6 +53,8 @@ def main():
             return bp.measure_batched_c5(ctx, **{**kw, **({"batch": args.batch} if args.batch else {}), **({"log2n": args.log2n} if args.log2n else {})})
         if args.point == "dense":
             return bp.measure_dense(ctx, **{**kw, **({"N": args.n} if args.n else {}), **({"batch": args.batch} if args.batch else {})})
+        if args.point == "pauli":
+            return bp.measure_pauli(ctx, spins=args.spins or 20, model="xxz" if args.pattern == "xxz" else "tfim", **kw)
         if args.point == "liouville":
             return bp.measure_liouville(ctx, **({"n": args.n} if args.n else {}))
         return bp.measure_cheby(ctx, pattern=args.pattern, fmt=args.format, real=args.real, spins=args.spins,

@@ -48,7 +48,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s measured copy)
 KERNEL_OF_FORMAT = {1: "csr_spmv_kernel", 2: "rbcsr_spmv_kernel", 3: "hrb_spmv_kernel"}
-STATIC_PMC = os.path.join("profiles", "r05", "bench_pmc_summary.json")
+STATIC_PMC = os.path.join("profiles", "r06", "bench_pmc_summary.json")
 
 
 def pmc_traffic(argv_inner, kernel_substr, timeout_s, how="mean"):
@@ -215,10 +215,10 @@ def exchange_model(sh, world, rows, us_per_term):
 
 
 MACHINERY_FACTOR = 74.7 / 68.8      # overlapped native step / plain term at 2^21 rows on one GPU (profiles/r03/sharded_machinery_1gpu.txt)
-STATIC_SIZES = os.path.join("profiles", "r05", "single_gpu_sizes.json")
+STATIC_SIZES = os.path.join("profiles", "r06", "single_gpu_sizes.json")
 
 
-def scaling_prediction(us_per_term_by_log2rows, value_1gpu, nterms, source):
+def scaling_prediction(us_per_term_by_log2rows, value_1gpu, nterms, source, one_term=None):
     """What 1 / 2 / 4 / 8 GPUs of one xGMI node should deliver, from per-term times measured on ONE GPU at the row counts a rank
     would own plus the exchange model -- so that the first real multi-GPU run is read against a table, not a guess.
 
@@ -232,11 +232,14 @@ def scaling_prediction(us_per_term_by_log2rows, value_1gpu, nterms, source):
     WEAK default of `bench.py --gpus G` (2^21 rows per GPU): value in 2^20-row blocks per second against this run's 1-GPU value
     (N = 2^20, Infinity-Cache resident) -- the efficiency the driver will compute."""
     t = {int(k): float(v) for k, v in us_per_term_by_log2rows.items()}
+    # A rank of the row-partitioned step launches its terms one by one (it exchanges after every term): its compute time is the ONE-TERM
+    # walk's, while one GPU alone takes the two-term walk beyond the Infinity Cache (round 6) -- the denominator got faster, the ranks did not.
+    t_rank = {int(k): float(v) for k, v in (one_term or {}).items()}
     startup, link = 10.0, XGMI_LINK_GBS * 1e3      # us, bytes per us
     fixed = []
     for G in (1, 2, 4, 8):
         lg = 24 - G.bit_length() + 1
-        tc = t.get(lg)
+        tc = t.get(lg) if G == 1 else t_rank.get(lg, t.get(lg))
         if tc is None:
             continue
         row = {"gpus": G, "rows_per_gpu": 1 << lg, "us_per_term_compute": tc}
@@ -259,11 +262,11 @@ def scaling_prediction(us_per_term_by_log2rows, value_1gpu, nterms, source):
     weak = []
     if t.get(21):
         for G in (1, 2, 4, 8):
-            per = MACHINERY_FACTOR * t[21] if G > 1 else t[21]
+            per = MACHINERY_FACTOR * t_rank.get(21, t[21]) if G > 1 else t[21]
             v = G * 2.0 * 1e6 / (nterms * per)
             weak.append({"gpus": G, "rows_per_gpu": 1 << 21, "predicted_value_blocks_per_s": v,
                          "predicted_efficiency_vs_1gpu_value": (v / (G * value_1gpu)) if value_1gpu else None})
-    return {"source_of_compute_times": source, "us_per_term_by_log2_rows": t, "terms_per_step": nterms,
+    return {"source_of_compute_times": source, "us_per_term_by_log2_rows": t, "us_per_term_one_term_walk_by_log2_rows": t_rank or None, "terms_per_step": nterms,
             "assumptions": {"xgmi_link_gbs": XGMI_LINK_GBS, "exchange_startup_us": startup, "overlap_machinery_factor": MACHINERY_FACTOR,
                             "halo_rows_per_neighbour": 8192},
             "fixed_problem_N_2^24": fixed, "bench_default_weak_2^21_rows_per_gpu": weak,
@@ -296,7 +299,7 @@ def scaling_prediction_static(nterms):
     with open(path) as f:
         d = json.load(f)
     return scaling_prediction(d["us_per_term_by_log2_rows"], d.get("value_1gpu"), nterms,
-                              f"STATIC: {STATIC_SIZES} (single-GPU run of bench.py on another box)")
+                              f"STATIC: {STATIC_SIZES} (single-GPU run of bench.py on another box)", one_term=d.get("us_per_term_one_term_walk_by_log2_rows"))
 
 
 LINE_LIMIT = 4096          # the driver parses the LAST stdout line; r04's 36 KB line defeated it
@@ -1141,6 +1144,10 @@ def main():
                              ("banded_n22", dict(pattern="banded", log2n=22, steps=5)),
                              ("banded_n23", dict(pattern="banded", log2n=23, steps=4, warmup=3)),
                              ("banded_n24", dict(pattern="banded", log2n=24, steps=4, warmup=3)),
+                             # the one-term walk at the row counts a rank of 8 / 4 / 2 GPUs owns (the row-partitioned step never pairs terms)
+                             ("banded_n21_one_term", dict(pattern="banded", log2n=21, steps=8, knobs={"walk_pair": 0})),
+                             ("banded_n22_one_term", dict(pattern="banded", log2n=22, steps=5, knobs={"walk_pair": 0})),
+                             ("banded_n23_one_term", dict(pattern="banded", log2n=23, steps=4, warmup=3, knobs={"walk_pair": 0})),
                              ("c2_alpha2", dict(pattern="banded", log2n=20, dt=0.2, steps=20)),
                              ("c2_alpha50", dict(pattern="banded", log2n=20, dt=5.0, steps=5)),
                              ("c2_real_f64", dict(pattern="banded", log2n=20, real=True)),
@@ -1246,7 +1253,9 @@ def main():
                        (23, extras.get("banded_n23") or {}), (24, p24)):
             if pt.get("us_per_term"):
                 sizes[lg] = pt["us_per_term"]
-        out["scaling_prediction"] = scaling_prediction(sizes, out["value"], nterms, "measured in this run on one GPU")
+        one_term = {lg: extras[f"banded_n{lg}_one_term"]["us_per_term"] for lg in (21, 22, 23)
+                    if (extras.get(f"banded_n{lg}_one_term") or {}).get("us_per_term")}
+        out["scaling_prediction"] = scaling_prediction(sizes, out["value"], nterms, "measured in this run on one GPU", one_term=one_term)
     out["degraded"] = False
     out["native_path"] = "ok" if world > 1 else None
     if watchdog is not None:

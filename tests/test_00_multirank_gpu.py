@@ -176,7 +176,9 @@ def test_bench_eight_ranks_full_c4_flow_one_gpu():
     # the collective north_star names has a measured point of its own next to the halo headline
     ag = d["allgather_form"]
     assert ag["us_per_term"] > 0 and ag["blocks_per_s"] > 0 and "error" not in ag
-    assert d["prediction"]["fixed_n24_speedup_8gpu_halo"] > 6.0 > d["prediction"]["fixed_n24_speedup_8gpu_allgather"]
+    # (round 6: the denominator is the two-term walk's single-GPU time, 1.6 x faster than round 5's, while a rank still launches its
+    # terms one by one: the predicted ratio for the halo form is ~5, the ranks' absolute rate is what it was)
+    assert d["prediction"]["fixed_n24_speedup_8gpu_halo"] > 4.5 > d["prediction"]["fixed_n24_speedup_8gpu_allgather"]
     # the complete record next to the script
     assert d["extras_file"] == "bench_extras_c4_gpus8.json"
     with open(os.path.join(ROOT, d["extras_file"])) as f:
@@ -188,7 +190,8 @@ def test_bench_eight_ranks_full_c4_flow_one_gpu():
     assert xm["rows_sent_per_rank_per_term"] == 8192 and xm["peers"] == 2
     pred = full["scaling_prediction"]         # the 1 / 2 / 4 / 8 table the first real run is read against
     assert [r["gpus"] for r in pred["fixed_problem_N_2^24"]] == [1, 2, 4, 8]
-    assert pred["fixed_problem_N_2^24"][-1]["speedup_halo_overlap"] > 6.0 > pred["fixed_problem_N_2^24"][-1]["speedup_allgather"]
+    assert pred["fixed_problem_N_2^24"][-1]["speedup_halo_overlap"] > 4.5 > pred["fixed_problem_N_2^24"][-1]["speedup_allgather"]
+    assert pred["us_per_term_one_term_walk_by_log2_rows"]["21"] > pred["us_per_term_by_log2_rows"]["21"] * 0.95
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -49,6 +49,13 @@ def test_scaling_prediction_table():
     assert rows[3]["speedup_allgather"] < 3.0 and rows[1]["speedup_allgather"] < 1.0
     weak = p["bench_default_weak_2^21_rows_per_gpu"]
     assert [w["gpus"] for w in weak] == [1, 2, 4, 8] and 0.8 < weak[3]["predicted_efficiency_vs_1gpu_value"] < 1.0
+    # round 6: one GPU alone takes the two-term walk beyond the Infinity Cache, a rank of the row-partitioned step does not (it exchanges
+    # after every term): the denominator of the fixed problem is the faster single-GPU time, the ranks keep the one-term walk's times
+    p2 = b.scaling_prediction({20: 30.9, 21: 57.0, 22: 103.0, 23: 185.0, 24: 364.0}, 1042.0, 31, "test", one_term={21: 67.0, 22: 136.0, 23: 285.0})
+    r2 = p2["fixed_problem_N_2^24"]
+    assert r2[0]["us_per_term_compute"] == 364.0 and r2[3]["us_per_term_compute"] == 67.0 and r2[1]["us_per_term_compute"] == 285.0
+    assert 4.5 < r2[3]["speedup_halo_overlap"] < 5.5          # 364 / (1.086 x 67): below the 6 x that the one-term denominator gave
+    assert p2["us_per_term_one_term_walk_by_log2_rows"] == {21: 67.0, 22: 136.0, 23: 285.0}
     # a run that lacks a size leaves that row out instead of inventing it
     q = b.scaling_prediction({21: 65.5, 24: 629.6}, 1036.5, 31, "test")
     assert [r["gpus"] for r in q["fixed_problem_N_2^24"]] == [1, 8]

@@ -283,7 +283,21 @@ def measure_pauli(ctx, spins=20, model="tfim", steps=10, warmup=2, repeats=3):
 
 
 def measure_cheby(ctx, pattern="banded", log2n=20, fmt="auto", steps=10, warmup=2, real=False, dt=1.0, grid=None, repeats=3,
-                  grid_order=2, spins=None, offsets=None):
+                  grid_order=2, spins=None, offsets=None, knobs=None):
+    saved = {k: ctx.tuning_get(k) for k in (knobs or {})}
+    for k, v in (knobs or {}).items():
+        ctx.tuning_set(k, v)
+    try:
+        out = _measure_cheby(ctx, pattern, log2n, fmt, steps, warmup, real, dt, grid, repeats, grid_order, spins, offsets)
+    finally:
+        for k, v in saved.items():
+            ctx.tuning_set(k, v)
+    if knobs:
+        out["knobs"] = dict(knobs)
+    return out
+
+
+def _measure_cheby(ctx, pattern, log2n, fmt, steps, warmup, real, dt, grid, repeats, grid_order, spins, offsets):
     """Cheby prop_step! on one GPU for a pattern / size / device format; per-term time from HIP events on
     the kernels' stream -- the MEDIAN of `repeats` timed regions of `steps` steps, with min, max and an `unstable` flag --;
     layout-byte and CSR-equivalent rates.  grid = (nx, ny): the finite-difference Hamiltonian of an

@@ -10,7 +10,9 @@ import sys
 line = json.load(open(sys.argv[1]))
 sp = line["scaling_prediction"]
 out = {"source": f"{sys.argv[1]}: python bench.py on one MI355X (value {line['value']:.1f} {line['unit']})",
-       "value_1gpu": line["value"], "us_per_term_by_log2_rows": sp["us_per_term_by_log2_rows"]}
+       "value_1gpu": line["value"], "us_per_term_by_log2_rows": sp["us_per_term_by_log2_rows"],
+       # what a rank of the row-partitioned step achieves (terms one by one): the one-term walk's times
+       "us_per_term_one_term_walk_by_log2_rows": sp.get("us_per_term_one_term_walk_by_log2_rows")}
 with open(sys.argv[2], "w") as f:
     json.dump(out, f, indent=1)
     f.write("\n")

@@ -268,60 +268,98 @@ __global__ __launch_bounds__(64 * WS) void arnoldi_onepass_kernel(
   for (int k = 0; k <= JT; ++k) d[k] = g[k] = make_double2(0.0, 0.0);
   double aa = 0.0;
   const int rounds = (int)((nblocks + (int64_t)gridDim.x * WS - 1) / ((int64_t)gridDim.x * WS));
-  for (int t = 0; t < rounds; ++t) {
-    const int64_t b = ((int64_t)t * gridDim.x + wg) * WS + wave;
-    const bool active = b < nblocks;   // (wave-uniform)
-    const int64_t bc = active ? b : nblocks - 1;
-    const int64_t row = bc * kRB + lane;
-    const bool valid = active && row < nrows;
-    const int64_t rowc = row < nrows ? row : nrows - 1;
-    const unsigned ro = (unsigned)rowc;   // (the launcher takes this kernel only below 2^28 rows)
-    const double2 ar = a_in[ro];
-    // first chunk of the basis: in flight during the mat-vec
-    double2 qa[4], qb[4];
+  // NBK row blocks in flight per wavefront.  The accumulators are per WAVEFRONT, not per block, so a second block costs only its
+  // streams' registers -- and with the register file of a SIMD to one wavefront (WS = 4) there is room: every phase of a round
+  // (the gathers of the mat-vec, the first sweep over the basis rows, the second) then has two blocks' loads in flight, and a
+  // column takes half as many rounds of dependent memory latencies (N = 2^18: 2 instead of 4).  Block order inside a wavefront and
+  // the order of every sum are unchanged: the same bits as with one block at a time.
+  // (JT <= 12 only: with 2 (JT + 1) = 34 / 42 complex accumulators the second block's streams no longer fit the 512 registers of a
+  // wavefront that has the SIMD to itself -- 60 / 580 bytes of scratch per lane at JT = 16 / 20)
+  constexpr int NBK = (WS == 4 && JT <= 12) ? 2 : 1;
+  for (int t = 0; t < rounds; t += NBK) {
+    bool valid[NBK];
+    int64_t rows[NBK], bcs[NBK];
+    unsigned ro[NBK];
+    double2 ar[NBK], qa[NBK][4], qb[NBK][4], z[NBK], u[NBK], y[NBK], qn[NBK], an[NBK];
+    bool act[NBK];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) qa[u] = (Qs + (size_t)min(u, nbl) * ldqs)[ro];
-    double2 z = make_double2(0.0, 0.0);
-    if constexpr (MV) {
-      const int64_t base = bptr[bc];
-      const int nq = active ? (int)((bptr[bc + 1] - base) >> 8) : 0;
-      const VT* __restrict__ v = vals + base + lane;
-      const int64_t cm = cmeta[bc];
-      double2 s0a = make_double2(0.0, 0.0), s1a = make_double2(0.0, 0.0);
-#pragma unroll 2
-      for (int q = 0; q < nq; ++q) {
-        const int4 cc = ld_cols<NT>(colbytes, cm, q, lane, (int)rowc);
-        const double2 a0 = ld_val<NT>(v + (size_t)(4 * q + 0) * 64);
-        const double2 a1 = ld_val<NT>(v + (size_t)(4 * q + 1) * 64);
-        const double2 a2 = ld_val<NT>(v + (size_t)(4 * q + 2) * 64);
-        const double2 a3 = ld_val<NT>(v + (size_t)(4 * q + 3) * 64);
-        const double2 x0 = a_in[cc.x];
-        const double2 x1 = a_in[cc.y];
-        const double2 x2 = a_in[cc.z];
-        const double2 x3 = a_in[cc.w];
-        cfma(s0a, a0, x0);
-        cfma(s1a, a1, x1);
-        cfma(s0a, a2, x2);
-        cfma(s1a, a3, x3);
-      }
-      z = make_double2(s0a.x + s1a.x, s0a.y + s1a.y);
+    for (int j = 0; j < NBK; ++j) {
+      const int64_t b = ((int64_t)(t + j) * gridDim.x + wg) * WS + wave;
+      act[j] = (t + j) < rounds && b < nblocks;   // (wave-uniform)
+      bcs[j] = act[j] ? b : nblocks - 1;
+      rows[j] = bcs[j] * kRB + lane;
+      valid[j] = act[j] && rows[j] < nrows;
+      const int64_t rowc = rows[j] < nrows ? rows[j] : nrows - 1;
+      ro[j] = (unsigned)rowc;   // (the launcher takes this kernel only below 2^28 rows)
+      ar[j] = a_in[ro[j]];
+      // first chunk of the basis: in flight during the mat-vec
+#pragma unroll
+      for (int e = 0; e < 4; ++e) qa[j][e] = (Qs + (size_t)min(e, nbl) * ldqs)[ro[j]];
+      z[j] = make_double2(0.0, 0.0);
     }
-    // ---- first sweep over the block's basis rows (from memory, chunks of four, one chunk ahead): the projection of a_t
+    if constexpr (MV) {
+      int64_t base[NBK], cm[NBK];
+      int nq[NBK];
+      const VT* __restrict__ v[NBK];
+      double2 s0a[NBK], s1a[NBK];
+      int nqm = 0;
+#pragma unroll
+      for (int j = 0; j < NBK; ++j) {
+        base[j] = bptr[bcs[j]];
+        nq[j] = act[j] ? (int)((bptr[bcs[j] + 1] - base[j]) >> 8) : 0;
+        v[j] = vals + base[j] + lane;
+        cm[j] = cmeta[bcs[j]];
+        s0a[j] = s1a[j] = make_double2(0.0, 0.0);
+        nqm = max(nqm, nq[j]);
+      }
+      (void)nqm;
+      // (one block after the other: the gathers of a block are four to eight lines, and holding both blocks' values and operands at
+      // once spilled 520 bytes per lane next to the 2 (JT + 1) accumulators; the sweeps over the basis rows below are interleaved)
+#pragma unroll
+      for (int j = 0; j < NBK; ++j) {
+#pragma unroll 2
+        for (int q = 0; q < nq[j]; ++q) {
+          const int4 cc = ld_cols<NT>(colbytes, cm[j], q, lane, (int)ro[j]);
+          const double2 a0 = ld_val<NT>(v[j] + (size_t)(4 * q + 0) * 64);
+          const double2 a1 = ld_val<NT>(v[j] + (size_t)(4 * q + 1) * 64);
+          const double2 a2 = ld_val<NT>(v[j] + (size_t)(4 * q + 2) * 64);
+          const double2 a3 = ld_val<NT>(v[j] + (size_t)(4 * q + 3) * 64);
+          const double2 x0 = a_in[cc.x];
+          const double2 x1 = a_in[cc.y];
+          const double2 x2 = a_in[cc.z];
+          const double2 x3 = a_in[cc.w];
+          cfma(s0a[j], a0, x0);
+          cfma(s1a[j], a1, x1);
+          cfma(s0a[j], a2, x2);
+          cfma(s1a[j], a3, x3);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NBK; ++j) z[j] = make_double2(s0a[j].x + s1a[j].x, s0a[j].y + s1a[j].y);
+    }
+    // ---- first sweep over the blocks' basis rows (from memory, chunks of four, one chunk ahead): the projection of a_t
     // (ascending k, as the sequential axpys of src/arnoldi.jl:86) and the same sum with gamma for H a_t
-    double2 u = ar, y = z;
-    auto project = [&](const double2 (&qq)[4], int k0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < NBK; ++j) {
+      u[j] = ar[j];
+      y[j] = z[j];
+    }
+    auto project = [&](const double2 (&qq)[NBK][4], int k0) __attribute__((always_inline)) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const double2 hk = L.hs[k0 + e], gk = (k0 + e) < nb ? L.gam[k0 + e] : make_double2(0.0, 0.0);
-        u.x = fma(-hk.x, qq[e].x, u.x);
-        u.x = fma(hk.y, qq[e].y, u.x);
-        u.y = fma(-hk.x, qq[e].y, u.y);
-        u.y = fma(-hk.y, qq[e].x, u.y);
-        if constexpr (MV) {
-          y.x = fma(-gk.x, qq[e].x, y.x);
-          y.x = fma(gk.y, qq[e].y, y.x);
-          y.y = fma(-gk.x, qq[e].y, y.y);
-          y.y = fma(-gk.y, qq[e].x, y.y);
+#pragma unroll
+        for (int j = 0; j < NBK; ++j) {
+          u[j].x = fma(-hk.x, qq[j][e].x, u[j].x);
+          u[j].x = fma(hk.y, qq[j][e].y, u[j].x);
+          u[j].y = fma(-hk.x, qq[j][e].y, u[j].y);
+          u[j].y = fma(-hk.y, qq[j][e].x, u[j].y);
+          if constexpr (MV) {
+            y[j].x = fma(-gk.x, qq[j][e].x, y[j].x);
+            y[j].x = fma(gk.y, qq[j][e].y, y[j].x);
+            y[j].y = fma(-gk.x, qq[j][e].y, y[j].y);
+            y[j].y = fma(-gk.y, qq[j][e].x, y[j].y);
+          }
         }
       }
     };
@@ -329,13 +367,17 @@ __global__ __launch_bounds__(64 * WS) void arnoldi_onepass_kernel(
     for (int kb = 0; kb < JT; kb += 8) {
       if (kb + 4 < JT) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) qb[e] = (Qs + (size_t)min(kb + 4 + e, nbl) * ldqs)[ro];
+        for (int j = 0; j < NBK; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) qb[j][e] = (Qs + (size_t)min(kb + 4 + e, nbl) * ldqs)[ro[j]];
       }
       __builtin_amdgcn_sched_barrier(0);
       project(qa, kb);
       if (kb + 8 < JT) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) qa[e] = (Qs + (size_t)min(kb + 8 + e, nbl) * ldqs)[ro];
+        for (int j = 0; j < NBK; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) qa[j][e] = (Qs + (size_t)min(kb + 8 + e, nbl) * ldqs)[ro[j]];
       }
       __builtin_amdgcn_sched_barrier(0);
       if (kb + 4 < JT) project(qb, kb + 4);
@@ -345,60 +387,74 @@ __global__ __launch_bounds__(64 * WS) void arnoldi_onepass_kernel(
     // registers at once -- the accumulators below leave no room for that.)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) qa[e] = (Qs + (size_t)min(e, nbl) * ldqs)[ro];
-    double2 qn = make_double2(s * u.x, s * u.y);
-    double2 an = make_double2(0.0, 0.0);
-    if constexpr (MV) {
-      y.x = fma(-gam_own.x, qn.x, y.x);
-      y.x = fma(gam_own.y, qn.y, y.x);
-      y.y = fma(-gam_own.x, qn.y, y.y);
-      y.y = fma(-gam_own.y, qn.x, y.y);
-      an = make_double2(s * y.x, s * y.y);
-    }
-    if (valid) {
-      q_out[row] = qn;
-      if constexpr (MV) a_out[row] = an;
-    } else {
-      qn = an = make_double2(0.0, 0.0);
+    for (int j = 0; j < NBK; ++j) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) qa[j][e] = (Qs + (size_t)min(e, nbl) * ldqs)[ro[j]];
+      qn[j] = make_double2(s * u[j].x, s * u[j].y);
+      an[j] = make_double2(0.0, 0.0);
+      if constexpr (MV) {
+        y[j].x = fma(-gam_own.x, qn[j].x, y[j].x);
+        y[j].x = fma(gam_own.y, qn[j].y, y[j].x);
+        y[j].y = fma(-gam_own.x, qn[j].y, y[j].y);
+        y[j].y = fma(-gam_own.y, qn[j].x, y[j].y);
+        an[j] = make_double2(s * y[j].x, s * y[j].y);
+      }
+      if (valid[j]) {
+        q_out[rows[j]] = qn[j];
+        if constexpr (MV) a_out[rows[j]] = an[j];
+      } else {
+        qn[j] = an[j] = make_double2(0.0, 0.0);
+      }
     }
     // ---- second sweep over the same rows (the lines are in the L1 / L2 now): d_k += conj(qh_k) a_new, g_k += conj(qh_k) qh_new;
-    // accumulators beyond nb collect numbers nobody reads; slot JT: the new vector with itself
-    auto dots = [&](const double2 (&qq)[4], int k0) __attribute__((always_inline)) {
+    // accumulators beyond nb collect numbers nobody reads; slot JT: the new vector with itself.  (Block 0 then block 1 into the same
+    // accumulator: the order in which one block at a time adds them.)
+    auto dots = [&](const double2 (&qq)[NBK][4], int k0) __attribute__((always_inline)) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        if constexpr (MV) {
-          const double2 pd = cconj_mul(qq[e], an);
-          d[k0 + e].x += pd.x;
-          d[k0 + e].y += pd.y;
+#pragma unroll
+        for (int j = 0; j < NBK; ++j) {
+          if constexpr (MV) {
+            const double2 pd = cconj_mul(qq[j][e], an[j]);
+            d[k0 + e].x += pd.x;
+            d[k0 + e].y += pd.y;
+          }
+          const double2 pg = cconj_mul(qq[j][e], qn[j]);
+          g[k0 + e].x += pg.x;
+          g[k0 + e].y += pg.y;
         }
-        const double2 pg = cconj_mul(qq[e], qn);
-        g[k0 + e].x += pg.x;
-        g[k0 + e].y += pg.y;
       }
     };
 #pragma unroll
     for (int kb = 0; kb < JT; kb += 8) {
       if (kb + 4 < JT) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) qb[e] = (Qs + (size_t)min(kb + 4 + e, nbl) * ldqs)[ro];
+        for (int j = 0; j < NBK; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) qb[j][e] = (Qs + (size_t)min(kb + 4 + e, nbl) * ldqs)[ro[j]];
       }
       __builtin_amdgcn_sched_barrier(0);
       dots(qa, kb);
       if (kb + 8 < JT) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) qa[e] = (Qs + (size_t)min(kb + 8 + e, nbl) * ldqs)[ro];
+        for (int j = 0; j < NBK; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) qa[j][e] = (Qs + (size_t)min(kb + 8 + e, nbl) * ldqs)[ro[j]];
       }
       __builtin_amdgcn_sched_barrier(0);
       if (kb + 4 < JT) dots(qb, kb + 4);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (MV) {
-      const double2 pd = cconj_mul(qn, an);
-      d[JT].x += pd.x;
-      d[JT].y += pd.y;
-      aa += an.x * an.x + an.y * an.y;
+#pragma unroll
+    for (int j = 0; j < NBK; ++j) {
+      if constexpr (MV) {
+        const double2 pd = cconj_mul(qn[j], an[j]);
+        d[JT].x += pd.x;
+        d[JT].y += pd.y;
+        aa += an[j].x * an[j].x + an[j].y * an[j].y;
+      }
+      g[JT].x += qn[j].x * qn[j].x + qn[j].y * qn[j].y;
     }
-    g[JT].x += qn.x * qn.x + qn.y * qn.y;
   }
   // NV sums over the lanes of every wavefront, then over the wavefronts (the transpose of kernels_arnoldi.hip: eight values
   // at a time through a wavefront-private LDS tile, row = lane, nine doubles wide; fixed order, no atomics)

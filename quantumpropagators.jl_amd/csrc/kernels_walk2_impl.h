@@ -20,7 +20,7 @@
 //     forms y on all 64 lanes but z (and the stored y) only on the W = 64 - 2 d_max lanes in the middle; the chunks overlap by
 //     2 d_max rows (W = 56 for the headline lattice: 19 chunks per 1024-row strip step instead of 16).
 // A segment of L steps runs in 2 K steps before its first z (K of y alone, then K more until y is K blocks ahead).  One wavefront
-// per SIMD (the rings and the history need ~400 registers; LDS: 33 KB per wavefront).  y and z go to two fresh vectors: writing in
+// per SIMD (the rings and the history need ~370 registers: 256 VGPRs + 116 AGPRs at (4, 4); LDS: 33 KB per wavefront).  y and z go to two fresh vectors: writing in
 // place would race with the neighbouring columns' halo reads of x and p.
 //
 // Blocks outside the region where BOTH phases have their operands inside the lattice run -- the one-term walk's edge blocks and K strip
@@ -28,7 +28,7 @@
 // they only read x and p) and term m + 1 from a per-block launch over the same list afterwards (engine_cheby.hip).
 //
 // Both row sums are the one-term walk's (lower slots then upper slots in storage order, two interleaved partial sums) and both
-// epilogues are ChebyOp's: bit-identical to one-term launches (tests/test_gpu_parity.py: test_two_term_walk_*).
+// epilogues are ChebyOp's: bit-identical to one-term launches (tests/test_gpu_walk2.py).
 #pragma once
 #include <atomic>
 

@@ -249,6 +249,37 @@ function operator_walk_info(op::Handle)
             first_block = out[6], end_block = out[7], edge_blocks = out[8])
 end
 
+# Does qp_cheby_step form TWO Chebyshev terms per pass over the matrix values for this operator (csrc/kernels_walk2.hip: lattice
+# operators beyond the Infinity Cache; same results bit for bit) and how is that walk cut?
+function operator_walk2_info(op::Handle)
+    out = zeros(Int64, 8)
+    GC.@preserve out check(ccall((:qp_operator_walk2_info, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}), op, out))
+    return (valid = out[1] != 0, first_block = out[2], end_block = out[3], edge_blocks = out[4], useful_rows_per_chunk = Int(out[5]),
+            chunks_per_strip_step = Int(out[6]), steps_per_wavefront = Int(out[7]), segments = Int(out[8]))
+end
+
+# A qubit-register generator applied from its Pauli strings instead of stored matrices (include/qprop.h: qp_pauli_operator_create;
+# csrc/engine_pauli.hip): `terms[l]` = the strings of H_l of the lazy sum as (amplitude, xmask, zmask) -- xmask = the qubits with X
+# or Y, zmask = those with Z or Y, qubit i = bit i of the basis index --, the last `ncoeffs` terms carry the controls' coefficients
+# (set_coeffs!), as for make_operator.  What the reference would be handed as SparseMatrixCSC terms (src/generators.jl:634-645).
+struct PauliString                  # qp_pauli_string
+    xmask::UInt64; zmask::UInt64
+    coef::C128
+    op::Cint
+end
+
+function make_pauli_operator(ctx::Handle, nqubits::Integer, terms::AbstractVector, ncoeffs::Integer)
+    flat = PauliString[]
+    for (l, strings) in enumerate(terms), (amp, xm, zm) in strings
+        push!(flat, PauliString(UInt64(xm), UInt64(zm), ComplexF64(amp), Cint(l - 1)))
+    end
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve flat check(ccall((:qp_pauli_operator_create, LIB), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{PauliString}, Cint, Cint, Cint, Ptr{Ptr{Cvoid}}),
+        ctx, nqubits, flat, length(flat), length(terms), ncoeffs, out))
+    return Handle(out[], _operator_destroy, ctx)
+end
+
 # long distance (rows) of a walk plan with one further pair beyond its far reach (three-dimensional grids), 0 if none
 function operator_walk_long(op::Handle)
     n = Ref{Int64}(0)

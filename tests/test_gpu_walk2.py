@@ -142,6 +142,32 @@ def test_two_term_walk_lazy_sum_and_check_normalization(ctx):
             ctx.tuning_set(k, v)
 
 
+def test_two_term_walk_inside_the_fused_propagate_loop(ctx):
+    """`propagate` with the step loop inside the library (qp_propagate: N1 of SURVEY 8f) and a time-dependent control: every step's
+    evaluate! + cheby! with the terms in pairs gives the bits of the one-term walk, states stored after every step included."""
+    import qprop_amd.propagator as P
+    N = 1 << 15
+    rp, col, v1 = synth.hermitian_offsets_csr(N, offsets=(1, 2, 3, 4, 128, 256, 384, 512))
+    _, _, v2 = synth.hermitian_offsets_csr(N, offsets=(1, 2, 3, 4, 128, 256, 384, 512), seed=78)
+    H0, H1 = synth.to_scipy(rp, col, v1, N), synth.to_scipy(rp, col, v2, N)
+    tlist = np.linspace(0.0, 0.6, 7)
+    psi0 = synth.random_state(N)
+    outs = {}
+    saved = {k: ctx.tuning_get(k) for k in ("walk_pair", "walk_min_blocks")}
+    try:
+        ctx.tuning_set("walk_min_blocks", 16)
+        for pair in (0, 1):
+            ctx.tuning_set("walk_pair", pair)
+            psi_T, states = P.propagate(psi0, P.hamiltonian(H0, (H1, lambda t: 0.5 * np.cos(4.0 * t))), tlist, method="cheby", storage=True,
+                                        ctx=ctx, specrange_method="manual", E_min=-16.0, E_max=16.0)
+            outs[pair] = (np.asarray(psi_T), np.asarray(states))
+    finally:
+        for k, v in saved.items():
+            ctx.tuning_set(k, v)
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert abs(np.linalg.norm(outs[1][0]) - 1.0) < 1e-11
+
+
 def test_two_term_walk_full_size_against_the_c_port():
     """N = 2^22 (beyond the Infinity Cache: the AUTOMATIC rule takes the two-term walk): two steps forward and one back against the one-term
     walk (bit for bit) and, on a window of 2^18 rows, against the C port of the reference (a row depends on the rows within

@@ -81,10 +81,10 @@ def parse_header():
 
 
 JL_SCALARS = {"Cint": "int", "Cdouble": "double", "Int64": "int64", "Csize_t": "size_t", "C128": "c128", "ComplexF64": "c128",
-              "Cstring": "cstring", "Cvoid": "void"}
+              "Cstring": "cstring", "Cvoid": "void", "UInt64": "uint64"}
 
 
-JL_STRUCTS = {"NewtonStats": "qp_newton_stats"}      # Julia mirror -> C struct (fields compared below)
+JL_STRUCTS = {"NewtonStats": "qp_newton_stats", "PauliString": "qp_pauli_string"}      # Julia mirror -> C struct (fields compared below)
 
 
 def jl_class(t):
@@ -327,6 +327,22 @@ def test_newton_stats_mirror_matches_field_by_field():
             nm, ty = stmt.split("::")
             jfields.append((JL_SCALARS[ty.strip()], nm.strip()))
     assert jfields == cfields, (jfields, cfields)
+
+
+def test_pauli_string_mirror_matches_field_by_field():
+    """julia/QuantumPropagatorsHIPExt.jl: struct PauliString is passed to qp_pauli_operator_create as an array of qp_pauli_string."""
+    _, structs = parse_header()
+    cfields = structs["qp_pauli_string"]
+    txt = open(JL).read()
+    body = re.search(r"struct PauliString[^\n]*\n(.*?)\nend", txt, flags=re.S).group(1)
+    jfields = []
+    for stmt in re.split(r"[;\n]", body):
+        stmt = stmt.split("#")[0].strip()
+        if stmt:
+            nm, ty = stmt.split("::")
+            jfields.append((JL_SCALARS[ty.strip()], nm.strip()))
+    assert [n for _, n in jfields] == [n for _, n in cfields], (jfields, cfields)
+    assert [t for t, _ in jfields] == [t for t, _ in cfields], (jfields, cfields)
 
 
 def test_glue_has_a_device_resident_state_and_takes_every_generator_form():

@@ -457,7 +457,8 @@ def run_c5(args, world, rank, local_rank, one_gpu, dist, L, synth, bp):
     sched = L.acc_schedule(wrk.coeffs)
     nupd = sum(0 if d.skip else 1 for d in sched)
     # bytes one GPU must move per fused term: the matrix once (CSR mirror), its share of X, v_{m-2}, v_m, the accumulator
-    lay = 20.0 * nnz + 12.0 * N + 16.0 * N * b * (3.0 - 2.0 / nterms + (2.0 * nupd - 1.0) / nterms)
+    kname, kshort, mbytes = bp.panel_kernel(op, b, nnz, N)
+    lay = mbytes + 16.0 * N * b * (3.0 - 2.0 / nterms + (2.0 * nupd - 1.0) / nterms)
     alg = 20.0 * nnz + 4.0 * (N + 1) + 80.0 * N * b
     out = {"metric": "batched Cheby prop_step!: state-steps/s, 64 states x N=2^18 CSR fp64 (BASELINE configs[4])",
            "value": args.batch * args.steps / el, "unit": "state_step/s", "n_gpus": world, "steps": args.steps,
@@ -466,7 +467,7 @@ def run_c5(args, world, rank, local_rank, one_gpu, dist, L, synth, bp):
            "config": {"workload": f"BASELINE configs[4]: batched Cheby prop_step!, {args.batch} states x N=2^{log2n} CSR H (16 nnz/row), "
                                   f"batch split over {world} GPU(s): {b} states per GPU, H replicated, no communication",
                       "states_per_gpu": b, "N": N, "n_coeffs": int(wrk.n_coeffs), "matvecs_per_step": nterms, "dt": args.dt,
-                      "kernel": "spmm_rows_smem_kernel (wave per row, lane = state)" if b > 32 else "csr_spmm_kernel (state-tiled)",
+                      "kernel": kname, "lds_tiles": op.spmm_tiles(b),
                       "row_walk": dict(zip(("inner_dimension", "strip_width"), op.spmm_walk(b))),
                       "parallelism": "single GPU" if world == 1 else f"batch-split x{world} (replicas of H, zero communication)"
                                      + (" [TEST MODE: ranks share one GPU]" if one_gpu else "")},
@@ -483,7 +484,7 @@ def run_c5(args, world, rank, local_rank, one_gpu, dist, L, synth, bp):
     out["config"]["nnz_per_row"] = nnz / N
     out["config"]["device_format"] = bp.FMT_NAME[op.format]
     rfl = out["roofline"]
-    rfl["kernel"] = "spmm_rows_smem_kernel" if b > 32 else "csr_spmm_kernel"
+    rfl["kernel"] = kshort
     rfl["bytes_per_launch"] = lay
     rfl["model"] = "layout"
     # the reference's CPU path beside it (rank 0 of a single-GPU run, after the timed region): a sample of the panel's states
@@ -495,7 +496,7 @@ def run_c5(args, world, rank, local_rank, one_gpu, dist, L, synth, bp):
     if rank == 0 and world == 1 and not args.no_pmc and args.batch == 64 and log2n == 18:
         bs.close()
         bs = None
-        tr, det = pmc_traffic(["--point", "c5", "--steps", "2"], "spmm_rows_smem_kernel", timeout_s=240, how="mean")
+        tr, det = pmc_traffic(["--point", "c5", "--steps", "2"], kshort, timeout_s=240, how="mean")
         rfl = out["roofline"]
         rfl["traffic"] = tr
         rfl["traffic_source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of `bench.py --point c5`, "
@@ -1189,7 +1190,7 @@ def main():
             if not args.no_pmc:
                 for name, argv, subs, how, per in (
                         ("c3_newton", ["--point", "c3", "--steps", "3"], NEWTON_KERNELS, "sum", 6.0),       # the child runs 2 x 3 identical steps
-                        ("c5_batched", ["--point", "c5", "--steps", "2"], "spmm_rows_smem_kernel", "mean", 1.0)):
+                        ("c5_batched", ["--point", "c5", "--steps", "2"], extras.get("c5_batched", {}).get("kernel_symbol", "spmm_rows_smem_kernel"), "mean", 1.0)):
                     pt = extras.get(name)
                     if not pt or "error" in pt:
                         continue

@@ -273,6 +273,10 @@ int qp_operator_walk_reason(const qp_operator* op, int* code, char* text, size_t
  * g: H = H_a (x) 1 + 1 (x) H_c), out[1] = strip width (rows are visited strip by strip so that the gather
  * window of the panel stays inside an XCD's L2); both 0 when the rows are visited in natural order. */
 int qp_operator_spmm_walk(qp_operator* op, int batch, int64_t out[2]);
+/* Whether qp_cheby_step_batched will take the LDS-staged tiles for a panel of `batch` states (a lattice operator whose
+ * interior rows all carry the same entries, near distances <= 4 and far distances m g with |m| <= 4: 4 x 4 patches of rows
+ * whose operands are staged once per workgroup): out = {taken (0 / 1), tiles, rows left to the row kernel, g, K, NN}. */
+int qp_operator_spmm_tiles(qp_operator* op, int batch, int64_t out[6]);
 /* read the DEVICE copy (union pattern, currently combined values) back as canonical
  * CSR: the device-format round trip must be bit-exact. */
 int qp_operator_get_csr(qp_operator* op, int64_t* rowptr, int32_t* col, qp_c128* vals);

@@ -258,6 +258,14 @@ function operator_walk2_info(op::Handle)
             chunks_per_strip_step = Int(out[6]), steps_per_wavefront = Int(out[7]), segments = Int(out[8]))
 end
 
+# Will qp_cheby_step_batched take the LDS-staged 4 x 4 tiles for a panel of `batch` states (a lattice operator's interior rows; the rest goes
+# to the row kernel; same results bit for bit)?
+function operator_spmm_tiles(op::Handle, batch::Integer)
+    out = zeros(Int64, 6)
+    GC.@preserve out check(ccall((:qp_operator_spmm_tiles, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Int64}), op, batch, out))
+    return (taken = out[1] != 0, tiles = out[2], rest_rows = out[3], rows_per_step = out[4], far = Int(out[5]), near = Int(out[6]))
+end
+
 # A qubit-register generator applied from its Pauli strings instead of stored matrices (include/qprop.h: qp_pauli_operator_create;
 # csrc/engine_pauli.hip): `terms[l]` = the strings of H_l of the lazy sum as (amplitude, xmask, zmask) -- xmask = the qubits with X
 # or Y, zmask = those with Z or Y, qubit i = bit i of the basis index --, the last `ncoeffs` terms carry the controls' coefficients

@@ -323,7 +323,7 @@ struct Tuning {
   int small_nnz = 8192;       // qp_propagate: register-resident Cheby systems up to this nnz run as ONE persistent launch (0: off)
   int newton_pipeline = 1;    // newton!: Hessenberg eigenvalues overlap the Arnoldi sweep
   int spmm_rows = 1;          // batched SpMM: wave-per-row kernel (lane = state) for panels of more than 32 states (0: always the state-tiled kernel)
-  int spmm_rw = 0;            // batched SpMM, wave-per-row kernel: 0 = matrix entries through the scalar unit (one row per wavefront), 1 / 2 / 4 / 8 = entries one per lane + readlane broadcast, that many rows per wavefront
+  int spmm_rw = -1;           // batched SpMM, wave-per-row kernel: -1 = 4 x 4 tiles of a lattice operator's rows staged in LDS where the pattern allows (SpmmTiles), else as 0; 0 = matrix entries through the scalar unit (one row per wavefront), 1 / 2 / 4 / 8 = entries one per lane + readlane broadcast, that many rows per wavefront
   int spmm_strip = 0;         // batched SpMM row walk: inner-index strip width (0 = chosen from the L2 size; -1 = natural row order)
   int hrb_walk = 1;           // Hermitian-packed fused term of a whole lattice operator: the strip-walk kernel (kernels_walk.hip) when the operator has a walk plan
   int walk_waves = 0;         // strip walk: wavefronts the walk is cut into (0: 768 for an operator that fits the Infinity Cache, else 8 per CU on every CU the edge workgroups leave free -- 1856 for the headline lattice --, or 2048 with the edge blocks inside the walk; the two-term walk: one per SIMD = 4 per compute unit)
@@ -358,6 +358,38 @@ int launch_sparse_planes_update(hipStream_t s, double2* vals, const double2* bas
 int launch_spmm_cheby(hipStream_t s, const int64_t* rowptr, const int32_t* cols, const double2* vals,
                       const double2* X, int64_t nrows, int64_t nnz, int b, const ChebyEpi& e, const Tuning& tun,
                       bool rows_kernel, const int32_t* order, Stats* st);
+// Tiles of the batched path.  A lattice operator's interior rows all carry the same entries (row + d for the nd distances d of
+// the pattern, each either near, |d| <= NN <= 4, or far, d = m g with |m| <= K <= 4).  A 4 x 4 patch of such rows -- rows
+// r0 + i g + j, i, j < 4 -- reads 17 x 16 panel rows of which only 16 + 8 K + 8 NN are distinct: the workgroup stages those once
+// in LDS (one KiB per row: 64 states) and its sixteen wavefronts, one per row as in the row kernel, take their operands from
+// there.  What decides the speed of the row kernel is the bytes it pulls out of L2 (17-21 KiB per row at the L2's ~18 TB/s:
+// tools/probe/panel_tile_probe.hip, profiles/r06/panel_tile_probe.txt); the tile pulls 5 + the row-local streams.
+constexpr int kSpmmTileMaxEntries = 24;   // entries per row (2 K + 2 NN + 1 = 17 at most; a multiple of 8: the sums go in groups of eight)
+constexpr int kSpmmTileSlots = 80;        // staged rows at most (K = NN = 4): 80 KiB of LDS, two workgroups per compute unit
+struct SpmmTileShape {
+  int nd = 0, K = 0, NN = 0;
+  int dfar[kSpmmTileMaxEntries] = {0};    // entry k: strip steps m (d = m g) when dnear[k] == 0 ...
+  int dnear[kSpmmTileMaxEntries] = {0};   // ... else the near distance d
+};
+// the kernel's table (device, int32): [0, 80) row of staged slot s relative to the tile's first row r0; then for wavefront w = 4 i + j
+// and entry k the LDS byte offset of that entry's operand (24 per wavefront); then the wavefront's own row relative to r0 (16) and
+// the LDS byte offset of its own element (16)
+constexpr int kSpmmTileTab = kSpmmTileSlots + 16 * kSpmmTileMaxEntries + 32;
+struct SpmmTiles {
+  bool built = false;
+  int valid = 0;
+  int knob = 0;
+  SpmmTileShape shape;
+  int64_t g = 0, sw = 0;
+  int32_t* tiles = nullptr;   // device: first row r0 of every tile, in the order of the row walk (strips of sw columns, tiles of a strip step side by side)
+  int64_t ntiles = 0;
+  int32_t* rest = nullptr;    // device: the rows outside the tiles (edges of the lattice, ragged ends): row kernel
+  int64_t nrest = 0;
+  int32_t* tab = nullptr;     // device: kSpmmTileTab entries (above)
+  int T = 0;                  // staged rows: 16 + 8 K + 8 NN
+};
+int launch_spmm_tile_cheby(hipStream_t s, const int64_t* rowptr, const int32_t* cols, const double2* vals, const double2* X,
+                           int64_t nrows, int64_t nnz, int b, const ChebyEpi& e, const Tuning& tun, const SpmmTiles& P, Stats* st);
 // panels of more than 32 states take the wave-per-row kernel (lane = state) unless knob spmm_rows is 0
 inline bool spmm_uses_rows_kernel(const Tuning& tun, int b) { return tun.spmm_rows != 0 && b > 32; }
 // ---- small systems: the whole Cheby time grid in one single-workgroup launch -------------

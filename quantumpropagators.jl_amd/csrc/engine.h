@@ -92,6 +92,7 @@ struct qp_operator {
   int m_order_batch = 0, m_order_knob = 0;
   bool m_order_valid = false;
   int64_t m_order_g = 0, m_order_sw = 0;   // what was detected: inner dimension and strip width (0: none)
+  qp::SpmmTiles m_tiles;                   // LDS-staged tiles of the batched path (operator_spmm_tiles), built lazily
   int nops = 0, ncoeffs = 0;
   std::vector<int64_t> u_rowptr;  // union pattern (host), for get_csr and plane scatter
   std::vector<int32_t> u_col;
@@ -278,6 +279,7 @@ inline int dot_sync(qp_ctx* ctx, const double2* x, const double2* y, int64_t n, 
 int operator_csr_mirror(qp_operator* op, bool gather = true);
 // row order in which the batched (SpMM) kernel visits the rows for a panel of `batch` states
 int operator_spmm_order(qp_operator* op, int batch, const int32_t** order_out);
+int operator_spmm_tiles(qp_operator* op, const qp::SpmmTiles** out);
 // which terms of a cheby! touch the Psi accumulator (include/qprop.h, qp_acc_defer)
 void acc_schedule(const double* a, int n_coeffs, bool defer, qp_acc_defer* out);
 void set_defer(qp::ChebyEpi& e, const qp_acc_defer* d);

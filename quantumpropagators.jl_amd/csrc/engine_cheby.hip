@@ -438,7 +438,9 @@ int qp_cheby_step_batched(qp_cheby* w, qp_operator* op, qp_state* psi, int batch
   // kernel choice (knob spmm_rows): the wave-per-row kernel for wide panels, else the state-tiled kernel
   const bool rows_kernel = !dense && qp::spmm_uses_rows_kernel(ctx->tun, batch);
   const int32_t* order = nullptr;   // row walk of the wave-per-row kernel
-  if (rows_kernel) QP_CHECK(operator_spmm_order(op, batch, &order));
+  const qp::SpmmTiles* tiles = nullptr;   // LDS-staged tiles of a lattice operator's interior rows (knob spmm_rw -1, the default)
+  if (rows_kernel && ctx->tun.spmm_rw < 0) QP_CHECK(operator_spmm_tiles(op, &tiles));
+  if (rows_kernel && !tiles) QP_CHECK(operator_spmm_order(op, batch, &order));
 
   const double beta = (Delta / 2) + E_min;
   cplx c = (dt > 0) ? cplx(0, -2.0) / Delta : cplx(0, 2.0) / Delta;
@@ -490,6 +492,11 @@ int qp_cheby_step_batched(qp_cheby* w, qp_operator* op, qp_state* psi, int batch
     bool walked = false;
     if (dense) {
       QP_CHECK(qp::launch_dense_zgemm_cheby(ctx->stream, op->A, x, batch, e, &ctx->stats));
+      walked = true;
+    }
+    if (!walked && tiles) {
+      QP_CHECK(qp::launch_spmm_tile_cheby(ctx->stream, op->m_rowptr, op->m_cols, op->m_vals, x, n, op->A.nnz, batch, e, ctx->tun,
+                                          *tiles, &ctx->stats));
       walked = true;
     }
     if (!walked)

@@ -173,6 +173,14 @@ struct ChebyOpT {
     p.acc = e.acc_in ? ld_stream<NT>(e.acc_in + i) : make_double2(0.0, 0.0);
     return p;
   }
+  // pre() without x_i, for a kernel that holds the row's own element already (the LDS tile of the batched path sets p.xi itself)
+  __device__ __forceinline__ Pre pre_streams(int64_t i) const {
+    Pre p;
+    p.xi = make_double2(0.0, 0.0);
+    p.v0 = e.v0 ? ld_stream<NT>(e.v0 + i) : make_double2(0.0, 0.0);
+    p.acc = e.acc_in ? ld_stream<NT>(e.acc_in + i) : make_double2(0.0, 0.0);
+    return p;
+  }
   __device__ __forceinline__ void row(int64_t i, double2 s, const Pre& p, double2& chk, double& nrm,
                                       int64_t slot) const {
     const double2 xi = p.xi;

@@ -1,5 +1,6 @@
 // Batched states (BASELINE configs[4]): the panel kernels of the fused Chebyshev term and the CSR-ordered mirror's gather
 // (split out of kernels.hip in round 4; kernel notes below and in DESIGN 4).
+#include <atomic>
 #include <cstring>
 #include <type_traits>
 
@@ -109,18 +110,11 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {   // l wave-un
 // WS wavefronts (consecutive walk positions) per workgroup: 8 measured 282 us per term of config C5
 // against 302 with 4 and 290 with 16; 2-D tiles of walk positions per workgroup instead of runs: no difference
 // (profiles/r02/batched_c5_sweep.txt)
-template <class Op, int WS>
-__global__ __launch_bounds__(64 * WS) void spmm_rows_smem_kernel(const int64_t* __restrict__ rowptr,
-                                                                  const int32_t* __restrict__ cols,
-                                                                  const double2* __restrict__ vals,
-                                                                  const double2* __restrict__ X, int64_t nrows, int b, Op op,
-                                                                  const int32_t* __restrict__ order) {
-  const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  const int64_t pos = (int64_t)wg * WS + wave;
-  if (pos >= nrows) return;
-  const int64_t row = order ? (int64_t)__builtin_amdgcn_readfirstlane(order[pos]) : pos;
+// (the row's work as a device function: the tile kernel below sends the rows outside its tiles through the same code)
+template <class Op>
+__device__ __forceinline__ void spmm_row_scalar_entries(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+                                                        const double2* __restrict__ vals, const double2* __restrict__ X, int b,
+                                                        const Op& op, int64_t row, int lane) {
   const int st = blockIdx.y * 64 + lane;
   const bool active = st < b;
   const int stc = active ? st : b - 1;
@@ -163,6 +157,129 @@ __global__ __launch_bounds__(64 * WS) void spmm_rows_smem_kernel(const int64_t* 
     k += 4;
   }
   for (; k < len; ++k) cfma(acc0, rv[k], Xs[(int64_t)rc[k] * b]);
+  if (active) op.row(e, make_double2(acc0.x + acc1.x, acc0.y + acc1.y), pre, chk, nrm, e);
+}
+
+template <class Op, int WS>
+__global__ __launch_bounds__(64 * WS) void spmm_rows_smem_kernel(const int64_t* __restrict__ rowptr,
+                                                                  const int32_t* __restrict__ cols,
+                                                                  const double2* __restrict__ vals,
+                                                                  const double2* __restrict__ X, int64_t nrows, int b, Op op,
+                                                                  const int32_t* __restrict__ order) {
+  const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int64_t pos = (int64_t)wg * WS + wave;
+  if (pos >= nrows) return;
+  const int64_t row = order ? (int64_t)__builtin_amdgcn_readfirstlane(order[pos]) : pos;
+  spmm_row_scalar_entries(rowptr, cols, vals, X, b, op, row, lane);
+}
+
+// ---------------------------------------------------------------------------
+// LDS-staged 4 x 4 tiles of a lattice operator's interior rows (SpmmTiles, device.h; plan: operator_spmm_tiles in engine_core.hip).
+// Sixteen wavefronts = the sixteen rows r0 + i g + j of the tile, lane = state.  The workgroup first loads the 16 + 8 K + 8 NN
+// distinct panel rows its rows read -- slots [(4 + 2 K) strip steps][4 columns], then [4 strip steps][2 NN near-halo columns] --
+// five per wavefront, issued before the row-local streams so that the barrier waits on them as little as possible; after the
+// barrier every wavefront sums its row exactly as spmm_rows_smem_kernel does (same entries, same order, same two partial sums:
+// the same bits), with ds_read_b128 in place of the gathers.  Measured on the bare loop (profiles/r06/panel_tile_probe.txt):
+// larger tiles or tiles held in registers lose to the occupancy they cost; two workgroups of 80 KiB per compute unit do not.
+// ---------------------------------------------------------------------------
+template <class Op>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void spmm_tile_kernel(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+                                                         const double2* __restrict__ vals, const double2* __restrict__ X,
+                                                         int64_t nrows, int b, Op op, const int32_t* __restrict__ tiles,
+                                                         const int32_t* __restrict__ tab, int nd, int T, int ntiles,
+                                                         const int32_t* __restrict__ rest, int nrest) {
+  extern __shared__ double2 tile_lds[];
+  const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  // the rows outside the tiles, sixteen per workgroup, by the row kernel's code: those workgroups are spread evenly over the launch
+  // (every `stride`-th position of the walk; at its end they would all run on the last XCD, after its tiles)
+  const unsigned nrwg = (unsigned)(nrest + 15) >> 4;
+  unsigned tile = wg;
+  if (nrwg > 0) {
+    const unsigned stride = gridDim.x / nrwg;
+    const unsigned before = min((wg + 1) / stride, nrwg);      // rest workgroups at positions <= wg
+    if (wg % stride == stride - 1 && wg / stride < nrwg) {
+      const int pos = (int)(wg / stride) * 16 + wave;
+      if (pos < nrest) spmm_row_scalar_entries(rowptr, cols, vals, X, b, op, (int64_t)__builtin_amdgcn_readfirstlane(rest[pos]), lane);
+      return;
+    }
+    tile = wg - before;
+  }
+  const int64_t r0 = (int64_t)__builtin_amdgcn_readfirstlane(tiles[tile]);
+  const int st = blockIdx.y * 64 + lane;
+  const bool active = st < b;
+  const int stc = active ? st : b - 1;
+  const double2* __restrict__ Xs = X + stc;
+  // everything the row needs from memory is requested before the barrier: the wavefront's share of the staged rows (tab[slot] = that
+  // slot's row relative to r0), the row's entries one per lane (broadcast later with v_readlane: after the barrier no load is left
+  // whose latency only two resident workgroups per compute unit would have to hide), the LDS byte offset of every entry's operand
+  // (tab[kSpmmTileSlots + 24 wave + k]: host arithmetic, SpmmTiles), the row-local streams
+  double2 stg[5];
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    const int slot = min(wave + 16 * q, T - 1);      // wave-uniform; past the last slot the load is repeated and not stored
+    int64_t gr = r0 + tab[slot];
+    gr = gr < 0 ? 0 : (gr >= nrows ? nrows - 1 : gr);   // (a slot no row of the tile reads: a pattern with gaps at the lattice's edge)
+    stg[q] = Xs[gr * b];
+  }
+  const int64_t row = r0 + tab[kSpmmTileSlots + kSpmmTileMaxEntries * 16 + wave];
+  const int64_t e = row * (int64_t)b + stc;
+  const int lk = lane < nd ? lane : nd - 1;
+  const double2 mv = vals[rowptr[row] + lk];
+  const int mo = tab[kSpmmTileSlots + kSpmmTileMaxEntries * wave + lk];
+  const int own = __builtin_amdgcn_readfirstlane(tab[kSpmmTileSlots + kSpmmTileMaxEntries * 16 + 16 + wave]);
+  typename Op::Pre pre = op.pre_streams(e);
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    const int slot = wave + 16 * q;
+    if (slot < T) tile_lds[slot * 64 + lane] = stg[q];
+  }
+  __syncthreads();
+  const char* __restrict__ L = (const char*)(tile_lds + lane);
+  pre.xi = *(const double2*)(L + own);
+  const int len = nd;
+  auto xk = [&](int k) -> double2 { return *(const double2*)(L + __builtin_amdgcn_readlane(mo, k)); };      // k: compile-time
+  auto ak = [&](int k) -> double2 { return make_double2(readlane_f64(mv.x, k), readlane_f64(mv.y, k)); };
+  double2 acc0 = make_double2(0.0, 0.0), acc1 = make_double2(0.0, 0.0);
+  double2 chk = make_double2(0.0, 0.0);
+  double nrm = 0.0;
+  // sums in the order of spmm_rows_smem_kernel / csr_spmm_kernel: groups of eight alternating between the two partial sums while
+  // eight entries are left, then one group of four, then the last one to three entries into the first sum
+#pragma unroll
+  for (int kk = 0; kk < kSpmmTileMaxEntries; kk += 8) {
+    if (kk + 7 < len) {      // (operands four at a time: the order of the sums is that of a group of eight, the registers are half)
+#pragma unroll
+      for (int h = 0; h < 8; h += 4) {
+        double2 x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[u] = xk(kk + h + u);
+        cfma(acc0, ak(kk + h), x[0]);
+        cfma(acc1, ak(kk + h + 1), x[1]);
+        cfma(acc0, ak(kk + h + 2), x[2]);
+        cfma(acc1, ak(kk + h + 3), x[3]);
+      }
+    } else if (kk < len) {
+      if (kk + 3 < len) {
+        double2 x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[u] = xk(kk + u);
+        cfma(acc0, ak(kk), x[0]);
+        cfma(acc1, ak(kk + 1), x[1]);
+        cfma(acc0, ak(kk + 2), x[2]);
+        cfma(acc1, ak(kk + 3), x[3]);
+#pragma unroll
+        for (int u = 4; u < 7; ++u)
+          if (kk + u < len) cfma(acc0, ak(kk + u), xk(kk + u));
+      } else {
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+          if (kk + u < len) cfma(acc0, ak(kk + u), xk(kk + u));
+      }
+    }
+  }
   if (active) op.row(e, make_double2(acc0.x + acc1.x, acc0.y + acc1.y), pre, chk, nrm, e);
 }
 
@@ -286,12 +403,62 @@ static void launch_spmm_cheby_t(hipStream_t s, const int64_t* rowptr, const int3
   }
 }
 
+static bool spmm_streams_nt(const Tuning& tun, int64_t nrows, int b) {
+  return tun.spmm_nt == 2 || (tun.spmm_nt == 1 && (double)nrows * b * sizeof(double2) >= 128.0 * 1024 * 1024);
+}
+
+template <class Op>
+static void launch_rows_smem(hipStream_t s, const int64_t* rowptr, const int32_t* cols, const double2* vals, const double2* X,
+                             int64_t nrows, int b, const Op& op, const int32_t* order) {
+  constexpr int WS = 8;
+  dim3 grid((unsigned)((nrows + WS - 1) / WS), (unsigned)((b + 63) / 64));
+  hipLaunchKernelGGL((spmm_rows_smem_kernel<Op, WS>), grid, dim3(64 * WS), 0, s, rowptr, cols, vals, X, nrows, b, op, order);
+}
+
+template <class Op>
+static int launch_tiles_t(hipStream_t s, const int64_t* rowptr, const int32_t* cols, const double2* vals, const double2* X,
+                          int64_t nrows, int b, const Op& op, const SpmmTiles& P) {
+  const size_t lds = (size_t)P.T * 64 * sizeof(double2);
+  // more than the 64 KiB a launch may ask for by default: a property of the function on a device, set once per device (the call
+  // is a slow one: hundreds of microseconds on the host)
+  static std::atomic<uint64_t> done{0};
+  int dev = 0;
+  QP_HIP(hipGetDevice(&dev));
+  if (dev >= 64 || !(done.load(std::memory_order_acquire) >> dev & 1)) {
+    QP_HIP(hipFuncSetAttribute((const void*)spmm_tile_kernel<Op>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    if (dev < 64) done.fetch_or((uint64_t)1 << dev, std::memory_order_release);
+  }
+  dim3 grid((unsigned)(P.ntiles + (P.nrest + 15) / 16), (unsigned)((b + 63) / 64));
+  hipLaunchKernelGGL((spmm_tile_kernel<Op>), grid, dim3(1024), lds, s, rowptr, cols, vals, X, nrows, b, op, P.tiles, P.tab, P.shape.nd,
+                     P.T, (int)P.ntiles, P.rest, (int)P.nrest);
+  return QP_OK;
+}
+
+int launch_spmm_tile_cheby(hipStream_t s, const int64_t* rowptr, const int32_t* cols, const double2* vals, const double2* X,
+                           int64_t nrows, int64_t nnz, int b, const ChebyEpi& e, const Tuning& tun, const SpmmTiles& P, Stats* st) {
+  if (nrows == 0) return QP_OK;
+  if (spmm_streams_nt(tun, nrows, b)) {
+    ChebyOpT<true> op{e};
+    if (const int rc = launch_tiles_t(s, rowptr, cols, vals, X, nrows, b, op, P)) return rc;
+  } else {
+    ChebyOp op{e};
+    if (const int rc = launch_tiles_t(s, rowptr, cols, vals, X, nrows, b, op, P)) return rc;
+  }
+  QP_HIP(hipGetLastError());
+  if (st) {
+    st->n_launch++;
+    st->n_matvec++;
+    st->spmv_bytes += 20.0 * (double)nnz + 4.0 * (double)(nrows + 1) + 80.0 * (double)nrows * b;
+  }
+  return QP_OK;
+}
+
 int launch_spmm_cheby(hipStream_t s, const int64_t* rowptr, const int32_t* cols, const double2* vals,
                       const double2* X, int64_t nrows, int64_t nnz, int b, const ChebyEpi& e, const Tuning& tun,
                       bool rows_kernel, const int32_t* order, Stats* st) {
   if (nrows == 0) return QP_OK;
   if (rows_kernel) {
-    const bool nt = tun.spmm_nt == 2 || (tun.spmm_nt == 1 && (double)nrows * b * sizeof(double2) >= 128.0 * 1024 * 1024);
+    const bool nt = spmm_streams_nt(tun, nrows, b);
 #define QP_SPMM_ROWS(RW)                                                                                         \
   {                                                                                                              \
     const int64_t per_wg = (int64_t)(kThreads / 64) * RW;                                                        \
@@ -304,20 +471,14 @@ int launch_spmm_cheby(hipStream_t s, const int64_t* rowptr, const int32_t* cols,
       hipLaunchKernelGGL((spmm_rows_kernel<ChebyOp, RW, 8>), grid, dim3(kThreads), 0, s, rowptr, cols, vals, X, nrows, b, op, order); \
     }                                                                                                            \
   }
-    if (tun.spmm_rw == 0 && nnz <= (int64_t)INT32_MAX) {   // (the scalar-entry kernel broadcasts a 32-bit row pointer)
-#define QP_SPMM_SMEM(WS)                                                                                          \
-  {                                                                                                               \
-    dim3 grid((unsigned)((nrows + (WS) - 1) / (WS)), (unsigned)((b + 63) / 64));                                  \
-    if (nt) {                                                                                                     \
-      ChebyOpT<true> op{e};                                                                                       \
-      hipLaunchKernelGGL((spmm_rows_smem_kernel<ChebyOpT<true>, WS>), grid, dim3(64 * (WS)), 0, s, rowptr, cols, vals, X, nrows, b, op, order); \
-    } else {                                                                                                      \
-      ChebyOp op{e};                                                                                              \
-      hipLaunchKernelGGL((spmm_rows_smem_kernel<ChebyOp, WS>), grid, dim3(64 * (WS)), 0, s, rowptr, cols, vals, X, nrows, b, op, order); \
-    }                                                                                                             \
-  }
-      QP_SPMM_SMEM(8)
-#undef QP_SPMM_SMEM
+    if (tun.spmm_rw <= 0 && nnz <= (int64_t)INT32_MAX) {   // (the scalar-entry kernel broadcasts a 32-bit row pointer)
+      if (nt) {
+        ChebyOpT<true> op{e};
+        launch_rows_smem(s, rowptr, cols, vals, X, nrows, b, op, order);
+      } else {
+        ChebyOp op{e};
+        launch_rows_smem(s, rowptr, cols, vals, X, nrows, b, op, order);
+      }
     } else
     switch (tun.spmm_rw) {
       case 2: QP_SPMM_ROWS(2) break;

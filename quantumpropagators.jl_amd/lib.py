@@ -150,6 +150,7 @@ SIGNATURES = {
     "qp_operator_colblock_info": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "qp_lattice_fill_host": (C.c_int, [C.c_int64, C.c_int64, _i64p, _i32p, C.c_int, _i64p, _i32p, C.c_int64, C.POINTER(C.c_int64)]),
     "qp_operator_spmm_walk": (C.c_int, [_P, C.c_int, _i64p]),
+    "qp_operator_spmm_tiles": (C.c_int, [_P, C.c_int, _i64p]),
     "qp_state_create": (C.c_int, [_P, C.c_int64, C.POINTER(_P)]),
     "qp_state_wrap": (C.c_int, [_P, _P, C.c_int64, C.POINTER(_P)]),
     "qp_state_destroy": (C.c_int, [_P]),
@@ -648,6 +649,12 @@ class Operator:
         out = np.zeros(2, dtype=np.int64)
         check(self.lib.qp_operator_spmm_walk(self._h, int(batch), _ptr(out, _i64p)))
         return int(out[0]), int(out[1])
+
+    def spmm_tiles(self, batch):
+        """LDS-staged tiles of the batched kernel for ``batch`` states (include/qprop.h: qp_operator_spmm_tiles)."""
+        out = np.zeros(6, dtype=np.int64)
+        check(self.lib.qp_operator_spmm_tiles(self._h, int(batch), _ptr(out, _i64p)))
+        return dict(zip(("taken", "tiles", "rest_rows", "g", "K", "NN"), (int(v) for v in out)))
 
     def set_coeffs(self, coeffs):
         a, p = _as_c128(np.atleast_1d(coeffs))

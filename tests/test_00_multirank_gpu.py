@@ -332,7 +332,9 @@ def test_bench_c5_batch_split_flow_one_gpu(world):
     assert abs(d["value"] - full["value"]) < 1e-5 * full["value"]
     assert 0 < d["roofline"]["frac"] <= 1.0 and d["max_norm_drift"] < 1e-10
     assert ("csr_spmm_kernel" in full["config"]["kernel"]) == (64 // world <= 32)
-    assert d["roofline"]["kernel"] == ("csr_spmm_kernel" if 64 // world <= 32 else "spmm_rows_smem_kernel")
+    assert d["roofline"]["kernel"] == ("csr_spmm_kernel" if 64 // world <= 32 else "spmm_tile_kernel")      # (the lattice's interior rows in LDS-staged tiles)
+    if world == 1:
+        assert full["config"]["lds_tiles"]["taken"] == 1 and full["config"]["lds_tiles"]["tiles"] * 16 + full["config"]["lds_tiles"]["rest_rows"] == 1 << 14
     assert d["cpu_baseline"] is None                    # --cpu-steps 0; the default run of `--config c5` carries one (test below)
 
 

@@ -1930,7 +1930,8 @@ def test_cheby_batched_rows_kernel_and_row_walk_bit_identical(ctx, batch):
     states = np.stack([synth.random_state(N, seed=3000 + s) for s in range(batch)], axis=1)
     outs, walks = {}, {}
     try:
-        for rows, strip, rw in ((0, 0, 1), (1, -1, 1), (1, 0, 1), (1, 32, 1), (1, 64, 1), (1, 48, 1), (1, 32, 2), (1, 64, 4), (1, -1, 8), (1, -1, 0), (1, 0, 0), (1, 64, 0)):
+        for rows, strip, rw in ((0, 0, 1), (1, -1, 1), (1, 0, 1), (1, 32, 1), (1, 64, 1), (1, 48, 1), (1, 32, 2), (1, 64, 4), (1, -1, 8), (1, -1, 0), (1, 0, 0), (1, 64, 0),
+                                (1, 0, -1), (1, 32, -1)):
             ctx.tuning_set("spmm_rows", rows)
             ctx.tuning_set("spmm_strip", strip)
             ctx.tuning_set("spmm_rw", rw)
@@ -1941,10 +1942,14 @@ def test_cheby_batched_rows_kernel_and_row_walk_bit_identical(ctx, batch):
             outs[(rows, strip, rw)] = panel.numpy()
             if rw == 1:
                 walks[(rows, strip)] = Op.spmm_walk(batch)
+            if rw == -1:      # the LDS-staged tiles (the default): strip steps 4 .. 27 of 32 are interior, 6 x 64 tiles; the rest by the row kernel
+                assert Op.spmm_tiles(batch) == {"taken": 1, "tiles": 384, "rest_rows": N - 16 * 384, "g": 256, "K": 4, "NN": 4}
+            else:
+                assert Op.spmm_tiles(batch)["taken"] == 0
     finally:
         ctx.tuning_set("spmm_rows", 1)
         ctx.tuning_set("spmm_strip", 0)
-        ctx.tuning_set("spmm_rw", 0)
+        ctx.tuning_set("spmm_rw", -1)
     ref = outs[(0, 0, 1)]
     for k, v in outs.items():
         assert np.array_equal(v, ref), k

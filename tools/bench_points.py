@@ -442,6 +442,21 @@ def measure_newton_c3(ctx, n=512, m=20, dt=0.5, steps=10, warmup=60, repeats=3):
     return out
 
 
+def panel_kernel(op, batch, nnz, N):
+    """Which kernel qp_cheby_step_batched takes for a panel of `batch` states on this operator, its symbol (for rocprof / PMC filters)
+    and the MATRIX bytes of the layout it reads per term: the CSR-ordered mirror's values (16 B) and columns (4 B) per entry + row
+    pointer (8 B) and walk position (4 B) per row for the row kernels; the LDS tiles read no columns (the operands' places are a
+    table) and one tile entry per sixteen rows."""
+    if batch <= 32:
+        return "csr_spmm_kernel (state-tiled)", "csr_spmm_kernel", 20.0 * nnz + 12.0 * N
+    t = op.spmm_tiles(batch)
+    if not t["taken"]:
+        return "spmm_rows_smem_kernel (wave per row, lane = state)", "spmm_rows_smem_kernel", 20.0 * nnz + 12.0 * N
+    ft = 16.0 * t["tiles"] / N
+    return ("spmm_tile_kernel (4 x 4 rows per workgroup, operands staged in LDS; wave per row, lane = state)", "spmm_tile_kernel",
+            nnz * (16.0 * ft + 20.0 * (1.0 - ft)) + 8.0 * N + 4.0 * t["tiles"] + 4.0 * t["rest_rows"])
+
+
 def measure_batched_c5(ctx, log2n=18, batch=64, steps=5, warmup=2, repeats=3):
     """BASELINE configs[4]: `batch` states x N = 2^log2n CSR H, Chebyshev on the panel."""
     N = 1 << log2n
@@ -465,11 +480,12 @@ def measure_batched_c5(ctx, log2n=18, batch=64, steps=5, warmup=2, repeats=3):
     nupd = sum(0 if d.skip else 1 for d in sched)
     # what the shipped step must move per term: matrix once (CSR mirror: 20 B per entry + row pointers + walk order),
     # X, v_{m-2} read, v_m written, accumulator read + written by the terms of the deferred schedule
-    lay = 20.0 * nnz + 12.0 * N + 16.0 * N * batch * (3.0 - 2.0 / nterms + (2.0 * nupd - 1.0) / nterms)
+    kname, kshort, mbytes = panel_kernel(op, batch, nnz, N)
+    lay = mbytes + 16.0 * N * batch * (3.0 - 2.0 / nterms + (2.0 * nupd - 1.0) / nterms)
     norms = np.linalg.norm(panel.numpy().reshape(N, batch), axis=0)
     out = {"workload": f"BASELINE configs[4]: batched Cheby prop_step!, {batch} states x N=2^{log2n} CSR H (16 nnz/row)"
                        + ("" if batch == 64 else f" [the per-GPU share of the 64-state panel split over {64 // batch} GPUs]"),
-           "kernel": "spmm_rows_smem_kernel (wave per row, lane = state)" if batch > 32 else "csr_spmm_kernel (state-tiled)",
+           "kernel": kname, "kernel_symbol": kshort, "lds_tiles": op.spmm_tiles(batch),
            "N": N, "batch": batch, "steps": steps, "ms_per_panel_step": ms / steps,
            "state_steps_per_s": batch * steps / (ms * 1e-3), "us_per_term": t_term * 1e6,
            "us_per_term_min": sp["min"], "us_per_term_max": sp["max"], "repeats": sp["repeats"], "unstable": sp["unstable"],

@@ -375,10 +375,12 @@ __global__ __launch_bounds__(64 * RA * RC) void lds_tile_kernel(Args A) {
   if (PD > 0 && pf.x == 1.2345678e-300 && pf.y == -9.87654321e-301) A.acc_out[row * NS + lane] = pf;
 }
 
-// the workgroup tile, several tiles per workgroup in turn: the staging loads (and the row-local streams) of tile t + 1 are issued
-// into registers before tile t is computed from LDS, so the load phase of one tile overlaps the compute phase of the other
-template <int RA, int RC>
-__global__ __launch_bounds__(64 * RA * RC) void lds_tile_loop_kernel(Args A) {
+// the workgroup tile, several tiles per workgroup in turn (a persistent workgroup: no relaunch, whose granularity -- sixteen wavefront
+// slots and 80 KiB at once -- leaves slots idle until a workgroup's slowest wavefront has retired).  LATE = 0: the loads of tile t + 1
+// are issued before tile t is computed (they overlap its LDS phase but must be held in registers through it: 120 VGPRs, one workgroup
+// per compute unit); LATE = 1: they are issued after the sums of tile t, in front of its epilogue and stores (<= 64 VGPRs)
+template <int RA, int RC, int LATE>
+__global__ __launch_bounds__(64 * RA * RC) __attribute__((amdgpu_waves_per_eu(LATE ? 8 : 4, 8))) void lds_tile_loop_kernel(Args A) {
   extern __shared__ d2 lds[];
   constexpr int NW = RA * RC, T = (RA + 8) * RC + RA * 8, PER = (T + NW - 1) / NW;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -389,33 +391,38 @@ __global__ __launch_bounds__(64 * RA * RC) void lds_tile_loop_kernel(Args A) {
   const int i = wave / RC, j = wave % RC;
   d2 st[PER], v0, av = {0.0, 0.0};
   long long row = 0;
-  auto issue = [&](long long tile) {
-    const long long strip = tile / (nta * ntc), r = tile - strip * nta * ntc;
-    const long long ta = r / ntc, tc = r - ta * ntc;
-    const long long a0 = ta * RA, c0 = strip * A.sw + tc * RC;
-    row = (a0 + i) * A.g + c0 + j;
+  const unsigned g32 = (unsigned)A.g, na32 = (unsigned)na, ntc32 = (unsigned)ntc, per_strip = (unsigned)(nta * ntc), sw32 = (unsigned)A.sw;
+  auto issue_x = [&](long long tile64) {      // (32-bit index arithmetic: a 64-bit division in the loop costs dozens of registers while the loop's state is live)
+    const unsigned tile = (unsigned)tile64;
+    const unsigned strip = tile / per_strip, r = tile - strip * per_strip;
+    const unsigned ta = r / ntc32, tc = r - ta * ntc32;
+    const int a0 = (int)(ta * RA), c0 = (int)(strip * sw32 + tc * RC);
+    row = (long long)((unsigned)(a0 + i) * g32 + (unsigned)(c0 + j));
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
-      const int slot = wave + q * NW;
-      if (slot < T) {
-        long long gr;
-        if (slot < (RA + 8) * RC) {
-          const int ai = slot / RC, jj = slot % RC;
-          gr = clampll(a0 - 4 + ai, 0, na - 1) * A.g + c0 + jj;
-        } else {
-          const int s2 = slot - (RA + 8) * RC, ii = s2 / 8, jj = s2 % 8;
-          gr = (a0 + ii) * A.g + clampll(jj < 4 ? c0 - 4 + jj : c0 + RC + jj - 4, 0, A.g - 1);
-        }
-        st[q] = A.x[gr * NS + lane];
+      const int slot = wave + q * NW < T ? wave + q * NW : T - 1;
+      unsigned gr;
+      if (slot < (RA + 8) * RC) {
+        const int ai = slot / RC, jj = slot % RC;
+        const int aa = a0 - 4 + ai;
+        gr = (unsigned)(aa < 0 ? 0 : (aa > (int)na32 - 1 ? (int)na32 - 1 : aa)) * g32 + (unsigned)(c0 + jj);
+      } else {
+        const int s2 = slot - (RA + 8) * RC, ii = s2 / 8, jj = s2 % 8;
+        const int cc = jj < 4 ? c0 - 4 + jj : c0 + RC + jj - 4;
+        gr = (unsigned)(a0 + ii) * g32 + (unsigned)(cc < 0 ? 0 : (cc > (int)g32 - 1 ? (int)g32 - 1 : cc));
       }
+      st[q] = A.x[(size_t)gr * NS + lane];
     }
+  };
+  auto issue_streams = [&]() {
     v0 = __builtin_nontemporal_load(A.p + row * NS + lane);
     if (A.with_acc) av = __builtin_nontemporal_load(A.acc + row * NS + lane);
   };
   long long tile = (long long)wg * tpw;
   const long long tend = tile + tpw < ntiles ? tile + tpw : ntiles;
   if (tile >= tend) return;
-  issue(tile);
+  issue_x(tile);
+  issue_streams();
   for (; tile < tend; ++tile) {
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
@@ -423,28 +430,31 @@ __global__ __launch_bounds__(64 * RA * RC) void lds_tile_loop_kernel(Args A) {
       if (slot < T) lds[slot * NS + lane] = st[q];
     }
     const long long crow = row;
-    const d2 cv0 = v0, cav = av;
     __syncthreads();
-    if (tile + 1 < tend) issue(tile + 1);
+    if (!LATE && tile + 1 < tend) issue_x(tile + 1);
     const d2* __restrict__ rv = A.vals + crow * NE;
-    d2 x[NE];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      x[k] = lds[((i + k) * RC + j) * NS + lane];
-      x[12 + k] = lds[((i + 5 + k) * RC + j) * NS + lane];
-      const int nl = j - 4 + k, nh = j + 1 + k;
-      x[4 + k] = nl >= 0 ? lds[((i + 4) * RC + nl) * NS + lane] : lds[((RA + 8) * RC + i * 8 + 4 + nl) * NS + lane];
-      x[8 + k] = nh < RC ? lds[((i + 4) * RC + nh) * NS + lane] : lds[((RA + 8) * RC + i * 8 + 4 + nh - RC) * NS + lane];
-    }
     const d2 xi = lds[((i + 4) * RC + j) * NS + lane];
     d2 s0 = {0.0, 0.0}, s1 = {0.0, 0.0};
 #pragma unroll
-    for (int k = 0; k < NE; k += 2) {
-      cfma(s0, rv[k], x[k]);
-      cfma(s1, rv[k + 1], x[k + 1]);
+    for (int h = 0; h < 4; ++h) {      // entries 4 h .. 4 h + 3: far below, near below, near above, far above
+      d2 x[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (h == 0) x[k] = lds[((i + k) * RC + j) * NS + lane];
+        if (h == 3) x[k] = lds[((i + 5 + k) * RC + j) * NS + lane];
+        const int nl = j - 4 + k, nh = j + 1 + k;
+        if (h == 1) x[k] = nl >= 0 ? lds[((i + 4) * RC + nl) * NS + lane] : lds[((RA + 8) * RC + i * 8 + 4 + nl) * NS + lane];
+        if (h == 2) x[k] = nh < RC ? lds[((i + 4) * RC + nh) * NS + lane] : lds[((RA + 8) * RC + i * 8 + 4 + nh - RC) * NS + lane];
+      }
+      cfma(s0, rv[4 * h], x[0]);
+      cfma(s1, rv[4 * h + 1], x[1]);
+      cfma(s0, rv[4 * h + 2], x[2]);
+      cfma(s1, rv[4 * h + 3], x[3]);
     }
-    finish2(A, crow, lane, s0, s1, xi, cv0, cav);
     __syncthreads();
+    if (LATE && tile + 1 < tend) issue_x(tile + 1);      // (the row-local streams of the next tile after this tile's epilogue: their registers are this tile's until then)
+    finish2(A, crow, lane, s0, s1, xi, v0, av);
+    if (tile + 1 < tend) issue_streams();
   }
 }
 
@@ -702,25 +712,28 @@ int main(int argc, char** argv) {
         }, reps, bytes, &got)) return 1;                                                                                          \
     printf("{\"lds_tile_slice\": \"%dx%dx%d\", \"lds_kib\": %zu, \"bit_identical_to_rows\": %s}\n", RA, RC, S, ldsb / 1024, memcmp(ref.data(), got.data(), pe * sizeof(d2)) == 0 ? "true" : "false"); \
   }
-#define LDSL(RA, RC, TPW)                                                                                                         \
+#define LDSL(RA, RC, TPW, LATE)                                                                                                         \
   {                                                                                                                               \
     if (reset()) return 1;                                                                                                        \
     const long long ntask = (n / g / RA) * (long long)(g / RC);                                                                    \
     const size_t ldsb = (size_t)((RA + 8) * RC + RA * 8) * NS * sizeof(d2);                                                        \
-    CK(hipFuncSetAttribute((const void*)lds_tile_loop_kernel<RA, RC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));     \
+    CK(hipFuncSetAttribute((const void*)lds_tile_loop_kernel<RA, RC, LATE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb)); \
     Args B2 = A;                                                                                                                  \
     B2.persist = TPW;                                                                                                             \
-    if (time_it("lds_tile_loop_" #TPW, RA, RC, B2, bufs, [&](const Args& a) {                                                     \
-          hipLaunchKernelGGL((lds_tile_loop_kernel<RA, RC>), dim3((unsigned)((ntask + TPW - 1) / TPW)), dim3(64 * RA * RC), ldsb, 0, a); \
+    if (time_it("lds_tile_loop_" #TPW "_late_" #LATE, RA, RC, B2, bufs, [&](const Args& a) {                                      \
+          hipLaunchKernelGGL((lds_tile_loop_kernel<RA, RC, LATE>), dim3((unsigned)((ntask + TPW - 1) / TPW)), dim3(64 * RA * RC), ldsb, 0, a); \
         }, reps, bytes, &got)) return 1;                                                                                          \
     printf("{\"lds_tile_loop\": \"%dx%d\", \"tiles_per_workgroup\": %d, \"bit_identical_to_rows\": %s}\n", RA, RC, TPW, memcmp(ref.data(), got.data(), pe * sizeof(d2)) == 0 ? "true" : "false"); \
   }
-  LDSL(4, 4, 1)
-  LDSL(4, 4, 2)
-  LDSL(4, 4, 4)
-  LDSL(4, 4, 8)
-  LDSL(4, 4, 16)
-  LDSL(4, 4, 32)
+  LDSL(4, 4, 1, 1)
+  LDSL(4, 4, 2, 1)
+  LDSL(4, 4, 4, 1)
+  LDSL(4, 4, 8, 1)
+  LDSL(4, 4, 16, 1)
+  LDSL(4, 4, 31, 1)
+  LDSL(4, 4, 62, 1)
+  LDSL(4, 4, 8, 0)
+  if (argc > 9) return 0;
   LDSS(4, 4, 64)
   LDSS(4, 4, 32)
   LDSS(4, 4, 16)

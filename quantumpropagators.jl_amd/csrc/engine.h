@@ -34,6 +34,11 @@ struct qp_ctx {
   // collector -- Python's, Julia's -- run in no particular order)
   bool closed = false;
   qp::Tuning tun;              // this context's developer knobs (qp_ctx_tuning_set)
+  // two pinned staging buffers for the operator build's value upload (host threads fill one while the other is on its way to
+  // the device), allocated by the first large build and kept: pinning is the slow part
+  void* stage[2] = {nullptr, nullptr};
+  size_t stage_bytes = 0;
+  hipEvent_t stage_ev[2] = {nullptr, nullptr};
 };
 
 struct qp_state {
@@ -43,12 +48,36 @@ struct qp_state {
   bool own;
 };
 
+// Host arrays of the size of a matrix (gigabytes at N = 2^24): resize() leaves the new elements unwritten -- whoever resizes fills them,
+// on several threads -- instead of one thread zeroing them first (std::vector<T>: a serial pass over memory before the real one)
+namespace qp {
+template <class T>
+struct NoInitAlloc {
+  using value_type = T;
+  NoInitAlloc() = default;
+  template <class U>
+  NoInitAlloc(const NoInitAlloc<U>&) {}
+  T* allocate(size_t n) { return static_cast<T*>(::operator new(n * sizeof(T))); }
+  void deallocate(T* p, size_t) { ::operator delete(p); }
+  template <class U, class... A>
+  void construct(U* p, A&&... a) {
+    if constexpr (sizeof...(A) > 0) ::new ((void*)p) U(std::forward<A>(a)...);      // (no arguments: nothing written)
+  }
+  template <class U>
+  bool operator==(const NoInitAlloc<U>&) const { return true; }
+  template <class U>
+  bool operator!=(const NoInitAlloc<U>&) const { return false; }
+};
+template <class T>
+using HostVec = std::vector<T, NoInitAlloc<T>>;
+}  // namespace qp
+
 struct qp_matrix {  // canonical host CSR (the result of the boundary's index work)
   qp_ctx* ctx;
   int64_t nrows, ncols, nnz;
-  std::vector<int64_t> rowptr;
-  std::vector<int32_t> col;
-  std::vector<cplx> vals;
+  qp::HostVec<int64_t> rowptr;
+  qp::HostVec<int32_t> col;
+  qp::HostVec<cplx> vals;
 };
 
 struct HostLayoutData {
@@ -94,8 +123,8 @@ struct qp_operator {
   int64_t m_order_g = 0, m_order_sw = 0;   // what was detected: inner dimension and strip width (0: none)
   qp::SpmmTiles m_tiles;                   // LDS-staged tiles of the batched path (operator_spmm_tiles), built lazily
   int nops = 0, ncoeffs = 0;
-  std::vector<int64_t> u_rowptr;  // union pattern (host), for get_csr and plane scatter
-  std::vector<int32_t> u_col;
+  qp::HostVec<int64_t> u_rowptr;  // union pattern (host), for get_csr and plane scatter
+  qp::HostVec<int32_t> u_col;
   std::vector<double2*> planes;   // device value planes, one per term, layout of A.vals
   double2** planes_dev = nullptr;
   double2* combined = nullptr;    // device, allocated on first non-trivial coefficient set

@@ -220,6 +220,13 @@ int qp_ctx_destroy(qp_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->d_part) (void)hipFree(ctx->d_part);
   if (ctx->h_part) (void)hipHostFree(ctx->h_part);
+  for (int k = 0; k < 2; ++k) {
+    if (ctx->stage[k]) (void)hipHostFree(ctx->stage[k]);
+    if (ctx->stage_ev[k]) (void)hipEventDestroy(ctx->stage_ev[k]);
+    ctx->stage[k] = nullptr;
+    ctx->stage_ev[k] = nullptr;
+  }
+  ctx->stage_bytes = 0;
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -306,12 +313,14 @@ int qp_matrix_create(qp_ctx* ctx, int64_t nrows, int64_t ncols, int64_t nnz, con
   m->rowptr.resize(nrows + 1);
   m->col.resize(nnz);
   m->vals.resize(nnz);
-  std::vector<qp_c128> cv;
+  qp::HostVec<qp_c128> cv;
   const qp_c128* v128 = nullptr;
   if (val_dtype == QP_VAL_F64) {
     cv.resize(nnz);
     const double* r = static_cast<const double*>(vals);
-    for (int64_t p = 0; p < nnz; ++p) cv[p] = qp_c128{r[p], 0.0};
+    parallel_rows(nnz, [&](int64_t p0, int64_t p1) {
+      for (int64_t p = p0; p < p1; ++p) cv[p] = qp_c128{r[p], 0.0};
+    }, (int64_t)1 << 20);
     v128 = cv.data();
   } else {
     v128 = static_cast<const qp_c128*>(vals);
@@ -326,28 +335,45 @@ int qp_matrix_create(qp_ctx* ctx, int64_t nrows, int64_t ncols, int64_t nnz, con
   } else if (layout == QP_LAYOUT_CSR) {
     if (ptr[nrows] - index_base != nnz) return qp::fail(QP_E_BAD_ARG, "rowptr[end] does not match nnz");
     if (ptr[0] != index_base) return qp::fail(QP_E_BAD_ARG, "rowptr[0] must equal the index base (%d)", index_base);
-    for (int64_t r = 0; r <= nrows; ++r) m->rowptr[r] = ptr[r] - index_base;
-    for (int64_t r = 0; r < nrows; ++r)
-      if (m->rowptr[r + 1] < m->rowptr[r]) return qp::fail(QP_E_BAD_ARG, "rowptr not monotone at row %lld", (long long)r);
-    for (int64_t p = 0; p < nnz; ++p) {
-      int64_t c = idx[p] - index_base;
-      if (c < 0 || c >= ncols) return qp::fail(QP_E_BAD_ARG, "column index out of range at %lld", (long long)p);
-      m->col[p] = (int32_t)c;
-      m->vals[p] = cplx(v128[p].re, v128[p].im);
-    }
-    // canonical form: columns ascending within each row (stable)
-    std::vector<std::pair<int32_t, cplx>> tmp;
-    for (int64_t r = 0; r < nrows; ++r) {
-      int64_t a = m->rowptr[r], b = m->rowptr[r + 1];
-      bool sorted = true;
-      for (int64_t p = a + 1; p < b; ++p)
-        if (m->col[p] < m->col[p - 1]) { sorted = false; break; }
-      if (sorted) continue;
-      tmp.resize(b - a);
-      for (int64_t p = a; p < b; ++p) tmp[p - a] = {m->col[p], m->vals[p]};
-      std::stable_sort(tmp.begin(), tmp.end(), [](auto& x, auto& y) { return x.first < y.first; });
-      for (int64_t p = a; p < b; ++p) { m->col[p] = tmp[p - a].first; m->vals[p] = tmp[p - a].second; }
-    }
+    // rows in chunks on the host threads (N = 2^24: 5 GB of index and value arrays; one thread took 1.5 s): the copy with its range
+    // checks, then per row the canonical form -- columns ascending (stable: duplicates keep their order and are summed later)
+    std::atomic<int64_t> bad_row{-1}, bad_col{-1};
+    parallel_rows(nrows + 1, [&](int64_t r0, int64_t r1) {
+      for (int64_t r = r0; r < r1; ++r) m->rowptr[r] = ptr[r] - index_base;
+    });
+    parallel_rows(nrows, [&](int64_t r0, int64_t r1) {
+      for (int64_t r = r0; r < r1; ++r)
+        if (m->rowptr[r + 1] < m->rowptr[r] || m->rowptr[r] < 0 || m->rowptr[r + 1] > nnz) {
+          int64_t none = -1;
+          bad_row.compare_exchange_strong(none, r);
+          return;
+        }
+    });
+    if (bad_row.load() >= 0) return qp::fail(QP_E_BAD_ARG, "rowptr not monotone at row %lld", (long long)bad_row.load());
+    parallel_rows(nrows, [&](int64_t r0, int64_t r1) {
+      std::vector<std::pair<int32_t, cplx>> tmp;
+      for (int64_t r = r0; r < r1; ++r) {
+        const int64_t a = m->rowptr[r], b = m->rowptr[r + 1];
+        bool sorted = true;
+        for (int64_t p = a; p < b; ++p) {
+          const int64_t c = idx[p] - index_base;
+          if (c < 0 || c >= ncols) {
+            int64_t none = -1;
+            bad_col.compare_exchange_strong(none, p);
+            return;
+          }
+          m->col[p] = (int32_t)c;
+          m->vals[p] = cplx(v128[p].re, v128[p].im);
+          if (p > a && m->col[p] < m->col[p - 1]) sorted = false;
+        }
+        if (sorted) continue;
+        tmp.resize((size_t)(b - a));
+        for (int64_t p = a; p < b; ++p) tmp[(size_t)(p - a)] = {m->col[p], m->vals[p]};
+        std::stable_sort(tmp.begin(), tmp.end(), [](auto& x, auto& y) { return x.first < y.first; });
+        for (int64_t p = a; p < b; ++p) { m->col[p] = tmp[(size_t)(p - a)].first; m->vals[p] = tmp[(size_t)(p - a)].second; }
+      }
+    });
+    if (bad_col.load() >= 0) return qp::fail(QP_E_BAD_ARG, "column index out of range at %lld", (long long)bad_col.load());
   } else {
     return qp::fail(QP_E_BAD_ARG, "bad layout");
   }
@@ -487,7 +513,7 @@ struct PlaneView {
   size_t size() const { return n; }
   const cplx* begin() const { return p; }
   const cplx* end() const { return p + n; }
-  void borrow(const std::vector<cplx>& v) {
+  void borrow(const qp::HostVec<cplx>& v) {
     std::vector<cplx>().swap(own);
     p = v.data();
     n = v.size();
@@ -506,7 +532,7 @@ struct PlaneView {
 };
 using Planes = std::vector<PlaneView>;
 
-static bool csr_is_hermitian(int64_t n, const std::vector<int64_t>& rp, const std::vector<int32_t>& col,
+static bool csr_is_hermitian(int64_t n, const qp::HostVec<int64_t>& rp, const qp::HostVec<int32_t>& col,
                              const PlaneView& vals) {
   // Every row on its own (rows in chunks on a few host threads): columns strictly ascending, a real diagonal, and for every
   // lower entry (r, c), c < r, the upper entry (c, r) with the conjugate value -- found by bisection in row c (rows are short);
@@ -856,7 +882,9 @@ static int operator_build_device_impl(qp_operator* op, int format, const Planes&
     trace.mark("  upper column sections + upload");
     if (hrb) {
       // lower section: (column, position of the conj-transposed value in the upper section)
-      std::vector<int32_t> lpos((size_t)std::max<int64_t>(A.lstored, 1), -1);
+      qp::HostVec<int32_t> lpos;      // (half a gigabyte at N = 2^24: filled on the host threads, not by one)
+      lpos.resize((size_t)std::max<int64_t>(A.lstored, 1));
+      parallel_rows((int64_t)lpos.size(), [&](int64_t a, int64_t b) { std::fill(lpos.begin() + a, lpos.begin() + b, (int32_t)-1); }, (int64_t)1 << 20);
       if (Lh.stored >= (int64_t)INT32_MAX) return qp::fail(QP_E_BAD_ARG, "Hermitian-packed format needs < 2^31 stored values per GPU");
       parallel_rows(nrows, [&](int64_t r_begin, int64_t r_end) {
         for (int64_t r = r_begin; r < r_end; ++r) {
@@ -944,29 +972,81 @@ static int operator_build_device_impl(qp_operator* op, int format, const Planes&
       }, (int64_t)1 << 20);
     op->planes_real = all_real.load();
   }
-  // (raw storage: a std::vector would zero its 2 GB serially at N = 2^24 before the threaded fill below does it again)
   const size_t hplane_n = (size_t)std::max<int64_t>(A.stored, 1);
-  std::unique_ptr<cplx, void (*)(void*)> hplane_buf(static_cast<cplx*>(std::malloc(hplane_n * sizeof(cplx))), std::free);
-  if (!hplane_buf) return qp::fail(QP_E_ALLOC, "out of host memory building the operator (%zu bytes)", hplane_n * sizeof(cplx));
-  cplx* const hplane = hplane_buf.get();
   // positions a control term touches (kept while it may still belong to the sparse suffix, see qp_operator::sparse_from)
   const int drift_planes = nops - op->ncoeffs;
   std::vector<std::vector<std::pair<int32_t, cplx>>> touched((size_t)nops);
   std::vector<char> is_sparse((size_t)nops, 0);
   const bool sparse_candidates = nops >= 2 && op->ncoeffs >= 1 && A.stored < (int64_t)INT32_MAX;
-  for (int l = 0; l < nops; ++l) {
-    parallel_rows((int64_t)hplane_n, [&](int64_t a, int64_t b) { std::fill(hplane + a, hplane + b, cplx(0.0)); }, (int64_t)1 << 20);
-    const auto& pv = planes_csr[l];
-    parallel_rows(nrows, [&](int64_t r_begin, int64_t r_end) {
-      for (int64_t r = r_begin; r < r_end; ++r) {
-        const int64_t nl = (format == QP_FMT_HRB) ? op->layout.nlow[r] : 0;
-        for (int64_t k = nl; k < ur[r + 1] - ur[r]; ++k) {
-          const int64_t pos = qp::csr_layout(format) ? ur[r] + k : rb_val_pos(op->layout.bptr, r, k - nl);
-          hplane[pos] = pv[ur[r] + k];
-        }
+  // position of the first stored value of 64-row unit u (row blocks of the two row-block formats, 64 rows of a CSR layout): the
+  // values of the rows of units [u0, u1) fill the positions [unit_pos(u0), unit_pos(u1)) and nothing else
+  const int64_t nunits = (nrows + kRB - 1) / kRB;
+  auto unit_pos = [&](int64_t u) -> int64_t {
+    if (qp::csr_layout(format)) return ur[std::min(nrows, u * kRB)];
+    return u >= nunits ? op->layout.bptr[(size_t)A.nblocks] : op->layout.bptr[(size_t)u];
+  };
+  auto scatter_rows = [&](const PlaneView& pv, int64_t r_begin, int64_t r_end, cplx* dst, int64_t dst_pos0) {
+    for (int64_t r = r_begin; r < r_end; ++r) {
+      const int64_t nl = (format == QP_FMT_HRB) ? op->layout.nlow[r] : 0;
+      for (int64_t k = nl; k < ur[r + 1] - ur[r]; ++k) {
+        const int64_t pos = qp::csr_layout(format) ? ur[r] + k : rb_val_pos(op->layout.bptr, r, k - nl);
+        dst[pos - dst_pos0] = pv[ur[r] + k];
       }
-    });
-    if (sparse_candidates && l >= drift_planes && l >= 1) {
+    }
+  };
+  constexpr size_t kStageBytes = (size_t)64 << 20;
+  std::unique_ptr<cplx, void (*)(void*)> hplane_buf(nullptr, std::free);
+  cplx* hplane = nullptr;
+  for (int l = 0; l < nops; ++l) {
+    const auto& pv = planes_csr[l];
+    double2* dp = nullptr;
+    QP_CHECK(dev_alloc(&dp, (size_t)A.stored));
+    op->planes.push_back(dp);
+    const bool candidate = sparse_candidates && l >= drift_planes && l >= 1;      // (its positions are inspected on the host below)
+    if (!candidate && (size_t)A.stored * sizeof(cplx) >= 4 * kStageBytes) {
+      // a large plane: units in chunks of 64 MiB, written in device order into one of two pinned buffers by the host threads while
+      // the other buffer's chunk is on its way to the device (one pageable 2.4 GB copy after a 2.4 GB fill took 0.42 s at N = 2^24)
+      if (ctx->stage_bytes < kStageBytes) {
+        for (int k = 0; k < 2; ++k) {
+          if (ctx->stage[k]) (void)hipHostFree(ctx->stage[k]);
+          ctx->stage[k] = nullptr;
+          QP_HIP(hipHostMalloc(&ctx->stage[k], kStageBytes, hipHostMallocDefault));
+          if (!ctx->stage_ev[k]) QP_HIP(hipEventCreateWithFlags(&ctx->stage_ev[k], hipEventDisableTiming));
+        }
+        ctx->stage_bytes = kStageBytes;
+      }
+      const int64_t cap = (int64_t)(kStageBytes / sizeof(cplx));
+      int which = 0;
+      bool used[2] = {false, false};
+      for (int64_t u0 = 0; u0 < nunits;) {
+        int64_t u1 = u0 + 1;
+        while (u1 < nunits && unit_pos(u1 + 1) - unit_pos(u0) <= cap) ++u1;
+        const int64_t p0 = unit_pos(u0), p1 = unit_pos(u1);
+        if (p1 - p0 > cap) return qp::fail(QP_E_BAD_ARG, "operator build: a 64-row block of %lld stored values exceeds the staging buffer", (long long)(p1 - p0));
+        cplx* buf = static_cast<cplx*>(ctx->stage[which]);
+        if (used[which]) QP_HIP(hipEventSynchronize(ctx->stage_ev[which]));
+        parallel_rows(p1 - p0, [&](int64_t a, int64_t b) { std::fill(buf + a, buf + b, cplx(0.0)); }, (int64_t)1 << 18);
+        parallel_rows(std::min(nrows, u1 * kRB) - u0 * kRB, [&](int64_t a, int64_t b) { scatter_rows(pv, u0 * kRB + a, u0 * kRB + b, buf, p0); }, 1024);
+        if (p1 > p0) QP_HIP(hipMemcpyAsync(dp + p0, buf, (size_t)(p1 - p0) * sizeof(double2), hipMemcpyHostToDevice, ctx->stream));
+        QP_HIP(hipEventRecord(ctx->stage_ev[which], ctx->stream));
+        used[which] = true;
+        which ^= 1;
+        u0 = u1;
+      }
+      const int64_t pend = unit_pos(nunits);      // (the slack behind the last block: zeros)
+      if (A.stored > pend) QP_HIP(hipMemsetAsync(dp + pend, 0, (size_t)(A.stored - pend) * sizeof(double2), ctx->stream));
+      QP_HIP(hipStreamSynchronize(ctx->stream));
+      continue;
+    }
+    if (!hplane) {
+      // (raw storage: a std::vector would zero its gigabytes serially before the threaded fill below does it again)
+      hplane_buf.reset(static_cast<cplx*>(std::malloc(hplane_n * sizeof(cplx))));
+      if (!hplane_buf) return qp::fail(QP_E_ALLOC, "out of host memory building the operator (%zu bytes)", hplane_n * sizeof(cplx));
+      hplane = hplane_buf.get();
+    }
+    parallel_rows((int64_t)hplane_n, [&](int64_t a, int64_t b) { std::fill(hplane + a, hplane + b, cplx(0.0)); }, (int64_t)1 << 20);
+    parallel_rows(nrows, [&](int64_t r_begin, int64_t r_end) { scatter_rows(pv, r_begin, r_end, hplane, 0); });
+    if (candidate) {
       auto& t = touched[(size_t)l];
       const size_t limit = (size_t)(A.stored / 4);
       bool few = true;
@@ -978,9 +1058,6 @@ static int operator_build_device_impl(qp_operator* op, int format, const Planes&
       if (few) is_sparse[(size_t)l] = 1;
       else t.clear(), t.shrink_to_fit();
     }
-    double2* dp = nullptr;
-    QP_CHECK(dev_alloc(&dp, (size_t)A.stored));
-    op->planes.push_back(dp);
     QP_HIP(hipMemcpy(dp, hplane, (size_t)A.stored * sizeof(double2), hipMemcpyHostToDevice));
   }
   {
@@ -1128,9 +1205,13 @@ static int build_coded_values(qp_operator* op, const Planes& planes_csr) {
 // coefficient forces a Hermitian-packed operator back to plain row blocks); qp_operator_build_info reports it
 static int operator_build_device(qp_operator* op, int format, const Planes& planes_csr) {
   const auto t0 = std::chrono::steady_clock::now();
+  BuildTrace trace;
   int rc = operator_build_device_impl(op, format, planes_csr);
+  trace.mark("  (layout and value planes, with their scratch released)");
   if (rc == QP_OK) rc = build_colblock(op);
+  trace.mark("  column-block plan");
   if (rc == QP_OK && !(op->cb.valid && op->ctx->tun.colblock != 0)) rc = build_coded_values(op, planes_csr);
+  trace.mark("  value dictionary");
   op->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   op->build_ms_total += op->build_ms;
   op->n_builds++;
@@ -1197,7 +1278,6 @@ int qp_operator_create(qp_ctx* ctx, qp_matrix* const* ops, int nops, int ncoeffs
   // ---- union sparsity pattern (sorted merge per row) ----
   auto& ur = op->u_rowptr;
   auto& uc = op->u_col;
-  ur.assign(nrows + 1, 0);
   // (one term whose rows are strictly ascending IS the union pattern; a term with repeated or unsorted columns goes through the
   // merge like several terms do, so that density, completeness and every layout decision below see each position once --
   // a duplicate could make the stored count reach nrows x ncols with positions missing)
@@ -1215,9 +1295,12 @@ int qp_operator_create(qp_ctx* ctx, qp_matrix* const* ops, int nops, int ncoeffs
     canonical = asc.load();
   }
   if (canonical) {
-    ur = ops[0]->rowptr;
-    uc = ops[0]->col;
+    ur.resize(ops[0]->rowptr.size());
+    uc.resize(ops[0]->col.size());
+    parallel_copy(ur.data(), ops[0]->rowptr.data(), ur.size());
+    parallel_copy(uc.data(), ops[0]->col.data(), uc.size());
   } else {
+    ur.assign(nrows + 1, 0);
     std::vector<int32_t> merged;
     for (int64_t r = 0; r < nrows; ++r) {
       merged.clear();
@@ -1260,8 +1343,8 @@ int qp_operator_create(qp_ctx* ctx, qp_matrix* const* ops, int nops, int ncoeffs
   // tentatively, keep the original pattern, and take the completion back if the operator turns out non-Hermitian, is laid
   // out otherwise, or has no plan after all (a non-Hermitian lattice-shaped Liouvillian kept up to 12 % stored
   // zeros for nothing -- more bytes per mat-vec, and 0 * Inf = NaN where the reference has no entry).
-  std::vector<int64_t> ur_orig;
-  std::vector<int32_t> uc_orig;
+  qp::HostVec<int64_t> ur_orig;
+  qp::HostVec<int32_t> uc_orig;
   if (!dense && (format == QP_FMT_AUTO || format == QP_FMT_HRB)) {
     const int64_t before = ur[nrows];
     lattice_fill(ctx->tun, nrows, ncols, ur, uc, &ur_orig, &uc_orig);      // (ur_orig / uc_orig stay empty when nothing was completed)
@@ -1539,8 +1622,8 @@ int qp_lattice_fill_host(int64_t nrows, int64_t ncols, const int64_t* rowptr, co
   QP_TRY
   if (!rowptr || !col || !rowptr_out || !col_out || !nnz_out || nrows < 0 || ncols < 0 || rowptr[0] != 0)
     return qp::fail(QP_E_BAD_ARG, "qp_lattice_fill_host: bad arguments");
-  std::vector<int64_t> ur(rowptr, rowptr + nrows + 1);
-  std::vector<int32_t> uc(col, col + rowptr[nrows]);
+  qp::HostVec<int64_t> ur(rowptr, rowptr + nrows + 1);
+  qp::HostVec<int32_t> uc(col, col + rowptr[nrows]);
   qp::Tuning tun;
   tun.lattice_fill = 1;
   tun.walk_min_blocks = min_blocks;

@@ -22,7 +22,14 @@ inline unsigned host_threads() {
       }
       std::fclose(f);
     }
-    return std::max(1u, std::min(8u, hw > 2 ? hw - 1 : hw));
+    // up to 16 (the passes are memory-bound: more threads than that buy little; eight ranks of a node each take their share);
+    // QP_HOST_THREADS overrides
+    unsigned cap = 16;
+    if (const char* e = std::getenv("QP_HOST_THREADS")) {
+      const long v = std::atol(e);
+      if (v >= 1) cap = (unsigned)std::min<long>(v, 256);
+    }
+    return std::max(1u, std::min(cap, hw > 2 ? hw - 1 : hw));
   }();
   return n;
 }
@@ -67,6 +74,14 @@ inline void parallel_rows(int64_t n, F&& fn, int64_t serial_below = (int64_t)1 <
 }
 
 
+// dst[0, n) = src[0, n) on the host threads (gigabyte arrays: one thread's memcpy is a third of the machine's rate)
+template <class T>
+inline void parallel_copy(T* dst, const T* src, size_t n) {
+  if (n == 0) return;      // (memcpy's pointers must not be null, even for no bytes)
+  parallel_rows((int64_t)n, [&](int64_t a, int64_t b) { std::memcpy(static_cast<void*>(dst + a), static_cast<const void*>(src + a), (size_t)(b - a) * sizeof(T)); },
+                (int64_t)1 << 20);
+}
+
 // ---- host-side layout of the two row-block formats --------------------------------
 // Within a 64-row block, entry k of row r sits at  base + 64 k + (r % 64); column
 // indices (and the lower section's positions) are packed four k per lane.
@@ -82,8 +97,8 @@ using HostLayout = HostLayoutData;
 // engine_plans.hip
 struct WalkShape;
 int choose_format(qp_operator* op, int requested, bool hermitian);
-void lattice_fill(const qp::Tuning& tun, int64_t n, int64_t ncols, std::vector<int64_t>& ur, std::vector<int32_t>& uc,
-                  std::vector<int64_t>* ur_before = nullptr, std::vector<int32_t>* uc_before = nullptr);
+void lattice_fill(const qp::Tuning& tun, int64_t n, int64_t ncols, qp::HostVec<int64_t>& ur, qp::HostVec<int32_t>& uc,
+                  qp::HostVec<int64_t>* ur_before = nullptr, qp::HostVec<int32_t>* uc_before = nullptr);
 int build_walk_plan(qp_operator* op);
 int build_colblock(qp_operator* op);
 // position of every union-CSR entry in the operator's value array (-(position) - 1: its complex conjugate)

@@ -556,8 +556,8 @@ int choose_format(qp_operator* op, int requested, bool hermitian) {
 // list, that list has the walk's shape, and at most 12 % of the entries are missing (a 64 x 8 x nz grid: 4 %), the missing ones are stored as explicit
 // zeros (with their transposes, so that the pattern stays structurally symmetric).  Index work only; 0 * x terms change no
 // row sum beyond the order in which the two accumulators of a row take their entries.
-void lattice_fill(const qp::Tuning& tun, int64_t n, int64_t ncols, std::vector<int64_t>& ur, std::vector<int32_t>& uc,
-                  std::vector<int64_t>* ur_before, std::vector<int32_t>* uc_before) {
+void lattice_fill(const qp::Tuning& tun, int64_t n, int64_t ncols, qp::HostVec<int64_t>& ur, qp::HostVec<int32_t>& uc,
+                  qp::HostVec<int64_t>* ur_before, qp::HostVec<int32_t>* uc_before) {
   if (!tun.lattice_fill || ncols < n || n / kRB < std::max(tun.walk_min_blocks, 16)) return;
   // (ncols > n: the local rows of a row-partitioned operator; its halo columns appear only in the first / last K g rows)
   // the reference row: the fullest one near the middle (the middle row itself may sit on the grid's edge)
@@ -621,8 +621,8 @@ void lattice_fill(const qp::Tuning& tun, int64_t n, int64_t ncols, std::vector<i
     }
   }
   std::sort(extra.begin(), extra.end());
-  std::vector<int64_t> nr((size_t)n + 1, 0);
-  std::vector<int32_t> nc;
+  qp::HostVec<int64_t> nr((size_t)n + 1, 0);
+  qp::HostVec<int32_t> nc;
   nc.reserve(uc.size() + (size_t)missing + extra.size());
   size_t ex = 0;
   std::vector<int32_t> row;

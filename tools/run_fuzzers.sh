@@ -12,3 +12,4 @@ timeout 900 python tools/fuzz_dense.py 400 53 > gpurun_out/fz/fuzz_dense.txt 2>&
 timeout 900 python tools/fuzz_colblock.py 300 55 > gpurun_out/fz/fuzz_colblock.txt 2>&1; tail -1 gpurun_out/fz/fuzz_colblock.txt
 timeout 1500 python tools/fuzz_walk.py 400 5123 4 > gpurun_out/fz/fuzz_walk_diagonals_and_long_pairs.txt 2>&1; tail -1 gpurun_out/fz/fuzz_walk_diagonals_and_long_pairs.txt
 timeout 900 python tools/fuzz_pauli.py 300 71 > gpurun_out/fz/fuzz_pauli.txt 2>&1; tail -1 gpurun_out/fz/fuzz_pauli.txt
+timeout 1200 python tools/fuzz_spmm_tiles.py 300 91 > gpurun_out/fz/fuzz_spmm_tiles.txt 2>&1; tail -1 gpurun_out/fz/fuzz_spmm_tiles.txt

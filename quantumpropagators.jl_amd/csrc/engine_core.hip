@@ -501,7 +501,7 @@ static int operator_free(qp_operator* op) {
 // A term's values in union order: the term's own array (one canonical term: the union pattern IS the term's -- no 4 GB copy at
 // N = 2^24) or an array of its own.
 struct PlaneView {
-  std::vector<cplx> own;
+  qp::HostVec<cplx> own;
   const cplx* p = nullptr;
   size_t n = 0;
   PlaneView() = default;
@@ -514,18 +514,20 @@ struct PlaneView {
   const cplx* begin() const { return p; }
   const cplx* end() const { return p + n; }
   void borrow(const qp::HostVec<cplx>& v) {
-    std::vector<cplx>().swap(own);
+    qp::HostVec<cplx>().swap(own);
     p = v.data();
     n = v.size();
   }
-  std::vector<cplx>& make_own(size_t count) {
-    own.assign(count, cplx(0));
+  qp::HostVec<cplx>& make_own(size_t count) {      // zeros, written by the host threads
+    own.resize(count);
+    cplx* o = own.data();
+    parallel_rows((int64_t)count, [o](int64_t a, int64_t b) { std::fill(o + a, o + b, cplx(0.0)); }, (int64_t)1 << 20);
     p = own.data();
     n = count;
     return own;
   }
   void clear() {
-    std::vector<cplx>().swap(own);
+    qp::HostVec<cplx>().swap(own);
     p = nullptr;
     n = 0;
   }

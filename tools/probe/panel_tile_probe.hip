@@ -504,8 +504,19 @@ __global__ __launch_bounds__(RA * RC * S) void lds_tile_s_kernel(Args A) {
   __syncthreads();
   const d2* __restrict__ rv = A.vals + row * NE;
   d2 v[NE];
+  if (S == 32) {
+    // two rows per wavefront: each half's lanes 0 .. 15 hold their row's entries (one coalesced load of 2 x 256 B, issued before the
+    // barrier would be better still), broadcast by v_readlane from both halves and selected per half
+    const d2 mv = rv[stl & 15];
 #pragma unroll
-  for (int k = 0; k < NE; ++k) v[k] = rv[k];
+    for (int k = 0; k < NE; ++k) {
+      const d2 lo = d2{readlane_f64(mv.x, k), readlane_f64(mv.y, k)}, hi = d2{readlane_f64(mv.x, 32 + k), readlane_f64(mv.y, 32 + k)};
+      v[k] = (tid & 32) ? hi : lo;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < NE; ++k) v[k] = rv[k];
+  }
   d2 x[NE];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {

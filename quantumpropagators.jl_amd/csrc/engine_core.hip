@@ -1365,7 +1365,15 @@ int qp_operator_create(qp_ctx* ctx, qp_matrix* const* ops, int nops, int ncoeffs
   for (int l = 0; l < nops; ++l) {
     const qp_matrix* M = ops[l];
     auto& pv = planes_csr[l];
-    if (nops == 1 && canonical && (int64_t)M->vals.size() == op->A.nnz && ur == M->rowptr && uc == M->col) {
+    auto same = [](const auto& a, const auto& b) {      // a == b, on the host threads (a gigabyte of columns at N = 2^24)
+      if (a.size() != b.size()) return false;
+      std::atomic<bool> eq{true};
+      parallel_rows((int64_t)a.size(), [&](int64_t i0, int64_t i1) {
+        if (i1 > i0 && std::memcmp(a.data() + i0, b.data() + i0, (size_t)(i1 - i0) * sizeof(a[0])) != 0) eq.store(false, std::memory_order_relaxed);
+      }, (int64_t)1 << 20);
+      return eq.load();
+    };
+    if (nops == 1 && canonical && (int64_t)M->vals.size() == op->A.nnz && same(ur, M->rowptr) && same(uc, M->col)) {
       // one canonical term and no completion: the union pattern IS the term's own (same columns, not merely as many) -- a plain copy
       pv.borrow(M->vals);      // (the term outlives this call: the operator build reads it, nothing keeps the pointer)
       continue;

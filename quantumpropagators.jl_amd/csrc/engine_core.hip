@@ -2059,238 +2059,6 @@ int qp_dot_op(const qp_state* x, qp_operator* op, const qp_state* y, qp_state* t
 
 // CSR-ordered mirror of the operator for the batched (SpMM) path and the persistent
 // small-system kernels, built lazily
-// Row walk for the batched kernel (kernels_spmm.hip: spmm_rows_kernel).  The pattern is
-// sampled for its offsets d = col - row (folded to (-n/2, n/2]); when the far ones (|d| >= 64) are all
-// multiples of one inner dimension g -- H = H_a (x) 1 + 1 (x) H_c, i = a g + c: lattice and tensor-product
-// operators -- the rows are listed strip by strip: `sw` consecutive inner indices c, all outer indices a
-// in turn.  Then the rows that gather a given row of X (its +-k g and +-near neighbours) are visited
-// within a few strip widths of each other instead of 2 a_max g rows apart, and the strip width is chosen
-// so that this window, plus the rows in flight, fits half an XCD's L2 at `batch` states per row.
-// Anything else (no far offsets, no common inner dimension, strips narrower than four times the near
-// reach) keeps the natural order.  Index work only: the arithmetic per row does not change.
-static void spmm_walk_host(const qp_operator* op, int batch, int knob, std::vector<int32_t>* order,
-                           int64_t* g_out, int64_t* sw_out) {
-  order->clear();
-  *g_out = *sw_out = 0;
-  const int64_t n = op->A.nrows;
-  const auto& ur = op->u_rowptr;
-  const auto& uc = op->u_col;
-  if (knob < 0 || n < 4096 || n > INT32_MAX || op->A.ncols != n || ur.empty()) return;
-  int64_t g = 0, far_max = 0, near_max = 0;
-  const int64_t nsample = std::min<int64_t>(n, 4096), stride = n / nsample;
-  for (int64_t t = 0; t < nsample; ++t) {
-    const int64_t r = t * stride;
-    for (int64_t p = ur[r]; p < ur[r + 1]; ++p) {
-      int64_t d = (int64_t)uc[p] - r;
-      if (d > n / 2) d -= n;
-      if (d <= -(n + 1) / 2) d += n;
-      d = std::llabs(d);
-      if (d >= 64) {
-        g = std::gcd(g, d);
-        far_max = std::max(far_max, d);
-      } else {
-        near_max = std::max(near_max, d);
-      }
-    }
-  }
-  if (g < 256 || far_max / g > 64) return;
-  const int64_t amax = far_max / g;
-  const int64_t l2_budget = 1280 * 1024;                 // under a third of an XCD's 4 MiB L2 for the gather window (measured at
-                                                         // 64 states: strips of 64 beat 128 and 32, profiles/r02/batched_c5_sweep.txt)
-  const int64_t row_bytes = (int64_t)std::min(batch, 64) * (int64_t)sizeof(double2);
-  int64_t sw;
-  if (knob > 0) {
-    sw = knob;
-  } else {
-    const int64_t inflight = 512;                         // rows an XCD has in flight (32 CUs x 16 waves)
-    sw = (l2_budget / row_bytes - inflight) / (2 * amax + 1);
-  }
-  sw = std::min(sw, g);
-  while (sw > 1 && g % sw != 0) --sw;                     // every strip the same width
-  if (sw < 1) return;
-  if (knob == 0 && (sw < 4 * std::max<int64_t>(near_max, 1) || sw < 16)) return;
-  if (sw >= g) return;                                    // one strip = the natural order
-  order->resize((size_t)n);
-  const int64_t na = (n + g - 1) / g;
-  size_t k = 0;
-  for (int64_t c0 = 0; c0 < g; c0 += sw)
-    for (int64_t a = 0; a < na; ++a)
-      for (int64_t c = c0; c < c0 + sw; ++c) {
-        const int64_t i = a * g + c;
-        if (i < n) (*order)[k++] = (int32_t)i;
-      }
-  if ((int64_t)k != n) {   // cannot happen; fall back to the natural order rather than skip rows
-    order->clear();
-    return;
-  }
-  *g_out = g;
-  *sw_out = sw;
-}
-
-int operator_spmm_order(qp_operator* op, int batch, const int32_t** order_out) {
-  qp_ctx* ctx = op->ctx;
-  const int knob = ctx->tun.spmm_strip;
-  if (op->m_order_valid && op->m_order_batch == batch && op->m_order_knob == knob) {
-    *order_out = op->m_order;
-    return QP_OK;
-  }
-  if (op->m_order) (void)hipFree(op->m_order);
-  op->m_order = nullptr;
-  op->m_order_valid = true;
-  op->m_order_batch = batch;
-  op->m_order_knob = knob;
-  op->m_order_g = op->m_order_sw = 0;
-  *order_out = nullptr;
-  std::vector<int32_t> order;
-  int64_t g = 0, sw = 0;
-  spmm_walk_host(op, batch, knob, &order, &g, &sw);
-  if (order.empty()) return QP_OK;
-  QP_CHECK(dev_alloc(&op->m_order, order.size()));
-  QP_HIP(hipMemcpy(op->m_order, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-  op->m_order_g = g;
-  op->m_order_sw = sw;
-  *order_out = op->m_order;
-  return QP_OK;
-}
-
-// Tiles of the batched path (device.h: SpmmTiles; kernel: spmm_tile_kernel).  The pattern of the row in the middle of the matrix is
-// the candidate: every distance near (|d| <= 4) or a multiple m g of the far distances' gcd with |m| <= 4.  A row is regular when
-// its entries are exactly that pattern; a tile is sixteen regular rows r0 + i g + j (i, j < 4, r0 = 4 ta g + 4 tc).  Tiles are
-// listed strip by strip like the row walk above (the kernel is not sensitive to the strip width: any order that keeps the tiles of
-// neighbouring strip steps close in time serves the far halo from L2); every other row goes to the row kernel.  Index work only.
-static void spmm_tiles_host(const qp_operator* op, int knob, qp::SpmmTileShape* shape, std::vector<int32_t>* tiles,
-                            std::vector<int32_t>* rest, int64_t* g_out, int64_t* sw_out) {
-  tiles->clear();
-  rest->clear();
-  *g_out = *sw_out = 0;
-  const int64_t n = op->A.nrows;
-  const auto& ur = op->u_rowptr;
-  const auto& uc = op->u_col;
-  if (knob < 0 || n < 4096 || n > INT32_MAX || op->A.ncols != n || ur.empty() || op->A.nnz > (int64_t)INT32_MAX) return;
-  const int64_t rm = n / 2;
-  const int nd = (int)(ur[rm + 1] - ur[rm]);
-  if (nd < 2 || nd > qp::kSpmmTileMaxEntries) return;
-  std::vector<int64_t> D((size_t)nd);
-  int64_t g = 0, far_max = 0, near_max = 0;
-  for (int k = 0; k < nd; ++k) {
-    const int64_t d = (int64_t)uc[ur[rm] + k] - rm;
-    D[(size_t)k] = d;
-    const int64_t ad = std::llabs(d);
-    if (ad <= 4) near_max = std::max(near_max, ad);
-    else if (ad >= 64) {
-      g = std::gcd(g, ad);
-      far_max = std::max(far_max, ad);
-    } else return;
-  }
-  if (g < 64 || far_max / g > 4) return;
-  qp::SpmmTileShape sh;
-  sh.nd = nd;
-  sh.K = (int)(far_max / g);
-  sh.NN = (int)near_max;
-  for (int k = 0; k < nd; ++k) {
-    const int64_t d = D[(size_t)k];
-    const bool nearby = std::llabs(d) <= 4 && d != 0;
-    sh.dnear[k] = nearby ? (int)d : 0;
-    sh.dfar[k] = nearby ? 0 : (int)(d / g);
-  }
-  std::vector<uint8_t> regular((size_t)n);
-  parallel_rows(n, [&](int64_t r_begin, int64_t r_end) {
-    for (int64_t r = r_begin; r < r_end; ++r) {
-      bool ok = ur[r + 1] - ur[r] == nd;
-      for (int k = 0; ok && k < nd; ++k) ok = (int64_t)uc[ur[r] + k] - r == D[(size_t)k];
-      regular[(size_t)r] = ok ? 1 : 0;
-    }
-  });
-  const int64_t na = (n + g - 1) / g;
-  int64_t sw = knob > 0 ? knob : 128;
-  sw = std::max<int64_t>(4, std::min(sw, g) / 4 * 4);
-  std::vector<uint8_t> covered((size_t)n, 0);
-  for (int64_t c0 = 0; c0 < g; c0 += sw)
-    for (int64_t a0 = 0; a0 + 3 < na; a0 += 4)
-      for (int64_t c = c0; c + 3 < std::min(c0 + sw, g); c += 4) {
-        const int64_t r0 = a0 * g + c;
-        if (r0 + 3 * g + 3 >= n) continue;
-        bool ok = true;
-        for (int i = 0; ok && i < 4; ++i)
-          for (int j = 0; ok && j < 4; ++j) ok = regular[(size_t)(r0 + i * g + j)] != 0;
-        if (!ok) continue;
-        tiles->push_back((int32_t)r0);
-        for (int i = 0; i < 4; ++i)
-          for (int j = 0; j < 4; ++j) covered[(size_t)(r0 + i * g + j)] = 1;
-      }
-  if ((int64_t)tiles->size() * 16 < n / 2) {   // mostly edges: the row kernel alone
-    tiles->clear();
-    return;
-  }
-  for (int64_t r = 0; r < n; ++r)
-    if (!covered[(size_t)r]) rest->push_back((int32_t)r);
-  *shape = sh;
-  *g_out = g;
-  *sw_out = sw;
-}
-
-int operator_spmm_tiles(qp_operator* op, const qp::SpmmTiles** out) {
-  qp_ctx* ctx = op->ctx;
-  qp::SpmmTiles& P = op->m_tiles;
-  const int knob = ctx->tun.spmm_strip;
-  *out = nullptr;
-  if (!P.built || P.knob != knob) {
-    if (P.tiles) (void)hipFree(P.tiles);
-    if (P.rest) (void)hipFree(P.rest);
-    if (P.tab) (void)hipFree(P.tab);
-    P = qp::SpmmTiles();
-    P.built = true;
-    P.knob = knob;
-    std::vector<int32_t> tiles, rest;
-    spmm_tiles_host(op, knob, &P.shape, &tiles, &rest, &P.g, &P.sw);
-    if (!tiles.empty()) {
-      // the kernel's table: where the staged rows lie relative to r0, where every wavefront finds its operands in LDS
-      const int K = P.shape.K, NN = P.shape.NN, nfar = (4 + 2 * K) * 4;
-      P.T = nfar + 8 * NN;
-      std::vector<int32_t> tab((size_t)qp::kSpmmTileTab, 0);
-      for (int slot = 0; slot < P.T; ++slot) {
-        int64_t d;
-        if (slot < nfar) {
-          d = (int64_t)(slot / 4 - K) * P.g + slot % 4;
-        } else {
-          const int s2 = slot - nfar, ii = s2 / (2 * NN), jj = s2 % (2 * NN);
-          d = (int64_t)ii * P.g + (jj < NN ? jj - NN : 4 + jj - NN);
-        }
-        tab[(size_t)slot] = (int32_t)d;
-      }
-      for (int w = 0; w < 16; ++w) {
-        const int i = w / 4, j = w % 4, own = (i + K) * 4 + j;
-        for (int k = 0; k < P.shape.nd; ++k) {
-          int slot;
-          const int dn = P.shape.dnear[k];
-          if (dn == 0) {
-            slot = own + 4 * P.shape.dfar[k];
-          } else {
-            const int jj = j + dn;
-            slot = (jj >= 0 && jj < 4) ? own + dn : nfar + i * 2 * NN + (jj < 0 ? jj + NN : jj - 4 + NN);
-          }
-          tab[(size_t)(qp::kSpmmTileSlots + qp::kSpmmTileMaxEntries * w + k)] = slot * 64 * (int32_t)sizeof(double2);
-        }
-        tab[(size_t)(qp::kSpmmTileSlots + qp::kSpmmTileMaxEntries * 16 + w)] = (int32_t)((int64_t)i * P.g + j);
-        tab[(size_t)(qp::kSpmmTileSlots + qp::kSpmmTileMaxEntries * 16 + 16 + w)] = own * 64 * (int32_t)sizeof(double2);
-      }
-      QP_CHECK(dev_alloc(&P.tab, tab.size()));
-      QP_HIP(hipMemcpy(P.tab, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-      QP_CHECK(dev_alloc(&P.tiles, tiles.size()));
-      QP_HIP(hipMemcpy(P.tiles, tiles.data(), tiles.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-      if (!rest.empty()) {
-        QP_CHECK(dev_alloc(&P.rest, rest.size()));
-        QP_HIP(hipMemcpy(P.rest, rest.data(), rest.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-      }
-      P.ntiles = (int64_t)tiles.size();
-      P.nrest = (int64_t)rest.size();
-      P.valid = 1;
-    }
-  }
-  if (P.valid) *out = &P;
-  return QP_OK;
-}
-
 int operator_csr_mirror(qp_operator* op, bool gather) {
   if (op->A.format == QP_FMT_MATFREE) return qp::fail(QP_E_BAD_ARG, "a matrix-free operator has no stored entries");
   qp_ctx* ctx = op->ctx;

@@ -44,6 +44,8 @@ struct Pauli {
   int ndiag = 0;                    // strings of the diagonal group (group 0), 0: none
   double2* d_diag = nullptr;        // n entries of storage; read as double[n] while every current coefficient of the group is real
   bool diag_real = false;
+  bool walked_real = false;         // every current coefficient of the walked strings (those outside the diagonal group) is real (pauli_refresh)
+  bool walked_nosign = false;       // none of them has a Z mask (X strings only): no sign to compute
 };
 
 // epilogue of the plain application
@@ -63,6 +65,9 @@ struct PauliTables {
   const double2* tc;       // [nstrings] current coefficients
   int ngroups, nstrings;
   int g_begin;             // first group the term kernel walks (1 when the diagonal group is applied from the diagonal vector)
+  int g_hi;                // first walked group whose x mask reaches another 64-row block (masks ascending)
+  int gs;                  // > 0: every walked group has exactly gs strings (an Ising chain's X_i: 1; XX + YY pairs: 2) -- the strings of
+                           // group g are then gfirst[g_begin] + (g - g_begin) gs .. without a look-up of gfirst per group
   const double* diag_r;    // [n] the diagonal group's weights when they are all real, else
   const double2* diag_c;   //     complex (both NULL: no diagonal vector)
 };
@@ -74,11 +79,12 @@ __device__ __forceinline__ double2 lane_xor2(double2 v, int lane, int m) {
                       __hiloint2double(__builtin_amdgcn_ds_bpermute(idx, __double2hiint(v.y)), __builtin_amdgcn_ds_bpermute(idx, __double2loint(v.y))));
 }
 
-// One wavefront per 64-row block, several blocks per wavefront (grid-stride: the tables are staged once per workgroup).  A group's
+// One wavefront per 64-row block (the grid-stride loop only matters beyond 2^31 workgroups).  A group's
 // partner elements x[r xor xm] are the 1-KiB line of block (b xor (xm >> 6)) with its lanes permuted by xm & 63: one coalesced,
 // line-aligned load per group with high bits (none for a group inside the block: the wavefront's own line) + a lane permutation
 // through the LDS crossbar -- no address ever leaves the wavefront's line set.
-template <class Epi, bool STAGE>
+// FAST (with GS = 1): X strings with real coefficients only (a transverse field) -- no sign, two FMAs per string instead of four
+template <class Epi, bool STAGE, int GS = 0, bool FAST = false>
 __global__ __launch_bounds__(256) void pauli_spmv_kernel(PauliTables T, const double2* __restrict__ x, int64_t nblocks, Epi ep) {
   // dynamic LDS sized by the launcher to the tables it stages: [tc: nstrings double2][tz: nstrings][gx: ngroups][first: ngroups + 1]
   extern __shared__ double2 pauli_lds[];
@@ -121,41 +127,62 @@ __global__ __launch_bounds__(256) void pauli_spmv_kernel(PauliTables T, const do
       s = qp::cmul(T.diag_c[r], own);
     }
     constexpr int GB = 8;      // groups whose lines are in flight together
-    for (int g0 = T.g_begin; g0 < T.ngroups; g0 += GB) {
+    const int tbase = GS > 0 ? __builtin_amdgcn_readfirstlane(gfirst[T.g_begin]) : 0;
+    // the strings of group g applied to its (permuted) line pv; signs as an XOR of the sign bit (bit 31 of the high dword): no
+    // compare / select per string
+    auto apply = [&](int g, uint32_t xmg, const double2& pv) {
+      const uint32_t partner = (uint32_t)r ^ xmg;
+      int t0, t1;
+      if constexpr (GS > 0) {      // groups of GS strings each: no look-up (a dependent LDS round trip + readfirstlane per group otherwise)
+        t0 = tbase + (g - T.g_begin) * GS;
+        t1 = t0 + GS;
+      } else {
+        t0 = __builtin_amdgcn_readfirstlane(gfirst[g]);
+        t1 = __builtin_amdgcn_readfirstlane(gfirst[g + 1]);
+      }
+      if constexpr (FAST) {
+        const double c = tc[t0].x;
+        s.x = fma(c, pv.x, s.x);
+        s.y = fma(c, pv.y, s.y);
+      } else if (GS == 1 || (GS == 0 && t1 - t0 == 1)) {      // one string (every X_i of an Ising chain): its sign goes onto the gathered element
+        const int flip = (int)((__popc(partner & tz[t0]) & 1u) << 31);
+        const double2 c = tc[t0];
+        const double2 sv = make_double2(__hiloint2double(__double2hiint(pv.x) ^ flip, __double2loint(pv.x)),
+                                        __hiloint2double(__double2hiint(pv.y) ^ flip, __double2loint(pv.y)));
+        qp::cfma(s, c, sv);
+      } else {
+        double2 w = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int t = t0; t < (GS > 0 ? t0 + GS : t1); ++t) {
+          const double2 c = tc[t];
+          const int flip = (int)((__popc(partner & tz[t]) & 1u) << 31);
+          w.x += __hiloint2double(__double2hiint(c.x) ^ flip, __double2loint(c.x));
+          w.y += __hiloint2double(__double2hiint(c.y) ^ flip, __double2loint(c.y));
+        }
+        qp::cfma(s, w, pv);
+      }
+    };
+    // groups inside the block (x mask < 64; the masks are listed in ascending order): lane permutations of the wavefront's own line
+    for (int g = T.g_begin; g < T.g_hi; ++g) {
+      const uint32_t xmg = (uint32_t)__builtin_amdgcn_readfirstlane((int)gx[g]);
+      apply(g, xmg, lane_xor2(own, lane, (int)xmg));
+    }
+    // groups that reach another block: GB lines in flight, then a lane permutation where the mask has low bits too
+    for (int g0 = T.g_hi; g0 < T.ngroups; g0 += GB) {
       double2 xv[GB];
       uint32_t xm[GB];
 #pragma unroll
-      for (int u = 0; u < GB; ++u) {      // the groups' lines in flight first (a group inside the block: the wavefront's own)
+      for (int u = 0; u < GB; ++u) {
         const int g = min(g0 + u, T.ngroups - 1);
-        xm[u] = gx[g];
-        const int64_t pb = b ^ (int64_t)(xm[u] >> 6);
-        xv[u] = (xm[u] >> 6) ? x[pb * qp::kRB + lane] : own;
+        xm[u] = (uint32_t)__builtin_amdgcn_readfirstlane((int)gx[g]);      // (wave-uniform: the branches below are scalar)
+        xv[u] = x[(b ^ (int64_t)(xm[u] >> 6)) * qp::kRB + lane];
       }
 #pragma unroll
       for (int u = 0; u < GB; ++u) {
         const int g = g0 + u;
         if (g >= T.ngroups) break;
         const int lo = (int)(xm[u] & 63u);
-        const double2 pv = lo ? lane_xor2(xv[u], lane, lo) : xv[u];
-        const uint32_t partner = (uint32_t)(r ^ (int64_t)xm[u]);
-        // signs as an XOR of the sign bit (bit 31 of the high dword): no compare / select per string
-        const int t0 = __builtin_amdgcn_readfirstlane(gfirst[g]), t1 = __builtin_amdgcn_readfirstlane(gfirst[g + 1]);
-        if (t1 - t0 == 1) {      // one string (every X_i of an Ising chain): its sign goes onto the gathered element
-          const int flip = (int)((__popc(partner & tz[t0]) & 1u) << 31);
-          const double2 c = tc[t0];
-          const double2 sv = make_double2(__hiloint2double(__double2hiint(pv.x) ^ flip, __double2loint(pv.x)),
-                                          __hiloint2double(__double2hiint(pv.y) ^ flip, __double2loint(pv.y)));
-          qp::cfma(s, c, sv);
-        } else {
-          double2 w = make_double2(0.0, 0.0);
-          for (int t = t0; t < t1; ++t) {
-            const double2 c = tc[t];
-            const int flip = (int)((__popc(partner & tz[t]) & 1u) << 31);
-            w.x += __hiloint2double(__double2hiint(c.x) ^ flip, __double2loint(c.x));
-            w.y += __hiloint2double(__double2hiint(c.y) ^ flip, __double2loint(c.y));
-          }
-          qp::cfma(s, w, pv);
-        }
+        apply(g, xm[u], lo ? lane_xor2(xv[u], lane, lo) : xv[u]);
       }
     }
     if constexpr (std::is_same<Epi, PauliPlain>::value) {
@@ -210,6 +237,8 @@ int pauli_refresh(qp_operator* op) {
   // stream-ordered (a term launched before this call keeps the coefficients it was launched with); from pageable memory the call
   // returns once the bytes have left `tc` for the runtime's staging buffer
   QP_HIP(hipMemcpyAsync(P->d_tc, tc.data(), tc.size() * sizeof(double2), hipMemcpyHostToDevice, op->ctx->stream));
+  P->walked_real = true;
+  for (int t = P->ndiag; t < P->nterms; ++t) P->walked_real = P->walked_real && tc[(size_t)t].y == 0.0;
   if (P->ndiag > 0) {
     P->diag_real = true;
     for (int t = 0; t < P->ndiag; ++t) P->diag_real = P->diag_real && tc[(size_t)t].y == 0.0;
@@ -231,6 +260,15 @@ static PauliTables pauli_tables(const Pauli* P) {
   T.ngroups = P->ngroups;
   T.nstrings = P->nterms;
   T.g_begin = P->ndiag > 0 ? 1 : 0;
+  T.g_hi = T.g_begin;
+  while (T.g_hi < P->ngroups && P->gx[(size_t)T.g_hi] < 64u) ++T.g_hi;
+  T.gs = 0;
+  if (T.g_begin < P->ngroups) {
+    const int gs0 = P->gfirst[(size_t)T.g_begin + 1] - P->gfirst[(size_t)T.g_begin];
+    bool same = gs0 >= 1 && gs0 <= 2;
+    for (int g = T.g_begin; same && g < P->ngroups; ++g) same = P->gfirst[(size_t)g + 1] - P->gfirst[(size_t)g] == gs0;
+    if (same) T.gs = gs0;
+  }
   T.diag_r = (P->ndiag > 0 && P->diag_real) ? reinterpret_cast<const double*>(P->d_diag) : nullptr;
   T.diag_c = (P->ndiag > 0 && !P->diag_real) ? P->d_diag : nullptr;
   return T;
@@ -240,13 +278,16 @@ template <class Epi>
 static void pauli_launch(hipStream_t s, const Pauli* P, const double2* x, const Epi& ep) {
   const int64_t nblocks = P->n / qp::kRB;
   const PauliTables T = pauli_tables(P);
-  // a few blocks per wavefront: the tables are staged once per workgroup (eight workgroups per compute unit at most)
+  // one 64-row block per wavefront (measured: 22 spins 109 -> 96 us per term, 24 spins 509 -> 480 against a few blocks per wavefront
+  // in turn; the tables a workgroup stages are a few hundred bytes)
   const size_t lds_tables = (size_t)P->nterms * (sizeof(double2) + sizeof(uint32_t)) + (size_t)(2 * P->ngroups + 1) * sizeof(int);
-  const int cus = qp::device_cu_count();
-  const unsigned grid = (unsigned)std::min<int64_t>((nblocks + 3) / 4, (int64_t)8 * cus);
+  const unsigned grid = (unsigned)std::min<int64_t>((nblocks + 3) / 4, (int64_t)INT32_MAX);
   if (P->ngroups <= kPauliMaxGroups && P->nterms <= kPauliMaxStrings) {
     const size_t lds = lds_tables;
-    hipLaunchKernelGGL((pauli_spmv_kernel<Epi, true>), dim3(grid), dim3(256), lds, s, T, x, nblocks, ep);
+    if (T.gs == 1 && P->walked_real && P->walked_nosign) hipLaunchKernelGGL((pauli_spmv_kernel<Epi, true, 1, true>), dim3(grid), dim3(256), lds, s, T, x, nblocks, ep);
+    else if (T.gs == 1) hipLaunchKernelGGL((pauli_spmv_kernel<Epi, true, 1>), dim3(grid), dim3(256), lds, s, T, x, nblocks, ep);
+    else if (T.gs == 2) hipLaunchKernelGGL((pauli_spmv_kernel<Epi, true, 2>), dim3(grid), dim3(256), lds, s, T, x, nblocks, ep);
+    else hipLaunchKernelGGL((pauli_spmv_kernel<Epi, true>), dim3(grid), dim3(256), lds, s, T, x, nblocks, ep);
   } else {
     hipLaunchKernelGGL((pauli_spmv_kernel<Epi, false>), dim3(grid), dim3(256), 0, s, T, x, nblocks, ep);
   }
@@ -357,6 +398,8 @@ int qp_pauli_operator_create(qp_ctx* ctx, int nqubits, const qp_pauli_string* st
     Pp->ndiag = Pp->gfirst[1];
     QP_CHECK(dev_alloc(&Pp->d_diag, (size_t)Pp->n));
   }
+  Pp->walked_nosign = true;
+  for (int t = Pp->ndiag; t < nstrings; ++t) Pp->walked_nosign = Pp->walked_nosign && Pp->zmask[(size_t)t] == 0;
   QP_HIP(hipMemcpy(Pp->d_gx, Pp->gx.data(), Pp->gx.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   QP_HIP(hipMemcpy(Pp->d_gfirst, Pp->gfirst.data(), Pp->gfirst.size() * sizeof(int), hipMemcpyHostToDevice));
   QP_HIP(hipMemcpy(Pp->d_tz, Pp->zmask.data(), Pp->zmask.size() * sizeof(uint32_t), hipMemcpyHostToDevice));

@@ -141,6 +141,31 @@ def test_pauli_propagator_interface(ctx):
     assert check_propagator(p, quiet=True)
 
 
+def test_pauli_fast_paths_follow_the_coefficients(ctx):
+    """The term kernel has a two-FMA path for X strings with real coefficients (a transverse field) and look-up-free paths for
+    groups of one and of two strings (csrc/engine_pauli.hip: GS, FAST); which one runs is decided per launch from the CURRENT
+    coefficients: a transverse-field chain with a real scale, then a complex one (Y-like phases on every string), then real again; an
+    XX + YY chain (two strings per group, Z masks on the YY strings); every mul! against the Kronecker-built matrix."""
+    n = 9
+    N = 1 << n
+    x0 = synth.random_state(N, seed=21)
+    for strings in (synth.tfim_pauli_terms(n), synth.xxz_pauli_terms(n)):
+        H = synth.pauli_sum_matrix(n, strings)
+        op = L.PauliOperator(ctx, n, [strings])
+        x, y = L.State(ctx, data=x0), L.State(ctx, data=x0)
+        for scale in (1.0, -0.3 + 2.0j, 0.5, 1.0j, -2.0):
+            op.set_scale(scale)
+            op.mul(x, y)
+            assert np.linalg.norm(y.numpy() - scale * (H @ x0)) < 1e-12, scale
+        op.set_scale(1.0)
+        b = 1.05 * _bound(strings)
+        wrk = L.ChebyWrk(ctx, N, 2 * b, -b, 3.0 / b)
+        psi = L.State(ctx, data=x0)
+        L.cheby(psi, op, 3.0 / b, wrk)
+        ref = qo.cheby(x0.copy(), H, 3.0 / b, qo.ChebyWrk(x0, 2 * b, -b, 3.0 / b))
+        assert np.linalg.norm(psi.numpy() - ref) < TOL
+
+
 def test_pauli_create_argument_errors(ctx):
     with pytest.raises(L.QPError):
         L.PauliOperator(ctx, 5, [[(1.0, (1, 0))]])                 # fewer than 64 rows
